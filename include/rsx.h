@@ -1,0 +1,298 @@
+/*
+ * rsx.h -- C-ABI of the MI355X-native RAW decompression core ("rsx").
+ *
+ * This is the drop-in boundary behind rawspeed's decompressor classes.  The
+ * reference (darktable-org/rawspeed, paths relative to src/librawspeed/)
+ * exposes no plugin/FFI interface for decompressors; the seam is created by
+ * forwarding from three concrete C++ methods (plus the DNG tile fan-out) into
+ * the entry points below.  Every entry point cites the reference interface it
+ * replaces.  Plain C types only: no C++ objects, no torch types, no
+ * exceptions cross this boundary.  All pointers are borrowed for the duration
+ * of the call.  Entry points are re-entrant per context; one context may be
+ * shared by several host threads (calls are serialised on the context).
+ *
+ * Two families of entry points:
+ *   - host-pointer calls (rsx_unpack_u16, rsx_ljpeg_decode, rsx_cr2_decode,
+ *     rsx_dng_decompress): exactly what the patched reference methods call;
+ *     input is pageable host memory, output is the RawImage's host buffer.
+ *     They stage H2D / D2H internally.
+ *   - device-resident plans (rsx_*_plan_*): inputs and outputs already live in
+ *     HBM, launches go to a caller-supplied hipStream_t.  These are what the
+ *     roofline measurement and the batched multi-GPU path use.
+ */
+#ifndef RSX_H
+#define RSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSX_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------ */
+/* Status codes.  Kernels cannot throw; the C++ forwarding shim converts a   */
+/* non-OK status into ThrowRDE / ThrowIOE.                  */
+/* ------------------------------------------------------------------------ */
+typedef enum rsx_status {
+  RSX_OK = 0,
+  /* descriptor rejected by the same checks the reference constructor makes
+   * (ThrowRDE in UncompressedDecompressor.cpp:106-169,
+   * LJpegDecompressor.cpp:52-152, Cr2DecompressorImpl.h:279-363) */
+  RSX_ERR_INVALID_ARG = 1,
+  /* not enough input (ThrowIOE: UncompressedDecompressor.cpp:52-74,
+   * BitStreamer.h:58-59 "Bit stream size is smaller than MaxProcessBytes") */
+  RSX_ERR_IO = 2,
+  /* "bad Huffman code" (codes/PrefixCodeLookupDecoder.h:152-155) */
+  RSX_ERR_BAD_HUFFMAN_CODE = 3,
+  /* restart marker missing / wrong (LJpegDecompressor.cpp:288-297) */
+  RSX_ERR_RESTART_MARKER = 4,
+  /* "Buffer overflow read in BitStreamer" (bitstreams/BitStreamer.h:125-127) */
+  RSX_ERR_INPUT_OVERFLOW = 5,
+  /* HIP runtime failure (no reference equivalent) */
+  RSX_ERR_DEVICE = 6,
+  /* valid for the reference but not implemented by this core yet */
+  RSX_ERR_UNSUPPORTED = 7,
+  RSX_ERR_NOMEM = 8,
+  /* AbstractDngDecompressor: at least one tile failed
+   * (AbstractDngDecompressor.cpp:247-251 "Too many errors") */
+  RSX_ERR_TILE_ERRORS = 9
+} rsx_status;
+
+/* Bit orders; numeric values equal rawspeed::BitOrder
+ * (bitstreams/BitStreams.h:27-35). */
+typedef enum rsx_bit_order {
+  RSX_ORDER_LSB = 0,
+  RSX_ORDER_MSB = 1,
+  RSX_ORDER_MSB16 = 2,
+  RSX_ORDER_MSB32 = 3,
+  RSX_ORDER_JPEG = 4
+} rsx_bit_order;
+
+/* ------------------------------------------------------------------------ */
+/* The RawImage view (common/RawImage.h:289-296): uint16 samples,            */
+/* `pitch_bytes` between rows (never assume roundUp(w*bpp,16):               */
+/* RawImage.cpp:85-90), `dim_x` x `dim_y` pixels of `cpp` samples each.      */
+/* `data` is a host pointer for the host-pointer calls and a device pointer  */
+/* for the plan calls.                                                       */
+/* ------------------------------------------------------------------------ */
+typedef struct rsx_image {
+  void* data;
+  uint32_t pitch_bytes;
+  int32_t dim_x;
+  int32_t dim_y;
+  int32_t cpp;
+  int32_t is_cfa; /* RawImageData::isCFA; only Cr2 sRaw validation reads it */
+} rsx_image;
+
+/* ------------------------------------------------------------------------ */
+/* Context: one per (host thread group, device).  Owns a HIP stream, staging */
+/* buffers and scratch.                                                      */
+/* ------------------------------------------------------------------------ */
+typedef struct rsx_ctx rsx_ctx;
+
+int rsx_abi_version(void);
+const char* rsx_status_string(int status);
+/* Number of visible HIP devices (0 when no GPU / no driver). */
+int rsx_device_count(void);
+/* Creates a context on HIP device `device`.  Fails with RSX_ERR_DEVICE when
+ * there is no usable GPU: there is NO CPU fallback in this library. */
+int rsx_ctx_create(int device, rsx_ctx** out_ctx);
+void rsx_ctx_destroy(rsx_ctx* ctx);
+/* Last error text of this context (never NULL). */
+const char* rsx_ctx_last_error(const rsx_ctx* ctx);
+
+/* ------------------------------------------------------------------------ */
+/* 1. UncompressedDecompressor                                               */
+/*    replaces UncompressedDecompressor::readUncompressedRaw()               */
+/*    (decompressors/UncompressedDecompressor.h:75, .cpp:202-268) for the    */
+/*    UINT16 packed-integer paths, i.e. decodePackedInt<BitStreamerXXX>      */
+/*    (.cpp:188-200) and the 16-bit-LSB copyPixels fast path (.cpp:255-265). */
+/*    Fields mirror the constructor (.h:64-66, .cpp:106-169).                */
+/* ------------------------------------------------------------------------ */
+typedef struct rsx_unpack_desc {
+  int32_t crop_x, crop_y; /* iRectangle2D crop.pos (pixels) */
+  int32_t crop_w, crop_h; /* iRectangle2D crop.dim (pixels) */
+  int32_t input_pitch_bytes;
+  int32_t bits_per_pixel; /* 1..16 for UINT16 images */
+  int32_t bit_order;      /* rsx_bit_order, JPEG rejected */
+} rsx_unpack_desc;
+
+/* Validation only (the reference constructor): RSX_OK or the error the
+ * reference would throw.  Needs no GPU. */
+int rsx_unpack_validate(const rsx_unpack_desc* d, const rsx_image* img,
+                        size_t in_bytes);
+
+int rsx_unpack_u16(rsx_ctx* ctx, const rsx_unpack_desc* d, const uint8_t* in,
+                   size_t in_bytes, const rsx_image* img);
+
+/* ------------------------------------------------------------------------ */
+/* Huffman table exactly as the DHT payload the host already parsed          */
+/* (codes/HuffmanCode.h:99-166): 16 counts + the code values (= SSSS         */
+/* difference categories, each <= 16 in full-decode mode,                    */
+/* codes/AbstractPrefixCodeTranscoder.h:71-84).  The canonical code is       */
+/* re-derived on our side; the reference's LUT memory is never read.         */
+/* ------------------------------------------------------------------------ */
+#define RSX_MAX_CODE_VALUES 162 /* codes/AbstractPrefixCode.h BaselineCodeTag */
+typedef struct rsx_huff_table {
+  uint8_t n_codes_per_length[16]; /* index 0 = code length 1 */
+  uint8_t code_values[RSX_MAX_CODE_VALUES];
+  uint8_t n_code_values;
+  uint8_t fix_dng_bug16; /* AbstractPrefixCodeDecoder.h:58-62 */
+} rsx_huff_table;
+
+#define RSX_MAX_COMPONENTS 4
+
+/* ------------------------------------------------------------------------ */
+/* 2. LJpegDecompressor                                                      */
+/*    replaces LJpegDecompressor::decode() (LJpegDecompressor.h:94,          */
+/*    .cpp:341-370 -> decodeN .cpp:254-339 -> decodeRowN .cpp:184-251).      */
+/*    Fields mirror the constructor (.h:89-93, .cpp:52-152).                 */
+/* ------------------------------------------------------------------------ */
+typedef struct rsx_ljpeg_desc {
+  int32_t tile_x, tile_y, tile_w, tile_h; /* imgFrame, pixels */
+  int32_t mcu_w, mcu_h;                   /* Frame::mcu */
+  int32_t frame_w, frame_h;               /* Frame::dim, in MCUs */
+  int32_t n_comp;                         /* rec.size() == mcu_w*mcu_h */
+  int32_t rows_per_restart_interval;      /* numLJpegRowsPerRestartInterval */
+  uint16_t init_pred[RSX_MAX_COMPONENTS]; /* PerComponentRecipe::initPred */
+  uint8_t table_index[RSX_MAX_COMPONENTS]; /* PerComponentRecipe::ht -> tables[] */
+  int32_t n_tables;
+  rsx_huff_table tables[RSX_MAX_COMPONENTS];
+} rsx_ljpeg_desc;
+
+int rsx_ljpeg_validate(const rsx_ljpeg_desc* d, const rsx_image* img,
+                       size_t in_bytes);
+
+/* `in` = entropy-coded data from just after the SOS header to the end of the
+ * tile buffer (what LJpegDecoder::decodeScan passes, LJpegDecoder.cpp:161-164).
+ * `consumed` = ByteStream::size_type return value of decode() (closed form:
+ * SURVEY.md A.6). */
+int rsx_ljpeg_decode(rsx_ctx* ctx, const rsx_ljpeg_desc* d, const uint8_t* in,
+                     size_t in_bytes, const rsx_image* img,
+                     uint32_t* consumed);
+
+/* ------------------------------------------------------------------------ */
+/* 3. Cr2Decompressor<PrefixCodeDecoder<>>                                   */
+/*    replaces Cr2Decompressor::decompress() (Cr2Decompressor.h:174,         */
+/*    Cr2DecompressorImpl.h:471-485 -> decompressN_X_Y :396-468).            */
+/*    Fields mirror the constructor (Cr2Decompressor.h:168-172,              */
+/*    Cr2DecompressorImpl.h:279-363).                                        */
+/* ------------------------------------------------------------------------ */
+typedef struct rsx_cr2_desc {
+  int32_t n_comp, x_s_f, y_s_f; /* format tuple */
+  int32_t frame_w, frame_h;     /* iPoint2D frame (as passed, before /X_S_F) */
+  int32_t num_slices, slice_width, last_slice_width; /* Cr2SliceWidths */
+  uint16_t init_pred[RSX_MAX_COMPONENTS];
+  uint8_t table_index[RSX_MAX_COMPONENTS];
+  int32_t n_tables;
+  rsx_huff_table tables[RSX_MAX_COMPONENTS];
+} rsx_cr2_desc;
+
+int rsx_cr2_validate(const rsx_cr2_desc* d, const rsx_image* img,
+                     size_t in_bytes);
+
+int rsx_cr2_decode(rsx_ctx* ctx, const rsx_cr2_desc* d, const uint8_t* in,
+                   size_t in_bytes, const rsx_image* img, uint32_t* consumed);
+
+/* ------------------------------------------------------------------------ */
+/* 4. AbstractDngDecompressor tile fan-out                                   */
+/*    replaces AbstractDngDecompressor::decompress()                         */
+/*    (AbstractDngDecompressor.h:141, .cpp:240-252) for compression 1        */
+/*    (decompressThread<1> .cpp:54-110: per-tile UncompressedDecompressor)   */
+/*    and compression 7 (decompressThread<7> .cpp:112-131: per-tile          */
+/*    LJpegDecoder; the host keeps parsing each tile's JPEG headers and      */
+/*    hands us one rsx_ljpeg_desc per tile).  All tiles are decoded by ONE   */
+/*    batched launch sequence instead of one OpenMP thread per tile.         */
+/*    Per-tile failures are reported in tile_status[] (the reference appends */
+/*    them to the ErrorLog, .cpp:122-129); the call returns                  */
+/*    RSX_ERR_TILE_ERRORS if any tile failed (.cpp:247-251).                 */
+/* ------------------------------------------------------------------------ */
+typedef struct rsx_dng_ljpeg_tile {
+  rsx_ljpeg_desc desc;
+  const uint8_t* in; /* entropy-coded data of this tile */
+  size_t in_bytes;
+} rsx_dng_ljpeg_tile;
+
+int rsx_dng_decompress_ljpeg(rsx_ctx* ctx, int n_tiles,
+                             const rsx_dng_ljpeg_tile* tiles,
+                             const rsx_image* img, int32_t* tile_status,
+                             uint32_t* tile_consumed);
+
+typedef struct rsx_dng_unpack_tile {
+  rsx_unpack_desc desc;
+  const uint8_t* in;
+  size_t in_bytes;
+} rsx_dng_unpack_tile;
+
+int rsx_dng_decompress_uncompressed(rsx_ctx* ctx, int n_tiles,
+                                    const rsx_dng_unpack_tile* tiles,
+                                    const rsx_image* img,
+                                    int32_t* tile_status);
+
+/* ------------------------------------------------------------------------ */
+/* Device-resident plans (inputs/outputs already in HBM).                    */
+/*                                                                           */
+/* A plan is "validate + size scratch + upload tables once, launch many".   */
+/* `in_dev`/`out_dev` are device base pointers; each job addresses           */
+/* [in_offset, in_offset+in_bytes) of the input and an image view starting  */
+/* `img_offset` bytes into the output.  `stream` is a hipStream_t (may be    */
+/* NULL = the context's stream).  run() only enqueues; results() blocks on   */
+/* the stream, then reports per-job status / consumed byte counts.           */
+/* ------------------------------------------------------------------------ */
+typedef struct rsx_plan rsx_plan;
+
+typedef struct rsx_unpack_job {
+  rsx_unpack_desc desc;
+  uint64_t in_offset;
+  uint64_t in_bytes;
+  uint64_t img_offset;
+  rsx_image img; /* .data ignored */
+} rsx_unpack_job;
+
+typedef struct rsx_ljpeg_job {
+  rsx_ljpeg_desc desc;
+  uint64_t in_offset;
+  uint64_t in_bytes;
+  uint64_t img_offset;
+  rsx_image img; /* .data ignored */
+} rsx_ljpeg_job;
+
+typedef struct rsx_cr2_job {
+  rsx_cr2_desc desc;
+  uint64_t in_offset;
+  uint64_t in_bytes;
+  uint64_t img_offset;
+  rsx_image img; /* .data ignored */
+} rsx_cr2_job;
+
+int rsx_unpack_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_unpack_job* jobs,
+                           rsx_plan** out_plan);
+int rsx_ljpeg_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_ljpeg_job* jobs,
+                          rsx_plan** out_plan);
+int rsx_cr2_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_cr2_job* jobs,
+                        rsx_plan** out_plan);
+/* Enqueue one pass of the plan on `stream`. */
+int rsx_plan_run(rsx_plan* plan, const void* in_dev, void* out_dev,
+                 void* stream);
+/* Wait for the last run and fetch per-job results.  `job_status` and
+ * `job_consumed` may be NULL.  Returns RSX_OK iff every job is RSX_OK. */
+int rsx_plan_results(rsx_plan* plan, int32_t* job_status,
+                     uint32_t* job_consumed);
+/* Name of the dominant kernel of this plan and the average duration (ms) of
+ * its launches since the previous call, measured with hipEvents recorded on
+ * the stream the kernel is launched on.  Timing is off by default; enable
+ * with rsx_plan_set_timing(plan, 1).  Returns RSX_OK, or RSX_ERR_INVALID_ARG
+ * if timing is disabled / no launches happened. */
+int rsx_plan_set_timing(rsx_plan* plan, int enable);
+int rsx_plan_kernel_time(rsx_plan* plan, const char** kernel_name,
+                         double* avg_ms, int* n_launches);
+void rsx_plan_destroy(rsx_plan* plan);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* RSX_H */

@@ -1,0 +1,329 @@
+// TEST INFRASTRUCTURE -- not part of the product.
+//
+// C wrapper around the *unmodified* reference implementation (rawspeed),
+// compiled from the sources where they lie under /root/reference into
+// oracle/_ref/librawspeed_ref.so (see oracle/Makefile).  No reference source
+// is copied into this repository; this file is our own glue that constructs
+// the reference's objects and calls the reference's own entry points:
+//   UncompressedDecompressor::readUncompressedRaw  (UncompressedDecompressor.cpp:202)
+//   LJpegDecompressor::decode                      (LJpegDecompressor.cpp:341)
+//   Cr2Decompressor<>::decompress                  (Cr2DecompressorImpl.h:471)
+//   LJpegDecoder::decode / Cr2LJpegDecoder::decode (container level)
+//   AbstractDngDecompressor::decompress            (AbstractDngDecompressor.cpp:240)
+// It is used (a) to validate oracle/rsx_oracle.c, (b) to generate/verify
+// golden vectors, (c) as bench.py's cpu_baseline (kind "reference").
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load it.
+
+#include "rawspeedconfig.h"
+
+#include "adt/Array1DRef.h"
+#include "adt/Point.h"
+#include "bitstreams/BitStreams.h"
+#include "codes/HuffmanCode.h"
+#include "codes/PrefixCodeDecoder.h"
+#include "common/RawImage.h"
+#include "common/RawspeedException.h"
+#include "decoders/RawDecoderException.h"
+#include "decompressors/AbstractDngDecompressor.h"
+#include "decompressors/Cr2Decompressor.h"
+#include "decompressors/Cr2LJpegDecoder.h"
+#include "decompressors/LJpegDecoder.h"
+#include "decompressors/LJpegDecompressor.h"
+#include "decompressors/UncompressedDecompressor.h"
+#include "io/Buffer.h"
+#include "io/ByteStream.h"
+#include "io/Endianness.h"
+#include "io/IOException.h"
+
+#include "../include/rsx.h"
+
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace rawspeed;
+
+namespace {
+
+thread_local std::string g_last_error;
+int g_threads = 1;
+
+struct RefImage {
+  RawImage img;
+  explicit RefImage(RawImage i) : img(std::move(i)) {}
+};
+
+int classify(const std::exception& e) {
+  g_last_error = e.what();
+  const std::string& s = g_last_error;
+  if (s.find("bad Huffman code") != std::string::npos)
+    return RSX_ERR_BAD_HUFFMAN_CODE;
+  if (s.find("restart marker") != std::string::npos ||
+      s.find("Jpeg marker not encountered") != std::string::npos ||
+      s.find("Not a restart marker") != std::string::npos)
+    return RSX_ERR_RESTART_MARKER;
+  if (s.find("Buffer overflow read in BitStreamer") != std::string::npos)
+    return RSX_ERR_INPUT_OVERFLOW;
+  if (s.find("Too many errors") != std::string::npos)
+    return RSX_ERR_TILE_ERRORS;
+  if (dynamic_cast<const IOException*>(&e) != nullptr)
+    return RSX_ERR_IO;
+  return RSX_ERR_INVALID_ARG;
+}
+
+PrefixCodeDecoder<> makeTable(const rsx_huff_table& t) {
+  HuffmanCode<BaselineCodeTag> hc;
+  const Buffer counts(t.n_codes_per_length, 16);
+  const auto n = hc.setNCodesPerLength(counts);
+  if (n != t.n_code_values)
+    ThrowRDE("code value count mismatch");
+  hc.setCodeValues(Array1DRef<const uint8_t>(t.code_values, int(n)));
+  PrefixCodeDecoder<> d(std::move(hc));
+  d.setup(/*fullDecode=*/true, t.fix_dng_bug16 != 0);
+  return d;
+}
+
+template <typename F> int guarded(F&& f) {
+  try {
+    g_last_error.clear();
+    f();
+    return RSX_OK;
+  } catch (const RawspeedException& e) {
+    return classify(e);
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return RSX_ERR_INVALID_ARG;
+  }
+}
+
+} // namespace
+
+// The embedding application must provide this hook (common/Common.h:41).
+extern "C" int rawspeed_get_number_of_processor_cores() { return g_threads; }
+
+extern "C" {
+
+const char* ref_last_error() { return g_last_error.c_str(); }
+
+void ref_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+
+int ref_max_threads() {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+// RawImage lifetime: UINT16 image of dim_x x dim_y pixels, cpp samples each.
+void* ref_image_create(int dim_x, int dim_y, int cpp, int is_cfa) {
+  try {
+    RawImage img = RawImage::create(RawImageType::UINT16);
+    img->dim = iPoint2D(dim_x, dim_y);
+    img->setCpp(cpp);
+    img->isCFA = is_cfa != 0;
+    img->createData();
+    return new RefImage(std::move(img));
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return nullptr;
+  }
+}
+void ref_image_destroy(void* h) { delete static_cast<RefImage*>(h); }
+uint8_t* ref_image_data(void* h) {
+  auto a = static_cast<RefImage*>(h)->img->getByteDataAsUncroppedArray2DRef();
+  return reinterpret_cast<uint8_t*>(&a(0, 0));
+}
+int ref_image_pitch(void* h) { return static_cast<RefImage*>(h)->img->pitch; }
+void ref_image_fill(void* h, int byte) {
+  auto* r = static_cast<RefImage*>(h);
+  std::memset(ref_image_data(h), byte,
+              size_t(r->img->pitch) * size_t(r->img->dim.y));
+}
+
+int ref_unpack_u16(void* h, const rsx_unpack_desc* d, const uint8_t* in,
+                   size_t in_bytes) {
+  auto* r = static_cast<RefImage*>(h);
+  return guarded([&] {
+    const Buffer b(in, implicit_cast<Buffer::size_type>(in_bytes));
+    const ByteStream bs(DataBuffer(b, Endianness::little));
+    UncompressedDecompressor u(
+        bs, r->img,
+        iRectangle2D({d->crop_x, d->crop_y}, {d->crop_w, d->crop_h}),
+        d->input_pitch_bytes, d->bits_per_pixel,
+        static_cast<BitOrder>(d->bit_order));
+    u.readUncompressedRaw();
+  });
+}
+
+int ref_ljpeg_decompress(void* h, const rsx_ljpeg_desc* d, const uint8_t* in,
+                         size_t in_bytes, uint32_t* consumed) {
+  auto* r = static_cast<RefImage*>(h);
+  return guarded([&] {
+    std::vector<PrefixCodeDecoder<>> tables;
+    tables.reserve(RSX_MAX_COMPONENTS);
+    for (int i = 0; i < d->n_tables; ++i)
+      tables.emplace_back(makeTable(d->tables[i]));
+    std::vector<LJpegDecompressor::PerComponentRecipe> rec;
+    for (int c = 0; c < d->n_comp; ++c) {
+      if (d->table_index[c] >= tables.size())
+        ThrowRDE("bad table index");
+      rec.push_back({tables[d->table_index[c]], d->init_pred[c]});
+    }
+    const LJpegDecompressor::Frame frame{iPoint2D(d->mcu_w, d->mcu_h),
+                                         iPoint2D(d->frame_w, d->frame_h)};
+    LJpegDecompressor dec(
+        r->img,
+        iRectangle2D({d->tile_x, d->tile_y}, {d->tile_w, d->tile_h}), frame,
+        rec, d->rows_per_restart_interval,
+        Array1DRef<const uint8_t>(in, implicit_cast<int>(in_bytes)));
+    const auto n = dec.decode();
+    if (consumed)
+      *consumed = n;
+  });
+}
+
+int ref_cr2_decompress(void* h, const rsx_cr2_desc* d, const uint8_t* in,
+                       size_t in_bytes, uint32_t* consumed) {
+  auto* r = static_cast<RefImage*>(h);
+  return guarded([&] {
+    std::vector<PrefixCodeDecoder<>> tables;
+    tables.reserve(RSX_MAX_COMPONENTS);
+    for (int i = 0; i < d->n_tables; ++i)
+      tables.emplace_back(makeTable(d->tables[i]));
+    using Dec = Cr2Decompressor<PrefixCodeDecoder<>>;
+    std::vector<Dec::PerComponentRecipe> rec;
+    for (int c = 0; c < d->n_comp; ++c) {
+      if (d->table_index[c] >= tables.size())
+        ThrowRDE("bad table index");
+      rec.push_back({tables[d->table_index[c]], d->init_pred[c]});
+    }
+    Dec dec(r->img, std::make_tuple(d->n_comp, d->x_s_f, d->y_s_f),
+            iPoint2D(d->frame_w, d->frame_h),
+            Cr2SliceWidths(implicit_cast<uint16_t>(d->num_slices),
+                           implicit_cast<uint16_t>(d->slice_width),
+                           implicit_cast<uint16_t>(d->last_slice_width)),
+            rec, Array1DRef<const uint8_t>(in, implicit_cast<int>(in_bytes)));
+    const auto n = dec.decompress();
+    if (consumed)
+      *consumed = n;
+  });
+}
+
+// Container level: a whole SOI..EOI blob through LJpegDecoder
+// (decompressors/LJpegDecoder.cpp:66-102).
+int ref_ljpeg_decode_container(void* h, const uint8_t* blob, size_t blob_bytes,
+                               uint32_t off_x, uint32_t off_y, uint32_t w,
+                               uint32_t hgt, int max_dim_x, int max_dim_y,
+                               int fix_dng_bug16) {
+  auto* r = static_cast<RefImage*>(h);
+  return guarded([&] {
+    const Buffer b(blob, implicit_cast<Buffer::size_type>(blob_bytes));
+    const ByteStream bs(DataBuffer(b, Endianness::little));
+    LJpegDecoder d(bs, r->img);
+    d.decode(off_x, off_y, w, hgt, iPoint2D(max_dim_x, max_dim_y),
+             fix_dng_bug16 != 0);
+  });
+}
+
+// Container level: Cr2LJpegDecoder::decode (Cr2LJpegDecoder.cpp:156-165).
+int ref_cr2_decode_container(void* h, const uint8_t* blob, size_t blob_bytes,
+                             int num_slices, int slice_width,
+                             int last_slice_width) {
+  auto* r = static_cast<RefImage*>(h);
+  return guarded([&] {
+    const Buffer b(blob, implicit_cast<Buffer::size_type>(blob_bytes));
+    const ByteStream bs(DataBuffer(b, Endianness::little));
+    Cr2LJpegDecoder d(bs, r->img);
+    d.decode(Cr2SliceWidths(implicit_cast<uint16_t>(num_slices),
+                            implicit_cast<uint16_t>(slice_width),
+                            implicit_cast<uint16_t>(last_slice_width)));
+  });
+}
+
+// AbstractDngDecompressor::decompress over `n_tiles` tiles, row-major tile
+// order; compression 7 (LJPEG blobs) or 1 (uncompressed, `bps` bits).
+// tile_blobs[i] / tile_bytes[i] = data of tile i.
+int ref_dng_decompress(void* h, int compression, uint32_t tile_w,
+                       uint32_t tile_h, int n_tiles,
+                       const uint8_t* const* tile_blobs,
+                       const size_t* tile_bytes, int fix_ljpeg, uint32_t bps,
+                       int big_endian) {
+  auto* r = static_cast<RefImage*>(h);
+  return guarded([&] {
+    const DngTilingDescription dsc(r->img->dim, tile_w, tile_h);
+    if (int(dsc.numTiles) != n_tiles)
+      ThrowRDE("tile count mismatch: %u vs %d", dsc.numTiles, n_tiles);
+    AbstractDngDecompressor slices(r->img, dsc, compression, fix_ljpeg != 0,
+                                   bps, /*predictor=*/1);
+    slices.slices.reserve(n_tiles);
+    for (int i = 0; i < n_tiles; ++i) {
+      const Buffer b(tile_blobs[i],
+                     implicit_cast<Buffer::size_type>(tile_bytes[i]));
+      const ByteStream bs(DataBuffer(
+          b, big_endian ? Endianness::big : Endianness::little));
+      slices.slices.emplace_back(slices.dsc, i, bs);
+    }
+    slices.decompress();
+  });
+}
+
+// Frames-parallel CPU baseline (the shape of rstest's `omp parallel for` over
+// files, src/utilities/rstest/rstest.cpp:570): decode `n_frames` independent
+// container blobs, each into its own image, with `threads` OpenMP threads.
+// kind 0: LJpegDecoder full-image tile; kind 1: Cr2LJpegDecoder single slice.
+int ref_ljpeg_frames_parallel(int n_frames, void* const* images,
+                              const uint8_t* const* blobs,
+                              const size_t* blob_bytes, int kind,
+                              int threads) {
+  int rc = RSX_OK;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+#endif
+  for (int i = 0; i < n_frames; ++i) {
+    auto* r = static_cast<RefImage*>(images[i]);
+    int st;
+    if (kind == 0)
+      st = ref_ljpeg_decode_container(images[i], blobs[i], blob_bytes[i], 0, 0,
+                                      r->img->dim.x, r->img->dim.y,
+                                      r->img->dim.x, r->img->dim.y, 0);
+    else
+      st = ref_cr2_decode_container(images[i], blobs[i], blob_bytes[i], 1, 0,
+                                    r->img->dim.x);
+    if (st != RSX_OK) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+      rc = st;
+    }
+  }
+  return rc;
+}
+
+int ref_unpack_frames_parallel(int n_frames, void* const* images,
+                               const rsx_unpack_desc* d,
+                               const uint8_t* const* ins, size_t in_bytes,
+                               int threads) {
+  int rc = RSX_OK;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+#endif
+  for (int i = 0; i < n_frames; ++i) {
+    const int st = ref_unpack_u16(images[i], d, ins[i], in_bytes);
+    if (st != RSX_OK) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+      rc = st;
+    }
+  }
+  return rc;
+}
+
+} // extern "C"

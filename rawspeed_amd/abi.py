@@ -1,0 +1,130 @@
+"""ctypes mirror of include/rsx.h (the C-ABI of the decompression core).
+
+Only plain C types cross the boundary.  These structures are shared by the
+product binding (rawspeed_amd/capi.py) and by the test-only bindings of the
+oracle (tests/oracle_lib.py), which use the same descriptors.
+"""
+import ctypes as C
+
+RSX_ABI_VERSION = 1
+
+# rsx_status
+RSX_OK = 0
+RSX_ERR_INVALID_ARG = 1
+RSX_ERR_IO = 2
+RSX_ERR_BAD_HUFFMAN_CODE = 3
+RSX_ERR_RESTART_MARKER = 4
+RSX_ERR_INPUT_OVERFLOW = 5
+RSX_ERR_DEVICE = 6
+RSX_ERR_UNSUPPORTED = 7
+RSX_ERR_NOMEM = 8
+RSX_ERR_TILE_ERRORS = 9
+
+STATUS_NAMES = {
+    0: "RSX_OK", 1: "RSX_ERR_INVALID_ARG", 2: "RSX_ERR_IO",
+    3: "RSX_ERR_BAD_HUFFMAN_CODE", 4: "RSX_ERR_RESTART_MARKER",
+    5: "RSX_ERR_INPUT_OVERFLOW", 6: "RSX_ERR_DEVICE", 7: "RSX_ERR_UNSUPPORTED",
+    8: "RSX_ERR_NOMEM", 9: "RSX_ERR_TILE_ERRORS",
+}
+
+# rsx_bit_order == rawspeed::BitOrder (bitstreams/BitStreams.h:27-35)
+ORDER_LSB, ORDER_MSB, ORDER_MSB16, ORDER_MSB32, ORDER_JPEG = range(5)
+
+RSX_MAX_CODE_VALUES = 162
+RSX_MAX_COMPONENTS = 4
+
+
+class Image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("pitch_bytes", C.c_uint32),
+                ("dim_x", C.c_int32), ("dim_y", C.c_int32),
+                ("cpp", C.c_int32), ("is_cfa", C.c_int32)]
+
+
+class UnpackDesc(C.Structure):
+    _fields_ = [("crop_x", C.c_int32), ("crop_y", C.c_int32),
+                ("crop_w", C.c_int32), ("crop_h", C.c_int32),
+                ("input_pitch_bytes", C.c_int32),
+                ("bits_per_pixel", C.c_int32), ("bit_order", C.c_int32)]
+
+
+class HuffTable(C.Structure):
+    _fields_ = [("n_codes_per_length", C.c_uint8 * 16),
+                ("code_values", C.c_uint8 * RSX_MAX_CODE_VALUES),
+                ("n_code_values", C.c_uint8), ("fix_dng_bug16", C.c_uint8)]
+
+    @classmethod
+    def make(cls, counts, values, fix_dng_bug16=False):
+        t = cls()
+        assert len(counts) == 16 and len(values) <= RSX_MAX_CODE_VALUES
+        for i, c in enumerate(counts):
+            t.n_codes_per_length[i] = c
+        for i, v in enumerate(values):
+            t.code_values[i] = v
+        t.n_code_values = len(values)
+        t.fix_dng_bug16 = 1 if fix_dng_bug16 else 0
+        return t
+
+
+class LJpegDesc(C.Structure):
+    _fields_ = [("tile_x", C.c_int32), ("tile_y", C.c_int32),
+                ("tile_w", C.c_int32), ("tile_h", C.c_int32),
+                ("mcu_w", C.c_int32), ("mcu_h", C.c_int32),
+                ("frame_w", C.c_int32), ("frame_h", C.c_int32),
+                ("n_comp", C.c_int32),
+                ("rows_per_restart_interval", C.c_int32),
+                ("init_pred", C.c_uint16 * RSX_MAX_COMPONENTS),
+                ("table_index", C.c_uint8 * RSX_MAX_COMPONENTS),
+                ("n_tables", C.c_int32),
+                ("tables", HuffTable * RSX_MAX_COMPONENTS)]
+
+
+class Cr2Desc(C.Structure):
+    _fields_ = [("n_comp", C.c_int32), ("x_s_f", C.c_int32),
+                ("y_s_f", C.c_int32),
+                ("frame_w", C.c_int32), ("frame_h", C.c_int32),
+                ("num_slices", C.c_int32), ("slice_width", C.c_int32),
+                ("last_slice_width", C.c_int32),
+                ("init_pred", C.c_uint16 * RSX_MAX_COMPONENTS),
+                ("table_index", C.c_uint8 * RSX_MAX_COMPONENTS),
+                ("n_tables", C.c_int32),
+                ("tables", HuffTable * RSX_MAX_COMPONENTS)]
+
+
+class DngLJpegTile(C.Structure):
+    _fields_ = [("desc", LJpegDesc), ("in_", C.c_void_p),
+                ("in_bytes", C.c_size_t)]
+
+
+class DngUnpackTile(C.Structure):
+    _fields_ = [("desc", UnpackDesc), ("in_", C.c_void_p),
+                ("in_bytes", C.c_size_t)]
+
+
+class UnpackJob(C.Structure):
+    _fields_ = [("desc", UnpackDesc), ("in_offset", C.c_uint64),
+                ("in_bytes", C.c_uint64), ("img_offset", C.c_uint64),
+                ("img", Image)]
+
+
+class LJpegJob(C.Structure):
+    _fields_ = [("desc", LJpegDesc), ("in_offset", C.c_uint64),
+                ("in_bytes", C.c_uint64), ("img_offset", C.c_uint64),
+                ("img", Image)]
+
+
+class Cr2Job(C.Structure):
+    _fields_ = [("desc", Cr2Desc), ("in_offset", C.c_uint64),
+                ("in_bytes", C.c_uint64), ("img_offset", C.c_uint64),
+                ("img", Image)]
+
+
+def fill_recipe(desc, tables, table_index, init_pred):
+    """Fill the PerComponentRecipe part of an LJpegDesc / Cr2Desc."""
+    assert 1 <= len(tables) <= RSX_MAX_COMPONENTS
+    desc.n_tables = len(tables)
+    for i, t in enumerate(tables):
+        desc.tables[i] = t
+    for c, ti in enumerate(table_index):
+        desc.table_index[c] = ti
+    for c, p in enumerate(init_pred):
+        desc.init_pred[c] = p

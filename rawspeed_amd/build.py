@@ -1,0 +1,73 @@
+"""In-tree builds of the native libraries (no JIT cache, no site-packages).
+
+  rawspeed_amd/librsx.so        HIP kernels + C-ABI, hipcc --offload-arch=gfx950
+  rawspeed_amd/librsx_synth.so  host-side stream writers (gcc)
+
+hipcc cross-compiles gfx950 without a GPU, so this runs in the build container
+as well as on the MI355X box.  A library is rebuilt only when a source is newer.
+"""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+
+LIB_CORE = os.path.join(PKG, "librsx.so")
+LIB_SYNTH = os.path.join(PKG, "librsx_synth.so")
+
+CORE_SOURCES = ["rsx_api.hip", "rsx_unpack.hip", "rsx_ljpeg.hip", "rsx_host.cpp"]
+CORE_HEADERS = ["rsx_internal.h", "rsx_device.h"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def build_synth(force=False):
+    src = os.path.join(CSRC, "synth", "rsx_synth.c")
+    if force or _stale(LIB_SYNTH, [src]):
+        _run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-Wall", "-Wextra",
+              "-o", LIB_SYNTH, src])
+    return LIB_SYNTH
+
+
+def build_core(force=False, extra_flags=()):
+    srcs = [os.path.join(CSRC, s) for s in CORE_SOURCES]
+    srcs = [s for s in srcs if os.path.exists(s)]
+    deps = srcs + [os.path.join(CSRC, h) for h in CORE_HEADERS] + \
+        [os.path.join(INCLUDE, "rsx.h")]
+    if force or _stale(LIB_CORE, deps):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+               "-shared", "-Wall", "-Wno-unused-function", "-I" + INCLUDE,
+               "-I" + CSRC, *extra_flags, "-o", LIB_CORE, *srcs]
+        _run(cmd)
+    return LIB_CORE
+
+
+def build_all(force=False):
+    return build_core(force), build_synth(force)
+
+
+if __name__ == "__main__":
+    import sys
+    print(build_all(force="--force" in sys.argv))

@@ -1,0 +1,153 @@
+"""Synthetic input generators (numpy front-end of librsx_synth.so).
+
+Mirrors what the reference's tests/benchmarks do with BitVacuumer* and
+PrefixCodeVectorEncoder (bitstreams/BitVacuumer.h, codes/PrefixCodeVectorEncoder.h):
+packed-integer strips for UncompressedDecompressor and lossless-JPEG streams /
+containers for LJpegDecompressor, Cr2Decompressor and DNG tiles.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi, build
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = build.LIB_SYNTH
+        if not os.path.exists(path):
+            build.build_synth()
+        _lib = C.CDLL(path)
+        _lib.rsx_synth_pack_rows.restype = C.c_size_t
+        _lib.rsx_synth_pack_rows.argtypes = [
+            C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+            C.c_void_p]
+        _lib.rsx_synth_uniform.argtypes = [C.c_void_p, C.c_size_t, C.c_int,
+                                           C.c_uint64]
+        _lib.rsx_synth_sensor_image.argtypes = [
+            C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_uint64]
+        _lib.rsx_synth_ljpeg_encode_scan.restype = C.c_size_t
+        _lib.rsx_synth_ljpeg_encode_scan.argtypes = [
+            C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p,
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+            C.c_size_t, C.c_void_p]
+        _lib.rsx_synth_ljpeg_header.restype = C.c_size_t
+        _lib.rsx_synth_ljpeg_header.argtypes = [
+            C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    return _lib
+
+
+# The 14-bit lossless Nikon tree (decompressors/NikonDecompressor.cpp:64-66) is
+# the table SURVEY.md 8(d) uses for the synthetic LJPEG streams: 15 categories
+# (0..14), so 14-bit data never needs SSSS 15/16.
+NIKON14_COUNTS = [0, 1, 4, 2, 2, 3, 1, 2, 0, 0, 0, 0, 0, 0, 0, 0]
+NIKON14_VALUES = [7, 6, 8, 5, 9, 4, 10, 3, 11, 12, 2, 0, 1, 13, 14]
+
+# A table with all 17 categories 0..16 (JPEG Annex K luminance-DC shaped, extended
+# to 17 codes the way Hasselblad files do, AbstractLJpegDecoder.cpp:249-252).
+FULL17_COUNTS = [0, 1, 5, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0]
+FULL17_VALUES = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]
+
+# Short-code-heavy table (different shape from the two above).
+ALT_COUNTS = [0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1]
+ALT_VALUES = [5, 6, 4, 7, 3, 8, 2, 9, 1, 10, 0, 11, 12, 13, 14, 15, 16]
+
+
+def uniform(n, bits, seed):
+    out = np.empty(n, dtype=np.uint16)
+    lib().rsx_synth_uniform(out.ctypes.data, n, bits, seed)
+    return out
+
+
+def sensor_image(w, h, prec=14, seed=1):
+    out = np.empty((h, w), dtype=np.uint16)
+    lib().rsx_synth_sensor_image(out.ctypes.data, w, h, w, prec, seed)
+    return out
+
+
+def pack_rows(samples, bps, order, pitch_bytes=None):
+    """samples: (rows, cols) uint16 -> packed strip bytes (rows*pitch)."""
+    samples = np.ascontiguousarray(samples, dtype=np.uint16)
+    rows, cols = samples.shape
+    if pitch_bytes is None:
+        pitch_bytes = cols * bps // 8
+    out = np.empty(rows * pitch_bytes, dtype=np.uint8)
+    n = lib().rsx_synth_pack_rows(order, bps, samples.ctypes.data, cols, cols,
+                                  rows, pitch_bytes, out.ctypes.data)
+    if n == 0:
+        raise ValueError("cannot pack: bad bps/pitch/order combination")
+    return out
+
+
+def _table_ptrs(tables):
+    counts = [np.asarray(t[0], dtype=np.uint8) for t in tables]
+    values = [np.asarray(t[1], dtype=np.uint8) for t in tables]
+    n = len(tables)
+    cp = (C.c_void_p * n)(*[c.ctypes.data for c in counts])
+    vp = (C.c_void_p * n)(*[v.ctypes.data for v in values])
+    nv = (C.c_int * n)(*[len(v) for v in values])
+    return counts, values, cp, vp, nv
+
+
+def ljpeg_encode_scan(stream_rows, n_comp, init_pred, comp_tables,
+                      rows_per_ri=0, fix16=False):
+    """stream_rows: (rows, frame_w*n_comp) uint16 in stream order.
+    comp_tables: one (counts, values) per component.  Returns
+    (entropy bytes as np.uint8, symbol bits)."""
+    stream_rows = np.ascontiguousarray(stream_rows, dtype=np.uint16)
+    rows, row_samples = stream_rows.shape
+    assert row_samples % n_comp == 0 and len(comp_tables) == n_comp
+    keep = _table_ptrs(comp_tables)
+    _, _, cp, vp, nv = keep
+    ip = np.asarray(init_pred, dtype=np.uint16)
+    cap = rows * row_samples * 5 + 4096
+    out = np.empty(cap, dtype=np.uint8)
+    bits = C.c_uint64(0)
+    n = lib().rsx_synth_ljpeg_encode_scan(
+        stream_rows.ctypes.data, row_samples, row_samples, rows, n_comp,
+        ip.ctypes.data, cp, vp, nv, rows_per_ri, 1 if fix16 else 0,
+        out.ctypes.data, cap, C.byref(bits))
+    if n == 0:
+        raise ValueError("LJPEG encode failed (category missing from table?)")
+    return out[:n].copy(), bits.value
+
+
+def ljpeg_container(stream_rows, n_comp, prec, comp_slot, slot_tables,
+                    rows_per_ri=0, fix16=False, frame_wh=None, samp=None,
+                    tail=16):
+    """Full SOI..EOI blob.  comp_slot[c] = DHT slot of component c,
+    slot_tables[i] = (counts, values) of slot i.  frame_wh overrides the SOF
+    (w, h) (e.g. Canon's half-height quirk); default (row_samples/n_comp, rows).
+    Returns (blob, scan_offset, scan_bytes, symbol_bits)."""
+    stream_rows = np.ascontiguousarray(stream_rows, dtype=np.uint16)
+    rows, row_samples = stream_rows.shape
+    fw, fh = frame_wh if frame_wh else (row_samples // n_comp, rows)
+    init_pred = [1 << (prec - 1)] * n_comp
+    scan, bits = ljpeg_encode_scan(
+        stream_rows, n_comp, init_pred, [slot_tables[s] for s in comp_slot],
+        rows_per_ri, fix16)
+    keep = _table_ptrs(slot_tables)
+    _, _, cp, vp, nv = keep
+    hdr = np.empty(1024, dtype=np.uint8)
+    cs = (C.c_int * n_comp)(*comp_slot)
+    hs = vs = None
+    if samp is not None:
+        hs = (C.c_int * n_comp)(*[s[0] for s in samp])
+        vs = (C.c_int * n_comp)(*[s[1] for s in samp])
+    ri_mcus = rows_per_ri * fw if rows_per_ri else 0
+    nh = lib().rsx_synth_ljpeg_header(hdr.ctypes.data, prec, fw, fh, n_comp, cs,
+                                      len(slot_tables), cp, vp, nv, ri_mcus,
+                                      hs, vs)
+    blob = np.concatenate([hdr[:nh], scan,
+                           np.array([0xFF, 0xD9], dtype=np.uint8),
+                           np.zeros(tail, dtype=np.uint8)])
+    return blob, nh, len(scan), bits
+
+
+def huff_tables(*pairs, fix16=False):
+    return [abi.HuffTable.make(c, v, fix16) for c, v in pairs]

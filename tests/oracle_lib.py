@@ -1,0 +1,240 @@
+"""TEST INFRASTRUCTURE: ctypes bindings of the two checkers.
+
+  Oracle  -- oracle/liboracle.so, our plain-C restatement (oracle/rsx_oracle.c)
+  Ref     -- oracle/_ref/librawspeed_ref.so, the unmodified reference compiled
+             from /root/reference (present only where it was built; it travels
+             to the GPU box as a prebuilt .so)
+
+Both take the same descriptors as the product's C-ABI (include/rsx.h).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from rawspeed_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "librawspeed_ref.so")
+
+
+def build_oracle():
+    src = os.path.join(ORACLE_DIR, "rsx_oracle.c")
+    if (not os.path.exists(ORACLE_SO)
+            or os.path.getmtime(src) > os.path.getmtime(ORACLE_SO)):
+        subprocess.run(["make", "-C", ORACLE_DIR, "oracle"], check=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return ORACLE_SO
+
+
+def out_pitch(dim_x, cpp):
+    """RawImageData::createData pitch (common/RawImage.cpp:80-83)."""
+    return (dim_x * cpp * 2 + 15) // 16 * 16
+
+
+class HostImage:
+    """A host uint16 image laid out like RawImageData (pitch = roundUp(w*bpp,16))."""
+
+    def __init__(self, dim_x, dim_y, cpp=1, is_cfa=True, fill=0xA5, pitch=None):
+        self.dim_x, self.dim_y, self.cpp, self.is_cfa = dim_x, dim_y, cpp, is_cfa
+        self.pitch = pitch or out_pitch(dim_x, cpp)
+        self.buf = np.full(self.pitch * dim_y, fill, dtype=np.uint8)
+
+    def view(self):
+        v = abi.Image()
+        v.data = self.buf.ctypes.data
+        v.pitch_bytes = self.pitch
+        v.dim_x, v.dim_y, v.cpp = self.dim_x, self.dim_y, self.cpp
+        v.is_cfa = 1 if self.is_cfa else 0
+        return v
+
+    def u16(self):
+        return self.buf.view(np.uint16).reshape(self.dim_y, self.pitch // 2)
+
+    def pixels(self):
+        return self.u16()[:, :self.dim_x * self.cpp]
+
+
+def _as_u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data, a.size
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = C.CDLL(build_oracle())
+        L = self.lib
+        L.oracle_unpack_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.oracle_unpack_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_ljpeg_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.c_void_p]
+        L.oracle_ljpeg_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_cr2_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.c_void_p, C.c_void_p]
+        L.oracle_cr2_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_bitreader_get.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_int,
+                                           C.c_void_p, C.c_void_p]
+        L.oracle_huff_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                         C.c_void_p]
+
+    def unpack(self, desc, data, img):
+        a, p, n = _as_u8(data)
+        v = img.view()
+        return self.lib.oracle_unpack_u16(C.byref(desc), p, n, C.byref(v))
+
+    def unpack_validate(self, desc, img, n):
+        v = img.view()
+        return self.lib.oracle_unpack_validate(C.byref(desc), C.byref(v), n)
+
+    def ljpeg(self, desc, data, img):
+        a, p, n = _as_u8(data)
+        v = img.view()
+        consumed = C.c_uint32(0)
+        st = self.lib.oracle_ljpeg_decode(C.byref(desc), p, n, C.byref(v),
+                                          C.byref(consumed))
+        return st, consumed.value
+
+    def ljpeg_validate(self, desc, img, n=0):
+        v = img.view()
+        return self.lib.oracle_ljpeg_validate(C.byref(desc), C.byref(v), n)
+
+    def cr2(self, desc, data, img):
+        a, p, n = _as_u8(data)
+        v = img.view()
+        consumed = C.c_uint32(0)
+        st = self.lib.oracle_cr2_decode(C.byref(desc), p, n, C.byref(v),
+                                        C.byref(consumed))
+        return st, consumed.value
+
+    def cr2_validate(self, desc, img, n=0):
+        v = img.view()
+        return self.lib.oracle_cr2_validate(C.byref(desc), C.byref(v), n)
+
+    def bitreader_get(self, order, data, lens):
+        a, p, n = _as_u8(data)
+        lens = np.asarray(lens, dtype=np.int32)
+        out = np.zeros(len(lens), dtype=np.uint32)
+        st = self.lib.oracle_bitreader_get(order, p, n, len(lens), lens.ctypes.data,
+                                           out.ctypes.data)
+        return st, out
+
+    def huff_decode(self, table, data, n):
+        a, p, nb = _as_u8(data)
+        out = np.zeros(n, dtype=np.int32)
+        st = self.lib.oracle_huff_decode(C.byref(table), p, nb, n, out.ctypes.data)
+        return st, out
+
+
+class RefImage:
+    """RawImage owned by the reference build."""
+
+    def __init__(self, ref, dim_x, dim_y, cpp=1, is_cfa=True, fill=0xA5):
+        self.ref = ref
+        self.dim_x, self.dim_y, self.cpp = dim_x, dim_y, cpp
+        self.h = ref.lib.ref_image_create(dim_x, dim_y, cpp, 1 if is_cfa else 0)
+        if not self.h:
+            raise RuntimeError(ref.last_error())
+        self.pitch = ref.lib.ref_image_pitch(self.h)
+        ref.lib.ref_image_fill(self.h, fill)
+
+    def u16(self):
+        p = self.ref.lib.ref_image_data(self.h)
+        n = self.pitch * self.dim_y
+        buf = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,))
+        return buf.view(np.uint16).reshape(self.dim_y, self.pitch // 2)
+
+    def pixels(self):
+        return self.u16()[:, :self.dim_x * self.cpp]
+
+    def close(self):
+        if self.h:
+            self.ref.lib.ref_image_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Ref:
+    @staticmethod
+    def available():
+        return os.path.exists(REF_SO)
+
+    def __init__(self):
+        self.lib = C.CDLL(REF_SO)
+        L = self.lib
+        L.ref_last_error.restype = C.c_char_p
+        L.ref_image_create.restype = C.c_void_p
+        L.ref_image_create.argtypes = [C.c_int] * 4
+        L.ref_image_destroy.argtypes = [C.c_void_p]
+        L.ref_image_data.restype = C.c_void_p
+        L.ref_image_data.argtypes = [C.c_void_p]
+        L.ref_image_pitch.argtypes = [C.c_void_p]
+        L.ref_image_fill.argtypes = [C.c_void_p, C.c_int]
+        L.ref_unpack_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ref_ljpeg_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_size_t, C.c_void_p]
+        L.ref_cr2_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_void_p]
+        L.ref_ljpeg_decode_container.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32,
+            C.c_uint32, C.c_int, C.c_int, C.c_int]
+        L.ref_cr2_decode_container.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
+                                               C.c_int, C.c_int, C.c_int]
+        L.ref_dng_decompress.argtypes = [
+            C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p,
+            C.c_void_p, C.c_int, C.c_uint32, C.c_int]
+        L.ref_ljpeg_frames_parallel.argtypes = [C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_int, C.c_int]
+        L.ref_unpack_frames_parallel.argtypes = [C.c_int, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_size_t, C.c_int]
+        L.ref_set_threads.argtypes = [C.c_int]
+
+    def last_error(self):
+        return self.lib.ref_last_error().decode(errors="replace")
+
+    def image(self, dim_x, dim_y, cpp=1, is_cfa=True, fill=0xA5):
+        return RefImage(self, dim_x, dim_y, cpp, is_cfa, fill)
+
+    def unpack(self, desc, data, img):
+        a, p, n = _as_u8(data)
+        return self.lib.ref_unpack_u16(img.h, C.byref(desc), p, n)
+
+    def ljpeg(self, desc, data, img):
+        a, p, n = _as_u8(data)
+        consumed = C.c_uint32(0)
+        st = self.lib.ref_ljpeg_decompress(img.h, C.byref(desc), p, n,
+                                           C.byref(consumed))
+        return st, consumed.value
+
+    def cr2(self, desc, data, img):
+        a, p, n = _as_u8(data)
+        consumed = C.c_uint32(0)
+        st = self.lib.ref_cr2_decompress(img.h, C.byref(desc), p, n,
+                                         C.byref(consumed))
+        return st, consumed.value
+
+    def ljpeg_container(self, blob, img, off_x, off_y, w, h, max_dim, fix16=False):
+        a, p, n = _as_u8(blob)
+        return self.lib.ref_ljpeg_decode_container(img.h, p, n, off_x, off_y, w, h,
+                                                   max_dim[0], max_dim[1],
+                                                   1 if fix16 else 0)
+
+    def cr2_container(self, blob, img, num_slices, slice_w, last_w):
+        a, p, n = _as_u8(blob)
+        return self.lib.ref_cr2_decode_container(img.h, p, n, num_slices, slice_w,
+                                                 last_w)
+
+    def dng(self, img, compression, tile_w, tile_h, blobs, fix_ljpeg=False, bps=16,
+            big_endian=False, threads=1):
+        arrs = [np.ascontiguousarray(b, dtype=np.uint8) for b in blobs]
+        n = len(arrs)
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        sizes = (C.c_size_t * n)(*[a.size for a in arrs])
+        self.lib.ref_set_threads(threads)
+        return self.lib.ref_dng_decompress(img.h, compression, tile_w, tile_h, n, ptrs,
+                                           sizes, 1 if fix_ljpeg else 0, bps,
+                                           1 if big_endian else 0)
