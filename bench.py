@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X RAW decompression core.
+
+Metric (BASELINE.json): MPix/s decoded bit-exact + achieved HBM GB/s vs roofline.
+
+A "step" is one pass of the hot path over one batch of synthetic input that is
+already resident in HBM: FRAMES frames of BASELINE configs[1]
+(UncompressedDecompressor, 14-bit packed MSB, 8192x5464) decoded by ONE plan
+launch through the C-ABI (rawspeed_amd/librsx.so).  The batch is larger than
+the 256 MiB Infinity Cache on purpose, so the rate is an HBM rate.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
+
+N>1: one process per GPU (torchrun), every rank decodes its own shard of
+independent frames (weak scaling, no data-path collective; RCCL is used for the
+barrier / max-reduction of the timing and, with --broadcast, to distribute the
+packed buffer from rank 0 over xGMI, timed separately).
+
+Rank 0 prints ONE JSON line.  At N=1 it also carries
+  roofline      -- dominant kernel: algorithmic bytes / hipEvent-measured launch time
+  cpu_baseline  -- the unmodified reference (oracle/_ref) timed on this host's cores
+  extra         -- the LJPEG configs (cfg 3 / cfg 4) measured the same way
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 achievable
+
+CFG2 = dict(w=8192, h=5464, bps=14, order=1)  # BitOrder::MSB
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--broadcast", action="store_true",
+                    help="N>1: rank 0 synthesises the packed batch and broadcasts it over RCCL")
+    return ap.parse_args()
+
+
+def out_pitch():
+    return (CFG2["w"] * 2 + 15) // 16 * 16  # RawImageData pitch (RawImage.cpp:80-83)
+
+
+def make_frames(frames, seed0):
+    """Packed strips of `frames` uniform-random 14-bit frames (+ frame 0's pixels)."""
+    from rawspeed_amd import synth
+    w, h, bps, order = CFG2["w"], CFG2["h"], CFG2["bps"], CFG2["order"]
+    packed, px0 = [], None
+    for f in range(frames):
+        px = synth.uniform(w * h, bps, seed0 + f).reshape(h, w)
+        packed.append(synth.pack_rows(px, bps, order))
+        if f == 0:
+            px0 = px
+    return np.concatenate(packed), px0
+
+
+def unpack_jobs(frames):
+    from rawspeed_amd import abi
+    w, h, bps, order = CFG2["w"], CFG2["h"], CFG2["bps"], CFG2["order"]
+    pitch, opitch = w * bps // 8, out_pitch()
+    jobs = []
+    for f in range(frames):
+        j = abi.UnpackJob()
+        j.desc = abi.UnpackDesc(0, 0, w, h, pitch, bps, order)
+        j.in_offset, j.in_bytes = f * h * pitch, h * pitch
+        j.img_offset = f * h * opitch
+        j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
+            opitch, w, h, 1, 1
+        jobs.append(j)
+    return jobs
+
+
+def cpu_baseline_unpack(packed_frame, budget_s=20.0):
+    """The unmodified reference (oracle/_ref) on this host: 1 thread, then
+    independent frames on all cores (the shape of rstest's omp-for over files)."""
+    from oracle_lib import Ref
+    from rawspeed_amd import abi
+    if not Ref.available():
+        return None
+    ref = Ref()
+    w, h, bps, order = CFG2["w"], CFG2["h"], CFG2["bps"], CFG2["order"]
+    d = abi.UnpackDesc(0, 0, w, h, w * bps // 8, bps, order)
+    img = ref.image(w, h, 1)
+    ref.unpack(d, packed_frame, img)  # warm-up / page touch
+    times = []
+    t_end = time.perf_counter() + budget_s / 3
+    while len(times) < 5 and (time.perf_counter() < t_end or len(times) < 2):
+        t0 = time.perf_counter()
+        st = ref.unpack(d, packed_frame, img)
+        times.append(time.perf_counter() - t0)
+        assert st == 0
+    single = w * h / min(times) / 1e6
+    cores = os.cpu_count() or 1
+    nthreads = max(1, min(cores, ref.lib.ref_max_threads()))
+    imgs = [ref.image(w, h, 1) for _ in range(nthreads)]
+    ptrs = (C.c_void_p * nthreads)(*[i.h for i in imgs])
+    a = np.ascontiguousarray(packed_frame)
+    ins = (C.c_void_p * nthreads)(*[a.ctypes.data] * nthreads)
+    ref.lib.ref_unpack_frames_parallel(nthreads, ptrs, C.byref(d), ins, a.size, nthreads)
+    mt = []
+    t_end = time.perf_counter() + budget_s * 2 / 3
+    while len(mt) < 5 and (time.perf_counter() < t_end or len(mt) < 2):
+        t0 = time.perf_counter()
+        ref.lib.ref_unpack_frames_parallel(nthreads, ptrs, C.byref(d), ins, a.size,
+                                           nthreads)
+        mt.append(time.perf_counter() - t0)
+    multi = nthreads * w * h / min(mt) / 1e6
+    return {"value": round(multi, 1), "unit": "MPix/s", "cores": nthreads,
+            "kind": "reference",
+            "single_thread_value": round(single, 1),
+            "sample": "%d x one 8192x5464 14-bit MSB frame on %d threads (best of %d), "
+                      "and 1 frame on 1 thread (best of %d); UncompressedDecompressor::"
+                      "readUncompressedRaw of the unmodified reference (oracle/_ref, "
+                      "clang -O3 -march=x86-64-v2)" % (nthreads, nthreads, len(mt), len(times))}
+
+
+def main():
+    args = parse()
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    n_gpus = world if distributed else 1
+    if args.gpus != n_gpus and rank == 0:
+        log("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus))
+    torch.cuda.set_device(local_rank)
+
+    import __graft_entry__ as ge
+    ge.build()
+    from rawspeed_amd import capi
+
+    ctx = capi.Context(local_rank)
+    F = args.frames
+    w, h, bps = CFG2["w"], CFG2["h"], CFG2["bps"]
+    opitch = out_pitch()
+    jobs = unpack_jobs(F)
+    bcast_ms = None
+    if distributed and args.broadcast:
+        # rank 0 synthesises the batch; everyone receives it over RCCL / xGMI
+        if rank == 0:
+            packed, px0 = make_frames(F, 1000)
+            inp = torch.from_numpy(packed).cuda()
+        else:
+            packed, px0 = None, None
+            inp = torch.empty(F * h * (w * bps // 8), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        dist.barrier()
+        tb = time.perf_counter()
+        dist.broadcast(inp, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - tb) * 1e3
+    else:
+        packed, px0 = make_frames(F, 1000 + 100 * rank)
+        inp = torch.from_numpy(packed).cuda()
+    out = torch.empty(F * h * opitch, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    plan = ctx.unpack_plan(jobs)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        plan.run(inp.data_ptr(), out.data_ptr(), stream)
+    barrier()
+    # bit-exactness of what is being timed: frame 0 of this rank vs its source
+    rc, st, _ = plan.results()
+    assert rc == 0, (rc, st)
+    bit_exact = None
+    if px0 is not None:
+        got = out[:h * opitch].cpu().numpy().view(np.uint16).reshape(h, opitch // 2)[:, :w]
+        bit_exact = bool(np.array_equal(got, px0))
+        assert bit_exact, "GPU output differs from the packed source"
+    plan.set_timing(True)
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        plan.run(inp.data_ptr(), out.data_ptr(), stream)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    ktime = plan.kernel_time()
+    plan.set_timing(False)
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    pix_per_step = F * w * h * n_gpus
+    value = pix_per_step * args.steps / elapsed / 1e6
+    result = {
+        "metric": "MPix/s decoded (bit-exact)",
+        "value": round(value, 1),
+        "unit": "MPix/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u16",
+        "data": "synthetic",
+        "bit_exact": bit_exact,
+        "config": {
+            "workload": "UncompressedDecompressor 14-bit packed MSB 8192x5464 "
+                        "(BASELINE configs[1]), %d independent frames per GPU per step, "
+                        "inputs and outputs resident in HBM" % F,
+            "frames_per_gpu": F,
+            "parallelism": "frames sharded across %d GPU(s), no data-path collective"
+                           % n_gpus,
+        },
+    }
+    if bcast_ms is not None:
+        result["config"]["input_broadcast_ms"] = round(bcast_ms, 2)
+
+    if rank == 0 and n_gpus == 1:
+        alg_bytes = F * (h * (w * bps // 8) + h * w * 2)  # packed read once + u16 written once
+        if ktime:
+            name, avg_ms, n = ktime
+            achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            result["roofline"] = {
+                "bound": "hbm", "kernel": name,
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_kernel_ms": round(avg_ms, 5), "launches_timed": n,
+            }
+        if not args.no_extra:
+            try:
+                import bench_ljpeg
+                result["extra"] = bench_ljpeg.run(ctx, torch, log)
+            except Exception as e:  # the headline number must survive
+                result["extra"] = {"error": repr(e)}
+        if not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline_unpack(
+                    packed[:h * (w * bps // 8)])
+            except Exception as e:
+                result["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -225,6 +225,23 @@ int oracle_bitreader_get(int order, const uint8_t* data, size_t size, int n,
   return RSX_OK;
 }
 
+/* peekBits(len) for len = 1..n without consuming (IncreasingPeekLengthTest,
+ * BitStreamerTest.h:97-110). */
+int oracle_bitreader_peek_increasing(int order, const uint8_t* data, size_t size,
+                                     int n, uint32_t* out) {
+  bitreader b;
+  br_init(&b, data, (int64_t)size, order);
+  if (b.err)
+    return b.err;
+  for (int len = 1; len <= n; ++len) {
+    br_fill(&b, len);
+    if (b.err)
+      return b.err;
+    out[len - 1] = br_peek_nofill(&b, len);
+  }
+  return RSX_OK;
+}
+
 /* ======================================================================== */
 /* UncompressedDecompressor                                                   */
 /* ======================================================================== */
@@ -408,15 +425,16 @@ static int huff_decode_diff(const hufftab* h, bitreader* b, int* err) {
 }
 
 /* Known-answer probe (test/librawspeed/codes/HuffmanTableTest.cpp:69-132):
- * decode `n` differences from a JPEG-order stream with one table. */
-int oracle_huff_decode(const rsx_huff_table* t, const uint8_t* data,
+ * decode `n` differences from a stream of the given bit order with one table
+ * (the reference test drives the decoder with BitStreamerMSB). */
+int oracle_huff_decode(const rsx_huff_table* t, int order, const uint8_t* data,
                        size_t size, int n, int32_t* out) {
   hufftab h;
   int st = huff_setup(&h, t);
   if (st)
     return st;
   bitreader b;
-  br_init(&b, data, (int64_t)size, RSX_ORDER_JPEG);
+  br_init(&b, data, (int64_t)size, order);
   if (b.err)
     return b.err;
   for (int i = 0; i < n; ++i) {

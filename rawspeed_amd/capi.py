@@ -1,0 +1,212 @@
+"""ctypes binding of the product library rawspeed_amd/librsx.so (include/rsx.h).
+
+The library is the product; this module only marshals arguments.  Loading fails
+loudly if the library is missing, and every decode entry point fails with
+RSX_ERR_DEVICE when there is no GPU -- there is no CPU fallback anywhere.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi, build
+
+_lib = None
+
+# every symbol include/rsx.h declares (tests check that all of them resolve)
+EXPORTS = [
+    "rsx_abi_version", "rsx_status_string", "rsx_device_count", "rsx_ctx_create",
+    "rsx_ctx_destroy", "rsx_ctx_last_error",
+    "rsx_unpack_validate", "rsx_unpack_u16",
+    "rsx_ljpeg_validate", "rsx_ljpeg_decode",
+    "rsx_cr2_validate", "rsx_cr2_decode",
+    "rsx_dng_decompress_ljpeg", "rsx_dng_decompress_uncompressed",
+    "rsx_unpack_plan_create", "rsx_ljpeg_plan_create", "rsx_cr2_plan_create",
+    "rsx_plan_run", "rsx_plan_results", "rsx_plan_set_timing",
+    "rsx_plan_kernel_time", "rsx_plan_destroy",
+]
+
+
+class RsxError(RuntimeError):
+    def __init__(self, status, what=""):
+        self.status = status
+        super().__init__("%s (%d) %s" % (abi.STATUS_NAMES.get(status, "?"), status, what))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = build.LIB_CORE
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "rawspeed_amd/librsx.so is not built: run `python -m rawspeed_amd.build` "
+                "(or __graft_entry__.build()); there is no fallback implementation")
+        L = C.CDLL(path)
+        L.rsx_status_string.restype = C.c_char_p
+        L.rsx_ctx_last_error.restype = C.c_char_p
+        L.rsx_ctx_last_error.argtypes = [C.c_void_p]
+        L.rsx_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.rsx_ctx_destroy.argtypes = [C.c_void_p]
+        L.rsx_unpack_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.rsx_ljpeg_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.rsx_cr2_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.rsx_unpack_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]
+        L.rsx_ljpeg_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                       C.c_void_p, C.c_void_p]
+        L.rsx_cr2_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p, C.c_void_p]
+        L.rsx_dng_decompress_ljpeg.argtypes = [C.c_void_p, C.c_int, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rsx_dng_decompress_uncompressed.argtypes = [C.c_void_p, C.c_int, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p]
+        for name in ("rsx_unpack_plan_create", "rsx_ljpeg_plan_create",
+                     "rsx_cr2_plan_create"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p,
+                                         C.POINTER(C.c_void_p)]
+        L.rsx_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rsx_plan_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rsx_plan_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.rsx_plan_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_char_p),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.rsx_plan_destroy.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def status_string(st):
+    return lib().rsx_status_string(st).decode()
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a
+
+
+class Context:
+    """rsx_ctx: one per device."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        st = lib().rsx_ctx_create(device, C.byref(self._h))
+        if st != abi.RSX_OK:
+            raise RsxError(st, "rsx_ctx_create(device=%d): no usable GPU" % device)
+        self.device = device
+
+    def last_error(self):
+        return lib().rsx_ctx_last_error(self._h).decode(errors="replace")
+
+    def close(self):
+        if self._h:
+            lib().rsx_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-pointer calls (what the patched reference methods call) ------
+    def unpack_u16(self, desc, data, img_view):
+        a = _u8(data)
+        return lib().rsx_unpack_u16(self._h, C.byref(desc), a.ctypes.data, a.size,
+                                    C.byref(img_view))
+
+    def ljpeg_decode(self, desc, data, img_view):
+        a = _u8(data)
+        consumed = C.c_uint32(0)
+        st = lib().rsx_ljpeg_decode(self._h, C.byref(desc), a.ctypes.data, a.size,
+                                    C.byref(img_view), C.byref(consumed))
+        return st, consumed.value
+
+    def cr2_decode(self, desc, data, img_view):
+        a = _u8(data)
+        consumed = C.c_uint32(0)
+        st = lib().rsx_cr2_decode(self._h, C.byref(desc), a.ctypes.data, a.size,
+                                  C.byref(img_view), C.byref(consumed))
+        return st, consumed.value
+
+    def dng_decompress_ljpeg(self, descs, datas, img_view):
+        n = len(descs)
+        arrs = [_u8(d) for d in datas]
+        tiles = (abi.DngLJpegTile * n)()
+        for i in range(n):
+            tiles[i].desc = descs[i]
+            tiles[i].in_ = arrs[i].ctypes.data
+            tiles[i].in_bytes = arrs[i].size
+        st = (C.c_int32 * n)()
+        cons = (C.c_uint32 * n)()
+        rc = lib().rsx_dng_decompress_ljpeg(self._h, n, tiles, C.byref(img_view), st,
+                                            cons)
+        return rc, list(st), list(cons)
+
+    def dng_decompress_uncompressed(self, descs, datas, img_view):
+        n = len(descs)
+        arrs = [_u8(d) for d in datas]
+        tiles = (abi.DngUnpackTile * n)()
+        for i in range(n):
+            tiles[i].desc = descs[i]
+            tiles[i].in_ = arrs[i].ctypes.data
+            tiles[i].in_bytes = arrs[i].size
+        st = (C.c_int32 * n)()
+        rc = lib().rsx_dng_decompress_uncompressed(self._h, n, tiles,
+                                                   C.byref(img_view), st)
+        return rc, list(st)
+
+    # ---- device-resident plans ---------------------------------------------
+    def unpack_plan(self, jobs):
+        return Plan(self, "rsx_unpack_plan_create", abi.UnpackJob, jobs)
+
+    def ljpeg_plan(self, jobs):
+        return Plan(self, "rsx_ljpeg_plan_create", abi.LJpegJob, jobs)
+
+    def cr2_plan(self, jobs):
+        return Plan(self, "rsx_cr2_plan_create", abi.Cr2Job, jobs)
+
+
+class Plan:
+    def __init__(self, ctx, create_fn, job_type, jobs):
+        self.ctx = ctx
+        self.n = len(jobs)
+        arr = (job_type * self.n)(*jobs)
+        self._h = C.c_void_p()
+        st = getattr(lib(), create_fn)(ctx._h, self.n, arr, C.byref(self._h))
+        if st != abi.RSX_OK:
+            raise RsxError(st, ctx.last_error())
+
+    def run(self, in_ptr, out_ptr, stream=None):
+        st = lib().rsx_plan_run(self._h, C.c_void_p(in_ptr), C.c_void_p(out_ptr),
+                                C.c_void_p(stream or 0))
+        if st != abi.RSX_OK:
+            raise RsxError(st, self.ctx.last_error())
+
+    def results(self):
+        st = (C.c_int32 * self.n)()
+        cons = (C.c_uint32 * self.n)()
+        rc = lib().rsx_plan_results(self._h, st, cons)
+        return rc, list(st), list(cons)
+
+    def set_timing(self, on=True):
+        lib().rsx_plan_set_timing(self._h, 1 if on else 0)
+
+    def kernel_time(self):
+        name = C.c_char_p()
+        ms = C.c_double(0)
+        n = C.c_int(0)
+        st = lib().rsx_plan_kernel_time(self._h, C.byref(name), C.byref(ms),
+                                        C.byref(n))
+        if st != abi.RSX_OK:
+            return None
+        return name.value.decode(), ms.value, n.value
+
+    def close(self):
+        if self._h:
+            lib().rsx_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,729 @@
+// rsx_api.hip -- the C-ABI entry points declared in include/rsx.h.
+//
+// Host glue only: validation, staging, plan bookkeeping, launches.  There is
+// no CPU decode path anywhere in this library: without a GPU, context creation
+// fails with RSX_ERR_DEVICE.
+#include "rsx_device.h"
+#include "rsx_internal.h"
+#include "rsx_ljpeg.h"
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+
+using namespace rsx;
+
+// ---------------------------------------------------------------------------
+// Plan
+// ---------------------------------------------------------------------------
+namespace {
+
+enum PlanKind { PLAN_UNPACK = 0, PLAN_LJPEG = 1 };
+
+struct UnpackLaunch {
+  int order = 0;
+  int n_jobs = 0;
+  uint32_t total_blocks = 0;
+  DeviceBuffer d_jobs, d_block_start;
+  std::vector<UnpackJobDev> jobs; // host copy (alignment flags patched per base)
+  uintptr_t last_out_base = ~uintptr_t(0);
+};
+
+struct EventPair {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+
+} // namespace
+
+struct rsx_plan {
+  rsx_ctx* ctx = nullptr;
+  PlanKind kind = PLAN_UNPACK;
+  int n_jobs = 0;
+  std::vector<int32_t> job_status; // host-side validation result per job
+  std::vector<UnpackLaunch> unpack;
+  std::unique_ptr<LJpegPlan, LJpegPlanDeleter> ljpeg;
+  hipStream_t last_stream = nullptr;
+  bool ran = false;
+  // dominant-kernel timing
+  bool timing = false;
+  std::vector<EventPair> events;
+  size_t events_used = 0;
+};
+
+namespace {
+
+int upload(rsx_ctx* ctx, DeviceBuffer& buf, const void* src, size_t bytes) {
+  if (int st = buf.ensure(bytes ? bytes : 16))
+    return st;
+  if (bytes)
+    RSX_HIP_CHECK(ctx, hipMemcpy(buf.ptr, src, bytes, hipMemcpyHostToDevice));
+  return RSX_OK;
+}
+
+EventPair* next_events(rsx_plan* p) {
+  if (p->events_used == p->events.size()) {
+    EventPair e;
+    if (hipEventCreate(&e.start) != hipSuccess ||
+        hipEventCreate(&e.stop) != hipSuccess)
+      return nullptr;
+    p->events.push_back(e);
+  }
+  return &p->events[p->events_used++];
+}
+
+int flatten_unpack_job(const rsx_unpack_job& j, UnpackJobDev* out, int* order) {
+  const rsx_unpack_desc& d = j.desc;
+  if (int st = validate_unpack(d, j.img, size_t(j.in_bytes)))
+    return st;
+  if (j.img.pitch_bytes % 2 != 0)
+    return RSX_ERR_INVALID_ARG;
+  UnpackJobDev u{};
+  u.in_offset = j.in_offset;
+  u.stream_bytes = uint64_t(d.crop_h) * uint64_t(d.input_pitch_bytes);
+  u.in_pitch = uint32_t(d.input_pitch_bytes);
+  u.out_pitch = j.img.pitch_bytes;
+  // h = min(h + oy, dim.y); rows [oy, h)  (UncompressedDecompressor.cpp:209-210)
+  const int64_t rows_avail = int64_t(j.img.dim_y) - d.crop_y;
+  u.n_rows = uint32_t(std::min<int64_t>(d.crop_h, rows_avail));
+  u.cols = uint32_t(d.crop_w) * uint32_t(j.img.cpp);
+  u.bps = uint32_t(d.bits_per_pixel);
+  uint64_t out_off = j.img_offset + uint64_t(d.crop_y) * j.img.pitch_bytes;
+  // Only the 16-bit LSB copyPixels path honours offset.x (:257-264); the
+  // packed paths write from column 0 (:196) -- replicated.
+  if (d.bit_order == RSX_ORDER_LSB && d.bits_per_pixel == 16)
+    out_off += uint64_t(d.crop_x) * uint64_t(j.img.cpp) * 2;
+  u.out_offset = out_off;
+  unpack_blocks_for(u.n_rows, u.cols, &u.segs_per_row, &u.groups_per_row);
+  u.out_aligned = 0; // resolved at run time (needs the output base pointer)
+  *out = u;
+  *order = d.bit_order;
+  return RSX_OK;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// Misc
+// ---------------------------------------------------------------------------
+extern "C" int rsx_abi_version(void) { return RSX_ABI_VERSION; }
+
+extern "C" const char* rsx_status_string(int status) {
+  switch (status) {
+  case RSX_OK: return "RSX_OK";
+  case RSX_ERR_INVALID_ARG: return "RSX_ERR_INVALID_ARG";
+  case RSX_ERR_IO: return "RSX_ERR_IO";
+  case RSX_ERR_BAD_HUFFMAN_CODE: return "RSX_ERR_BAD_HUFFMAN_CODE";
+  case RSX_ERR_RESTART_MARKER: return "RSX_ERR_RESTART_MARKER";
+  case RSX_ERR_INPUT_OVERFLOW: return "RSX_ERR_INPUT_OVERFLOW";
+  case RSX_ERR_DEVICE: return "RSX_ERR_DEVICE";
+  case RSX_ERR_UNSUPPORTED: return "RSX_ERR_UNSUPPORTED";
+  case RSX_ERR_NOMEM: return "RSX_ERR_NOMEM";
+  case RSX_ERR_TILE_ERRORS: return "RSX_ERR_TILE_ERRORS";
+  default: return "RSX_ERR_UNKNOWN";
+  }
+}
+
+extern "C" int rsx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+extern "C" int rsx_ctx_create(int device, rsx_ctx** out_ctx) {
+  if (!out_ctx)
+    return RSX_ERR_INVALID_ARG;
+  *out_ctx = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n)
+    return RSX_ERR_DEVICE; // no GPU: fail loudly, there is no CPU fallback
+  if (hipSetDevice(device) != hipSuccess)
+    return RSX_ERR_DEVICE;
+  auto* ctx = new rsx_ctx();
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return RSX_ERR_DEVICE;
+  }
+  *out_ctx = ctx;
+  return RSX_OK;
+}
+
+extern "C" void rsx_ctx_destroy(rsx_ctx* ctx) {
+  if (!ctx)
+    return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+  }
+  ctx->d_in.release();
+  ctx->d_out.release();
+  delete ctx;
+}
+
+extern "C" const char* rsx_ctx_last_error(const rsx_ctx* ctx) {
+  return ctx ? ctx->last_error.c_str() : "";
+}
+
+extern "C" int rsx_unpack_validate(const rsx_unpack_desc* d, const rsx_image* img,
+                                   size_t in_bytes) {
+  if (!d || !img)
+    return RSX_ERR_INVALID_ARG;
+  return validate_unpack(*d, *img, in_bytes);
+}
+
+extern "C" int rsx_ljpeg_validate(const rsx_ljpeg_desc* d, const rsx_image* img,
+                                  size_t in_bytes) {
+  (void)in_bytes;
+  if (!d || !img)
+    return RSX_ERR_INVALID_ARG;
+  return validate_ljpeg(*d, *img);
+}
+
+extern "C" int rsx_cr2_validate(const rsx_cr2_desc* d, const rsx_image* img,
+                                size_t in_bytes) {
+  (void)in_bytes;
+  if (!d || !img)
+    return RSX_ERR_INVALID_ARG;
+  return validate_cr2(*d, *img);
+}
+
+// ---------------------------------------------------------------------------
+// Plans
+// ---------------------------------------------------------------------------
+extern "C" int rsx_unpack_plan_create(rsx_ctx* ctx, int n_jobs,
+                                      const rsx_unpack_job* jobs,
+                                      rsx_plan** out_plan) {
+  if (!ctx || !jobs || n_jobs < 1 || !out_plan)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto plan = std::make_unique<rsx_plan>();
+  plan->ctx = ctx;
+  plan->kind = PLAN_UNPACK;
+  plan->n_jobs = n_jobs;
+  plan->job_status.assign(n_jobs, RSX_OK);
+  std::vector<UnpackJobDev> per_order[4];
+  for (int i = 0; i < n_jobs; ++i) {
+    UnpackJobDev u;
+    int order = 0;
+    const int st = flatten_unpack_job(jobs[i], &u, &order);
+    plan->job_status[i] = st;
+    if (st == RSX_OK && u.n_rows > 0)
+      per_order[order].push_back(u);
+  }
+  for (int order = 0; order < 4; ++order) {
+    auto& v = per_order[order];
+    if (v.empty())
+      continue;
+    plan->unpack.emplace_back();
+    UnpackLaunch& L = plan->unpack.back();
+    L.order = order;
+    L.n_jobs = int(v.size());
+    std::vector<uint32_t> starts(v.size() + 1, 0);
+    for (size_t k = 0; k < v.size(); ++k)
+      starts[k + 1] = starts[k] + v[k].n_rows * v[k].segs_per_row;
+    L.total_blocks = starts.back();
+    L.jobs = v;
+    if (int st = upload(ctx, L.d_jobs, v.data(), v.size() * sizeof(UnpackJobDev)))
+      return st;
+    if (int st = upload(ctx, L.d_block_start, starts.data(),
+                        starts.size() * sizeof(uint32_t)))
+      return st;
+  }
+  *out_plan = plan.release();
+  return RSX_OK;
+}
+
+// Whether 16-byte stores are legal depends on the run-time output base; the
+// flag is re-resolved (and re-uploaded) only when the base pointer changes.
+namespace {
+
+int run_unpack(rsx_plan* p, const void* in_dev, void* out_dev, hipStream_t s) {
+  rsx_ctx* ctx = p->ctx;
+  for (UnpackLaunch& L : p->unpack) {
+    const uintptr_t base = reinterpret_cast<uintptr_t>(out_dev);
+    if (base != L.last_out_base) {
+      bool changed = false;
+      for (auto& u : L.jobs) {
+        const uintptr_t a = base + u.out_offset;
+        const uint32_t al = ((a & 15) == 0 && (u.out_pitch & 15) == 0) ? 1u : 0u;
+        if (al != u.out_aligned) {
+          u.out_aligned = al;
+          changed = true;
+        }
+      }
+      if (changed)
+        RSX_HIP_CHECK(ctx, hipMemcpyAsync(L.d_jobs.ptr, L.jobs.data(),
+                                          L.jobs.size() * sizeof(UnpackJobDev),
+                                          hipMemcpyHostToDevice, s));
+      L.last_out_base = base;
+    }
+    EventPair* ev = p->timing ? next_events(p) : nullptr;
+    if (ev)
+      RSX_HIP_CHECK(ctx, hipEventRecord(ev->start, s));
+    RSX_HIP_CHECK(ctx, launch_unpack(L.order,
+                                     static_cast<const UnpackJobDev*>(L.d_jobs.ptr),
+                                     static_cast<const uint32_t*>(L.d_block_start.ptr),
+                                     L.n_jobs, L.total_blocks, in_dev, out_dev, s));
+    if (ev)
+      RSX_HIP_CHECK(ctx, hipEventRecord(ev->stop, s));
+  }
+  return RSX_OK;
+}
+
+} // namespace
+
+extern "C" int rsx_plan_run(rsx_plan* plan, const void* in_dev, void* out_dev,
+                            void* stream) {
+  if (!plan || !in_dev || !out_dev)
+    return RSX_ERR_INVALID_ARG;
+  rsx_ctx* ctx = plan->ctx;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  plan->last_stream = s;
+  plan->ran = true;
+  if (plan->kind == PLAN_UNPACK)
+    return run_unpack(plan, in_dev, out_dev, s);
+  EventPair* ev = plan->timing ? next_events(plan) : nullptr;
+  return ljpeg_plan_run(plan->ljpeg.get(), in_dev, out_dev, s,
+                        ev ? ev->start : nullptr, ev ? ev->stop : nullptr);
+}
+
+extern "C" int rsx_plan_results(rsx_plan* plan, int32_t* job_status,
+                                uint32_t* job_consumed) {
+  if (!plan)
+    return RSX_ERR_INVALID_ARG;
+  rsx_ctx* ctx = plan->ctx;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (plan->ran)
+    RSX_HIP_CHECK(ctx, hipStreamSynchronize(plan->last_stream));
+  int rc = RSX_OK;
+  if (plan->kind == PLAN_UNPACK) {
+    for (int i = 0; i < plan->n_jobs; ++i) {
+      if (job_status)
+        job_status[i] = plan->job_status[i];
+      if (job_consumed)
+        job_consumed[i] = 0;
+      if (plan->job_status[i] != RSX_OK)
+        rc = plan->job_status[i];
+    }
+    return rc;
+  }
+  return ljpeg_plan_results(plan->ljpeg.get(), plan->last_stream, plan->ran,
+                            job_status, job_consumed);
+}
+
+extern "C" int rsx_plan_set_timing(rsx_plan* plan, int enable) {
+  if (!plan)
+    return RSX_ERR_INVALID_ARG;
+  plan->timing = enable != 0;
+  plan->events_used = 0;
+  return RSX_OK;
+}
+
+extern "C" int rsx_plan_kernel_time(rsx_plan* plan, const char** kernel_name,
+                                    double* avg_ms, int* n_launches) {
+  if (!plan || !plan->timing || plan->events_used == 0)
+    return RSX_ERR_INVALID_ARG;
+  rsx_ctx* ctx = plan->ctx;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  double total = 0;
+  for (size_t i = 0; i < plan->events_used; ++i) {
+    RSX_HIP_CHECK(ctx, hipEventSynchronize(plan->events[i].stop));
+    float ms = 0;
+    RSX_HIP_CHECK(ctx, hipEventElapsedTime(&ms, plan->events[i].start,
+                                           plan->events[i].stop));
+    total += ms;
+  }
+  if (kernel_name)
+    *kernel_name = plan->kind == PLAN_UNPACK ? unpack_kernel_name()
+                                             : ljpeg_dominant_kernel_name();
+  if (avg_ms)
+    *avg_ms = total / double(plan->events_used);
+  if (n_launches)
+    *n_launches = int(plan->events_used);
+  plan->events_used = 0;
+  return RSX_OK;
+}
+
+extern "C" void rsx_plan_destroy(rsx_plan* plan) {
+  if (!plan)
+    return;
+  rsx_ctx* ctx = plan->ctx;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    if (plan->ran)
+      (void)hipStreamSynchronize(plan->last_stream);
+    for (auto& L : plan->unpack) {
+      L.d_jobs.release();
+      L.d_block_start.release();
+    }
+    for (auto& e : plan->events) {
+      (void)hipEventDestroy(e.start);
+      (void)hipEventDestroy(e.stop);
+    }
+    plan->ljpeg.reset();
+  }
+  delete plan;
+}
+
+// ---------------------------------------------------------------------------
+// Host-pointer calls: stage H2D, run a temporary plan, stage D2H.
+// ---------------------------------------------------------------------------
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Runs n unpack tiles that all write into the same host image.
+int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
+                const uint8_t* const* ins, const size_t* in_bytes,
+                const rsx_image* img, int32_t* statuses) {
+  // device-side layout: inputs back to back (16-byte aligned), one compact
+  // output rectangle per tile
+  std::vector<rsx_unpack_job> jobs(n);
+  std::vector<int32_t> st(n, RSX_OK);
+  size_t in_total = 0, out_total = 0;
+  struct OutRect {
+    size_t dev_off, dev_pitch, width_bytes, rows, host_off;
+  };
+  std::vector<OutRect> rects(n);
+  for (int i = 0; i < n; ++i) {
+    st[i] = validate_unpack(descs[i], *img, in_bytes[i]);
+    if (st[i] != RSX_OK)
+      continue;
+    const rsx_unpack_desc& d = descs[i];
+    const size_t strip = size_t(d.crop_h) * size_t(d.input_pitch_bytes);
+    rsx_unpack_job& j = jobs[i];
+    j.desc = d;
+    j.in_offset = in_total;
+    j.in_bytes = strip;
+    in_total += align_up(strip, 16);
+    const size_t cols = size_t(d.crop_w) * size_t(img->cpp);
+    const int64_t rows =
+        std::min<int64_t>(d.crop_h, int64_t(img->dim_y) - d.crop_y);
+    const bool copy_path = d.bit_order == RSX_ORDER_LSB && d.bits_per_pixel == 16;
+    OutRect r;
+    r.dev_pitch = align_up(cols * 2, 16);
+    r.width_bytes = cols * 2;
+    r.rows = size_t(std::max<int64_t>(rows, 0));
+    r.dev_off = out_total;
+    r.host_off = size_t(d.crop_y) * img->pitch_bytes +
+                 (copy_path ? size_t(d.crop_x) * img->cpp * 2 : 0);
+    out_total += r.dev_pitch * r.rows;
+    rects[i] = r;
+    // The device image view is the compact rectangle: same dims as the host
+    // image but re-based so that row crop_y, column 0 (or crop_x for the copy
+    // path) is the rectangle's origin.
+    j.img = *img;
+    j.img.pitch_bytes = uint32_t(r.dev_pitch);
+    j.img_offset = 0; // patched below via desc-relative offset
+  }
+  if (int e = ctx->d_in.ensure(in_total + 16))
+    return e;
+  if (int e = ctx->d_out.ensure(out_total + 16))
+    return e;
+  hipStream_t s = ctx->stream;
+  for (int i = 0; i < n; ++i) {
+    if (st[i] != RSX_OK)
+      continue;
+    RSX_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t*>(ctx->d_in.ptr) +
+                                          jobs[i].in_offset,
+                                      ins[i], jobs[i].in_bytes,
+                                      hipMemcpyHostToDevice, s));
+  }
+  // Build device jobs directly (the compact rectangles are not expressible as
+  // a plain image view when crop_y > 0, so bypass flatten's offset arithmetic).
+  std::vector<UnpackJobDev> per_order[4];
+  for (int i = 0; i < n; ++i) {
+    if (st[i] != RSX_OK || rects[i].rows == 0)
+      continue;
+    const rsx_unpack_desc& d = descs[i];
+    UnpackJobDev u{};
+    u.in_offset = jobs[i].in_offset;
+    u.stream_bytes = uint64_t(d.crop_h) * uint64_t(d.input_pitch_bytes);
+    u.in_pitch = uint32_t(d.input_pitch_bytes);
+    u.out_pitch = uint32_t(rects[i].dev_pitch);
+    u.n_rows = uint32_t(rects[i].rows);
+    u.cols = uint32_t(d.crop_w) * uint32_t(img->cpp);
+    u.bps = uint32_t(d.bits_per_pixel);
+    u.out_offset = rects[i].dev_off;
+    unpack_blocks_for(u.n_rows, u.cols, &u.segs_per_row, &u.groups_per_row);
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ctx->d_out.ptr) + u.out_offset;
+    u.out_aligned = ((a & 15) == 0 && (u.out_pitch & 15) == 0) ? 1u : 0u;
+    per_order[d.bit_order].push_back(u);
+  }
+  DeviceBuffer d_jobs, d_starts;
+  for (int order = 0; order < 4; ++order) {
+    auto& v = per_order[order];
+    if (v.empty())
+      continue;
+    std::vector<uint32_t> starts(v.size() + 1, 0);
+    for (size_t k = 0; k < v.size(); ++k)
+      starts[k + 1] = starts[k] + v[k].n_rows * v[k].segs_per_row;
+    // stream-ordered: sync before the temporaries are reused by the next order
+    if (int e = d_jobs.ensure(v.size() * sizeof(UnpackJobDev)))
+      return e;
+    if (int e = d_starts.ensure(starts.size() * sizeof(uint32_t)))
+      return e;
+    RSX_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs.ptr, v.data(),
+                                      v.size() * sizeof(UnpackJobDev),
+                                      hipMemcpyHostToDevice, s));
+    RSX_HIP_CHECK(ctx, hipMemcpyAsync(d_starts.ptr, starts.data(),
+                                      starts.size() * sizeof(uint32_t),
+                                      hipMemcpyHostToDevice, s));
+    RSX_HIP_CHECK(ctx, launch_unpack(order, static_cast<UnpackJobDev*>(d_jobs.ptr),
+                                     static_cast<uint32_t*>(d_starts.ptr),
+                                     int(v.size()), starts.back(), ctx->d_in.ptr,
+                                     ctx->d_out.ptr, s));
+    RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  }
+  for (int i = 0; i < n; ++i) {
+    if (st[i] != RSX_OK || rects[i].rows == 0)
+      continue;
+    const OutRect& r = rects[i];
+    RSX_HIP_CHECK(ctx, hipMemcpy2DAsync(static_cast<uint8_t*>(img->data) + r.host_off,
+                                        img->pitch_bytes,
+                                        static_cast<uint8_t*>(ctx->d_out.ptr) + r.dev_off,
+                                        r.dev_pitch, r.width_bytes, r.rows,
+                                        hipMemcpyDeviceToHost, s));
+  }
+  RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  d_jobs.release();
+  d_starts.release();
+  int rc = RSX_OK;
+  for (int i = 0; i < n; ++i) {
+    if (statuses)
+      statuses[i] = st[i];
+    if (st[i] != RSX_OK)
+      rc = st[i];
+  }
+  return rc;
+}
+
+} // namespace
+
+extern "C" int rsx_unpack_u16(rsx_ctx* ctx, const rsx_unpack_desc* d,
+                              const uint8_t* in, size_t in_bytes,
+                              const rsx_image* img) {
+  if (!ctx || !d || !in || !img || !img->data)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  return unpack_host(ctx, 1, d, &in, &in_bytes, img, nullptr);
+}
+
+extern "C" int rsx_dng_decompress_uncompressed(rsx_ctx* ctx, int n_tiles,
+                                               const rsx_dng_unpack_tile* tiles,
+                                               const rsx_image* img,
+                                               int32_t* tile_status) {
+  if (!ctx || !tiles || n_tiles < 1 || !img || !img->data)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  std::vector<rsx_unpack_desc> descs(n_tiles);
+  std::vector<const uint8_t*> ins(n_tiles);
+  std::vector<size_t> sizes(n_tiles);
+  for (int i = 0; i < n_tiles; ++i) {
+    descs[i] = tiles[i].desc;
+    ins[i] = tiles[i].in;
+    sizes[i] = tiles[i].in_bytes;
+  }
+  std::vector<int32_t> st(n_tiles, RSX_OK);
+  const int rc = unpack_host(ctx, n_tiles, descs.data(), ins.data(), sizes.data(),
+                             img, st.data());
+  if (tile_status)
+    std::copy(st.begin(), st.end(), tile_status);
+  if (rc == RSX_ERR_DEVICE || rc == RSX_ERR_NOMEM)
+    return rc;
+  for (int i = 0; i < n_tiles; ++i)
+    if (st[i] != RSX_OK)
+      return RSX_ERR_TILE_ERRORS; // AbstractDngDecompressor.cpp:247-251
+  return RSX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// LJPEG / CR2 entry points: see rsx_ljpeg.hip for the implementation.
+// ---------------------------------------------------------------------------
+extern "C" int rsx_ljpeg_plan_create(rsx_ctx* ctx, int n_jobs,
+                                     const rsx_ljpeg_job* jobs,
+                                     rsx_plan** out_plan) {
+  if (!ctx || !jobs || n_jobs < 1 || !out_plan)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto plan = std::make_unique<rsx_plan>();
+  plan->ctx = ctx;
+  plan->kind = PLAN_LJPEG;
+  plan->n_jobs = n_jobs;
+  std::vector<LJpegJobIn> in(n_jobs);
+  for (int i = 0; i < n_jobs; ++i) {
+    in[i].status = build_ljpeg_stream(jobs[i].desc, jobs[i].img, &in[i].geom);
+    in[i].geom.in_offset = jobs[i].in_offset;
+    in[i].geom.in_bytes = jobs[i].in_bytes;
+    in[i].geom.img_offset = jobs[i].img_offset;
+    in[i].tables = jobs[i].desc.tables;
+    in[i].n_tables = jobs[i].desc.n_tables;
+    in[i].rows_per_restart_interval = jobs[i].desc.rows_per_restart_interval;
+    in[i].frame_h = jobs[i].desc.frame_h;
+  }
+  LJpegPlan* lp = nullptr;
+  if (int st = ljpeg_plan_create(ctx, in, &lp))
+    return st;
+  plan->ljpeg.reset(lp);
+  *out_plan = plan.release();
+  return RSX_OK;
+}
+
+extern "C" int rsx_cr2_plan_create(rsx_ctx* ctx, int n_jobs,
+                                   const rsx_cr2_job* jobs, rsx_plan** out_plan) {
+  if (!ctx || !jobs || n_jobs < 1 || !out_plan)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto plan = std::make_unique<rsx_plan>();
+  plan->ctx = ctx;
+  plan->kind = PLAN_LJPEG;
+  plan->n_jobs = n_jobs;
+  std::vector<LJpegJobIn> in(n_jobs);
+  for (int i = 0; i < n_jobs; ++i) {
+    in[i].status = build_cr2_stream(jobs[i].desc, jobs[i].img, &in[i].geom);
+    in[i].geom.in_offset = jobs[i].in_offset;
+    in[i].geom.in_bytes = jobs[i].in_bytes;
+    in[i].geom.img_offset = jobs[i].img_offset;
+    in[i].tables = jobs[i].desc.tables;
+    in[i].n_tables = jobs[i].desc.n_tables;
+    in[i].rows_per_restart_interval = 0; // CR2 rejects DRI (Cr2LJpegDecoder.cpp:59-60)
+    in[i].frame_h = 0;
+  }
+  LJpegPlan* lp = nullptr;
+  if (int st = ljpeg_plan_create(ctx, in, &lp))
+    return st;
+  plan->ljpeg.reset(lp);
+  *out_plan = plan.release();
+  return RSX_OK;
+}
+
+namespace {
+
+// Generic host-pointer runner for LJPEG-family jobs sharing one host image.
+template <typename JobT, typename CreateFn>
+int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
+                      const uint8_t* const* ins, const rsx_image* img,
+                      CreateFn create, int32_t* statuses, uint32_t* consumed) {
+  // inputs back to back (16-byte aligned) + 64 zero bytes of slack each
+  size_t in_total = 0;
+  for (int i = 0; i < n; ++i) {
+    jobs[i].in_offset = in_total;
+    in_total += align_up(size_t(jobs[i].in_bytes) + 64, 16);
+    jobs[i].img = *img;
+    jobs[i].img_offset = 0;
+  }
+  const size_t out_bytes = size_t(img->pitch_bytes) * size_t(img->dim_y);
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (int e = ctx->d_in.ensure(in_total + 64))
+      return e;
+    if (int e = ctx->d_out.ensure(out_bytes + 64))
+      return e;
+    hipStream_t s = ctx->stream;
+    RSX_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_in.ptr, 0, in_total + 64, s));
+    for (int i = 0; i < n; ++i)
+      RSX_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t*>(ctx->d_in.ptr) +
+                                            jobs[i].in_offset,
+                                        ins[i], jobs[i].in_bytes,
+                                        hipMemcpyHostToDevice, s));
+    // tiles write only their rectangle: bring the current host image over so
+    // untouched pixels survive the round trip
+    RSX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_out.ptr, img->data, out_bytes,
+                                      hipMemcpyHostToDevice, s));
+    RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  }
+  rsx_plan* plan = nullptr;
+  if (int st = create(ctx, n, jobs.data(), &plan))
+    return st;
+  int rc = rsx_plan_run(plan, ctx->d_in.ptr, ctx->d_out.ptr, ctx->stream);
+  if (rc == RSX_OK)
+    rc = rsx_plan_results(plan, statuses, consumed);
+  rsx_plan_destroy(plan);
+  if (rc == RSX_ERR_DEVICE || rc == RSX_ERR_NOMEM)
+    return rc;
+  {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    RSX_HIP_CHECK(ctx, hipMemcpy(img->data, ctx->d_out.ptr, out_bytes,
+                                 hipMemcpyDeviceToHost));
+  }
+  return rc;
+}
+
+} // namespace
+
+extern "C" int rsx_ljpeg_decode(rsx_ctx* ctx, const rsx_ljpeg_desc* d,
+                                const uint8_t* in, size_t in_bytes,
+                                const rsx_image* img, uint32_t* consumed) {
+  if (!ctx || !d || !in || !img || !img->data)
+    return RSX_ERR_INVALID_ARG;
+  std::vector<rsx_ljpeg_job> jobs(1);
+  jobs[0].desc = *d;
+  jobs[0].in_bytes = in_bytes;
+  int32_t st = RSX_OK;
+  uint32_t c = 0;
+  const int rc = ljpeg_family_host(ctx, 1, jobs, &in, img, rsx_ljpeg_plan_create,
+                                   &st, &c);
+  if (consumed)
+    *consumed = c;
+  return rc;
+}
+
+extern "C" int rsx_cr2_decode(rsx_ctx* ctx, const rsx_cr2_desc* d,
+                              const uint8_t* in, size_t in_bytes,
+                              const rsx_image* img, uint32_t* consumed) {
+  if (!ctx || !d || !in || !img || !img->data)
+    return RSX_ERR_INVALID_ARG;
+  std::vector<rsx_cr2_job> jobs(1);
+  jobs[0].desc = *d;
+  jobs[0].in_bytes = in_bytes;
+  int32_t st = RSX_OK;
+  uint32_t c = 0;
+  const int rc = ljpeg_family_host(ctx, 1, jobs, &in, img, rsx_cr2_plan_create,
+                                   &st, &c);
+  if (consumed)
+    *consumed = c;
+  return rc;
+}
+
+extern "C" int rsx_dng_decompress_ljpeg(rsx_ctx* ctx, int n_tiles,
+                                        const rsx_dng_ljpeg_tile* tiles,
+                                        const rsx_image* img,
+                                        int32_t* tile_status,
+                                        uint32_t* tile_consumed) {
+  if (!ctx || !tiles || n_tiles < 1 || !img || !img->data)
+    return RSX_ERR_INVALID_ARG;
+  std::vector<rsx_ljpeg_job> jobs(n_tiles);
+  std::vector<const uint8_t*> ins(n_tiles);
+  for (int i = 0; i < n_tiles; ++i) {
+    jobs[i].desc = tiles[i].desc;
+    jobs[i].in_bytes = tiles[i].in_bytes;
+    ins[i] = tiles[i].in;
+  }
+  std::vector<int32_t> st(n_tiles, RSX_OK);
+  std::vector<uint32_t> cons(n_tiles, 0);
+  const int rc = ljpeg_family_host(ctx, n_tiles, jobs, ins.data(), img,
+                                   rsx_ljpeg_plan_create, st.data(), cons.data());
+  if (tile_status)
+    std::copy(st.begin(), st.end(), tile_status);
+  if (tile_consumed)
+    std::copy(cons.begin(), cons.end(), tile_consumed);
+  if (rc == RSX_ERR_DEVICE || rc == RSX_ERR_NOMEM)
+    return rc;
+  for (int i = 0; i < n_tiles; ++i)
+    if (st[i] != RSX_OK)
+      return RSX_ERR_TILE_ERRORS; // AbstractDngDecompressor.cpp:247-251
+  return RSX_OK;
+}

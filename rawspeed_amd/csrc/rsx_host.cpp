@@ -1,0 +1,413 @@
+// rsx_host.cpp -- host-side logic of the core: descriptor validation (the
+// reference constructors' checks), canonical Huffman table construction and
+// output-geometry flattening.  No device code here.
+#include "rsx_internal.h"
+
+#include <cstring>
+
+namespace rsx {
+
+// ------------------------------------------------------------------------
+// UncompressedDecompressor::UncompressedDecompressor
+// (decompressors/UncompressedDecompressor.cpp:106-169), same order of checks.
+// ------------------------------------------------------------------------
+int validate_unpack(const rsx_unpack_desc& d, const rsx_image& img,
+                    size_t in_bytes) {
+  // input_.getStream(crop.dim.y, inputPitchBytes_) is the first member
+  // initialiser: bounds / overflow -> IOException (io/ByteStream.h getStream).
+  const uint64_t need = uint64_t(uint32_t(d.crop_h)) *
+                        uint64_t(uint32_t(d.input_pitch_bytes));
+  if (need > 0xFFFFFFFFull || need > in_bytes)
+    return RSX_ERR_IO;
+  if (d.crop_w <= 0 || d.crop_h <= 0) // "Empty tile." :112-113
+    return RSX_ERR_INVALID_ARG;
+  if (d.input_pitch_bytes < 1) // :115-116
+    return RSX_ERR_INVALID_ARG;
+  if (d.bit_order < RSX_ORDER_LSB || d.bit_order > RSX_ORDER_MSB32) // :118-127
+    return RSX_ERR_INVALID_ARG;
+  if (img.cpp < 1 || img.cpp > 3) // :135-136
+    return RSX_ERR_INVALID_ARG;
+  if (d.bits_per_pixel < 1 || d.bits_per_pixel > 16) // :138-140 (UINT16)
+    return RSX_ERR_INVALID_ARG;
+  const uint64_t bits =
+      uint64_t(d.crop_w) * uint64_t(img.cpp) * uint64_t(d.bits_per_pixel);
+  if (bits % 8 != 0) // :145-149
+    return RSX_ERR_INVALID_ARG;
+  if (uint64_t(d.input_pitch_bytes) < bits / 8) // :155-156
+    return RSX_ERR_INVALID_ARG;
+  if (d.crop_x < 0 || d.crop_y < 0)
+    return RSX_ERR_INVALID_ARG;
+  if (uint64_t(d.crop_y) > uint64_t(img.dim_y)) // :165-166
+    return RSX_ERR_INVALID_ARG;
+  if (uint64_t(d.crop_x) + uint64_t(d.crop_w) > uint64_t(img.dim_x)) // :167-168
+    return RSX_ERR_INVALID_ARG;
+  // BitStreamerReplenisherBase ctor: "Bit stream size is smaller than
+  // MaxProcessBytes" (bitstreams/BitStreamer.h:58-59); the 16-bit LSB
+  // copyPixels path never builds a bit streamer (:255-265).
+  const bool copy_path =
+      d.bit_order == RSX_ORDER_LSB && d.bits_per_pixel == 16;
+  if (!copy_path && need < 4)
+    return RSX_ERR_IO;
+  return RSX_OK;
+}
+
+// ------------------------------------------------------------------------
+// HuffmanCode::setNCodesPerLength / setCodeValues (codes/HuffmanCode.h:99-166)
+// + full-decode requirement (codes/AbstractPrefixCodeTranscoder.h:71-84).
+// ------------------------------------------------------------------------
+int validate_huff_table(const rsx_huff_table& t) {
+  int max_len = 16;
+  while (max_len > 0 && t.n_codes_per_length[max_len - 1] == 0)
+    --max_len;
+  if (max_len == 0)
+    return RSX_ERR_INVALID_ARG; // "Codes-per-length table is empty"
+  unsigned count = 0;
+  for (int l = 1; l <= max_len; ++l)
+    count += t.n_codes_per_length[l - 1];
+  if (count > RSX_MAX_CODE_VALUES || count != t.n_code_values)
+    return RSX_ERR_INVALID_ARG;
+  unsigned max_codes = 2;
+  for (int l = 1; l <= max_len; ++l) {
+    const unsigned n = t.n_codes_per_length[l - 1];
+    if (n > (1u << l) || n > max_codes)
+      return RSX_ERR_INVALID_ARG; // "Corrupt Huffman"
+    max_codes = (max_codes - n) * 2;
+  }
+  for (unsigned i = 0; i < count; ++i)
+    if (t.code_values[i] > 16)
+      return RSX_ERR_INVALID_ARG; // value is a difference length
+  return RSX_OK;
+}
+
+// Canonical code -> device table.  Symbol semantics:
+// AbstractPrefixCodeDecoder::processSymbol (AbstractPrefixCodeDecoder.h:43-66).
+void build_device_table(const rsx_huff_table& t, DeviceHuffTable* out) {
+  std::memset(out, 0, sizeof *out);
+  int max_len = 16;
+  while (max_len > 0 && t.n_codes_per_length[max_len - 1] == 0)
+    --max_len;
+  out->max_len = uint8_t(max_len);
+  out->fix16 = t.fix_dng_bug16 ? 1 : 0;
+  std::memcpy(out->values, t.code_values, t.n_code_values);
+  for (int l = 0; l < 18; ++l)
+    out->max_code[l] = 0xFFFFFFFFu;
+  uint32_t code = 0;
+  unsigned k = 0;
+  for (int l = 1; l <= max_len; ++l) {
+    const unsigned n = t.n_codes_per_length[l - 1];
+    if (n) {
+      out->val_offset[l] = uint16_t(code - k);
+      out->max_code[l] = code + n - 1;
+      for (unsigned i = 0; i < n; ++i, ++k, ++code) {
+        const unsigned ssss = t.code_values[k];
+        unsigned total = l + (ssss == 16 ? (out->fix16 ? 16u : 0u) : ssss);
+        if (l <= LUT_BITS) {
+          const uint16_t e = uint16_t(l | (ssss << 5) | (total << 10));
+          const uint32_t lo = code << (LUT_BITS - l);
+          const uint32_t hi = lo | ((1u << (LUT_BITS - l)) - 1u);
+          for (uint32_t c = lo; c <= hi; ++c)
+            out->lut[c] = e;
+        }
+        if (code == 0 && l >= 1 && i == 0 && k == 0)
+          out->zero_sym_bits = uint8_t(total); // all-zero code = first code
+      }
+    }
+    code <<= 1;
+  }
+}
+
+// ------------------------------------------------------------------------
+// LJpegDecompressor::LJpegDecompressor (decompressors/LJpegDecompressor.cpp:52-152)
+// ------------------------------------------------------------------------
+static int validate_recipe(const rsx_huff_table* tables, int n_tables,
+                           const uint8_t* table_index, int n_comp) {
+  if (n_tables < 1 || n_tables > RSX_MAX_COMPONENTS)
+    return RSX_ERR_INVALID_ARG;
+  for (int i = 0; i < n_tables; ++i)
+    if (int st = validate_huff_table(tables[i]))
+      return st;
+  for (int c = 0; c < n_comp; ++c)
+    if (table_index[c] >= n_tables)
+      return RSX_ERR_INVALID_ARG;
+  return RSX_OK;
+}
+
+int validate_ljpeg(const rsx_ljpeg_desc& d, const rsx_image& img) {
+  if (img.cpp < 1 || img.cpp > 3) // :61-68
+    return RSX_ERR_INVALID_ARG;
+  if (img.dim_x <= 0 || img.dim_y <= 0) // :70-71
+    return RSX_ERR_INVALID_ARG;
+  if (d.tile_w <= 0 || d.tile_h <= 0) // :73-74
+    return RSX_ERR_INVALID_ARG;
+  if (d.tile_x < 0 || d.tile_y < 0)
+    return RSX_ERR_INVALID_ARG;
+  if (d.tile_x >= img.dim_x || d.tile_y >= img.dim_y) // :84-87
+    return RSX_ERR_INVALID_ARG;
+  if (d.tile_w > img.dim_x || d.tile_h > img.dim_y) // :89-92
+    return RSX_ERR_INVALID_ARG;
+  if (int64_t(d.tile_x) + d.tile_w > img.dim_x ||
+      int64_t(d.tile_y) + d.tile_h > img.dim_y) // :94-97
+    return RSX_ERR_INVALID_ARG;
+  if (d.frame_w <= 0 || d.frame_h <= 0) // :99-100
+    return RSX_ERR_INVALID_ARG;
+  const int mw = d.mcu_w, mh = d.mcu_h;
+  if (!((mh == 1 && mw >= 1 && mw <= 4) || (mw == 2 && mh == 2))) // :102-105
+    return RSX_ERR_INVALID_ARG;
+  if (d.n_comp != mw * mh) // :107-108
+    return RSX_ERR_INVALID_ARG;
+  if (d.rows_per_restart_interval < 1) // :115-116
+    return RSX_ERR_INVALID_ARG;
+  if (int64_t(mw) * d.frame_w > 0x7FFFFFFF ||
+      int64_t(mh) * d.frame_h > 0x7FFFFFFF) // :118-122
+    return RSX_ERR_INVALID_ARG;
+  if (d.tile_w < mw || d.tile_h < mh) // :128-129
+    return RSX_ERR_INVALID_ARG;
+  if (d.tile_h % mh != 0) // :131-132
+    return RSX_ERR_INVALID_ARG;
+  const int64_t req_w = int64_t(img.cpp) * d.tile_w;
+  const int64_t mcus_to_consume = (req_w + mw - 1) / mw;
+  if (d.frame_w < mcus_to_consume || int64_t(mh) * d.frame_h < d.tile_h ||
+      int64_t(mw) * d.frame_w < req_w) // :137-146
+    return RSX_ERR_INVALID_ARG;
+  return validate_recipe(d.tables, d.n_tables, d.table_index, d.n_comp);
+}
+
+// ------------------------------------------------------------------------
+// Cr2Decompressor geometry (Cr2DecompressorImpl.h:76-244, 279-363)
+// ------------------------------------------------------------------------
+namespace {
+
+struct Rect {
+  int x, y, w, h;
+};
+
+struct Cr2Geom {
+  int N, xsf, ysf, sub, slice_col_step, px_per_group, group_size;
+  int dim_x, dim_y, frame_x, frame_y, n_slices, slice_w, last_w;
+};
+
+// evaluateConsecutiveTiles :60-72
+int consecutive(const Rect& a, const Rect& b) {
+  if (a.x == b.x && a.y + a.h == b.y && a.w == b.w)
+    return 1; // ContinuesColumn
+  if (b.y == 0 && b.x == a.x + a.w)
+    return 2; // BeginsNewColumn
+  return 0;
+}
+
+// Cr2OutputTileIterator :104-154, materialised.
+std::vector<Rect> all_output_tiles(const Cr2Geom& g) {
+  std::vector<Rect> tiles;
+  int ox = 0, oy = 0, slice_row = 0, id = 0;
+  while (id < g.n_slices) {
+    Rect t{ox, oy, id + 1 == g.n_slices ? g.last_w : g.slice_w, 0};
+    const int out_rem = g.dim_y - oy, tile_rem = g.frame_y - slice_row;
+    t.h = out_rem < tile_rem ? out_rem : tile_rem;
+    tiles.push_back(t);
+    slice_row += t.h;
+    oy += t.h;
+    if (slice_row == g.frame_y) {
+      ++id;
+      slice_row = 0;
+    }
+    if (oy == g.dim_y) {
+      oy = 0;
+      ox += t.w;
+    }
+    if (t.h <= 0 && tiles.size() > 100000)
+      break; // defensive: cannot happen for validated geometry
+  }
+  return tiles;
+}
+
+int cr2_geom(const rsx_cr2_desc& d, const rsx_image& img, Cr2Geom* g) {
+  if (d.num_slices < 1) // Cr2SliceWidths ctor, Cr2Decompressor.h:66-67
+    return RSX_ERR_INVALID_ARG;
+  if (img.cpp != 1) // :290-291
+    return RSX_ERR_INVALID_ARG;
+  const int N = d.n_comp, X = d.x_s_f, Y = d.y_s_f;
+  if (!((N == 3 && X == 2 && Y == 2) || (N == 3 && X == 2 && Y == 1) ||
+        (N == 2 && X == 1 && Y == 1) || (N == 4 && X == 1 && Y == 1))) // :293-298
+    return RSX_ERR_INVALID_ARG;
+  g->N = N;
+  g->xsf = X;
+  g->ysf = Y;
+  g->sub = (X != 1 || Y != 1);
+  g->slice_col_step = N * X;
+  g->px_per_group = X * Y;
+  g->group_size = !g->sub ? N : 2 + g->px_per_group; // Dsc :250-275
+  if (img.dim_x <= 0 || img.dim_y <= 0 || img.dim_x % g->group_size != 0) // :300-302
+    return RSX_ERR_INVALID_ARG;
+  g->dim_x = img.dim_x / g->group_size;
+  g->dim_y = img.dim_y;
+  if (d.frame_w <= 0 || d.frame_h <= 0 || d.frame_w % X != 0 ||
+      d.frame_h % Y != 0) // :305-308
+    return RSX_ERR_INVALID_ARG;
+  if (img.dim_x > 19440 || img.dim_y > 5920) // :313-316
+    return RSX_ERR_INVALID_ARG;
+  for (int i = 0; i < d.num_slices; ++i) { // :318-322
+    const int w = i + 1 == d.num_slices ? d.last_slice_width : d.slice_width;
+    if (w <= 0)
+      return RSX_ERR_INVALID_ARG;
+  }
+  if (g->sub == (img.is_cfa != 0)) // :324-325
+    return RSX_ERR_INVALID_ARG;
+  if (int st = validate_recipe(d.tables, d.n_tables, d.table_index, N)) // :327-333
+    return st;
+  if (d.slice_width % g->slice_col_step != 0 ||
+      d.last_slice_width % g->slice_col_step != 0) // :335-341
+    return RSX_ERR_INVALID_ARG;
+  g->frame_x = d.frame_w / X;
+  g->frame_y = d.frame_h / Y;
+  g->n_slices = d.num_slices;
+  g->slice_w = d.slice_width / g->slice_col_step;
+  g->last_w = d.last_slice_width / g->slice_col_step;
+  if (int64_t(g->frame_x) * g->frame_y < int64_t(g->dim_x) * g->dim_y) // :343-344
+    return RSX_ERR_INVALID_ARG;
+  return RSX_OK;
+}
+
+// ctor tiling checks :346-362; returns the tiles that contribute
+int cr2_output_tiles(const Cr2Geom& g, std::vector<Rect>* out) {
+  const std::vector<Rect> all = all_output_tiles(g);
+  bool have_last = false;
+  Rect last{};
+  size_t n_used = 0;
+  for (size_t i = 0; i < all.size(); ++i) {
+    const Rect& t = all[i];
+    if (have_last && consecutive(last, t) == 0)
+      return RSX_ERR_INVALID_ARG; // "Invalid tiling"
+    if (t.x + t.w <= g.dim_x && t.y + t.h <= g.dim_y) {
+      last = t;
+      have_last = true;
+      n_used = i + 1;
+      continue;
+    }
+    if (t.x < g.dim_x && t.y < g.dim_y)
+      return RSX_ERR_INVALID_ARG; // "Output tile partially outside of image"
+    break;
+  }
+  if (!have_last)
+    return RSX_ERR_INVALID_ARG; // "No tiles are provided"
+  if (last.x + last.w != g.dim_x || last.y + last.h != g.dim_y)
+    return RSX_ERR_INVALID_ARG; // "Tiles do not cover the entire image area."
+  // getOutputTiles :224-231: up to and including the first tile whose
+  // bottom-right corner is the image's.
+  out->clear();
+  for (size_t i = 0; i < n_used; ++i) {
+    out->push_back(all[i]);
+    if (all[i].x + all[i].w == g.dim_x && all[i].y + all[i].h == g.dim_y)
+      break;
+  }
+  return RSX_OK;
+}
+
+} // namespace
+
+int validate_cr2(const rsx_cr2_desc& d, const rsx_image& img) {
+  Cr2Geom g;
+  if (int st = cr2_geom(d, img, &g))
+    return st;
+  std::vector<Rect> tiles;
+  return cr2_output_tiles(g, &tiles);
+}
+
+int build_ljpeg_stream(const rsx_ljpeg_desc& d, const rsx_image& img,
+                       StreamGeom* s) {
+  if (int st = validate_ljpeg(d, img))
+    return st;
+  std::memset(s, 0, sizeof *s);
+  s->kind = 0;
+  s->n_comp = uint32_t(d.n_comp);
+  s->period = uint32_t(d.n_comp);
+  for (int c = 0; c < d.n_comp; ++c) {
+    s->comp_of_phase[c] = d.table_index[c];
+    s->pred_of_phase[c] = uint8_t(c);
+    s->init_pred[c] = d.init_pred[c];
+  }
+  s->row_samples = uint32_t(d.frame_w) * uint32_t(d.n_comp);
+  s->rows = uint32_t(d.tile_h / d.mcu_h); // rows below the tile are never decoded (:312-315)
+  s->mcu_w = uint32_t(d.mcu_w);
+  s->mcu_h = uint32_t(d.mcu_h);
+  s->out_x = uint32_t(img.cpp) * uint32_t(d.tile_x);
+  s->out_y = uint32_t(d.tile_y);
+  s->keep_samples = uint32_t(img.cpp) * uint32_t(d.tile_w);
+  s->img_pitch_bytes = img.pitch_bytes;
+  return RSX_OK;
+}
+
+int build_cr2_stream(const rsx_cr2_desc& d, const rsx_image& img,
+                     StreamGeom* s) {
+  Cr2Geom g;
+  if (int st = cr2_geom(d, img, &g))
+    return st;
+  std::vector<Rect> tiles;
+  if (int st = cr2_output_tiles(g, &tiles))
+    return st;
+  if (g.sub)
+    return RSX_ERR_UNSUPPORTED; // sRaw <3,2,1>/<3,2,2>: SURVEY 8(f) "next"
+  std::memset(s, 0, sizeof *s);
+  s->kind = 1;
+  s->n_comp = uint32_t(g.N);
+  s->period = uint32_t(g.N);
+  for (int c = 0; c < g.N; ++c) {
+    s->comp_of_phase[c] = d.table_index[c];
+    s->pred_of_phase[c] = uint8_t(c);
+    s->init_pred[c] = d.init_pred[c];
+  }
+  s->row_samples = uint32_t(g.frame_x) * uint32_t(g.group_size);
+  // Only the groups that land in the image are decoded: dim.area() groups
+  // (:431-465 walks output strips, not the frame).
+  const uint64_t total_groups = uint64_t(g.dim_x) * uint64_t(g.dim_y);
+  s->rows = uint32_t((total_groups + g.frame_x - 1) / g.frame_x);
+  s->mcu_w = uint32_t(g.group_size);
+  s->mcu_h = 1;
+  s->img_pitch_bytes = img.pitch_bytes;
+  // coalesce vertically adjacent tiles into strips (:156-205)
+  std::vector<Rect> strips;
+  for (const Rect& t : tiles) {
+    if (!strips.empty() && consecutive(strips.back(), t) == 1 &&
+        strips.back().y + strips.back().h == t.y)
+      strips.back().h += t.h;
+    else
+      strips.push_back(t);
+  }
+  if (strips.size() > size_t(MAX_CR2_STRIPS))
+    return RSX_ERR_UNSUPPORTED;
+  s->n_strips = uint32_t(strips.size());
+  uint64_t first = 0;
+  for (size_t k = 0; k < strips.size(); ++k) {
+    s->strip_x0[k] = uint32_t(strips[k].x) * uint32_t(g.group_size);
+    s->strip_w[k] = uint32_t(strips[k].w) * uint32_t(g.group_size);
+    s->strip_y0[k] = uint32_t(strips[k].y);
+    s->strip_h[k] = uint32_t(strips[k].h);
+    s->strip_first_sample[k] = first;
+    first += uint64_t(s->strip_w[k]) * uint64_t(s->strip_h[k]);
+  }
+  s->strip_first_sample[strips.size()] = first;
+  return RSX_OK;
+}
+
+int DeviceBuffer::ensure(size_t n) {
+  if (n <= bytes)
+    return RSX_OK;
+  release();
+  // round up so that repeated slightly-growing requests do not reallocate
+  size_t want = (n + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+  if (hipMalloc(&ptr, want) != hipSuccess) {
+    ptr = nullptr;
+    bytes = 0;
+    return RSX_ERR_NOMEM;
+  }
+  bytes = want;
+  return RSX_OK;
+}
+
+void DeviceBuffer::release() {
+  if (ptr)
+    (void)hipFree(ptr);
+  ptr = nullptr;
+  bytes = 0;
+}
+
+} // namespace rsx

@@ -1,0 +1,137 @@
+// rsx_internal.h -- shared declarations of the MI355X decompression core.
+// Host-side structures only; device code lives in the .hip files.
+#pragma once
+
+#include "rsx.h"
+
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+namespace rsx {
+
+// ------------------------------------------------------------------------
+// Host-side validation = the reference constructors' checks, in their order
+// (file:line cited at each check in rsx_host.cpp).
+// ------------------------------------------------------------------------
+int validate_unpack(const rsx_unpack_desc& d, const rsx_image& img,
+                    size_t in_bytes);
+int validate_ljpeg(const rsx_ljpeg_desc& d, const rsx_image& img);
+int validate_cr2(const rsx_cr2_desc& d, const rsx_image& img);
+int validate_huff_table(const rsx_huff_table& t);
+
+// ------------------------------------------------------------------------
+// Device-side Huffman table.  Canonical JPEG code (HuffmanCode.h:66-92) turned
+// into (a) a direct LUT on the next LUT_BITS stream bits and (b) the Annex F
+// maxcode/valptr arrays for longer codes.  Layout is ours, not the
+// reference's 11-bit/int32 LUT (PrefixCodeLUTDecoder.h:86-92).
+//   lut entry (u16): bits 0..4  code length (0 = code longer than LUT_BITS or
+//                                invalid -> slow path)
+//                    bits 5..9  SSSS category
+//                    bits 10..15 total bits consumed by the symbol
+//                                (code + difference bits, + the DNG-bug-16 skip)
+// ------------------------------------------------------------------------
+constexpr int LUT_BITS = 11;
+constexpr int LUT_SIZE = 1 << LUT_BITS;
+
+struct DeviceHuffTable {
+  uint16_t lut[LUT_SIZE];
+  // slow path (codes longer than LUT_BITS): for len in 1..16
+  uint32_t max_code[18]; // 0xFFFFFFFF = no code of this length
+  uint16_t val_offset[18]; // code - val_offset[len] = index into values
+  uint8_t values[RSX_MAX_CODE_VALUES];
+  uint8_t max_len;
+  uint8_t fix16;
+  // the symbol decoded from an all-zero bit stream (what the reference reads
+  // past the end-of-stream marker, BitStreamerJPEG.h:155-179)
+  uint8_t zero_sym_bits; // bits consumed by that symbol (0 = invalid code)
+  uint8_t pad;
+};
+
+void build_device_table(const rsx_huff_table& t, DeviceHuffTable* out);
+
+// ------------------------------------------------------------------------
+// Job geometry handed to the LJPEG kernels.  One "stream" = one entropy-coded
+// segment decoded with fresh predictors: a whole scan, or one restart
+// interval.  Output mapping kinds:
+//   LJPEG : stream sample (row r, s) -> MCU m = s / n_comp, comp c = s % n_comp
+//           -> image (tile_y + mcu_h*r + c / mcu_w, tile_x_samples + mcu_w*m + c % mcu_w)
+//           kept iff mcu_w*m + c%mcu_w < tile_w_samples (decodeRowN, LJpegDecompressor.cpp:200-250)
+//   CR2   : stream group g -> vertical output strips (Cr2DecompressorImpl.h:431-465)
+// ------------------------------------------------------------------------
+constexpr int MAX_CR2_STRIPS = 64;
+
+struct StreamGeom {
+  // entropy-coded input of this stream, relative to the batch input base
+  uint64_t in_offset;
+  uint64_t in_bytes;
+  // output image view, relative to the batch output base
+  uint64_t img_offset;
+  uint32_t img_pitch_bytes;
+  // stream shape: `rows` stream rows of `row_samples` samples each
+  uint32_t rows;        // rows actually decoded (tile rows / mcu_h, or frame rows)
+  uint32_t row_samples; // frame_w * n_comp  (samples per stream row)
+  uint32_t n_comp;      // predictor stride within a row
+  uint32_t period;      // table cycle length (== n_comp for non-subsampled)
+  uint8_t comp_of_phase[8]; // table slot for symbol index % period
+  uint8_t pred_of_phase[8]; // predictor component for symbol index % period
+  uint16_t init_pred[4];
+  uint32_t table_base;  // index of this job's first DeviceHuffTable
+  // LJPEG mapping
+  uint32_t kind;        // 0 LJPEG, 1 CR2
+  uint32_t mcu_w, mcu_h;
+  uint32_t out_x;       // first output sample column (cpp * tile_x)
+  uint32_t out_y;       // first output row
+  uint32_t keep_samples; // cpp * tile_w: samples of each output row that are stored
+  // CR2 mapping: strips in stream order; strip k covers output sample columns
+  // [x0, x0 + w) and rows [y0, y0 + h); groups of `group_size` samples
+  uint32_t n_strips;
+  uint32_t strip_x0[MAX_CR2_STRIPS];
+  uint32_t strip_w[MAX_CR2_STRIPS];
+  uint32_t strip_y0[MAX_CR2_STRIPS];
+  uint32_t strip_h[MAX_CR2_STRIPS];
+  uint64_t strip_first_sample[MAX_CR2_STRIPS + 1]; // prefix: stream sample index
+  uint32_t job; // owning job (status / consumed are reported per job)
+};
+
+int build_ljpeg_stream(const rsx_ljpeg_desc& d, const rsx_image& img,
+                       StreamGeom* g);
+int build_cr2_stream(const rsx_cr2_desc& d, const rsx_image& img,
+                     StreamGeom* g);
+
+// ------------------------------------------------------------------------
+// Context / plan
+// ------------------------------------------------------------------------
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t n); // grow-only; returns RSX_OK / RSX_ERR_NOMEM
+  void release();
+};
+
+} // namespace rsx
+
+struct rsx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  std::string last_error;
+  // staging for the host-pointer calls
+  rsx::DeviceBuffer d_in, d_out;
+  void* h_pinned = nullptr;
+  size_t h_pinned_bytes = 0;
+};
+
+#define RSX_HIP_CHECK(ctx, expr)                                               \
+  do {                                                                         \
+    hipError_t _e = (expr);                                                    \
+    if (_e != hipSuccess) {                                                    \
+      if (ctx)                                                                 \
+        (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e); \
+      return RSX_ERR_DEVICE;                                                   \
+    }                                                                          \
+  } while (0)

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/golden_hashes.json from the REFERENCE build.
+
+Run in the build container (needs /root/reference -> oracle/_ref):
+    make -C oracle ref && python tests/golden/make_golden.py
+Every entry is {status, consumed, hash} as produced by the unmodified
+reference (oracle/ref_shim.cpp); hash = rstest-style md5 of per-line md5s.
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import golden_cases as G  # noqa: E402
+from oracle_lib import Ref  # noqa: E402
+
+
+def main():
+    ref = Ref()
+    out = {"unpack": {}, "ljpeg": {}, "cr2": {}}
+    for i, c in enumerate(G.UNPACK_CASES):
+        d, data, (w, h, cpp) = G.build_unpack(c)
+        img = ref.image(w, h, cpp)
+        st = ref.unpack(d, data, img)
+        out["unpack"][str(i)] = {"status": st, "hash": G.image_hash(img.pixels())}
+    for c in G.LJPEG_CASES:
+        d, data, (w, h, cpp), _ = G.build_ljpeg(c)
+        img = ref.image(w, h, cpp)
+        st, consumed = ref.ljpeg(d, data, img)
+        out["ljpeg"][c["name"]] = {"status": st, "consumed": consumed,
+                                   "hash": G.image_hash(img.pixels())}
+    for c in G.CR2_CASES:
+        d, data, (w, h, cpp), _ = G.build_cr2(c)
+        img = ref.image(w, h, cpp)
+        st, consumed = ref.cr2(d, data, img)
+        out["cr2"][c["name"]] = {"status": st, "consumed": consumed,
+                                 "hash": G.image_hash(img.pixels())}
+    path = os.path.join(HERE, "golden_hashes.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote", path, {k: len(v) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

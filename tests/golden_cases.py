@@ -1,0 +1,97 @@
+"""The seeded case list behind tests/golden/*.json.
+
+Each case is rebuilt deterministically from its parameters (numpy Generator
+PCG64 + librsx_synth), decoded, and hashed rstest-style: md5 of the
+concatenated per-line md5 hex digests of the uncropped image, padding excluded
+(src/utilities/rstest/rstest.cpp:131-146).  tests/golden/make_golden.py stores
+the hashes produced by the *reference build* (oracle/_ref); the tests then hold
+the oracle -- and, on the GPU, the HIP path -- to those hashes.
+"""
+import hashlib
+
+import numpy as np
+
+from rawspeed_amd import abi
+
+import cases as C
+
+
+def image_hash(pixels):
+    """pixels: (rows, dim_x*cpp) uint16 view without row padding."""
+    lines = "".join(hashlib.md5(np.ascontiguousarray(r).tobytes()).hexdigest()
+                    for r in pixels)
+    return hashlib.md5(lines.encode()).hexdigest()
+
+
+UNPACK_CASES = []
+for order in range(4):
+    for bps in (1, 4, 7, 8, 10, 12, 13, 14, 15, 16):
+        for (w, h, pad, oy) in ((48, 9, 0, 0), (80, 5, 3, 2), (2056, 3, 1, 0)):
+            if (w * bps) % 8:
+                continue
+            UNPACK_CASES.append(dict(order=order, bps=bps, w=w, h=h, pad=pad, oy=oy))
+
+
+def build_unpack(c, seed=1234):
+    rng = np.random.default_rng([seed, c["order"], c["bps"], c["w"], c["pad"]])
+    pitch = c["w"] * c["bps"] // 8 + c["pad"]
+    data = rng.integers(0, 256, size=c["h"] * pitch, dtype=np.uint8)
+    d = abi.UnpackDesc(0, c["oy"], c["w"], c["h"], pitch, c["bps"], c["order"])
+    return d, data, (c["w"], c["h"] + c["oy"], 1)
+
+
+LJPEG_CASES = [
+    dict(name="mcu2x1_full", img=(64, 8, 1), tile=(0, 0, 64, 8), mcu=(2, 1)),
+    dict(name="mcu1x1", img=(64, 8, 1), tile=(0, 0, 64, 8), mcu=(1, 1)),
+    dict(name="mcu3x1", img=(63, 8, 1), tile=(0, 0, 63, 8), mcu=(3, 1)),
+    dict(name="mcu4x1", img=(64, 8, 1), tile=(0, 0, 64, 8), mcu=(4, 1)),
+    dict(name="mcu2x2", img=(64, 8, 1), tile=(0, 0, 64, 8), mcu=(2, 2)),
+    dict(name="overhang_br", img=(29, 13, 1), tile=(16, 8, 13, 5), mcu=(2, 1), frame=(8, 8)),
+    dict(name="overhang_tl", img=(29, 13, 1), tile=(0, 0, 16, 8), mcu=(2, 1), frame=(8, 8)),
+    dict(name="cpp3", img=(20, 12, 3), tile=(2, 3, 10, 6), mcu=(3, 1)),
+    dict(name="cpp2_wideframe", img=(20, 12, 2), tile=(2, 2, 9, 6), mcu=(4, 1), frame=(6, 7)),
+    dict(name="dri3", img=(64, 12, 1), tile=(0, 0, 64, 12), mcu=(2, 1), rows_per_ri=3),
+    dict(name="dri5", img=(64, 12, 1), tile=(0, 0, 64, 12), mcu=(2, 1), rows_per_ri=5),
+    dict(name="two_tables", img=(64, 16, 1), tile=(0, 0, 64, 16), mcu=(2, 1),
+         tables=("NIKON", "ALT"), table_index=[0, 1]),
+    dict(name="full17_16bit", img=(64, 16, 1), tile=(0, 0, 64, 16), mcu=(2, 1),
+         tables=("FULL17",), full_range=True, prec=16),
+    dict(name="full17_16bit_fix16", img=(64, 16, 1), tile=(0, 0, 64, 16), mcu=(2, 1),
+         tables=("FULL17",), full_range=True, prec=16, fix16=True),
+    dict(name="medium", img=(640, 160, 1), tile=(0, 0, 640, 160), mcu=(2, 1)),
+    dict(name="medium_2x2_tables", img=(320, 128, 1), tile=(0, 0, 320, 128), mcu=(2, 2),
+         tables=("NIKON", "ALT", "FULL17"), table_index=[0, 1, 2, 1]),
+    dict(name="large", img=(2048, 512, 1), tile=(0, 0, 2048, 512), mcu=(2, 1)),
+]
+
+TABLES = {"NIKON": C.NIKON, "FULL17": C.FULL17, "ALT": C.ALT}
+
+
+def build_ljpeg(c, seed=4321):
+    rng = np.random.default_rng([seed, sum(map(ord, c["name"]))])
+    kw = {k: v for k, v in c.items() if k not in ("name", "img", "tables")}
+    kw["tables"] = tuple(TABLES[t] for t in c.get("tables", ("NIKON",)))
+    w, h, cpp = c["img"]
+    d, data, tile_px, scan_len = C.make_ljpeg_case(rng, img_w=w, img_h=h, cpp=cpp, **kw)
+    return d, data, (w, h, cpp), tile_px
+
+
+CR2_CASES = [
+    dict(name="one_slice", w=64, h=8, n=2, slices=(1, 0, 64)),
+    dict(name="three_slices", w=40, h=24, n=2, slices=(3, 16, 8)),
+    dict(name="four_comp", w=48, h=24, n=4, slices=(3, 16, 16)),
+    dict(name="four_comp_tables", w=48, h=24, n=4, slices=(2, 32, 16),
+         tables=("NIKON", "ALT"), table_index=[0, 1, 1, 0]),
+    dict(name="medium", w=672, h=448, n=2, slices=(3, 224, 224)),
+    dict(name="large", w=2016, h=640, n=2, slices=(3, 672, 672)),
+]
+
+
+def build_cr2(c, seed=777):
+    rng = np.random.default_rng([seed, sum(map(ord, c["name"]))])
+    kw = {}
+    if "tables" in c:
+        kw["tables"] = tuple(TABLES[t] for t in c["tables"])
+        kw["table_index"] = c["table_index"]
+    d, data, img, scan_len = C.make_cr2_case(rng, c["w"], c["h"], c["n"], c["slices"], **kw)
+    return d, data, (c["w"], c["h"], 1), img

@@ -77,8 +77,10 @@ class Oracle:
         L.oracle_cr2_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_bitreader_get.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_int,
                                            C.c_void_p, C.c_void_p]
-        L.oracle_huff_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
-                                         C.c_void_p]
+        L.oracle_huff_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t,
+                                         C.c_int, C.c_void_p]
+        L.oracle_bitreader_peek_increasing.argtypes = [C.c_int, C.c_void_p, C.c_size_t,
+                                                       C.c_int, C.c_void_p]
 
     def unpack(self, desc, data, img):
         a, p, n = _as_u8(data)
@@ -121,10 +123,17 @@ class Oracle:
                                            out.ctypes.data)
         return st, out
 
-    def huff_decode(self, table, data, n):
+    def huff_decode(self, table, data, n, order=abi.ORDER_MSB):
         a, p, nb = _as_u8(data)
         out = np.zeros(n, dtype=np.int32)
-        st = self.lib.oracle_huff_decode(C.byref(table), p, nb, n, out.ctypes.data)
+        st = self.lib.oracle_huff_decode(C.byref(table), order, p, nb, n,
+                                         out.ctypes.data)
+        return st, out
+
+    def peek_increasing(self, order, data, n):
+        a, p, nb = _as_u8(data)
+        out = np.zeros(n, dtype=np.uint32)
+        st = self.lib.oracle_bitreader_peek_increasing(order, p, nb, n, out.ctypes.data)
         return st, out
 
 

@@ -1,0 +1,137 @@
+"""CPU-side checks of the product library: it loads, exports every symbol
+include/rsx.h declares, validates descriptors exactly like the oracle (= the
+reference constructors), and refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from rawspeed_amd import abi, build, capi
+
+from oracle_lib import HostImage
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_core()
+    return capi.lib()
+
+
+def test_exports_match_header(lib):
+    hdr = open(os.path.join(ROOT, "include", "rsx.h")).read()
+    declared = set(re.findall(r"\b(rsx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.rsx_abi_version() == abi.RSX_ABI_VERSION
+
+
+def test_struct_sizes_are_stable():
+    # the ctypes mirror must match the C layout the library was compiled with
+    assert C.sizeof(abi.HuffTable) == 16 + 162 + 2
+    assert C.sizeof(abi.UnpackDesc) == 28
+    assert C.sizeof(abi.Image) == 32
+    assert C.sizeof(abi.LJpegDesc) == 4 * 10 + 8 + 4 + 4 + 4 * 180
+    assert C.sizeof(abi.Cr2Desc) == 4 * 8 + 8 + 4 + 4 + 4 * 180
+
+
+def test_status_strings(lib):
+    for code, name in abi.STATUS_NAMES.items():
+        assert capi.status_string(code) == name
+
+
+@pytest.mark.skipif(capi.lib().rsx_device_count() > 0, reason="GPU present")
+def test_no_gpu_means_loud_failure(lib):
+    with pytest.raises(capi.RsxError) as e:
+        capi.Context(0)
+    assert e.value.status == abi.RSX_ERR_DEVICE
+
+
+def test_unpack_validate_matches_oracle(lib, oracle):
+    rng = np.random.default_rng(11)
+    n_ok = 0
+    for _ in range(3000):
+        w = int(rng.integers(1, 40))
+        h = int(rng.integers(1, 12))
+        cpp = int(rng.choice([1, 1, 1, 2, 3, 4]))
+        img = HostImage(max(w, 1), max(h, 1), cpp if cpp <= 3 else 1)
+        img.cpp = cpp
+        d = abi.UnpackDesc(int(rng.integers(-1, 4)), int(rng.integers(-1, h + 2)),
+                           int(rng.integers(0, w + 3)), int(rng.integers(0, h + 3)),
+                           int(rng.integers(0, 80)), int(rng.integers(0, 19)),
+                           int(rng.integers(-1, 6)))
+        n = int(rng.integers(0, 600))
+        v = img.view()
+        a = lib.rsx_unpack_validate(C.byref(d), C.byref(v), n)
+        b = oracle.unpack_validate(d, img, n)
+        # the library additionally reports the bit-streamer "< 4 bytes" IOE at
+        # validation time; the oracle raises it when decoding starts
+        if a != b:
+            assert (a, b) == (abi.RSX_ERR_IO, abi.RSX_OK), (list(bytes(d)), n, a, b)
+            assert d.crop_h * d.input_pitch_bytes < 4
+        n_ok += a == 0
+    assert n_ok > 20
+
+
+def test_ljpeg_validate_matches_oracle(lib, oracle):
+    import cases as cs
+    rng = np.random.default_rng(12)
+    d0, _, _, _ = cs.make_ljpeg_case(rng, img_w=32, img_h=8, cpp=1, tile=(0, 0, 32, 8),
+                                     mcu=(2, 1))
+    n_ok = 0
+    for _ in range(3000):
+        d = abi.LJpegDesc.from_buffer_copy(d0)
+        cpp = int(rng.choice([1, 1, 1, 2, 3, 4]))
+        img = HostImage(int(rng.integers(28, 40)), int(rng.integers(6, 12)), min(cpp, 3))
+        img.cpp = cpp
+        # perturb a random subset of the fields of a valid descriptor
+        pert = {
+            "tile_x": lambda: int(rng.integers(-1, 8)), "tile_y": lambda: int(rng.integers(-1, 6)),
+            "tile_w": lambda: int(rng.integers(0, 40)), "tile_h": lambda: int(rng.integers(0, 12)),
+            "mcu_w": lambda: int(rng.integers(0, 5)), "mcu_h": lambda: int(rng.integers(0, 3)),
+            "frame_w": lambda: int(rng.integers(0, 40)), "frame_h": lambda: int(rng.integers(0, 12)),
+            "n_comp": lambda: int(rng.integers(0, 5)),
+            "rows_per_restart_interval": lambda: int(rng.integers(0, 4)),
+        }
+        for name in rng.choice(list(pert), size=int(rng.integers(0, 3)), replace=False):
+            setattr(d, name, pert[name]())
+        if rng.integers(0, 10) == 0:
+            d.table_index[0] = 3
+        if rng.integers(0, 10) == 0:
+            d.tables[0].code_values[0] = 17
+        v = img.view()
+        a = lib.rsx_ljpeg_validate(C.byref(d), C.byref(v), 100)
+        b = oracle.ljpeg_validate(d, img, 100)
+        assert a == b
+        n_ok += a == 0
+    assert n_ok > 5
+
+
+def test_cr2_validate_matches_oracle(lib, oracle):
+    import cases as cs
+    rng = np.random.default_rng(13)
+    d0, _, _, _ = cs.make_cr2_case(rng, 48, 24, 2, (3, 16, 16))
+    n_ok = 0
+    for _ in range(3000):
+        d = abi.Cr2Desc.from_buffer_copy(d0)
+        w = int(rng.choice([24, 36, 40, 48, 47]))
+        h = int(rng.choice([12, 24]))
+        img = HostImage(w, h, 1, is_cfa=bool(rng.integers(0, 2)))
+        fmt = [(2, 1, 1), (4, 1, 1), (3, 2, 1), (3, 2, 2), (2, 2, 1), (1, 1, 1)]
+        d.n_comp, d.x_s_f, d.y_s_f = fmt[int(rng.integers(0, len(fmt)))]
+        d.frame_w = int(rng.choice([w // 2, w // 4, w, 10, 12, 0]))
+        d.frame_h = int(rng.choice([h, 2 * h, h // 2, 3 * h]))
+        d.num_slices = int(rng.integers(0, 5))
+        d.slice_width = int(rng.choice([0, 8, 12, 16, 24, 7]))
+        d.last_slice_width = int(rng.choice([0, 8, 12, 16, 24, 48, 40]))
+        v = img.view()
+        a = lib.rsx_cr2_validate(C.byref(d), C.byref(v), 100)
+        b = oracle.cr2_validate(d, img, 100)
+        assert a == b, (w, h, d.n_comp, d.x_s_f, d.y_s_f, d.frame_w, d.frame_h,
+                        d.num_slices, d.slice_width, d.last_slice_width, a, b)
+        n_ok += a == 0
+    assert n_ok > 5

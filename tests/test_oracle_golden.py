@@ -1,0 +1,154 @@
+"""Oracle (oracle/rsx_oracle.c) vs the golden hashes the reference produced
+(tests/golden/golden_hashes.json, generator tests/golden/make_golden.py) and,
+where oracle/_ref is present, vs the reference itself, full-buffer compare."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases as G
+from oracle_lib import HostImage
+
+with open(os.path.join(os.path.dirname(__file__), "golden", "golden_hashes.json")) as f:
+    GOLD = json.load(f)
+
+
+@pytest.mark.parametrize("i", range(len(G.UNPACK_CASES)))
+def test_unpack_golden(oracle, i):
+    d, data, (w, h, cpp) = G.build_unpack(G.UNPACK_CASES[i])
+    img = HostImage(w, h, cpp)
+    st = oracle.unpack(d, data, img)
+    g = GOLD["unpack"][str(i)]
+    assert st == g["status"]
+    assert G.image_hash(img.pixels()) == g["hash"]
+
+
+@pytest.mark.parametrize("c", G.LJPEG_CASES, ids=lambda c: c["name"])
+def test_ljpeg_golden(oracle, c):
+    d, data, (w, h, cpp), tile_px = G.build_ljpeg(c)
+    img = HostImage(w, h, cpp)
+    st, consumed = oracle.ljpeg(d, data, img)
+    g = GOLD["ljpeg"][c["name"]]
+    assert (st, consumed) == (g["status"], g["consumed"])
+    assert G.image_hash(img.pixels()) == g["hash"]
+    # round trip: the decoded tile is the image the stream was encoded from
+    tx, ty, tw, th = c["tile"]
+    assert np.array_equal(img.pixels()[ty:ty + th, cpp * tx:cpp * (tx + tw)], tile_px)
+
+
+@pytest.mark.parametrize("c", G.CR2_CASES, ids=lambda c: c["name"])
+def test_cr2_golden(oracle, c):
+    d, data, (w, h, cpp), src = G.build_cr2(c)
+    img = HostImage(w, h, cpp)
+    st, consumed = oracle.cr2(d, data, img)
+    g = GOLD["cr2"][c["name"]]
+    assert (st, consumed) == (g["status"], g["consumed"])
+    assert G.image_hash(img.pixels()) == g["hash"]
+    assert np.array_equal(img.pixels(), src)
+
+
+# ---- live cross-checks against the compiled reference ----------------------
+
+def test_unpack_vs_ref_sweep(oracle, ref):
+    from rawspeed_amd import abi
+    rng = np.random.default_rng(0)
+    n = 0
+    for order in range(4):
+        for bps in range(1, 17):
+            for w in (8, 24, 40):
+                for pad in (0, 1, 3):
+                    for oy in (0, 2):
+                        if (w * bps) % 8:
+                            continue
+                        h = 5
+                        pitch = w * bps // 8 + pad
+                        data = rng.integers(0, 256, size=h * pitch, dtype=np.uint8)
+                        d = abi.UnpackDesc(0, oy, w, h, pitch, bps, order)
+                        hi, ri = HostImage(w, h + oy), ref.image(w, h + oy)
+                        assert oracle.unpack(d, data, hi) == ref.unpack(d, data, ri)
+                        assert np.array_equal(hi.u16(), ri.u16()), (order, bps, w, pad, oy)
+                        n += 1
+    assert n > 1000
+
+
+def test_unpack_errors_vs_ref(oracle, ref):
+    from rawspeed_amd import abi
+    data = np.zeros(64, np.uint8)
+    for d in [abi.UnpackDesc(0, 0, 8, 4, 12, 12, 0),     # ok
+              abi.UnpackDesc(0, 0, 8, 40, 12, 12, 0),    # not enough rows -> IOE
+              abi.UnpackDesc(0, 0, 0, 4, 12, 12, 0),     # empty tile
+              abi.UnpackDesc(0, 0, 8, 4, 11, 12, 0),     # pitch too small
+              abi.UnpackDesc(0, 0, 8, 4, 12, 12, 4),     # JPEG order
+              abi.UnpackDesc(0, 0, 8, 4, 12, 17, 0),     # bps > 16
+              abi.UnpackDesc(0, 0, 7, 4, 12, 12, 0),     # bits % 8
+              abi.UnpackDesc(0, 5, 8, 4, 12, 12, 0),     # oy > dim.y
+              abi.UnpackDesc(1, 0, 8, 4, 12, 12, 0),     # ox + w > dim.x
+              abi.UnpackDesc(0, 0, 8, 1, 2, 2, 1)]:      # stream < 4 bytes
+        hi, ri = HostImage(8, 4), ref.image(8, 4)
+        assert oracle.unpack(d, data, hi) == ref.unpack(d, data, ri), list(bytes(d))
+
+
+@pytest.mark.parametrize("c", G.LJPEG_CASES, ids=lambda c: c["name"])
+def test_ljpeg_vs_ref(oracle, ref, c):
+    d, data, (w, h, cpp), _ = G.build_ljpeg(c)
+    hi, ri = HostImage(w, h, cpp), ref.image(w, h, cpp)
+    assert oracle.ljpeg(d, data, hi) == ref.ljpeg(d, data, ri)
+    assert np.array_equal(hi.u16(), ri.u16())
+
+
+def test_ljpeg_corrupt_streams_vs_ref(oracle, ref):
+    """Random corruption: status, consumed bytes and (on success) pixels agree."""
+    rng = np.random.default_rng(5)
+    c = next(x for x in G.LJPEG_CASES if x["name"] == "medium")
+    d, data, (w, h, cpp), _ = G.build_ljpeg(c)
+    n_fail = 0
+    for trial in range(40):
+        bad = data.copy()
+        if trial % 4 == 0:
+            bad = bad[:rng.integers(8, len(bad) // 2)]            # truncation
+        elif trial % 4 == 1:
+            bad[rng.integers(0, len(bad) - 20)] = 0xFF            # early marker
+        else:
+            idx = rng.integers(0, len(bad) - 20, size=3)
+            bad[idx] = rng.integers(0, 256, size=3)
+        hi, ri = HostImage(w, h, cpp), ref.image(w, h, cpp)
+        so, sr = oracle.ljpeg(d, bad, hi), ref.ljpeg(d, bad, ri)
+        assert so[0] == sr[0], (trial, so, sr, ref.last_error())
+        if so[0] == 0:
+            assert so[1] == sr[1]
+            assert np.array_equal(hi.u16(), ri.u16())
+        else:
+            n_fail += 1
+    assert n_fail > 0
+
+
+@pytest.mark.parametrize("c", G.CR2_CASES, ids=lambda c: c["name"])
+def test_cr2_vs_ref(oracle, ref, c):
+    d, data, (w, h, cpp), _ = G.build_cr2(c)
+    hi, ri = HostImage(w, h, cpp), ref.image(w, h, cpp)
+    assert oracle.cr2(d, data, hi) == ref.cr2(d, data, ri)
+    assert np.array_equal(hi.u16(), ri.u16())
+
+
+def test_cr2_geometry_vs_ref(oracle, ref):
+    """Slice / frame shapes incl. wrapped slices (frame.y != dim.y) and rejects."""
+    import cases as C
+    rng = np.random.default_rng(9)
+    d, data, img, _ = C.make_cr2_case(rng, 40, 24, 2, (3, 16, 8))
+    variants = []
+    for (fw, fh, ns, sw, lw) in [(20, 24, 3, 16, 8), (20, 24, 3, 16, 6), (10, 48, 2, 20, 20),
+                                 (40, 12, 1, 0, 40), (20, 24, 2, 20, 20), (20, 24, 3, 14, 12),
+                                 (20, 24, 1, 0, 38), (5, 96, 4, 10, 10), (20, 24, 0, 0, 40)]:
+        v = type(d).from_buffer_copy(d)
+        v.frame_w, v.frame_h, v.num_slices, v.slice_width, v.last_slice_width = fw, fh, ns, sw, lw
+        variants.append(v)
+    n_ok = 0
+    for v in variants:
+        hi, ri = HostImage(40, 24, 1), ref.image(40, 24, 1)
+        so, sr = oracle.cr2(v, data, hi), ref.cr2(v, data, ri)
+        assert so[0] == sr[0], (v.frame_w, v.frame_h, v.num_slices, so, sr, ref.last_error())
+        if so[0] == 0:
+            n_ok += 1
+            assert so[1] == sr[1] and np.array_equal(hi.u16(), ri.u16())
+    assert n_ok >= 3
