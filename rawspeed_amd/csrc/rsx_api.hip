@@ -322,6 +322,18 @@ extern "C" int rsx_plan_set_timing(rsx_plan* plan, int enable) {
     return RSX_ERR_INVALID_ARG;
   plan->timing = enable != 0;
   plan->events_used = 0;
+  if (plan->timing && plan->events.size() < 64) {
+    // event creation is slow on ROCm: pre-create the pool outside timed regions
+    std::lock_guard<std::mutex> lock(plan->ctx->mu);
+    (void)hipSetDevice(plan->ctx->device);
+    while (plan->events.size() < 64) {
+      EventPair e;
+      if (hipEventCreate(&e.start) != hipSuccess ||
+          hipEventCreate(&e.stop) != hipSuccess)
+        return RSX_ERR_DEVICE;
+      plan->events.push_back(e);
+    }
+  }
   return RSX_OK;
 }
 

@@ -60,7 +60,13 @@ def test_unpack_sweep_vs_oracle(gpu, oracle):
                 if dim_y == 0:
                     dim_y = 1
                 want = HostImage(w, dim_y, 1)
-                assert oracle.unpack(d, data, want) == 0
+                st = oracle.unpack(d, data, want)
+                if st != 0:
+                    # < 4 bytes of stream: the bit streamer refuses (BitStreamer.h:58-59)
+                    assert st == abi.RSX_ERR_IO and h * pitch < 4
+                    got = HostImage(w, dim_y, 1)
+                    assert gpu.unpack_u16(d, data, got.view()) == st
+                    continue
                 j = abi.UnpackJob()
                 j.desc = d
                 j.in_offset, j.in_bytes = in_off, data.size
