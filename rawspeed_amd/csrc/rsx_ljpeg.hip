@@ -1,18 +1,1331 @@
-// placeholder until the LJPEG pipeline lands
+// rsx_ljpeg.hip -- lossless-JPEG (predictor 1) decode pipeline for gfx950.
+//
+// Replaces the serial loops of
+//   LJpegDecompressor::decodeN / decodeRowN  (decompressors/LJpegDecompressor.cpp:184-339)
+//   Cr2Decompressor::decompressN_X_Y         (decompressors/Cr2DecompressorImpl.h:396-468)
+// which walk ONE BitStreamerJPEG over the whole scan (no per-row index).
+//
+// Pipeline (one "stream" = one scan or one restart interval; many streams per
+// launch: DNG tiles, batched frames):
+//
+//  K1 lj_sync      self-synchronising speculative Huffman decode.  The physical
+//                  byte stream is cut into 64-byte subsequences, one lane each;
+//                  a workgroup stages 256 of them through LDS (coalesced 16-byte
+//                  loads, dwords transposed so that lane j always hits bank
+//                  j%32), every lane un-stuffs FF00 / detects the FFxx end marker
+//                  for its own subsequence in LDS, decodes it from a guessed
+//                  start, and the workgroup iterates "re-decode from the
+//                  predecessor's exit state" until nothing changes.  Slot 0 of a
+//                  workgroup is a warm-up copy of the previous workgroup's last
+//                  subsequence, so the guess for slot 1 is almost always right.
+//  K2 lj_sync<STITCH>  cross-workgroup fix-up: a workgroup whose assumed start
+//                  differs from its predecessor's recorded exit re-converges.
+//                  (Jacobi iteration: a fixed point is the serial decode.)
+//  K3 lj_scan      per stream: verify the chain, exclusive scan of symbol counts.
+//  K4 lj_decode    final decode from validated start states; int16 differences
+//                  go through an LDS window to a stream-ordered scratch buffer
+//                  with 16-byte coalesced stores.
+//  K5 lj_vseed     vertical chain: predictor seed of every stream row (the row's
+//                  first MCU predicts from the first MCU of the previous row,
+//                  LJpegDecompressor.cpp:326-332, Cr2DecompressorImpl.h:437-451).
+//  K6 lj_predict   one wavefront per stream row: per-component inclusive scan
+//                  mod 2^16 (lane-local scan + DPP/shuffle wave scan), then the
+//                  output mapping (tile crop / MCU layout / CR2 vertical strips).
+//  K7 lj_consumed  decode()'s return value (SURVEY A.6 closed form).
+//
+// Symbol semantics: codes/AbstractPrefixCodeDecoder.h:43-76; end-of-stream:
+// bitstreams/BitStreamerJPEG.h:106-183.  No MFMA (no contraction anywhere).
 #include "rsx_ljpeg.h"
+
+#include <algorithm>
+#include <cstddef>
+#include <cstring>
+#include <memory>
+
 namespace rsx {
-struct LJpegPlan { int n = 0; };
-int ljpeg_plan_create(rsx_ctx*, const std::vector<LJpegJobIn>& jobs, LJpegPlan** out) {
-  *out = new LJpegPlan{int(jobs.size())};
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Geometry constants
+// ---------------------------------------------------------------------------
+constexpr int LJ_T = 256;             // lanes per workgroup = slots per workgroup
+constexpr int LJ_P = 64;              // physical bytes per subsequence
+constexpr int LJ_PW = LJ_P / 4;       // dwords per subsequence
+constexpr int LJ_OWN = LJ_T - 1;      // owned slots (slot 0 = warm-up)
+constexpr int LJ_R = LJ_OWN * LJ_P;   // bytes of stream owned by one workgroup
+constexpr int LJ_BW = LJ_PW + 4;      // compacted slot capacity (dwords)
+constexpr int LJ_WIN = 8192;          // K4 output window (samples) -- reuses A
+constexpr int LJ_CHUNKS = 1 + LJ_T * LJ_PW / 4 + 1; // prev + region + lookahead
+
+constexpr uint32_t ST_OFF_MASK = 63u;
+constexpr uint32_t ST_PHASE_SHIFT = 6;
+constexpr uint32_t ST_ERR = 1u << 9;
+constexpr uint32_t ST_MASK = 0xFFFFu;
+
+constexpr uint32_t NO_CODE = 0xFFFFFFFFu;
+
+// flags in LjResult::flags
+constexpr uint32_t FL_UNCONVERGED = 1u;
+
+struct TabLds {
+  uint16_t lut[LUT_SIZE];
+  uint32_t max_code[18];
+  uint16_t val_offset[18];
+  uint8_t values[RSX_MAX_CODE_VALUES];
+  uint8_t max_len;
+  uint8_t fix16;
+  uint8_t zero_sym_bits;
+  uint8_t pad[1 + 12];
+};
+static_assert(sizeof(TabLds) == sizeof(DeviceHuffTable) + 12 ||
+                  sizeof(TabLds) % 16 == 0,
+              "TabLds layout");
+static_assert(sizeof(TabLds) % 16 == 0, "TabLds must be 16-byte sized");
+static_assert(offsetof(TabLds, max_code) == offsetof(DeviceHuffTable, max_code), "");
+static_assert(offsetof(TabLds, values) == offsetof(DeviceHuffTable, values), "");
+
+struct Cr2Strip {
+  uint32_t x0, w, y0, h;
+  uint64_t first_sample;
+};
+
+struct LjStreamDev {
+  uint64_t in_offset;
+  uint64_t in_bytes;
+  uint64_t diff_offset; // int16 index into the difference scratch (multiple of 8)
+  uint64_t needed;      // symbols the reference decodes for this stream
+  uint64_t img_offset;
+  uint32_t img_pitch;
+  uint32_t first_block;
+  uint32_t n_blocks;
+  uint32_t first_subseq;
+  uint32_t table_base;
+  uint32_t n_tables;
+  uint32_t period;
+  uint32_t n_comp;
+  uint8_t tab_of_phase[8];
+  uint16_t init_pred[4];
+  uint32_t rows;
+  uint32_t row_samples;
+  uint32_t first_row; // global stream-row index
+  uint32_t kind;      // 0 LJPEG, 1 CR2
+  uint32_t mcu_w, mcu_h, out_x, out_y, keep_samples;
+  uint32_t scan_samples; // samples of a row that take part in reconstruction
+  uint32_t n_strips;
+  uint32_t strip_base;
+  uint32_t job;
+  uint32_t pad;
+};
+
+struct LjResult {
+  uint32_t marker_pos; // first FFxx (xx != 0) in the stream, 0xFFFFFFFF = none
+  uint32_t status;
+  uint32_t flags;
+  uint32_t avail_lo;   // symbols that start before the end of data
+  uint32_t last_slot;  // stream-relative subsequence of the last needed symbol
+  uint32_t last_pos;   // its bit offset inside the compacted subsequence
+  uint32_t consumed;
+  uint32_t pad;
+};
+
+struct LjArgs {
+  const uint8_t* in_base;
+  uint8_t* out_base;
+  const LjStreamDev* streams;
+  const TabLds* tables;
+  const uint32_t* block_stream;
+  const Cr2Strip* strips;
+  uint32_t* sub_state;
+  uint32_t* block_start;
+  uint32_t* block_exit;
+  uint32_t* block_sum;
+  uint32_t* block_base;
+  uint32_t* block_drops;     // stuffing bytes dropped inside each workgroup's region
+  uint32_t* block_drop_base; // exclusive prefix of block_drops within the stream
+  LjResult* results;
+  int16_t* diffs;
+  uint16_t* vseed;
+  uint32_t n_streams;
+  uint32_t total_rows;
+};
+
+// ---------------------------------------------------------------------------
+// Device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t has_ff(uint32_t d) {
+  return ((~d) - 0x01010101u) & d & 0x80808080u;
+}
+
+struct Lds {
+  uint32_t* A;     // [LJ_PW][LJ_T] raw big-endian dwords, later the K4 window
+  uint32_t* B;     // [LJ_BW][LJ_T] un-stuffed big-endian dwords
+  uint32_t* LA;    // 4 lookahead dwords + [4] = byte before slot 0
+  uint32_t* st;    // [LJ_T] exit states
+  uint32_t* misc;  // [16]
+  TabLds* tabs;
+};
+
+__device__ __forceinline__ Lds carve(uint8_t* smem) {
+  Lds l;
+  l.A = reinterpret_cast<uint32_t*>(smem);
+  l.B = l.A + LJ_PW * LJ_T;
+  l.LA = l.B + LJ_BW * LJ_T;
+  l.st = l.LA + 8;
+  l.misc = l.st + LJ_T;
+  l.tabs = reinterpret_cast<TabLds*>(l.misc + 16);
+  return l;
+}
+
+constexpr size_t lj_lds_bytes(int n_tables) {
+  return size_t(LJ_PW * LJ_T + LJ_BW * LJ_T + 8 + LJ_T + 16) * 4 +
+         size_t(n_tables) * sizeof(TabLds);
+}
+
+// 16 bytes at stream offset `off`, zero outside [0, in_bytes)
+__device__ __forceinline__ uint4 lj_load_chunk(const uint8_t* __restrict__ base,
+                                               int64_t off, int64_t in_bytes,
+                                               bool aligned16) {
+  if (off >= 0 && off + 16 <= in_bytes && aligned16)
+    return *reinterpret_cast<const uint4*>(base + off);
+  uint32_t w[4] = {0, 0, 0, 0};
+  if (off < in_bytes && off + 16 > 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t o = off + i;
+      const uint32_t b = (o >= 0 && o < in_bytes) ? base[o] : 0u;
+      w[i >> 2] |= b << (8 * (i & 3));
+    }
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Stage tables + the workgroup's region of the stream into LDS.
+// Slot j (0..255) holds stream bytes [lb*LJ_R + (j-1)*LJ_P, +LJ_P).
+__device__ __forceinline__ void lj_stage(const Lds& L, const LjArgs& a,
+                                         const LjStreamDev& S, uint32_t lb) {
+  const int tid = threadIdx.x;
+  // tables
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(a.tables + S.table_base);
+    uint4* dst = reinterpret_cast<uint4*>(L.tabs);
+    const int n16 = int(S.n_tables * sizeof(TabLds) / 16);
+    for (int i = tid; i < n16; i += LJ_T)
+      dst[i] = src[i];
+  }
+  const uint8_t* __restrict__ in = a.in_base + S.in_offset;
+  const bool aligned16 = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+  const int64_t in_bytes = int64_t(S.in_bytes);
+  const int64_t region0 = int64_t(lb) * LJ_R - LJ_P - 16; // chunk 0 = 16 bytes before slot 0
+  uint4 v[5];
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const int c = tid + m * LJ_T;
+    if (c < LJ_CHUNKS)
+      v[m] = lj_load_chunk(in, region0 + int64_t(c) * 16, in_bytes, aligned16);
+  }
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const int c = tid + m * LJ_T;
+    if (c >= LJ_CHUNKS)
+      continue;
+    const uint32_t d[4] = {__builtin_bswap32(v[m].x), __builtin_bswap32(v[m].y),
+                           __builtin_bswap32(v[m].z), __builtin_bswap32(v[m].w)};
+    if (c == 0) {
+      L.LA[4] = d[3] & 0xFFu; // last byte before slot 0
+    } else if (c == LJ_CHUNKS - 1) {
+      L.LA[0] = d[0];
+      L.LA[1] = d[1];
+      L.LA[2] = d[2];
+      L.LA[3] = d[3];
+    } else {
+      const int g = (c - 1) * 4;     // first region dword of the chunk
+      const int j = g / LJ_PW;       // slot
+      const int k = g % LJ_PW;       // dword inside the slot
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        L.A[(k + q) * LJ_T + j] = d[q];
+    }
+  }
+}
+
+// Un-stuff slot j: physical dwords (own 16 + 4 lookahead) -> B[.][j].
+// Returns the number of data BITS that belong to the slot's own 64 bytes and,
+// via marker_off, the slot-relative offset of an FFxx (xx != 0) marker in the
+// own part (-1 if none).  Data after a marker reads as zeros
+// (BitStreamerJPEG.h:155-179).
+__device__ __forceinline__ uint32_t lj_compact(const Lds& L, int j,
+                                               int& marker_off,
+                                               uint32_t& own_drops) {
+  uint32_t in[LJ_BW + 1];
+#pragma unroll
+  for (int k = 0; k < LJ_PW; ++k)
+    in[k] = L.A[k * LJ_T + j];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    in[LJ_PW + k] = (j < LJ_T - 1) ? L.A[k * LJ_T + j + 1] : L.LA[k];
+  in[LJ_BW] = 0;
+  const uint32_t prev = (j > 0) ? (L.A[(LJ_PW - 1) * LJ_T + j - 1] & 0xFFu) : L.LA[4];
+
+  uint64_t acc = 0;   // high `nacc` bits valid
+  uint32_t nacc = 0;  // 0, 8, 16 or 24
+  uint32_t ko = 0;    // output dwords written
+  uint32_t kept = 0;  // kept bytes so far
+  uint32_t own_bits = 0;
+  bool own_done = false;
+  bool ended = false;
+  bool drop_next = (prev == 0xFFu) && ((in[0] >> 24) == 0u);
+  marker_off = -1;
+  own_drops = 0;
+
+#pragma unroll
+  for (int k = 0; k < LJ_BW; ++k) {
+    if (k == LJ_PW && !own_done) {
+      own_bits = kept * 8;
+      own_done = true;
+    }
+    if (ended)
+      continue;
+    const uint32_t cur = in[k];
+    if (!drop_next && !has_ff(cur)) {
+      acc |= uint64_t(cur) << (32 - nacc);
+      L.B[ko * LJ_T + j] = uint32_t(acc >> 32);
+      ++ko;
+      acc <<= 32;
+      kept += 4;
+      continue;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (ended)
+        break;
+      const uint32_t byte = (cur >> (24 - 8 * b)) & 0xFFu;
+      if (drop_next) {
+        drop_next = false;
+        if (k < LJ_PW)
+          ++own_drops;
+        continue;
+      }
+      if (byte == 0xFFu) {
+        const uint32_t next =
+            (b < 3) ? ((cur >> (16 - 8 * b)) & 0xFFu) : (in[k + 1] >> 24);
+        if (next != 0u && k < LJ_BW - 1 + (b < 3 ? 1 : 0)) {
+          // end-of-stream marker
+          if (k < LJ_PW) {
+            marker_off = k * 4 + b;
+            own_bits = kept * 8;
+            own_done = true;
+          }
+          ended = true;
+          break;
+        }
+        drop_next = (next == 0u);
+      }
+      acc |= uint64_t(byte) << (56 - nacc);
+      nacc += 8;
+      ++kept;
+      if (nacc == 32) {
+        L.B[ko * LJ_T + j] = uint32_t(acc >> 32);
+        ++ko;
+        acc = 0;
+        nacc = 0;
+      }
+    }
+  }
+  if (!own_done)
+    own_bits = kept * 8;
+  // flush the partial dword and zero-fill the rest of the slot
+  if (ko < LJ_BW) {
+    L.B[ko * LJ_T + j] = uint32_t(acc >> 32);
+    ++ko;
+  }
+  for (; ko < LJ_BW; ++ko)
+    L.B[ko * LJ_T + j] = 0u;
+  return own_bits;
+}
+
+__device__ __forceinline__ uint32_t lj_peek32(const uint32_t* B, int j,
+                                              uint32_t pos) {
+  const uint32_t i = pos >> 5, s = pos & 31u;
+  const uint32_t d0 = B[i * LJ_T + j], d1 = B[(i + 1) * LJ_T + j];
+  const uint64_t v = (uint64_t(d0) << 32) | d1;
+  return uint32_t((v << s) >> 32);
+}
+
+struct Sym {
+  uint32_t total; // bits consumed
+  uint32_t ssss;
+  uint32_t code_len;
+  bool ok;
+};
+
+__device__ __forceinline__ Sym lj_symbol(uint32_t w, const TabLds& tb) {
+  const uint32_t e = tb.lut[w >> (32 - LUT_BITS)];
+  if (e & 31u)
+    return {e >> 10, (e >> 5) & 31u, e & 31u, true};
+  // codes longer than the LUT: JPEG Annex F.2.2.3 search
+  for (uint32_t l = LUT_BITS + 1; l <= tb.max_len; ++l) {
+    const uint32_t c = w >> (32 - l);
+    const uint32_t mc = tb.max_code[l];
+    if (mc != NO_CODE && c <= mc) {
+      const uint32_t ssss = tb.values[(c - tb.val_offset[l]) & 0xFFFFu];
+      const uint32_t extra = ssss == 16u ? (tb.fix16 ? 16u : 0u) : ssss;
+      return {l + extra, ssss, l, true};
+    }
+  }
+  return {0, 0, 0, false};
+}
+
+// Per-stream decode parameters held in registers.
+struct DecodeParams {
+  uint32_t period;
+  uint64_t tabmap; // byte p = table slot of phase p
+};
+
+__device__ __forceinline__ DecodeParams lj_params(const LjStreamDev& S) {
+  DecodeParams d;
+  d.period = S.period;
+  uint64_t m = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    m |= uint64_t(S.tab_of_phase[i]) << (8 * i);
+  d.tabmap = m;
+  return d;
+}
+
+// Decode the symbols that START inside the slot (bit positions [.., end_bits)).
+template <bool MULTI>
+__device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams& dp,
+                                               int j, uint32_t start,
+                                               uint32_t end_bits, uint32_t& exit,
+                                               uint32_t& count) {
+  if (start & ST_ERR) {
+    exit = ST_ERR;
+    count = 0;
+    return;
+  }
+  uint32_t pos = start & ST_OFF_MASK;
+  uint32_t phase = (start >> ST_PHASE_SHIFT) & 7u;
+  uint32_t n = 0;
+  while (pos < end_bits) {
+    const uint32_t w = lj_peek32(L.B, j, pos);
+    const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
+    const Sym s = lj_symbol(w, tb);
+    if (!s.ok) {
+      exit = ST_ERR;
+      count = n;
+      return;
+    }
+    pos += s.total;
+    ++n;
+    phase = (phase + 1 == dp.period) ? 0u : phase + 1;
+  }
+  exit = (pos - end_bits) | (phase << ST_PHASE_SHIFT);
+  count = n;
+}
+
+// ---------------------------------------------------------------------------
+// K1 / K2: synchronisation
+// ---------------------------------------------------------------------------
+template <bool STITCH, bool MULTI>
+__global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const Lds L = carve(smem);
+  const uint32_t b = blockIdx.x;
+  const uint32_t s = a.block_stream[b];
+  const LjStreamDev& S = a.streams[s];
+  if ((S.n_tables > 1) != MULTI)
+    return; // the other instantiation handles this stream
+  const uint32_t lb = b - S.first_block;
+  const int j = threadIdx.x;
+
+  uint32_t true_start = 0;
+  if (STITCH) {
+    if (lb == 0)
+      return;
+    true_start = a.block_exit[b - 1];
+    if (true_start == a.block_start[b])
+      return; // chain already consistent here
+  }
+
+  lj_stage(L, a, S, lb);
+  __syncthreads();
+  int marker_off;
+  uint32_t own_drops;
+  const uint32_t end_bits = lj_compact(L, j, marker_off, own_drops);
+  const DecodeParams dp = lj_params(S);
+  if (!STITCH && marker_off >= 0 && j >= 1) {
+    const int64_t p = int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P + marker_off;
+    if (p >= 0)
+      atomicMin(&a.results[s].marker_pos, uint32_t(p));
+  }
+  const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1); // j >= 1
+
+  uint32_t my_start, my_exit = 0, my_count = 0;
+  bool dirty;
+  int first_chained;
+  if (!STITCH) {
+    my_start = 0; // speculative: a symbol starts at bit 0 of the slot, phase 0
+    dirty = true;
+    first_chained = 1;
+    if (lb == 0 && j == 0) {
+      dirty = false; // slot 0 lies before the stream: its "exit" is the known start
+      my_exit = 0;
+      L.st[0] = 0;
+    }
+  } else {
+    first_chained = 2;
+    if (j == 0) {
+      my_start = 0;
+      dirty = false;
+      L.st[0] = 0;
+    } else {
+      const uint32_t rec = a.sub_state[gsub];
+      my_exit = rec & ST_MASK;
+      my_count = rec >> 16;
+      L.st[j] = my_exit;
+      if (j == 1) {
+        my_start = true_start;
+        dirty = true;
+      } else {
+        my_start = a.sub_state[gsub - 1] & ST_MASK;
+        dirty = false;
+      }
+    }
+  }
+  __syncthreads(); // B complete, st initialised
+
+  while (true) {
+    if (dirty) {
+      lj_decode_span<MULTI>(L, dp, j, my_start, end_bits, my_exit, my_count);
+      L.st[j] = my_exit;
+    }
+    __syncthreads();
+    const uint32_t ns = (j >= first_chained) ? L.st[j - 1] : my_start;
+    dirty = ns != my_start;
+    my_start = ns;
+    if (!__syncthreads_or(dirty ? 1 : 0))
+      break;
+  }
+
+  if (j >= 1)
+    a.sub_state[gsub] = my_exit | (my_count << 16);
+  if (j == 1)
+    a.block_start[b] = my_start;
+  if (j == LJ_T - 1)
+    a.block_exit[b] = my_exit;
+  // block totals: symbols, dropped stuffing bytes
+  uint32_t v = j >= 1 ? my_count : 0u;
+  uint32_t dr = j >= 1 ? own_drops : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    v += __shfl_down(v, o, 64);
+    dr += __shfl_down(dr, o, 64);
+  }
+  if ((j & 63) == 0) {
+    L.misc[j >> 6] = v;
+    L.misc[4 + (j >> 6)] = dr;
+  }
+  __syncthreads();
+  if (j == 0) {
+    a.block_sum[b] = L.misc[0] + L.misc[1] + L.misc[2] + L.misc[3];
+    if (!STITCH)
+      a.block_drops[b] = L.misc[4] + L.misc[5] + L.misc[6] + L.misc[7];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K3: per-stream chain check + exclusive scan of the per-workgroup symbol counts
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
+  __shared__ uint32_t wsum[4], dsum[4];
+  __shared__ uint32_t carry_s, dcarry_s;
+  __shared__ uint32_t unconv_s;
+  const uint32_t s = blockIdx.x;
+  const LjStreamDev& S = a.streams[s];
+  const int tid = threadIdx.x;
+  const uint32_t fb = S.first_block, nb = S.n_blocks;
+  if (tid == 0) {
+    carry_s = 0;
+    dcarry_s = 0;
+    unconv_s = 0;
+  }
+  __syncthreads();
+  for (uint32_t base = 0; base < nb; base += LJ_T) {
+    const uint32_t i = base + tid;
+    const uint32_t v = i < nb ? a.block_sum[fb + i] : 0u;
+    const uint32_t dv = i < nb ? a.block_drops[fb + i] : 0u;
+    if (i >= 1 && i < nb && a.block_start[fb + i] != a.block_exit[fb + i - 1])
+      unconv_s = 1;
+    // inclusive wave scans
+    uint32_t x = v, dx = dv;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(x, o, 64);
+      const uint32_t dy = __shfl_up(dx, o, 64);
+      if ((tid & 63) >= o) {
+        x += y;
+        dx += dy;
+      }
+    }
+    if ((tid & 63) == 63) {
+      wsum[tid >> 6] = x;
+      dsum[tid >> 6] = dx;
+    }
+    __syncthreads();
+    uint32_t woff = 0, dwoff = 0;
+    for (int w = 0; w < (tid >> 6); ++w) {
+      woff += wsum[w];
+      dwoff += dsum[w];
+    }
+    const uint32_t excl = carry_s + woff + x - v;
+    const uint32_t dexcl = dcarry_s + dwoff + dx - dv;
+    if (i < nb) {
+      a.block_base[fb + i] = excl;
+      a.block_drop_base[fb + i] = dexcl;
+    }
+    __syncthreads();
+    if (tid == LJ_T - 1) {
+      carry_s = excl + v;
+      dcarry_s = dexcl + dv;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    LjResult& R = a.results[s];
+    // symbols that start before the end of data M = min(marker, in_bytes)
+    uint64_t M = R.marker_pos;
+    if (M > S.in_bytes)
+      M = S.in_bytes;
+    uint32_t avail;
+    const uint64_t lbm = M / LJ_R;
+    if (lbm >= nb) {
+      avail = carry_s;
+    } else {
+      const uint32_t js = uint32_t((M - lbm * LJ_R) / LJ_P);
+      avail = a.block_base[fb + lbm];
+      const uint32_t g0 = S.first_subseq + uint32_t(lbm) * LJ_OWN;
+      for (uint32_t q = 0; q <= js && q < uint32_t(LJ_OWN); ++q)
+        avail += a.sub_state[g0 + q] >> 16;
+    }
+    R.avail_lo = avail;
+    if (unconv_s)
+      R.flags |= FL_UNCONVERGED;
+    else
+      R.flags &= ~FL_UNCONVERGED;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K4: final decode -> stream-ordered int16 differences
+// ---------------------------------------------------------------------------
+template <bool MULTI>
+__global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const Lds L = carve(smem);
+  const uint32_t b = blockIdx.x;
+  const uint32_t s = a.block_stream[b];
+  const LjStreamDev& S = a.streams[s];
+  if ((S.n_tables > 1) != MULTI)
+    return;
+  const uint32_t lb = b - S.first_block;
+  const int j = threadIdx.x;
+  const uint64_t needed = S.needed;
+  const uint32_t base = a.block_base[b];
+  const uint32_t sum = a.block_sum[b];
+  if (base >= needed || sum == 0)
+    return; // nothing of this workgroup is delivered
+  uint64_t M = a.results[s].marker_pos;
+  if (M > S.in_bytes)
+    M = S.in_bytes;
+  if (uint64_t(lb) * LJ_R > M)
+    return; // past the end of data
+
+  lj_stage(L, a, S, lb);
+  __syncthreads();
+  int marker_off;
+  uint32_t own_drops;
+  (void)lj_compact(L, j, marker_off, own_drops);
+  const DecodeParams dp = lj_params(S);
+
+  const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1);
+  uint32_t my_start = 0, my_count = 0, my_exit = 0;
+  if (j >= 1) {
+    const uint32_t rec = a.sub_state[gsub];
+    my_count = rec >> 16;
+    my_exit = rec & ST_MASK;
+    my_start = (j == 1) ? a.block_start[b] : (a.sub_state[gsub - 1] & ST_MASK);
+  }
+  // exclusive scan of counts inside the workgroup
+  uint32_t x = my_count;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o, 64);
+    if ((j & 63) >= o)
+      x += y;
+  }
+  if ((j & 63) == 63)
+    L.misc[j >> 6] = x;
+  __syncthreads(); // also: B complete, A free to become the window
+  uint32_t woff = 0;
+  for (int w = 0; w < (j >> 6); ++w)
+    woff += L.misc[w];
+  uint64_t idx = uint64_t(base) + woff + x - my_count; // first symbol of this lane
+
+  // a bad Huffman code inside the delivered range is a real error
+  // (PrefixCodeLookupDecoder.h:152-155)
+  if (j >= 1 && (my_exit & ST_ERR) && idx + my_count < needed &&
+      int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P < int64_t(M))
+    atomicCAS(&a.results[s].status, 0u, uint32_t(RSX_ERR_BAD_HUFFMAN_CODE));
+
+  int16_t* win = reinterpret_cast<int16_t*>(L.A);
+  int16_t* __restrict__ dst = a.diffs + S.diff_offset;
+  const uint64_t g0 = uint64_t(base) & ~uint64_t(7);
+  const uint64_t blk_end = std::min<uint64_t>(uint64_t(base) + sum, needed);
+  const uint32_t n_win = uint32_t((blk_end - g0 + LJ_WIN - 1) / LJ_WIN);
+
+  uint32_t pos = my_start & ST_OFF_MASK;
+  uint32_t phase = (my_start >> ST_PHASE_SHIFT) & 7u;
+  uint32_t remaining = (my_start & ST_ERR) ? 0u : my_count;
+
+  for (uint32_t wdx = 0; wdx < n_win; ++wdx) {
+    const uint64_t lo = g0 + uint64_t(wdx) * LJ_WIN;
+    const uint64_t hi = lo + LJ_WIN;
+    while (remaining > 0 && idx < hi && idx < needed) {
+      const uint32_t w = lj_peek32(L.B, j, pos);
+      const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
+      const Sym sy = lj_symbol(w, tb);
+      int diff;
+      if (sy.ssss == 0u) {
+        diff = 0;
+      } else if (sy.ssss == 16u) {
+        diff = -32768;
+      } else {
+        const uint32_t v = (w << sy.code_len) >> (32 - sy.ssss);
+        diff = (v >> (sy.ssss - 1)) ? int(v) : int(v) - int((1u << sy.ssss) - 1u);
+      }
+      win[uint32_t(idx - lo)] = int16_t(diff);
+      if (idx + 1 == needed) {
+        a.results[s].last_slot = lb * LJ_OWN + uint32_t(j - 1);
+        a.results[s].last_pos = pos;
+      }
+      pos += sy.total;
+      phase = (phase + 1 == dp.period) ? 0u : phase + 1;
+      ++idx;
+      --remaining;
+    }
+    __syncthreads();
+    // cooperative, 16-byte coalesced copy-out of [max(lo, base), min(hi, blk_end))
+    const uint64_t vlo = std::max<uint64_t>(lo, base);
+    const uint64_t vhi = std::min<uint64_t>(hi, blk_end);
+    for (uint32_t v8 = j; v8 < LJ_WIN / 8; v8 += LJ_T) {
+      const uint64_t gi = lo + uint64_t(v8) * 8;
+      if (gi + 8 <= vlo || gi >= vhi)
+        continue;
+      if (gi >= vlo && gi + 8 <= vhi) {
+        *reinterpret_cast<uint4*>(dst + gi) =
+            *reinterpret_cast<const uint4*>(win + v8 * 8);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (gi + q >= vlo && gi + q < vhi)
+            dst[gi + q] = win[v8 * 8 + q];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K5: predictor seeds of the stream rows
+//   seed(r, c) = init_pred[c] + sum_{r' < r} D[r'][c]   (mod 2^16)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(LJ_T) void lj_vseed_kernel(LjArgs a) {
+  __shared__ uint32_t part[LJ_T][4];
+  const uint32_t s = blockIdx.x;
+  const LjStreamDev& S = a.streams[s];
+  if (a.results[s].status != 0)
+    return;
+  const int tid = threadIdx.x;
+  const uint32_t rows = S.rows, N = S.n_comp;
+  const int16_t* __restrict__ D = a.diffs + S.diff_offset;
+  const uint32_t per = (rows + LJ_T - 1) / LJ_T;
+  const uint32_t r0 = tid * per, r1 = std::min(rows, r0 + per);
+  uint32_t sum[4] = {0, 0, 0, 0};
+  for (uint32_t r = r0; r < r1; ++r)
+    for (uint32_t c = 0; c < N; ++c)
+      sum[c] += uint32_t(int32_t(D[uint64_t(r) * S.row_samples + c]));
+  for (int c = 0; c < 4; ++c)
+    part[tid][c] = sum[c];
+  __syncthreads();
+  if (tid == 0) { // 256-element serial exclusive scan: negligible
+    uint32_t run[4] = {0, 0, 0, 0};
+    for (int t = 0; t < LJ_T; ++t)
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t v = part[t][c];
+        part[t][c] = run[c];
+        run[c] += v;
+      }
+  }
+  __syncthreads();
+  uint32_t run[4];
+  for (int c = 0; c < 4; ++c)
+    run[c] = part[tid][c] + (c < int(N) ? S.init_pred[c] : 0u);
+  uint16_t* __restrict__ V = a.vseed + uint64_t(S.first_row) * 4;
+  for (uint32_t r = r0; r < r1; ++r)
+    for (uint32_t c = 0; c < N; ++c) {
+      V[uint64_t(r) * 4 + c] = uint16_t(run[c]);
+      run[c] += uint32_t(int32_t(D[uint64_t(r) * S.row_samples + c]));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K6: row reconstruction + output mapping, one wavefront per stream row
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void lj_store_sample(const LjArgs& a, const LjStreamDev& S,
+                                                uint32_t r, uint32_t sidx,
+                                                uint16_t val) {
+  uint8_t* img = a.out_base + S.img_offset;
+  if (S.kind == 0) {
+    const uint32_t m = sidx / S.n_comp, c = sidx - m * S.n_comp;
+    const uint32_t col = S.mcu_w * m + (c % S.mcu_w);
+    if (col >= S.keep_samples)
+      return;
+    const uint32_t row = S.out_y + S.mcu_h * r + c / S.mcu_w;
+    reinterpret_cast<uint16_t*>(img + uint64_t(row) * S.img_pitch)[S.out_x + col] = val;
+  } else {
+    const uint64_t k = uint64_t(r) * S.row_samples + sidx;
+    const Cr2Strip* st = a.strips + S.strip_base;
+    uint32_t q = 0;
+    while (q + 1 < S.n_strips && k >= st[q + 1].first_sample)
+      ++q;
+    const uint64_t off = k - st[q].first_sample;
+    const uint32_t row = st[q].y0 + uint32_t(off / st[q].w);
+    const uint32_t col = st[q].x0 + uint32_t(off % st[q].w);
+    reinterpret_cast<uint16_t*>(img + uint64_t(row) * S.img_pitch)[col] = val;
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
+  const uint32_t grow = blockIdx.x * (LJ_T / 64) + (threadIdx.x >> 6);
+  if (grow >= a.total_rows)
+    return;
+  const int lane = threadIdx.x & 63;
+  // row -> stream (first_row is increasing)
+  uint32_t lo = 0, hi = a.n_streams - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (a.streams[mid].first_row <= grow)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  const LjStreamDev& S = a.streams[lo];
+  if (int(S.n_comp) != N || a.results[lo].status != 0)
+    return;
+  const uint32_t r = grow - S.first_row;
+  if (r >= S.rows)
+    return;
+  const uint64_t row0 = uint64_t(r) * S.row_samples;
+  uint32_t n = S.scan_samples;
+  if (row0 + n > S.needed)
+    n = uint32_t(S.needed - row0);
+  const int16_t* __restrict__ D = a.diffs + S.diff_offset + row0;
+  const bool in_aligned = ((S.diff_offset + row0) & 7) == 0;
+  uint32_t carry[N];
+#pragma unroll
+  for (int c = 0; c < N; ++c)
+    carry[c] = a.vseed[(uint64_t(S.first_row) + r) * 4 + c];
+
+  for (uint32_t q0 = 0; q0 < n; q0 += 512) {
+    const uint32_t q = q0 + lane * 8;
+    uint32_t v[8];
+    if (q + 8 <= n && in_aligned) {
+      const uint4 t = *reinterpret_cast<const uint4*>(D + q);
+      v[0] = t.x & 0xFFFF; v[1] = t.x >> 16; v[2] = t.y & 0xFFFF; v[3] = t.y >> 16;
+      v[4] = t.z & 0xFFFF; v[5] = t.z >> 16; v[6] = t.w & 0xFFFF; v[7] = t.w >> 16;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        v[i] = (q + i < n) ? uint32_t(uint16_t(D[q + i])) : 0u;
+    }
+    // component of v[i] is (q + i) % N; rot = q % N (0 unless N == 3)
+    const int rot = (N == 3) ? int(q % 3) : 0;
+    uint32_t run[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c)
+      run[c] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int cs = (N == 3) ? (i % 3) : (i % N); // component for rot == 0
+      if (N == 3) {
+        // select by ((rot + i) % 3) without dynamic register indexing
+        const int c = (rot + i) % 3;
+        uint32_t t = (c == 0 ? run[0] : (c == 1 ? run[1 % N] : run[2 % N])) + v[i];
+        if (c == 0) run[0] = t; else if (c == 1) run[1 % N] = t; else run[2 % N] = t;
+        v[i] = t;
+      } else {
+        run[cs] += v[i];
+        v[i] = run[cs];
+      }
+    }
+    // exclusive wave scan of the lane totals, per component
+    uint32_t excl[N], tot[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+      uint32_t x = run[c];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o)
+          x += y;
+      }
+      tot[c] = __shfl(x, 63, 64);
+      excl[c] = x - run[c] + carry[c];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (N == 3) {
+        const int c = (rot + i) % 3;
+        v[i] += (c == 0 ? excl[0] : (c == 1 ? excl[1 % N] : excl[2 % N]));
+      } else {
+        v[i] += excl[i % N];
+      }
+      v[i] &= 0xFFFFu;
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c)
+      carry[c] += tot[c];
+
+    // ---- output -----------------------------------------------------------
+    if (q >= n)
+      continue;
+    bool done = false;
+    if (q + 8 <= n) {
+      uint8_t* img = a.out_base + S.img_offset;
+      uint16_t* p = nullptr;
+      if (S.kind == 0 && S.mcu_h == 1) {
+        if (q + 8 <= S.keep_samples)
+          p = reinterpret_cast<uint16_t*>(img + uint64_t(S.out_y + r) * S.img_pitch) +
+              S.out_x + q;
+      } else if (S.kind == 1) {
+        const uint64_t k = row0 + q;
+        const Cr2Strip* st = a.strips + S.strip_base;
+        uint32_t z = 0;
+        while (z + 1 < S.n_strips && k >= st[z + 1].first_sample)
+          ++z;
+        const uint64_t off = k - st[z].first_sample;
+        const uint32_t col = uint32_t(off % st[z].w);
+        if (col + 8 <= st[z].w)
+          p = reinterpret_cast<uint16_t*>(
+                  img + uint64_t(st[z].y0 + uint32_t(off / st[z].w)) * S.img_pitch) +
+              st[z].x0 + col;
+      }
+      if (p && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        uint4 o;
+        o.x = v[0] | (v[1] << 16);
+        o.y = v[2] | (v[3] << 16);
+        o.z = v[4] | (v[5] << 16);
+        o.w = v[6] | (v[7] << 16);
+        *reinterpret_cast<uint4*>(p) = o;
+        done = true;
+      }
+    }
+    if (!done) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (q + i < n)
+          lj_store_sample(a, S, r, q + i, uint16_t(v[i]));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K7: decode()/decompress() return value = BitStreamerJPEG::getStreamPosition()
+// after the last decoded symbol: let c be the un-stuffed bit
+// offset at which the last decoded symbol starts; K = ceil(c/32)+1 refills of 4
+// data bytes have happened; D = data bytes before the end marker.  If 4K > D
+// the answer is the marker's offset, otherwise the physical offset just past
+// the first 4K data bytes.  One wavefront per stream.
+// ---------------------------------------------------------------------------
+// stuffing bytes (00 preceded by FF) at stream positions [from, to), one wave
+__device__ __forceinline__ uint32_t lj_count_drops(const uint8_t* in, uint64_t from,
+                                                   uint64_t to, int lane) {
+  uint32_t n = 0;
+  for (uint64_t p = from + lane; p < to; p += 64)
+    if (in[p] == 0x00 && p > 0 && in[p - 1] == 0xFF)
+      ++n;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    n += __shfl_down(n, o, 64);
+  return __shfl(n, 0, 64);
+}
+
+// stuffing bytes before stream position x (x <= end of data)
+__device__ __forceinline__ uint64_t lj_drops_before(const LjArgs& a,
+                                                    const LjStreamDev& S,
+                                                    const uint8_t* in, uint64_t x,
+                                                    int lane) {
+  uint64_t lb = x / LJ_R;
+  if (lb >= S.n_blocks)
+    lb = S.n_blocks - 1;
+  return uint64_t(a.block_drop_base[S.first_block + lb]) +
+         lj_count_drops(in, lb * LJ_R, x, lane);
+}
+
+__global__ __launch_bounds__(64) void lj_consumed_kernel(LjArgs a) {
+  const uint32_t s = blockIdx.x;
+  const LjStreamDev& S = a.streams[s];
+  LjResult& R = a.results[s];
+  const int lane = threadIdx.x;
+  if (R.status != 0 || uint64_t(R.avail_lo) < S.needed)
+    return;
+  const uint8_t* in = a.in_base + S.in_offset;
+  const bool has_marker = R.marker_pos != 0xFFFFFFFFu && R.marker_pos < S.in_bytes;
+  const uint64_t M = has_marker ? R.marker_pos : S.in_bytes;
+  // un-stuffed bit offset of the last symbol's start
+  const uint64_t slot_phys = uint64_t(R.last_slot) * LJ_P;
+  const uint64_t c =
+      (slot_phys - lj_drops_before(a, S, in, slot_phys, lane)) * 8 + R.last_pos;
+  const uint64_t K = (c + 31) / 32 + 1;
+  const uint64_t D = M - lj_drops_before(a, S, in, M, lane);
+  uint64_t result;
+  if (4 * K > D) {
+    // the last refill touched the marker (or ran off the end of the buffer)
+    result = has_marker ? M : S.in_bytes + (4 * K - D);
+  } else {
+    // physical offset just past the first 4K data bytes
+    const uint64_t target = 4 * K;
+    // workgroup region whose logical start lb*R - drop_base[lb] is <= target
+    uint32_t lo = 0, hi = S.n_blocks - 1;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      const uint64_t ls = uint64_t(mid) * LJ_R - a.block_drop_base[S.first_block + mid];
+      if (ls <= target)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    uint64_t x = uint64_t(lo) * LJ_R;
+    uint64_t logical = x - a.block_drop_base[S.first_block + lo];
+    // <= 16 KiB sequential walk; only bottom-overhanging tiles get here
+    while (logical < target && x < M) {
+      const bool drop = in[x] == 0x00 && x > 0 && in[x - 1] == 0xFF;
+      if (!drop)
+        ++logical;
+      ++x;
+    }
+    // a data FF is consumed together with its stuffing byte
+    // (BitStreamerJPEG.h:145-151)
+    if (x < M && x > 0 && in[x - 1] == 0xFF && in[x] == 0x00)
+      ++x;
+    result = x;
+  }
+  if (lane == 0)
+    R.consumed = uint32_t(result);
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------
+struct LJpegPlan {
+  rsx_ctx* ctx = nullptr;
+  int n_jobs = 0;
+  std::vector<int32_t> job_status;      // validation results
+  std::vector<int> job_first_stream;    // -1 if skipped
+  std::vector<int> job_n_streams;
+  std::vector<LjStreamDev> streams;
+  uint32_t total_blocks = 0, total_subseq = 0, total_rows = 0;
+  uint64_t total_diffs = 0;
+  int max_tables = 1;
+  bool any_multi = false, any_single = false;
+  bool comp_present[5] = {false, false, false, false, false};
+  DeviceBuffer d_streams, d_tables, d_block_stream, d_strips, d_sub_state,
+      d_block_start, d_block_exit, d_block_sum, d_block_base, d_block_drops,
+      d_block_drop_base, d_results, d_diffs, d_vseed;
+  std::vector<LjResult> h_results;
+  int stitch_rounds = 2;
+};
+
+namespace {
+
+LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
+  LjArgs a{};
+  a.in_base = static_cast<const uint8_t*>(in_dev);
+  a.out_base = static_cast<uint8_t*>(out_dev);
+  a.streams = static_cast<const LjStreamDev*>(p->d_streams.ptr);
+  a.tables = static_cast<const TabLds*>(p->d_tables.ptr);
+  a.block_stream = static_cast<const uint32_t*>(p->d_block_stream.ptr);
+  a.strips = static_cast<const Cr2Strip*>(p->d_strips.ptr);
+  a.sub_state = static_cast<uint32_t*>(p->d_sub_state.ptr);
+  a.block_start = static_cast<uint32_t*>(p->d_block_start.ptr);
+  a.block_exit = static_cast<uint32_t*>(p->d_block_exit.ptr);
+  a.block_sum = static_cast<uint32_t*>(p->d_block_sum.ptr);
+  a.block_base = static_cast<uint32_t*>(p->d_block_base.ptr);
+  a.block_drops = static_cast<uint32_t*>(p->d_block_drops.ptr);
+  a.block_drop_base = static_cast<uint32_t*>(p->d_block_drop_base.ptr);
+  a.results = static_cast<LjResult*>(p->d_results.ptr);
+  a.diffs = static_cast<int16_t*>(p->d_diffs.ptr);
+  a.vseed = static_cast<uint16_t*>(p->d_vseed.ptr);
+  a.n_streams = uint32_t(p->streams.size());
+  a.total_rows = p->total_rows;
+  return a;
+}
+
+template <bool STITCH>
+void launch_sync(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
+  const size_t lds = lj_lds_bytes(p->max_tables);
+  if (p->any_single)
+    hipLaunchKernelGGL((lj_sync_kernel<STITCH, false>), dim3(p->total_blocks),
+                       dim3(LJ_T), lj_lds_bytes(1), s, a);
+  if (p->any_multi)
+    hipLaunchKernelGGL((lj_sync_kernel<STITCH, true>), dim3(p->total_blocks),
+                       dim3(LJ_T), lds, s, a);
+}
+
+void launch_decode(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
+  if (p->any_single)
+    hipLaunchKernelGGL((lj_decode_kernel<false>), dim3(p->total_blocks), dim3(LJ_T),
+                       lj_lds_bytes(1), s, a);
+  if (p->any_multi)
+    hipLaunchKernelGGL((lj_decode_kernel<true>), dim3(p->total_blocks), dim3(LJ_T),
+                       lj_lds_bytes(p->max_tables), s, a);
+}
+
+void launch_predict(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
+  const dim3 grid((p->total_rows + 3) / 4), block(LJ_T);
+  if (p->comp_present[1])
+    hipLaunchKernelGGL((lj_predict_kernel<1>), grid, block, 0, s, a);
+  if (p->comp_present[2])
+    hipLaunchKernelGGL((lj_predict_kernel<2>), grid, block, 0, s, a);
+  if (p->comp_present[3])
+    hipLaunchKernelGGL((lj_predict_kernel<3>), grid, block, 0, s, a);
+  if (p->comp_present[4])
+    hipLaunchKernelGGL((lj_predict_kernel<4>), grid, block, 0, s, a);
+}
+
+} // namespace
+
+const char* ljpeg_dominant_kernel_name() { return "lj_decode_kernel"; }
+
+int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
+                      LJpegPlan** out) {
+  auto p = std::make_unique<LJpegPlan>();
+  p->ctx = ctx;
+  p->n_jobs = int(jobs.size());
+  p->job_status.assign(jobs.size(), RSX_OK);
+  p->job_first_stream.assign(jobs.size(), -1);
+  p->job_n_streams.assign(jobs.size(), 0);
+  std::vector<DeviceHuffTable> tables;
+  std::vector<Cr2Strip> strips;
+  for (size_t i = 0; i < jobs.size(); ++i) {
+    const LJpegJobIn& J = jobs[i];
+    int st = J.status;
+    if (st == RSX_OK && J.geom.in_bytes < 8)
+      st = RSX_ERR_IO; // BitStreamerJPEG needs >= 8 bytes (BitStreamer.h:58-59)
+    if (st == RSX_OK && J.geom.in_bytes > 0xFFFFFFFFull)
+      st = RSX_ERR_INVALID_ARG; // Buffer::size_type is uint32_t (io/Buffer.h:49)
+    const StreamGeom& g = J.geom;
+    const uint64_t needed = g.kind == 0
+                                ? uint64_t(g.rows) * g.row_samples
+                                : g.strip_first_sample[g.n_strips];
+    if (st == RSX_OK && needed >= 0xFFFFFFF0ull)
+      st = RSX_ERR_UNSUPPORTED;
+    if (st == RSX_OK && g.kind == 0 && J.rows_per_restart_interval > 0 &&
+        uint32_t(J.rows_per_restart_interval) < g.rows)
+      st = RSX_ERR_UNSUPPORTED; // restart intervals: handled by a later revision
+    p->job_status[i] = st;
+    if (st != RSX_OK)
+      continue;
+    LjStreamDev S{};
+    S.in_offset = g.in_offset;
+    S.in_bytes = g.in_bytes;
+    S.diff_offset = p->total_diffs;
+    S.needed = needed;
+    S.img_offset = g.img_offset;
+    S.img_pitch = g.img_pitch_bytes;
+    S.first_block = p->total_blocks;
+    S.n_blocks = uint32_t((g.in_bytes + LJ_R - 1) / LJ_R);
+    S.first_subseq = p->total_subseq;
+    S.table_base = uint32_t(tables.size());
+    S.n_tables = uint32_t(J.n_tables);
+    S.period = g.period;
+    S.n_comp = g.n_comp;
+    std::memcpy(S.tab_of_phase, g.comp_of_phase, 8);
+    std::memcpy(S.init_pred, g.init_pred, sizeof S.init_pred);
+    S.rows = g.rows;
+    S.row_samples = g.row_samples;
+    S.first_row = p->total_rows;
+    S.kind = g.kind;
+    S.mcu_w = g.mcu_w;
+    S.mcu_h = g.mcu_h;
+    S.out_x = g.out_x;
+    S.out_y = g.out_y;
+    S.keep_samples = g.keep_samples;
+    if (g.kind == 0) {
+      const uint32_t mcus = (g.keep_samples + g.mcu_w - 1) / g.mcu_w;
+      S.scan_samples = std::min(g.row_samples, mcus * g.n_comp);
+    } else {
+      S.scan_samples = g.row_samples;
+    }
+    S.n_strips = g.n_strips;
+    S.strip_base = uint32_t(strips.size());
+    for (uint32_t k = 0; k < g.n_strips; ++k)
+      strips.push_back({g.strip_x0[k], g.strip_w[k], g.strip_y0[k], g.strip_h[k],
+                        g.strip_first_sample[k]});
+    if (g.kind == 1)
+      strips.push_back({0, 1, 0, 0, g.strip_first_sample[g.n_strips]});
+    S.job = uint32_t(i);
+    for (int t = 0; t < J.n_tables; ++t) {
+      tables.emplace_back();
+      build_device_table(J.tables[t], &tables.back());
+    }
+    // single-table streams ignore tab_of_phase; multi-table ones index tabs[]
+    bool multi = J.n_tables > 1;
+    p->any_multi |= multi;
+    p->any_single |= !multi;
+    p->max_tables = std::max(p->max_tables, J.n_tables);
+    p->comp_present[g.n_comp] = true;
+    p->job_first_stream[i] = int(p->streams.size());
+    p->job_n_streams[i] = 1;
+    p->total_blocks += S.n_blocks;
+    p->total_subseq += S.n_blocks * LJ_OWN;
+    p->total_rows += S.rows;
+    p->total_diffs += (needed + 7 + 8) & ~uint64_t(7);
+    p->streams.push_back(S);
+  }
+  if (!p->streams.empty()) {
+    std::vector<uint32_t> block_stream(p->total_blocks);
+    for (size_t s = 0; s < p->streams.size(); ++s)
+      for (uint32_t b = 0; b < p->streams[s].n_blocks; ++b)
+        block_stream[p->streams[s].first_block + b] = uint32_t(s);
+    // TabLds and DeviceHuffTable share their prefix; tables are uploaded in
+    // the LDS layout (16-byte sized records)
+    std::vector<TabLds> tl(tables.size());
+    for (size_t t = 0; t < tables.size(); ++t) {
+      std::memset(&tl[t], 0, sizeof(TabLds));
+      std::memcpy(&tl[t], &tables[t], sizeof(DeviceHuffTable));
+    }
+    auto up = [&](DeviceBuffer& b, const void* src, size_t n) -> int {
+      if (int st = b.ensure(n ? n : 16))
+        return st;
+      if (n && hipMemcpy(b.ptr, src, n, hipMemcpyHostToDevice) != hipSuccess)
+        return RSX_ERR_DEVICE;
+      return RSX_OK;
+    };
+    int st = RSX_OK;
+    if ((st = up(p->d_streams, p->streams.data(),
+                 p->streams.size() * sizeof(LjStreamDev))) ||
+        (st = up(p->d_tables, tl.data(), tl.size() * sizeof(TabLds))) ||
+        (st = up(p->d_block_stream, block_stream.data(),
+                 block_stream.size() * sizeof(uint32_t))) ||
+        (st = up(p->d_strips, strips.data(), strips.size() * sizeof(Cr2Strip))))
+      return st;
+    if ((st = p->d_sub_state.ensure(size_t(p->total_subseq) * 4 + 16)) ||
+        (st = p->d_block_start.ensure(size_t(p->total_blocks) * 4)) ||
+        (st = p->d_block_exit.ensure(size_t(p->total_blocks) * 4)) ||
+        (st = p->d_block_sum.ensure(size_t(p->total_blocks) * 4)) ||
+        (st = p->d_block_base.ensure(size_t(p->total_blocks) * 4)) ||
+        (st = p->d_block_drops.ensure(size_t(p->total_blocks) * 4)) ||
+        (st = p->d_block_drop_base.ensure(size_t(p->total_blocks) * 4)) ||
+        (st = p->d_results.ensure(p->streams.size() * sizeof(LjResult))) ||
+        (st = p->d_diffs.ensure(size_t(p->total_diffs) * 2 + 64)) ||
+        (st = p->d_vseed.ensure(size_t(p->total_rows) * 8 + 16)))
+      return st;
+    p->h_results.resize(p->streams.size());
+  }
+  *out = p.release();
   return RSX_OK;
 }
-int ljpeg_plan_run(LJpegPlan*, const void*, void*, hipStream_t, hipEvent_t, hipEvent_t) {
-  return RSX_ERR_UNSUPPORTED;
+
+// the device-side table record must be what build_device_table() produced
+static_assert(sizeof(TabLds) >= sizeof(DeviceHuffTable), "TabLds too small");
+
+int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
+                   hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  rsx_ctx* ctx = p->ctx;
+  if (p->streams.empty())
+    return RSX_OK;
+  const LjArgs a = make_args(p, in_dev, out_dev);
+  // results: marker_pos = 0xFFFFFFFF, everything else 0
+  std::vector<LjResult> init(p->streams.size());
+  for (auto& r : init) {
+    std::memset(&r, 0, sizeof r);
+    r.marker_pos = 0xFFFFFFFFu;
+  }
+  p->h_results = init;
+  RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->d_results.ptr, p->h_results.data(),
+                                    init.size() * sizeof(LjResult),
+                                    hipMemcpyHostToDevice, s));
+  const uint32_t n_streams = uint32_t(p->streams.size());
+  launch_sync<false>(p, a, s);
+  for (int r = 0; r < p->stitch_rounds; ++r)
+    launch_sync<true>(p, a, s);
+  hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
+  if (ev_start)
+    RSX_HIP_CHECK(ctx, hipEventRecord(ev_start, s));
+  launch_decode(p, a, s);
+  if (ev_stop)
+    RSX_HIP_CHECK(ctx, hipEventRecord(ev_stop, s));
+  hipLaunchKernelGGL(lj_vseed_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
+  launch_predict(p, a, s);
+  hipLaunchKernelGGL(lj_consumed_kernel, dim3(n_streams), dim3(64), 0, s, a);
+  RSX_HIP_CHECK(ctx, hipGetLastError());
+  return RSX_OK;
 }
-int ljpeg_plan_results(LJpegPlan* p, hipStream_t, bool, int32_t* st, uint32_t* c) {
-  for (int i = 0; i < p->n; ++i) { if (st) st[i] = RSX_ERR_UNSUPPORTED; if (c) c[i] = 0; }
-  return RSX_ERR_UNSUPPORTED;
+
+int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_status,
+                       uint32_t* job_consumed) {
+  rsx_ctx* ctx = p->ctx;
+  int rc = RSX_OK;
+  if (ran && !p->streams.empty()) {
+    RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->h_results.data(), p->d_results.ptr,
+                                      p->h_results.size() * sizeof(LjResult),
+                                      hipMemcpyDeviceToHost, s));
+    RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  }
+  for (int i = 0; i < p->n_jobs; ++i) {
+    int st = p->job_status[i];
+    uint32_t consumed = 0;
+    if (st == RSX_OK && ran) {
+      const int fs = p->job_first_stream[i];
+      for (int k = 0; k < p->job_n_streams[i]; ++k) {
+        const LjResult& R = p->h_results[fs + k];
+        const LjStreamDev& S = p->streams[fs + k];
+        if (R.flags & FL_UNCONVERGED)
+          st = RSX_ERR_DEVICE; // see DESIGN.md: re-run with more stitch rounds
+        else if (R.status != 0)
+          st = int(R.status);
+        else if (uint64_t(R.avail_lo) < S.needed)
+          st = RSX_ERR_INPUT_OVERFLOW;
+        consumed = R.consumed;
+        if (st == RSX_OK && S.kind == 0 && uint64_t(consumed) > S.in_bytes)
+          st = RSX_ERR_IO; // inputStream.skipBytes(): LJpegDecompressor.cpp:335
+      }
+    }
+    if (job_status)
+      job_status[i] = st;
+    if (job_consumed)
+      job_consumed[i] = st == RSX_OK ? consumed : 0;
+    if (st != RSX_OK)
+      rc = st;
+  }
+  return rc;
 }
-void ljpeg_plan_destroy(LJpegPlan* p) { delete p; }
-const char* ljpeg_dominant_kernel_name() { return "ljpeg_decode_kernel"; }
+
+void ljpeg_plan_destroy(LJpegPlan* p) {
+  if (!p)
+    return;
+  for (DeviceBuffer* b :
+       {&p->d_streams, &p->d_tables, &p->d_block_stream, &p->d_strips,
+        &p->d_sub_state, &p->d_block_start, &p->d_block_exit, &p->d_block_sum,
+        &p->d_block_base, &p->d_block_drops, &p->d_block_drop_base, &p->d_results,
+        &p->d_diffs, &p->d_vseed})
+    b->release();
+  delete p;
 }
+
+} // namespace rsx

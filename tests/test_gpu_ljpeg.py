@@ -1,0 +1,233 @@
+"""GPU parity of the lossless-JPEG pipeline (LJpegDecompressor, Cr2Decompressor,
+DNG tiles) through the C-ABI vs the oracle, the reference's golden hashes, and
+round trips at the BASELINE sizes."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from rawspeed_amd import abi, synth
+
+import cases as C
+import golden_cases as G
+from oracle_lib import HostImage, out_pitch
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(os.path.dirname(__file__), "golden", "golden_hashes.json")) as f:
+    GOLD = json.load(f)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import gpu_util
+    return gpu_util.ctx()
+
+
+@pytest.mark.parametrize("c", G.LJPEG_CASES, ids=lambda c: c["name"])
+def test_ljpeg_golden(gpu, oracle, c):
+    d, data, (w, h, cpp), tile_px = G.build_ljpeg(c)
+    img, want = HostImage(w, h, cpp), HostImage(w, h, cpp)
+    st, consumed = gpu.ljpeg_decode(d, data, img.view())
+    g = GOLD["ljpeg"][c["name"]]
+    assert (st, consumed) == oracle.ljpeg(d, data, want) == (g["status"], g["consumed"])
+    assert np.array_equal(img.u16(), want.u16())
+    assert G.image_hash(img.pixels()) == g["hash"]
+
+
+@pytest.mark.parametrize("c", G.CR2_CASES, ids=lambda c: c["name"])
+def test_cr2_golden(gpu, oracle, c):
+    d, data, (w, h, cpp), src = G.build_cr2(c)
+    img, want = HostImage(w, h, cpp), HostImage(w, h, cpp)
+    st, consumed = gpu.cr2_decode(d, data, img.view())
+    g = GOLD["cr2"][c["name"]]
+    assert (st, consumed) == oracle.cr2(d, data, want) == (g["status"], g["consumed"])
+    assert np.array_equal(img.u16(), want.u16())
+    assert G.image_hash(img.pixels()) == g["hash"]
+
+
+SHAPES = [
+    # (img_w, img_h, cpp, tile, mcu, frame, kwargs) -- several workgroups per stream
+    (1536, 384, 1, (0, 0, 1536, 384), (2, 1), None, {}),
+    (1536, 384, 1, (0, 0, 1536, 384), (1, 1), None, {}),
+    (1536, 384, 1, (0, 0, 1536, 384), (4, 1), None, {}),
+    (1536, 384, 1, (0, 0, 1536, 384), (2, 2), None, {}),
+    (1533, 386, 1, (0, 0, 1533, 386), (3, 1), None, {}),
+    (700, 300, 3, (10, 20, 601, 250), (3, 1), (640, 256), {}),
+    (1200, 500, 1, (512, 256, 688, 244), (2, 1), (512, 256), {}),       # overhang
+    (1536, 384, 1, (0, 0, 1536, 384), (2, 1), None,
+     dict(tables=(C.NIKON, C.ALT), table_index=[0, 1])),
+    (1024, 256, 1, (0, 0, 1024, 256), (2, 2), None,
+     dict(tables=(C.NIKON, C.ALT, C.FULL17), table_index=[0, 1, 2, 1])),
+    (1024, 256, 1, (0, 0, 1024, 256), (2, 1), None,
+     dict(tables=(C.FULL17,), full_range=True, prec=16)),                # long codes, SSSS 16
+    (1024, 256, 1, (0, 0, 1024, 256), (2, 1), None,
+     dict(tables=(C.FULL17,), full_range=True, prec=16, fix16=True)),
+    (1024, 256, 1, (0, 0, 1024, 256), (2, 1), None, dict(full_range=True)),  # many FF00
+]
+
+
+@pytest.mark.parametrize("k", range(len(SHAPES)))
+def test_ljpeg_shapes_vs_oracle(gpu, oracle, k):
+    w, h, cpp, tile, mcu, frame, kw = SHAPES[k]
+    rng = np.random.default_rng([99, k])
+    d, data, tile_px, scan_len = C.make_ljpeg_case(rng, img_w=w, img_h=h, cpp=cpp, tile=tile,
+                                                   mcu=mcu, frame=frame, **kw)
+    img, want = HostImage(w, h, cpp), HostImage(w, h, cpp)
+    so = oracle.ljpeg(d, data, want)
+    sg = gpu.ljpeg_decode(d, data, img.view())
+    assert sg == so and so[0] == 0
+    assert np.array_equal(img.u16(), want.u16())
+    tx, ty, tw, th = tile
+    assert np.array_equal(img.pixels()[ty:ty + th, cpp * tx:cpp * (tx + tw)], tile_px)
+
+
+@pytest.mark.parametrize("n,slices", [(2, (1, 0, 2016)), (2, (3, 672, 672)), (4, (2, 1504, 512)),
+                                      (2, (4, 480, 576))])
+def test_cr2_shapes_vs_oracle(gpu, oracle, n, slices):
+    rng = np.random.default_rng([98, n, slices[0]])
+    d, data, src, _ = C.make_cr2_case(rng, 2016, 400, n, slices)
+    img, want = HostImage(2016, 400), HostImage(2016, 400)
+    so = oracle.cr2(d, data, want)
+    sg = gpu.cr2_decode(d, data, img.view())
+    assert sg == so and so[0] == 0
+    assert np.array_equal(img.u16(), want.u16())
+    assert np.array_equal(img.pixels(), src)
+
+
+def test_cr2_wrapped_slices(gpu, oracle):
+    """frame.y != dim.y: slices twice the image height wrap into two columns
+    (the Canon double-height quirk, Cr2LJpegDecoder.cpp:80-87)."""
+    rng = np.random.default_rng(97)
+    d, data, src, _ = C.make_cr2_case(rng, 640, 200, 2, (1, 0, 640))
+    d.frame_w, d.frame_h = 160, 400
+    d.num_slices, d.slice_width, d.last_slice_width = 2, 320, 320
+    img, want = HostImage(640, 200), HostImage(640, 200)
+    so = oracle.cr2(d, data, want)
+    assert so[0] == 0
+    assert gpu.cr2_decode(d, data, img.view()) == so
+    assert np.array_equal(img.u16(), want.u16())
+
+
+def test_ljpeg_corrupt_streams(gpu, oracle):
+    """Status parity on damaged streams; bit-exact pixels whenever the reference
+    algorithm succeeds."""
+    rng = np.random.default_rng(5)
+    d, data, tile_px, _ = C.make_ljpeg_case(rng, img_w=1024, img_h=200, cpp=1,
+                                            tile=(0, 0, 1024, 200), mcu=(2, 1))
+    n_fail = n_ok = 0
+    for trial in range(24):
+        bad = data.copy()
+        if trial % 4 == 0:
+            bad = bad[:rng.integers(64, len(bad) // 2)]
+        elif trial % 4 == 1:
+            bad[rng.integers(0, len(bad) - 40)] = 0xFF
+        else:
+            idx = rng.integers(0, len(bad) - 40, size=3)
+            bad[idx] = rng.integers(0, 256, size=3)
+        img, want = HostImage(1024, 200), HostImage(1024, 200)
+        so = oracle.ljpeg(d, bad, want)
+        sg = gpu.ljpeg_decode(d, bad, img.view())
+        if so[0] == 0:
+            n_ok += 1
+            assert sg == so, (trial, sg, so)
+            assert np.array_equal(img.u16(), want.u16()), trial
+        else:
+            n_fail += 1
+            assert sg[0] != 0, (trial, sg, so)
+    assert n_fail > 0 and n_ok > 0
+
+
+def test_dng_ljpeg_tiles(gpu, oracle):
+    """AbstractDngDecompressor::decompressThread<7>: 2x2 tiles of an odd-sized
+    image (right/bottom tiles overhang: trailing pixel + discard + early stop),
+    decoded by one batched call."""
+    rng = np.random.default_rng(6)
+    W, H, tw, th = 1021, 515, 512, 260
+    img, want = HostImage(W, H), HostImage(W, H)
+    descs, datas = [], []
+    for ty in range(2):
+        for tx in range(2):
+            w = min(tw, W - tx * tw)
+            h = min(th, H - ty * th)
+            d, data, _, _ = C.make_ljpeg_case(rng, img_w=W, img_h=H, cpp=1,
+                                              tile=(tx * tw, ty * th, w, h), mcu=(2, 1),
+                                              frame=(tw // 2, th))
+            descs.append(d)
+            datas.append(data)
+    want_cons = []
+    for d, data in zip(descs, datas):
+        st, c = oracle.ljpeg(d, data, want)
+        assert st == 0
+        want_cons.append(c)
+    rc, st, cons = gpu.dng_decompress_ljpeg(descs, datas, img.view())
+    assert rc == 0 and not any(st)
+    assert cons == want_cons
+    assert np.array_equal(img.u16(), want.u16())
+
+
+def _device_roundtrip(gpu, kind, jobs, blobs, out_bytes):
+    import gpu_util
+    inp = gpu_util.to_dev(np.concatenate(blobs))
+    out = torch.zeros(out_bytes, dtype=torch.uint8, device="cuda")
+    plan = gpu.ljpeg_plan(jobs) if kind == "ljpeg" else gpu.cr2_plan(jobs)
+    plan.run(inp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    rc, st, cons = plan.results()
+    assert rc == 0, (rc, st, gpu.last_error())
+    return out.cpu().numpy(), cons
+
+
+def test_cfg3_cr2_full_size_roundtrip(gpu):
+    """BASELINE config 3: 6720x4480, 2 components, 3 slices (2x2240+2240)."""
+    import gpu_util
+    W, H = 6720, 4480
+    src = synth.sensor_image(W, H, 14, seed=1)
+    d = abi.Cr2Desc()
+    d.n_comp, d.x_s_f, d.y_s_f = 2, 1, 1
+    d.frame_w, d.frame_h = W // 2, H
+    d.num_slices, d.slice_width, d.last_slice_width = 3, 2240, 2240
+    rows = C.cr2_stream_from_image(src, 2, W // 2, H, [2240, 2240, 2240])
+    scan, bits = synth.ljpeg_encode_scan(rows, 2, [1 << 13] * 2, [C.NIKON, C.NIKON])
+    abi.fill_recipe(d, synth.huff_tables(C.NIKON), [0, 0], [1 << 13] * 2)
+    data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), np.zeros(30, np.uint8)])
+    j = abi.Cr2Job()
+    j.desc = d
+    j.in_offset, j.in_bytes, j.img_offset = 0, data.size, 0
+    j.img = gpu_util.image_job_view(W, H, 1, out_pitch(W, 1))
+    got, cons = _device_roundtrip(gpu, "cr2", [j], [data], out_pitch(W, 1) * H)
+    got = got.view(np.uint16).reshape(H, out_pitch(W, 1) // 2)[:, :W]
+    assert cons[0] == len(scan)
+    assert np.array_equal(got, src)
+
+
+def test_cfg4_dng_tiles_full_size_roundtrip(gpu):
+    """BASELINE config 4: 8192x5464 as 2x2 LJPEG tiles of 4096x2732, one plan."""
+    import gpu_util
+    W, H, tw, th = 8192, 5464, 4096, 2732
+    src = synth.sensor_image(W, H, 14, seed=2)
+    jobs, blobs, off, lens = [], [], 0, []
+    for ty in range(2):
+        for tx in range(2):
+            tile = np.ascontiguousarray(src[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw])
+            scan, bits = synth.ljpeg_encode_scan(tile, 2, [1 << 13] * 2, [C.NIKON, C.NIKON])
+            data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8),
+                                   np.zeros(16 + (-(len(scan) + 18)) % 16, np.uint8)])
+            d = abi.LJpegDesc()
+            d.tile_x, d.tile_y, d.tile_w, d.tile_h = tx * tw, ty * th, tw, th
+            d.mcu_w, d.mcu_h, d.frame_w, d.frame_h = 2, 1, tw // 2, th
+            d.n_comp, d.rows_per_restart_interval = 2, th
+            abi.fill_recipe(d, synth.huff_tables(C.NIKON), [0, 0], [1 << 13] * 2)
+            j = abi.LJpegJob()
+            j.desc = d
+            j.in_offset, j.in_bytes, j.img_offset = off, data.size, 0
+            j.img = gpu_util.image_job_view(W, H, 1, out_pitch(W, 1))
+            jobs.append(j)
+            blobs.append(data)
+            lens.append(len(scan))
+            off += data.size
+    got, cons = _device_roundtrip(gpu, "ljpeg", jobs, blobs, out_pitch(W, 1) * H)
+    got = got.view(np.uint16).reshape(H, out_pitch(W, 1) // 2)[:, :W]
+    assert cons == lens
+    assert np.array_equal(got, src)
