@@ -60,14 +60,11 @@ int upload(rsx_ctx* ctx, DeviceBuffer& buf, const void* src, size_t bytes) {
   return RSX_OK;
 }
 
+// The pool is created by rsx_plan_set_timing(); once it is exhausted further
+// launches simply go untimed (event creation is far too slow for a hot path).
 EventPair* next_events(rsx_plan* p) {
-  if (p->events_used == p->events.size()) {
-    EventPair e;
-    if (hipEventCreate(&e.start) != hipSuccess ||
-        hipEventCreate(&e.stop) != hipSuccess)
-      return nullptr;
-    p->events.push_back(e);
-  }
+  if (p->events_used == p->events.size())
+    return nullptr;
   return &p->events[p->events_used++];
 }
 
