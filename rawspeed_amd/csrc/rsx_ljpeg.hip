@@ -418,9 +418,13 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
     }
     pos += s.total;
     ++n;
-    phase = (phase + 1 == dp.period) ? 0u : phase + 1;
+    if (MULTI)
+      phase = (phase + 1 == dp.period) ? 0u : phase + 1;
   }
-  exit = (pos - end_bits) | (phase << ST_PHASE_SHIFT);
+  // With one shared table the component phase does not influence the parse, so
+  // it is left out of the state (it would never self-synchronise); with
+  // several tables it is part of what has to match.
+  exit = (pos - end_bits) | (MULTI ? (phase << ST_PHASE_SHIFT) : 0u);
   count = n;
 }
 
@@ -710,7 +714,8 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
         a.results[s].last_pos = pos;
       }
       pos += sy.total;
-      phase = (phase + 1 == dp.period) ? 0u : phase + 1;
+      if (MULTI)
+        phase = (phase + 1 == dp.period) ? 0u : phase + 1;
       ++idx;
       --remaining;
     }
@@ -1048,6 +1053,9 @@ struct LJpegPlan {
       d_block_drop_base, d_results, d_diffs, d_vseed;
   std::vector<LjResult> h_results;
   int stitch_rounds = 2;
+  const void* last_in = nullptr;
+  void* last_out = nullptr;
+  int extra_stitch_rounds = 0; // statistics: rounds needed beyond the default
 };
 
 namespace {
@@ -1244,27 +1252,13 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
 // the device-side table record must be what build_device_table() produced
 static_assert(sizeof(TabLds) >= sizeof(DeviceHuffTable), "TabLds too small");
 
-int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
-                   hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+namespace {
+
+// everything after synchronisation: scan, decode, reconstruct, consumed
+int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s, hipEvent_t ev_start,
+                hipEvent_t ev_stop) {
   rsx_ctx* ctx = p->ctx;
-  if (p->streams.empty())
-    return RSX_OK;
-  const LjArgs a = make_args(p, in_dev, out_dev);
-  // results: marker_pos = 0xFFFFFFFF, everything else 0
-  std::vector<LjResult> init(p->streams.size());
-  for (auto& r : init) {
-    std::memset(&r, 0, sizeof r);
-    r.marker_pos = 0xFFFFFFFFu;
-  }
-  p->h_results = init;
-  RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->d_results.ptr, p->h_results.data(),
-                                    init.size() * sizeof(LjResult),
-                                    hipMemcpyHostToDevice, s));
   const uint32_t n_streams = uint32_t(p->streams.size());
-  launch_sync<false>(p, a, s);
-  for (int r = 0; r < p->stitch_rounds; ++r)
-    launch_sync<true>(p, a, s);
-  hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
   if (ev_start)
     RSX_HIP_CHECK(ctx, hipEventRecord(ev_start, s));
   launch_decode(p, a, s);
@@ -1277,15 +1271,76 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
   return RSX_OK;
 }
 
+} // namespace
+
+int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
+                   hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+  rsx_ctx* ctx = p->ctx;
+  if (p->streams.empty())
+    return RSX_OK;
+  p->last_in = in_dev;
+  p->last_out = out_dev;
+  const LjArgs a = make_args(p, in_dev, out_dev);
+  // results: marker_pos = 0xFFFFFFFF, everything else 0
+  for (auto& r : p->h_results) {
+    std::memset(&r, 0, sizeof r);
+    r.marker_pos = 0xFFFFFFFFu;
+  }
+  RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->d_results.ptr, p->h_results.data(),
+                                    p->h_results.size() * sizeof(LjResult),
+                                    hipMemcpyHostToDevice, s));
+  const uint32_t n_streams = uint32_t(p->streams.size());
+  launch_sync<false>(p, a, s);
+  for (int r = 0; r < p->stitch_rounds; ++r)
+    launch_sync<true>(p, a, s);
+  hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
+  return launch_tail(p, a, s, ev_start, ev_stop);
+}
+
 int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_status,
                        uint32_t* job_consumed) {
   rsx_ctx* ctx = p->ctx;
   int rc = RSX_OK;
-  if (ran && !p->streams.empty()) {
+  auto fetch = [&]() -> int {
     RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->h_results.data(), p->d_results.ptr,
                                       p->h_results.size() * sizeof(LjResult),
                                       hipMemcpyDeviceToHost, s));
     RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    return RSX_OK;
+  };
+  if (ran && !p->streams.empty()) {
+    if (int st = fetch())
+      return st;
+    // The optimistic pipeline ran with a fixed number of stitch rounds.  If a
+    // chain was still inconsistent (rare: a start state that needs more than
+    // one subsequence to synchronise across several workgroups), iterate the
+    // fix-up to its fixed point and redo the tail.  Jacobi iteration: at most
+    // n_blocks rounds, the fixed point is the serial decode.
+    auto unconverged = [&]() {
+      for (const LjResult& R : p->h_results)
+        if (R.flags & FL_UNCONVERGED)
+          return true;
+      return false;
+    };
+    if (unconverged()) {
+      const LjArgs a = make_args(p, p->last_in, p->last_out);
+      const uint32_t n_streams = uint32_t(p->streams.size());
+      uint32_t rounds = 0;
+      while (unconverged() && rounds <= p->total_blocks) {
+        for (int k = 0; k < 4; ++k)
+          launch_sync<true>(p, a, s);
+        rounds += 4;
+        hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
+        RSX_HIP_CHECK(ctx, hipGetLastError());
+        if (int st = fetch())
+          return st;
+      }
+      p->extra_stitch_rounds += int(rounds);
+      if (int st = launch_tail(p, a, s, nullptr, nullptr))
+        return st;
+      if (int st = fetch())
+        return st;
+    }
   }
   for (int i = 0; i < p->n_jobs; ++i) {
     int st = p->job_status[i];
@@ -1296,7 +1351,7 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
         const LjResult& R = p->h_results[fs + k];
         const LjStreamDev& S = p->streams[fs + k];
         if (R.flags & FL_UNCONVERGED)
-          st = RSX_ERR_DEVICE; // see DESIGN.md: re-run with more stitch rounds
+          st = RSX_ERR_DEVICE; // cannot happen: the loop above runs to the fixed point
         else if (R.status != 0)
           st = int(R.status);
         else if (uint64_t(R.avail_lo) < S.needed)
