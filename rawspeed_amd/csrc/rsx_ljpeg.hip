@@ -126,7 +126,9 @@ struct LjResult {
   uint32_t last_slot;  // stream-relative subsequence of the last needed symbol
   uint32_t last_pos;   // its bit offset inside the compacted subsequence
   uint32_t consumed;
-  uint32_t pad;
+  uint32_t tail_used;  // 1: the tail kernel delivered the last symbols
+  uint32_t last_c_lo;  // un-stuffed bit offset of the last symbol (tail path)
+  uint32_t last_c_hi;
 };
 
 struct LjArgs {
@@ -254,7 +256,9 @@ __device__ __forceinline__ void lj_stage(const Lds& L, const LjArgs& a,
 // via marker_off, the slot-relative offset of an FFxx (xx != 0) marker in the
 // own part (-1 if none).  Data after a marker reads as zeros
 // (BitStreamerJPEG.h:155-179).
-__device__ __forceinline__ uint32_t lj_compact(const Lds& L, int j,
+// `valid` = physical bytes from the slot start that lie inside the buffer (may
+// be <= 0 or >= 80): bytes past the end of the buffer are not data.
+__device__ __forceinline__ uint32_t lj_compact(const Lds& L, int j, int valid,
                                                int& marker_off,
                                                uint32_t& own_drops) {
   uint32_t in[LJ_BW + 1];
@@ -286,8 +290,16 @@ __device__ __forceinline__ uint32_t lj_compact(const Lds& L, int j,
     }
     if (ended)
       continue;
+    if (4 * k >= valid) { // end of the buffer
+      if (!own_done) {
+        own_bits = kept * 8;
+        own_done = true;
+      }
+      ended = true;
+      continue;
+    }
     const uint32_t cur = in[k];
-    if (!drop_next && !has_ff(cur)) {
+    if (!drop_next && !has_ff(cur) && 4 * k + 4 <= valid) {
       acc |= uint64_t(cur) << (32 - nacc);
       L.B[ko * LJ_T + j] = uint32_t(acc >> 32);
       ++ko;
@@ -299,6 +311,14 @@ __device__ __forceinline__ uint32_t lj_compact(const Lds& L, int j,
     for (int b = 0; b < 4; ++b) {
       if (ended)
         break;
+      if (4 * k + b >= valid) { // end of the buffer
+        if (!own_done) {
+          own_bits = kept * 8;
+          own_done = true;
+        }
+        ended = true;
+        break;
+      }
       const uint32_t byte = (cur >> (24 - 8 * b)) & 0xFFu;
       if (drop_next) {
         drop_next = false;
@@ -342,6 +362,13 @@ __device__ __forceinline__ uint32_t lj_compact(const Lds& L, int j,
   for (; ko < LJ_BW; ++ko)
     L.B[ko * LJ_T + j] = 0u;
   return own_bits;
+}
+
+__device__ __forceinline__ int lj_valid_bytes(const LjStreamDev& S, uint32_t lb,
+                                              int j) {
+  const int64_t start = int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P;
+  const int64_t v = int64_t(S.in_bytes) - start;
+  return v < 0 ? 0 : (v > 4 * LJ_BW ? 4 * LJ_BW : int(v));
 }
 
 __device__ __forceinline__ uint32_t lj_peek32(const uint32_t* B, int j,
@@ -456,7 +483,8 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   __syncthreads();
   int marker_off;
   uint32_t own_drops;
-  const uint32_t end_bits = lj_compact(L, j, marker_off, own_drops);
+  const uint32_t end_bits =
+      lj_compact(L, j, lj_valid_bytes(S, lb, j), marker_off, own_drops);
   const DecodeParams dp = lj_params(S);
   if (!STITCH && marker_off >= 0 && j >= 1) {
     const int64_t p = int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P + marker_off;
@@ -649,7 +677,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   __syncthreads();
   int marker_off;
   uint32_t own_drops;
-  (void)lj_compact(L, j, marker_off, own_drops);
+  (void)lj_compact(L, j, lj_valid_bytes(S, lb, j), marker_off, own_drops);
   const DecodeParams dp = lj_params(S);
 
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1);
@@ -739,6 +767,146 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
     }
     __syncthreads();
   }
+}
+
+// ---------------------------------------------------------------------------
+// K4b: end-of-stream tail.  The reference keeps decoding when the symbols run
+// past the end of data: after the FFxx marker the bit reader supplies zeros
+// (BitStreamerJPEG.h:155-179) until its position budget is exhausted, then
+// throws "Buffer overflow read in BitStreamer" (BitStreamer.h:120-131).  With
+// c* = the symbol start whose refill first touches the marker, symbols may
+// start at un-stuffed bit offsets <= c* + 160 (64 cache bits + 4 more refills);
+// without a marker, at offsets <= 32*floor((D+16)/4), D = data bytes.
+// Only damaged / truncated streams get here: one lane re-reads the last few
+// subsequences sequentially and delivers the symbols K4 could not.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lj_count_drops(const uint8_t* in, uint64_t from,
+                                                   uint64_t to, int lane);
+__device__ __forceinline__ uint64_t lj_drops_before(const LjArgs& a,
+                                                    const LjStreamDev& S,
+                                                    const uint8_t* in, uint64_t x,
+                                                    int lane);
+
+__device__ __forceinline__ Sym lj_symbol_global(uint32_t w, const TabLds* tb) {
+  const uint32_t e = tb->lut[w >> (32 - LUT_BITS)];
+  if (e & 31u)
+    return {e >> 10, (e >> 5) & 31u, e & 31u, true};
+  for (uint32_t l = LUT_BITS + 1; l <= tb->max_len; ++l) {
+    const uint32_t c = w >> (32 - l);
+    const uint32_t mc = tb->max_code[l];
+    if (mc != NO_CODE && c <= mc) {
+      const uint32_t ssss = tb->values[(c - tb->val_offset[l]) & 0xFFFFu];
+      const uint32_t extra = ssss == 16u ? (tb->fix16 ? 16u : 0u) : ssss;
+      return {l + extra, ssss, l, true};
+    }
+  }
+  return {0, 0, 0, false};
+}
+
+__global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
+  const uint32_t s = blockIdx.x;
+  const LjStreamDev& S = a.streams[s];
+  LjResult& R = a.results[s];
+  const int lane = threadIdx.x;
+  const uint32_t avail = R.avail_lo;
+  if (R.status != 0 || uint64_t(avail) >= S.needed)
+    return; // the common case: every symbol starts inside the data
+  const uint8_t* in = a.in_base + S.in_offset;
+  const bool has_marker = R.marker_pos != 0xFFFFFFFFu && R.marker_pos < S.in_bytes;
+  const uint64_t M = has_marker ? R.marker_pos : S.in_bytes;
+  const uint64_t D = M - lj_drops_before(a, S, in, M, lane);
+  // start two subsequences before the one holding the last data byte
+  const uint64_t ps = M > 0 ? (M - 1) / LJ_P : 0;
+  const uint64_t s0 = ps >= 2 ? ps - 2 : 0;
+  const uint64_t L0 = s0 * LJ_P - lj_drops_before(a, S, in, s0 * LJ_P, lane);
+  if (lane != 0)
+    return;
+  const uint32_t st0 = s0 == 0 ? 0u : (a.sub_state[S.first_subseq + s0 - 1] & ST_MASK);
+  if (st0 & ST_ERR) {
+    atomicCAS(&R.status, 0u, uint32_t(RSX_ERR_BAD_HUFFMAN_CODE));
+    return;
+  }
+  const uint32_t b0 = uint32_t(s0 / LJ_OWN);
+  uint64_t idx = a.block_base[S.first_block + b0];
+  for (uint64_t q = uint64_t(b0) * LJ_OWN; q < s0; ++q)
+    idx += a.sub_state[S.first_subseq + q] >> 16;
+
+  // sequential un-stuffing reader over physical bytes [x, M), zeros afterwards
+  uint64_t x = s0 * LJ_P;
+  if (x < M && x > 0 && in[x] == 0x00 && in[x - 1] == 0xFF)
+    ++x; // the slot starts on a stuffing byte
+  uint64_t buf = 0;
+  uint32_t nb = 0;
+  auto refill = [&]() {
+    while (nb <= 56) {
+      uint32_t byte = 0;
+      if (x < M) {
+        byte = in[x++];
+        if (byte == 0xFF)
+          ++x; // its stuffing byte (every FF before M is followed by 00)
+      }
+      buf |= uint64_t(byte) << (56 - nb);
+      nb += 8;
+    }
+  };
+  refill();
+  uint64_t c = 8 * L0; // un-stuffed bit offset of the reader
+  {
+    uint32_t skip = st0 & ST_OFF_MASK;
+    buf <<= skip;
+    nb -= skip;
+    c += skip;
+  }
+  uint32_t phase = (st0 >> ST_PHASE_SHIFT) & 7u;
+  const bool multi = S.n_tables > 1;
+  const TabLds* tabs = a.tables + S.table_base;
+  const int64_t T0 = int64_t(32 * (D / 4)) - 31;
+  const uint64_t limit_nomarker = 32 * ((D + 16) / 4);
+  int64_t cstar = -1;
+  int16_t* __restrict__ dst = a.diffs + S.diff_offset;
+  while (idx < S.needed) {
+    if (has_marker) {
+      if (cstar < 0 && int64_t(c) >= T0)
+        cstar = int64_t(c);
+      if (cstar >= 0 && int64_t(c) > cstar + 160) {
+        atomicCAS(&R.status, 0u, uint32_t(RSX_ERR_INPUT_OVERFLOW));
+        return;
+      }
+    } else if (c > limit_nomarker) {
+      atomicCAS(&R.status, 0u, uint32_t(RSX_ERR_INPUT_OVERFLOW));
+      return;
+    }
+    refill();
+    const uint32_t w = uint32_t(buf >> 32);
+    const Sym sy = lj_symbol_global(w, tabs + (multi ? S.tab_of_phase[phase] : 0));
+    if (!sy.ok) {
+      atomicCAS(&R.status, 0u, uint32_t(RSX_ERR_BAD_HUFFMAN_CODE));
+      return;
+    }
+    int diff;
+    if (sy.ssss == 0u) {
+      diff = 0;
+    } else if (sy.ssss == 16u) {
+      diff = -32768;
+    } else {
+      const uint32_t v = (w << sy.code_len) >> (32 - sy.ssss);
+      diff = (v >> (sy.ssss - 1)) ? int(v) : int(v) - int((1u << sy.ssss) - 1u);
+    }
+    if (idx >= avail)
+      dst[idx] = int16_t(diff);
+    if (idx + 1 == S.needed) {
+      R.tail_used = 1;
+      R.last_c_lo = uint32_t(c);
+      R.last_c_hi = uint32_t(c >> 32);
+    }
+    buf <<= sy.total;
+    nb -= sy.total;
+    c += sy.total;
+    if (multi)
+      phase = (phase + 1 == S.period) ? 0u : phase + 1;
+    ++idx;
+  }
+  R.avail_lo = uint32_t(S.needed);
 }
 
 // ---------------------------------------------------------------------------
@@ -991,8 +1159,10 @@ __global__ __launch_bounds__(64) void lj_consumed_kernel(LjArgs a) {
   const uint64_t M = has_marker ? R.marker_pos : S.in_bytes;
   // un-stuffed bit offset of the last symbol's start
   const uint64_t slot_phys = uint64_t(R.last_slot) * LJ_P;
-  const uint64_t c =
+  uint64_t c =
       (slot_phys - lj_drops_before(a, S, in, slot_phys, lane)) * 8 + R.last_pos;
+  if (R.tail_used)
+    c = (uint64_t(R.last_c_hi) << 32) | R.last_c_lo;
   const uint64_t K = (c + 31) / 32 + 1;
   const uint64_t D = M - lj_drops_before(a, S, in, M, lane);
   uint64_t result;
@@ -1031,6 +1201,28 @@ __global__ __launch_bounds__(64) void lj_consumed_kernel(LjArgs a) {
     R.consumed = uint32_t(result);
 }
 
+// ---------------------------------------------------------------------------
+// Restart intervals (LJpegDecompressor.cpp:276-298): every FF xx (xx != 00) in
+// the scan is a marker; interval i+1 starts 2 bytes after the i-th one.  This
+// kernel lists them (unordered; the host sorts the handful of entries).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lj_marker_scan_kernel(
+    const uint8_t* __restrict__ in, uint64_t bytes, uint32_t* count, uint2* list,
+    uint32_t cap) {
+  const uint64_t off = (uint64_t(blockIdx.x) * 256 + threadIdx.x) * 16;
+  if (off >= bytes)
+    return;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    const uint64_t p = off + b;
+    if (p + 1 < bytes && in[p] == 0xFF && in[p + 1] != 0x00) {
+      const uint32_t i = atomicAdd(count, 1u);
+      if (i < cap)
+        list[i] = make_uint2(uint32_t(p), uint32_t(in[p + 1]));
+    }
+  }
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -1056,6 +1248,23 @@ struct LJpegPlan {
   const void* last_in = nullptr;
   void* last_out = nullptr;
   int extra_stitch_rounds = 0; // statistics: rounds needed beyond the default
+  // jobs with restart intervals: their streams are only known once the RSTn
+  // markers have been located on the device (one host round trip per run)
+  struct DriJob {
+    int job = 0;
+    LJpegJobIn in;
+    std::vector<rsx_huff_table> tables;
+    uint32_t rows_per_ri = 0, n_ri = 0;
+    std::vector<uint32_t> starts;  // interval start offsets (job-relative)
+    std::vector<uint32_t> markers; // sorted marker offsets (job-relative)
+    std::vector<uint8_t> codes;
+    int status = RSX_OK;
+  };
+  std::vector<DriJob> dri;
+  DeviceBuffer d_marker_count, d_marker_list;
+  std::vector<uint32_t> dri_signature; // marker layout the child plan was built for
+  LJpegPlan* child = nullptr;          // one stream per restart interval
+  std::vector<std::pair<int, int>> child_owner; // child job -> (dri index, interval)
 };
 
 namespace {
@@ -1142,12 +1351,20 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
                                 : g.strip_first_sample[g.n_strips];
     if (st == RSX_OK && needed >= 0xFFFFFFF0ull)
       st = RSX_ERR_UNSUPPORTED;
-    if (st == RSX_OK && g.kind == 0 && J.rows_per_restart_interval > 0 &&
-        uint32_t(J.rows_per_restart_interval) < g.rows)
-      st = RSX_ERR_UNSUPPORTED; // restart intervals: handled by a later revision
     p->job_status[i] = st;
     if (st != RSX_OK)
       continue;
+    if (g.kind == 0 && J.rows_per_restart_interval > 0 &&
+        uint32_t(J.rows_per_restart_interval) < g.rows) {
+      LJpegPlan::DriJob dj;
+      dj.job = int(i);
+      dj.in = J;
+      dj.tables.assign(J.tables, J.tables + J.n_tables);
+      dj.rows_per_ri = uint32_t(J.rows_per_restart_interval);
+      dj.n_ri = (g.rows + dj.rows_per_ri - 1) / dj.rows_per_ri; // :277-278
+      p->dri.push_back(std::move(dj));
+      continue;
+    }
     LjStreamDev S{};
     S.in_offset = g.in_offset;
     S.in_bytes = g.in_bytes;
@@ -1264,6 +1481,7 @@ int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s, hipEvent_t ev_star
   launch_decode(p, a, s);
   if (ev_stop)
     RSX_HIP_CHECK(ctx, hipEventRecord(ev_stop, s));
+  hipLaunchKernelGGL(lj_tail_kernel, dim3(n_streams), dim3(64), 0, s, a);
   hipLaunchKernelGGL(lj_vseed_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
   launch_predict(p, a, s);
   hipLaunchKernelGGL(lj_consumed_kernel, dim3(n_streams), dim3(64), 0, s, a);
@@ -1273,13 +1491,115 @@ int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s, hipEvent_t ev_star
 
 } // namespace
 
+namespace {
+
+// Locate the RSTn markers of every restart-interval job, turn each interval
+// into a stream of a child plan (fresh predictors, byte-aligned start:
+// LJpegDecompressor.cpp:283-300) and run it.  One host round trip per run; the
+// child plan is reused while the marker layout does not change.
+int run_dri(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s) {
+  rsx_ctx* ctx = p->ctx;
+  const uint8_t* in_base = static_cast<const uint8_t*>(in_dev);
+  std::vector<uint32_t> signature;
+  for (auto& dj : p->dri) {
+    dj.status = RSX_OK;
+    const uint64_t bytes = dj.in.geom.in_bytes;
+    uint32_t cap = dj.n_ri + 1024;
+    std::vector<uint2> list;
+    uint32_t count = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if (int st = p->d_marker_count.ensure(16))
+        return st;
+      if (int st = p->d_marker_list.ensure(size_t(cap) * sizeof(uint2)))
+        return st;
+      RSX_HIP_CHECK(ctx, hipMemsetAsync(p->d_marker_count.ptr, 0, 4, s));
+      const uint32_t blocks = uint32_t((bytes + 4095) / 4096);
+      hipLaunchKernelGGL(lj_marker_scan_kernel, dim3(blocks), dim3(256), 0, s,
+                         in_base + dj.in.geom.in_offset, bytes,
+                         static_cast<uint32_t*>(p->d_marker_count.ptr),
+                         static_cast<uint2*>(p->d_marker_list.ptr), cap);
+      RSX_HIP_CHECK(ctx, hipGetLastError());
+      RSX_HIP_CHECK(ctx, hipMemcpyAsync(&count, p->d_marker_count.ptr, 4,
+                                        hipMemcpyDeviceToHost, s));
+      RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+      if (count <= cap)
+        break;
+      cap = count; // rare: lots of FFxx after the scan -- list them all
+    }
+    list.resize(count);
+    if (count)
+      RSX_HIP_CHECK(ctx, hipMemcpy(list.data(), p->d_marker_list.ptr,
+                                   size_t(count) * sizeof(uint2),
+                                   hipMemcpyDeviceToHost));
+    std::sort(list.begin(), list.end(),
+              [](const uint2& x, const uint2& y) { return x.x < y.x; });
+    dj.markers.clear();
+    dj.codes.clear();
+    dj.starts.assign(1, 0u);
+    for (uint32_t i = 0; i + 1 < dj.n_ri; ++i) {
+      if (i >= list.size()) {
+        dj.status = RSX_ERR_RESTART_MARKER; // "Jpeg marker not encountered"
+        break;
+      }
+      dj.markers.push_back(list[i].x);
+      dj.codes.push_back(uint8_t(list[i].y));
+      dj.starts.push_back(list[i].x + 2);
+    }
+    signature.push_back(uint32_t(dj.status));
+    signature.insert(signature.end(), dj.starts.begin(), dj.starts.end());
+  }
+  if (!p->child || signature != p->dri_signature) {
+    if (p->child) {
+      ljpeg_plan_destroy(p->child);
+      p->child = nullptr;
+    }
+    std::vector<LJpegJobIn> jobs;
+    p->child_owner.clear();
+    for (size_t d = 0; d < p->dri.size(); ++d) {
+      auto& dj = p->dri[d];
+      if (dj.status != RSX_OK)
+        continue;
+      const StreamGeom& g = dj.in.geom;
+      for (uint32_t i = 0; i < dj.n_ri; ++i) {
+        LJpegJobIn J = dj.in;
+        J.tables = dj.tables.data();
+        J.rows_per_restart_interval = 0;
+        const uint64_t start = dj.starts[i];
+        // up to and including the closing marker (the reference hands every
+        // interval the whole remaining buffer; >= 8 bytes: BitStreamer.h:58-59)
+        uint64_t end = (i + 1 < dj.n_ri) ? uint64_t(dj.markers[i]) + 2 : g.in_bytes;
+        end = std::min<uint64_t>(g.in_bytes, std::max<uint64_t>(end, start + 8));
+        J.geom.in_offset = g.in_offset + start;
+        J.geom.in_bytes = end - start;
+        const uint32_t r0 = i * dj.rows_per_ri;
+        J.geom.rows = std::min(dj.rows_per_ri, g.rows - r0);
+        J.geom.out_y = g.out_y + g.mcu_h * r0;
+        jobs.push_back(J);
+        p->child_owner.emplace_back(int(d), int(i));
+      }
+    }
+    if (!jobs.empty())
+      if (int st = ljpeg_plan_create(ctx, jobs, &p->child))
+        return st;
+    p->dri_signature = signature;
+  }
+  if (p->child)
+    return ljpeg_plan_run(p->child, in_dev, out_dev, s, nullptr, nullptr);
+  return RSX_OK;
+}
+
+} // namespace
+
 int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
                    hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   rsx_ctx* ctx = p->ctx;
-  if (p->streams.empty())
-    return RSX_OK;
   p->last_in = in_dev;
   p->last_out = out_dev;
+  if (!p->dri.empty())
+    if (int st = run_dri(p, in_dev, out_dev, s))
+      return st;
+  if (p->streams.empty())
+    return RSX_OK;
   const LjArgs a = make_args(p, in_dev, out_dev);
   // results: marker_pos = 0xFFFFFFFF, everything else 0
   for (auto& r : p->h_results) {
@@ -1342,10 +1662,59 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
         return st;
     }
   }
+  // restart-interval jobs: fold the child plan's per-interval results
+  std::vector<int32_t> dri_status(p->dri.size(), RSX_OK);
+  std::vector<uint32_t> dri_consumed(p->dri.size(), 0);
+  if (ran && !p->dri.empty()) {
+    std::vector<int32_t> cst;
+    std::vector<uint32_t> ccons;
+    if (p->child) {
+      cst.assign(p->child->n_jobs, RSX_OK);
+      ccons.assign(p->child->n_jobs, 0);
+      const int crc = ljpeg_plan_results(p->child, s, true, cst.data(), ccons.data());
+      if (crc == RSX_ERR_DEVICE || crc == RSX_ERR_NOMEM)
+        return crc;
+    }
+    for (size_t d = 0; d < p->dri.size(); ++d)
+      dri_status[d] = p->dri[d].status;
+    for (size_t c = 0; c < p->child_owner.size(); ++c) {
+      const int d = p->child_owner[c].first;
+      const uint32_t i = uint32_t(p->child_owner[c].second);
+      const auto& dj = p->dri[d];
+      if (dri_status[d] != RSX_OK)
+        continue; // the first failing interval decides (the reference stops there)
+      if (i > 0) {
+        // marker in front of interval i must be RST((i-1) % 8) (:288-297)
+        const uint8_t code = dj.codes[i - 1];
+        if (code < 0xD0 || code > 0xD7 || uint32_t(code - 0xD0) != ((i - 1) % 8)) {
+          dri_status[d] = RSX_ERR_RESTART_MARKER;
+          continue;
+        }
+      }
+      if (cst[c] != RSX_OK) {
+        dri_status[d] = cst[c];
+        continue;
+      }
+      if (i + 1 < dj.n_ri && dj.starts[i] + ccons[c] != dj.markers[i]) {
+        // the interval must end exactly on its marker (:289-291, :335)
+        dri_status[d] = RSX_ERR_RESTART_MARKER;
+        continue;
+      }
+      dri_consumed[d] = dj.starts[i] + ccons[c];
+    }
+    for (size_t d = 0; d < p->dri.size(); ++d)
+      if (dri_status[d] == RSX_OK && dri_consumed[d] > p->dri[d].in.geom.in_bytes)
+        dri_status[d] = RSX_ERR_IO;
+  }
   for (int i = 0; i < p->n_jobs; ++i) {
     int st = p->job_status[i];
     uint32_t consumed = 0;
-    if (st == RSX_OK && ran) {
+    for (size_t d = 0; d < p->dri.size(); ++d)
+      if (p->dri[d].job == i && st == RSX_OK && ran) {
+        st = dri_status[d];
+        consumed = dri_consumed[d];
+      }
+    if (st == RSX_OK && ran && p->job_first_stream[i] >= 0) {
       const int fs = p->job_first_stream[i];
       for (int k = 0; k < p->job_n_streams[i]; ++k) {
         const LjResult& R = p->h_results[fs + k];
@@ -1374,6 +1743,10 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
 void ljpeg_plan_destroy(LJpegPlan* p) {
   if (!p)
     return;
+  if (p->child)
+    ljpeg_plan_destroy(p->child);
+  p->d_marker_count.release();
+  p->d_marker_list.release();
   for (DeviceBuffer* b :
        {&p->d_streams, &p->d_tables, &p->d_block_stream, &p->d_strips,
         &p->d_sub_state, &p->d_block_start, &p->d_block_exit, &p->d_block_sum,
