@@ -1,0 +1,198 @@
+"""LJPEG legs of bench.py (BASELINE configs 3 and 4), measured like the headline
+number: inputs/outputs resident in HBM, one plan launch per step, hipEvent time
+of the dominant kernel, and the same workload through the unmodified reference
+(oracle/_ref) on the host cores."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+NIKON = None
+
+
+def _nikon():
+    from rawspeed_amd import synth
+    return (synth.NIKON14_COUNTS, synth.NIKON14_VALUES)
+
+
+def out_pitch(w):
+    return (w * 2 + 15) // 16 * 16
+
+
+def make_cr2_frame(W, H, slices, seed):
+    """cfg 3: CR2-style 2-component stream of a WxH sensor-like image."""
+    from rawspeed_amd import abi, synth
+    import cases
+    src = synth.sensor_image(W, H, 14, seed=seed)
+    sl = cases.cr2_slices(*slices)
+    rows = cases.cr2_stream_from_image(src, 2, W // 2, H, sl)
+    scan, bits = synth.ljpeg_encode_scan(rows, 2, [1 << 13] * 2, [_nikon(), _nikon()])
+    d = abi.Cr2Desc()
+    d.n_comp, d.x_s_f, d.y_s_f = 2, 1, 1
+    d.frame_w, d.frame_h = W // 2, H
+    d.num_slices, d.slice_width, d.last_slice_width = slices
+    abi.fill_recipe(d, synth.huff_tables(_nikon()), [0, 0], [1 << 13] * 2)
+    pad = (-(len(scan) + 2)) % 16 + 16
+    data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), np.zeros(pad, np.uint8)])
+    return d, data, src, len(scan), bits
+
+
+def make_tile(src_tile, tx, ty, tw, th):
+    from rawspeed_amd import abi, synth
+    scan, bits = synth.ljpeg_encode_scan(np.ascontiguousarray(src_tile), 2, [1 << 13] * 2,
+                                         [_nikon(), _nikon()])
+    d = abi.LJpegDesc()
+    d.tile_x, d.tile_y, d.tile_w, d.tile_h = tx, ty, tw, th
+    d.mcu_w, d.mcu_h, d.frame_w, d.frame_h = 2, 1, tw // 2, th
+    d.n_comp, d.rows_per_restart_interval = 2, th
+    abi.fill_recipe(d, synth.huff_tables(_nikon()), [0, 0], [1 << 13] * 2)
+    pad = (-(len(scan) + 2)) % 16 + 16
+    data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), np.zeros(pad, np.uint8)])
+    return d, data, len(scan), bits
+
+
+def _time_plan(torch, plan, inp, out, steps, warmup):
+    s = torch.cuda.current_stream().cuda_stream
+    plan.run(inp.data_ptr(), out.data_ptr(), s)
+    rc, st, cons = plan.results()
+    assert rc == 0, (rc, st)
+    plan.set_timing(True)
+    plan.set_timing(False)
+    for _ in range(warmup):
+        plan.run(inp.data_ptr(), out.data_ptr(), s)
+    plan.set_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.run(inp.data_ptr(), out.data_ptr(), s)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kt = plan.kernel_time()
+    plan.set_timing(False)
+    return dt, kt, cons
+
+
+def run_cfg3(ctx, torch, log, frames=8, steps=10, warmup=2):
+    """configs[2]: CR2-style 6720x4480, 2 components, 3 slices; `frames` frames/step."""
+    from rawspeed_amd import abi
+    W, H = 6720, 4480
+    d, data, src, scan_len, bits = make_cr2_frame(W, H, (3, 2240, 2240), seed=1)
+    jobs, off = [], 0
+    for f in range(frames):
+        j = abi.Cr2Job()
+        j.desc = d
+        j.in_offset, j.in_bytes = off, data.size
+        j.img_offset = f * out_pitch(W) * H
+        j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
+            out_pitch(W), W, H, 1, 1
+        jobs.append(j)
+        off += data.size
+    inp = torch.from_numpy(np.tile(data, frames)).cuda()
+    out = torch.zeros(frames * out_pitch(W) * H, dtype=torch.uint8, device="cuda")
+    plan = ctx.cr2_plan(jobs)
+    dt, kt, cons = _time_plan(torch, plan, inp, out, steps, warmup)
+    got = out[:out_pitch(W) * H].cpu().numpy().view(np.uint16).reshape(H, out_pitch(W) // 2)[:, :W]
+    exact = bool(np.array_equal(got, src)) and all(c == scan_len for c in cons)
+    alg = frames * (scan_len + W * H * 2)
+    res = {
+        "workload": "Cr2Decompressor <2,1,1> 6720x4480, 3 slices, %d frames/step" % frames,
+        "mpix_per_s": round(frames * W * H / dt / 1e6, 1),
+        "ms_per_step": round(dt * 1e3, 4),
+        "bit_exact": exact,
+        "entropy_bits_per_px": round(scan_len * 8 / (W * H), 3),
+        "algorithmic_bytes_per_step": alg,
+        "achieved_gbps_whole_pipeline": round(alg / dt / 1e9, 1),
+        "frac_of_hbm_peak": round(alg / dt / 1e9 / 8000.0, 4),
+    }
+    if kt:
+        res["dominant_kernel"] = {"name": kt[0], "avg_ms": round(kt[1], 4)}
+    return res, (d, data, W, H)
+
+
+def run_cfg4(ctx, torch, log, steps=10, warmup=2):
+    """configs[3]: 8192x5464 as 2x2 DNG tiles of 4096x2732 (one plan, tiles-parallel)."""
+    from rawspeed_amd import abi, synth
+    W, H, tw, th = 8192, 5464, 4096, 2732
+    src = synth.sensor_image(W, H, 14, seed=2)
+    jobs, blobs, off, lens = [], [], 0, []
+    for ty in range(2):
+        for tx in range(2):
+            d, data, scan_len, bits = make_tile(src[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw],
+                                                tx * tw, ty * th, tw, th)
+            j = abi.LJpegJob()
+            j.desc = d
+            j.in_offset, j.in_bytes, j.img_offset = off, data.size, 0
+            j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
+                out_pitch(W), W, H, 1, 1
+            jobs.append(j)
+            blobs.append(data)
+            lens.append(scan_len)
+            off += data.size
+    inp = torch.from_numpy(np.concatenate(blobs)).cuda()
+    out = torch.zeros(out_pitch(W) * H, dtype=torch.uint8, device="cuda")
+    plan = ctx.ljpeg_plan(jobs)
+    dt, kt, cons = _time_plan(torch, plan, inp, out, steps, warmup)
+    got = out.cpu().numpy().view(np.uint16).reshape(H, out_pitch(W) // 2)[:, :W]
+    exact = bool(np.array_equal(got, src)) and cons == lens
+    alg = sum(lens) + W * H * 2
+    res = {
+        "workload": "LJpegDecompressor via DNG tiles: 8192x5464 as 2x2 tiles, 1 frame/step",
+        "mpix_per_s": round(W * H / dt / 1e6, 1),
+        "ms_per_step": round(dt * 1e3, 4),
+        "bit_exact": exact,
+        "entropy_bits_per_px": round(sum(lens) * 8 / (W * H), 3),
+        "algorithmic_bytes_per_step": alg,
+        "achieved_gbps_whole_pipeline": round(alg / dt / 1e9, 1),
+        "frac_of_hbm_peak": round(alg / dt / 1e9 / 8000.0, 4),
+    }
+    if kt:
+        res["dominant_kernel"] = {"name": kt[0], "avg_ms": round(kt[1], 4)}
+    return res
+
+
+def cpu_baseline_cr2(d, data, W, H, budget_s=10.0):
+    from oracle_lib import Ref
+    if not Ref.available():
+        return None
+    ref = Ref()
+    img = ref.image(W, H, 1)
+    st, _ = ref.cr2(d, data, img)
+    assert st == 0
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 5 and (time.perf_counter() < t_end or len(times) < 2):
+        t0 = time.perf_counter()
+        ref.cr2(d, data, img)
+        times.append(time.perf_counter() - t0)
+    return {"value": round(W * H / min(times) / 1e6, 1), "unit": "MPix/s", "cores": 1,
+            "kind": "reference",
+            "sample": "Cr2Decompressor::decompress of the unmodified reference on the same "
+                      "6720x4480 stream, 1 thread (the decoder has no internal threading), "
+                      "best of %d" % len(times)}
+
+
+def run(ctx, torch, log):
+    out = {}
+    r3, ref_args = run_cfg3(ctx, torch, log)
+    out["cfg3_cr2_6720x4480"] = r3
+    out["cfg4_dng_tiles_8192x5464"] = run_cfg4(ctx, torch, log)
+    try:
+        out["cfg3_cpu_baseline"] = cpu_baseline_cr2(*ref_args)
+    except Exception as e:
+        out["cfg3_cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
+if __name__ == "__main__":
+    import json
+    import torch
+    import __graft_entry__ as ge
+    ge.build()
+    from rawspeed_amd import capi
+    print(json.dumps(run(capi.Context(0), torch, print), indent=1))

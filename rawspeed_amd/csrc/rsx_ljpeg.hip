@@ -39,6 +39,8 @@
 
 #include <algorithm>
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -1656,6 +1658,15 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
           return st;
       }
       p->extra_stitch_rounds += int(rounds);
+      // the optimistic tail ran on an inconsistent chain: forget what it reported
+      for (LjResult& R : p->h_results) {
+        R.status = 0;
+        R.tail_used = 0;
+        R.last_slot = R.last_pos = R.consumed = 0;
+      }
+      RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->d_results.ptr, p->h_results.data(),
+                                        p->h_results.size() * sizeof(LjResult),
+                                        hipMemcpyHostToDevice, s));
       if (int st = launch_tail(p, a, s, nullptr, nullptr))
         return st;
       if (int st = fetch())
@@ -1705,6 +1716,20 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
     for (size_t d = 0; d < p->dri.size(); ++d)
       if (dri_status[d] == RSX_OK && dri_consumed[d] > p->dri[d].in.geom.in_bytes)
         dri_status[d] = RSX_ERR_IO;
+  }
+  if (getenv("RSX_DEBUG")) {
+    fprintf(stderr, "[rsx] ljpeg plan: %zu streams, extra stitch rounds %d\n",
+            p->streams.size(), p->extra_stitch_rounds);
+    for (size_t k = 0; k < p->h_results.size(); ++k) {
+      const LjResult& R = p->h_results[k];
+      fprintf(stderr,
+              "[rsx]  stream %zu: marker %u status %u flags %u avail %u needed %llu "
+              "last_slot %u last_pos %u consumed %u tail %u blocks %u in_bytes %llu\n",
+              k, R.marker_pos, R.status, R.flags, R.avail_lo,
+              (unsigned long long)p->streams[k].needed, R.last_slot, R.last_pos,
+              R.consumed, R.tail_used, p->streams[k].n_blocks,
+              (unsigned long long)p->streams[k].in_bytes);
+    }
   }
   for (int i = 0; i < p->n_jobs; ++i) {
     int st = p->job_status[i];
