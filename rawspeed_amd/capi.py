@@ -41,6 +41,13 @@ def lib():
             raise RuntimeError(
                 "rawspeed_amd/librsx.so is not built: run `python -m rawspeed_amd.build` "
                 "(or __graft_entry__.build()); there is no fallback implementation")
+        # PyTorch bundles its own libamdhip64; two HIP runtimes in one process do
+        # not coexist ("No HIP GPUs are available").  Loading torch's first makes
+        # librsx.so's DT_NEEDED libamdhip64 resolve to the same, single runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         L.rsx_status_string.restype = C.c_char_p
         L.rsx_ctx_last_error.restype = C.c_char_p
