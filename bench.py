@@ -89,6 +89,20 @@ def unpack_jobs(frames):
     return jobs
 
 
+def pmc_traffic(frames):
+    """HBM bytes per launch from the rocprofv3 PMC passes of this kernel
+    (profiles/r01/unpack_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
+    --pmc runs of this same command).  bench.py cannot run rocprofv3 on itself,
+    so the committed per-launch measurement is scaled to the batch size."""
+    path = os.path.join(ROOT, "profiles", "r01", "unpack_pmc.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return int(d["traffic_bytes_per_launch"] * frames / 8)
+    except Exception:
+        return None
+
+
 def cpu_baseline_unpack(packed_frame, budget_s=20.0):
     """The unmodified reference (oracle/_ref) on this host: 1 thread, then
     independent frames on all cores (the shape of rstest's omp-for over files)."""
@@ -251,7 +265,7 @@ def main():
                 "bound": "hbm", "kernel": name,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic(F),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_kernel_ms": round(avg_ms, 5), "launches_timed": n,
             }
