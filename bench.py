@@ -150,19 +150,15 @@ def cpu_baseline_unpack(packed_frame, budget_s=20.0):
 def main():
     args = parse()
     import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+    from rawspeed_amd import dist as rdist
+    world, rank, local_rank = rdist.env_world()
+    torch.cuda.set_device(local_rank)
+    grp = rdist.Group(backend="nccl", device=torch.device("cuda", local_rank))
+    distributed = grp.enabled
+    dist = grp.dist if distributed else None
     n_gpus = world if distributed else 1
     if args.gpus != n_gpus and rank == 0:
         log("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus))
-    torch.cuda.set_device(local_rank)
 
     import __graft_entry__ as ge
     ge.build()
@@ -195,11 +191,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     plan = ctx.unpack_plan(jobs)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize()
+    barrier = grp.barrier
 
     # untimed: first-touch of the buffers, bit-exactness of the path being timed
     plan.run(inp.data_ptr(), out.data_ptr(), stream)
@@ -223,10 +215,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     ktime = plan.kernel_time()
     plan.set_timing(False)
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = grp.max_over_ranks(elapsed)
 
     pix_per_step = F * w * h * n_gpus
     value = pix_per_step * args.steps / elapsed / 1e6
@@ -283,9 +272,7 @@ def main():
                 result["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":
