@@ -57,8 +57,8 @@ constexpr int LJ_PW = LJ_P / 4;       // dwords per subsequence
 constexpr int LJ_OWN = LJ_T - 1;      // owned slots (slot 0 = warm-up)
 constexpr int LJ_R = LJ_OWN * LJ_P;   // bytes of stream owned by one workgroup
 constexpr int LJ_BW = LJ_PW + 4;      // compacted slot capacity (dwords)
-constexpr int LJ_WIN = 8192;          // K4 output window (samples) -- reuses A
-constexpr int LJ_CHUNKS = 1 + LJ_T * LJ_PW / 4 + 1; // prev + region + lookahead
+constexpr int LJ_WIN = 4096;          // K4 output window (samples)
+constexpr uint32_t LJ_WARM = 128;     // warm-up bits decoded ahead of a slot for its start guess
 
 constexpr uint32_t ST_OFF_MASK = 63u;
 constexpr uint32_t ST_PHASE_SHIFT = 6;
@@ -162,28 +162,36 @@ __device__ __forceinline__ uint32_t has_ff(uint32_t d) {
 }
 
 struct Lds {
-  uint32_t* A;     // [LJ_PW][LJ_T] raw big-endian dwords, later the K4 window
-  uint32_t* B;     // [LJ_BW][LJ_T] un-stuffed big-endian dwords
-  uint32_t* LA;    // 4 lookahead dwords + [4] = byte before slot 0
-  uint32_t* st;    // [LJ_T] exit states
-  uint32_t* misc;  // [16]
+  uint32_t* B;    // [LJ_BW][LJ_T] big-endian dwords of every slot, un-stuffed in place
+  uint32_t* su;   // [LJ_T] start state each slot was last decoded from
+  uint32_t* st;   // [LJ_T] exit state of each slot
+  uint32_t* cn;   // [LJ_T] symbols that start inside each slot
+  uint32_t* ob;   // [LJ_T] data bits of each slot's own 64 bytes
+  uint32_t* list; // [LJ_T] dense list of slots to re-decode
+  uint32_t* misc; // [16]
   TabLds* tabs;
+  int16_t* win;   // K4 only: output window
 };
 
-__device__ __forceinline__ Lds carve(uint8_t* smem) {
+constexpr size_t LJ_LDS_WORDS = size_t(LJ_BW) * LJ_T + 5 * LJ_T + 16;
+
+__device__ __forceinline__ Lds carve(uint8_t* smem, int n_tables) {
   Lds l;
-  l.A = reinterpret_cast<uint32_t*>(smem);
-  l.B = l.A + LJ_PW * LJ_T;
-  l.LA = l.B + LJ_BW * LJ_T;
-  l.st = l.LA + 8;
-  l.misc = l.st + LJ_T;
+  l.B = reinterpret_cast<uint32_t*>(smem);
+  l.su = l.B + LJ_BW * LJ_T;
+  l.st = l.su + LJ_T;
+  l.cn = l.st + LJ_T;
+  l.ob = l.cn + LJ_T;
+  l.list = l.ob + LJ_T;
+  l.misc = l.list + LJ_T;
   l.tabs = reinterpret_cast<TabLds*>(l.misc + 16);
+  l.win = reinterpret_cast<int16_t*>(l.tabs + n_tables);
   return l;
 }
 
-constexpr size_t lj_lds_bytes(int n_tables) {
-  return size_t(LJ_PW * LJ_T + LJ_BW * LJ_T + 8 + LJ_T + 16) * 4 +
-         size_t(n_tables) * sizeof(TabLds);
+constexpr size_t lj_lds_bytes(int n_tables, bool with_window) {
+  return LJ_LDS_WORDS * 4 + size_t(n_tables) * sizeof(TabLds) +
+         (with_window ? size_t(LJ_WIN) * 2 : 0);
 }
 
 // 16 bytes at stream offset `off`, zero outside [0, in_bytes)
@@ -204,120 +212,50 @@ __device__ __forceinline__ uint4 lj_load_chunk(const uint8_t* __restrict__ base,
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// Stage tables + the workgroup's region of the stream into LDS.
-// Slot j (0..255) holds stream bytes [lb*LJ_R + (j-1)*LJ_P, +LJ_P).
-__device__ __forceinline__ void lj_stage(const Lds& L, const LjArgs& a,
-                                         const LjStreamDev& S, uint32_t lb) {
-  const int tid = threadIdx.x;
-  // tables
-  {
-    const uint4* src = reinterpret_cast<const uint4*>(a.tables + S.table_base);
-    uint4* dst = reinterpret_cast<uint4*>(L.tabs);
-    const int n16 = int(S.n_tables * sizeof(TabLds) / 16);
-    for (int i = tid; i < n16; i += LJ_T)
-      dst[i] = src[i];
-  }
-  const uint8_t* __restrict__ in = a.in_base + S.in_offset;
-  const bool aligned16 = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
-  const int64_t in_bytes = int64_t(S.in_bytes);
-  const int64_t region0 = int64_t(lb) * LJ_R - LJ_P - 16; // chunk 0 = 16 bytes before slot 0
-  uint4 v[5];
-#pragma unroll
-  for (int m = 0; m < 5; ++m) {
-    const int c = tid + m * LJ_T;
-    if (c < LJ_CHUNKS)
-      v[m] = lj_load_chunk(in, region0 + int64_t(c) * 16, in_bytes, aligned16);
-  }
-#pragma unroll
-  for (int m = 0; m < 5; ++m) {
-    const int c = tid + m * LJ_T;
-    if (c >= LJ_CHUNKS)
-      continue;
-    const uint32_t d[4] = {__builtin_bswap32(v[m].x), __builtin_bswap32(v[m].y),
-                           __builtin_bswap32(v[m].z), __builtin_bswap32(v[m].w)};
-    if (c == 0) {
-      L.LA[4] = d[3] & 0xFFu; // last byte before slot 0
-    } else if (c == LJ_CHUNKS - 1) {
-      L.LA[0] = d[0];
-      L.LA[1] = d[1];
-      L.LA[2] = d[2];
-      L.LA[3] = d[3];
-    } else {
-      const int g = (c - 1) * 4;     // first region dword of the chunk
-      const int j = g / LJ_PW;       // slot
-      const int k = g % LJ_PW;       // dword inside the slot
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        L.A[(k + q) * LJ_T + j] = d[q];
-    }
-  }
+__device__ __forceinline__ void lj_stage_tables(const Lds& L, const LjArgs& a,
+                                                const LjStreamDev& S) {
+  const uint4* src = reinterpret_cast<const uint4*>(a.tables + S.table_base);
+  uint4* dst = reinterpret_cast<uint4*>(L.tabs);
+  const int n16 = int(S.n_tables * sizeof(TabLds) / 16);
+  for (int i = threadIdx.x; i < n16; i += LJ_T)
+    dst[i] = src[i];
 }
 
-// Un-stuff slot j: physical dwords (own 16 + 4 lookahead) -> B[.][j].
-// Returns the number of data BITS that belong to the slot's own 64 bytes and,
-// via marker_off, the slot-relative offset of an FFxx (xx != 0) marker in the
-// own part (-1 if none).  Data after a marker reads as zeros
-// (BitStreamerJPEG.h:155-179).
-// `valid` = physical bytes from the slot start that lie inside the buffer (may
-// be <= 0 or >= 80): bytes past the end of the buffer are not data.
-__device__ __forceinline__ uint32_t lj_compact(const Lds& L, int j, int valid,
-                                               int& marker_off,
-                                               uint32_t& own_drops) {
-  uint32_t in[LJ_BW + 1];
-#pragma unroll
-  for (int k = 0; k < LJ_PW; ++k)
-    in[k] = L.A[k * LJ_T + j];
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    in[LJ_PW + k] = (j < LJ_T - 1) ? L.A[k * LJ_T + j + 1] : L.LA[k];
-  in[LJ_BW] = 0;
-  const uint32_t prev = (j > 0) ? (L.A[(LJ_PW - 1) * LJ_T + j - 1] & 0xFFu) : L.LA[4];
-
-  uint64_t acc = 0;   // high `nacc` bits valid
-  uint32_t nacc = 0;  // 0, 8, 16 or 24
-  uint32_t ko = 0;    // output dwords written
-  uint32_t kept = 0;  // kept bytes so far
-  uint32_t own_bits = 0;
-  bool own_done = false;
-  bool ended = false;
-  bool drop_next = (prev == 0xFFu) && ((in[0] >> 24) == 0u);
+// In-place un-stuffing of slot j's column of B (only lanes whose 80 bytes hold
+// an FF, or that start on a stuffing byte, get here).  FF00 -> FF; FFxx (xx != 0)
+// or the end of the buffer end the data, everything after reads as zero
+// (BitStreamerJPEG.h:106-183).  Reads run ahead of writes, so in place is safe.
+__device__ __noinline__ void lj_fix_slot(uint32_t* B, int j, uint32_t prev, int valid,
+                                         uint32_t& own_bits, int& marker_off,
+                                         uint32_t& own_drops) {
+  uint64_t acc = 0;  // high `nacc` bits valid
+  uint32_t nacc = 0; // 0, 8, 16 or 24
+  uint32_t ko = 0;   // output dwords written
+  uint32_t kept = 0; // kept bytes so far
+  bool own_done = false, ended = false;
+  bool drop_next = (prev == 0xFFu) && ((B[j] >> 24) == 0u);
+  own_bits = 0;
   marker_off = -1;
   own_drops = 0;
-
-#pragma unroll
-  for (int k = 0; k < LJ_BW; ++k) {
+  for (int k = 0; k < LJ_BW && !ended; ++k) {
     if (k == LJ_PW && !own_done) {
       own_bits = kept * 8;
       own_done = true;
     }
-    if (ended)
-      continue;
-    if (4 * k >= valid) { // end of the buffer
-      if (!own_done) {
-        own_bits = kept * 8;
-        own_done = true;
-      }
-      ended = true;
-      continue;
-    }
-    const uint32_t cur = in[k];
+    if (4 * k >= valid)
+      break; // end of the buffer
+    const uint32_t cur = B[k * LJ_T + j];
+    const uint32_t nxt = k + 1 < LJ_BW ? B[(k + 1) * LJ_T + j] : 0u;
     if (!drop_next && !has_ff(cur) && 4 * k + 4 <= valid) {
       acc |= uint64_t(cur) << (32 - nacc);
-      L.B[ko * LJ_T + j] = uint32_t(acc >> 32);
+      B[ko * LJ_T + j] = uint32_t(acc >> 32);
       ++ko;
       acc <<= 32;
       kept += 4;
       continue;
     }
-#pragma unroll
     for (int b = 0; b < 4; ++b) {
-      if (ended)
-        break;
       if (4 * k + b >= valid) { // end of the buffer
-        if (!own_done) {
-          own_bits = kept * 8;
-          own_done = true;
-        }
         ended = true;
         break;
       }
@@ -329,15 +267,11 @@ __device__ __forceinline__ uint32_t lj_compact(const Lds& L, int j, int valid,
         continue;
       }
       if (byte == 0xFFu) {
-        const uint32_t next =
-            (b < 3) ? ((cur >> (16 - 8 * b)) & 0xFFu) : (in[k + 1] >> 24);
-        if (next != 0u && k < LJ_BW - 1 + (b < 3 ? 1 : 0)) {
-          // end-of-stream marker
-          if (k < LJ_PW) {
-            marker_off = k * 4 + b;
-            own_bits = kept * 8;
-            own_done = true;
-          }
+        const uint32_t next = (b < 3) ? ((cur >> (16 - 8 * b)) & 0xFFu) : (nxt >> 24);
+        const bool last_byte = (k == LJ_BW - 1) && (b == 3);
+        if (next != 0u && !last_byte) {
+          if (k < LJ_PW)
+            marker_off = k * 4 + b; // end-of-stream marker inside the own part
           ended = true;
           break;
         }
@@ -347,7 +281,7 @@ __device__ __forceinline__ uint32_t lj_compact(const Lds& L, int j, int valid,
       nacc += 8;
       ++kept;
       if (nacc == 32) {
-        L.B[ko * LJ_T + j] = uint32_t(acc >> 32);
+        B[ko * LJ_T + j] = uint32_t(acc >> 32);
         ++ko;
         acc = 0;
         nacc = 0;
@@ -356,29 +290,60 @@ __device__ __forceinline__ uint32_t lj_compact(const Lds& L, int j, int valid,
   }
   if (!own_done)
     own_bits = kept * 8;
-  // flush the partial dword and zero-fill the rest of the slot
   if (ko < LJ_BW) {
-    L.B[ko * LJ_T + j] = uint32_t(acc >> 32);
+    B[ko * LJ_T + j] = uint32_t(acc >> 32);
     ++ko;
   }
   for (; ko < LJ_BW; ++ko)
-    L.B[ko * LJ_T + j] = 0u;
+    B[ko * LJ_T + j] = 0u;
+}
+
+// Load slot j (its 64 bytes + 16 bytes of lookahead) straight from global
+// memory into registers, park it big-endian in column j of B, and un-stuff the
+// column in place when it needs it.  Slot j of workgroup lb holds stream bytes
+// [lb*LJ_R + (j-1)*LJ_P, +LJ_P).  Returns the slot's own data bits.
+__device__ __forceinline__ uint32_t lj_load_slot(const Lds& L, const LjArgs& a,
+                                                 const LjStreamDev& S, uint32_t lb,
+                                                 int j, int& marker_off,
+                                                 uint32_t& own_drops) {
+  const uint8_t* __restrict__ in = a.in_base + S.in_offset;
+  const bool aligned16 = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+  const int64_t in_bytes = int64_t(S.in_bytes);
+  const int64_t start = int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P;
+  uint4 v[5];
+#pragma unroll
+  for (int m = 0; m < 5; ++m)
+    v[m] = lj_load_chunk(in, start + 16 * m, in_bytes, aligned16);
+  const uint32_t prev =
+      (start >= 1 && start - 1 < in_bytes) ? uint32_t(in[start - 1]) : 0u;
+  uint32_t any = 0;
+#pragma unroll
+  for (int m = 0; m < 5; ++m) {
+    const uint32_t d[4] = {__builtin_bswap32(v[m].x), __builtin_bswap32(v[m].y),
+                           __builtin_bswap32(v[m].z), __builtin_bswap32(v[m].w)};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      any |= has_ff(d[q]);
+      L.B[(4 * m + q) * LJ_T + j] = d[q];
+    }
+  }
+  const int64_t vb = in_bytes - start;
+  const int valid = vb < 0 ? 0 : (vb > 4 * LJ_BW ? 4 * LJ_BW : int(vb));
+  uint32_t own_bits = 8u * uint32_t(valid > LJ_P ? LJ_P : valid);
+  marker_off = -1;
+  own_drops = 0;
+  if (any != 0u || prev == 0xFFu)
+    lj_fix_slot(L.B, j, prev, valid, own_bits, marker_off, own_drops);
   return own_bits;
 }
 
-__device__ __forceinline__ int lj_valid_bytes(const LjStreamDev& S, uint32_t lb,
-                                              int j) {
-  const int64_t start = int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P;
-  const int64_t v = int64_t(S.in_bytes) - start;
-  return v < 0 ? 0 : (v > 4 * LJ_BW ? 4 * LJ_BW : int(v));
-}
-
-__device__ __forceinline__ uint32_t lj_peek32(const uint32_t* B, int j,
+__device__ __forceinline__ uint32_t lj_peek32(const uint32_t* B, int col,
                                               uint32_t pos) {
   const uint32_t i = pos >> 5, s = pos & 31u;
-  const uint32_t d0 = B[i * LJ_T + j], d1 = B[(i + 1) * LJ_T + j];
-  const uint64_t v = (uint64_t(d0) << 32) | d1;
-  return uint32_t((v << s) >> 32);
+  const uint32_t d0 = B[i * LJ_T + col], d1 = B[(i + 1) * LJ_T + col];
+  // funnel shift left by s (s == 0 must yield d0)
+  const uint32_t f = __builtin_amdgcn_alignbit(d0, d1, 32u - s);
+  return s ? f : d0;
 }
 
 struct Sym {
@@ -422,10 +387,11 @@ __device__ __forceinline__ DecodeParams lj_params(const LjStreamDev& S) {
   return d;
 }
 
-// Decode the symbols that START inside the slot (bit positions [.., end_bits)).
+// Decode the symbols that START inside slot `col` (bit positions [.., end_bits)),
+// beginning at state `start`.
 template <bool MULTI>
 __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams& dp,
-                                               int j, uint32_t start,
+                                               int col, uint32_t start,
                                                uint32_t end_bits, uint32_t& exit,
                                                uint32_t& count) {
   if (start & ST_ERR) {
@@ -437,7 +403,7 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
   uint32_t phase = (start >> ST_PHASE_SHIFT) & 7u;
   uint32_t n = 0;
   while (pos < end_bits) {
-    const uint32_t w = lj_peek32(L.B, j, pos);
+    const uint32_t w = lj_peek32(L.B, col, pos);
     const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
     const Sym s = lj_symbol(w, tb);
     if (!s.ok) {
@@ -457,18 +423,34 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
   count = n;
 }
 
+// Start-state guess for slot j: decode the last LJ_WARM bits of slot j-1 from an
+// arbitrary bit position; Huffman streams self-synchronise within a few
+// symbols, so the position at which this runs into slot j is almost always the
+// true one.  (Checked against the predecessor's real exit afterwards.)
+template <bool MULTI>
+__device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& dp,
+                                              int j) {
+  const uint32_t prev_bits = L.ob[j - 1];
+  if (prev_bits == 0)
+    return 0u;
+  const uint32_t from = prev_bits > LJ_WARM ? prev_bits - LJ_WARM : 0u;
+  uint32_t e, c;
+  lj_decode_span<MULTI>(L, dp, j - 1, from, prev_bits, e, c);
+  return (e & ST_ERR) ? 0u : e;
+}
+
 // ---------------------------------------------------------------------------
 // K1 / K2: synchronisation
 // ---------------------------------------------------------------------------
 template <bool STITCH, bool MULTI>
 __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const Lds L = carve(smem);
   const uint32_t b = blockIdx.x;
   const uint32_t s = a.block_stream[b];
   const LjStreamDev& S = a.streams[s];
   if ((S.n_tables > 1) != MULTI)
     return; // the other instantiation handles this stream
+  const Lds L = carve(smem, int(S.n_tables));
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
 
@@ -481,12 +463,11 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       return; // chain already consistent here
   }
 
-  lj_stage(L, a, S, lb);
-  __syncthreads();
+  lj_stage_tables(L, a, S);
   int marker_off;
   uint32_t own_drops;
-  const uint32_t end_bits =
-      lj_compact(L, j, lj_valid_bytes(S, lb, j), marker_off, own_drops);
+  const uint32_t own_bits = lj_load_slot(L, a, S, lb, j, marker_off, own_drops);
+  L.ob[j] = own_bits;
   const DecodeParams dp = lj_params(S);
   if (!STITCH && marker_off >= 0 && j >= 1) {
     const int64_t p = int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P + marker_off;
@@ -494,60 +475,77 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       atomicMin(&a.results[s].marker_pos, uint32_t(p));
   }
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1); // j >= 1
+  __syncthreads(); // tables, B and ob complete
 
-  uint32_t my_start, my_exit = 0, my_count = 0;
-  bool dirty;
-  int first_chained;
+  // initial decode / initial records
   if (!STITCH) {
-    my_start = 0; // speculative: a symbol starts at bit 0 of the slot, phase 0
-    dirty = true;
-    first_chained = 1;
+    uint32_t start = 0, e = 0, c = 0;
     if (lb == 0 && j == 0) {
-      dirty = false; // slot 0 lies before the stream: its "exit" is the known start
-      my_exit = 0;
-      L.st[0] = 0;
+      // slot 0 lies before the stream: its "exit" is the known start state
+    } else {
+      if (j >= 2 || (j == 1 && lb > 0))
+        start = lj_warmup<MULTI>(L, dp, j);
+      lj_decode_span<MULTI>(L, dp, j, start, own_bits, e, c);
     }
+    L.su[j] = start;
+    L.st[j] = e;
+    L.cn[j] = c;
   } else {
-    first_chained = 2;
     if (j == 0) {
-      my_start = 0;
-      dirty = false;
+      L.su[0] = 0;
       L.st[0] = 0;
+      L.cn[0] = 0;
     } else {
       const uint32_t rec = a.sub_state[gsub];
-      my_exit = rec & ST_MASK;
-      my_count = rec >> 16;
-      L.st[j] = my_exit;
-      if (j == 1) {
-        my_start = true_start;
-        dirty = true;
-      } else {
-        my_start = a.sub_state[gsub - 1] & ST_MASK;
-        dirty = false;
-      }
+      L.st[j] = rec & ST_MASK;
+      L.cn[j] = rec >> 16;
+      L.su[j] = (j == 1) ? a.block_start[b] : (a.sub_state[gsub - 1] & ST_MASK);
     }
   }
-  __syncthreads(); // B complete, st initialised
 
+  // Jacobi iteration with a dense work list: a slot whose recorded start state
+  // differs from its predecessor's exit is re-decoded; the (few) such slots are
+  // packed onto the first lanes so that a handful of stragglers do not cost a
+  // whole-workgroup pass.
+  const int first_chained = STITCH ? 2 : 1;
   while (true) {
-    if (dirty) {
-      lj_decode_span<MULTI>(L, dp, j, my_start, end_bits, my_exit, my_count);
-      L.st[j] = my_exit;
+    if (j == 0)
+      L.misc[8] = 0;
+    __syncthreads();
+    uint32_t want = L.su[j];
+    if (STITCH && j == 1)
+      want = true_start;
+    else if (j >= first_chained)
+      want = L.st[j - 1];
+    if (want != L.su[j]) {
+      const uint32_t k = atomicAdd(&L.misc[8], 1u);
+      L.list[k] = uint32_t(j);
     }
     __syncthreads();
-    const uint32_t ns = (j >= first_chained) ? L.st[j - 1] : my_start;
-    dirty = ns != my_start;
-    my_start = ns;
-    if (!__syncthreads_or(dirty ? 1 : 0))
+    const uint32_t n = L.misc[8];
+    if (n == 0)
       break;
+    uint32_t idx = 0, w = 0, e = 0, c = 0;
+    if (uint32_t(j) < n) {
+      idx = L.list[j];
+      w = (STITCH && idx == 1) ? true_start : L.st[idx - 1];
+      lj_decode_span<MULTI>(L, dp, int(idx), w, L.ob[idx], e, c);
+    }
+    __syncthreads(); // every read of st[] precedes the updates
+    if (uint32_t(j) < n) {
+      L.su[idx] = w;
+      L.st[idx] = e;
+      L.cn[idx] = c;
+    }
   }
 
+  const uint32_t my_count = L.cn[j];
   if (j >= 1)
-    a.sub_state[gsub] = my_exit | (my_count << 16);
+    a.sub_state[gsub] = L.st[j] | (my_count << 16);
   if (j == 1)
-    a.block_start[b] = my_start;
+    a.block_start[b] = L.su[1];
   if (j == LJ_T - 1)
-    a.block_exit[b] = my_exit;
+    a.block_exit[b] = L.st[j];
   // block totals: symbols, dropped stuffing bytes
   uint32_t v = j >= 1 ? my_count : 0u;
   uint32_t dr = j >= 1 ? own_drops : 0u;
@@ -656,12 +654,12 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
 template <bool MULTI>
 __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const Lds L = carve(smem);
   const uint32_t b = blockIdx.x;
   const uint32_t s = a.block_stream[b];
   const LjStreamDev& S = a.streams[s];
   if ((S.n_tables > 1) != MULTI)
     return;
+  const Lds L = carve(smem, int(S.n_tables));
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
   const uint64_t needed = S.needed;
@@ -675,11 +673,10 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   if (uint64_t(lb) * LJ_R > M)
     return; // past the end of data
 
-  lj_stage(L, a, S, lb);
-  __syncthreads();
+  lj_stage_tables(L, a, S);
   int marker_off;
   uint32_t own_drops;
-  (void)lj_compact(L, j, lj_valid_bytes(S, lb, j), marker_off, own_drops);
+  (void)lj_load_slot(L, a, S, lb, j, marker_off, own_drops);
   const DecodeParams dp = lj_params(S);
 
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1);
@@ -700,7 +697,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   }
   if ((j & 63) == 63)
     L.misc[j >> 6] = x;
-  __syncthreads(); // also: B complete, A free to become the window
+  __syncthreads(); // also: tables and B complete
   uint32_t woff = 0;
   for (int w = 0; w < (j >> 6); ++w)
     woff += L.misc[w];
@@ -712,7 +709,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
       int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P < int64_t(M))
     atomicCAS(&a.results[s].status, 0u, uint32_t(RSX_ERR_BAD_HUFFMAN_CODE));
 
-  int16_t* win = reinterpret_cast<int16_t*>(L.A);
+  int16_t* win = L.win;
   int16_t* __restrict__ dst = a.diffs + S.diff_offset;
   const uint64_t g0 = uint64_t(base) & ~uint64_t(7);
   const uint64_t blk_end = std::min<uint64_t>(uint64_t(base) + sum, needed);
@@ -1296,22 +1293,21 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
 
 template <bool STITCH>
 void launch_sync(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
-  const size_t lds = lj_lds_bytes(p->max_tables);
   if (p->any_single)
     hipLaunchKernelGGL((lj_sync_kernel<STITCH, false>), dim3(p->total_blocks),
-                       dim3(LJ_T), lj_lds_bytes(1), s, a);
+                       dim3(LJ_T), lj_lds_bytes(1, false), s, a);
   if (p->any_multi)
     hipLaunchKernelGGL((lj_sync_kernel<STITCH, true>), dim3(p->total_blocks),
-                       dim3(LJ_T), lds, s, a);
+                       dim3(LJ_T), lj_lds_bytes(p->max_tables, false), s, a);
 }
 
 void launch_decode(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
   if (p->any_single)
     hipLaunchKernelGGL((lj_decode_kernel<false>), dim3(p->total_blocks), dim3(LJ_T),
-                       lj_lds_bytes(1), s, a);
+                       lj_lds_bytes(1, true), s, a);
   if (p->any_multi)
     hipLaunchKernelGGL((lj_decode_kernel<true>), dim3(p->total_blocks), dim3(LJ_T),
-                       lj_lds_bytes(p->max_tables), s, a);
+                       lj_lds_bytes(p->max_tables, true), s, a);
 }
 
 void launch_predict(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
