@@ -190,9 +190,22 @@ def run(ctx, torch, log):
 
 
 if __name__ == "__main__":
+    import argparse
     import json
     import torch
     import __graft_entry__ as ge
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=10)
+    args = ap.parse_args()
     ge.build()
     from rawspeed_amd import capi
-    print(json.dumps(run(capi.Context(0), torch, print), indent=1))
+    ctx = capi.Context(0)
+    if args.only == "cfg3":
+        r, _ = run_cfg3(ctx, torch, print, frames=args.frames, steps=args.steps)
+        print(json.dumps(r, indent=1))
+    elif args.only == "cfg4":
+        print(json.dumps(run_cfg4(ctx, torch, print, steps=args.steps), indent=1))
+    else:
+        print(json.dumps(run(ctx, torch, print), indent=1))

@@ -57,7 +57,6 @@ constexpr int LJ_PW = LJ_P / 4;       // dwords per subsequence
 constexpr int LJ_OWN = LJ_T - 1;      // owned slots (slot 0 = warm-up)
 constexpr int LJ_R = LJ_OWN * LJ_P;   // bytes of stream owned by one workgroup
 constexpr int LJ_BW = LJ_PW + 4;      // compacted slot capacity (dwords)
-constexpr int LJ_WIN = 4096;          // K4 output window (samples)
 constexpr uint32_t LJ_WARM = 128;     // warm-up bits decoded ahead of a slot for its start guess
 
 constexpr uint32_t ST_OFF_MASK = 63u;
@@ -168,12 +167,12 @@ struct Lds {
   uint32_t* cn;   // [LJ_T] symbols that start inside each slot
   uint32_t* ob;   // [LJ_T] data bits of each slot's own 64 bytes
   uint32_t* list; // [LJ_T] dense list of slots to re-decode
+  uint32_t* bm;   // [2*LJ_T] per slot: bitmap of symbol starts at bit positions < 64
   uint32_t* misc; // [16]
   TabLds* tabs;
-  int16_t* win;   // K4 only: output window
 };
 
-constexpr size_t LJ_LDS_WORDS = size_t(LJ_BW) * LJ_T + 5 * LJ_T + 16;
+constexpr size_t LJ_LDS_WORDS = size_t(LJ_BW) * LJ_T + 7 * LJ_T + 16;
 
 __device__ __forceinline__ Lds carve(uint8_t* smem, int n_tables) {
   Lds l;
@@ -183,15 +182,14 @@ __device__ __forceinline__ Lds carve(uint8_t* smem, int n_tables) {
   l.cn = l.st + LJ_T;
   l.ob = l.cn + LJ_T;
   l.list = l.ob + LJ_T;
-  l.misc = l.list + LJ_T;
+  l.bm = l.list + LJ_T;
+  l.misc = l.bm + 2 * LJ_T;
   l.tabs = reinterpret_cast<TabLds*>(l.misc + 16);
-  l.win = reinterpret_cast<int16_t*>(l.tabs + n_tables);
   return l;
 }
 
-constexpr size_t lj_lds_bytes(int n_tables, bool with_window) {
-  return LJ_LDS_WORDS * 4 + size_t(n_tables) * sizeof(TabLds) +
-         (with_window ? size_t(LJ_WIN) * 2 : 0);
+constexpr size_t lj_lds_bytes(int n_tables) {
+  return LJ_LDS_WORDS * 4 + size_t(n_tables) * sizeof(TabLds);
 }
 
 // 16 bytes at stream offset `off`, zero outside [0, in_bytes)
@@ -387,13 +385,33 @@ __device__ __forceinline__ DecodeParams lj_params(const LjStreamDev& S) {
   return d;
 }
 
-// Decode the symbols that START inside slot `col` (bit positions [.., end_bits)),
-// beginning at state `start`.
+// One symbol at bit position `pos` of slot `col`; false on an invalid code.
 template <bool MULTI>
+__device__ __forceinline__ bool lj_step(const Lds& L, const DecodeParams& dp, int col,
+                                        uint32_t& pos, uint32_t& phase) {
+  const uint32_t w = lj_peek32(L.B, col, pos);
+  const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
+  const Sym s = lj_symbol(w, tb);
+  pos += s.total;
+  if (MULTI)
+    phase = (phase + 1 == dp.period) ? 0u : phase + 1;
+  return s.ok;
+}
+
+// Decode the symbols that START inside slot `col` (bit positions [.., end_bits)),
+// beginning at state `start`.  With RECORD, *bm receives the bitmap of symbol
+// starts at bit positions < 64 (the slot's "trajectory", used for early-out
+// re-synchronisation).
+// With one shared table the component phase does not influence the parse, so it
+// is left out of the state (it would never self-synchronise); with several
+// tables it is part of what has to match.
+template <bool MULTI, bool RECORD>
 __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams& dp,
                                                int col, uint32_t start,
                                                uint32_t end_bits, uint32_t& exit,
-                                               uint32_t& count) {
+                                               uint32_t& count, uint64_t* bm) {
+  if (RECORD)
+    *bm = 0;
   if (start & ST_ERR) {
     exit = ST_ERR;
     count = 0;
@@ -402,25 +420,58 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
   uint32_t pos = start & ST_OFF_MASK;
   uint32_t phase = (start >> ST_PHASE_SHIFT) & 7u;
   uint32_t n = 0;
-  while (pos < end_bits) {
-    const uint32_t w = lj_peek32(L.B, col, pos);
-    const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
-    const Sym s = lj_symbol(w, tb);
-    if (!s.ok) {
-      exit = ST_ERR;
-      count = n;
+  bool ok = true;
+  if (RECORD) {
+    uint64_t m = 0;
+    const uint32_t lim = end_bits < 64u ? end_bits : 64u;
+    while (pos < lim && ok) {
+      m |= 1ull << pos;
+      ok = lj_step<MULTI>(L, dp, col, pos, phase);
+      n += ok ? 1u : 0u;
+    }
+    *bm = m;
+  }
+  while (pos < end_bits && ok) {
+    ok = lj_step<MULTI>(L, dp, col, pos, phase);
+    n += ok ? 1u : 0u;
+  }
+  exit = ok ? ((pos - end_bits) | (MULTI ? (phase << ST_PHASE_SHIFT) : 0u)) : ST_ERR;
+  count = n;
+}
+
+// Re-decode slot `col` from a new start state, stopping as soon as the new
+// trajectory lands on a symbol start of the old one (single-table streams: the
+// parse from there on is identical, so the old exit and the old tail count
+// stand).  Updates the slot's records in registers.
+__device__ __forceinline__ void lj_redecode_sync(const Lds& L, const DecodeParams& dp,
+                                                 int col, uint32_t start,
+                                                 uint32_t end_bits, uint64_t old_bm,
+                                                 uint32_t old_exit, uint32_t old_cn,
+                                                 uint32_t& exit, uint32_t& count,
+                                                 uint64_t& bm) {
+  uint32_t pos = start & ST_OFF_MASK, phase = 0, n = 0;
+  uint64_t m = 0;
+  bool ok = true;
+  const uint32_t lim = end_bits < 64u ? end_bits : 64u;
+  while (pos < lim && ok) {
+    if ((old_bm >> pos) & 1ull) {
+      const uint64_t below = old_bm & ((1ull << pos) - 1ull);
+      count = n + old_cn - uint32_t(__builtin_popcountll(below));
+      exit = old_exit;
+      bm = m | (old_bm & ~((1ull << pos) - 1ull));
       return;
     }
-    pos += s.total;
-    ++n;
-    if (MULTI)
-      phase = (phase + 1 == dp.period) ? 0u : phase + 1;
+    m |= 1ull << pos;
+    ok = lj_step<false>(L, dp, col, pos, phase);
+    n += ok ? 1u : 0u;
   }
-  // With one shared table the component phase does not influence the parse, so
-  // it is left out of the state (it would never self-synchronise); with
-  // several tables it is part of what has to match.
-  exit = (pos - end_bits) | (MULTI ? (phase << ST_PHASE_SHIFT) : 0u);
+  while (pos < end_bits && ok) {
+    ok = lj_step<false>(L, dp, col, pos, phase);
+    n += ok ? 1u : 0u;
+  }
+  exit = ok ? (pos - end_bits) : ST_ERR;
   count = n;
+  bm = m;
 }
 
 // Start-state guess for slot j: decode the last LJ_WARM bits of slot j-1 from an
@@ -435,7 +486,7 @@ __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& 
     return 0u;
   const uint32_t from = prev_bits > LJ_WARM ? prev_bits - LJ_WARM : 0u;
   uint32_t e, c;
-  lj_decode_span<MULTI>(L, dp, j - 1, from, prev_bits, e, c);
+  lj_decode_span<MULTI, false>(L, dp, j - 1, from, prev_bits, e, c, nullptr);
   return (e & ST_ERR) ? 0u : e;
 }
 
@@ -480,17 +531,22 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   // initial decode / initial records
   if (!STITCH) {
     uint32_t start = 0, e = 0, c = 0;
+    uint64_t bm = 0;
     if (lb == 0 && j == 0) {
       // slot 0 lies before the stream: its "exit" is the known start state
     } else {
       if (j >= 2 || (j == 1 && lb > 0))
         start = lj_warmup<MULTI>(L, dp, j);
-      lj_decode_span<MULTI>(L, dp, j, start, own_bits, e, c);
+      lj_decode_span<MULTI, !MULTI>(L, dp, j, start, own_bits, e, c, &bm);
     }
     L.su[j] = start;
     L.st[j] = e;
     L.cn[j] = c;
+    L.bm[2 * j] = uint32_t(bm);
+    L.bm[2 * j + 1] = uint32_t(bm >> 32);
   } else {
+    L.bm[2 * j] = 0; // no trajectory on record: the first re-decode is a full one
+    L.bm[2 * j + 1] = 0;
     if (j == 0) {
       L.su[0] = 0;
       L.st[0] = 0;
@@ -526,16 +582,25 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     if (n == 0)
       break;
     uint32_t idx = 0, w = 0, e = 0, c = 0;
+    uint64_t bm = 0;
     if (uint32_t(j) < n) {
       idx = L.list[j];
       w = (STITCH && idx == 1) ? true_start : L.st[idx - 1];
-      lj_decode_span<MULTI>(L, dp, int(idx), w, L.ob[idx], e, c);
+      if (MULTI || (w & ST_ERR)) {
+        lj_decode_span<MULTI, false>(L, dp, int(idx), w, L.ob[idx], e, c, nullptr);
+      } else {
+        const uint64_t old_bm = uint64_t(L.bm[2 * idx]) | (uint64_t(L.bm[2 * idx + 1]) << 32);
+        lj_redecode_sync(L, dp, int(idx), w, L.ob[idx], old_bm, L.st[idx], L.cn[idx], e,
+                         c, bm);
+      }
     }
     __syncthreads(); // every read of st[] precedes the updates
     if (uint32_t(j) < n) {
       L.su[idx] = w;
       L.st[idx] = e;
       L.cn[idx] = c;
+      L.bm[2 * idx] = uint32_t(bm);
+      L.bm[2 * idx + 1] = uint32_t(bm >> 32);
     }
   }
 
@@ -697,74 +762,77 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   }
   if ((j & 63) == 63)
     L.misc[j >> 6] = x;
-  __syncthreads(); // also: tables and B complete
+  __syncthreads(); // also: tables complete
   uint32_t woff = 0;
   for (int w = 0; w < (j >> 6); ++w)
     woff += L.misc[w];
-  uint64_t idx = uint64_t(base) + woff + x - my_count; // first symbol of this lane
+  const uint64_t first = uint64_t(base) + woff + x - my_count; // first symbol of this lane
 
   // a bad Huffman code inside the delivered range is a real error
   // (PrefixCodeLookupDecoder.h:152-155)
-  if (j >= 1 && (my_exit & ST_ERR) && idx + my_count < needed &&
+  if (j >= 1 && (my_exit & ST_ERR) && first + my_count < needed &&
       int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P < int64_t(M))
     atomicCAS(&a.results[s].status, 0u, uint32_t(RSX_ERR_BAD_HUFFMAN_CODE));
 
-  int16_t* win = L.win;
-  int16_t* __restrict__ dst = a.diffs + S.diff_offset;
-  const uint64_t g0 = uint64_t(base) & ~uint64_t(7);
-  const uint64_t blk_end = std::min<uint64_t>(uint64_t(base) + sum, needed);
-  const uint32_t n_win = uint32_t((blk_end - g0 + LJ_WIN - 1) / LJ_WIN);
+  // Every lane streams its own symbols to the stream-ordered scratch: 8
+  // differences are packed in registers and leave as one 16-byte store (the
+  // lane's output range starts on an arbitrary 2-byte boundary; gfx950 global
+  // stores take unaligned addresses).  No LDS staging, no barriers.
+  uint32_t remaining = (my_start & ST_ERR) ? 0u : my_count;
+  if (first >= needed)
+    remaining = 0;
+  else if (first + remaining > needed)
+    remaining = uint32_t(needed - first);
+  int16_t* __restrict__ out = a.diffs + S.diff_offset + first;
+  // local index of the last symbol the reference decodes (for K7), if it is ours
+  const uint32_t last_local =
+      (needed >= 1 && needed - 1 >= first && needed - 1 < first + remaining)
+          ? uint32_t(needed - 1 - first)
+          : 0xFFFFFFFFu;
 
   uint32_t pos = my_start & ST_OFF_MASK;
   uint32_t phase = (my_start >> ST_PHASE_SHIFT) & 7u;
-  uint32_t remaining = (my_start & ST_ERR) ? 0u : my_count;
+  uint32_t last_pos = 0;
+  auto next_diff = [&](uint32_t local) -> uint32_t {
+    const uint32_t w = lj_peek32(L.B, j, pos);
+    const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
+    const Sym sy = lj_symbol(w, tb);
+    int diff;
+    if (sy.ssss == 0u) {
+      diff = 0;
+    } else if (sy.ssss == 16u) {
+      diff = -32768;
+    } else {
+      const uint32_t v = (w << sy.code_len) >> (32 - sy.ssss);
+      diff = (v >> (sy.ssss - 1)) ? int(v) : int(v) - int((1u << sy.ssss) - 1u);
+    }
+    if (local == last_local)
+      last_pos = pos;
+    pos += sy.total;
+    if (MULTI)
+      phase = (phase + 1 == dp.period) ? 0u : phase + 1;
+    return uint32_t(diff) & 0xFFFFu;
+  };
 
-  for (uint32_t wdx = 0; wdx < n_win; ++wdx) {
-    const uint64_t lo = g0 + uint64_t(wdx) * LJ_WIN;
-    const uint64_t hi = lo + LJ_WIN;
-    while (remaining > 0 && idx < hi && idx < needed) {
-      const uint32_t w = lj_peek32(L.B, j, pos);
-      const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
-      const Sym sy = lj_symbol(w, tb);
-      int diff;
-      if (sy.ssss == 0u) {
-        diff = 0;
-      } else if (sy.ssss == 16u) {
-        diff = -32768;
-      } else {
-        const uint32_t v = (w << sy.code_len) >> (32 - sy.ssss);
-        diff = (v >> (sy.ssss - 1)) ? int(v) : int(v) - int((1u << sy.ssss) - 1u);
-      }
-      win[uint32_t(idx - lo)] = int16_t(diff);
-      if (idx + 1 == needed) {
-        a.results[s].last_slot = lb * LJ_OWN + uint32_t(j - 1);
-        a.results[s].last_pos = pos;
-      }
-      pos += sy.total;
-      if (MULTI)
-        phase = (phase + 1 == dp.period) ? 0u : phase + 1;
-      ++idx;
-      --remaining;
-    }
-    __syncthreads();
-    // cooperative, 16-byte coalesced copy-out of [max(lo, base), min(hi, blk_end))
-    const uint64_t vlo = std::max<uint64_t>(lo, base);
-    const uint64_t vhi = std::min<uint64_t>(hi, blk_end);
-    for (uint32_t v8 = j; v8 < LJ_WIN / 8; v8 += LJ_T) {
-      const uint64_t gi = lo + uint64_t(v8) * 8;
-      if (gi + 8 <= vlo || gi >= vhi)
-        continue;
-      if (gi >= vlo && gi + 8 <= vhi) {
-        *reinterpret_cast<uint4*>(dst + gi) =
-            *reinterpret_cast<const uint4*>(win + v8 * 8);
-      } else {
+  const uint32_t groups = remaining >> 3;
+  uint32_t local = 0;
+  for (uint32_t g = 0; g < groups; ++g) {
+    uint32_t p[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (gi + q >= vlo && gi + q < vhi)
-            dst[gi + q] = win[v8 * 8 + q];
-      }
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t lo = next_diff(local);
+      const uint32_t hi = next_diff(local + 1);
+      local += 2;
+      p[q] = lo | (hi << 16);
     }
-    __syncthreads();
+    const uint4 v = make_uint4(p[0], p[1], p[2], p[3]);
+    __builtin_memcpy(out + 8 * g, &v, 16);
+  }
+  for (; local < remaining; ++local)
+    out[local] = int16_t(next_diff(local));
+  if (last_local != 0xFFFFFFFFu) {
+    a.results[s].last_slot = lb * LJ_OWN + uint32_t(j - 1);
+    a.results[s].last_pos = last_pos;
   }
 }
 
@@ -1010,18 +1078,30 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
   for (int c = 0; c < N; ++c)
     carry[c] = a.vseed[(uint64_t(S.first_row) + r) * 4 + c];
 
+  // 8 differences of this lane for the step starting at q0 (packed 2 x u16 per
+  // dword); loads run two steps ahead of the scan so that HBM latency overlaps
+  auto load8 = [&](uint32_t q0) -> uint4 {
+    const uint32_t q = q0 + lane * 8;
+    if (q + 8 <= n && in_aligned)
+      return *reinterpret_cast<const uint4*>(D + q);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (q + i < n)
+        w[i >> 1] |= uint32_t(uint16_t(D[q + i])) << (16 * (i & 1));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  };
+  uint4 t0 = load8(0);
+  uint4 t1 = 512 < n ? load8(512) : make_uint4(0, 0, 0, 0);
   for (uint32_t q0 = 0; q0 < n; q0 += 512) {
     const uint32_t q = q0 + lane * 8;
+    const uint4 t = t0;
+    t0 = t1;
+    if (q0 + 1024 < n)
+      t1 = load8(q0 + 1024);
     uint32_t v[8];
-    if (q + 8 <= n && in_aligned) {
-      const uint4 t = *reinterpret_cast<const uint4*>(D + q);
-      v[0] = t.x & 0xFFFF; v[1] = t.x >> 16; v[2] = t.y & 0xFFFF; v[3] = t.y >> 16;
-      v[4] = t.z & 0xFFFF; v[5] = t.z >> 16; v[6] = t.w & 0xFFFF; v[7] = t.w >> 16;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        v[i] = (q + i < n) ? uint32_t(uint16_t(D[q + i])) : 0u;
-    }
+    v[0] = t.x & 0xFFFF; v[1] = t.x >> 16; v[2] = t.y & 0xFFFF; v[3] = t.y >> 16;
+    v[4] = t.z & 0xFFFF; v[5] = t.z >> 16; v[6] = t.w & 0xFFFF; v[7] = t.w >> 16;
     // component of v[i] is (q + i) % N; rot = q % N (0 unless N == 3)
     const int rot = (N == 3) ? int(q % 3) : 0;
     uint32_t run[N];
@@ -1295,19 +1375,19 @@ template <bool STITCH>
 void launch_sync(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
   if (p->any_single)
     hipLaunchKernelGGL((lj_sync_kernel<STITCH, false>), dim3(p->total_blocks),
-                       dim3(LJ_T), lj_lds_bytes(1, false), s, a);
+                       dim3(LJ_T), lj_lds_bytes(1), s, a);
   if (p->any_multi)
     hipLaunchKernelGGL((lj_sync_kernel<STITCH, true>), dim3(p->total_blocks),
-                       dim3(LJ_T), lj_lds_bytes(p->max_tables, false), s, a);
+                       dim3(LJ_T), lj_lds_bytes(p->max_tables), s, a);
 }
 
 void launch_decode(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
   if (p->any_single)
     hipLaunchKernelGGL((lj_decode_kernel<false>), dim3(p->total_blocks), dim3(LJ_T),
-                       lj_lds_bytes(1, true), s, a);
+                       lj_lds_bytes(1), s, a);
   if (p->any_multi)
     hipLaunchKernelGGL((lj_decode_kernel<true>), dim3(p->total_blocks), dim3(LJ_T),
-                       lj_lds_bytes(p->max_tables, true), s, a);
+                       lj_lds_bytes(p->max_tables), s, a);
 }
 
 void launch_predict(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
