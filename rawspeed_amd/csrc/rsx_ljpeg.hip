@@ -130,6 +130,10 @@ struct LjResult {
   uint32_t tail_used;  // 1: the tail kernel delivered the last symbols
   uint32_t last_c_lo;  // un-stuffed bit offset of the last symbol (tail path)
   uint32_t last_c_hi;
+  uint32_t stat_rounds; // statistics: re-decode rounds summed over workgroups
+  uint32_t stat_redo;   // statistics: slots re-decoded
+  uint32_t stat_stitch; // statistics: workgroups re-converged by the stitch kernel
+  uint32_t pad2;
 };
 
 struct LjArgs {
@@ -351,21 +355,33 @@ struct Sym {
   bool ok;
 };
 
-__device__ __forceinline__ Sym lj_symbol(uint32_t w, const TabLds& tb) {
-  const uint32_t e = tb.lut[w >> (32 - LUT_BITS)];
-  if (e & 31u)
-    return {e >> 10, (e >> 5) & 31u, e & 31u, true};
+// Packed symbol entry (the LUT's format): bits 0..4 code length, 5..9 SSSS,
+// 10..15 bits consumed.  0 = invalid code.
+__device__ __noinline__ uint32_t lj_slow_entry(uint32_t w, const TabLds* tb) {
   // codes longer than the LUT: JPEG Annex F.2.2.3 search
-  for (uint32_t l = LUT_BITS + 1; l <= tb.max_len; ++l) {
+  for (uint32_t l = LUT_BITS + 1; l <= tb->max_len; ++l) {
     const uint32_t c = w >> (32 - l);
-    const uint32_t mc = tb.max_code[l];
+    const uint32_t mc = tb->max_code[l];
     if (mc != NO_CODE && c <= mc) {
-      const uint32_t ssss = tb.values[(c - tb.val_offset[l]) & 0xFFFFu];
-      const uint32_t extra = ssss == 16u ? (tb.fix16 ? 16u : 0u) : ssss;
-      return {l + extra, ssss, l, true};
+      const uint32_t ssss = tb->values[(c - tb->val_offset[l]) & 0xFFFFu];
+      const uint32_t extra = ssss == 16u ? (tb->fix16 ? 16u : 0u) : ssss;
+      return l | (ssss << 5) | ((l + extra) << 10);
     }
   }
-  return {0, 0, 0, false};
+  return 0u;
+}
+
+// Entry of the symbol whose first 32 bits are w.  `live` lanes matter; the
+// out-of-line search only runs when some live lane missed the LUT (codes longer
+// than LUT_BITS are rare, and never occur with the short tables real files use),
+// so the common path has no divergent control flow at all.
+__device__ __forceinline__ uint32_t lj_entry(uint32_t w, const TabLds& tb, bool live) {
+  uint32_t e = tb.lut[w >> (32 - LUT_BITS)];
+  if (__builtin_expect(__any(live && (e & 31u) == 0u), 0)) {
+    if (live && (e & 31u) == 0u)
+      e = lj_slow_entry(w, &tb);
+  }
+  return e;
 }
 
 // Per-stream decode parameters held in registers.
@@ -385,23 +401,24 @@ __device__ __forceinline__ DecodeParams lj_params(const LjStreamDev& S) {
   return d;
 }
 
-// One symbol at bit position `pos` of slot `col`; false on an invalid code.
+// One predicated decode step of slot `col`: live lanes advance by one symbol.
+// Returns the entry (0 = invalid code) -- callers stop the lane on 0.
 template <bool MULTI>
-__device__ __forceinline__ bool lj_step(const Lds& L, const DecodeParams& dp, int col,
-                                        uint32_t& pos, uint32_t& phase) {
+__device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp,
+                                            int col, uint32_t pos, uint32_t phase,
+                                            bool live, uint32_t* w_out = nullptr) {
   const uint32_t w = lj_peek32(L.B, col, pos);
+  if (w_out)
+    *w_out = w;
   const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
-  const Sym s = lj_symbol(w, tb);
-  pos += s.total;
-  if (MULTI)
-    phase = (phase + 1 == dp.period) ? 0u : phase + 1;
-  return s.ok;
+  return lj_entry(w, tb, live);
 }
 
 // Decode the symbols that START inside slot `col` (bit positions [.., end_bits)),
 // beginning at state `start`.  With RECORD, *bm receives the bitmap of symbol
 // starts at bit positions < 64 (the slot's "trajectory", used for early-out
-// re-synchronisation).
+// re-synchronisation).  All lanes of the wave run the same loop; a lane that is
+// done simply stops advancing (no divergent branches in the hot loop).
 // With one shared table the component phase does not influence the parse, so it
 // is left out of the state (it would never self-synchronise); with several
 // tables it is part of what has to match.
@@ -409,32 +426,53 @@ template <bool MULTI, bool RECORD>
 __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams& dp,
                                                int col, uint32_t start,
                                                uint32_t end_bits, uint32_t& exit,
-                                               uint32_t& count, uint64_t* bm) {
-  if (RECORD)
-    *bm = 0;
-  if (start & ST_ERR) {
-    exit = ST_ERR;
-    count = 0;
-    return;
-  }
+                                               uint32_t& count, uint64_t* bm,
+                                               bool enabled = true) {
   uint32_t pos = start & ST_OFF_MASK;
   uint32_t phase = (start >> ST_PHASE_SHIFT) & 7u;
   uint32_t n = 0;
-  bool ok = true;
+  bool ok = !(start & ST_ERR);
+  if (!ok || !enabled)
+    end_bits = 0; // lane takes no steps
+  uint64_t m = 0;
   if (RECORD) {
-    uint64_t m = 0;
     const uint32_t lim = end_bits < 64u ? end_bits : 64u;
-    while (pos < lim && ok) {
-      m |= 1ull << pos;
-      ok = lj_step<MULTI>(L, dp, col, pos, phase);
-      n += ok ? 1u : 0u;
+    while (__any(pos < lim)) {
+      const bool live = pos < lim;
+      const uint32_t e = lj_step<MULTI>(L, dp, col, pos, phase, live);
+      if (live) {
+        m |= 1ull << pos;
+        if (e == 0u) {
+          ok = false;
+          end_bits = 0;
+        } else {
+          pos += e >> 10;
+          ++n;
+          if (MULTI)
+            phase = (phase + 1 == dp.period) ? 0u : phase + 1;
+        }
+      }
+      if (!ok)
+        break;
     }
     *bm = m;
   }
-  while (pos < end_bits && ok) {
-    ok = lj_step<MULTI>(L, dp, col, pos, phase);
-    n += ok ? 1u : 0u;
+  while (__any(pos < end_bits)) {
+    const bool live = pos < end_bits;
+    const uint32_t e = lj_step<MULTI>(L, dp, col, pos, phase, live);
+    const bool bad = live && e == 0u;
+    const uint32_t adv = live ? (e >> 10) : 0u;
+    pos += adv;
+    n += (live && !bad) ? 1u : 0u;
+    if (MULTI)
+      phase = (live && !bad) ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
+    if (bad) {
+      ok = false;
+      end_bits = 0;
+    }
   }
+  if (!enabled)
+    return;
   exit = ok ? ((pos - end_bits) | (MULTI ? (phase << ST_PHASE_SHIFT) : 0u)) : ST_ERR;
   count = n;
 }
@@ -448,30 +486,58 @@ __device__ __forceinline__ void lj_redecode_sync(const Lds& L, const DecodeParam
                                                  uint32_t end_bits, uint64_t old_bm,
                                                  uint32_t old_exit, uint32_t old_cn,
                                                  uint32_t& exit, uint32_t& count,
-                                                 uint64_t& bm) {
-  uint32_t pos = start & ST_OFF_MASK, phase = 0, n = 0;
+                                                 uint64_t& bm, bool enabled) {
+  uint32_t pos = start & ST_OFF_MASK, n = 0;
   uint64_t m = 0;
-  bool ok = true;
-  const uint32_t lim = end_bits < 64u ? end_bits : 64u;
-  while (pos < lim && ok) {
-    if ((old_bm >> pos) & 1ull) {
-      const uint64_t below = old_bm & ((1ull << pos) - 1ull);
-      count = n + old_cn - uint32_t(__builtin_popcountll(below));
-      exit = old_exit;
-      bm = m | (old_bm & ~((1ull << pos) - 1ull));
-      return;
+  bool ok = true, synced = false;
+  if (!enabled)
+    end_bits = 0;
+  const uint32_t real_end = end_bits;
+  uint32_t lim = end_bits < 64u ? end_bits : 64u;
+  while (__any(pos < lim)) {
+    bool live = pos < lim;
+    if (live && ((old_bm >> pos) & 1ull)) {
+      synced = true;
+      lim = 0;
+      end_bits = 0;
+      live = false;
     }
-    m |= 1ull << pos;
-    ok = lj_step<false>(L, dp, col, pos, phase);
-    n += ok ? 1u : 0u;
+    const uint32_t e = lj_step<false>(L, dp, col, pos, 0u, live);
+    if (live) {
+      m |= 1ull << pos;
+      if (e == 0u) {
+        ok = false;
+        lim = 0;
+        end_bits = 0;
+      } else {
+        pos += e >> 10;
+        ++n;
+      }
+    }
   }
-  while (pos < end_bits && ok) {
-    ok = lj_step<false>(L, dp, col, pos, phase);
-    n += ok ? 1u : 0u;
+  while (__any(pos < end_bits)) {
+    const bool live = pos < end_bits;
+    const uint32_t e = lj_step<false>(L, dp, col, pos, 0u, live);
+    const bool bad = live && e == 0u;
+    pos += live ? (e >> 10) : 0u;
+    n += (live && !bad) ? 1u : 0u;
+    if (bad) {
+      ok = false;
+      end_bits = 0;
+    }
   }
-  exit = ok ? (pos - end_bits) : ST_ERR;
-  count = n;
-  bm = m;
+  if (!enabled)
+    return;
+  if (synced) {
+    const uint64_t below = old_bm & ((1ull << pos) - 1ull);
+    count = n + old_cn - uint32_t(__builtin_popcountll(below));
+    exit = old_exit;
+    bm = m | (old_bm & ~((1ull << pos) - 1ull));
+  } else {
+    exit = ok ? (pos - real_end) : ST_ERR;
+    count = n;
+    bm = m;
+  }
 }
 
 // Start-state guess for slot j: decode the last LJ_WARM bits of slot j-1 from an
@@ -481,12 +547,13 @@ __device__ __forceinline__ void lj_redecode_sync(const Lds& L, const DecodeParam
 template <bool MULTI>
 __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& dp,
                                               int j) {
-  const uint32_t prev_bits = L.ob[j - 1];
-  if (prev_bits == 0)
-    return 0u;
+  // j == 0 has no predecessor slot in LDS: it takes no steps (`enabled` false)
+  const bool enabled = j >= 1;
+  const uint32_t prev_bits = enabled ? L.ob[j - 1] : 0u;
   const uint32_t from = prev_bits > LJ_WARM ? prev_bits - LJ_WARM : 0u;
-  uint32_t e, c;
-  lj_decode_span<MULTI, false>(L, dp, j - 1, from, prev_bits, e, c, nullptr);
+  uint32_t e = 0, c = 0;
+  lj_decode_span<MULTI, false>(L, dp, enabled ? j - 1 : 0, from, prev_bits, e, c, nullptr,
+                               enabled && prev_bits != 0);
   return (e & ST_ERR) ? 0u : e;
 }
 
@@ -514,6 +581,8 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       return; // chain already consistent here
   }
 
+  if (STITCH && j == 0)
+    atomicAdd(&a.results[s].stat_stitch, 1u);
   lj_stage_tables(L, a, S);
   int marker_off;
   uint32_t own_drops;
@@ -532,12 +601,18 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   if (!STITCH) {
     uint32_t start = 0, e = 0, c = 0;
     uint64_t bm = 0;
-    if (lb == 0 && j == 0) {
-      // slot 0 lies before the stream: its "exit" is the known start state
-    } else {
-      if (j >= 2 || (j == 1 && lb > 0))
-        start = lj_warmup<MULTI>(L, dp, j);
-      lj_decode_span<MULTI, !MULTI>(L, dp, j, start, own_bits, e, c, &bm);
+    // slot 0 of the first workgroup lies before the stream: its "exit" is the
+    // known start state; every other slot decodes from its warm-up guess
+    // (slot 0 of later workgroups from bit 0)
+    const bool real_slot = !(lb == 0 && j == 0);
+    const uint32_t guess = lj_warmup<MULTI>(L, dp, j);
+    if (j >= 2 || (j == 1 && lb > 0))
+      start = guess;
+    lj_decode_span<MULTI, !MULTI>(L, dp, j, start, own_bits, e, c, &bm, real_slot);
+    if (!real_slot) {
+      e = 0;
+      c = 0;
+      bm = 0;
     }
     L.su[j] = start;
     L.st[j] = e;
@@ -581,17 +656,29 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     const uint32_t n = L.misc[8];
     if (n == 0)
       break;
+    if (j == 0) {
+      atomicAdd(&a.results[s].stat_rounds, 1u);
+      atomicAdd(&a.results[s].stat_redo, n);
+    }
     uint32_t idx = 0, w = 0, e = 0, c = 0;
     uint64_t bm = 0;
-    if (uint32_t(j) < n) {
-      idx = L.list[j];
+    // only the waves that hold list entries do anything (wave-uniform test)
+    if (uint32_t(j & ~63) < n) {
+      const bool mine = uint32_t(j) < n;
+      idx = mine ? L.list[j] : 1u;
       w = (STITCH && idx == 1) ? true_start : L.st[idx - 1];
-      if (MULTI || (w & ST_ERR)) {
-        lj_decode_span<MULTI, false>(L, dp, int(idx), w, L.ob[idx], e, c, nullptr);
+      if (MULTI) {
+        lj_decode_span<MULTI, false>(L, dp, int(idx), w, L.ob[idx], e, c, nullptr, mine);
       } else {
         const uint64_t old_bm = uint64_t(L.bm[2 * idx]) | (uint64_t(L.bm[2 * idx + 1]) << 32);
+        const bool err = (w & ST_ERR) != 0;
         lj_redecode_sync(L, dp, int(idx), w, L.ob[idx], old_bm, L.st[idx], L.cn[idx], e,
-                         c, bm);
+                         c, bm, mine && !err);
+        if (err) {
+          e = ST_ERR;
+          c = 0;
+          bm = 0;
+        }
       }
     }
     __syncthreads(); // every read of st[] precedes the updates
@@ -777,62 +864,83 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   // Every lane streams its own symbols to the stream-ordered scratch: 8
   // differences are packed in registers and leave as one 16-byte store (the
   // lane's output range starts on an arbitrary 2-byte boundary; gfx950 global
-  // stores take unaligned addresses).  No LDS staging, no barriers.
+  // stores take unaligned addresses).  No LDS staging, no barriers.  The loop
+  // is wave-uniform: every lane runs max-over-the-wave groups, lanes that are
+  // past their last symbol stop advancing and their stores are masked.
   uint32_t remaining = (my_start & ST_ERR) ? 0u : my_count;
   if (first >= needed)
     remaining = 0;
   else if (first + remaining > needed)
     remaining = uint32_t(needed - first);
   int16_t* __restrict__ out = a.diffs + S.diff_offset + first;
-  // local index of the last symbol the reference decodes (for K7), if it is ours
-  const uint32_t last_local =
-      (needed >= 1 && needed - 1 >= first && needed - 1 < first + remaining)
-          ? uint32_t(needed - 1 - first)
-          : 0xFFFFFFFFu;
+
+  uint32_t wmax = remaining;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    wmax = max(wmax, uint32_t(__shfl_xor(wmax, o, 64)));
+  const uint32_t n_groups = (wmax + 7) >> 3;
 
   uint32_t pos = my_start & ST_OFF_MASK;
   uint32_t phase = (my_start >> ST_PHASE_SHIFT) & 7u;
-  uint32_t last_pos = 0;
-  auto next_diff = [&](uint32_t local) -> uint32_t {
-    const uint32_t w = lj_peek32(L.B, j, pos);
-    const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
-    const Sym sy = lj_symbol(w, tb);
-    int diff;
-    if (sy.ssss == 0u) {
-      diff = 0;
-    } else if (sy.ssss == 16u) {
-      diff = -32768;
-    } else {
-      const uint32_t v = (w << sy.code_len) >> (32 - sy.ssss);
-      diff = (v >> (sy.ssss - 1)) ? int(v) : int(v) - int((1u << sy.ssss) - 1u);
-    }
-    if (local == last_local)
-      last_pos = pos;
-    pos += sy.total;
-    if (MULTI)
-      phase = (phase + 1 == dp.period) ? 0u : phase + 1;
-    return uint32_t(diff) & 0xFFFFu;
-  };
-
-  const uint32_t groups = remaining >> 3;
-  uint32_t local = 0;
-  for (uint32_t g = 0; g < groups; ++g) {
+  uint32_t tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0; // the lane's last, partial group
+  for (uint32_t g = 0; g < n_groups; ++g) {
     uint32_t p[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t lo = next_diff(local);
-      const uint32_t hi = next_diff(local + 1);
-      local += 2;
-      p[q] = lo | (hi << 16);
+    for (int q = 0; q < 8; ++q) {
+      const bool live = 8 * g + q < remaining;
+      uint32_t w;
+      const uint32_t e = lj_step<MULTI>(L, dp, j, pos, phase, live, &w);
+      const uint32_t cl = e & 31u, ssss = (e >> 5) & 31u;
+      // v = the SSSS bits after the code; diff per JPEG F.2.2.1 "EXTEND"
+      const uint32_t v = uint32_t((uint64_t(w << cl) << ssss) >> 32);
+      const uint32_t half = (1u << ssss) >> 1;
+      uint32_t diff = v >= half ? v : v + 1u - (1u << ssss);
+      diff = ssss == 0u ? 0u : diff;
+      diff = ssss == 16u ? 0x8000u : diff;
+      diff &= 0xFFFFu;
+      pos += live ? (e >> 10) : 0u;
+      if (MULTI)
+        phase = live ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
+      if (q & 1)
+        p[q >> 1] |= diff << 16;
+      else
+        p[q >> 1] = diff;
     }
-    const uint4 v = make_uint4(p[0], p[1], p[2], p[3]);
-    __builtin_memcpy(out + 8 * g, &v, 16);
+    if (8 * g + 8 <= remaining) {
+      const uint4 v = make_uint4(p[0], p[1], p[2], p[3]);
+      __builtin_memcpy(out + 8 * g, &v, 16);
+    } else if (8 * g < remaining) {
+      tp0 = p[0];
+      tp1 = p[1];
+      tp2 = p[2];
+      tp3 = p[3];
+    }
   }
-  for (; local < remaining; ++local)
-    out[local] = int16_t(next_diff(local));
-  if (last_local != 0xFFFFFFFFu) {
+  // partial last group: 2-byte stores
+  {
+    const uint32_t full = remaining & ~7u, tail = remaining & 7u;
+    for (uint32_t t = 0; t < tail; ++t) {
+      const uint32_t word = (t >> 1) == 0 ? tp0 : ((t >> 1) == 1 ? tp1 : ((t >> 1) == 2 ? tp2 : tp3));
+      out[full + t] = int16_t((t & 1) ? (word >> 16) : (word & 0xFFFFu));
+    }
+  }
+  // K7 needs the bit position at which the reference's last symbol starts:
+  // exactly one lane of the whole stream owns it and walks there again
+  if (needed >= 1 && needed - 1 >= first && needed - 1 < first + remaining) {
+    const uint32_t target = uint32_t(needed - 1 - first);
+    uint32_t p2 = my_start & ST_OFF_MASK, ph2 = (my_start >> ST_PHASE_SHIFT) & 7u;
+    for (uint32_t t = 0; t < target; ++t) {
+      const uint32_t w = lj_peek32(L.B, j, p2);
+      const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * ph2)) & 0xFFu : 0u];
+      uint32_t e = tb.lut[w >> (32 - LUT_BITS)];
+      if ((e & 31u) == 0u)
+        e = lj_slow_entry(w, &tb);
+      p2 += e >> 10;
+      if (MULTI)
+        ph2 = (ph2 + 1 == dp.period) ? 0u : ph2 + 1;
+    }
     a.results[s].last_slot = lb * LJ_OWN + uint32_t(j - 1);
-    a.results[s].last_pos = last_pos;
+    a.results[s].last_pos = p2;
   }
 }
 
@@ -1800,11 +1908,13 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
       const LjResult& R = p->h_results[k];
       fprintf(stderr,
               "[rsx]  stream %zu: marker %u status %u flags %u avail %u needed %llu "
-              "last_slot %u last_pos %u consumed %u tail %u blocks %u in_bytes %llu\n",
+              "last_slot %u last_pos %u consumed %u tail %u blocks %u in_bytes %llu "
+              "redo_rounds %u redo_slots %u stitched %u\n",
               k, R.marker_pos, R.status, R.flags, R.avail_lo,
               (unsigned long long)p->streams[k].needed, R.last_slot, R.last_pos,
               R.consumed, R.tail_used, p->streams[k].n_blocks,
-              (unsigned long long)p->streams[k].in_bytes);
+              (unsigned long long)p->streams[k].in_bytes, R.stat_rounds, R.stat_redo,
+              R.stat_stitch);
     }
   }
   for (int i = 0; i < p->n_jobs; ++i) {
