@@ -155,6 +155,7 @@ struct LjArgs {
   uint16_t* vseed;
   uint32_t n_streams;
   uint32_t total_rows;
+  uint32_t ablate; // profiling aid (RSX_ABLATE): 1 = no K4 stores, 2 = no K4 decode loop, 4 = no K1 decode
 };
 
 // ---------------------------------------------------------------------------
@@ -608,7 +609,8 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     const uint32_t guess = lj_warmup<MULTI>(L, dp, j);
     if (j >= 2 || (j == 1 && lb > 0))
       start = guess;
-    lj_decode_span<MULTI, !MULTI>(L, dp, j, start, own_bits, e, c, &bm, real_slot);
+    lj_decode_span<MULTI, !MULTI>(L, dp, j, start, own_bits, e, c, &bm,
+                                  real_slot && !(a.ablate & 4u));
     if (!real_slot) {
       e = 0;
       c = 0;
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1)
     wmax = max(wmax, uint32_t(__shfl_xor(wmax, o, 64)));
-  const uint32_t n_groups = (wmax + 7) >> 3;
+  const uint32_t n_groups = (a.ablate & 2u) ? 0u : (wmax + 7) >> 3;
 
   uint32_t pos = my_start & ST_OFF_MASK;
   uint32_t phase = (my_start >> ST_PHASE_SHIFT) & 7u;
@@ -906,7 +908,9 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
       else
         p[q >> 1] = diff;
     }
-    if (8 * g + 8 <= remaining) {
+    if (a.ablate & 1u) {
+      asm volatile("" ::"v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]));
+    } else if (8 * g + 8 <= remaining) {
       const uint4 v = make_uint4(p[0], p[1], p[2], p[3]);
       __builtin_memcpy(out + 8 * g, &v, 16);
     } else if (8 * g < remaining) {
@@ -1476,6 +1480,7 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.vseed = static_cast<uint16_t*>(p->d_vseed.ptr);
   a.n_streams = uint32_t(p->streams.size());
   a.total_rows = p->total_rows;
+  a.ablate = getenv("RSX_ABLATE") ? uint32_t(atoi(getenv("RSX_ABLATE"))) : 0u;
   return a;
 }
 

@@ -1,0 +1,17 @@
+"""GPU experiment: ablations of the LJPEG kernels (RSX_ABLATE) -- timing only,
+results are wrong by construction when a phase is skipped."""
+import os, sys, time, subprocess, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for ab in (0, 1, 2, 4, 6):
+    env = dict(os.environ, RSX_ABLATE=str(ab))
+    cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", "/tmp/abl%d" % ab,
+           "-o", "x", "--", sys.executable, os.path.join(ROOT, "scripts", "exp_lj_run.py")]
+    subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd="/tmp")
+    import csv
+    rows = list(csv.DictReader(open("/tmp/abl%d/x_kernel_stats.csv" % ab)))
+    out = {}
+    for r in rows:
+        for k in ("lj_sync_kernel<false", "lj_decode_kernel", "lj_predict"):
+            if k in r["Name"]:
+                out[k] = round(float(r["AverageNs"]) / 1e3, 1)
+    print("ablate", ab, out, flush=True)

@@ -1,0 +1,30 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import bench_ljpeg as B
+from rawspeed_amd import abi, capi
+ctx = capi.Context(0)
+W, H = 6720, 4480
+cache = "/tmp/cfg3_frame.npz"
+if os.path.exists(cache):
+    z = np.load(cache); data = z["data"]; scan_len = int(z["scan_len"])
+    d = abi.Cr2Desc.from_buffer_copy(z["desc"].tobytes())
+else:
+    d, data, src, scan_len, bits = B.make_cr2_frame(W, H, (3, 2240, 2240), seed=1)
+    np.savez(cache, data=data, scan_len=scan_len, desc=np.frombuffer(bytes(d), dtype=np.uint8))
+frames = 4
+jobs, off = [], 0
+for f in range(frames):
+    j = abi.Cr2Job(); j.desc = d
+    j.in_offset, j.in_bytes = off, data.size
+    j.img_offset = f * B.out_pitch(W) * H
+    j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = B.out_pitch(W), W, H, 1, 1
+    jobs.append(j); off += data.size
+inp = torch.from_numpy(np.tile(data, frames)).cuda()
+out = torch.zeros(frames * B.out_pitch(W) * H, dtype=torch.uint8, device="cuda")
+plan = ctx.cr2_plan(jobs)
+s = torch.cuda.current_stream().cuda_stream
+for _ in range(4):
+    plan.run(inp.data_ptr(), out.data_ptr(), s)
+torch.cuda.synchronize()
