@@ -150,6 +150,7 @@ struct LjArgs {
   uint32_t* block_base;
   uint32_t* block_drops;     // stuffing bytes dropped inside each workgroup's region
   uint32_t* block_drop_base; // exclusive prefix of block_drops within the stream
+  uint4* unstuffed;          // per workgroup: its LDS image of un-stuffed slots (LJ_BW*LJ_T dwords)
   LjResult* results;
   int16_t* diffs;
   uint16_t* vseed;
@@ -228,7 +229,7 @@ __device__ __forceinline__ void lj_stage_tables(const Lds& L, const LjArgs& a,
 // an FF, or that start on a stuffing byte, get here).  FF00 -> FF; FFxx (xx != 0)
 // or the end of the buffer end the data, everything after reads as zero
 // (BitStreamerJPEG.h:106-183).  Reads run ahead of writes, so in place is safe.
-__device__ __noinline__ void lj_fix_slot(uint32_t* B, int j, uint32_t prev, int valid,
+__device__ __forceinline__ void lj_fix_slot(uint32_t* B, int j, uint32_t prev, int valid,
                                          uint32_t& own_bits, int& marker_off,
                                          uint32_t& own_drops) {
   uint64_t acc = 0;  // high `nacc` bits valid
@@ -240,6 +241,7 @@ __device__ __noinline__ void lj_fix_slot(uint32_t* B, int j, uint32_t prev, int 
   own_bits = 0;
   marker_off = -1;
   own_drops = 0;
+#pragma unroll 1
   for (int k = 0; k < LJ_BW && !ended; ++k) {
     if (k == LJ_PW && !own_done) {
       own_bits = kept * 8;
@@ -257,6 +259,7 @@ __device__ __noinline__ void lj_fix_slot(uint32_t* B, int j, uint32_t prev, int 
       kept += 4;
       continue;
     }
+#pragma unroll 1
     for (int b = 0; b < 4; ++b) {
       if (4 * k + b >= valid) { // end of the buffer
         ended = true;
@@ -316,8 +319,9 @@ __device__ __forceinline__ uint32_t lj_load_slot(const Lds& L, const LjArgs& a,
   uint4 v[5];
 #pragma unroll
   for (int m = 0; m < 5; ++m)
-    v[m] = lj_load_chunk(in, start + 16 * m, in_bytes, aligned16);
-  const uint32_t prev =
+    v[m] = (a.ablate & 16u) ? make_uint4(j, m, 3, 4)
+                            : lj_load_chunk(in, start + 16 * m, in_bytes, aligned16);
+  const uint32_t prev = (a.ablate & 32u) ? 0u :
       (start >= 1 && start - 1 < in_bytes) ? uint32_t(in[start - 1]) : 0u;
   uint32_t any = 0;
 #pragma unroll
@@ -335,7 +339,7 @@ __device__ __forceinline__ uint32_t lj_load_slot(const Lds& L, const LjArgs& a,
   uint32_t own_bits = 8u * uint32_t(valid > LJ_P ? LJ_P : valid);
   marker_off = -1;
   own_drops = 0;
-  if (any != 0u || prev == 0xFFu)
+  if ((any != 0u || prev == 0xFFu) && !(a.ablate & 8u))
     lj_fix_slot(L.B, j, prev, valid, own_bits, marker_off, own_drops);
   return own_bits;
 }
@@ -597,6 +601,15 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   }
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1); // j >= 1
   __syncthreads(); // tables, B and ob complete
+  if (!STITCH) {
+    // keep the un-stuffed image for the final decode (K4): un-stuffing is the
+    // expensive part of staging and is done exactly once per subsequence
+    uint4* __restrict__ dst = a.unstuffed + size_t(b) * (LJ_BW * LJ_T / 4);
+    const uint4* src = reinterpret_cast<const uint4*>(L.B);
+#pragma unroll
+    for (int m = 0; m < LJ_BW * LJ_T / 4 / LJ_T; ++m)
+      dst[m * LJ_T + j] = src[m * LJ_T + j];
+  }
 
   // initial decode / initial records
   if (!STITCH) {
@@ -828,9 +841,18 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
     return; // past the end of data
 
   lj_stage_tables(L, a, S);
-  int marker_off;
-  uint32_t own_drops;
-  (void)lj_load_slot(L, a, S, lb, j, marker_off, own_drops);
+  {
+    // the workgroup's un-stuffed slots, exactly as K1 had them in LDS
+    const uint4* __restrict__ src = a.unstuffed + size_t(b) * (LJ_BW * LJ_T / 4);
+    uint4* dst = reinterpret_cast<uint4*>(L.B);
+    uint4 t[LJ_BW * LJ_T / 4 / LJ_T];
+#pragma unroll
+    for (int m = 0; m < LJ_BW * LJ_T / 4 / LJ_T; ++m)
+      t[m] = src[m * LJ_T + j];
+#pragma unroll
+    for (int m = 0; m < LJ_BW * LJ_T / 4 / LJ_T; ++m)
+      dst[m * LJ_T + j] = t[m];
+  }
   const DecodeParams dp = lj_params(S);
 
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1);
@@ -1433,7 +1455,7 @@ struct LJpegPlan {
   bool comp_present[5] = {false, false, false, false, false};
   DeviceBuffer d_streams, d_tables, d_block_stream, d_strips, d_sub_state,
       d_block_start, d_block_exit, d_block_sum, d_block_base, d_block_drops,
-      d_block_drop_base, d_results, d_diffs, d_vseed;
+      d_block_drop_base, d_results, d_diffs, d_vseed, d_unstuffed;
   std::vector<LjResult> h_results;
   int stitch_rounds = 2;
   const void* last_in = nullptr;
@@ -1475,6 +1497,7 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.block_base = static_cast<uint32_t*>(p->d_block_base.ptr);
   a.block_drops = static_cast<uint32_t*>(p->d_block_drops.ptr);
   a.block_drop_base = static_cast<uint32_t*>(p->d_block_drop_base.ptr);
+  a.unstuffed = static_cast<uint4*>(p->d_unstuffed.ptr);
   a.results = static_cast<LjResult*>(p->d_results.ptr);
   a.diffs = static_cast<int16_t*>(p->d_diffs.ptr);
   a.vseed = static_cast<uint16_t*>(p->d_vseed.ptr);
@@ -1647,6 +1670,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         (st = p->d_block_base.ensure(size_t(p->total_blocks) * 4)) ||
         (st = p->d_block_drops.ensure(size_t(p->total_blocks) * 4)) ||
         (st = p->d_block_drop_base.ensure(size_t(p->total_blocks) * 4)) ||
+        (st = p->d_unstuffed.ensure(size_t(p->total_blocks) * LJ_BW * LJ_T * 4)) ||
         (st = p->d_results.ensure(p->streams.size() * sizeof(LjResult))) ||
         (st = p->d_diffs.ensure(size_t(p->total_diffs) * 2 + 64)) ||
         (st = p->d_vseed.ensure(size_t(p->total_rows) * 8 + 16)))
@@ -1967,7 +1991,7 @@ void ljpeg_plan_destroy(LJpegPlan* p) {
        {&p->d_streams, &p->d_tables, &p->d_block_stream, &p->d_strips,
         &p->d_sub_state, &p->d_block_start, &p->d_block_exit, &p->d_block_sum,
         &p->d_block_base, &p->d_block_drops, &p->d_block_drop_base, &p->d_results,
-        &p->d_diffs, &p->d_vseed})
+        &p->d_diffs, &p->d_vseed, &p->d_unstuffed})
     b->release();
   delete p;
 }

@@ -2,7 +2,7 @@
 results are wrong by construction when a phase is skipped."""
 import os, sys, time, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for ab in (0, 1, 2, 4, 6):
+for ab in [int(x) for x in (sys.argv[1:] or ['0','2','10','18','34','26','58'])]:
     env = dict(os.environ, RSX_ABLATE=str(ab))
     cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", "/tmp/abl%d" % ab,
            "-o", "x", "--", sys.executable, os.path.join(ROOT, "scripts", "exp_lj_run.py")]
