@@ -225,40 +225,47 @@ __device__ __forceinline__ void lj_stage_tables(const Lds& L, const LjArgs& a,
     dst[i] = src[i];
 }
 
-// In-place un-stuffing of slot j's column of B (only lanes whose 80 bytes hold
-// an FF, or that start on a stuffing byte, get here).  FF00 -> FF; FFxx (xx != 0)
-// or the end of the buffer end the data, everything after reads as zero
-// (BitStreamerJPEG.h:106-183).  Reads run ahead of writes, so in place is safe.
-__device__ __forceinline__ void lj_fix_slot(uint32_t* B, int j, uint32_t prev, int valid,
-                                         uint32_t& own_bits, int& marker_off,
-                                         uint32_t& own_drops) {
+// Un-stuff one slot held in registers (20 big-endian dwords = its 64 bytes + 16
+// bytes of lookahead) into column `col` of B.  FF00 -> FF; FFxx (xx != 0) or the
+// end of the buffer end the data, everything after reads as zero
+// (BitStreamerJPEG.h:106-183).  `valid` = bytes of the slot that lie inside the
+// buffer.  The dword loop is unrolled (static register indexing), the byte loop
+// for a dword that holds an FF is not.
+__device__ __forceinline__ void lj_fix_regs(const uint32_t (&in)[LJ_BW + 1], uint32_t* B,
+                                            int col, uint32_t prev, int valid,
+                                            uint32_t& own_bits, int& marker_off,
+                                            uint32_t& own_drops) {
   uint64_t acc = 0;  // high `nacc` bits valid
   uint32_t nacc = 0; // 0, 8, 16 or 24
   uint32_t ko = 0;   // output dwords written
   uint32_t kept = 0; // kept bytes so far
   bool own_done = false, ended = false;
-  bool drop_next = (prev == 0xFFu) && ((B[j] >> 24) == 0u);
+  bool drop_next = (prev == 0xFFu) && ((in[0] >> 24) == 0u);
   own_bits = 0;
   marker_off = -1;
   own_drops = 0;
-#pragma unroll 1
-  for (int k = 0; k < LJ_BW && !ended; ++k) {
+#pragma unroll
+  for (int k = 0; k < LJ_BW; ++k) {
     if (k == LJ_PW && !own_done) {
       own_bits = kept * 8;
       own_done = true;
     }
-    if (4 * k >= valid)
-      break; // end of the buffer
-    const uint32_t cur = B[k * LJ_T + j];
-    const uint32_t nxt = k + 1 < LJ_BW ? B[(k + 1) * LJ_T + j] : 0u;
+    if (ended)
+      continue;
+    if (4 * k >= valid) { // end of the buffer
+      ended = true;
+      continue;
+    }
+    const uint32_t cur = in[k];
     if (!drop_next && !has_ff(cur) && 4 * k + 4 <= valid) {
       acc |= uint64_t(cur) << (32 - nacc);
-      B[ko * LJ_T + j] = uint32_t(acc >> 32);
+      B[ko * LJ_T + col] = uint32_t(acc >> 32);
       ++ko;
       acc <<= 32;
       kept += 4;
       continue;
     }
+    const uint32_t nxt = in[k + 1];
 #pragma unroll 1
     for (int b = 0; b < 4; ++b) {
       if (4 * k + b >= valid) { // end of the buffer
@@ -287,7 +294,7 @@ __device__ __forceinline__ void lj_fix_slot(uint32_t* B, int j, uint32_t prev, i
       nacc += 8;
       ++kept;
       if (nacc == 32) {
-        B[ko * LJ_T + j] = uint32_t(acc >> 32);
+        B[ko * LJ_T + col] = uint32_t(acc >> 32);
         ++ko;
         acc = 0;
         nacc = 0;
@@ -297,21 +304,32 @@ __device__ __forceinline__ void lj_fix_slot(uint32_t* B, int j, uint32_t prev, i
   if (!own_done)
     own_bits = kept * 8;
   if (ko < LJ_BW) {
-    B[ko * LJ_T + j] = uint32_t(acc >> 32);
+    B[ko * LJ_T + col] = uint32_t(acc >> 32);
     ++ko;
   }
+#pragma unroll 1
   for (; ko < LJ_BW; ++ko)
-    B[ko * LJ_T + j] = 0u;
+    B[ko * LJ_T + col] = 0u;
 }
 
-// Load slot j (its 64 bytes + 16 bytes of lookahead) straight from global
-// memory into registers, park it big-endian in column j of B, and un-stuff the
-// column in place when it needs it.  Slot j of workgroup lb holds stream bytes
-// [lb*LJ_R + (j-1)*LJ_P, +LJ_P).  Returns the slot's own data bits.
-__device__ __forceinline__ uint32_t lj_load_slot(const Lds& L, const LjArgs& a,
-                                                 const LjStreamDev& S, uint32_t lb,
-                                                 int j, int& marker_off,
-                                                 uint32_t& own_drops) {
+__device__ __forceinline__ int lj_valid_bytes(const LjStreamDev& S, uint32_t lb, int j) {
+  const int64_t vb = int64_t(S.in_bytes) - (int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P);
+  return vb < 0 ? 0 : (vb > 4 * LJ_BW ? 4 * LJ_BW : int(vb));
+}
+
+// Stage the workgroup's 256 slots: every lane loads its slot (64 bytes + 16
+// bytes of lookahead) straight from global memory and parks it big-endian in
+// column j of B.  Slots that hold an FF anywhere (~27 % of them) need
+// un-stuffing; they are collected in a dense list and fixed by the first lanes
+// of the workgroup, so the rare byte-level work runs at full lane utilisation
+// instead of dragging every wavefront through it.  Slot j of workgroup lb holds
+// stream bytes [lb*LJ_R + (j-1)*LJ_P, +LJ_P).
+// Outputs (LDS): B, ob[] (own data bits per slot), misc[9] (stuffing bytes
+// dropped in owned slots); the end marker goes to results[s].marker_pos.
+// Ends with a workgroup barrier.
+__device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
+                                               const LjStreamDev& S, uint32_t s,
+                                               uint32_t lb, int j, bool report_marker) {
   const uint8_t* __restrict__ in = a.in_base + S.in_offset;
   const bool aligned16 = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
   const int64_t in_bytes = int64_t(S.in_bytes);
@@ -319,10 +337,13 @@ __device__ __forceinline__ uint32_t lj_load_slot(const Lds& L, const LjArgs& a,
   uint4 v[5];
 #pragma unroll
   for (int m = 0; m < 5; ++m)
-    v[m] = (a.ablate & 16u) ? make_uint4(j, m, 3, 4)
-                            : lj_load_chunk(in, start + 16 * m, in_bytes, aligned16);
-  const uint32_t prev = (a.ablate & 32u) ? 0u :
+    v[m] = lj_load_chunk(in, start + 16 * m, in_bytes, aligned16);
+  const uint32_t prev =
       (start >= 1 && start - 1 < in_bytes) ? uint32_t(in[start - 1]) : 0u;
+  if (j == 0) {
+    L.misc[9] = 0;  // dropped stuffing bytes
+    L.misc[10] = 0; // fix-list length
+  }
   uint32_t any = 0;
 #pragma unroll
   for (int m = 0; m < 5; ++m) {
@@ -334,14 +355,40 @@ __device__ __forceinline__ uint32_t lj_load_slot(const Lds& L, const LjArgs& a,
       L.B[(4 * m + q) * LJ_T + j] = d[q];
     }
   }
-  const int64_t vb = in_bytes - start;
-  const int valid = vb < 0 ? 0 : (vb > 4 * LJ_BW ? 4 * LJ_BW : int(vb));
-  uint32_t own_bits = 8u * uint32_t(valid > LJ_P ? LJ_P : valid);
-  marker_off = -1;
-  own_drops = 0;
+  const int valid = lj_valid_bytes(S, lb, j);
+  L.ob[j] = 8u * uint32_t(valid > LJ_P ? LJ_P : valid);
+  L.su[j] = prev; // su[] doubles as the "byte before the slot" array during staging
+  __syncthreads();
   if ((any != 0u || prev == 0xFFu) && !(a.ablate & 8u))
-    lj_fix_slot(L.B, j, prev, valid, own_bits, marker_off, own_drops);
-  return own_bits;
+    L.list[atomicAdd(&L.misc[10], 1u)] = uint32_t(j);
+  __syncthreads();
+  const uint32_t n = L.misc[10];
+  if (uint32_t(j & ~63) < n) { // wave-uniform
+    const bool mine = uint32_t(j) < n;
+    const int idx = mine ? int(L.list[j]) : 0;
+    uint32_t r[LJ_BW + 1];
+#pragma unroll
+    for (int k = 0; k < LJ_BW; ++k)
+      r[k] = L.B[k * LJ_T + idx];
+    r[LJ_BW] = 0;
+    if (mine) {
+      uint32_t own_bits, drops;
+      int marker_off;
+      lj_fix_regs(r, L.B, idx, L.su[idx], lj_valid_bytes(S, lb, idx), own_bits,
+                  marker_off, drops);
+      L.ob[idx] = own_bits;
+      if (idx >= 1) {
+        if (drops)
+          atomicAdd(&L.misc[9], drops);
+        if (report_marker && marker_off >= 0) {
+          const int64_t p = int64_t(lb) * LJ_R + int64_t(idx - 1) * LJ_P + marker_off;
+          if (p >= 0)
+            atomicMin(&a.results[s].marker_pos, uint32_t(p));
+        }
+      }
+    }
+  }
+  __syncthreads();
 }
 
 __device__ __forceinline__ uint32_t lj_peek32(const uint32_t* B, int col,
@@ -589,18 +636,11 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   if (STITCH && j == 0)
     atomicAdd(&a.results[s].stat_stitch, 1u);
   lj_stage_tables(L, a, S);
-  int marker_off;
-  uint32_t own_drops;
-  const uint32_t own_bits = lj_load_slot(L, a, S, lb, j, marker_off, own_drops);
-  L.ob[j] = own_bits;
+  lj_stage_slots(L, a, S, s, lb, j, !STITCH); // ends with a barrier
+  const uint32_t own_bits = L.ob[j];
+  const uint32_t block_drops = L.misc[9];
   const DecodeParams dp = lj_params(S);
-  if (!STITCH && marker_off >= 0 && j >= 1) {
-    const int64_t p = int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P + marker_off;
-    if (p >= 0)
-      atomicMin(&a.results[s].marker_pos, uint32_t(p));
-  }
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1); // j >= 1
-  __syncthreads(); // tables, B and ob complete
   if (!STITCH) {
     // keep the un-stuffed image for the final decode (K4): un-stuffing is the
     // expensive part of staging and is done exactly once per subsequence
@@ -715,21 +755,16 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     a.block_exit[b] = L.st[j];
   // block totals: symbols, dropped stuffing bytes
   uint32_t v = j >= 1 ? my_count : 0u;
-  uint32_t dr = j >= 1 ? own_drops : 0u;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
+  for (int o = 32; o > 0; o >>= 1)
     v += __shfl_down(v, o, 64);
-    dr += __shfl_down(dr, o, 64);
-  }
-  if ((j & 63) == 0) {
+  if ((j & 63) == 0)
     L.misc[j >> 6] = v;
-    L.misc[4 + (j >> 6)] = dr;
-  }
   __syncthreads();
   if (j == 0) {
     a.block_sum[b] = L.misc[0] + L.misc[1] + L.misc[2] + L.misc[3];
     if (!STITCH)
-      a.block_drops[b] = L.misc[4] + L.misc[5] + L.misc[6] + L.misc[7];
+      a.block_drops[b] = block_drops;
   }
 }
 
