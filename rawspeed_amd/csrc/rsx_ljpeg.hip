@@ -57,6 +57,7 @@ constexpr int LJ_PW = LJ_P / 4;       // dwords per subsequence
 constexpr int LJ_OWN = LJ_T - 1;      // owned slots (slot 0 = warm-up)
 constexpr int LJ_R = LJ_OWN * LJ_P;   // bytes of stream owned by one workgroup
 constexpr int LJ_BW = LJ_PW + 4;      // compacted slot capacity (dwords)
+constexpr int LJ_IMG_U4 = (LJ_BW + 1) * LJ_T / 4; // per-workgroup un-stuffed image: B + ob[], in uint4
 constexpr uint32_t LJ_WARM = 128;     // warm-up bits decoded ahead of a slot for its start guess
 
 constexpr uint32_t ST_OFF_MASK = 63u;
@@ -610,6 +611,50 @@ __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& 
 }
 
 // ---------------------------------------------------------------------------
+// K0: un-stuffing.  Every workgroup stages its 256 slots (lj_stage_slots) and
+// writes the un-stuffed LDS image -- B plus the per-slot data-bit counts -- to
+// global memory once; the synchronisation, stitch and decode kernels start from
+// that image with plain 16-byte coalesced loads.  Keeping the byte-level work in
+// its own light kernel (23 KB LDS, high occupancy) hides its latency.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t b = blockIdx.x;
+  const uint32_t s = a.block_stream[b];
+  const LjStreamDev& S = a.streams[s];
+  const Lds L = carve(smem, 0);
+  const uint32_t lb = b - S.first_block;
+  const int j = threadIdx.x;
+  lj_stage_slots(L, a, S, s, lb, j, true); // ends with a barrier
+  uint4* __restrict__ dst = a.unstuffed + size_t(b) * LJ_IMG_U4;
+  const uint4* src = reinterpret_cast<const uint4*>(L.B);
+#pragma unroll
+  for (int m = 0; m < LJ_BW / 4; ++m)
+    dst[m * LJ_T + j] = src[m * LJ_T + j];
+  reinterpret_cast<uint32_t*>(dst + (LJ_BW / 4) * LJ_T)[j] = L.ob[j];
+  if (j == 0)
+    a.block_drops[b] = L.misc[9];
+}
+
+// Load the workgroup's un-stuffed image (K0's output) into LDS: B and ob[].
+// Ends with a workgroup barrier.
+__device__ __forceinline__ void lj_load_image(const Lds& L, const LjArgs& a, uint32_t b,
+                                              int j) {
+  const uint4* __restrict__ src = a.unstuffed + size_t(b) * LJ_IMG_U4;
+  uint4* dst = reinterpret_cast<uint4*>(L.B);
+  uint4 t[LJ_BW / 4];
+#pragma unroll
+  for (int m = 0; m < LJ_BW / 4; ++m)
+    t[m] = src[m * LJ_T + j];
+  const uint32_t ob = reinterpret_cast<const uint32_t*>(src + (LJ_BW / 4) * LJ_T)[j];
+#pragma unroll
+  for (int m = 0; m < LJ_BW / 4; ++m)
+    dst[m * LJ_T + j] = t[m];
+  L.ob[j] = ob;
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
 // K1 / K2: synchronisation
 // ---------------------------------------------------------------------------
 template <bool STITCH, bool MULTI>
@@ -636,20 +681,10 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   if (STITCH && j == 0)
     atomicAdd(&a.results[s].stat_stitch, 1u);
   lj_stage_tables(L, a, S);
-  lj_stage_slots(L, a, S, s, lb, j, !STITCH); // ends with a barrier
+  lj_load_image(L, a, b, j); // ends with a barrier
   const uint32_t own_bits = L.ob[j];
-  const uint32_t block_drops = L.misc[9];
   const DecodeParams dp = lj_params(S);
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1); // j >= 1
-  if (!STITCH) {
-    // keep the un-stuffed image for the final decode (K4): un-stuffing is the
-    // expensive part of staging and is done exactly once per subsequence
-    uint4* __restrict__ dst = a.unstuffed + size_t(b) * (LJ_BW * LJ_T / 4);
-    const uint4* src = reinterpret_cast<const uint4*>(L.B);
-#pragma unroll
-    for (int m = 0; m < LJ_BW * LJ_T / 4 / LJ_T; ++m)
-      dst[m * LJ_T + j] = src[m * LJ_T + j];
-  }
 
   // initial decode / initial records
   if (!STITCH) {
@@ -761,11 +796,8 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   if ((j & 63) == 0)
     L.misc[j >> 6] = v;
   __syncthreads();
-  if (j == 0) {
+  if (j == 0)
     a.block_sum[b] = L.misc[0] + L.misc[1] + L.misc[2] + L.misc[3];
-    if (!STITCH)
-      a.block_drops[b] = block_drops;
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -876,18 +908,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
     return; // past the end of data
 
   lj_stage_tables(L, a, S);
-  {
-    // the workgroup's un-stuffed slots, exactly as K1 had them in LDS
-    const uint4* __restrict__ src = a.unstuffed + size_t(b) * (LJ_BW * LJ_T / 4);
-    uint4* dst = reinterpret_cast<uint4*>(L.B);
-    uint4 t[LJ_BW * LJ_T / 4 / LJ_T];
-#pragma unroll
-    for (int m = 0; m < LJ_BW * LJ_T / 4 / LJ_T; ++m)
-      t[m] = src[m * LJ_T + j];
-#pragma unroll
-    for (int m = 0; m < LJ_BW * LJ_T / 4 / LJ_T; ++m)
-      dst[m * LJ_T + j] = t[m];
-  }
+  lj_load_image(L, a, b, j); // ends with a barrier
   const DecodeParams dp = lj_params(S);
 
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1);
@@ -1705,7 +1726,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         (st = p->d_block_base.ensure(size_t(p->total_blocks) * 4)) ||
         (st = p->d_block_drops.ensure(size_t(p->total_blocks) * 4)) ||
         (st = p->d_block_drop_base.ensure(size_t(p->total_blocks) * 4)) ||
-        (st = p->d_unstuffed.ensure(size_t(p->total_blocks) * LJ_BW * LJ_T * 4)) ||
+        (st = p->d_unstuffed.ensure(size_t(p->total_blocks) * LJ_IMG_U4 * 16)) ||
         (st = p->d_results.ensure(p->streams.size() * sizeof(LjResult))) ||
         (st = p->d_diffs.ensure(size_t(p->total_diffs) * 2 + 64)) ||
         (st = p->d_vseed.ensure(size_t(p->total_rows) * 8 + 16)))
@@ -1860,6 +1881,8 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
                                     p->h_results.size() * sizeof(LjResult),
                                     hipMemcpyHostToDevice, s));
   const uint32_t n_streams = uint32_t(p->streams.size());
+  hipLaunchKernelGGL(lj_unstuff_kernel, dim3(p->total_blocks), dim3(LJ_T),
+                     lj_lds_bytes(0), s, a);
   launch_sync<false>(p, a, s);
   for (int r = 0; r < p->stitch_rounds; ++r)
     launch_sync<true>(p, a, s);

@@ -11,7 +11,7 @@ for ab in [int(x) for x in (sys.argv[1:] or ['0','2','10','18','34','26','58'])]
     rows = list(csv.DictReader(open("/tmp/abl%d/x_kernel_stats.csv" % ab)))
     out = {}
     for r in rows:
-        for k in ("lj_sync_kernel<false", "lj_decode_kernel", "lj_predict"):
+        for k in ("lj_unstuff", "lj_sync_kernel<false", "lj_decode_kernel", "lj_predict"):
             if k in r["Name"]:
                 out[k] = round(float(r["AverageNs"]) / 1e3, 1)
     print("ablate", ab, out, flush=True)
