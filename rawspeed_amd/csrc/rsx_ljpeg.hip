@@ -226,20 +226,41 @@ __device__ __forceinline__ void lj_stage_tables(const Lds& L, const LjArgs& a,
     dst[i] = src[i];
 }
 
-// Un-stuff one slot held in registers (20 big-endian dwords = its 64 bytes + 16
-// bytes of lookahead) into column `col` of B.  FF00 -> FF; FFxx (xx != 0) or the
-// end of the buffer end the data, everything after reads as zero
-// (BitStreamerJPEG.h:106-183).  `valid` = bytes of the slot that lie inside the
-// buffer.  The dword loop is unrolled (static register indexing), the byte loop
-// for a dword that holds an FF is not.
-__device__ __forceinline__ void lj_fix_regs(const uint32_t (&in)[LJ_BW + 1], uint32_t* B,
-                                            int col, uint32_t prev, int valid,
-                                            uint32_t& own_bits, int& marker_off,
-                                            uint32_t& own_drops) {
+// Un-stuffing state of one slot: kept bytes are shifted into `acc` and leave as
+// whole big-endian dwords into column `col` of B.
+struct Unstuff {
   uint64_t acc = 0;  // high `nacc` bits valid
   uint32_t nacc = 0; // 0, 8, 16 or 24
   uint32_t ko = 0;   // output dwords written
   uint32_t kept = 0; // kept bytes so far
+};
+
+// append the top n bytes (n = 0..4) of v
+__device__ __forceinline__ void us_append(Unstuff& u, uint32_t* B, int col, uint32_t v,
+                                          uint32_t n) {
+  const uint32_t keep = n ? (0xFFFFFFFFu << (32u - 8u * n)) : 0u;
+  u.acc |= uint64_t(v & keep) << (32 - u.nacc);
+  u.nacc += 8 * n;
+  u.kept += n;
+  if (u.nacc >= 32) {
+    B[u.ko * LJ_T + col] = uint32_t(u.acc >> 32);
+    ++u.ko;
+    u.acc <<= 32;
+    u.nacc -= 32;
+  }
+}
+
+// Un-stuff one slot held in registers (20 big-endian dwords = its 64 bytes + 16
+// bytes of lookahead) into column `col` of B.  FF00 -> FF; FFxx (xx != 0) or the
+// end of the buffer end the data, everything after reads as zero
+// (BitStreamerJPEG.h:106-183).  `valid` = bytes of the slot that lie inside the
+// buffer.  Dwords without an FF are appended whole; a dword with FF bytes is
+// walked FF by FF (not byte by byte).
+__device__ __forceinline__ void lj_fix_regs(const uint32_t (&in)[LJ_BW + 1], uint32_t* B,
+                                            int col, uint32_t prev, int valid,
+                                            uint32_t& own_bits, int& marker_off,
+                                            uint32_t& own_drops) {
+  Unstuff u;
   bool own_done = false, ended = false;
   bool drop_next = (prev == 0xFFu) && ((in[0] >> 24) == 0u);
   own_bits = 0;
@@ -248,69 +269,83 @@ __device__ __forceinline__ void lj_fix_regs(const uint32_t (&in)[LJ_BW + 1], uin
 #pragma unroll
   for (int k = 0; k < LJ_BW; ++k) {
     if (k == LJ_PW && !own_done) {
-      own_bits = kept * 8;
+      own_bits = u.kept * 8;
       own_done = true;
     }
     if (ended)
       continue;
-    if (4 * k >= valid) { // end of the buffer
+    // bytes of this dword that lie inside the buffer
+    const int vb = valid - 4 * k;
+    if (vb <= 0) {
       ended = true;
       continue;
     }
     const uint32_t cur = in[k];
-    if (!drop_next && !has_ff(cur) && 4 * k + 4 <= valid) {
-      acc |= uint64_t(cur) << (32 - nacc);
-      B[ko * LJ_T + col] = uint32_t(acc >> 32);
-      ++ko;
-      acc <<= 32;
-      kept += 4;
+    if (!drop_next && !has_ff(cur) && vb >= 4) {
+      us_append(u, B, col, cur, 4);
       continue;
     }
-    const uint32_t nxt = in[k + 1];
+    uint32_t rem = cur;              // unread bytes, top-aligned
+    uint32_t nb = vb >= 4 ? 4u : uint32_t(vb); // how many
+    uint32_t at = 0;                 // byte index of rem's top byte inside the dword
+    if (drop_next) {
+      drop_next = false;
+      rem <<= 8;
+      --nb;
+      ++at;
+      if (k < LJ_PW)
+        ++own_drops;
+    }
 #pragma unroll 1
-    for (int b = 0; b < 4; ++b) {
-      if (4 * k + b >= valid) { // end of the buffer
+    while (nb > 0) {
+      // exact per-byte FF flags (bit 24/16/8/0 for byte 0/1/2/3), top nb bytes only
+      uint32_t x = rem & (rem >> 4);
+      x &= x >> 2;
+      x &= x >> 1;
+      x &= 0x01010101u & (0xFFFFFFFFu << (32u - 8u * nb));
+      if (x == 0u) {
+        us_append(u, B, col, rem, nb);
+        break;
+      }
+      const uint32_t p = uint32_t(__builtin_clz(x)) >> 3; // first FF byte of rem
+      const bool in_dword = p + 1 < nb;
+      // byte after the FF: inside this dword, or the first byte of the next one
+      // (past the end of the buffer / of the lookahead it reads as 00)
+      uint32_t next = in_dword ? ((rem >> (16u - 8u * p)) & 0xFFu)
+                               : ((vb >= 4 && k + 1 < LJ_BW) ? (in[k + 1] >> 24) : 0u);
+      if (!in_dword && vb >= 4 && 4 * (k + 1) >= valid)
+        next = 0u;
+      if (next != 0u) { // end-of-stream marker: keep what precedes the FF
+        us_append(u, B, col, rem, p);
+        if (k < LJ_PW)
+          marker_off = 4 * k + int(at + p);
         ended = true;
         break;
       }
-      const uint32_t byte = (cur >> (24 - 8 * b)) & 0xFFu;
-      if (drop_next) {
-        drop_next = false;
+      us_append(u, B, col, rem, p + 1); // ... FF
+      if (in_dword) {                   // skip its stuffing byte
         if (k < LJ_PW)
           ++own_drops;
-        continue;
-      }
-      if (byte == 0xFFu) {
-        const uint32_t next = (b < 3) ? ((cur >> (16 - 8 * b)) & 0xFFu) : (nxt >> 24);
-        const bool last_byte = (k == LJ_BW - 1) && (b == 3);
-        if (next != 0u && !last_byte) {
-          if (k < LJ_PW)
-            marker_off = k * 4 + b; // end-of-stream marker inside the own part
-          ended = true;
-          break;
-        }
-        drop_next = (next == 0u);
-      }
-      acc |= uint64_t(byte) << (56 - nacc);
-      nacc += 8;
-      ++kept;
-      if (nacc == 32) {
-        B[ko * LJ_T + col] = uint32_t(acc >> 32);
-        ++ko;
-        acc = 0;
-        nacc = 0;
+        rem = (p + 2 < 4) ? (rem << (8u * (p + 2))) : 0u;
+        nb -= p + 2;
+        at += p + 2;
+      } else {
+        drop_next = true;
+        nb = 0;
       }
     }
+    if (vb < 4)
+      ended = true; // the buffer ends inside this dword
   }
   if (!own_done)
-    own_bits = kept * 8;
-  if (ko < LJ_BW) {
-    B[ko * LJ_T + col] = uint32_t(acc >> 32);
-    ++ko;
+    own_bits = u.kept * 8;
+  if (u.ko < LJ_BW) {
+    B[u.ko * LJ_T + col] = uint32_t(u.acc >> 32);
+    ++u.ko;
   }
 #pragma unroll 1
-  for (; ko < LJ_BW; ++ko)
-    B[ko * LJ_T + col] = 0u;
+  for (; u.ko < LJ_BW; ++u.ko)
+    B[u.ko * LJ_T + col] = 0u;
 }
 
 __device__ __forceinline__ int lj_valid_bytes(const LjStreamDev& S, uint32_t lb, int j) {
