@@ -489,17 +489,50 @@ __device__ __forceinline__ DecodeParams lj_params(const LjStreamDev& S) {
   return d;
 }
 
-// One predicated decode step of slot `col`: live lanes advance by one symbol.
-// Returns the entry (0 = invalid code) -- callers stop the lane on 0.
+// Register bit reader over column `col` of B.  The next 33..64 stream bits sit
+// MSB-first in `buf`; the following dword is already prefetched in `nextw`, so the
+// only LDS access on a symbol's critical path is the code-table lookup.
+struct BitReader {
+  uint64_t buf;
+  uint32_t nb;    // valid bits in buf (33..64 between symbols)
+  uint32_t wi;    // dword index of nextw
+  uint32_t nextw;
+};
+
+__device__ __forceinline__ BitReader br_open(const uint32_t* B, int col, uint32_t pos) {
+  BitReader r;
+  const uint32_t i = pos >> 5, sh = pos & 31u;
+  const uint32_t d0 = B[i * LJ_T + col], d1 = B[(i + 1) * LJ_T + col];
+  r.buf = ((uint64_t(d0) << 32) | d1) << sh;
+  r.nb = 64u - sh;
+  r.wi = i + 2;
+  r.nextw = B[r.wi * LJ_T + col];
+  return r;
+}
+
+// consume `len` bits (0 for a lane that must not advance) and top the buffer up
+__device__ __forceinline__ void br_advance(BitReader& r, const uint32_t* B, int col,
+                                           uint32_t len) {
+  r.buf <<= len;
+  r.nb -= len;
+  const bool need = r.nb <= 32u;
+  const uint64_t add = uint64_t(r.nextw) << ((32u - r.nb) & 31u);
+  r.buf |= need ? add : 0ull;
+  r.nb += need ? 32u : 0u;
+  r.wi += need ? 1u : 0u;
+  // past the slot's 20 dwords there is nothing to read (a stopped lane may sit
+  // there); clamp instead of branching
+  const uint32_t wi = r.wi < uint32_t(LJ_BW) ? r.wi : uint32_t(LJ_BW - 1);
+  r.nextw = B[wi * LJ_T + col];
+}
+
+// Entry of the symbol at the head of the reader (0 = invalid code).
 template <bool MULTI>
-__device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp,
-                                            int col, uint32_t pos, uint32_t phase,
-                                            bool live, uint32_t* w_out = nullptr) {
-  const uint32_t w = lj_peek32(L.B, col, pos);
-  if (w_out)
-    *w_out = w;
+__device__ __forceinline__ uint32_t lj_head(const Lds& L, const DecodeParams& dp,
+                                            const BitReader& r, uint32_t phase,
+                                            bool live) {
   const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
-  return lj_entry(w, tb, live);
+  return lj_entry(uint32_t(r.buf >> 32), tb, live);
 }
 
 // Decode the symbols that START inside slot `col` (bit positions [.., end_bits)),
@@ -515,41 +548,44 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
                                                int col, uint32_t start,
                                                uint32_t end_bits, uint32_t& exit,
                                                uint32_t& count, uint64_t* bm,
-                                               bool enabled = true) {
-  uint32_t pos = start & ST_OFF_MASK;
+                                               bool enabled = true,
+                                               uint32_t pos_override = 0xFFFFFFFFu) {
+  // pos_override: start at an arbitrary bit position of the slot (warm-up)
+  uint32_t pos = pos_override != 0xFFFFFFFFu ? pos_override : (start & ST_OFF_MASK);
   uint32_t phase = (start >> ST_PHASE_SHIFT) & 7u;
   uint32_t n = 0;
   bool ok = !(start & ST_ERR);
   if (!ok || !enabled)
     end_bits = 0; // lane takes no steps
+  BitReader r = br_open(L.B, col, pos);
   uint64_t m = 0;
   if (RECORD) {
-    const uint32_t lim = end_bits < 64u ? end_bits : 64u;
+    uint32_t lim = end_bits < 64u ? end_bits : 64u;
     while (__any(pos < lim)) {
       const bool live = pos < lim;
-      const uint32_t e = lj_step<MULTI>(L, dp, col, pos, phase, live);
-      if (live) {
-        m |= 1ull << pos;
-        if (e == 0u) {
-          ok = false;
-          end_bits = 0;
-        } else {
-          pos += e >> 10;
-          ++n;
-          if (MULTI)
-            phase = (phase + 1 == dp.period) ? 0u : phase + 1;
-        }
+      const uint32_t e = lj_head<MULTI>(L, dp, r, phase, live);
+      const bool bad = live && e == 0u;
+      const uint32_t adv = (live && !bad) ? (e >> 10) : 0u;
+      m |= live ? (1ull << (pos & 63u)) : 0ull;
+      br_advance(r, L.B, col, adv);
+      pos += adv;
+      n += (live && !bad) ? 1u : 0u;
+      if (MULTI)
+        phase = (live && !bad) ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
+      if (bad) {
+        ok = false;
+        lim = 0;
+        end_bits = 0;
       }
-      if (!ok)
-        break;
     }
     *bm = m;
   }
   while (__any(pos < end_bits)) {
     const bool live = pos < end_bits;
-    const uint32_t e = lj_step<MULTI>(L, dp, col, pos, phase, live);
+    const uint32_t e = lj_head<MULTI>(L, dp, r, phase, live);
     const bool bad = live && e == 0u;
-    const uint32_t adv = live ? (e >> 10) : 0u;
+    const uint32_t adv = (live && !bad) ? (e >> 10) : 0u;
+    br_advance(r, L.B, col, adv);
     pos += adv;
     n += (live && !bad) ? 1u : 0u;
     if (MULTI)
@@ -582,32 +618,35 @@ __device__ __forceinline__ void lj_redecode_sync(const Lds& L, const DecodeParam
     end_bits = 0;
   const uint32_t real_end = end_bits;
   uint32_t lim = end_bits < 64u ? end_bits : 64u;
+  BitReader r = br_open(L.B, col, pos);
   while (__any(pos < lim)) {
     bool live = pos < lim;
-    if (live && ((old_bm >> pos) & 1ull)) {
+    if (live && ((old_bm >> (pos & 63u)) & 1ull)) {
       synced = true;
       lim = 0;
       end_bits = 0;
       live = false;
     }
-    const uint32_t e = lj_step<false>(L, dp, col, pos, 0u, live);
-    if (live) {
-      m |= 1ull << pos;
-      if (e == 0u) {
-        ok = false;
-        lim = 0;
-        end_bits = 0;
-      } else {
-        pos += e >> 10;
-        ++n;
-      }
+    const uint32_t e = lj_head<false>(L, dp, r, 0u, live);
+    const bool bad = live && e == 0u;
+    const uint32_t adv = (live && !bad) ? (e >> 10) : 0u;
+    m |= live ? (1ull << (pos & 63u)) : 0ull;
+    br_advance(r, L.B, col, adv);
+    pos += adv;
+    n += (live && !bad) ? 1u : 0u;
+    if (bad) {
+      ok = false;
+      lim = 0;
+      end_bits = 0;
     }
   }
   while (__any(pos < end_bits)) {
     const bool live = pos < end_bits;
-    const uint32_t e = lj_step<false>(L, dp, col, pos, 0u, live);
+    const uint32_t e = lj_head<false>(L, dp, r, 0u, live);
     const bool bad = live && e == 0u;
-    pos += live ? (e >> 10) : 0u;
+    const uint32_t adv = (live && !bad) ? (e >> 10) : 0u;
+    br_advance(r, L.B, col, adv);
+    pos += adv;
     n += (live && !bad) ? 1u : 0u;
     if (bad) {
       ok = false;
@@ -640,8 +679,8 @@ __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& 
   const uint32_t prev_bits = enabled ? L.ob[j - 1] : 0u;
   const uint32_t from = prev_bits > LJ_WARM ? prev_bits - LJ_WARM : 0u;
   uint32_t e = 0, c = 0;
-  lj_decode_span<MULTI, false>(L, dp, enabled ? j - 1 : 0, from, prev_bits, e, c, nullptr,
-                               enabled && prev_bits != 0);
+  lj_decode_span<MULTI, false>(L, dp, enabled ? j - 1 : 0, 0u, prev_bits, e, c, nullptr,
+                               enabled && prev_bits != 0, from);
   return (e & ST_ERR) ? 0u : e;
 }
 
@@ -677,14 +716,15 @@ __device__ __forceinline__ void lj_load_image(const Lds& L, const LjArgs& a, uin
                                               int j) {
   const uint4* __restrict__ src = a.unstuffed + size_t(b) * LJ_IMG_U4;
   uint4* dst = reinterpret_cast<uint4*>(L.B);
-  uint4 t[LJ_BW / 4];
-#pragma unroll
-  for (int m = 0; m < LJ_BW / 4; ++m)
-    t[m] = src[m * LJ_T + j];
+  const uint4 t0 = src[0 * LJ_T + j], t1 = src[1 * LJ_T + j], t2 = src[2 * LJ_T + j],
+              t3 = src[3 * LJ_T + j], t4 = src[4 * LJ_T + j];
+  static_assert(LJ_BW / 4 == 5, "image loader is written for 5 x 16 bytes per lane");
   const uint32_t ob = reinterpret_cast<const uint32_t*>(src + (LJ_BW / 4) * LJ_T)[j];
-#pragma unroll
-  for (int m = 0; m < LJ_BW / 4; ++m)
-    dst[m * LJ_T + j] = t[m];
+  dst[0 * LJ_T + j] = t0;
+  dst[1 * LJ_T + j] = t1;
+  dst[2 * LJ_T + j] = t2;
+  dst[3 * LJ_T + j] = t3;
+  dst[4 * LJ_T + j] = t4;
   L.ob[j] = ob;
   __syncthreads();
 }
@@ -995,16 +1035,19 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
     wmax = max(wmax, uint32_t(__shfl_xor(wmax, o, 64)));
   const uint32_t n_groups = (a.ablate & 2u) ? 0u : (wmax + 7) >> 3;
 
-  uint32_t pos = my_start & ST_OFF_MASK;
   uint32_t phase = (my_start >> ST_PHASE_SHIFT) & 7u;
+  BitReader r = br_open(L.B, j, my_start & ST_OFF_MASK);
   uint32_t tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0; // the lane's last, partial group
   for (uint32_t g = 0; g < n_groups; ++g) {
     uint32_t p[4];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const bool live = 8 * g + q < remaining;
-      uint32_t w;
-      const uint32_t e = lj_step<MULTI>(L, dp, j, pos, phase, live, &w);
+      const uint32_t w = uint32_t(r.buf >> 32);
+      const uint32_t e = lj_head<MULTI>(L, dp, r, phase, live);
+      br_advance(r, L.B, j, live ? (e >> 10) : 0u);
+      if (MULTI)
+        phase = live ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
       const uint32_t cl = e & 31u, ssss = (e >> 5) & 31u;
       // v = the SSSS bits after the code; diff per JPEG F.2.2.1 "EXTEND"
       const uint32_t v = uint32_t((uint64_t(w << cl) << ssss) >> 32);
@@ -1013,9 +1056,6 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
       diff = ssss == 0u ? 0u : diff;
       diff = ssss == 16u ? 0x8000u : diff;
       diff &= 0xFFFFu;
-      pos += live ? (e >> 10) : 0u;
-      if (MULTI)
-        phase = live ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
       if (q & 1)
         p[q >> 1] |= diff << 16;
       else
@@ -1205,43 +1245,62 @@ __global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
 // K5: predictor seeds of the stream rows
 //   seed(r, c) = init_pred[c] + sum_{r' < r} D[r'][c]   (mod 2^16)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(LJ_T) void lj_vseed_kernel(LjArgs a) {
-  __shared__ uint32_t part[LJ_T][4];
+// 1024 lanes per stream, one row per lane per step (the per-row reads are 8-byte
+// gathers at a pitch of a whole stream row, so they are issued for many rows at
+// once); block-wide exclusive scan per step with shuffles, carry across steps.
+constexpr int VS_T = 1024;
+__global__ __launch_bounds__(VS_T) void lj_vseed_kernel(LjArgs a) {
+  __shared__ uint32_t wtot[VS_T / 64][4];
+  __shared__ uint32_t carry_s[4];
   const uint32_t s = blockIdx.x;
   const LjStreamDev& S = a.streams[s];
   if (a.results[s].status != 0)
     return;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const uint32_t rows = S.rows, N = S.n_comp;
   const int16_t* __restrict__ D = a.diffs + S.diff_offset;
-  const uint32_t per = (rows + LJ_T - 1) / LJ_T;
-  const uint32_t r0 = tid * per, r1 = std::min(rows, r0 + per);
-  uint32_t sum[4] = {0, 0, 0, 0};
-  for (uint32_t r = r0; r < r1; ++r)
-    for (uint32_t c = 0; c < N; ++c)
-      sum[c] += uint32_t(int32_t(D[uint64_t(r) * S.row_samples + c]));
-  for (int c = 0; c < 4; ++c)
-    part[tid][c] = sum[c];
-  __syncthreads();
-  if (tid == 0) { // 256-element serial exclusive scan: negligible
-    uint32_t run[4] = {0, 0, 0, 0};
-    for (int t = 0; t < LJ_T; ++t)
-      for (int c = 0; c < 4; ++c) {
-        const uint32_t v = part[t][c];
-        part[t][c] = run[c];
-        run[c] += v;
-      }
-  }
-  __syncthreads();
-  uint32_t run[4];
-  for (int c = 0; c < 4; ++c)
-    run[c] = part[tid][c] + (c < int(N) ? S.init_pred[c] : 0u);
   uint16_t* __restrict__ V = a.vseed + uint64_t(S.first_row) * 4;
-  for (uint32_t r = r0; r < r1; ++r)
-    for (uint32_t c = 0; c < N; ++c) {
-      V[uint64_t(r) * 4 + c] = uint16_t(run[c]);
-      run[c] += uint32_t(int32_t(D[uint64_t(r) * S.row_samples + c]));
+  if (tid < 4)
+    carry_s[tid] = tid < int(N) ? S.init_pred[tid] : 0u;
+  __syncthreads();
+  for (uint32_t r0 = 0; r0 < rows; r0 += VS_T) {
+    const uint32_t r = r0 + tid;
+    uint32_t d[4] = {0, 0, 0, 0};
+    if (r < rows)
+      for (uint32_t c = 0; c < N; ++c)
+        d[c] = uint32_t(int32_t(D[uint64_t(r) * S.row_samples + c]));
+    uint32_t inc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint32_t x = d[c];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o)
+          x += y;
+      }
+      inc[c] = x;
+      if (lane == 63)
+        wtot[wv][c] = x;
     }
+    __syncthreads();
+    uint32_t base[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint32_t o = carry_s[c];
+      for (int w = 0; w < wv; ++w)
+        o += wtot[w][c];
+      base[c] = o;
+    }
+    if (r < rows)
+      for (uint32_t c = 0; c < N; ++c)
+        V[uint64_t(r) * 4 + c] = uint16_t(base[c] + inc[c] - d[c]); // exclusive
+    __syncthreads();
+    if (tid == VS_T - 1)
+      for (int c = 0; c < 4; ++c)
+        carry_s[c] = base[c] + inc[c];
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1426,13 +1485,20 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
 // the answer is the marker's offset, otherwise the physical offset just past
 // the first 4K data bytes.  One wavefront per stream.
 // ---------------------------------------------------------------------------
-// stuffing bytes (00 preceded by FF) at stream positions [from, to), one wave
+// stuffing bytes (00 preceded by FF) at stream positions [from, to), one wave;
+// each lane scans 16-byte pieces (byte loads of a 17-byte window hit L1/L2)
 __device__ __forceinline__ uint32_t lj_count_drops(const uint8_t* in, uint64_t from,
                                                    uint64_t to, int lane) {
   uint32_t n = 0;
-  for (uint64_t p = from + lane; p < to; p += 64)
-    if (in[p] == 0x00 && p > 0 && in[p - 1] == 0xFF)
-      ++n;
+  for (uint64_t p0 = from + uint64_t(lane) * 16; p0 < to; p0 += 64 * 16) {
+    uint32_t prev = p0 > 0 ? in[p0 - 1] : 0u;
+    const uint64_t end = p0 + 16 < to ? p0 + 16 : to;
+    for (uint64_t p = p0; p < end; ++p) {
+      const uint32_t c = in[p];
+      n += (c == 0u && prev == 0xFFu) ? 1u : 0u;
+      prev = c;
+    }
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1)
     n += __shfl_down(n, o, 64);
@@ -1788,7 +1854,7 @@ int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s, hipEvent_t ev_star
   if (ev_stop)
     RSX_HIP_CHECK(ctx, hipEventRecord(ev_stop, s));
   hipLaunchKernelGGL(lj_tail_kernel, dim3(n_streams), dim3(64), 0, s, a);
-  hipLaunchKernelGGL(lj_vseed_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
+  hipLaunchKernelGGL(lj_vseed_kernel, dim3(n_streams), dim3(VS_T), 0, s, a);
   launch_predict(p, a, s);
   hipLaunchKernelGGL(lj_consumed_kernel, dim3(n_streams), dim3(64), 0, s, a);
   RSX_HIP_CHECK(ctx, hipGetLastError());
