@@ -1478,6 +1478,181 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// K6 fast path (2 or 4 components, the BASELINE shapes).  One wavefront per
+// stream row.  The row is walked in chunks of 2048 samples: coalesced 16-byte
+// loads -> LDS transpose so that every lane owns 32 CONSECUTIVE samples -> the
+// lane scans them with packed 16-bit adds (both components of a pair at once)
+// -> one DPP wave scan of the 64 lane totals (row_shr / row_bcast, no LDS
+// round trips) -> back through LDS to the coalesced layout -> output mapping.
+// ---------------------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_add(uint32_t x, uint32_t y) {
+  const u16x2 r = __builtin_bit_cast(u16x2, x) + __builtin_bit_cast(u16x2, y);
+  return __builtin_bit_cast(uint32_t, r);
+}
+
+// inclusive wave64 scan with packed 16-bit adds (DPP: rows of 16, then row
+// broadcasts -- gfx9 encodings row_shr:n = 0x110+n, row_bcast15 = 0x142,
+// row_bcast31 = 0x143)
+__device__ __forceinline__ uint32_t pk_wave_scan(uint32_t x) {
+  x = pk_add(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x111, 0xF, 0xF, false)));
+  x = pk_add(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x112, 0xF, 0xF, false)));
+  x = pk_add(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x114, 0xF, 0xF, false)));
+  x = pk_add(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x118, 0xF, 0xF, false)));
+  x = pk_add(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x142, 0xA, 0xF, false)));
+  x = pk_add(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x143, 0xC, 0xF, false)));
+  return x;
+}
+
+// store the 8 reconstructed samples that start at sample q of stream row r
+__device__ __forceinline__ void lj_store8(const LjArgs& a, const LjStreamDev& S, uint32_t r,
+                                          uint64_t row0, uint32_t q, uint32_t n,
+                                          const uint4& o) {
+  if (q >= n)
+    return;
+  if (q + 8 <= n) {
+    uint8_t* img = a.out_base + S.img_offset;
+    uint16_t* p = nullptr;
+    if (S.kind == 0 && S.mcu_h == 1) {
+      if (q + 8 <= S.keep_samples)
+        p = reinterpret_cast<uint16_t*>(img + uint64_t(S.out_y + r) * S.img_pitch) +
+            S.out_x + q;
+    } else if (S.kind == 1) {
+      const uint64_t k = row0 + q;
+      const Cr2Strip* st = a.strips + S.strip_base;
+      uint32_t z = 0;
+      while (z + 1 < S.n_strips && k >= st[z + 1].first_sample)
+        ++z;
+      const uint64_t off = k - st[z].first_sample;
+      const uint32_t col = uint32_t(off % st[z].w);
+      if (col + 8 <= st[z].w)
+        p = reinterpret_cast<uint16_t*>(
+                img + uint64_t(st[z].y0 + uint32_t(off / st[z].w)) * S.img_pitch) +
+            st[z].x0 + col;
+    }
+    if (p && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+      *reinterpret_cast<uint4*>(p) = o;
+      return;
+    }
+  }
+  const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (q + i < n)
+      lj_store_sample(a, S, r, q + i, uint16_t(w[i >> 1] >> (16 * (i & 1))));
+}
+
+constexpr int PF_STRIDE = 80;   // LDS bytes per lane (64 + 16 pad against bank conflicts)
+constexpr int PF_CHUNK = 2048;  // samples per wave per step
+
+template <int N>
+__global__ __launch_bounds__(LJ_T) void lj_predict_fast_kernel(LjArgs a) {
+  static_assert(N == 2 || N == 4, "fast path handles 2 or 4 components");
+  __shared__ __attribute__((aligned(16))) uint8_t tr_all[LJ_T / 64][64 * PF_STRIDE];
+  const uint32_t grow = blockIdx.x * (LJ_T / 64) + (threadIdx.x >> 6);
+  if (grow >= a.total_rows)
+    return;
+  const int lane = threadIdx.x & 63;
+  uint8_t* tr = tr_all[threadIdx.x >> 6];
+  uint32_t lo = 0, hi = a.n_streams - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (a.streams[mid].first_row <= grow)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  const LjStreamDev& S = a.streams[lo];
+  if (int(S.n_comp) != N || a.results[lo].status != 0)
+    return;
+  const uint32_t r = grow - S.first_row;
+  if (r >= S.rows)
+    return;
+  const uint64_t row0 = uint64_t(r) * S.row_samples;
+  uint32_t n = S.scan_samples;
+  if (row0 + n > S.needed)
+    n = uint32_t(S.needed - row0);
+  const int16_t* __restrict__ D = a.diffs + S.diff_offset + row0;
+  const bool in_aligned = ((S.diff_offset + row0) & 7) == 0;
+  // running predictor, packed pairs: (c0,c1) [, (c2,c3)]
+  const uint16_t* vs = a.vseed + (uint64_t(S.first_row) + r) * 4;
+  uint32_t carry0 = uint32_t(vs[0]) | (uint32_t(vs[1]) << 16);
+  uint32_t carry1 = N == 4 ? (uint32_t(vs[2]) | (uint32_t(vs[3]) << 16)) : 0u;
+
+  auto load8 = [&](uint32_t q) -> uint4 {
+    if (q + 8 <= n && in_aligned)
+      return *reinterpret_cast<const uint4*>(D + q);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (q + i < n)
+        w[i >> 1] |= uint32_t(uint16_t(D[q + i])) << (16 * (i & 1));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  };
+
+  uint4 nx[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+    nx[m] = load8((m * 64 + lane) * 8);
+  for (uint32_t c0 = 0; c0 < n; c0 += PF_CHUNK) {
+    // coalesced registers -> LDS (lane g/4 owns uint4 g)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int g = m * 64 + lane;
+      *reinterpret_cast<uint4*>(tr + (g >> 2) * PF_STRIDE + (g & 3) * 16) = nx[m];
+    }
+    // prefetch the next chunk while this one is processed
+    if (c0 + PF_CHUNK < n) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+        nx[m] = load8(c0 + PF_CHUNK + (m * 64 + lane) * 8);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t w[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint4 t = *reinterpret_cast<const uint4*>(tr + lane * PF_STRIDE + i * 16);
+      w[4 * i] = t.x;
+      w[4 * i + 1] = t.y;
+      w[4 * i + 2] = t.z;
+      w[4 * i + 3] = t.w;
+    }
+    // lane-local inclusive scan (dword = one (c0,c1) pair; N == 4: pairs alternate)
+#pragma unroll
+    for (int i = N / 2; i < 16; ++i)
+      w[i] = pk_add(w[i], w[i - N / 2]);
+    // wave scan of the lane totals
+    const uint32_t inc0 = pk_wave_scan(w[N == 2 ? 15 : 14]);
+    const uint32_t inc1 = N == 4 ? pk_wave_scan(w[15]) : 0u;
+    // exclusive offset of this lane = inclusive of the lane before + carry
+    uint32_t ex0 = uint32_t(__builtin_amdgcn_update_dpp(0, int(inc0), 0x138 /*wave_shr:1*/, 0xF, 0xF, false));
+    uint32_t ex1 = N == 4 ? uint32_t(__builtin_amdgcn_update_dpp(0, int(inc1), 0x138, 0xF, 0xF, false)) : 0u;
+    ex0 = pk_add(ex0, carry0);
+    ex1 = pk_add(ex1, carry1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      w[i] = pk_add(w[i], (N == 2 || (i & 1) == 0) ? ex0 : ex1);
+    carry0 = pk_add(carry0, uint32_t(__builtin_amdgcn_readlane(int(inc0), 63)));
+    if (N == 4)
+      carry1 = pk_add(carry1, uint32_t(__builtin_amdgcn_readlane(int(inc1), 63)));
+    // back to the coalesced layout
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint4*>(tr + lane * PF_STRIDE + i * 16) =
+          make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int g = m * 64 + lane;
+      const uint4 o = *reinterpret_cast<const uint4*>(tr + (g >> 2) * PF_STRIDE + (g & 3) * 16);
+      lj_store8(a, S, r, row0, c0 + uint32_t(g) * 8, n, o);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K7: decode()/decompress() return value = BitStreamerJPEG::getStreamPosition()
 // after the last decoded symbol: let c be the un-stuffed bit
 // offset at which the last decoded symbol starts; K = ceil(c/32)+1 refills of 4
@@ -1688,11 +1863,11 @@ void launch_predict(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
   if (p->comp_present[1])
     hipLaunchKernelGGL((lj_predict_kernel<1>), grid, block, 0, s, a);
   if (p->comp_present[2])
-    hipLaunchKernelGGL((lj_predict_kernel<2>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((lj_predict_fast_kernel<2>), grid, block, 0, s, a);
   if (p->comp_present[3])
     hipLaunchKernelGGL((lj_predict_kernel<3>), grid, block, 0, s, a);
   if (p->comp_present[4])
-    hipLaunchKernelGGL((lj_predict_kernel<4>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((lj_predict_fast_kernel<4>), grid, block, 0, s, a);
 }
 
 } // namespace
