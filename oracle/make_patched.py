@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE.  Generates the *patched* copies of the three reference
+translation units that INTEGRATION.md describes, so that the drop-in boundary
+can be exercised for real: reference host code (JPEG header parsing, DNG tile
+fan-out, RawImage) -> forwarding hunk -> librsx.so -> MI355X.
+
+Inputs are read from /root/reference; outputs are written ONLY under
+oracle/_ref/patched/ (git-ignored).  Nothing of the reference is stored in the
+repository: this script holds our hunks and the one-line anchors they attach to.
+"""
+import os
+import sys
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+S = os.path.join(REF, "src", "librawspeed")
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "_ref", "patched")
+
+HUNK_UNPACK = r'''
+  // ---- rsx: forward the UINT16 paths to the MI355X core (INTEGRATION.md 1) ----
+  if (mRaw->getDataType() == RawImageType::UINT16) {
+    rsx_unpack_desc d{};
+    d.crop_x = offset.x;
+    d.crop_y = offset.y;
+    d.crop_w = size.x;
+    d.crop_h = size.y;
+    d.input_pitch_bytes = inputPitchBytes;
+    d.bits_per_pixel = bitPerPixel;
+    d.bit_order = static_cast<int32_t>(order);
+    const rsx_image img = rsx_shim::view(mRaw);
+    const Buffer in = input.peekRemainingBuffer();
+    if (int st = rsx_unpack_u16(rsx_shim::context(), &d, in.begin(), in.getSize(), &img))
+      rsx_shim::raise(st);
+    return;
+  }
+'''
+
+HUNK_LJPEG = r'''
+  // ---- rsx: forward to the MI355X core (INTEGRATION.md 2) ----
+  {
+    rsx_ljpeg_desc d{};
+    d.tile_x = imgFrame.pos.x;
+    d.tile_y = imgFrame.pos.y;
+    d.tile_w = imgFrame.dim.x;
+    d.tile_h = imgFrame.dim.y;
+    d.mcu_w = frame.mcu.x;
+    d.mcu_h = frame.mcu.y;
+    d.frame_w = frame.dim.x;
+    d.frame_h = frame.dim.y;
+    d.n_comp = implicit_cast<int32_t>(rec.size());
+    d.rows_per_restart_interval = numLJpegRowsPerRestartInterval;
+    rsx_shim::recipes(rec, &d);
+    const rsx_image img = rsx_shim::view(mRaw);
+    uint32_t consumed = 0;
+    if (int st = rsx_ljpeg_decode(rsx_shim::context(), &d, input.begin(),
+                                  implicit_cast<size_t>(input.size()), &img, &consumed))
+      rsx_shim::raise(st);
+    return consumed;
+  }
+'''
+
+HUNK_CR2 = r'''
+  // ---- rsx: forward <N,1,1> to the MI355X core (INTEGRATION.md 3) ----
+  if (std::get<1>(format) == 1 && std::get<2>(format) == 1) {
+    rsx_cr2_desc d{};
+    d.n_comp = std::get<0>(format);
+    d.x_s_f = 1;
+    d.y_s_f = 1;
+    d.frame_w = frame.x;
+    d.frame_h = frame.y;
+    d.num_slices = slicing.numSlices;
+    d.slice_width = slicing.sliceWidth * d.n_comp;
+    d.last_slice_width = slicing.lastSliceWidth * d.n_comp;
+    rsx_shim::recipes(rec, &d);
+    const rsx_image img = rsx_shim::view(mRaw);
+    uint32_t consumed = 0;
+    if (int st = rsx_cr2_decode(rsx_shim::context(), &d, input.begin(),
+                                implicit_cast<size_t>(input.size()), &img, &consumed))
+      rsx_shim::raise(st);
+    return consumed;
+  }
+'''
+
+PATCHES = [
+    ("decompressors/UncompressedDecompressor.cpp",
+     "void UncompressedDecompressor::readUncompressedRaw() {", HUNK_UNPACK),
+    ("decompressors/LJpegDecompressor.cpp",
+     "ByteStream::size_type LJpegDecompressor::decode() const {", HUNK_LJPEG),
+    ("decompressors/Cr2DecompressorImpl.h",
+     "ByteStream::size_type Cr2Decompressor<PrefixCodeDecoder>::decompress() const {",
+     HUNK_CR2),
+]
+
+
+def main():
+    for rel, anchor, hunk in PATCHES:
+        src = open(os.path.join(S, rel)).read()
+        if src.count(anchor) != 1:
+            raise SystemExit("anchor not found exactly once in %s" % rel)
+        # the shim include goes after the file's last #include
+        last_inc = src.rfind("#include ")
+        eol = src.index("\n", last_inc) + 1
+        src = src[:eol] + '#include "rsx_rawspeed_shim.h" // rsx drop-in\n' + src[eol:]
+        src = src.replace(anchor, anchor + hunk, 1)
+        dst = os.path.join(OUT, rel)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        with open(dst, "w") as f:
+            f.write(src)
+        print("patched", rel)
+
+
+if __name__ == "__main__":
+    main()

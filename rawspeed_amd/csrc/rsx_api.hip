@@ -194,7 +194,7 @@ extern "C" int rsx_unpack_plan_create(rsx_ctx* ctx, int n_jobs,
                                       rsx_plan** out_plan) {
   if (!ctx || !jobs || n_jobs < 1 || !out_plan)
     return RSX_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   auto plan = std::make_unique<rsx_plan>();
   plan->ctx = ctx;
@@ -277,7 +277,7 @@ extern "C" int rsx_plan_run(rsx_plan* plan, const void* in_dev, void* out_dev,
   if (!plan || !in_dev || !out_dev)
     return RSX_ERR_INVALID_ARG;
   rsx_ctx* ctx = plan->ctx;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
   plan->last_stream = s;
@@ -294,7 +294,7 @@ extern "C" int rsx_plan_results(rsx_plan* plan, int32_t* job_status,
   if (!plan)
     return RSX_ERR_INVALID_ARG;
   rsx_ctx* ctx = plan->ctx;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (plan->ran)
     RSX_HIP_CHECK(ctx, hipStreamSynchronize(plan->last_stream));
@@ -321,7 +321,7 @@ extern "C" int rsx_plan_set_timing(rsx_plan* plan, int enable) {
   plan->events_used = 0;
   if (plan->timing && plan->events.size() < 64) {
     // event creation is slow on ROCm: pre-create the pool outside timed regions
-    std::lock_guard<std::mutex> lock(plan->ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(plan->ctx->mu);
     (void)hipSetDevice(plan->ctx->device);
     while (plan->events.size() < 64) {
       EventPair e;
@@ -339,7 +339,7 @@ extern "C" int rsx_plan_kernel_time(rsx_plan* plan, const char** kernel_name,
   if (!plan || !plan->timing || plan->events_used == 0)
     return RSX_ERR_INVALID_ARG;
   rsx_ctx* ctx = plan->ctx;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   double total = 0;
   for (size_t i = 0; i < plan->events_used; ++i) {
@@ -365,7 +365,7 @@ extern "C" void rsx_plan_destroy(rsx_plan* plan) {
     return;
   rsx_ctx* ctx = plan->ctx;
   {
-    std::lock_guard<std::mutex> lock(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     (void)hipSetDevice(ctx->device);
     if (plan->ran)
       (void)hipStreamSynchronize(plan->last_stream);
@@ -522,7 +522,7 @@ extern "C" int rsx_unpack_u16(rsx_ctx* ctx, const rsx_unpack_desc* d,
                               const rsx_image* img) {
   if (!ctx || !d || !in || !img || !img->data)
     return RSX_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return unpack_host(ctx, 1, d, &in, &in_bytes, img, nullptr);
 }
@@ -533,7 +533,7 @@ extern "C" int rsx_dng_decompress_uncompressed(rsx_ctx* ctx, int n_tiles,
                                                int32_t* tile_status) {
   if (!ctx || !tiles || n_tiles < 1 || !img || !img->data)
     return RSX_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   std::vector<rsx_unpack_desc> descs(n_tiles);
   std::vector<const uint8_t*> ins(n_tiles);
@@ -564,7 +564,7 @@ extern "C" int rsx_ljpeg_plan_create(rsx_ctx* ctx, int n_jobs,
                                      rsx_plan** out_plan) {
   if (!ctx || !jobs || n_jobs < 1 || !out_plan)
     return RSX_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   auto plan = std::make_unique<rsx_plan>();
   plan->ctx = ctx;
@@ -593,7 +593,7 @@ extern "C" int rsx_cr2_plan_create(rsx_ctx* ctx, int n_jobs,
                                    const rsx_cr2_job* jobs, rsx_plan** out_plan) {
   if (!ctx || !jobs || n_jobs < 1 || !out_plan)
     return RSX_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   auto plan = std::make_unique<rsx_plan>();
   plan->ctx = ctx;
@@ -621,10 +621,25 @@ extern "C" int rsx_cr2_plan_create(rsx_ctx* ctx, int n_jobs,
 namespace {
 
 // Generic host-pointer runner for LJPEG-family jobs sharing one host image.
+// rectangle of the host image a successful job has written (bytes)
+struct HostRect {
+  size_t row0, rows, byte0, bytes;
+};
+HostRect out_rect(const rsx_ljpeg_job& j) {
+  return {size_t(j.desc.tile_y), size_t(j.desc.tile_h),
+          size_t(j.desc.tile_x) * j.img.cpp * 2, size_t(j.desc.tile_w) * j.img.cpp * 2};
+}
+HostRect out_rect(const rsx_cr2_job& j) {
+  return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
+}
+
 template <typename JobT, typename CreateFn>
 int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
                       const uint8_t* const* ins, const rsx_image* img,
                       CreateFn create, int32_t* statuses, uint32_t* consumed) {
+  // the staging buffers belong to the context: one host-pointer call at a time
+  std::lock_guard<std::recursive_mutex> whole_call(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   // inputs back to back (16-byte aligned) + 64 zero bytes of slack each
   size_t in_total = 0;
   for (int i = 0; i < n; ++i) {
@@ -634,40 +649,45 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
     jobs[i].img_offset = 0;
   }
   const size_t out_bytes = size_t(img->pitch_bytes) * size_t(img->dim_y);
-  {
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if (int e = ctx->d_in.ensure(in_total + 64))
-      return e;
-    if (int e = ctx->d_out.ensure(out_bytes + 64))
-      return e;
-    hipStream_t s = ctx->stream;
-    RSX_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_in.ptr, 0, in_total + 64, s));
-    for (int i = 0; i < n; ++i)
-      RSX_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t*>(ctx->d_in.ptr) +
-                                            jobs[i].in_offset,
-                                        ins[i], jobs[i].in_bytes,
-                                        hipMemcpyHostToDevice, s));
-    // tiles write only their rectangle: bring the current host image over so
-    // untouched pixels survive the round trip
-    RSX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_out.ptr, img->data, out_bytes,
-                                      hipMemcpyHostToDevice, s));
-    RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-  }
+  if (int e = ctx->d_in.ensure(in_total + 64))
+    return e;
+  if (int e = ctx->d_out.ensure(out_bytes + 64))
+    return e;
+  hipStream_t s = ctx->stream;
+  RSX_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_in.ptr, 0, in_total + 64, s));
+  for (int i = 0; i < n; ++i)
+    RSX_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t*>(ctx->d_in.ptr) +
+                                          jobs[i].in_offset,
+                                      ins[i], jobs[i].in_bytes, hipMemcpyHostToDevice, s));
   rsx_plan* plan = nullptr;
   if (int st = create(ctx, n, jobs.data(), &plan))
     return st;
-  int rc = rsx_plan_run(plan, ctx->d_in.ptr, ctx->d_out.ptr, ctx->stream);
+  std::vector<int32_t> st(n, RSX_OK);
+  std::vector<uint32_t> cons(n, 0);
+  int rc = rsx_plan_run(plan, ctx->d_in.ptr, ctx->d_out.ptr, s);
   if (rc == RSX_OK)
-    rc = rsx_plan_results(plan, statuses, consumed);
+    rc = rsx_plan_results(plan, st.data(), cons.data());
   rsx_plan_destroy(plan);
   if (rc == RSX_ERR_DEVICE || rc == RSX_ERR_NOMEM)
     return rc;
-  {
-    std::lock_guard<std::mutex> lock(ctx->mu);
-    RSX_HIP_CHECK(ctx, hipMemcpy(img->data, ctx->d_out.ptr, out_bytes,
-                                 hipMemcpyDeviceToHost));
+  // only the rectangle a successful job decoded goes back to the host image:
+  // pixels outside it (other tiles, padding) are never touched
+  for (int i = 0; i < n; ++i) {
+    if (statuses)
+      statuses[i] = st[i];
+    if (consumed)
+      consumed[i] = cons[i];
+    if (st[i] != RSX_OK)
+      continue;
+    const HostRect r = out_rect(jobs[i]);
+    const size_t off = r.row0 * img->pitch_bytes + r.byte0;
+    RSX_HIP_CHECK(ctx, hipMemcpy2DAsync(static_cast<uint8_t*>(img->data) + off,
+                                        img->pitch_bytes,
+                                        static_cast<uint8_t*>(ctx->d_out.ptr) + off,
+                                        img->pitch_bytes, r.bytes, r.rows,
+                                        hipMemcpyDeviceToHost, s));
   }
+  RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
   return rc;
 }
 

@@ -118,7 +118,9 @@ struct DeviceBuffer {
 struct rsx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  std::mutex mu;
+  // recursive: the host-pointer calls hold it for their whole duration (they
+  // own the context's staging buffers) and call the plan API underneath
+  std::recursive_mutex mu;
   std::string last_error;
   // staging for the host-pointer calls
   rsx::DeviceBuffer d_in, d_out;

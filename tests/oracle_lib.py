@@ -19,6 +19,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "librawspeed_ref.so")
+# the same reference with INTEGRATION.md's forwarding hunks applied, linked to librsx.so
+REF_RSX_SO = os.path.join(ORACLE_DIR, "_ref", "librawspeed_rsx.so")
 
 
 def build_oracle():
@@ -169,11 +171,11 @@ class RefImage:
 
 class Ref:
     @staticmethod
-    def available():
-        return os.path.exists(REF_SO)
+    def available(path=None):
+        return os.path.exists(path or REF_SO)
 
-    def __init__(self):
-        self.lib = C.CDLL(REF_SO)
+    def __init__(self, path=None):
+        self.lib = C.CDLL(path or REF_SO)
         L = self.lib
         L.ref_last_error.restype = C.c_char_p
         L.ref_image_create.restype = C.c_void_p

@@ -1,0 +1,130 @@
+"""The drop-in boundary exercised for real: the reference's own host code
+(LJpegDecoder / Cr2LJpegDecoder header parsing, AbstractDngDecompressor tile
+fan-out with OpenMP, UncompressedDecompressor) built twice from /root/reference --
+unmodified (oracle/_ref/librawspeed_ref.so) and with INTEGRATION.md's three
+forwarding hunks applied and linked against librsx.so
+(oracle/_ref/librawspeed_rsx.so, recipe: oracle/make_patched.py + Makefile).
+The same entry points must give bit-identical RawImages."""
+import numpy as np
+import pytest
+
+from rawspeed_amd import abi, capi, synth
+
+import cases as C
+from oracle_lib import REF_RSX_SO, Ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pair():
+    if not (Ref.available() and Ref.available(REF_RSX_SO)):
+        pytest.skip("oracle/_ref builds absent")
+    capi.lib()  # torch's HIP runtime first (one runtime per process)
+    return Ref(), Ref(REF_RSX_SO)
+
+
+def both(pair, fn, dims):
+    out = []
+    for lib in pair:
+        img = lib.image(*dims)
+        st = fn(lib, img)
+        out.append((st, img.u16().copy(), lib.last_error()))
+    return out
+
+
+def test_ljpeg_container_full_image(pair):
+    rng = np.random.default_rng(31)
+    W, H = 1536, 400
+    src = C.smooth_image(rng, H, W)
+    blob, _, _, _ = synth.ljpeg_container(src, 2, 14, [0, 0], [C.NIKON])
+    (s0, a, e0), (s1, b, e1) = both(
+        pair, lambda lib, img: lib.ljpeg_container(blob, img, 0, 0, W, H, (W, H)), (W, H, 1))
+    assert s0 == 0 and s1 == 0, (e0, e1)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[:, :W], src)
+
+
+def test_ljpeg_container_two_tables_and_dri(pair):
+    rng = np.random.default_rng(32)
+    W, H = 1024, 240
+    src = C.smooth_image(rng, H, W)
+    blob, _, _, _ = synth.ljpeg_container(src, 2, 14, [0, 1], [C.NIKON, C.ALT], rows_per_ri=40)
+    (s0, a, e0), (s1, b, e1) = both(
+        pair, lambda lib, img: lib.ljpeg_container(blob, img, 0, 0, W, H, (W, H)), (W, H, 1))
+    assert s0 == 0 and s1 == 0, (e0, e1)
+    assert np.array_equal(a, b)
+
+
+def test_cr2_container_slices(pair):
+    rng = np.random.default_rng(33)
+    W, H = 2016, 1100   # frame.w*cps = 2016 <= 2*1100: no Canon double-height quirk
+    src = C.smooth_image(rng, H, W)
+    rows = C.cr2_stream_from_image(src, 2, W // 2, H, [672, 672, 672])
+    blob, _, _, _ = synth.ljpeg_container(rows, 2, 14, [0, 0], [C.NIKON])
+    (s0, a, e0), (s1, b, e1) = both(
+        pair, lambda lib, img: lib.cr2_container(blob, img, 3, 672, 672), (W, H, 1))
+    assert s0 == 0 and s1 == 0, (e0, e1)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[:, :W], src)
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_dng_ljpeg_tiles_through_reference_fanout(pair, threads):
+    """AbstractDngDecompressor::decompress(): odd-sized image, 2x3 tiles; with 4
+    OpenMP threads the tile threads enter the C-ABI concurrently."""
+    rng = np.random.default_rng(34)
+    W, H, tw, th = 1021, 700, 512, 256
+    src = C.smooth_image(rng, H, W)
+    blobs = []
+    for ty in range((H + th - 1) // th):
+        for tx in range((W + tw - 1) // tw):
+            tile = np.zeros((th, tw), np.uint16)
+            part = src[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw]
+            tile[:part.shape[0], :part.shape[1]] = part
+            tile[part.shape[0]:, :] = 1000
+            tile[:, part.shape[1]:] = 1000
+            blob, _, _, _ = synth.ljpeg_container(tile, 2, 14, [0, 0], [C.NIKON])
+            blobs.append(blob)
+    (s0, a, e0), (s1, b, e1) = both(
+        pair, lambda lib, img: lib.dng(img, 7, tw, th, blobs, threads=threads), (W, H, 1))
+    assert s0 == 0 and s1 == 0, (e0, e1)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[:, :W], src)
+
+
+def test_dng_uncompressed_tiles_through_reference_fanout(pair):
+    rng = np.random.default_rng(35)
+    W, H, tw, th, bps = 1000, 300, 256, 128, 12
+    blobs = [rng.integers(0, 256, size=th * tw * bps // 8, dtype=np.uint8)
+             for _ in range(((H + th - 1) // th) * ((W + tw - 1) // tw))]
+    (s0, a, e0), (s1, b, e1) = both(
+        pair, lambda lib, img: lib.dng(img, 1, tw, th, blobs, bps=bps, threads=4), (W, H, 1))
+    assert s0 == 0 and s1 == 0, (e0, e1)
+    assert np.array_equal(a, b)
+
+
+def test_unpack_entry_point(pair):
+    rng = np.random.default_rng(36)
+    for order, bps in ((abi.ORDER_LSB, 12), (abi.ORDER_MSB, 14), (abi.ORDER_MSB16, 10),
+                       (abi.ORDER_MSB32, 12), (abi.ORDER_LSB, 16)):
+        W, H = 2048, 64
+        pitch = W * bps // 8 + 4
+        data = rng.integers(0, 256, size=H * pitch, dtype=np.uint8)
+        d = abi.UnpackDesc(0, 0, W, H, pitch, bps, order)
+        (s0, a, _), (s1, b, _) = both(pair, lambda lib, img: lib.unpack(d, data, img), (W, H, 1))
+        assert s0 == 0 and s1 == 0
+        assert np.array_equal(a, b), (order, bps)
+
+
+def test_corrupt_tile_is_reported_by_both(pair):
+    rng = np.random.default_rng(37)
+    W, H = 512, 128
+    src = C.smooth_image(rng, H, W)
+    blob, hdr, scan_len, _ = synth.ljpeg_container(src, 2, 14, [0, 0], [(
+        [0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0], list(range(15)))])
+    bad = blob.copy()
+    bad[hdr + 100:hdr + 140] = 0xFE   # runs of 1-bits: an invalid code in this table
+    res = both(pair, lambda lib, img: lib.ljpeg_container(bad, img, 0, 0, W, H, (W, H)),
+               (W, H, 1))
+    assert res[0][0] != 0 and res[1][0] != 0
