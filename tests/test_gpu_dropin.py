@@ -94,8 +94,22 @@ def test_dng_ljpeg_tiles_through_reference_fanout(pair, threads):
 
 
 def test_dng_uncompressed_tiles_through_reference_fanout(pair):
+    """decompressThread<1>.  Packed (non 8/16/32-bit) tiles write from column 0
+    whatever their x offset (UncompressedDecompressor.cpp:196), so with several
+    tile COLUMNS the reference's own OpenMP threads race on the same pixels; the
+    comparable shapes are one tile column of packed data, and multi-column 16-bit
+    tiles (the copyPixels path honours offset.x)."""
     rng = np.random.default_rng(35)
-    W, H, tw, th, bps = 1000, 300, 256, 128, 12
+    # one column of 12-bit tiles, 3 tile rows, bottom one overhanging
+    W, H, tw, th, bps = 256, 300, 256, 128, 12
+    blobs = [rng.integers(0, 256, size=th * tw * bps // 8, dtype=np.uint8)
+             for _ in range((H + th - 1) // th)]
+    (s0, a, e0), (s1, b, e1) = both(
+        pair, lambda lib, img: lib.dng(img, 1, tw, th, blobs, bps=bps, threads=4), (W, H, 1))
+    assert s0 == 0 and s1 == 0, (e0, e1)
+    assert np.array_equal(a, b)
+    # 4 x 3 tiles of 16-bit little-endian data
+    W, H, tw, th, bps = 1000, 300, 256, 128, 16
     blobs = [rng.integers(0, 256, size=th * tw * bps // 8, dtype=np.uint8)
              for _ in range(((H + th - 1) // th) * ((W + tw - 1) // tw))]
     (s0, a, e0), (s1, b, e1) = both(
@@ -121,10 +135,9 @@ def test_corrupt_tile_is_reported_by_both(pair):
     rng = np.random.default_rng(37)
     W, H = 512, 128
     src = C.smooth_image(rng, H, W)
-    blob, hdr, scan_len, _ = synth.ljpeg_container(src, 2, 14, [0, 0], [(
-        [0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0], list(range(15)))])
+    blob, hdr, scan_len, _ = synth.ljpeg_container(src, 2, 14, [0, 0], [C.NIKON])
     bad = blob.copy()
-    bad[hdr + 100:hdr + 140] = 0xFE   # runs of 1-bits: an invalid code in this table
+    bad[hdr + 100:hdr + 102] = 0xFF   # FF FF: the scan ends here, far too early
     res = both(pair, lambda lib, img: lib.ljpeg_container(bad, img, 0, 0, W, H, (W, H)),
                (W, H, 1))
     assert res[0][0] != 0 and res[1][0] != 0
