@@ -156,6 +156,42 @@ def run_cfg4(ctx, torch, log, steps=10, warmup=2):
     return res
 
 
+def make_cfg5_plan(ctx, torch, frames, distinct=4, seed0=1000):
+    """configs[4]: a batch of independent 8192x5464 LJPEG frames (SOF3: 4096 x 5464,
+    2 components, one scan each), `frames` per GPU; `distinct` different frames are
+    synthesised and repeated.  Returns (plan, inp, out, meta)."""
+    from rawspeed_amd import abi
+    W, H = 8192, 5464
+    blobs, srcs, lens = [], [], []
+    from rawspeed_amd import synth
+    for k in range(distinct):
+        src = synth.sensor_image(W, H, 14, seed=seed0 + k)
+        d, data, scan_len, bits = make_tile(src, 0, 0, W, H)
+        blobs.append((d, data))
+        lens.append(scan_len)
+        if k == 0:
+            srcs.append(src)
+    jobs, off, parts = [], 0, []
+    for f in range(frames):
+        d, data = blobs[f % distinct]
+        j = abi.LJpegJob()
+        j.desc = d
+        j.in_offset, j.in_bytes = off, data.size
+        j.img_offset = f * out_pitch(W) * H
+        j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
+            out_pitch(W), W, H, 1, 1
+        jobs.append(j)
+        parts.append(data)
+        off += data.size
+    inp = torch.from_numpy(np.concatenate(parts)).cuda()
+    out = torch.zeros(frames * out_pitch(W) * H, dtype=torch.uint8, device="cuda")
+    plan = ctx.ljpeg_plan(jobs)
+    meta = dict(W=W, H=H, src0=srcs[0], lens=[lens[f % distinct] for f in range(frames)],
+                alg_bytes=sum(lens[f % distinct] for f in range(frames)) + frames * W * H * 2,
+                bits_per_px=sum(lens) * 8 / (distinct * W * H))
+    return plan, inp, out, meta
+
+
 def cpu_baseline_cr2(d, data, W, H, budget_s=10.0):
     from oracle_lib import Ref
     if not Ref.available():
