@@ -36,7 +36,8 @@ class RsxError(RuntimeError):
 def lib():
     global _lib
     if _lib is None:
-        path = build.LIB_CORE
+        # RSX_LIB: A/B experiments with alternative builds of the same library
+        path = os.environ.get("RSX_LIB") or build.LIB_CORE
         if not os.path.exists(path):
             raise RuntimeError(
                 "rawspeed_amd/librsx.so is not built: run `python -m rawspeed_amd.build` "

@@ -52,13 +52,19 @@ namespace {
 // Geometry constants
 // ---------------------------------------------------------------------------
 constexpr int LJ_T = 256;             // lanes per workgroup = slots per workgroup
-constexpr int LJ_P = 64;              // physical bytes per subsequence
+#ifndef RSX_LJ_P
+#define RSX_LJ_P 64
+#endif
+constexpr int LJ_P = RSX_LJ_P;        // physical bytes per subsequence
 constexpr int LJ_PW = LJ_P / 4;       // dwords per subsequence
 constexpr int LJ_OWN = LJ_T - 1;      // owned slots (slot 0 = warm-up)
 constexpr int LJ_R = LJ_OWN * LJ_P;   // bytes of stream owned by one workgroup
 constexpr int LJ_BW = LJ_PW + 4;      // compacted slot capacity (dwords)
 constexpr int LJ_IMG_U4 = (LJ_BW + 1) * LJ_T / 4; // per-workgroup un-stuffed image: B + ob[], in uint4
-constexpr uint32_t LJ_WARM = 128;     // warm-up bits decoded ahead of a slot for its start guess
+#ifndef RSX_LJ_WARM
+#define RSX_LJ_WARM 512
+#endif
+constexpr uint32_t LJ_WARM = RSX_LJ_WARM;     // warm-up bits decoded ahead of a slot for its start guess
 
 constexpr uint32_t ST_OFF_MASK = 63u;
 constexpr uint32_t ST_PHASE_SHIFT = 6;
@@ -370,9 +376,9 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
   const bool aligned16 = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
   const int64_t in_bytes = int64_t(S.in_bytes);
   const int64_t start = int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P;
-  uint4 v[5];
+  uint4 v[LJ_BW / 4];
 #pragma unroll
-  for (int m = 0; m < 5; ++m)
+  for (int m = 0; m < LJ_BW / 4; ++m)
     v[m] = lj_load_chunk(in, start + 16 * m, in_bytes, aligned16);
   const uint32_t prev =
       (start >= 1 && start - 1 < in_bytes) ? uint32_t(in[start - 1]) : 0u;
@@ -382,7 +388,7 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
   }
   uint32_t any = 0;
 #pragma unroll
-  for (int m = 0; m < 5; ++m) {
+  for (int m = 0; m < LJ_BW / 4; ++m) {
     const uint32_t d[4] = {__builtin_bswap32(v[m].x), __builtin_bswap32(v[m].y),
                            __builtin_bswap32(v[m].z), __builtin_bswap32(v[m].w)};
 #pragma unroll
@@ -716,15 +722,21 @@ __device__ __forceinline__ void lj_load_image(const Lds& L, const LjArgs& a, uin
                                               int j) {
   const uint4* __restrict__ src = a.unstuffed + size_t(b) * LJ_IMG_U4;
   uint4* dst = reinterpret_cast<uint4*>(L.B);
-  const uint4 t0 = src[0 * LJ_T + j], t1 = src[1 * LJ_T + j], t2 = src[2 * LJ_T + j],
-              t3 = src[3 * LJ_T + j], t4 = src[4 * LJ_T + j];
-  static_assert(LJ_BW / 4 == 5, "image loader is written for 5 x 16 bytes per lane");
   const uint32_t ob = reinterpret_cast<const uint32_t*>(src + (LJ_BW / 4) * LJ_T)[j];
-  dst[0 * LJ_T + j] = t0;
-  dst[1 * LJ_T + j] = t1;
-  dst[2 * LJ_T + j] = t2;
-  dst[3 * LJ_T + j] = t3;
-  dst[4 * LJ_T + j] = t4;
+  // (a register array here ends up in scratch; copy in two halves instead)
+#pragma unroll
+  for (int h = 0; h < LJ_BW / 4; h += 3) {
+    uint4 t0 = src[h * LJ_T + j], t1 = t0, t2 = t0;
+    if (h + 1 < LJ_BW / 4)
+      t1 = src[(h + 1) * LJ_T + j];
+    if (h + 2 < LJ_BW / 4)
+      t2 = src[(h + 2) * LJ_T + j];
+    dst[h * LJ_T + j] = t0;
+    if (h + 1 < LJ_BW / 4)
+      dst[(h + 1) * LJ_T + j] = t1;
+    if (h + 2 < LJ_BW / 4)
+      dst[(h + 2) * LJ_T + j] = t2;
+  }
   L.ob[j] = ob;
   __syncthreads();
 }

@@ -14,4 +14,4 @@ for ab in [int(x) for x in (sys.argv[1:] or ['0','2','10','18','34','26','58'])]
         for k in ("lj_unstuff", "lj_sync_kernel<false", "lj_decode_kernel", "lj_predict"):
             if k in r["Name"]:
                 out[k] = round(float(r["AverageNs"]) / 1e3, 1)
-    print("ablate", ab, out, flush=True)
+    print(os.environ.get("RSX_LIB", "default").split("/")[-1], "ablate", ab, out, "total", round(sum(out.values()), 1), flush=True)
