@@ -6,31 +6,36 @@
 // which walk ONE BitStreamerJPEG over the whole scan (no per-row index).
 //
 // Pipeline (one "stream" = one scan or one restart interval; many streams per
-// launch: DNG tiles, batched frames):
+// launch: DNG tiles, batched frames).  The physical byte stream is cut into
+// 64-byte subsequences ("slots"), one lane each, 256 per workgroup; slot 0 of a
+// workgroup is a copy of the previous workgroup's last slot.
 //
-//  K1 lj_sync      self-synchronising speculative Huffman decode.  The physical
-//                  byte stream is cut into 64-byte subsequences, one lane each;
-//                  a workgroup stages 256 of them through LDS (coalesced 16-byte
-//                  loads, dwords transposed so that lane j always hits bank
-//                  j%32), every lane un-stuffs FF00 / detects the FFxx end marker
-//                  for its own subsequence in LDS, decodes it from a guessed
-//                  start, and the workgroup iterates "re-decode from the
-//                  predecessor's exit state" until nothing changes.  Slot 0 of a
-//                  workgroup is a warm-up copy of the previous workgroup's last
-//                  subsequence, so the guess for slot 1 is almost always right.
+//  K0 lj_unstuff   every lane loads its slot (+16 bytes of lookahead) into
+//                  registers and parks it big-endian in its LDS column (dword k of
+//                  slot j at k*256+j: lane j always hits bank j%32).  Slots that
+//                  hold an FF are collected in a dense list and un-stuffed by the
+//                  first lanes (FF00 -> FF, FFxx / end of buffer end the data).
+//                  The LDS image is written to global memory once.
+//  K1 lj_sync      self-synchronising speculative Huffman decode: lane j decodes
+//                  the tail of slot j-1 from an arbitrary bit to find where its own
+//                  slot most likely starts, decodes the slot, and the workgroup
+//                  iterates "re-decode from the predecessor's exit state" on a
+//                  dense list of the few slots that guessed wrong (early-out when
+//                  the new trajectory meets the recorded one).
 //  K2 lj_sync<STITCH>  cross-workgroup fix-up: a workgroup whose assumed start
 //                  differs from its predecessor's recorded exit re-converges.
 //                  (Jacobi iteration: a fixed point is the serial decode.)
 //  K3 lj_scan      per stream: verify the chain, exclusive scan of symbol counts.
-//  K4 lj_decode    final decode from validated start states; int16 differences
-//                  go through an LDS window to a stream-ordered scratch buffer
-//                  with 16-byte coalesced stores.
+//  K4 lj_decode    final decode from validated start states: wave-uniform loop,
+//                  register bit reader with prefetched refill, 8 differences per
+//                  unaligned 16-byte store into a stream-ordered int16 scratch.
+//  K4b lj_tail     exact end-of-stream semantics for damaged streams.
 //  K5 lj_vseed     vertical chain: predictor seed of every stream row (the row's
 //                  first MCU predicts from the first MCU of the previous row,
 //                  LJpegDecompressor.cpp:326-332, Cr2DecompressorImpl.h:437-451).
 //  K6 lj_predict   one wavefront per stream row: per-component inclusive scan
-//                  mod 2^16 (lane-local scan + DPP/shuffle wave scan), then the
-//                  output mapping (tile crop / MCU layout / CR2 vertical strips).
+//                  mod 2^16 (LDS transpose, packed 16-bit adds, DPP wave scan),
+//                  then the output mapping (tile crop / MCU layout / CR2 strips).
 //  K7 lj_consumed  decode()'s return value (SURVEY A.6 closed form).
 //
 // Symbol semantics: codes/AbstractPrefixCodeDecoder.h:43-76; end-of-stream:
