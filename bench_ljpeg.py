@@ -213,8 +213,52 @@ def cpu_baseline_cr2(d, data, W, H, budget_s=10.0):
                       "best of %d" % len(times)}
 
 
+def run_variants(ctx, torch, log, frames=8, steps=50, warmup=20):
+    """The fixed-layout UncompressedDecompressor entry points at the
+    cfg2 sensor size: decode12BitRawWithControl<big>, decode12BitRawUnpacked-
+    LeftAligned<little>, decode8BitRaw<true>; same timing as the headline."""
+    from rawspeed_amd import abi
+    W, H = 8280, 5520
+    out = {}
+    rng = np.random.default_rng(9)
+    for name, variant, big in (("12bit_with_control_be", 1, 1),
+                               ("12bit_left_aligned_le", 2, 0), ("8bit_raw", 0, 0)):
+        bpl = (W, 12 * W // 8 + (W + 2) // 10, 2 * W)[variant]
+        in_stride = (bpl * H + 15) // 16 * 16
+        pitch = out_pitch(W)
+        frame = rng.integers(0, 256, size=in_stride, dtype=np.uint8)
+        inp = torch.from_numpy(np.tile(frame, frames)).cuda()
+        outb = torch.empty(frames * pitch * H, dtype=torch.uint8, device="cuda")
+        jobs = []
+        for f in range(frames):
+            j = abi.UnpackVariantJob()
+            j.desc = abi.UnpackVariantDesc(variant, big, W, H)
+            j.in_offset, j.in_bytes, j.img_offset = f * in_stride, bpl * H, f * pitch * H
+            j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = pitch, W, H, 1, 1
+            jobs.append(j)
+        plan = ctx.unpack_variant_plan(jobs)
+        dt, kt, _ = _time_plan(torch, plan, inp, outb, steps, warmup)
+        plan.close()
+        alg = frames * H * (bpl + 2 * W)
+        r = {"frames": frames, "ms_per_step": round(dt * 1e3, 4),
+             "gpix_per_s": round(frames * W * H / dt / 1e9, 1)}
+        if kt:
+            r["kernel"] = kt[0]
+            r["avg_kernel_ms"] = round(kt[1], 5)
+            r["achieved_gbps"] = round(alg / (kt[1] * 1e-3) / 1e9, 1)
+            r["frac_of_8tbps"] = round(alg / (kt[1] * 1e-3) / 8e12, 4)
+        out[name] = r
+        log("variant %s: %s" % (name, r))
+        del inp, outb
+    return out
+
+
 def run(ctx, torch, log):
     out = {}
+    try:
+        out["uncompressed_variants_8280x5520"] = run_variants(ctx, torch, log)
+    except Exception as e:
+        out["uncompressed_variants_8280x5520"] = {"error": repr(e)}
     r3, ref_args = run_cfg3(ctx, torch, log)
     out["cfg3_cr2_6720x4480"] = r3
     out["cfg4_dng_tiles_8192x5464"] = run_cfg4(ctx, torch, log)
@@ -241,6 +285,9 @@ if __name__ == "__main__":
     if args.only == "cfg3":
         r, _ = run_cfg3(ctx, torch, print, frames=args.frames, steps=args.steps)
         print(json.dumps(r, indent=1))
+    elif args.only == "variants":
+        print(json.dumps(run_variants(ctx, torch, print, frames=args.frames,
+                                      steps=args.steps), indent=1))
     elif args.only == "cfg4":
         print(json.dumps(run_cfg4(ctx, torch, print, steps=args.steps), indent=1))
     else:

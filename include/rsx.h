@@ -129,6 +129,35 @@ int rsx_unpack_u16(rsx_ctx* ctx, const rsx_unpack_desc* d, const uint8_t* in,
                    size_t in_bytes, const rsx_image* img);
 
 /* ------------------------------------------------------------------------ */
+/* 1b. The fixed-layout entry points of the same class                       */
+/*    UncompressedDecompressor::decode8BitRaw<true>()        (.cpp:270-291)  */
+/*    UncompressedDecompressor::decode12BitRawWithControl<e>() (.cpp:296-349)*/
+/*    UncompressedDecompressor::decode12BitRawUnpackedLeftAligned<e>()       */
+/*                                                           (.cpp:356-378)  */
+/*    They use only size = crop.dim of the constructor and write from pixel  */
+/*    (0,0) of the image, ignoring crop.pos -- replicated.  The curve/dither */
+/*    flavour decode8BitRaw<false> (TableLookUp) is post-processing and not  */
+/*    part of this core.                                                     */
+/* ------------------------------------------------------------------------ */
+typedef enum rsx_unpack_variant {
+  RSX_UNPACK_8BIT_RAW = 0,
+  RSX_UNPACK_12BIT_WITH_CONTROL = 1,
+  RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED = 2
+} rsx_unpack_variant;
+
+typedef struct rsx_unpack_variant_desc {
+  int32_t variant;    /* rsx_unpack_variant */
+  int32_t big_endian; /* template parameter Endianness e (ignored for 8-bit) */
+  int32_t w, h;       /* size.x, size.y */
+} rsx_unpack_variant_desc;
+
+int rsx_unpack_variant_validate(const rsx_unpack_variant_desc* d,
+                                const rsx_image* img, size_t in_bytes);
+int rsx_unpack_variant_u16(rsx_ctx* ctx, const rsx_unpack_variant_desc* d,
+                           const uint8_t* in, size_t in_bytes,
+                           const rsx_image* img);
+
+/* ------------------------------------------------------------------------ */
 /* Huffman table exactly as the DHT payload the host already parsed          */
 /* (codes/HuffmanCode.h:99-166): 16 counts + the code values (= SSSS         */
 /* difference categories, each <= 16 in full-decode mode,                    */
@@ -252,6 +281,14 @@ typedef struct rsx_unpack_job {
   rsx_image img; /* .data ignored */
 } rsx_unpack_job;
 
+typedef struct rsx_unpack_variant_job {
+  rsx_unpack_variant_desc desc;
+  uint64_t in_offset;
+  uint64_t in_bytes;
+  uint64_t img_offset;
+  rsx_image img; /* .data ignored */
+} rsx_unpack_variant_job;
+
 typedef struct rsx_ljpeg_job {
   rsx_ljpeg_desc desc;
   uint64_t in_offset;
@@ -270,6 +307,9 @@ typedef struct rsx_cr2_job {
 
 int rsx_unpack_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_unpack_job* jobs,
                            rsx_plan** out_plan);
+int rsx_unpack_variant_plan_create(rsx_ctx* ctx, int n_jobs,
+                                   const rsx_unpack_variant_job* jobs,
+                                   rsx_plan** out_plan);
 int rsx_ljpeg_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_ljpeg_job* jobs,
                           rsx_plan** out_plan);
 int rsx_cr2_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_cr2_job* jobs,

@@ -35,6 +35,30 @@ HUNK_UNPACK = r'''
   }
 '''
 
+HUNK_VARIANT = r'''
+  // ---- rsx: forward to the MI355X core (INTEGRATION.md 1b) ----
+  {
+    rsx_unpack_variant_desc d{};
+    d.variant = %(variant)s;
+    d.big_endian = %(big)s;
+    d.w = size.x;
+    d.h = size.y;
+    const rsx_image img = rsx_shim::view(mRaw);
+    const Buffer in = input.peekRemainingBuffer();
+    if (int st = rsx_unpack_variant_u16(rsx_shim::context(), &d, in.begin(), in.getSize(), &img))
+      rsx_shim::raise(st);
+    input.skipBytes(input.getRemainSize());
+    return;
+  }
+'''
+
+HUNK_8BIT = ("\n  if constexpr (uncorrectedRawValues) {" +
+             HUNK_VARIANT % dict(variant="RSX_UNPACK_8BIT_RAW", big="0") + "  }\n")
+HUNK_CONTROL = HUNK_VARIANT % dict(variant="RSX_UNPACK_12BIT_WITH_CONTROL",
+                                   big="e == Endianness::big")
+HUNK_LEFT = HUNK_VARIANT % dict(variant="RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED",
+                                big="e == Endianness::big")
+
 HUNK_LJPEG = r'''
   // ---- rsx: forward to the MI355X core (INTEGRATION.md 2) ----
   {
@@ -82,26 +106,31 @@ HUNK_CR2 = r'''
 '''
 
 PATCHES = [
-    ("decompressors/UncompressedDecompressor.cpp",
-     "void UncompressedDecompressor::readUncompressedRaw() {", HUNK_UNPACK),
-    ("decompressors/LJpegDecompressor.cpp",
-     "ByteStream::size_type LJpegDecompressor::decode() const {", HUNK_LJPEG),
-    ("decompressors/Cr2DecompressorImpl.h",
-     "ByteStream::size_type Cr2Decompressor<PrefixCodeDecoder>::decompress() const {",
-     HUNK_CR2),
+    ("decompressors/UncompressedDecompressor.cpp", [
+        ("void UncompressedDecompressor::readUncompressedRaw() {", HUNK_UNPACK),
+        ("void UncompressedDecompressor::decode8BitRaw() {", HUNK_8BIT),
+        ("void UncompressedDecompressor::decode12BitRawWithControl() {", HUNK_CONTROL),
+        ("void UncompressedDecompressor::decode12BitRawUnpackedLeftAligned() {", HUNK_LEFT),
+    ]),
+    ("decompressors/LJpegDecompressor.cpp", [
+        ("ByteStream::size_type LJpegDecompressor::decode() const {", HUNK_LJPEG)]),
+    ("decompressors/Cr2DecompressorImpl.h", [
+        ("ByteStream::size_type Cr2Decompressor<PrefixCodeDecoder>::decompress() const {",
+         HUNK_CR2)]),
 ]
 
 
 def main():
-    for rel, anchor, hunk in PATCHES:
+    for rel, hunks in PATCHES:
         src = open(os.path.join(S, rel)).read()
-        if src.count(anchor) != 1:
-            raise SystemExit("anchor not found exactly once in %s" % rel)
         # the shim include goes after the file's last #include
         last_inc = src.rfind("#include ")
         eol = src.index("\n", last_inc) + 1
         src = src[:eol] + '#include "rsx_rawspeed_shim.h" // rsx drop-in\n' + src[eol:]
-        src = src.replace(anchor, anchor + hunk, 1)
+        for anchor, hunk in hunks:
+            if src.count(anchor) != 1:
+                raise SystemExit("anchor %r not found exactly once in %s" % (anchor, rel))
+            src = src.replace(anchor, anchor + hunk, 1)
         dst = os.path.join(OUT, rel)
         os.makedirs(os.path.dirname(dst), exist_ok=True)
         with open(dst, "w") as f:

@@ -162,6 +162,47 @@ int ref_unpack_u16(void* h, const rsx_unpack_desc* d, const uint8_t* in,
   });
 }
 
+// The variant entry points, constructed the way their callers do
+// (DcsDecoder.cpp:72-79, ErfDecoder.cpp:61-67, OrfDecoder.cpp:213-245,
+// Rw2Decoder.cpp:98-111).
+int ref_unpack_variant_u16(void* h, const rsx_unpack_variant_desc* d,
+                           const uint8_t* in, size_t in_bytes) {
+  auto* r = static_cast<RefImage*>(h);
+  return guarded([&] {
+    const Buffer b(in, implicit_cast<Buffer::size_type>(in_bytes));
+    const ByteStream bs(DataBuffer(b, Endianness::little));
+    const int w = d->w;
+    const iRectangle2D crop({0, 0}, iPoint2D(w, d->h));
+    switch (d->variant) {
+    case RSX_UNPACK_8BIT_RAW: {
+      UncompressedDecompressor u(bs, r->img, crop, 8 * w / 8, 8, BitOrder::LSB);
+      u.decode8BitRaw<true>();
+      break;
+    }
+    case RSX_UNPACK_12BIT_WITH_CONTROL: {
+      UncompressedDecompressor u(bs, r->img, crop, (12 * w / 8) + ((w + 2) / 10),
+                                 12, d->big_endian ? BitOrder::MSB : BitOrder::LSB);
+      if (d->big_endian)
+        u.decode12BitRawWithControl<Endianness::big>();
+      else
+        u.decode12BitRawWithControl<Endianness::little>();
+      break;
+    }
+    case RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED: {
+      UncompressedDecompressor u(bs, r->img, crop, 16 * w / 8, 16,
+                                 d->big_endian ? BitOrder::MSB : BitOrder::LSB);
+      if (d->big_endian)
+        u.decode12BitRawUnpackedLeftAligned<Endianness::big>();
+      else
+        u.decode12BitRawUnpackedLeftAligned<Endianness::little>();
+      break;
+    }
+    default:
+      ThrowRDE("unknown variant");
+    }
+  });
+}
+
 int ref_ljpeg_decompress(void* h, const rsx_ljpeg_desc* d, const uint8_t* in,
                          size_t in_bytes, uint32_t* consumed) {
   auto* r = static_cast<RefImage*>(h);

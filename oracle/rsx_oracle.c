@@ -322,6 +322,95 @@ int oracle_unpack_u16(const rsx_unpack_desc* d, const uint8_t* in,
   return RSX_OK;
 }
 
+/* ---- the fixed-layout entry points of the same class ---------------------- */
+
+/* UncompressedDecompressor::bytesPerLine (UncompressedDecompressor.cpp:88-104)
+ * and the bpl the two sanityCheck(w, &h, bpp) callers use (:76-86). */
+static int variant_bpl(const rsx_unpack_variant_desc* d, uint64_t* bpl) {
+  const uint64_t w = (uint32_t)d->w;
+  if (d->variant == RSX_UNPACK_8BIT_RAW) {
+    *bpl = w; /* sanityCheck(w, &h, 1) :273 */
+  } else if (d->variant == RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED) {
+    *bpl = 2 * w; /* sanityCheck(w, &h, 2) :360 */
+  } else if (d->variant == RSX_UNPACK_12BIT_WITH_CONTROL) {
+    if ((12 * w) % 8 != 0)
+      return RSX_ERR_IO; /* "Bad image width" :91-92 */
+    *bpl = 12 * w / 8 + (w + 2) / 10; /* :95-101 */
+  } else {
+    return RSX_ERR_INVALID_ARG;
+  }
+  return RSX_OK;
+}
+
+int oracle_unpack_variant_validate(const rsx_unpack_variant_desc* d,
+                                   const rsx_image* img, size_t in_bytes) {
+  if (d->variant < 0 || d->variant > RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED)
+    return RSX_ERR_INVALID_ARG;
+  if (d->w <= 0 || d->h <= 0)
+    return RSX_ERR_INVALID_ARG; /* invariant(w > 0), invariant(*h > 0) */
+  /* out(row, col) indexes the uncropped array: keep inside it */
+  if (img->cpp < 1 || img->dim_x <= 0 || img->dim_y <= 0 ||
+      (uint64_t)d->w > (uint64_t)img->dim_x * (uint64_t)img->cpp ||
+      d->h > img->dim_y)
+    return RSX_ERR_INVALID_ARG;
+  uint64_t bpl = 0;
+  int st = variant_bpl(d, &bpl);
+  if (st)
+    return st;
+  /* sanityCheck(h, bpl) :52-70 then input.getData(bpl * h): IOException */
+  if (bpl > 0x7FFFFFFFull || (uint64_t)in_bytes / bpl < (uint64_t)d->h)
+    return RSX_ERR_IO;
+  return RSX_OK;
+}
+
+int oracle_unpack_variant_u16(const rsx_unpack_variant_desc* d, const uint8_t* in,
+                              size_t in_bytes, const rsx_image* img) {
+  int st = oracle_unpack_variant_validate(d, img, in_bytes);
+  if (st)
+    return st;
+  uint64_t bpl = 0;
+  variant_bpl(d, &bpl);
+  uint8_t* out = (uint8_t*)img->data;
+  const uint32_t w = (uint32_t)d->w, h = (uint32_t)d->h;
+  for (uint32_t row = 0; row < h; ++row) {
+    uint16_t* o = (uint16_t*)(out + (size_t)row * img->pitch_bytes);
+    const uint8_t* r = in + (size_t)row * bpl;
+    if (d->variant == RSX_UNPACK_8BIT_RAW) {
+      /* decode8BitRaw<true> :270-291 */
+      for (uint32_t col = 0; col < w; ++col)
+        o[col] = r[col];
+    } else if (d->variant == RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED) {
+      /* decode12BitRawUnpackedLeftAligned<e> :356-378 */
+      for (uint32_t col = 0; col < w; ++col) {
+        const uint32_t g1 = r[2 * col], g2 = r[2 * col + 1];
+        const uint16_t pix =
+            d->big_endian ? (uint16_t)((g1 << 8) | g2) : (uint16_t)((g2 << 8) | g1);
+        o[col] = pix >> 4;
+      }
+    } else {
+      /* decode12BitRawWithControl<e> :296-349: process(i, invert, p1, p2)
+       * takes the "(p1 << 4) | (p2 >> 4)" form iff invert == (e == little) */
+      uint32_t col = 0;
+      for (uint32_t x = 0; x < w; x += 2) {
+        uint32_t g1 = r[col], g2 = r[col + 1];
+        if (d->big_endian)
+          o[x] = (uint16_t)((g1 << 4) | (g2 >> 4));
+        else
+          o[x] = (uint16_t)(((g2 & 0x0f) << 8) | g1);
+        g1 = r[col + 2];
+        if (d->big_endian)
+          o[x + 1] = (uint16_t)(((g2 & 0x0f) << 8) | g1);
+        else
+          o[x + 1] = (uint16_t)((g1 << 4) | (g2 >> 4));
+        col += 3;
+        if ((x % 10) == 8)
+          col++;
+      }
+    }
+  }
+  return RSX_OK;
+}
+
 /* ======================================================================== */
 /* Huffman: codes/HuffmanCode.h, PrefixCodeLookupDecoder.h,                    */
 /* AbstractPrefixCodeDecoder.h                                                */

@@ -47,6 +47,14 @@ class UnpackDesc(C.Structure):
                 ("bits_per_pixel", C.c_int32), ("bit_order", C.c_int32)]
 
 
+UNPACK_8BIT_RAW, UNPACK_12BIT_WITH_CONTROL, UNPACK_12BIT_UNPACKED_LEFT_ALIGNED = range(3)
+
+
+class UnpackVariantDesc(C.Structure):
+    _fields_ = [("variant", C.c_int32), ("big_endian", C.c_int32),
+                ("w", C.c_int32), ("h", C.c_int32)]
+
+
 class HuffTable(C.Structure):
     _fields_ = [("n_codes_per_length", C.c_uint8 * 16),
                 ("code_values", C.c_uint8 * RSX_MAX_CODE_VALUES),
@@ -102,6 +110,12 @@ class DngUnpackTile(C.Structure):
 
 class UnpackJob(C.Structure):
     _fields_ = [("desc", UnpackDesc), ("in_offset", C.c_uint64),
+                ("in_bytes", C.c_uint64), ("img_offset", C.c_uint64),
+                ("img", Image)]
+
+
+class UnpackVariantJob(C.Structure):
+    _fields_ = [("desc", UnpackVariantDesc), ("in_offset", C.c_uint64),
                 ("in_bytes", C.c_uint64), ("img_offset", C.c_uint64),
                 ("img", Image)]
 

@@ -21,6 +21,7 @@ namespace {
 enum PlanKind { PLAN_UNPACK = 0, PLAN_LJPEG = 1 };
 
 struct UnpackLaunch {
+  int mode = UNPACK_MODE_PACKED;
   int order = 0;
   int n_jobs = 0;
   uint32_t total_blocks = 0;
@@ -90,7 +91,7 @@ int flatten_unpack_job(const rsx_unpack_job& j, UnpackJobDev* out, int* order) {
   if (d.bit_order == RSX_ORDER_LSB && d.bits_per_pixel == 16)
     out_off += uint64_t(d.crop_x) * uint64_t(j.img.cpp) * 2;
   u.out_offset = out_off;
-  unpack_blocks_for(u.n_rows, u.cols, &u.segs_per_row, &u.groups_per_row);
+  unpack_blocks_for(&u);
   u.out_aligned = 0; // resolved at run time (needs the output base pointer)
   *out = u;
   *order = d.bit_order;
@@ -233,6 +234,101 @@ extern "C" int rsx_unpack_plan_create(rsx_ctx* ctx, int n_jobs,
   return RSX_OK;
 }
 
+// decode8BitRaw<true> is the 8-bit packed walk over rows of w bytes;
+// decode12BitRawUnpackedLeftAligned<e> the 16-bit LSB/MSB walk + ">> 4";
+// decode12BitRawWithControl<e> has its own kernel.  All three write from pixel
+// (0,0) and count `w` in samples of the uncropped array (cpp is not applied).
+extern "C" int rsx_unpack_variant_validate(const rsx_unpack_variant_desc* d,
+                                           const rsx_image* img, size_t in_bytes) {
+  if (!d || !img)
+    return RSX_ERR_INVALID_ARG;
+  return validate_unpack_variant(*d, *img, in_bytes);
+}
+
+extern "C" int rsx_unpack_variant_plan_create(rsx_ctx* ctx, int n_jobs,
+                                              const rsx_unpack_variant_job* jobs,
+                                              rsx_plan** out_plan) {
+  if (!ctx || !jobs || n_jobs < 1 || !out_plan)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto plan = std::make_unique<rsx_plan>();
+  plan->ctx = ctx;
+  plan->kind = PLAN_UNPACK;
+  plan->n_jobs = n_jobs;
+  plan->job_status.assign(n_jobs, RSX_OK);
+  // launch classes: [mode][order]
+  struct Class {
+    int mode, order;
+    std::vector<UnpackJobDev> v;
+  };
+  Class classes[5] = {{UNPACK_MODE_PACKED, RSX_ORDER_LSB, {}},
+                      {UNPACK_MODE_SHIFT, RSX_ORDER_LSB, {}},
+                      {UNPACK_MODE_SHIFT, RSX_ORDER_MSB, {}},
+                      {UNPACK_MODE_CONTROL, RSX_ORDER_LSB, {}},
+                      {UNPACK_MODE_CONTROL, RSX_ORDER_MSB, {}}};
+  for (int i = 0; i < n_jobs; ++i) {
+    const rsx_unpack_variant_job& j = jobs[i];
+    int st = validate_unpack_variant(j.desc, j.img, size_t(j.in_bytes));
+    if (st == RSX_OK && j.img.pitch_bytes % 2 != 0)
+      st = RSX_ERR_INVALID_ARG;
+    plan->job_status[i] = st;
+    if (st != RSX_OK)
+      continue;
+    uint64_t bpl = 0;
+    unpack_variant_bytes_per_line(j.desc, &bpl);
+    UnpackJobDev u{};
+    u.in_offset = j.in_offset;
+    u.stream_bytes = bpl * uint64_t(j.desc.h);
+    u.in_pitch = uint32_t(bpl);
+    u.out_pitch = j.img.pitch_bytes;
+    u.n_rows = uint32_t(j.desc.h);
+    u.cols = uint32_t(j.desc.w);
+    u.out_offset = j.img_offset;
+    int cls = 0;
+    switch (j.desc.variant) {
+    case RSX_UNPACK_8BIT_RAW:
+      u.bps = 8;
+      unpack_blocks_for(&u);
+      cls = 0;
+      break;
+    case RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED:
+      u.bps = 16;
+      u.post_shift = 4;
+      unpack_blocks_for(&u);
+      cls = j.desc.big_endian ? 2 : 1;
+      break;
+    default:
+      u.bps = j.desc.big_endian ? 1 : 0;
+      unpack_control_blocks_for(&u);
+      cls = j.desc.big_endian ? 4 : 3;
+      break;
+    }
+    classes[cls].v.push_back(u);
+  }
+  for (Class& c : classes) {
+    if (c.v.empty())
+      continue;
+    plan->unpack.emplace_back();
+    UnpackLaunch& L = plan->unpack.back();
+    L.mode = c.mode;
+    L.order = c.order;
+    L.n_jobs = int(c.v.size());
+    std::vector<uint32_t> starts(c.v.size() + 1, 0);
+    for (size_t k = 0; k < c.v.size(); ++k)
+      starts[k + 1] = starts[k] + c.v[k].n_rows * c.v[k].segs_per_row;
+    L.total_blocks = starts.back();
+    L.jobs = c.v;
+    if (int st = upload(ctx, L.d_jobs, c.v.data(), c.v.size() * sizeof(UnpackJobDev)))
+      return st;
+    if (int st = upload(ctx, L.d_block_start, starts.data(),
+                        starts.size() * sizeof(uint32_t)))
+      return st;
+  }
+  *out_plan = plan.release();
+  return RSX_OK;
+}
+
 // Whether 16-byte stores are legal depends on the run-time output base; the
 // flag is re-resolved (and re-uploaded) only when the base pointer changes.
 namespace {
@@ -260,10 +356,10 @@ int run_unpack(rsx_plan* p, const void* in_dev, void* out_dev, hipStream_t s) {
     EventPair* ev = p->timing ? next_events(p) : nullptr;
     if (ev)
       RSX_HIP_CHECK(ctx, hipEventRecord(ev->start, s));
-    RSX_HIP_CHECK(ctx, launch_unpack(L.order,
-                                     static_cast<const UnpackJobDev*>(L.d_jobs.ptr),
-                                     static_cast<const uint32_t*>(L.d_block_start.ptr),
-                                     L.n_jobs, L.total_blocks, in_dev, out_dev, s));
+    RSX_HIP_CHECK(ctx, launch_unpack_mode(L.mode, L.order,
+                                          static_cast<const UnpackJobDev*>(L.d_jobs.ptr),
+                                          static_cast<const uint32_t*>(L.d_block_start.ptr),
+                                          L.n_jobs, L.total_blocks, in_dev, out_dev, s));
     if (ev)
       RSX_HIP_CHECK(ctx, hipEventRecord(ev->stop, s));
   }
@@ -350,8 +446,11 @@ extern "C" int rsx_plan_kernel_time(rsx_plan* plan, const char** kernel_name,
     total += ms;
   }
   if (kernel_name)
-    *kernel_name = plan->kind == PLAN_UNPACK ? unpack_kernel_name()
-                                             : ljpeg_dominant_kernel_name();
+    *kernel_name = plan->kind != PLAN_UNPACK ? ljpeg_dominant_kernel_name()
+                   : (!plan->unpack.empty() &&
+                      plan->unpack[0].mode == UNPACK_MODE_CONTROL)
+                       ? "unpack_control_kernel"
+                       : unpack_kernel_name();
   if (avg_ms)
     *avg_ms = total / double(plan->events_used);
   if (n_launches)
@@ -462,7 +561,7 @@ int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
     u.cols = uint32_t(d.crop_w) * uint32_t(img->cpp);
     u.bps = uint32_t(d.bits_per_pixel);
     u.out_offset = rects[i].dev_off;
-    unpack_blocks_for(u.n_rows, u.cols, &u.segs_per_row, &u.groups_per_row);
+    unpack_blocks_for(&u);
     const uintptr_t a = reinterpret_cast<uintptr_t>(ctx->d_out.ptr) + u.out_offset;
     u.out_aligned = ((a & 15) == 0 && (u.out_pitch & 15) == 0) ? 1u : 0u;
     per_order[d.bit_order].push_back(u);
@@ -525,6 +624,52 @@ extern "C" int rsx_unpack_u16(rsx_ctx* ctx, const rsx_unpack_desc* d,
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return unpack_host(ctx, 1, d, &in, &in_bytes, img, nullptr);
+}
+
+extern "C" int rsx_unpack_variant_u16(rsx_ctx* ctx, const rsx_unpack_variant_desc* d,
+                                      const uint8_t* in, size_t in_bytes,
+                                      const rsx_image* img) {
+  if (!ctx || !d || !in || !img || !img->data)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int st = validate_unpack_variant(*d, *img, in_bytes))
+    return st;
+  uint64_t bpl = 0;
+  unpack_variant_bytes_per_line(*d, &bpl);
+  const size_t used = size_t(bpl) * size_t(d->h);
+  // device image = the compact w x h rectangle at the image origin
+  rsx_unpack_variant_job job{};
+  job.desc = *d;
+  job.in_offset = 0;
+  job.in_bytes = used;
+  job.img_offset = 0;
+  job.img = *img;
+  job.img.pitch_bytes = uint32_t(align_up(size_t(d->w) * 2, 16));
+  const size_t out_bytes = size_t(job.img.pitch_bytes) * size_t(d->h);
+  if (int e = ctx->d_in.ensure(used + 16))
+    return e;
+  if (int e = ctx->d_out.ensure(out_bytes + 16))
+    return e;
+  hipStream_t s = ctx->stream;
+  RSX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_in.ptr, in, used, hipMemcpyHostToDevice, s));
+  rsx_plan* plan = nullptr;
+  if (int st = rsx_unpack_variant_plan_create(ctx, 1, &job, &plan))
+    return st;
+  int rc = rsx_plan_run(plan, ctx->d_in.ptr, ctx->d_out.ptr, s);
+  if (rc == RSX_OK) {
+    hipError_t e = hipMemcpy2DAsync(img->data, img->pitch_bytes, ctx->d_out.ptr,
+                                    job.img.pitch_bytes, size_t(d->w) * 2, size_t(d->h),
+                                    hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      ctx->last_error = std::string("unpack_variant D2H: ") + hipGetErrorString(e);
+      rc = RSX_ERR_DEVICE;
+    }
+  }
+  rsx_plan_destroy(plan);
+  return rc;
 }
 
 extern "C" int rsx_dng_decompress_uncompressed(rsx_ctx* ctx, int n_tiles,

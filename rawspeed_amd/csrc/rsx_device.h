@@ -23,13 +23,26 @@ struct UnpackJobDev {
   uint32_t bps;
   uint32_t groups_per_row; // ceil(cols / 8)
   uint32_t segs_per_row;
+  uint32_t seg_groups;   // groups per segment (rows are split evenly)
   uint32_t out_aligned;  // every output row start is 16-byte aligned
+  uint32_t post_shift;   // UNPACK_MODE_SHIFT: samples are shifted right by this
 };
 
+// Launch flavours.  PACKED is decodePackedInt; SHIFT is the same stream walk
+// followed by `>> post_shift` (decode12BitRawUnpackedLeftAligned); CONTROL is
+// decode12BitRawWithControl (bps field = 1 for big-endian nibble order).
+enum UnpackMode { UNPACK_MODE_PACKED = 0, UNPACK_MODE_SHIFT = 1, UNPACK_MODE_CONTROL = 2 };
+
 size_t unpack_lds_bytes();
-uint32_t unpack_blocks_for(uint32_t n_rows, uint32_t cols, uint32_t* segs_per_row,
-                           uint32_t* groups_per_row);
+// fill groups_per_row / segs_per_row / seg_groups from n_rows and cols;
+// return the number of workgroups of the job
+uint32_t unpack_blocks_for(UnpackJobDev* u);
 const char* unpack_kernel_name();
+uint32_t unpack_control_blocks_for(UnpackJobDev* u);
+hipError_t launch_unpack_mode(int mode, int order, const UnpackJobDev* d_jobs,
+                              const uint32_t* d_block_start, int n_jobs,
+                              uint32_t total_blocks, const void* in_base,
+                              void* out_base, hipStream_t stream);
 hipError_t launch_unpack(int order, const UnpackJobDev* d_jobs,
                          const uint32_t* d_block_start, int n_jobs,
                          uint32_t total_blocks, const void* in_base,

@@ -55,6 +55,53 @@ int validate_unpack(const rsx_unpack_desc& d, const rsx_image& img,
 // HuffmanCode::setNCodesPerLength / setCodeValues (codes/HuffmanCode.h:99-166)
 // + full-decode requirement (codes/AbstractPrefixCodeTranscoder.h:71-84).
 // ------------------------------------------------------------------------
+// ------------------------------------------------------------------------
+// decode8BitRaw<true> / decode12BitRawWithControl<e> /
+// decode12BitRawUnpackedLeftAligned<e>
+// (decompressors/UncompressedDecompressor.cpp:270-378).  The constructor ran
+// on the reference side already; these are the checks the methods add.
+// ------------------------------------------------------------------------
+int unpack_variant_bytes_per_line(const rsx_unpack_variant_desc& d, uint64_t* bpl) {
+  const uint64_t w = uint64_t(uint32_t(d.w));
+  switch (d.variant) {
+  case RSX_UNPACK_8BIT_RAW: // sanityCheck(w, &h, 1) :273
+    *bpl = w;
+    return RSX_OK;
+  case RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED: // sanityCheck(w, &h, 2) :360
+    *bpl = 2 * w;
+    return RSX_OK;
+  case RSX_UNPACK_12BIT_WITH_CONTROL:
+    if ((12 * w) % 8 != 0) // bytesPerLine: ThrowIOE("Bad image width") :91-92
+      return RSX_ERR_IO;
+    *bpl = 12 * w / 8 + (w + 2) / 10; // :95-101
+    return RSX_OK;
+  default:
+    return RSX_ERR_INVALID_ARG;
+  }
+}
+
+int validate_unpack_variant(const rsx_unpack_variant_desc& d, const rsx_image& img,
+                            size_t in_bytes) {
+  if (d.variant < RSX_UNPACK_8BIT_RAW ||
+      d.variant > RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED)
+    return RSX_ERR_INVALID_ARG;
+  if (d.w <= 0 || d.h <= 0) // invariant(w > 0), invariant(*h > 0) :54, :78
+    return RSX_ERR_INVALID_ARG;
+  // out(row, col) addresses the uncropped u16 array (dim.x * cpp samples per
+  // row); anything larger would be an out-of-bounds write in the reference
+  if (img.cpp < 1 || img.dim_x <= 0 || img.dim_y <= 0 ||
+      uint64_t(d.w) > uint64_t(img.dim_x) * uint64_t(img.cpp) || d.h > img.dim_y)
+    return RSX_ERR_INVALID_ARG;
+  uint64_t bpl = 0;
+  if (int st = unpack_variant_bytes_per_line(d, &bpl))
+    return st;
+  // sanityCheck(h, bpl): fullRows = remain / bpl must reach h (:52-70), then
+  // input.getData(bpl * h) (:277, :318, :363) -- both IOException
+  if (bpl > 0x7FFFFFFFull || uint64_t(in_bytes) / bpl < uint64_t(d.h))
+    return RSX_ERR_IO;
+  return RSX_OK;
+}
+
 int validate_huff_table(const rsx_huff_table& t) {
   int max_len = 16;
   while (max_len > 0 && t.n_codes_per_length[max_len - 1] == 0)

@@ -20,6 +20,9 @@ namespace rsx {
 // ------------------------------------------------------------------------
 int validate_unpack(const rsx_unpack_desc& d, const rsx_image& img,
                     size_t in_bytes);
+int validate_unpack_variant(const rsx_unpack_variant_desc& d, const rsx_image& img,
+                            size_t in_bytes);
+int unpack_variant_bytes_per_line(const rsx_unpack_variant_desc& d, uint64_t* bpl);
 int validate_ljpeg(const rsx_ljpeg_desc& d, const rsx_image& img);
 int validate_cr2(const rsx_cr2_desc& d, const rsx_image& img);
 int validate_huff_table(const rsx_huff_table& t);

@@ -20,12 +20,17 @@ from oracle_lib import Ref  # noqa: E402
 
 def main():
     ref = Ref()
-    out = {"unpack": {}, "ljpeg": {}, "cr2": {}}
+    out = {"unpack": {}, "variant": {}, "ljpeg": {}, "cr2": {}}
     for i, c in enumerate(G.UNPACK_CASES):
         d, data, (w, h, cpp) = G.build_unpack(c)
         img = ref.image(w, h, cpp)
         st = ref.unpack(d, data, img)
         out["unpack"][str(i)] = {"status": st, "hash": G.image_hash(img.pixels())}
+    for i, c in enumerate(G.VARIANT_CASES):
+        d, data, (w, h, cpp) = G.build_variant(c)
+        img = ref.image(w, h, cpp)
+        st = ref.unpack_variant(d, data, img)
+        out["variant"][str(i)] = {"status": st, "hash": G.image_hash(img.pixels())}
     for c in G.LJPEG_CASES:
         d, data, (w, h, cpp), _ = G.build_ljpeg(c)
         img = ref.image(w, h, cpp)

@@ -40,6 +40,28 @@ def build_unpack(c, seed=1234):
     return d, data, (c["w"], c["h"] + c["oy"], 1)
 
 
+# decode8BitRaw<true> / decode12BitRawWithControl<e> /
+# decode12BitRawUnpackedLeftAligned<e>: (variant, big_endian, w, h, extra input bytes)
+VARIANT_CASES = []
+for variant in range(3):
+    for big in ((0,) if variant == 0 else (0, 1)):
+        for (w, h, extra) in ((10, 3, 0), (48, 5, 0), (62, 4, 7), (2568, 3, 0),
+                              (5126, 2, 1)):
+            VARIANT_CASES.append(dict(variant=variant, big=big, w=w, h=h, extra=extra))
+
+
+def variant_bpl(variant, w):
+    return (w, 12 * w // 8 + (w + 2) // 10, 2 * w)[variant]
+
+
+def build_variant(c, seed=4321):
+    rng = np.random.default_rng([seed, c["variant"], c["big"], c["w"], c["h"]])
+    n = variant_bpl(c["variant"], c["w"]) * c["h"] + c["extra"]
+    data = rng.integers(0, 256, size=n, dtype=np.uint8)
+    d = abi.UnpackVariantDesc(c["variant"], c["big"], c["w"], c["h"])
+    return d, data, (c["w"], c["h"], 1)
+
+
 LJPEG_CASES = [
     dict(name="mcu2x1_full", img=(64, 8, 1), tile=(0, 0, 64, 8), mcu=(2, 1)),
     dict(name="mcu1x1", img=(64, 8, 1), tile=(0, 0, 64, 8), mcu=(1, 1)),

@@ -71,6 +71,9 @@ class Oracle:
         L = self.lib
         L.oracle_unpack_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.oracle_unpack_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_unpack_variant_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
+                                                C.c_void_p]
+        L.oracle_unpack_variant_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_ljpeg_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_void_p, C.c_void_p]
         L.oracle_ljpeg_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -92,6 +95,15 @@ class Oracle:
     def unpack_validate(self, desc, img, n):
         v = img.view()
         return self.lib.oracle_unpack_validate(C.byref(desc), C.byref(v), n)
+
+    def unpack_variant(self, desc, data, img):
+        a, p, n = _as_u8(data)
+        v = img.view()
+        return self.lib.oracle_unpack_variant_u16(C.byref(desc), p, n, C.byref(v))
+
+    def unpack_variant_validate(self, desc, img, n):
+        v = img.view()
+        return self.lib.oracle_unpack_variant_validate(C.byref(desc), C.byref(v), n)
 
     def ljpeg(self, desc, data, img):
         a, p, n = _as_u8(data)
@@ -186,6 +198,8 @@ class Ref:
         L.ref_image_pitch.argtypes = [C.c_void_p]
         L.ref_image_fill.argtypes = [C.c_void_p, C.c_int]
         L.ref_unpack_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ref_unpack_variant_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_size_t]
         L.ref_ljpeg_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_size_t, C.c_void_p]
         L.ref_cr2_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
@@ -213,6 +227,10 @@ class Ref:
     def unpack(self, desc, data, img):
         a, p, n = _as_u8(data)
         return self.lib.ref_unpack_u16(img.h, C.byref(desc), p, n)
+
+    def unpack_variant(self, desc, data, img):
+        a, p, n = _as_u8(data)
+        return self.lib.ref_unpack_variant_u16(img.h, C.byref(desc), p, n)
 
     def ljpeg(self, desc, data, img):
         a, p, n = _as_u8(data)

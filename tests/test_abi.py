@@ -34,6 +34,8 @@ def test_struct_sizes_are_stable():
     # the ctypes mirror must match the C layout the library was compiled with
     assert C.sizeof(abi.HuffTable) == 16 + 162 + 2
     assert C.sizeof(abi.UnpackDesc) == 28
+    assert C.sizeof(abi.UnpackVariantDesc) == 16
+    assert C.sizeof(abi.UnpackVariantJob) == 16 + 24 + 32
     assert C.sizeof(abi.Image) == 32
     assert C.sizeof(abi.LJpegDesc) == 4 * 10 + 8 + 4 + 4 + 4 * 180
     assert C.sizeof(abi.Cr2Desc) == 4 * 8 + 8 + 4 + 4 + 4 * 180
@@ -75,6 +77,23 @@ def test_unpack_validate_matches_oracle(lib, oracle):
             assert d.crop_h * d.input_pitch_bytes < 4
         n_ok += a == 0
     assert n_ok > 20
+
+
+def test_unpack_variant_validate_matches_oracle(lib, oracle):
+    rng = np.random.default_rng(12)
+    seen = set()
+    for _ in range(3000):
+        w = int(rng.integers(1, 40))
+        h = int(rng.integers(1, 12))
+        img = HostImage(w, h, int(rng.choice([1, 1, 2])))
+        d = abi.UnpackVariantDesc(int(rng.integers(-1, 4)), int(rng.integers(0, 2)),
+                                  int(rng.integers(-1, w + 3)), int(rng.integers(-1, h + 2)))
+        n = int(rng.integers(0, 2 * w * h + 4))
+        v = img.view()
+        a = lib.rsx_unpack_variant_validate(C.byref(d), C.byref(v), n)
+        assert a == oracle.unpack_variant_validate(d, img, n), (list(bytes(d)), n)
+        seen.add(a)
+    assert seen == {abi.RSX_OK, abi.RSX_ERR_INVALID_ARG, abi.RSX_ERR_IO}
 
 
 def test_ljpeg_validate_matches_oracle(lib, oracle):

@@ -141,3 +141,20 @@ def test_corrupt_tile_is_reported_by_both(pair):
     res = both(pair, lambda lib, img: lib.ljpeg_container(bad, img, 0, 0, W, H, (W, H)),
                (W, H, 1))
     assert res[0][0] != 0 and res[1][0] != 0
+
+
+def test_uncompressed_variant_methods(pair):
+    """decode8BitRaw<true>, decode12BitRawWithControl<e> and
+    decode12BitRawUnpackedLeftAligned<e> through the patched reference class
+    (constructed the way DcsDecoder / ErfDecoder / OrfDecoder / Rw2Decoder do)."""
+    rng = np.random.default_rng(36)
+    for variant in range(3):
+        for big in ((0,) if variant == 0 else (0, 1)):
+            for (w, h, cut) in ((3000, 37, 0), (126, 5, 0), (500, 4, 9)):
+                bpl = (w, 12 * w // 8 + (w + 2) // 10, 2 * w)[variant]
+                data = rng.integers(0, 256, size=bpl * h - cut, dtype=np.uint8)
+                d = abi.UnpackVariantDesc(variant, big, w, h)
+                (s0, a, e0), (s1, b, e1) = both(
+                    pair, lambda lib, img: lib.unpack_variant(d, data, img), (w, h, 1))
+                assert s0 == s1 and (s0 == 0) == (cut == 0), (variant, big, w, e0, e1)
+                assert np.array_equal(a, b)

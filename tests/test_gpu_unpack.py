@@ -175,3 +175,117 @@ def test_unpack_baseline_sizes_roundtrip(gpu, cfg):
     want = HostImage(w, 64)
     assert Oracle().unpack(d, packed[r0 * pitch:(r0 + 64) * pitch], want) == 0
     assert np.array_equal(want.pixels(), got[r0:r0 + 64])
+
+
+# ---- decode8BitRaw<true> / decode12BitRawWithControl<e> /
+# ---- decode12BitRawUnpackedLeftAligned<e> ------------------------------------
+
+@pytest.mark.parametrize("i", range(len(G.VARIANT_CASES)))
+def test_unpack_variant_golden_host_api(gpu, oracle, i):
+    d, data, (w, h, cpp) = G.build_variant(G.VARIANT_CASES[i])
+    img, want = HostImage(w, h, cpp), HostImage(w, h, cpp)
+    st = gpu.unpack_variant_u16(d, data, img.view())
+    assert st == oracle.unpack_variant(d, data, want) == GOLD["variant"][str(i)]["status"]
+    assert np.array_equal(img.u16(), want.u16())
+    assert G.image_hash(img.pixels()) == GOLD["variant"][str(i)]["hash"]
+
+
+def test_unpack_variant_sweep_vs_oracle(gpu, oracle):
+    """Every width class (mod 8, mod 10, segment boundaries of the kernels),
+    aligned and unaligned image bases / pitches, one device-resident plan."""
+    import gpu_util
+    rng = np.random.default_rng(23)
+    jobs, wants, in_chunks = [], [], []
+    in_off = out_off = 0
+    widths = list(range(2, 64, 2)) + [2558, 2560, 2562, 8192, 10246]
+    for variant in range(3):
+        for big in ((0,) if variant == 0 else (0, 1)):
+            for w in widths:
+                h = int(rng.integers(1, 4))
+                bpl = G.variant_bpl(variant, w)
+                data = rng.integers(0, 256, size=bpl * h + int(rng.integers(0, 3)),
+                                    dtype=np.uint8)
+                d = abi.UnpackVariantDesc(variant, big, w, h)
+                dim_x = w + int(rng.integers(0, 3))
+                dim_y = h + int(rng.integers(0, 2))
+                want = HostImage(dim_x, dim_y, 1)
+                assert oracle.unpack_variant(d, data, want) == 0
+                j = abi.UnpackVariantJob()
+                j.desc = d
+                j.in_offset, j.in_bytes, j.img_offset = in_off, data.size, out_off
+                j.img = gpu_util.image_job_view(dim_x, dim_y, 1, want.pitch)
+                jobs.append(j)
+                wants.append(want)
+                in_chunks.append((in_off, data))
+                in_off += data.size + int(rng.integers(0, 3)) * 3
+                # a third of the images start 2 bytes off a 16-byte boundary
+                out_off += want.buf.size + (2 if rng.integers(0, 3) == 0 else 0)
+                out_off += (-out_off) % 2
+    in_host = np.zeros(in_off + 16, dtype=np.uint8)
+    for off, data in in_chunks:
+        in_host[off:off + data.size] = data
+    out_host = np.full(out_off + 16, 0xA5, dtype=np.uint8)
+    d_in, d_out = gpu_util.to_dev(in_host), gpu_util.to_dev(out_host)
+    plan = gpu.unpack_variant_plan(jobs)
+    plan.run(d_in.data_ptr(), d_out.data_ptr())
+    rc, status, _ = plan.results()
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    assert rc == 0 and all(s == 0 for s in status)
+    for j, want in zip(jobs, wants):
+        a = got[j.img_offset:j.img_offset + want.buf.size]
+        assert np.array_equal(a, want.buf), (j.desc.variant, j.desc.big_endian, j.desc.w)
+    plan.close()
+
+
+def test_unpack_variant_errors(gpu, oracle):
+    for variant, w, h, n in ((1, 11, 2, 64), (1, 10, 2, 31), (0, 10, 2, 19),
+                             (2, 10, 2, 39), (0, 12, 2, 24), (3, 10, 2, 100)):
+        d = abi.UnpackVariantDesc(variant, 0, w, h)
+        data = np.zeros(n, dtype=np.uint8)
+        img, want = HostImage(10, 2, 1), HostImage(10, 2, 1)
+        st = gpu.unpack_variant_u16(d, data, img.view())
+        assert st != 0 and st == oracle.unpack_variant(d, data, want)
+        assert np.array_equal(img.u16(), want.u16())
+
+
+def test_unpack_variant_full_frame_properties(gpu):
+    """Full sensor size: the with-control layout is the 12-bit packed layout
+    with one byte inserted every 15; both kernels must agree, and the
+    left-aligned variant is the 16-bit unpack shifted by 4."""
+    import gpu_util
+    w, h = 8280, 5520  # multiple of 10: every unit is complete
+    rng = np.random.default_rng(3)
+    pix = rng.integers(0, 4096, size=(h, w), dtype=np.uint16)
+    packed = synth.pack_rows(pix, 12, abi.ORDER_MSB)          # (h, w*12/8)
+    units = packed.reshape(h, w // 10, 15)
+    ctrl = np.concatenate([units, np.full((h, w // 10, 1), 0x5A, np.uint8)], axis=2)
+    ctrl = np.ascontiguousarray(ctrl.reshape(h, -1))
+    assert ctrl.shape[1] == G.variant_bpl(1, w)
+    pitch = out_pitch(w, 1)
+    j = abi.UnpackVariantJob()
+    j.desc = abi.UnpackVariantDesc(abi.UNPACK_12BIT_WITH_CONTROL, 1, w, h)
+    j.in_offset, j.in_bytes, j.img_offset = 0, ctrl.size, 0
+    j.img = gpu_util.image_job_view(w, h, 1, pitch)
+    d_in = gpu_util.to_dev(ctrl.reshape(-1))
+    d_out = torch.zeros(pitch * h, dtype=torch.uint8, device="cuda")
+    plan = gpu.unpack_variant_plan([j])
+    plan.run(d_in.data_ptr(), d_out.data_ptr())
+    assert plan.results()[:2] == (0, [0])
+    got = d_out.cpu().numpy().view(np.uint16).reshape(h, pitch // 2)[:, :w]
+    assert np.array_equal(got, pix)
+    plan.close()
+
+    left = (pix.astype(np.uint16) << 4) | rng.integers(0, 16, size=pix.shape, dtype=np.uint16)
+    for big in (0, 1):
+        raw = left.astype(">u2" if big else "<u2").view(np.uint8).reshape(-1)
+        j.desc = abi.UnpackVariantDesc(abi.UNPACK_12BIT_UNPACKED_LEFT_ALIGNED, big, w, h)
+        j.in_bytes = raw.size
+        d_in = gpu_util.to_dev(raw)
+        d_out.zero_()
+        plan = gpu.unpack_variant_plan([j])
+        plan.run(d_in.data_ptr(), d_out.data_ptr())
+        assert plan.results()[:2] == (0, [0])
+        got = d_out.cpu().numpy().view(np.uint16).reshape(h, pitch // 2)[:, :w]
+        assert np.array_equal(got, pix)
+        plan.close()
