@@ -115,6 +115,46 @@ def run_cfg3(ctx, torch, log, frames=8, steps=10, warmup=2):
     return res, (d, data, W, H)
 
 
+def run_sraw(ctx, torch, log, frames=8, steps=10, warmup=2):
+    """Canon sRaw1/mRAW <3,2,2> of a 3960x2640 px frame: 1980 groups
+    x 1320 rows x 6 samples (Y Y Y Y Cb Cr), 3 slices; samples/s is the unit."""
+    import cases
+    from rawspeed_amd import abi
+    from rawspeed_amd import synth
+    src = synth.sensor_image(1980 * 6, 1320, 14, seed=4)
+    d, data, src, scan_len = cases.make_cr2_sraw_case(None, 2, (3, 660, 660), 1320, img=src)
+    pad = (-data.size) % 16
+    data = np.concatenate([data, np.zeros(pad, np.uint8)])
+    H, W = src.shape
+    jobs = []
+    for f in range(frames):
+        j = abi.Cr2Job()
+        j.desc = d
+        j.in_offset, j.in_bytes = f * data.size, data.size
+        j.img_offset = f * out_pitch(W) * H
+        j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
+            out_pitch(W), W, H, 1, 0
+        jobs.append(j)
+    inp = torch.from_numpy(np.tile(data, frames)).cuda()
+    out = torch.zeros(frames * out_pitch(W) * H, dtype=torch.uint8, device="cuda")
+    plan = ctx.cr2_plan(jobs)
+    dt, kt, cons = _time_plan(torch, plan, inp, out, steps, warmup)
+    got = out[-out_pitch(W) * H:].cpu().numpy().view(np.uint16).reshape(H, out_pitch(W) // 2)[:, :W]
+    exact = bool(np.array_equal(got, src)) and all(c == scan_len for c in cons)
+    alg = frames * (scan_len + W * H * 2)
+    return {
+        "workload": "Cr2Decompressor <3,2,2> (sRaw1) 3960x2640 px = %dx%d samples, 3 slices, "
+                    "%d frames/step" % (W, H, frames),
+        "msamples_per_s": round(frames * W * H / dt / 1e6, 1),
+        "mpix_per_s": round(frames * 3960 * 2640 / dt / 1e6, 1),
+        "ms_per_step": round(dt * 1e3, 4),
+        "bit_exact": exact,
+        "entropy_bits_per_sample": round(scan_len * 8 / (W * H), 3),
+        "algorithmic_bytes_per_step": alg,
+        "achieved_gbps_whole_pipeline": round(alg / dt / 1e9, 1),
+    }
+
+
 def run_cfg4(ctx, torch, log, steps=10, warmup=2):
     """configs[3]: 8192x5464 as 2x2 DNG tiles of 4096x2732 (one plan, tiles-parallel)."""
     from rawspeed_amd import abi, synth
@@ -263,6 +303,10 @@ def run(ctx, torch, log):
     out["cfg3_cr2_6720x4480"] = r3
     out["cfg4_dng_tiles_8192x5464"] = run_cfg4(ctx, torch, log)
     try:
+        out["cr2_sraw1_3960x2640"] = run_sraw(ctx, torch, log)
+    except Exception as e:
+        out["cr2_sraw1_3960x2640"] = {"error": repr(e)}
+    try:
         out["cfg3_cpu_baseline"] = cpu_baseline_cr2(*ref_args)
     except Exception as e:
         out["cfg3_cpu_baseline"] = {"error": repr(e)}
@@ -288,6 +332,9 @@ if __name__ == "__main__":
     elif args.only == "variants":
         print(json.dumps(run_variants(ctx, torch, print, frames=args.frames,
                                       steps=args.steps), indent=1))
+    elif args.only == "sraw":
+        print(json.dumps(run_sraw(ctx, torch, print, frames=args.frames, steps=args.steps),
+                         indent=1))
     elif args.only == "cfg4":
         print(json.dumps(run_cfg4(ctx, torch, print, steps=args.steps), indent=1))
     else:

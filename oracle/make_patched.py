@@ -84,17 +84,19 @@ HUNK_LJPEG = r'''
 '''
 
 HUNK_CR2 = r'''
-  // ---- rsx: forward <N,1,1> to the MI355X core (INTEGRATION.md 3) ----
-  if (std::get<1>(format) == 1 && std::get<2>(format) == 1) {
+  // ---- rsx: forward to the MI355X core (INTEGRATION.md 3) ----
+  {
+    // the constructor divided frame / slice widths by the sampling factors
+    // (Cr2DecompressorImpl.h:305-341); the C-ABI takes them as in the file
     rsx_cr2_desc d{};
     d.n_comp = std::get<0>(format);
-    d.x_s_f = 1;
-    d.y_s_f = 1;
-    d.frame_w = frame.x;
-    d.frame_h = frame.y;
+    d.x_s_f = std::get<1>(format);
+    d.y_s_f = std::get<2>(format);
+    d.frame_w = frame.x * d.x_s_f;
+    d.frame_h = frame.y * d.y_s_f;
     d.num_slices = slicing.numSlices;
-    d.slice_width = slicing.sliceWidth * d.n_comp;
-    d.last_slice_width = slicing.lastSliceWidth * d.n_comp;
+    d.slice_width = slicing.sliceWidth * d.n_comp * d.x_s_f;
+    d.last_slice_width = slicing.lastSliceWidth * d.n_comp * d.x_s_f;
     rsx_shim::recipes(rec, &d);
     const rsx_image img = rsx_shim::view(mRaw);
     uint32_t consumed = 0;

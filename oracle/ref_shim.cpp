@@ -136,6 +136,11 @@ void* ref_image_create(int dim_x, int dim_y, int cpp, int is_cfa) {
   }
 }
 void ref_image_destroy(void* h) { delete static_cast<RefImage*>(h); }
+// what Cr2Decoder sets for sRaw files before decoding (Cr2Decoder.cpp sRaw path);
+// AbstractLJpegDecoder::parseSOF checks the SOF against it (:172-176)
+void ref_image_set_subsampling(void* h, int x, int y) {
+  static_cast<RefImage*>(h)->img->metadata.subsampling = iPoint2D(x, y);
+}
 uint8_t* ref_image_data(void* h) {
   auto a = static_cast<RefImage*>(h)->img->getByteDataAsUncroppedArray2DRef();
   return reinterpret_cast<uint8_t*>(&a(0, 0));

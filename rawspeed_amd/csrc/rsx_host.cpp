@@ -371,6 +371,7 @@ int build_ljpeg_stream(const rsx_ljpeg_desc& d, const rsx_image& img,
     s->comp_of_phase[c] = d.table_index[c];
     s->pred_of_phase[c] = uint8_t(c);
     s->init_pred[c] = d.init_pred[c];
+    s->seed_pos[c] = uint8_t(c);
   }
   s->row_samples = uint32_t(d.frame_w) * uint32_t(d.n_comp);
   s->rows = uint32_t(d.tile_h / d.mcu_h); // rows below the tile are never decoded (:312-315)
@@ -391,16 +392,21 @@ int build_cr2_stream(const rsx_cr2_desc& d, const rsx_image& img,
   std::vector<Rect> tiles;
   if (int st = cr2_output_tiles(g, &tiles))
     return st;
-  if (g.sub)
-    return RSX_ERR_UNSUPPORTED; // sRaw <3,2,1>/<3,2,2>: SURVEY 8(f) "next"
   std::memset(s, 0, sizeof *s);
   s->kind = 1;
   s->n_comp = uint32_t(g.N);
-  s->period = uint32_t(g.N);
+  // symbol p of a group belongs to component (p < pixelsPerGroup ? 0 :
+  // p - pixelsPerGroup + 1) (:457-458); for <N,1,1> that is p itself
+  s->period = uint32_t(g.group_size);
+  for (int p = 0; p < g.group_size; ++p) {
+    const int c = !g.sub ? p : (p < g.px_per_group ? 0 : p - g.px_per_group + 1);
+    s->comp_of_phase[p] = d.table_index[c];
+    s->pred_of_phase[p] = uint8_t(c);
+  }
   for (int c = 0; c < g.N; ++c) {
-    s->comp_of_phase[c] = d.table_index[c];
-    s->pred_of_phase[c] = uint8_t(c);
     s->init_pred[c] = d.init_pred[c];
+    // the row predictor comes from predNext(c == 0 ? 0 : groupSize - (N - c)) :443-444
+    s->seed_pos[c] = uint8_t(c == 0 ? 0 : g.group_size - (g.N - c));
   }
   s->row_samples = uint32_t(g.frame_x) * uint32_t(g.group_size);
   // Only the groups that land in the image are decoded: dim.area() groups

@@ -83,6 +83,7 @@ struct StreamGeom {
   uint8_t comp_of_phase[8]; // table slot for symbol index % period
   uint8_t pred_of_phase[8]; // predictor component for symbol index % period
   uint16_t init_pred[4];
+  uint8_t seed_pos[4];      // first sample of predictor component c in a row
   uint32_t table_base;  // index of this job's first DeviceHuffTable
   // LJPEG mapping
   uint32_t kind;        // 0 LJPEG, 1 CR2

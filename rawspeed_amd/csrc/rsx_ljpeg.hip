@@ -119,6 +119,7 @@ struct LjStreamDev {
   uint32_t n_comp;
   uint8_t tab_of_phase[8];
   uint16_t init_pred[4];
+  uint8_t seed_pos[4]; // first sample of component c inside a stream row
   uint32_t rows;
   uint32_t row_samples;
   uint32_t first_row; // global stream-row index
@@ -128,7 +129,6 @@ struct LjStreamDev {
   uint32_t n_strips;
   uint32_t strip_base;
   uint32_t job;
-  uint32_t pad;
 };
 
 struct LjResult {
@@ -1260,7 +1260,9 @@ __global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
 
 // ---------------------------------------------------------------------------
 // K5: predictor seeds of the stream rows
-//   seed(r, c) = init_pred[c] + sum_{r' < r} D[r'][c]   (mod 2^16)
+//   seed(r, c) = init_pred[c] + sum_{r' < r} D[r'][seed_pos[c]]   (mod 2^16)
+// seed_pos[c] = c for interleaved components; (0, gs-2, gs-1) for Canon sRaw
+// groups (Cr2DecompressorImpl.h:443-444).
 // ---------------------------------------------------------------------------
 // 1024 lanes per stream, one row per lane per step (the per-row reads are 8-byte
 // gathers at a pitch of a whole stream row, so they are issued for many rows at
@@ -1285,7 +1287,7 @@ __global__ __launch_bounds__(VS_T) void lj_vseed_kernel(LjArgs a) {
     uint32_t d[4] = {0, 0, 0, 0};
     if (r < rows)
       for (uint32_t c = 0; c < N; ++c)
-        d[c] = uint32_t(int32_t(D[uint64_t(r) * S.row_samples + c]));
+        d[c] = uint32_t(int32_t(D[uint64_t(r) * S.row_samples + S.seed_pos[c]]));
     uint32_t inc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1347,8 +1349,15 @@ __device__ __forceinline__ void lj_store_sample(const LjArgs& a, const LjStreamD
   }
 }
 
-template <int N>
+// P == N: sample s belongs to component s % N.  P != N (N == 3): Canon sRaw
+// groups of P samples, P - 2 luma samples (component 0) then Cb, Cr
+// (Cr2DecompressorImpl.h:455-462).
+template <int N, int P = N>
 __global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
+  constexpr bool DYN = (8 % P) != 0; // lane chunks of 8 do not start on a group
+  auto comp_of = [](int ph) -> int {
+    return P == N ? ph : (ph < P - 2 ? 0 : ph - (P - 3));
+  };
   const uint32_t grow = blockIdx.x * (LJ_T / 64) + (threadIdx.x >> 6);
   if (grow >= a.total_rows)
     return;
@@ -1363,7 +1372,7 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
       hi = mid - 1;
   }
   const LjStreamDev& S = a.streams[lo];
-  if (int(S.n_comp) != N || a.results[lo].status != 0)
+  if (int(S.n_comp) != N || int(S.period) != P || a.results[lo].status != 0)
     return;
   const uint32_t r = grow - S.first_row;
   if (r >= S.rows)
@@ -1403,22 +1412,22 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
     uint32_t v[8];
     v[0] = t.x & 0xFFFF; v[1] = t.x >> 16; v[2] = t.y & 0xFFFF; v[3] = t.y >> 16;
     v[4] = t.z & 0xFFFF; v[5] = t.z >> 16; v[6] = t.w & 0xFFFF; v[7] = t.w >> 16;
-    // component of v[i] is (q + i) % N; rot = q % N (0 unless N == 3)
-    const int rot = (N == 3) ? int(q % 3) : 0;
+    // component of v[i] is comp_of((q + i) % P); rot = q % P (0 unless DYN)
+    const int rot = DYN ? int(q % P) : 0;
     uint32_t run[N];
 #pragma unroll
     for (int c = 0; c < N; ++c)
       run[c] = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int cs = (N == 3) ? (i % 3) : (i % N); // component for rot == 0
-      if (N == 3) {
-        // select by ((rot + i) % 3) without dynamic register indexing
-        const int c = (rot + i) % 3;
+      if (DYN) {
+        // select by component without dynamic register indexing
+        const int c = comp_of((rot + i) % P);
         uint32_t t = (c == 0 ? run[0] : (c == 1 ? run[1 % N] : run[2 % N])) + v[i];
         if (c == 0) run[0] = t; else if (c == 1) run[1 % N] = t; else run[2 % N] = t;
         v[i] = t;
       } else {
+        const int cs = comp_of(i % P);
         run[cs] += v[i];
         v[i] = run[cs];
       }
@@ -1439,11 +1448,11 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      if (N == 3) {
-        const int c = (rot + i) % 3;
+      if (DYN) {
+        const int c = comp_of((rot + i) % P);
         v[i] += (c == 0 ? excl[0] : (c == 1 ? excl[1 % N] : excl[2 % N]));
       } else {
-        v[i] += excl[i % N];
+        v[i] += excl[comp_of(i % P)];
       }
       v[i] &= 0xFFFFu;
     }
@@ -1581,7 +1590,7 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_fast_kernel(LjArgs a) {
       hi = mid - 1;
   }
   const LjStreamDev& S = a.streams[lo];
-  if (int(S.n_comp) != N || a.results[lo].status != 0)
+  if (int(S.n_comp) != N || int(S.period) != N || a.results[lo].status != 0)
     return;
   const uint32_t r = grow - S.first_row;
   if (r >= S.rows)
@@ -1801,7 +1810,7 @@ struct LJpegPlan {
   uint64_t total_diffs = 0;
   int max_tables = 1;
   bool any_multi = false, any_single = false;
-  bool comp_present[5] = {false, false, false, false, false};
+  bool comp_present[7] = {}; // [1..4] interleaved n_comp; [5], [6]: sRaw groups of 4, 6
   DeviceBuffer d_streams, d_tables, d_block_stream, d_strips, d_sub_state,
       d_block_start, d_block_exit, d_block_sum, d_block_base, d_block_drops,
       d_block_drop_base, d_results, d_diffs, d_vseed, d_unstuffed;
@@ -1885,6 +1894,10 @@ void launch_predict(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((lj_predict_kernel<3>), grid, block, 0, s, a);
   if (p->comp_present[4])
     hipLaunchKernelGGL((lj_predict_fast_kernel<4>), grid, block, 0, s, a);
+  if (p->comp_present[5])
+    hipLaunchKernelGGL((lj_predict_kernel<3, 4>), grid, block, 0, s, a);
+  if (p->comp_present[6])
+    hipLaunchKernelGGL((lj_predict_kernel<3, 6>), grid, block, 0, s, a);
 }
 
 } // namespace
@@ -1944,6 +1957,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     S.n_comp = g.n_comp;
     std::memcpy(S.tab_of_phase, g.comp_of_phase, 8);
     std::memcpy(S.init_pred, g.init_pred, sizeof S.init_pred);
+    std::memcpy(S.seed_pos, g.seed_pos, 4);
     S.rows = g.rows;
     S.row_samples = g.row_samples;
     S.first_row = p->total_rows;
@@ -1976,7 +1990,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     p->any_multi |= multi;
     p->any_single |= !multi;
     p->max_tables = std::max(p->max_tables, J.n_tables);
-    p->comp_present[g.n_comp] = true;
+    p->comp_present[g.period == g.n_comp ? g.n_comp : (g.period == 4 ? 5u : 6u)] = true;
     p->job_first_stream[i] = int(p->streams.size());
     p->job_n_streams[i] = 1;
     p->total_blocks += S.n_blocks;

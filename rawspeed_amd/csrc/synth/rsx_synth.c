@@ -215,6 +215,16 @@ static int enc_table_build(enc_table* t, const uint8_t counts[16],
  * rows_per_ri: 0 = no restart markers; else RSTn (n = (i-1)%8) is written
  * between intervals.  fix16: emit 16 extra (zero) bits after an SSSS=16 code.
  * Returns the number of entropy bytes, or 0 on overflow / missing category. */
+size_t rsx_synth_ljpeg_encode_pattern(const uint16_t* samples, size_t row_stride,
+                                      int row_samples, int rows, int n_comp,
+                                      int period, const uint8_t* comp_of_phase,
+                                      const uint16_t* init_pred,
+                                      const uint8_t* const* counts,
+                                      const uint8_t* const* values,
+                                      const int* n_values, int rows_per_ri,
+                                      int fix16, uint8_t* out, size_t cap,
+                                      uint64_t* n_symbol_bits);
+
 size_t rsx_synth_ljpeg_encode_scan(const uint16_t* samples, size_t row_stride,
                                    int row_samples, int rows, int n_comp,
                                    const uint16_t* init_pred,
@@ -223,12 +233,41 @@ size_t rsx_synth_ljpeg_encode_scan(const uint16_t* samples, size_t row_stride,
                                    const int* n_values, int rows_per_ri,
                                    int fix16, uint8_t* out, size_t cap,
                                    uint64_t* n_symbol_bits) {
+  static const uint8_t identity[4] = {0, 1, 2, 3};
+  return rsx_synth_ljpeg_encode_pattern(samples, row_stride, row_samples, rows, n_comp,
+                                        n_comp, identity, init_pred, counts, values,
+                                        n_values, rows_per_ri, fix16, out, cap,
+                                        n_symbol_bits);
+}
+
+/* General form: sample s of a row belongs to component comp_of_phase[s % period]
+ * (period <= 8).  Its predictor is the previous sample of the same component in
+ * the row; for the first one of a row it is init_pred[c] (first row / first row
+ * of a restart interval) or the first sample of that component in the row above.
+ * period == n_comp with the identity map is plain LJPEG predictor 1; period 4
+ * (0,0,1,2) / 6 (0,0,0,0,1,2) are Canon sRaw <3,2,1> / <3,2,2>
+ * (the layout Cr2DecompressorImpl.h:431-465 decodes). */
+size_t rsx_synth_ljpeg_encode_pattern(const uint16_t* samples, size_t row_stride,
+                                      int row_samples, int rows, int n_comp,
+                                      int period, const uint8_t* comp_of_phase,
+                                      const uint16_t* init_pred,
+                                      const uint8_t* const* counts,
+                                      const uint8_t* const* values,
+                                      const int* n_values, int rows_per_ri,
+                                      int fix16, uint8_t* out, size_t cap,
+                                      uint64_t* n_symbol_bits) {
   enc_table tabs[4];
-  if (n_comp < 1 || n_comp > 4)
+  if (n_comp < 1 || n_comp > 4 || period < 1 || period > 8)
     return 0;
   for (int c = 0; c < n_comp; ++c)
     if (enc_table_build(&tabs[c], counts[c], values[c], n_values[c]))
       return 0;
+  int first_pos[4] = {-1, -1, -1, -1};
+  for (int p = period - 1; p >= 0; --p) {
+    if (comp_of_phase[p] >= n_comp)
+      return 0;
+    first_pos[comp_of_phase[p]] = p;
+  }
   jpeg_writer w = {out, cap, 0, 0, 0, 0};
   uint64_t bits = 0;
   for (int r = 0; r < rows; ++r) {
@@ -240,13 +279,15 @@ size_t rsx_synth_ljpeg_encode_scan(const uint16_t* samples, size_t row_stride,
       jw_byte_raw(&w, 0xFF);
       jw_byte_raw(&w, (uint8_t)(0xD0 + ((r / rows_per_ri - 1) % 8)));
     }
+    int last[4] = {-1, -1, -1, -1};
     for (int s = 0; s < row_samples; ++s) {
-      const int c = s % n_comp;
+      const int c = comp_of_phase[s % period];
       uint16_t pred;
-      if (s >= n_comp)
-        pred = cur[s - n_comp];
+      if (last[c] >= 0)
+        pred = cur[last[c]];
       else
-        pred = ri_first ? init_pred[c] : up[s];
+        pred = ri_first ? init_pred[c] : up[first_pos[c]];
+      last[c] = s;
       const int d = (int16_t)(uint16_t)(cur[s] - pred);
       int ssss = 0;
       if (d == -32768) {

@@ -35,6 +35,11 @@ def lib():
             C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p,
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
             C.c_size_t, C.c_void_p]
+        _lib.rsx_synth_ljpeg_encode_pattern.restype = C.c_size_t
+        _lib.rsx_synth_ljpeg_encode_pattern.argtypes = [
+            C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+            C.c_void_p, C.c_size_t, C.c_void_p]
         _lib.rsx_synth_ljpeg_header.restype = C.c_size_t
         _lib.rsx_synth_ljpeg_header.argtypes = [
             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -94,22 +99,30 @@ def _table_ptrs(tables):
     return counts, values, cp, vp, nv
 
 
+SRAW_PATTERN = {4: (0, 0, 1, 2), 6: (0, 0, 0, 0, 1, 2)}  # <3,2,1>, <3,2,2>
+
+
 def ljpeg_encode_scan(stream_rows, n_comp, init_pred, comp_tables,
-                      rows_per_ri=0, fix16=False):
+                      rows_per_ri=0, fix16=False, pattern=None):
     """stream_rows: (rows, frame_w*n_comp) uint16 in stream order.
-    comp_tables: one (counts, values) per component.  Returns
-    (entropy bytes as np.uint8, symbol bits)."""
+    comp_tables: one (counts, values) per component.  pattern: component of
+    sample s is pattern[s % len(pattern)] (default: s % n_comp; SRAW_PATTERN
+    for Canon sRaw groups).  Returns (entropy bytes as np.uint8, symbol bits)."""
     stream_rows = np.ascontiguousarray(stream_rows, dtype=np.uint16)
     rows, row_samples = stream_rows.shape
-    assert row_samples % n_comp == 0 and len(comp_tables) == n_comp
+    if pattern is None:
+        pattern = tuple(range(n_comp))
+    assert row_samples % len(pattern) == 0 and len(comp_tables) == n_comp
     keep = _table_ptrs(comp_tables)
     _, _, cp, vp, nv = keep
     ip = np.asarray(init_pred, dtype=np.uint16)
+    pat = np.asarray(pattern, dtype=np.uint8)
     cap = rows * row_samples * 5 + 4096
     out = np.empty(cap, dtype=np.uint8)
     bits = C.c_uint64(0)
-    n = lib().rsx_synth_ljpeg_encode_scan(
+    n = lib().rsx_synth_ljpeg_encode_pattern(
         stream_rows.ctypes.data, row_samples, row_samples, rows, n_comp,
+        len(pattern), pat.ctypes.data,
         ip.ctypes.data, cp, vp, nv, rows_per_ri, 1 if fix16 else 0,
         out.ctypes.data, cap, C.byref(bits))
     if n == 0:
@@ -119,10 +132,12 @@ def ljpeg_encode_scan(stream_rows, n_comp, init_pred, comp_tables,
 
 def ljpeg_container(stream_rows, n_comp, prec, comp_slot, slot_tables,
                     rows_per_ri=0, fix16=False, frame_wh=None, samp=None,
-                    tail=16):
+                    tail=16, pattern=None):
     """Full SOI..EOI blob.  comp_slot[c] = DHT slot of component c,
     slot_tables[i] = (counts, values) of slot i.  frame_wh overrides the SOF
     (w, h) (e.g. Canon's half-height quirk); default (row_samples/n_comp, rows).
+    samp = per-component (H, V) sampling factors, pattern = the component of
+    each sample of a group (SRAW_PATTERN) for Canon sRaw scans.
     Returns (blob, scan_offset, scan_bytes, symbol_bits)."""
     stream_rows = np.ascontiguousarray(stream_rows, dtype=np.uint16)
     rows, row_samples = stream_rows.shape
@@ -130,7 +145,7 @@ def ljpeg_container(stream_rows, n_comp, prec, comp_slot, slot_tables,
     init_pred = [1 << (prec - 1)] * n_comp
     scan, bits = ljpeg_encode_scan(
         stream_rows, n_comp, init_pred, [slot_tables[s] for s in comp_slot],
-        rows_per_ri, fix16)
+        rows_per_ri, fix16, pattern)
     keep = _table_ptrs(slot_tables)
     _, _, cp, vp, nv = keep
     hdr = np.empty(1024, dtype=np.uint8)

@@ -21,7 +21,10 @@ def smooth_image(rng, h, w, prec=14, sigma=20.0, full_range=False):
     base = rng.integers(1000, maxv - 1000)
     x = np.arange(w)[None, :]
     y = np.arange(h)[:, None]
-    img = base + 3.0 * x + 2.0 * y + rng.normal(0, sigma, size=(h, w))
+    # bounded ramps: wide images must not run into the clip value (a saturated,
+    # constant region is a separate, deliberately slow, case for the decoder)
+    sx, sy = min(3.0, 0.4 * maxv / w), min(2.0, 0.2 * maxv / h)
+    img = base + sx * x + sy * y + rng.normal(0, sigma, size=(h, w))
     return np.clip(img, 0, maxv).astype(np.uint16)
 
 
@@ -109,4 +112,66 @@ def make_cr2_case(rng, img_w, img_h, n_comp, slices, tables=(NIKON,),
     abi.fill_recipe(d, synth.huff_tables(*tables), table_index, init_pred)
     data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8),
                            np.zeros(16, np.uint8)])
+    return d, data, img, len(scan)
+
+
+def cr2_output_tiles(widths, dim_x, dim_y, frame_y):
+    """The Cr2OutputTileIterator walk (Cr2DecompressorImpl.h:104-154) in groups:
+    every slice is frame_y rows tall and wraps to the next output column when it
+    reaches the bottom of the image."""
+    tiles, ox, oy = [], 0, 0
+    for w in widths:
+        left = frame_y
+        while left and ox < dim_x:
+            h = min(left, dim_y - oy)
+            tiles.append((ox, oy, w, h))
+            left -= h
+            oy += h
+            if oy == dim_y:
+                oy, ox = 0, ox + w
+    return tiles
+
+
+def make_cr2_sraw_case(rng, ysf, slices, dim_y, dim_x=None, frame_y=None,
+                       tables=(NIKON,), table_index=(0, 0, 0), prec=14,
+                       full_range=False, with_rows=False, img=None):
+    """Canon sRaw <3,2,ysf> stream (Cr2DecompressorImpl.h:250-275): groups of
+    gs = 2 + 2*ysf samples (Y.. Cb Cr).  `slices` = (num, width, last_width) in
+    GROUPS; the image is dim_x groups (default: sum of the widths) = dim_x*gs
+    samples wide, dim_y rows, cpp 1, not CFA.  frame_y = LJPEG frame rows after
+    the /Y_S_F (default dim_y; smaller values make slices wrap into further
+    output columns); the last frame row may be partial (frame area > image area)."""
+    gs = 2 + 2 * ysf
+    widths = cr2_slices(*slices)
+    if dim_x is None:
+        dim_x = sum(widths)
+    if frame_y is None:
+        frame_y = dim_y
+    if img is None:
+        img = smooth_image(rng, dim_y, dim_x * gs, prec, full_range=full_range)
+    assert img.shape == (dim_y, dim_x * gs)
+    parts = [img[y:y + h, x * gs:(x + w) * gs].reshape(-1)
+             for (x, y, w, h) in cr2_output_tiles(widths, dim_x, dim_y, frame_y)]
+    flat = np.concatenate(parts)
+    assert flat.size == dim_x * gs * dim_y, "tiles do not cover the image"
+    frame_x = -(-dim_x * dim_y // frame_y)
+    row = frame_x * gs
+    pad = frame_y * row - flat.size
+    if pad:  # never decoded (only dim.area() groups are walked)
+        flat = np.concatenate([flat, np.resize(flat, pad)])
+    rows = np.ascontiguousarray(flat.reshape(frame_y, row))
+    init_pred = [1 << (prec - 1)] * 3
+    scan, bits = synth.ljpeg_encode_scan(rows, 3, init_pred,
+                                         [tables[i] for i in table_index],
+                                         pattern=synth.SRAW_PATTERN[gs])
+    d = abi.Cr2Desc()
+    d.n_comp, d.x_s_f, d.y_s_f = 3, 2, ysf
+    d.frame_w, d.frame_h = frame_x * 2, frame_y * ysf
+    d.num_slices = slices[0]
+    d.slice_width, d.last_slice_width = slices[1] * 6, slices[2] * 6
+    abi.fill_recipe(d, synth.huff_tables(*tables), list(table_index), init_pred)
+    data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8),
+                           np.zeros(16, np.uint8)])
+    if with_rows:
+        return d, data, img, len(scan), rows
     return d, data, img, len(scan)

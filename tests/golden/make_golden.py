@@ -39,7 +39,7 @@ def main():
                                    "hash": G.image_hash(img.pixels())}
     for c in G.CR2_CASES:
         d, data, (w, h, cpp), _ = G.build_cr2(c)
-        img = ref.image(w, h, cpp)
+        img = ref.image(w, h, cpp, is_cfa="sraw" not in c)
         st, consumed = ref.cr2(d, data, img)
         out["cr2"][c["name"]] = {"status": st, "consumed": consumed,
                                  "hash": G.image_hash(img.pixels())}

@@ -106,6 +106,16 @@ CR2_CASES = [
          tables=("NIKON", "ALT"), table_index=[0, 1, 1, 0]),
     dict(name="medium", w=672, h=448, n=2, slices=(3, 224, 224)),
     dict(name="large", w=2016, h=640, n=2, slices=(3, 672, 672)),
+    # Canon sRaw: slices in groups, image = sum(widths) * (2 + 2*ysf) samples wide
+    dict(name="sraw_321_one_slice", sraw=1, slices=(1, 0, 24), h=10),
+    dict(name="sraw_321_slices", sraw=1, slices=(3, 40, 24), h=36),
+    dict(name="sraw_322_slices", sraw=2, slices=(3, 32, 20), h=30),
+    dict(name="sraw_322_tables", sraw=2, slices=(2, 48, 16), h=24,
+         tables=("NIKON", "ALT"), table_index=[0, 1, 1]),
+    dict(name="sraw_321_wrapped", sraw=1, slices=(4, 30, 30), h=20, dim_x=60, frame_y=10),
+    dict(name="sraw_322_wrapped_partial", sraw=2, slices=(5, 16, 16), h=21, dim_x=32,
+         frame_y=9),
+    dict(name="sraw_322_medium", sraw=2, slices=(3, 160, 128), h=300),
 ]
 
 
@@ -115,5 +125,11 @@ def build_cr2(c, seed=777):
     if "tables" in c:
         kw["tables"] = tuple(TABLES[t] for t in c["tables"])
         kw["table_index"] = c["table_index"]
+    if "sraw" in c:
+        for k in ("dim_x", "frame_y"):
+            if k in c:
+                kw[k] = c[k]
+        d, data, img, scan_len = C.make_cr2_sraw_case(rng, c["sraw"], c["slices"], c["h"], **kw)
+        return d, data, (img.shape[1], c["h"], 1), img
     d, data, img, scan_len = C.make_cr2_case(rng, c["w"], c["h"], c["n"], c["slices"], **kw)
     return d, data, (c["w"], c["h"], 1), img

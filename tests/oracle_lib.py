@@ -172,6 +172,10 @@ class RefImage:
     def pixels(self):
         return self.u16()[:, :self.dim_x * self.cpp]
 
+    def set_subsampling(self, x, y):
+        """RawImageData::metadata.subsampling (sRaw files)."""
+        self.ref.lib.ref_image_set_subsampling(self.h, x, y)
+
     def close(self):
         if self.h:
             self.ref.lib.ref_image_destroy(self.h)
@@ -197,6 +201,7 @@ class Ref:
         L.ref_image_data.argtypes = [C.c_void_p]
         L.ref_image_pitch.argtypes = [C.c_void_p]
         L.ref_image_fill.argtypes = [C.c_void_p, C.c_int]
+        L.ref_image_set_subsampling.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.ref_unpack_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.ref_unpack_variant_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_size_t]

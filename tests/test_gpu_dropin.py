@@ -69,6 +69,30 @@ def test_cr2_container_slices(pair):
     assert np.array_equal(a[:, :W], src)
 
 
+@pytest.mark.parametrize("ysf", [1, 2])
+def test_cr2_sraw_container(pair, ysf):
+    """Canon sRaw: Cr2LJpegDecoder reads the 2x1 / 2x2 luma sampling factors
+    from the SOF, fixes up the <3,2,1> slice widths (Cr2LJpegDecoder.cpp:88-120)
+    and hands <3,2,ysf> to Cr2Decompressor -> forwarding hunk -> librsx."""
+    rng = np.random.default_rng([35, ysf])
+    groups = (3, 216, 160)
+    d, data, src, _, rows = C.make_cr2_sraw_case(rng, ysf, groups, 300, with_rows=True)
+    blob, _, _, _ = synth.ljpeg_container(
+        rows, 3, 14, [0, 0, 0], [C.NIKON], frame_wh=(d.frame_w, d.frame_h),
+        samp=[(2, ysf), (1, 1), (1, 1)], pattern=synth.SRAW_PATTERN[2 + 2 * ysf])
+    # <3,2,1>: the decoder multiplies the slice widths by 3/2 itself
+    unit = 4 if ysf == 1 else 6
+    h, w = src.shape
+    def run(lib, img):
+        img.set_subsampling(2, ysf)  # what Cr2Decoder sets for sRaw files
+        return lib.cr2_container(blob, img, 3, groups[1] * unit, groups[2] * unit)
+
+    (s0, a, e0), (s1, b, e1) = both(pair, run, (w, h, 1, False))
+    assert s0 == 0 and s1 == 0, (e0, e1)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a[:, :w], src)
+
+
 @pytest.mark.parametrize("threads", [1, 4])
 def test_dng_ljpeg_tiles_through_reference_fanout(pair, threads):
     """AbstractDngDecompressor::decompress(): odd-sized image, 2x3 tiles; with 4

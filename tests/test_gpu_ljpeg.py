@@ -40,7 +40,8 @@ def test_ljpeg_golden(gpu, oracle, c):
 @pytest.mark.parametrize("c", G.CR2_CASES, ids=lambda c: c["name"])
 def test_cr2_golden(gpu, oracle, c):
     d, data, (w, h, cpp), src = G.build_cr2(c)
-    img, want = HostImage(w, h, cpp), HostImage(w, h, cpp)
+    cfa = "sraw" not in c
+    img, want = HostImage(w, h, cpp, is_cfa=cfa), HostImage(w, h, cpp, is_cfa=cfa)
     st, consumed = gpu.cr2_decode(d, data, img.view())
     g = GOLD["cr2"][c["name"]]
     assert (st, consumed) == oracle.cr2(d, data, want) == (g["status"], g["consumed"])
@@ -109,6 +110,56 @@ def test_cr2_wrapped_slices(gpu, oracle):
     assert so[0] == 0
     assert gpu.cr2_decode(d, data, img.view()) == so
     assert np.array_equal(img.u16(), want.u16())
+
+
+@pytest.mark.parametrize("ysf,slices,dim_y,kw", [
+    (1, (1, 0, 1296), 300, {}),
+    (1, (3, 432, 432), 300, {}),
+    (2, (3, 320, 224), 260, {}),
+    (2, (4, 216, 216), 240, dict(dim_x=432, frame_y=120)),              # wrapped slices
+    (1, (3, 432, 432), 200, dict(tables=(C.NIKON, C.ALT), table_index=(0, 1, 1))),
+    (2, (2, 400, 464), 200, dict(tables=(C.FULL17,), full_range=True, prec=16)),
+])
+def test_cr2_sraw_vs_oracle(gpu, oracle, ysf, slices, dim_y, kw):
+    """Canon sRaw <3,2,1> / <3,2,2>: groups of 4 / 6 samples, luma predicted
+    along the group, chroma from the previous group, row predictors from the
+    first group of the previous frame row (Cr2DecompressorImpl.h:431-465)."""
+    rng = np.random.default_rng([96, ysf, slices[0], dim_y])
+    d, data, src, _ = C.make_cr2_sraw_case(rng, ysf, slices, dim_y, **kw)
+    h, w = src.shape
+    img, want = HostImage(w, h, is_cfa=False), HostImage(w, h, is_cfa=False)
+    so = oracle.cr2(d, data, want)
+    sg = gpu.cr2_decode(d, data, img.view())
+    assert sg == so and so[0] == 0
+    assert np.array_equal(img.u16(), want.u16())
+    assert np.array_equal(img.pixels(), src)
+
+
+def test_cr2_sraw_corrupt_streams(gpu, oracle):
+    rng = np.random.default_rng(6)
+    d, data, src, _ = C.make_cr2_sraw_case(rng, 2, (3, 160, 128), 120)
+    h, w = src.shape
+    n_ok = n_fail = 0
+    for trial in range(16):
+        bad = data.copy()
+        if trial % 4 == 0:
+            bad = bad[:rng.integers(64, len(bad) // 2)]
+        elif trial % 4 == 1:
+            bad[rng.integers(0, len(bad) - 40)] = 0xFF
+        else:
+            idx = rng.integers(0, len(bad) - 40, size=3)
+            bad[idx] = rng.integers(0, 256, size=3)
+        img, want = HostImage(w, h, is_cfa=False), HostImage(w, h, is_cfa=False)
+        so = oracle.cr2(d, bad, want)
+        sg = gpu.cr2_decode(d, bad, img.view())
+        assert sg[0] == so[0], (trial, sg, so)
+        if so[0] == 0:
+            n_ok += 1
+            assert sg == so
+            assert np.array_equal(img.u16(), want.u16())
+        else:
+            n_fail += 1
+    assert n_ok and n_fail
 
 
 def test_ljpeg_corrupt_streams(gpu, oracle):
@@ -231,3 +282,29 @@ def test_cfg4_dng_tiles_full_size_roundtrip(gpu):
     got = got.view(np.uint16).reshape(H, out_pitch(W, 1) // 2)[:, :W]
     assert cons == lens
     assert np.array_equal(got, src)
+
+
+def test_constant_regions_converge(gpu, oracle):
+    """Blown highlights: inside a run of identical samples the bit stream is
+    periodic and a mis-aligned speculative parse can cycle without ever meeting
+    the true one (e.g. the Nikon table's SSSS=0 code '111110' repeated), so
+    those subsequences only get their entry state by propagation.  Slow path,
+    same result."""
+    rng = np.random.default_rng(44)
+    W, H = 2048, 96
+    src = C.smooth_image(rng, H, W)
+    src[10:60, 300:1900] = 16383           # saturated block, many subsequences long
+    src[70:, :] = 0                        # black rows: whole workgroups of zeros
+    rows = C.cr2_stream_from_image(src, 2, W // 2, H, [W])
+    scan, _ = synth.ljpeg_encode_scan(rows, 2, [1 << 13] * 2, [C.NIKON, C.NIKON])
+    d = abi.Cr2Desc()
+    d.n_comp, d.x_s_f, d.y_s_f = 2, 1, 1
+    d.frame_w, d.frame_h = W // 2, H
+    d.num_slices, d.slice_width, d.last_slice_width = 1, 0, W
+    abi.fill_recipe(d, synth.huff_tables(C.NIKON), [0, 0], [1 << 13] * 2)
+    data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), np.zeros(16, np.uint8)])
+    img, want = HostImage(W, H), HostImage(W, H)
+    so = oracle.cr2(d, data, want)
+    assert so[0] == 0 and gpu.cr2_decode(d, data, img.view()) == so
+    assert np.array_equal(img.u16(), want.u16())
+    assert np.array_equal(img.pixels(), src)

@@ -50,7 +50,7 @@ def test_ljpeg_golden(oracle, c):
 @pytest.mark.parametrize("c", G.CR2_CASES, ids=lambda c: c["name"])
 def test_cr2_golden(oracle, c):
     d, data, (w, h, cpp), src = G.build_cr2(c)
-    img = HostImage(w, h, cpp)
+    img = HostImage(w, h, cpp, is_cfa="sraw" not in c)
     st, consumed = oracle.cr2(d, data, img)
     g = GOLD["cr2"][c["name"]]
     assert (st, consumed) == (g["status"], g["consumed"])
@@ -165,7 +165,8 @@ def test_ljpeg_corrupt_streams_vs_ref(oracle, ref):
 @pytest.mark.parametrize("c", G.CR2_CASES, ids=lambda c: c["name"])
 def test_cr2_vs_ref(oracle, ref, c):
     d, data, (w, h, cpp), _ = G.build_cr2(c)
-    hi, ri = HostImage(w, h, cpp), ref.image(w, h, cpp)
+    cfa = "sraw" not in c
+    hi, ri = HostImage(w, h, cpp, is_cfa=cfa), ref.image(w, h, cpp, is_cfa=cfa)
     assert oracle.cr2(d, data, hi) == ref.cr2(d, data, ri)
     assert np.array_equal(hi.u16(), ri.u16())
 
