@@ -227,6 +227,44 @@ int rsx_cr2_decode(rsx_ctx* ctx, const rsx_cr2_desc* d, const uint8_t* in,
                    size_t in_bytes, const rsx_image* img, uint32_t* consumed);
 
 /* ------------------------------------------------------------------------ */
+/* 3b. NikonDecompressor                                                     */
+/*    replaces NikonDecompressor::decompress(input, uncorrectedRawValues)    */
+/*    (decompressors/NikonDecompressor.h:57, .cpp:541-560 ->                 */
+/*    decompress<Huffman>(bits, start_y, end_y) :515-539).  The constructor  */
+/*    (.cpp:473-513: metadata parsing, createCurve :381-445) stays on the    */
+/*    host; its results are the fields below.                                */
+/*      - bit stream: BitStreamerMSB over `in` (no byte stuffing, no markers)*/
+/*      - tables[0] = nikon_tree[huffSelect] decoded by PrefixCodeDecoder<>  */
+/*        (full decode, no DNG bug); rows >= split (if split != 0) use       */
+/*        tables[1] = nikon_tree[huffSelect + 1] with the "lossy after       */
+/*        split" semantics of NikonLASDecompressor::decodeDifference         */
+/*        (.cpp:331-376): code value v -> len = v & 15, shl = v >> 4,        */
+/*        len - shl raw bits, diff = ((bits << 1) + 1) << shl >> 1, sign     */
+/*        extension on bit len-1; v == 16 -> -32768                          */
+/*      - predictor: int accumulators pred[col & 1] seeded from              */
+/*        pUp[row & 1][col & 1], which the first two columns update          */
+/*      - output: clampBits(pred, 15), then RawImageData::setWithLookUp      */
+/*        (common/RawImage.h:335-353): as is when uncorrected_raw_values,    */
+/*        else through the dithering TableLookUp built from `curve`          */
+/*        (common/TableLookUp.cpp:50-84) with the serial random state seeded */
+/*        from bits.peekBits(24) (.cpp:549)                                  */
+/* ------------------------------------------------------------------------ */
+typedef struct rsx_nikon_desc {
+  int32_t bits_ps; /* 12 or 14 (.cpp:485-491) */
+  int32_t split;   /* 0 = no split (already clamped against dim.y, .cpp:511-512) */
+  int32_t p_up[2][2]; /* pUp[row & 1][col & 1] (.cpp:506-509) */
+  int32_t uncorrected_raw_values;
+  int32_t curve_size;    /* entries of `curve` (1 .. 65536) */
+  const uint16_t* curve; /* host pointer; copied during the call */
+  rsx_huff_table tables[2];
+} rsx_nikon_desc;
+
+int rsx_nikon_validate(const rsx_nikon_desc* d, const rsx_image* img);
+
+int rsx_nikon_decompress(rsx_ctx* ctx, const rsx_nikon_desc* d, const uint8_t* in,
+                         size_t in_bytes, const rsx_image* img);
+
+/* ------------------------------------------------------------------------ */
 /* 4. AbstractDngDecompressor tile fan-out                                   */
 /*    replaces AbstractDngDecompressor::decompress()                         */
 /*    (AbstractDngDecompressor.h:141, .cpp:240-252) for compression 1        */
@@ -305,6 +343,14 @@ typedef struct rsx_cr2_job {
   rsx_image img; /* .data ignored */
 } rsx_cr2_job;
 
+typedef struct rsx_nikon_job {
+  rsx_nikon_desc desc; /* desc.curve: host pointer, copied at plan creation */
+  uint64_t in_offset;
+  uint64_t in_bytes;
+  uint64_t img_offset;
+  rsx_image img; /* .data ignored */
+} rsx_nikon_job;
+
 int rsx_unpack_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_unpack_job* jobs,
                            rsx_plan** out_plan);
 int rsx_unpack_variant_plan_create(rsx_ctx* ctx, int n_jobs,
@@ -314,6 +360,10 @@ int rsx_ljpeg_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_ljpeg_job* jobs,
                           rsx_plan** out_plan);
 int rsx_cr2_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_cr2_job* jobs,
                         rsx_plan** out_plan);
+/* (jobs with split != 0 cost one host round trip per run: the second table
+ * starts at a bit position only known once the first part is decoded) */
+int rsx_nikon_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_nikon_job* jobs,
+                          rsx_plan** out_plan);
 /* Enqueue one pass of the plan on `stream`. */
 int rsx_plan_run(rsx_plan* plan, const void* in_dev, void* out_dev,
                  void* stream);

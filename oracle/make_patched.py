@@ -107,6 +107,42 @@ HUNK_CR2 = r'''
   }
 '''
 
+HUNK_NIKON = r'''
+  // ---- rsx: forward to the MI355X core (INTEGRATION.md 3b) ----
+  {
+    rsx_nikon_desc d{};
+    d.bits_ps = implicit_cast<int32_t>(bitsPS);
+    d.split = implicit_cast<int32_t>(split);
+    for (int r = 0; r < 2; ++r)
+      for (int c = 0; c < 2; ++c)
+        d.p_up[r][c] = pUp[r][c];
+    d.uncorrected_raw_values = uncorrectedRawValues;
+    d.curve = curve.data();
+    d.curve_size = implicit_cast<int32_t>(curve.size());
+    for (int t = 0; t < (split ? 2 : 1); ++t) {
+      const auto& tree = nikon_tree[huffSelect + t];
+      int n = 0;
+      for (int i = 0; i < 16; ++i) {
+        d.tables[t].n_codes_per_length[i] = tree[0][i];
+        n += tree[0][i];
+      }
+      for (int i = 0; i < n; ++i)
+        d.tables[t].code_values[i] = tree[1][i];
+      d.tables[t].n_code_values = implicit_cast<uint8_t>(n);
+    }
+    const rsx_image img = rsx_shim::view(mRaw);
+    if (int st = rsx_nikon_decompress(rsx_shim::context(), &d, input.begin(),
+                                      implicit_cast<size_t>(input.size()), &img))
+      rsx_shim::raise(st);
+    // what ~RawImageCurveGuard leaves behind (common/RawImage.h:376-382)
+    if (uncorrectedRawValues)
+      mRaw->setTable(curve, false);
+    else
+      mRaw->setTable(nullptr);
+    return;
+  }
+'''
+
 PATCHES = [
     ("decompressors/UncompressedDecompressor.cpp", [
         ("void UncompressedDecompressor::readUncompressedRaw() {", HUNK_UNPACK),
@@ -114,6 +150,9 @@ PATCHES = [
         ("void UncompressedDecompressor::decode12BitRawWithControl() {", HUNK_CONTROL),
         ("void UncompressedDecompressor::decode12BitRawUnpackedLeftAligned() {", HUNK_LEFT),
     ]),
+    ("decompressors/NikonDecompressor.cpp", [
+        ("void NikonDecompressor::decompress(Array1DRef<const uint8_t> input,\n"
+         "                                   bool uncorrectedRawValues) {", HUNK_NIKON)]),
     ("decompressors/LJpegDecompressor.cpp", [
         ("ByteStream::size_type LJpegDecompressor::decode() const {", HUNK_LJPEG)]),
     ("decompressors/Cr2DecompressorImpl.h", [

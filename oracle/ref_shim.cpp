@@ -29,6 +29,7 @@
 #include "decompressors/Cr2LJpegDecoder.h"
 #include "decompressors/LJpegDecoder.h"
 #include "decompressors/LJpegDecompressor.h"
+#include "decompressors/NikonDecompressor.h"
 #include "decompressors/UncompressedDecompressor.h"
 #include "io/Buffer.h"
 #include "io/ByteStream.h"
@@ -275,6 +276,21 @@ int ref_ljpeg_decode_container(void* h, const uint8_t* blob, size_t blob_bytes,
     LJpegDecoder d(bs, r->img);
     d.decode(off_x, off_y, w, hgt, iPoint2D(max_dim_x, max_dim_y),
              fix_dng_bug16 != 0);
+  });
+}
+
+// NikonDecompressor, driven the way NefDecoder does (NefDecoder.cpp:133-135):
+// the constructor parses the makernote linearisation blob (`meta`, big-endian
+// TIFF entry data).
+int ref_nikon_decompress(void* h, const uint8_t* meta, size_t meta_bytes,
+                         uint32_t bits_ps, const uint8_t* in, size_t in_bytes,
+                         int uncorrected_raw_values) {
+  auto* r = static_cast<RefImage*>(h);
+  return guarded([&] {
+    const Buffer mb(meta, implicit_cast<Buffer::size_type>(meta_bytes));
+    NikonDecompressor n(r->img, ByteStream(DataBuffer(mb, Endianness::big)), bits_ps);
+    n.decompress(Array1DRef<const uint8_t>(in, implicit_cast<int>(in_bytes)),
+                 uncorrected_raw_values != 0);
   });
 }
 

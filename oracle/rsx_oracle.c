@@ -970,3 +970,237 @@ int oracle_cr2_decode(const rsx_cr2_desc* d, const uint8_t* in, size_t in_bytes,
     *consumed = (uint32_t)br_jpeg_stream_position(&b); /* :467 */
   return RSX_OK;
 }
+
+/* ======================================================================== */
+/* NikonDecompressor (decompressors/NikonDecompressor.cpp)                    */
+/* ======================================================================== */
+
+/* NikonLASDecompressor (.cpp:79-377): JPEG Annex C/F tables of the "lossy
+ * after split" trees.  The 14-bit bigTable (:225-294) is an accelerator with
+ * the same results as this slow path for every entry it accepts (plain SSSS
+ * values with code + SSSS <= 14 bits); everything else falls through to it. */
+typedef struct lastab {
+  int bits[17];
+  int huffval[256];
+  int mincode[17];
+  int maxcode[18];
+  int valptr[17];
+  int numbits[256];
+} lastab;
+
+static int las_validate(const rsx_huff_table* t) {
+  unsigned total = 0;
+  uint32_t code = 0;
+  for (int l = 1; l <= 16; ++l) {
+    const unsigned n = t->n_codes_per_length[l - 1];
+    total += n;
+    code += n;
+    if (code > (1u << l))
+      return RSX_ERR_INVALID_ARG;
+    code <<= 1;
+  }
+  if (total == 0 || total > RSX_MAX_CODE_VALUES || total != t->n_code_values)
+    return RSX_ERR_INVALID_ARG;
+  /* values the reference cannot decode without undefined behaviour
+   * (getBits(len - shl) with a negative count, :373) are rejected */
+  for (unsigned i = 0; i < total; ++i) {
+    const unsigned v = t->code_values[i];
+    if (v != 16 && (v >> 4) != 0 && (v >> 4) >= (v & 15u))
+      return RSX_ERR_INVALID_ARG; /* getBits(<= 0) */
+  }
+  return RSX_OK;
+}
+
+/* createPrefixCodeDecoder :108-213 */
+static void las_setup(lastab* t, const rsx_huff_table* h) {
+  int huffsize[258], huffcode[258];
+  int p = 0;
+  memset(t, 0, sizeof *t);
+  for (int l = 1; l <= 16; ++l) {
+    t->bits[l] = h->n_codes_per_length[l - 1];
+    for (int i = 1; i <= t->bits[l]; ++i)
+      huffsize[p++] = l; /* Figure C.1 */
+  }
+  huffsize[p] = 0;
+  const int lastp = p;
+  for (int i = 0; i < h->n_code_values; ++i)
+    t->huffval[i] = h->code_values[i];
+  int code = 0, si = huffsize[0];
+  p = 0;
+  while (huffsize[p]) { /* Figure C.2 */
+    while (huffsize[p] == si)
+      huffcode[p++] = code++;
+    code <<= 1;
+    si++;
+  }
+  p = 0;
+  for (int l = 1; l <= 16; ++l) { /* Figure F.15 */
+    if (t->bits[l]) {
+      t->valptr[l] = p;
+      t->mincode[l] = huffcode[p];
+      p += t->bits[l];
+      t->maxcode[l] = huffcode[p - 1];
+    } else {
+      t->valptr[l] = 0xff;
+      t->maxcode[l] = -1;
+    }
+  }
+  t->maxcode[17] = 0xFFFFF;
+  for (p = 0; p < lastp; ++p) { /* :188-206 */
+    const int size = huffsize[p];
+    if (size <= 8) {
+      const int ll = huffcode[p] << (8 - size);
+      const int ul = size < 8 ? (ll | ((1 << (8 - size)) - 1)) : ll;
+      for (int i = ll; i <= ul && i < 256; ++i)
+        t->numbits[i] = size | (t->huffval[p] << 4);
+    }
+  }
+}
+
+/* decodeDifference :331-376 */
+static int las_decode_diff(const lastab* t, bitreader* b, int* err) {
+  br_fill(b, 32);
+  if (b->err) {
+    *err = b->err;
+    return 0;
+  }
+  int rv;
+  int code = (int)br_peek_nofill(b, 8);
+  const int val = t->numbits[code];
+  int l = val & 15;
+  if (l) {
+    br_skip_nofill(b, l);
+    rv = val >> 4;
+  } else {
+    br_skip_nofill(b, 8);
+    l = 8;
+    while (code > t->maxcode[l]) {
+      code = (code << 1) | (int)br_get_nofill(b, 1);
+      l++;
+    }
+    if (l > 16) {
+      *err = RSX_ERR_BAD_HUFFMAN_CODE; /* "Corrupt JPEG data: bad Huffman code" */
+      return 0;
+    }
+    rv = t->huffval[t->valptr[l] + (code - t->mincode[l])];
+  }
+  if (rv == 16)
+    return -32768;
+  const int len = rv & 15, shl = rv >> 4;
+  if (len == 0)
+    return 0; /* bigTable entry "rv == 0" :290-291 */
+  const int nb = len - shl;
+  const uint32_t bits = nb ? br_get(b, nb) : 0;
+  if (b->err) {
+    *err = b->err;
+    return 0;
+  }
+  int diff = (int)((((bits << 1) + 1) << shl) >> 1);
+  if ((diff & (1 << (len - 1))) == 0)
+    diff -= (1 << len) - !shl;
+  return diff;
+}
+
+int oracle_nikon_validate(const rsx_nikon_desc* d, const rsx_image* img) {
+  if (img->cpp != 1)
+    return RSX_ERR_INVALID_ARG; /* :476-478 */
+  if (img->dim_x <= 0 || img->dim_y <= 0 || img->dim_x % 2 != 0 ||
+      img->dim_x > 8288 || img->dim_y > 5520)
+    return RSX_ERR_INVALID_ARG; /* :480-483 */
+  if (d->bits_ps != 12 && d->bits_ps != 14)
+    return RSX_ERR_INVALID_ARG; /* :485-491 */
+  if (d->split < 0 || d->split >= img->dim_y)
+    return RSX_ERR_INVALID_ARG; /* :511-512: out-of-image splits arrive as 0 */
+  for (int i = 0; i < 4; ++i)
+    if ((&d->p_up[0][0])[i] < 0 || (&d->p_up[0][0])[i] > 65535)
+      return RSX_ERR_INVALID_ARG; /* getU16 :506-509 */
+  if (!d->uncorrected_raw_values &&
+      (d->curve == NULL || d->curve_size < 1 || d->curve_size > 65536))
+    return RSX_ERR_INVALID_ARG; /* TableLookUp.cpp:50-57 */
+  hufftab h;
+  int st = huff_setup(&h, &d->tables[0]);
+  if (st)
+    return st;
+  if (d->tables[0].fix_dng_bug16)
+    return RSX_ERR_INVALID_ARG; /* ht.setup(true, false) :468 */
+  if (d->split != 0 && (st = las_validate(&d->tables[1])))
+    return st;
+  return RSX_OK;
+}
+
+/* decompress(input, uncorrectedRawValues) :541-560 and
+ * decompress<Huffman>(bits, start_y, end_y) :515-539, with
+ * RawImageDataU16::setWithLookUp (common/RawImage.h:335-353) and
+ * TableLookUp::setTable (common/TableLookUp.cpp:50-84) inlined. */
+int oracle_nikon_decompress(const rsx_nikon_desc* d, const uint8_t* in,
+                            size_t in_bytes, const rsx_image* img) {
+  int st = oracle_nikon_validate(d, img);
+  if (st)
+    return st;
+  /* the dithering table (RawImageCurveGuard -> setTable(curve, true)) */
+  uint16_t* tab = NULL;
+  if (!d->uncorrected_raw_values) {
+    tab = (uint16_t*)malloc(2 * 65536 * sizeof(uint16_t));
+    const int n = d->curve_size;
+    for (int i = 0; i < 65536; ++i) {
+      if (i < n) {
+        const int center = d->curve[i];
+        int lower = i > 0 ? d->curve[i - 1] : center;
+        int upper = i < n - 1 ? d->curve[i + 1] : center;
+        if (lower > center)
+          lower = center;
+        if (upper < center)
+          upper = center;
+        const int delta = upper - lower;
+        int base = center - ((upper - lower + 2) / 4);
+        base = base < 0 ? 0 : (base > 65535 ? 65535 : base);
+        tab[2 * i] = (uint16_t)base;
+        tab[2 * i + 1] = (uint16_t)delta;
+      } else {
+        tab[2 * i] = d->curve[n - 1];
+        tab[2 * i + 1] = 0;
+      }
+    }
+  }
+  bitreader b;
+  br_init(&b, in, (int64_t)in_bytes, RSX_ORDER_MSB);
+  if (b.err) {
+    free(tab);
+    return b.err;
+  }
+  br_fill(&b, 24);
+  uint32_t random = br_peek_nofill(&b, 24); /* :549 */
+  hufftab h0;
+  lastab h1;
+  huff_setup(&h0, &d->tables[0]);
+  if (d->split)
+    las_setup(&h1, &d->tables[1]);
+  int pup[2][2] = {{d->p_up[0][0], d->p_up[0][1]}, {d->p_up[1][0], d->p_up[1][1]}};
+  const int W = img->dim_x, H = img->dim_y;
+  int err = 0;
+  for (int row = 0; row < H && !err; ++row) {
+    const int after = d->split && row >= d->split;
+    int pred[2] = {pup[row & 1][0], pup[row & 1][1]};
+    uint16_t* o = (uint16_t*)((uint8_t*)img->data + (size_t)row * img->pitch_bytes);
+    for (int col = 0; col < W; ++col) {
+      pred[col & 1] += after ? las_decode_diff(&h1, &b, &err)
+                             : huff_decode_diff(&h0, &b, &err);
+      if (err)
+        break;
+      if (col < 2)
+        pup[row & 1][col & 1] = pred[col & 1];
+      int v = pred[col & 1];
+      v = v < 0 ? 0 : (v > 32767 ? 32767 : v); /* clampBits(.., 15) */
+      if (!tab) {
+        o[col] = (uint16_t)v;
+      } else {
+        const uint32_t base = tab[2 * v], delta = tab[2 * v + 1];
+        o[col] = (uint16_t)(base + ((delta * (random & 2047) + 1024) >> 12));
+        random = 15700 * (random & 65535) + (random >> 16);
+      }
+    }
+  }
+  free(tab);
+  return err;
+}
+

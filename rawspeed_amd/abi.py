@@ -6,6 +6,8 @@ oracle (tests/oracle_lib.py), which use the same descriptors.
 """
 import ctypes as C
 
+import numpy as np
+
 RSX_ABI_VERSION = 1
 
 # rsx_status
@@ -98,6 +100,19 @@ class Cr2Desc(C.Structure):
                 ("tables", HuffTable * RSX_MAX_COMPONENTS)]
 
 
+class NikonDesc(C.Structure):
+    _fields_ = [("bits_ps", C.c_int32), ("split", C.c_int32),
+                ("p_up", (C.c_int32 * 2) * 2),
+                ("uncorrected_raw_values", C.c_int32), ("curve_size", C.c_int32),
+                ("curve", C.c_void_p), ("tables", HuffTable * 2)]
+
+    def set_curve(self, curve):
+        """Keeps the numpy array alive on the descriptor."""
+        self._curve = np.ascontiguousarray(curve, dtype=np.uint16)
+        self.curve = self._curve.ctypes.data
+        self.curve_size = self._curve.size
+
+
 class DngLJpegTile(C.Structure):
     _fields_ = [("desc", LJpegDesc), ("in_", C.c_void_p),
                 ("in_bytes", C.c_size_t)]
@@ -122,6 +137,12 @@ class UnpackVariantJob(C.Structure):
 
 class LJpegJob(C.Structure):
     _fields_ = [("desc", LJpegDesc), ("in_offset", C.c_uint64),
+                ("in_bytes", C.c_uint64), ("img_offset", C.c_uint64),
+                ("img", Image)]
+
+
+class NikonJob(C.Structure):
+    _fields_ = [("desc", NikonDesc), ("in_offset", C.c_uint64),
                 ("in_bytes", C.c_uint64), ("img_offset", C.c_uint64),
                 ("img", Image)]
 

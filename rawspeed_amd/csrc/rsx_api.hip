@@ -763,6 +763,70 @@ extern "C" int rsx_cr2_plan_create(rsx_ctx* ctx, int n_jobs,
   return RSX_OK;
 }
 
+extern "C" int rsx_nikon_validate(const rsx_nikon_desc* d, const rsx_image* img) {
+  if (!d || !img)
+    return RSX_ERR_INVALID_ARG;
+  return validate_nikon(*d, *img);
+}
+
+extern "C" int rsx_nikon_plan_create(rsx_ctx* ctx, int n_jobs,
+                                     const rsx_nikon_job* jobs, rsx_plan** out_plan) {
+  if (!ctx || !jobs || n_jobs < 1 || !out_plan)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto plan = std::make_unique<rsx_plan>();
+  plan->ctx = ctx;
+  plan->kind = PLAN_LJPEG;
+  plan->n_jobs = n_jobs;
+  std::vector<LJpegJobIn> in(n_jobs);
+  for (int i = 0; i < n_jobs; ++i) {
+    const rsx_nikon_desc& d = jobs[i].desc;
+    const rsx_image& img = jobs[i].img;
+    LJpegJobIn& J = in[i];
+    J.status = validate_nikon(d, img);
+    if (J.status == RSX_OK && img.pitch_bytes % 2 != 0)
+      J.status = RSX_ERR_INVALID_ARG;
+    if (J.status != RSX_OK)
+      continue;
+    StreamGeom& g = J.geom;
+    std::memset(&g, 0, sizeof g);
+    g.kind = 2;
+    g.raw = 1;
+    g.in_offset = jobs[i].in_offset;
+    g.in_bytes = jobs[i].in_bytes;
+    g.img_offset = jobs[i].img_offset;
+    g.img_pitch_bytes = img.pitch_bytes;
+    // one table for the whole stream: the two columns alternate (:525-527) but
+    // share it, so the "component" only matters to the reconstruction
+    g.n_comp = 2;
+    g.period = 2;
+    g.rows = uint32_t(d.split ? d.split : img.dim_y); // decompress(bits, 0, split) :555-556
+    g.row_samples = uint32_t(img.dim_x);
+    g.mcu_w = g.mcu_h = 1;
+    g.keep_samples = g.row_samples;
+    J.tables = &d.tables[0];
+    J.n_tables = 1;
+    NikonIn& N = J.nikon;
+    for (int k = 0; k < 4; ++k)
+      N.p_up[k] = (&d.p_up[0][0])[k];
+    N.uncorrected = d.uncorrected_raw_values != 0;
+    N.split = d.split;
+    N.height = img.dim_y;
+    N.seed_offset = jobs[i].in_offset;
+    if (d.split)
+      N.table_after_split = d.tables[1];
+    if (!N.uncorrected)
+      build_dither_table(d.curve, d.curve_size, &N.dither);
+  }
+  LJpegPlan* lp = nullptr;
+  if (int st = ljpeg_plan_create(ctx, in, &lp))
+    return st;
+  plan->ljpeg.reset(lp);
+  *out_plan = plan.release();
+  return RSX_OK;
+}
+
 namespace {
 
 // Generic host-pointer runner for LJPEG-family jobs sharing one host image.
@@ -775,6 +839,9 @@ HostRect out_rect(const rsx_ljpeg_job& j) {
           size_t(j.desc.tile_x) * j.img.cpp * 2, size_t(j.desc.tile_w) * j.img.cpp * 2};
 }
 HostRect out_rect(const rsx_cr2_job& j) {
+  return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
+}
+HostRect out_rect(const rsx_nikon_job& j) {
   return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
 }
 
@@ -870,6 +937,18 @@ extern "C" int rsx_cr2_decode(rsx_ctx* ctx, const rsx_cr2_desc* d,
   if (consumed)
     *consumed = c;
   return rc;
+}
+
+extern "C" int rsx_nikon_decompress(rsx_ctx* ctx, const rsx_nikon_desc* d,
+                                    const uint8_t* in, size_t in_bytes,
+                                    const rsx_image* img) {
+  if (!ctx || !d || !in || !img || !img->data)
+    return RSX_ERR_INVALID_ARG;
+  std::vector<rsx_nikon_job> jobs(1);
+  jobs[0].desc = *d;
+  jobs[0].in_bytes = in_bytes;
+  int32_t st = RSX_OK;
+  return ljpeg_family_host(ctx, 1, jobs, &in, img, rsx_nikon_plan_create, &st, nullptr);
 }
 
 extern "C" int rsx_dng_decompress_ljpeg(rsx_ctx* ctx, int n_tiles,

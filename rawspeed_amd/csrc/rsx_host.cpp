@@ -128,8 +128,34 @@ int validate_huff_table(const rsx_huff_table& t) {
 
 // Canonical code -> device table.  Symbol semantics:
 // AbstractPrefixCodeDecoder::processSymbol (AbstractPrefixCodeDecoder.h:43-66).
-void build_device_table(const rsx_huff_table& t, DeviceHuffTable* out) {
+// NikonLASDecompressor (NikonDecompressor.cpp:79-377) takes any DHT-style table
+// and has undefined behaviour for values it cannot decode; we accept what it can:
+// a canonical code (no length overflowing its code space) whose values are 16
+// (-32768), a plain SSSS 0..15, or len | shl << 4 with 0 < shl < len.
+int validate_las_table(const rsx_huff_table& t) {
+  unsigned total = 0;
+  uint32_t code = 0;
+  for (int l = 1; l <= 16; ++l) {
+    const unsigned n = t.n_codes_per_length[l - 1];
+    total += n;
+    code += n;
+    if (code > (1u << l))
+      return RSX_ERR_INVALID_ARG;
+    code <<= 1;
+  }
+  if (total == 0 || total > RSX_MAX_CODE_VALUES || total != t.n_code_values)
+    return RSX_ERR_INVALID_ARG;
+  for (unsigned i = 0; i < total; ++i) {
+    const unsigned v = t.code_values[i];
+    if (v != 16 && (v >> 4) != 0 && (v >> 4) >= (v & 15u))
+      return RSX_ERR_INVALID_ARG; // getBits(len - shl <= 0) in the reference
+  }
+  return RSX_OK;
+}
+
+void build_device_table(const rsx_huff_table& t, DeviceHuffTable* out, bool las) {
   std::memset(out, 0, sizeof *out);
+  out->las = las ? 1 : 0;
   int max_len = 16;
   while (max_len > 0 && t.n_codes_per_length[max_len - 1] == 0)
     --max_len;
@@ -146,8 +172,11 @@ void build_device_table(const rsx_huff_table& t, DeviceHuffTable* out) {
       out->val_offset[l] = uint16_t(code - k);
       out->max_code[l] = code + n - 1;
       for (unsigned i = 0; i < n; ++i, ++k, ++code) {
-        const unsigned ssss = t.code_values[k];
-        unsigned total = l + (ssss == 16 ? (out->fix16 ? 16u : 0u) : ssss);
+        const unsigned val = t.code_values[k];
+        // LAS: the SSSS field holds len, the stream carries len - shl bits
+        const unsigned ssss = (las && val != 16) ? (val & 15u) : val;
+        unsigned total = l + (ssss == 16 ? (out->fix16 ? 16u : 0u)
+                                         : (las ? ssss - (val >> 4) : ssss));
         if (l <= LUT_BITS) {
           const uint16_t e = uint16_t(l | (ssss << 5) | (total << 10));
           const uint32_t lo = code << (LUT_BITS - l);
@@ -439,6 +468,60 @@ int build_cr2_stream(const rsx_cr2_desc& d, const rsx_image& img,
   }
   s->strip_first_sample[strips.size()] = first;
   return RSX_OK;
+}
+
+// ------------------------------------------------------------------------
+// NikonDecompressor::NikonDecompressor (decompressors/NikonDecompressor.cpp:473-513)
+// -- the part of it that is about the image and the decode parameters; the
+// metadata parsing itself (v0/v1, curve, split) stays in the reference.
+// ------------------------------------------------------------------------
+int validate_nikon(const rsx_nikon_desc& d, const rsx_image& img) {
+  if (img.cpp != 1) // :476-478
+    return RSX_ERR_INVALID_ARG;
+  if (img.dim_x <= 0 || img.dim_y <= 0 || img.dim_x % 2 != 0 || img.dim_x > 8288 ||
+      img.dim_y > 5520) // :480-483
+    return RSX_ERR_INVALID_ARG;
+  if (d.bits_ps != 12 && d.bits_ps != 14) // :485-491
+    return RSX_ERR_INVALID_ARG;
+  // "If the 'split' happens outside of the image, it does not actually
+  // happen" (:511-512): the caller passes the clamped value
+  if (d.split < 0 || d.split >= img.dim_y)
+    return RSX_ERR_INVALID_ARG;
+  for (int i = 0; i < 4; ++i) // metadata.getU16() :506-509
+    if ((&d.p_up[0][0])[i] < 0 || (&d.p_up[0][0])[i] > 65535)
+      return RSX_ERR_INVALID_ARG;
+  if (!d.uncorrected_raw_values &&
+      (d.curve == nullptr || d.curve_size < 1 || d.curve_size > 65536))
+    return RSX_ERR_INVALID_ARG; // TableLookUp::setTable (TableLookUp.cpp:50-57)
+  if (int st = validate_huff_table(d.tables[0])) // createPrefixCodeDecoder :455-470
+    return st;
+  if (d.tables[0].fix_dng_bug16) // ht.setup(true, false)
+    return RSX_ERR_INVALID_ARG;
+  if (d.split != 0)
+    if (int st = validate_las_table(d.tables[1]))
+      return st;
+  return RSX_OK;
+}
+
+// TableLookUp::setTable, dither branch (common/TableLookUp.cpp:66-84).  Only
+// the first 32768 entries can be addressed: the index is clampBits(pred, 15).
+void build_dither_table(const uint16_t* curve, int n, std::vector<uint32_t>* out) {
+  out->assign(32768, 0u);
+  for (int i = 0; i < 32768; ++i) {
+    if (i < n) {
+      const int center = curve[i];
+      int lower = i > 0 ? curve[i - 1] : center;
+      int upper = i < n - 1 ? curve[i + 1] : center;
+      lower = lower < center ? lower : center;
+      upper = upper > center ? upper : center;
+      const int delta = upper - lower;
+      int base = center - ((upper - lower + 2) / 4);
+      base = base < 0 ? 0 : (base > 65535 ? 65535 : base); // clampBits(.., 16)
+      (*out)[i] = uint32_t(base) | (uint32_t(delta) << 16);
+    } else {
+      (*out)[i] = curve[n - 1];
+    }
+  }
 }
 
 int DeviceBuffer::ensure(size_t n) {

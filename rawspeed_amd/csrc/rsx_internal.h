@@ -25,6 +25,9 @@ int validate_unpack_variant(const rsx_unpack_variant_desc& d, const rsx_image& i
 int unpack_variant_bytes_per_line(const rsx_unpack_variant_desc& d, uint64_t* bpl);
 int validate_ljpeg(const rsx_ljpeg_desc& d, const rsx_image& img);
 int validate_cr2(const rsx_cr2_desc& d, const rsx_image& img);
+int validate_nikon(const rsx_nikon_desc& d, const rsx_image& img);
+// TableLookUp::setTable with dither (common/TableLookUp.cpp:50-84), 15-bit domain
+void build_dither_table(const uint16_t* curve, int n, std::vector<uint32_t>* out);
 int validate_huff_table(const rsx_huff_table& t);
 
 // ------------------------------------------------------------------------
@@ -52,10 +55,13 @@ struct DeviceHuffTable {
   // the symbol decoded from an all-zero bit stream (what the reference reads
   // past the end-of-stream marker, BitStreamerJPEG.h:155-179)
   uint8_t zero_sym_bits; // bits consumed by that symbol (0 = invalid code)
-  uint8_t pad;
+  // values are Nikon "lossy after split" codes (len | shl << 4; 16 = -32768):
+  // NikonLASDecompressor::decodeDifference, NikonDecompressor.cpp:331-376
+  uint8_t las;
 };
 
-void build_device_table(const rsx_huff_table& t, DeviceHuffTable* out);
+void build_device_table(const rsx_huff_table& t, DeviceHuffTable* out, bool las = false);
+int validate_las_table(const rsx_huff_table& t);
 
 // ------------------------------------------------------------------------
 // Job geometry handed to the LJPEG kernels.  One "stream" = one entropy-coded
@@ -86,7 +92,7 @@ struct StreamGeom {
   uint8_t seed_pos[4];      // first sample of predictor component c in a row
   uint32_t table_base;  // index of this job's first DeviceHuffTable
   // LJPEG mapping
-  uint32_t kind;        // 0 LJPEG, 1 CR2
+  uint32_t kind;        // 0 LJPEG, 1 CR2, 2 Nikon (rows of row_samples at out_y, full width)
   uint32_t mcu_w, mcu_h;
   uint32_t out_x;       // first output sample column (cpp * tile_x)
   uint32_t out_y;       // first output row
@@ -100,6 +106,11 @@ struct StreamGeom {
   uint32_t strip_h[MAX_CR2_STRIPS];
   uint64_t strip_first_sample[MAX_CR2_STRIPS + 1]; // prefix: stream sample index
   uint32_t job; // owning job (status / consumed are reported per job)
+  // kind 2 (NikonDecompressor): plain MSB bit stream (BitStreamerMSB)
+  uint8_t raw;       // no FF00 un-stuffing, no markers, 8-byte over-read budget
+  uint8_t start_bit; // the first symbol starts this many bits into in_offset
+  uint8_t las;       // table 0 holds "lossy after split" values
+  uint64_t raw_limit; // != 0: last bit offset at which a symbol may start
 };
 
 int build_ljpeg_stream(const rsx_ljpeg_desc& d, const rsx_image& img,

@@ -8,6 +8,19 @@
 
 namespace rsx {
 
+// NikonDecompressor jobs (StreamGeom::kind == 2): what the reconstruction
+// kernels need besides the entropy decode.
+struct NikonIn {
+  int32_t p_up[4] = {0, 0, 0, 0}; // pUp[row & 1][col & 1] at [2 * (row & 1) + (col & 1)]
+  const int32_t* pup_in = nullptr; // device pointer overriding p_up (rows after a split)
+  bool uncorrected = true;
+  int split = 0;          // rows >= split use table_after_split (0 = none)
+  int height = 0;         // image rows
+  std::vector<uint32_t> dither; // 32768 x (base | delta << 16); empty if uncorrected
+  rsx_huff_table table_after_split{};
+  uint64_t seed_offset = 0; // first byte of the job's input (the 24-bit dither seed)
+};
+
 struct LJpegJobIn {
   int status = RSX_OK;    // validation result; failed jobs are skipped
   StreamGeom geom;        // flattened geometry (rsx_host.cpp)
@@ -15,6 +28,7 @@ struct LJpegJobIn {
   int n_tables = 0;
   int rows_per_restart_interval = 0; // LJPEG only; 0 = no restart markers
   int frame_h = 0;
+  NikonIn nikon;          // kind 2 only
 };
 
 struct LJpegPlan;

@@ -89,7 +89,8 @@ struct TabLds {
   uint8_t max_len;
   uint8_t fix16;
   uint8_t zero_sym_bits;
-  uint8_t pad[1 + 12];
+  uint8_t las;
+  uint8_t pad[12];
 };
 static_assert(sizeof(TabLds) == sizeof(DeviceHuffTable) + 12 ||
                   sizeof(TabLds) % 16 == 0,
@@ -120,6 +121,11 @@ struct LjStreamDev {
   uint8_t tab_of_phase[8];
   uint16_t init_pred[4];
   uint8_t seed_pos[4]; // first sample of component c inside a stream row
+  uint8_t raw;         // 1: plain MSB bit stream (BitStreamerMSB): no FF00 un-stuffing,
+                       //    no markers, position budget of 8 bytes instead of 16
+  uint8_t start_bit;   // first symbol starts this many bits into the stream (0..7)
+  uint8_t las;         // table values are Nikon "lossy after split" (len | shl << 4)
+  uint8_t pad8;
   uint32_t rows;
   uint32_t row_samples;
   uint32_t first_row; // global stream-row index
@@ -129,6 +135,18 @@ struct LjStreamDev {
   uint32_t n_strips;
   uint32_t strip_base;
   uint32_t job;
+  uint64_t raw_limit;  // raw streams: 1 + last bit offset a symbol may start at (0 = derive)
+};
+
+// Per-stream parameters of NikonDecompressor streams (kind 2), indexed like streams[].
+struct NkStreamDev {
+  int32_t p_up[4];       // pUp[row & 1][col & 1] at [2 * (row & 1) + (col & 1)]
+  const int32_t* pup_in; // non-null: read the initial pUp from here instead (rows after the split)
+  uint32_t uncorrected;  // 1: store clampBits(pred, 15) as is
+  uint32_t table_off;    // first entry of this stream's dither table in nk_tables
+  uint32_t rowpow_off;   // first entry of this stream's row powers in nk_rowpow
+  uint32_t pad;
+  uint64_t seed_offset;  // byte offset (from in_base) of the job's first input byte
 };
 
 struct LjResult {
@@ -145,6 +163,8 @@ struct LjResult {
   uint32_t stat_rounds; // statistics: re-decode rounds summed over workgroups
   uint32_t stat_redo;   // statistics: slots re-decoded
   uint32_t stat_stitch; // statistics: workgroups re-converged by the stitch kernel
+  uint32_t end_lo;      // raw streams: bit offset just past the last needed symbol
+  uint32_t end_hi;
   uint32_t pad2;
 };
 
@@ -169,6 +189,11 @@ struct LjArgs {
   uint32_t n_streams;
   uint32_t total_rows;
   uint32_t ablate; // profiling aid (RSX_ABLATE): 1 = no K4 stores, 2 = no K4 decode loop, 4 = no K1 decode
+  // NikonDecompressor streams
+  const NkStreamDev* nk;
+  const uint32_t* nk_tables; // dither tables: base | delta << 16 per 15-bit value
+  const uint32_t* nk_rowpow; // 15700^(y * W) mod (15700 * 2^16 - 1) per output row
+  int32_t* nk_pup;           // [stream][4]: pUp after the stream's last row
 };
 
 // ---------------------------------------------------------------------------
@@ -406,7 +431,7 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
   L.ob[j] = 8u * uint32_t(valid > LJ_P ? LJ_P : valid);
   L.su[j] = prev; // su[] doubles as the "byte before the slot" array during staging
   __syncthreads();
-  if ((any != 0u || prev == 0xFFu) && !(a.ablate & 8u))
+  if ((any != 0u || prev == 0xFFu) && !(a.ablate & 8u) && !S.raw)
     L.list[atomicAdd(&L.misc[10], 1u)] = uint32_t(j);
   __syncthreads();
   const uint32_t n = L.misc[10];
@@ -462,8 +487,10 @@ __device__ __noinline__ uint32_t lj_slow_entry(uint32_t w, const TabLds* tb) {
     const uint32_t c = w >> (32 - l);
     const uint32_t mc = tb->max_code[l];
     if (mc != NO_CODE && c <= mc) {
-      const uint32_t ssss = tb->values[(c - tb->val_offset[l]) & 0xFFFFu];
-      const uint32_t extra = ssss == 16u ? (tb->fix16 ? 16u : 0u) : ssss;
+      const uint32_t val = tb->values[(c - tb->val_offset[l]) & 0xFFFFu];
+      const uint32_t ssss = (tb->las && val != 16u) ? (val & 15u) : val;
+      const uint32_t extra = ssss == 16u ? (tb->fix16 ? 16u : 0u)
+                                         : (tb->las ? ssss - (val >> 4) : ssss);
       return l | (ssss << 5) | ((l + extra) << 10);
     }
   }
@@ -789,10 +816,12 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     const uint32_t guess = lj_warmup<MULTI>(L, dp, j);
     if (j >= 2 || (j == 1 && lb > 0))
       start = guess;
+    else if (j == 1)
+      start = S.start_bit; // the stream's first symbol
     lj_decode_span<MULTI, !MULTI>(L, dp, j, start, own_bits, e, c, &bm,
                                   real_slot && !(a.ablate & 4u));
     if (!real_slot) {
-      e = 0;
+      e = S.start_bit;
       c = 0;
       bm = 0;
     }
@@ -1053,6 +1082,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   const uint32_t n_groups = (a.ablate & 2u) ? 0u : (wmax + 7) >> 3;
 
   uint32_t phase = (my_start >> ST_PHASE_SHIFT) & 7u;
+  const bool las = S.las != 0;
   BitReader r = br_open(L.B, j, my_start & ST_OFF_MASK);
   uint32_t tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0; // the lane's last, partial group
   for (uint32_t g = 0; g < n_groups; ++g) {
@@ -1066,10 +1096,20 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
       if (MULTI)
         phase = live ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
       const uint32_t cl = e & 31u, ssss = (e >> 5) & 31u;
-      // v = the SSSS bits after the code; diff per JPEG F.2.2.1 "EXTEND"
-      const uint32_t v = uint32_t((uint64_t(w << cl) << ssss) >> 32);
-      const uint32_t half = (1u << ssss) >> 1;
-      uint32_t diff = v >= half ? v : v + 1u - (1u << ssss);
+      uint32_t diff;
+      if (las) { // stream-uniform: NikonLASDecompressor::decodeDifference (.cpp:366-376)
+        const uint32_t nbits = (e >> 10) - cl, shl = ssss - nbits;
+        const uint32_t v = uint32_t((uint64_t(w << cl) << nbits) >> 32);
+        int d = int((((v << 1) + 1u) << shl) >> 1);
+        if ((d & (1 << ((ssss - 1u) & 31u))) == 0)
+          d -= (1 << ssss) - (shl ? 0 : 1);
+        diff = uint32_t(d);
+      } else {
+        // v = the SSSS bits after the code; diff per JPEG F.2.2.1 "EXTEND"
+        const uint32_t v = uint32_t((uint64_t(w << cl) << ssss) >> 32);
+        const uint32_t half = (1u << ssss) >> 1;
+        diff = v >= half ? v : v + 1u - (1u << ssss);
+      }
       diff = ssss == 0u ? 0u : diff;
       diff = ssss == 16u ? 0x8000u : diff;
       diff &= 0xFFFFu;
@@ -1144,8 +1184,10 @@ __device__ __forceinline__ Sym lj_symbol_global(uint32_t w, const TabLds* tb) {
     const uint32_t c = w >> (32 - l);
     const uint32_t mc = tb->max_code[l];
     if (mc != NO_CODE && c <= mc) {
-      const uint32_t ssss = tb->values[(c - tb->val_offset[l]) & 0xFFFFu];
-      const uint32_t extra = ssss == 16u ? (tb->fix16 ? 16u : 0u) : ssss;
+      const uint32_t val = tb->values[(c - tb->val_offset[l]) & 0xFFFFu];
+      const uint32_t ssss = (tb->las && val != 16u) ? (val & 15u) : val;
+      const uint32_t extra = ssss == 16u ? (tb->fix16 ? 16u : 0u)
+                                         : (tb->las ? ssss - (val >> 4) : ssss);
       return {l + extra, ssss, l, true};
     }
   }
@@ -1170,7 +1212,8 @@ __global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
   const uint64_t L0 = s0 * LJ_P - lj_drops_before(a, S, in, s0 * LJ_P, lane);
   if (lane != 0)
     return;
-  const uint32_t st0 = s0 == 0 ? 0u : (a.sub_state[S.first_subseq + s0 - 1] & ST_MASK);
+  const uint32_t st0 =
+      s0 == 0 ? uint32_t(S.start_bit) : (a.sub_state[S.first_subseq + s0 - 1] & ST_MASK);
   if (st0 & ST_ERR) {
     atomicCAS(&R.status, 0u, uint32_t(RSX_ERR_BAD_HUFFMAN_CODE));
     return;
@@ -1182,7 +1225,8 @@ __global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
 
   // sequential un-stuffing reader over physical bytes [x, M), zeros afterwards
   uint64_t x = s0 * LJ_P;
-  if (x < M && x > 0 && in[x] == 0x00 && in[x - 1] == 0xFF)
+  const bool raw = S.raw != 0;
+  if (!raw && x < M && x > 0 && in[x] == 0x00 && in[x - 1] == 0xFF)
     ++x; // the slot starts on a stuffing byte
   uint64_t buf = 0;
   uint32_t nb = 0;
@@ -1191,7 +1235,7 @@ __global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
       uint32_t byte = 0;
       if (x < M) {
         byte = in[x++];
-        if (byte == 0xFF)
+        if (byte == 0xFF && !raw)
           ++x; // its stuffing byte (every FF before M is followed by 00)
       }
       buf |= uint64_t(byte) << (56 - nb);
@@ -1210,7 +1254,10 @@ __global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
   const bool multi = S.n_tables > 1;
   const TabLds* tabs = a.tables + S.table_base;
   const int64_t T0 = int64_t(32 * (D / 4)) - 31;
-  const uint64_t limit_nomarker = 32 * ((D + 16) / 4);
+  // refill k reads bytes [4k, 4k+4) and throws once 4k > size + 2*MaxProcessBytes
+  // (BitStreamer.h:125-127): 16 for BitStreamerJPEG, 8 for BitStreamerMSB
+  const uint64_t limit_nomarker =
+      (raw && S.raw_limit) ? S.raw_limit - 1 : 32 * ((D + (raw ? 8 : 16)) / 4);
   int64_t cstar = -1;
   int16_t* __restrict__ dst = a.diffs + S.diff_offset;
   while (idx < S.needed) {
@@ -1238,8 +1285,12 @@ __global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
     } else if (sy.ssss == 16u) {
       diff = -32768;
     } else {
-      const uint32_t v = (w << sy.code_len) >> (32 - sy.ssss);
-      diff = (v >> (sy.ssss - 1)) ? int(v) : int(v) - int((1u << sy.ssss) - 1u);
+      // (NikonLASDecompressor: only len - shl of the len bits are in the stream)
+      const uint32_t nbits = sy.total - sy.code_len, shl = sy.ssss - nbits;
+      const uint32_t v = nbits ? (w << sy.code_len) >> (32 - nbits) : 0u;
+      diff = int((((v << 1) + 1u) << shl) >> 1);
+      if ((diff & (1 << (sy.ssss - 1))) == 0)
+        diff -= (1 << sy.ssss) - (shl ? 0 : 1);
     }
     if (idx >= avail)
       dst[idx] = int16_t(diff);
@@ -1273,7 +1324,7 @@ __global__ __launch_bounds__(VS_T) void lj_vseed_kernel(LjArgs a) {
   __shared__ uint32_t carry_s[4];
   const uint32_t s = blockIdx.x;
   const LjStreamDev& S = a.streams[s];
-  if (a.results[s].status != 0)
+  if (a.results[s].status != 0 || S.kind == 2)
     return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const uint32_t rows = S.rows, N = S.n_comp;
@@ -1372,7 +1423,8 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
       hi = mid - 1;
   }
   const LjStreamDev& S = a.streams[lo];
-  if (int(S.n_comp) != N || int(S.period) != P || a.results[lo].status != 0)
+  if (int(S.n_comp) != N || int(S.period) != P || S.kind == 2 ||
+      a.results[lo].status != 0)
     return;
   const uint32_t r = grow - S.first_row;
   if (r >= S.rows)
@@ -1590,7 +1642,8 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_fast_kernel(LjArgs a) {
       hi = mid - 1;
   }
   const LjStreamDev& S = a.streams[lo];
-  if (int(S.n_comp) != N || int(S.period) != N || a.results[lo].status != 0)
+  if (int(S.n_comp) != N || int(S.period) != N || S.kind == 2 ||
+      a.results[lo].status != 0)
     return;
   const uint32_t r = grow - S.first_row;
   if (r >= S.rows)
@@ -1679,6 +1732,205 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_fast_kernel(LjArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// NikonDecompressor reconstruction (NikonDecompressor.cpp:515-539).  Unlike the
+// JPEG predictors these sums are plain ints -- nothing wraps mod 2^16 -- and
+// only the stored value is clamped to 15 bits.
+//   pred(y, x) = pUp_y[x & 1] + sum_{x' <= x, x' = x (2)} D[y][x']
+//   pUp_y[c]   = pUp_init[y & 1][c] + sum_{y' < y, y' = y (2)} D[y'][c]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(VS_T) void nk_vseed_kernel(LjArgs a) {
+  __shared__ int32_t wtot[VS_T / 64][4];
+  __shared__ int32_t carry_s[4];
+  const uint32_t s = blockIdx.x;
+  const LjStreamDev& S = a.streams[s];
+  if (S.kind != 2 || a.results[s].status != 0)
+    return;
+  const NkStreamDev& K = a.nk[s];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t rows = S.rows;
+  const int16_t* __restrict__ D = a.diffs + S.diff_offset;
+  int32_t* __restrict__ V = reinterpret_cast<int32_t*>(a.vseed) + uint64_t(S.first_row) * 2;
+  if (tid < 4)
+    carry_s[tid] = K.pup_in ? K.pup_in[tid] : K.p_up[tid];
+  __syncthreads();
+  for (uint32_t r0 = 0; r0 < rows; r0 += VS_T) {
+    const uint32_t r = r0 + tid;
+    const uint32_t par = (S.out_y + r) & 1u;
+    int32_t d[4] = {0, 0, 0, 0};
+    if (r < rows) {
+      d[2 * par] = D[uint64_t(r) * S.row_samples];
+      d[2 * par + 1] = D[uint64_t(r) * S.row_samples + 1];
+    }
+    int32_t inc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int32_t x = d[c];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int32_t y = __shfl_up(x, o, 64);
+        if (lane >= o)
+          x += y;
+      }
+      inc[c] = x;
+      if (lane == 63)
+        wtot[wv][c] = x;
+    }
+    __syncthreads();
+    int32_t base[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int32_t o = carry_s[c];
+      for (int w = 0; w < wv; ++w)
+        o += wtot[w][c];
+      base[c] = o;
+    }
+    if (r < rows) {
+      // exclusive: the value of pUp[row & 1] when row r starts
+      V[uint64_t(r) * 2] = par ? base[2] + inc[2] - d[2] : base[0] + inc[0] - d[0];
+      V[uint64_t(r) * 2 + 1] = par ? base[3] + inc[3] - d[3] : base[1] + inc[1] - d[1];
+    }
+    __syncthreads();
+    if (tid == VS_T - 1)
+      for (int c = 0; c < 4; ++c)
+        carry_s[c] = base[c] + inc[c];
+    __syncthreads();
+  }
+  if (tid < 4)
+    a.nk_pup[s * 4 + tid] = carry_s[tid];
+}
+
+// The dither state of RawImageDataU16::setWithLookUp (common/RawImage.h:335-353)
+// is a lag-1 multiply-with-carry generator, r' = 15700 * (r & 65535) + (r >> 16),
+// advanced once per pixel in decode order.  With m = 15700 * 2^16 - 1 one has
+// 2^16 * r' = r (mod m), i.e. r_n = r_0 * 15700^n mod m for r_0 < m (the seed is
+// 24 bits): a lane jumps to its first pixel and then steps like the reference.
+constexpr uint64_t NK_MWC_A = 15700, NK_MWC_M = NK_MWC_A * 65536 - 1;
+__device__ __forceinline__ uint32_t nk_mulmod(uint32_t x, uint32_t y) {
+  return uint32_t((uint64_t(x) * y) % NK_MWC_M);
+}
+
+__global__ __launch_bounds__(LJ_T) void nk_predict_kernel(LjArgs a) {
+  const uint32_t grow = blockIdx.x * (LJ_T / 64) + (threadIdx.x >> 6);
+  if (grow >= a.total_rows)
+    return;
+  const int lane = threadIdx.x & 63;
+  uint32_t lo = 0, hi = a.n_streams - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (a.streams[mid].first_row <= grow)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  const LjStreamDev& S = a.streams[lo];
+  if (S.kind != 2 || a.results[lo].status != 0)
+    return;
+  const NkStreamDev& K = a.nk[lo];
+  const uint32_t r = grow - S.first_row;
+  if (r >= S.rows)
+    return;
+  const uint32_t W = S.row_samples;
+  const uint32_t y = S.out_y + r;
+  const uint64_t row0 = uint64_t(r) * W;
+  const int16_t* __restrict__ D = a.diffs + S.diff_offset + row0;
+  const bool in_aligned = ((S.diff_offset + row0) & 7) == 0;
+  const int32_t* V = reinterpret_cast<const int32_t*>(a.vseed) + uint64_t(grow) * 2;
+  int32_t carry0 = V[0], carry1 = V[1];
+  uint8_t* out_row = a.out_base + S.img_offset + uint64_t(y) * S.img_pitch;
+  const bool out_aligned = (reinterpret_cast<uintptr_t>(out_row) & 15) == 0;
+
+  const bool dither = K.uncorrected == 0;
+  const uint32_t* __restrict__ tab = a.nk_tables + K.table_off;
+  uint32_t step_state = 0, lane_mul = 1, a512 = 1;
+  if (dither) {
+    const uint8_t* in0 = a.in_base + K.seed_offset;
+    const uint32_t seed = (uint32_t(in0[0]) << 16) | (uint32_t(in0[1]) << 8) | in0[2];
+    step_state = nk_mulmod(seed, a.nk_rowpow[K.rowpow_off + r]);
+    // 15700^(8 * lane) and 15700^512 by square-and-multiply (once per row)
+    uint32_t b = uint32_t(NK_MWC_A), e = 8u * uint32_t(lane);
+    for (int i = 0; i < 9; ++i) {
+      if (e & 1u)
+        lane_mul = nk_mulmod(lane_mul, b);
+      b = nk_mulmod(b, b);
+      e >>= 1;
+    }
+    a512 = b; // b = 15700^(2^9)
+  }
+
+  for (uint32_t q0 = 0; q0 < W; q0 += 512) {
+    const uint32_t q = q0 + lane * 8;
+    int32_t v[8];
+    if (q + 8 <= W && in_aligned) {
+      const uint4 t = *reinterpret_cast<const uint4*>(D + q);
+      v[0] = int16_t(t.x); v[1] = int32_t(t.x) >> 16;
+      v[2] = int16_t(t.y); v[3] = int32_t(t.y) >> 16;
+      v[4] = int16_t(t.z); v[5] = int32_t(t.z) >> 16;
+      v[6] = int16_t(t.w); v[7] = int32_t(t.w) >> 16;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        v[i] = q + i < W ? int32_t(D[q + i]) : 0;
+    }
+    int32_t run0 = 0, run1 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      run0 += v[i];
+      v[i] = run0;
+      run1 += v[i + 1];
+      v[i + 1] = run1;
+    }
+    int32_t x0 = run0, x1 = run1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t y0 = __shfl_up(x0, o, 64), y1 = __shfl_up(x1, o, 64);
+      if (lane >= o) {
+        x0 += y0;
+        x1 += y1;
+      }
+    }
+    const int32_t tot0 = __shfl(x0, 63, 64), tot1 = __shfl(x1, 63, 64);
+    const int32_t e0 = x0 - run0 + carry0, e1 = x1 - run1 + carry1;
+    carry0 += tot0;
+    carry1 += tot1;
+
+    uint32_t st = 0;
+    if (dither) {
+      st = nk_mulmod(step_state, lane_mul);
+      step_state = nk_mulmod(step_state, a512);
+    }
+    uint32_t px[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int32_t p = v[i] + ((i & 1) ? e1 : e0);
+      p = p < 0 ? 0 : (p > 32767 ? 32767 : p); // clampBits(pred, 15)
+      if (dither) {
+        const uint32_t t = tab[p];
+        px[i] = ((t & 0xFFFFu) + (((t >> 16) * (st & 2047u) + 1024u) >> 12)) & 0xFFFFu;
+        st = 15700u * (st & 65535u) + (st >> 16);
+      } else {
+        px[i] = uint32_t(p);
+      }
+    }
+    if (q >= W)
+      continue;
+    uint16_t* dst = reinterpret_cast<uint16_t*>(out_row) + q;
+    if (q + 8 <= W && out_aligned) {
+      uint4 o;
+      o.x = px[0] | (px[1] << 16);
+      o.y = px[2] | (px[3] << 16);
+      o.z = px[4] | (px[5] << 16);
+      o.w = px[6] | (px[7] << 16);
+      *reinterpret_cast<uint4*>(dst) = o;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (q + i < W)
+          dst[i] = uint16_t(px[i]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K7: decode()/decompress() return value = BitStreamerJPEG::getStreamPosition()
 // after the last decoded symbol: let c be the un-stuffed bit
 // offset at which the last decoded symbol starts; K = ceil(c/32)+1 refills of 4
@@ -1711,6 +1963,8 @@ __device__ __forceinline__ uint64_t lj_drops_before(const LjArgs& a,
                                                     const LjStreamDev& S,
                                                     const uint8_t* in, uint64_t x,
                                                     int lane) {
+  if (S.raw)
+    return 0;
   uint64_t lb = x / LJ_R;
   if (lb >= S.n_blocks)
     lb = S.n_blocks - 1;
@@ -1734,6 +1988,25 @@ __global__ __launch_bounds__(64) void lj_consumed_kernel(LjArgs a) {
       (slot_phys - lj_drops_before(a, S, in, slot_phys, lane)) * 8 + R.last_pos;
   if (R.tail_used)
     c = (uint64_t(R.last_c_hi) << 32) | R.last_c_lo;
+  if (S.raw) {
+    // where the next symbol would start: the last one's start + its length
+    // (bytes past the end of the buffer read as zero)
+    if (lane == 0) {
+      uint32_t w = 0;
+      const uint64_t by = c >> 3;
+      uint64_t acc = 0;
+      for (int i = 0; i < 5; ++i) {
+        const uint64_t q = by + i;
+        acc = (acc << 8) | (q < S.in_bytes ? in[q] : 0u);
+      }
+      w = uint32_t((acc << (c & 7)) >> 8);
+      const Sym sy = lj_symbol_global(w, a.tables + S.table_base);
+      const uint64_t end = c + (sy.ok ? sy.total : 0u);
+      R.end_lo = uint32_t(end);
+      R.end_hi = uint32_t(end >> 32);
+    }
+    return;
+  }
   const uint64_t K = (c + 31) / 32 + 1;
   const uint64_t D = M - lj_drops_before(a, S, in, M, lane);
   uint64_t result;
@@ -1836,6 +2109,23 @@ struct LJpegPlan {
   std::vector<uint32_t> dri_signature; // marker layout the child plan was built for
   LJpegPlan* child = nullptr;          // one stream per restart interval
   std::vector<std::pair<int, int>> child_owner; // child job -> (dri index, interval)
+  // NikonDecompressor streams
+  bool any_nikon = false;
+  std::vector<NkStreamDev> nk;         // parallel to streams
+  DeviceBuffer d_nk, d_nk_tables, d_nk_rowpow, d_nk_pup;
+  // jobs with a split row: the rows after it are a second stream (other table)
+  // that starts at the bit where the first part ends -- known after it ran
+  struct NkSplit {
+    int job = 0;
+    int stream = 0; // first part
+    LJpegJobIn in;
+    rsx_huff_table table{};
+    int status = RSX_OK;
+  };
+  std::vector<NkSplit> nk_split;
+  std::vector<uint64_t> nk_signature; // end bits the split child was built for
+  LJpegPlan* nk_child = nullptr;
+  std::vector<int> nk_child_owner;    // child job -> nk_split index
 };
 
 namespace {
@@ -1862,6 +2152,10 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.n_streams = uint32_t(p->streams.size());
   a.total_rows = p->total_rows;
   a.ablate = getenv("RSX_ABLATE") ? uint32_t(atoi(getenv("RSX_ABLATE"))) : 0u;
+  a.nk = static_cast<const NkStreamDev*>(p->d_nk.ptr);
+  a.nk_tables = static_cast<const uint32_t*>(p->d_nk_tables.ptr);
+  a.nk_rowpow = static_cast<const uint32_t*>(p->d_nk_rowpow.ptr);
+  a.nk_pup = static_cast<int32_t*>(p->d_nk_pup.ptr);
   return a;
 }
 
@@ -1898,6 +2192,8 @@ void launch_predict(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((lj_predict_kernel<3, 4>), grid, block, 0, s, a);
   if (p->comp_present[6])
     hipLaunchKernelGGL((lj_predict_kernel<3, 6>), grid, block, 0, s, a);
+  if (p->any_nikon)
+    hipLaunchKernelGGL(nk_predict_kernel, grid, block, 0, s, a);
 }
 
 } // namespace
@@ -1914,15 +2210,17 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
   p->job_n_streams.assign(jobs.size(), 0);
   std::vector<DeviceHuffTable> tables;
   std::vector<Cr2Strip> strips;
+  std::vector<uint32_t> nk_tables, nk_rowpow;
   for (size_t i = 0; i < jobs.size(); ++i) {
     const LJpegJobIn& J = jobs[i];
     int st = J.status;
-    if (st == RSX_OK && J.geom.in_bytes < 8)
-      st = RSX_ERR_IO; // BitStreamerJPEG needs >= 8 bytes (BitStreamer.h:58-59)
+    // BitStreamerJPEG needs >= 8 bytes, BitStreamerMSB >= 4 (BitStreamer.h:58-59)
+    if (st == RSX_OK && J.geom.in_bytes < (J.geom.raw ? 4u : 8u))
+      st = RSX_ERR_IO;
     if (st == RSX_OK && J.geom.in_bytes > 0xFFFFFFFFull)
       st = RSX_ERR_INVALID_ARG; // Buffer::size_type is uint32_t (io/Buffer.h:49)
     const StreamGeom& g = J.geom;
-    const uint64_t needed = g.kind == 0
+    const uint64_t needed = g.kind != 1
                                 ? uint64_t(g.rows) * g.row_samples
                                 : g.strip_first_sample[g.n_strips];
     if (st == RSX_OK && needed >= 0xFFFFFFF0ull)
@@ -1958,6 +2256,10 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     std::memcpy(S.tab_of_phase, g.comp_of_phase, 8);
     std::memcpy(S.init_pred, g.init_pred, sizeof S.init_pred);
     std::memcpy(S.seed_pos, g.seed_pos, 4);
+    S.raw = g.raw;
+    S.start_bit = g.start_bit;
+    S.las = g.las;
+    S.raw_limit = g.raw_limit;
     S.rows = g.rows;
     S.row_samples = g.row_samples;
     S.first_row = p->total_rows;
@@ -1983,14 +2285,53 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     S.job = uint32_t(i);
     for (int t = 0; t < J.n_tables; ++t) {
       tables.emplace_back();
-      build_device_table(J.tables[t], &tables.back());
+      build_device_table(J.tables[t], &tables.back(), g.las != 0);
     }
+    NkStreamDev K{};
+    if (g.kind == 2) {
+      const NikonIn& N = J.nikon;
+      std::memcpy(K.p_up, N.p_up, sizeof K.p_up);
+      K.pup_in = N.pup_in;
+      K.uncorrected = N.uncorrected ? 1u : 0u;
+      K.seed_offset = N.seed_offset;
+      K.table_off = uint32_t(nk_tables.size());
+      if (!N.uncorrected)
+        nk_tables.insert(nk_tables.end(), N.dither.begin(), N.dither.end());
+      // 15700^(y * W) mod m for the stream's rows: the dither state at (y, 0)
+      K.rowpow_off = uint32_t(nk_rowpow.size());
+      if (!N.uncorrected) {
+        const uint64_t m = 15700ull * 65536 - 1;
+        auto powmod = [&](uint64_t e) {
+          uint64_t r = 1, b = 15700;
+          for (; e; e >>= 1, b = b * b % m)
+            if (e & 1)
+              r = r * b % m;
+          return r;
+        };
+        const uint64_t step = powmod(g.row_samples);
+        uint64_t cur = powmod(uint64_t(g.out_y) * g.row_samples);
+        for (uint32_t r = 0; r < g.rows; ++r, cur = cur * step % m)
+          nk_rowpow.push_back(uint32_t(cur));
+      }
+      p->any_nikon = true;
+      if (N.split > 0 && N.pup_in == nullptr && g.out_y == 0 &&
+          uint32_t(N.split) == g.rows && N.split < N.height) {
+        LJpegPlan::NkSplit sp;
+        sp.job = int(i);
+        sp.stream = int(p->streams.size());
+        sp.in = J;
+        sp.table = N.table_after_split;
+        p->nk_split.push_back(std::move(sp));
+      }
+    }
+    p->nk.push_back(K);
     // single-table streams ignore tab_of_phase; multi-table ones index tabs[]
     bool multi = J.n_tables > 1;
     p->any_multi |= multi;
     p->any_single |= !multi;
     p->max_tables = std::max(p->max_tables, J.n_tables);
-    p->comp_present[g.period == g.n_comp ? g.n_comp : (g.period == 4 ? 5u : 6u)] = true;
+    if (g.kind != 2)
+      p->comp_present[g.period == g.n_comp ? g.n_comp : (g.period == 4 ? 5u : 6u)] = true;
     p->job_first_stream[i] = int(p->streams.size());
     p->job_n_streams[i] = 1;
     p->total_blocks += S.n_blocks;
@@ -2025,6 +2366,12 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         (st = up(p->d_block_stream, block_stream.data(),
                  block_stream.size() * sizeof(uint32_t))) ||
         (st = up(p->d_strips, strips.data(), strips.size() * sizeof(Cr2Strip))))
+      return st;
+    if (p->any_nikon &&
+        ((st = up(p->d_nk, p->nk.data(), p->nk.size() * sizeof(NkStreamDev))) ||
+         (st = up(p->d_nk_tables, nk_tables.data(), nk_tables.size() * 4)) ||
+         (st = up(p->d_nk_rowpow, nk_rowpow.data(), nk_rowpow.size() * 4)) ||
+         (st = p->d_nk_pup.ensure(p->streams.size() * 16))))
       return st;
     if ((st = p->d_sub_state.ensure(size_t(p->total_subseq) * 4 + 16)) ||
         (st = p->d_block_start.ensure(size_t(p->total_blocks) * 4)) ||
@@ -2061,6 +2408,8 @@ int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s, hipEvent_t ev_star
     RSX_HIP_CHECK(ctx, hipEventRecord(ev_stop, s));
   hipLaunchKernelGGL(lj_tail_kernel, dim3(n_streams), dim3(64), 0, s, a);
   hipLaunchKernelGGL(lj_vseed_kernel, dim3(n_streams), dim3(VS_T), 0, s, a);
+  if (p->any_nikon)
+    hipLaunchKernelGGL(nk_vseed_kernel, dim3(n_streams), dim3(VS_T), 0, s, a);
   launch_predict(p, a, s);
   hipLaunchKernelGGL(lj_consumed_kernel, dim3(n_streams), dim3(64), 0, s, a);
   RSX_HIP_CHECK(ctx, hipGetLastError());
@@ -2168,6 +2517,78 @@ int run_dri(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s) {
 
 } // namespace
 
+namespace {
+
+int converge(LJpegPlan* p, hipStream_t s);
+
+// NikonDecompressor::decompress with a split (NikonDecompressor.cpp:555-559):
+// the rows from `split` on are decoded with the next table by the same bit
+// reader, i.e. they start at the bit where the first part ended.  One host
+// round trip per run; the child plan is reused while those bits do not move.
+int run_nikon_split(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s) {
+  rsx_ctx* ctx = p->ctx;
+  if (int st = converge(p, s))
+    return st;
+  std::vector<uint64_t> signature;
+  for (auto& sp : p->nk_split) {
+    const LjResult& R = p->h_results[sp.stream];
+    const LjStreamDev& S = p->streams[sp.stream];
+    sp.status = RSX_OK;
+    if (R.status != 0 || uint64_t(R.avail_lo) < S.needed) {
+      signature.push_back(~uint64_t(0)); // the first part failed; reported by its stream
+      continue;
+    }
+    signature.push_back((uint64_t(R.end_hi) << 32) | R.end_lo);
+  }
+  if (!p->nk_child || signature != p->nk_signature) {
+    if (p->nk_child) {
+      ljpeg_plan_destroy(p->nk_child);
+      p->nk_child = nullptr;
+    }
+    std::vector<LJpegJobIn> jobs;
+    p->nk_child_owner.clear();
+    for (size_t k = 0; k < p->nk_split.size(); ++k) {
+      auto& sp = p->nk_split[k];
+      if (signature[k] == ~uint64_t(0))
+        continue;
+      const StreamGeom& g = sp.in.geom;
+      const uint64_t end = signature[k], off = end / 8;
+      const uint64_t rest =
+          uint64_t(sp.in.nikon.height - sp.in.nikon.split) * g.row_samples;
+      if (off + 4 > g.in_bytes) {
+        // fewer than 4 bytes left: the reference keeps reading zeros for at
+        // most 8 + 3 more bytes, far less than `rest` symbols need
+        sp.status = rest > 48 ? RSX_ERR_INPUT_OVERFLOW : RSX_ERR_UNSUPPORTED;
+        continue;
+      }
+      LJpegJobIn J = sp.in;
+      J.geom.in_offset = g.in_offset + off;
+      J.geom.in_bytes = g.in_bytes - off;
+      J.geom.start_bit = uint8_t(end % 8);
+      // the position budget belongs to the whole input (BitStreamer.h:125-127)
+      J.geom.raw_limit = 32 * ((g.in_bytes + 8) / 4) - 8 * off + 1;
+      J.geom.rows = uint32_t(sp.in.nikon.height - sp.in.nikon.split);
+      J.geom.out_y = uint32_t(sp.in.nikon.split);
+      J.geom.las = 1;
+      J.tables = &sp.table;
+      J.n_tables = 1;
+      J.nikon.split = 0;
+      J.nikon.pup_in = static_cast<const int32_t*>(p->d_nk_pup.ptr) + 4 * sp.stream;
+      jobs.push_back(J);
+      p->nk_child_owner.push_back(int(k));
+    }
+    if (!jobs.empty())
+      if (int st = ljpeg_plan_create(ctx, jobs, &p->nk_child))
+        return st;
+    p->nk_signature = signature;
+  }
+  if (p->nk_child)
+    return ljpeg_plan_run(p->nk_child, in_dev, out_dev, s, nullptr, nullptr);
+  return RSX_OK;
+}
+
+} // namespace
+
 int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
                    hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
   rsx_ctx* ctx = p->ctx;
@@ -2194,13 +2615,22 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
   for (int r = 0; r < p->stitch_rounds; ++r)
     launch_sync<true>(p, a, s);
   hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
-  return launch_tail(p, a, s, ev_start, ev_stop);
+  if (int st = launch_tail(p, a, s, ev_start, ev_stop))
+    return st;
+  if (!p->nk_split.empty())
+    return run_nikon_split(p, in_dev, out_dev, s);
+  return RSX_OK;
 }
 
-int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_status,
-                       uint32_t* job_consumed) {
+namespace {
+
+// Wait for the last run, fetch the per-stream results and, if a chain was still
+// inconsistent after the fixed number of stitch rounds (rare: a start state
+// that needs more than one subsequence to synchronise across several
+// workgroups), iterate the fix-up to its fixed point and redo the tail.
+// Jacobi iteration: at most n_blocks rounds, the fixed point is the serial decode.
+int converge(LJpegPlan* p, hipStream_t s) {
   rsx_ctx* ctx = p->ctx;
-  int rc = RSX_OK;
   auto fetch = [&]() -> int {
     RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->h_results.data(), p->d_results.ptr,
                                       p->h_results.size() * sizeof(LjResult),
@@ -2208,48 +2638,66 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
     RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
     return RSX_OK;
   };
-  if (ran && !p->streams.empty()) {
+  if (int st = fetch())
+    return st;
+  auto unconverged = [&]() {
+    for (const LjResult& R : p->h_results)
+      if (R.flags & FL_UNCONVERGED)
+        return true;
+    return false;
+  };
+  if (!unconverged())
+    return RSX_OK;
+  const LjArgs a = make_args(p, p->last_in, p->last_out);
+  const uint32_t n_streams = uint32_t(p->streams.size());
+  uint32_t rounds = 0;
+  while (unconverged() && rounds <= p->total_blocks) {
+    for (int k = 0; k < 4; ++k)
+      launch_sync<true>(p, a, s);
+    rounds += 4;
+    hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
+    RSX_HIP_CHECK(ctx, hipGetLastError());
     if (int st = fetch())
       return st;
-    // The optimistic pipeline ran with a fixed number of stitch rounds.  If a
-    // chain was still inconsistent (rare: a start state that needs more than
-    // one subsequence to synchronise across several workgroups), iterate the
-    // fix-up to its fixed point and redo the tail.  Jacobi iteration: at most
-    // n_blocks rounds, the fixed point is the serial decode.
-    auto unconverged = [&]() {
-      for (const LjResult& R : p->h_results)
-        if (R.flags & FL_UNCONVERGED)
-          return true;
-      return false;
-    };
-    if (unconverged()) {
-      const LjArgs a = make_args(p, p->last_in, p->last_out);
-      const uint32_t n_streams = uint32_t(p->streams.size());
-      uint32_t rounds = 0;
-      while (unconverged() && rounds <= p->total_blocks) {
-        for (int k = 0; k < 4; ++k)
-          launch_sync<true>(p, a, s);
-        rounds += 4;
-        hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
-        RSX_HIP_CHECK(ctx, hipGetLastError());
-        if (int st = fetch())
-          return st;
-      }
-      p->extra_stitch_rounds += int(rounds);
-      // the optimistic tail ran on an inconsistent chain: forget what it reported
-      for (LjResult& R : p->h_results) {
-        R.status = 0;
-        R.tail_used = 0;
-        R.last_slot = R.last_pos = R.consumed = 0;
-      }
-      RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->d_results.ptr, p->h_results.data(),
-                                        p->h_results.size() * sizeof(LjResult),
-                                        hipMemcpyHostToDevice, s));
-      if (int st = launch_tail(p, a, s, nullptr, nullptr))
-        return st;
-      if (int st = fetch())
-        return st;
+  }
+  p->extra_stitch_rounds += int(rounds);
+  // the optimistic tail ran on an inconsistent chain: forget what it reported
+  for (LjResult& R : p->h_results) {
+    R.status = 0;
+    R.tail_used = 0;
+    R.last_slot = R.last_pos = R.consumed = 0;
+  }
+  RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->d_results.ptr, p->h_results.data(),
+                                    p->h_results.size() * sizeof(LjResult),
+                                    hipMemcpyHostToDevice, s));
+  if (int st = launch_tail(p, a, s, nullptr, nullptr))
+    return st;
+  return fetch();
+}
+
+} // namespace
+
+int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_status,
+                       uint32_t* job_consumed) {
+  int rc = RSX_OK;
+  if (ran && !p->streams.empty())
+    if (int st = converge(p, s))
+      return st;
+  // NikonDecompressor jobs with a split: the rows after it are the child's jobs
+  std::vector<int32_t> nk_status(p->nk_split.size(), RSX_OK);
+  if (ran && !p->nk_split.empty()) {
+    std::vector<int32_t> cst;
+    if (p->nk_child) {
+      cst.assign(p->nk_child->n_jobs, RSX_OK);
+      const int crc = ljpeg_plan_results(p->nk_child, s, true, cst.data(), nullptr);
+      if (crc == RSX_ERR_DEVICE || crc == RSX_ERR_NOMEM)
+        return crc;
     }
+    for (size_t k = 0; k < p->nk_split.size(); ++k)
+      nk_status[k] = p->nk_split[k].status;
+    for (size_t c = 0; c < p->nk_child_owner.size(); ++c)
+      if (nk_status[p->nk_child_owner[c]] == RSX_OK)
+        nk_status[p->nk_child_owner[c]] = cst[c];
   }
   // restart-interval jobs: fold the child plan's per-interval results
   std::vector<int32_t> dri_status(p->dri.size(), RSX_OK);
@@ -2335,6 +2783,9 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
           st = RSX_ERR_IO; // inputStream.skipBytes(): LJpegDecompressor.cpp:335
       }
     }
+    for (size_t k = 0; k < p->nk_split.size(); ++k)
+      if (p->nk_split[k].job == i && st == RSX_OK && ran)
+        st = nk_status[k];
     if (job_status)
       job_status[i] = st;
     if (job_consumed)
@@ -2350,6 +2801,10 @@ void ljpeg_plan_destroy(LJpegPlan* p) {
     return;
   if (p->child)
     ljpeg_plan_destroy(p->child);
+  if (p->nk_child)
+    ljpeg_plan_destroy(p->nk_child);
+  for (DeviceBuffer* b : {&p->d_nk, &p->d_nk_tables, &p->d_nk_rowpow, &p->d_nk_pup})
+    b->release();
   p->d_marker_count.release();
   p->d_marker_list.release();
   for (DeviceBuffer* b :

@@ -150,6 +150,7 @@ typedef struct jpeg_writer {
   uint64_t acc;
   int nacc;
   int overflow;
+  int raw; /* 1: plain MSB bit stream, no FF00 stuffing (BitStreamerMSB input) */
 } jpeg_writer;
 
 static void jw_byte_raw(jpeg_writer* w, uint8_t b) {
@@ -161,7 +162,7 @@ static void jw_byte_raw(jpeg_writer* w, uint8_t b) {
 }
 static void jw_data_byte(jpeg_writer* w, uint8_t b) {
   jw_byte_raw(w, b);
-  if (b == 0xFF)
+  if (b == 0xFF && !w->raw)
     jw_byte_raw(w, 0x00); /* byte stuffing */
 }
 static void jw_bits(jpeg_writer* w, uint32_t v, int n) {
@@ -268,7 +269,7 @@ size_t rsx_synth_ljpeg_encode_pattern(const uint16_t* samples, size_t row_stride
       return 0;
     first_pos[comp_of_phase[p]] = p;
   }
-  jpeg_writer w = {out, cap, 0, 0, 0, 0};
+  jpeg_writer w = {out, cap, 0, 0, 0, 0, 0};
   uint64_t bits = 0;
   for (int r = 0; r < rows; ++r) {
     const uint16_t* cur = samples + (size_t)r * row_stride;
@@ -320,6 +321,51 @@ size_t rsx_synth_ljpeg_encode_pattern(const uint16_t* samples, size_t row_stride
   if (n_symbol_bits)
     *n_symbol_bits = bits;
   return w.overflow ? 0 : w.n;
+}
+
+/* NikonDecompressor stream (NikonDecompressor.cpp:515-539) for an image of
+ * 15-bit values: plain MSB bit stream, one Huffman table, the sample at
+ * (row, col) is predicted from (row, col - 2), the first two of a row from
+ * (row - 2, col) and those of rows 0 / 1 from p_up[2 * row + col].  Differences
+ * are plain ints here (the decoder does not wrap), so |diff| must fit the
+ * table's categories.  Returns the byte count (padded with zero bits), 0 on
+ * overflow / missing category. */
+size_t rsx_synth_nikon_encode(const uint16_t* samples, size_t row_stride, int w,
+                              int h, const int32_t* p_up, const uint8_t* counts,
+                              const uint8_t* values, int n_values, uint8_t* out,
+                              size_t cap, uint64_t* n_symbol_bits) {
+  enc_table tab;
+  if (enc_table_build(&tab, counts, values, n_values))
+    return 0;
+  jpeg_writer wr = {out, cap, 0, 0, 0, 0, 1};
+  uint64_t bits = 0;
+  for (int r = 0; r < h; ++r) {
+    const uint16_t* cur = samples + (size_t)r * row_stride;
+    for (int x = 0; x < w; ++x) {
+      int pred;
+      if (x >= 2)
+        pred = cur[x - 2];
+      else if (r >= 2)
+        pred = samples[(size_t)(r - 2) * row_stride + x];
+      else
+        pred = p_up[2 * r + x];
+      const int d = (int)cur[x] - pred;
+      int ssss = 0;
+      for (int a = d < 0 ? -d : d; a; a >>= 1)
+        ++ssss;
+      if (ssss > 15 || tab.len[ssss] == 0)
+        return 0;
+      jw_bits(&wr, tab.code[ssss], tab.len[ssss]);
+      bits += tab.len[ssss] + ssss;
+      if (ssss)
+        jw_bits(&wr, d >= 0 ? (uint32_t)d : (uint32_t)(d + (1 << ssss) - 1), ssss);
+    }
+  }
+  if (wr.nacc > 0)
+    jw_bits(&wr, 0, 8 - wr.nacc);
+  if (n_symbol_bits)
+    *n_symbol_bits = bits;
+  return wr.overflow ? 0 : wr.n;
 }
 
 static void put16(uint8_t** p, unsigned v) {

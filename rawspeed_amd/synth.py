@@ -40,6 +40,10 @@ def lib():
             C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
             C.c_void_p, C.c_size_t, C.c_void_p]
+        _lib.rsx_synth_nikon_encode.restype = C.c_size_t
+        _lib.rsx_synth_nikon_encode.argtypes = [
+            C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+            C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         _lib.rsx_synth_ljpeg_header.restype = C.c_size_t
         _lib.rsx_synth_ljpeg_header.argtypes = [
             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -162,6 +166,45 @@ def ljpeg_container(stream_rows, n_comp, prec, comp_slot, slot_tables,
                            np.array([0xFF, 0xD9], dtype=np.uint8),
                            np.zeros(tail, dtype=np.uint8)])
     return blob, nh, len(scan), bits
+
+
+# NikonDecompressor::nikon_tree (decompressors/NikonDecompressor.cpp:47-66): the
+# six Huffman trees of the NEF format, (16 counts, values).  Trees 1 and 4
+# ("after split") carry len | shl << 4 values decoded by NikonLASDecompressor.
+NIKON_TREE = [
+    ([0, 1, 5, 1, 1, 1, 1, 1, 1, 2, 0, 0, 0, 0, 0, 0],
+     [5, 4, 3, 6, 2, 7, 1, 0, 8, 9, 11, 10, 12, 0]),  # 12-bit lossy (14 codes: the
+                                                       # std::array's zero fill is the 14th value)
+    ([0, 1, 5, 1, 1, 1, 1, 1, 1, 2, 0, 0, 0, 0, 0, 0],
+     [0x39, 0x5a, 0x38, 0x27, 0x16, 5, 4, 3, 2, 1, 0, 11, 12, 12]),      # ... after split
+    ([0, 1, 4, 2, 3, 1, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+     [5, 4, 6, 3, 7, 2, 8, 1, 9, 0, 10, 11, 12]),                        # 12-bit lossless
+    ([0, 1, 4, 3, 1, 1, 1, 1, 1, 2, 0, 0, 0, 0, 0, 0],
+     [5, 6, 4, 7, 8, 3, 9, 2, 1, 0, 10, 11, 12, 13, 14]),                # 14-bit lossy
+    ([0, 1, 5, 1, 1, 1, 1, 1, 1, 1, 2, 0, 0, 0, 0, 0],
+     [8, 0x5c, 0x4b, 0x3a, 0x29, 7, 6, 5, 4, 3, 2, 1, 0, 13, 14]),       # ... after split
+    (NIKON14_COUNTS, NIKON14_VALUES),                                    # 14-bit lossless
+]
+
+
+def nikon_encode(img, p_up, table):
+    """img: (h, w) uint16 of 15-bit values -> NikonDecompressor MSB stream
+    (np.uint8) that decodes to it with uncorrectedRawValues; p_up = the four
+    metadata predictors [row0col0, row0col1, row1col0, row1col1]."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    h, w = img.shape
+    counts = np.asarray(table[0], dtype=np.uint8)
+    values = np.asarray(table[1], dtype=np.uint8)
+    pu = np.asarray(p_up, dtype=np.int32)
+    cap = h * w * 4 + 64
+    out = np.empty(cap, dtype=np.uint8)
+    bits = C.c_uint64(0)
+    n = lib().rsx_synth_nikon_encode(img.ctypes.data, w, w, h, pu.ctypes.data,
+                                     counts.ctypes.data, values.ctypes.data,
+                                     len(values), out.ctypes.data, cap, C.byref(bits))
+    if n == 0:
+        raise ValueError("Nikon encode failed (difference too large for the table?)")
+    return out[:n].copy(), bits.value
 
 
 def huff_tables(*pairs, fix16=False):

@@ -20,7 +20,7 @@ from oracle_lib import Ref  # noqa: E402
 
 def main():
     ref = Ref()
-    out = {"unpack": {}, "variant": {}, "ljpeg": {}, "cr2": {}}
+    out = {"unpack": {}, "variant": {}, "ljpeg": {}, "cr2": {}, "nikon": {}}
     for i, c in enumerate(G.UNPACK_CASES):
         d, data, (w, h, cpp) = G.build_unpack(c)
         img = ref.image(w, h, cpp)
@@ -43,6 +43,11 @@ def main():
         st, consumed = ref.cr2(d, data, img)
         out["cr2"][c["name"]] = {"status": st, "consumed": consumed,
                                  "hash": G.image_hash(img.pixels())}
+    for c in G.NIKON_CASES:
+        meta, d, data, (w, h, cpp), _ = G.build_nikon(c)
+        img = ref.image(w, h, cpp)
+        st = ref.nikon(meta, c["bits"], data, img, bool(c["unc"]))
+        out["nikon"][c["name"]] = {"status": st, "hash": G.image_hash(img.pixels())}
     path = os.path.join(HERE, "golden_hashes.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

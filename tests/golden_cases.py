@@ -11,7 +11,7 @@ import hashlib
 
 import numpy as np
 
-from rawspeed_amd import abi
+from rawspeed_amd import abi, synth
 
 import cases as C
 
@@ -133,3 +133,65 @@ def build_cr2(c, seed=777):
         return d, data, (img.shape[1], c["h"], 1), img
     d, data, img, scan_len = C.make_cr2_case(rng, c["w"], c["h"], c["n"], c["slices"], **kw)
     return d, data, (c["w"], c["h"], 1), img
+
+
+# ---- NikonDecompressor -------------------------------------------------------
+# v0/v1 pick the metadata flavour (NikonDecompressor.cpp:493-513, createCurve):
+# 70 = lossless (identity curve), 68/32|64 = lossy with an interpolated curve and
+# a split row, anything else = a literal curve.  kind "image": a smooth 15-bit
+# image encoded with tree huffSelect (round trip when uncorrected); "symbols":
+# random symbols (the only way to exercise the "after split" trees).
+NIKON_CASES = [
+    dict(name="lossless14_image", v0=70, v1=0, bits=14, w=64, h=20, kind="image", unc=1),
+    dict(name="lossless14_dither", v0=70, v1=0, bits=14, w=64, h=20, kind="image", unc=0),
+    dict(name="lossless12_image", v0=70, v1=0, bits=12, w=48, h=18, kind="image", unc=1),
+    dict(name="lossy12_curve", v0=68, v1=32, bits=12, w=40, h=16, kind="symbols", unc=0),
+    dict(name="lossy12_split", v0=68, v1=32, bits=12, w=40, h=16, split=7, kind="symbols", unc=0),
+    dict(name="lossy12_split_unc", v0=68, v1=32, bits=12, w=40, h=16, split=7, kind="symbols", unc=1),
+    dict(name="lossy14_z7_split", v0=68, v1=64, bits=14, w=48, h=20, split=9, kind="symbols", unc=0),
+    dict(name="lossy14_curve", v0=68, v1=32, bits=14, w=48, h=12, kind="symbols", unc=0),
+    dict(name="literal_curve", v0=68, v1=16, bits=12, w=40, h=10, kind="symbols", unc=0),
+    dict(name="skip2110", v0=73, v1=0, bits=12, w=32, h=8, kind="symbols", unc=0),
+    dict(name="lossless_v1_88", v0=70, v1=88, bits=14, w=32, h=8, kind="symbols", unc=0),
+    dict(name="split_outside", v0=68, v1=32, bits=12, w=40, h=16, split=16, kind="symbols", unc=0),
+    dict(name="medium_image", v0=70, v1=0, bits=14, w=1200, h=300, kind="image", unc=0),
+    dict(name="medium_split", v0=68, v1=32, bits=12, w=800, h=200, split=77, kind="symbols", unc=0),
+]
+
+
+def nikon_curve_points(n, maxv):
+    x = np.linspace(0, 1, n)
+    c = (maxv * x ** 0.8).astype(int)
+    c[5:8] = c[5:8][::-1]  # a non-monotonic kink (TableLookUp.cpp:71-73)
+    return c
+
+
+def build_nikon(c, seed=2024):
+    import nikon_cases as N
+    rng = np.random.default_rng([seed, sum(map(ord, c["name"]))])
+    v0, v1, bits, w, h = c["v0"], c["v1"], c["bits"], c["w"], c["h"]
+    if v0 == 68 and v1 in (32, 64):
+        pts = nikon_curve_points(257, (1 << (bits - 2 if v1 == 64 else bits)) - 1)
+    elif v0 != 70:
+        pts = nikon_curve_points(300, 4000)
+    else:
+        pts = []
+    p_up = [int(x) for x in rng.integers(1500, 2500, size=4)]
+    meta = N.metadata(v0, v1, p_up, pts, c.get("split", 0), pad_to=3000)
+    P = N.parse(meta, bits, h)
+    hs = P["huff_select"]
+    src = None
+    if c["kind"] == "image":
+        src = N.smooth15(rng, h, w, maxv=(1 << bits) - 1)
+        pu = P["p_up"]
+        data, _ = synth.nikon_encode(src, [pu[0][0], pu[0][1], pu[1][0], pu[1][1]],
+                                     synth.NIKON_TREE[hs])
+        data = np.concatenate([data, np.zeros(8, np.uint8)])
+    else:
+        sp = P["split"]
+        n0 = (sp or h) * w
+        n1 = (h - sp) * w if sp else 0
+        data = N.symbol_stream(rng, n0, synth.NIKON_TREE[hs], n1,
+                               synth.NIKON_TREE[hs + 1] if n1 else None)
+    d = N.desc(P, bits, bool(c["unc"]))
+    return meta, d, data, (w, h, 1), src

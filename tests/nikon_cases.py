@@ -1,0 +1,138 @@
+"""NikonDecompressor test inputs: the makernote linearisation blob the reference
+constructor parses (NikonDecompressor.cpp:473-513, createCurve :381-445), a
+restatement of that parse (what fills rsx_nikon_desc on the reference side), and
+two stream generators."""
+import numpy as np
+
+from rawspeed_amd import abi, synth
+
+
+def metadata(v0, v1, p_up, points=None, split=0, pad_to=600):
+    """Big-endian blob: v0, v1, [2110 skipped bytes], pUp x4, csize, curve
+    points ..., and the split row at absolute offset 562."""
+    b = bytearray([v0, v1])
+    if v0 == 73 or v1 == 88:
+        b += bytes(2110)
+    for p in p_up:
+        b += int(p).to_bytes(2, "big")
+    points = [] if points is None else list(points)
+    b += len(points).to_bytes(2, "big")
+    for p in points:
+        b += int(p).to_bytes(2, "big")
+    if len(b) < pad_to:
+        b += bytes(pad_to - len(b))
+    if split:
+        b[562:564] = int(split).to_bytes(2, "big")
+    return np.frombuffer(bytes(b), dtype=np.uint8).copy()
+
+
+def parse(meta, bits_ps, dim_y):
+    """NikonDecompressor::NikonDecompressor + createCurve, restated."""
+    m = bytes(meta)
+    pos = 0
+
+    def u16():
+        nonlocal pos
+        v = int.from_bytes(m[pos:pos + 2], "big")
+        pos += 2
+        return v
+
+    v0, v1 = m[0], m[1]
+    pos = 2
+    if v0 == 73 or v1 == 88:
+        pos += 2110
+    huff_select = 2 if v0 == 70 else 0
+    if bits_ps == 14:
+        huff_select += 3
+    p_up = [u16(), u16(), u16(), u16()]            # [0][0], [1][0], [0][1], [1][1]
+    p_up = [[p_up[0], p_up[2]], [p_up[1], p_up[3]]]
+    cbits = bits_ps - 2 if (v0 == 68 and v1 == 64) else bits_ps   # Z7 hack
+    curve = list(range(((1 << cbits) & 0x7fff) + 1))
+    split = 0
+    csize = u16()
+    step = len(curve) // (csize - 1) if csize > 1 else 0
+    if v0 == 68 and v1 in (32, 64) and step > 0:
+        assert (csize - 1) * step == len(curve) - 1, "Bad curve segment count"
+        for i in range(csize):
+            curve[i * step] = u16()
+        for i in range(len(curve) - 1):
+            b_scale = i % step
+            a_pos = i - b_scale
+            b_pos = a_pos + step
+            a_scale = step - b_scale
+            curve[i] = ((a_scale * curve[a_pos] + b_scale * curve[b_pos]) // step) & 0xFFFF
+        split = int.from_bytes(m[562:564], "big")
+    elif v0 != 70:
+        assert 0 < csize <= 0x4001
+        curve = [u16() for _ in range(csize)] + [0]
+    curve = curve[:-1]
+    if split >= dim_y:
+        split = 0
+    return dict(huff_select=huff_select, p_up=p_up, curve=np.array(curve, np.uint16),
+                split=split)
+
+
+def desc(parsed, bits_ps, uncorrected):
+    d = abi.NikonDesc()
+    d.bits_ps = bits_ps
+    d.split = parsed["split"]
+    for r in range(2):
+        for c in range(2):
+            d.p_up[r][c] = parsed["p_up"][r][c]
+    d.uncorrected_raw_values = 1 if uncorrected else 0
+    d.set_curve(parsed["curve"])
+    hs = parsed["huff_select"]
+    d.tables[0] = abi.HuffTable.make(*synth.NIKON_TREE[hs])
+    if parsed["split"]:
+        d.tables[1] = abi.HuffTable.make(*synth.NIKON_TREE[hs + 1])
+    return d
+
+
+def _canonical(tree):
+    counts, values = tree
+    out, code, k = [], 0, 0
+    for l in range(1, 17):
+        for _ in range(counts[l - 1]):
+            out.append((code, l, values[k]))
+            code += 1
+            k += 1
+        code <<= 1
+    return out
+
+
+def symbol_stream(rng, n0, tree0, n1=0, tree1=None, tail=8):
+    """n0 random symbols of tree0 (plain SSSS values) followed by n1 of tree1
+    ("after split": len | shl << 4, len - shl raw bits), as an MSB bit stream.
+    The decoded image is whatever the reference makes of it."""
+    vals, lens = [], []
+    for n, tree, las in ((n0, tree0, False), (n1, tree1, True)):
+        if not n:
+            continue
+        sym = _canonical(tree)
+        p = np.array([2.0 ** -l for (_, l, _) in sym])
+        idx = rng.choice(len(sym), size=n, p=p / p.sum())
+        code = np.array([s[0] for s in sym], np.int64)[idx]
+        clen = np.array([s[1] for s in sym], np.int64)[idx]
+        v = np.array([s[2] for s in sym], np.int64)[idx]
+        nb = np.where(v == 16, 0, (v & 15) - (v >> 4)) if las else np.where(v == 16, 0, v)
+        extra = rng.integers(0, 1 << 16, size=n, dtype=np.int64) & ((1 << nb) - 1)
+        # keep the walk near the middle: mostly small magnitudes
+        vals.append((code << nb) | extra)
+        lens.append(clen + nb)
+    val, ln = np.concatenate(vals), np.concatenate(lens)
+    start = np.concatenate([[0], np.cumsum(ln)[:-1]])
+    total = int(ln.sum())
+    bits = np.zeros(total + 8, np.uint8)
+    for k in range(int(ln.max())):
+        m = k < ln
+        bits[start[m] + k] = (val[m] >> (ln[m] - 1 - k)) & 1
+    return np.concatenate([np.packbits(bits), np.zeros(tail, np.uint8)])
+
+
+def smooth15(rng, h, w, maxv=16383, sigma=12.0):
+    """A 2x2-CFA-like image whose same-colour neighbour differences are small."""
+    x = np.arange(w)[None, :]
+    y = np.arange(h)[:, None]
+    img = (0.25 * maxv + 0.3 * maxv * x / w + 0.2 * maxv * y / h +
+           0.05 * maxv * ((x & 1) + 2 * (y & 1)) + rng.normal(0, sigma, size=(h, w)))
+    return np.clip(img, 0, maxv).astype(np.uint16)

@@ -74,6 +74,9 @@ class Oracle:
         L.oracle_unpack_variant_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                                 C.c_void_p]
         L.oracle_unpack_variant_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_nikon_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_nikon_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
+                                              C.c_void_p]
         L.oracle_ljpeg_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_void_p, C.c_void_p]
         L.oracle_ljpeg_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -104,6 +107,15 @@ class Oracle:
     def unpack_variant_validate(self, desc, img, n):
         v = img.view()
         return self.lib.oracle_unpack_variant_validate(C.byref(desc), C.byref(v), n)
+
+    def nikon(self, desc, data, img):
+        a, p, n = _as_u8(data)
+        v = img.view()
+        return self.lib.oracle_nikon_decompress(C.byref(desc), p, n, C.byref(v))
+
+    def nikon_validate(self, desc, img):
+        v = img.view()
+        return self.lib.oracle_nikon_validate(C.byref(desc), C.byref(v))
 
     def ljpeg(self, desc, data, img):
         a, p, n = _as_u8(data)
@@ -205,6 +217,8 @@ class Ref:
         L.ref_unpack_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.ref_unpack_variant_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_size_t]
+        L.ref_nikon_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
+                                           C.c_void_p, C.c_size_t, C.c_int]
         L.ref_ljpeg_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_size_t, C.c_void_p]
         L.ref_cr2_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
@@ -236,6 +250,12 @@ class Ref:
     def unpack_variant(self, desc, data, img):
         a, p, n = _as_u8(data)
         return self.lib.ref_unpack_variant_u16(img.h, C.byref(desc), p, n)
+
+    def nikon(self, meta, bits_ps, data, img, uncorrected):
+        m, mp, mn = _as_u8(meta)
+        a, p, n = _as_u8(data)
+        return self.lib.ref_nikon_decompress(img.h, mp, mn, bits_ps, p, n,
+                                             1 if uncorrected else 0)
 
     def ljpeg(self, desc, data, img):
         a, p, n = _as_u8(data)

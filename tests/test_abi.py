@@ -36,6 +36,7 @@ def test_struct_sizes_are_stable():
     assert C.sizeof(abi.UnpackDesc) == 28
     assert C.sizeof(abi.UnpackVariantDesc) == 16
     assert C.sizeof(abi.UnpackVariantJob) == 16 + 24 + 32
+    assert C.sizeof(abi.NikonDesc) == 8 * 4 + 8 + 2 * 180
     assert C.sizeof(abi.Image) == 32
     assert C.sizeof(abi.LJpegDesc) == 4 * 10 + 8 + 4 + 4 + 4 * 180
     assert C.sizeof(abi.Cr2Desc) == 4 * 8 + 8 + 4 + 4 + 4 * 180
@@ -128,6 +129,46 @@ def test_ljpeg_validate_matches_oracle(lib, oracle):
         assert a == b
         n_ok += a == 0
     assert n_ok > 5
+
+
+def test_nikon_validate_matches_oracle(lib, oracle):
+    import nikon_cases as N
+    from rawspeed_amd import synth
+    rng = np.random.default_rng(14)
+    seen = set()
+    for trial in range(1500):
+        w = int(rng.choice([2, 3, 40, 64, 8288, 8290]))
+        h = int(rng.choice([1, 16, 5520, 5521]))
+        img = HostImage(8, 2, int(rng.choice([1, 1, 1, 2])))
+        img.dim_x, img.dim_y = w, h       # validation never touches the pixels
+        meta = N.metadata(70, 0, [1, 2, 3, 4])
+        P = N.parse(meta, 14, 16)
+        d = N.desc(P, int(rng.choice([12, 14, 14, 13])), bool(rng.integers(0, 2)))
+        d.split = int(rng.choice([0, 0, 3, h - 1, h, -1]))
+        if rng.integers(0, 6) == 0:
+            d.p_up[1][0] = int(rng.choice([-1, 65535, 65536]))
+        if rng.integers(0, 6) == 0:
+            d.curve_size = int(rng.choice([0, 1, 65536, 65537]))
+        t = rng.integers(0, 8)
+        if t == 0:
+            d.tables[0].n_codes_per_length[0] = 3          # over-subscribed
+        elif t == 1:
+            d.tables[0].code_values[2] = 17                # not a difference length
+        elif t == 2:
+            d.tables[0].fix_dng_bug16 = 1
+        d.tables[1] = abi.HuffTable.make(*synth.NIKON_TREE[4])
+        t = rng.integers(0, 8)
+        if t == 0:
+            d.tables[1].code_values[1] = 0x55              # len == shl: getBits(0)
+        elif t == 1:
+            d.tables[1].code_values[1] = 0x72              # shl > len
+        elif t == 2:
+            d.tables[1].n_code_values = 3
+        v = img.view()
+        a = lib.rsx_nikon_validate(C.byref(d), C.byref(v))
+        assert a == oracle.nikon_validate(d, img), trial
+        seen.add(a)
+    assert seen == {abi.RSX_OK, abi.RSX_ERR_INVALID_ARG}
 
 
 def test_cr2_validate_matches_oracle(lib, oracle):

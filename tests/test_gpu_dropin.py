@@ -182,3 +182,18 @@ def test_uncompressed_variant_methods(pair):
                     pair, lambda lib, img: lib.unpack_variant(d, data, img), (w, h, 1))
                 assert s0 == s1 and (s0 == 0) == (cut == 0), (variant, big, w, e0, e1)
                 assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["lossless14_dither", "lossy12_split", "lossy14_z7_split",
+                                  "literal_curve", "medium_image", "medium_split"])
+def test_nikon_decompressor(pair, name):
+    """NikonDecompressor: the reference constructor parses the makernote blob
+    (curve, split, pUp), the patched decompress() forwards to librsx."""
+    import golden_cases as G
+    c = next(c for c in G.NIKON_CASES if c["name"] == name)
+    meta, d, data, (w, h, cpp), _ = G.build_nikon(c)
+    for unc in (True, False):
+        (s0, a, e0), (s1, b, e1) = both(
+            pair, lambda lib, img: lib.nikon(meta, c["bits"], data, img, unc), (w, h, cpp))
+        assert s0 == 0 and s1 == 0, (e0, e1)
+        assert np.array_equal(a, b)

@@ -1,0 +1,153 @@
+"""GPU parity: NikonDecompressor through the C-ABI (rsx_nikon_decompress /
+rsx_nikon_plan_create) vs the oracle and the reference's golden hashes."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from rawspeed_amd import abi, synth
+
+import golden_cases as G
+import nikon_cases as N
+from oracle_lib import HostImage, out_pitch
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(os.path.dirname(__file__), "golden", "golden_hashes.json")) as f:
+    GOLD = json.load(f)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import gpu_util
+    return gpu_util.ctx()
+
+
+@pytest.mark.parametrize("c", G.NIKON_CASES, ids=lambda c: c["name"])
+def test_nikon_golden(gpu, oracle, c):
+    meta, d, data, (w, h, cpp), src = G.build_nikon(c)
+    img, want = HostImage(w, h, cpp), HostImage(w, h, cpp)
+    st = gpu.nikon_decompress(d, data, img.view())
+    assert st == oracle.nikon(d, data, want) == GOLD["nikon"][c["name"]]["status"] == 0
+    assert np.array_equal(img.u16(), want.u16())
+    assert G.image_hash(img.pixels()) == GOLD["nikon"][c["name"]]["hash"]
+    if src is not None and c["unc"]:
+        assert np.array_equal(img.pixels(), src)
+
+
+@pytest.mark.parametrize("bits,w,h,unc", [(14, 2144, 400, 1), (14, 2144, 400, 0),
+                                          (12, 1000, 333, 0), (14, 8288, 64, 0)])
+def test_nikon_lossless_sizes(gpu, oracle, bits, w, h, unc):
+    """Several workgroups per stream, odd heights, the maximum width."""
+    rng = np.random.default_rng([51, bits, w])
+    src = N.smooth15(rng, h, w, maxv=(1 << bits) - 1)
+    meta = N.metadata(70, 0, [2000, 2100, 2200, 2300])
+    P = N.parse(meta, bits, h)
+    pu = P["p_up"]
+    data, _ = synth.nikon_encode(src, [pu[0][0], pu[0][1], pu[1][0], pu[1][1]],
+                                 synth.NIKON_TREE[P["huff_select"]])
+    data = np.concatenate([data, np.zeros(8, np.uint8)])
+    d = N.desc(P, bits, bool(unc))
+    img, want = HostImage(w, h), HostImage(w, h)
+    assert gpu.nikon_decompress(d, data, img.view()) == oracle.nikon(d, data, want) == 0
+    assert np.array_equal(img.u16(), want.u16())
+    if unc:
+        assert np.array_equal(img.pixels(), src)
+
+
+@pytest.mark.parametrize("bits,v1,w,h,split", [(12, 32, 1504, 300, 131), (14, 32, 1000, 240, 1),
+                                               (14, 64, 640, 200, 199), (12, 32, 2000, 90, 45)])
+def test_nikon_split_sizes(gpu, oracle, bits, v1, w, h, split):
+    """The "lossy after split" table starts at a bit position that only the
+    decode of the first part reveals (two-phase plan); clamping at 0 / 32767."""
+    rng = np.random.default_rng([52, bits, w, split])
+    pts = G.nikon_curve_points(257, (1 << (bits - 2 if v1 == 64 else bits)) - 1)
+    meta = N.metadata(68, v1, [3000, 3100, 3200, 3300], pts, split, pad_to=3000)
+    P = N.parse(meta, bits, h)
+    assert P["split"] == split
+    hs = P["huff_select"]
+    data = N.symbol_stream(rng, split * w, synth.NIKON_TREE[hs], (h - split) * w,
+                           synth.NIKON_TREE[hs + 1])
+    for unc in (1, 0):
+        d = N.desc(P, bits, bool(unc))
+        img, want = HostImage(w, h), HostImage(w, h)
+        assert gpu.nikon_decompress(d, data, img.view()) == oracle.nikon(d, data, want) == 0
+        assert np.array_equal(img.u16(), want.u16())
+
+
+def test_nikon_truncated(gpu, oracle):
+    """Status parity at every cut of a split stream (BitStreamerMSB reads zeros
+    for 8 bytes past the end, then throws)."""
+    c = dict(name="trunc", v0=68, v1=32, bits=12, w=40, h=16, split=7, kind="symbols", unc=1)
+    meta, d, data, (w, h, cpp), _ = G.build_nikon(c)
+    full = int(np.flatnonzero(data)[-1]) + 1
+    seen = set()
+    for cut in list(range(0, 40)) + [60, 100, 200, full // 2, full - 3]:
+        n = full - cut
+        if n < 1:
+            continue
+        part = data[:n]
+        img, want = HostImage(w, h, cpp), HostImage(w, h, cpp)
+        so = oracle.nikon(d, part, want)
+        sg = gpu.nikon_decompress(d, part, img.view())
+        assert sg == so, (cut, sg, so)
+        if so == 0:
+            assert np.array_equal(img.u16(), want.u16())
+        seen.add(so)
+    assert 0 in seen and len(seen) >= 2
+
+
+def test_nikon_plan_batch(gpu, oracle):
+    """Device-resident plan: several frames (with and without split, both output
+    modes) in one launch sequence; run twice (the split child plan is reused)."""
+    import gpu_util
+    rng = np.random.default_rng(53)
+    jobs, wants, chunks = [], [], []
+    in_off = out_off = 0
+    keep = []
+    for k, (bits, split, unc) in enumerate([(14, 0, 1), (12, 40, 0), (14, 0, 0), (12, 17, 1)]):
+        w, h = 640 + 64 * k, 120
+        if split:
+            pts = G.nikon_curve_points(257, (1 << bits) - 1)
+            meta = N.metadata(68, 32, [3000, 3100, 3200, 3300], pts, split, pad_to=3000)
+            P = N.parse(meta, bits, h)
+            hs = P["huff_select"]
+            data = N.symbol_stream(rng, split * w, synth.NIKON_TREE[hs], (h - split) * w,
+                                   synth.NIKON_TREE[hs + 1])
+        else:
+            meta = N.metadata(70, 0, [2000, 2100, 2200, 2300])
+            P = N.parse(meta, bits, h)
+            src = N.smooth15(rng, h, w, maxv=(1 << bits) - 1)
+            pu = P["p_up"]
+            data, _ = synth.nikon_encode(src, [pu[0][0], pu[0][1], pu[1][0], pu[1][1]],
+                                         synth.NIKON_TREE[P["huff_select"]])
+            data = np.concatenate([data, np.zeros(8, np.uint8)])
+        d = N.desc(P, bits, bool(unc))
+        keep.append(d)
+        want = HostImage(w, h)
+        assert oracle.nikon(d, data, want) == 0
+        j = abi.NikonJob()
+        j.desc = d
+        j.in_offset, j.in_bytes, j.img_offset = in_off, data.size, out_off
+        j.img = gpu_util.image_job_view(w, h, 1, want.pitch)
+        jobs.append(j)
+        wants.append(want)
+        chunks.append((in_off, data))
+        in_off += (data.size + 64 + 15) // 16 * 16
+        out_off += want.buf.size
+    in_host = np.zeros(in_off + 64, np.uint8)
+    for off, data in chunks:
+        in_host[off:off + data.size] = data
+    d_in = gpu_util.to_dev(in_host)
+    plan = gpu.nikon_plan(jobs)
+    for _ in range(2):
+        d_out = torch.full((out_off + 16,), 0xA5, dtype=torch.uint8, device="cuda")
+        plan.run(d_in.data_ptr(), d_out.data_ptr())
+        rc, status, _ = plan.results()
+        assert rc == 0 and status == [0] * len(jobs)
+        got = d_out.cpu().numpy()
+        for j, want in zip(jobs, wants):
+            assert np.array_equal(got[j.img_offset:j.img_offset + want.buf.size], want.buf)
+    plan.close()

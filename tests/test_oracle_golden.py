@@ -58,7 +58,53 @@ def test_cr2_golden(oracle, c):
     assert np.array_equal(img.pixels(), src)
 
 
+@pytest.mark.parametrize("c", G.NIKON_CASES, ids=lambda c: c["name"])
+def test_nikon_golden(oracle, c):
+    meta, d, data, (w, h, cpp), src = G.build_nikon(c)
+    img = HostImage(w, h, cpp)
+    st = oracle.nikon(d, data, img)
+    g = GOLD["nikon"][c["name"]]
+    assert st == g["status"] == 0
+    assert G.image_hash(img.pixels()) == g["hash"]
+    if src is not None and c["unc"]:
+        assert np.array_equal(img.pixels(), src)   # round trip
+
+
 # ---- live cross-checks against the compiled reference ----------------------
+
+@pytest.mark.parametrize("c", G.NIKON_CASES, ids=lambda c: c["name"])
+def test_nikon_vs_ref(oracle, ref, c):
+    """Full-buffer compare; also pins tests/nikon_cases.parse (the constructor
+    restatement that fills rsx_nikon_desc) against the reference's own parse."""
+    meta, d, data, (w, h, cpp), _ = G.build_nikon(c)
+    for unc in (True, False):
+        d.uncorrected_raw_values = 1 if unc else 0
+        hi, ri = HostImage(w, h, cpp), ref.image(w, h, cpp)
+        assert oracle.nikon(d, data, hi) == ref.nikon(meta, c["bits"], data, ri, unc) == 0
+        assert np.array_equal(hi.u16(), ri.u16())
+
+
+def test_nikon_truncated_vs_ref(oracle, ref):
+    """BitStreamerMSB's position budget: zeros are read for 8 bytes past the end,
+    then IOException (BitStreamer.h:120-131) -- status parity at every cut."""
+    import nikon_cases as N
+    c = dict(name="trunc", v0=68, v1=32, bits=12, w=40, h=16, split=7, kind="symbols", unc=1)
+    meta, d, data, (w, h, cpp), _ = G.build_nikon(c)
+    full = int(np.flatnonzero(data)[-1]) + 1
+    seen = set()
+    for cut in list(range(0, 40)) + [60, 100, 200, full // 2]:
+        n = full - cut
+        if n < 1:
+            continue
+        part = data[:n]
+        hi, ri = HostImage(w, h, cpp), ref.image(w, h, cpp)
+        so, sr = oracle.nikon(d, part, hi), ref.nikon(meta, 12, part, ri, True)
+        assert so == sr, (cut, so, sr, ref.last_error())
+        if so == 0:
+            assert np.array_equal(hi.u16(), ri.u16())
+        seen.add(so)
+    assert 0 in seen and len(seen) >= 2
+
 
 def test_unpack_variant_vs_ref_sweep(oracle, ref):
     """decode8BitRaw<true>, decode12BitRawWithControl<e>,
