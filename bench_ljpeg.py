@@ -253,6 +253,72 @@ def cpu_baseline_cr2(d, data, W, H, budget_s=10.0):
                       "best of %d" % len(times)}
 
 
+def run_nikon(ctx, torch, log, frames=8, steps=10, warmup=2, cpu=True):
+    """NikonDecompressor: 14-bit lossless NEF of a 6016x4016 sensor
+    (tree 5, identity curve), default output mode = curve table with dither."""
+    import nikon_cases as N
+    from rawspeed_amd import abi, synth
+    W, H, bits = 6016, 4016, 14
+    rng = np.random.default_rng(8)
+    src = synth.sensor_image(W, H, 14, seed=8)
+    meta = N.metadata(70, 0, [2000, 2500, 2500, 3000])
+    P = N.parse(meta, bits, H)
+    pu = P["p_up"]
+    data, sym_bits = synth.nikon_encode(src, [pu[0][0], pu[0][1], pu[1][0], pu[1][1]],
+                                        synth.NIKON_TREE[P["huff_select"]])
+    data = np.concatenate([data, np.zeros(16 + (-len(data)) % 16, np.uint8)])
+    out = {"workload": "NikonDecompressor 14-bit lossless %dx%d, %d frames/step" % (W, H, frames),
+           "entropy_bits_per_px": round(sym_bits / (W * H), 3)}
+    for mode, unc in (("curve_dither", 0), ("uncorrected", 1)):
+        d = N.desc(P, bits, bool(unc))
+        jobs = []
+        for f in range(frames):
+            j = abi.NikonJob()
+            j.desc = d
+            j.in_offset, j.in_bytes = f * data.size, data.size
+            j.img_offset = f * out_pitch(W) * H
+            j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
+                out_pitch(W), W, H, 1, 1
+            jobs.append(j)
+        inp = torch.from_numpy(np.tile(data, frames)).cuda()
+        outb = torch.zeros(frames * out_pitch(W) * H, dtype=torch.uint8, device="cuda")
+        plan = ctx.nikon_plan(jobs)
+        dt, kt, _ = _time_plan(torch, plan, inp, outb, steps, warmup)
+        plan.close()
+        got = outb[-out_pitch(W) * H:].cpu().numpy().view(np.uint16).reshape(
+            H, out_pitch(W) // 2)[:, :W]
+        r = {"mpix_per_s": round(frames * W * H / dt / 1e6, 1),
+             "ms_per_step": round(dt * 1e3, 4)}
+        if unc:
+            r["bit_exact"] = bool(np.array_equal(got, src))
+        else:
+            dith = got.copy()  # checked against the reference build below
+        out[mode] = r
+        log("nikon %s: %s" % (mode, r))
+        del inp, outb
+    if cpu:
+        try:
+            from oracle_lib import Ref
+            if Ref.available():
+                ref = Ref()
+                img = ref.image(W, H, 1)
+                assert ref.nikon(meta, bits, data, img, False) == 0
+                out["curve_dither"]["bit_exact"] = bool(np.array_equal(img.pixels(), dith))
+                times = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    ref.nikon(meta, bits, data, img, False)
+                    times.append(time.perf_counter() - t0)
+                out["cpu_baseline"] = {
+                    "value": round(W * H / min(times) / 1e6, 1), "unit": "MPix/s", "cores": 1,
+                    "kind": "reference",
+                    "sample": "NikonDecompressor::decompress of the unmodified reference on the "
+                              "same stream (curve + dither), 1 thread, best of 3"}
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
 def run_variants(ctx, torch, log, frames=8, steps=50, warmup=20):
     """The fixed-layout UncompressedDecompressor entry points at the
     cfg2 sensor size: decode12BitRawWithControl<big>, decode12BitRawUnpacked-
@@ -303,6 +369,10 @@ def run(ctx, torch, log):
     out["cfg3_cr2_6720x4480"] = r3
     out["cfg4_dng_tiles_8192x5464"] = run_cfg4(ctx, torch, log)
     try:
+        out["nikon_lossless14_6016x4016"] = run_nikon(ctx, torch, log)
+    except Exception as e:
+        out["nikon_lossless14_6016x4016"] = {"error": repr(e)}
+    try:
         out["cr2_sraw1_3960x2640"] = run_sraw(ctx, torch, log)
     except Exception as e:
         out["cr2_sraw1_3960x2640"] = {"error": repr(e)}
@@ -332,6 +402,9 @@ if __name__ == "__main__":
     elif args.only == "variants":
         print(json.dumps(run_variants(ctx, torch, print, frames=args.frames,
                                       steps=args.steps), indent=1))
+    elif args.only == "nikon":
+        print(json.dumps(run_nikon(ctx, torch, print, frames=args.frames, steps=args.steps),
+                         indent=1))
     elif args.only == "sraw":
         print(json.dumps(run_sraw(ctx, torch, print, frames=args.frames, steps=args.steps),
                          indent=1))
