@@ -128,6 +128,19 @@ int rsx_unpack_validate(const rsx_unpack_desc* d, const rsx_image* img,
 int rsx_unpack_u16(rsx_ctx* ctx, const rsx_unpack_desc* d, const uint8_t* in,
                    size_t in_bytes, const rsx_image* img);
 
+/* 1a. The same method on RawImageType::F32 images (.cpp:212-245):            */
+/*    bits_per_pixel 32 -> copyPixels (.cpp:213-222), 16 / 24 with MSB or LSB*/
+/*    order -> decodePackedFP<Pump, Binary16 | Binary24> (.cpp:171-186,      */
+/*    common/FloatingPoint.h:109-145: exact widening to binary32, subnormals */
+/*    renormalised, NaN payloads kept).  Anything else is the reference's    */
+/*    "Unsupported floating-point input bitwidth/bit packing".  `img->data`  */
+/*    holds 4-byte samples; unlike the integer path, decodePackedFP honours  */
+/*    crop_x (as a SAMPLE offset, .cpp:181) -- replicated.                   */
+int rsx_unpack_f32_validate(const rsx_unpack_desc* d, const rsx_image* img,
+                            size_t in_bytes);
+int rsx_unpack_f32(rsx_ctx* ctx, const rsx_unpack_desc* d, const uint8_t* in,
+                   size_t in_bytes, const rsx_image* img);
+
 /* ------------------------------------------------------------------------ */
 /* 1b. The fixed-layout entry points of the same class                       */
 /*    UncompressedDecompressor::decode8BitRaw<true>()        (.cpp:270-291)  */
@@ -135,20 +148,24 @@ int rsx_unpack_u16(rsx_ctx* ctx, const rsx_unpack_desc* d, const uint8_t* in,
 /*    UncompressedDecompressor::decode12BitRawUnpackedLeftAligned<e>()       */
 /*                                                           (.cpp:356-378)  */
 /*    They use only size = crop.dim of the constructor and write from pixel  */
-/*    (0,0) of the image, ignoring crop.pos -- replicated.  The curve/dither */
-/*    flavour decode8BitRaw<false> (TableLookUp) is post-processing and not  */
-/*    part of this core.                                                     */
+/*    (0,0) of the image, ignoring crop.pos -- replicated.                   */
+/*    decode8BitRaw<false>() stores setWithLookUp(byte) instead              */
+/*    (common/RawImage.h:335-353) with a random state that starts at 0 and   */
+/*    therefore stays 0: the result is a pure function of the byte, passed   */
+/*    as `lut` (for a dithering table: tables[2 * v], else tables[v]).       */
 /* ------------------------------------------------------------------------ */
 typedef enum rsx_unpack_variant {
   RSX_UNPACK_8BIT_RAW = 0,
   RSX_UNPACK_12BIT_WITH_CONTROL = 1,
-  RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED = 2
+  RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED = 2,
+  RSX_UNPACK_8BIT_LOOKUP = 3 /* decode8BitRaw<false> */
 } rsx_unpack_variant;
 
 typedef struct rsx_unpack_variant_desc {
   int32_t variant;    /* rsx_unpack_variant */
   int32_t big_endian; /* template parameter Endianness e (ignored for 8-bit) */
   int32_t w, h;       /* size.x, size.y */
+  uint16_t lut[256];  /* RSX_UNPACK_8BIT_LOOKUP only */
 } rsx_unpack_variant_desc;
 
 int rsx_unpack_variant_validate(const rsx_unpack_variant_desc* d,
@@ -353,6 +370,9 @@ typedef struct rsx_nikon_job {
 
 int rsx_unpack_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_unpack_job* jobs,
                            rsx_plan** out_plan);
+/* F32 images: same job structure, img describes 4-byte samples */
+int rsx_unpack_f32_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_unpack_job* jobs,
+                               rsx_plan** out_plan);
 int rsx_unpack_variant_plan_create(rsx_ctx* ctx, int n_jobs,
                                    const rsx_unpack_variant_job* jobs,
                                    rsx_plan** out_plan);

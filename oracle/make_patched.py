@@ -17,7 +17,22 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_ref", "patched")
 
 HUNK_UNPACK = r'''
-  // ---- rsx: forward the UINT16 paths to the MI355X core (INTEGRATION.md 1) ----
+  // ---- rsx: forward to the MI355X core (INTEGRATION.md 1) ----
+  if (mRaw->getDataType() == RawImageType::F32) {
+    rsx_unpack_desc d{};
+    d.crop_x = offset.x;
+    d.crop_y = offset.y;
+    d.crop_w = size.x;
+    d.crop_h = size.y;
+    d.input_pitch_bytes = inputPitchBytes;
+    d.bits_per_pixel = bitPerPixel;
+    d.bit_order = static_cast<int32_t>(order);
+    const rsx_image img = rsx_shim::view(mRaw);
+    const Buffer in = input.peekRemainingBuffer();
+    if (int st = rsx_unpack_f32(rsx_shim::context(), &d, in.begin(), in.getSize(), &img))
+      rsx_shim::raise(st);
+    return;
+  }
   if (mRaw->getDataType() == RawImageType::UINT16) {
     rsx_unpack_desc d{};
     d.crop_x = offset.x;
@@ -52,8 +67,31 @@ HUNK_VARIANT = r'''
   }
 '''
 
-HUNK_8BIT = ("\n  if constexpr (uncorrectedRawValues) {" +
-             HUNK_VARIANT % dict(variant="RSX_UNPACK_8BIT_RAW", big="0") + "  }\n")
+HUNK_8BIT = r'''
+  // ---- rsx: forward to the MI355X core (INTEGRATION.md 1b) ----
+  {
+    rsx_unpack_variant_desc d{};
+    d.variant = uncorrectedRawValues ? RSX_UNPACK_8BIT_RAW : RSX_UNPACK_8BIT_LOOKUP;
+    d.w = size.x;
+    d.h = size.y;
+    if constexpr (!uncorrectedRawValues) {
+      // the loop below starts with random = 0, which setWithLookUp maps to 0 again:
+      // the stored value is a pure function of the byte
+      for (int v = 0; v < 256; ++v) {
+        uint16_t px = 0;
+        uint32_t rnd = 0;
+        mRaw->setWithLookUp(implicit_cast<uint16_t>(v), reinterpret_cast<std::byte*>(&px), &rnd);
+        d.lut[v] = px;
+      }
+    }
+    const rsx_image img = rsx_shim::view(mRaw);
+    const Buffer in = input.peekRemainingBuffer();
+    if (int st = rsx_unpack_variant_u16(rsx_shim::context(), &d, in.begin(), in.getSize(), &img))
+      rsx_shim::raise(st);
+    input.skipBytes(input.getRemainSize());
+    return;
+  }
+'''
 HUNK_CONTROL = HUNK_VARIANT % dict(variant="RSX_UNPACK_12BIT_WITH_CONTROL",
                                    big="e == Endianness::big")
 HUNK_LEFT = HUNK_VARIANT % dict(variant="RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED",

@@ -136,6 +136,18 @@ void* ref_image_create(int dim_x, int dim_y, int cpp, int is_cfa) {
     return nullptr;
   }
 }
+void* ref_image_create_f32(int dim_x, int dim_y, int cpp) {
+  try {
+    RawImage img = RawImage::create(RawImageType::F32);
+    img->dim = iPoint2D(dim_x, dim_y);
+    img->setCpp(cpp);
+    img->createData();
+    return new RefImage(std::move(img));
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return nullptr;
+  }
+}
 void ref_image_destroy(void* h) { delete static_cast<RefImage*>(h); }
 // what Cr2Decoder sets for sRaw files before decoding (Cr2Decoder.cpp sRaw path);
 // AbstractLJpegDecoder::parseSOF checks the SOF against it (:172-176)
@@ -206,6 +218,21 @@ int ref_unpack_variant_u16(void* h, const rsx_unpack_variant_desc* d,
     default:
       ThrowRDE("unknown variant");
     }
+  });
+}
+
+// decode8BitRaw<false> under a RawImageCurveGuard, as DcsDecoder.cpp:68-81 does
+int ref_decode8bit_lookup(void* h, const uint16_t* curve, int curve_size, int w,
+                          int hh, const uint8_t* in, size_t in_bytes) {
+  auto* r = static_cast<RefImage*>(h);
+  return guarded([&] {
+    const Buffer b(in, implicit_cast<Buffer::size_type>(in_bytes));
+    const ByteStream bs(DataBuffer(b, Endianness::little));
+    const std::vector<uint16_t> table(curve, curve + curve_size);
+    RawImageCurveGuard curveHandler(&r->img, table, /*uncorrectedRawValues=*/false);
+    UncompressedDecompressor u(bs, r->img, iRectangle2D({0, 0}, iPoint2D(w, hh)),
+                               8 * w / 8, 8, BitOrder::LSB);
+    u.decode8BitRaw<false>();
   });
 }
 

@@ -322,13 +322,117 @@ int oracle_unpack_u16(const rsx_unpack_desc* d, const uint8_t* in,
   return RSX_OK;
 }
 
+/* ---- RawImageType::F32 images ------------------------------------------------ */
+
+/* extendBinaryFloatingPoint<Narrow, Binary32> (common/FloatingPoint.h:109-145) */
+static uint32_t widen_fp(uint32_t narrow, int frac_w, int exp_w) {
+  const int bias = (1 << (exp_w - 1)) - 1;
+  const uint32_t sign = (narrow >> (frac_w + exp_w)) & 1;
+  const uint32_t ne = (narrow >> frac_w) & ((1u << exp_w) - 1);
+  const uint32_t nf = narrow & ((1u << frac_w) - 1);
+  uint32_t we = (uint32_t)((int32_t)ne - bias + 127);
+  uint32_t wf = nf << (23 - frac_w);
+  if (ne == ((1u << exp_w) - 1)) {
+    we = 255; /* infinity or NaN; the fraction is kept / widened */
+  } else if (ne == 0) {
+    if (nf == 0) {
+      we = 0;
+      wf = 0;
+    } else { /* subnormal: normalise */
+      we = (uint32_t)(1 - bias + 127);
+      while (!(wf & (1u << 23))) {
+        we -= 1;
+        wf <<= 1;
+      }
+      wf &= (1u << 23) - 1;
+    }
+  }
+  return (sign << 31) | (we << 23) | wf;
+}
+
+/* constructor (:106-169) for an F32 image, then the dispatch of
+ * readUncompressedRaw (:212-245) */
+int oracle_unpack_f32_validate(const rsx_unpack_desc* d, const rsx_image* img,
+                               size_t in_bytes) {
+  const uint64_t need =
+      (uint64_t)(uint32_t)d->crop_h * (uint64_t)(uint32_t)d->input_pitch_bytes;
+  if (need > 0xFFFFFFFFull || need > in_bytes)
+    return RSX_ERR_IO;
+  if (d->crop_w <= 0 || d->crop_h <= 0)
+    return RSX_ERR_INVALID_ARG;
+  if (d->input_pitch_bytes < 1)
+    return RSX_ERR_INVALID_ARG;
+  if (d->bit_order < RSX_ORDER_LSB || d->bit_order > RSX_ORDER_MSB32)
+    return RSX_ERR_INVALID_ARG;
+  if (img->cpp < 1 || img->cpp > 3)
+    return RSX_ERR_INVALID_ARG;
+  if (d->bits_per_pixel < 1 || d->bits_per_pixel > 32)
+    return RSX_ERR_INVALID_ARG; /* :138-140 */
+  const uint64_t bits =
+      (uint64_t)d->crop_w * (uint64_t)img->cpp * (uint64_t)d->bits_per_pixel;
+  if (bits % 8 != 0)
+    return RSX_ERR_INVALID_ARG;
+  if ((uint64_t)d->input_pitch_bytes < bits / 8)
+    return RSX_ERR_INVALID_ARG;
+  if (d->crop_y < 0 || d->crop_x < 0)
+    return RSX_ERR_INVALID_ARG;
+  if ((uint64_t)d->crop_y > (uint64_t)img->dim_y)
+    return RSX_ERR_INVALID_ARG;
+  if ((uint64_t)d->crop_x + (uint64_t)d->crop_w > (uint64_t)img->dim_x)
+    return RSX_ERR_INVALID_ARG;
+  if (d->bits_per_pixel == 32)
+    return RSX_OK; /* copyPixels :213-222 */
+  if ((d->bit_order != RSX_ORDER_MSB && d->bit_order != RSX_ORDER_LSB) ||
+      (d->bits_per_pixel != 16 && d->bits_per_pixel != 24))
+    return RSX_ERR_INVALID_ARG; /* :243-244 */
+  return RSX_OK;
+}
+
+int oracle_unpack_f32(const rsx_unpack_desc* d, const uint8_t* in, size_t in_bytes,
+                      const rsx_image* img) {
+  int st = oracle_unpack_f32_validate(d, img, in_bytes);
+  if (st)
+    return st;
+  uint8_t* out = (uint8_t*)img->data;
+  const int64_t cols = (int64_t)d->crop_w * img->cpp;
+  int64_t y = d->crop_y;
+  int64_t h = (int64_t)d->crop_h + d->crop_y;
+  if (h > img->dim_y)
+    h = img->dim_y;
+  if (d->bits_per_pixel == 32) {
+    for (int64_t r = y; r < h; ++r)
+      memcpy(out + r * img->pitch_bytes + (size_t)d->crop_x * img->cpp * 4,
+             in + (r - y) * d->input_pitch_bytes, (size_t)cols * 4);
+    return RSX_OK;
+  }
+  /* decodePackedFP<Pump, Binary16 | Binary24> :171-186 */
+  const int64_t stream_bytes = (int64_t)d->crop_h * d->input_pitch_bytes;
+  const int64_t skip = d->input_pitch_bytes - cols * d->bits_per_pixel / 8;
+  bitreader b;
+  br_init(&b, in, stream_bytes, d->bit_order);
+  if (b.err)
+    return b.err;
+  for (int64_t row = y; row < h; ++row) {
+    uint32_t* orow = (uint32_t*)(out + row * img->pitch_bytes);
+    for (int64_t col = 0; col < cols; ++col) {
+      const uint32_t v = br_get(&b, d->bits_per_pixel);
+      orow[d->crop_x + col] = d->bits_per_pixel == 16 ? widen_fp(v, 10, 5)
+                                                      : widen_fp(v, 16, 7);
+    }
+    br_skip_bytes(&b, skip);
+    if (b.err)
+      return b.err;
+  }
+  return RSX_OK;
+}
+
 /* ---- the fixed-layout entry points of the same class ---------------------- */
 
 /* UncompressedDecompressor::bytesPerLine (UncompressedDecompressor.cpp:88-104)
  * and the bpl the two sanityCheck(w, &h, bpp) callers use (:76-86). */
 static int variant_bpl(const rsx_unpack_variant_desc* d, uint64_t* bpl) {
   const uint64_t w = (uint32_t)d->w;
-  if (d->variant == RSX_UNPACK_8BIT_RAW) {
+  if (d->variant == RSX_UNPACK_8BIT_RAW || d->variant == RSX_UNPACK_8BIT_LOOKUP) {
     *bpl = w; /* sanityCheck(w, &h, 1) :273 */
   } else if (d->variant == RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED) {
     *bpl = 2 * w; /* sanityCheck(w, &h, 2) :360 */
@@ -344,7 +448,7 @@ static int variant_bpl(const rsx_unpack_variant_desc* d, uint64_t* bpl) {
 
 int oracle_unpack_variant_validate(const rsx_unpack_variant_desc* d,
                                    const rsx_image* img, size_t in_bytes) {
-  if (d->variant < 0 || d->variant > RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED)
+  if (d->variant < 0 || d->variant > RSX_UNPACK_8BIT_LOOKUP)
     return RSX_ERR_INVALID_ARG;
   if (d->w <= 0 || d->h <= 0)
     return RSX_ERR_INVALID_ARG; /* invariant(w > 0), invariant(*h > 0) */
@@ -379,6 +483,11 @@ int oracle_unpack_variant_u16(const rsx_unpack_variant_desc* d, const uint8_t* i
       /* decode8BitRaw<true> :270-291 */
       for (uint32_t col = 0; col < w; ++col)
         o[col] = r[col];
+    } else if (d->variant == RSX_UNPACK_8BIT_LOOKUP) {
+      /* decode8BitRaw<false>: setWithLookUp with random == 0 throughout
+       * (15700 * 0 + 0 == 0), so the dither term is (delta * 0 + 1024) >> 12 == 0 */
+      for (uint32_t col = 0; col < w; ++col)
+        o[col] = d->lut[r[col]];
     } else if (d->variant == RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED) {
       /* decode12BitRawUnpackedLeftAligned<e> :356-378 */
       for (uint32_t col = 0; col < w; ++col) {

@@ -49,12 +49,18 @@ class UnpackDesc(C.Structure):
                 ("bits_per_pixel", C.c_int32), ("bit_order", C.c_int32)]
 
 
-UNPACK_8BIT_RAW, UNPACK_12BIT_WITH_CONTROL, UNPACK_12BIT_UNPACKED_LEFT_ALIGNED = range(3)
+(UNPACK_8BIT_RAW, UNPACK_12BIT_WITH_CONTROL, UNPACK_12BIT_UNPACKED_LEFT_ALIGNED,
+ UNPACK_8BIT_LOOKUP) = range(4)
 
 
 class UnpackVariantDesc(C.Structure):
     _fields_ = [("variant", C.c_int32), ("big_endian", C.c_int32),
-                ("w", C.c_int32), ("h", C.c_int32)]
+                ("w", C.c_int32), ("h", C.c_int32), ("lut", C.c_uint16 * 256)]
+
+    def set_lut(self, lut):
+        for i, v in enumerate(lut):
+            self.lut[i] = int(v)
+        return self
 
 
 class HuffTable(C.Structure):

@@ -18,6 +18,7 @@ EXPORTS = [
     "rsx_abi_version", "rsx_status_string", "rsx_device_count", "rsx_ctx_create",
     "rsx_ctx_destroy", "rsx_ctx_last_error",
     "rsx_unpack_validate", "rsx_unpack_u16",
+    "rsx_unpack_f32_validate", "rsx_unpack_f32", "rsx_unpack_f32_plan_create",
     "rsx_unpack_variant_validate", "rsx_unpack_variant_u16", "rsx_unpack_variant_plan_create",
     "rsx_ljpeg_validate", "rsx_ljpeg_decode",
     "rsx_cr2_validate", "rsx_cr2_decode",
@@ -62,6 +63,9 @@ def lib():
         L.rsx_cr2_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rsx_unpack_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                      C.c_void_p]
+        L.rsx_unpack_f32_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.rsx_unpack_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]
         L.rsx_unpack_variant_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.rsx_unpack_variant_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_size_t, C.c_void_p]
@@ -78,7 +82,7 @@ def lib():
                                                       C.c_void_p, C.c_void_p]
         for name in ("rsx_unpack_plan_create", "rsx_ljpeg_plan_create",
                      "rsx_cr2_plan_create", "rsx_unpack_variant_plan_create",
-                     "rsx_nikon_plan_create"):
+                     "rsx_nikon_plan_create", "rsx_unpack_f32_plan_create"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p,
                                          C.POINTER(C.c_void_p)]
         L.rsx_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -128,6 +132,11 @@ class Context:
     def unpack_u16(self, desc, data, img_view):
         a = _u8(data)
         return lib().rsx_unpack_u16(self._h, C.byref(desc), a.ctypes.data, a.size,
+                                    C.byref(img_view))
+
+    def unpack_f32(self, desc, data, img_view):
+        a = _u8(data)
+        return lib().rsx_unpack_f32(self._h, C.byref(desc), a.ctypes.data, a.size,
                                     C.byref(img_view))
 
     def unpack_variant_u16(self, desc, data, img_view):
@@ -184,6 +193,9 @@ class Context:
     # ---- device-resident plans ---------------------------------------------
     def unpack_plan(self, jobs):
         return Plan(self, "rsx_unpack_plan_create", abi.UnpackJob, jobs)
+
+    def unpack_f32_plan(self, jobs):
+        return Plan(self, "rsx_unpack_f32_plan_create", abi.UnpackJob, jobs)
 
     def unpack_variant_plan(self, jobs):
         return Plan(self, "rsx_unpack_variant_plan_create", abi.UnpackVariantJob, jobs)

@@ -234,6 +234,87 @@ extern "C" int rsx_unpack_plan_create(rsx_ctx* ctx, int n_jobs,
   return RSX_OK;
 }
 
+// F32 images: readUncompressedRaw's floating-point branches (:212-245)
+extern "C" int rsx_unpack_f32_validate(const rsx_unpack_desc* d, const rsx_image* img,
+                                       size_t in_bytes) {
+  if (!d || !img)
+    return RSX_ERR_INVALID_ARG;
+  return validate_unpack_f32(*d, *img, in_bytes);
+}
+
+extern "C" int rsx_unpack_f32_plan_create(rsx_ctx* ctx, int n_jobs,
+                                          const rsx_unpack_job* jobs,
+                                          rsx_plan** out_plan) {
+  if (!ctx || !jobs || n_jobs < 1 || !out_plan)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto plan = std::make_unique<rsx_plan>();
+  plan->ctx = ctx;
+  plan->kind = PLAN_UNPACK;
+  plan->n_jobs = n_jobs;
+  plan->job_status.assign(n_jobs, RSX_OK);
+  struct Class {
+    int order, bps;
+    std::vector<UnpackJobDev> v;
+  };
+  Class classes[5] = {{RSX_ORDER_LSB, 32, {}}, {RSX_ORDER_LSB, 16, {}},
+                      {RSX_ORDER_LSB, 24, {}}, {RSX_ORDER_MSB, 16, {}},
+                      {RSX_ORDER_MSB, 24, {}}};
+  for (int i = 0; i < n_jobs; ++i) {
+    const rsx_unpack_job& j = jobs[i];
+    const rsx_unpack_desc& d = j.desc;
+    int st = validate_unpack_f32(d, j.img, size_t(j.in_bytes));
+    if (st == RSX_OK && j.img.pitch_bytes % 4 != 0)
+      st = RSX_ERR_INVALID_ARG;
+    plan->job_status[i] = st;
+    if (st != RSX_OK)
+      continue;
+    UnpackJobDev u{};
+    u.in_offset = j.in_offset;
+    u.stream_bytes = uint64_t(d.crop_h) * uint64_t(d.input_pitch_bytes);
+    u.in_pitch = uint32_t(d.input_pitch_bytes);
+    u.out_pitch = j.img.pitch_bytes;
+    const int64_t rows_avail = int64_t(j.img.dim_y) - d.crop_y; // :209-210
+    u.n_rows = uint32_t(std::min<int64_t>(d.crop_h, rows_avail));
+    u.cols = uint32_t(d.crop_w) * uint32_t(j.img.cpp);
+    u.bps = uint32_t(d.bits_per_pixel);
+    // copyPixels starts at out(y, offset.x * cpp) (:216-217), decodePackedFP
+    // writes out(row, offset.x + col) (:181)
+    const uint64_t x0 = d.bits_per_pixel == 32 ? uint64_t(d.crop_x) * j.img.cpp
+                                               : uint64_t(d.crop_x);
+    u.out_offset = j.img_offset + uint64_t(d.crop_y) * j.img.pitch_bytes + x0 * 4;
+    unpack_fp_blocks_for(&u);
+    if (u.n_rows == 0)
+      continue;
+    int cls = 0;
+    if (d.bits_per_pixel != 32)
+      cls = (d.bit_order == RSX_ORDER_MSB ? 3 : 1) + (d.bits_per_pixel == 24 ? 1 : 0);
+    classes[cls].v.push_back(u);
+  }
+  for (Class& c : classes) {
+    if (c.v.empty())
+      continue;
+    plan->unpack.emplace_back();
+    UnpackLaunch& L = plan->unpack.back();
+    L.mode = UNPACK_MODE_FP;
+    L.order = (c.bps << 8) | c.order;
+    L.n_jobs = int(c.v.size());
+    std::vector<uint32_t> starts(c.v.size() + 1, 0);
+    for (size_t k = 0; k < c.v.size(); ++k)
+      starts[k + 1] = starts[k] + c.v[k].n_rows * c.v[k].segs_per_row;
+    L.total_blocks = starts.back();
+    L.jobs = c.v;
+    if (int st = upload(ctx, L.d_jobs, c.v.data(), c.v.size() * sizeof(UnpackJobDev)))
+      return st;
+    if (int st = upload(ctx, L.d_block_start, starts.data(),
+                        starts.size() * sizeof(uint32_t)))
+      return st;
+  }
+  *out_plan = plan.release();
+  return RSX_OK;
+}
+
 // decode8BitRaw<true> is the 8-bit packed walk over rows of w bytes;
 // decode12BitRawUnpackedLeftAligned<e> the 16-bit LSB/MSB walk + ">> 4";
 // decode12BitRawWithControl<e> has its own kernel.  All three write from pixel
@@ -262,11 +343,13 @@ extern "C" int rsx_unpack_variant_plan_create(rsx_ctx* ctx, int n_jobs,
     int mode, order;
     std::vector<UnpackJobDev> v;
   };
-  Class classes[5] = {{UNPACK_MODE_PACKED, RSX_ORDER_LSB, {}},
+  Class classes[6] = {{UNPACK_MODE_PACKED, RSX_ORDER_LSB, {}},
                       {UNPACK_MODE_SHIFT, RSX_ORDER_LSB, {}},
                       {UNPACK_MODE_SHIFT, RSX_ORDER_MSB, {}},
                       {UNPACK_MODE_CONTROL, RSX_ORDER_LSB, {}},
-                      {UNPACK_MODE_CONTROL, RSX_ORDER_MSB, {}}};
+                      {UNPACK_MODE_CONTROL, RSX_ORDER_MSB, {}},
+                      {UNPACK_MODE_LUT8, RSX_ORDER_LSB, {}}};
+  std::vector<uint16_t> luts; // tables of the LUT8 class, in job order
   for (int i = 0; i < n_jobs; ++i) {
     const rsx_unpack_variant_job& j = jobs[i];
     int st = validate_unpack_variant(j.desc, j.img, size_t(j.in_bytes));
@@ -291,6 +374,13 @@ extern "C" int rsx_unpack_variant_plan_create(rsx_ctx* ctx, int n_jobs,
       u.bps = 8;
       unpack_blocks_for(&u);
       cls = 0;
+      break;
+    case RSX_UNPACK_8BIT_LOOKUP:
+      u.bps = 8;
+      u.post_shift = uint32_t(luts.size() / 256);
+      luts.insert(luts.end(), j.desc.lut, j.desc.lut + 256);
+      unpack_blocks_for(&u);
+      cls = 5;
       break;
     case RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED:
       u.bps = 16;
@@ -319,7 +409,14 @@ extern "C" int rsx_unpack_variant_plan_create(rsx_ctx* ctx, int n_jobs,
       starts[k + 1] = starts[k] + c.v[k].n_rows * c.v[k].segs_per_row;
     L.total_blocks = starts.back();
     L.jobs = c.v;
-    if (int st = upload(ctx, L.d_jobs, c.v.data(), c.v.size() * sizeof(UnpackJobDev)))
+    // the LUT8 class keeps its tables right behind the job array
+    std::vector<uint8_t> blob(c.v.size() * sizeof(UnpackJobDev) +
+                              (c.mode == UNPACK_MODE_LUT8 ? luts.size() * 2 : 0));
+    std::memcpy(blob.data(), c.v.data(), c.v.size() * sizeof(UnpackJobDev));
+    if (c.mode == UNPACK_MODE_LUT8)
+      std::memcpy(blob.data() + c.v.size() * sizeof(UnpackJobDev), luts.data(),
+                  luts.size() * 2);
+    if (int st = upload(ctx, L.d_jobs, blob.data(), blob.size()))
       return st;
     if (int st = upload(ctx, L.d_block_start, starts.data(),
                         starts.size() * sizeof(uint32_t)))
@@ -624,6 +721,57 @@ extern "C" int rsx_unpack_u16(rsx_ctx* ctx, const rsx_unpack_desc* d,
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return unpack_host(ctx, 1, d, &in, &in_bytes, img, nullptr);
+}
+
+extern "C" int rsx_unpack_f32(rsx_ctx* ctx, const rsx_unpack_desc* d, const uint8_t* in,
+                              size_t in_bytes, const rsx_image* img) {
+  if (!ctx || !d || !in || !img || !img->data)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int st = validate_unpack_f32(*d, *img, in_bytes))
+    return st;
+  const size_t used = size_t(d->crop_h) * size_t(d->input_pitch_bytes);
+  const int64_t rows = std::min<int64_t>(d->crop_h, int64_t(img->dim_y) - d->crop_y);
+  if (rows <= 0)
+    return RSX_OK;
+  // device image = the compact rectangle that is written
+  const size_t width_bytes = size_t(d->crop_w) * img->cpp * 4;
+  rsx_unpack_job job{};
+  job.desc = *d;
+  job.desc.crop_x = 0;
+  job.desc.crop_y = 0;
+  job.in_bytes = used;
+  job.img = *img;
+  job.img.dim_y = int32_t(rows);
+  job.img.pitch_bytes = uint32_t(align_up(width_bytes, 16));
+  if (int e = ctx->d_in.ensure(used + 16))
+    return e;
+  if (int e = ctx->d_out.ensure(size_t(job.img.pitch_bytes) * size_t(rows) + 16))
+    return e;
+  hipStream_t s = ctx->stream;
+  RSX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_in.ptr, in, used, hipMemcpyHostToDevice, s));
+  rsx_plan* plan = nullptr;
+  if (int st = rsx_unpack_f32_plan_create(ctx, 1, &job, &plan))
+    return st;
+  int rc = rsx_plan_run(plan, ctx->d_in.ptr, ctx->d_out.ptr, s);
+  if (rc == RSX_OK) {
+    const size_t x0 = d->bits_per_pixel == 32 ? size_t(d->crop_x) * img->cpp
+                                              : size_t(d->crop_x);
+    uint8_t* dst = static_cast<uint8_t*>(img->data) +
+                   size_t(d->crop_y) * img->pitch_bytes + x0 * 4;
+    hipError_t e = hipMemcpy2DAsync(dst, img->pitch_bytes, ctx->d_out.ptr,
+                                    job.img.pitch_bytes, width_bytes, size_t(rows),
+                                    hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      ctx->last_error = std::string("unpack_f32 D2H: ") + hipGetErrorString(e);
+      rc = RSX_ERR_DEVICE;
+    }
+  }
+  rsx_plan_destroy(plan);
+  return rc;
 }
 
 extern "C" int rsx_unpack_variant_u16(rsx_ctx* ctx, const rsx_unpack_variant_desc* d,

@@ -25,13 +25,21 @@ struct UnpackJobDev {
   uint32_t segs_per_row;
   uint32_t seg_groups;   // groups per segment (rows are split evenly)
   uint32_t out_aligned;  // every output row start is 16-byte aligned
-  uint32_t post_shift;   // UNPACK_MODE_SHIFT: samples are shifted right by this
+  uint32_t post_shift;   // UNPACK_MODE_SHIFT: samples are shifted right by this;
+                         // UNPACK_MODE_LUT8: index of the job's table
 };
 
 // Launch flavours.  PACKED is decodePackedInt; SHIFT is the same stream walk
 // followed by `>> post_shift` (decode12BitRawUnpackedLeftAligned); CONTROL is
 // decode12BitRawWithControl (bps field = 1 for big-endian nibble order).
-enum UnpackMode { UNPACK_MODE_PACKED = 0, UNPACK_MODE_SHIFT = 1, UNPACK_MODE_CONTROL = 2 };
+// FP: F32 images -- bps 16 / 24 widened to binary32 (decodePackedFP), bps 32 copied.
+enum UnpackMode {
+  UNPACK_MODE_PACKED = 0,
+  UNPACK_MODE_SHIFT = 1,
+  UNPACK_MODE_CONTROL = 2,
+  UNPACK_MODE_FP = 3,
+  UNPACK_MODE_LUT8 = 4 // decode8BitRaw<false>: 8-bit walk + 256-entry table
+};
 
 size_t unpack_lds_bytes();
 // fill groups_per_row / segs_per_row / seg_groups from n_rows and cols;
@@ -39,6 +47,7 @@ size_t unpack_lds_bytes();
 uint32_t unpack_blocks_for(UnpackJobDev* u);
 const char* unpack_kernel_name();
 uint32_t unpack_control_blocks_for(UnpackJobDev* u);
+uint32_t unpack_fp_blocks_for(UnpackJobDev* u);
 hipError_t launch_unpack_mode(int mode, int order, const UnpackJobDev* d_jobs,
                               const uint32_t* d_block_start, int n_jobs,
                               uint32_t total_blocks, const void* in_base,

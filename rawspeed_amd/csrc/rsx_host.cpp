@@ -56,6 +56,49 @@ int validate_unpack(const rsx_unpack_desc& d, const rsx_image& img,
 // + full-decode requirement (codes/AbstractPrefixCodeTranscoder.h:71-84).
 // ------------------------------------------------------------------------
 // ------------------------------------------------------------------------
+// The same constructor for RawImageType::F32 images, then the dispatch of
+// readUncompressedRaw (:212-245).
+// ------------------------------------------------------------------------
+int validate_unpack_f32(const rsx_unpack_desc& d, const rsx_image& img,
+                        size_t in_bytes) {
+  const uint64_t need = uint64_t(uint32_t(d.crop_h)) *
+                        uint64_t(uint32_t(d.input_pitch_bytes));
+  if (need > 0xFFFFFFFFull || need > in_bytes) // getStream, first initialiser
+    return RSX_ERR_IO;
+  if (d.crop_w <= 0 || d.crop_h <= 0) // :112-113
+    return RSX_ERR_INVALID_ARG;
+  if (d.input_pitch_bytes < 1) // :115-116
+    return RSX_ERR_INVALID_ARG;
+  if (d.bit_order < RSX_ORDER_LSB || d.bit_order > RSX_ORDER_MSB32) // :118-127
+    return RSX_ERR_INVALID_ARG;
+  if (img.cpp < 1 || img.cpp > 3) // :135-136
+    return RSX_ERR_INVALID_ARG;
+  if (d.bits_per_pixel < 1 || d.bits_per_pixel > 32) // :138-140 (F32 image)
+    return RSX_ERR_INVALID_ARG;
+  const uint64_t bits =
+      uint64_t(d.crop_w) * uint64_t(img.cpp) * uint64_t(d.bits_per_pixel);
+  if (bits % 8 != 0) // :145-149
+    return RSX_ERR_INVALID_ARG;
+  if (uint64_t(d.input_pitch_bytes) < bits / 8) // :155-156
+    return RSX_ERR_INVALID_ARG;
+  if (d.crop_x < 0 || d.crop_y < 0)
+    return RSX_ERR_INVALID_ARG;
+  if (uint64_t(d.crop_y) > uint64_t(img.dim_y)) // :165-166
+    return RSX_ERR_INVALID_ARG;
+  if (uint64_t(d.crop_x) + uint64_t(d.crop_w) > uint64_t(img.dim_x)) // :167-168
+    return RSX_ERR_INVALID_ARG;
+  // readUncompressedRaw :212-245
+  if (d.bits_per_pixel == 32)
+    return RSX_OK; // copyPixels, no bit streamer
+  const bool byte_order = d.bit_order == RSX_ORDER_MSB || d.bit_order == RSX_ORDER_LSB;
+  if (!byte_order || (d.bits_per_pixel != 16 && d.bits_per_pixel != 24))
+    return RSX_ERR_INVALID_ARG; // "Unsupported floating-point input bitwidth/bit packing"
+  if (need < 4) // the bit streamer refuses < 4 bytes (BitStreamer.h:58-59)
+    return RSX_ERR_IO;
+  return RSX_OK;
+}
+
+// ------------------------------------------------------------------------
 // decode8BitRaw<true> / decode12BitRawWithControl<e> /
 // decode12BitRawUnpackedLeftAligned<e>
 // (decompressors/UncompressedDecompressor.cpp:270-378).  The constructor ran
@@ -65,6 +108,7 @@ int unpack_variant_bytes_per_line(const rsx_unpack_variant_desc& d, uint64_t* bp
   const uint64_t w = uint64_t(uint32_t(d.w));
   switch (d.variant) {
   case RSX_UNPACK_8BIT_RAW: // sanityCheck(w, &h, 1) :273
+  case RSX_UNPACK_8BIT_LOOKUP:
     *bpl = w;
     return RSX_OK;
   case RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED: // sanityCheck(w, &h, 2) :360
@@ -82,8 +126,7 @@ int unpack_variant_bytes_per_line(const rsx_unpack_variant_desc& d, uint64_t* bp
 
 int validate_unpack_variant(const rsx_unpack_variant_desc& d, const rsx_image& img,
                             size_t in_bytes) {
-  if (d.variant < RSX_UNPACK_8BIT_RAW ||
-      d.variant > RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED)
+  if (d.variant < RSX_UNPACK_8BIT_RAW || d.variant > RSX_UNPACK_8BIT_LOOKUP)
     return RSX_ERR_INVALID_ARG;
   if (d.w <= 0 || d.h <= 0) // invariant(w > 0), invariant(*h > 0) :54, :78
     return RSX_ERR_INVALID_ARG;

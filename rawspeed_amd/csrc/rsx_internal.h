@@ -20,6 +20,7 @@ namespace rsx {
 // ------------------------------------------------------------------------
 int validate_unpack(const rsx_unpack_desc& d, const rsx_image& img,
                     size_t in_bytes);
+int validate_unpack_f32(const rsx_unpack_desc& d, const rsx_image& img, size_t in_bytes);
 int validate_unpack_variant(const rsx_unpack_variant_desc& d, const rsx_image& img,
                             size_t in_bytes);
 int unpack_variant_bytes_per_line(const rsx_unpack_variant_desc& d, uint64_t* bpl);

@@ -160,7 +160,9 @@ __device__ __forceinline__ void store8(uint16_t* __restrict__ dst, const uint32_
 // ORDER: 0 LSB, 1 MSB, 2 MSB16, 3 MSB32.  POST: shift every sample right by
 // J.post_shift afterwards (decode12BitRawUnpackedLeftAligned<e>,
 // UncompressedDecompressor.cpp:356-378, is the 16-bit LSB / MSB walk + ">> 4").
-template <int ORDER, bool POST = false>
+// POST 2: every sample goes through a 256-entry u16 table instead (decode8BitRaw
+// <false>); the tables of a launch sit behind its job array, post_shift = index.
+template <int ORDER, int POST = 0>
 __global__ __launch_bounds__(UNPACK_THREADS) void unpack_kernel(
     const UnpackJobDev* __restrict__ jobs, const uint32_t* __restrict__ job_block_start,
     int n_jobs, const uint8_t* __restrict__ in_base, uint8_t* __restrict__ out_base) {
@@ -228,10 +230,16 @@ __global__ __launch_bounds__(UNPACK_THREADS) void unpack_kernel(
         break;
       uint32_t s[8];
       extract8<ORDER>(d[k][0], d[k][1], d[k][2], d[k][3], 0u, 0u, bps, s);
-      if (POST) {
+      if (POST == 1) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           s[i] >>= J.post_shift;
+      } else if (POST == 2) {
+        const uint16_t* __restrict__ lut =
+            reinterpret_cast<const uint16_t*>(jobs + n_jobs) + 256 * J.post_shift;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          s[i] = lut[s[i] & 0xFFu];
       }
       const uint32_t g = g0 + gl;
       store8(reinterpret_cast<uint16_t*>(out_row) + uint64_t(g) * 8, s, J.cols - g * 8,
@@ -273,10 +281,16 @@ __global__ __launch_bounds__(UNPACK_THREADS) void unpack_kernel(
     const uint32_t kb = ob & 3; // byte shift inside the first dword
     uint32_t s[8];
     extract8<ORDER>(lds[wi], lds[wi + 1], lds[wi + 2], lds[wi + 3], lds[wi + 4], kb, bps, s);
-    if (POST) {
+    if (POST == 1) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         s[i] >>= J.post_shift;
+    } else if (POST == 2) {
+      const uint16_t* __restrict__ lut =
+          reinterpret_cast<const uint16_t*>(jobs + n_jobs) + 256 * J.post_shift;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        s[i] = lut[s[i] & 0xFFu];
     }
     const uint32_t g = g0 + gl;
     store8(reinterpret_cast<uint16_t*>(out_row) + uint64_t(g) * 8, s, J.cols - g * 8,
@@ -381,6 +395,112 @@ __global__ __launch_bounds__(UNPACK_THREADS) void unpack_control_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// F32 images (UncompressedDecompressor.cpp:171-186, :212-245): samples of 16,
+// 24 or 32 bits on byte boundaries.  One lane owns 4 samples: 8 / 12 / 16 input
+// bytes (unaligned loads, contiguous across the wave), one 16-byte store.
+// extendBinaryFloatingPoint<Narrow, Binary32> (common/FloatingPoint.h:109-145)
+// in integer arithmetic: exact, subnormals renormalised, NaN payload kept.
+// ---------------------------------------------------------------------------
+template <int FRAC, int EXPW>
+__device__ __forceinline__ uint32_t widen_fp(uint32_t narrow) {
+  constexpr int BIAS = (1 << (EXPW - 1)) - 1;
+  const uint32_t sign = (narrow >> (FRAC + EXPW)) & 1u;
+  const uint32_t ne = (narrow >> FRAC) & ((1u << EXPW) - 1u);
+  const uint32_t nf = narrow & ((1u << FRAC) - 1u);
+  uint32_t we = ne - BIAS + 127;
+  uint32_t wf = nf << (23 - FRAC);
+  if (ne == (1u << EXPW) - 1u) {
+    we = 255; // infinity / NaN, fraction widened
+  } else if (ne == 0) {
+    if (nf == 0) {
+      we = 0;
+      wf = 0;
+    } else {
+      // subnormal: normalise (shift until the hidden bit appears)
+      const uint32_t sh = uint32_t(__builtin_clz(wf)) - 8u; // wf < 2^23
+      we = 1 - BIAS + 127 - sh;
+      wf = (wf << sh) & 0x7FFFFFu;
+    }
+  }
+  return (sign << 31) | (we << 23) | wf;
+}
+
+// BPS in {16, 24, 32}; MSB: the bytes of a sample arrive most significant first
+template <int BPS, bool MSB>
+__global__ __launch_bounds__(UNPACK_THREADS) void unpack_fp_kernel(
+    const UnpackJobDev* __restrict__ jobs, const uint32_t* __restrict__ job_block_start,
+    int n_jobs, const uint8_t* __restrict__ in_base, uint8_t* __restrict__ out_base) {
+  const int job = find_job(job_block_start, n_jobs);
+  const UnpackJobDev J = jobs[job];
+  const uint32_t local_block = blockIdx.x - job_block_start[job];
+  const uint32_t row = local_block / J.segs_per_row;
+  const uint32_t seg = local_block - row * J.segs_per_row;
+  const uint32_t g = seg * UNPACK_THREADS + threadIdx.x; // group of 4 samples
+  if (g >= J.groups_per_row)
+    return;
+  constexpr int BYTES = BPS / 8;
+  const uint8_t* __restrict__ src =
+      in_base + J.in_offset + uint64_t(row) * J.in_pitch + uint64_t(g) * (4 * BYTES);
+  uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(
+      out_base + J.out_offset + uint64_t(row) * J.out_pitch) + uint64_t(g) * 4;
+  const uint32_t cnt = J.cols - g * 4;
+  uint32_t v[4] = {0, 0, 0, 0};
+  if (cnt >= 4) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    __builtin_memcpy(w, src, 4 * BYTES);
+    if (BPS == 32) {
+      v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3];
+    } else if (BPS == 16) {
+      v[0] = w[0] & 0xFFFFu; v[1] = w[0] >> 16; v[2] = w[1] & 0xFFFFu; v[3] = w[1] >> 16;
+      if (MSB) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          v[i] = ((v[i] & 0xFFu) << 8) | (v[i] >> 8);
+      }
+    } else {
+      // 12 bytes b0..b11: sample i = bytes 3i .. 3i+2
+      v[0] = w[0] & 0xFFFFFFu;
+      v[1] = (w[0] >> 24) | ((w[1] & 0xFFFFu) << 8);
+      v[2] = (w[1] >> 16) | ((w[2] & 0xFFu) << 16);
+      v[3] = w[2] >> 8;
+      if (MSB) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          v[i] = ((v[i] & 0xFFu) << 16) | (v[i] & 0xFF00u) | (v[i] >> 16);
+      }
+    }
+  } else {
+    for (uint32_t i = 0; i < cnt; ++i) {
+      uint32_t x = 0;
+      for (int b = 0; b < BYTES; ++b) {
+        const uint32_t byte = src[i * BYTES + b];
+        x = MSB && BPS != 32 ? (x << 8) | byte : x | (byte << (8 * b));
+      }
+      v[i] = x;
+    }
+  }
+  if (BPS == 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v[i] = widen_fp<10, 5>(v[i]);
+  } else if (BPS == 24) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v[i] = widen_fp<16, 7>(v[i]);
+  }
+  if (cnt >= 4 && J.out_aligned) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 t;
+    t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3];
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(dst));
+  } else {
+    for (uint32_t i = 0; i < 4; ++i)
+      if (i < cnt)
+        dst[i] = v[i];
+  }
+}
+
 } // namespace
 
 size_t unpack_lds_bytes() { return size_t(SEG_CHUNKS) * 16; }
@@ -406,6 +526,15 @@ uint32_t unpack_control_blocks_for(UnpackJobDev* u) {
   return u->n_rows * segs;
 }
 
+uint32_t unpack_fp_blocks_for(UnpackJobDev* u) {
+  const uint32_t groups = (u->cols + 3) / 4;
+  const uint32_t segs = (groups + UNPACK_THREADS - 1) / UNPACK_THREADS;
+  u->segs_per_row = segs;
+  u->groups_per_row = groups;
+  u->seg_groups = UNPACK_THREADS;
+  return u->n_rows * segs;
+}
+
 const char* unpack_kernel_name() { return "unpack_kernel"; }
 
 hipError_t launch_unpack_mode(int mode, int order, const UnpackJobDev* d_jobs,
@@ -420,13 +549,39 @@ hipError_t launch_unpack_mode(int mode, int order, const UnpackJobDev* d_jobs,
   const dim3 grid(total_blocks), block(UNPACK_THREADS);
   const uint8_t* in = static_cast<const uint8_t*>(in_base);
   uint8_t* out = static_cast<uint8_t*>(out_base);
+  if (mode == UNPACK_MODE_FP) {
+    // FP launch classes are (byte order, bit width): `order` = width << 8 | order
+    const int bps = order >> 8;
+    const bool msb = (order & 0xFF) == RSX_ORDER_MSB;
+    if (bps == 32)
+      hipLaunchKernelGGL((unpack_fp_kernel<32, false>), grid, block, 0, stream, d_jobs,
+                         d_block_start, n_jobs, in, out);
+    else if (bps == 16 && msb)
+      hipLaunchKernelGGL((unpack_fp_kernel<16, true>), grid, block, 0, stream, d_jobs,
+                         d_block_start, n_jobs, in, out);
+    else if (bps == 16)
+      hipLaunchKernelGGL((unpack_fp_kernel<16, false>), grid, block, 0, stream, d_jobs,
+                         d_block_start, n_jobs, in, out);
+    else if (msb)
+      hipLaunchKernelGGL((unpack_fp_kernel<24, true>), grid, block, 0, stream, d_jobs,
+                         d_block_start, n_jobs, in, out);
+    else
+      hipLaunchKernelGGL((unpack_fp_kernel<24, false>), grid, block, 0, stream, d_jobs,
+                         d_block_start, n_jobs, in, out);
+    return hipGetLastError();
+  }
+  if (mode == UNPACK_MODE_LUT8) {
+    hipLaunchKernelGGL((unpack_kernel<0, 2>), grid, block, unpack_lds_bytes(), stream,
+                       d_jobs, d_block_start, n_jobs, in, out);
+    return hipGetLastError();
+  }
   if (mode == UNPACK_MODE_SHIFT) {
     const size_t lds = unpack_lds_bytes();
     if (order == RSX_ORDER_LSB)
-      hipLaunchKernelGGL((unpack_kernel<0, true>), grid, block, lds, stream, d_jobs,
+      hipLaunchKernelGGL((unpack_kernel<0, 1>), grid, block, lds, stream, d_jobs,
                          d_block_start, n_jobs, in, out);
     else
-      hipLaunchKernelGGL((unpack_kernel<1, true>), grid, block, lds, stream, d_jobs,
+      hipLaunchKernelGGL((unpack_kernel<1, 1>), grid, block, lds, stream, d_jobs,
                          d_block_start, n_jobs, in, out);
   } else {
     if (order == RSX_ORDER_LSB)

@@ -43,7 +43,7 @@ inline rsx_ctx* context() {
 
 inline rsx_image view(const RawImage& img) {
   rsx_image v{};
-  const auto a = img->getU16DataAsUncroppedArray2DRef();
+  const auto a = img->getByteDataAsUncroppedArray2DRef(); // UINT16 and F32 images
   v.data = &a(0, 0);
   v.pitch_bytes = implicit_cast<uint32_t>(img->pitch);
   v.dim_x = img->dim.x;

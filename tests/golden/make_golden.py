@@ -20,12 +20,17 @@ from oracle_lib import Ref  # noqa: E402
 
 def main():
     ref = Ref()
-    out = {"unpack": {}, "variant": {}, "ljpeg": {}, "cr2": {}, "nikon": {}}
+    out = {"unpack": {}, "f32": {}, "variant": {}, "ljpeg": {}, "cr2": {}, "nikon": {}}
     for i, c in enumerate(G.UNPACK_CASES):
         d, data, (w, h, cpp) = G.build_unpack(c)
         img = ref.image(w, h, cpp)
         st = ref.unpack(d, data, img)
         out["unpack"][str(i)] = {"status": st, "hash": G.image_hash(img.pixels())}
+    for i, c in enumerate(G.F32_CASES):
+        d, data, (w, h, cpp) = G.build_f32(c)
+        img = ref.image(w, h, cpp, f32=True)
+        st = ref.unpack(d, data, img)
+        out["f32"][str(i)] = {"status": st, "hash": G.image_hash(img.u32()[:, :w * cpp])}
     for i, c in enumerate(G.VARIANT_CASES):
         d, data, (w, h, cpp) = G.build_variant(c)
         img = ref.image(w, h, cpp)

@@ -62,6 +62,32 @@ def build_variant(c, seed=4321):
     return d, data, (c["w"], c["h"], 1)
 
 
+# F32 images: (order, bps, w, h, cpp, pad, ox, oy); special values (zero, subnormals,
+# inf, NaN payloads) are forced into the first samples
+F32_CASES = []
+for order, bps in ((0, 16), (1, 16), (0, 24), (1, 24), (0, 32), (1, 32), (2, 32)):
+    for (w, h, cpp, pad, ox, oy) in ((40, 6, 1, 0, 0, 0), (30, 5, 2, 3, 2, 1), (1028, 3, 3, 1, 0, 0)):
+        F32_CASES.append(dict(order=order, bps=bps, w=w, h=h, cpp=cpp, pad=pad, ox=ox, oy=oy))
+
+
+def build_f32(c, seed=99):
+    rng = np.random.default_rng([seed, c["order"], c["bps"], c["w"], c["cpp"]])
+    nbytes = c["bps"] // 8
+    row = c["w"] * c["cpp"] * nbytes
+    pitch = row + c["pad"]
+    data = rng.integers(0, 256, size=c["h"] * pitch, dtype=np.uint8)
+    # specials: exponent all-zero / all-one with zero and non-zero fractions
+    specials = {16: [0x0000, 0x8000, 0x0001, 0x83FF, 0x7C00, 0xFC00, 0x7C01, 0xFFFF, 0x0400],
+                24: [0x000000, 0x800000, 0x000001, 0x80FFFF, 0x7F0000, 0xFF0000, 0x7F0001,
+                     0xFFFFFF, 0x010000],
+                32: [0, 0x80000000, 1, 0x7F800000, 0x7FC00001]}[c["bps"]]
+    for i, v in enumerate(specials):
+        b = int(v).to_bytes(nbytes, "big" if c["order"] == 1 and c["bps"] != 32 else "little")
+        data[i * nbytes:(i + 1) * nbytes] = np.frombuffer(b, np.uint8)
+    d = abi.UnpackDesc(c["ox"], c["oy"], c["w"], c["h"], pitch, c["bps"], c["order"])
+    return d, data, (c["w"] + c["ox"] + 1, c["h"] + c["oy"], c["cpp"])
+
+
 LJPEG_CASES = [
     dict(name="mcu2x1_full", img=(64, 8, 1), tile=(0, 0, 64, 8), mcu=(2, 1)),
     dict(name="mcu1x1", img=(64, 8, 1), tile=(0, 0, 64, 8), mcu=(1, 1)),

@@ -38,11 +38,12 @@ def out_pitch(dim_x, cpp):
 
 
 class HostImage:
-    """A host uint16 image laid out like RawImageData (pitch = roundUp(w*bpp,16))."""
+    """A host uint16 image laid out like RawImageData (pitch = roundUp(w*bpp,16));
+    bpc=4 for RawImageType::F32 images."""
 
-    def __init__(self, dim_x, dim_y, cpp=1, is_cfa=True, fill=0xA5, pitch=None):
+    def __init__(self, dim_x, dim_y, cpp=1, is_cfa=True, fill=0xA5, pitch=None, bpc=2):
         self.dim_x, self.dim_y, self.cpp, self.is_cfa = dim_x, dim_y, cpp, is_cfa
-        self.pitch = pitch or out_pitch(dim_x, cpp)
+        self.pitch = pitch or (dim_x * cpp * bpc + 15) // 16 * 16
         self.buf = np.full(self.pitch * dim_y, fill, dtype=np.uint8)
 
     def view(self):
@@ -59,6 +60,26 @@ class HostImage:
     def pixels(self):
         return self.u16()[:, :self.dim_x * self.cpp]
 
+    def u32(self):
+        return self.buf.view(np.uint32).reshape(self.dim_y, self.pitch // 4)
+
+
+def dither_lut8(curve):
+    """What setWithLookUp(v, .., random = 0) stores for v < 256 under a dithering
+    TableLookUp built from `curve` (TableLookUp.cpp:66-84): tables[2 * v]."""
+    c = [int(x) for x in curve]
+    n = len(c)
+    out = []
+    for i in range(256):
+        if i < n:
+            center = c[i]
+            lower = min(c[i - 1] if i > 0 else center, center)
+            upper = max(c[i + 1] if i < n - 1 else center, center)
+            out.append(min(max(center - ((upper - lower + 2) // 4), 0), 65535))
+        else:
+            out.append(c[n - 1])
+    return out
+
 
 def _as_u8(a):
     a = np.ascontiguousarray(a, dtype=np.uint8)
@@ -73,6 +94,8 @@ class Oracle:
         L.oracle_unpack_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_unpack_variant_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                                 C.c_void_p]
+        L.oracle_unpack_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.oracle_unpack_f32_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_unpack_variant_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_nikon_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_nikon_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
@@ -98,6 +121,15 @@ class Oracle:
     def unpack_validate(self, desc, img, n):
         v = img.view()
         return self.lib.oracle_unpack_validate(C.byref(desc), C.byref(v), n)
+
+    def unpack_f32(self, desc, data, img):
+        a, p, n = _as_u8(data)
+        v = img.view()
+        return self.lib.oracle_unpack_f32(C.byref(desc), p, n, C.byref(v))
+
+    def unpack_f32_validate(self, desc, img, n):
+        v = img.view()
+        return self.lib.oracle_unpack_f32_validate(C.byref(desc), C.byref(v), n)
 
     def unpack_variant(self, desc, data, img):
         a, p, n = _as_u8(data)
@@ -166,10 +198,13 @@ class Oracle:
 class RefImage:
     """RawImage owned by the reference build."""
 
-    def __init__(self, ref, dim_x, dim_y, cpp=1, is_cfa=True, fill=0xA5):
+    def __init__(self, ref, dim_x, dim_y, cpp=1, is_cfa=True, fill=0xA5, f32=False):
         self.ref = ref
         self.dim_x, self.dim_y, self.cpp = dim_x, dim_y, cpp
-        self.h = ref.lib.ref_image_create(dim_x, dim_y, cpp, 1 if is_cfa else 0)
+        if f32:
+            self.h = ref.lib.ref_image_create_f32(dim_x, dim_y, cpp)
+        else:
+            self.h = ref.lib.ref_image_create(dim_x, dim_y, cpp, 1 if is_cfa else 0)
         if not self.h:
             raise RuntimeError(ref.last_error())
         self.pitch = ref.lib.ref_image_pitch(self.h)
@@ -180,6 +215,9 @@ class RefImage:
         n = self.pitch * self.dim_y
         buf = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,))
         return buf.view(np.uint16).reshape(self.dim_y, self.pitch // 2)
+
+    def u32(self):
+        return self.u16().view(np.uint32)
 
     def pixels(self):
         return self.u16()[:, :self.dim_x * self.cpp]
@@ -208,6 +246,8 @@ class Ref:
         L.ref_last_error.restype = C.c_char_p
         L.ref_image_create.restype = C.c_void_p
         L.ref_image_create.argtypes = [C.c_int] * 4
+        L.ref_image_create_f32.argtypes = [C.c_int] * 3
+        L.ref_image_create_f32.restype = C.c_void_p
         L.ref_image_destroy.argtypes = [C.c_void_p]
         L.ref_image_data.restype = C.c_void_p
         L.ref_image_data.argtypes = [C.c_void_p]
@@ -217,6 +257,8 @@ class Ref:
         L.ref_unpack_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.ref_unpack_variant_u16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_size_t]
+        L.ref_decode8bit_lookup.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                            C.c_int, C.c_void_p, C.c_size_t]
         L.ref_nikon_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
                                            C.c_void_p, C.c_size_t, C.c_int]
         L.ref_ljpeg_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
@@ -240,8 +282,8 @@ class Ref:
     def last_error(self):
         return self.lib.ref_last_error().decode(errors="replace")
 
-    def image(self, dim_x, dim_y, cpp=1, is_cfa=True, fill=0xA5):
-        return RefImage(self, dim_x, dim_y, cpp, is_cfa, fill)
+    def image(self, dim_x, dim_y, cpp=1, is_cfa=True, fill=0xA5, f32=False):
+        return RefImage(self, dim_x, dim_y, cpp, is_cfa, fill, f32)
 
     def unpack(self, desc, data, img):
         a, p, n = _as_u8(data)
@@ -250,6 +292,11 @@ class Ref:
     def unpack_variant(self, desc, data, img):
         a, p, n = _as_u8(data)
         return self.lib.ref_unpack_variant_u16(img.h, C.byref(desc), p, n)
+
+    def decode8bit_lookup(self, curve, w, h, data, img):
+        c = np.ascontiguousarray(curve, dtype=np.uint16)
+        a, p, n = _as_u8(data)
+        return self.lib.ref_decode8bit_lookup(img.h, c.ctypes.data, c.size, w, h, p, n)
 
     def nikon(self, meta, bits_ps, data, img, uncorrected):
         m, mp, mn = _as_u8(meta)

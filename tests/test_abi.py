@@ -34,8 +34,8 @@ def test_struct_sizes_are_stable():
     # the ctypes mirror must match the C layout the library was compiled with
     assert C.sizeof(abi.HuffTable) == 16 + 162 + 2
     assert C.sizeof(abi.UnpackDesc) == 28
-    assert C.sizeof(abi.UnpackVariantDesc) == 16
-    assert C.sizeof(abi.UnpackVariantJob) == 16 + 24 + 32
+    assert C.sizeof(abi.UnpackVariantDesc) == 16 + 512
+    assert C.sizeof(abi.UnpackVariantJob) == 16 + 512 + 24 + 32
     assert C.sizeof(abi.NikonDesc) == 8 * 4 + 8 + 2 * 180
     assert C.sizeof(abi.Image) == 32
     assert C.sizeof(abi.LJpegDesc) == 4 * 10 + 8 + 4 + 4 + 4 * 180
@@ -78,6 +78,29 @@ def test_unpack_validate_matches_oracle(lib, oracle):
             assert d.crop_h * d.input_pitch_bytes < 4
         n_ok += a == 0
     assert n_ok > 20
+
+
+def test_unpack_f32_validate_matches_oracle(lib, oracle):
+    rng = np.random.default_rng(13)
+    seen = set()
+    for _ in range(3000):
+        w = int(rng.integers(1, 20))
+        h = int(rng.integers(1, 8))
+        cpp = int(rng.choice([1, 1, 2, 3, 4]))
+        img = HostImage(w, h, cpp if cpp <= 3 else 1, bpc=4)
+        img.cpp = cpp
+        d = abi.UnpackDesc(int(rng.integers(-1, 3)), int(rng.integers(-1, h + 2)),
+                           int(rng.integers(0, w + 2)), int(rng.integers(0, h + 2)),
+                           int(rng.integers(0, 200)), int(rng.choice([0, 8, 16, 24, 32, 33])),
+                           int(rng.integers(-1, 6)))
+        n = int(rng.integers(0, 1200))
+        v = img.view()
+        a = lib.rsx_unpack_f32_validate(C.byref(d), C.byref(v), n)
+        b = oracle.unpack_f32_validate(d, img, n)
+        if a != b:  # the bit streamer's "< 4 bytes" IOE is reported up front by the library
+            assert (a, b) == (abi.RSX_ERR_IO, abi.RSX_OK) and d.crop_h * d.input_pitch_bytes < 4
+        seen.add(a)
+    assert seen == {abi.RSX_OK, abi.RSX_ERR_INVALID_ARG, abi.RSX_ERR_IO}
 
 
 def test_unpack_variant_validate_matches_oracle(lib, oracle):

@@ -197,3 +197,33 @@ def test_nikon_decompressor(pair, name):
             pair, lambda lib, img: lib.nikon(meta, c["bits"], data, img, unc), (w, h, cpp))
         assert s0 == 0 and s1 == 0, (e0, e1)
         assert np.array_equal(a, b)
+
+
+def test_decode8bit_lookup_method(pair):
+    """decode8BitRaw<false> under a RawImageCurveGuard (DcsDecoder.cpp:68-81)."""
+    rng = np.random.default_rng(37)
+    curve = np.sort(rng.integers(0, 65536, size=256)).astype(np.uint16)
+    w, h = 3000, 41
+    data = rng.integers(0, 256, size=w * h, dtype=np.uint8)
+    (s0, a, e0), (s1, b, e1) = both(
+        pair, lambda lib, img: lib.decode8bit_lookup(curve, w, h, data, img), (w, h, 1))
+    assert s0 == 0 and s1 == 0, (e0, e1)
+    assert np.array_equal(a, b)
+
+
+def test_uncompressed_f32_image(pair):
+    """readUncompressedRaw on a RawImageType::F32 image: fp16 / fp24 widening and
+    the 32-bit copy, through the patched reference method."""
+    rng = np.random.default_rng(38)
+    for order, bps in ((1, 16), (0, 24), (0, 32)):
+        w, h, cpp = 1200, 33, 3
+        pitch = w * cpp * bps // 8 + 4
+        data = rng.integers(0, 256, size=h * pitch, dtype=np.uint8)
+        d = abi.UnpackDesc(2, 1, w, h, pitch, bps, order)
+        out = []
+        for lib in pair:
+            img = lib.image(w + 2, h + 1, cpp, f32=True)
+            out.append((lib.unpack(d, data, img), img.u32().copy(), lib.last_error()))
+        (s0, a, e0), (s1, b, e1) = out
+        assert s0 == 0 and s1 == 0, (e0, e1)
+        assert np.array_equal(a, b)

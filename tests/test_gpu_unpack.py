@@ -240,7 +240,7 @@ def test_unpack_variant_sweep_vs_oracle(gpu, oracle):
 
 def test_unpack_variant_errors(gpu, oracle):
     for variant, w, h, n in ((1, 11, 2, 64), (1, 10, 2, 31), (0, 10, 2, 19),
-                             (2, 10, 2, 39), (0, 12, 2, 24), (3, 10, 2, 100)):
+                             (2, 10, 2, 39), (0, 12, 2, 24), (4, 10, 2, 100)):
         d = abi.UnpackVariantDesc(variant, 0, w, h)
         data = np.zeros(n, dtype=np.uint8)
         img, want = HostImage(10, 2, 1), HostImage(10, 2, 1)
@@ -289,3 +289,112 @@ def test_unpack_variant_full_frame_properties(gpu):
         got = d_out.cpu().numpy().view(np.uint16).reshape(h, pitch // 2)[:, :w]
         assert np.array_equal(got, pix)
         plan.close()
+
+
+# ---- RawImageType::F32 images (decodePackedFP fp16 / fp24, 32-bit copy) -------
+
+@pytest.mark.parametrize("i", range(len(G.F32_CASES)))
+def test_unpack_f32_golden_host_api(gpu, oracle, i):
+    d, data, (w, h, cpp) = G.build_f32(G.F32_CASES[i])
+    img, want = HostImage(w, h, cpp, bpc=4), HostImage(w, h, cpp, bpc=4)
+    st = gpu.unpack_f32(d, data, img.view())
+    assert st == oracle.unpack_f32(d, data, want) == GOLD["f32"][str(i)]["status"] == 0
+    assert np.array_equal(img.u32(), want.u32())
+    assert G.image_hash(img.u32()[:, :w * cpp]) == GOLD["f32"][str(i)]["hash"]
+
+
+def test_unpack_f32_every_half_and_sweep(gpu, oracle):
+    """All 65536 binary16 patterns in both byte orders, then a shape sweep of
+    fp24 / fp16 / 32-bit jobs in one device-resident plan."""
+    import gpu_util
+    allh = np.arange(65536, dtype=np.uint16)
+    for order in (0, 1):
+        data = allh.astype(">u2" if order else "<u2").view(np.uint8)
+        d = abi.UnpackDesc(0, 0, 1024, 64, 2048, 16, order)
+        img, want = HostImage(1024, 64, 1, bpc=4), HostImage(1024, 64, 1, bpc=4)
+        assert gpu.unpack_f32(d, data, img.view()) == oracle.unpack_f32(d, data, want) == 0
+        assert np.array_equal(img.u32(), want.u32())
+        f = img.u32()[:, :1024].reshape(-1).view(np.float32)
+        ref = allh.view(np.float16).astype(np.float32)
+        ok = np.isnan(ref) | (f == ref)
+        assert ok.all()                     # numpy agrees wherever it is a number
+
+    rng = np.random.default_rng(24)
+    jobs, wants, chunks = [], [], []
+    in_off = out_off = 0
+    for order, bps in ((0, 16), (1, 16), (0, 24), (1, 24), (0, 32), (3, 32)):
+        for w in (1, 2, 3, 5, 64, 1023, 1024, 1025, 4100):
+            cpp = int(rng.integers(1, 4))
+            if (w * cpp * bps) % 8:
+                continue
+            h, pad = int(rng.integers(1, 4)), int(rng.integers(0, 4))
+            ox, oy = int(rng.integers(0, 3)), int(rng.integers(0, 2))
+            pitch = w * cpp * bps // 8 + pad
+            if h * pitch < 4:
+                continue
+            data = rng.integers(0, 256, size=h * pitch, dtype=np.uint8)
+            d = abi.UnpackDesc(ox, oy, w, h, pitch, bps, order)
+            want = HostImage(w + ox, h + oy, cpp, bpc=4)
+            assert oracle.unpack_f32(d, data, want) == 0
+            j = abi.UnpackJob()
+            j.desc = d
+            j.in_offset, j.in_bytes, j.img_offset = in_off, data.size, out_off
+            j.img = gpu_util.image_job_view(w + ox, h + oy, cpp, want.pitch)
+            jobs.append(j)
+            wants.append(want)
+            chunks.append((in_off, data))
+            in_off += data.size + int(rng.integers(0, 3)) * 7
+            out_off += want.buf.size
+    in_host = np.zeros(in_off + 16, np.uint8)
+    for off, data in chunks:
+        in_host[off:off + data.size] = data
+    d_in = gpu_util.to_dev(in_host)
+    d_out = torch.full((out_off + 16,), 0xA5, dtype=torch.uint8, device="cuda")
+    plan = gpu.unpack_f32_plan(jobs)
+    plan.run(d_in.data_ptr(), d_out.data_ptr())
+    rc, status, _ = plan.results()
+    assert rc == 0 and all(s == 0 for s in status)
+    got = d_out.cpu().numpy()
+    for j, want in zip(jobs, wants):
+        assert np.array_equal(got[j.img_offset:j.img_offset + want.buf.size], want.buf), \
+            (j.desc.bit_order, j.desc.bits_per_pixel, j.desc.crop_w)
+    plan.close()
+
+
+def test_decode8bit_lookup(gpu, oracle):
+    """decode8BitRaw<false>: several frames with different tables in one plan."""
+    import gpu_util
+    from oracle_lib import dither_lut8
+    rng = np.random.default_rng(25)
+    jobs, wants, chunks = [], [], []
+    in_off = out_off = 0
+    for w, h in ((16, 3), (250, 4), (8200, 2), (4096, 5)):
+        curve = np.sort(rng.integers(0, 65536, size=256)).astype(np.uint16)
+        d = abi.UnpackVariantDesc(abi.UNPACK_8BIT_LOOKUP, 0, w, h).set_lut(dither_lut8(curve))
+        data = rng.integers(0, 256, size=w * h, dtype=np.uint8)
+        want, img = HostImage(w, h, 1), HostImage(w, h, 1)
+        assert oracle.unpack_variant(d, data, want) == 0
+        assert gpu.unpack_variant_u16(d, data, img.view()) == 0      # host-pointer call
+        assert np.array_equal(img.u16(), want.u16())
+        j = abi.UnpackVariantJob()
+        j.desc = d
+        j.in_offset, j.in_bytes, j.img_offset = in_off, data.size, out_off
+        j.img = gpu_util.image_job_view(w, h, 1, want.pitch)
+        jobs.append(j)
+        wants.append(want)
+        chunks.append((in_off, data))
+        in_off += data.size + 5
+        out_off += want.buf.size
+    in_host = np.zeros(in_off + 16, np.uint8)
+    for off, data in chunks:
+        in_host[off:off + data.size] = data
+    d_in = gpu_util.to_dev(in_host)
+    d_out = torch.full((out_off + 16,), 0xA5, dtype=torch.uint8, device="cuda")
+    plan = gpu.unpack_variant_plan(jobs)
+    plan.run(d_in.data_ptr(), d_out.data_ptr())
+    rc, status, _ = plan.results()
+    assert rc == 0 and status == [0] * len(jobs)
+    got = d_out.cpu().numpy()
+    for j, want in zip(jobs, wants):
+        assert np.array_equal(got[j.img_offset:j.img_offset + want.buf.size], want.buf)
+    plan.close()

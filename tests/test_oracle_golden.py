@@ -24,6 +24,16 @@ def test_unpack_golden(oracle, i):
     assert G.image_hash(img.pixels()) == g["hash"]
 
 
+@pytest.mark.parametrize("i", range(len(G.F32_CASES)))
+def test_unpack_f32_golden(oracle, i):
+    d, data, (w, h, cpp) = G.build_f32(G.F32_CASES[i])
+    img = HostImage(w, h, cpp, bpc=4)
+    st = oracle.unpack_f32(d, data, img)
+    g = GOLD["f32"][str(i)]
+    assert st == g["status"] == 0
+    assert G.image_hash(img.u32()[:, :w * cpp]) == g["hash"]
+
+
 @pytest.mark.parametrize("i", range(len(G.VARIANT_CASES)))
 def test_unpack_variant_golden(oracle, i):
     d, data, (w, h, cpp) = G.build_variant(G.VARIANT_CASES[i])
@@ -104,6 +114,52 @@ def test_nikon_truncated_vs_ref(oracle, ref):
             assert np.array_equal(hi.u16(), ri.u16())
         seen.add(so)
     assert 0 in seen and len(seen) >= 2
+
+
+def test_decode8bit_lookup_vs_ref(oracle, ref):
+    """decode8BitRaw<false>: the curve/dither flavour is a pure table lookup
+    because its random state starts at 0 and 15700 * 0 + 0 == 0."""
+    from rawspeed_amd import abi
+    from oracle_lib import dither_lut8
+    rng = np.random.default_rng(8)
+    for n_curve in (256, 100, 1):
+        curve = np.sort(rng.integers(0, 65536, size=n_curve)).astype(np.uint16)
+        if n_curve > 10:
+            curve[3:6] = curve[3:6][::-1]
+        for (w, h) in ((16, 3), (250, 4)):
+            data = rng.integers(0, 256, size=w * h, dtype=np.uint8)
+            d = abi.UnpackVariantDesc(abi.UNPACK_8BIT_LOOKUP, 0, w, h).set_lut(dither_lut8(curve))
+            a, b = HostImage(w, h, 1), ref.image(w, h, 1)
+            assert oracle.unpack_variant(d, data, a) == 0
+            assert ref.decode8bit_lookup(curve, w, h, data, b) == 0, ref.last_error()
+            assert np.array_equal(a.u16(), b.u16())
+
+
+def test_unpack_f32_vs_ref_sweep(oracle, ref):
+    """F32 images: every (order, bps) the reference accepts or rejects, random bit
+    patterns (all exponent classes), crops, paddings; compared as raw bits."""
+    from rawspeed_amd import abi
+    rng = np.random.default_rng(6)
+    n_ok = n_err = 0
+    for order in range(4):
+        for bps in (8, 16, 24, 32):
+            for (w, h, cpp, pad, ox, oy) in ((4, 1, 1, 0, 0, 0), (12, 3, 1, 0, 0, 0),
+                                             (10, 4, 2, 5, 3, 1), (9, 2, 3, 1, 0, 2)):
+                pitch = w * cpp * bps // 8 + pad
+                for cut in (0, 1):
+                    n = h * pitch - cut
+                    data = rng.integers(0, 256, size=max(n, 1), dtype=np.uint8)[:n]
+                    d = abi.UnpackDesc(ox, oy, w, h, pitch, bps, order)
+                    dim_y = h + oy - int(rng.integers(0, 2))
+                    a = HostImage(w + ox, max(dim_y, 1), cpp, bpc=4)
+                    b = ref.image(w + ox, max(dim_y, 1), cpp, f32=True)
+                    sa, sb = oracle.unpack_f32(d, data, a), ref.unpack(d, data, b)
+                    assert sa == sb, (order, bps, w, h, cpp, pad, ox, oy, cut, sa, sb,
+                                      ref.last_error())
+                    assert np.array_equal(a.u32(), b.u32())
+                    n_ok += sa == 0
+                    n_err += sa != 0
+    assert n_ok >= 20 and n_err >= 40
 
 
 def test_unpack_variant_vs_ref_sweep(oracle, ref):
