@@ -194,6 +194,7 @@ struct LjArgs {
   const uint32_t* nk_tables; // dither tables: base | delta << 16 per 15-bit value
   const uint32_t* nk_rowpow; // 15700^(y * W) mod (15700 * 2^16 - 1) per output row
   int32_t* nk_pup;           // [stream][4]: pUp after the stream's last row
+  uint16_t* transfer;        // [workgroup][512]: exit state per entry state (fallback path)
 };
 
 // ---------------------------------------------------------------------------
@@ -258,7 +259,7 @@ __device__ __forceinline__ void lj_stage_tables(const Lds& L, const LjArgs& a,
   const uint4* src = reinterpret_cast<const uint4*>(a.tables + S.table_base);
   uint4* dst = reinterpret_cast<uint4*>(L.tabs);
   const int n16 = int(S.n_tables * sizeof(TabLds) / 16);
-  for (int i = threadIdx.x; i < n16; i += LJ_T)
+  for (int i = threadIdx.x; i < n16; i += int(blockDim.x))
     dst[i] = src[i];
 }
 
@@ -919,6 +920,68 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   __syncthreads();
   if (j == 0)
     a.block_sum[b] = L.misc[0] + L.misc[1] + L.misc[2] + L.misc[3];
+}
+
+// ---------------------------------------------------------------------------
+// Fallback for streams that do not self-synchronise (constant image regions make
+// the bit stream periodic, and a mis-aligned parse of a periodic stream can
+// cycle forever without meeting the true one).  Propagating the true state
+// workgroup by workgroup would take one stitch launch per 16 KB; instead every
+// workgroup of such a stream computes its TRANSFER FUNCTION -- the exit state
+// for each of the (at most 64 x period) possible entry states, one lane per
+// entry state, each lane a plain sequential decode of the workgroup's 255
+// slots -- and one lane per stream then chains the functions.  After that every
+// workgroup knows its true entry state and a single stitch pass finishes the job.
+// ---------------------------------------------------------------------------
+constexpr int TF_ENTRIES = 512; // index = state & 0x1FF (offset | phase << 6)
+
+// The un-stuffed image is read straight from global memory here (all lanes of
+// a wavefront read the same dwords): without the 28 KB LDS image the kernel is
+// limited by wave slots, not LDS, and every workgroup of the plan is resident.
+template <bool MULTI>
+__global__ __launch_bounds__(LJ_T) void lj_transfer_kernel(LjArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t b = blockIdx.x;
+  const uint32_t s = a.block_stream[b];
+  const LjStreamDev& S = a.streams[s];
+  if ((S.n_tables > 1) != MULTI || !(a.results[s].flags & FL_UNCONVERGED))
+    return;
+  Lds L{};
+  L.B = const_cast<uint32_t*>(
+      reinterpret_cast<const uint32_t*>(a.unstuffed + size_t(b) * LJ_IMG_U4));
+  L.ob = L.B + LJ_BW * LJ_T;
+  L.tabs = reinterpret_cast<TabLds*>(smem);
+  const int j = threadIdx.x;
+  lj_stage_tables(L, a, S);
+  __syncthreads();
+  const DecodeParams dp = lj_params(S);
+  // lane -> entry state: offset 0..63 (0..31 | phase << 6 with several tables)
+  const uint32_t off = MULTI ? uint32_t(j) & 31u : uint32_t(j) & 63u;
+  const uint32_t phase = MULTI ? uint32_t(j) >> 5 : 0u;
+  const bool enabled = !MULTI || phase < S.period;
+  uint32_t state = off | (phase << ST_PHASE_SHIFT);
+  for (int slot = 1; slot < LJ_T; ++slot) {
+    uint32_t e = ST_ERR, c = 0;
+    lj_decode_span<MULTI, false>(L, dp, slot, state, L.ob[slot], e, c, nullptr, enabled);
+    state = e;
+  }
+  if (enabled)
+    a.transfer[size_t(b) * TF_ENTRIES + (off | (phase << ST_PHASE_SHIFT))] =
+        uint16_t(state & ST_MASK);
+}
+
+__global__ __launch_bounds__(64) void lj_chain_kernel(LjArgs a) {
+  const uint32_t s = blockIdx.x;
+  const LjStreamDev& S = a.streams[s];
+  if (threadIdx.x != 0 || !(a.results[s].flags & FL_UNCONVERGED))
+    return;
+  uint32_t state = S.start_bit;
+  for (uint32_t lb = 0; lb < S.n_blocks; ++lb) {
+    const uint32_t b = S.first_block + lb;
+    state = (state & ST_ERR) ? ST_ERR
+                             : uint32_t(a.transfer[size_t(b) * TF_ENTRIES + (state & 0x1FFu)]);
+    a.block_exit[b] = state;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2113,6 +2176,7 @@ struct LJpegPlan {
   bool any_nikon = false;
   std::vector<NkStreamDev> nk;         // parallel to streams
   DeviceBuffer d_nk, d_nk_tables, d_nk_rowpow, d_nk_pup;
+  DeviceBuffer d_transfer; // fallback path only (allocated on first use)
   // jobs with a split row: the rows after it are a second stream (other table)
   // that starts at the bit where the first part ends -- known after it ran
   struct NkSplit {
@@ -2156,6 +2220,7 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.nk_tables = static_cast<const uint32_t*>(p->d_nk_tables.ptr);
   a.nk_rowpow = static_cast<const uint32_t*>(p->d_nk_rowpow.ptr);
   a.nk_pup = static_cast<int32_t*>(p->d_nk_pup.ptr);
+  a.transfer = static_cast<uint16_t*>(p->d_transfer.ptr);
   return a;
 }
 
@@ -2648,8 +2713,27 @@ int converge(LJpegPlan* p, hipStream_t s) {
   };
   if (!unconverged())
     return RSX_OK;
-  const LjArgs a = make_args(p, p->last_in, p->last_out);
   const uint32_t n_streams = uint32_t(p->streams.size());
+  // transfer functions + chain: every workgroup learns its true entry state at
+  // once, however badly the stream synchronises; one stitch pass then settles it
+  if (int st = p->d_transfer.ensure(size_t(p->total_blocks) * TF_ENTRIES * 2))
+    return st;
+  const LjArgs a = make_args(p, p->last_in, p->last_out);
+  {
+    if (p->any_single)
+      hipLaunchKernelGGL((lj_transfer_kernel<false>), dim3(p->total_blocks), dim3(64),
+                         sizeof(TabLds), s, a);
+    if (p->any_multi)
+      hipLaunchKernelGGL((lj_transfer_kernel<true>), dim3(p->total_blocks), dim3(LJ_T),
+                         size_t(p->max_tables) * sizeof(TabLds), s, a);
+    hipLaunchKernelGGL(lj_chain_kernel, dim3(n_streams), dim3(64), 0, s, a);
+    launch_sync<true>(p, a, s);
+    hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
+    RSX_HIP_CHECK(ctx, hipGetLastError());
+    p->extra_stitch_rounds += 1;
+    if (int st = fetch())
+      return st;
+  }
   uint32_t rounds = 0;
   while (unconverged() && rounds <= p->total_blocks) {
     for (int k = 0; k < 4; ++k)
@@ -2803,7 +2887,8 @@ void ljpeg_plan_destroy(LJpegPlan* p) {
     ljpeg_plan_destroy(p->child);
   if (p->nk_child)
     ljpeg_plan_destroy(p->nk_child);
-  for (DeviceBuffer* b : {&p->d_nk, &p->d_nk_tables, &p->d_nk_rowpow, &p->d_nk_pup})
+  for (DeviceBuffer* b :
+       {&p->d_nk, &p->d_nk_tables, &p->d_nk_rowpow, &p->d_nk_pup, &p->d_transfer})
     b->release();
   p->d_marker_count.release();
   p->d_marker_list.release();

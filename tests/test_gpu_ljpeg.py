@@ -308,3 +308,25 @@ def test_constant_regions_converge(gpu, oracle):
     assert so[0] == 0 and gpu.cr2_decode(d, data, img.view()) == so
     assert np.array_equal(img.u16(), want.u16())
     assert np.array_equal(img.pixels(), src)
+
+
+@pytest.mark.parametrize("value", [0, 16383, 8192])
+def test_constant_frame(gpu, oracle, value):
+    """A frame of one value (lens cap / fully blown): ~100 workgroups of a
+    perfectly periodic bit stream.  No subsequence synchronises by itself; the
+    transfer-function fallback gives every workgroup its entry state."""
+    W, H = 4096, 512
+    src = np.full((H, W), value, np.uint16)
+    rows = C.cr2_stream_from_image(src, 2, W // 2, H, [W])
+    scan, _ = synth.ljpeg_encode_scan(rows, 2, [1 << 13] * 2, [C.NIKON, C.NIKON])
+    d = abi.Cr2Desc()
+    d.n_comp, d.x_s_f, d.y_s_f = 2, 1, 1
+    d.frame_w, d.frame_h = W // 2, H
+    d.num_slices, d.slice_width, d.last_slice_width = 1, 0, W
+    abi.fill_recipe(d, synth.huff_tables(C.NIKON), [0, 0], [1 << 13] * 2)
+    data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), np.zeros(16, np.uint8)])
+    img, want = HostImage(W, H), HostImage(W, H)
+    so = oracle.cr2(d, data, want)
+    assert so[0] == 0 and gpu.cr2_decode(d, data, img.view()) == so
+    assert np.array_equal(img.u16(), want.u16())
+    assert np.array_equal(img.pixels(), src)
