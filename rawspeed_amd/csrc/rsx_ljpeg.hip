@@ -1069,13 +1069,15 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
 // ---------------------------------------------------------------------------
 // K4: final decode -> stream-ordered int16 differences
 // ---------------------------------------------------------------------------
-template <bool MULTI>
+// LAS: the stream's table holds Nikon "lossy after split" values (its own
+// instantiation so that the JPEG hot loop carries no extra branch)
+template <bool MULTI, bool LAS = false>
 __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t b = blockIdx.x;
   const uint32_t s = a.block_stream[b];
   const LjStreamDev& S = a.streams[s];
-  if ((S.n_tables > 1) != MULTI)
+  if ((S.n_tables > 1) != MULTI || (S.las != 0) != LAS)
     return;
   const Lds L = carve(smem, int(S.n_tables));
   const uint32_t lb = b - S.first_block;
@@ -1145,7 +1147,6 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   const uint32_t n_groups = (a.ablate & 2u) ? 0u : (wmax + 7) >> 3;
 
   uint32_t phase = (my_start >> ST_PHASE_SHIFT) & 7u;
-  const bool las = S.las != 0;
   BitReader r = br_open(L.B, j, my_start & ST_OFF_MASK);
   uint32_t tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0; // the lane's last, partial group
   for (uint32_t g = 0; g < n_groups; ++g) {
@@ -1160,7 +1161,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
         phase = live ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
       const uint32_t cl = e & 31u, ssss = (e >> 5) & 31u;
       uint32_t diff;
-      if (las) { // stream-uniform: NikonLASDecompressor::decodeDifference (.cpp:366-376)
+      if (LAS) { // NikonLASDecompressor::decodeDifference (.cpp:366-376)
         const uint32_t nbits = (e >> 10) - cl, shl = ssss - nbits;
         const uint32_t v = uint32_t((uint64_t(w << cl) << nbits) >> 32);
         int d = int((((v << 1) + 1u) << shl) >> 1);
@@ -2173,7 +2174,7 @@ struct LJpegPlan {
   LJpegPlan* child = nullptr;          // one stream per restart interval
   std::vector<std::pair<int, int>> child_owner; // child job -> (dri index, interval)
   // NikonDecompressor streams
-  bool any_nikon = false;
+  bool any_nikon = false, any_las = false, any_plain = false;
   std::vector<NkStreamDev> nk;         // parallel to streams
   DeviceBuffer d_nk, d_nk_tables, d_nk_rowpow, d_nk_pup;
   DeviceBuffer d_transfer; // fallback path only (allocated on first use)
@@ -2235,8 +2236,11 @@ void launch_sync(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
 }
 
 void launch_decode(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
-  if (p->any_single)
+  if (p->any_plain)
     hipLaunchKernelGGL((lj_decode_kernel<false>), dim3(p->total_blocks), dim3(LJ_T),
+                       lj_lds_bytes(1), s, a);
+  if (p->any_las)
+    hipLaunchKernelGGL((lj_decode_kernel<false, true>), dim3(p->total_blocks), dim3(LJ_T),
                        lj_lds_bytes(1), s, a);
   if (p->any_multi)
     hipLaunchKernelGGL((lj_decode_kernel<true>), dim3(p->total_blocks), dim3(LJ_T),
@@ -2394,6 +2398,8 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     bool multi = J.n_tables > 1;
     p->any_multi |= multi;
     p->any_single |= !multi;
+    p->any_plain |= !multi && !g.las;
+    p->any_las |= g.las != 0;
     p->max_tables = std::max(p->max_tables, J.n_tables);
     if (g.kind != 2)
       p->comp_present[g.period == g.n_comp ? g.n_comp : (g.period == 4 ? 5u : 6u)] = true;
