@@ -58,7 +58,9 @@ typedef enum rsx_status {
   RSX_ERR_NOMEM = 8,
   /* AbstractDngDecompressor: at least one tile failed
    * (AbstractDngDecompressor.cpp:247-251 "Too many errors") */
-  RSX_ERR_TILE_ERRORS = 9
+  RSX_ERR_TILE_ERRORS = 9,
+  /* "decoded value out of bounds" (PentaxDecompressor.cpp:170-171) */
+  RSX_ERR_VALUE_RANGE = 10
 } rsx_status;
 
 /* Bit orders; numeric values equal rawspeed::BitOrder
@@ -282,6 +284,24 @@ int rsx_nikon_decompress(rsx_ctx* ctx, const rsx_nikon_desc* d, const uint8_t* i
                          size_t in_bytes, const rsx_image* img);
 
 /* ------------------------------------------------------------------------ */
+/* 3c. PentaxDecompressor                                                    */
+/*    replaces PentaxDecompressor::decompress(ByteStream data)               */
+/*    (decompressors/PentaxDecompressor.h, .cpp:152-176): BitStreamerMSB,    */
+/*    one PrefixCodeDecoder<> (the legacy tree or the one the constructor    */
+/*    derives from the makernote, .cpp:69-150 -- stays on the host),         */
+/*    pred[col & 1] += diff with both predictors starting from the pixels    */
+/*    two rows up (0 for the first two rows); a value outside [0, 65535]     */
+/*    is RSX_ERR_VALUE_RANGE.                                                */
+/* ------------------------------------------------------------------------ */
+typedef struct rsx_pentax_desc {
+  rsx_huff_table table;
+} rsx_pentax_desc;
+
+int rsx_pentax_validate(const rsx_pentax_desc* d, const rsx_image* img);
+int rsx_pentax_decompress(rsx_ctx* ctx, const rsx_pentax_desc* d, const uint8_t* in,
+                          size_t in_bytes, const rsx_image* img);
+
+/* ------------------------------------------------------------------------ */
 /* 4. AbstractDngDecompressor tile fan-out                                   */
 /*    replaces AbstractDngDecompressor::decompress()                         */
 /*    (AbstractDngDecompressor.h:141, .cpp:240-252) for compression 1        */
@@ -368,6 +388,14 @@ typedef struct rsx_nikon_job {
   rsx_image img; /* .data ignored */
 } rsx_nikon_job;
 
+typedef struct rsx_pentax_job {
+  rsx_pentax_desc desc;
+  uint64_t in_offset;
+  uint64_t in_bytes;
+  uint64_t img_offset;
+  rsx_image img; /* .data ignored */
+} rsx_pentax_job;
+
 int rsx_unpack_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_unpack_job* jobs,
                            rsx_plan** out_plan);
 /* F32 images: same job structure, img describes 4-byte samples */
@@ -384,6 +412,8 @@ int rsx_cr2_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_cr2_job* jobs,
  * starts at a bit position only known once the first part is decoded) */
 int rsx_nikon_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_nikon_job* jobs,
                           rsx_plan** out_plan);
+int rsx_pentax_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_pentax_job* jobs,
+                           rsx_plan** out_plan);
 /* Enqueue one pass of the plan on `stream`. */
 int rsx_plan_run(rsx_plan* plan, const void* in_dev, void* out_dev,
                  void* stream);

@@ -181,6 +181,19 @@ HUNK_NIKON = r'''
   }
 '''
 
+HUNK_PENTAX = r'''
+  // ---- rsx: forward to the MI355X core (INTEGRATION.md 3c) ----
+  {
+    rsx_pentax_desc d{};
+    d.table = rsx_shim::table(ht);
+    const rsx_image img = rsx_shim::view(mRaw);
+    const Buffer in = data.peekRemainingBuffer();
+    if (int st = rsx_pentax_decompress(rsx_shim::context(), &d, in.begin(), in.getSize(), &img))
+      rsx_shim::raise(st);
+    return;
+  }
+'''
+
 PATCHES = [
     ("decompressors/UncompressedDecompressor.cpp", [
         ("void UncompressedDecompressor::readUncompressedRaw() {", HUNK_UNPACK),
@@ -191,6 +204,8 @@ PATCHES = [
     ("decompressors/NikonDecompressor.cpp", [
         ("void NikonDecompressor::decompress(Array1DRef<const uint8_t> input,\n"
          "                                   bool uncorrectedRawValues) {", HUNK_NIKON)]),
+    ("decompressors/PentaxDecompressor.cpp", [
+        ("void PentaxDecompressor::decompress(ByteStream data) const {", HUNK_PENTAX)]),
     ("decompressors/LJpegDecompressor.cpp", [
         ("ByteStream::size_type LJpegDecompressor::decode() const {", HUNK_LJPEG)]),
     ("decompressors/Cr2DecompressorImpl.h", [

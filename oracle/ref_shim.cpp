@@ -30,6 +30,7 @@
 #include "decompressors/LJpegDecoder.h"
 #include "decompressors/LJpegDecompressor.h"
 #include "decompressors/NikonDecompressor.h"
+#include "decompressors/PentaxDecompressor.h"
 #include "decompressors/UncompressedDecompressor.h"
 #include "io/Buffer.h"
 #include "io/ByteStream.h"
@@ -318,6 +319,22 @@ int ref_nikon_decompress(void* h, const uint8_t* meta, size_t meta_bytes,
     NikonDecompressor n(r->img, ByteStream(DataBuffer(mb, Endianness::big)), bits_ps);
     n.decompress(Array1DRef<const uint8_t>(in, implicit_cast<int>(in_bytes)),
                  uncorrected_raw_values != 0);
+  });
+}
+
+// PentaxDecompressor (PefDecoder.cpp): `meta` = the makernote Huffman description
+// (big-endian), or NULL for the legacy tree.
+int ref_pentax_decompress(void* h, const uint8_t* meta, size_t meta_bytes,
+                          const uint8_t* in, size_t in_bytes) {
+  auto* r = static_cast<RefImage*>(h);
+  return guarded([&] {
+    Optional<ByteStream> md;
+    const Buffer mb(meta, implicit_cast<Buffer::size_type>(meta_bytes));
+    if (meta)
+      md = ByteStream(DataBuffer(mb, Endianness::big));
+    PentaxDecompressor p(r->img, md);
+    const Buffer b(in, implicit_cast<Buffer::size_type>(in_bytes));
+    p.decompress(ByteStream(DataBuffer(b, Endianness::little)));
   });
 }
 

@@ -1313,3 +1313,58 @@ int oracle_nikon_decompress(const rsx_nikon_desc* d, const uint8_t* in,
   return err;
 }
 
+/* ======================================================================== */
+/* PentaxDecompressor (decompressors/PentaxDecompressor.cpp)                  */
+/* ======================================================================== */
+
+int oracle_pentax_validate(const rsx_pentax_desc* d, const rsx_image* img) {
+  if (img->cpp != 1)
+    return RSX_ERR_INVALID_ARG; /* :58-60 */
+  if (img->dim_x <= 0 || img->dim_y <= 0 || img->dim_x % 2 != 0 ||
+      img->dim_x > 8384 || img->dim_y > 6208)
+    return RSX_ERR_INVALID_ARG; /* :62-66 */
+  hufftab h;
+  int st = huff_setup(&h, &d->table);
+  if (st)
+    return st;
+  if (d->table.fix_dng_bug16)
+    return RSX_ERR_INVALID_ARG; /* ht.setup(true, false) :147 */
+  return RSX_OK;
+}
+
+/* decompress :152-176 */
+int oracle_pentax_decompress(const rsx_pentax_desc* d, const uint8_t* in,
+                             size_t in_bytes, const rsx_image* img) {
+  int st = oracle_pentax_validate(d, img);
+  if (st)
+    return st;
+  hufftab h;
+  huff_setup(&h, &d->table);
+  bitreader b;
+  br_init(&b, in, (int64_t)in_bytes, RSX_ORDER_MSB);
+  if (b.err)
+    return b.err;
+  const int W = img->dim_x, H = img->dim_y;
+  int err = 0;
+  for (int row = 0; row < H; ++row) {
+    uint16_t* o = (uint16_t*)((uint8_t*)img->data + (size_t)row * img->pitch_bytes);
+    int pred[2] = {0, 0};
+    if (row >= 2) {
+      const uint16_t* up =
+          (const uint16_t*)((const uint8_t*)img->data + (size_t)(row - 2) * img->pitch_bytes);
+      pred[0] = up[0];
+      pred[1] = up[1];
+    }
+    for (int col = 0; col < W; ++col) {
+      pred[col & 1] += huff_decode_diff(&h, &b, &err);
+      if (err)
+        return err;
+      const int value = pred[col & 1];
+      if (((unsigned)value >> 16) != 0)
+        return RSX_ERR_VALUE_RANGE; /* !isIntN(value, 16) :170-171 */
+      o[col] = (uint16_t)value;
+    }
+  }
+  return RSX_OK;
+}
+

@@ -21,12 +21,15 @@ RSX_ERR_DEVICE = 6
 RSX_ERR_UNSUPPORTED = 7
 RSX_ERR_NOMEM = 8
 RSX_ERR_TILE_ERRORS = 9
+RSX_ERR_VALUE_RANGE = 10
+RSX_ERR_VALUE_RANGE = 10
 
 STATUS_NAMES = {
     0: "RSX_OK", 1: "RSX_ERR_INVALID_ARG", 2: "RSX_ERR_IO",
     3: "RSX_ERR_BAD_HUFFMAN_CODE", 4: "RSX_ERR_RESTART_MARKER",
     5: "RSX_ERR_INPUT_OVERFLOW", 6: "RSX_ERR_DEVICE", 7: "RSX_ERR_UNSUPPORTED",
     8: "RSX_ERR_NOMEM", 9: "RSX_ERR_TILE_ERRORS",
+    10: "RSX_ERR_VALUE_RANGE",
 }
 
 # rsx_bit_order == rawspeed::BitOrder (bitstreams/BitStreams.h:27-35)
@@ -117,6 +120,16 @@ class NikonDesc(C.Structure):
         self._curve = np.ascontiguousarray(curve, dtype=np.uint16)
         self.curve = self._curve.ctypes.data
         self.curve_size = self._curve.size
+
+
+class PentaxDesc(C.Structure):
+    _fields_ = [("table", HuffTable)]
+
+
+class PentaxJob(C.Structure):
+    _fields_ = [("desc", PentaxDesc), ("in_offset", C.c_uint64),
+                ("in_bytes", C.c_uint64), ("img_offset", C.c_uint64),
+                ("img", Image)]
 
 
 class DngLJpegTile(C.Structure):

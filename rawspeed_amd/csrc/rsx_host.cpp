@@ -546,6 +546,20 @@ int validate_nikon(const rsx_nikon_desc& d, const rsx_image& img) {
   return RSX_OK;
 }
 
+// PentaxDecompressor::PentaxDecompressor (decompressors/PentaxDecompressor.cpp:55-67)
+int validate_pentax(const rsx_pentax_desc& d, const rsx_image& img) {
+  if (img.cpp != 1) // :58-60
+    return RSX_ERR_INVALID_ARG;
+  if (img.dim_x <= 0 || img.dim_y <= 0 || img.dim_x % 2 != 0 || img.dim_x > 8384 ||
+      img.dim_y > 6208) // :62-66
+    return RSX_ERR_INVALID_ARG;
+  if (int st = validate_huff_table(d.table)) // SetupPrefixCodeDecoder :139-150
+    return st;
+  if (d.table.fix_dng_bug16) // ht.setup(true, false)
+    return RSX_ERR_INVALID_ARG;
+  return RSX_OK;
+}
+
 // TableLookUp::setTable, dither branch (common/TableLookUp.cpp:66-84).  Only
 // the first 32768 entries can be addressed: the index is clampBits(pred, 15).
 void build_dither_table(const uint16_t* curve, int n, std::vector<uint32_t>* out) {

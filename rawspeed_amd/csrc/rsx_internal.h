@@ -27,6 +27,7 @@ int unpack_variant_bytes_per_line(const rsx_unpack_variant_desc& d, uint64_t* bp
 int validate_ljpeg(const rsx_ljpeg_desc& d, const rsx_image& img);
 int validate_cr2(const rsx_cr2_desc& d, const rsx_image& img);
 int validate_nikon(const rsx_nikon_desc& d, const rsx_image& img);
+int validate_pentax(const rsx_pentax_desc& d, const rsx_image& img);
 // TableLookUp::setTable with dither (common/TableLookUp.cpp:50-84), 15-bit domain
 void build_dither_table(const uint16_t* curve, int n, std::vector<uint32_t>* out);
 int validate_huff_table(const rsx_huff_table& t);

@@ -14,6 +14,7 @@ struct NikonIn {
   int32_t p_up[4] = {0, 0, 0, 0}; // pUp[row & 1][col & 1] at [2 * (row & 1) + (col & 1)]
   const int32_t* pup_in = nullptr; // device pointer overriding p_up (rows after a split)
   bool uncorrected = true;
+  bool pentax = false;    // PentaxDecompressor: values outside [0, 65535] are an error
   int split = 0;          // rows >= split use table_after_split (0 = none)
   int height = 0;         // image rows
   std::vector<uint32_t> dither; // 32768 x (base | delta << 16); empty if uncorrected

@@ -145,7 +145,8 @@ struct NkStreamDev {
   uint32_t uncorrected;  // 1: store clampBits(pred, 15) as is
   uint32_t table_off;    // first entry of this stream's dither table in nk_tables
   uint32_t rowpow_off;   // first entry of this stream's row powers in nk_rowpow
-  uint32_t pad;
+  uint32_t pentax;       // 1: PentaxDecompressor (.cpp:152-176): no clamp, values outside
+                         //    [0, 65535] are RSX_ERR_VALUE_RANGE
   uint64_t seed_offset;  // byte offset (from in_base) of the job's first input byte
 };
 
@@ -1963,10 +1964,23 @@ __global__ __launch_bounds__(LJ_T) void nk_predict_kernel(LjArgs a) {
       step_state = nk_mulmod(step_state, a512);
     }
     uint32_t px[8];
+    if (K.pentax) {
+      // isIntN(value, 16) (PentaxDecompressor.cpp:170): the value as unsigned
+      // must fit 16 bits
+      bool bad = false;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        bad |= q + i < W && (uint32_t(v[i] + ((i & 1) ? e1 : e0)) >> 16) != 0;
+      if (bad)
+        atomicCAS(&a.results[lo].status, 0u, uint32_t(RSX_ERR_VALUE_RANGE));
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       int32_t p = v[i] + ((i & 1) ? e1 : e0);
-      p = p < 0 ? 0 : (p > 32767 ? 32767 : p); // clampBits(pred, 15)
+      if (K.pentax)
+        p &= 0xFFFF;
+      else
+        p = p < 0 ? 0 : (p > 32767 ? 32767 : p); // clampBits(pred, 15)
       if (dither) {
         const uint32_t t = tab[p];
         px[i] = ((t & 0xFFFFu) + (((t >> 16) * (st & 2047u) + 1024u) >> 12)) & 0xFFFFu;
@@ -2362,6 +2376,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       std::memcpy(K.p_up, N.p_up, sizeof K.p_up);
       K.pup_in = N.pup_in;
       K.uncorrected = N.uncorrected ? 1u : 0u;
+      K.pentax = N.pentax ? 1u : 0u;
       K.seed_offset = N.seed_offset;
       K.table_off = uint32_t(nk_tables.size());
       if (!N.uncorrected)

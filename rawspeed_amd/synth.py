@@ -187,6 +187,11 @@ NIKON_TREE = [
 ]
 
 
+# PentaxDecompressor::pentax_tree (decompressors/PentaxDecompressor.cpp:46-53)
+PENTAX_TREE = ([0, 2, 3, 1, 1, 1, 1, 1, 1, 2, 0, 0, 0, 0, 0, 0],
+               [3, 4, 2, 5, 1, 6, 0, 7, 8, 9, 10, 11, 12])
+
+
 def nikon_encode(img, p_up, table):
     """img: (h, w) uint16 of 15-bit values -> NikonDecompressor MSB stream
     (np.uint8) that decodes to it with uncorrectedRawValues; p_up = the four

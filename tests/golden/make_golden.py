@@ -20,7 +20,8 @@ from oracle_lib import Ref  # noqa: E402
 
 def main():
     ref = Ref()
-    out = {"unpack": {}, "f32": {}, "variant": {}, "ljpeg": {}, "cr2": {}, "nikon": {}}
+    out = {"unpack": {}, "f32": {}, "variant": {}, "ljpeg": {}, "cr2": {}, "nikon": {},
+           "pentax": {}}
     for i, c in enumerate(G.UNPACK_CASES):
         d, data, (w, h, cpp) = G.build_unpack(c)
         img = ref.image(w, h, cpp)
@@ -53,6 +54,11 @@ def main():
         img = ref.image(w, h, cpp)
         st = ref.nikon(meta, c["bits"], data, img, bool(c["unc"]))
         out["nikon"][c["name"]] = {"status": st, "hash": G.image_hash(img.pixels())}
+    for c in G.PENTAX_CASES:
+        meta, d, data, (w, h, cpp), _ = G.build_pentax(c)
+        img = ref.image(w, h, cpp)
+        st = ref.pentax(meta, data, img)
+        out["pentax"][c["name"]] = {"status": st, "hash": G.image_hash(img.pixels())}
     path = os.path.join(HERE, "golden_hashes.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

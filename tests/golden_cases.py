@@ -221,3 +221,32 @@ def build_nikon(c, seed=2024):
                                synth.NIKON_TREE[hs + 1] if n1 else None)
     d = N.desc(P, bits, bool(c["unc"]))
     return meta, d, data, (w, h, 1), src
+
+
+# ---- PentaxDecompressor ----------------------------------------------------------
+# tree: "legacy" = pentax_tree (always handed over as a makernote blob: the
+# reference's legacy branch is not reachable in our -O3 build of it, its
+# Optional::has_value() is declared readnone), "modern" = a 15-symbol tree.
+PENTAX_CASES = [
+    dict(name="legacy_small", tree="legacy", w=64, h=20, maxv=4095),
+    dict(name="modern_small", tree="modern", w=48, h=17, maxv=16383),
+    dict(name="legacy_medium", tree="legacy", w=1200, h=300, maxv=4095),
+    dict(name="modern_wide", tree="modern", w=8384, h=12, maxv=16383),
+    dict(name="range_error", tree="legacy", w=64, h=20, maxv=4095, symbols=True),
+]
+
+
+def build_pentax(c, seed=515):
+    import nikon_cases as N
+    rng = np.random.default_rng([seed, sum(map(ord, c["name"]))])
+    tree = synth.PENTAX_TREE if c["tree"] == "legacy" else N.PENTAX_MODERN
+    meta = N.pentax_metadata(tree)
+    w, h = c["w"], c["h"]
+    src = None
+    if c.get("symbols"):
+        data = N.symbol_stream(rng, w * h, tree)  # a random walk: leaves [0, 65535] quickly
+    else:
+        src = N.smooth15(rng, h, w, maxv=c["maxv"], sigma=6.0)
+        data, _ = N.pentax_encode(src, tree)
+        data = np.concatenate([data, np.zeros(8, np.uint8)])
+    return meta, N.pentax_desc(tree), data, (w, h, 1), src

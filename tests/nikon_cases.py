@@ -136,3 +136,40 @@ def smooth15(rng, h, w, maxv=16383, sigma=12.0):
     img = (0.25 * maxv + 0.3 * maxv * x / w + 0.2 * maxv * y / h +
            0.05 * maxv * ((x & 1) + 2 * (y & 1)) + rng.normal(0, sigma, size=(h, w)))
     return np.clip(img, 0, maxv).astype(np.uint16)
+
+
+# ---- PentaxDecompressor ---------------------------------------------------------
+
+def pentax_metadata(tree):
+    """The makernote blob SetupPrefixCodeDecoder_Modern (PentaxDecompressor.cpp:
+    85-137) turns back into `tree`: depth - 12 (u16), 12 skipped bytes, per
+    difference length its code left-aligned in 12 bits (u16), then its length."""
+    sym = _canonical(tree)
+    depth = len(sym)
+    assert 12 <= depth <= 15 and sorted(v for _, _, v in sym) == list(range(depth))
+    v0, v1 = [0] * depth, [0] * depth
+    for code, l, v in sym:
+        assert l <= 12
+        v0[v], v1[v] = code << (12 - l), l
+    b = bytearray((depth - 12).to_bytes(2, "big")) + bytes(12)
+    for x in v0:
+        b += x.to_bytes(2, "big")
+    b += bytes(v1)
+    return np.frombuffer(bytes(b), np.uint8).copy()
+
+
+def pentax_desc(tree):
+    d = abi.PentaxDesc()
+    d.table = abi.HuffTable.make(*tree)
+    return d
+
+
+# a "modern" tree: 15 difference lengths, none longer than 12 bits
+PENTAX_MODERN = ([0, 1, 3, 3, 2, 2, 1, 1, 1, 0, 1, 0, 0, 0, 0, 0],
+                 [4, 3, 5, 2, 6, 1, 7, 0, 8, 9, 10, 11, 12, 13, 14])
+
+
+def pentax_encode(img, tree):
+    """NikonDecompressor's predictor with all four pUp = 0 is PentaxDecompressor's
+    (rows 0 and 1 start from 0, later rows from the pixels two rows up)."""
+    return synth.nikon_encode(img, [0, 0, 0, 0], tree)

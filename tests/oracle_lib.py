@@ -98,6 +98,9 @@ class Oracle:
         L.oracle_unpack_f32_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_unpack_variant_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_nikon_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_pentax_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_pentax_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
+                                               C.c_void_p]
         L.oracle_nikon_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                               C.c_void_p]
         L.oracle_ljpeg_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
@@ -144,6 +147,15 @@ class Oracle:
         a, p, n = _as_u8(data)
         v = img.view()
         return self.lib.oracle_nikon_decompress(C.byref(desc), p, n, C.byref(v))
+
+    def pentax(self, desc, data, img):
+        a, p, n = _as_u8(data)
+        v = img.view()
+        return self.lib.oracle_pentax_decompress(C.byref(desc), p, n, C.byref(v))
+
+    def pentax_validate(self, desc, img):
+        v = img.view()
+        return self.lib.oracle_pentax_validate(C.byref(desc), C.byref(v))
 
     def nikon_validate(self, desc, img):
         v = img.view()
@@ -259,6 +271,8 @@ class Ref:
                                              C.c_size_t]
         L.ref_decode8bit_lookup.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                             C.c_int, C.c_void_p, C.c_size_t]
+        L.ref_pentax_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_size_t]
         L.ref_nikon_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
                                            C.c_void_p, C.c_size_t, C.c_int]
         L.ref_ljpeg_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
@@ -297,6 +311,13 @@ class Ref:
         c = np.ascontiguousarray(curve, dtype=np.uint16)
         a, p, n = _as_u8(data)
         return self.lib.ref_decode8bit_lookup(img.h, c.ctypes.data, c.size, w, h, p, n)
+
+    def pentax(self, meta, data, img):
+        a, p, n = _as_u8(data)
+        if meta is None:
+            return self.lib.ref_pentax_decompress(img.h, None, 0, p, n)
+        m, mp, mn = _as_u8(meta)
+        return self.lib.ref_pentax_decompress(img.h, mp, mn, p, n)
 
     def nikon(self, meta, bits_ps, data, img, uncorrected):
         m, mp, mn = _as_u8(meta)

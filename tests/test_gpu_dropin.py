@@ -227,3 +227,17 @@ def test_uncompressed_f32_image(pair):
         (s0, a, e0), (s1, b, e1) = out
         assert s0 == 0 and s1 == 0, (e0, e1)
         assert np.array_equal(a, b)
+
+
+def test_pentax_decompressor(pair):
+    """PentaxDecompressor: the constructor rebuilds the Huffman table from the
+    makernote blob, the patched decompress() forwards it to librsx."""
+    import golden_cases as G
+    for name in ("legacy_medium", "modern_wide", "range_error"):
+        c = next(c for c in G.PENTAX_CASES if c["name"] == name)
+        meta, d, data, (w, h, cpp), _ = G.build_pentax(c)
+        (s0, a, e0), (s1, b, e1) = both(
+            pair, lambda lib, img: lib.pentax(meta, data, img), (w, h, cpp))
+        assert s0 == s1, (e0, e1)
+        if s0 == 0:
+            assert np.array_equal(a, b)

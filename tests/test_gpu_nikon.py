@@ -151,3 +151,38 @@ def test_nikon_plan_batch(gpu, oracle):
         for j, want in zip(jobs, wants):
             assert np.array_equal(got[j.img_offset:j.img_offset + want.buf.size], want.buf)
     plan.close()
+
+
+# ---- PentaxDecompressor ----------------------------------------------------------
+
+@pytest.mark.parametrize("c", G.PENTAX_CASES, ids=lambda c: c["name"])
+def test_pentax_golden(gpu, oracle, c):
+    meta, d, data, (w, h, cpp), src = G.build_pentax(c)
+    img, want = HostImage(w, h, cpp), HostImage(w, h, cpp)
+    st = gpu.pentax_decompress(d, data, img.view())
+    assert st == oracle.pentax(d, data, want)
+    if st == 0:
+        assert np.array_equal(img.u16(), want.u16())
+        assert G.image_hash(img.pixels()) == GOLD["pentax"][c["name"]]["hash"]
+        assert np.array_equal(img.pixels(), src)
+    else:
+        assert st == abi.RSX_ERR_VALUE_RANGE
+
+
+def test_pentax_sizes_and_truncation(gpu, oracle):
+    rng = np.random.default_rng(54)
+    for tree, w, h in ((synth.PENTAX_TREE, 4000, 333), (N.PENTAX_MODERN, 6000, 120)):
+        src = N.smooth15(rng, h, w, maxv=16383 if tree is N.PENTAX_MODERN else 4095, sigma=6.0)
+        data, _ = N.pentax_encode(src, tree)
+        d = N.pentax_desc(tree)
+        full = np.concatenate([data, np.zeros(8, np.uint8)])
+        img, want = HostImage(w, h), HostImage(w, h)
+        assert gpu.pentax_decompress(d, full, img.view()) == oracle.pentax(d, full, want) == 0
+        assert np.array_equal(img.u16(), want.u16()) and np.array_equal(img.pixels(), src)
+        for cut in (1, 5, 9, 13, 40, len(data) // 2):
+            part = data[:len(data) - cut]
+            img, want = HostImage(w, h), HostImage(w, h)
+            so = oracle.pentax(d, part, want)
+            assert gpu.pentax_decompress(d, part, img.view()) == so, cut
+            if so == 0:
+                assert np.array_equal(img.u16(), want.u16())

@@ -80,7 +80,38 @@ def test_nikon_golden(oracle, c):
         assert np.array_equal(img.pixels(), src)   # round trip
 
 
+@pytest.mark.parametrize("c", G.PENTAX_CASES, ids=lambda c: c["name"])
+def test_pentax_golden(oracle, c):
+    meta, d, data, (w, h, cpp), src = G.build_pentax(c)
+    img = HostImage(w, h, cpp)
+    st = oracle.pentax(d, data, img)
+    g = GOLD["pentax"][c["name"]]
+    # the reference's "decoded value out of bounds" is a RawDecoderException
+    # (status 1 in the shim); the C-ABI has a code of its own for it
+    assert (st, g["status"]) in ((0, 0), (10, 1))
+    if st == 0:
+        assert G.image_hash(img.pixels()) == g["hash"]
+        assert np.array_equal(img.pixels(), src)
+    else:
+        assert st == 10  # RSX_ERR_VALUE_RANGE <-> "decoded value out of bounds"
+
+
 # ---- live cross-checks against the compiled reference ----------------------
+
+@pytest.mark.parametrize("c", G.PENTAX_CASES, ids=lambda c: c["name"])
+def test_pentax_vs_ref(oracle, ref, c):
+    """Also pins nikon_cases.pentax_metadata: the reference rebuilds the same
+    Huffman table from the blob (SetupPrefixCodeDecoder_Modern)."""
+    meta, d, data, (w, h, cpp), _ = G.build_pentax(c)
+    hi, ri = HostImage(w, h, cpp), ref.image(w, h, cpp)
+    so, sr = oracle.pentax(d, data, hi), ref.pentax(meta, data, ri)
+    # the reference reports the range error as a RawDecoderException (status 1)
+    assert (so, sr) in ((0, 0), (10, 1)), (so, sr, ref.last_error())
+    if so == 0:
+        assert np.array_equal(hi.u16(), ri.u16())
+    else:
+        assert "out of bounds" in ref.last_error()
+
 
 @pytest.mark.parametrize("c", G.NIKON_CASES, ids=lambda c: c["name"])
 def test_nikon_vs_ref(oracle, ref, c):
