@@ -19,7 +19,7 @@ LIB_CORE = os.path.join(PKG, "librsx.so")
 LIB_SYNTH = os.path.join(PKG, "librsx_synth.so")
 
 CORE_SOURCES = ["rsx_api.hip", "rsx_unpack.hip", "rsx_ljpeg.hip", "rsx_host.cpp"]
-CORE_HEADERS = ["rsx_internal.h", "rsx_device.h"]
+CORE_HEADERS = ["rsx_internal.h", "rsx_device.h", "rsx_ljpeg.h"]
 
 
 def _hipcc():
@@ -62,6 +62,19 @@ def build_core(force=False, extra_flags=()):
                "-I" + CSRC, *extra_flags, "-o", LIB_CORE, *srcs]
         _run(cmd)
     return LIB_CORE
+
+
+def build_variant(name, extra_flags):
+    """A/B builds: rawspeed_amd/variants/librsx_<name>.so (git-ignored; load with
+    RSX_LIB=<path>)."""
+    d = os.path.join(PKG, "variants")
+    os.makedirs(d, exist_ok=True)
+    out = os.path.join(d, "librsx_%s.so" % name)
+    srcs = [os.path.join(CSRC, s) for s in CORE_SOURCES]
+    _run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+          "-Wall", "-Wno-unused-function", "-I" + INCLUDE, "-I" + CSRC, *extra_flags,
+          "-o", out, *srcs])
+    return out
 
 
 def build_all(force=False):

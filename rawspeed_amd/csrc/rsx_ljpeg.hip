@@ -71,6 +71,20 @@ constexpr int LJ_IMG_U4 = (LJ_BW + 1) * LJ_T / 4; // per-workgroup un-stuffed im
 #endif
 constexpr uint32_t LJ_WARM = RSX_LJ_WARM;     // warm-up bits decoded ahead of a slot for its start guess
 
+// Bit reader of the decode loops.  1: every symbol fetches its 32-bit window from
+// the slot's two LDS dwords (17 VALU instructions per symbol instead of 27, but
+// two dependent LDS round trips); 0: a 64-bit register buffer with the next dword
+// prefetched (LDS off the critical path).  Measured (PMC + A/B):
+// the synchronisation passes are VALU-issue bound and gain 4 % from the window
+// form; K4, whose time goes mostly to its scattered 16-byte stores and its
+// staging prologue, is 8 % faster with the register buffer.
+#ifndef RSX_LJ_WINDOW
+#define RSX_LJ_WINDOW 1
+#endif
+#ifndef RSX_LJ_K4_WINDOW
+#define RSX_LJ_K4_WINDOW 0
+#endif
+
 constexpr uint32_t ST_OFF_MASK = 63u;
 constexpr uint32_t ST_PHASE_SHIFT = 6;
 constexpr uint32_t ST_ERR = 1u << 9;
@@ -575,6 +589,25 @@ __device__ __forceinline__ uint32_t lj_head(const Lds& L, const DecodeParams& dp
   return lj_entry(uint32_t(r.buf >> 32), tb, live);
 }
 
+// The 32 stream bits at bit position `pos` of slot `col`.
+__device__ __forceinline__ uint32_t lj_window(const uint32_t* B, int col, uint32_t pos) {
+  const uint32_t wi = pos >> 5;
+  const uint32_t d0 = B[wi * LJ_T + col], d1 = B[(wi + 1) * LJ_T + col];
+  return uint32_t((((uint64_t(d0) << 32) | d1) << (pos & 31u)) >> 32);
+}
+
+// Entry of the symbol that starts at `pos` (0 = invalid code); *w_out = its window.
+template <bool MULTI>
+__device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp, int col,
+                                            uint32_t pos, uint32_t phase, bool live,
+                                            uint32_t* w_out = nullptr) {
+  const uint32_t w = lj_window(L.B, col, pos);
+  if (w_out)
+    *w_out = w;
+  const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
+  return lj_entry(w, tb, live);
+}
+
 // Decode the symbols that START inside slot `col` (bit positions [.., end_bits)),
 // beginning at state `start`.  With RECORD, *bm receives the bitmap of symbol
 // starts at bit positions < 64 (the slot's "trajectory", used for early-out
@@ -597,17 +630,25 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
   bool ok = !(start & ST_ERR);
   if (!ok || !enabled)
     end_bits = 0; // lane takes no steps
+#if !RSX_LJ_WINDOW
   BitReader r = br_open(L.B, col, pos);
+#endif
   uint64_t m = 0;
   if (RECORD) {
     uint32_t lim = end_bits < 64u ? end_bits : 64u;
     while (__any(pos < lim)) {
       const bool live = pos < lim;
+#if RSX_LJ_WINDOW
+      const uint32_t e = lj_step<MULTI>(L, dp, col, pos, phase, live);
+#else
       const uint32_t e = lj_head<MULTI>(L, dp, r, phase, live);
+#endif
       const bool bad = live && e == 0u;
       const uint32_t adv = (live && !bad) ? (e >> 10) : 0u;
       m |= live ? (1ull << (pos & 63u)) : 0ull;
+#if !RSX_LJ_WINDOW
       br_advance(r, L.B, col, adv);
+#endif
       pos += adv;
       n += (live && !bad) ? 1u : 0u;
       if (MULTI)
@@ -622,10 +663,16 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
   }
   while (__any(pos < end_bits)) {
     const bool live = pos < end_bits;
+#if RSX_LJ_WINDOW
+    const uint32_t e = lj_step<MULTI>(L, dp, col, pos, phase, live);
+#else
     const uint32_t e = lj_head<MULTI>(L, dp, r, phase, live);
+#endif
     const bool bad = live && e == 0u;
     const uint32_t adv = (live && !bad) ? (e >> 10) : 0u;
+#if !RSX_LJ_WINDOW
     br_advance(r, L.B, col, adv);
+#endif
     pos += adv;
     n += (live && !bad) ? 1u : 0u;
     if (MULTI)
@@ -658,7 +705,9 @@ __device__ __forceinline__ void lj_redecode_sync(const Lds& L, const DecodeParam
     end_bits = 0;
   const uint32_t real_end = end_bits;
   uint32_t lim = end_bits < 64u ? end_bits : 64u;
+#if !RSX_LJ_WINDOW
   BitReader r = br_open(L.B, col, pos);
+#endif
   while (__any(pos < lim)) {
     bool live = pos < lim;
     if (live && ((old_bm >> (pos & 63u)) & 1ull)) {
@@ -667,11 +716,17 @@ __device__ __forceinline__ void lj_redecode_sync(const Lds& L, const DecodeParam
       end_bits = 0;
       live = false;
     }
+#if RSX_LJ_WINDOW
+    const uint32_t e = lj_step<false>(L, dp, col, pos, 0u, live);
+#else
     const uint32_t e = lj_head<false>(L, dp, r, 0u, live);
+#endif
     const bool bad = live && e == 0u;
     const uint32_t adv = (live && !bad) ? (e >> 10) : 0u;
     m |= live ? (1ull << (pos & 63u)) : 0ull;
+#if !RSX_LJ_WINDOW
     br_advance(r, L.B, col, adv);
+#endif
     pos += adv;
     n += (live && !bad) ? 1u : 0u;
     if (bad) {
@@ -682,10 +737,16 @@ __device__ __forceinline__ void lj_redecode_sync(const Lds& L, const DecodeParam
   }
   while (__any(pos < end_bits)) {
     const bool live = pos < end_bits;
+#if RSX_LJ_WINDOW
+    const uint32_t e = lj_step<false>(L, dp, col, pos, 0u, live);
+#else
     const uint32_t e = lj_head<false>(L, dp, r, 0u, live);
+#endif
     const bool bad = live && e == 0u;
     const uint32_t adv = (live && !bad) ? (e >> 10) : 0u;
+#if !RSX_LJ_WINDOW
     br_advance(r, L.B, col, adv);
+#endif
     pos += adv;
     n += (live && !bad) ? 1u : 0u;
     if (bad) {
@@ -1148,16 +1209,26 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   const uint32_t n_groups = (a.ablate & 2u) ? 0u : (wmax + 7) >> 3;
 
   uint32_t phase = (my_start >> ST_PHASE_SHIFT) & 7u;
+#if RSX_LJ_K4_WINDOW
+  uint32_t pos = my_start & ST_OFF_MASK;
+#else
   BitReader r = br_open(L.B, j, my_start & ST_OFF_MASK);
+#endif
   uint32_t tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0; // the lane's last, partial group
   for (uint32_t g = 0; g < n_groups; ++g) {
     uint32_t p[4];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const bool live = 8 * g + q < remaining;
+#if RSX_LJ_K4_WINDOW
+      uint32_t w;
+      const uint32_t e = lj_step<MULTI>(L, dp, j, pos, phase, live, &w);
+      pos += live ? (e >> 10) : 0u;
+#else
       const uint32_t w = uint32_t(r.buf >> 32);
       const uint32_t e = lj_head<MULTI>(L, dp, r, phase, live);
       br_advance(r, L.B, j, live ? (e >> 10) : 0u);
+#endif
       if (MULTI)
         phase = live ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
       const uint32_t cl = e & 31u, ssss = (e >> 5) & 31u;
@@ -1171,11 +1242,19 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
         diff = uint32_t(d);
       } else {
         // v = the SSSS bits after the code; diff per JPEG F.2.2.1 "EXTEND"
+#if RSX_LJ_K4_WINDOW
+        // (SSSS = 0: v = 0 and the shift count wraps to 31, so diff = 0 + 1 - 1)
+        const uint32_t v = __builtin_amdgcn_ubfe(w, 32u - (e >> 10), ssss);
+        diff = (v >> ((ssss - 1u) & 31u)) ? v : v + 1u - (1u << ssss);
+        (void)cl;
+      }
+#else
         const uint32_t v = uint32_t((uint64_t(w << cl) << ssss) >> 32);
         const uint32_t half = (1u << ssss) >> 1;
         diff = v >= half ? v : v + 1u - (1u << ssss);
       }
       diff = ssss == 0u ? 0u : diff;
+#endif
       diff = ssss == 16u ? 0x8000u : diff;
       diff &= 0xFFFFu;
       if (q & 1)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# PMC passes over the cfg-3 LJPEG leg (run on the GPU box): instruction mix,
+# wait / active cycles, LDS conflicts for K0/K1/K4/K6.
+set -u
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/pmc_lj
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
+           "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_LDS"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --output-format csv -d /tmp/pl_$i -- \
+    python $REPO/bench_ljpeg.py --only cfg3 --frames 8 --steps 2 > /dev/null 2>&1
+  cp $(find /tmp/pl_$i -name "*counter_collection.csv" | head -1) $OUT/set$i.csv
+done
+python $REPO/scripts/pmc_summary.py $OUT/set1.csv lj_ | head -60
