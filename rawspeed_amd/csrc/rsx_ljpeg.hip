@@ -1,9 +1,14 @@
-// rsx_ljpeg.hip -- lossless-JPEG (predictor 1) decode pipeline for gfx950.
+// rsx_ljpeg.hip -- lossless-JPEG family decode pipeline for gfx950: the entropy
+// kernels and the host-side plan.  (Reconstruction -- K5/K6 and the Nikon /
+// Pentax kernels -- lives in rsx_ljpeg_recon.hip; shared structures in
+// rsx_ljpeg_dev.h.)
 //
 // Replaces the serial loops of
 //   LJpegDecompressor::decodeN / decodeRowN  (decompressors/LJpegDecompressor.cpp:184-339)
 //   Cr2Decompressor::decompressN_X_Y         (decompressors/Cr2DecompressorImpl.h:396-468)
-// which walk ONE BitStreamerJPEG over the whole scan (no per-row index).
+//   NikonDecompressor::decompress            (decompressors/NikonDecompressor.cpp:515-560)
+//   PentaxDecompressor::decompress           (decompressors/PentaxDecompressor.cpp:152-176)
+// which walk ONE bit streamer over the whole scan (no per-row index).
 //
 // Pipeline (one "stream" = one scan or one restart interval; many streams per
 // launch: DNG tiles, batched frames).  The physical byte stream is cut into
@@ -30,6 +35,10 @@
 //                  register bit reader with prefetched refill, 8 differences per
 //                  unaligned 16-byte store into a stream-ordered int16 scratch.
 //  K4b lj_tail     exact end-of-stream semantics for damaged streams.
+//  --  lj_transfer / lj_chain   fallback for streams that do not self-synchronise
+//                  (periodic data): per-workgroup transfer functions over all
+//                  entry states, chained by one lane per stream.
+//  (rsx_ljpeg_recon.hip:)
 //  K5 lj_vseed     vertical chain: predictor seed of every stream row (the row's
 //                  first MCU predicts from the first MCU of the previous row,
 //                  LJpegDecompressor.cpp:326-332, Cr2DecompressorImpl.h:437-451).
@@ -41,6 +50,7 @@
 // Symbol semantics: codes/AbstractPrefixCodeDecoder.h:43-76; end-of-stream:
 // bitstreams/BitStreamerJPEG.h:106-183.  No MFMA (no contraction anywhere).
 #include "rsx_ljpeg.h"
+#include "rsx_ljpeg_dev.h"
 
 #include <algorithm>
 #include <cstddef>
@@ -52,165 +62,6 @@
 namespace rsx {
 
 namespace {
-
-// ---------------------------------------------------------------------------
-// Geometry constants
-// ---------------------------------------------------------------------------
-constexpr int LJ_T = 256;             // lanes per workgroup = slots per workgroup
-#ifndef RSX_LJ_P
-#define RSX_LJ_P 64
-#endif
-constexpr int LJ_P = RSX_LJ_P;        // physical bytes per subsequence
-constexpr int LJ_PW = LJ_P / 4;       // dwords per subsequence
-constexpr int LJ_OWN = LJ_T - 1;      // owned slots (slot 0 = warm-up)
-constexpr int LJ_R = LJ_OWN * LJ_P;   // bytes of stream owned by one workgroup
-constexpr int LJ_BW = LJ_PW + 4;      // compacted slot capacity (dwords)
-constexpr int LJ_IMG_U4 = (LJ_BW + 1) * LJ_T / 4; // per-workgroup un-stuffed image: B + ob[], in uint4
-#ifndef RSX_LJ_WARM
-#define RSX_LJ_WARM 512
-#endif
-constexpr uint32_t LJ_WARM = RSX_LJ_WARM;     // warm-up bits decoded ahead of a slot for its start guess
-
-// Bit reader of the decode loops.  1: every symbol fetches its 32-bit window from
-// the slot's two LDS dwords (17 VALU instructions per symbol instead of 27, but
-// two dependent LDS round trips); 0: a 64-bit register buffer with the next dword
-// prefetched (LDS off the critical path).  Measured (PMC + A/B):
-// the synchronisation passes are VALU-issue bound and gain 4 % from the window
-// form; K4, whose time goes mostly to its scattered 16-byte stores and its
-// staging prologue, is 8 % faster with the register buffer.
-#ifndef RSX_LJ_WINDOW
-#define RSX_LJ_WINDOW 1
-#endif
-#ifndef RSX_LJ_K4_WINDOW
-#define RSX_LJ_K4_WINDOW 0
-#endif
-
-constexpr uint32_t ST_OFF_MASK = 63u;
-constexpr uint32_t ST_PHASE_SHIFT = 6;
-constexpr uint32_t ST_ERR = 1u << 9;
-constexpr uint32_t ST_MASK = 0xFFFFu;
-
-constexpr uint32_t NO_CODE = 0xFFFFFFFFu;
-
-// flags in LjResult::flags
-constexpr uint32_t FL_UNCONVERGED = 1u;
-
-struct TabLds {
-  uint16_t lut[LUT_SIZE];
-  uint32_t max_code[18];
-  uint16_t val_offset[18];
-  uint8_t values[RSX_MAX_CODE_VALUES];
-  uint8_t max_len;
-  uint8_t fix16;
-  uint8_t zero_sym_bits;
-  uint8_t las;
-  uint8_t pad[12];
-};
-static_assert(sizeof(TabLds) == sizeof(DeviceHuffTable) + 12 ||
-                  sizeof(TabLds) % 16 == 0,
-              "TabLds layout");
-static_assert(sizeof(TabLds) % 16 == 0, "TabLds must be 16-byte sized");
-static_assert(offsetof(TabLds, max_code) == offsetof(DeviceHuffTable, max_code), "");
-static_assert(offsetof(TabLds, values) == offsetof(DeviceHuffTable, values), "");
-
-struct Cr2Strip {
-  uint32_t x0, w, y0, h;
-  uint64_t first_sample;
-};
-
-struct LjStreamDev {
-  uint64_t in_offset;
-  uint64_t in_bytes;
-  uint64_t diff_offset; // int16 index into the difference scratch (multiple of 8)
-  uint64_t needed;      // symbols the reference decodes for this stream
-  uint64_t img_offset;
-  uint32_t img_pitch;
-  uint32_t first_block;
-  uint32_t n_blocks;
-  uint32_t first_subseq;
-  uint32_t table_base;
-  uint32_t n_tables;
-  uint32_t period;
-  uint32_t n_comp;
-  uint8_t tab_of_phase[8];
-  uint16_t init_pred[4];
-  uint8_t seed_pos[4]; // first sample of component c inside a stream row
-  uint8_t raw;         // 1: plain MSB bit stream (BitStreamerMSB): no FF00 un-stuffing,
-                       //    no markers, position budget of 8 bytes instead of 16
-  uint8_t start_bit;   // first symbol starts this many bits into the stream (0..7)
-  uint8_t las;         // table values are Nikon "lossy after split" (len | shl << 4)
-  uint8_t pad8;
-  uint32_t rows;
-  uint32_t row_samples;
-  uint32_t first_row; // global stream-row index
-  uint32_t kind;      // 0 LJPEG, 1 CR2
-  uint32_t mcu_w, mcu_h, out_x, out_y, keep_samples;
-  uint32_t scan_samples; // samples of a row that take part in reconstruction
-  uint32_t n_strips;
-  uint32_t strip_base;
-  uint32_t job;
-  uint64_t raw_limit;  // raw streams: 1 + last bit offset a symbol may start at (0 = derive)
-};
-
-// Per-stream parameters of NikonDecompressor streams (kind 2), indexed like streams[].
-struct NkStreamDev {
-  int32_t p_up[4];       // pUp[row & 1][col & 1] at [2 * (row & 1) + (col & 1)]
-  const int32_t* pup_in; // non-null: read the initial pUp from here instead (rows after the split)
-  uint32_t uncorrected;  // 1: store clampBits(pred, 15) as is
-  uint32_t table_off;    // first entry of this stream's dither table in nk_tables
-  uint32_t rowpow_off;   // first entry of this stream's row powers in nk_rowpow
-  uint32_t pentax;       // 1: PentaxDecompressor (.cpp:152-176): no clamp, values outside
-                         //    [0, 65535] are RSX_ERR_VALUE_RANGE
-  uint64_t seed_offset;  // byte offset (from in_base) of the job's first input byte
-};
-
-struct LjResult {
-  uint32_t marker_pos; // first FFxx (xx != 0) in the stream, 0xFFFFFFFF = none
-  uint32_t status;
-  uint32_t flags;
-  uint32_t avail_lo;   // symbols that start before the end of data
-  uint32_t last_slot;  // stream-relative subsequence of the last needed symbol
-  uint32_t last_pos;   // its bit offset inside the compacted subsequence
-  uint32_t consumed;
-  uint32_t tail_used;  // 1: the tail kernel delivered the last symbols
-  uint32_t last_c_lo;  // un-stuffed bit offset of the last symbol (tail path)
-  uint32_t last_c_hi;
-  uint32_t stat_rounds; // statistics: re-decode rounds summed over workgroups
-  uint32_t stat_redo;   // statistics: slots re-decoded
-  uint32_t stat_stitch; // statistics: workgroups re-converged by the stitch kernel
-  uint32_t end_lo;      // raw streams: bit offset just past the last needed symbol
-  uint32_t end_hi;
-  uint32_t pad2;
-};
-
-struct LjArgs {
-  const uint8_t* in_base;
-  uint8_t* out_base;
-  const LjStreamDev* streams;
-  const TabLds* tables;
-  const uint32_t* block_stream;
-  const Cr2Strip* strips;
-  uint32_t* sub_state;
-  uint32_t* block_start;
-  uint32_t* block_exit;
-  uint32_t* block_sum;
-  uint32_t* block_base;
-  uint32_t* block_drops;     // stuffing bytes dropped inside each workgroup's region
-  uint32_t* block_drop_base; // exclusive prefix of block_drops within the stream
-  uint4* unstuffed;          // per workgroup: its LDS image of un-stuffed slots (LJ_BW*LJ_T dwords)
-  LjResult* results;
-  int16_t* diffs;
-  uint16_t* vseed;
-  uint32_t n_streams;
-  uint32_t total_rows;
-  uint32_t ablate; // profiling aid (RSX_ABLATE): 1 = no K4 stores, 2 = no K4 decode loop, 4 = no K1 decode
-  // NikonDecompressor streams
-  const NkStreamDev* nk;
-  const uint32_t* nk_tables; // dither tables: base | delta << 16 per 15-bit value
-  const uint32_t* nk_rowpow; // 15700^(y * W) mod (15700 * 2^16 - 1) per output row
-  int32_t* nk_pup;           // [stream][4]: pUp after the stream's last row
-  uint16_t* transfer;        // [workgroup][512]: exit state per entry state (fallback path)
-};
 
 // ---------------------------------------------------------------------------
 // Device helpers
@@ -1454,640 +1305,6 @@ __global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// K5: predictor seeds of the stream rows
-//   seed(r, c) = init_pred[c] + sum_{r' < r} D[r'][seed_pos[c]]   (mod 2^16)
-// seed_pos[c] = c for interleaved components; (0, gs-2, gs-1) for Canon sRaw
-// groups (Cr2DecompressorImpl.h:443-444).
-// ---------------------------------------------------------------------------
-// 1024 lanes per stream, one row per lane per step (the per-row reads are 8-byte
-// gathers at a pitch of a whole stream row, so they are issued for many rows at
-// once); block-wide exclusive scan per step with shuffles, carry across steps.
-constexpr int VS_T = 1024;
-__global__ __launch_bounds__(VS_T) void lj_vseed_kernel(LjArgs a) {
-  __shared__ uint32_t wtot[VS_T / 64][4];
-  __shared__ uint32_t carry_s[4];
-  const uint32_t s = blockIdx.x;
-  const LjStreamDev& S = a.streams[s];
-  if (a.results[s].status != 0 || S.kind == 2)
-    return;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint32_t rows = S.rows, N = S.n_comp;
-  const int16_t* __restrict__ D = a.diffs + S.diff_offset;
-  uint16_t* __restrict__ V = a.vseed + uint64_t(S.first_row) * 4;
-  if (tid < 4)
-    carry_s[tid] = tid < int(N) ? S.init_pred[tid] : 0u;
-  __syncthreads();
-  for (uint32_t r0 = 0; r0 < rows; r0 += VS_T) {
-    const uint32_t r = r0 + tid;
-    uint32_t d[4] = {0, 0, 0, 0};
-    if (r < rows)
-      for (uint32_t c = 0; c < N; ++c)
-        d[c] = uint32_t(int32_t(D[uint64_t(r) * S.row_samples + S.seed_pos[c]]));
-    uint32_t inc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      uint32_t x = d[c];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(x, o, 64);
-        if (lane >= o)
-          x += y;
-      }
-      inc[c] = x;
-      if (lane == 63)
-        wtot[wv][c] = x;
-    }
-    __syncthreads();
-    uint32_t base[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      uint32_t o = carry_s[c];
-      for (int w = 0; w < wv; ++w)
-        o += wtot[w][c];
-      base[c] = o;
-    }
-    if (r < rows)
-      for (uint32_t c = 0; c < N; ++c)
-        V[uint64_t(r) * 4 + c] = uint16_t(base[c] + inc[c] - d[c]); // exclusive
-    __syncthreads();
-    if (tid == VS_T - 1)
-      for (int c = 0; c < 4; ++c)
-        carry_s[c] = base[c] + inc[c];
-    __syncthreads();
-  }
-}
-
-// ---------------------------------------------------------------------------
-// K6: row reconstruction + output mapping, one wavefront per stream row
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void lj_store_sample(const LjArgs& a, const LjStreamDev& S,
-                                                uint32_t r, uint32_t sidx,
-                                                uint16_t val) {
-  uint8_t* img = a.out_base + S.img_offset;
-  if (S.kind == 0) {
-    const uint32_t m = sidx / S.n_comp, c = sidx - m * S.n_comp;
-    const uint32_t col = S.mcu_w * m + (c % S.mcu_w);
-    if (col >= S.keep_samples)
-      return;
-    const uint32_t row = S.out_y + S.mcu_h * r + c / S.mcu_w;
-    reinterpret_cast<uint16_t*>(img + uint64_t(row) * S.img_pitch)[S.out_x + col] = val;
-  } else {
-    const uint64_t k = uint64_t(r) * S.row_samples + sidx;
-    const Cr2Strip* st = a.strips + S.strip_base;
-    uint32_t q = 0;
-    while (q + 1 < S.n_strips && k >= st[q + 1].first_sample)
-      ++q;
-    const uint64_t off = k - st[q].first_sample;
-    const uint32_t row = st[q].y0 + uint32_t(off / st[q].w);
-    const uint32_t col = st[q].x0 + uint32_t(off % st[q].w);
-    reinterpret_cast<uint16_t*>(img + uint64_t(row) * S.img_pitch)[col] = val;
-  }
-}
-
-// P == N: sample s belongs to component s % N.  P != N (N == 3): Canon sRaw
-// groups of P samples, P - 2 luma samples (component 0) then Cb, Cr
-// (Cr2DecompressorImpl.h:455-462).
-template <int N, int P = N>
-__global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
-  constexpr bool DYN = (8 % P) != 0; // lane chunks of 8 do not start on a group
-  auto comp_of = [](int ph) -> int {
-    return P == N ? ph : (ph < P - 2 ? 0 : ph - (P - 3));
-  };
-  const uint32_t grow = blockIdx.x * (LJ_T / 64) + (threadIdx.x >> 6);
-  if (grow >= a.total_rows)
-    return;
-  const int lane = threadIdx.x & 63;
-  // row -> stream (first_row is increasing)
-  uint32_t lo = 0, hi = a.n_streams - 1;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi + 1) >> 1;
-    if (a.streams[mid].first_row <= grow)
-      lo = mid;
-    else
-      hi = mid - 1;
-  }
-  const LjStreamDev& S = a.streams[lo];
-  if (int(S.n_comp) != N || int(S.period) != P || S.kind == 2 ||
-      a.results[lo].status != 0)
-    return;
-  const uint32_t r = grow - S.first_row;
-  if (r >= S.rows)
-    return;
-  const uint64_t row0 = uint64_t(r) * S.row_samples;
-  uint32_t n = S.scan_samples;
-  if (row0 + n > S.needed)
-    n = uint32_t(S.needed - row0);
-  const int16_t* __restrict__ D = a.diffs + S.diff_offset + row0;
-  const bool in_aligned = ((S.diff_offset + row0) & 7) == 0;
-  uint32_t carry[N];
-#pragma unroll
-  for (int c = 0; c < N; ++c)
-    carry[c] = a.vseed[(uint64_t(S.first_row) + r) * 4 + c];
-
-  // 8 differences of this lane for the step starting at q0 (packed 2 x u16 per
-  // dword); loads run two steps ahead of the scan so that HBM latency overlaps
-  auto load8 = [&](uint32_t q0) -> uint4 {
-    const uint32_t q = q0 + lane * 8;
-    if (q + 8 <= n && in_aligned)
-      return *reinterpret_cast<const uint4*>(D + q);
-    uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (q + i < n)
-        w[i >> 1] |= uint32_t(uint16_t(D[q + i])) << (16 * (i & 1));
-    return make_uint4(w[0], w[1], w[2], w[3]);
-  };
-  uint4 t0 = load8(0);
-  uint4 t1 = 512 < n ? load8(512) : make_uint4(0, 0, 0, 0);
-  for (uint32_t q0 = 0; q0 < n; q0 += 512) {
-    const uint32_t q = q0 + lane * 8;
-    const uint4 t = t0;
-    t0 = t1;
-    if (q0 + 1024 < n)
-      t1 = load8(q0 + 1024);
-    uint32_t v[8];
-    v[0] = t.x & 0xFFFF; v[1] = t.x >> 16; v[2] = t.y & 0xFFFF; v[3] = t.y >> 16;
-    v[4] = t.z & 0xFFFF; v[5] = t.z >> 16; v[6] = t.w & 0xFFFF; v[7] = t.w >> 16;
-    // component of v[i] is comp_of((q + i) % P); rot = q % P (0 unless DYN)
-    const int rot = DYN ? int(q % P) : 0;
-    uint32_t run[N];
-#pragma unroll
-    for (int c = 0; c < N; ++c)
-      run[c] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (DYN) {
-        // select by component without dynamic register indexing
-        const int c = comp_of((rot + i) % P);
-        uint32_t t = (c == 0 ? run[0] : (c == 1 ? run[1 % N] : run[2 % N])) + v[i];
-        if (c == 0) run[0] = t; else if (c == 1) run[1 % N] = t; else run[2 % N] = t;
-        v[i] = t;
-      } else {
-        const int cs = comp_of(i % P);
-        run[cs] += v[i];
-        v[i] = run[cs];
-      }
-    }
-    // exclusive wave scan of the lane totals, per component
-    uint32_t excl[N], tot[N];
-#pragma unroll
-    for (int c = 0; c < N; ++c) {
-      uint32_t x = run[c];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(x, o, 64);
-        if (lane >= o)
-          x += y;
-      }
-      tot[c] = __shfl(x, 63, 64);
-      excl[c] = x - run[c] + carry[c];
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (DYN) {
-        const int c = comp_of((rot + i) % P);
-        v[i] += (c == 0 ? excl[0] : (c == 1 ? excl[1 % N] : excl[2 % N]));
-      } else {
-        v[i] += excl[comp_of(i % P)];
-      }
-      v[i] &= 0xFFFFu;
-    }
-#pragma unroll
-    for (int c = 0; c < N; ++c)
-      carry[c] += tot[c];
-
-    // ---- output -----------------------------------------------------------
-    if (q >= n)
-      continue;
-    bool done = false;
-    if (q + 8 <= n) {
-      uint8_t* img = a.out_base + S.img_offset;
-      uint16_t* p = nullptr;
-      if (S.kind == 0 && S.mcu_h == 1) {
-        if (q + 8 <= S.keep_samples)
-          p = reinterpret_cast<uint16_t*>(img + uint64_t(S.out_y + r) * S.img_pitch) +
-              S.out_x + q;
-      } else if (S.kind == 1) {
-        const uint64_t k = row0 + q;
-        const Cr2Strip* st = a.strips + S.strip_base;
-        uint32_t z = 0;
-        while (z + 1 < S.n_strips && k >= st[z + 1].first_sample)
-          ++z;
-        const uint64_t off = k - st[z].first_sample;
-        const uint32_t col = uint32_t(off % st[z].w);
-        if (col + 8 <= st[z].w)
-          p = reinterpret_cast<uint16_t*>(
-                  img + uint64_t(st[z].y0 + uint32_t(off / st[z].w)) * S.img_pitch) +
-              st[z].x0 + col;
-      }
-      if (p && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-        uint4 o;
-        o.x = v[0] | (v[1] << 16);
-        o.y = v[2] | (v[3] << 16);
-        o.z = v[4] | (v[5] << 16);
-        o.w = v[6] | (v[7] << 16);
-        *reinterpret_cast<uint4*>(p) = o;
-        done = true;
-      }
-    }
-    if (!done) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (q + i < n)
-          lj_store_sample(a, S, r, q + i, uint16_t(v[i]));
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// K6 fast path (2 or 4 components, the BASELINE shapes).  One wavefront per
-// stream row.  The row is walked in chunks of 2048 samples: coalesced 16-byte
-// loads -> LDS transpose so that every lane owns 32 CONSECUTIVE samples -> the
-// lane scans them with packed 16-bit adds (both components of a pair at once)
-// -> one DPP wave scan of the 64 lane totals (row_shr / row_bcast, no LDS
-// round trips) -> back through LDS to the coalesced layout -> output mapping.
-// ---------------------------------------------------------------------------
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pk_add(uint32_t x, uint32_t y) {
-  const u16x2 r = __builtin_bit_cast(u16x2, x) + __builtin_bit_cast(u16x2, y);
-  return __builtin_bit_cast(uint32_t, r);
-}
-
-// inclusive wave64 scan with packed 16-bit adds (DPP: rows of 16, then row
-// broadcasts -- gfx9 encodings row_shr:n = 0x110+n, row_bcast15 = 0x142,
-// row_bcast31 = 0x143)
-__device__ __forceinline__ uint32_t pk_wave_scan(uint32_t x) {
-  x = pk_add(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x111, 0xF, 0xF, false)));
-  x = pk_add(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x112, 0xF, 0xF, false)));
-  x = pk_add(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x114, 0xF, 0xF, false)));
-  x = pk_add(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x118, 0xF, 0xF, false)));
-  x = pk_add(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x142, 0xA, 0xF, false)));
-  x = pk_add(x, uint32_t(__builtin_amdgcn_update_dpp(0, int(x), 0x143, 0xC, 0xF, false)));
-  return x;
-}
-
-// store the 8 reconstructed samples that start at sample q of stream row r
-__device__ __forceinline__ void lj_store8(const LjArgs& a, const LjStreamDev& S, uint32_t r,
-                                          uint64_t row0, uint32_t q, uint32_t n,
-                                          const uint4& o) {
-  if (q >= n)
-    return;
-  if (q + 8 <= n) {
-    uint8_t* img = a.out_base + S.img_offset;
-    uint16_t* p = nullptr;
-    if (S.kind == 0 && S.mcu_h == 1) {
-      if (q + 8 <= S.keep_samples)
-        p = reinterpret_cast<uint16_t*>(img + uint64_t(S.out_y + r) * S.img_pitch) +
-            S.out_x + q;
-    } else if (S.kind == 1) {
-      const uint64_t k = row0 + q;
-      const Cr2Strip* st = a.strips + S.strip_base;
-      uint32_t z = 0;
-      while (z + 1 < S.n_strips && k >= st[z + 1].first_sample)
-        ++z;
-      const uint64_t off = k - st[z].first_sample;
-      const uint32_t col = uint32_t(off % st[z].w);
-      if (col + 8 <= st[z].w)
-        p = reinterpret_cast<uint16_t*>(
-                img + uint64_t(st[z].y0 + uint32_t(off / st[z].w)) * S.img_pitch) +
-            st[z].x0 + col;
-    }
-    if (p && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-      *reinterpret_cast<uint4*>(p) = o;
-      return;
-    }
-  }
-  const uint32_t w[4] = {o.x, o.y, o.z, o.w};
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    if (q + i < n)
-      lj_store_sample(a, S, r, q + i, uint16_t(w[i >> 1] >> (16 * (i & 1))));
-}
-
-constexpr int PF_STRIDE = 80;   // LDS bytes per lane (64 + 16 pad against bank conflicts)
-constexpr int PF_CHUNK = 2048;  // samples per wave per step
-
-template <int N>
-__global__ __launch_bounds__(LJ_T) void lj_predict_fast_kernel(LjArgs a) {
-  static_assert(N == 2 || N == 4, "fast path handles 2 or 4 components");
-  __shared__ __attribute__((aligned(16))) uint8_t tr_all[LJ_T / 64][64 * PF_STRIDE];
-  const uint32_t grow = blockIdx.x * (LJ_T / 64) + (threadIdx.x >> 6);
-  if (grow >= a.total_rows)
-    return;
-  const int lane = threadIdx.x & 63;
-  uint8_t* tr = tr_all[threadIdx.x >> 6];
-  uint32_t lo = 0, hi = a.n_streams - 1;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi + 1) >> 1;
-    if (a.streams[mid].first_row <= grow)
-      lo = mid;
-    else
-      hi = mid - 1;
-  }
-  const LjStreamDev& S = a.streams[lo];
-  if (int(S.n_comp) != N || int(S.period) != N || S.kind == 2 ||
-      a.results[lo].status != 0)
-    return;
-  const uint32_t r = grow - S.first_row;
-  if (r >= S.rows)
-    return;
-  const uint64_t row0 = uint64_t(r) * S.row_samples;
-  uint32_t n = S.scan_samples;
-  if (row0 + n > S.needed)
-    n = uint32_t(S.needed - row0);
-  const int16_t* __restrict__ D = a.diffs + S.diff_offset + row0;
-  const bool in_aligned = ((S.diff_offset + row0) & 7) == 0;
-  // running predictor, packed pairs: (c0,c1) [, (c2,c3)]
-  const uint16_t* vs = a.vseed + (uint64_t(S.first_row) + r) * 4;
-  uint32_t carry0 = uint32_t(vs[0]) | (uint32_t(vs[1]) << 16);
-  uint32_t carry1 = N == 4 ? (uint32_t(vs[2]) | (uint32_t(vs[3]) << 16)) : 0u;
-
-  auto load8 = [&](uint32_t q) -> uint4 {
-    if (q + 8 <= n && in_aligned)
-      return *reinterpret_cast<const uint4*>(D + q);
-    uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (q + i < n)
-        w[i >> 1] |= uint32_t(uint16_t(D[q + i])) << (16 * (i & 1));
-    return make_uint4(w[0], w[1], w[2], w[3]);
-  };
-
-  uint4 nx[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-    nx[m] = load8((m * 64 + lane) * 8);
-  for (uint32_t c0 = 0; c0 < n; c0 += PF_CHUNK) {
-    // coalesced registers -> LDS (lane g/4 owns uint4 g)
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int g = m * 64 + lane;
-      *reinterpret_cast<uint4*>(tr + (g >> 2) * PF_STRIDE + (g & 3) * 16) = nx[m];
-    }
-    // prefetch the next chunk while this one is processed
-    if (c0 + PF_CHUNK < n) {
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-        nx[m] = load8(c0 + PF_CHUNK + (m * 64 + lane) * 8);
-    }
-    __builtin_amdgcn_wave_barrier();
-    uint32_t w[16];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint4 t = *reinterpret_cast<const uint4*>(tr + lane * PF_STRIDE + i * 16);
-      w[4 * i] = t.x;
-      w[4 * i + 1] = t.y;
-      w[4 * i + 2] = t.z;
-      w[4 * i + 3] = t.w;
-    }
-    // lane-local inclusive scan (dword = one (c0,c1) pair; N == 4: pairs alternate)
-#pragma unroll
-    for (int i = N / 2; i < 16; ++i)
-      w[i] = pk_add(w[i], w[i - N / 2]);
-    // wave scan of the lane totals
-    const uint32_t inc0 = pk_wave_scan(w[N == 2 ? 15 : 14]);
-    const uint32_t inc1 = N == 4 ? pk_wave_scan(w[15]) : 0u;
-    // exclusive offset of this lane = inclusive of the lane before + carry
-    uint32_t ex0 = uint32_t(__builtin_amdgcn_update_dpp(0, int(inc0), 0x138 /*wave_shr:1*/, 0xF, 0xF, false));
-    uint32_t ex1 = N == 4 ? uint32_t(__builtin_amdgcn_update_dpp(0, int(inc1), 0x138, 0xF, 0xF, false)) : 0u;
-    ex0 = pk_add(ex0, carry0);
-    ex1 = pk_add(ex1, carry1);
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-      w[i] = pk_add(w[i], (N == 2 || (i & 1) == 0) ? ex0 : ex1);
-    carry0 = pk_add(carry0, uint32_t(__builtin_amdgcn_readlane(int(inc0), 63)));
-    if (N == 4)
-      carry1 = pk_add(carry1, uint32_t(__builtin_amdgcn_readlane(int(inc1), 63)));
-    // back to the coalesced layout
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint4*>(tr + lane * PF_STRIDE + i * 16) =
-          make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int g = m * 64 + lane;
-      const uint4 o = *reinterpret_cast<const uint4*>(tr + (g >> 2) * PF_STRIDE + (g & 3) * 16);
-      lj_store8(a, S, r, row0, c0 + uint32_t(g) * 8, n, o);
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// ---------------------------------------------------------------------------
-// NikonDecompressor reconstruction (NikonDecompressor.cpp:515-539).  Unlike the
-// JPEG predictors these sums are plain ints -- nothing wraps mod 2^16 -- and
-// only the stored value is clamped to 15 bits.
-//   pred(y, x) = pUp_y[x & 1] + sum_{x' <= x, x' = x (2)} D[y][x']
-//   pUp_y[c]   = pUp_init[y & 1][c] + sum_{y' < y, y' = y (2)} D[y'][c]
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(VS_T) void nk_vseed_kernel(LjArgs a) {
-  __shared__ int32_t wtot[VS_T / 64][4];
-  __shared__ int32_t carry_s[4];
-  const uint32_t s = blockIdx.x;
-  const LjStreamDev& S = a.streams[s];
-  if (S.kind != 2 || a.results[s].status != 0)
-    return;
-  const NkStreamDev& K = a.nk[s];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint32_t rows = S.rows;
-  const int16_t* __restrict__ D = a.diffs + S.diff_offset;
-  int32_t* __restrict__ V = reinterpret_cast<int32_t*>(a.vseed) + uint64_t(S.first_row) * 2;
-  if (tid < 4)
-    carry_s[tid] = K.pup_in ? K.pup_in[tid] : K.p_up[tid];
-  __syncthreads();
-  for (uint32_t r0 = 0; r0 < rows; r0 += VS_T) {
-    const uint32_t r = r0 + tid;
-    const uint32_t par = (S.out_y + r) & 1u;
-    int32_t d[4] = {0, 0, 0, 0};
-    if (r < rows) {
-      d[2 * par] = D[uint64_t(r) * S.row_samples];
-      d[2 * par + 1] = D[uint64_t(r) * S.row_samples + 1];
-    }
-    int32_t inc[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      int32_t x = d[c];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int32_t y = __shfl_up(x, o, 64);
-        if (lane >= o)
-          x += y;
-      }
-      inc[c] = x;
-      if (lane == 63)
-        wtot[wv][c] = x;
-    }
-    __syncthreads();
-    int32_t base[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      int32_t o = carry_s[c];
-      for (int w = 0; w < wv; ++w)
-        o += wtot[w][c];
-      base[c] = o;
-    }
-    if (r < rows) {
-      // exclusive: the value of pUp[row & 1] when row r starts
-      V[uint64_t(r) * 2] = par ? base[2] + inc[2] - d[2] : base[0] + inc[0] - d[0];
-      V[uint64_t(r) * 2 + 1] = par ? base[3] + inc[3] - d[3] : base[1] + inc[1] - d[1];
-    }
-    __syncthreads();
-    if (tid == VS_T - 1)
-      for (int c = 0; c < 4; ++c)
-        carry_s[c] = base[c] + inc[c];
-    __syncthreads();
-  }
-  if (tid < 4)
-    a.nk_pup[s * 4 + tid] = carry_s[tid];
-}
-
-// The dither state of RawImageDataU16::setWithLookUp (common/RawImage.h:335-353)
-// is a lag-1 multiply-with-carry generator, r' = 15700 * (r & 65535) + (r >> 16),
-// advanced once per pixel in decode order.  With m = 15700 * 2^16 - 1 one has
-// 2^16 * r' = r (mod m), i.e. r_n = r_0 * 15700^n mod m for r_0 < m (the seed is
-// 24 bits): a lane jumps to its first pixel and then steps like the reference.
-constexpr uint64_t NK_MWC_A = 15700, NK_MWC_M = NK_MWC_A * 65536 - 1;
-__device__ __forceinline__ uint32_t nk_mulmod(uint32_t x, uint32_t y) {
-  return uint32_t((uint64_t(x) * y) % NK_MWC_M);
-}
-
-__global__ __launch_bounds__(LJ_T) void nk_predict_kernel(LjArgs a) {
-  const uint32_t grow = blockIdx.x * (LJ_T / 64) + (threadIdx.x >> 6);
-  if (grow >= a.total_rows)
-    return;
-  const int lane = threadIdx.x & 63;
-  uint32_t lo = 0, hi = a.n_streams - 1;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi + 1) >> 1;
-    if (a.streams[mid].first_row <= grow)
-      lo = mid;
-    else
-      hi = mid - 1;
-  }
-  const LjStreamDev& S = a.streams[lo];
-  if (S.kind != 2 || a.results[lo].status != 0)
-    return;
-  const NkStreamDev& K = a.nk[lo];
-  const uint32_t r = grow - S.first_row;
-  if (r >= S.rows)
-    return;
-  const uint32_t W = S.row_samples;
-  const uint32_t y = S.out_y + r;
-  const uint64_t row0 = uint64_t(r) * W;
-  const int16_t* __restrict__ D = a.diffs + S.diff_offset + row0;
-  const bool in_aligned = ((S.diff_offset + row0) & 7) == 0;
-  const int32_t* V = reinterpret_cast<const int32_t*>(a.vseed) + uint64_t(grow) * 2;
-  int32_t carry0 = V[0], carry1 = V[1];
-  uint8_t* out_row = a.out_base + S.img_offset + uint64_t(y) * S.img_pitch;
-  const bool out_aligned = (reinterpret_cast<uintptr_t>(out_row) & 15) == 0;
-
-  const bool dither = K.uncorrected == 0;
-  const uint32_t* __restrict__ tab = a.nk_tables + K.table_off;
-  uint32_t step_state = 0, lane_mul = 1, a512 = 1;
-  if (dither) {
-    const uint8_t* in0 = a.in_base + K.seed_offset;
-    const uint32_t seed = (uint32_t(in0[0]) << 16) | (uint32_t(in0[1]) << 8) | in0[2];
-    step_state = nk_mulmod(seed, a.nk_rowpow[K.rowpow_off + r]);
-    // 15700^(8 * lane) and 15700^512 by square-and-multiply (once per row)
-    uint32_t b = uint32_t(NK_MWC_A), e = 8u * uint32_t(lane);
-    for (int i = 0; i < 9; ++i) {
-      if (e & 1u)
-        lane_mul = nk_mulmod(lane_mul, b);
-      b = nk_mulmod(b, b);
-      e >>= 1;
-    }
-    a512 = b; // b = 15700^(2^9)
-  }
-
-  for (uint32_t q0 = 0; q0 < W; q0 += 512) {
-    const uint32_t q = q0 + lane * 8;
-    int32_t v[8];
-    if (q + 8 <= W && in_aligned) {
-      const uint4 t = *reinterpret_cast<const uint4*>(D + q);
-      v[0] = int16_t(t.x); v[1] = int32_t(t.x) >> 16;
-      v[2] = int16_t(t.y); v[3] = int32_t(t.y) >> 16;
-      v[4] = int16_t(t.z); v[5] = int32_t(t.z) >> 16;
-      v[6] = int16_t(t.w); v[7] = int32_t(t.w) >> 16;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        v[i] = q + i < W ? int32_t(D[q + i]) : 0;
-    }
-    int32_t run0 = 0, run1 = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i += 2) {
-      run0 += v[i];
-      v[i] = run0;
-      run1 += v[i + 1];
-      v[i + 1] = run1;
-    }
-    int32_t x0 = run0, x1 = run1;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int32_t y0 = __shfl_up(x0, o, 64), y1 = __shfl_up(x1, o, 64);
-      if (lane >= o) {
-        x0 += y0;
-        x1 += y1;
-      }
-    }
-    const int32_t tot0 = __shfl(x0, 63, 64), tot1 = __shfl(x1, 63, 64);
-    const int32_t e0 = x0 - run0 + carry0, e1 = x1 - run1 + carry1;
-    carry0 += tot0;
-    carry1 += tot1;
-
-    uint32_t st = 0;
-    if (dither) {
-      st = nk_mulmod(step_state, lane_mul);
-      step_state = nk_mulmod(step_state, a512);
-    }
-    uint32_t px[8];
-    if (K.pentax) {
-      // isIntN(value, 16) (PentaxDecompressor.cpp:170): the value as unsigned
-      // must fit 16 bits
-      bool bad = false;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        bad |= q + i < W && (uint32_t(v[i] + ((i & 1) ? e1 : e0)) >> 16) != 0;
-      if (bad)
-        atomicCAS(&a.results[lo].status, 0u, uint32_t(RSX_ERR_VALUE_RANGE));
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int32_t p = v[i] + ((i & 1) ? e1 : e0);
-      if (K.pentax)
-        p &= 0xFFFF;
-      else
-        p = p < 0 ? 0 : (p > 32767 ? 32767 : p); // clampBits(pred, 15)
-      if (dither) {
-        const uint32_t t = tab[p];
-        px[i] = ((t & 0xFFFFu) + (((t >> 16) * (st & 2047u) + 1024u) >> 12)) & 0xFFFFu;
-        st = 15700u * (st & 65535u) + (st >> 16);
-      } else {
-        px[i] = uint32_t(p);
-      }
-    }
-    if (q >= W)
-      continue;
-    uint16_t* dst = reinterpret_cast<uint16_t*>(out_row) + q;
-    if (q + 8 <= W && out_aligned) {
-      uint4 o;
-      o.x = px[0] | (px[1] << 16);
-      o.y = px[2] | (px[3] << 16);
-      o.z = px[4] | (px[5] << 16);
-      o.w = px[6] | (px[7] << 16);
-      *reinterpret_cast<uint4*>(dst) = o;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (q + i < W)
-          dst[i] = uint16_t(px[i]);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
 // K7: decode()/decompress() return value = BitStreamerJPEG::getStreamPosition()
 // after the last decoded symbol: let c be the un-stuffed bit
 // offset at which the last decoded symbol starts; K = ceil(c/32)+1 refills of 4
@@ -2340,23 +1557,6 @@ void launch_decode(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
                        lj_lds_bytes(p->max_tables), s, a);
 }
 
-void launch_predict(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
-  const dim3 grid((p->total_rows + 3) / 4), block(LJ_T);
-  if (p->comp_present[1])
-    hipLaunchKernelGGL((lj_predict_kernel<1>), grid, block, 0, s, a);
-  if (p->comp_present[2])
-    hipLaunchKernelGGL((lj_predict_fast_kernel<2>), grid, block, 0, s, a);
-  if (p->comp_present[3])
-    hipLaunchKernelGGL((lj_predict_kernel<3>), grid, block, 0, s, a);
-  if (p->comp_present[4])
-    hipLaunchKernelGGL((lj_predict_fast_kernel<4>), grid, block, 0, s, a);
-  if (p->comp_present[5])
-    hipLaunchKernelGGL((lj_predict_kernel<3, 4>), grid, block, 0, s, a);
-  if (p->comp_present[6])
-    hipLaunchKernelGGL((lj_predict_kernel<3, 6>), grid, block, 0, s, a);
-  if (p->any_nikon)
-    hipLaunchKernelGGL(nk_predict_kernel, grid, block, 0, s, a);
-}
 
 } // namespace
 
@@ -2572,10 +1772,12 @@ int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s, hipEvent_t ev_star
   if (ev_stop)
     RSX_HIP_CHECK(ctx, hipEventRecord(ev_stop, s));
   hipLaunchKernelGGL(lj_tail_kernel, dim3(n_streams), dim3(64), 0, s, a);
-  hipLaunchKernelGGL(lj_vseed_kernel, dim3(n_streams), dim3(VS_T), 0, s, a);
-  if (p->any_nikon)
-    hipLaunchKernelGGL(nk_vseed_kernel, dim3(n_streams), dim3(VS_T), 0, s, a);
-  launch_predict(p, a, s);
+  ReconLaunch rl;
+  rl.n_streams = n_streams;
+  rl.total_rows = p->total_rows;
+  std::copy(p->comp_present, p->comp_present + 7, rl.comp_present);
+  rl.any_nikon = p->any_nikon;
+  ljpeg_launch_reconstruct(a, rl, s);
   hipLaunchKernelGGL(lj_consumed_kernel, dim3(n_streams), dim3(64), 0, s, a);
   RSX_HIP_CHECK(ctx, hipGetLastError());
   return RSX_OK;

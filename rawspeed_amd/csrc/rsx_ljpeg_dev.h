@@ -1,0 +1,188 @@
+// rsx_ljpeg_dev.h -- constants and device-visible structures shared by the
+// translation units of the lossless-JPEG family pipeline:
+//   rsx_ljpeg.hip        entropy decode (K0-K4, tail, fallback) + the host plan
+//   rsx_ljpeg_recon.hip  reconstruction (K5 seeds, K6 row scans, Nikon / Pentax)
+#pragma once
+
+#include "rsx_internal.h"
+
+#include <cstddef>
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+namespace rsx {
+
+// ---------------------------------------------------------------------------
+// Geometry constants
+// ---------------------------------------------------------------------------
+constexpr int LJ_T = 256;             // lanes per workgroup = slots per workgroup
+#ifndef RSX_LJ_P
+#define RSX_LJ_P 64
+#endif
+constexpr int LJ_P = RSX_LJ_P;        // physical bytes per subsequence
+constexpr int LJ_PW = LJ_P / 4;       // dwords per subsequence
+constexpr int LJ_OWN = LJ_T - 1;      // owned slots (slot 0 = warm-up)
+constexpr int LJ_R = LJ_OWN * LJ_P;   // bytes of stream owned by one workgroup
+constexpr int LJ_BW = LJ_PW + 4;      // compacted slot capacity (dwords)
+constexpr int LJ_IMG_U4 = (LJ_BW + 1) * LJ_T / 4; // per-workgroup un-stuffed image: B + ob[], in uint4
+#ifndef RSX_LJ_WARM
+#define RSX_LJ_WARM 512
+#endif
+constexpr uint32_t LJ_WARM = RSX_LJ_WARM;     // warm-up bits decoded ahead of a slot for its start guess
+
+// Bit reader of the decode loops.  1: every symbol fetches its 32-bit window from
+// the slot's two LDS dwords (17 VALU instructions per symbol instead of 27, but
+// two dependent LDS round trips); 0: a 64-bit register buffer with the next dword
+// prefetched (LDS off the critical path).  Measured (PMC + A/B):
+// the synchronisation passes are VALU-issue bound and gain 4 % from the window
+// form; K4, whose time goes mostly to its scattered 16-byte stores and its
+// staging prologue, is 8 % faster with the register buffer.
+#ifndef RSX_LJ_WINDOW
+#define RSX_LJ_WINDOW 1
+#endif
+#ifndef RSX_LJ_K4_WINDOW
+#define RSX_LJ_K4_WINDOW 0
+#endif
+
+constexpr uint32_t ST_OFF_MASK = 63u;
+constexpr uint32_t ST_PHASE_SHIFT = 6;
+constexpr uint32_t ST_ERR = 1u << 9;
+constexpr uint32_t ST_MASK = 0xFFFFu;
+
+constexpr uint32_t NO_CODE = 0xFFFFFFFFu;
+
+// flags in LjResult::flags
+constexpr uint32_t FL_UNCONVERGED = 1u;
+
+struct TabLds {
+  uint16_t lut[LUT_SIZE];
+  uint32_t max_code[18];
+  uint16_t val_offset[18];
+  uint8_t values[RSX_MAX_CODE_VALUES];
+  uint8_t max_len;
+  uint8_t fix16;
+  uint8_t zero_sym_bits;
+  uint8_t las;
+  uint8_t pad[12];
+};
+static_assert(sizeof(TabLds) == sizeof(DeviceHuffTable) + 12 ||
+                  sizeof(TabLds) % 16 == 0,
+              "TabLds layout");
+static_assert(sizeof(TabLds) % 16 == 0, "TabLds must be 16-byte sized");
+static_assert(offsetof(TabLds, max_code) == offsetof(DeviceHuffTable, max_code), "");
+static_assert(offsetof(TabLds, values) == offsetof(DeviceHuffTable, values), "");
+
+struct Cr2Strip {
+  uint32_t x0, w, y0, h;
+  uint64_t first_sample;
+};
+
+struct LjStreamDev {
+  uint64_t in_offset;
+  uint64_t in_bytes;
+  uint64_t diff_offset; // int16 index into the difference scratch (multiple of 8)
+  uint64_t needed;      // symbols the reference decodes for this stream
+  uint64_t img_offset;
+  uint32_t img_pitch;
+  uint32_t first_block;
+  uint32_t n_blocks;
+  uint32_t first_subseq;
+  uint32_t table_base;
+  uint32_t n_tables;
+  uint32_t period;
+  uint32_t n_comp;
+  uint8_t tab_of_phase[8];
+  uint16_t init_pred[4];
+  uint8_t seed_pos[4]; // first sample of component c inside a stream row
+  uint8_t raw;         // 1: plain MSB bit stream (BitStreamerMSB): no FF00 un-stuffing,
+                       //    no markers, position budget of 8 bytes instead of 16
+  uint8_t start_bit;   // first symbol starts this many bits into the stream (0..7)
+  uint8_t las;         // table values are Nikon "lossy after split" (len | shl << 4)
+  uint8_t pad8;
+  uint32_t rows;
+  uint32_t row_samples;
+  uint32_t first_row; // global stream-row index
+  uint32_t kind;      // 0 LJPEG, 1 CR2
+  uint32_t mcu_w, mcu_h, out_x, out_y, keep_samples;
+  uint32_t scan_samples; // samples of a row that take part in reconstruction
+  uint32_t n_strips;
+  uint32_t strip_base;
+  uint32_t job;
+  uint64_t raw_limit;  // raw streams: 1 + last bit offset a symbol may start at (0 = derive)
+};
+
+// Per-stream parameters of NikonDecompressor streams (kind 2), indexed like streams[].
+struct NkStreamDev {
+  int32_t p_up[4];       // pUp[row & 1][col & 1] at [2 * (row & 1) + (col & 1)]
+  const int32_t* pup_in; // non-null: read the initial pUp from here instead (rows after the split)
+  uint32_t uncorrected;  // 1: store clampBits(pred, 15) as is
+  uint32_t table_off;    // first entry of this stream's dither table in nk_tables
+  uint32_t rowpow_off;   // first entry of this stream's row powers in nk_rowpow
+  uint32_t pentax;       // 1: PentaxDecompressor (.cpp:152-176): no clamp, values outside
+                         //    [0, 65535] are RSX_ERR_VALUE_RANGE
+  uint64_t seed_offset;  // byte offset (from in_base) of the job's first input byte
+};
+
+struct LjResult {
+  uint32_t marker_pos; // first FFxx (xx != 0) in the stream, 0xFFFFFFFF = none
+  uint32_t status;
+  uint32_t flags;
+  uint32_t avail_lo;   // symbols that start before the end of data
+  uint32_t last_slot;  // stream-relative subsequence of the last needed symbol
+  uint32_t last_pos;   // its bit offset inside the compacted subsequence
+  uint32_t consumed;
+  uint32_t tail_used;  // 1: the tail kernel delivered the last symbols
+  uint32_t last_c_lo;  // un-stuffed bit offset of the last symbol (tail path)
+  uint32_t last_c_hi;
+  uint32_t stat_rounds; // statistics: re-decode rounds summed over workgroups
+  uint32_t stat_redo;   // statistics: slots re-decoded
+  uint32_t stat_stitch; // statistics: workgroups re-converged by the stitch kernel
+  uint32_t end_lo;      // raw streams: bit offset just past the last needed symbol
+  uint32_t end_hi;
+  uint32_t pad2;
+};
+
+struct LjArgs {
+  const uint8_t* in_base;
+  uint8_t* out_base;
+  const LjStreamDev* streams;
+  const TabLds* tables;
+  const uint32_t* block_stream;
+  const Cr2Strip* strips;
+  uint32_t* sub_state;
+  uint32_t* block_start;
+  uint32_t* block_exit;
+  uint32_t* block_sum;
+  uint32_t* block_base;
+  uint32_t* block_drops;     // stuffing bytes dropped inside each workgroup's region
+  uint32_t* block_drop_base; // exclusive prefix of block_drops within the stream
+  uint4* unstuffed;          // per workgroup: its LDS image of un-stuffed slots (LJ_BW*LJ_T dwords)
+  LjResult* results;
+  int16_t* diffs;
+  uint16_t* vseed;
+  uint32_t n_streams;
+  uint32_t total_rows;
+  uint32_t ablate; // profiling aid (RSX_ABLATE): 1 = no K4 stores, 2 = no K4 decode loop, 4 = no K1 decode
+  // NikonDecompressor streams
+  const NkStreamDev* nk;
+  const uint32_t* nk_tables; // dither tables: base | delta << 16 per 15-bit value
+  const uint32_t* nk_rowpow; // 15700^(y * W) mod (15700 * 2^16 - 1) per output row
+  int32_t* nk_pup;           // [stream][4]: pUp after the stream's last row
+  uint16_t* transfer;        // [workgroup][512]: exit state per entry state (fallback path)
+};
+
+constexpr int VS_T = 1024; // lanes of the per-stream seed kernels
+
+// what the reconstruction launch needs to know about the plan
+struct ReconLaunch {
+  uint32_t n_streams = 0;
+  uint32_t total_rows = 0;
+  bool comp_present[7] = {}; // [1..4] interleaved n_comp; [5], [6]: sRaw groups of 4, 6
+  bool any_nikon = false;
+};
+
+// K5 + K6 (and their Nikon / Pentax counterparts) on `stream`
+void ljpeg_launch_reconstruct(const LjArgs& a, const ReconLaunch& r, hipStream_t stream);
+
+} // namespace rsx
