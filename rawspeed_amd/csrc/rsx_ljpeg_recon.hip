@@ -559,20 +559,32 @@ __global__ __launch_bounds__(LJ_T) void nk_predict_kernel(LjArgs a) {
     a512 = b; // b = 15700^(2^9)
   }
 
+  // 8 differences of this lane for the step starting at q0 (2 x int16 per dword);
+  // loads run two steps ahead of the scan so that HBM latency overlaps
+  auto load8 = [&](uint32_t q0) -> uint4 {
+    const uint32_t q = q0 + lane * 8;
+    if (q + 8 <= W && in_aligned)
+      return *reinterpret_cast<const uint4*>(D + q);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (q + i < W)
+        w[i >> 1] |= uint32_t(uint16_t(D[q + i])) << (16 * (i & 1));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  };
+  uint4 t0 = load8(0);
+  uint4 t1 = 512 < W ? load8(512) : make_uint4(0, 0, 0, 0);
   for (uint32_t q0 = 0; q0 < W; q0 += 512) {
     const uint32_t q = q0 + lane * 8;
+    const uint4 t = t0;
+    t0 = t1;
+    if (q0 + 1024 < W)
+      t1 = load8(q0 + 1024);
     int32_t v[8];
-    if (q + 8 <= W && in_aligned) {
-      const uint4 t = *reinterpret_cast<const uint4*>(D + q);
-      v[0] = int16_t(t.x); v[1] = int32_t(t.x) >> 16;
-      v[2] = int16_t(t.y); v[3] = int32_t(t.y) >> 16;
-      v[4] = int16_t(t.z); v[5] = int32_t(t.z) >> 16;
-      v[6] = int16_t(t.w); v[7] = int32_t(t.w) >> 16;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        v[i] = q + i < W ? int32_t(D[q + i]) : 0;
-    }
+    v[0] = int16_t(t.x); v[1] = int32_t(t.x) >> 16;
+    v[2] = int16_t(t.y); v[3] = int32_t(t.y) >> 16;
+    v[4] = int16_t(t.z); v[5] = int32_t(t.z) >> 16;
+    v[6] = int16_t(t.w); v[7] = int32_t(t.w) >> 16;
     int32_t run0 = 0, run1 = 0;
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
