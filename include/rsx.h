@@ -302,6 +302,28 @@ int rsx_pentax_decompress(rsx_ctx* ctx, const rsx_pentax_desc* d, const uint8_t*
                           size_t in_bytes, const rsx_image* img);
 
 /* ------------------------------------------------------------------------ */
+/* 3d. SamsungV1Decompressor                                                 */
+/*    replaces SamsungV1Decompressor::decompress()                           */
+/*    (decompressors/SamsungV1Decompressor.cpp:81-140): BitStreamerMSB, a    */
+/*    fixed prefix code given as (encLen, diffLen) pairs that fill a 10-bit  */
+/*    table in order (.cpp:88-117) -- NOT a canonical JPEG code, so it is    */
+/*    handed over in that form --, samsungDiff (.cpp:63-79: fill(23),        */
+/*    diffLen raw bits, sign extension), and the two-rows-up predictor of    */
+/*    PentaxDecompressor with values limited to `bits` bits (.cpp:129-136).  */
+/* ------------------------------------------------------------------------ */
+#define RSX_SAMSUNG_V1_MAX_ENTRIES 32
+typedef struct rsx_samsung_v1_desc {
+  int32_t bits;      /* the constructor accepts only 12 (.cpp:53-54) */
+  int32_t n_entries; /* 14 in the reference */
+  uint8_t enc_len[RSX_SAMSUNG_V1_MAX_ENTRIES];  /* tab[i][0], 1..10 */
+  uint8_t diff_len[RSX_SAMSUNG_V1_MAX_ENTRIES]; /* tab[i][1], 0..13 */
+} rsx_samsung_v1_desc;
+
+int rsx_samsung_v1_validate(const rsx_samsung_v1_desc* d, const rsx_image* img);
+int rsx_samsung_v1_decompress(rsx_ctx* ctx, const rsx_samsung_v1_desc* d,
+                              const uint8_t* in, size_t in_bytes, const rsx_image* img);
+
+/* ------------------------------------------------------------------------ */
 /* 4. AbstractDngDecompressor tile fan-out                                   */
 /*    replaces AbstractDngDecompressor::decompress()                         */
 /*    (AbstractDngDecompressor.h:141, .cpp:240-252) for compression 1        */
@@ -396,6 +418,14 @@ typedef struct rsx_pentax_job {
   rsx_image img; /* .data ignored */
 } rsx_pentax_job;
 
+typedef struct rsx_samsung_v1_job {
+  rsx_samsung_v1_desc desc;
+  uint64_t in_offset;
+  uint64_t in_bytes;
+  uint64_t img_offset;
+  rsx_image img; /* .data ignored */
+} rsx_samsung_v1_job;
+
 int rsx_unpack_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_unpack_job* jobs,
                            rsx_plan** out_plan);
 /* F32 images: same job structure, img describes 4-byte samples */
@@ -414,6 +444,8 @@ int rsx_nikon_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_nikon_job* jobs,
                           rsx_plan** out_plan);
 int rsx_pentax_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_pentax_job* jobs,
                            rsx_plan** out_plan);
+int rsx_samsung_v1_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_samsung_v1_job* jobs,
+                               rsx_plan** out_plan);
 /* Enqueue one pass of the plan on `stream`. */
 int rsx_plan_run(rsx_plan* plan, const void* in_dev, void* out_dev,
                  void* stream);

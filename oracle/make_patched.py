@@ -194,6 +194,27 @@ HUNK_PENTAX = r'''
   }
 '''
 
+HUNK_SAMSUNG_V1 = r'''
+  // ---- rsx: forward to the MI355X core (INTEGRATION.md 3d) ----
+  {
+    // the encoding table of this method (same pairs as `tab` below)
+    static const std::array<std::array<uint8_t, 2>, 14> rsx_tab = {{{3, 4}, {3, 7}, {2, 6}, {2, 5},
+        {4, 3}, {6, 0}, {7, 9}, {8, 10}, {9, 11}, {10, 12}, {10, 13}, {5, 1}, {4, 8}, {4, 2}}};
+    rsx_samsung_v1_desc d{};
+    d.bits = bits;
+    d.n_entries = 14;
+    for (int i = 0; i < 14; ++i) {
+      d.enc_len[i] = rsx_tab[i][0];
+      d.diff_len[i] = rsx_tab[i][1];
+    }
+    const rsx_image img = rsx_shim::view(mRaw);
+    const Buffer in = bs.peekRemainingBuffer();
+    if (int st = rsx_samsung_v1_decompress(rsx_shim::context(), &d, in.begin(), in.getSize(), &img))
+      rsx_shim::raise(st);
+    return;
+  }
+'''
+
 PATCHES = [
     ("decompressors/UncompressedDecompressor.cpp", [
         ("void UncompressedDecompressor::readUncompressedRaw() {", HUNK_UNPACK),
@@ -206,6 +227,8 @@ PATCHES = [
          "                                   bool uncorrectedRawValues) {", HUNK_NIKON)]),
     ("decompressors/PentaxDecompressor.cpp", [
         ("void PentaxDecompressor::decompress(ByteStream data) const {", HUNK_PENTAX)]),
+    ("decompressors/SamsungV1Decompressor.cpp", [
+        ("void SamsungV1Decompressor::decompress() const {", HUNK_SAMSUNG_V1)]),
     ("decompressors/LJpegDecompressor.cpp", [
         ("ByteStream::size_type LJpegDecompressor::decode() const {", HUNK_LJPEG)]),
     ("decompressors/Cr2DecompressorImpl.h", [

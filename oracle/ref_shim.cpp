@@ -31,6 +31,7 @@
 #include "decompressors/LJpegDecompressor.h"
 #include "decompressors/NikonDecompressor.h"
 #include "decompressors/PentaxDecompressor.h"
+#include "decompressors/SamsungV1Decompressor.h"
 #include "decompressors/UncompressedDecompressor.h"
 #include "io/Buffer.h"
 #include "io/ByteStream.h"
@@ -335,6 +336,16 @@ int ref_pentax_decompress(void* h, const uint8_t* meta, size_t meta_bytes,
     PentaxDecompressor p(r->img, md);
     const Buffer b(in, implicit_cast<Buffer::size_type>(in_bytes));
     p.decompress(ByteStream(DataBuffer(b, Endianness::little)));
+  });
+}
+
+// SamsungV1Decompressor, as SrwDecoder.cpp:107-119 drives it
+int ref_samsung_v1_decompress(void* h, int bits, const uint8_t* in, size_t in_bytes) {
+  auto* r = static_cast<RefImage*>(h);
+  return guarded([&] {
+    const Buffer b(in, implicit_cast<Buffer::size_type>(in_bytes));
+    SamsungV1Decompressor s1(r->img, ByteStream(DataBuffer(b, Endianness::little)), bits);
+    s1.decompress();
   });
 }
 

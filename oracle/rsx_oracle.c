@@ -1368,3 +1368,78 @@ int oracle_pentax_decompress(const rsx_pentax_desc* d, const uint8_t* in,
   return RSX_OK;
 }
 
+/* ======================================================================== */
+/* SamsungV1Decompressor (decompressors/SamsungV1Decompressor.cpp)            */
+/* ======================================================================== */
+
+int oracle_samsung_v1_validate(const rsx_samsung_v1_desc* d, const rsx_image* img) {
+  if (img->cpp != 1)
+    return RSX_ERR_INVALID_ARG; /* :48-50 */
+  if (d->bits != 12)
+    return RSX_ERR_INVALID_ARG; /* :53-54 */
+  if (img->dim_x <= 0 || img->dim_y <= 0 || img->dim_x % 32 != 0 ||
+      img->dim_y % 2 != 0 || img->dim_x > 5664 || img->dim_y > 3714)
+    return RSX_ERR_INVALID_ARG; /* :59-61 */
+  if (d->n_entries < 1 || d->n_entries > RSX_SAMSUNG_V1_MAX_ENTRIES)
+    return RSX_ERR_INVALID_ARG;
+  uint32_t filled = 0;
+  for (int i = 0; i < d->n_entries; ++i) {
+    if (d->enc_len[i] < 1 || d->enc_len[i] > 10 || d->diff_len[i] > 13)
+      return RSX_ERR_INVALID_ARG;
+    filled += 1024u >> d->enc_len[i];
+  }
+  return filled == 1024 ? RSX_OK : RSX_ERR_INVALID_ARG; /* the table is 1024 entries :102 */
+}
+
+/* decompress :81-140 with samsungDiff :63-79 */
+int oracle_samsung_v1_decompress(const rsx_samsung_v1_desc* d, const uint8_t* in,
+                                 size_t in_bytes, const rsx_image* img) {
+  int st = oracle_samsung_v1_validate(d, img);
+  if (st)
+    return st;
+  uint8_t enc[1024], dif[1024];
+  uint32_t n = 0;
+  for (int i = 0; i < d->n_entries; ++i) /* :110-117 */
+    for (uint32_t c = 0; c < (1024u >> d->enc_len[i]); ++c) {
+      enc[n] = d->enc_len[i];
+      dif[n] = d->diff_len[i];
+      ++n;
+    }
+  bitreader b;
+  br_init(&b, in, (int64_t)in_bytes, RSX_ORDER_MSB);
+  if (b.err)
+    return b.err;
+  const int W = img->dim_x, H = img->dim_y;
+  for (int row = 0; row < H; ++row) {
+    uint16_t* o = (uint16_t*)((uint8_t*)img->data + (size_t)row * img->pitch_bytes);
+    int pred[2] = {0, 0};
+    if (row >= 2) {
+      const uint16_t* up =
+          (const uint16_t*)((const uint8_t*)img->data + (size_t)(row - 2) * img->pitch_bytes);
+      pred[0] = up[0];
+      pred[1] = up[1];
+    }
+    for (int col = 0; col < W; ++col) {
+      br_fill(&b, 23); /* :66 */
+      if (b.err)
+        return b.err;
+      const uint32_t c = br_peek_nofill(&b, 10);
+      br_skip_nofill(&b, enc[c]);
+      const int len = dif[c];
+      int diff = 0;
+      if (len) {
+        const uint32_t v = br_get_nofill(&b, len);
+        diff = (int)v;
+        if ((v & (1u << (len - 1))) == 0)
+          diff -= (1 << len) - 1; /* PrefixCodeDecoder<>::extend */
+      }
+      pred[col & 1] += diff;
+      const int value = pred[col & 1];
+      if (((unsigned)value >> d->bits) != 0)
+        return RSX_ERR_VALUE_RANGE; /* !isIntN(value, bits) :133-134 */
+      o[col] = (uint16_t)value;
+    }
+  }
+  return RSX_OK;
+}
+

@@ -132,6 +132,25 @@ class PentaxJob(C.Structure):
                 ("img", Image)]
 
 
+class SamsungV1Desc(C.Structure):
+    _fields_ = [("bits", C.c_int32), ("n_entries", C.c_int32),
+                ("enc_len", C.c_uint8 * 32), ("diff_len", C.c_uint8 * 32)]
+
+    @classmethod
+    def make(cls, tab, bits=12):
+        d = cls()
+        d.bits, d.n_entries = bits, len(tab)
+        for i, (e, l) in enumerate(tab):
+            d.enc_len[i], d.diff_len[i] = e, l
+        return d
+
+
+class SamsungV1Job(C.Structure):
+    _fields_ = [("desc", SamsungV1Desc), ("in_offset", C.c_uint64),
+                ("in_bytes", C.c_uint64), ("img_offset", C.c_uint64),
+                ("img", Image)]
+
+
 class DngLJpegTile(C.Structure):
     _fields_ = [("desc", LJpegDesc), ("in_", C.c_void_p),
                 ("in_bytes", C.c_size_t)]

@@ -24,6 +24,7 @@ EXPORTS = [
     "rsx_cr2_validate", "rsx_cr2_decode",
     "rsx_nikon_validate", "rsx_nikon_decompress", "rsx_nikon_plan_create",
     "rsx_pentax_validate", "rsx_pentax_decompress", "rsx_pentax_plan_create",
+    "rsx_samsung_v1_validate", "rsx_samsung_v1_decompress", "rsx_samsung_v1_plan_create",
     "rsx_dng_decompress_ljpeg", "rsx_dng_decompress_uncompressed",
     "rsx_unpack_plan_create", "rsx_ljpeg_plan_create", "rsx_cr2_plan_create",
     "rsx_plan_run", "rsx_plan_results", "rsx_plan_set_timing",
@@ -76,6 +77,9 @@ def lib():
                                      C.c_void_p, C.c_void_p]
         L.rsx_nikon_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.rsx_pentax_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.rsx_samsung_v1_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.rsx_samsung_v1_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_size_t, C.c_void_p]
         L.rsx_pentax_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_size_t, C.c_void_p]
         L.rsx_nikon_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
@@ -87,7 +91,7 @@ def lib():
         for name in ("rsx_unpack_plan_create", "rsx_ljpeg_plan_create",
                      "rsx_cr2_plan_create", "rsx_unpack_variant_plan_create",
                      "rsx_nikon_plan_create", "rsx_unpack_f32_plan_create",
-                     "rsx_pentax_plan_create"):
+                     "rsx_pentax_plan_create", "rsx_samsung_v1_plan_create"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p,
                                          C.POINTER(C.c_void_p)]
         L.rsx_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -173,6 +177,11 @@ class Context:
         return lib().rsx_pentax_decompress(self._h, C.byref(desc), a.ctypes.data, a.size,
                                            C.byref(img_view))
 
+    def samsung_v1_decompress(self, desc, data, img_view):
+        a = _u8(data)
+        return lib().rsx_samsung_v1_decompress(self._h, C.byref(desc), a.ctypes.data,
+                                               a.size, C.byref(img_view))
+
     def dng_decompress_ljpeg(self, descs, datas, img_view):
         n = len(descs)
         arrs = [_u8(d) for d in datas]
@@ -215,6 +224,9 @@ class Context:
 
     def cr2_plan(self, jobs):
         return Plan(self, "rsx_cr2_plan_create", abi.Cr2Job, jobs)
+
+    def samsung_v1_plan(self, jobs):
+        return Plan(self, "rsx_samsung_v1_plan_create", abi.SamsungV1Job, jobs)
 
     def pentax_plan(self, jobs):
         return Plan(self, "rsx_pentax_plan_create", abi.PentaxJob, jobs)

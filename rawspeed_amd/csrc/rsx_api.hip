@@ -1030,6 +1030,67 @@ extern "C" int rsx_pentax_plan_create(rsx_ctx* ctx, int n_jobs,
   return RSX_OK;
 }
 
+extern "C" int rsx_samsung_v1_validate(const rsx_samsung_v1_desc* d, const rsx_image* img) {
+  if (!d || !img)
+    return RSX_ERR_INVALID_ARG;
+  return validate_samsung_v1(*d, *img);
+}
+
+extern "C" int rsx_samsung_v1_plan_create(rsx_ctx* ctx, int n_jobs,
+                                          const rsx_samsung_v1_job* jobs,
+                                          rsx_plan** out_plan) {
+  if (!ctx || !jobs || n_jobs < 1 || !out_plan)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto plan = std::make_unique<rsx_plan>();
+  plan->ctx = ctx;
+  plan->kind = PLAN_LJPEG;
+  plan->n_jobs = n_jobs;
+  std::vector<LJpegJobIn> in(n_jobs);
+  for (int i = 0; i < n_jobs; ++i) {
+    const rsx_image& img = jobs[i].img;
+    LJpegJobIn& J = in[i];
+    J.status = validate_samsung_v1(jobs[i].desc, img);
+    if (J.status == RSX_OK && img.pitch_bytes % 2 != 0)
+      J.status = RSX_ERR_INVALID_ARG;
+    if (J.status != RSX_OK)
+      continue;
+    StreamGeom& g = J.geom;
+    std::memset(&g, 0, sizeof g);
+    g.kind = 2; // the Nikon / Pentax reconstruction kernels
+    g.raw = 1;
+    g.in_offset = jobs[i].in_offset;
+    g.in_bytes = jobs[i].in_bytes;
+    g.img_offset = jobs[i].img_offset;
+    g.img_pitch_bytes = img.pitch_bytes;
+    g.n_comp = 2;
+    g.period = 2;
+    g.rows = uint32_t(img.dim_y);
+    g.row_samples = uint32_t(img.dim_x);
+    g.mcu_w = g.mcu_h = 1;
+    g.keep_samples = g.row_samples;
+    // samsungDiff refills with fill(23), not fill(32) (.cpp:66): a symbol at bit c
+    // needs 32 K - c >= 23, so symbols may start 9 bits later than with fill(32)
+    g.raw_limit = 32 * ((uint64_t(jobs[i].in_bytes) + 8) / 4) + 9 + 1;
+    J.n_tables = 1;
+    J.explicit_enc_len = jobs[i].desc.enc_len;
+    J.explicit_diff_len = jobs[i].desc.diff_len;
+    J.explicit_n = jobs[i].desc.n_entries;
+    J.nikon.uncorrected = true;
+    J.nikon.pentax = true;
+    J.nikon.range_bits = jobs[i].desc.bits;
+    J.nikon.height = img.dim_y;
+    J.nikon.seed_offset = jobs[i].in_offset;
+  }
+  LJpegPlan* lp = nullptr;
+  if (int st = ljpeg_plan_create(ctx, in, &lp))
+    return st;
+  plan->ljpeg.reset(lp);
+  *out_plan = plan.release();
+  return RSX_OK;
+}
+
 namespace {
 
 // Generic host-pointer runner for LJPEG-family jobs sharing one host image.
@@ -1048,6 +1109,9 @@ HostRect out_rect(const rsx_nikon_job& j) {
   return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
 }
 HostRect out_rect(const rsx_pentax_job& j) {
+  return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
+}
+HostRect out_rect(const rsx_samsung_v1_job& j) {
   return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
 }
 
@@ -1167,6 +1231,18 @@ extern "C" int rsx_pentax_decompress(rsx_ctx* ctx, const rsx_pentax_desc* d,
   jobs[0].in_bytes = in_bytes;
   int32_t st = RSX_OK;
   return ljpeg_family_host(ctx, 1, jobs, &in, img, rsx_pentax_plan_create, &st, nullptr);
+}
+
+extern "C" int rsx_samsung_v1_decompress(rsx_ctx* ctx, const rsx_samsung_v1_desc* d,
+                                         const uint8_t* in, size_t in_bytes,
+                                         const rsx_image* img) {
+  if (!ctx || !d || !in || !img || !img->data)
+    return RSX_ERR_INVALID_ARG;
+  std::vector<rsx_samsung_v1_job> jobs(1);
+  jobs[0].desc = *d;
+  jobs[0].in_bytes = in_bytes;
+  int32_t st = RSX_OK;
+  return ljpeg_family_host(ctx, 1, jobs, &in, img, rsx_samsung_v1_plan_create, &st, nullptr);
 }
 
 extern "C" int rsx_dng_decompress_ljpeg(rsx_ctx* ctx, int n_tiles,

@@ -560,6 +560,48 @@ int validate_pentax(const rsx_pentax_desc& d, const rsx_image& img) {
   return RSX_OK;
 }
 
+// SamsungV1Decompressor::SamsungV1Decompressor (SamsungV1Decompressor.cpp:45-61)
+// and the table its decompress() builds (:88-117)
+int validate_samsung_v1(const rsx_samsung_v1_desc& d, const rsx_image& img) {
+  if (img.cpp != 1) // :48-50
+    return RSX_ERR_INVALID_ARG;
+  if (d.bits != 12) // :53-54
+    return RSX_ERR_INVALID_ARG;
+  if (img.dim_x <= 0 || img.dim_y <= 0 || img.dim_x % 32 != 0 || img.dim_y % 2 != 0 ||
+      img.dim_x > 5664 || img.dim_y > 3714) // :59-61
+    return RSX_ERR_INVALID_ARG;
+  // the pairs must tile the 1024-entry table exactly, as the reference's do
+  if (d.n_entries < 1 || d.n_entries > RSX_SAMSUNG_V1_MAX_ENTRIES)
+    return RSX_ERR_INVALID_ARG;
+  uint32_t filled = 0;
+  for (int i = 0; i < d.n_entries; ++i) {
+    if (d.enc_len[i] < 1 || d.enc_len[i] > 10 || d.diff_len[i] > 13)
+      return RSX_ERR_INVALID_ARG; // fill(23) covers at most 10 + 13 bits (:66)
+    filled += 1024u >> d.enc_len[i];
+  }
+  return filled == 1024 ? RSX_OK : RSX_ERR_INVALID_ARG;
+}
+
+void build_device_table_explicit(const uint8_t* enc_len, const uint8_t* diff_len, int n,
+                                 DeviceHuffTable* out) {
+  std::memset(out, 0, sizeof *out);
+  for (int l = 0; l < 18; ++l)
+    out->max_code[l] = 0xFFFFFFFFu;
+  out->max_len = 10;
+  uint32_t pos = 0; // index into the 1024-entry table of the reference
+  for (int i = 0; i < n; ++i) {
+    const uint32_t l = enc_len[i], ssss = diff_len[i];
+    const uint16_t e = uint16_t(l | (ssss << 5) | ((l + ssss) << 10));
+    const uint32_t cnt = 1024u >> l;
+    // LUT_BITS = 11: every 10-bit index covers two LUT slots
+    for (uint32_t c = pos; c < pos + cnt; ++c)
+      out->lut[2 * c] = out->lut[2 * c + 1] = e;
+    if (pos == 0)
+      out->zero_sym_bits = uint8_t(l + ssss);
+    pos += cnt;
+  }
+}
+
 // TableLookUp::setTable, dither branch (common/TableLookUp.cpp:66-84).  Only
 // the first 32768 entries can be addressed: the index is clampBits(pred, 15).
 void build_dither_table(const uint16_t* curve, int n, std::vector<uint32_t>* out) {

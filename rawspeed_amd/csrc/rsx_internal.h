@@ -28,6 +28,8 @@ int validate_ljpeg(const rsx_ljpeg_desc& d, const rsx_image& img);
 int validate_cr2(const rsx_cr2_desc& d, const rsx_image& img);
 int validate_nikon(const rsx_nikon_desc& d, const rsx_image& img);
 int validate_pentax(const rsx_pentax_desc& d, const rsx_image& img);
+int validate_samsung_v1(const rsx_samsung_v1_desc& d, const rsx_image& img);
+
 // TableLookUp::setTable with dither (common/TableLookUp.cpp:50-84), 15-bit domain
 void build_dither_table(const uint16_t* curve, int n, std::vector<uint32_t>* out);
 int validate_huff_table(const rsx_huff_table& t);
@@ -63,6 +65,10 @@ struct DeviceHuffTable {
 };
 
 void build_device_table(const rsx_huff_table& t, DeviceHuffTable* out, bool las = false);
+// (encLen, diffLen) pairs in table-fill order -> the device LUT (no slow path:
+// every code is at most 10 bits)
+void build_device_table_explicit(const uint8_t* enc_len, const uint8_t* diff_len, int n,
+                                 DeviceHuffTable* out);
 int validate_las_table(const rsx_huff_table& t);
 
 // ------------------------------------------------------------------------

@@ -14,7 +14,9 @@ struct NikonIn {
   int32_t p_up[4] = {0, 0, 0, 0}; // pUp[row & 1][col & 1] at [2 * (row & 1) + (col & 1)]
   const int32_t* pup_in = nullptr; // device pointer overriding p_up (rows after a split)
   bool uncorrected = true;
-  bool pentax = false;    // PentaxDecompressor: values outside [0, 65535] are an error
+  bool pentax = false;    // PentaxDecompressor / SamsungV1: predictors start at 0, a
+                          // value that does not fit range_bits bits is an error
+  int range_bits = 16;
   int split = 0;          // rows >= split use table_after_split (0 = none)
   int height = 0;         // image rows
   std::vector<uint32_t> dither; // 32768 x (base | delta << 16); empty if uncorrected
@@ -30,6 +32,11 @@ struct LJpegJobIn {
   int rows_per_restart_interval = 0; // LJPEG only; 0 = no restart markers
   int frame_h = 0;
   NikonIn nikon;          // kind 2 only
+  // != nullptr: the one table of the job is not a canonical JPEG code; it is
+  // given as the reference's own (encLen, diffLen) pairs (SamsungV1)
+  const uint8_t* explicit_enc_len = nullptr;
+  const uint8_t* explicit_diff_len = nullptr;
+  int explicit_n = 0;
 };
 
 struct LJpegPlan;

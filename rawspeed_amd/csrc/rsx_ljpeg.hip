@@ -1645,9 +1645,15 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     if (g.kind == 1)
       strips.push_back({0, 1, 0, 0, g.strip_first_sample[g.n_strips]});
     S.job = uint32_t(i);
-    for (int t = 0; t < J.n_tables; ++t) {
+    if (J.explicit_n > 0) {
       tables.emplace_back();
-      build_device_table(J.tables[t], &tables.back(), g.las != 0);
+      build_device_table_explicit(J.explicit_enc_len, J.explicit_diff_len, J.explicit_n,
+                                  &tables.back());
+    } else {
+      for (int t = 0; t < J.n_tables; ++t) {
+        tables.emplace_back();
+        build_device_table(J.tables[t], &tables.back(), g.las != 0);
+      }
     }
     NkStreamDev K{};
     if (g.kind == 2) {
@@ -1655,7 +1661,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       std::memcpy(K.p_up, N.p_up, sizeof K.p_up);
       K.pup_in = N.pup_in;
       K.uncorrected = N.uncorrected ? 1u : 0u;
-      K.pentax = N.pentax ? 1u : 0u;
+      K.pentax = N.pentax ? uint32_t(N.range_bits) : 0u;
       K.seed_offset = N.seed_offset;
       K.table_off = uint32_t(nk_tables.size());
       if (!N.uncorrected)

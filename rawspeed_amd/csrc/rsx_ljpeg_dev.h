@@ -119,8 +119,9 @@ struct NkStreamDev {
   uint32_t uncorrected;  // 1: store clampBits(pred, 15) as is
   uint32_t table_off;    // first entry of this stream's dither table in nk_tables
   uint32_t rowpow_off;   // first entry of this stream's row powers in nk_rowpow
-  uint32_t pentax;       // 1: PentaxDecompressor (.cpp:152-176): no clamp, values outside
-                         //    [0, 65535] are RSX_ERR_VALUE_RANGE
+  uint32_t pentax;       // != 0: PentaxDecompressor (.cpp:152-176) / SamsungV1 (.cpp:125-137):
+                         //    no clamp; = number of bits a value may have, more is
+                         //    RSX_ERR_VALUE_RANGE
   uint64_t seed_offset;  // byte offset (from in_base) of the job's first input byte
 };
 

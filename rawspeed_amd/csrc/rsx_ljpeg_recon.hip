@@ -614,12 +614,12 @@ __global__ __launch_bounds__(LJ_T) void nk_predict_kernel(LjArgs a) {
     }
     uint32_t px[8];
     if (K.pentax) {
-      // isIntN(value, 16) (PentaxDecompressor.cpp:170): the value as unsigned
-      // must fit 16 bits
+      // isIntN(value, bits) (PentaxDecompressor.cpp:170, SamsungV1Decompressor.cpp:
+      // 133): the value as unsigned must fit `bits` bits
       bool bad = false;
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        bad |= q + i < W && (uint32_t(v[i] + ((i & 1) ? e1 : e0)) >> 16) != 0;
+        bad |= q + i < W && (uint32_t(v[i] + ((i & 1) ? e1 : e0)) >> K.pentax) != 0;
       if (bad)
         atomicCAS(&a.results[lo].status, 0u, uint32_t(RSX_ERR_VALUE_RANGE));
     }

@@ -330,13 +330,9 @@ size_t rsx_synth_ljpeg_encode_pattern(const uint16_t* samples, size_t row_stride
  * are plain ints here (the decoder does not wrap), so |diff| must fit the
  * table's categories.  Returns the byte count (padded with zero bits), 0 on
  * overflow / missing category. */
-size_t rsx_synth_nikon_encode(const uint16_t* samples, size_t row_stride, int w,
-                              int h, const int32_t* p_up, const uint8_t* counts,
-                              const uint8_t* values, int n_values, uint8_t* out,
-                              size_t cap, uint64_t* n_symbol_bits) {
-  enc_table tab;
-  if (enc_table_build(&tab, counts, values, n_values))
-    return 0;
+static size_t nikon_encode_tab(const uint16_t* samples, size_t row_stride, int w, int h,
+                               const int32_t* p_up, const enc_table* tab, uint8_t* out,
+                               size_t cap, uint64_t* n_symbol_bits) {
   jpeg_writer wr = {out, cap, 0, 0, 0, 0, 1};
   uint64_t bits = 0;
   for (int r = 0; r < h; ++r) {
@@ -353,10 +349,10 @@ size_t rsx_synth_nikon_encode(const uint16_t* samples, size_t row_stride, int w,
       int ssss = 0;
       for (int a = d < 0 ? -d : d; a; a >>= 1)
         ++ssss;
-      if (ssss > 15 || tab.len[ssss] == 0)
+      if (ssss > 15 || tab->len[ssss] == 0)
         return 0;
-      jw_bits(&wr, tab.code[ssss], tab.len[ssss]);
-      bits += tab.len[ssss] + ssss;
+      jw_bits(&wr, tab->code[ssss], tab->len[ssss]);
+      bits += tab->len[ssss] + ssss;
       if (ssss)
         jw_bits(&wr, d >= 0 ? (uint32_t)d : (uint32_t)(d + (1 << ssss) - 1), ssss);
     }
@@ -366,6 +362,39 @@ size_t rsx_synth_nikon_encode(const uint16_t* samples, size_t row_stride, int w,
   if (n_symbol_bits)
     *n_symbol_bits = bits;
   return wr.overflow ? 0 : wr.n;
+}
+
+size_t rsx_synth_nikon_encode(const uint16_t* samples, size_t row_stride, int w,
+                              int h, const int32_t* p_up, const uint8_t* counts,
+                              const uint8_t* values, int n_values, uint8_t* out,
+                              size_t cap, uint64_t* n_symbol_bits) {
+  enc_table tab;
+  if (enc_table_build(&tab, counts, values, n_values))
+    return 0;
+  return nikon_encode_tab(samples, row_stride, w, h, p_up, &tab, out, cap, n_symbol_bits);
+}
+
+/* Same stream layout with a prefix code that is not a canonical JPEG one
+ * (SamsungV1Decompressor.cpp:88-117): entry i = (enc_len[i], diff_len[i]) owns
+ * the next 1024 >> enc_len[i] slots of a 10-bit table, so its code is the first
+ * slot's index >> (10 - enc_len[i]). */
+size_t rsx_synth_prefix_encode(const uint16_t* samples, size_t row_stride, int w, int h,
+                               const int32_t* p_up, const uint8_t* enc_len,
+                               const uint8_t* diff_len, int n_entries, uint8_t* out,
+                               size_t cap, uint64_t* n_symbol_bits) {
+  enc_table tab;
+  memset(&tab, 0, sizeof tab);
+  unsigned pos = 0;
+  for (int i = 0; i < n_entries; ++i) {
+    if (enc_len[i] < 1 || enc_len[i] > 10 || diff_len[i] > 16)
+      return 0;
+    tab.code[diff_len[i]] = (uint16_t)(pos >> (10 - enc_len[i]));
+    tab.len[diff_len[i]] = enc_len[i];
+    pos += 1024u >> enc_len[i];
+  }
+  if (pos != 1024)
+    return 0;
+  return nikon_encode_tab(samples, row_stride, w, h, p_up, &tab, out, cap, n_symbol_bits);
 }
 
 static void put16(uint8_t** p, unsigned v) {

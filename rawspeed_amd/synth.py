@@ -44,6 +44,10 @@ def lib():
         _lib.rsx_synth_nikon_encode.argtypes = [
             C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
             C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        _lib.rsx_synth_prefix_encode.restype = C.c_size_t
+        _lib.rsx_synth_prefix_encode.argtypes = [
+            C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+            C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         _lib.rsx_synth_ljpeg_header.restype = C.c_size_t
         _lib.rsx_synth_ljpeg_header.argtypes = [
             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -209,6 +213,31 @@ def nikon_encode(img, p_up, table):
                                      len(values), out.ctypes.data, cap, C.byref(bits))
     if n == 0:
         raise ValueError("Nikon encode failed (difference too large for the table?)")
+    return out[:n].copy(), bits.value
+
+
+# The encoding table of SamsungV1Decompressor::decompress
+# (decompressors/SamsungV1Decompressor.cpp:88-101): (encLen, diffLen) pairs.
+SAMSUNG_V1_TAB = [(3, 4), (3, 7), (2, 6), (2, 5), (4, 3), (6, 0), (7, 9), (8, 10), (9, 11),
+                  (10, 12), (10, 13), (5, 1), (4, 8), (4, 2)]
+
+
+def prefix_encode(img, p_up, tab):
+    """Like nikon_encode, with the prefix code given as (encLen, diffLen) pairs
+    in table-fill order (SamsungV1)."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    h, w = img.shape
+    enc = np.asarray([t[0] for t in tab], dtype=np.uint8)
+    dif = np.asarray([t[1] for t in tab], dtype=np.uint8)
+    pu = np.asarray(p_up, dtype=np.int32)
+    cap = h * w * 4 + 64
+    out = np.empty(cap, dtype=np.uint8)
+    bits = C.c_uint64(0)
+    n = lib().rsx_synth_prefix_encode(img.ctypes.data, w, w, h, pu.ctypes.data,
+                                      enc.ctypes.data, dif.ctypes.data, len(tab),
+                                      out.ctypes.data, cap, C.byref(bits))
+    if n == 0:
+        raise ValueError("prefix encode failed")
     return out[:n].copy(), bits.value
 
 

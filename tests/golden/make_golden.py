@@ -21,7 +21,7 @@ from oracle_lib import Ref  # noqa: E402
 def main():
     ref = Ref()
     out = {"unpack": {}, "f32": {}, "variant": {}, "ljpeg": {}, "cr2": {}, "nikon": {},
-           "pentax": {}}
+           "pentax": {}, "samsung_v1": {}}
     for i, c in enumerate(G.UNPACK_CASES):
         d, data, (w, h, cpp) = G.build_unpack(c)
         img = ref.image(w, h, cpp)
@@ -59,6 +59,11 @@ def main():
         img = ref.image(w, h, cpp)
         st = ref.pentax(meta, data, img)
         out["pentax"][c["name"]] = {"status": st, "hash": G.image_hash(img.pixels())}
+    for c in G.SAMSUNG_V1_CASES:
+        d, data, (w, h, cpp), _ = G.build_samsung_v1(c)
+        img = ref.image(w, h, cpp)
+        st = ref.samsung_v1(12, data, img)
+        out["samsung_v1"][c["name"]] = {"status": st, "hash": G.image_hash(img.pixels())}
     path = os.path.join(HERE, "golden_hashes.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

@@ -250,3 +250,27 @@ def build_pentax(c, seed=515):
         data, _ = N.pentax_encode(src, tree)
         data = np.concatenate([data, np.zeros(8, np.uint8)])
     return meta, N.pentax_desc(tree), data, (w, h, 1), src
+
+
+# ---- SamsungV1Decompressor -------------------------------------------------------
+SAMSUNG_V1_CASES = [
+    dict(name="small", w=64, h=20),
+    dict(name="medium", w=1024, h=300),
+    dict(name="max_width", w=5664, h=12),
+    dict(name="range_error", w=64, h=20, symbols=True),
+]
+
+
+def build_samsung_v1(c, seed=616):
+    import nikon_cases as N
+    rng = np.random.default_rng([seed, sum(map(ord, c["name"]))])
+    w, h = c["w"], c["h"]
+    d = abi.SamsungV1Desc.make(synth.SAMSUNG_V1_TAB)
+    src = None
+    if c.get("symbols"):
+        data = rng.integers(0, 256, size=w * h * 2, dtype=np.uint8)  # any bits parse
+    else:
+        src = N.smooth15(rng, h, w, maxv=4095, sigma=6.0)
+        data, _ = synth.prefix_encode(src, [0, 0, 0, 0], synth.SAMSUNG_V1_TAB)
+        data = np.concatenate([data, np.zeros(8, np.uint8)])
+    return d, data, (w, h, 1), src

@@ -99,6 +99,9 @@ class Oracle:
         L.oracle_unpack_variant_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_nikon_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_pentax_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_samsung_v1_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_samsung_v1_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
+                                                   C.c_void_p]
         L.oracle_pentax_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                                C.c_void_p]
         L.oracle_nikon_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
@@ -152,6 +155,15 @@ class Oracle:
         a, p, n = _as_u8(data)
         v = img.view()
         return self.lib.oracle_pentax_decompress(C.byref(desc), p, n, C.byref(v))
+
+    def samsung_v1(self, desc, data, img):
+        a, p, n = _as_u8(data)
+        v = img.view()
+        return self.lib.oracle_samsung_v1_decompress(C.byref(desc), p, n, C.byref(v))
+
+    def samsung_v1_validate(self, desc, img):
+        v = img.view()
+        return self.lib.oracle_samsung_v1_validate(C.byref(desc), C.byref(v))
 
     def pentax_validate(self, desc, img):
         v = img.view()
@@ -271,6 +283,7 @@ class Ref:
                                              C.c_size_t]
         L.ref_decode8bit_lookup.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                             C.c_int, C.c_void_p, C.c_size_t]
+        L.ref_samsung_v1_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.ref_pentax_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                             C.c_void_p, C.c_size_t]
         L.ref_nikon_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
@@ -311,6 +324,10 @@ class Ref:
         c = np.ascontiguousarray(curve, dtype=np.uint16)
         a, p, n = _as_u8(data)
         return self.lib.ref_decode8bit_lookup(img.h, c.ctypes.data, c.size, w, h, p, n)
+
+    def samsung_v1(self, bits, data, img):
+        a, p, n = _as_u8(data)
+        return self.lib.ref_samsung_v1_decompress(img.h, bits, p, n)
 
     def pentax(self, meta, data, img):
         a, p, n = _as_u8(data)

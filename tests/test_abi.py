@@ -218,6 +218,29 @@ def test_pentax_validate_matches_oracle(lib, oracle):
     assert seen == {abi.RSX_OK, abi.RSX_ERR_INVALID_ARG}
 
 
+def test_samsung_v1_validate_matches_oracle(lib, oracle):
+    from rawspeed_amd import synth
+    rng = np.random.default_rng(16)
+    seen = set()
+    for trial in range(600):
+        img = HostImage(8, 2, int(rng.choice([1, 1, 1, 2])))
+        img.dim_x = int(rng.choice([0, 32, 48, 64, 5664, 5696]))
+        img.dim_y = int(rng.choice([0, 1, 2, 16, 3714, 3716]))
+        d = abi.SamsungV1Desc.make(synth.SAMSUNG_V1_TAB, bits=int(rng.choice([12, 12, 12, 14])))
+        t = rng.integers(0, 8)
+        if t == 0:
+            d.enc_len[3] = 3            # the pairs no longer tile the 10-bit table
+        elif t == 1:
+            d.diff_len[2] = 14
+        elif t == 2:
+            d.n_entries = int(rng.choice([0, 13, 33]))
+        v = img.view()
+        a = lib.rsx_samsung_v1_validate(C.byref(d), C.byref(v))
+        assert a == oracle.samsung_v1_validate(d, img), trial
+        seen.add(a)
+    assert seen == {abi.RSX_OK, abi.RSX_ERR_INVALID_ARG}
+
+
 def test_cr2_validate_matches_oracle(lib, oracle):
     import cases as cs
     rng = np.random.default_rng(13)

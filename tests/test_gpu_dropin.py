@@ -241,3 +241,15 @@ def test_pentax_decompressor(pair):
         assert s0 == s1, (e0, e1)
         if s0 == 0:
             assert np.array_equal(a, b)
+
+
+def test_samsung_v1_decompressor(pair):
+    import golden_cases as G
+    for name in ("medium", "max_width", "range_error"):
+        c = next(c for c in G.SAMSUNG_V1_CASES if c["name"] == name)
+        d, data, (w, h, cpp), _ = G.build_samsung_v1(c)
+        (s0, a, e0), (s1, b, e1) = both(
+            pair, lambda lib, img: lib.samsung_v1(12, data, img), (w, h, cpp))
+        assert s0 == s1, (e0, e1)
+        if s0 == 0:
+            assert np.array_equal(a, b)

@@ -186,3 +186,39 @@ def test_pentax_sizes_and_truncation(gpu, oracle):
             assert gpu.pentax_decompress(d, part, img.view()) == so, cut
             if so == 0:
                 assert np.array_equal(img.u16(), want.u16())
+
+
+# ---- SamsungV1Decompressor -------------------------------------------------------
+
+@pytest.mark.parametrize("c", G.SAMSUNG_V1_CASES, ids=lambda c: c["name"])
+def test_samsung_v1_golden(gpu, oracle, c):
+    d, data, (w, h, cpp), src = G.build_samsung_v1(c)
+    img, want = HostImage(w, h, cpp), HostImage(w, h, cpp)
+    st = gpu.samsung_v1_decompress(d, data, img.view())
+    assert st == oracle.samsung_v1(d, data, want)
+    if st == 0:
+        assert np.array_equal(img.u16(), want.u16())
+        assert G.image_hash(img.pixels()) == GOLD["samsung_v1"][c["name"]]["hash"]
+        assert np.array_equal(img.pixels(), src)
+    else:
+        assert st == abi.RSX_ERR_VALUE_RANGE
+
+
+def test_samsung_v1_truncation(gpu, oracle):
+    """fill(23) instead of fill(32): symbols may start 9 bits later before the
+    bit streamer overflows -- status parity at every cut."""
+    rng = np.random.default_rng(55)
+    w, h = 2048, 64
+    src = N.smooth15(rng, h, w, maxv=4095, sigma=6.0)
+    data, _ = synth.prefix_encode(src, [0, 0, 0, 0], synth.SAMSUNG_V1_TAB)
+    d = abi.SamsungV1Desc.make(synth.SAMSUNG_V1_TAB)
+    seen = set()
+    for cut in range(0, 24):
+        part = data[:len(data) - cut]
+        img, want = HostImage(w, h), HostImage(w, h)
+        so = oracle.samsung_v1(d, part, want)
+        assert gpu.samsung_v1_decompress(d, part, img.view()) == so, cut
+        if so == 0:
+            assert np.array_equal(img.u16(), want.u16())
+        seen.add(so)
+    assert 0 in seen and len(seen) >= 2

@@ -96,7 +96,41 @@ def test_pentax_golden(oracle, c):
         assert st == 10  # RSX_ERR_VALUE_RANGE <-> "decoded value out of bounds"
 
 
+@pytest.mark.parametrize("c", G.SAMSUNG_V1_CASES, ids=lambda c: c["name"])
+def test_samsung_v1_golden(oracle, c):
+    d, data, (w, h, cpp), src = G.build_samsung_v1(c)
+    img = HostImage(w, h, cpp)
+    st = oracle.samsung_v1(d, data, img)
+    g = GOLD["samsung_v1"][c["name"]]
+    assert (st, g["status"]) in ((0, 0), (10, 1))   # range error = RawDecoderException
+    if st == 0:
+        assert G.image_hash(img.pixels()) == g["hash"]
+        assert np.array_equal(img.pixels(), src)
+
+
 # ---- live cross-checks against the compiled reference ----------------------
+
+def test_samsung_v1_vs_ref(oracle, ref):
+    """Full buffers, and status parity at every cut of a truncated stream
+    (samsungDiff refills with fill(23): a 9-bit later position budget)."""
+    for c in G.SAMSUNG_V1_CASES:
+        d, data, (w, h, cpp), _ = G.build_samsung_v1(c)
+        hi, ri = HostImage(w, h, cpp), ref.image(w, h, cpp)
+        so, sr = oracle.samsung_v1(d, data, hi), ref.samsung_v1(12, data, ri)
+        assert (so, sr) in ((0, 0), (10, 1)), (c["name"], so, sr, ref.last_error())
+        if so == 0:
+            assert np.array_equal(hi.u16(), ri.u16())
+    d, data, (w, h, cpp), _ = G.build_samsung_v1(G.SAMSUNG_V1_CASES[0])
+    full = len(data) - 8
+    seen = set()
+    for cut in range(0, 40):
+        part = data[:full - cut]
+        hi, ri = HostImage(w, h, cpp), ref.image(w, h, cpp)
+        so, sr = oracle.samsung_v1(d, part, hi), ref.samsung_v1(12, part, ri)
+        assert so == sr or (so, sr) == (10, 1), (cut, so, sr, ref.last_error())
+        seen.add(so)
+    assert 0 in seen and len(seen) >= 2
+
 
 @pytest.mark.parametrize("c", G.PENTAX_CASES, ids=lambda c: c["name"])
 def test_pentax_vs_ref(oracle, ref, c):
