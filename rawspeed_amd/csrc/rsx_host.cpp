@@ -4,6 +4,8 @@
 #include "rsx_internal.h"
 
 #include <cstring>
+#include <map>
+#include <mutex>
 
 namespace rsx {
 
@@ -623,24 +625,89 @@ void build_dither_table(const uint16_t* curve, int n, std::vector<uint32_t>* out
   }
 }
 
+// Device allocations are recycled: a host-pointer call builds and drops a plan
+// (some 20 buffers) per image, and hipMalloc / hipFree (which synchronises the
+// device) would otherwise cost more than the kernels.  Freed blocks are kept per
+// device, keyed by size, up to a cap; a request takes the smallest cached block
+// that is large enough and at most twice what it asked for.  Callers release a
+// buffer only after the stream that used it has been synchronised.
+namespace {
+
+struct BlockCache {
+  static constexpr int kMaxDevices = 64;
+  static constexpr size_t kMaxCachedBytes = size_t(8) << 30;
+  std::mutex mu;
+  std::multimap<size_t, void*> free_blocks[kMaxDevices];
+  size_t cached_bytes = 0;
+};
+
+BlockCache& block_cache() {
+  static BlockCache* c = new BlockCache; // never destroyed: the HIP runtime may
+  return *c;                             // already be gone at static-destruction time
+}
+
+int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= BlockCache::kMaxDevices)
+    return 0;
+  return d;
+}
+
+} // namespace
+
 int DeviceBuffer::ensure(size_t n) {
   if (n <= bytes)
     return RSX_OK;
   release();
-  // round up so that repeated slightly-growing requests do not reallocate
-  size_t want = (n + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+  // size classes: 64 KiB steps below 1 MiB, 1 MiB steps above
+  const size_t step = n < (size_t(1) << 20) ? (size_t(1) << 16) : (size_t(1) << 20);
+  const size_t want = (n + step - 1) / step * step;
+  {
+    BlockCache& c = block_cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    auto& m = c.free_blocks[current_device()];
+    auto it = m.lower_bound(want);
+    if (it != m.end() && it->first <= 2 * want) {
+      ptr = it->second;
+      bytes = it->first;
+      c.cached_bytes -= it->first;
+      m.erase(it);
+      return RSX_OK;
+    }
+  }
   if (hipMalloc(&ptr, want) != hipSuccess) {
-    ptr = nullptr;
-    bytes = 0;
-    return RSX_ERR_NOMEM;
+    // give the cache back to the driver and retry once
+    BlockCache& c = block_cache();
+    {
+      std::lock_guard<std::mutex> lock(c.mu);
+      auto& m = c.free_blocks[current_device()];
+      for (auto& kv : m) {
+        (void)hipFree(kv.second);
+        c.cached_bytes -= kv.first;
+      }
+      m.clear();
+    }
+    if (hipMalloc(&ptr, want) != hipSuccess) {
+      ptr = nullptr;
+      bytes = 0;
+      return RSX_ERR_NOMEM;
+    }
   }
   bytes = want;
   return RSX_OK;
 }
 
 void DeviceBuffer::release() {
-  if (ptr)
-    (void)hipFree(ptr);
+  if (ptr) {
+    BlockCache& c = block_cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (c.cached_bytes + bytes <= BlockCache::kMaxCachedBytes) {
+      c.free_blocks[current_device()].emplace(bytes, ptr);
+      c.cached_bytes += bytes;
+    } else {
+      (void)hipFree(ptr);
+    }
+  }
   ptr = nullptr;
   bytes = 0;
 }
