@@ -141,8 +141,32 @@ def run_sraw(ctx, torch, log, frames=8, steps=10, warmup=2):
     dt, kt, cons = _time_plan(torch, plan, inp, out, steps, warmup)
     got = out[-out_pitch(W) * H:].cpu().numpy().view(np.uint16).reshape(H, out_pitch(W) // 2)[:, :W]
     exact = bool(np.array_equal(got, src)) and all(c == scan_len for c in cons)
+    # Cr2sRawInterpolator on the decoded frames, still in HBM (Cr2Decoder.cpp:585-625)
+    ow, oh = 2 * (W // 6), 2 * H
+    opitch = (ow * 3 * 2 + 15) // 16 * 16
+    sjobs = []
+    for f in range(frames):
+        sj = abi.SrawJob()
+        sj.desc = abi.SrawDesc.make(2, 2, [2100, 1024, 1650], -80)
+        sj.in_offset, sj.img_offset = f * out_pitch(W) * H, f * opitch * oh
+        sj.in_.pitch_bytes, sj.in_.dim_x, sj.in_.dim_y, sj.in_.cpp = out_pitch(W), W, H, 1
+        sj.img.pitch_bytes, sj.img.dim_x, sj.img.dim_y, sj.img.cpp = opitch, ow, oh, 3
+        sjobs.append(sj)
+    rgb = torch.empty(frames * opitch * oh, dtype=torch.uint8, device="cuda")
+    splan = ctx.sraw_plan(sjobs)
+    sdt, skt, _ = _time_plan(torch, splan, out, rgb, 20, 5)
+    splan.close()
+    salg = frames * (W * H * 2 + ow * oh * 3 * 2)
+    interp = {"workload": "Cr2sRawInterpolator 4:2:0 v2 -> %dx%d RGB, %d frames/step" % (ow, oh, frames),
+              "ms_per_step": round(sdt * 1e3, 4),
+              "mpix_per_s": round(frames * ow * oh / sdt / 1e6, 1)}
+    if skt:
+        interp.update(kernel=skt[0], avg_kernel_ms=round(skt[1], 5),
+                      achieved_gbps=round(salg / (skt[1] * 1e-3) / 1e9, 1),
+                      frac_of_8tbps=round(salg / (skt[1] * 1e-3) / 8e12, 4))
     alg = frames * (scan_len + W * H * 2)
     return {
+        "interpolate": interp,
         "workload": "Cr2Decompressor <3,2,2> (sRaw1) 3960x2640 px = %dx%d samples, 3 slices, "
                     "%d frames/step" % (W, H, frames),
         "msamples_per_s": round(frames * W * H / dt / 1e6, 1),

@@ -246,6 +246,28 @@ int rsx_cr2_decode(rsx_ctx* ctx, const rsx_cr2_desc* d, const uint8_t* in,
                    size_t in_bytes, const rsx_image* img, uint32_t* consumed);
 
 /* ------------------------------------------------------------------------ */
+/* 3a. Cr2sRawInterpolator                                                   */
+/*    replaces Cr2sRawInterpolator::interpolate(version)                     */
+/*    (interpolators/Cr2sRawInterpolator.h:49, .cpp:510-542 ->               */
+/*    interpolate_422<v> :95-186 / interpolate_420<v> :188-460,              */
+/*    YUV_TO_RGB<v> :470-506): the step Cr2Decoder runs right after the sRaw */
+/*    decompress (Cr2Decoder.cpp:585-625).  `in` is the decoded subsampled   */
+/*    image (cpp 1: groups of Y Y Cb Cr or Y Y Y Y Cb Cr), `out` the         */
+/*    interpolated one (cpp 3, 2 * groups pixels wide, subsampling_y * rows  */
+/*    high).  All arithmetic is the reference's int arithmetic.              */
+/* ------------------------------------------------------------------------ */
+typedef struct rsx_sraw_desc {
+  int32_t version;        /* 0, 1, 2 (0 only with subsampling_y == 1) */
+  int32_t subsampling_y;  /* 1: 4:2:2 (groups of 4), 2: 4:2:0 (groups of 6); x is always 2 */
+  int32_t sraw_coeffs[3];
+  int32_t hue;
+} rsx_sraw_desc;
+
+int rsx_sraw_validate(const rsx_sraw_desc* d, const rsx_image* in, const rsx_image* out);
+int rsx_sraw_interpolate(rsx_ctx* ctx, const rsx_sraw_desc* d, const rsx_image* in,
+                         const rsx_image* out);
+
+/* ------------------------------------------------------------------------ */
 /* 3b. NikonDecompressor                                                     */
 /*    replaces NikonDecompressor::decompress(input, uncorrectedRawValues)    */
 /*    (decompressors/NikonDecompressor.h:57, .cpp:541-560 ->                 */
@@ -418,6 +440,16 @@ typedef struct rsx_pentax_job {
   rsx_image img; /* .data ignored */
 } rsx_pentax_job;
 
+/* in_offset / img_offset address the subsampled input image and the interpolated
+ * output image inside the plan's input / output buffers */
+typedef struct rsx_sraw_job {
+  rsx_sraw_desc desc;
+  uint64_t in_offset;
+  uint64_t img_offset;
+  rsx_image in;  /* .data ignored */
+  rsx_image img; /* .data ignored */
+} rsx_sraw_job;
+
 typedef struct rsx_samsung_v1_job {
   rsx_samsung_v1_desc desc;
   uint64_t in_offset;
@@ -446,6 +478,8 @@ int rsx_pentax_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_pentax_job* jobs,
                            rsx_plan** out_plan);
 int rsx_samsung_v1_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_samsung_v1_job* jobs,
                                rsx_plan** out_plan);
+int rsx_sraw_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_sraw_job* jobs,
+                         rsx_plan** out_plan);
 /* Enqueue one pass of the plan on `stream`. */
 int rsx_plan_run(rsx_plan* plan, const void* in_dev, void* out_dev,
                  void* stream);

@@ -215,6 +215,31 @@ HUNK_SAMSUNG_V1 = r'''
   }
 '''
 
+HUNK_SRAW = r'''
+  // ---- rsx: forward to the MI355X core (INTEGRATION.md 3a) ----
+  {
+    rsx_sraw_desc d{};
+    d.version = version;
+    d.subsampling_y = mRaw->metadata.subsampling.y;
+    if (mRaw->metadata.subsampling.x != 2)
+      ThrowRDE("Unknown subsampling: (%i; %i)", mRaw->metadata.subsampling.x,
+               mRaw->metadata.subsampling.y);
+    for (int c = 0; c < 3; ++c)
+      d.sraw_coeffs[c] = sraw_coeffs[c];
+    d.hue = hue;
+    rsx_image in{};
+    in.data = const_cast<uint16_t*>(&input(0, 0));
+    in.pitch_bytes = implicit_cast<uint32_t>(input.pitch() * sizeof(uint16_t));
+    in.dim_x = input.width();
+    in.dim_y = input.height();
+    in.cpp = 1;
+    const rsx_image out = rsx_shim::view(mRaw);
+    if (int st = rsx_sraw_interpolate(rsx_shim::context(), &d, &in, &out))
+      rsx_shim::raise(st);
+    return;
+  }
+'''
+
 PATCHES = [
     ("decompressors/UncompressedDecompressor.cpp", [
         ("void UncompressedDecompressor::readUncompressedRaw() {", HUNK_UNPACK),
@@ -229,6 +254,8 @@ PATCHES = [
         ("void PentaxDecompressor::decompress(ByteStream data) const {", HUNK_PENTAX)]),
     ("decompressors/SamsungV1Decompressor.cpp", [
         ("void SamsungV1Decompressor::decompress() const {", HUNK_SAMSUNG_V1)]),
+    ("interpolators/Cr2sRawInterpolator.cpp", [
+        ("void Cr2sRawInterpolator::interpolate(int version) {", HUNK_SRAW)]),
     ("decompressors/LJpegDecompressor.cpp", [
         ("ByteStream::size_type LJpegDecompressor::decode() const {", HUNK_LJPEG)]),
     ("decompressors/Cr2DecompressorImpl.h", [

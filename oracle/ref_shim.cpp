@@ -33,6 +33,7 @@
 #include "decompressors/PentaxDecompressor.h"
 #include "decompressors/SamsungV1Decompressor.h"
 #include "decompressors/UncompressedDecompressor.h"
+#include "interpolators/Cr2sRawInterpolator.h"
 #include "io/Buffer.h"
 #include "io/ByteStream.h"
 #include "io/Endianness.h"
@@ -346,6 +347,20 @@ int ref_samsung_v1_decompress(void* h, int bits, const uint8_t* in, size_t in_by
     const Buffer b(in, implicit_cast<Buffer::size_type>(in_bytes));
     SamsungV1Decompressor s1(r->img, ByteStream(DataBuffer(b, Endianness::little)), bits);
     s1.decompress();
+  });
+}
+
+// Cr2sRawInterpolator, set up like Cr2Decoder::sRawInterpolate (Cr2Decoder.cpp:585-625):
+// `h_in` the subsampled image (cpp 1), `h_out` the interpolated one (cpp 3)
+int ref_sraw_interpolate(void* h_in, void* h_out, const rsx_sraw_desc* d) {
+  auto* in = static_cast<RefImage*>(h_in);
+  auto* out = static_cast<RefImage*>(h_out);
+  return guarded([&] {
+    out->img->metadata.subsampling = iPoint2D(2, d->subsampling_y);
+    out->img->isCFA = false;
+    Cr2sRawInterpolator i(out->img, in->img->getU16DataAsUncroppedArray2DRef(),
+                          {d->sraw_coeffs[0], d->sraw_coeffs[1], d->sraw_coeffs[2]}, d->hue);
+    i.interpolate(d->version);
   });
 }
 

@@ -1443,3 +1443,177 @@ int oracle_samsung_v1_decompress(const rsx_samsung_v1_desc* d, const uint8_t* in
   return RSX_OK;
 }
 
+/* ======================================================================== */
+/* Cr2sRawInterpolator (interpolators/Cr2sRawInterpolator.cpp)                */
+/* ======================================================================== */
+
+int oracle_sraw_validate(const rsx_sraw_desc* d, const rsx_image* in,
+                         const rsx_image* out) {
+  if (d->version < 0 || d->version > 2)
+    return RSX_ERR_INVALID_ARG; /* :511 */
+  if (d->subsampling_y != 1 && d->subsampling_y != 2)
+    return RSX_ERR_INVALID_ARG; /* :540-541 */
+  if (d->subsampling_y == 2 && d->version == 0)
+    return RSX_ERR_INVALID_ARG; /* :529-538 */
+  const int gs = 2 + 2 * d->subsampling_y;
+  if (in->cpp != 1 || out->cpp != 3)
+    return RSX_ERR_INVALID_ARG;
+  if (in->dim_x <= 0 || in->dim_y <= 0 || in->dim_x % gs != 0)
+    return RSX_ERR_INVALID_ARG; /* :104, :201 */
+  const int mcus = in->dim_x / gs;
+  if (mcus <= 1)
+    return RSX_ERR_INVALID_ARG; /* :106, :203 */
+  if (out->dim_x != 2 * mcus || out->dim_y != d->subsampling_y * in->dim_y)
+    return RSX_ERR_INVALID_ARG; /* Cr2Decoder.cpp:589-596 */
+  return RSX_OK;
+}
+
+typedef struct ycc {
+  int Y, Cb, Cr;
+} ycc;
+
+static uint16_t clamp16(int v) { return (uint16_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v)); }
+
+/* YUV_TO_RGB<version> :470-506 + STORE_RGB :462-468 (int arithmetic; the
+ * products are computed unsigned so that the wrap is defined) */
+static void sraw_store(const rsx_sraw_desc* d, ycc p, uint16_t* o) {
+  int r, g, b;
+  if (d->version == 0) {
+    r = p.Y + p.Cr - 512;
+    g = p.Y + ((-778 * p.Cb - (p.Cr * 2048)) >> 12) - 512;
+    b = p.Y + (p.Cb - 512);
+  } else if (d->version == 1) {
+    r = p.Y + ((50 * p.Cb + 22929 * p.Cr) >> 12);
+    g = p.Y + ((-5640 * p.Cb - 11751 * p.Cr) >> 12);
+    b = p.Y + ((29040 * p.Cb - 101 * p.Cr) >> 12);
+  } else {
+    r = p.Y + p.Cr;
+    g = p.Y + ((-778 * p.Cb - (p.Cr * 2048)) >> 12);
+    b = p.Y + p.Cb;
+  }
+  r = (int)((uint32_t)d->sraw_coeffs[0] * (uint32_t)r);
+  g = (int)((uint32_t)d->sraw_coeffs[1] * (uint32_t)g);
+  b = (int)((uint32_t)d->sraw_coeffs[2] * (uint32_t)b);
+  o[0] = clamp16(r >> 8);
+  o[1] = clamp16(g >> 8);
+  o[2] = clamp16(b >> 8);
+}
+
+/* LoadMCU (:113-122 / :208-223): the Ys, and the chroma into pixel [0] */
+static void sraw_load(const uint16_t* row, int m, int gs, ycc* px /* gs - 2 pixels */) {
+  for (int i = 0; i < gs - 2; ++i) {
+    px[i].Y = row[gs * m + i];
+    px[i].Cb = px[i].Cr = 0;
+  }
+  px[0].Cb = row[gs * m + gs - 2];
+  px[0].Cr = row[gs * m + gs - 1];
+}
+static void sraw_process(ycc* p, int hue) { /* signExtend + applyHue :69-80 */
+  p->Cb += hue - 16384;
+  p->Cr += hue - 16384;
+}
+
+int oracle_sraw_interpolate(const rsx_sraw_desc* d, const rsx_image* in,
+                            const rsx_image* out) {
+  int st = oracle_sraw_validate(d, in, out);
+  if (st)
+    return st;
+  const int gs = 2 + 2 * d->subsampling_y, n = in->dim_x / gs, H = in->dim_y;
+  const uint8_t* ib = (const uint8_t*)in->data;
+  uint8_t* ob = (uint8_t*)out->data;
+#define IROW(r) ((const uint16_t*)(ib + (size_t)(r) * in->pitch_bytes))
+#define OROW(r) ((uint16_t*)(ob + (size_t)(r) * out->pitch_bytes))
+  if (gs == 4) { /* interpolate_422_row :95-176 */
+    for (int row = 0; row < H; ++row) {
+      int m;
+      for (m = 0; m < n - 1; ++m) {
+        ycc a[2], b[2];
+        sraw_load(IROW(row), m, 4, a);
+        sraw_load(IROW(row), m + 1, 4, b);
+        sraw_process(&a[0], d->hue);
+        sraw_process(&b[0], d->hue);
+        a[1].Cb = (a[0].Cb + b[0].Cb) >> 1;
+        a[1].Cr = (a[0].Cr + b[0].Cr) >> 1;
+        sraw_store(d, a[0], OROW(row) + 6 * m);
+        sraw_store(d, a[1], OROW(row) + 6 * m + 3);
+      }
+      ycc a[2];
+      sraw_load(IROW(row), m, 4, a);
+      sraw_process(&a[0], d->hue);
+      a[1].Cb = a[0].Cb;
+      a[1].Cr = a[0].Cr;
+      sraw_store(d, a[0], OROW(row) + 6 * m);
+      sraw_store(d, a[1], OROW(row) + 6 * m + 3);
+    }
+    return RSX_OK;
+  }
+  /* interpolate_420: rows 0 .. H-2 by interpolate_420_row (:188-345), then the last
+   * input row (:385-460); pixel [MCURow][MCUCol] = px[2 * MCURow + MCUCol] */
+  for (int row = 0; row < H - 1; ++row) {
+    int m;
+    for (m = 0; m < n - 1; ++m) {
+      ycc a[4], b[4], c[4], e[4]; /* (row,m) (row,m+1) (row+1,m) (row+1,m+1) */
+      sraw_load(IROW(row), m, 6, a);
+      sraw_load(IROW(row), m + 1, 6, b);
+      sraw_load(IROW(row + 1), m, 6, c);
+      sraw_load(IROW(row + 1), m + 1, 6, e);
+      sraw_process(&a[0], d->hue);
+      sraw_process(&b[0], d->hue);
+      sraw_process(&c[0], d->hue);
+      sraw_process(&e[0], d->hue);
+      a[1].Cb = (a[0].Cb + b[0].Cb) >> 1;
+      a[1].Cr = (a[0].Cr + b[0].Cr) >> 1;
+      a[2].Cb = (a[0].Cb + c[0].Cb) >> 1;
+      a[2].Cr = (a[0].Cr + c[0].Cr) >> 1;
+      a[3].Cb = (a[0].Cb + b[0].Cb + c[0].Cb + e[0].Cb) >> 2;
+      a[3].Cr = (a[0].Cr + b[0].Cr + c[0].Cr + e[0].Cr) >> 2;
+      for (int k = 0; k < 4; ++k)
+        sraw_store(d, a[k], OROW(2 * row + (k >> 1)) + 6 * m + 3 * (k & 1));
+    }
+    ycc a[4], c[4]; /* last MCU of the line :333-345 */
+    sraw_load(IROW(row), m, 6, a);
+    sraw_load(IROW(row + 1), m, 6, c);
+    sraw_process(&a[0], d->hue);
+    sraw_process(&c[0], d->hue);
+    a[2].Cb = (a[0].Cb + c[0].Cb) >> 1;
+    a[2].Cr = (a[0].Cr + c[0].Cr) >> 1;
+    a[1].Cb = a[0].Cb;
+    a[1].Cr = a[0].Cr;
+    a[3].Cb = a[2].Cb;
+    a[3].Cr = a[2].Cr;
+    for (int k = 0; k < 4; ++k)
+      sraw_store(d, a[k], OROW(2 * row + (k >> 1)) + 6 * m + 3 * (k & 1));
+  }
+  {
+    const int row = H - 1;
+    int m;
+    for (m = 0; m < n - 1; ++m) { /* :397-423 */
+      ycc a[4], b[4];
+      sraw_load(IROW(row), m, 6, a);
+      sraw_load(IROW(row), m + 1, 6, b);
+      sraw_process(&a[0], d->hue);
+      sraw_process(&b[0], d->hue);
+      a[1].Cb = (a[0].Cb + b[0].Cb) >> 1;
+      a[1].Cr = (a[0].Cr + b[0].Cr) >> 1;
+      a[2].Cb = a[0].Cb;
+      a[2].Cr = a[0].Cr;
+      a[3].Cb = a[1].Cb;
+      a[3].Cr = a[1].Cr;
+      for (int k = 0; k < 4; ++k)
+        sraw_store(d, a[k], OROW(2 * row + (k >> 1)) + 6 * m + 3 * (k & 1));
+    }
+    ycc a[4]; /* :440-459 */
+    sraw_load(IROW(row), m, 6, a);
+    sraw_process(&a[0], d->hue);
+    for (int k = 1; k < 4; ++k) {
+      a[k].Cb = a[0].Cb;
+      a[k].Cr = a[0].Cr;
+    }
+    for (int k = 0; k < 4; ++k)
+      sraw_store(d, a[k], OROW(2 * row + (k >> 1)) + 6 * m + 3 * (k & 1));
+  }
+#undef IROW
+#undef OROW
+  return RSX_OK;
+}
+

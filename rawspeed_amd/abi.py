@@ -151,6 +151,24 @@ class SamsungV1Job(C.Structure):
                 ("img", Image)]
 
 
+class SrawDesc(C.Structure):
+    _fields_ = [("version", C.c_int32), ("subsampling_y", C.c_int32),
+                ("sraw_coeffs", C.c_int32 * 3), ("hue", C.c_int32)]
+
+    @classmethod
+    def make(cls, version, subsampling_y, coeffs, hue):
+        d = cls()
+        d.version, d.subsampling_y, d.hue = version, subsampling_y, hue
+        for i, c in enumerate(coeffs):
+            d.sraw_coeffs[i] = c
+        return d
+
+
+class SrawJob(C.Structure):
+    _fields_ = [("desc", SrawDesc), ("in_offset", C.c_uint64), ("img_offset", C.c_uint64),
+                ("in_", Image), ("img", Image)]
+
+
 class DngLJpegTile(C.Structure):
     _fields_ = [("desc", LJpegDesc), ("in_", C.c_void_p),
                 ("in_bytes", C.c_size_t)]

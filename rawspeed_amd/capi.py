@@ -22,6 +22,7 @@ EXPORTS = [
     "rsx_unpack_variant_validate", "rsx_unpack_variant_u16", "rsx_unpack_variant_plan_create",
     "rsx_ljpeg_validate", "rsx_ljpeg_decode",
     "rsx_cr2_validate", "rsx_cr2_decode",
+    "rsx_sraw_validate", "rsx_sraw_interpolate", "rsx_sraw_plan_create",
     "rsx_nikon_validate", "rsx_nikon_decompress", "rsx_nikon_plan_create",
     "rsx_pentax_validate", "rsx_pentax_decompress", "rsx_pentax_plan_create",
     "rsx_samsung_v1_validate", "rsx_samsung_v1_decompress", "rsx_samsung_v1_plan_create",
@@ -75,6 +76,8 @@ def lib():
                                        C.c_void_p, C.c_void_p]
         L.rsx_cr2_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                      C.c_void_p, C.c_void_p]
+        L.rsx_sraw_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.rsx_sraw_interpolate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rsx_nikon_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.rsx_pentax_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.rsx_samsung_v1_validate.argtypes = [C.c_void_p, C.c_void_p]
@@ -91,7 +94,8 @@ def lib():
         for name in ("rsx_unpack_plan_create", "rsx_ljpeg_plan_create",
                      "rsx_cr2_plan_create", "rsx_unpack_variant_plan_create",
                      "rsx_nikon_plan_create", "rsx_unpack_f32_plan_create",
-                     "rsx_pentax_plan_create", "rsx_samsung_v1_plan_create"):
+                     "rsx_pentax_plan_create", "rsx_samsung_v1_plan_create",
+                     "rsx_sraw_plan_create"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p,
                                          C.POINTER(C.c_void_p)]
         L.rsx_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -167,6 +171,10 @@ class Context:
                                   C.byref(img_view), C.byref(consumed))
         return st, consumed.value
 
+    def sraw_interpolate(self, desc, in_view, out_view):
+        return lib().rsx_sraw_interpolate(self._h, C.byref(desc), C.byref(in_view),
+                                          C.byref(out_view))
+
     def nikon_decompress(self, desc, data, img_view):
         a = _u8(data)
         return lib().rsx_nikon_decompress(self._h, C.byref(desc), a.ctypes.data, a.size,
@@ -230,6 +238,9 @@ class Context:
 
     def pentax_plan(self, jobs):
         return Plan(self, "rsx_pentax_plan_create", abi.PentaxJob, jobs)
+
+    def sraw_plan(self, jobs):
+        return Plan(self, "rsx_sraw_plan_create", abi.SrawJob, jobs)
 
     def nikon_plan(self, jobs):
         return Plan(self, "rsx_nikon_plan_create", abi.NikonJob, jobs)

@@ -18,7 +18,7 @@ using namespace rsx;
 // ---------------------------------------------------------------------------
 namespace {
 
-enum PlanKind { PLAN_UNPACK = 0, PLAN_LJPEG = 1 };
+enum PlanKind { PLAN_UNPACK = 0, PLAN_LJPEG = 1, PLAN_SRAW = 2 };
 
 struct UnpackLaunch {
   int mode = UNPACK_MODE_PACKED;
@@ -43,6 +43,11 @@ struct rsx_plan {
   std::vector<int32_t> job_status; // host-side validation result per job
   std::vector<UnpackLaunch> unpack;
   std::unique_ptr<LJpegPlan, LJpegPlanDeleter> ljpeg;
+  // PLAN_SRAW
+  DeviceBuffer d_sraw_jobs, d_sraw_starts;
+  int n_sraw = 0;
+  uint32_t sraw_blocks = 0;
+  bool sraw_versions[3] = {false, false, false};
   hipStream_t last_stream = nullptr;
   bool ran = false;
   // dominant-kernel timing
@@ -479,6 +484,17 @@ extern "C" int rsx_plan_run(rsx_plan* plan, const void* in_dev, void* out_dev,
   if (plan->kind == PLAN_UNPACK)
     return run_unpack(plan, in_dev, out_dev, s);
   EventPair* ev = plan->timing ? next_events(plan) : nullptr;
+  if (plan->kind == PLAN_SRAW) {
+    if (ev)
+      RSX_HIP_CHECK(ctx, hipEventRecord(ev->start, s));
+    RSX_HIP_CHECK(ctx, launch_sraw(static_cast<const SrawJobDev*>(plan->d_sraw_jobs.ptr),
+                                   static_cast<const uint32_t*>(plan->d_sraw_starts.ptr),
+                                   plan->n_sraw, plan->sraw_blocks, plan->sraw_versions,
+                                   in_dev, out_dev, s));
+    if (ev)
+      RSX_HIP_CHECK(ctx, hipEventRecord(ev->stop, s));
+    return RSX_OK;
+  }
   return ljpeg_plan_run(plan->ljpeg.get(), in_dev, out_dev, s,
                         ev ? ev->start : nullptr, ev ? ev->stop : nullptr);
 }
@@ -493,7 +509,7 @@ extern "C" int rsx_plan_results(rsx_plan* plan, int32_t* job_status,
   if (plan->ran)
     RSX_HIP_CHECK(ctx, hipStreamSynchronize(plan->last_stream));
   int rc = RSX_OK;
-  if (plan->kind == PLAN_UNPACK) {
+  if (plan->kind == PLAN_UNPACK || plan->kind == PLAN_SRAW) {
     for (int i = 0; i < plan->n_jobs; ++i) {
       if (job_status)
         job_status[i] = plan->job_status[i];
@@ -544,7 +560,8 @@ extern "C" int rsx_plan_kernel_time(rsx_plan* plan, const char** kernel_name,
     total += ms;
   }
   if (kernel_name)
-    *kernel_name = plan->kind != PLAN_UNPACK ? ljpeg_dominant_kernel_name()
+    *kernel_name = plan->kind == PLAN_SRAW ? "sraw_kernel"
+                   : plan->kind != PLAN_UNPACK ? ljpeg_dominant_kernel_name()
                    : (!plan->unpack.empty() &&
                       plan->unpack[0].mode == UNPACK_MODE_CONTROL)
                        ? "unpack_control_kernel"
@@ -570,6 +587,8 @@ extern "C" void rsx_plan_destroy(rsx_plan* plan) {
       L.d_jobs.release();
       L.d_block_start.release();
     }
+    plan->d_sraw_jobs.release();
+    plan->d_sraw_starts.release();
     for (auto& e : plan->events) {
       (void)hipEventDestroy(e.start);
       (void)hipEventDestroy(e.stop);
@@ -910,6 +929,111 @@ extern "C" int rsx_cr2_plan_create(rsx_ctx* ctx, int n_jobs,
   plan->ljpeg.reset(lp);
   *out_plan = plan.release();
   return RSX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Cr2sRawInterpolator
+// ---------------------------------------------------------------------------
+extern "C" int rsx_sraw_validate(const rsx_sraw_desc* d, const rsx_image* in,
+                                 const rsx_image* out) {
+  if (!d || !in || !out)
+    return RSX_ERR_INVALID_ARG;
+  return validate_sraw(*d, *in, *out);
+}
+
+extern "C" int rsx_sraw_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_sraw_job* jobs,
+                                    rsx_plan** out_plan) {
+  if (!ctx || !jobs || n_jobs < 1 || !out_plan)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto plan = std::make_unique<rsx_plan>();
+  plan->ctx = ctx;
+  plan->kind = PLAN_SRAW;
+  plan->n_jobs = n_jobs;
+  plan->job_status.assign(n_jobs, RSX_OK);
+  std::vector<SrawJobDev> v;
+  std::vector<uint32_t> starts(1, 0);
+  for (int i = 0; i < n_jobs; ++i) {
+    const rsx_sraw_job& j = jobs[i];
+    int st = validate_sraw(j.desc, j.in, j.img);
+    // the kernel moves 16-byte pieces: RawImage rows are (pitch = roundUp(.., 16),
+    // common/RawImage.cpp:80-83), the image bases must be as well
+    if (st == RSX_OK && (j.in.pitch_bytes % 16 != 0 || j.img.pitch_bytes % 16 != 0 ||
+                         j.in_offset % 16 != 0 || j.img_offset % 16 != 0))
+      st = RSX_ERR_INVALID_ARG;
+    plan->job_status[i] = st;
+    if (st != RSX_OK)
+      continue;
+    SrawJobDev d{};
+    d.in_offset = j.in_offset;
+    d.out_offset = j.img_offset;
+    d.in_pitch = j.in.pitch_bytes;
+    d.out_pitch = j.img.pitch_bytes;
+    d.rows = uint32_t(j.in.dim_y);
+    d.gs = uint32_t(2 + 2 * j.desc.subsampling_y);
+    d.num_mcus = uint32_t(j.in.dim_x) / d.gs;
+    d.version = uint32_t(j.desc.version);
+    for (int k = 0; k < 3; ++k)
+      d.coeffs[k] = j.desc.sraw_coeffs[k];
+    d.hue = j.desc.hue;
+    starts.push_back(starts.back() + sraw_blocks_for(&d));
+    v.push_back(d);
+    plan->sraw_versions[j.desc.version] = true;
+  }
+  plan->n_sraw = int(v.size());
+  plan->sraw_blocks = starts.back();
+  if (int st = upload(ctx, plan->d_sraw_jobs, v.data(), v.size() * sizeof(SrawJobDev)))
+    return st;
+  if (int st = upload(ctx, plan->d_sraw_starts, starts.data(), starts.size() * 4))
+    return st;
+  *out_plan = plan.release();
+  return RSX_OK;
+}
+
+extern "C" int rsx_sraw_interpolate(rsx_ctx* ctx, const rsx_sraw_desc* d,
+                                    const rsx_image* in, const rsx_image* out) {
+  if (!ctx || !d || !in || !out || !in->data || !out->data)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int st = validate_sraw(*d, *in, *out))
+    return st;
+  // compact device images (row padding never travels)
+  rsx_sraw_job job{};
+  job.desc = *d;
+  job.in = *in;
+  job.img = *out;
+  const size_t in_w = size_t(in->dim_x) * 2, out_w = size_t(out->dim_x) * 3 * 2;
+  job.in.pitch_bytes = uint32_t(align_up(in_w, 16));
+  job.img.pitch_bytes = uint32_t(align_up(out_w, 16));
+  const size_t in_bytes = size_t(job.in.pitch_bytes) * in->dim_y;
+  const size_t out_bytes = size_t(job.img.pitch_bytes) * out->dim_y;
+  if (int e = ctx->d_in.ensure(in_bytes + 16))
+    return e;
+  if (int e = ctx->d_out.ensure(out_bytes + 16))
+    return e;
+  hipStream_t s = ctx->stream;
+  RSX_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->d_in.ptr, job.in.pitch_bytes, in->data,
+                                      in->pitch_bytes, in_w, size_t(in->dim_y),
+                                      hipMemcpyHostToDevice, s));
+  rsx_plan* plan = nullptr;
+  if (int st = rsx_sraw_plan_create(ctx, 1, &job, &plan))
+    return st;
+  int rc = rsx_plan_run(plan, ctx->d_in.ptr, ctx->d_out.ptr, s);
+  if (rc == RSX_OK) {
+    hipError_t e = hipMemcpy2DAsync(out->data, out->pitch_bytes, ctx->d_out.ptr,
+                                    job.img.pitch_bytes, out_w, size_t(out->dim_y),
+                                    hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+      ctx->last_error = std::string("sraw D2H: ") + hipGetErrorString(e);
+      rc = RSX_ERR_DEVICE;
+    }
+  }
+  rsx_plan_destroy(plan);
+  return rc;
 }
 
 extern "C" int rsx_nikon_validate(const rsx_nikon_desc* d, const rsx_image* img) {

@@ -57,4 +57,23 @@ hipError_t launch_unpack(int order, const UnpackJobDev* d_jobs,
                          uint32_t total_blocks, const void* in_base,
                          void* out_base, hipStream_t stream);
 
+// One Cr2sRawInterpolator job, flattened for the kernel (rsx_sraw.hip).
+struct SrawJobDev {
+  uint64_t in_offset;  // subsampled image, relative to the plan's input base
+  uint64_t out_offset; // interpolated image, relative to the output base
+  uint32_t in_pitch, out_pitch; // bytes
+  uint32_t rows;       // input rows
+  uint32_t num_mcus;   // groups per input row
+  uint32_t gs;         // samples per group: 4 (4:2:2) or 6 (4:2:0)
+  uint32_t version;
+  int32_t coeffs[3];
+  int32_t hue;
+  uint32_t blocks_per_row;
+};
+
+uint32_t sraw_blocks_for(SrawJobDev* j);
+hipError_t launch_sraw(const SrawJobDev* d_jobs, const uint32_t* d_block_start, int n_jobs,
+                       uint32_t total_blocks, const bool versions[3], const void* in_base,
+                       void* out_base, hipStream_t stream);
+
 } // namespace rsx

@@ -604,6 +604,29 @@ void build_device_table_explicit(const uint8_t* enc_len, const uint8_t* diff_len
   }
 }
 
+// Cr2sRawInterpolator::interpolate (interpolators/Cr2sRawInterpolator.cpp:510-542) and
+// the shapes Cr2Decoder::sRawInterpolate sets up (Cr2Decoder.cpp:589-601)
+int validate_sraw(const rsx_sraw_desc& d, const rsx_image& in, const rsx_image& out) {
+  if (d.version < 0 || d.version > 2) // invariant :511
+    return RSX_ERR_INVALID_ARG;
+  if (d.subsampling_y != 1 && d.subsampling_y != 2) // "Unknown subsampling" :540-541
+    return RSX_ERR_INVALID_ARG;
+  if (d.subsampling_y == 2 && d.version == 0) // "no known sraws with version 0" :529-538
+    return RSX_ERR_INVALID_ARG;
+  const int gs = 2 + 2 * d.subsampling_y;
+  if (in.cpp != 1 || out.cpp != 3)
+    return RSX_ERR_INVALID_ARG;
+  if (in.dim_x <= 0 || in.dim_y <= 0 || in.dim_x % gs != 0) // :104, :201
+    return RSX_ERR_INVALID_ARG;
+  const int mcus = in.dim_x / gs;
+  if (mcus <= 1) // invariant(numMCUs > 1) :106, :203
+    return RSX_ERR_INVALID_ARG;
+  // Cr2Decoder.cpp:589-596: the output is 2 pixels per group wide, y * rows high
+  if (out.dim_x != 2 * mcus || out.dim_y != d.subsampling_y * in.dim_y)
+    return RSX_ERR_INVALID_ARG;
+  return RSX_OK;
+}
+
 // TableLookUp::setTable, dither branch (common/TableLookUp.cpp:66-84).  Only
 // the first 32768 entries can be addressed: the index is clampBits(pred, 15).
 void build_dither_table(const uint16_t* curve, int n, std::vector<uint32_t>* out) {

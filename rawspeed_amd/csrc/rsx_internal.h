@@ -29,6 +29,7 @@ int validate_cr2(const rsx_cr2_desc& d, const rsx_image& img);
 int validate_nikon(const rsx_nikon_desc& d, const rsx_image& img);
 int validate_pentax(const rsx_pentax_desc& d, const rsx_image& img);
 int validate_samsung_v1(const rsx_samsung_v1_desc& d, const rsx_image& img);
+int validate_sraw(const rsx_sraw_desc& d, const rsx_image& in, const rsx_image& out);
 
 // TableLookUp::setTable with dither (common/TableLookUp.cpp:50-84), 15-bit domain
 void build_dither_table(const uint16_t* curve, int n, std::vector<uint32_t>* out);

@@ -21,7 +21,7 @@ from oracle_lib import Ref  # noqa: E402
 def main():
     ref = Ref()
     out = {"unpack": {}, "f32": {}, "variant": {}, "ljpeg": {}, "cr2": {}, "nikon": {},
-           "pentax": {}, "samsung_v1": {}}
+           "pentax": {}, "samsung_v1": {}, "sraw": {}}
     for i, c in enumerate(G.UNPACK_CASES):
         d, data, (w, h, cpp) = G.build_unpack(c)
         img = ref.image(w, h, cpp)
@@ -64,6 +64,12 @@ def main():
         img = ref.image(w, h, cpp)
         st = ref.samsung_v1(12, data, img)
         out["samsung_v1"][c["name"]] = {"status": st, "hash": G.image_hash(img.pixels())}
+    for c in G.SRAW_CASES:
+        d, px, (iw, ih), (ow, oh) = G.build_sraw(c)
+        src, dst = ref.image(iw, ih, 1, False), ref.image(ow, oh, 3, False)
+        src.set_pixels(px)
+        st = ref.sraw(d, src, dst)
+        out["sraw"][c["name"]] = {"status": st, "hash": G.image_hash(dst.pixels())}
     path = os.path.join(HERE, "golden_hashes.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

@@ -274,3 +274,38 @@ def build_samsung_v1(c, seed=616):
         data, _ = synth.prefix_encode(src, [0, 0, 0, 0], synth.SAMSUNG_V1_TAB)
         data = np.concatenate([data, np.zeros(8, np.uint8)])
     return d, data, (w, h, 1), src
+
+
+# ---- Cr2sRawInterpolator -----------------------------------------------------------
+# (version, subsampling_y, groups per row, input rows); hue and white-balance
+# coefficients in the range Cr2Decoder derives them (Cr2Decoder.cpp:560-625)
+SRAW_CASES = [
+    dict(name="422_v0", version=0, ysf=1, groups=24, rows=9),
+    dict(name="422_v1", version=1, ysf=1, groups=40, rows=6),
+    dict(name="422_v2", version=2, ysf=1, groups=2, rows=3),
+    dict(name="420_v1", version=1, ysf=2, groups=24, rows=9),
+    dict(name="420_v2", version=2, ysf=2, groups=40, rows=1),
+    dict(name="420_v2_two_groups", version=2, ysf=2, groups=2, rows=2),
+    dict(name="422_v2_medium", version=2, ysf=1, groups=1296, rows=200),
+    dict(name="420_v1_medium", version=1, ysf=2, groups=990, rows=160),
+    dict(name="420_v2_extreme", version=2, ysf=2, groups=64, rows=8, extreme=True),
+]
+
+
+def build_sraw(c, seed=717):
+    rng = np.random.default_rng([seed, sum(map(ord, c["name"]))])
+    gs = 2 + 2 * c["ysf"]
+    w = c["groups"] * gs
+    if c.get("extreme"):   # any 16-bit input, huge coefficients: int wrap-around paths
+        px = rng.integers(0, 65536, size=(c["rows"], w), dtype=np.uint16)
+        coeffs = [65535, 40000, 65535]
+        hue = 3000
+    else:
+        px = np.empty((c["rows"], w), np.uint16)
+        g = px.reshape(c["rows"], c["groups"], gs)
+        g[:, :, :gs - 2] = rng.integers(200, 15000, size=(c["rows"], c["groups"], gs - 2))
+        g[:, :, gs - 2:] = rng.integers(16384 - 3000, 16384 + 3000, size=(c["rows"], c["groups"], 2))
+        coeffs = [int(x) for x in rng.integers(800, 2600, size=3)]
+        hue = int(rng.integers(-600, 600))
+    d = abi.SrawDesc.make(c["version"], c["ysf"], coeffs, hue)
+    return d, px, (w, c["rows"]), (2 * c["groups"], c["ysf"] * c["rows"])

@@ -97,6 +97,8 @@ class Oracle:
         L.oracle_unpack_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.oracle_unpack_f32_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.oracle_unpack_variant_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.oracle_sraw_validate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_sraw_interpolate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_nikon_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_pentax_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_samsung_v1_validate.argtypes = [C.c_void_p, C.c_void_p]
@@ -168,6 +170,14 @@ class Oracle:
     def pentax_validate(self, desc, img):
         v = img.view()
         return self.lib.oracle_pentax_validate(C.byref(desc), C.byref(v))
+
+    def sraw(self, desc, img_in, img_out):
+        a, b = img_in.view(), img_out.view()
+        return self.lib.oracle_sraw_interpolate(C.byref(desc), C.byref(a), C.byref(b))
+
+    def sraw_validate(self, desc, img_in, img_out):
+        a, b = img_in.view(), img_out.view()
+        return self.lib.oracle_sraw_validate(C.byref(desc), C.byref(a), C.byref(b))
 
     def nikon_validate(self, desc, img):
         v = img.view()
@@ -246,6 +256,10 @@ class RefImage:
     def pixels(self):
         return self.u16()[:, :self.dim_x * self.cpp]
 
+    def set_pixels(self, px):
+        """Copy a (dim_y, dim_x * cpp) uint16 array into the image."""
+        self.u16()[:, :px.shape[1]] = px
+
     def set_subsampling(self, x, y):
         """RawImageData::metadata.subsampling (sRaw files)."""
         self.ref.lib.ref_image_set_subsampling(self.h, x, y)
@@ -286,6 +300,7 @@ class Ref:
         L.ref_samsung_v1_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.ref_pentax_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                             C.c_void_p, C.c_size_t]
+        L.ref_sraw_interpolate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.ref_nikon_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
                                            C.c_void_p, C.c_size_t, C.c_int]
         L.ref_ljpeg_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
@@ -335,6 +350,9 @@ class Ref:
             return self.lib.ref_pentax_decompress(img.h, None, 0, p, n)
         m, mp, mn = _as_u8(meta)
         return self.lib.ref_pentax_decompress(img.h, mp, mn, p, n)
+
+    def sraw(self, desc, img_in, img_out):
+        return self.lib.ref_sraw_interpolate(img_in.h, img_out.h, C.byref(desc))
 
     def nikon(self, meta, bits_ps, data, img, uncorrected):
         m, mp, mn = _as_u8(meta)

@@ -241,6 +241,27 @@ def test_samsung_v1_validate_matches_oracle(lib, oracle):
     assert seen == {abi.RSX_OK, abi.RSX_ERR_INVALID_ARG}
 
 
+def test_sraw_validate_matches_oracle(lib, oracle):
+    rng = np.random.default_rng(17)
+    seen = set()
+    for trial in range(1000):
+        ysf = int(rng.choice([1, 2, 2, 3]))
+        gs = 2 + 2 * min(ysf, 2)
+        groups = int(rng.choice([1, 2, 5, 40]))
+        rows = int(rng.choice([1, 2, 7]))
+        a = HostImage(8, 2, int(rng.choice([1, 1, 1, 3])))
+        b = HostImage(8, 2, int(rng.choice([3, 3, 3, 1])))
+        a.dim_x, a.dim_y = groups * gs + int(rng.choice([0, 0, 0, 1])), rows
+        b.dim_x = 2 * groups + int(rng.choice([0, 0, 0, 2]))
+        b.dim_y = min(ysf, 2) * rows + int(rng.choice([0, 0, 0, 1]))
+        d = abi.SrawDesc.make(int(rng.integers(-1, 4)), ysf, [1000, 1024, 1100], 0)
+        va, vb = a.view(), b.view()
+        x = lib.rsx_sraw_validate(C.byref(d), C.byref(va), C.byref(vb))
+        assert x == oracle.sraw_validate(d, a, b), trial
+        seen.add(x)
+    assert seen == {abi.RSX_OK, abi.RSX_ERR_INVALID_ARG}
+
+
 def test_cr2_validate_matches_oracle(lib, oracle):
     import cases as cs
     rng = np.random.default_rng(13)

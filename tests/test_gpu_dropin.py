@@ -253,3 +253,19 @@ def test_samsung_v1_decompressor(pair):
         assert s0 == s1, (e0, e1)
         if s0 == 0:
             assert np.array_equal(a, b)
+
+
+def test_sraw_interpolator(pair):
+    """Cr2sRawInterpolator::interpolate through the patched class."""
+    import golden_cases as G
+    for name in ("422_v0", "422_v2_medium", "420_v1_medium", "420_v2_extreme"):
+        c = next(c for c in G.SRAW_CASES if c["name"] == name)
+        d, px, (iw, ih), (ow, oh) = G.build_sraw(c)
+        out = []
+        for lib in pair:
+            src, dst = lib.image(iw, ih, 1, False), lib.image(ow, oh, 3, False)
+            src.set_pixels(px)
+            out.append((lib.sraw(d, src, dst), dst.u16().copy(), lib.last_error()))
+        (s0, a, e0), (s1, b, e1) = out
+        assert s0 == 0 and s1 == 0, (e0, e1)
+        assert np.array_equal(a, b)

@@ -330,3 +330,52 @@ def test_constant_frame(gpu, oracle, value):
     assert so[0] == 0 and gpu.cr2_decode(d, data, img.view()) == so
     assert np.array_equal(img.u16(), want.u16())
     assert np.array_equal(img.pixels(), src)
+
+
+# ---- Cr2sRawInterpolator --------------------------------------------------------
+
+@pytest.mark.parametrize("c", G.SRAW_CASES, ids=lambda c: c["name"])
+def test_sraw_interpolate_golden(gpu, oracle, c):
+    d, px, (iw, ih), (ow, oh) = G.build_sraw(c)
+    src = HostImage(iw, ih, 1, is_cfa=False)
+    src.pixels()[:] = px
+    got, want = HostImage(ow, oh, 3, is_cfa=False), HostImage(ow, oh, 3, is_cfa=False)
+    assert gpu.sraw_interpolate(d, src.view(), got.view()) == oracle.sraw(d, src, want) == 0
+    assert np.array_equal(got.u16(), want.u16())
+    assert G.image_hash(got.pixels()) == GOLD["sraw"][c["name"]]["hash"]
+
+
+def test_sraw_decode_then_interpolate_on_device(gpu, oracle):
+    """The Cr2Decoder sRaw flow without leaving HBM: Cr2Decompressor <3,2,2> plan,
+    then the interpolation plan on its output buffer."""
+    import gpu_util
+    rng = np.random.default_rng(77)
+    d, data, src, _ = C.make_cr2_sraw_case(rng, 2, (3, 160, 128), 120)
+    h, w = src.shape
+    j = abi.Cr2Job()
+    j.desc = d
+    j.in_offset, j.in_bytes, j.img_offset = 0, data.size, 0
+    sub_pitch = out_pitch(w, 1)
+    j.img = gpu_util.image_job_view(w, h, 1, sub_pitch, is_cfa=False)
+    d_in = gpu_util.to_dev(np.concatenate([data, np.zeros(64, np.uint8)]))
+    d_sub = torch.zeros(sub_pitch * h, dtype=torch.uint8, device="cuda")
+    p1 = gpu.cr2_plan([j])
+    p1.run(d_in.data_ptr(), d_sub.data_ptr())
+    assert p1.results()[:2] == (0, [0])
+    sd = abi.SrawDesc.make(2, 2, [2000, 1024, 1500], -120)
+    ow, oh = 2 * (w // 6), 2 * h
+    want_sub, want = HostImage(w, h, 1, is_cfa=False), HostImage(ow, oh, 3, is_cfa=False)
+    want_sub.pixels()[:] = src
+    assert oracle.sraw(sd, want_sub, want) == 0
+    sj = abi.SrawJob()
+    sj.desc = sd
+    sj.in_offset, sj.img_offset = 0, 0
+    sj.in_ = gpu_util.image_job_view(w, h, 1, sub_pitch, is_cfa=False)
+    sj.img = gpu_util.image_job_view(ow, oh, 3, want.pitch, is_cfa=False)
+    d_out = torch.full((want.buf.size,), 0xA5, dtype=torch.uint8, device="cuda")
+    p2 = gpu.sraw_plan([sj])
+    p2.run(d_sub.data_ptr(), d_out.data_ptr())
+    assert p2.results()[:2] == (0, [0])
+    assert np.array_equal(d_out.cpu().numpy(), want.buf)
+    p1.close()
+    p2.close()

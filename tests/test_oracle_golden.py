@@ -108,7 +108,27 @@ def test_samsung_v1_golden(oracle, c):
         assert np.array_equal(img.pixels(), src)
 
 
+@pytest.mark.parametrize("c", G.SRAW_CASES, ids=lambda c: c["name"])
+def test_sraw_golden(oracle, c):
+    d, px, (iw, ih), (ow, oh) = G.build_sraw(c)
+    src, dst = HostImage(iw, ih, 1, is_cfa=False), HostImage(ow, oh, 3, is_cfa=False)
+    src.pixels()[:] = px
+    assert oracle.sraw(d, src, dst) == GOLD["sraw"][c["name"]]["status"] == 0
+    assert G.image_hash(dst.pixels()) == GOLD["sraw"][c["name"]]["hash"]
+
+
 # ---- live cross-checks against the compiled reference ----------------------
+
+@pytest.mark.parametrize("c", G.SRAW_CASES, ids=lambda c: c["name"])
+def test_sraw_vs_ref(oracle, ref, c):
+    d, px, (iw, ih), (ow, oh) = G.build_sraw(c)
+    src, dst = HostImage(iw, ih, 1, is_cfa=False), HostImage(ow, oh, 3, is_cfa=False)
+    src.pixels()[:] = px
+    rsrc, rdst = ref.image(iw, ih, 1, False), ref.image(ow, oh, 3, False)
+    rsrc.set_pixels(px)
+    assert oracle.sraw(d, src, dst) == ref.sraw(d, rsrc, rdst) == 0, ref.last_error()
+    assert np.array_equal(dst.u16(), rdst.u16())
+
 
 def test_samsung_v1_vs_ref(oracle, ref):
     """Full buffers, and status parity at every cut of a truncated stream
