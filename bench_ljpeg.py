@@ -343,6 +343,59 @@ def run_nikon(ctx, torch, log, frames=8, steps=10, warmup=2, cpu=True):
     return out
 
 
+def run_hasselblad(ctx, torch, log, frames=4, steps=10, warmup=2, cpu=True):
+    """HasselbladDecompressor: 8272x6200 16-bit frames (H5D-50c class),
+    pair-coded symbols on an MSB32 stream."""
+    import cases
+    from rawspeed_amd import abi, synth
+    W, H = 8272, 6200
+    src = synth.sensor_image(W, H, 14, seed=11)
+    data, sym_bits = synth.hasselblad_encode(src, 0x2000, cases.FULL17)
+    data = np.concatenate([data, np.zeros(16 + (-len(data)) % 16, np.uint8)])
+    d = abi.HasselbladDesc.make(cases.FULL17, 0x2000)
+    jobs = []
+    for f in range(frames):
+        j = abi.HasselbladJob()
+        j.desc = d
+        j.in_offset, j.in_bytes = f * data.size, data.size
+        j.img_offset = f * out_pitch(W) * H
+        j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
+            out_pitch(W), W, H, 1, 1
+        jobs.append(j)
+    inp = torch.from_numpy(np.tile(data, frames)).cuda()
+    outb = torch.zeros(frames * out_pitch(W) * H, dtype=torch.uint8, device="cuda")
+    plan = ctx.hasselblad_plan(jobs)
+    dt, kt, _ = _time_plan(torch, plan, inp, outb, steps, warmup)
+    plan.close()
+    got = outb[-out_pitch(W) * H:].cpu().numpy().view(np.uint16).reshape(
+        H, out_pitch(W) // 2)[:, :W]
+    out = {"workload": "HasselbladDecompressor %dx%d, %d frames/step" % (W, H, frames),
+           "mpix_per_s": round(frames * W * H / dt / 1e6, 1),
+           "ms_per_step": round(dt * 1e3, 4),
+           "bit_exact": bool(np.array_equal(got, src)),
+           "entropy_bits_per_px": round(sym_bits / (W * H), 3)}
+    if cpu:
+        try:
+            from oracle_lib import Ref
+            if Ref.available():
+                ref = Ref()
+                img = ref.image(W, H, 1)
+                assert ref.hasselblad(d, data, img)[0] == 0
+                times = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    ref.hasselblad(d, data, img)
+                    times.append(time.perf_counter() - t0)
+                out["cpu_baseline"] = {
+                    "value": round(W * H / min(times) / 1e6, 1), "unit": "MPix/s", "cores": 1,
+                    "kind": "reference",
+                    "sample": "HasselbladDecompressor::decompress of the unmodified reference on "
+                              "the same stream, 1 thread, best of 3"}
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
 def run_variants(ctx, torch, log, frames=8, steps=50, warmup=20):
     """The fixed-layout UncompressedDecompressor entry points at the
     cfg2 sensor size: decode12BitRawWithControl<big>, decode12BitRawUnpacked-
@@ -397,6 +450,10 @@ def run(ctx, torch, log):
     except Exception as e:
         out["nikon_lossless14_6016x4016"] = {"error": repr(e)}
     try:
+        out["hasselblad_8272x6200"] = run_hasselblad(ctx, torch, log)
+    except Exception as e:
+        out["hasselblad_8272x6200"] = {"error": repr(e)}
+    try:
         out["cr2_sraw1_3960x2640"] = run_sraw(ctx, torch, log)
     except Exception as e:
         out["cr2_sraw1_3960x2640"] = {"error": repr(e)}
@@ -429,6 +486,8 @@ if __name__ == "__main__":
     elif args.only == "nikon":
         print(json.dumps(run_nikon(ctx, torch, print, frames=args.frames, steps=args.steps),
                          indent=1))
+    elif args.only == "hasselblad":
+        print(json.dumps(run_hasselblad(ctx, torch, print, steps=args.steps), indent=1))
     elif args.only == "sraw":
         print(json.dumps(run_sraw(ctx, torch, print, frames=args.frames, steps=args.steps),
                          indent=1))

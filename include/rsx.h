@@ -346,6 +346,26 @@ int rsx_samsung_v1_decompress(rsx_ctx* ctx, const rsx_samsung_v1_desc* d,
                               const uint8_t* in, size_t in_bytes, const rsx_image* img);
 
 /* ------------------------------------------------------------------------ */
+/* 3e. HasselbladDecompressor                                                */
+/*    replaces HasselbladDecompressor::decompress()                          */
+/*    (decompressors/HasselbladDecompressor.h:53, .cpp:71-100): BitStreamer- */
+/*    MSB32 (little-endian 32-bit words, MSB first, no stuffing), pixels     */
+/*    coded two at a time as [len1 code][len2 code][len1 bits][len2 bits]    */
+/*    with one PrefixCodeDecoder<> used for its code VALUES only             */
+/*    (decodeCodeValue), getBits (.cpp:60-69: JPEG sign extension, all-ones  */
+/*    16-bit field = -32768), both predictors restart from initPred on every */
+/*    row, results stored mod 2^16.  Returns getStreamPosition().            */
+/* ------------------------------------------------------------------------ */
+typedef struct rsx_hasselblad_desc {
+  rsx_huff_table table; /* rec.ht (values = difference lengths 0..16) */
+  uint16_t init_pred;   /* rec.initPred */
+} rsx_hasselblad_desc;
+
+int rsx_hasselblad_validate(const rsx_hasselblad_desc* d, const rsx_image* img);
+int rsx_hasselblad_decompress(rsx_ctx* ctx, const rsx_hasselblad_desc* d, const uint8_t* in,
+                              size_t in_bytes, const rsx_image* img, uint32_t* consumed);
+
+/* ------------------------------------------------------------------------ */
 /* 4. AbstractDngDecompressor tile fan-out                                   */
 /*    replaces AbstractDngDecompressor::decompress()                         */
 /*    (AbstractDngDecompressor.h:141, .cpp:240-252) for compression 1        */
@@ -450,6 +470,14 @@ typedef struct rsx_sraw_job {
   rsx_image img; /* .data ignored */
 } rsx_sraw_job;
 
+typedef struct rsx_hasselblad_job {
+  rsx_hasselblad_desc desc;
+  uint64_t in_offset;
+  uint64_t in_bytes;
+  uint64_t img_offset;
+  rsx_image img; /* .data ignored */
+} rsx_hasselblad_job;
+
 typedef struct rsx_samsung_v1_job {
   rsx_samsung_v1_desc desc;
   uint64_t in_offset;
@@ -480,6 +508,8 @@ int rsx_samsung_v1_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_samsung_v1_jo
                                rsx_plan** out_plan);
 int rsx_sraw_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_sraw_job* jobs,
                          rsx_plan** out_plan);
+int rsx_hasselblad_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_hasselblad_job* jobs,
+                               rsx_plan** out_plan);
 /* Enqueue one pass of the plan on `stream`. */
 int rsx_plan_run(rsx_plan* plan, const void* in_dev, void* out_dev,
                  void* stream);

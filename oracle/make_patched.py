@@ -240,6 +240,22 @@ HUNK_SRAW = r'''
   }
 '''
 
+HUNK_HASSELBLAD = r'''
+  // ---- rsx: forward to the MI355X core (INTEGRATION.md 3e) ----
+  {
+    rec.ht.verifyCodeValuesAsDiffLengths();
+    rsx_hasselblad_desc d{};
+    d.table = rsx_shim::table(rec.ht);
+    d.init_pred = rec.initPred;
+    const rsx_image img = rsx_shim::view(mRaw);
+    uint32_t consumed = 0;
+    if (int st = rsx_hasselblad_decompress(rsx_shim::context(), &d, input.begin(),
+                                           implicit_cast<size_t>(input.size()), &img, &consumed))
+      rsx_shim::raise(st);
+    return consumed;
+  }
+'''
+
 PATCHES = [
     ("decompressors/UncompressedDecompressor.cpp", [
         ("void UncompressedDecompressor::readUncompressedRaw() {", HUNK_UNPACK),
@@ -256,6 +272,8 @@ PATCHES = [
         ("void SamsungV1Decompressor::decompress() const {", HUNK_SAMSUNG_V1)]),
     ("interpolators/Cr2sRawInterpolator.cpp", [
         ("void Cr2sRawInterpolator::interpolate(int version) {", HUNK_SRAW)]),
+    ("decompressors/HasselbladDecompressor.cpp", [
+        ("ByteStream::size_type HasselbladDecompressor::decompress() {", HUNK_HASSELBLAD)]),
     ("decompressors/LJpegDecompressor.cpp", [
         ("ByteStream::size_type LJpegDecompressor::decode() const {", HUNK_LJPEG)]),
     ("decompressors/Cr2DecompressorImpl.h", [

@@ -27,6 +27,7 @@
 #include "decompressors/AbstractDngDecompressor.h"
 #include "decompressors/Cr2Decompressor.h"
 #include "decompressors/Cr2LJpegDecoder.h"
+#include "decompressors/HasselbladDecompressor.h"
 #include "decompressors/LJpegDecoder.h"
 #include "decompressors/LJpegDecompressor.h"
 #include "decompressors/NikonDecompressor.h"
@@ -361,6 +362,29 @@ int ref_sraw_interpolate(void* h_in, void* h_out, const rsx_sraw_desc* d) {
     Cr2sRawInterpolator i(out->img, in->img->getU16DataAsUncroppedArray2DRef(),
                           {d->sraw_coeffs[0], d->sraw_coeffs[1], d->sraw_coeffs[2]}, d->hue);
     i.interpolate(d->version);
+  });
+}
+
+// HasselbladDecompressor, set up like HasselbladLJpegDecoder::decodeScan
+// (HasselbladLJpegDecoder.cpp:50-66) with a non-full-decode table
+int ref_hasselblad_decompress(void* h, const rsx_hasselblad_desc* d, const uint8_t* in,
+                              size_t in_bytes, uint32_t* consumed) {
+  auto* r = static_cast<RefImage*>(h);
+  return guarded([&] {
+    HuffmanCode<BaselineCodeTag> hc;
+    const Buffer nb(d->table.n_codes_per_length, 16);
+    const auto n = hc.setNCodesPerLength(nb);
+    if (n != d->table.n_code_values)
+      ThrowRDE("code value count mismatch");
+    hc.setCodeValues(Array1DRef<const uint8_t>(d->table.code_values, implicit_cast<int>(n)));
+    PrefixCodeDecoder<> ht(std::move(hc));
+    ht.setup(/*fullDecode=*/false, /*fixDNGBug16=*/false);
+    const HasselbladDecompressor::PerComponentRecipe rec = {ht, d->init_pred};
+    HasselbladDecompressor dec(r->img, rec,
+                               Array1DRef<const uint8_t>(in, implicit_cast<int>(in_bytes)));
+    const auto c = dec.decompress();
+    if (consumed)
+      *consumed = c;
   });
 }
 

@@ -1617,3 +1617,100 @@ int oracle_sraw_interpolate(const rsx_sraw_desc* d, const rsx_image* in,
   return RSX_OK;
 }
 
+/* ======================================================================== */
+/* HasselbladDecompressor (decompressors/HasselbladDecompressor.cpp)          */
+/* ======================================================================== */
+
+int oracle_hasselblad_validate(const rsx_hasselblad_desc* d, const rsx_image* img) {
+  if (img->cpp != 1)
+    return RSX_ERR_INVALID_ARG; /* :44-45 */
+  if (img->dim_x <= 0 || img->dim_y <= 0 || img->dim_x % 2 != 0 ||
+      img->dim_x > 12000 || img->dim_y > 8842)
+    return RSX_ERR_INVALID_ARG; /* :48-52 */
+  hufftab h;
+  int st = huff_setup(&h, &d->table); /* incl. verifyCodeValuesAsDiffLengths :80 */
+  if (st)
+    return st;
+  if (d->table.fix_dng_bug16)
+    return RSX_ERR_INVALID_ARG;
+  return RSX_OK;
+}
+
+/* PrefixCodeLookupDecoder::decodeCodeValue: fill(32), then the code walk */
+static int huff_decode_value(const hufftab* h, bitreader* b, int* err) {
+  br_fill(b, 32);
+  if (b->err) {
+    *err = b->err;
+    return 0;
+  }
+  uint32_t code = 0;
+  int len = 0;
+  while (len < h->max_len &&
+         (h->max_code[len] == 0xFFFFFFFFu || code > h->max_code[len])) {
+    code = (code << 1) | br_get_nofill(b, 1);
+    ++len;
+  }
+  if (len > h->max_len || h->max_code[len] == 0xFFFFFFFFu || code > h->max_code[len]) {
+    *err = RSX_ERR_BAD_HUFFMAN_CODE;
+    return 0;
+  }
+  return h->values[(code - h->code_offset[len]) & 0xFFFFu];
+}
+
+/* getBits :60-69 */
+static int hb_get_bits(bitreader* b, int len, int* err) {
+  if (!len)
+    return 0;
+  const uint32_t v = br_get(b, len);
+  if (b->err) {
+    *err = b->err;
+    return 0;
+  }
+  int diff = (int)v;
+  if ((v & (1u << (len - 1))) == 0)
+    diff -= (1 << len) - 1; /* PrefixCodeDecoder<>::extend */
+  if (diff == 65535)
+    return -32768;
+  return diff;
+}
+
+/* decompress :71-100; *consumed = bitStreamer.getStreamPosition() =
+ * getInputPosition() - (fillLevel >> 3) (BitStreamer.h:238-241) */
+int oracle_hasselblad_decompress(const rsx_hasselblad_desc* d, const uint8_t* in,
+                                 size_t in_bytes, const rsx_image* img,
+                                 uint32_t* consumed) {
+  int st = oracle_hasselblad_validate(d, img);
+  if (st)
+    return st;
+  hufftab h;
+  huff_setup(&h, &d->table);
+  bitreader b;
+  br_init(&b, in, (int64_t)in_bytes, RSX_ORDER_MSB32);
+  if (b.err)
+    return b.err;
+  int err = 0;
+  for (int row = 0; row < img->dim_y; ++row) {
+    uint16_t* o = (uint16_t*)((uint8_t*)img->data + (size_t)row * img->pitch_bytes);
+    int p1 = d->init_pred, p2 = d->init_pred;
+    for (int col = 0; col < img->dim_x; col += 2) {
+      const int len1 = huff_decode_value(&h, &b, &err);
+      if (err)
+        return err;
+      const int len2 = huff_decode_value(&h, &b, &err);
+      if (err)
+        return err;
+      p1 += hb_get_bits(&b, len1, &err);
+      if (err)
+        return err;
+      p2 += hb_get_bits(&b, len2, &err);
+      if (err)
+        return err;
+      o[col] = (uint16_t)p1;
+      o[col + 1] = (uint16_t)p2;
+    }
+  }
+  if (consumed)
+    *consumed = (uint32_t)(b.pos - (b.fill >> 3));
+  return RSX_OK;
+}
+

@@ -169,6 +169,23 @@ class SrawJob(C.Structure):
                 ("in_", Image), ("img", Image)]
 
 
+class HasselbladDesc(C.Structure):
+    _fields_ = [("table", HuffTable), ("init_pred", C.c_uint16)]
+
+    @classmethod
+    def make(cls, table, init_pred):
+        d = cls()
+        d.table = HuffTable.make(*table)
+        d.init_pred = init_pred
+        return d
+
+
+class HasselbladJob(C.Structure):
+    _fields_ = [("desc", HasselbladDesc), ("in_offset", C.c_uint64),
+                ("in_bytes", C.c_uint64), ("img_offset", C.c_uint64),
+                ("img", Image)]
+
+
 class DngLJpegTile(C.Structure):
     _fields_ = [("desc", LJpegDesc), ("in_", C.c_void_p),
                 ("in_bytes", C.c_size_t)]

@@ -25,6 +25,7 @@ EXPORTS = [
     "rsx_sraw_validate", "rsx_sraw_interpolate", "rsx_sraw_plan_create",
     "rsx_nikon_validate", "rsx_nikon_decompress", "rsx_nikon_plan_create",
     "rsx_pentax_validate", "rsx_pentax_decompress", "rsx_pentax_plan_create",
+    "rsx_hasselblad_validate", "rsx_hasselblad_decompress", "rsx_hasselblad_plan_create",
     "rsx_samsung_v1_validate", "rsx_samsung_v1_decompress", "rsx_samsung_v1_plan_create",
     "rsx_dng_decompress_ljpeg", "rsx_dng_decompress_uncompressed",
     "rsx_unpack_plan_create", "rsx_ljpeg_plan_create", "rsx_cr2_plan_create",
@@ -80,6 +81,9 @@ def lib():
         L.rsx_sraw_interpolate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rsx_nikon_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.rsx_pentax_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.rsx_hasselblad_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.rsx_hasselblad_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_size_t, C.c_void_p, C.c_void_p]
         L.rsx_samsung_v1_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.rsx_samsung_v1_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p]
@@ -95,7 +99,7 @@ def lib():
                      "rsx_cr2_plan_create", "rsx_unpack_variant_plan_create",
                      "rsx_nikon_plan_create", "rsx_unpack_f32_plan_create",
                      "rsx_pentax_plan_create", "rsx_samsung_v1_plan_create",
-                     "rsx_sraw_plan_create"):
+                     "rsx_sraw_plan_create", "rsx_hasselblad_plan_create"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p,
                                          C.POINTER(C.c_void_p)]
         L.rsx_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -185,6 +189,13 @@ class Context:
         return lib().rsx_pentax_decompress(self._h, C.byref(desc), a.ctypes.data, a.size,
                                            C.byref(img_view))
 
+    def hasselblad_decompress(self, desc, data, img_view):
+        a = _u8(data)
+        consumed = C.c_uint32(0)
+        st = lib().rsx_hasselblad_decompress(self._h, C.byref(desc), a.ctypes.data, a.size,
+                                             C.byref(img_view), C.byref(consumed))
+        return st, consumed.value
+
     def samsung_v1_decompress(self, desc, data, img_view):
         a = _u8(data)
         return lib().rsx_samsung_v1_decompress(self._h, C.byref(desc), a.ctypes.data,
@@ -232,6 +243,9 @@ class Context:
 
     def cr2_plan(self, jobs):
         return Plan(self, "rsx_cr2_plan_create", abi.Cr2Job, jobs)
+
+    def hasselblad_plan(self, jobs):
+        return Plan(self, "rsx_hasselblad_plan_create", abi.HasselbladJob, jobs)
 
     def samsung_v1_plan(self, jobs):
         return Plan(self, "rsx_samsung_v1_plan_create", abi.SamsungV1Job, jobs)

@@ -1154,6 +1154,65 @@ extern "C" int rsx_pentax_plan_create(rsx_ctx* ctx, int n_jobs,
   return RSX_OK;
 }
 
+extern "C" int rsx_hasselblad_validate(const rsx_hasselblad_desc* d, const rsx_image* img) {
+  if (!d || !img)
+    return RSX_ERR_INVALID_ARG;
+  return validate_hasselblad(*d, *img);
+}
+
+extern "C" int rsx_hasselblad_plan_create(rsx_ctx* ctx, int n_jobs,
+                                          const rsx_hasselblad_job* jobs,
+                                          rsx_plan** out_plan) {
+  if (!ctx || !jobs || n_jobs < 1 || !out_plan)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto plan = std::make_unique<rsx_plan>();
+  plan->ctx = ctx;
+  plan->kind = PLAN_LJPEG;
+  plan->n_jobs = n_jobs;
+  std::vector<LJpegJobIn> in(n_jobs);
+  for (int i = 0; i < n_jobs; ++i) {
+    const rsx_image& img = jobs[i].img;
+    LJpegJobIn& J = in[i];
+    J.status = validate_hasselblad(jobs[i].desc, img);
+    if (J.status == RSX_OK && img.pitch_bytes % 2 != 0)
+      J.status = RSX_ERR_INVALID_ARG;
+    if (J.status != RSX_OK)
+      continue;
+    StreamGeom& g = J.geom;
+    std::memset(&g, 0, sizeof g);
+    g.kind = 0; // rows of W samples written in place, like an LJPEG tile that is the image
+    g.raw = 1;  // BitStreamerMSB32: no stuffing, no markers, 8-byte over-read budget
+    g.pair = 1;
+    g.no_vertical = 1; // "int p1 = rec.initPred; int p2 = rec.initPred;" per row (:83-85)
+    g.in_offset = jobs[i].in_offset;
+    g.in_bytes = jobs[i].in_bytes;
+    g.img_offset = jobs[i].img_offset;
+    g.img_pitch_bytes = img.pitch_bytes;
+    g.n_comp = 2; // p1 / p2 alternate along the row (:86-96)
+    g.period = 2;
+    g.pred_of_phase[0] = 0;
+    g.pred_of_phase[1] = 1;
+    g.init_pred[0] = g.init_pred[1] = jobs[i].desc.init_pred;
+    g.seed_pos[0] = 0;
+    g.seed_pos[1] = 1;
+    g.rows = uint32_t(img.dim_y);
+    g.row_samples = uint32_t(img.dim_x);
+    g.mcu_w = 2;
+    g.mcu_h = 1;
+    g.keep_samples = g.row_samples;
+    J.tables = &jobs[i].desc.table;
+    J.n_tables = 1;
+  }
+  LJpegPlan* lp = nullptr;
+  if (int st = ljpeg_plan_create(ctx, in, &lp))
+    return st;
+  plan->ljpeg.reset(lp);
+  *out_plan = plan.release();
+  return RSX_OK;
+}
+
 extern "C" int rsx_samsung_v1_validate(const rsx_samsung_v1_desc* d, const rsx_image* img) {
   if (!d || !img)
     return RSX_ERR_INVALID_ARG;
@@ -1236,6 +1295,9 @@ HostRect out_rect(const rsx_pentax_job& j) {
   return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
 }
 HostRect out_rect(const rsx_samsung_v1_job& j) {
+  return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
+}
+HostRect out_rect(const rsx_hasselblad_job& j) {
   return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
 }
 
@@ -1355,6 +1417,23 @@ extern "C" int rsx_pentax_decompress(rsx_ctx* ctx, const rsx_pentax_desc* d,
   jobs[0].in_bytes = in_bytes;
   int32_t st = RSX_OK;
   return ljpeg_family_host(ctx, 1, jobs, &in, img, rsx_pentax_plan_create, &st, nullptr);
+}
+
+extern "C" int rsx_hasselblad_decompress(rsx_ctx* ctx, const rsx_hasselblad_desc* d,
+                                         const uint8_t* in, size_t in_bytes,
+                                         const rsx_image* img, uint32_t* consumed) {
+  if (!ctx || !d || !in || !img || !img->data)
+    return RSX_ERR_INVALID_ARG;
+  std::vector<rsx_hasselblad_job> jobs(1);
+  jobs[0].desc = *d;
+  jobs[0].in_bytes = in_bytes;
+  int32_t st = RSX_OK;
+  uint32_t c = 0;
+  const int rc =
+      ljpeg_family_host(ctx, 1, jobs, &in, img, rsx_hasselblad_plan_create, &st, &c);
+  if (consumed)
+    *consumed = c;
+  return rc;
 }
 
 extern "C" int rsx_samsung_v1_decompress(rsx_ctx* ctx, const rsx_samsung_v1_desc* d,

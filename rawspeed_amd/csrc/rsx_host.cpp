@@ -627,6 +627,21 @@ int validate_sraw(const rsx_sraw_desc& d, const rsx_image& in, const rsx_image& 
   return RSX_OK;
 }
 
+// HasselbladDecompressor::HasselbladDecompressor (HasselbladDecompressor.cpp:37-57) and
+// ht.verifyCodeValuesAsDiffLengths() (:80)
+int validate_hasselblad(const rsx_hasselblad_desc& d, const rsx_image& img) {
+  if (img.cpp != 1) // :44-45
+    return RSX_ERR_INVALID_ARG;
+  if (img.dim_x <= 0 || img.dim_y <= 0 || img.dim_x % 2 != 0 || img.dim_x > 12000 ||
+      img.dim_y > 8842) // :48-52
+    return RSX_ERR_INVALID_ARG;
+  if (int st = validate_huff_table(d.table))
+    return st;
+  if (d.table.fix_dng_bug16)
+    return RSX_ERR_INVALID_ARG;
+  return RSX_OK;
+}
+
 // TableLookUp::setTable, dither branch (common/TableLookUp.cpp:66-84).  Only
 // the first 32768 entries can be addressed: the index is clampBits(pred, 15).
 void build_dither_table(const uint16_t* curve, int n, std::vector<uint32_t>* out) {

@@ -29,6 +29,7 @@ int validate_cr2(const rsx_cr2_desc& d, const rsx_image& img);
 int validate_nikon(const rsx_nikon_desc& d, const rsx_image& img);
 int validate_pentax(const rsx_pentax_desc& d, const rsx_image& img);
 int validate_samsung_v1(const rsx_samsung_v1_desc& d, const rsx_image& img);
+int validate_hasselblad(const rsx_hasselblad_desc& d, const rsx_image& img);
 int validate_sraw(const rsx_sraw_desc& d, const rsx_image& in, const rsx_image& out);
 
 // TableLookUp::setTable with dither (common/TableLookUp.cpp:50-84), 15-bit domain
@@ -119,6 +120,8 @@ struct StreamGeom {
   uint8_t raw;       // no FF00 un-stuffing, no markers, 8-byte over-read budget
   uint8_t start_bit; // the first symbol starts this many bits into in_offset
   uint8_t las;       // table 0 holds "lossy after split" values
+  uint8_t pair;      // Hasselblad: pair-coded symbols on an MSB32 stream
+  uint8_t no_vertical; // rows do not inherit predictors from the row above
   uint64_t raw_limit; // != 0: last bit offset at which a symbol may start
 };
 

@@ -251,8 +251,16 @@ __device__ __forceinline__ void lj_fix_regs(const uint32_t (&in)[LJ_BW + 1], uin
     B[u.ko * LJ_T + col] = 0u;
 }
 
+// End of the data the bit reader hands out before its zero padding.  An MSB32
+// reader consumes whole little-endian words: the bytes of a partial last word are
+// its LOW-order (= last) stream bits, so the data ends at the next word boundary.
+__device__ __forceinline__ uint64_t lj_data_end(const LjStreamDev& S) {
+  return S.pair ? (S.in_bytes + 3) & ~uint64_t(3) : S.in_bytes;
+}
+
 __device__ __forceinline__ int lj_valid_bytes(const LjStreamDev& S, uint32_t lb, int j) {
-  const int64_t vb = int64_t(S.in_bytes) - (int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P);
+  const int64_t vb =
+      int64_t(lj_data_end(S)) - (int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P);
   return vb < 0 ? 0 : (vb > 4 * LJ_BW ? 4 * LJ_BW : int(vb));
 }
 
@@ -286,8 +294,12 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
   uint32_t any = 0;
 #pragma unroll
   for (int m = 0; m < LJ_BW / 4; ++m) {
-    const uint32_t d[4] = {__builtin_bswap32(v[m].x), __builtin_bswap32(v[m].y),
-                           __builtin_bswap32(v[m].z), __builtin_bswap32(v[m].w)};
+    // MSB32 (Hasselblad): a little-endian word already is the next 32 stream bits
+    const bool le = S.pair != 0;
+    const uint32_t d[4] = {le ? v[m].x : __builtin_bswap32(v[m].x),
+                           le ? v[m].y : __builtin_bswap32(v[m].y),
+                           le ? v[m].z : __builtin_bswap32(v[m].z),
+                           le ? v[m].w : __builtin_bswap32(v[m].w)};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       any |= has_ff(d[q]);
@@ -448,7 +460,7 @@ __device__ __forceinline__ uint32_t lj_window(const uint32_t* B, int col, uint32
 }
 
 // Entry of the symbol that starts at `pos` (0 = invalid code); *w_out = its window.
-template <bool MULTI>
+template <bool MULTI, bool PAIR = false>
 __device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp, int col,
                                             uint32_t pos, uint32_t phase, bool live,
                                             uint32_t* w_out = nullptr) {
@@ -456,7 +468,14 @@ __device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp
   if (w_out)
     *w_out = w;
   const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
-  return lj_entry(w, tb, live);
+  const uint32_t e = lj_entry(w, tb, live);
+  if (PAIR) {
+    // HasselbladDecompressor.cpp:87-92: two length codes, then the two bit fields.
+    // The step covers the whole pair: advance = both codes + both fields (<= 64).
+    const uint32_t e2 = lj_entry(lj_window(L.B, col, pos + (e & 31u)), tb, live && e != 0u);
+    return (e != 0u && e2 != 0u) ? ((((e >> 10) + (e2 >> 10)) << 10) | 1u) : 0u;
+  }
+  return e;
 }
 
 // Decode the symbols that START inside slot `col` (bit positions [.., end_bits)),
@@ -467,7 +486,7 @@ __device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp
 // With one shared table the component phase does not influence the parse, so it
 // is left out of the state (it would never self-synchronise); with several
 // tables it is part of what has to match.
-template <bool MULTI, bool RECORD>
+template <bool MULTI, bool RECORD, bool PAIR = false>
 __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams& dp,
                                                int col, uint32_t start,
                                                uint32_t end_bits, uint32_t& exit,
@@ -490,7 +509,7 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
     while (__any(pos < lim)) {
       const bool live = pos < lim;
 #if RSX_LJ_WINDOW
-      const uint32_t e = lj_step<MULTI>(L, dp, col, pos, phase, live);
+      const uint32_t e = lj_step<MULTI, PAIR>(L, dp, col, pos, phase, live);
 #else
       const uint32_t e = lj_head<MULTI>(L, dp, r, phase, live);
 #endif
@@ -515,7 +534,7 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
   while (__any(pos < end_bits)) {
     const bool live = pos < end_bits;
 #if RSX_LJ_WINDOW
-    const uint32_t e = lj_step<MULTI>(L, dp, col, pos, phase, live);
+    const uint32_t e = lj_step<MULTI, PAIR>(L, dp, col, pos, phase, live);
 #else
     const uint32_t e = lj_head<MULTI>(L, dp, r, phase, live);
 #endif
@@ -543,6 +562,7 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
 // trajectory lands on a symbol start of the old one (single-table streams: the
 // parse from there on is identical, so the old exit and the old tail count
 // stand).  Updates the slot's records in registers.
+template <bool PAIR = false>
 __device__ __forceinline__ void lj_redecode_sync(const Lds& L, const DecodeParams& dp,
                                                  int col, uint32_t start,
                                                  uint32_t end_bits, uint64_t old_bm,
@@ -568,7 +588,7 @@ __device__ __forceinline__ void lj_redecode_sync(const Lds& L, const DecodeParam
       live = false;
     }
 #if RSX_LJ_WINDOW
-    const uint32_t e = lj_step<false>(L, dp, col, pos, 0u, live);
+    const uint32_t e = lj_step<false, PAIR>(L, dp, col, pos, 0u, live);
 #else
     const uint32_t e = lj_head<false>(L, dp, r, 0u, live);
 #endif
@@ -589,7 +609,7 @@ __device__ __forceinline__ void lj_redecode_sync(const Lds& L, const DecodeParam
   while (__any(pos < end_bits)) {
     const bool live = pos < end_bits;
 #if RSX_LJ_WINDOW
-    const uint32_t e = lj_step<false>(L, dp, col, pos, 0u, live);
+    const uint32_t e = lj_step<false, PAIR>(L, dp, col, pos, 0u, live);
 #else
     const uint32_t e = lj_head<false>(L, dp, r, 0u, live);
 #endif
@@ -623,7 +643,7 @@ __device__ __forceinline__ void lj_redecode_sync(const Lds& L, const DecodeParam
 // arbitrary bit position; Huffman streams self-synchronise within a few
 // symbols, so the position at which this runs into slot j is almost always the
 // true one.  (Checked against the predecessor's real exit afterwards.)
-template <bool MULTI>
+template <bool MULTI, bool PAIR = false>
 __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& dp,
                                               int j) {
   // j == 0 has no predecessor slot in LDS: it takes no steps (`enabled` false)
@@ -631,8 +651,8 @@ __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& 
   const uint32_t prev_bits = enabled ? L.ob[j - 1] : 0u;
   const uint32_t from = prev_bits > LJ_WARM ? prev_bits - LJ_WARM : 0u;
   uint32_t e = 0, c = 0;
-  lj_decode_span<MULTI, false>(L, dp, enabled ? j - 1 : 0, 0u, prev_bits, e, c, nullptr,
-                               enabled && prev_bits != 0, from);
+  lj_decode_span<MULTI, false, PAIR>(L, dp, enabled ? j - 1 : 0, 0u, prev_bits, e, c,
+                                     nullptr, enabled && prev_bits != 0, from);
   return (e & ST_ERR) ? 0u : e;
 }
 
@@ -690,14 +710,14 @@ __device__ __forceinline__ void lj_load_image(const Lds& L, const LjArgs& a, uin
 // ---------------------------------------------------------------------------
 // K1 / K2: synchronisation
 // ---------------------------------------------------------------------------
-template <bool STITCH, bool MULTI>
+template <bool STITCH, bool MULTI, bool PAIR = false>
 __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t b = blockIdx.x;
   const uint32_t s = a.block_stream[b];
   const LjStreamDev& S = a.streams[s];
-  if ((S.n_tables > 1) != MULTI)
-    return; // the other instantiation handles this stream
+  if ((S.n_tables > 1) != MULTI || (S.pair != 0) != PAIR)
+    return; // another instantiation handles this stream
   const Lds L = carve(smem, int(S.n_tables));
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
@@ -727,12 +747,12 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     // known start state; every other slot decodes from its warm-up guess
     // (slot 0 of later workgroups from bit 0)
     const bool real_slot = !(lb == 0 && j == 0);
-    const uint32_t guess = lj_warmup<MULTI>(L, dp, j);
+    const uint32_t guess = lj_warmup<MULTI, PAIR>(L, dp, j);
     if (j >= 2 || (j == 1 && lb > 0))
       start = guess;
     else if (j == 1)
       start = S.start_bit; // the stream's first symbol
-    lj_decode_span<MULTI, !MULTI>(L, dp, j, start, own_bits, e, c, &bm,
+    lj_decode_span<MULTI, !MULTI, PAIR>(L, dp, j, start, own_bits, e, c, &bm,
                                   real_slot && !(a.ablate & 4u));
     if (!real_slot) {
       e = S.start_bit;
@@ -793,11 +813,12 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       idx = mine ? L.list[j] : 1u;
       w = (STITCH && idx == 1) ? true_start : L.st[idx - 1];
       if (MULTI) {
-        lj_decode_span<MULTI, false>(L, dp, int(idx), w, L.ob[idx], e, c, nullptr, mine);
+        lj_decode_span<MULTI, false, PAIR>(L, dp, int(idx), w, L.ob[idx], e, c, nullptr,
+                                           mine);
       } else {
         const uint64_t old_bm = uint64_t(L.bm[2 * idx]) | (uint64_t(L.bm[2 * idx + 1]) << 32);
         const bool err = (w & ST_ERR) != 0;
-        lj_redecode_sync(L, dp, int(idx), w, L.ob[idx], old_bm, L.st[idx], L.cn[idx], e,
+        lj_redecode_sync<PAIR>(L, dp, int(idx), w, L.ob[idx], old_bm, L.st[idx], L.cn[idx], e,
                          c, bm, mine && !err);
         if (err) {
           e = ST_ERR;
@@ -851,13 +872,14 @@ constexpr int TF_ENTRIES = 512; // index = state & 0x1FF (offset | phase << 6)
 // The un-stuffed image is read straight from global memory here (all lanes of
 // a wavefront read the same dwords): without the 28 KB LDS image the kernel is
 // limited by wave slots, not LDS, and every workgroup of the plan is resident.
-template <bool MULTI>
+template <bool MULTI, bool PAIR = false>
 __global__ __launch_bounds__(LJ_T) void lj_transfer_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t b = blockIdx.x;
   const uint32_t s = a.block_stream[b];
   const LjStreamDev& S = a.streams[s];
-  if ((S.n_tables > 1) != MULTI || !(a.results[s].flags & FL_UNCONVERGED))
+  if ((S.n_tables > 1) != MULTI || (S.pair != 0) != PAIR ||
+      !(a.results[s].flags & FL_UNCONVERGED))
     return;
   Lds L{};
   L.B = const_cast<uint32_t*>(
@@ -875,7 +897,8 @@ __global__ __launch_bounds__(LJ_T) void lj_transfer_kernel(LjArgs a) {
   uint32_t state = off | (phase << ST_PHASE_SHIFT);
   for (int slot = 1; slot < LJ_T; ++slot) {
     uint32_t e = ST_ERR, c = 0;
-    lj_decode_span<MULTI, false>(L, dp, slot, state, L.ob[slot], e, c, nullptr, enabled);
+    lj_decode_span<MULTI, false, PAIR>(L, dp, slot, state, L.ob[slot], e, c, nullptr,
+                                       enabled);
     state = e;
   }
   if (enabled)
@@ -958,8 +981,8 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
     LjResult& R = a.results[s];
     // symbols that start before the end of data M = min(marker, in_bytes)
     uint64_t M = R.marker_pos;
-    if (M > S.in_bytes)
-      M = S.in_bytes;
+    if (M > lj_data_end(S))
+      M = lj_data_end(S);
     uint32_t avail;
     const uint64_t lbm = M / LJ_R;
     if (lbm >= nb) {
@@ -990,7 +1013,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   const uint32_t b = blockIdx.x;
   const uint32_t s = a.block_stream[b];
   const LjStreamDev& S = a.streams[s];
-  if ((S.n_tables > 1) != MULTI || (S.las != 0) != LAS)
+  if ((S.n_tables > 1) != MULTI || (S.las != 0) != LAS || S.pair)
     return;
   const Lds L = carve(smem, int(S.n_tables));
   const uint32_t lb = b - S.first_block;
@@ -1001,8 +1024,8 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   if (base >= needed || sum == 0)
     return; // nothing of this workgroup is delivered
   uint64_t M = a.results[s].marker_pos;
-  if (M > S.in_bytes)
-    M = S.in_bytes;
+  if (M > lj_data_end(S))
+    M = lj_data_end(S);
   if (uint64_t(lb) * LJ_R > M)
     return; // past the end of data
 
@@ -1154,6 +1177,122 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// K4 for HasselbladDecompressor streams (HasselbladDecompressor.cpp:71-100): a
+// step is a pair [len1 code][len2 code][len1 bits][len2 bits] and yields two
+// differences; getBits() (.cpp:60-69) sign-extends like JPEG except that the
+// all-ones 16-bit field means -32768.  Same skeleton as lj_decode_kernel: 4 pairs
+// = 8 differences = one 16-byte store.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lj_hb_diff(uint32_t w, uint32_t ssss) {
+  const uint32_t v = __builtin_amdgcn_ubfe(w, 32u - ssss, ssss);
+  uint32_t d = (v >> ((ssss - 1u) & 31u)) ? v : v + 1u - (1u << ssss);
+  d = (ssss == 16u && v == 0xFFFFu) ? 0x8000u : d;
+  return d & 0xFFFFu;
+}
+
+__global__ __launch_bounds__(LJ_T) void lj_decode_pair_kernel(LjArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t b = blockIdx.x;
+  const uint32_t s = a.block_stream[b];
+  const LjStreamDev& S = a.streams[s];
+  if (!S.pair)
+    return;
+  const Lds L = carve(smem, 1);
+  const uint32_t lb = b - S.first_block;
+  const int j = threadIdx.x;
+  const uint64_t needed = S.needed; // pairs
+  const uint32_t base = a.block_base[b];
+  const uint32_t sum = a.block_sum[b];
+  if (base >= needed || sum == 0)
+    return;
+  if (uint64_t(lb) * LJ_R > lj_data_end(S))
+    return;
+  lj_stage_tables(L, a, S);
+  lj_load_image(L, a, b, j); // ends with a barrier
+  const DecodeParams dp = lj_params(S);
+  const TabLds& tb = L.tabs[0];
+
+  const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1);
+  uint32_t my_start = 0, my_count = 0, my_exit = 0;
+  if (j >= 1) {
+    const uint32_t rec = a.sub_state[gsub];
+    my_count = rec >> 16;
+    my_exit = rec & ST_MASK;
+    my_start = (j == 1) ? a.block_start[b] : (a.sub_state[gsub - 1] & ST_MASK);
+  }
+  uint32_t x = my_count;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o, 64);
+    if ((j & 63) >= o)
+      x += y;
+  }
+  if ((j & 63) == 63)
+    L.misc[j >> 6] = x;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < (j >> 6); ++w)
+    woff += L.misc[w];
+  const uint64_t first = uint64_t(base) + woff + x - my_count; // first pair of this lane
+  if (j >= 1 && (my_exit & ST_ERR) && first + my_count < needed &&
+      int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P < int64_t(lj_data_end(S)))
+    atomicCAS(&a.results[s].status, 0u, uint32_t(RSX_ERR_BAD_HUFFMAN_CODE));
+
+  uint32_t remaining = (my_start & ST_ERR) ? 0u : my_count;
+  if (first >= needed)
+    remaining = 0;
+  else if (first + remaining > needed)
+    remaining = uint32_t(needed - first);
+  uint32_t* __restrict__ out =
+      reinterpret_cast<uint32_t*>(a.diffs + S.diff_offset) + first; // one dword per pair
+
+  uint32_t wmax = remaining;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    wmax = max(wmax, uint32_t(__shfl_xor(wmax, o, 64)));
+  const uint32_t n_groups = (wmax + 3) >> 2;
+
+  uint32_t pos = my_start & ST_OFF_MASK;
+  uint32_t tp[4] = {0, 0, 0, 0};
+  for (uint32_t g = 0; g < n_groups; ++g) {
+    uint32_t p[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool live = 4 * g + q < remaining;
+      const uint32_t e1 = lj_entry(lj_window(L.B, j, pos), tb, live);
+      const uint32_t p1 = pos + (e1 & 31u);
+      const uint32_t e2 = lj_entry(lj_window(L.B, j, p1), tb, live && e1 != 0u);
+      const uint32_t p2 = p1 + (e2 & 31u);
+      const uint32_t s1 = (e1 >> 5) & 31u, s2 = (e2 >> 5) & 31u;
+      const uint32_t d1 = lj_hb_diff(lj_window(L.B, j, p2), s1);
+      const uint32_t d2 = lj_hb_diff(lj_window(L.B, j, p2 + s1), s2);
+      p[q] = d1 | (d2 << 16);
+      pos = (live && e1 != 0u && e2 != 0u) ? p2 + s1 + s2 : pos;
+    }
+    if (4 * g + 4 <= remaining) {
+      const uint4 v = make_uint4(p[0], p[1], p[2], p[3]);
+      __builtin_memcpy(out + 4 * g, &v, 16);
+    } else if (4 * g < remaining) {
+      tp[0] = p[0]; tp[1] = p[1]; tp[2] = p[2]; tp[3] = p[3];
+    }
+  }
+  {
+    const uint32_t full = remaining & ~3u, tail = remaining & 3u;
+    for (uint32_t t = 0; t < tail; ++t)
+      out[full + t] = t == 0 ? tp[0] : (t == 1 ? tp[1] : tp[2]);
+  }
+  // K7 needs the bit position at which the last pair starts
+  if (needed >= 1 && needed - 1 >= first && needed - 1 < first + remaining) {
+    const uint32_t target = uint32_t(needed - 1 - first);
+    uint32_t p2 = my_start & ST_OFF_MASK;
+    for (uint32_t t = 0; t < target; ++t)
+      p2 += lj_step<false, true>(L, dp, j, p2, 0u, true) >> 10;
+    a.results[s].last_slot = lb * LJ_OWN + uint32_t(j - 1);
+    a.results[s].last_pos = p2;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K4b: end-of-stream tail.  The reference keeps decoding when the symbols run
 // past the end of data: after the FFxx marker the bit reader supplies zeros
 // (BitStreamerJPEG.h:155-179) until its position budget is exhausted, then
@@ -1199,7 +1338,7 @@ __global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
     return; // the common case: every symbol starts inside the data
   const uint8_t* in = a.in_base + S.in_offset;
   const bool has_marker = R.marker_pos != 0xFFFFFFFFu && R.marker_pos < S.in_bytes;
-  const uint64_t M = has_marker ? R.marker_pos : S.in_bytes;
+  const uint64_t M = has_marker ? R.marker_pos : lj_data_end(S);
   const uint64_t D = M - lj_drops_before(a, S, in, M, lane);
   // start two subsequences before the one holding the last data byte
   const uint64_t ps = M > 0 ? (M - 1) / LJ_P : 0;
@@ -1229,7 +1368,10 @@ __global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
     while (nb <= 56) {
       uint32_t byte = 0;
       if (x < M) {
-        byte = in[x++];
+        // MSB32: stream byte x is byte x ^ 3 of memory (zero past the real end)
+        const uint64_t mx = S.pair ? (x ^ 3) : x;
+        byte = mx < S.in_bytes ? in[mx] : 0u;
+        ++x;
         if (byte == 0xFF && !raw)
           ++x; // its stuffing byte (every FF before M is followed by 00)
       }
@@ -1255,6 +1397,63 @@ __global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
       (raw && S.raw_limit) ? S.raw_limit - 1 : 32 * ((D + (raw ? 8 : 16)) / 4);
   int64_t cstar = -1;
   int16_t* __restrict__ dst = a.diffs + S.diff_offset;
+  if (S.pair) {
+    // HasselbladDecompressor.cpp:87-92: decodeCodeValue x 2 (each fills 32 bits),
+    // getBits(len) x 2 (each fills len bits).  Refill k reads word k and throws once
+    // 4 k > size + 8 (BitStreamer.h:125-127), so a fill point at bit c that needs n
+    // bits is fine iff c + n <= 32 * (floor((size + 8) / 4) + 1).
+    const uint64_t lim = 32 * ((S.in_bytes + 8) / 4 + 1);
+    const TabLds* tb = tabs;
+    uint32_t* dst32 = reinterpret_cast<uint32_t*>(a.diffs + S.diff_offset);
+    while (idx < S.needed) {
+      const uint64_t c0 = c;
+      uint32_t len[2], d[2];
+      for (int k = 0; k < 2; ++k) {
+        if (c + 32 > lim) {
+          atomicCAS(&R.status, 0u, uint32_t(RSX_ERR_INPUT_OVERFLOW));
+          return;
+        }
+        refill();
+        const Sym sy = lj_symbol_global(uint32_t(buf >> 32), tb);
+        if (!sy.ok) {
+          atomicCAS(&R.status, 0u, uint32_t(RSX_ERR_BAD_HUFFMAN_CODE));
+          return;
+        }
+        len[k] = sy.ssss;
+        buf <<= sy.code_len;
+        nb -= sy.code_len;
+        c += sy.code_len;
+      }
+      for (int k = 0; k < 2; ++k) {
+        d[k] = 0;
+        if (len[k]) {
+          if (c + len[k] > lim) {
+            atomicCAS(&R.status, 0u, uint32_t(RSX_ERR_INPUT_OVERFLOW));
+            return;
+          }
+          refill();
+          const uint32_t v = uint32_t(buf >> (64 - len[k]));
+          uint32_t x2 = (v >> (len[k] - 1)) ? v : v + 1u - (1u << len[k]);
+          if (len[k] == 16 && v == 0xFFFFu)
+            x2 = 0x8000u; // "if (diff == 65535) return -32768" :66-67
+          d[k] = x2 & 0xFFFFu;
+          buf <<= len[k];
+          nb -= len[k];
+          c += len[k];
+        }
+      }
+      if (idx >= avail)
+        dst32[idx] = d[0] | (d[1] << 16);
+      if (idx + 1 == S.needed) {
+        R.tail_used = 1;
+        R.last_c_lo = uint32_t(c0);
+        R.last_c_hi = uint32_t(c0 >> 32);
+      }
+      ++idx;
+    }
+    R.avail_lo = uint32_t(S.needed);
+    return;
+  }
   while (idx < S.needed) {
     if (has_marker) {
       if (cstar < 0 && int64_t(c) >= T0)
@@ -1355,7 +1554,7 @@ __global__ __launch_bounds__(64) void lj_consumed_kernel(LjArgs a) {
     return;
   const uint8_t* in = a.in_base + S.in_offset;
   const bool has_marker = R.marker_pos != 0xFFFFFFFFu && R.marker_pos < S.in_bytes;
-  const uint64_t M = has_marker ? R.marker_pos : S.in_bytes;
+  const uint64_t M = has_marker ? R.marker_pos : lj_data_end(S);
   // un-stuffed bit offset of the last symbol's start
   const uint64_t slot_phys = uint64_t(R.last_slot) * LJ_P;
   uint64_t c =
@@ -1366,16 +1565,26 @@ __global__ __launch_bounds__(64) void lj_consumed_kernel(LjArgs a) {
     // where the next symbol would start: the last one's start + its length
     // (bytes past the end of the buffer read as zero)
     if (lane == 0) {
-      uint32_t w = 0;
-      const uint64_t by = c >> 3;
-      uint64_t acc = 0;
-      for (int i = 0; i < 5; ++i) {
-        const uint64_t q = by + i;
-        acc = (acc << 8) | (q < S.in_bytes ? in[q] : 0u);
+      // the 32 stream bits at bit offset cc (zero past the end of the buffer)
+      auto window = [&](uint64_t cc) -> uint32_t {
+        const uint64_t by = cc >> 3;
+        uint64_t acc = 0;
+        for (int i = 0; i < 5; ++i) {
+          const uint64_t q = by + i, mq = S.pair ? (q ^ 3) : q;
+          acc = (acc << 8) | (mq < S.in_bytes ? in[mq] : 0u);
+        }
+        return uint32_t((acc << (cc & 7)) >> 8);
+      };
+      const TabLds* tb = a.tables + S.table_base;
+      const Sym sy = lj_symbol_global(window(c), tb);
+      uint64_t end = c + (sy.ok ? sy.total : 0u);
+      if (S.pair && sy.ok) {
+        // [code1][code2][bits1][bits2]: sy.total covers code1 + bits1
+        const Sym s2 = lj_symbol_global(window(c + sy.code_len), tb);
+        end += s2.ok ? s2.total : 0u;
+        // BitStreamer::getStreamPosition: pos - (fillLevel >> 3) = ceil(end / 8)
+        R.consumed = uint32_t((end + 7) / 8);
       }
-      w = uint32_t((acc << (c & 7)) >> 8);
-      const Sym sy = lj_symbol_global(w, a.tables + S.table_base);
-      const uint64_t end = c + (sy.ok ? sy.total : 0u);
       R.end_lo = uint32_t(end);
       R.end_hi = uint32_t(end >> 32);
     }
@@ -1456,7 +1665,7 @@ struct LJpegPlan {
   uint32_t total_blocks = 0, total_subseq = 0, total_rows = 0;
   uint64_t total_diffs = 0;
   int max_tables = 1;
-  bool any_multi = false, any_single = false;
+  bool any_multi = false, any_single = false, any_single_plain = false;
   bool comp_present[7] = {}; // [1..4] interleaved n_comp; [5], [6]: sRaw groups of 4, 6
   DeviceBuffer d_streams, d_tables, d_block_stream, d_strips, d_sub_state,
       d_block_start, d_block_exit, d_block_sum, d_block_base, d_block_drops,
@@ -1484,7 +1693,7 @@ struct LJpegPlan {
   LJpegPlan* child = nullptr;          // one stream per restart interval
   std::vector<std::pair<int, int>> child_owner; // child job -> (dri index, interval)
   // NikonDecompressor streams
-  bool any_nikon = false, any_las = false, any_plain = false;
+  bool any_nikon = false, any_las = false, any_plain = false, any_pair = false;
   std::vector<NkStreamDev> nk;         // parallel to streams
   DeviceBuffer d_nk, d_nk_tables, d_nk_rowpow, d_nk_pup;
   DeviceBuffer d_transfer; // fallback path only (allocated on first use)
@@ -1537,8 +1746,11 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
 
 template <bool STITCH>
 void launch_sync(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
-  if (p->any_single)
+  if (p->any_single_plain)
     hipLaunchKernelGGL((lj_sync_kernel<STITCH, false>), dim3(p->total_blocks),
+                       dim3(LJ_T), lj_lds_bytes(1), s, a);
+  if (p->any_pair)
+    hipLaunchKernelGGL((lj_sync_kernel<STITCH, false, true>), dim3(p->total_blocks),
                        dim3(LJ_T), lj_lds_bytes(1), s, a);
   if (p->any_multi)
     hipLaunchKernelGGL((lj_sync_kernel<STITCH, true>), dim3(p->total_blocks),
@@ -1551,6 +1763,9 @@ void launch_decode(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
                        lj_lds_bytes(1), s, a);
   if (p->any_las)
     hipLaunchKernelGGL((lj_decode_kernel<false, true>), dim3(p->total_blocks), dim3(LJ_T),
+                       lj_lds_bytes(1), s, a);
+  if (p->any_pair)
+    hipLaunchKernelGGL(lj_decode_pair_kernel, dim3(p->total_blocks), dim3(LJ_T),
                        lj_lds_bytes(1), s, a);
   if (p->any_multi)
     hipLaunchKernelGGL((lj_decode_kernel<true>), dim3(p->total_blocks), dim3(LJ_T),
@@ -1582,8 +1797,9 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     if (st == RSX_OK && J.geom.in_bytes > 0xFFFFFFFFull)
       st = RSX_ERR_INVALID_ARG; // Buffer::size_type is uint32_t (io/Buffer.h:49)
     const StreamGeom& g = J.geom;
+    // symbols of the entropy stage (a Hasselblad symbol is a pair of samples)
     const uint64_t needed = g.kind != 1
-                                ? uint64_t(g.rows) * g.row_samples
+                                ? uint64_t(g.rows) * g.row_samples / (g.pair ? 2 : 1)
                                 : g.strip_first_sample[g.n_strips];
     if (st == RSX_OK && needed >= 0xFFFFFFF0ull)
       st = RSX_ERR_UNSUPPORTED;
@@ -1621,6 +1837,8 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     S.raw = g.raw;
     S.start_bit = g.start_bit;
     S.las = g.las;
+    S.pair = g.pair;
+    S.no_vertical = g.no_vertical;
     S.raw_limit = g.raw_limit;
     S.rows = g.rows;
     S.row_samples = g.row_samples;
@@ -1652,7 +1870,12 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     } else {
       for (int t = 0; t < J.n_tables; ++t) {
         tables.emplace_back();
-        build_device_table(J.tables[t], &tables.back(), g.las != 0);
+        rsx_huff_table ht = J.tables[t];
+        // Hasselblad's getBits(16) reads 16 bits (HasselbladDecompressor.cpp:60-69);
+        // in JPEG terms that is the "SSSS = 16 is followed by 16 bits" variant
+        if (g.pair)
+          ht.fix_dng_bug16 = 1;
+        build_device_table(ht, &tables.back(), g.las != 0);
       }
     }
     NkStreamDev K{};
@@ -1698,8 +1921,10 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     bool multi = J.n_tables > 1;
     p->any_multi |= multi;
     p->any_single |= !multi;
-    p->any_plain |= !multi && !g.las;
+    p->any_single_plain |= !multi && !g.pair;
+    p->any_plain |= !multi && !g.las && !g.pair;
     p->any_las |= g.las != 0;
+    p->any_pair |= g.pair != 0;
     p->max_tables = std::max(p->max_tables, J.n_tables);
     if (g.kind != 2)
       p->comp_present[g.period == g.n_comp ? g.n_comp : (g.period == 4 ? 5u : 6u)] = true;
@@ -1708,7 +1933,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     p->total_blocks += S.n_blocks;
     p->total_subseq += S.n_blocks * LJ_OWN;
     p->total_rows += S.rows;
-    p->total_diffs += (needed + 7 + 8) & ~uint64_t(7);
+    p->total_diffs += ((g.pair ? 2 * needed : needed) + 7 + 8) & ~uint64_t(7);
     p->streams.push_back(S);
   }
   if (!p->streams.empty()) {
@@ -2028,8 +2253,11 @@ int converge(LJpegPlan* p, hipStream_t s) {
     return st;
   const LjArgs a = make_args(p, p->last_in, p->last_out);
   {
-    if (p->any_single)
+    if (p->any_single_plain)
       hipLaunchKernelGGL((lj_transfer_kernel<false>), dim3(p->total_blocks), dim3(64),
+                         sizeof(TabLds), s, a);
+    if (p->any_pair)
+      hipLaunchKernelGGL((lj_transfer_kernel<false, true>), dim3(p->total_blocks), dim3(64),
                          sizeof(TabLds), s, a);
     if (p->any_multi)
       hipLaunchKernelGGL((lj_transfer_kernel<true>), dim3(p->total_blocks), dim3(LJ_T),
@@ -2171,7 +2399,7 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
         else if (uint64_t(R.avail_lo) < S.needed)
           st = RSX_ERR_INPUT_OVERFLOW;
         consumed = R.consumed;
-        if (st == RSX_OK && S.kind == 0 && uint64_t(consumed) > S.in_bytes)
+        if (st == RSX_OK && S.kind == 0 && !S.pair && uint64_t(consumed) > S.in_bytes)
           st = RSX_ERR_IO; // inputStream.skipBytes(): LJpegDecompressor.cpp:335
       }
     }

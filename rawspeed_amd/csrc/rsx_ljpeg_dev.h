@@ -99,7 +99,10 @@ struct LjStreamDev {
                        //    no markers, position budget of 8 bytes instead of 16
   uint8_t start_bit;   // first symbol starts this many bits into the stream (0..7)
   uint8_t las;         // table values are Nikon "lossy after split" (len | shl << 4)
-  uint8_t pad8;
+  uint8_t pair;        // HasselbladDecompressor: a symbol is [code1][code2][bits1][bits2]
+                       // (2 differences); the stream is MSB32 (LE 32-bit words, MSB first)
+  uint8_t no_vertical; // every stream row starts from init_pred (no seed chain)
+  uint8_t pad8[3];
   uint32_t rows;
   uint32_t row_samples;
   uint32_t first_row; // global stream-row index

@@ -74,8 +74,9 @@ __global__ __launch_bounds__(VS_T) void lj_vseed_kernel(LjArgs a) {
       base[c] = o;
     }
     if (r < rows)
-      for (uint32_t c = 0; c < N; ++c)
-        V[uint64_t(r) * 4 + c] = uint16_t(base[c] + inc[c] - d[c]); // exclusive
+      for (uint32_t c = 0; c < N; ++c) // exclusive; Hasselblad rows all start from initPred
+        V[uint64_t(r) * 4 + c] =
+            S.no_vertical ? S.init_pred[c] : uint16_t(base[c] + inc[c] - d[c]);
     __syncthreads();
     if (tid == VS_T - 1)
       for (int c = 0; c < 4; ++c)
@@ -142,8 +143,9 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
     return;
   const uint64_t row0 = uint64_t(r) * S.row_samples;
   uint32_t n = S.scan_samples;
-  if (row0 + n > S.needed)
-    n = uint32_t(S.needed - row0);
+  const uint64_t n_diffs = S.pair ? 2 * S.needed : S.needed; // a pair symbol = 2 differences
+  if (row0 + n > n_diffs)
+    n = uint32_t(n_diffs - row0);
   const int16_t* __restrict__ D = a.diffs + S.diff_offset + row0;
   const bool in_aligned = ((S.diff_offset + row0) & 7) == 0;
   uint32_t carry[N];
@@ -361,8 +363,9 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_fast_kernel(LjArgs a) {
     return;
   const uint64_t row0 = uint64_t(r) * S.row_samples;
   uint32_t n = S.scan_samples;
-  if (row0 + n > S.needed)
-    n = uint32_t(S.needed - row0);
+  const uint64_t n_diffs = S.pair ? 2 * S.needed : S.needed; // a pair symbol = 2 differences
+  if (row0 + n > n_diffs)
+    n = uint32_t(n_diffs - row0);
   const int16_t* __restrict__ D = a.diffs + S.diff_offset + row0;
   const bool in_aligned = ((S.diff_offset + row0) & 7) == 0;
   // running predictor, packed pairs: (c0,c1) [, (c2,c3)]

@@ -397,6 +397,70 @@ size_t rsx_synth_prefix_encode(const uint16_t* samples, size_t row_stride, int w
   return nikon_encode_tab(samples, row_stride, w, h, p_up, &tab, out, cap, n_symbol_bits);
 }
 
+/* HasselbladDecompressor stream (HasselbladDecompressor.cpp:71-100): pixels two at
+ * a time as [len1 code][len2 code][len1 bits][len2 bits], both predictors restart
+ * from init_pred on every row, arithmetic mod 2^16; BitStreamerMSB32 input, i.e.
+ * the MSB-first bit stream is stored as little-endian 32-bit words.  Returns the
+ * byte count (a multiple of 4), 0 on overflow / missing category. */
+size_t rsx_synth_hasselblad_encode(const uint16_t* samples, size_t row_stride, int w,
+                                   int h, unsigned init_pred, const uint8_t* counts,
+                                   const uint8_t* values, int n_values, uint8_t* out,
+                                   size_t cap, uint64_t* n_symbol_bits) {
+  enc_table tab;
+  if (enc_table_build(&tab, counts, values, n_values) || (w & 1))
+    return 0;
+  jpeg_writer wr = {out, cap, 0, 0, 0, 0, 1};
+  uint64_t bits = 0;
+  for (int r = 0; r < h; ++r) {
+    const uint16_t* cur = samples + (size_t)r * row_stride;
+    uint16_t p[2] = {(uint16_t)init_pred, (uint16_t)init_pred};
+    for (int x = 0; x < w; x += 2) {
+      int d[2], ssss[2];
+      for (int k = 0; k < 2; ++k) {
+        d[k] = (int16_t)(uint16_t)(cur[x + k] - p[k]); /* -32768 .. 32767 */
+        p[k] = cur[x + k];
+        ssss[k] = 0;
+        if (d[k] == -32768) {
+          ssss[k] = 16; /* the all-ones field */
+        } else {
+          for (int a = d[k] < 0 ? -d[k] : d[k]; a; a >>= 1)
+            ++ssss[k];
+        }
+        if (tab.len[ssss[k]] == 0)
+          return 0;
+      }
+      for (int k = 0; k < 2; ++k) {
+        jw_bits(&wr, tab.code[ssss[k]], tab.len[ssss[k]]);
+        bits += tab.len[ssss[k]] + ssss[k];
+      }
+      for (int k = 0; k < 2; ++k) {
+        if (ssss[k] == 16)
+          jw_bits(&wr, 0xFFFFu, 16);
+        else if (ssss[k])
+          jw_bits(&wr, d[k] >= 0 ? (uint32_t)d[k] : (uint32_t)(d[k] + (1 << ssss[k]) - 1),
+                  ssss[k]);
+      }
+    }
+  }
+  if (wr.nacc > 0)
+    jw_bits(&wr, 0, 8 - wr.nacc);
+  while (wr.n % 4)
+    jw_byte_raw(&wr, 0);
+  if (wr.overflow)
+    return 0;
+  for (size_t i = 0; i + 4 <= wr.n; i += 4) { /* MSB-first words -> little-endian */
+    uint8_t t = out[i];
+    out[i] = out[i + 3];
+    out[i + 3] = t;
+    t = out[i + 1];
+    out[i + 1] = out[i + 2];
+    out[i + 2] = t;
+  }
+  if (n_symbol_bits)
+    *n_symbol_bits = bits;
+  return wr.n;
+}
+
 static void put16(uint8_t** p, unsigned v) {
   *(*p)++ = (uint8_t)(v >> 8);
   *(*p)++ = (uint8_t)v;

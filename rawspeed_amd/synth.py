@@ -48,6 +48,10 @@ def lib():
         _lib.rsx_synth_prefix_encode.argtypes = [
             C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
             C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        _lib.rsx_synth_hasselblad_encode.restype = C.c_size_t
+        _lib.rsx_synth_hasselblad_encode.argtypes = [
+            C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_uint, C.c_void_p,
+            C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         _lib.rsx_synth_ljpeg_header.restype = C.c_size_t
         _lib.rsx_synth_ljpeg_header.argtypes = [
             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -238,6 +242,25 @@ def prefix_encode(img, p_up, tab):
                                       out.ctypes.data, cap, C.byref(bits))
     if n == 0:
         raise ValueError("prefix encode failed")
+    return out[:n].copy(), bits.value
+
+
+def hasselblad_encode(img, init_pred, table):
+    """img: (h, w) uint16 -> HasselbladDecompressor stream (MSB32 words, pairs of
+    [len code][len code][bits][bits]); table = (counts, values) with the lengths
+    0..16 it needs.  Returns (np.uint8 bytes, symbol bits)."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    h, w = img.shape
+    counts = np.asarray(table[0], dtype=np.uint8)
+    values = np.asarray(table[1], dtype=np.uint8)
+    cap = h * w * 5 + 64
+    out = np.empty(cap, dtype=np.uint8)
+    bits = C.c_uint64(0)
+    n = lib().rsx_synth_hasselblad_encode(img.ctypes.data, w, w, h, init_pred,
+                                          counts.ctypes.data, values.ctypes.data,
+                                          len(values), out.ctypes.data, cap, C.byref(bits))
+    if n == 0:
+        raise ValueError("Hasselblad encode failed")
     return out[:n].copy(), bits.value
 
 

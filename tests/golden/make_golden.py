@@ -21,7 +21,8 @@ from oracle_lib import Ref  # noqa: E402
 def main():
     ref = Ref()
     out = {"unpack": {}, "f32": {}, "variant": {}, "ljpeg": {}, "cr2": {}, "nikon": {},
-           "pentax": {}, "samsung_v1": {}, "sraw": {}}
+           "pentax": {}, "samsung_v1": {}, "sraw": {},
+           "hasselblad": {}}
     for i, c in enumerate(G.UNPACK_CASES):
         d, data, (w, h, cpp) = G.build_unpack(c)
         img = ref.image(w, h, cpp)
@@ -70,6 +71,12 @@ def main():
         src.set_pixels(px)
         st = ref.sraw(d, src, dst)
         out["sraw"][c["name"]] = {"status": st, "hash": G.image_hash(dst.pixels())}
+    for c in G.HASSELBLAD_CASES:
+        d, data, (w, h, cpp), _ = G.build_hasselblad(c)
+        img = ref.image(w, h, cpp)
+        st, consumed = ref.hasselblad(d, data, img)
+        out["hasselblad"][c["name"]] = {"status": st, "consumed": consumed,
+                                        "hash": G.image_hash(img.pixels())}
     path = os.path.join(HERE, "golden_hashes.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

@@ -309,3 +309,26 @@ def build_sraw(c, seed=717):
         hue = int(rng.integers(-600, 600))
     d = abi.SrawDesc.make(c["version"], c["ysf"], coeffs, hue)
     return d, px, (w, c["rows"]), (2 * c["groups"], c["ysf"] * c["rows"])
+
+
+# ---- HasselbladDecompressor -------------------------------------------------------
+HASSELBLAD_CASES = [
+    dict(name="small", w=64, h=20),
+    dict(name="full_range", w=66, h=7, full=True),
+    dict(name="medium", w=1200, h=300),
+    dict(name="max_width", w=12000, h=6),
+    dict(name="odd_tail", w=130, h=9),
+]
+
+
+def build_hasselblad(c, seed=818):
+    rng = np.random.default_rng([seed, sum(map(ord, c["name"]))])
+    w, h = c["w"], c["h"]
+    if c.get("full"):
+        src = rng.integers(0, 65536, size=(h, w), dtype=np.uint16)
+        src[2, 4:8] = [0, 32768, 32768, 0]   # differences of exactly -32768
+    else:
+        src = C.smooth_image(rng, h, w, 14)
+    init = 0x8000 if c.get("full") else 0x2000
+    data, _ = synth.hasselblad_encode(src, init, C.FULL17)
+    return abi.HasselbladDesc.make(C.FULL17, init), data, (w, h, 1), src

@@ -101,6 +101,9 @@ class Oracle:
         L.oracle_sraw_interpolate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_nikon_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_pentax_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_hasselblad_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_hasselblad_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
+                                                   C.c_void_p, C.c_void_p]
         L.oracle_samsung_v1_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_samsung_v1_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                                    C.c_void_p]
@@ -166,6 +169,18 @@ class Oracle:
     def samsung_v1_validate(self, desc, img):
         v = img.view()
         return self.lib.oracle_samsung_v1_validate(C.byref(desc), C.byref(v))
+
+    def hasselblad(self, desc, data, img):
+        a, p, n = _as_u8(data)
+        v = img.view()
+        consumed = C.c_uint32(0)
+        st = self.lib.oracle_hasselblad_decompress(C.byref(desc), p, n, C.byref(v),
+                                                   C.byref(consumed))
+        return st, consumed.value
+
+    def hasselblad_validate(self, desc, img):
+        v = img.view()
+        return self.lib.oracle_hasselblad_validate(C.byref(desc), C.byref(v))
 
     def pentax_validate(self, desc, img):
         v = img.view()
@@ -298,6 +313,8 @@ class Ref:
         L.ref_decode8bit_lookup.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                             C.c_int, C.c_void_p, C.c_size_t]
         L.ref_samsung_v1_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.ref_hasselblad_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_size_t, C.c_void_p]
         L.ref_pentax_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                             C.c_void_p, C.c_size_t]
         L.ref_sraw_interpolate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -343,6 +360,12 @@ class Ref:
     def samsung_v1(self, bits, data, img):
         a, p, n = _as_u8(data)
         return self.lib.ref_samsung_v1_decompress(img.h, bits, p, n)
+
+    def hasselblad(self, desc, data, img):
+        a, p, n = _as_u8(data)
+        consumed = C.c_uint32(0)
+        st = self.lib.ref_hasselblad_decompress(img.h, C.byref(desc), p, n, C.byref(consumed))
+        return st, consumed.value
 
     def pentax(self, meta, data, img):
         a, p, n = _as_u8(data)

@@ -262,6 +262,29 @@ def test_sraw_validate_matches_oracle(lib, oracle):
     assert seen == {abi.RSX_OK, abi.RSX_ERR_INVALID_ARG}
 
 
+def test_hasselblad_validate_matches_oracle(lib, oracle):
+    import cases as Cs
+    rng = np.random.default_rng(18)
+    seen = set()
+    for trial in range(600):
+        img = HostImage(8, 2, int(rng.choice([1, 1, 1, 2])))
+        img.dim_x = int(rng.choice([0, 2, 3, 64, 12000, 12002]))
+        img.dim_y = int(rng.choice([0, 1, 16, 8842, 8843]))
+        d = abi.HasselbladDesc.make(Cs.FULL17, int(rng.integers(0, 65536)))
+        t = rng.integers(0, 8)
+        if t == 0:
+            d.table.n_codes_per_length[0] = 3
+        elif t == 1:
+            d.table.code_values[2] = 17
+        elif t == 2:
+            d.table.fix_dng_bug16 = 1
+        v = img.view()
+        a = lib.rsx_hasselblad_validate(C.byref(d), C.byref(v))
+        assert a == oracle.hasselblad_validate(d, img), trial
+        seen.add(a)
+    assert seen == {abi.RSX_OK, abi.RSX_ERR_INVALID_ARG}
+
+
 def test_cr2_validate_matches_oracle(lib, oracle):
     import cases as cs
     rng = np.random.default_rng(13)

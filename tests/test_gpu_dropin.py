@@ -269,3 +269,14 @@ def test_sraw_interpolator(pair):
         (s0, a, e0), (s1, b, e1) = out
         assert s0 == 0 and s1 == 0, (e0, e1)
         assert np.array_equal(a, b)
+
+
+def test_hasselblad_decompressor(pair):
+    import golden_cases as G
+    for name in ("full_range", "medium", "max_width"):
+        c = next(c for c in G.HASSELBLAD_CASES if c["name"] == name)
+        d, data, (w, h, cpp), _ = G.build_hasselblad(c)
+        (s0, a, e0), (s1, b, e1) = both(
+            pair, lambda lib, img: lib.hasselblad(d, data, img), (w, h, cpp))
+        assert s0 == s1 and s0[0] == 0, (s0, s1, e0, e1)
+        assert np.array_equal(a, b)

@@ -222,3 +222,44 @@ def test_samsung_v1_truncation(gpu, oracle):
             assert np.array_equal(img.u16(), want.u16())
         seen.add(so)
     assert 0 in seen and len(seen) >= 2
+
+
+# ---- HasselbladDecompressor -------------------------------------------------------
+
+@pytest.mark.parametrize("c", G.HASSELBLAD_CASES, ids=lambda c: c["name"])
+def test_hasselblad_golden(gpu, oracle, c):
+    d, data, (w, h, cpp), src = G.build_hasselblad(c)
+    img, want = HostImage(w, h, cpp), HostImage(w, h, cpp)
+    g = GOLD["hasselblad"][c["name"]]
+    sg = gpu.hasselblad_decompress(d, data, img.view())
+    assert sg == oracle.hasselblad(d, data, want) == (0, g["consumed"])
+    assert np.array_equal(img.u16(), want.u16())
+    assert G.image_hash(img.pixels()) == g["hash"]
+    assert np.array_equal(img.pixels(), src)
+
+
+def test_hasselblad_sizes_and_truncation(gpu, oracle):
+    """Several workgroups per stream; status and getStreamPosition() parity at every
+    cut (partial last MSB32 word, 8-byte position budget)."""
+    import cases as C
+    rng = np.random.default_rng(56)
+    for w, h, full in ((4000, 250, False), (2048, 96, True)):
+        src = (rng.integers(0, 65536, size=(h, w), dtype=np.uint16) if full
+               else C.smooth_image(rng, h, w, 14))
+        data, _ = synth.hasselblad_encode(src, 0x4000, C.FULL17)
+        d = abi.HasselbladDesc.make(C.FULL17, 0x4000)
+        img, want = HostImage(w, h), HostImage(w, h)
+        so = oracle.hasselblad(d, data, want)
+        assert so[0] == 0 and gpu.hasselblad_decompress(d, data, img.view()) == so
+        assert np.array_equal(img.u16(), want.u16()) and np.array_equal(img.pixels(), src)
+        seen = set()
+        for cut in list(range(1, 20)) + [40, 101, len(data) // 2]:
+            part = data[:len(data) - cut]
+            img, want = HostImage(w, h), HostImage(w, h)
+            so = oracle.hasselblad(d, part, want)
+            sg = gpu.hasselblad_decompress(d, part, img.view())
+            assert sg[0] == so[0], (cut, sg, so)
+            if so[0] == 0:
+                assert sg == so and np.array_equal(img.u16(), want.u16())
+            seen.add(so[0])
+        assert len(seen) >= 2

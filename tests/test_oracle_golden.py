@@ -117,7 +117,38 @@ def test_sraw_golden(oracle, c):
     assert G.image_hash(dst.pixels()) == GOLD["sraw"][c["name"]]["hash"]
 
 
+@pytest.mark.parametrize("c", G.HASSELBLAD_CASES, ids=lambda c: c["name"])
+def test_hasselblad_golden(oracle, c):
+    d, data, (w, h, cpp), src = G.build_hasselblad(c)
+    img = HostImage(w, h, cpp)
+    g = GOLD["hasselblad"][c["name"]]
+    assert oracle.hasselblad(d, data, img) == (g["status"], g["consumed"]) == (0, g["consumed"])
+    assert G.image_hash(img.pixels()) == g["hash"]
+    assert np.array_equal(img.pixels(), src)
+
+
 # ---- live cross-checks against the compiled reference ----------------------
+
+def test_hasselblad_vs_ref(oracle, ref):
+    """Full buffers, getStreamPosition(), and status parity at every cut (the
+    MSB32 reader's partial last word and 8-byte position budget)."""
+    for c in G.HASSELBLAD_CASES:
+        d, data, (w, h, cpp), _ = G.build_hasselblad(c)
+        hi, ri = HostImage(w, h, cpp), ref.image(w, h, cpp)
+        assert oracle.hasselblad(d, data, hi) == ref.hasselblad(d, data, ri), ref.last_error()
+        assert np.array_equal(hi.u16(), ri.u16())
+    d, data, (w, h, cpp), _ = G.build_hasselblad(G.HASSELBLAD_CASES[1])
+    seen = set()
+    for cut in list(range(1, 40)) + [60, 100, 300, len(data) // 2]:
+        part = data[:len(data) - cut]
+        hi, ri = HostImage(w, h, cpp), ref.image(w, h, cpp)
+        so, sr = oracle.hasselblad(d, part, hi), ref.hasselblad(d, part, ri)
+        assert so == sr, (cut, so, sr, ref.last_error())
+        if so[0] == 0:
+            assert np.array_equal(hi.u16(), ri.u16())
+        seen.add(so[0])
+    assert 0 in seen and len(seen) >= 2
+
 
 @pytest.mark.parametrize("c", G.SRAW_CASES, ids=lambda c: c["name"])
 def test_sraw_vs_ref(oracle, ref, c):
