@@ -19,7 +19,9 @@ packed buffer from rank 0 over xGMI, timed separately).
 Rank 0 prints ONE JSON line.  At N=1 it also carries
   roofline      -- dominant kernel: algorithmic bytes / hipEvent-measured launch time
   cpu_baseline  -- the unmodified reference (oracle/_ref) timed on this host's cores
-  extra         -- the LJPEG configs (cfg 3 / cfg 4) measured the same way
+  extra         -- the other legs measured the same way (bench_ljpeg.py): the LJPEG
+                   configs (cfg 3 / cfg 4 / cfg 5), the fixed-layout unpack entry
+                   points, Canon sRaw + Cr2sRawInterpolator, Nikon, Hasselblad
 """
 import argparse
 import ctypes as C
