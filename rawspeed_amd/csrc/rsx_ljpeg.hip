@@ -568,7 +568,8 @@ __device__ __forceinline__ void lj_redecode_sync(const Lds& L, const DecodeParam
                                                  uint32_t end_bits, uint64_t old_bm,
                                                  uint32_t old_exit, uint32_t old_cn,
                                                  uint32_t& exit, uint32_t& count,
-                                                 uint64_t& bm, bool enabled) {
+                                                 uint64_t& bm, bool enabled,
+                                                 uint32_t* steps = nullptr) {
   uint32_t pos = start & ST_OFF_MASK, n = 0;
   uint64_t m = 0;
   bool ok = true, synced = false;
@@ -627,6 +628,8 @@ __device__ __forceinline__ void lj_redecode_sync(const Lds& L, const DecodeParam
   }
   if (!enabled)
     return;
+  if (steps)
+    *steps = n | (synced ? 0u : 0x10000u);
   if (synced) {
     const uint64_t below = old_bm & ((1ull << pos) - 1ull);
     count = n + old_cn - uint32_t(__builtin_popcountll(below));
@@ -731,7 +734,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       return; // chain already consistent here
   }
 
-  if (STITCH && j == 0)
+  if (STITCH && j == 0 && (a.ablate & 128u))
     atomicAdd(&a.results[s].stat_stitch, 1u);
   lj_stage_tables(L, a, S);
   lj_load_image(L, a, b, j); // ends with a barrier
@@ -747,7 +750,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     // known start state; every other slot decodes from its warm-up guess
     // (slot 0 of later workgroups from bit 0)
     const bool real_slot = !(lb == 0 && j == 0);
-    const uint32_t guess = lj_warmup<MULTI, PAIR>(L, dp, j);
+    const uint32_t guess = (a.ablate & 16u) ? 0u : lj_warmup<MULTI, PAIR>(L, dp, j);
     if (j >= 2 || (j == 1 && lb > 0))
       start = guess;
     else if (j == 1)
@@ -799,9 +802,9 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     }
     __syncthreads();
     const uint32_t n = L.misc[8];
-    if (n == 0)
+    if (n == 0 || (a.ablate & 32u))
       break;
-    if (j == 0) {
+    if (j == 0 && (a.ablate & 128u)) {
       atomicAdd(&a.results[s].stat_rounds, 1u);
       atomicAdd(&a.results[s].stat_redo, n);
     }
@@ -818,8 +821,23 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       } else {
         const uint64_t old_bm = uint64_t(L.bm[2 * idx]) | (uint64_t(L.bm[2 * idx + 1]) << 32);
         const bool err = (w & ST_ERR) != 0;
+        uint32_t steps = 0;
         lj_redecode_sync<PAIR>(L, dp, int(idx), w, L.ob[idx], old_bm, L.st[idx], L.cn[idx], e,
-                         c, bm, mine && !err);
+                         c, bm, mine && !err, &steps);
+        if (a.ablate & 128u) {
+          if (!mine)
+            steps = 0;
+          uint32_t mx = steps & 0xFFFFu, full = steps >> 16;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            mx = max(mx, uint32_t(__shfl_xor(mx, o, 64)));
+            full += __shfl_xor(full, o, 64);
+          }
+          if ((j & 63) == 0) {
+            atomicAdd(&a.results[s].pad2, mx);
+            atomicAdd(&a.results[s].stat_stitch, full);
+          }
+        }
         if (err) {
           e = ST_ERR;
           c = 0;
@@ -1736,6 +1754,8 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.n_streams = uint32_t(p->streams.size());
   a.total_rows = p->total_rows;
   a.ablate = getenv("RSX_ABLATE") ? uint32_t(atoi(getenv("RSX_ABLATE"))) : 0u;
+  if (getenv("RSX_DEBUG"))
+    a.ablate |= 128u; // collect the re-decode statistics
   a.nk = static_cast<const NkStreamDev*>(p->d_nk.ptr);
   a.nk_tables = static_cast<const uint32_t*>(p->d_nk_tables.ptr);
   a.nk_rowpow = static_cast<const uint32_t*>(p->d_nk_rowpow.ptr);
@@ -2371,12 +2391,12 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
       fprintf(stderr,
               "[rsx]  stream %zu: marker %u status %u flags %u avail %u needed %llu "
               "last_slot %u last_pos %u consumed %u tail %u blocks %u in_bytes %llu "
-              "redo_rounds %u redo_slots %u stitched %u\n",
+              "redo_rounds %u redo_slots %u stitched %u maxsteps %u\n",
               k, R.marker_pos, R.status, R.flags, R.avail_lo,
               (unsigned long long)p->streams[k].needed, R.last_slot, R.last_pos,
               R.consumed, R.tail_used, p->streams[k].n_blocks,
               (unsigned long long)p->streams[k].in_bytes, R.stat_rounds, R.stat_redo,
-              R.stat_stitch);
+              R.stat_stitch, R.pad2);
     }
   }
   for (int i = 0; i < p->n_jobs; ++i) {

@@ -167,7 +167,7 @@ struct LjArgs {
   uint16_t* vseed;
   uint32_t n_streams;
   uint32_t total_rows;
-  uint32_t ablate; // profiling aid (RSX_ABLATE): 1 = no K4 stores, 2 = no K4 decode loop, 4 = no K1 decode
+  uint32_t ablate; // profiling aid (RSX_ABLATE): 1 = no K4 stores, 2 = no K4 decode loop, 4 = no K1 decode, 16 = no K1 warm-up, 32 = no K1 Jacobi rounds; 128 = collect the stat_* counters (RSX_DEBUG)
   // NikonDecompressor streams
   const NkStreamDev* nk;
   const uint32_t* nk_tables; // dither tables: base | delta << 16 per 15-bit value

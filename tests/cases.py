@@ -18,7 +18,8 @@ def smooth_image(rng, h, w, prec=14, sigma=20.0, full_range=False):
     maxv = (1 << prec) - 1
     if full_range:
         return rng.integers(0, maxv + 1, size=(h, w), dtype=np.uint16)
-    base = rng.integers(1000, maxv - 1000)
+    margin = min(1000, maxv // 4)
+    base = rng.integers(margin, maxv - margin)
     x = np.arange(w)[None, :]
     y = np.arange(h)[:, None]
     # bounded ramps: wide images must not run into the clip value (a saturated,
@@ -44,7 +45,7 @@ def ljpeg_stream_rows(tile, mcu_w, mcu_h, frame_w, frame_h, rng, prec=14):
 
 def make_ljpeg_case(rng, img_w, img_h, cpp, tile, mcu, frame=None, tables=(NIKON,),
                     table_index=None, rows_per_ri=0, fix16=False, prec=14,
-                    full_range=False, init_pred=None):
+                    full_range=False, init_pred=None, sigma=20.0):
     """tile = (x, y, w, h) in pixels; mcu = (mcu_w, mcu_h); frame = (w, h) in MCUs."""
     tx, ty, tw, th = tile
     mw, mh = mcu
@@ -53,7 +54,7 @@ def make_ljpeg_case(rng, img_w, img_h, cpp, tile, mcu, frame=None, tables=(NIKON
     if frame is None:
         frame = ((req_w + mw - 1) // mw, th // mh)
     fw, fh = frame
-    tile_px = smooth_image(rng, th, req_w, prec, full_range=full_range)
+    tile_px = smooth_image(rng, th, req_w, prec, sigma=sigma, full_range=full_range)
     rows = ljpeg_stream_rows(tile_px, mw, mh, fw, fh, rng, prec)
     if table_index is None:
         table_index = [0] * n
@@ -72,6 +73,39 @@ def make_ljpeg_case(rng, img_w, img_h, cpp, tile, mcu, frame=None, tables=(NIKON
     data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8),
                            np.zeros(16, np.uint8)])
     return d, data, tile_px, len(scan)
+
+
+def random_huffman_table(rng, n_cat=17, skew=None):
+    """A random canonical JPEG table (counts[16], values) that has a code for every
+    category 0..n_cat-1: Huffman code lengths of random weights (so the Kraft sum
+    is exactly 1 before JPEG's reserved all-ones code is accounted for by adding
+    one dummy symbol), redrawn until no code is longer than 16 bits."""
+    while True:
+        if skew is None:
+            skew_ = rng.uniform(0.3, 3.0)
+        else:
+            skew_ = skew
+        wts = rng.random(n_cat + 1) ** skew_ + 1e-6
+        nodes = [(wt, [i]) for i, wt in enumerate(wts)]   # symbol n_cat = dummy
+        length = [0] * (n_cat + 1)
+        while len(nodes) > 1:
+            nodes.sort(key=lambda t: t[0])
+            (w0, s0), (w1, s1) = nodes[0], nodes[1]
+            for i in s0 + s1:
+                length[i] += 1
+            nodes = nodes[2:] + [(w0 + w1, s0 + s1)]
+        if max(length) > 16:
+            continue
+        # the dummy must own the all-ones code: make it (one of) the longest
+        lmax = max(length)
+        if length[n_cat] != lmax:
+            j = length.index(lmax)
+            length[j], length[n_cat] = length[n_cat], length[j]
+        order = sorted(range(n_cat), key=lambda i: (length[i], rng.random()))
+        counts = [0] * 16
+        for i in range(n_cat):
+            counts[length[i] - 1] += 1
+        return counts, order
 
 
 def cr2_slices(num_slices, slice_w, last_w):
@@ -94,10 +128,10 @@ def cr2_stream_from_image(img, n_comp, frame_w, frame_h, slices):
 
 
 def make_cr2_case(rng, img_w, img_h, n_comp, slices, tables=(NIKON,),
-                  table_index=None, prec=14, full_range=False):
+                  table_index=None, prec=14, full_range=False, sigma=20.0):
     """<N,1,1> CR2 stream whose LJPEG frame is img_w/n_comp x img_h."""
     frame_w, frame_h = img_w // n_comp, img_h
-    img = smooth_image(rng, img_h, img_w, prec, full_range=full_range)
+    img = smooth_image(rng, img_h, img_w, prec, sigma=sigma, full_range=full_range)
     sl = cr2_slices(*slices)
     rows = cr2_stream_from_image(img, n_comp, frame_w, frame_h, sl)
     if table_index is None:
