@@ -221,6 +221,16 @@ def main():
     ktime = plan.kernel_time()
     plan.set_timing(False)
     elapsed = grp.max_over_ranks(elapsed)
+    # copy ceiling for the same read:write mix (outside the timed region): a plain
+    # streaming kernel over the very same buffers
+    copy_ms = None
+    if rank == 0 and n_gpus == 1:
+        try:
+            copy_ms = ctx.probe_stream_copy(inp.data_ptr(), F * h * (w * bps // 8),
+                                            out.data_ptr(), F * h * opitch, stream, reps=20)
+            plan.run(inp.data_ptr(), out.data_ptr(), stream)  # the probe overwrote `out`
+        except Exception as e:
+            log("copy probe failed: %r" % (e,))
 
     pix_per_step = F * w * h * n_gpus
     value = pix_per_step * args.steps / elapsed / 1e6
@@ -305,6 +315,14 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_kernel_ms": round(avg_ms, 5), "launches_timed": n,
             }
+            if copy_ms:
+                ceil = alg_bytes / (copy_ms * 1e-3) / 1e9
+                result["roofline"]["copy_ceiling"] = {
+                    "gbps": round(ceil, 1), "avg_kernel_ms": round(copy_ms, 5),
+                    "frac_of_ceiling": round(achieved / ceil, 4),
+                    "what": "plain 16-byte load / non-temporal store kernel over the same "
+                            "buffers (same bytes in, same bytes out)",
+                }
         if not args.no_extra:
             try:
                 import bench_ljpeg

@@ -527,6 +527,16 @@ int rsx_plan_kernel_time(rsx_plan* plan, const char** kernel_name,
                          double* avg_ms, int* n_launches);
 void rsx_plan_destroy(rsx_plan* plan);
 
+/* Measurement aid, not part of the decode path: runs a plain streaming kernel
+ * (16-byte loads of in_bytes, 16-byte stores of out_bytes, device pointers) `reps`
+ * times on `stream` and returns the average duration in ms, measured with
+ * hipEvents on that stream.  bench.py uses it to report the copy ceiling of the
+ * device for the read:write mix of an unpack launch next to the vendor peak
+ * ("also report a measured device-copy ceiling"). */
+int rsx_probe_stream_copy(rsx_ctx* ctx, const void* in_dev, size_t in_bytes,
+                          void* out_dev, size_t out_bytes, void* stream, int reps,
+                          double* avg_ms);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -30,7 +30,7 @@ EXPORTS = [
     "rsx_dng_decompress_ljpeg", "rsx_dng_decompress_uncompressed",
     "rsx_unpack_plan_create", "rsx_ljpeg_plan_create", "rsx_cr2_plan_create",
     "rsx_plan_run", "rsx_plan_results", "rsx_plan_set_timing",
-    "rsx_plan_kernel_time", "rsx_plan_destroy",
+    "rsx_plan_kernel_time", "rsx_plan_destroy", "rsx_probe_stream_copy",
 ]
 
 
@@ -108,6 +108,9 @@ def lib():
         L.rsx_plan_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_char_p),
                                            C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.rsx_plan_destroy.argtypes = [C.c_void_p]
+        L.rsx_probe_stream_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                            C.c_size_t, C.c_void_p, C.c_int,
+                                            C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -144,6 +147,17 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def probe_stream_copy(self, in_ptr, in_bytes, out_ptr, out_bytes, stream=None, reps=20):
+        """Average ms of a plain streaming kernel moving in_bytes in / out_bytes out
+        (device pointers): the copy ceiling bench.py quotes next to the vendor peak."""
+        ms = C.c_double(0)
+        st = lib().rsx_probe_stream_copy(self._h, C.c_void_p(in_ptr), in_bytes,
+                                         C.c_void_p(out_ptr), out_bytes,
+                                         C.c_void_p(stream or 0), reps, C.byref(ms))
+        if st != abi.RSX_OK:
+            raise RsxError(st, self.last_error())
+        return ms.value
 
     # ---- host-pointer calls (what the patched reference methods call) ------
     def unpack_u16(self, desc, data, img_view):

@@ -1477,3 +1477,31 @@ extern "C" int rsx_dng_decompress_ljpeg(rsx_ctx* ctx, int n_tiles,
       return RSX_ERR_TILE_ERRORS; // AbstractDngDecompressor.cpp:247-251
   return RSX_OK;
 }
+
+extern "C" int rsx_probe_stream_copy(rsx_ctx* ctx, const void* in_dev, size_t in_bytes,
+                                     void* out_dev, size_t out_bytes, void* stream,
+                                     int reps, double* avg_ms) {
+  if (!ctx || !in_dev || !out_dev || reps < 1 || !avg_ms)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  RSX_HIP_CHECK(ctx, hipEventCreate(&e0));
+  RSX_HIP_CHECK(ctx, hipEventCreate(&e1));
+  hipError_t err = hipEventRecord(e0, s);
+  for (int i = 0; i < reps && err == hipSuccess; ++i)
+    err = launch_stream_probe(in_dev, in_bytes, out_dev, out_bytes, s);
+  if (err == hipSuccess)
+    err = hipEventRecord(e1, s);
+  if (err == hipSuccess)
+    err = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (err == hipSuccess)
+    err = hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  RSX_HIP_CHECK(ctx, err);
+  *avg_ms = double(ms) / reps;
+  return RSX_OK;
+}

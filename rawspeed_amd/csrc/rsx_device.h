@@ -71,6 +71,10 @@ struct SrawJobDev {
   uint32_t blocks_per_row;
 };
 
+// measurement aid: plain streaming kernel moving in_bytes in and out_bytes out
+hipError_t launch_stream_probe(const void* in, uint64_t in_bytes, void* out,
+                               uint64_t out_bytes, hipStream_t stream);
+
 uint32_t sraw_blocks_for(SrawJobDev* j);
 hipError_t launch_sraw(const SrawJobDev* d_jobs, const uint32_t* d_block_start, int n_jobs,
                        uint32_t total_blocks, const bool versions[3], const void* in_base,

@@ -625,4 +625,63 @@ hipError_t launch_unpack(int order, const UnpackJobDev* d_jobs,
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Measurement aid (rsx_probe_stream_copy): the plainest kernel that moves the
+// same bytes as an unpack launch -- 16-byte loads of `n_in16` chunks, 16-byte
+// non-temporal stores of `n_out16` chunks, nothing in between.  Its rate is the
+// copy ceiling of this device for that read:write mix; bench.py reports the
+// unpack kernel against it next to the 8 TB/s vendor peak.
+// ---------------------------------------------------------------------------
+namespace {
+template <int U>
+__global__ __launch_bounds__(256) void stream_probe_kernel(const uint4* __restrict__ in,
+                                                           uint64_t n_in16,
+                                                           uint4* __restrict__ out,
+                                                           uint64_t n_out16) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const uint64_t n = n_in16 > n_out16 ? n_in16 : n_out16;
+  // a workgroup owns U consecutive 4 KB pieces; all loads are issued before the stores
+  const uint64_t base = (uint64_t(blockIdx.x) * U) * 256 + threadIdx.x;
+  u32x4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint64_t i = base + uint64_t(u) * 256;
+    v[u] = u32x4{0u, 0u, 0u, 0u};
+    if (i < n_in16)
+      v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(in) + i);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint64_t i = base + uint64_t(u) * 256;
+    if (i < n_out16)
+      __builtin_nontemporal_store(v[u], reinterpret_cast<u32x4*>(out) + i);
+    else if (i < n && v[u].x == 0x12345678u && v[u].y == 0x9ABCDEF0u && v[u].z == v[u].w)
+      out[0].x = v[u].w; // keeps the load alive when there is no matching store
+  }
+}
+} // namespace
+
+hipError_t launch_stream_probe(const void* in, uint64_t in_bytes, void* out,
+                               uint64_t out_bytes, hipStream_t stream) {
+  const uint64_t n_in16 = in_bytes / 16, n_out16 = out_bytes / 16;
+  const uint64_t n = n_in16 > n_out16 ? n_in16 : n_out16;
+  if (n == 0)
+    return hipSuccess;
+  // one chunk per lane, like the unpack kernels (RSX_PROBE_UNROLL = 2 / 4: more
+  // loads in flight per lane)
+  static const int unroll = getenv("RSX_PROBE_UNROLL") ? atoi(getenv("RSX_PROBE_UNROLL")) : 1;
+  const int U = unroll == 4 ? 4 : unroll == 2 ? 2 : 1;
+  const uint64_t blocks = (n + 256ull * U - 1) / (256ull * U);
+  const dim3 grid{uint32_t(blocks)}, block(256);
+  const uint4* pi = static_cast<const uint4*>(in);
+  uint4* po = static_cast<uint4*>(out);
+  if (U == 4)
+    hipLaunchKernelGGL(stream_probe_kernel<4>, grid, block, 0, stream, pi, n_in16, po, n_out16);
+  else if (U == 2)
+    hipLaunchKernelGGL(stream_probe_kernel<2>, grid, block, 0, stream, pi, n_in16, po, n_out16);
+  else
+    hipLaunchKernelGGL(stream_probe_kernel<1>, grid, block, 0, stream, pi, n_in16, po, n_out16);
+  return hipGetLastError();
+}
+
 } // namespace rsx
