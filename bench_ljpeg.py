@@ -396,6 +396,56 @@ def run_hasselblad(ctx, torch, log, frames=4, steps=10, warmup=2, cpu=True):
     return out
 
 
+def run_sony_arw1(ctx, torch, log, frames=8, steps=10, warmup=2, cpu=True):
+    """SonyArw1Decompressor: the A100's 3881x2608 12-bit frame
+    (ArwDecoder.cpp:128-129), column-major stream, one running predictor."""
+    from rawspeed_amd import abi, synth
+    W, H = 3881, 2608
+    src = (synth.sensor_image(W + 1, H, 14, seed=12)[:, :W] >> 2).astype(np.uint16)
+    data, sym_bits = synth.sony_arw1_encode(src)
+    data = np.concatenate([data, np.zeros(16 + (-len(data)) % 16, np.uint8)])
+    jobs = []
+    for f in range(frames):
+        j = abi.SonyArw1Job()
+        j.in_offset, j.in_bytes = f * data.size, data.size
+        j.img_offset = f * out_pitch(W) * H
+        j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
+            out_pitch(W), W, H, 1, 1
+        jobs.append(j)
+    inp = torch.from_numpy(np.tile(data, frames)).cuda()
+    outb = torch.zeros(frames * out_pitch(W) * H, dtype=torch.uint8, device="cuda")
+    plan = ctx.sony_arw1_plan(jobs)
+    dt, kt, _ = _time_plan(torch, plan, inp, outb, steps, warmup)
+    plan.close()
+    got = outb[-out_pitch(W) * H:].cpu().numpy().view(np.uint16).reshape(
+        H, out_pitch(W) // 2)[:, :W]
+    out = {"workload": "SonyArw1Decompressor %dx%d, %d frames/step" % (W, H, frames),
+           "mpix_per_s": round(frames * W * H / dt / 1e6, 1),
+           "ms_per_step": round(dt * 1e3, 4),
+           "bit_exact": bool(np.array_equal(got, src)),
+           "entropy_bits_per_px": round(sym_bits / (W * H), 3)}
+    if cpu:
+        try:
+            from oracle_lib import Ref
+            if Ref.available():
+                ref = Ref()
+                img = ref.image(W, H, 1)
+                assert ref.sony_arw1(data, img) == 0
+                times = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    ref.sony_arw1(data, img)
+                    times.append(time.perf_counter() - t0)
+                out["cpu_baseline"] = {
+                    "value": round(W * H / min(times) / 1e6, 1), "unit": "MPix/s", "cores": 1,
+                    "kind": "reference",
+                    "sample": "SonyArw1Decompressor::decompress of the unmodified reference on "
+                              "the same stream, 1 thread, best of 3"}
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
 def run_variants(ctx, torch, log, frames=8, steps=50, warmup=20):
     """The fixed-layout UncompressedDecompressor entry points at the
     cfg2 sensor size: decode12BitRawWithControl<big>, decode12BitRawUnpacked-
@@ -454,6 +504,10 @@ def run(ctx, torch, log):
     except Exception as e:
         out["hasselblad_8272x6200"] = {"error": repr(e)}
     try:
+        out["sony_arw1_3881x2608"] = run_sony_arw1(ctx, torch, log)
+    except Exception as e:
+        out["sony_arw1_3881x2608"] = {"error": repr(e)}
+    try:
         out["cr2_sraw1_3960x2640"] = run_sraw(ctx, torch, log)
     except Exception as e:
         out["cr2_sraw1_3960x2640"] = {"error": repr(e)}
@@ -486,6 +540,8 @@ if __name__ == "__main__":
     elif args.only == "nikon":
         print(json.dumps(run_nikon(ctx, torch, print, frames=args.frames, steps=args.steps),
                          indent=1))
+    elif args.only == "sony":
+        print(json.dumps(run_sony_arw1(ctx, torch, print, steps=args.steps), indent=1))
     elif args.only == "hasselblad":
         print(json.dumps(run_hasselblad(ctx, torch, print, steps=args.steps), indent=1))
     elif args.only == "sraw":

@@ -366,6 +366,24 @@ int rsx_hasselblad_decompress(rsx_ctx* ctx, const rsx_hasselblad_desc* d, const 
                               size_t in_bytes, const rsx_image* img, uint32_t* consumed);
 
 /* ------------------------------------------------------------------------ */
+/* 3f. SonyArw1Decompressor                                                  */
+/*    replaces SonyArw1Decompressor::decompress(ByteStream)                  */
+/*    (decompressors/SonyArw1Decompressor.h:44, .cpp:59-93): BitStreamerMSB, */
+/*    a fixed prefix code for the difference length (2 bits -> 4 - x; "011"  */
+/*    = 0; "00" + k zeros + "1" = 4 + k, capped at 17, .cpp:76-83), JPEG     */
+/*    sign extension of the difference bits, ONE predictor running through   */
+/*    the whole image in decode order: columns right to left, in each column */
+/*    the even rows top to bottom and then the odd rows (.cpp:68-74).  A     */
+/*    value outside 0..4095 is an error (isIntN(pred, 12), .cpp:88-89).  The */
+/*    constructor's checks (cpp 1, U16, w <= 4600, h <= 3072, h even,        */
+/*    .cpp:39-51) are rsx_sony_arw1_validate.  No parameters besides the     */
+/*    image: the code is fixed.                                              */
+/* ------------------------------------------------------------------------ */
+int rsx_sony_arw1_validate(const rsx_image* img);
+int rsx_sony_arw1_decompress(rsx_ctx* ctx, const uint8_t* in, size_t in_bytes,
+                             const rsx_image* img);
+
+/* ------------------------------------------------------------------------ */
 /* 4. AbstractDngDecompressor tile fan-out                                   */
 /*    replaces AbstractDngDecompressor::decompress()                         */
 /*    (AbstractDngDecompressor.h:141, .cpp:240-252) for compression 1        */
@@ -486,6 +504,13 @@ typedef struct rsx_samsung_v1_job {
   rsx_image img; /* .data ignored */
 } rsx_samsung_v1_job;
 
+typedef struct rsx_sony_arw1_job {
+  uint64_t in_offset;
+  uint64_t in_bytes;
+  uint64_t img_offset;
+  rsx_image img; /* .data ignored */
+} rsx_sony_arw1_job;
+
 int rsx_unpack_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_unpack_job* jobs,
                            rsx_plan** out_plan);
 /* F32 images: same job structure, img describes 4-byte samples */
@@ -510,6 +535,8 @@ int rsx_sraw_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_sraw_job* jobs,
                          rsx_plan** out_plan);
 int rsx_hasselblad_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_hasselblad_job* jobs,
                                rsx_plan** out_plan);
+int rsx_sony_arw1_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_sony_arw1_job* jobs,
+                              rsx_plan** out_plan);
 /* Enqueue one pass of the plan on `stream`. */
 int rsx_plan_run(rsx_plan* plan, const void* in_dev, void* out_dev,
                  void* stream);

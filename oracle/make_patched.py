@@ -240,6 +240,17 @@ HUNK_SRAW = r'''
   }
 '''
 
+HUNK_SONY_ARW1 = r'''
+  // ---- rsx: forward to the MI355X core (INTEGRATION.md 3f) ----
+  {
+    const rsx_image img = rsx_shim::view(mRaw);
+    const Buffer in = input.peekRemainingBuffer();
+    if (int st = rsx_sony_arw1_decompress(rsx_shim::context(), in.begin(), in.getSize(), &img))
+      rsx_shim::raise(st);
+    return;
+  }
+'''
+
 HUNK_HASSELBLAD = r'''
   // ---- rsx: forward to the MI355X core (INTEGRATION.md 3e) ----
   {
@@ -274,6 +285,8 @@ PATCHES = [
         ("void Cr2sRawInterpolator::interpolate(int version) {", HUNK_SRAW)]),
     ("decompressors/HasselbladDecompressor.cpp", [
         ("ByteStream::size_type HasselbladDecompressor::decompress() {", HUNK_HASSELBLAD)]),
+    ("decompressors/SonyArw1Decompressor.cpp", [
+        ("void SonyArw1Decompressor::decompress(ByteStream input) const {", HUNK_SONY_ARW1)]),
     ("decompressors/LJpegDecompressor.cpp", [
         ("ByteStream::size_type LJpegDecompressor::decode() const {", HUNK_LJPEG)]),
     ("decompressors/Cr2DecompressorImpl.h", [

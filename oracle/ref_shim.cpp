@@ -33,6 +33,7 @@
 #include "decompressors/NikonDecompressor.h"
 #include "decompressors/PentaxDecompressor.h"
 #include "decompressors/SamsungV1Decompressor.h"
+#include "decompressors/SonyArw1Decompressor.h"
 #include "decompressors/UncompressedDecompressor.h"
 #include "interpolators/Cr2sRawInterpolator.h"
 #include "io/Buffer.h"
@@ -348,6 +349,16 @@ int ref_samsung_v1_decompress(void* h, int bits, const uint8_t* in, size_t in_by
     const Buffer b(in, implicit_cast<Buffer::size_type>(in_bytes));
     SamsungV1Decompressor s1(r->img, ByteStream(DataBuffer(b, Endianness::little)), bits);
     s1.decompress();
+  });
+}
+
+// SonyArw1Decompressor, as ArwDecoder drives it (ArwDecoder.cpp:133-136, :252-254)
+int ref_sony_arw1_decompress(void* h, const uint8_t* in, size_t in_bytes) {
+  auto* r = static_cast<RefImage*>(h);
+  return guarded([&] {
+    const Buffer b(in, implicit_cast<Buffer::size_type>(in_bytes));
+    SonyArw1Decompressor a(r->img);
+    a.decompress(ByteStream(DataBuffer(b, Endianness::little)));
   });
 }
 

@@ -1444,6 +1444,61 @@ int oracle_samsung_v1_decompress(const rsx_samsung_v1_desc* d, const uint8_t* in
 }
 
 /* ======================================================================== */
+/* SonyArw1Decompressor (decompressors/SonyArw1Decompressor.cpp)              */
+/* ======================================================================== */
+
+int oracle_sony_arw1_validate(const rsx_image* img) {
+  if (img->cpp != 1)
+    return RSX_ERR_INVALID_ARG; /* :41-43 */
+  if (img->dim_x <= 0 || img->dim_y <= 0 || img->dim_y % 2 != 0 || img->dim_x > 4600 ||
+      img->dim_y > 3072)
+    return RSX_ERR_INVALID_ARG; /* :48-49 */
+  return RSX_OK;
+}
+
+/* decompress :59-93 */
+int oracle_sony_arw1_decompress(const uint8_t* in, size_t in_bytes, const rsx_image* img) {
+  int st = oracle_sony_arw1_validate(img);
+  if (st)
+    return st;
+  bitreader b;
+  br_init(&b, in, (int64_t)in_bytes, RSX_ORDER_MSB);
+  if (b.err)
+    return b.err;
+  const int W = img->dim_x, H = img->dim_y;
+  int pred = 0;
+  for (int col = W - 1; col >= 0; --col) {
+    for (int row = 0; row < H + 1; row += 2) {
+      br_fill(&b, 32); /* :70 */
+      if (b.err)
+        return b.err;
+      if (row == H)
+        row = 1; /* :72-73: the odd rows follow the even ones */
+      uint32_t len = 4 - br_get_nofill(&b, 2);
+      if (len == 3 && br_get_nofill(&b, 1))
+        len = 0;
+      if (len == 4)
+        while (len < 17 && !br_get_nofill(&b, 1))
+          len++;
+      int diff = 0;
+      if (len) { /* getDiff :53-57 */
+        const uint32_t v = br_get_nofill(&b, (int)len);
+        diff = (int)v;
+        if ((v & (1u << (len - 1))) == 0)
+          diff -= (1 << len) - 1; /* PrefixCodeDecoder<>::extend */
+      }
+      pred += diff;
+      if (((unsigned)pred >> 12) != 0)
+        return RSX_ERR_VALUE_RANGE; /* !isIntN(pred, 12) :88-89: adt/Bit.h:85-90 tests
+                                       the value AS UNSIGNED, i.e. 0 <= pred < 4096 */
+      ((uint16_t*)((uint8_t*)img->data + (size_t)row * img->pitch_bytes))[col] =
+          (uint16_t)pred;
+    }
+  }
+  return RSX_OK;
+}
+
+/* ======================================================================== */
 /* Cr2sRawInterpolator (interpolators/Cr2sRawInterpolator.cpp)                */
 /* ======================================================================== */
 

@@ -151,6 +151,11 @@ class SamsungV1Job(C.Structure):
                 ("img", Image)]
 
 
+class SonyArw1Job(C.Structure):
+    _fields_ = [("in_offset", C.c_uint64), ("in_bytes", C.c_uint64),
+                ("img_offset", C.c_uint64), ("img", Image)]
+
+
 class SrawDesc(C.Structure):
     _fields_ = [("version", C.c_int32), ("subsampling_y", C.c_int32),
                 ("sraw_coeffs", C.c_int32 * 3), ("hue", C.c_int32)]

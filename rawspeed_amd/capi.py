@@ -27,6 +27,7 @@ EXPORTS = [
     "rsx_pentax_validate", "rsx_pentax_decompress", "rsx_pentax_plan_create",
     "rsx_hasselblad_validate", "rsx_hasselblad_decompress", "rsx_hasselblad_plan_create",
     "rsx_samsung_v1_validate", "rsx_samsung_v1_decompress", "rsx_samsung_v1_plan_create",
+    "rsx_sony_arw1_validate", "rsx_sony_arw1_decompress", "rsx_sony_arw1_plan_create",
     "rsx_dng_decompress_ljpeg", "rsx_dng_decompress_uncompressed",
     "rsx_unpack_plan_create", "rsx_ljpeg_plan_create", "rsx_cr2_plan_create",
     "rsx_plan_run", "rsx_plan_results", "rsx_plan_set_timing",
@@ -84,6 +85,9 @@ def lib():
         L.rsx_hasselblad_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.rsx_hasselblad_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p, C.c_void_p]
+        L.rsx_sony_arw1_validate.argtypes = [C.c_void_p]
+        L.rsx_sony_arw1_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
+                                               C.c_void_p]
         L.rsx_samsung_v1_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.rsx_samsung_v1_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p]
@@ -99,7 +103,8 @@ def lib():
                      "rsx_cr2_plan_create", "rsx_unpack_variant_plan_create",
                      "rsx_nikon_plan_create", "rsx_unpack_f32_plan_create",
                      "rsx_pentax_plan_create", "rsx_samsung_v1_plan_create",
-                     "rsx_sraw_plan_create", "rsx_hasselblad_plan_create"):
+                     "rsx_sraw_plan_create", "rsx_hasselblad_plan_create",
+                     "rsx_sony_arw1_plan_create"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p,
                                          C.POINTER(C.c_void_p)]
         L.rsx_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -215,6 +220,11 @@ class Context:
         return lib().rsx_samsung_v1_decompress(self._h, C.byref(desc), a.ctypes.data,
                                                a.size, C.byref(img_view))
 
+    def sony_arw1_decompress(self, data, img_view):
+        a = _u8(data)
+        return lib().rsx_sony_arw1_decompress(self._h, a.ctypes.data, a.size,
+                                              C.byref(img_view))
+
     def dng_decompress_ljpeg(self, descs, datas, img_view):
         n = len(descs)
         arrs = [_u8(d) for d in datas]
@@ -263,6 +273,9 @@ class Context:
 
     def samsung_v1_plan(self, jobs):
         return Plan(self, "rsx_samsung_v1_plan_create", abi.SamsungV1Job, jobs)
+
+    def sony_arw1_plan(self, jobs):
+        return Plan(self, "rsx_sony_arw1_plan_create", abi.SonyArw1Job, jobs)
 
     def pentax_plan(self, jobs):
         return Plan(self, "rsx_pentax_plan_create", abi.PentaxJob, jobs)

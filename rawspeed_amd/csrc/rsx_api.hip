@@ -1274,6 +1274,78 @@ extern "C" int rsx_samsung_v1_plan_create(rsx_ctx* ctx, int n_jobs,
   return RSX_OK;
 }
 
+extern "C" int rsx_sony_arw1_validate(const rsx_image* img) {
+  if (!img)
+    return RSX_ERR_INVALID_ARG;
+  return validate_sony_arw1(*img);
+}
+
+namespace {
+// SonyArw1Decompressor.cpp:76-83 as (code length, difference length) pairs in
+// ascending code order of an 11-bit table: "00" + k zeros + "1" = 4 + k for
+// k = 8 .. 0, "010" = 3, "011" = 0, "10" = 2, "11" = 1.  The first slot is the
+// prefix of the lengths 13..17 (codes of 12..15 bits): such a difference is at
+// least 4096 in magnitude, so the value always leaves 0..4095 and the
+// reference throws (.cpp:88-89) -- an invalid code here, reported the same way.
+constexpr uint8_t SONY_ENC[14] = {11, 11, 10, 9, 8, 7, 6, 5, 4, 3, 3, 3, 2, 2};
+constexpr uint8_t SONY_DIF[14] = {0xFF, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 0, 2, 1};
+} // namespace
+
+extern "C" int rsx_sony_arw1_plan_create(rsx_ctx* ctx, int n_jobs,
+                                         const rsx_sony_arw1_job* jobs,
+                                         rsx_plan** out_plan) {
+  if (!ctx || !jobs || n_jobs < 1 || !out_plan)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto plan = std::make_unique<rsx_plan>();
+  plan->ctx = ctx;
+  plan->kind = PLAN_LJPEG;
+  plan->n_jobs = n_jobs;
+  std::vector<LJpegJobIn> in(n_jobs);
+  for (int i = 0; i < n_jobs; ++i) {
+    const rsx_image& img = jobs[i].img;
+    LJpegJobIn& J = in[i];
+    J.status = validate_sony_arw1(img);
+    if (J.status == RSX_OK && img.pitch_bytes % 2 != 0)
+      J.status = RSX_ERR_INVALID_ARG;
+    if (J.status != RSX_OK)
+      continue;
+    StreamGeom& g = J.geom;
+    std::memset(&g, 0, sizeof g);
+    g.kind = 2; // int32 sums + range check, like Pentax; sony_* reconstruction kernels
+    g.raw = 1;  // BitStreamerMSB, fill(32) per pixel (.cpp:70)
+    g.in_offset = jobs[i].in_offset;
+    g.in_bytes = jobs[i].in_bytes;
+    g.img_offset = jobs[i].img_offset;
+    g.img_pitch_bytes = img.pitch_bytes;
+    g.n_comp = 2;
+    g.period = 2;
+    // a stream row is an image column (.cpp:68-69): W rows of H samples
+    g.rows = uint32_t(img.dim_x);
+    g.row_samples = uint32_t(img.dim_y);
+    g.mcu_w = g.mcu_h = 1;
+    g.keep_samples = g.row_samples;
+    J.n_tables = 1;
+    J.explicit_enc_len = SONY_ENC;
+    J.explicit_diff_len = SONY_DIF;
+    J.explicit_n = 14;
+    J.explicit_bits = 11;
+    J.nikon.uncorrected = true;
+    J.nikon.pentax = true;
+    J.nikon.range_bits = 12;
+    J.nikon.sony = true;
+    J.nikon.height = img.dim_x;
+    J.nikon.seed_offset = jobs[i].in_offset;
+  }
+  LJpegPlan* lp = nullptr;
+  if (int st = ljpeg_plan_create(ctx, in, &lp))
+    return st;
+  plan->ljpeg.reset(lp);
+  *out_plan = plan.release();
+  return RSX_OK;
+}
+
 namespace {
 
 // Generic host-pointer runner for LJPEG-family jobs sharing one host image.
@@ -1295,6 +1367,9 @@ HostRect out_rect(const rsx_pentax_job& j) {
   return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
 }
 HostRect out_rect(const rsx_samsung_v1_job& j) {
+  return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
+}
+HostRect out_rect(const rsx_sony_arw1_job& j) {
   return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
 }
 HostRect out_rect(const rsx_hasselblad_job& j) {
@@ -1446,6 +1521,16 @@ extern "C" int rsx_samsung_v1_decompress(rsx_ctx* ctx, const rsx_samsung_v1_desc
   jobs[0].in_bytes = in_bytes;
   int32_t st = RSX_OK;
   return ljpeg_family_host(ctx, 1, jobs, &in, img, rsx_samsung_v1_plan_create, &st, nullptr);
+}
+
+extern "C" int rsx_sony_arw1_decompress(rsx_ctx* ctx, const uint8_t* in, size_t in_bytes,
+                                        const rsx_image* img) {
+  if (!ctx || !in || !img || !img->data)
+    return RSX_ERR_INVALID_ARG;
+  std::vector<rsx_sony_arw1_job> jobs(1);
+  jobs[0].in_bytes = in_bytes;
+  int32_t st = RSX_OK;
+  return ljpeg_family_host(ctx, 1, jobs, &in, img, rsx_sony_arw1_plan_create, &st, nullptr);
 }
 
 extern "C" int rsx_dng_decompress_ljpeg(rsx_ctx* ctx, int n_tiles,

@@ -585,23 +585,35 @@ int validate_samsung_v1(const rsx_samsung_v1_desc& d, const rsx_image& img) {
 }
 
 void build_device_table_explicit(const uint8_t* enc_len, const uint8_t* diff_len, int n,
-                                 DeviceHuffTable* out) {
+                                 DeviceHuffTable* out, int bits) {
   std::memset(out, 0, sizeof *out);
   for (int l = 0; l < 18; ++l)
     out->max_code[l] = 0xFFFFFFFFu;
-  out->max_len = 10;
-  uint32_t pos = 0; // index into the 1024-entry table of the reference
+  out->max_len = uint8_t(bits);
+  const uint32_t size = 1u << bits, rep = 1u << (LUT_BITS - bits);
+  uint32_t pos = 0; // index into the 2^bits-entry table of the reference
   for (int i = 0; i < n; ++i) {
     const uint32_t l = enc_len[i], ssss = diff_len[i];
-    const uint16_t e = uint16_t(l | (ssss << 5) | ((l + ssss) << 10));
-    const uint32_t cnt = 1024u >> l;
-    // LUT_BITS = 11: every 10-bit index covers two LUT slots
-    for (uint32_t c = pos; c < pos + cnt; ++c)
-      out->lut[2 * c] = out->lut[2 * c + 1] = e;
+    const bool invalid = diff_len[i] == 0xFF;
+    const uint16_t e = invalid ? uint16_t(0) : uint16_t(l | (ssss << 5) | ((l + ssss) << 10));
+    const uint32_t cnt = size >> l;
+    // every index of the reference's table covers `rep` LUT slots
+    for (uint32_t c = pos * rep; c < (pos + cnt) * rep; ++c)
+      out->lut[c] = e;
     if (pos == 0)
-      out->zero_sym_bits = uint8_t(l + ssss);
+      out->zero_sym_bits = invalid ? uint8_t(0) : uint8_t(l + ssss);
     pos += cnt;
   }
+}
+
+// SonyArw1Decompressor::SonyArw1Decompressor (decompressors/SonyArw1Decompressor.cpp:39-51)
+int validate_sony_arw1(const rsx_image& img) {
+  if (img.cpp != 1) // :41-43
+    return RSX_ERR_INVALID_ARG;
+  if (img.dim_x <= 0 || img.dim_y <= 0 || img.dim_y % 2 != 0 || img.dim_x > 4600 ||
+      img.dim_y > 3072) // :48-49
+    return RSX_ERR_INVALID_ARG;
+  return RSX_OK;
 }
 
 // Cr2sRawInterpolator::interpolate (interpolators/Cr2sRawInterpolator.cpp:510-542) and

@@ -29,6 +29,7 @@ int validate_cr2(const rsx_cr2_desc& d, const rsx_image& img);
 int validate_nikon(const rsx_nikon_desc& d, const rsx_image& img);
 int validate_pentax(const rsx_pentax_desc& d, const rsx_image& img);
 int validate_samsung_v1(const rsx_samsung_v1_desc& d, const rsx_image& img);
+int validate_sony_arw1(const rsx_image& img);
 int validate_hasselblad(const rsx_hasselblad_desc& d, const rsx_image& img);
 int validate_sraw(const rsx_sraw_desc& d, const rsx_image& in, const rsx_image& out);
 
@@ -68,9 +69,10 @@ struct DeviceHuffTable {
 
 void build_device_table(const rsx_huff_table& t, DeviceHuffTable* out, bool las = false);
 // (encLen, diffLen) pairs in table-fill order -> the device LUT (no slow path:
-// every code is at most 10 bits)
+// every code is at most `bits` <= LUT_BITS bits; the pairs tile a 2^bits table).
+// diffLen 0xFF marks codes that are always an error.
 void build_device_table_explicit(const uint8_t* enc_len, const uint8_t* diff_len, int n,
-                                 DeviceHuffTable* out);
+                                 DeviceHuffTable* out, int bits = 10);
 int validate_las_table(const rsx_huff_table& t);
 
 // ------------------------------------------------------------------------

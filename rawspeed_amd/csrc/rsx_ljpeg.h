@@ -17,6 +17,8 @@ struct NikonIn {
   bool pentax = false;    // PentaxDecompressor / SamsungV1: predictors start at 0, a
                           // value that does not fit range_bits bits is an error
   int range_bits = 16;
+  bool sony = false;      // SonyArw1Decompressor: a stream row is an image column, ONE
+                          // predictor runs through all rows, values must be 0..4095
   int split = 0;          // rows >= split use table_after_split (0 = none)
   int height = 0;         // image rows
   std::vector<uint32_t> dither; // 32768 x (base | delta << 16); empty if uncorrected
@@ -37,6 +39,7 @@ struct LJpegJobIn {
   const uint8_t* explicit_enc_len = nullptr;
   const uint8_t* explicit_diff_len = nullptr;
   int explicit_n = 0;
+  int explicit_bits = 10; // index width of that table (<= LUT_BITS)
 };
 
 struct LJpegPlan;

@@ -1712,6 +1712,7 @@ struct LJpegPlan {
   std::vector<std::pair<int, int>> child_owner; // child job -> (dri index, interval)
   // NikonDecompressor streams
   bool any_nikon = false, any_las = false, any_plain = false, any_pair = false;
+  bool any_sony = false;
   std::vector<NkStreamDev> nk;         // parallel to streams
   DeviceBuffer d_nk, d_nk_tables, d_nk_rowpow, d_nk_pup;
   DeviceBuffer d_transfer; // fallback path only (allocated on first use)
@@ -1886,7 +1887,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     if (J.explicit_n > 0) {
       tables.emplace_back();
       build_device_table_explicit(J.explicit_enc_len, J.explicit_diff_len, J.explicit_n,
-                                  &tables.back());
+                                  &tables.back(), J.explicit_bits);
     } else {
       for (int t = 0; t < J.n_tables; ++t) {
         tables.emplace_back();
@@ -1905,6 +1906,8 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       K.pup_in = N.pup_in;
       K.uncorrected = N.uncorrected ? 1u : 0u;
       K.pentax = N.pentax ? uint32_t(N.range_bits) : 0u;
+      K.sony = N.sony ? 1u : 0u;
+      p->any_sony |= N.sony;
       K.seed_offset = N.seed_offset;
       K.table_off = uint32_t(nk_tables.size());
       if (!N.uncorrected)
@@ -2028,6 +2031,7 @@ int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s, hipEvent_t ev_star
   rl.total_rows = p->total_rows;
   std::copy(p->comp_present, p->comp_present + 7, rl.comp_present);
   rl.any_nikon = p->any_nikon;
+  rl.any_sony = p->any_sony;
   ljpeg_launch_reconstruct(a, rl, s);
   hipLaunchKernelGGL(lj_consumed_kernel, dim3(n_streams), dim3(64), 0, s, a);
   RSX_HIP_CHECK(ctx, hipGetLastError());
@@ -2421,6 +2425,10 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
         consumed = R.consumed;
         if (st == RSX_OK && S.kind == 0 && !S.pair && uint64_t(consumed) > S.in_bytes)
           st = RSX_ERR_IO; // inputStream.skipBytes(): LJpegDecompressor.cpp:335
+        // SonyArw1: the codes missing from the table are the lengths 13..17, whose
+        // differences always take the value out of range (SonyArw1Decompressor.cpp:88)
+        if (st == RSX_ERR_BAD_HUFFMAN_CODE && S.kind == 2 && p->nk[fs + k].sony)
+          st = RSX_ERR_VALUE_RANGE;
       }
     }
     for (size_t k = 0; k < p->nk_split.size(); ++k)

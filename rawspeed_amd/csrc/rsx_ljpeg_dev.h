@@ -126,6 +126,10 @@ struct NkStreamDev {
                          //    no clamp; = number of bits a value may have, more is
                          //    RSX_ERR_VALUE_RANGE
   uint64_t seed_offset;  // byte offset (from in_base) of the job's first input byte
+  uint32_t sony;         // != 0: SonyArw1Decompressor (.cpp:59-93): stream row r = image column
+                         //    W-1-r (even rows, then odd rows), one predictor through all rows,
+                         //    values outside 0..4095 are RSX_ERR_VALUE_RANGE
+  uint32_t pad_;
 };
 
 struct LjResult {
@@ -184,6 +188,7 @@ struct ReconLaunch {
   uint32_t total_rows = 0;
   bool comp_present[7] = {}; // [1..4] interleaved n_comp; [5], [6]: sRaw groups of 4, 6
   bool any_nikon = false;
+  bool any_sony = false;
 };
 
 // K5 + K6 (and their Nikon / Pentax counterparts) on `stream`

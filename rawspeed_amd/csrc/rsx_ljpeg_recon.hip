@@ -460,6 +460,8 @@ __global__ __launch_bounds__(VS_T) void nk_vseed_kernel(LjArgs a) {
   if (S.kind != 2 || a.results[s].status != 0)
     return;
   const NkStreamDev& K = a.nk[s];
+  if (K.sony)
+    return; // sony_* kernels
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const uint32_t rows = S.rows;
   const int16_t* __restrict__ D = a.diffs + S.diff_offset;
@@ -540,6 +542,8 @@ __global__ __launch_bounds__(LJ_T) void nk_predict_kernel(LjArgs a) {
   if (S.kind != 2 || a.results[lo].status != 0)
     return;
   const NkStreamDev& K = a.nk[lo];
+  if (K.sony)
+    return; // sony_predict_kernel
   const uint32_t r = grow - S.first_row;
   if (r >= S.rows)
     return;
@@ -669,6 +673,227 @@ __global__ __launch_bounds__(LJ_T) void nk_predict_kernel(LjArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// SonyArw1Decompressor (decompressors/SonyArw1Decompressor.cpp:59-93).  A stream
+// row is an image column (the rightmost first): its H samples are the even image
+// rows top to bottom, then the odd ones.  ONE predictor, starting at 0, runs
+// through all columns, so the seed of stream row r is the sum of every difference
+// of the rows before it:
+//   sony_rowsum  one wavefront per stream row: its total            -> V[2r+1]
+//   sony_vseed   one workgroup per stream: exclusive scan of totals -> V[2r]
+//   sony_predict one wavefront per stream row: int32 scan, the 0..4095 range
+//                check (isIntN(pred, 12), adt/Bit.h:85-90), values back in place
+//   sony_transpose  64 x 64 tiles: stream order -> image columns
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool sony_row(const LjArgs& a, uint32_t grow, uint32_t* stream,
+                                         uint32_t* row) {
+  if (grow >= a.total_rows)
+    return false;
+  uint32_t lo = 0, hi = a.n_streams - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (a.streams[mid].first_row <= grow)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  const LjStreamDev& S = a.streams[lo];
+  if (S.kind != 2 || !a.nk[lo].sony || a.results[lo].status != 0)
+    return false;
+  const uint32_t r = grow - S.first_row;
+  if (r >= S.rows)
+    return false;
+  *stream = lo;
+  *row = r;
+  return true;
+}
+
+__device__ __forceinline__ uint4 sony_load8(const int16_t* __restrict__ D, uint32_t q,
+                                            uint32_t n, bool aligned) {
+  if (q + 8 <= n && aligned)
+    return *reinterpret_cast<const uint4*>(D + q);
+  uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (q + i < n)
+      w[i >> 1] |= uint32_t(uint16_t(D[q + i])) << (16 * (i & 1));
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__global__ __launch_bounds__(LJ_T) void sony_rowsum_kernel(LjArgs a) {
+  const uint32_t grow = blockIdx.x * (LJ_T / 64) + (threadIdx.x >> 6);
+  uint32_t s, r;
+  if (!sony_row(a, grow, &s, &r))
+    return;
+  const LjStreamDev& S = a.streams[s];
+  const int lane = threadIdx.x & 63;
+  const uint32_t n = S.row_samples;
+  const uint64_t row0 = uint64_t(r) * n;
+  const int16_t* __restrict__ D = a.diffs + S.diff_offset + row0;
+  const bool aligned = ((S.diff_offset + row0) & 7) == 0;
+  int32_t sum = 0;
+  for (uint32_t q = lane * 8; q < n; q += 512) {
+    const uint4 t = sony_load8(D, q, n, aligned);
+    sum += int16_t(t.x) + (int32_t(t.x) >> 16) + int16_t(t.y) + (int32_t(t.y) >> 16) +
+           int16_t(t.z) + (int32_t(t.z) >> 16) + int16_t(t.w) + (int32_t(t.w) >> 16);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    sum += __shfl_xor(sum, o, 64);
+  if (lane == 0)
+    reinterpret_cast<int32_t*>(a.vseed)[uint64_t(grow) * 2 + 1] = sum;
+}
+
+__global__ __launch_bounds__(VS_T) void sony_vseed_kernel(LjArgs a) {
+  __shared__ int32_t wtot[VS_T / 64];
+  __shared__ int32_t carry_s;
+  const uint32_t s = blockIdx.x;
+  const LjStreamDev& S = a.streams[s];
+  if (S.kind != 2 || !a.nk[s].sony || a.results[s].status != 0)
+    return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int32_t* __restrict__ V = reinterpret_cast<int32_t*>(a.vseed) + uint64_t(S.first_row) * 2;
+  if (tid == 0)
+    carry_s = 0; // "int pred = 0;" :67
+  __syncthreads();
+  for (uint32_t r0 = 0; r0 < S.rows; r0 += VS_T) {
+    const uint32_t r = r0 + tid;
+    const int32_t d = r < S.rows ? V[uint64_t(r) * 2 + 1] : 0;
+    int32_t x = d;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t y = __shfl_up(x, o, 64);
+      if (lane >= o)
+        x += y;
+    }
+    if (lane == 63)
+      wtot[wv] = x;
+    __syncthreads();
+    int32_t base = carry_s;
+    for (int w = 0; w < wv; ++w)
+      base += wtot[w];
+    if (r < S.rows)
+      V[uint64_t(r) * 2] = base + x - d; // exclusive
+    __syncthreads();
+    if (tid == VS_T - 1)
+      carry_s = base + x;
+    __syncthreads();
+  }
+}
+
+// Values are written back over the differences (stream order, coalesced); the
+// column scatter is sony_transpose_kernel's job.
+__global__ __launch_bounds__(LJ_T) void sony_predict_kernel(LjArgs a) {
+  const uint32_t grow = blockIdx.x * (LJ_T / 64) + (threadIdx.x >> 6);
+  uint32_t s, r;
+  if (!sony_row(a, grow, &s, &r))
+    return;
+  const LjStreamDev& S = a.streams[s];
+  const int lane = threadIdx.x & 63;
+  const uint32_t H = S.row_samples;
+  const uint64_t row0 = uint64_t(r) * H;
+  int16_t* __restrict__ D = a.diffs + S.diff_offset + row0;
+  const bool aligned = ((S.diff_offset + row0) & 7) == 0;
+  int32_t carry = reinterpret_cast<const int32_t*>(a.vseed)[uint64_t(grow) * 2];
+  uint4 t0 = sony_load8(D, lane * 8, H, aligned);
+  for (uint32_t q0 = 0; q0 < H; q0 += 512) {
+    const uint32_t q = q0 + lane * 8;
+    const uint4 t = t0;
+    if (q0 + 512 < H)
+      t0 = sony_load8(D, q + 512, H, aligned);
+    int32_t v[8];
+    v[0] = int16_t(t.x); v[1] = int32_t(t.x) >> 16;
+    v[2] = int16_t(t.y); v[3] = int32_t(t.y) >> 16;
+    v[4] = int16_t(t.z); v[5] = int32_t(t.z) >> 16;
+    v[6] = int16_t(t.w); v[7] = int32_t(t.w) >> 16;
+    int32_t run = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      run += v[i];
+      v[i] = run;
+    }
+    int32_t x = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t y = __shfl_up(x, o, 64);
+      if (lane >= o)
+        x += y;
+    }
+    const int32_t tot = __shfl(x, 63, 64);
+    const int32_t e = x - run + carry;
+    carry += tot;
+    bool bad = false;
+    uint32_t px[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int32_t p = v[i] + e;
+      bad |= q + i < H && (uint32_t(p) >> 12) != 0; // !isIntN(pred, 12) :88
+      px[i] = uint32_t(p) & 0xFFFFu;
+    }
+    if (bad)
+      atomicCAS(&a.results[s].status, 0u, uint32_t(RSX_ERR_VALUE_RANGE));
+    if (q >= H)
+      continue;
+    if (q + 8 <= H && aligned) {
+      uint4 o;
+      o.x = px[0] | (px[1] << 16);
+      o.y = px[2] | (px[3] << 16);
+      o.z = px[4] | (px[5] << 16);
+      o.w = px[6] | (px[7] << 16);
+      *reinterpret_cast<uint4*>(D + q) = o;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (q + i < H)
+          D[q + i] = int16_t(px[i]);
+    }
+  }
+}
+
+// Stream order -> image: stream row r is image column W-1-r ("for (int col =
+// out.width() - 1; col >= 0; col--)" :68), sample i of it is image row 2i for the
+// first half and 2(i - H/2) + 1 for the second (:69-74).  64 x 64 tiles through
+// LDS so that both the reads (along a stream row) and the writes (64 adjacent
+// image columns) are contiguous.
+constexpr int SONY_TILE = 64;
+constexpr uint32_t SONY_TILES_R = (4600 + SONY_TILE - 1) / SONY_TILE; // w <= 4600 (.cpp:48)
+constexpr uint32_t SONY_TILES_S = (3072 + SONY_TILE - 1) / SONY_TILE; // h <= 3072
+
+__global__ __launch_bounds__(LJ_T) void sony_transpose_kernel(LjArgs a) {
+  __shared__ uint16_t tile[SONY_TILE][SONY_TILE + 2];
+  const uint32_t s = blockIdx.y;
+  const LjStreamDev& S = a.streams[s];
+  if (S.kind != 2 || !a.nk[s].sony || a.results[s].status != 0)
+    return;
+  const uint32_t W = S.rows, H = S.row_samples, half = H >> 1;
+  const uint32_t r0 = (blockIdx.x / SONY_TILES_S) * SONY_TILE;
+  const uint32_t i0 = (blockIdx.x % SONY_TILES_S) * SONY_TILE;
+  if (r0 >= W || i0 >= H)
+    return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint16_t* __restrict__ P =
+      reinterpret_cast<const uint16_t*>(a.diffs + S.diff_offset);
+#pragma unroll 4
+  for (int k = 0; k < SONY_TILE / 4; ++k) {
+    const uint32_t rr = r0 + wv * (SONY_TILE / 4) + k, ii = i0 + lane;
+    tile[wv * (SONY_TILE / 4) + k][lane] =
+        (rr < W && ii < H) ? P[uint64_t(rr) * H + ii] : uint16_t(0);
+  }
+  __syncthreads();
+  uint8_t* img = a.out_base + S.img_offset;
+  const uint32_t rr = r0 + lane;
+#pragma unroll 4
+  for (int k = 0; k < SONY_TILE / 4; ++k) {
+    const uint32_t ii = i0 + wv * (SONY_TILE / 4) + k;
+    if (rr < W && ii < H) {
+      const uint32_t row = ii < half ? 2 * ii : 2 * (ii - half) + 1;
+      reinterpret_cast<uint16_t*>(img + uint64_t(row) * S.img_pitch)[W - 1 - rr] =
+          tile[lane][wv * (SONY_TILE / 4) + k];
+    }
+  }
+}
+
 } // namespace
 
 void ljpeg_launch_reconstruct(const LjArgs& a, const ReconLaunch& r, hipStream_t s) {
@@ -690,6 +915,13 @@ void ljpeg_launch_reconstruct(const LjArgs& a, const ReconLaunch& r, hipStream_t
     hipLaunchKernelGGL((lj_predict_kernel<3, 6>), grid, block, 0, s, a);
   if (r.any_nikon)
     hipLaunchKernelGGL(nk_predict_kernel, grid, block, 0, s, a);
+  if (r.any_sony) {
+    hipLaunchKernelGGL(sony_rowsum_kernel, grid, block, 0, s, a);
+    hipLaunchKernelGGL(sony_vseed_kernel, dim3(r.n_streams), dim3(VS_T), 0, s, a);
+    hipLaunchKernelGGL(sony_predict_kernel, grid, block, 0, s, a);
+    hipLaunchKernelGGL(sony_transpose_kernel, dim3(SONY_TILES_R * SONY_TILES_S, r.n_streams),
+                       block, 0, s, a);
+  }
 }
 
 } // namespace rsx

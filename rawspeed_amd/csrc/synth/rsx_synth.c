@@ -397,6 +397,62 @@ size_t rsx_synth_prefix_encode(const uint16_t* samples, size_t row_stride, int w
   return nikon_encode_tab(samples, row_stride, w, h, p_up, &tab, out, cap, n_symbol_bits);
 }
 
+/* SonyArw1Decompressor stream (SonyArw1Decompressor.cpp:59-93): plain MSB-first
+ * bits; per pixel the length code -- "11" 1, "10" 2, "010" 3, "011" 0, "00" +
+ * k zeros + "1" = 4 + k (the final "1" is absent for 17) -- then the difference
+ * bits with JPEG sign extension.  One predictor (start 0) runs over the whole
+ * image in decode order: columns right to left, in a column the even rows and
+ * then the odd rows.  `samples` may hold any int16-representable value stored as
+ * uint16 (the decoder rejects values outside 0..4095). */
+size_t rsx_synth_sony_arw1_encode(const uint16_t* samples, size_t row_stride, int w, int h,
+                                  uint8_t* out, size_t cap, uint64_t* n_symbol_bits) {
+  jpeg_writer wr = {out, cap, 0, 0, 0, 0, 1};
+  uint64_t bits = 0;
+  int pred = 0;
+  if (h & 1)
+    return 0;
+  for (int col = w - 1; col >= 0; --col) {
+    for (int i = 0; i < h; ++i) {
+      const int row = i < h / 2 ? 2 * i : 2 * (i - h / 2) + 1;
+      const int cur = (int16_t)samples[(size_t)row * row_stride + col];
+      const int d = cur - pred;
+      pred = cur;
+      int len = 0;
+      for (int a = d < 0 ? -d : d; a; a >>= 1)
+        ++len;
+      if (len > 17)
+        return 0;
+      int nb;
+      if (len == 0) {
+        jw_bits(&wr, 3, 3); /* 011 */
+        nb = 3;
+      } else if (len <= 3) {
+        static const uint8_t code[4] = {0, 3, 2, 2}, clen[4] = {0, 2, 2, 3};
+        jw_bits(&wr, code[len], clen[len]); /* 11, 10, 010 */
+        nb = clen[len];
+      } else {
+        const int k = len - 4;
+        jw_bits(&wr, 0, 2);
+        if (k)
+          jw_bits(&wr, 0, k);
+        nb = 2 + k;
+        if (len < 17) {
+          jw_bits(&wr, 1, 1);
+          ++nb;
+        }
+      }
+      bits += (uint64_t)(nb + len);
+      if (len)
+        jw_bits(&wr, d >= 0 ? (uint32_t)d : (uint32_t)(d + (1 << len) - 1), len);
+    }
+  }
+  if (wr.nacc > 0)
+    jw_bits(&wr, 0, 8 - wr.nacc);
+  if (n_symbol_bits)
+    *n_symbol_bits = bits;
+  return wr.overflow ? 0 : wr.n;
+}
+
 /* HasselbladDecompressor stream (HasselbladDecompressor.cpp:71-100): pixels two at
  * a time as [len1 code][len2 code][len1 bits][len2 bits], both predictors restart
  * from init_pred on every row, arithmetic mod 2^16; BitStreamerMSB32 input, i.e.

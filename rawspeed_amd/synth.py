@@ -52,6 +52,9 @@ def lib():
         _lib.rsx_synth_hasselblad_encode.argtypes = [
             C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_uint, C.c_void_p,
             C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        _lib.rsx_synth_sony_arw1_encode.restype = C.c_size_t
+        _lib.rsx_synth_sony_arw1_encode.argtypes = [
+            C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
         _lib.rsx_synth_ljpeg_header.restype = C.c_size_t
         _lib.rsx_synth_ljpeg_header.argtypes = [
             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
@@ -261,6 +264,22 @@ def hasselblad_encode(img, init_pred, table):
                                           len(values), out.ctypes.data, cap, C.byref(bits))
     if n == 0:
         raise ValueError("Hasselblad encode failed")
+    return out[:n].copy(), bits.value
+
+
+def sony_arw1_encode(img):
+    """img: (h, w) values in the decoder's range 0..4095 (or, to provoke its range
+    error, any int16 stored as uint16); SonyArw1Decompressor.cpp:59-93 stream:
+    columns right to left, even rows then odd rows, one running predictor."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    h, w = img.shape
+    cap = h * w * 5 + 64
+    out = np.empty(cap, dtype=np.uint8)
+    bits = C.c_uint64(0)
+    n = lib().rsx_synth_sony_arw1_encode(img.ctypes.data, w, w, h, out.ctypes.data, cap,
+                                         C.byref(bits))
+    if n == 0:
+        raise ValueError("Sony ARW1 encode failed")
     return out[:n].copy(), bits.value
 
 

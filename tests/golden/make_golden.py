@@ -22,7 +22,7 @@ def main():
     ref = Ref()
     out = {"unpack": {}, "f32": {}, "variant": {}, "ljpeg": {}, "cr2": {}, "nikon": {},
            "pentax": {}, "samsung_v1": {}, "sraw": {},
-           "hasselblad": {}}
+           "hasselblad": {}, "sony_arw1": {}}
     for i, c in enumerate(G.UNPACK_CASES):
         d, data, (w, h, cpp) = G.build_unpack(c)
         img = ref.image(w, h, cpp)
@@ -77,6 +77,11 @@ def main():
         st, consumed = ref.hasselblad(d, data, img)
         out["hasselblad"][c["name"]] = {"status": st, "consumed": consumed,
                                         "hash": G.image_hash(img.pixels())}
+    for c in G.SONY_ARW1_CASES:
+        data, (w, h, cpp), _ = G.build_sony_arw1(c)
+        img = ref.image(w, h, cpp)
+        st = ref.sony_arw1(data, img)
+        out["sony_arw1"][c["name"]] = {"status": st, "hash": G.image_hash(img.pixels())}
     path = os.path.join(HERE, "golden_hashes.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

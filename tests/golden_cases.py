@@ -276,6 +276,38 @@ def build_samsung_v1(c, seed=616):
     return d, data, (w, h, 1), src
 
 
+# ---- SonyArw1Decompressor ------------------------------------------------------------
+# (the decoder of the A100: 3881 x 2608, ArwDecoder.cpp:128-129; width may be odd)
+SONY_ARW1_CASES = [
+    dict(name="small", w=37, h=20, sigma=5.0),
+    dict(name="one_column", w=1, h=2, sigma=1.0),
+    dict(name="medium_odd_width", w=485, h=326, sigma=12.0),
+    dict(name="noisy_long_codes", w=200, h=100, sigma=700.0),
+    dict(name="tall", w=40, h=3072, sigma=8.0),
+    dict(name="wide", w=4600, h=6, sigma=8.0),
+    dict(name="range_error", w=64, h=20, sigma=5.0, poison=(7, 33, 5000)),
+    dict(name="negative_value", w=64, h=20, sigma=5.0, poison=(12, 3, -3)),
+    dict(name="random_bits", w=64, h=20, symbols=True),
+]
+
+
+def build_sony_arw1(c, seed=919):
+    rng = np.random.default_rng([seed, sum(map(ord, c["name"]))])
+    w, h = c["w"], c["h"]
+    if c.get("symbols"):
+        return rng.integers(0, 256, size=w * h * 2, dtype=np.uint8), (w, h, 1), None
+    x = np.arange(w)[None, :]
+    y = np.arange(h)[:, None]
+    src = 900 + 900.0 * x / max(w, 1) + 700.0 * y / max(h, 1) + rng.normal(0, c["sigma"], (h, w))
+    src = np.clip(src, 0, 4095).astype(np.int16)
+    if c.get("poison"):                     # a value the decoder must reject
+        r, col, v = c["poison"]
+        src[r, col] = v
+    data, _ = synth.sony_arw1_encode(src.view(np.uint16))
+    data = np.concatenate([data, np.zeros(8, np.uint8)])
+    return data, (w, h, 1), src.view(np.uint16)
+
+
 # ---- Cr2sRawInterpolator -----------------------------------------------------------
 # (version, subsampling_y, groups per row, input rows); hue and white-balance
 # coefficients in the range Cr2Decoder derives them (Cr2Decoder.cpp:560-625)

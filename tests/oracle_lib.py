@@ -104,6 +104,8 @@ class Oracle:
         L.oracle_hasselblad_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_hasselblad_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                                    C.c_void_p, C.c_void_p]
+        L.oracle_sony_arw1_validate.argtypes = [C.c_void_p]
+        L.oracle_sony_arw1_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.oracle_samsung_v1_validate.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_samsung_v1_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                                    C.c_void_p]
@@ -165,6 +167,15 @@ class Oracle:
         a, p, n = _as_u8(data)
         v = img.view()
         return self.lib.oracle_samsung_v1_decompress(C.byref(desc), p, n, C.byref(v))
+
+    def sony_arw1(self, data, img):
+        a, p, n = _as_u8(data)
+        v = img.view()
+        return self.lib.oracle_sony_arw1_decompress(p, n, C.byref(v))
+
+    def sony_arw1_validate(self, img):
+        v = img.view()
+        return self.lib.oracle_sony_arw1_validate(C.byref(v))
 
     def samsung_v1_validate(self, desc, img):
         v = img.view()
@@ -313,6 +324,7 @@ class Ref:
         L.ref_decode8bit_lookup.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                             C.c_int, C.c_void_p, C.c_size_t]
         L.ref_samsung_v1_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.ref_sony_arw1_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.ref_hasselblad_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p]
         L.ref_pentax_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
@@ -360,6 +372,10 @@ class Ref:
     def samsung_v1(self, bits, data, img):
         a, p, n = _as_u8(data)
         return self.lib.ref_samsung_v1_decompress(img.h, bits, p, n)
+
+    def sony_arw1(self, data, img):
+        a, p, n = _as_u8(data)
+        return self.lib.ref_sony_arw1_decompress(img.h, p, n)
 
     def hasselblad(self, desc, data, img):
         a, p, n = _as_u8(data)

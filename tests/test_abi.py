@@ -241,6 +241,20 @@ def test_samsung_v1_validate_matches_oracle(lib, oracle):
     assert seen == {abi.RSX_OK, abi.RSX_ERR_INVALID_ARG}
 
 
+def test_sony_arw1_validate_matches_oracle(lib, oracle):
+    rng = np.random.default_rng(18)
+    seen = set()
+    for trial in range(300):
+        img = HostImage(8, 2, int(rng.choice([1, 1, 1, 2])))
+        img.dim_x = int(rng.choice([0, 1, 37, 3881, 4600, 4601]))
+        img.dim_y = int(rng.choice([0, 1, 2, 2608, 3072, 3074, 3073]))
+        v = img.view()
+        a = lib.rsx_sony_arw1_validate(C.byref(v))
+        assert a == oracle.sony_arw1_validate(img), trial
+        seen.add(a)
+    assert seen == {abi.RSX_OK, abi.RSX_ERR_INVALID_ARG}
+
+
 def test_sraw_validate_matches_oracle(lib, oracle):
     rng = np.random.default_rng(17)
     seen = set()

@@ -280,3 +280,15 @@ def test_hasselblad_decompressor(pair):
             pair, lambda lib, img: lib.hasselblad(d, data, img), (w, h, cpp))
         assert s0 == s1 and s0[0] == 0, (s0, s1, e0, e1)
         assert np.array_equal(a, b)
+
+
+def test_sony_arw1_decompressor(pair):
+    import golden_cases as G
+    for name in ("medium_odd_width", "tall", "wide", "range_error"):
+        c = next(c for c in G.SONY_ARW1_CASES if c["name"] == name)
+        data, (w, h, cpp), _ = G.build_sony_arw1(c)
+        (s0, a, e0), (s1, b, e1) = both(
+            pair, lambda lib, img: lib.sony_arw1(data, img), (w, h, cpp))
+        assert s0 == s1, (e0, e1)
+        if s0 == 0:
+            assert np.array_equal(a, b)

@@ -224,6 +224,72 @@ def test_samsung_v1_truncation(gpu, oracle):
     assert 0 in seen and len(seen) >= 2
 
 
+# ---- SonyArw1Decompressor ----------------------------------------------------------
+
+@pytest.mark.parametrize("c", G.SONY_ARW1_CASES, ids=lambda c: c["name"])
+def test_sony_arw1_golden(gpu, oracle, c):
+    data, (w, h, cpp), src = G.build_sony_arw1(c)
+    img, want = HostImage(w, h, cpp), HostImage(w, h, cpp)
+    st = gpu.sony_arw1_decompress(data, img.view())
+    assert st == oracle.sony_arw1(data, want)
+    if st == 0:
+        assert np.array_equal(img.u16(), want.u16())
+        assert G.image_hash(img.pixels()) == GOLD["sony_arw1"][c["name"]]["hash"]
+        assert np.array_equal(img.pixels(), src)
+    else:
+        assert st == abi.RSX_ERR_VALUE_RANGE
+
+
+def test_sony_arw1_full_frame_and_truncation(gpu, oracle):
+    """The A100's 3881 x 2608 frame (ArwDecoder.cpp:128-129: odd width, several
+    hundred workgroups in one stream), then status parity at every cut."""
+    rng = np.random.default_rng(57)
+    w, h = 3881, 2608
+    x = np.arange(w)[None, :]
+    y = np.arange(h)[:, None]
+    src = np.clip(600 + 0.5 * x + 0.4 * y + rng.normal(0, 9, (h, w)), 0, 4095).astype(np.uint16)
+    data, _ = synth.sony_arw1_encode(src)
+    img, want = HostImage(w, h), HostImage(w, h)
+    assert gpu.sony_arw1_decompress(data, img.view()) == oracle.sony_arw1(data, want) == 0
+    assert np.array_equal(img.u16(), want.u16()) and np.array_equal(img.pixels(), src)
+    w, h = 300, 64
+    data, _ = synth.sony_arw1_encode(src[:h, :w])
+    seen = set()
+    for cut in list(range(0, 24)) + [len(data) // 2]:
+        part = data[:len(data) - cut]
+        img, want = HostImage(w, h), HostImage(w, h)
+        so = oracle.sony_arw1(part, want)
+        assert gpu.sony_arw1_decompress(part, img.view()) == so, cut
+        if so == 0:
+            assert np.array_equal(img.u16(), want.u16())
+        seen.add(so)
+    assert 0 in seen and len(seen) >= 2
+
+
+def test_sony_arw1_damaged(gpu, oracle):
+    """Random damage: whenever the reference algorithm succeeds, same pixels;
+    otherwise a failure (which error comes first is not part of the contract)."""
+    rng = np.random.default_rng(58)
+    w, h = 257, 128
+    src = np.clip(1500 + rng.normal(0, 40, (h, w)).cumsum(axis=0) * 0.2, 0, 4095).astype(np.uint16)
+    data, _ = synth.sony_arw1_encode(src)
+    n_ok = n_bad = 0
+    for trial in range(16):
+        bad = data.copy()
+        idx = rng.integers(0, len(bad), size=2)
+        bad[idx] ^= np.uint8(1) << rng.integers(0, 8, size=2).astype(np.uint8)
+        img, want = HostImage(w, h), HostImage(w, h)
+        so = oracle.sony_arw1(bad, want)
+        sg = gpu.sony_arw1_decompress(bad, img.view())
+        if so == 0:
+            n_ok += 1
+            assert sg == 0 and np.array_equal(img.u16(), want.u16()), trial
+        else:
+            n_bad += 1
+            assert sg != 0, trial
+    assert n_bad > 0
+
+
 # ---- HasselbladDecompressor -------------------------------------------------------
 
 @pytest.mark.parametrize("c", G.HASSELBLAD_CASES, ids=lambda c: c["name"])
