@@ -17,11 +17,12 @@ barrier / max-reduction of the timing and, with --broadcast, to distribute the
 packed buffer from rank 0 over xGMI, timed separately).
 
 Rank 0 prints ONE JSON line.  At N=1 it also carries
-  roofline      -- dominant kernel: algorithmic bytes / hipEvent-measured launch time
+  roofline      -- dominant kernel: algorithmic bytes / hipEvent-measured launch time,
+                   plus the measured copy ceiling of the device for the same bytes
   cpu_baseline  -- the unmodified reference (oracle/_ref) timed on this host's cores
   extra         -- the other legs measured the same way (bench_ljpeg.py): the LJPEG
                    configs (cfg 3 / cfg 4 / cfg 5), the fixed-layout unpack entry
-                   points, Canon sRaw + Cr2sRawInterpolator, Nikon, Hasselblad
+                   points, Canon sRaw + Cr2sRawInterpolator, Nikon, Hasselblad, Sony ARW1
 """
 import argparse
 import ctypes as C
