@@ -85,6 +85,21 @@ __global__ __launch_bounds__(VS_T) void lj_vseed_kernel(LjArgs a) {
   }
 }
 
+// offset inside a strip -> (row, column).  Strips of real images hold fewer than
+// 2^32 samples, and 64-bit division is an order of magnitude more instructions
+// than the 32-bit one on this hardware.
+__device__ __forceinline__ void strip_divmod(uint64_t off, uint32_t w, uint32_t* row,
+                                             uint32_t* col) {
+  if ((off >> 32) == 0) {
+    const uint32_t o = uint32_t(off), q = o / w;
+    *row = q;
+    *col = o - q * w;
+  } else {
+    *row = uint32_t(off / w);
+    *col = uint32_t(off % w);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // K6: row reconstruction + output mapping, one wavefront per stream row
 // ---------------------------------------------------------------------------
@@ -105,10 +120,10 @@ __device__ __forceinline__ void lj_store_sample(const LjArgs& a, const LjStreamD
     uint32_t q = 0;
     while (q + 1 < S.n_strips && k >= st[q + 1].first_sample)
       ++q;
-    const uint64_t off = k - st[q].first_sample;
-    const uint32_t row = st[q].y0 + uint32_t(off / st[q].w);
-    const uint32_t col = st[q].x0 + uint32_t(off % st[q].w);
-    reinterpret_cast<uint16_t*>(img + uint64_t(row) * S.img_pitch)[col] = val;
+    uint32_t srow, scol;
+    strip_divmod(k - st[q].first_sample, st[q].w, &srow, &scol);
+    reinterpret_cast<uint16_t*>(img + uint64_t(st[q].y0 + srow) * S.img_pitch)[st[q].x0 + scol] =
+        val;
   }
 }
 
@@ -242,11 +257,10 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
         uint32_t z = 0;
         while (z + 1 < S.n_strips && k >= st[z + 1].first_sample)
           ++z;
-        const uint64_t off = k - st[z].first_sample;
-        const uint32_t col = uint32_t(off % st[z].w);
+        uint32_t srow, col;
+        strip_divmod(k - st[z].first_sample, st[z].w, &srow, &col);
         if (col + 8 <= st[z].w)
-          p = reinterpret_cast<uint16_t*>(
-                  img + uint64_t(st[z].y0 + uint32_t(off / st[z].w)) * S.img_pitch) +
+          p = reinterpret_cast<uint16_t*>(img + uint64_t(st[z].y0 + srow) * S.img_pitch) +
               st[z].x0 + col;
       }
       if (p && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
@@ -315,11 +329,10 @@ __device__ __forceinline__ void lj_store8(const LjArgs& a, const LjStreamDev& S,
       uint32_t z = 0;
       while (z + 1 < S.n_strips && k >= st[z + 1].first_sample)
         ++z;
-      const uint64_t off = k - st[z].first_sample;
-      const uint32_t col = uint32_t(off % st[z].w);
+      uint32_t srow, col;
+      strip_divmod(k - st[z].first_sample, st[z].w, &srow, &col);
       if (col + 8 <= st[z].w)
-        p = reinterpret_cast<uint16_t*>(
-                img + uint64_t(st[z].y0 + uint32_t(off / st[z].w)) * S.img_pitch) +
+        p = reinterpret_cast<uint16_t*>(img + uint64_t(st[z].y0 + srow) * S.img_pitch) +
             st[z].x0 + col;
     }
     if (p && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
