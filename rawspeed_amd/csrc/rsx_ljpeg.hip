@@ -1531,13 +1531,30 @@ __global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
 // ---------------------------------------------------------------------------
 // stuffing bytes (00 preceded by FF) at stream positions [from, to), one wave;
 // each lane scans 16-byte pieces (byte loads of a 17-byte window hit L1/L2)
+__device__ __forceinline__ uint32_t lj_zero_bytes(uint32_t d) { // 0x80 per zero byte, exact
+  return ~(((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d | 0x7F7F7F7Fu);
+}
+
 __device__ __forceinline__ uint32_t lj_count_drops(const uint8_t* in, uint64_t from,
                                                    uint64_t to, int lane) {
   uint32_t n = 0;
   for (uint64_t p0 = from + uint64_t(lane) * 16; p0 < to; p0 += 64 * 16) {
     uint32_t prev = p0 > 0 ? in[p0 - 1] : 0u;
-    const uint64_t end = p0 + 16 < to ? p0 + 16 : to;
-    for (uint64_t p = p0; p < end; ++p) {
+    if (p0 + 16 <= to) {
+      // one 16-byte load (global loads take unaligned addresses); a stuffing byte
+      // is a zero byte whose predecessor is FF
+      uint4 v;
+      __builtin_memcpy(&v, in + p0, 16);
+      const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t z = lj_zero_bytes(d[k]), f = lj_zero_bytes(~d[k]);
+        n += uint32_t(__builtin_popcount(z & ((f << 8) | (prev == 0xFFu ? 0x80u : 0u))));
+        prev = d[k] >> 24;
+      }
+      continue;
+    }
+    for (uint64_t p = p0; p < to; ++p) {
       const uint32_t c = in[p];
       n += (c == 0u && prev == 0xFFu) ? 1u : 0u;
       prev = c;

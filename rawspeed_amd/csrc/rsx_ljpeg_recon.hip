@@ -38,18 +38,36 @@ __global__ __launch_bounds__(VS_T) void lj_vseed_kernel(LjArgs a) {
   if (a.results[s].status != 0 || S.kind == 2)
     return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint32_t rows = S.rows, N = S.n_comp;
+  // (the stream record is read once: stores to V could alias it for the compiler)
+  const uint32_t rows = S.rows, N = S.n_comp, row_samples = S.row_samples;
+  const bool no_vertical = S.no_vertical != 0;
+  uint32_t seed_pos[4], init_pred[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    seed_pos[c] = S.seed_pos[c];
+    init_pred[c] = S.init_pred[c];
+  }
   const int16_t* __restrict__ D = a.diffs + S.diff_offset;
   uint16_t* __restrict__ V = a.vseed + uint64_t(S.first_row) * 4;
   if (tid < 4)
-    carry_s[tid] = tid < int(N) ? S.init_pred[tid] : 0u;
+    carry_s[tid] = tid < int(N) ? init_pred[tid] : 0u;
   __syncthreads();
+  // the gathers of the next step are in flight while this one is scanned
+  auto gather = [&](uint32_t r, uint32_t (&d)[4]) {
+    d[0] = d[1] = d[2] = d[3] = 0;
+    if (r < rows) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (uint32_t(c) < N)
+          d[c] = uint32_t(int32_t(D[uint64_t(r) * row_samples + seed_pos[c]]));
+    }
+  };
+  uint32_t dn[4];
+  gather(tid, dn);
   for (uint32_t r0 = 0; r0 < rows; r0 += VS_T) {
     const uint32_t r = r0 + tid;
-    uint32_t d[4] = {0, 0, 0, 0};
-    if (r < rows)
-      for (uint32_t c = 0; c < N; ++c)
-        d[c] = uint32_t(int32_t(D[uint64_t(r) * S.row_samples + S.seed_pos[c]]));
+    uint32_t d[4] = {dn[0], dn[1], dn[2], dn[3]};
+    gather(r + VS_T, dn);
     uint32_t inc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -73,10 +91,13 @@ __global__ __launch_bounds__(VS_T) void lj_vseed_kernel(LjArgs a) {
         o += wtot[w][c];
       base[c] = o;
     }
-    if (r < rows)
-      for (uint32_t c = 0; c < N; ++c) // exclusive; Hasselblad rows all start from initPred
-        V[uint64_t(r) * 4 + c] =
-            S.no_vertical ? S.init_pred[c] : uint16_t(base[c] + inc[c] - d[c]);
+    if (r < rows) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) // exclusive; Hasselblad rows all start from initPred
+        if (uint32_t(c) < N)
+          V[uint64_t(r) * 4 + c] =
+              no_vertical ? uint16_t(init_pred[c]) : uint16_t(base[c] + inc[c] - d[c]);
+    }
     __syncthreads();
     if (tid == VS_T - 1)
       for (int c = 0; c < 4; ++c)
