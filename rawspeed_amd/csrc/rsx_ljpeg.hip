@@ -129,126 +129,111 @@ __device__ __forceinline__ void lj_stage_tables(const Lds& L, const LjArgs& a,
     dst[i] = src[i];
 }
 
-// Un-stuffing state of one slot: kept bytes are shifted into `acc` and leave as
-// whole big-endian dwords into column `col` of B.
-struct Unstuff {
-  uint64_t acc = 0;  // high `nacc` bits valid
-  uint32_t nacc = 0; // 0, 8, 16 or 24
-  uint32_t ko = 0;   // output dwords written
-  uint32_t kept = 0; // kept bytes so far
-};
-
-// append the top n bytes (n = 0..4) of v
-__device__ __forceinline__ void us_append(Unstuff& u, uint32_t* B, int col, uint32_t v,
-                                          uint32_t n) {
-  const uint32_t keep = n ? (0xFFFFFFFFu << (32u - 8u * n)) : 0u;
-  u.acc |= uint64_t(v & keep) << (32 - u.nacc);
-  u.nacc += 8 * n;
-  u.kept += n;
-  if (u.nacc >= 32) {
-    B[u.ko * LJ_T + col] = uint32_t(u.acc >> 32);
-    ++u.ko;
-    u.acc <<= 32;
-    u.nacc -= 32;
-  }
+// ---- un-stuffing of one slot, branch-free -----------------------------------
+// exact per-byte "== 0" flags of a dword (0x80 in every zero byte)
+__device__ __forceinline__ uint32_t lj_zero_flags(uint32_t d) {
+  return ~(((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d | 0x7F7F7F7Fu);
+}
+// flags at bits 31/23/15/7 (stream bytes 0..3 of a big-endian dword) -> bit j = byte j
+__device__ __forceinline__ uint32_t lj_flag_nibble(uint32_t m) {
+  return ((m >> 31) | (m >> 22) | (m >> 13) | (m >> 4)) & 0xFu;
+}
+// v_perm selector that moves the bytes kept by `nib` (bit j = stream byte j of a
+// big-endian dword) to the top of the result and zero-fills the rest
+__device__ __forceinline__ uint32_t lj_compact_selector(uint32_t nib) {
+  uint32_t sel = 0, o = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < 4; ++j)
+    if (nib & (1u << j)) {
+      sel |= (4u + 3u - j) << (8u * (3u - o)); // stream byte j = register byte 3 - j
+      ++o;
+    }
+  for (; o < 4; ++o)
+    sel |= 0x0Cu << (8u * (3u - o)); // constant 0x00
+  return sel;
 }
 
 // Un-stuff one slot held in registers (20 big-endian dwords = its 64 bytes + 16
 // bytes of lookahead) into column `col` of B.  FF00 -> FF; FFxx (xx != 0) or the
 // end of the buffer end the data, everything after reads as zero
 // (BitStreamerJPEG.h:106-183).  `valid` = bytes of the slot that lie inside the
-// buffer.  Dwords without an FF are appended whole; a dword with FF bytes is
-// walked FF by FF (not byte by byte).
+// buffer, `prev` = the byte before the slot, `sel` = 16 compaction selectors.
+//
+// Formulated on 80-bit byte masks (bit i = stream byte i of the slot) so that
+// the wavefront runs ONE instruction stream whatever the lanes hold -- the
+// byte-walking version this replaces took ~7000 instructions per wavefront as
+// soon as the lanes' FF bytes sat in different dwords:
+//   FF, Z   bytes equal to FF / 00          V      bytes inside the buffer
+//   M  = FF & V & ((V & ~Z) >> 1)           FF followed by a non-zero byte: a marker
+//   E  = first bit of M, else `valid`       the data of this slot ends here
+//   D  = Z & (FF << 1 | prev == FF) & [0,E) stuffing bytes: dropped
+//   K  = [0,E) & ~D                          kept; compacted dword by dword (v_perm)
 __device__ __forceinline__ void lj_fix_regs(const uint32_t (&in)[LJ_BW + 1], uint32_t* B,
                                             int col, uint32_t prev, int valid,
-                                            uint32_t& own_bits, int& marker_off,
-                                            uint32_t& own_drops) {
-  Unstuff u;
-  bool own_done = false, ended = false;
-  bool drop_next = (prev == 0xFFu) && ((in[0] >> 24) == 0u);
-  own_bits = 0;
-  marker_off = -1;
-  own_drops = 0;
+                                            const uint32_t* sel, uint32_t& own_bits,
+                                            int& marker_off, uint32_t& own_drops) {
+  static_assert(LJ_BW == 20 && LJ_PW == 16, "80-bit masks: 64 own + 16 lookahead bytes");
+  uint64_t ffl = 0, zl = 0; // bytes 0..63
+  uint32_t ffh = 0, zh = 0; // bytes 64..79
 #pragma unroll
   for (int k = 0; k < LJ_BW; ++k) {
-    if (k == LJ_PW && !own_done) {
-      own_bits = u.kept * 8;
-      own_done = true;
+    const uint32_t nz = lj_flag_nibble(lj_zero_flags(in[k]));
+    const uint32_t nf = lj_flag_nibble(lj_zero_flags(~in[k]));
+    if (k < LJ_PW) {
+      zl |= uint64_t(nz) << (4 * k);
+      ffl |= uint64_t(nf) << (4 * k);
+    } else {
+      zh |= nz << (4 * (k - LJ_PW));
+      ffh |= nf << (4 * (k - LJ_PW));
     }
-    if (ended)
-      continue;
-    // bytes of this dword that lie inside the buffer
-    const int vb = valid - 4 * k;
-    if (vb <= 0) {
-      ended = true;
-      continue;
-    }
-    const uint32_t cur = in[k];
-    if (!drop_next && !has_ff(cur) && vb >= 4) {
-      us_append(u, B, col, cur, 4);
-      continue;
-    }
-    uint32_t rem = cur;              // unread bytes, top-aligned
-    uint32_t nb = vb >= 4 ? 4u : uint32_t(vb); // how many
-    uint32_t at = 0;                 // byte index of rem's top byte inside the dword
-    if (drop_next) {
-      drop_next = false;
-      rem <<= 8;
-      --nb;
-      ++at;
-      if (k < LJ_PW)
-        ++own_drops;
-    }
-#pragma unroll 1
-    while (nb > 0) {
-      // exact per-byte FF flags (bit 24/16/8/0 for byte 0/1/2/3), top nb bytes only
-      uint32_t x = rem & (rem >> 4);
-      x &= x >> 2;
-      x &= x >> 1;
-      x &= 0x01010101u & (0xFFFFFFFFu << (32u - 8u * nb));
-      if (x == 0u) {
-        us_append(u, B, col, rem, nb);
-        break;
-      }
-      const uint32_t p = uint32_t(__builtin_clz(x)) >> 3; // first FF byte of rem
-      const bool in_dword = p + 1 < nb;
-      // byte after the FF: inside this dword, or the first byte of the next one
-      // (past the end of the buffer / of the lookahead it reads as 00)
-      uint32_t next = in_dword ? ((rem >> (16u - 8u * p)) & 0xFFu)
-                               : ((vb >= 4 && k + 1 < LJ_BW) ? (in[k + 1] >> 24) : 0u);
-      if (!in_dword && vb >= 4 && 4 * (k + 1) >= valid)
-        next = 0u;
-      if (next != 0u) { // end-of-stream marker: keep what precedes the FF
-        us_append(u, B, col, rem, p);
-        if (k < LJ_PW)
-          marker_off = 4 * k + int(at + p);
-        ended = true;
-        break;
-      }
-      us_append(u, B, col, rem, p + 1); // ... FF
-      if (in_dword) {                   // skip its stuffing byte
-        if (k < LJ_PW)
-          ++own_drops;
-        rem = (p + 2 < 4) ? (rem << (8u * (p + 2))) : 0u;
-        nb -= p + 2;
-        at += p + 2;
-      } else {
-        drop_next = true;
-        nb = 0;
-      }
-    }
-    if (vb < 4)
-      ended = true; // the buffer ends inside this dword
   }
-  if (!own_done)
-    own_bits = u.kept * 8;
-  if (u.ko < LJ_BW) {
-    B[u.ko * LJ_T + col] = uint32_t(u.acc >> 32);
-    ++u.ko;
+  const uint32_t nv = uint32_t(valid); // 0..80
+  const uint64_t vl = nv >= 64u ? ~0ull : ((1ull << nv) - 1ull);
+  const uint32_t vh = nv <= 64u ? 0u : ((1u << (nv - 64u)) - 1u);
+  // byte i + 1 exists and is not zero
+  const uint64_t nzl = ((vl & ~zl) >> 1) | (uint64_t(vh & ~zh & 1u) << 63);
+  const uint32_t nzh = (vh & ~zh) >> 1;
+  const uint64_t ml = ffl & vl & nzl;
+  const uint32_t mh = ffh & vh & nzh;
+  const bool marker = (ml != 0ull) || (mh != 0u);
+  const uint32_t E = ml ? uint32_t(__builtin_ctzll(ml))
+                        : (mh ? 64u + uint32_t(__builtin_ctz(mh)) : nv);
+  const uint64_t bl = E >= 64u ? ~0ull : ((1ull << E) - 1ull);
+  const uint32_t bh = E <= 64u ? 0u : ((1u << (E - 64u)) - 1u);
+  const uint64_t pfl = (ffl << 1) | (prev == 0xFFu ? 1ull : 0ull);
+  const uint32_t pfh = (ffh << 1) | uint32_t(ffl >> 63);
+  const uint64_t dl = zl & pfl & bl;
+  const uint32_t dh = zh & pfh & bh;
+  const uint64_t kl = bl & ~dl;
+  const uint32_t kh = bh & ~dh;
+  own_bits = 8u * uint32_t(__builtin_popcountll(kl));
+  own_drops = uint32_t(__builtin_popcountll(dl));
+  marker_off = (marker && E < 64u) ? int(E) : -1;
+
+  uint64_t acc = 0;  // kept bytes, top-aligned; the high `nacc` bits are valid
+  uint32_t nacc = 0; // 0, 8, 16 or 24 between dwords
+  uint32_t ko = 0;   // output dwords written
+#pragma unroll
+  for (int k = 0; k < LJ_BW; ++k) {
+    const uint32_t nib = k < LJ_PW ? uint32_t(kl >> (4 * k)) & 0xFu
+                                   : (kh >> (4 * (k - LJ_PW))) & 0xFu;
+    const uint32_t x = __builtin_amdgcn_perm(in[k], 0u, sel[nib]);
+    acc |= (uint64_t(x) << 32) >> nacc;
+    nacc += 8u * uint32_t(__builtin_popcount(nib));
+    if (nacc >= 32u) {
+      B[ko * LJ_T + col] = uint32_t(acc >> 32);
+      ++ko;
+      acc <<= 32;
+      nacc -= 32u;
+    }
+  }
+  if (ko < uint32_t(LJ_BW)) {
+    B[ko * LJ_T + col] = uint32_t(acc >> 32);
+    ++ko;
   }
 #pragma unroll 1
-  for (; u.ko < LJ_BW; ++u.ko)
-    B[u.ko * LJ_T + col] = 0u;
+  for (; ko < uint32_t(LJ_BW); ++ko)
+    B[ko * LJ_T + col] = 0u;
 }
 
 // End of the data the bit reader hands out before its zero padding.  An MSB32
@@ -291,6 +276,8 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
     L.misc[9] = 0;  // dropped stuffing bytes
     L.misc[10] = 0; // fix-list length
   }
+  if (j < 16) // bm[] is free during staging: the 16 byte-compaction selectors
+    L.bm[j] = lj_compact_selector(uint32_t(j));
   uint32_t any = 0;
 #pragma unroll
   for (int m = 0; m < LJ_BW / 4; ++m) {
@@ -325,7 +312,7 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
     if (mine) {
       uint32_t own_bits, drops;
       int marker_off;
-      lj_fix_regs(r, L.B, idx, L.su[idx], lj_valid_bytes(S, lb, idx), own_bits,
+      lj_fix_regs(r, L.B, idx, L.su[idx], lj_valid_bytes(S, lb, idx), L.bm, own_bits,
                   marker_off, drops);
       L.ob[idx] = own_bits;
       if (idx >= 1) {
