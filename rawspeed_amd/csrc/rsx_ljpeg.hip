@@ -76,13 +76,17 @@ struct Lds {
   uint32_t* st;   // [LJ_T] exit state of each slot
   uint32_t* cn;   // [LJ_T] symbols that start inside each slot
   uint32_t* ob;   // [LJ_T] data bits of each slot's own 64 bytes
-  uint32_t* list; // [LJ_T] dense list of slots to re-decode
+  uint16_t* list; // [LJ_T] dense list of slots to re-decode (16-bit: see LJ_LDS_WORDS)
   uint32_t* bm;   // [2*LJ_T] per slot: bitmap of symbol starts at bit positions < 64
   uint32_t* misc; // [16]
   TabLds* tabs;
 };
 
-constexpr size_t LJ_LDS_WORDS = size_t(LJ_BW) * LJ_T + 7 * LJ_T + 16;
+// Sized to the byte: gfx950 hands out LDS in 1280-byte granules (160 KB / 128), so
+// FIVE workgroups per CU need <= 25 granules = 32000 bytes each.  With one table
+// this comes to 31584 (the list as 16-bit entries is what gets it under; measured:
+// K1 377 -> 329 us per 4 cfg-3 frames when the fifth workgroup fits).
+constexpr size_t LJ_LDS_WORDS = size_t(LJ_BW) * LJ_T + 6 * LJ_T + LJ_T / 2 + 16;
 
 __device__ __forceinline__ Lds carve(uint8_t* smem, int n_tables) {
   Lds l;
@@ -91,9 +95,9 @@ __device__ __forceinline__ Lds carve(uint8_t* smem, int n_tables) {
   l.st = l.su + LJ_T;
   l.cn = l.st + LJ_T;
   l.ob = l.cn + LJ_T;
-  l.list = l.ob + LJ_T;
-  l.bm = l.list + LJ_T;
-  l.misc = l.bm + 2 * LJ_T;
+  l.bm = l.ob + LJ_T;
+  l.list = reinterpret_cast<uint16_t*>(l.bm + 2 * LJ_T);
+  l.misc = l.bm + 2 * LJ_T + LJ_T / 2;
   l.tabs = reinterpret_cast<TabLds*>(l.misc + 16);
   return l;
 }
@@ -101,6 +105,7 @@ __device__ __forceinline__ Lds carve(uint8_t* smem, int n_tables) {
 constexpr size_t lj_lds_bytes(int n_tables) {
   return LJ_LDS_WORDS * 4 + size_t(n_tables) * sizeof(TabLds);
 }
+static_assert(lj_lds_bytes(1) <= 25 * 1280, "single-table kernels must fit five workgroups per CU");
 
 // 16 bytes at stream offset `off`, zero outside [0, in_bytes)
 __device__ __forceinline__ uint4 lj_load_chunk(const uint8_t* __restrict__ base,
@@ -298,7 +303,7 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
   L.su[j] = prev; // su[] doubles as the "byte before the slot" array during staging
   __syncthreads();
   if ((any != 0u || prev == 0xFFu) && !(a.ablate & 8u) && !S.raw)
-    L.list[atomicAdd(&L.misc[10], 1u)] = uint32_t(j);
+    L.list[atomicAdd(&L.misc[10], 1u)] = uint16_t(j);
   __syncthreads();
   const uint32_t n = L.misc[10];
   if (uint32_t(j & ~63) < n) { // wave-uniform
@@ -785,7 +790,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       want = L.st[j - 1];
     if (want != L.su[j]) {
       const uint32_t k = atomicAdd(&L.misc[8], 1u);
-      L.list[k] = uint32_t(j);
+      L.list[k] = uint16_t(j);
     }
     __syncthreads();
     const uint32_t n = L.misc[8];
@@ -800,7 +805,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     // only the waves that hold list entries do anything (wave-uniform test)
     if (uint32_t(j & ~63) < n) {
       const bool mine = uint32_t(j) < n;
-      idx = mine ? L.list[j] : 1u;
+      idx = mine ? uint32_t(L.list[j]) : 1u;
       w = (STITCH && idx == 1) ? true_start : L.st[idx - 1];
       if (MULTI) {
         lj_decode_span<MULTI, false, PAIR>(L, dp, int(idx), w, L.ob[idx], e, c, nullptr,
@@ -1783,15 +1788,19 @@ void launch_sync(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
 }
 
 void launch_decode(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
+  // K4 is bound by its scattered 16-byte stores, not by latency: a fifth workgroup
+  // per CU makes it 5 % SLOWER (208 vs 199 us per 4 cfg-3 frames), so it asks for
+  // 26 LDS granules and stays at four.
+  constexpr size_t k4_lds = std::max(lj_lds_bytes(1), size_t(26 * 1280));
   if (p->any_plain)
     hipLaunchKernelGGL((lj_decode_kernel<false>), dim3(p->total_blocks), dim3(LJ_T),
-                       lj_lds_bytes(1), s, a);
+                       k4_lds, s, a);
   if (p->any_las)
     hipLaunchKernelGGL((lj_decode_kernel<false, true>), dim3(p->total_blocks), dim3(LJ_T),
-                       lj_lds_bytes(1), s, a);
+                       k4_lds, s, a);
   if (p->any_pair)
     hipLaunchKernelGGL(lj_decode_pair_kernel, dim3(p->total_blocks), dim3(LJ_T),
-                       lj_lds_bytes(1), s, a);
+                       k4_lds, s, a);
   if (p->any_multi)
     hipLaunchKernelGGL((lj_decode_kernel<true>), dim3(p->total_blocks), dim3(LJ_T),
                        lj_lds_bytes(p->max_tables), s, a);
