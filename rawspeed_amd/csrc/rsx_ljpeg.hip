@@ -71,41 +71,52 @@ __device__ __forceinline__ uint32_t has_ff(uint32_t d) {
 }
 
 struct Lds {
-  uint32_t* B;    // [LJ_BW][LJ_T] big-endian dwords of every slot, un-stuffed in place
-  uint32_t* su;   // [LJ_T] start state each slot was last decoded from
-  uint32_t* st;   // [LJ_T] exit state of each slot
-  uint32_t* cn;   // [LJ_T] symbols that start inside each slot
-  uint32_t* ob;   // [LJ_T] data bits of each slot's own 64 bytes
-  uint16_t* list; // [LJ_T] dense list of slots to re-decode (16-bit: see LJ_LDS_WORDS)
+  uint32_t* B;    // [bw][LJ_T] big-endian dwords of every slot, un-stuffed in place
+  uint16_t* su;   // [LJ_T] start state each slot was last decoded from
+  uint16_t* st;   // [LJ_T] exit state of each slot
+  uint16_t* cn;   // [LJ_T] symbols that start inside each slot (<= 512)
+  uint16_t* ob;   // [LJ_T] data bits of each slot's own 64 bytes (<= 512)
+  uint16_t* list; // [LJ_T] dense list of slots to re-decode
   uint32_t* bm;   // [2*LJ_T] per slot: bitmap of symbol starts at bit positions < 64
   uint32_t* misc; // [16]
   TabLds* tabs;
 };
 
-// Sized to the byte: gfx950 hands out LDS in 1280-byte granules (160 KB / 128), so
-// FIVE workgroups per CU need <= 25 granules = 32000 bytes each.  With one table
-// this comes to 31584 (the list as 16-bit entries is what gets it under; measured:
-// K1 377 -> 329 us per 4 cfg-3 frames when the fifth workgroup fits).
-constexpr size_t LJ_LDS_WORDS = size_t(LJ_BW) * LJ_T + 6 * LJ_T + LJ_T / 2 + 16;
+// Sized to the byte: gfx950 hands out LDS in 1280-byte granules (160 KB / 128) and
+// the synchronisation kernels are latency bound -- their speed is the number of
+// resident workgroups (measured per 4 cfg-3 frames: 4 per CU 377 us, 5 per CU
+// 329 us).  So the records are 16-bit and the kernels keep only the dwords of a slot
+// they can touch: K0 and K4 all LJ_BW = 20 (the un-stuffer writes them, the
+// register bit reader prefetches two dwords ahead), the window reader of the
+// synchronisation kernels 17 -- a live symbol starts before bit 512, its 32-bit
+// window ends in dword 16 -- or 18 for pair symbols (second code <= 16 bits later).
+// One table, 17 dwords: 26464 bytes = 21 granules -> SIX workgroups per CU.
+constexpr int LJ_BW_SYNC = LJ_PW + 1, LJ_BW_SYNC_PAIR = LJ_PW + 2;
+constexpr size_t lj_lds_words(int bw) {
+  return size_t(bw) * LJ_T + 4 * (LJ_T / 2) + 2 * LJ_T + LJ_T / 2 + 16;
+}
 
-__device__ __forceinline__ Lds carve(uint8_t* smem, int n_tables) {
+__device__ __forceinline__ Lds carve(uint8_t* smem, int n_tables, int bw = LJ_BW) {
   Lds l;
   l.B = reinterpret_cast<uint32_t*>(smem);
-  l.su = l.B + LJ_BW * LJ_T;
+  l.su = reinterpret_cast<uint16_t*>(l.B + bw * LJ_T);
   l.st = l.su + LJ_T;
   l.cn = l.st + LJ_T;
   l.ob = l.cn + LJ_T;
-  l.bm = l.ob + LJ_T;
+  l.bm = reinterpret_cast<uint32_t*>(l.ob + LJ_T);
   l.list = reinterpret_cast<uint16_t*>(l.bm + 2 * LJ_T);
   l.misc = l.bm + 2 * LJ_T + LJ_T / 2;
   l.tabs = reinterpret_cast<TabLds*>(l.misc + 16);
   return l;
 }
 
-constexpr size_t lj_lds_bytes(int n_tables) {
-  return LJ_LDS_WORDS * 4 + size_t(n_tables) * sizeof(TabLds);
+constexpr size_t lj_lds_bytes(int n_tables, int bw = LJ_BW) {
+  return lj_lds_words(bw) * 4 + size_t(n_tables) * sizeof(TabLds);
 }
-static_assert(lj_lds_bytes(1) <= 25 * 1280, "single-table kernels must fit five workgroups per CU");
+static_assert(lj_lds_bytes(1, LJ_BW_SYNC) <= 21 * 1280, "six sync workgroups per CU");
+static_assert(lj_lds_words(LJ_BW_SYNC) % 4 == 0 && lj_lds_words(LJ_BW_SYNC_PAIR) % 4 == 0 &&
+                  lj_lds_words(LJ_BW) % 4 == 0,
+              "the tables start on a 16-byte boundary");
 
 // 16 bytes at stream offset `off`, zero outside [0, in_bytes)
 __device__ __forceinline__ uint4 lj_load_chunk(const uint8_t* __restrict__ base,
@@ -679,26 +690,35 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
 
 // Load the workgroup's un-stuffed image (K0's output) into LDS: B and ob[].
 // Ends with a workgroup barrier.
+template <int BW = LJ_BW>
 __device__ __forceinline__ void lj_load_image(const Lds& L, const LjArgs& a, uint32_t b,
                                               int j) {
   const uint4* __restrict__ src = a.unstuffed + size_t(b) * LJ_IMG_U4;
   uint4* dst = reinterpret_cast<uint4*>(L.B);
   const uint32_t ob = reinterpret_cast<const uint32_t*>(src + (LJ_BW / 4) * LJ_T)[j];
-  // (a register array here ends up in scratch; copy in two halves instead)
+  // the image is B as it lies in LDS ([dword][slot]); the first BW dword rows are
+  // wanted: BW * LJ_T / 4 consecutive uint4 (a register array here ends up in
+  // scratch; copy in groups of three instead)
+  constexpr int n4 = BW * LJ_T / 4;
+  auto want = [&](int i) { return BW == LJ_BW || i < n4; };
 #pragma unroll
   for (int h = 0; h < LJ_BW / 4; h += 3) {
-    uint4 t0 = src[h * LJ_T + j], t1 = t0, t2 = t0;
-    if (h + 1 < LJ_BW / 4)
-      t1 = src[(h + 1) * LJ_T + j];
-    if (h + 2 < LJ_BW / 4)
-      t2 = src[(h + 2) * LJ_T + j];
-    dst[h * LJ_T + j] = t0;
-    if (h + 1 < LJ_BW / 4)
-      dst[(h + 1) * LJ_T + j] = t1;
-    if (h + 2 < LJ_BW / 4)
-      dst[(h + 2) * LJ_T + j] = t2;
+    const int i0 = h * LJ_T + j, i1 = i0 + LJ_T, i2 = i1 + LJ_T;
+    uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0, t2 = t0;
+    if (want(i0))
+      t0 = src[i0];
+    if (h + 1 < LJ_BW / 4 && want(i1))
+      t1 = src[i1];
+    if (h + 2 < LJ_BW / 4 && want(i2))
+      t2 = src[i2];
+    if (want(i0))
+      dst[i0] = t0;
+    if (h + 1 < LJ_BW / 4 && want(i1))
+      dst[i1] = t1;
+    if (h + 2 < LJ_BW / 4 && want(i2))
+      dst[i2] = t2;
   }
-  L.ob[j] = ob;
+  L.ob[j] = uint16_t(ob);
   __syncthreads();
 }
 
@@ -713,7 +733,8 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   const LjStreamDev& S = a.streams[s];
   if ((S.n_tables > 1) != MULTI || (S.pair != 0) != PAIR)
     return; // another instantiation handles this stream
-  const Lds L = carve(smem, int(S.n_tables));
+  constexpr int BWK = PAIR ? LJ_BW_SYNC_PAIR : LJ_BW_SYNC;
+  const Lds L = carve(smem, int(S.n_tables), BWK);
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
 
@@ -729,7 +750,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   if (STITCH && j == 0 && (a.ablate & 128u))
     atomicAdd(&a.results[s].stat_stitch, 1u);
   lj_stage_tables(L, a, S);
-  lj_load_image(L, a, b, j); // ends with a barrier
+  lj_load_image<BWK>(L, a, b, j); // ends with a barrier
   const uint32_t own_bits = L.ob[j];
   const DecodeParams dp = lj_params(S);
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1); // j >= 1
@@ -894,7 +915,7 @@ __global__ __launch_bounds__(LJ_T) void lj_transfer_kernel(LjArgs a) {
   Lds L{};
   L.B = const_cast<uint32_t*>(
       reinterpret_cast<const uint32_t*>(a.unstuffed + size_t(b) * LJ_IMG_U4));
-  L.ob = L.B + LJ_BW * LJ_T;
+  const uint32_t* ob32 = L.B + LJ_BW * LJ_T; // the image keeps ob[] as dwords
   L.tabs = reinterpret_cast<TabLds*>(smem);
   const int j = threadIdx.x;
   lj_stage_tables(L, a, S);
@@ -907,7 +928,7 @@ __global__ __launch_bounds__(LJ_T) void lj_transfer_kernel(LjArgs a) {
   uint32_t state = off | (phase << ST_PHASE_SHIFT);
   for (int slot = 1; slot < LJ_T; ++slot) {
     uint32_t e = ST_ERR, c = 0;
-    lj_decode_span<MULTI, false, PAIR>(L, dp, slot, state, L.ob[slot], e, c, nullptr,
+    lj_decode_span<MULTI, false, PAIR>(L, dp, slot, state, ob32[slot], e, c, nullptr,
                                        enabled);
     state = e;
   }
@@ -1778,19 +1799,19 @@ template <bool STITCH>
 void launch_sync(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
   if (p->any_single_plain)
     hipLaunchKernelGGL((lj_sync_kernel<STITCH, false>), dim3(p->total_blocks),
-                       dim3(LJ_T), lj_lds_bytes(1), s, a);
+                       dim3(LJ_T), lj_lds_bytes(1, LJ_BW_SYNC), s, a);
   if (p->any_pair)
     hipLaunchKernelGGL((lj_sync_kernel<STITCH, false, true>), dim3(p->total_blocks),
-                       dim3(LJ_T), lj_lds_bytes(1), s, a);
+                       dim3(LJ_T), lj_lds_bytes(1, LJ_BW_SYNC_PAIR), s, a);
   if (p->any_multi)
     hipLaunchKernelGGL((lj_sync_kernel<STITCH, true>), dim3(p->total_blocks),
-                       dim3(LJ_T), lj_lds_bytes(p->max_tables), s, a);
+                       dim3(LJ_T), lj_lds_bytes(p->max_tables, LJ_BW_SYNC), s, a);
 }
 
 void launch_decode(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
-  // K4 is bound by its scattered 16-byte stores, not by latency: a fifth workgroup
-  // per CU makes it 5 % SLOWER (208 vs 199 us per 4 cfg-3 frames), so it asks for
-  // 26 LDS granules and stays at four.
+  // K4 is bound by its scattered 16-byte stores, not by latency: measured per 4
+  // cfg-3 frames, 5 workgroups per CU 217 us, 4: 199-209, 3: 217, 2: 258 -- so it
+  // asks for 26 LDS granules and stays at four.
   constexpr size_t k4_lds = std::max(lj_lds_bytes(1), size_t(26 * 1280));
   if (p->any_plain)
     hipLaunchKernelGGL((lj_decode_kernel<false>), dim3(p->total_blocks), dim3(LJ_T),
