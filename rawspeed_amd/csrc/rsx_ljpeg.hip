@@ -667,7 +667,7 @@ __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& 
 // writes the un-stuffed LDS image -- B plus the per-slot data-bit counts -- to
 // global memory once; the synchronisation, stitch and decode kernels start from
 // that image with plain 16-byte coalesced loads.  Keeping the byte-level work in
-// its own light kernel (23 KB LDS, high occupancy) hides its latency.
+// its own light kernel (25 KB LDS) hides its latency.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
 constexpr int TF_ENTRIES = 512; // index = state & 0x1FF (offset | phase << 6)
 
 // The un-stuffed image is read straight from global memory here (all lanes of
-// a wavefront read the same dwords): without the 28 KB LDS image the kernel is
+// a wavefront read the same dwords): without the LDS image the kernel is
 // limited by wave slots, not LDS, and every workgroup of the plan is resident.
 template <bool MULTI, bool PAIR = false>
 __global__ __launch_bounds__(LJ_T) void lj_transfer_kernel(LjArgs a) {
