@@ -1038,6 +1038,11 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
 // ---------------------------------------------------------------------------
 // LAS: the stream's table holds Nikon "lossy after split" values (its own
 // instantiation so that the JPEG hot loop carries no extra branch)
+#ifndef RSX_K4_BURST
+#define RSX_K4_BURST 4
+#endif
+constexpr int K4_BURST = RSX_K4_BURST; // groups of 8 differences per store burst
+
 template <bool MULTI, bool LAS = false>
 __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1120,8 +1125,13 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   BitReader r = br_open(L.B, j, my_start & ST_OFF_MASK);
 #endif
   uint32_t tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0; // the lane's last, partial group
-  for (uint32_t g = 0; g < n_groups; ++g) {
-    uint32_t p[4];
+  // A lane's 16-byte stores land on an arbitrary 2-byte boundary of a region it
+  // shares cache lines with its neighbours'.  Issued one per group, every line
+  // stayed partially written for the length of the loop, ~32 MB of such lines
+  // device-wide against 32 MB of L2: they were evicted half-filled and the kernel
+  // wrote 2.8x its output to HBM (PMC WRITE_SIZE, profiles/r01/ljpeg_traffic*.json).
+  // So four groups are decoded into registers and leave as one 64-byte burst.
+  auto decode_group = [&](uint32_t g, uint32_t (&p)[4]) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const bool live = 8 * g + q < remaining;
@@ -1167,16 +1177,30 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
       else
         p[q >> 1] = diff;
     }
-    if (a.ablate & 1u) {
-      asm volatile("" ::"v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]));
-    } else if (8 * g + 8 <= remaining) {
-      const uint4 v = make_uint4(p[0], p[1], p[2], p[3]);
-      __builtin_memcpy(out + 8 * g, &v, 16);
-    } else if (8 * g < remaining) {
-      tp0 = p[0];
-      tp1 = p[1];
-      tp2 = p[2];
-      tp3 = p[3];
+  };
+  for (uint32_t g0 = 0; g0 < n_groups; g0 += K4_BURST) {
+    uint32_t pv[K4_BURST][4];
+#pragma unroll
+    for (int u = 0; u < K4_BURST; ++u)
+      if (g0 + u < n_groups) // wave-uniform
+        decode_group(g0 + u, pv[u]);
+#pragma unroll
+    for (int u = 0; u < K4_BURST; ++u) {
+      const uint32_t g = g0 + u;
+      if (g >= n_groups)
+        break;
+      const uint32_t(&p)[4] = pv[u];
+      if (a.ablate & 1u) {
+        asm volatile("" ::"v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]));
+      } else if (8 * g + 8 <= remaining) {
+        const uint4 v = make_uint4(p[0], p[1], p[2], p[3]);
+        __builtin_memcpy(out + 8 * g, &v, 16);
+      } else if (8 * g < remaining) {
+        tp0 = p[0];
+        tp1 = p[1];
+        tp2 = p[2];
+        tp3 = p[3];
+      }
     }
   }
   // partial last group: 2-byte stores
