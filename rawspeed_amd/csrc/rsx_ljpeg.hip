@@ -743,8 +743,8 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     if (lb == 0)
       return;
     true_start = a.block_exit[b - 1];
-    if (true_start == a.block_start[b])
-      return; // chain already consistent here
+    if (true_start == a.block_start[b] || (true_start & ST_ERR))
+      return; // chain already consistent here / broken by an error before it
   }
 
   if (STITCH && j == 0 && (a.ablate & 128u))
@@ -795,6 +795,8 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     }
   }
 
+  if (j == 0)
+    L.misc[12] = 0;
   // Jacobi iteration with a dense work list: a slot whose recorded start state
   // differs from its predecessor's exit is re-decoded; the (few) such slots are
   // packed onto the first lanes so that a handful of stragglers do not cost a
@@ -809,7 +811,22 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       want = true_start;
     else if (j >= first_chained)
       want = L.st[j - 1];
-    if (want != L.su[j]) {
+    // Slots past the end of the data hold no symbol start: whatever state enters
+    // them leaves them unchanged, and nothing after them is ever decoded (only a
+    // suffix of a stream can be empty).  Chaining them would cost one round PER
+    // SLOT -- up to 254 rounds in the last workgroup of every stream, which is
+    // dispatched last and was the tail of the whole kernel.  (The stitch pass still
+    // takes the entry state of an all-empty workgroup so that K3's chain check holds.)
+    const bool chained = own_bits != 0u || (STITCH && j == 1);
+    // An ERROR exit is not propagated either.  A slot decoded from a wrong guess can
+    // run into an invalid code; passing that "exit" on made every later slot of the
+    // workgroup re-decode into an error one round after the other, with the repair
+    // following one slot behind -- up to 255 rounds (seen: 230 on a Hasselblad
+    // frame).  Instead a slot whose predecessor currently ends in an error is left
+    // alone: if the error is transient the predecessor is repaired and the slot is
+    // compared again next round; if it is real, nothing after it is needed (K4
+    // reports it from the failing slot's own record).
+    if (want != L.su[j] && chained && !(want & ST_ERR)) {
       const uint32_t k = atomicAdd(&L.misc[8], 1u);
       L.list[k] = uint16_t(j);
     }
@@ -820,6 +837,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     if (j == 0 && (a.ablate & 128u)) {
       atomicAdd(&a.results[s].stat_rounds, 1u);
       atomicAdd(&a.results[s].stat_redo, n);
+      atomicMax(&a.results[s].pad2, ((++L.misc[12]) << 16) | (lb & 0x7FFFu) | (STITCH ? 0x8000u : 0u));
     }
     uint32_t idx = 0, w = 0, e = 0, c = 0;
     uint64_t bm = 0;
@@ -847,7 +865,6 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
             full += __shfl_xor(full, o, 64);
           }
           if ((j & 63) == 0) {
-            atomicAdd(&a.results[s].pad2, mx);
             atomicAdd(&a.results[s].stat_stitch, full);
           }
         }
@@ -972,7 +989,9 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
     const uint32_t i = base + tid;
     const uint32_t v = i < nb ? a.block_sum[fb + i] : 0u;
     const uint32_t dv = i < nb ? a.block_drops[fb + i] : 0u;
-    if (i >= 1 && i < nb && a.block_start[fb + i] != a.block_exit[fb + i - 1])
+    // (a workgroup after a real error keeps whatever entry state it has: see K1)
+    if (i >= 1 && i < nb && a.block_start[fb + i] != a.block_exit[fb + i - 1] &&
+        !(a.block_exit[fb + i - 1] & ST_ERR))
       unconv_s = 1;
     // inclusive wave scans
     uint32_t x = v, dx = dv;
@@ -2453,12 +2472,12 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
       fprintf(stderr,
               "[rsx]  stream %zu: marker %u status %u flags %u avail %u needed %llu "
               "last_slot %u last_pos %u consumed %u tail %u blocks %u in_bytes %llu "
-              "redo_rounds %u redo_slots %u stitched %u maxsteps %u\n",
+              "redo_rounds %u redo_slots %u not_merged+stitched %u max_rounds %u (workgroup %u%s)\n",
               k, R.marker_pos, R.status, R.flags, R.avail_lo,
               (unsigned long long)p->streams[k].needed, R.last_slot, R.last_pos,
               R.consumed, R.tail_used, p->streams[k].n_blocks,
               (unsigned long long)p->streams[k].in_bytes, R.stat_rounds, R.stat_redo,
-              R.stat_stitch, R.pad2);
+              R.stat_stitch, R.pad2 >> 16, R.pad2 & 0x7FFFu, (R.pad2 & 0x8000u) ? ", stitch" : "");
     }
   }
   for (int i = 0; i < p->n_jobs; ++i) {

@@ -148,7 +148,7 @@ struct LjResult {
   uint32_t stat_stitch; // statistics: workgroups re-converged by the stitch kernel
   uint32_t end_lo;      // raw streams: bit offset just past the last needed symbol
   uint32_t end_hi;
-  uint32_t pad2;
+  uint32_t pad2;        // statistics (RSX_DEBUG): most re-decode rounds of any workgroup << 16 | its index
 };
 
 struct LjArgs {
