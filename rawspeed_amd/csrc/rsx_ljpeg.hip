@@ -1852,10 +1852,11 @@ void launch_sync(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
 }
 
 void launch_decode(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
-  // K4 is bound by its scattered 16-byte stores, not by latency: measured per 4
-  // cfg-3 frames, 5 workgroups per CU 217 us, 4: 199-209, 3: 217, 2: 258 -- so it
-  // asks for 26 LDS granules and stays at four.
-  constexpr size_t k4_lds = std::max(lj_lds_bytes(1), size_t(26 * 1280));
+  // K4's occupancy optimum moved with its store pattern (per 4 cfg-3 frames).  One
+  // 16-byte store per group: 5 workgroups per CU 217 us, 4: 199, 3: 217, 2: 258 --
+  // more resident workgroups meant more half-written lines than the L2 holds.  With
+  // the 64-byte bursts: 5 per CU 188 us, 4: 195.  29.5 KB = 24 granules = 5 per CU.
+  constexpr size_t k4_lds = lj_lds_bytes(1);
   if (p->any_plain)
     hipLaunchKernelGGL((lj_decode_kernel<false>), dim3(p->total_blocks), dim3(LJ_T),
                        k4_lds, s, a);
