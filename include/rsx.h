@@ -552,6 +552,15 @@ int rsx_plan_results(rsx_plan* plan, int32_t* job_status,
 int rsx_plan_set_timing(rsx_plan* plan, int enable);
 int rsx_plan_kernel_time(rsx_plan* plan, const char** kernel_name,
                          double* avg_ms, int* n_launches);
+/* LJPEG-family plans run a sequence of kernels.  With timing enabled an event is
+ * recorded after every launch of a run (on the launch stream), and
+ * rsx_plan_kernel_time() names the kernel with the largest total.  This call
+ * returns the whole table -- up to `cap` kernel names with their average
+ * duration per run (ms) over the timed runs since timing was enabled -- so that
+ * the dominant kernel can be checked rather than believed.  *n_kernels = entries
+ * the plan has (may exceed cap), *n_runs = runs averaged over. */
+int rsx_plan_kernel_table(rsx_plan* plan, int cap, const char** names, double* avg_ms,
+                          int* n_kernels, int* n_runs);
 void rsx_plan_destroy(rsx_plan* plan);
 
 /* Measurement aid, not part of the decode path: runs a plain streaming kernel

@@ -31,7 +31,7 @@ EXPORTS = [
     "rsx_dng_decompress_ljpeg", "rsx_dng_decompress_uncompressed",
     "rsx_unpack_plan_create", "rsx_ljpeg_plan_create", "rsx_cr2_plan_create",
     "rsx_plan_run", "rsx_plan_results", "rsx_plan_set_timing",
-    "rsx_plan_kernel_time", "rsx_plan_destroy", "rsx_probe_stream_copy",
+    "rsx_plan_kernel_time", "rsx_plan_kernel_table", "rsx_plan_destroy", "rsx_probe_stream_copy",
 ]
 
 
@@ -110,6 +110,9 @@ def lib():
         L.rsx_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.rsx_plan_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.rsx_plan_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.rsx_plan_kernel_table.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p),
+                                            C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                            C.POINTER(C.c_int)]
         L.rsx_plan_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_char_p),
                                            C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.rsx_plan_destroy.argtypes = [C.c_void_p]
@@ -321,6 +324,18 @@ class Plan:
         if st != abi.RSX_OK:
             return None
         return name.value.decode(), ms.value, n.value
+
+    def kernel_table(self, cap=64):
+        """[(kernel name, average ms per run)] of the timed runs so far, and the run count
+        (LJPEG-family plans; call before kernel_time(), which resets the totals)."""
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        n = C.c_int(0)
+        runs = C.c_int(0)
+        st = lib().rsx_plan_kernel_table(self._h, cap, names, ms, C.byref(n), C.byref(runs))
+        if st != abi.RSX_OK:
+            return None
+        return [(names[i].decode(), ms[i]) for i in range(min(cap, n.value))], runs.value
 
     def close(self):
         if self._h:

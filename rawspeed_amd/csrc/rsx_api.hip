@@ -6,6 +6,7 @@
 #include "rsx_device.h"
 #include "rsx_internal.h"
 #include "rsx_ljpeg.h"
+#include "rsx_ljpeg_dev.h"
 
 #include <algorithm>
 #include <cstring>
@@ -54,6 +55,12 @@ struct rsx_plan {
   bool timing = false;
   std::vector<EventPair> events;
   size_t events_used = 0;
+  // LJPEG plans: an event after every kernel of a timed run; the totals per kernel
+  // name are folded in before the events are reused
+  std::unique_ptr<KernelTimer> ktimer;
+  bool ktimer_pending = false;
+  std::vector<std::pair<const char*, double>> ktotals;
+  int kruns = 0;
 };
 
 namespace {
@@ -72,6 +79,33 @@ EventPair* next_events(rsx_plan* p) {
   if (p->events_used == p->events.size())
     return nullptr;
   return &p->events[p->events_used++];
+}
+
+// add the durations of the last timed LJPEG run to the per-kernel totals
+int fold_kernel_timer(rsx_plan* p) {
+  if (!p->ktimer || !p->ktimer_pending)
+    return RSX_OK;
+  rsx_ctx* ctx = p->ctx;
+  KernelTimer& t = *p->ktimer;
+  p->ktimer_pending = false;
+  if (t.n == 0)
+    return RSX_OK;
+  RSX_HIP_CHECK(ctx, hipEventSynchronize(t.ev[t.n]));
+  for (int i = 0; i < t.n; ++i) {
+    float ms = 0;
+    RSX_HIP_CHECK(ctx, hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]));
+    bool found = false;
+    for (auto& kv : p->ktotals)
+      if (kv.first == t.name[i] || std::strcmp(kv.first, t.name[i]) == 0) {
+        kv.second += ms;
+        found = true;
+        break;
+      }
+    if (!found)
+      p->ktotals.emplace_back(t.name[i], double(ms));
+  }
+  ++p->kruns;
+  return RSX_OK;
 }
 
 int flatten_unpack_job(const rsx_unpack_job& j, UnpackJobDev* out, int* order) {
@@ -495,8 +529,15 @@ extern "C" int rsx_plan_run(rsx_plan* plan, const void* in_dev, void* out_dev,
       RSX_HIP_CHECK(ctx, hipEventRecord(ev->stop, s));
     return RSX_OK;
   }
-  return ljpeg_plan_run(plan->ljpeg.get(), in_dev, out_dev, s,
-                        ev ? ev->start : nullptr, ev ? ev->stop : nullptr);
+  (void)ev;
+  if (!plan->timing)
+    return ljpeg_plan_run(plan->ljpeg.get(), in_dev, out_dev, s, nullptr);
+  if (int st = fold_kernel_timer(plan)) // (waits for the previous timed run)
+    return st;
+  if (!plan->ktimer)
+    plan->ktimer = std::make_unique<KernelTimer>();
+  plan->ktimer_pending = true;
+  return ljpeg_plan_run(plan->ljpeg.get(), in_dev, out_dev, s, plan->ktimer.get());
 }
 
 extern "C" int rsx_plan_results(rsx_plan* plan, int32_t* job_status,
@@ -529,6 +570,11 @@ extern "C" int rsx_plan_set_timing(rsx_plan* plan, int enable) {
     return RSX_ERR_INVALID_ARG;
   plan->timing = enable != 0;
   plan->events_used = 0;
+  plan->ktotals.clear();
+  plan->kruns = 0;
+  plan->ktimer_pending = false;
+  if (plan->kind == PLAN_LJPEG)
+    return RSX_OK; // its events are created on the first timed run
   if (plan->timing && plan->events.size() < 64) {
     // event creation is slow on ROCm: pre-create the pool outside timed regions
     std::lock_guard<std::recursive_mutex> lock(plan->ctx->mu);
@@ -544,13 +590,63 @@ extern "C" int rsx_plan_set_timing(rsx_plan* plan, int enable) {
   return RSX_OK;
 }
 
-extern "C" int rsx_plan_kernel_time(rsx_plan* plan, const char** kernel_name,
-                                    double* avg_ms, int* n_launches) {
-  if (!plan || !plan->timing || plan->events_used == 0)
+extern "C" int rsx_plan_kernel_table(rsx_plan* plan, int cap, const char** names,
+                                     double* avg_ms, int* n_kernels, int* n_runs) {
+  if (!plan || plan->kind != PLAN_LJPEG || !plan->timing)
     return RSX_ERR_INVALID_ARG;
   rsx_ctx* ctx = plan->ctx;
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (int st = fold_kernel_timer(plan))
+    return st;
+  if (plan->kruns == 0)
+    return RSX_ERR_INVALID_ARG;
+  int n = 0;
+  for (const auto& kv : plan->ktotals) {
+    if (n < cap) {
+      if (names)
+        names[n] = kv.first;
+      if (avg_ms)
+        avg_ms[n] = kv.second / plan->kruns;
+    }
+    ++n;
+  }
+  if (n_kernels)
+    *n_kernels = n;
+  if (n_runs)
+    *n_runs = plan->kruns;
+  return RSX_OK;
+}
+
+extern "C" int rsx_plan_kernel_time(rsx_plan* plan, const char** kernel_name,
+                                    double* avg_ms, int* n_launches) {
+  if (!plan || !plan->timing)
+    return RSX_ERR_INVALID_ARG;
+  rsx_ctx* ctx = plan->ctx;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (plan->kind == PLAN_LJPEG) {
+    // the dominant kernel = the one with the largest share of the timed runs
+    if (int st = fold_kernel_timer(plan))
+      return st;
+    if (plan->kruns == 0 || plan->ktotals.empty())
+      return RSX_ERR_INVALID_ARG;
+    const auto* best = &plan->ktotals[0];
+    for (const auto& kv : plan->ktotals)
+      if (kv.second > best->second)
+        best = &kv;
+    if (kernel_name)
+      *kernel_name = best->first;
+    if (avg_ms)
+      *avg_ms = best->second / plan->kruns;
+    if (n_launches)
+      *n_launches = plan->kruns;
+    plan->ktotals.clear();
+    plan->kruns = 0;
+    return RSX_OK;
+  }
+  if (plan->events_used == 0)
+    return RSX_ERR_INVALID_ARG;
   double total = 0;
   for (size_t i = 0; i < plan->events_used; ++i) {
     RSX_HIP_CHECK(ctx, hipEventSynchronize(plan->events[i].stop));
@@ -561,7 +657,6 @@ extern "C" int rsx_plan_kernel_time(rsx_plan* plan, const char** kernel_name,
   }
   if (kernel_name)
     *kernel_name = plan->kind == PLAN_SRAW ? "sraw_kernel"
-                   : plan->kind != PLAN_UNPACK ? ljpeg_dominant_kernel_name()
                    : (!plan->unpack.empty() &&
                       plan->unpack[0].mode == UNPACK_MODE_CONTROL)
                        ? "unpack_control_kernel"
@@ -593,6 +688,9 @@ extern "C" void rsx_plan_destroy(rsx_plan* plan) {
       (void)hipEventDestroy(e.start);
       (void)hipEventDestroy(e.stop);
     }
+    if (plan->ktimer)
+      for (int i = 0; i < plan->ktimer->created; ++i)
+        (void)hipEventDestroy(plan->ktimer->ev[i]);
     plan->ljpeg.reset();
   }
   delete plan;

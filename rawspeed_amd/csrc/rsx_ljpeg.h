@@ -46,12 +46,12 @@ struct LJpegPlan;
 
 int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
                       LJpegPlan** out);
+struct KernelTimer; // rsx_ljpeg_dev.h: an event after every launch of the run
 int ljpeg_plan_run(LJpegPlan* plan, const void* in_dev, void* out_dev,
-                   hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop);
+                   hipStream_t stream, KernelTimer* timer);
 int ljpeg_plan_results(LJpegPlan* plan, hipStream_t stream, bool ran,
                        int32_t* job_status, uint32_t* job_consumed);
 void ljpeg_plan_destroy(LJpegPlan* plan);
-const char* ljpeg_dominant_kernel_name();
 
 struct LJpegPlanDeleter {
   void operator()(LJpegPlan* p) const { ljpeg_plan_destroy(p); }

@@ -1,7 +1,8 @@
-// rsx_ljpeg.hip -- lossless-JPEG family decode pipeline for gfx950: the entropy
-// kernels and the host-side plan.  (Reconstruction -- K5/K6 and the Nikon /
-// Pentax kernels -- lives in rsx_ljpeg_recon.hip; shared structures in
-// rsx_ljpeg_dev.h.)
+// rsx_ljpeg.hip -- lossless-JPEG family decode pipeline for gfx950: un-stuffing,
+// synchronisation, scans and the host-side plan.  (The fused decode +
+// reconstruction lives in rsx_ljpeg_direct.hip, the legacy reconstruction from
+// differences and the Nikon / Pentax / Sony kernels in rsx_ljpeg_recon.hip;
+// shared structures in rsx_ljpeg_dev.h, device building blocks in rsx_ljpeg_bits.h.)
 //
 // Replaces the serial loops of
 //   LJpegDecompressor::decodeN / decodeRowN  (decompressors/LJpegDecompressor.cpp:184-339)
@@ -16,41 +17,45 @@
 // workgroup is a copy of the previous workgroup's last slot.
 //
 //  K0 lj_unstuff   every lane loads its slot (+16 bytes of lookahead) into
-//                  registers and parks it big-endian in its LDS column (dword k of
-//                  slot j at k*256+j: lane j always hits bank j%32).  Slots that
+//                  registers and parks it big-endian in its LDS column.  Slots that
 //                  hold an FF are collected in a dense list and un-stuffed by the
 //                  first lanes (FF00 -> FF, FFxx / end of buffer end the data).
 //                  The LDS image is written to global memory once.
 //  K1 lj_sync      self-synchronising speculative Huffman decode: lane j decodes
 //                  the tail of slot j-1 from an arbitrary bit to find where its own
-//                  slot most likely starts, decodes the slot, and the workgroup
+//                  slot most likely starts, decodes the slot -- recording exit
+//                  state, symbol count and, for the fused path, the sums of its
+//                  differences by relative component phase -- and the workgroup
 //                  iterates "re-decode from the predecessor's exit state" on a
-//                  dense list of the few slots that guessed wrong (early-out when
-//                  the new trajectory meets the recorded one).
+//                  dense list of the few slots that guessed wrong.  A re-decode
+//                  walks the new parse and the recorded one in lock step (always
+//                  the one that is behind) and stops where they meet.
 //  K2 lj_sync<STITCH>  cross-workgroup fix-up: a workgroup whose assumed start
 //                  differs from its predecessor's recorded exit re-converges.
 //                  (Jacobi iteration: a fixed point is the serial decode.)
-//  K3 lj_scan      per stream: verify the chain, exclusive scan of symbol counts.
-//  K4 lj_decode    final decode from validated start states: wave-uniform loop,
-//                  register bit reader with prefetched refill, 8 differences per
-//                  unaligned 16-byte store into a stream-ordered int16 scratch.
-//  K4b lj_tail     exact end-of-stream semantics for damaged streams.
+//  K3 lj_scan      per stream: verify the chain, exclusive scans of the symbol
+//                  counts and of the difference sums (-> running sums P of every
+//                  component before each workgroup).
 //  --  lj_transfer / lj_chain   fallback for streams that do not self-synchronise
 //                  (periodic data): per-workgroup transfer functions over all
 //                  entry states, chained by one lane per stream.
-//  (rsx_ljpeg_recon.hip:)
-//  K5 lj_vseed     vertical chain: predictor seed of every stream row (the row's
-//                  first MCU predicts from the first MCU of the previous row,
-//                  LJpegDecompressor.cpp:326-332, Cr2DecompressorImpl.h:437-451).
-//  K6 lj_predict   one wavefront per stream row: per-component inclusive scan
-//                  mod 2^16 (LDS transpose, packed 16-bit adds, DPP wave scan),
-//                  then the output mapping (tile crop / MCU layout / CR2 strips).
-//  K7 lj_consumed  decode()'s return value (SURVEY A.6 closed form).
+//  then either (rsx_ljpeg_direct.hip: LJPEG / CR2 streams with 1, 2 or 4
+//  interleaved components)
+//  K5a lj_rowedge  P at the first MCU of every stream row
+//  K5b lj_rowoff   row offsets O(r, c): X(i) = P(i) + O(row(i), comp(i))
+//  K4d lj_decode_direct  final decode from validated start states straight into
+//                  the image: no difference scratch, no second pass
+//  or (every other stream kind, and damaged streams)
+//  K4 lj_decode    final decode into a stream-ordered int16 scratch
+//  K4b lj_tail     exact end-of-stream semantics for damaged streams
+//  K5 / K6         seeds + row scans (rsx_ljpeg_recon.hip)
+//  and
+//  K7 lj_consumed  decode()'s return value (SURVEY.md A.6 closed form).
 //
 // Symbol semantics: codes/AbstractPrefixCodeDecoder.h:43-76; end-of-stream:
 // bitstreams/BitStreamerJPEG.h:106-183.  No MFMA (no contraction anywhere).
 #include "rsx_ljpeg.h"
-#include "rsx_ljpeg_dev.h"
+#include "rsx_ljpeg_bits.h"
 
 #include <algorithm>
 #include <cstddef>
@@ -70,54 +75,6 @@ __device__ __forceinline__ uint32_t has_ff(uint32_t d) {
   return ((~d) - 0x01010101u) & d & 0x80808080u;
 }
 
-struct Lds {
-  uint32_t* B;    // [bw][LJ_T] big-endian dwords of every slot, un-stuffed in place
-  uint16_t* su;   // [LJ_T] start state each slot was last decoded from
-  uint16_t* st;   // [LJ_T] exit state of each slot
-  uint16_t* cn;   // [LJ_T] symbols that start inside each slot (<= 512)
-  uint16_t* ob;   // [LJ_T] data bits of each slot's own 64 bytes (<= 512)
-  uint16_t* list; // [LJ_T] dense list of slots to re-decode
-  uint32_t* bm;   // [2*LJ_T] per slot: bitmap of symbol starts at bit positions < 64
-  uint32_t* misc; // [16]
-  TabLds* tabs;
-};
-
-// Sized to the byte: gfx950 hands out LDS in 1280-byte granules (160 KB / 128) and
-// the synchronisation kernels are latency bound -- their speed is the number of
-// resident workgroups (measured per 4 cfg-3 frames: 4 per CU 377 us, 5 per CU
-// 329 us).  So the records are 16-bit and the kernels keep only the dwords of a slot
-// they can touch: K0 and K4 all LJ_BW = 20 (the un-stuffer writes them, the
-// register bit reader prefetches two dwords ahead), the window reader of the
-// synchronisation kernels 17 -- a live symbol starts before bit 512, its 32-bit
-// window ends in dword 16 -- or 18 for pair symbols (second code <= 16 bits later).
-// One table, 17 dwords: 26464 bytes = 21 granules -> SIX workgroups per CU.
-constexpr int LJ_BW_SYNC = LJ_PW + 1, LJ_BW_SYNC_PAIR = LJ_PW + 2;
-constexpr size_t lj_lds_words(int bw) {
-  return size_t(bw) * LJ_T + 4 * (LJ_T / 2) + 2 * LJ_T + LJ_T / 2 + 16;
-}
-
-__device__ __forceinline__ Lds carve(uint8_t* smem, int n_tables, int bw = LJ_BW) {
-  Lds l;
-  l.B = reinterpret_cast<uint32_t*>(smem);
-  l.su = reinterpret_cast<uint16_t*>(l.B + bw * LJ_T);
-  l.st = l.su + LJ_T;
-  l.cn = l.st + LJ_T;
-  l.ob = l.cn + LJ_T;
-  l.bm = reinterpret_cast<uint32_t*>(l.ob + LJ_T);
-  l.list = reinterpret_cast<uint16_t*>(l.bm + 2 * LJ_T);
-  l.misc = l.bm + 2 * LJ_T + LJ_T / 2;
-  l.tabs = reinterpret_cast<TabLds*>(l.misc + 16);
-  return l;
-}
-
-constexpr size_t lj_lds_bytes(int n_tables, int bw = LJ_BW) {
-  return lj_lds_words(bw) * 4 + size_t(n_tables) * sizeof(TabLds);
-}
-static_assert(lj_lds_bytes(1, LJ_BW_SYNC) <= 21 * 1280, "six sync workgroups per CU");
-static_assert(lj_lds_words(LJ_BW_SYNC) % 4 == 0 && lj_lds_words(LJ_BW_SYNC_PAIR) % 4 == 0 &&
-                  lj_lds_words(LJ_BW) % 4 == 0,
-              "the tables start on a 16-byte boundary");
-
 // 16 bytes at stream offset `off`, zero outside [0, in_bytes)
 __device__ __forceinline__ uint4 lj_load_chunk(const uint8_t* __restrict__ base,
                                                int64_t off, int64_t in_bytes,
@@ -134,15 +91,6 @@ __device__ __forceinline__ uint4 lj_load_chunk(const uint8_t* __restrict__ base,
     }
   }
   return make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-__device__ __forceinline__ void lj_stage_tables(const Lds& L, const LjArgs& a,
-                                                const LjStreamDev& S) {
-  const uint4* src = reinterpret_cast<const uint4*>(a.tables + S.table_base);
-  uint4* dst = reinterpret_cast<uint4*>(L.tabs);
-  const int n16 = int(S.n_tables * sizeof(TabLds) / 16);
-  for (int i = threadIdx.x; i < n16; i += int(blockDim.x))
-    dst[i] = src[i];
 }
 
 // ---- un-stuffing of one slot, branch-free -----------------------------------
@@ -252,13 +200,6 @@ __device__ __forceinline__ void lj_fix_regs(const uint32_t (&in)[LJ_BW + 1], uin
     B[ko * LJ_T + col] = 0u;
 }
 
-// End of the data the bit reader hands out before its zero padding.  An MSB32
-// reader consumes whole little-endian words: the bytes of a partial last word are
-// its LOW-order (= last) stream bits, so the data ends at the next word boundary.
-__device__ __forceinline__ uint64_t lj_data_end(const LjStreamDev& S) {
-  return S.pair ? (S.in_bytes + 3) & ~uint64_t(3) : S.in_bytes;
-}
-
 __device__ __forceinline__ int lj_valid_bytes(const LjStreamDev& S, uint32_t lb, int j) {
   const int64_t vb =
       int64_t(lj_data_end(S)) - (int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P);
@@ -292,8 +233,8 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
     L.misc[9] = 0;  // dropped stuffing bytes
     L.misc[10] = 0; // fix-list length
   }
-  if (j < 16) // bm[] is free during staging: the 16 byte-compaction selectors
-    L.bm[j] = lj_compact_selector(uint32_t(j));
+  if (j < 16) // sm[] is free during staging: the 16 byte-compaction selectors
+    L.sm[j] = lj_compact_selector(uint32_t(j));
   uint32_t any = 0;
 #pragma unroll
   for (int m = 0; m < LJ_BW / 4; ++m) {
@@ -313,7 +254,7 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
   L.ob[j] = 8u * uint32_t(valid > LJ_P ? LJ_P : valid);
   L.su[j] = prev; // su[] doubles as the "byte before the slot" array during staging
   __syncthreads();
-  if ((any != 0u || prev == 0xFFu) && !(a.ablate & 8u) && !S.raw)
+  if ((any != 0u || prev == 0xFFu) && !S.raw)
     L.list[atomicAdd(&L.misc[10], 1u)] = uint16_t(j);
   __syncthreads();
   const uint32_t n = L.misc[10];
@@ -328,7 +269,7 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
     if (mine) {
       uint32_t own_bits, drops;
       int marker_off;
-      lj_fix_regs(r, L.B, idx, L.su[idx], lj_valid_bytes(S, lb, idx), L.bm, own_bits,
+      lj_fix_regs(r, L.B, idx, L.su[idx], lj_valid_bytes(S, lb, idx), L.sm, own_bits,
                   marker_off, drops);
       L.ob[idx] = own_bits;
       if (idx >= 1) {
@@ -345,122 +286,6 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
   __syncthreads();
 }
 
-__device__ __forceinline__ uint32_t lj_peek32(const uint32_t* B, int col,
-                                              uint32_t pos) {
-  const uint32_t i = pos >> 5, s = pos & 31u;
-  const uint32_t d0 = B[i * LJ_T + col], d1 = B[(i + 1) * LJ_T + col];
-  // funnel shift left by s (s == 0 must yield d0)
-  const uint32_t f = __builtin_amdgcn_alignbit(d0, d1, 32u - s);
-  return s ? f : d0;
-}
-
-struct Sym {
-  uint32_t total; // bits consumed
-  uint32_t ssss;
-  uint32_t code_len;
-  bool ok;
-};
-
-// Packed symbol entry (the LUT's format): bits 0..4 code length, 5..9 SSSS,
-// 10..15 bits consumed.  0 = invalid code.
-__device__ __noinline__ uint32_t lj_slow_entry(uint32_t w, const TabLds* tb) {
-  // codes longer than the LUT: JPEG Annex F.2.2.3 search
-  for (uint32_t l = LUT_BITS + 1; l <= tb->max_len; ++l) {
-    const uint32_t c = w >> (32 - l);
-    const uint32_t mc = tb->max_code[l];
-    if (mc != NO_CODE && c <= mc) {
-      const uint32_t val = tb->values[(c - tb->val_offset[l]) & 0xFFFFu];
-      const uint32_t ssss = (tb->las && val != 16u) ? (val & 15u) : val;
-      const uint32_t extra = ssss == 16u ? (tb->fix16 ? 16u : 0u)
-                                         : (tb->las ? ssss - (val >> 4) : ssss);
-      return l | (ssss << 5) | ((l + extra) << 10);
-    }
-  }
-  return 0u;
-}
-
-// Entry of the symbol whose first 32 bits are w.  `live` lanes matter; the
-// out-of-line search only runs when some live lane missed the LUT (codes longer
-// than LUT_BITS are rare, and never occur with the short tables real files use),
-// so the common path has no divergent control flow at all.
-__device__ __forceinline__ uint32_t lj_entry(uint32_t w, const TabLds& tb, bool live) {
-  uint32_t e = tb.lut[w >> (32 - LUT_BITS)];
-  if (__builtin_expect(__any(live && (e & 31u) == 0u), 0)) {
-    if (live && (e & 31u) == 0u)
-      e = lj_slow_entry(w, &tb);
-  }
-  return e;
-}
-
-// Per-stream decode parameters held in registers.
-struct DecodeParams {
-  uint32_t period;
-  uint64_t tabmap; // byte p = table slot of phase p
-};
-
-__device__ __forceinline__ DecodeParams lj_params(const LjStreamDev& S) {
-  DecodeParams d;
-  d.period = S.period;
-  uint64_t m = 0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    m |= uint64_t(S.tab_of_phase[i]) << (8 * i);
-  d.tabmap = m;
-  return d;
-}
-
-// Register bit reader over column `col` of B.  The next 33..64 stream bits sit
-// MSB-first in `buf`; the following dword is already prefetched in `nextw`, so the
-// only LDS access on a symbol's critical path is the code-table lookup.
-struct BitReader {
-  uint64_t buf;
-  uint32_t nb;    // valid bits in buf (33..64 between symbols)
-  uint32_t wi;    // dword index of nextw
-  uint32_t nextw;
-};
-
-__device__ __forceinline__ BitReader br_open(const uint32_t* B, int col, uint32_t pos) {
-  BitReader r;
-  const uint32_t i = pos >> 5, sh = pos & 31u;
-  const uint32_t d0 = B[i * LJ_T + col], d1 = B[(i + 1) * LJ_T + col];
-  r.buf = ((uint64_t(d0) << 32) | d1) << sh;
-  r.nb = 64u - sh;
-  r.wi = i + 2;
-  r.nextw = B[r.wi * LJ_T + col];
-  return r;
-}
-
-// consume `len` bits (0 for a lane that must not advance) and top the buffer up
-__device__ __forceinline__ void br_advance(BitReader& r, const uint32_t* B, int col,
-                                           uint32_t len) {
-  r.buf <<= len;
-  r.nb -= len;
-  const bool need = r.nb <= 32u;
-  const uint64_t add = uint64_t(r.nextw) << ((32u - r.nb) & 31u);
-  r.buf |= need ? add : 0ull;
-  r.nb += need ? 32u : 0u;
-  r.wi += need ? 1u : 0u;
-  // past the slot's 20 dwords there is nothing to read (a stopped lane may sit
-  // there); clamp instead of branching
-  const uint32_t wi = r.wi < uint32_t(LJ_BW) ? r.wi : uint32_t(LJ_BW - 1);
-  r.nextw = B[wi * LJ_T + col];
-}
-
-// Entry of the symbol at the head of the reader (0 = invalid code).
-template <bool MULTI>
-__device__ __forceinline__ uint32_t lj_head(const Lds& L, const DecodeParams& dp,
-                                            const BitReader& r, uint32_t phase,
-                                            bool live) {
-  const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
-  return lj_entry(uint32_t(r.buf >> 32), tb, live);
-}
-
-// The 32 stream bits at bit position `pos` of slot `col`.
-__device__ __forceinline__ uint32_t lj_window(const uint32_t* B, int col, uint32_t pos) {
-  const uint32_t wi = pos >> 5;
-  const uint32_t d0 = B[wi * LJ_T + col], d1 = B[(wi + 1) * LJ_T + col];
-  return uint32_t((((uint64_t(d0) << 32) | d1) << (pos & 31u)) >> 32);
-}
 
 // Entry of the symbol that starts at `pos` (0 = invalid code); *w_out = its window.
 template <bool MULTI, bool PAIR = false>
@@ -470,7 +295,7 @@ __device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp
   const uint32_t w = lj_window(L.B, col, pos);
   if (w_out)
     *w_out = w;
-  const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
+  const TabLds& tb = lj_table<MULTI>(L, dp, phase);
   const uint32_t e = lj_entry(w, tb, live);
   if (PAIR) {
     // HasselbladDecompressor.cpp:87-92: two length codes, then the two bit fields.
@@ -482,18 +307,17 @@ __device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp
 }
 
 // Decode the symbols that START inside slot `col` (bit positions [.., end_bits)),
-// beginning at state `start`.  With RECORD, *bm receives the bitmap of symbol
-// starts at bit positions < 64 (the slot's "trajectory", used for early-out
-// re-synchronisation).  All lanes of the wave run the same loop; a lane that is
-// done simply stops advancing (no divergent branches in the hot loop).
-// With one shared table the component phase does not influence the parse, so it
-// is left out of the state (it would never self-synchronise); with several
-// tables it is part of what has to match.
-template <bool MULTI, bool RECORD, bool PAIR = false>
+// beginning at state `start`.  NS != 0: *sums receives the sums of the differences
+// by relative phase (k mod NS for the k-th symbol).  All lanes of the wave run the
+// same loop; a lane that is done simply stops advancing (no divergent branches in
+// the hot loop).  With one shared table the component phase does not influence the
+// parse, so it is left out of the state (it would never self-synchronise); with
+// several tables it is part of what has to match.
+template <bool MULTI, int NS, bool PAIR = false>
 __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams& dp,
                                                int col, uint32_t start,
                                                uint32_t end_bits, uint32_t& exit,
-                                               uint32_t& count, uint64_t* bm,
+                                               uint32_t& count, uint2* sums,
                                                bool enabled = true,
                                                uint32_t pos_override = 0xFFFFFFFFu) {
   // pos_override: start at an arbitrary bit position of the slot (warm-up)
@@ -503,53 +327,19 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
   bool ok = !(start & ST_ERR);
   if (!ok || !enabled)
     end_bits = 0; // lane takes no steps
-#if !RSX_LJ_WINDOW
-  BitReader r = br_open(L.B, col, pos);
-#endif
-  uint64_t m = 0;
-  if (RECORD) {
-    uint32_t lim = end_bits < 64u ? end_bits : 64u;
-    while (__any(pos < lim)) {
-      const bool live = pos < lim;
-#if RSX_LJ_WINDOW
-      const uint32_t e = lj_step<MULTI, PAIR>(L, dp, col, pos, phase, live);
-#else
-      const uint32_t e = lj_head<MULTI>(L, dp, r, phase, live);
-#endif
-      const bool bad = live && e == 0u;
-      const uint32_t adv = (live && !bad) ? (e >> 10) : 0u;
-      m |= live ? (1ull << (pos & 63u)) : 0ull;
-#if !RSX_LJ_WINDOW
-      br_advance(r, L.B, col, adv);
-#endif
-      pos += adv;
-      n += (live && !bad) ? 1u : 0u;
-      if (MULTI)
-        phase = (live && !bad) ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
-      if (bad) {
-        ok = false;
-        lim = 0;
-        end_bits = 0;
-      }
-    }
-    *bm = m;
-  }
+  PhaseSums<NS ? NS : 1> acc;
   while (__any(pos < end_bits)) {
     const bool live = pos < end_bits;
-#if RSX_LJ_WINDOW
-    const uint32_t e = lj_step<MULTI, PAIR>(L, dp, col, pos, phase, live);
-#else
-    const uint32_t e = lj_head<MULTI>(L, dp, r, phase, live);
-#endif
+    uint32_t w;
+    const uint32_t e = lj_step<MULTI, PAIR>(L, dp, col, pos, phase, live, &w);
     const bool bad = live && e == 0u;
-    const uint32_t adv = (live && !bad) ? (e >> 10) : 0u;
-#if !RSX_LJ_WINDOW
-    br_advance(r, L.B, col, adv);
-#endif
-    pos += adv;
-    n += (live && !bad) ? 1u : 0u;
+    const bool good = live && !bad;
+    if (NS)
+      acc.add(lj_extend(w, e), good);
+    pos += good ? (e >> 10) : 0u;
+    n += good ? 1u : 0u;
     if (MULTI)
-      phase = (live && !bad) ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
+      phase = good ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
     if (bad) {
       ok = false;
       end_bits = 0;
@@ -559,89 +349,76 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
     return;
   exit = ok ? ((pos - end_bits) | (MULTI ? (phase << ST_PHASE_SHIFT) : 0u)) : ST_ERR;
   count = n;
+  if (NS)
+    *sums = acc.get();
 }
 
-// Re-decode slot `col` from a new start state, stopping as soon as the new
-// trajectory lands on a symbol start of the old one (single-table streams: the
-// parse from there on is identical, so the old exit and the old tail count
-// stand).  Updates the slot's records in registers.
-template <bool PAIR = false>
-__device__ __forceinline__ void lj_redecode_sync(const Lds& L, const DecodeParams& dp,
-                                                 int col, uint32_t start,
-                                                 uint32_t end_bits, uint64_t old_bm,
-                                                 uint32_t old_exit, uint32_t old_cn,
-                                                 uint32_t& exit, uint32_t& count,
-                                                 uint64_t& bm, bool enabled,
-                                                 uint32_t* steps = nullptr) {
-  uint32_t pos = start & ST_OFF_MASK, n = 0;
-  uint64_t m = 0;
-  bool ok = true, synced = false;
-  if (!enabled)
-    end_bits = 0;
-  const uint32_t real_end = end_bits;
-  uint32_t lim = end_bits < 64u ? end_bits : 64u;
-#if !RSX_LJ_WINDOW
-  BitReader r = br_open(L.B, col, pos);
-#endif
-  while (__any(pos < lim)) {
-    bool live = pos < lim;
-    if (live && ((old_bm >> (pos & 63u)) & 1ull)) {
-      synced = true;
-      lim = 0;
-      end_bits = 0;
+// Re-decode slot `col` from a new start state (single-table streams).  The new
+// parse and the recorded one (from old_start) are advanced alternately -- always
+// the one that is behind -- until they stand on the same bit: from there on they
+// are the same parse, so the recorded exit, the recorded count and the recorded
+// sums of the tail stand (the tail's phases shift by the difference of the symbol
+// counts before the meeting point).  Huffman parses re-synchronise within a few
+// dozen bits, so a re-decode costs a fraction of a slot instead of all of it, and
+// no trajectory has to be kept in LDS.  (Model: tests/test_direct_recon_model.py.)
+template <int NS, bool PAIR = false>
+__device__ __forceinline__ void lj_redecode_merge(const Lds& L, const DecodeParams& dp,
+                                                  int col, uint32_t new_start,
+                                                  uint32_t old_start, uint32_t end_bits,
+                                                  uint32_t old_exit, uint32_t old_cn,
+                                                  uint2 old_sums, uint32_t& exit,
+                                                  uint32_t& count, uint2& sums,
+                                                  bool enabled) {
+  constexpr int N = NS ? NS : 1;
+  uint32_t pa = new_start & ST_OFF_MASK, pb = old_start & ST_OFF_MASK;
+  uint32_t na = 0, nb = 0;
+  PhaseSums<N> sa, sb;
+  bool ok = true, merged = false;
+  bool old_ok = !(old_start & ST_ERR); // the recorded parse can still be followed
+  uint32_t enda = enabled ? end_bits : 0u;
+  while (__any(pa < enda)) {
+    bool live = pa < enda;
+    if (live && old_ok && pa == pb) {
+      merged = true;
+      enda = 0;
       live = false;
     }
-#if RSX_LJ_WINDOW
-    const uint32_t e = lj_step<false, PAIR>(L, dp, col, pos, 0u, live);
-#else
-    const uint32_t e = lj_head<false>(L, dp, r, 0u, live);
-#endif
+    // the recorded parse steps while it is behind (and still inside the slot)
+    const bool step_b = live && old_ok && pb < pa && pb < end_bits;
+    uint32_t w;
+    const uint32_t e = lj_step<false, PAIR>(L, dp, col, step_b ? pb : pa, 0u, live, &w);
     const bool bad = live && e == 0u;
-    const uint32_t adv = (live && !bad) ? (e >> 10) : 0u;
-    m |= live ? (1ull << (pos & 63u)) : 0ull;
-#if !RSX_LJ_WINDOW
-    br_advance(r, L.B, col, adv);
-#endif
-    pos += adv;
-    n += (live && !bad) ? 1u : 0u;
-    if (bad) {
-      ok = false;
-      lim = 0;
-      end_bits = 0;
+    const uint32_t adv = e >> 10;
+    const uint32_t d = NS ? lj_extend(w, e) : 0u;
+    const bool adv_b = step_b && !bad, adv_a = live && !step_b && !bad;
+    pb += adv_b ? adv : 0u;
+    nb += adv_b ? 1u : 0u;
+    pa += adv_a ? adv : 0u;
+    na += adv_a ? 1u : 0u;
+    if (NS) {
+      sb.add(d, adv_b);
+      sa.add(d, adv_a);
     }
-  }
-  while (__any(pos < end_bits)) {
-    const bool live = pos < end_bits;
-#if RSX_LJ_WINDOW
-    const uint32_t e = lj_step<false, PAIR>(L, dp, col, pos, 0u, live);
-#else
-    const uint32_t e = lj_head<false>(L, dp, r, 0u, live);
-#endif
-    const bool bad = live && e == 0u;
-    const uint32_t adv = (live && !bad) ? (e >> 10) : 0u;
-#if !RSX_LJ_WINDOW
-    br_advance(r, L.B, col, adv);
-#endif
-    pos += adv;
-    n += (live && !bad) ? 1u : 0u;
-    if (bad) {
+    old_ok = old_ok && !(step_b && bad); // the recorded parse ran into an invalid code
+    if (live && !step_b && bad) {
       ok = false;
-      end_bits = 0;
+      enda = 0;
     }
   }
   if (!enabled)
     return;
-  if (steps)
-    *steps = n | (synced ? 0u : 0x10000u);
-  if (synced) {
-    const uint64_t below = old_bm & ((1ull << pos) - 1ull);
-    count = n + old_cn - uint32_t(__builtin_popcountll(below));
+  if (merged) {
+    count = na + old_cn - nb;
     exit = old_exit;
-    bm = m | (old_bm & ~((1ull << pos) - 1ull));
+    if (NS) {
+      const uint2 tail = pk_sub2(old_sums, sb.get());
+      sums = pk_add2(sa.get(), lj_rot_fields<N>(tail, (na - nb) & uint32_t(N - 1)));
+    }
   } else {
-    exit = ok ? (pos - real_end) : ST_ERR;
-    count = n;
-    bm = m;
+    exit = ok ? (pa - end_bits) : ST_ERR;
+    count = na;
+    if (NS)
+      sums = sa.get();
   }
 }
 
@@ -657,8 +434,8 @@ __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& 
   const uint32_t prev_bits = enabled ? L.ob[j - 1] : 0u;
   const uint32_t from = prev_bits > LJ_WARM ? prev_bits - LJ_WARM : 0u;
   uint32_t e = 0, c = 0;
-  lj_decode_span<MULTI, false, PAIR>(L, dp, enabled ? j - 1 : 0, 0u, prev_bits, e, c,
-                                     nullptr, enabled && prev_bits != 0, from);
+  lj_decode_span<MULTI, 0, PAIR>(L, dp, enabled ? j - 1 : 0, 0u, prev_bits, e, c, nullptr,
+                                 enabled && prev_bits != 0, from);
   return (e & ST_ERR) ? 0u : e;
 }
 
@@ -674,7 +451,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   const uint32_t b = blockIdx.x;
   const uint32_t s = a.block_stream[b];
   const LjStreamDev& S = a.streams[s];
-  const Lds L = carve(smem, 0);
+  const Lds L = carve(smem);
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
   lj_stage_slots(L, a, S, s, lb, j, true); // ends with a barrier
@@ -688,53 +465,32 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     a.block_drops[b] = L.misc[9];
 }
 
-// Load the workgroup's un-stuffed image (K0's output) into LDS: B and ob[].
-// Ends with a workgroup barrier.
-template <int BW = LJ_BW>
-__device__ __forceinline__ void lj_load_image(const Lds& L, const LjArgs& a, uint32_t b,
-                                              int j) {
-  const uint4* __restrict__ src = a.unstuffed + size_t(b) * LJ_IMG_U4;
-  uint4* dst = reinterpret_cast<uint4*>(L.B);
-  const uint32_t ob = reinterpret_cast<const uint32_t*>(src + (LJ_BW / 4) * LJ_T)[j];
-  // the image is B as it lies in LDS ([dword][slot]); the first BW dword rows are
-  // wanted: BW * LJ_T / 4 consecutive uint4 (a register array here ends up in
-  // scratch; copy in groups of three instead)
-  constexpr int n4 = BW * LJ_T / 4;
-  auto want = [&](int i) { return BW == LJ_BW || i < n4; };
+// inclusive scan of x over the wavefront
+__device__ __forceinline__ uint32_t lj_wave_scan(uint32_t x, int lane) {
 #pragma unroll
-  for (int h = 0; h < LJ_BW / 4; h += 3) {
-    const int i0 = h * LJ_T + j, i1 = i0 + LJ_T, i2 = i1 + LJ_T;
-    uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0, t2 = t0;
-    if (want(i0))
-      t0 = src[i0];
-    if (h + 1 < LJ_BW / 4 && want(i1))
-      t1 = src[i1];
-    if (h + 2 < LJ_BW / 4 && want(i2))
-      t2 = src[i2];
-    if (want(i0))
-      dst[i0] = t0;
-    if (h + 1 < LJ_BW / 4 && want(i1))
-      dst[i1] = t1;
-    if (h + 2 < LJ_BW / 4 && want(i2))
-      dst[i2] = t2;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o, 64);
+    if (lane >= o)
+      x += y;
   }
-  L.ob[j] = uint16_t(ob);
-  __syncthreads();
+  return x;
 }
 
 // ---------------------------------------------------------------------------
-// K1 / K2: synchronisation
+// K1 / K2: synchronisation.  NS = interleaved components of a fused-path stream
+// (its difference sums are recorded), 0 = none.
 // ---------------------------------------------------------------------------
-template <bool STITCH, bool MULTI, bool PAIR = false>
+template <bool STITCH, bool MULTI, bool PAIR, int NS>
 __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t b = blockIdx.x;
   const uint32_t s = a.block_stream[b];
   const LjStreamDev& S = a.streams[s];
-  if ((S.n_tables > 1) != MULTI || (S.pair != 0) != PAIR)
+  if ((S.n_tables > 1) != MULTI || (S.pair != 0) != PAIR || int(S.direct) != NS)
     return; // another instantiation handles this stream
   constexpr int BWK = PAIR ? LJ_BW_SYNC_PAIR : LJ_BW_SYNC;
-  const Lds L = carve(smem, int(S.n_tables), BWK);
+  constexpr int N = NS ? NS : 1;
+  const Lds L = carve(smem, BWK);
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
 
@@ -747,8 +503,10 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       return; // chain already consistent here / broken by an error before it
   }
 
-  if (STITCH && j == 0 && (a.ablate & 128u))
+#ifdef RSX_EXPERIMENT
+  if (STITCH && j == 0)
     atomicAdd(&a.results[s].stat_stitch, 1u);
+#endif
   lj_stage_tables(L, a, S);
   lj_load_image<BWK>(L, a, b, j); // ends with a barrier
   const uint32_t own_bits = L.ob[j];
@@ -758,31 +516,29 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   // initial decode / initial records
   if (!STITCH) {
     uint32_t start = 0, e = 0, c = 0;
-    uint64_t bm = 0;
+    uint2 sums = make_uint2(0, 0);
     // slot 0 of the first workgroup lies before the stream: its "exit" is the
     // known start state; every other slot decodes from its warm-up guess
     // (slot 0 of later workgroups from bit 0)
     const bool real_slot = !(lb == 0 && j == 0);
-    const uint32_t guess = (a.ablate & 16u) ? 0u : lj_warmup<MULTI, PAIR>(L, dp, j);
+    const uint32_t guess = lj_warmup<MULTI, PAIR>(L, dp, j);
     if (j >= 2 || (j == 1 && lb > 0))
       start = guess;
     else if (j == 1)
       start = S.start_bit; // the stream's first symbol
-    lj_decode_span<MULTI, !MULTI, PAIR>(L, dp, j, start, own_bits, e, c, &bm,
-                                  real_slot && !(a.ablate & 4u));
+    lj_decode_span<MULTI, NS, PAIR>(L, dp, j, start, own_bits, e, c, &sums, real_slot);
     if (!real_slot) {
       e = S.start_bit;
       c = 0;
-      bm = 0;
     }
     L.su[j] = start;
     L.st[j] = e;
     L.cn[j] = c;
-    L.bm[2 * j] = uint32_t(bm);
-    L.bm[2 * j + 1] = uint32_t(bm >> 32);
+    if (NS) {
+      L.sm[2 * j] = sums.x;
+      L.sm[2 * j + 1] = sums.y;
+    }
   } else {
-    L.bm[2 * j] = 0; // no trajectory on record: the first re-decode is a full one
-    L.bm[2 * j + 1] = 0;
     if (j == 0) {
       L.su[0] = 0;
       L.st[0] = 0;
@@ -792,11 +548,18 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       L.st[j] = rec & ST_MASK;
       L.cn[j] = rec >> 16;
       L.su[j] = (j == 1) ? a.block_start[b] : (a.sub_state[gsub - 1] & ST_MASK);
+      if (NS) {
+        const uint2 sums = a.sub_sums[gsub];
+        L.sm[2 * j] = sums.x;
+        L.sm[2 * j + 1] = sums.y;
+      }
     }
   }
 
+#ifdef RSX_EXPERIMENT
   if (j == 0)
     L.misc[12] = 0;
+#endif
   // Jacobi iteration with a dense work list: a slot whose recorded start state
   // differs from its predecessor's exit is re-decoded; the (few) such slots are
   // packed onto the first lanes so that a handful of stragglers do not cost a
@@ -824,84 +587,93 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     // following one slot behind -- up to 255 rounds (seen: 230 on a Hasselblad
     // frame).  Instead a slot whose predecessor currently ends in an error is left
     // alone: if the error is transient the predecessor is repaired and the slot is
-    // compared again next round; if it is real, nothing after it is needed (K4
-    // reports it from the failing slot's own record).
+    // compared again next round; if it is real, nothing after it is needed (the
+    // decode kernel reports it from the failing slot's own record).
     if (want != L.su[j] && chained && !(want & ST_ERR)) {
       const uint32_t k = atomicAdd(&L.misc[8], 1u);
       L.list[k] = uint16_t(j);
     }
     __syncthreads();
     const uint32_t n = L.misc[8];
-    if (n == 0 || (a.ablate & 32u))
+    if (n == 0)
       break;
-    if (j == 0 && (a.ablate & 128u)) {
+#ifdef RSX_EXPERIMENT
+    if (j == 0) {
       atomicAdd(&a.results[s].stat_rounds, 1u);
       atomicAdd(&a.results[s].stat_redo, n);
-      atomicMax(&a.results[s].pad2, ((++L.misc[12]) << 16) | (lb & 0x7FFFu) | (STITCH ? 0x8000u : 0u));
+      atomicMax(&a.results[s].pad2,
+                ((++L.misc[12]) << 16) | (lb & 0x7FFFu) | (STITCH ? 0x8000u : 0u));
     }
+#endif
     uint32_t idx = 0, w = 0, e = 0, c = 0;
-    uint64_t bm = 0;
+    uint2 sums = make_uint2(0, 0);
     // only the waves that hold list entries do anything (wave-uniform test)
     if (uint32_t(j & ~63) < n) {
       const bool mine = uint32_t(j) < n;
       idx = mine ? uint32_t(L.list[j]) : 1u;
       w = (STITCH && idx == 1) ? true_start : L.st[idx - 1];
       if (MULTI) {
-        lj_decode_span<MULTI, false, PAIR>(L, dp, int(idx), w, L.ob[idx], e, c, nullptr,
-                                           mine);
+        lj_decode_span<MULTI, NS, PAIR>(L, dp, int(idx), w, L.ob[idx], e, c, &sums, mine);
       } else {
-        const uint64_t old_bm = uint64_t(L.bm[2 * idx]) | (uint64_t(L.bm[2 * idx + 1]) << 32);
-        const bool err = (w & ST_ERR) != 0;
-        uint32_t steps = 0;
-        lj_redecode_sync<PAIR>(L, dp, int(idx), w, L.ob[idx], old_bm, L.st[idx], L.cn[idx], e,
-                         c, bm, mine && !err, &steps);
-        if (a.ablate & 128u) {
-          if (!mine)
-            steps = 0;
-          uint32_t mx = steps & 0xFFFFu, full = steps >> 16;
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {
-            mx = max(mx, uint32_t(__shfl_xor(mx, o, 64)));
-            full += __shfl_xor(full, o, 64);
-          }
-          if ((j & 63) == 0) {
-            atomicAdd(&a.results[s].stat_stitch, full);
-          }
-        }
-        if (err) {
-          e = ST_ERR;
-          c = 0;
-          bm = 0;
-        }
+        const uint2 old_sums = make_uint2(NS ? L.sm[2 * idx] : 0u, NS ? L.sm[2 * idx + 1] : 0u);
+        lj_redecode_merge<NS, PAIR>(L, dp, int(idx), w, L.su[idx], L.ob[idx], L.st[idx],
+                                    L.cn[idx], old_sums, e, c, sums, mine);
       }
     }
-    __syncthreads(); // every read of st[] precedes the updates
+    __syncthreads(); // every read of the records precedes the updates
     if (uint32_t(j) < n) {
       L.su[idx] = w;
       L.st[idx] = e;
       L.cn[idx] = c;
-      L.bm[2 * idx] = uint32_t(bm);
-      L.bm[2 * idx + 1] = uint32_t(bm >> 32);
+      if (NS) {
+        L.sm[2 * idx] = sums.x;
+        L.sm[2 * idx + 1] = sums.y;
+      }
     }
   }
 
-  const uint32_t my_count = L.cn[j];
-  if (j >= 1)
+  const uint32_t my_count = j >= 1 ? uint32_t(L.cn[j]) : 0u;
+  const uint2 my_sums =
+      (NS && j >= 1) ? make_uint2(L.sm[2 * j], L.sm[2 * j + 1]) : make_uint2(0u, 0u);
+  if (j >= 1) {
     a.sub_state[gsub] = L.st[j] | (my_count << 16);
+    if (NS)
+      a.sub_sums[gsub] = my_sums;
+  }
   if (j == 1)
     a.block_start[b] = L.su[1];
   if (j == LJ_T - 1)
     a.block_exit[b] = L.st[j];
-  // block totals: symbols, dropped stuffing bytes
-  uint32_t v = j >= 1 ? my_count : 0u;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-    v += __shfl_down(v, o, 64);
-  if ((j & 63) == 0)
-    L.misc[j >> 6] = v;
+  // block totals: symbols, and the difference sums with phases relative to the
+  // workgroup's first symbol (a slot's own phases start at its first symbol:
+  // rotate by the number of symbols before it)
+  const int lane = j & 63, wv = j >> 6;
+  const uint32_t incl = lj_wave_scan(my_count, lane);
+  if (lane == 63)
+    L.misc[wv] = incl;
   __syncthreads();
+  uint32_t before = incl - my_count;
+  for (int w = 0; w < wv; ++w)
+    before += L.misc[w];
   if (j == 0)
     a.block_sum[b] = L.misc[0] + L.misc[1] + L.misc[2] + L.misc[3];
+  if (NS) {
+    uint2 r = lj_rot_fields<N>(my_sums, before & uint32_t(N - 1));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+      r = pk_add2(r, make_uint2(__shfl_xor(r.x, o, 64), __shfl_xor(r.y, o, 64)));
+    if (lane == 0) {
+      L.misc[4 + 2 * wv] = r.x;
+      L.misc[5 + 2 * wv] = r.y;
+    }
+    __syncthreads();
+    if (j == 0) {
+      uint2 t = make_uint2(L.misc[4], L.misc[5]);
+      for (int w = 1; w < 4; ++w)
+        t = pk_add2(t, make_uint2(L.misc[4 + 2 * w], L.misc[5 + 2 * w]));
+      a.block_psum[b] = t;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -945,8 +717,7 @@ __global__ __launch_bounds__(LJ_T) void lj_transfer_kernel(LjArgs a) {
   uint32_t state = off | (phase << ST_PHASE_SHIFT);
   for (int slot = 1; slot < LJ_T; ++slot) {
     uint32_t e = ST_ERR, c = 0;
-    lj_decode_span<MULTI, false, PAIR>(L, dp, slot, state, ob32[slot], e, c, nullptr,
-                                       enabled);
+    lj_decode_span<MULTI, 0, PAIR>(L, dp, slot, state, ob32[slot], e, c, nullptr, enabled);
     state = e;
   }
   if (enabled)
@@ -968,20 +739,33 @@ __global__ __launch_bounds__(64) void lj_chain_kernel(LjArgs a) {
   }
 }
 
+// run-time flavour of lj_rot_fields (the per-stream scan kernel is not
+// instantiated per component count)
+__device__ __forceinline__ uint2 lj_rot_fields_rt(uint2 v, uint32_t f, uint32_t n) {
+  return n == 2 ? lj_rot_fields<2>(v, f) : (n == 4 ? lj_rot_fields<4>(v, f) : v);
+}
+
 // ---------------------------------------------------------------------------
-// K3: per-stream chain check + exclusive scan of the per-workgroup symbol counts
+// K3: per stream -- chain check; exclusive scans over the workgroups of the symbol
+// counts, the dropped stuffing bytes and (fused path) the difference sums: the
+// latter become P, the running sum of every component's differences over the
+// whole stream, before each workgroup's first symbol.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
   __shared__ uint32_t wsum[4], dsum[4];
+  __shared__ uint2 psum[4];
   __shared__ uint32_t carry_s, dcarry_s;
+  __shared__ uint2 pcarry_s;
   __shared__ uint32_t unconv_s;
   const uint32_t s = blockIdx.x;
   const LjStreamDev& S = a.streams[s];
   const int tid = threadIdx.x;
   const uint32_t fb = S.first_block, nb = S.n_blocks;
+  const uint32_t nd = S.direct;
   if (tid == 0) {
     carry_s = 0;
     dcarry_s = 0;
+    pcarry_s = make_uint2(0, 0);
     unconv_s = 0;
   }
   __syncthreads();
@@ -1020,6 +804,30 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
       a.block_base[fb + i] = excl;
       a.block_drop_base[fb + i] = dexcl;
     }
+    if (nd) {
+      // the workgroup's sums are kept by phases relative to its first symbol,
+      // whose index is now known
+      const uint2 pv = i < nb ? lj_rot_fields_rt(a.block_psum[fb + i], excl % nd, nd)
+                              : make_uint2(0u, 0u);
+      uint2 px = pv;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint2 py = make_uint2(__shfl_up(px.x, o, 64), __shfl_up(px.y, o, 64));
+        if ((tid & 63) >= o)
+          px = pk_add2(px, py);
+      }
+      if ((tid & 63) == 63)
+        psum[tid >> 6] = px;
+      __syncthreads();
+      uint2 pex = pk_add2(pcarry_s, pk_sub2(px, pv));
+      for (int w = 0; w < (tid >> 6); ++w)
+        pex = pk_add2(pex, psum[w]);
+      if (i < nb)
+        a.block_pbase[fb + i] = pex;
+      __syncthreads();
+      if (tid == LJ_T - 1)
+        pcarry_s = pk_add2(pex, pv);
+    }
     __syncthreads();
     if (tid == LJ_T - 1) {
       carry_s = excl + v;
@@ -1045,15 +853,20 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
         avail += a.sub_state[g0 + q] >> 16;
     }
     R.avail_lo = avail;
+    uint32_t flags = R.flags & ~(FL_UNCONVERGED | FL_NEED_LEGACY);
     if (unconv_s)
-      R.flags |= FL_UNCONVERGED;
-    else
-      R.flags &= ~FL_UNCONVERGED;
+      flags |= FL_UNCONVERGED;
+    // symbols past the end of the data: the reference's end-of-stream semantics
+    // live in the legacy tail kernel
+    if (nd && uint64_t(avail) < S.needed)
+      flags |= FL_NEED_LEGACY;
+    R.flags = flags;
   }
 }
 
 // ---------------------------------------------------------------------------
-// K4: final decode -> stream-ordered int16 differences
+// K4 (legacy path): final decode -> stream-ordered int16 differences.  Streams of
+// the fused path come here only when they are damaged (FL_NEED_LEGACY).
 // ---------------------------------------------------------------------------
 // LAS: the stream's table holds Nikon "lossy after split" values (its own
 // instantiation so that the JPEG hot loop carries no extra branch)
@@ -1070,7 +883,9 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   const LjStreamDev& S = a.streams[s];
   if ((S.n_tables > 1) != MULTI || (S.las != 0) != LAS || S.pair)
     return;
-  const Lds L = carve(smem, int(S.n_tables));
+  if (S.direct && !(a.results[s].flags & FL_NEED_LEGACY))
+    return; // decoded by lj_decode_direct_kernel
+  const Lds L = carve(smem, LJ_BW_DEC);
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
   const uint64_t needed = S.needed;
@@ -1085,7 +900,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
     return; // past the end of data
 
   lj_stage_tables(L, a, S);
-  lj_load_image(L, a, b, j); // ends with a barrier
+  lj_load_image<LJ_BW_DEC>(L, a, b, j); // ends with a barrier
   const DecodeParams dp = lj_params(S);
 
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1);
@@ -1135,14 +950,11 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1)
     wmax = max(wmax, uint32_t(__shfl_xor(wmax, o, 64)));
-  const uint32_t n_groups = (a.ablate & 2u) ? 0u : (wmax + 7) >> 3;
+  const uint32_t n_groups = (wmax + 7) >> 3;
 
   uint32_t phase = (my_start >> ST_PHASE_SHIFT) & 7u;
-#if RSX_LJ_K4_WINDOW
-  uint32_t pos = my_start & ST_OFF_MASK;
-#else
-  BitReader r = br_open(L.B, j, my_start & ST_OFF_MASK);
-#endif
+  BitReader<LJ_BW_DEC> r;
+  r.open(L.B, j, my_start & ST_OFF_MASK);
   uint32_t tp0 = 0, tp1 = 0, tp2 = 0, tp3 = 0; // the lane's last, partial group
   // A lane's 16-byte stores land on an arbitrary 2-byte boundary of a region it
   // shares cache lines with its neighbours'.  Issued one per group, every line
@@ -1154,15 +966,9 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const bool live = 8 * g + q < remaining;
-#if RSX_LJ_K4_WINDOW
-      uint32_t w;
-      const uint32_t e = lj_step<MULTI>(L, dp, j, pos, phase, live, &w);
-      pos += live ? (e >> 10) : 0u;
-#else
-      const uint32_t w = uint32_t(r.buf >> 32);
-      const uint32_t e = lj_head<MULTI>(L, dp, r, phase, live);
-      br_advance(r, L.B, j, live ? (e >> 10) : 0u);
-#endif
+      const uint32_t w = r.head();
+      const uint32_t e = lj_entry(w, lj_table<MULTI>(L, dp, phase), live);
+      r.advance(L.B, j, live ? (e >> 10) : 0u);
       if (MULTI)
         phase = live ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
       const uint32_t cl = e & 31u, ssss = (e >> 5) & 31u;
@@ -1173,24 +979,11 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
         int d = int((((v << 1) + 1u) << shl) >> 1);
         if ((d & (1 << ((ssss - 1u) & 31u))) == 0)
           d -= (1 << ssss) - (shl ? 0 : 1);
-        diff = uint32_t(d);
+        diff = ssss == 16u ? 0x8000u : uint32_t(d);
+        diff &= 0xFFFFu;
       } else {
-        // v = the SSSS bits after the code; diff per JPEG F.2.2.1 "EXTEND"
-#if RSX_LJ_K4_WINDOW
-        // (SSSS = 0: v = 0 and the shift count wraps to 31, so diff = 0 + 1 - 1)
-        const uint32_t v = __builtin_amdgcn_ubfe(w, 32u - (e >> 10), ssss);
-        diff = (v >> ((ssss - 1u) & 31u)) ? v : v + 1u - (1u << ssss);
-        (void)cl;
+        diff = lj_extend(w, e);
       }
-#else
-        const uint32_t v = uint32_t((uint64_t(w << cl) << ssss) >> 32);
-        const uint32_t half = (1u << ssss) >> 1;
-        diff = v >= half ? v : v + 1u - (1u << ssss);
-      }
-      diff = ssss == 0u ? 0u : diff;
-#endif
-      diff = ssss == 16u ? 0x8000u : diff;
-      diff &= 0xFFFFu;
       if (q & 1)
         p[q >> 1] |= diff << 16;
       else
@@ -1209,9 +1002,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
       if (g >= n_groups)
         break;
       const uint32_t(&p)[4] = pv[u];
-      if (a.ablate & 1u) {
-        asm volatile("" ::"v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]));
-      } else if (8 * g + 8 <= remaining) {
+      if (8 * g + 8 <= remaining) {
         const uint4 v = make_uint4(p[0], p[1], p[2], p[3]);
         __builtin_memcpy(out + 8 * g, &v, 16);
       } else if (8 * g < remaining) {
@@ -1236,8 +1027,8 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
     const uint32_t target = uint32_t(needed - 1 - first);
     uint32_t p2 = my_start & ST_OFF_MASK, ph2 = (my_start >> ST_PHASE_SHIFT) & 7u;
     for (uint32_t t = 0; t < target; ++t) {
-      const uint32_t w = lj_peek32(L.B, j, p2);
-      const TabLds& tb = L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * ph2)) & 0xFFu : 0u];
+      const uint32_t w = lj_window(L.B, j, p2);
+      const TabLds& tb = lj_table<MULTI>(L, dp, ph2);
       uint32_t e = tb.lut[w >> (32 - LUT_BITS)];
       if ((e & 31u) == 0u)
         e = lj_slow_entry(w, &tb);
@@ -1271,7 +1062,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_pair_kernel(LjArgs a) {
   const LjStreamDev& S = a.streams[s];
   if (!S.pair)
     return;
-  const Lds L = carve(smem, 1);
+  const Lds L = carve(smem);
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
   const uint64_t needed = S.needed; // pairs
@@ -1383,6 +1174,13 @@ __device__ __forceinline__ uint64_t lj_drops_before(const LjArgs& a,
                                                     const LjStreamDev& S,
                                                     const uint8_t* in, uint64_t x,
                                                     int lane);
+
+struct Sym {
+  uint32_t total; // bits consumed
+  uint32_t ssss;
+  uint32_t code_len;
+  bool ok;
+};
 
 __device__ __forceinline__ Sym lj_symbol_global(uint32_t w, const TabLds* tb) {
   const uint32_t e = tb->lut[w >> (32 - LUT_BITS)];
@@ -1742,7 +1540,6 @@ __global__ __launch_bounds__(256) void lj_marker_scan_kernel(
 }
 
 } // namespace
-
 // ---------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------
@@ -1756,11 +1553,24 @@ struct LJpegPlan {
   uint32_t total_blocks = 0, total_subseq = 0, total_rows = 0;
   uint64_t total_diffs = 0;
   int max_tables = 1;
-  bool any_multi = false, any_single = false, any_single_plain = false;
-  bool comp_present[7] = {}; // [1..4] interleaved n_comp; [5], [6]: sRaw groups of 4, 6
-  DeviceBuffer d_streams, d_tables, d_block_stream, d_strips, d_sub_state,
-      d_block_start, d_block_exit, d_block_sum, d_block_base, d_block_drops,
-      d_block_drop_base, d_results, d_diffs, d_vseed, d_unstuffed;
+  // kernel classes of the legacy route (difference scratch + K5 / K6): `legacy` for
+  // the streams that always take it, `fallback` for the fused-path streams should
+  // they turn out to be damaged
+  struct Classes {
+    bool plain = false, las = false, pair = false, multi = false;
+    bool comp[7] = {}; // [1..4] interleaved n_comp; [5], [6]: sRaw groups of 4, 6
+    bool nikon = false, sony = false;
+  };
+  Classes legacy, fallback;
+  // which instantiations the plan's streams need
+  bool sync_present[2][5] = {};   // [several tables][fused-path components, 0 = legacy]
+  bool direct_present[2][5] = {}; // fused path: [several tables][components]
+  bool any_direct = false, any_legacy = false;
+  bool legacy_fallback_ready = false; // difference scratch of the fused streams allocated
+  DeviceBuffer d_streams, d_tables, d_block_stream, d_strips, d_sub_state, d_sub_sums,
+      d_block_start, d_block_exit, d_block_sum, d_block_base, d_block_psum, d_block_pbase,
+      d_block_drops, d_block_drop_base, d_results, d_diffs, d_vseed, d_row_edge, d_unstuffed;
+  KernelTimer* timer = nullptr; // set for the duration of a timed run
   std::vector<LjResult> h_results;
   int stitch_rounds = 2;
   const void* last_in = nullptr;
@@ -1784,8 +1594,7 @@ struct LJpegPlan {
   LJpegPlan* child = nullptr;          // one stream per restart interval
   std::vector<std::pair<int, int>> child_owner; // child job -> (dri index, interval)
   // NikonDecompressor streams
-  bool any_nikon = false, any_las = false, any_plain = false, any_pair = false;
-  bool any_sony = false;
+  bool any_nikon = false, any_pair = false, any_multi = false;
   std::vector<NkStreamDev> nk;         // parallel to streams
   DeviceBuffer d_nk, d_nk_tables, d_nk_rowpow, d_nk_pup;
   DeviceBuffer d_transfer; // fallback path only (allocated on first use)
@@ -1815,6 +1624,10 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.block_stream = static_cast<const uint32_t*>(p->d_block_stream.ptr);
   a.strips = static_cast<const Cr2Strip*>(p->d_strips.ptr);
   a.sub_state = static_cast<uint32_t*>(p->d_sub_state.ptr);
+  a.sub_sums = static_cast<uint2*>(p->d_sub_sums.ptr);
+  a.block_psum = static_cast<uint2*>(p->d_block_psum.ptr);
+  a.block_pbase = static_cast<uint2*>(p->d_block_pbase.ptr);
+  a.row_edge = static_cast<uint4*>(p->d_row_edge.ptr);
   a.block_start = static_cast<uint32_t*>(p->d_block_start.ptr);
   a.block_exit = static_cast<uint32_t*>(p->d_block_exit.ptr);
   a.block_sum = static_cast<uint32_t*>(p->d_block_sum.ptr);
@@ -1827,9 +1640,6 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.vseed = static_cast<uint16_t*>(p->d_vseed.ptr);
   a.n_streams = uint32_t(p->streams.size());
   a.total_rows = p->total_rows;
-  a.ablate = getenv("RSX_ABLATE") ? uint32_t(atoi(getenv("RSX_ABLATE"))) : 0u;
-  if (getenv("RSX_DEBUG"))
-    a.ablate |= 128u; // collect the re-decode statistics
   a.nk = static_cast<const NkStreamDev*>(p->d_nk.ptr);
   a.nk_tables = static_cast<const uint32_t*>(p->d_nk_tables.ptr);
   a.nk_rowpow = static_cast<const uint32_t*>(p->d_nk_rowpow.ptr);
@@ -1838,43 +1648,89 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   return a;
 }
 
-template <bool STITCH>
-void launch_sync(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
-  if (p->any_single_plain)
-    hipLaunchKernelGGL((lj_sync_kernel<STITCH, false>), dim3(p->total_blocks),
-                       dim3(LJ_T), lj_lds_bytes(1, LJ_BW_SYNC), s, a);
-  if (p->any_pair)
-    hipLaunchKernelGGL((lj_sync_kernel<STITCH, false, true>), dim3(p->total_blocks),
-                       dim3(LJ_T), lj_lds_bytes(1, LJ_BW_SYNC_PAIR), s, a);
-  if (p->any_multi)
-    hipLaunchKernelGGL((lj_sync_kernel<STITCH, true>), dim3(p->total_blocks),
-                       dim3(LJ_T), lj_lds_bytes(p->max_tables, LJ_BW_SYNC), s, a);
+void mark(LJpegPlan* p, const char* name) {
+  if (p->timer)
+    p->timer->mark(name);
 }
 
-void launch_decode(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
+template <bool STITCH, bool MULTI, int NS>
+void launch_sync_one(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
+  if (!p->sync_present[MULTI ? 1 : 0][NS])
+    return;
+  hipLaunchKernelGGL((lj_sync_kernel<STITCH, MULTI, false, NS>), dim3(p->total_blocks),
+                     dim3(LJ_T), lj_lds_bytes(MULTI ? p->max_tables : 1, LJ_BW_SYNC), s, a);
+  mark(p, STITCH ? "lj_sync_kernel<stitch>" : "lj_sync_kernel");
+}
+
+template <bool STITCH>
+void launch_sync(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
+  launch_sync_one<STITCH, false, 0>(p, a, s);
+  launch_sync_one<STITCH, false, 1>(p, a, s);
+  launch_sync_one<STITCH, false, 2>(p, a, s);
+  launch_sync_one<STITCH, false, 4>(p, a, s);
+  launch_sync_one<STITCH, true, 0>(p, a, s);
+  launch_sync_one<STITCH, true, 1>(p, a, s);
+  launch_sync_one<STITCH, true, 2>(p, a, s);
+  launch_sync_one<STITCH, true, 4>(p, a, s);
+  if (p->any_pair) {
+    hipLaunchKernelGGL((lj_sync_kernel<STITCH, false, true, 0>), dim3(p->total_blocks),
+                       dim3(LJ_T), lj_lds_bytes(1, LJ_BW_SYNC_PAIR), s, a);
+    mark(p, STITCH ? "lj_sync_kernel<stitch,pair>" : "lj_sync_kernel<pair>");
+  }
+}
+
+void launch_decode(LJpegPlan* p, const LJpegPlan::Classes& c, const LjArgs& a,
+                   hipStream_t s) {
   // K4's occupancy optimum moved with its store pattern (per 4 cfg-3 frames).  One
   // 16-byte store per group: 5 workgroups per CU 217 us, 4: 199, 3: 217, 2: 258 --
   // more resident workgroups meant more half-written lines than the L2 holds.  With
   // the 64-byte bursts: 5 per CU 188 us, 4: 195.  29.5 KB = 24 granules = 5 per CU.
-  constexpr size_t k4_lds = lj_lds_bytes(1);
-  if (p->any_plain)
+  constexpr size_t k4_lds = lj_lds_bytes(1, LJ_BW_DEC);
+  if (c.plain) {
     hipLaunchKernelGGL((lj_decode_kernel<false>), dim3(p->total_blocks), dim3(LJ_T),
                        k4_lds, s, a);
-  if (p->any_las)
+    mark(p, "lj_decode_kernel");
+  }
+  if (c.las) {
     hipLaunchKernelGGL((lj_decode_kernel<false, true>), dim3(p->total_blocks), dim3(LJ_T),
                        k4_lds, s, a);
-  if (p->any_pair)
+    mark(p, "lj_decode_kernel<las>");
+  }
+  if (c.pair) {
     hipLaunchKernelGGL(lj_decode_pair_kernel, dim3(p->total_blocks), dim3(LJ_T),
-                       k4_lds, s, a);
-  if (p->any_multi)
+                       lj_lds_bytes(1), s, a);
+    mark(p, "lj_decode_pair_kernel");
+  }
+  if (c.multi) {
     hipLaunchKernelGGL((lj_decode_kernel<true>), dim3(p->total_blocks), dim3(LJ_T),
-                       lj_lds_bytes(p->max_tables), s, a);
+                       lj_lds_bytes(p->max_tables, LJ_BW_DEC), s, a);
+    mark(p, "lj_decode_kernel<multi>");
+  }
 }
 
 
 } // namespace
 
-const char* ljpeg_dominant_kernel_name() { return "lj_decode_kernel"; }
+void KernelTimer::begin(hipStream_t s) {
+  stream = s;
+  n = 0;
+  if (created == 0 && hipEventCreate(&ev[0]) == hipSuccess)
+    created = 1;
+  if (created)
+    (void)hipEventRecord(ev[0], s);
+}
+
+void KernelTimer::mark(const char* kernel) {
+  if (n >= MAX || created == 0)
+    return;
+  if (created <= n + 1) {
+    if (hipEventCreate(&ev[n + 1]) != hipSuccess)
+      return;
+    created = n + 2;
+  }
+  (void)hipEventRecord(ev[n + 1], stream);
+  name[n++] = kernel;
+}
 
 int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
                       LJpegPlan** out) {
@@ -1919,7 +1775,6 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     LjStreamDev S{};
     S.in_offset = g.in_offset;
     S.in_bytes = g.in_bytes;
-    S.diff_offset = p->total_diffs;
     S.needed = needed;
     S.img_offset = g.img_offset;
     S.img_pitch = g.img_pitch_bytes;
@@ -1938,6 +1793,15 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     S.las = g.las;
     S.pair = g.pair;
     S.no_vertical = g.no_vertical;
+    // LJPEG / CR2 streams with 1, 2 or 4 interleaved components take the fused
+    // decode + reconstruction; everything else (sRaw groups, 3 components, the
+    // Nikon-type kinds, Hasselblad pairs) the legacy route through differences
+#ifndef RSX_NO_DIRECT
+    if ((g.kind == 0 || g.kind == 1) && !g.raw && !g.las && !g.pair && !g.no_vertical &&
+        g.period == g.n_comp && (g.n_comp == 1 || g.n_comp == 2 || g.n_comp == 4) &&
+        J.explicit_n == 0)
+      S.direct = uint8_t(g.n_comp);
+#endif
     S.raw_limit = g.raw_limit;
     S.rows = g.rows;
     S.row_samples = g.row_samples;
@@ -1985,7 +1849,6 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       K.uncorrected = N.uncorrected ? 1u : 0u;
       K.pentax = N.pentax ? uint32_t(N.range_bits) : 0u;
       K.sony = N.sony ? 1u : 0u;
-      p->any_sony |= N.sony;
       K.seed_offset = N.seed_offset;
       K.table_off = uint32_t(nk_tables.size());
       if (!N.uncorrected)
@@ -2019,22 +1882,35 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     }
     p->nk.push_back(K);
     // single-table streams ignore tab_of_phase; multi-table ones index tabs[]
-    bool multi = J.n_tables > 1;
+    const bool multi = J.n_tables > 1;
     p->any_multi |= multi;
-    p->any_single |= !multi;
-    p->any_single_plain |= !multi && !g.pair;
-    p->any_plain |= !multi && !g.las && !g.pair;
-    p->any_las |= g.las != 0;
     p->any_pair |= g.pair != 0;
-    p->max_tables = std::max(p->max_tables, J.n_tables);
+    if (!g.pair)
+      p->sync_present[multi ? 1 : 0][S.direct] = true;
+    LJpegPlan::Classes& cls = S.direct ? p->fallback : p->legacy;
+    cls.plain |= !multi && !g.las && !g.pair;
+    cls.las |= g.las != 0;
+    cls.pair |= g.pair != 0;
+    cls.multi |= multi;
+    cls.nikon |= g.kind == 2;
+    cls.sony |= g.kind == 2 && J.nikon.sony;
     if (g.kind != 2)
-      p->comp_present[g.period == g.n_comp ? g.n_comp : (g.period == 4 ? 5u : 6u)] = true;
+      cls.comp[g.period == g.n_comp ? g.n_comp : (g.period == 4 ? 5u : 6u)] = true;
+    if (S.direct) {
+      p->any_direct = true;
+      p->direct_present[multi ? 1 : 0][S.direct] = true;
+    } else {
+      p->any_legacy = true;
+      // stream-ordered int16 scratch of the legacy route
+      S.diff_offset = p->total_diffs;
+      p->total_diffs += ((g.pair ? 2 * needed : needed) + 7 + 8) & ~uint64_t(7);
+    }
+    p->max_tables = std::max(p->max_tables, J.n_tables);
     p->job_first_stream[i] = int(p->streams.size());
     p->job_n_streams[i] = 1;
     p->total_blocks += S.n_blocks;
     p->total_subseq += S.n_blocks * LJ_OWN;
     p->total_rows += S.rows;
-    p->total_diffs += ((g.pair ? 2 * needed : needed) + 7 + 8) & ~uint64_t(7);
     p->streams.push_back(S);
   }
   if (!p->streams.empty()) {
@@ -2082,6 +1958,12 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         (st = p->d_diffs.ensure(size_t(p->total_diffs) * 2 + 64)) ||
         (st = p->d_vseed.ensure(size_t(p->total_rows) * 8 + 16)))
       return st;
+    if (p->any_direct &&
+        ((st = p->d_sub_sums.ensure(size_t(p->total_subseq) * 8 + 16)) ||
+         (st = p->d_block_psum.ensure(size_t(p->total_blocks) * 8)) ||
+         (st = p->d_block_pbase.ensure(size_t(p->total_blocks) * 8)) ||
+         (st = p->d_row_edge.ensure(size_t(p->total_rows) * 16 + 16))))
+      return st;
     p->h_results.resize(p->streams.size());
   }
   *out = p.release();
@@ -2093,25 +1975,41 @@ static_assert(sizeof(TabLds) >= sizeof(DeviceHuffTable), "TabLds too small");
 
 namespace {
 
-// everything after synchronisation: scan, decode, reconstruct, consumed
-int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s, hipEvent_t ev_start,
-                hipEvent_t ev_stop) {
-  rsx_ctx* ctx = p->ctx;
+// the legacy route for the streams of class set `c`: decode into differences, tail,
+// seeds + row scans
+void launch_legacy(LJpegPlan* p, const LJpegPlan::Classes& c, const LjArgs& a,
+                   hipStream_t s) {
   const uint32_t n_streams = uint32_t(p->streams.size());
-  if (ev_start)
-    RSX_HIP_CHECK(ctx, hipEventRecord(ev_start, s));
-  launch_decode(p, a, s);
-  if (ev_stop)
-    RSX_HIP_CHECK(ctx, hipEventRecord(ev_stop, s));
+  launch_decode(p, c, a, s);
   hipLaunchKernelGGL(lj_tail_kernel, dim3(n_streams), dim3(64), 0, s, a);
+  mark(p, "lj_tail_kernel");
   ReconLaunch rl;
   rl.n_streams = n_streams;
   rl.total_rows = p->total_rows;
-  std::copy(p->comp_present, p->comp_present + 7, rl.comp_present);
-  rl.any_nikon = p->any_nikon;
-  rl.any_sony = p->any_sony;
+  std::copy(c.comp, c.comp + 7, rl.comp_present);
+  rl.any_nikon = c.nikon;
+  rl.any_sony = c.sony;
   ljpeg_launch_reconstruct(a, rl, s);
+  mark(p, "legacy reconstruction (K5 + K6)");
+}
+
+// everything after synchronisation and the scan: decode, reconstruct, consumed
+int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
+  rsx_ctx* ctx = p->ctx;
+  const uint32_t n_streams = uint32_t(p->streams.size());
+  if (p->any_direct) {
+    DirectLaunch dl;
+    dl.n_streams = n_streams;
+    dl.total_blocks = p->total_blocks;
+    dl.total_rows = p->total_rows;
+    dl.max_tables = p->max_tables;
+    std::memcpy(dl.present, p->direct_present, sizeof dl.present);
+    ljpeg_launch_direct(a, dl, s, p->timer);
+  }
+  if (p->any_legacy)
+    launch_legacy(p, p->legacy, a, s);
   hipLaunchKernelGGL(lj_consumed_kernel, dim3(n_streams), dim3(64), 0, s, a);
+  mark(p, "lj_consumed_kernel");
   RSX_HIP_CHECK(ctx, hipGetLastError());
   return RSX_OK;
 }
@@ -2211,7 +2109,7 @@ int run_dri(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s) {
     p->dri_signature = signature;
   }
   if (p->child)
-    return ljpeg_plan_run(p->child, in_dev, out_dev, s, nullptr, nullptr);
+    return ljpeg_plan_run(p->child, in_dev, out_dev, s, nullptr);
   return RSX_OK;
 }
 
@@ -2283,17 +2181,24 @@ int run_nikon_split(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t
     p->nk_signature = signature;
   }
   if (p->nk_child)
-    return ljpeg_plan_run(p->nk_child, in_dev, out_dev, s, nullptr, nullptr);
+    return ljpeg_plan_run(p->nk_child, in_dev, out_dev, s, nullptr);
   return RSX_OK;
 }
 
 } // namespace
 
 int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
-                   hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                   hipStream_t s, KernelTimer* timer) {
   rsx_ctx* ctx = p->ctx;
   p->last_in = in_dev;
   p->last_out = out_dev;
+  struct TimerScope { // the timer covers this run's own launches only
+    LJpegPlan* p;
+    ~TimerScope() { p->timer = nullptr; }
+  } scope{p};
+  p->timer = timer;
+  if (timer)
+    timer->begin(s);
   if (!p->dri.empty())
     if (int st = run_dri(p, in_dev, out_dev, s))
       return st;
@@ -2311,11 +2216,13 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
   const uint32_t n_streams = uint32_t(p->streams.size());
   hipLaunchKernelGGL(lj_unstuff_kernel, dim3(p->total_blocks), dim3(LJ_T),
                      lj_lds_bytes(0), s, a);
+  mark(p, "lj_unstuff_kernel");
   launch_sync<false>(p, a, s);
   for (int r = 0; r < p->stitch_rounds; ++r)
     launch_sync<true>(p, a, s);
   hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
-  if (int st = launch_tail(p, a, s, ev_start, ev_stop))
+  mark(p, "lj_scan_kernel");
+  if (int st = launch_tail(p, a, s))
     return st;
   if (!p->nk_split.empty())
     return run_nikon_split(p, in_dev, out_dev, s);
@@ -2346,16 +2253,45 @@ int converge(LJpegPlan* p, hipStream_t s) {
         return true;
     return false;
   };
-  if (!unconverged())
-    return RSX_OK;
   const uint32_t n_streams = uint32_t(p->streams.size());
+  // Fused-path streams whose symbols run past the end of their data (damaged or
+  // truncated input): the legacy route knows the reference's end-of-stream
+  // semantics.  Its difference scratch for these streams is set up on first use.
+  auto legacy_fallback = [&]() -> int {
+    bool need = false;
+    for (const LjResult& R : p->h_results)
+      need |= (R.flags & FL_NEED_LEGACY) != 0;
+    if (!need)
+      return RSX_OK;
+    if (!p->legacy_fallback_ready) {
+      for (LjStreamDev& S : p->streams)
+        if (S.direct) {
+          S.diff_offset = p->total_diffs;
+          p->total_diffs += (S.needed + 7 + 8) & ~uint64_t(7);
+        }
+      if (int st = p->d_diffs.ensure(size_t(p->total_diffs) * 2 + 64))
+        return st;
+      RSX_HIP_CHECK(ctx, hipMemcpy(p->d_streams.ptr, p->streams.data(),
+                                   p->streams.size() * sizeof(LjStreamDev),
+                                   hipMemcpyHostToDevice));
+      p->legacy_fallback_ready = true;
+    }
+    const LjArgs a2 = make_args(p, p->last_in, p->last_out);
+    launch_legacy(p, p->fallback, a2, s);
+    hipLaunchKernelGGL(lj_consumed_kernel, dim3(n_streams), dim3(64), 0, s, a2);
+    RSX_HIP_CHECK(ctx, hipGetLastError());
+    return fetch();
+  };
+  if (!unconverged())
+    return legacy_fallback();
   // transfer functions + chain: every workgroup learns its true entry state at
   // once, however badly the stream synchronises; one stitch pass then settles it
   if (int st = p->d_transfer.ensure(size_t(p->total_blocks) * TF_ENTRIES * 2))
     return st;
   const LjArgs a = make_args(p, p->last_in, p->last_out);
   {
-    if (p->any_single_plain)
+    if (p->sync_present[0][0] || p->sync_present[0][1] || p->sync_present[0][2] ||
+        p->sync_present[0][4])
       hipLaunchKernelGGL((lj_transfer_kernel<false>), dim3(p->total_blocks), dim3(64),
                          sizeof(TabLds), s, a);
     if (p->any_pair)
@@ -2392,9 +2328,11 @@ int converge(LJpegPlan* p, hipStream_t s) {
   RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->d_results.ptr, p->h_results.data(),
                                     p->h_results.size() * sizeof(LjResult),
                                     hipMemcpyHostToDevice, s));
-  if (int st = launch_tail(p, a, s, nullptr, nullptr))
+  if (int st = launch_tail(p, a, s))
     return st;
-  return fetch();
+  if (int st = fetch())
+    return st;
+  return legacy_fallback();
 }
 
 } // namespace
@@ -2465,6 +2403,7 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
       if (dri_status[d] == RSX_OK && dri_consumed[d] > p->dri[d].in.geom.in_bytes)
         dri_status[d] = RSX_ERR_IO;
   }
+#ifdef RSX_EXPERIMENT
   if (getenv("RSX_DEBUG")) {
     fprintf(stderr, "[rsx] ljpeg plan: %zu streams, extra stitch rounds %d\n",
             p->streams.size(), p->extra_stitch_rounds);
@@ -2481,6 +2420,7 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
               R.stat_stitch, R.pad2 >> 16, R.pad2 & 0x7FFFu, (R.pad2 & 0x8000u) ? ", stitch" : "");
     }
   }
+#endif
   for (int i = 0; i < p->n_jobs; ++i) {
     int st = p->job_status[i];
     uint32_t consumed = 0;
@@ -2536,9 +2476,10 @@ void ljpeg_plan_destroy(LJpegPlan* p) {
   p->d_marker_list.release();
   for (DeviceBuffer* b :
        {&p->d_streams, &p->d_tables, &p->d_block_stream, &p->d_strips,
-        &p->d_sub_state, &p->d_block_start, &p->d_block_exit, &p->d_block_sum,
-        &p->d_block_base, &p->d_block_drops, &p->d_block_drop_base, &p->d_results,
-        &p->d_diffs, &p->d_vseed, &p->d_unstuffed})
+        &p->d_sub_state, &p->d_sub_sums, &p->d_block_start, &p->d_block_exit,
+        &p->d_block_sum, &p->d_block_base, &p->d_block_psum, &p->d_block_pbase,
+        &p->d_block_drops, &p->d_block_drop_base, &p->d_results, &p->d_diffs, &p->d_vseed,
+        &p->d_row_edge, &p->d_unstuffed})
     b->release();
   delete p;
 }

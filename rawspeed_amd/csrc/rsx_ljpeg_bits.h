@@ -1,0 +1,291 @@
+// rsx_ljpeg_bits.h -- device-side building blocks shared by the kernels of the
+// lossless-JPEG family pipeline (rsx_ljpeg.hip: un-stuffing, synchronisation,
+// legacy decode; rsx_ljpeg_direct.hip: the fused decode + reconstruction):
+// the per-workgroup LDS image of un-stuffed subsequences, the two bit readers,
+// the code-table lookup and the JPEG "EXTEND" of a difference.
+//
+// Symbol semantics: codes/AbstractPrefixCodeDecoder.h:43-76,
+// codes/PrefixCodeLUTDecoder.h:150-216.
+#pragma once
+
+#include "rsx_ljpeg_dev.h"
+
+namespace rsx {
+
+// LDS image of a workgroup.  B is [dword][slot] (dword k of slot j at k*LJ_T+j:
+// lane j always hits bank j%32); the 16-bit records follow.
+struct Lds {
+  uint32_t* B;    // [bw][LJ_T] big-endian dwords of every slot, un-stuffed
+  uint16_t* su;   // [LJ_T] start state each slot was last decoded from
+  uint16_t* st;   // [LJ_T] exit state of each slot
+  uint16_t* cn;   // [LJ_T] symbols that start inside each slot (<= 512)
+  uint16_t* ob;   // [LJ_T] data bits of each slot's own 64 bytes (<= 512)
+  uint16_t* list; // [LJ_T] dense list of slots to re-decode
+  uint32_t* sm;   // [2*LJ_T] per slot: sums of its differences by relative phase
+                  //          (4 x u16; K0 parks its 16 byte-compaction selectors here)
+  uint32_t* misc; // [16]
+  TabLds* tabs;
+};
+
+// Sized to the byte: gfx950 hands out LDS in 1280-byte granules (160 KB / 128) and
+// the synchronisation kernels are latency bound -- their speed is the number of
+// resident workgroups.  So the records are 16-bit and the kernels keep only the
+// dwords of a slot they can touch: the un-stuffer all LJ_BW = 20, the window reader
+// 17 -- a live symbol starts before bit 512, its 32-bit window ends in dword 16 --
+// or 18 for pair symbols (second code <= 16 bits later) and for the register bit
+// reader (which prefetches one dword past its 64-bit buffer).
+constexpr int LJ_BW_SYNC = LJ_PW + 1, LJ_BW_SYNC_PAIR = LJ_PW + 2, LJ_BW_DEC = LJ_PW + 2;
+constexpr size_t lj_lds_words(int bw) {
+  return size_t(bw) * LJ_T + 4 * (LJ_T / 2) + 2 * LJ_T + LJ_T / 2 + 16;
+}
+
+__device__ __forceinline__ Lds carve(uint8_t* smem, int bw = LJ_BW) {
+  Lds l;
+  l.B = reinterpret_cast<uint32_t*>(smem);
+  l.su = reinterpret_cast<uint16_t*>(l.B + bw * LJ_T);
+  l.st = l.su + LJ_T;
+  l.cn = l.st + LJ_T;
+  l.ob = l.cn + LJ_T;
+  l.sm = reinterpret_cast<uint32_t*>(l.ob + LJ_T);
+  l.list = reinterpret_cast<uint16_t*>(l.sm + 2 * LJ_T);
+  l.misc = l.sm + 2 * LJ_T + LJ_T / 2;
+  l.tabs = reinterpret_cast<TabLds*>(l.misc + 16);
+  return l;
+}
+
+constexpr size_t lj_lds_bytes(int n_tables, int bw = LJ_BW) {
+  return lj_lds_words(bw) * 4 + size_t(n_tables) * sizeof(TabLds);
+}
+static_assert(lj_lds_bytes(1, LJ_BW_SYNC) <= 21 * 1280, "six sync workgroups per CU");
+static_assert(lj_lds_words(LJ_BW_SYNC) % 4 == 0 && lj_lds_words(LJ_BW_SYNC_PAIR) % 4 == 0 &&
+                  lj_lds_words(LJ_BW) % 4 == 0,
+              "the tables start on a 16-byte boundary");
+
+__device__ __forceinline__ void lj_stage_tables(const Lds& L, const LjArgs& a,
+                                                const LjStreamDev& S) {
+  const uint4* src = reinterpret_cast<const uint4*>(a.tables + S.table_base);
+  uint4* dst = reinterpret_cast<uint4*>(L.tabs);
+  const int n16 = int(S.n_tables * sizeof(TabLds) / 16);
+  for (int i = threadIdx.x; i < n16; i += int(blockDim.x))
+    dst[i] = src[i];
+}
+
+// End of the data the bit reader hands out before its zero padding.  An MSB32
+// reader consumes whole little-endian words: the bytes of a partial last word are
+// its LOW-order (= last) stream bits, so the data ends at the next word boundary.
+__device__ __forceinline__ uint64_t lj_data_end(const LjStreamDev& S) {
+  return S.pair ? (S.in_bytes + 3) & ~uint64_t(3) : S.in_bytes;
+}
+
+// Load the first BW dword rows of the workgroup's un-stuffed image (K0's output)
+// into LDS, plus ob[].  Ends with a workgroup barrier.
+template <int BW = LJ_BW>
+__device__ __forceinline__ void lj_load_image(const Lds& L, const LjArgs& a, uint32_t b,
+                                              int j) {
+  const uint4* __restrict__ src = a.unstuffed + size_t(b) * LJ_IMG_U4;
+  uint4* dst = reinterpret_cast<uint4*>(L.B);
+  const uint32_t ob = reinterpret_cast<const uint32_t*>(src + (LJ_BW / 4) * LJ_T)[j];
+  // the image is B as it lies in LDS ([dword][slot]); BW * LJ_T / 4 consecutive uint4
+  // are wanted (a register array here ends up in scratch; copy in groups of three)
+  constexpr int n4 = BW * LJ_T / 4;
+  auto want = [&](int i) { return BW == LJ_BW || i < n4; };
+#pragma unroll
+  for (int h = 0; h < LJ_BW / 4; h += 3) {
+    const int i0 = h * LJ_T + j, i1 = i0 + LJ_T, i2 = i1 + LJ_T;
+    uint4 t0 = make_uint4(0, 0, 0, 0), t1 = t0, t2 = t0;
+    if (want(i0))
+      t0 = src[i0];
+    if (h + 1 < LJ_BW / 4 && want(i1))
+      t1 = src[i1];
+    if (h + 2 < LJ_BW / 4 && want(i2))
+      t2 = src[i2];
+    if (want(i0))
+      dst[i0] = t0;
+    if (h + 1 < LJ_BW / 4 && want(i1))
+      dst[i1] = t1;
+    if (h + 2 < LJ_BW / 4 && want(i2))
+      dst[i2] = t2;
+  }
+  L.ob[j] = uint16_t(ob);
+  __syncthreads();
+}
+
+// The 32 stream bits at bit position `pos` of slot `col` (column stride STRIDE).
+template <int STRIDE = LJ_T>
+__device__ __forceinline__ uint32_t lj_window(const uint32_t* B, int col, uint32_t pos) {
+  const uint32_t wi = pos >> 5;
+  const uint32_t d0 = B[wi * STRIDE + col], d1 = B[(wi + 1) * STRIDE + col];
+  return uint32_t((((uint64_t(d0) << 32) | d1) << (pos & 31u)) >> 32);
+}
+
+// Packed symbol entry (the LUT's format): bits 0..4 code length, 5..9 SSSS,
+// 10..15 bits consumed.  0 = invalid code.
+__device__ __noinline__ uint32_t lj_slow_entry(uint32_t w, const TabLds* tb) {
+  // codes longer than the LUT: JPEG Annex F.2.2.3 search
+  for (uint32_t l = LUT_BITS + 1; l <= tb->max_len; ++l) {
+    const uint32_t c = w >> (32 - l);
+    const uint32_t mc = tb->max_code[l];
+    if (mc != NO_CODE && c <= mc) {
+      const uint32_t val = tb->values[(c - tb->val_offset[l]) & 0xFFFFu];
+      const uint32_t ssss = (tb->las && val != 16u) ? (val & 15u) : val;
+      const uint32_t extra = ssss == 16u ? (tb->fix16 ? 16u : 0u)
+                                         : (tb->las ? ssss - (val >> 4) : ssss);
+      return l | (ssss << 5) | ((l + extra) << 10);
+    }
+  }
+  return 0u;
+}
+
+// Entry of the symbol whose first 32 bits are w.  `live` lanes matter; the
+// out-of-line search only runs when some live lane missed the LUT (codes longer
+// than LUT_BITS are rare, and never occur with the short tables real files use),
+// so the common path has no divergent control flow at all.
+__device__ __forceinline__ uint32_t lj_entry(uint32_t w, const TabLds& tb, bool live) {
+  uint32_t e = tb.lut[w >> (32 - LUT_BITS)];
+  if (__builtin_expect(__any(live && (e & 31u) == 0u), 0)) {
+    if (live && (e & 31u) == 0u)
+      e = lj_slow_entry(w, &tb);
+  }
+  return e;
+}
+
+// the same for a single lane reading the table from global memory
+__device__ __forceinline__ uint32_t lj_entry_global(uint32_t w, const TabLds* tb) {
+  uint32_t e = tb->lut[w >> (32 - LUT_BITS)];
+  if ((e & 31u) == 0u)
+    e = lj_slow_entry(w, tb);
+  return e;
+}
+
+// The difference a symbol stands for (JPEG F.2.2.1 "EXTEND"; SSSS = 16 is -32768,
+// AbstractPrefixCodeDecoder.h:55-76), as 16 bits: w = the symbol's window, e its entry.
+__device__ __forceinline__ uint32_t lj_extend(uint32_t w, uint32_t e) {
+  const uint32_t cl = e & 31u, ssss = (e >> 5) & 31u;
+  const uint32_t v = uint32_t((uint64_t(w << cl) << ssss) >> 32);
+  const uint32_t half = (1u << ssss) >> 1;
+  uint32_t diff = v >= half ? v : v + 1u - (1u << ssss);
+  diff = ssss == 16u ? 0x8000u : diff;
+  return diff & 0xFFFFu;
+}
+
+// Per-stream decode parameters held in registers.
+struct DecodeParams {
+  uint32_t period;
+  uint64_t tabmap; // byte p = table slot of phase p
+};
+
+__device__ __forceinline__ DecodeParams lj_params(const LjStreamDev& S) {
+  DecodeParams d;
+  d.period = S.period;
+  uint64_t m = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    m |= uint64_t(S.tab_of_phase[i]) << (8 * i);
+  d.tabmap = m;
+  return d;
+}
+
+// Register bit reader over column `col` of B.  The next 33..64 stream bits sit
+// MSB-first in `buf`; the following dword is already prefetched in `nextw`, so the
+// only LDS access on a symbol's critical path is the code-table lookup.
+template <int BW = LJ_BW>
+struct BitReader {
+  uint64_t buf;
+  uint32_t nb;    // valid bits in buf (33..64 between symbols)
+  uint32_t wi;    // dword index of nextw
+  uint32_t nextw;
+
+  __device__ __forceinline__ void open(const uint32_t* B, int col, uint32_t pos) {
+    const uint32_t i = pos >> 5, sh = pos & 31u;
+    const uint32_t d0 = B[i * LJ_T + col], d1 = B[(i + 1) * LJ_T + col];
+    buf = ((uint64_t(d0) << 32) | d1) << sh;
+    nb = 64u - sh;
+    wi = i + 2;
+    nextw = B[wi * LJ_T + col];
+  }
+  // consume `len` bits (0 for a lane that must not advance) and top the buffer up
+  __device__ __forceinline__ void advance(const uint32_t* B, int col, uint32_t len) {
+    buf <<= len;
+    nb -= len;
+    const bool need = nb <= 32u;
+    const uint64_t add = uint64_t(nextw) << ((32u - nb) & 31u);
+    buf |= need ? add : 0ull;
+    nb += need ? 32u : 0u;
+    wi += need ? 1u : 0u;
+    // past the slot's dwords there is nothing to read (a stopped lane may sit
+    // there, and the bits a live symbol can still need end in dword LJ_PW);
+    // clamp instead of branching
+    const uint32_t w2 = wi < uint32_t(BW) ? wi : uint32_t(BW - 1);
+    nextw = B[w2 * LJ_T + col];
+  }
+  __device__ __forceinline__ uint32_t head() const { return uint32_t(buf >> 32); }
+};
+
+template <bool MULTI>
+__device__ __forceinline__ const TabLds& lj_table(const Lds& L, const DecodeParams& dp,
+                                                  uint32_t phase) {
+  return L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
+}
+
+// ---- packed 16-bit arithmetic (predictors wrap mod 2^16) ---------------------
+typedef unsigned short rsx_u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_add(uint32_t x, uint32_t y) {
+  const rsx_u16x2 r = __builtin_bit_cast(rsx_u16x2, x) + __builtin_bit_cast(rsx_u16x2, y);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t x, uint32_t y) {
+  const rsx_u16x2 r = __builtin_bit_cast(rsx_u16x2, x) - __builtin_bit_cast(rsx_u16x2, y);
+  return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint2 pk_add2(uint2 x, uint2 y) {
+  return make_uint2(pk_add(x.x, y.x), pk_add(x.y, y.y));
+}
+__device__ __forceinline__ uint2 pk_sub2(uint2 x, uint2 y) {
+  return make_uint2(pk_sub(x.x, y.x), pk_sub(x.y, y.y));
+}
+
+// Four 16-bit fields q = 0..3 (x: q0 | q1 << 16, y: q2 | q3 << 16), of which the
+// first N are in use.  Rotation: out[c] = in[(c - f) mod N], i.e. field q moves to
+// q + f.  Sums kept by RELATIVE phase (k mod N for the k-th symbol of a run whose
+// first symbol has absolute index `first`) become sums by absolute phase with
+// f = first mod N; f = N - (first mod N) undoes it.
+template <int N>
+__device__ __forceinline__ uint2 lj_rot_fields(uint2 v, uint32_t f) {
+  if (N == 1)
+    return v;
+  if (N == 2) {
+    const uint32_t x = (f & 1u) ? __builtin_amdgcn_alignbit(v.x, v.x, 16) : v.x;
+    return make_uint2(x, 0u);
+  }
+  const uint64_t w = uint64_t(v.x) | (uint64_t(v.y) << 32);
+  const uint32_t sh = 16u * (f & 3u);
+  const uint64_t r = sh ? ((w << sh) | (w >> (64u - sh))) : w;
+  return make_uint2(uint32_t(r), uint32_t(r >> 32));
+}
+
+// Accumulator of differences by relative phase (N = 1, 2 or 4 components).
+template <int N>
+struct PhaseSums {
+  uint32_t a0 = 0, a1 = 0;
+  uint32_t ph = 0; // 16 * (symbols so far mod N)
+  __device__ __forceinline__ void add(uint32_t d16, bool live) {
+    const uint32_t d = live ? d16 : 0u;
+    if (N == 1) {
+      a0 += d;
+    } else if (N == 2) {
+      a0 = pk_add(a0, d << ph);
+      ph = live ? ph ^ 16u : ph;
+    } else {
+      const uint32_t t = d << (ph & 16u);
+      a0 = pk_add(a0, (ph & 32u) ? 0u : t);
+      a1 = pk_add(a1, (ph & 32u) ? t : 0u);
+      ph = live ? (ph + 16u) & 63u : ph;
+    }
+  }
+  __device__ __forceinline__ uint2 get() const {
+    return make_uint2(N == 1 ? (a0 & 0xFFFFu) : a0, N == 4 ? a1 : 0u);
+  }
+};
+
+} // namespace rsx

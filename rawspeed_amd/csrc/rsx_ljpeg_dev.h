@@ -1,7 +1,12 @@
 // rsx_ljpeg_dev.h -- constants and device-visible structures shared by the
 // translation units of the lossless-JPEG family pipeline:
-//   rsx_ljpeg.hip        entropy decode (K0-K4, tail, fallback) + the host plan
-//   rsx_ljpeg_recon.hip  reconstruction (K5 seeds, K6 row scans, Nikon / Pentax)
+//   rsx_ljpeg.hip         un-stuffing, synchronisation, scans, the host plan; the legacy
+//                         decode into int16 differences (K4, tail) for the stream kinds
+//                         the fused path does not cover
+//   rsx_ljpeg_direct.hip  fused decode + predictor reconstruction (row edges, row
+//                         offsets, decode straight into the image)
+//   rsx_ljpeg_recon.hip   legacy reconstruction from differences (K5 seeds, K6 row
+//                         scans) and the Nikon / Pentax / Sony kernels
 #pragma once
 
 #include "rsx_internal.h"
@@ -31,20 +36,6 @@ constexpr int LJ_IMG_U4 = (LJ_BW + 1) * LJ_T / 4; // per-workgroup un-stuffed im
 #endif
 constexpr uint32_t LJ_WARM = RSX_LJ_WARM;     // warm-up bits decoded ahead of a slot for its start guess
 
-// Bit reader of the decode loops.  1: every symbol fetches its 32-bit window from
-// the slot's two LDS dwords (17 VALU instructions per symbol instead of 27, but
-// two dependent LDS round trips); 0: a 64-bit register buffer with the next dword
-// prefetched (LDS off the critical path).  Measured (PMC + A/B):
-// the synchronisation passes are VALU-issue bound and gain 4 % from the window
-// form; K4, whose time goes mostly to its scattered 16-byte stores and its
-// staging prologue, is 8 % faster with the register buffer.
-#ifndef RSX_LJ_WINDOW
-#define RSX_LJ_WINDOW 1
-#endif
-#ifndef RSX_LJ_K4_WINDOW
-#define RSX_LJ_K4_WINDOW 0
-#endif
-
 constexpr uint32_t ST_OFF_MASK = 63u;
 constexpr uint32_t ST_PHASE_SHIFT = 6;
 constexpr uint32_t ST_ERR = 1u << 9;
@@ -54,6 +45,10 @@ constexpr uint32_t NO_CODE = 0xFFFFFFFFu;
 
 // flags in LjResult::flags
 constexpr uint32_t FL_UNCONVERGED = 1u;
+// a stream of the fused path whose symbols run past the end of its data (damaged or
+// truncated input): it is redone by the legacy kernels, which know the reference's
+// end-of-stream semantics (lj_tail_kernel)
+constexpr uint32_t FL_NEED_LEGACY = 2u;
 
 struct TabLds {
   uint16_t lut[LUT_SIZE];
@@ -102,7 +97,9 @@ struct LjStreamDev {
   uint8_t pair;        // HasselbladDecompressor: a symbol is [code1][code2][bits1][bits2]
                        // (2 differences); the stream is MSB32 (LE 32-bit words, MSB first)
   uint8_t no_vertical; // every stream row starts from init_pred (no seed chain)
-  uint8_t pad8[3];
+  uint8_t direct;      // != 0: fused decode + reconstruction (rsx_ljpeg_direct.hip); the
+                       //       value is the number of interleaved components (1, 2 or 4)
+  uint8_t pad8[2];
   uint32_t rows;
   uint32_t row_samples;
   uint32_t first_row; // global stream-row index
@@ -158,20 +155,27 @@ struct LjArgs {
   const TabLds* tables;
   const uint32_t* block_stream;
   const Cr2Strip* strips;
-  uint32_t* sub_state;
+  uint32_t* sub_state;       // per subsequence: exit state | symbols << 16
+  uint2* sub_sums;           // per subsequence: sums of its differences by relative phase
   uint32_t* block_start;
   uint32_t* block_exit;
   uint32_t* block_sum;
   uint32_t* block_base;
+  uint2* block_psum;         // per workgroup: sums of its differences, phases relative to
+                             // its first symbol
+  uint2* block_pbase;        // per workgroup: running sums P (absolute components) before
+                             // its first symbol
+  uint4* row_edge;           // per stream row: P before its first symbol (x, y) and at its
+                             // first MCU (z, w)
   uint32_t* block_drops;     // stuffing bytes dropped inside each workgroup's region
   uint32_t* block_drop_base; // exclusive prefix of block_drops within the stream
   uint4* unstuffed;          // per workgroup: its LDS image of un-stuffed slots (LJ_BW*LJ_T dwords)
   LjResult* results;
   int16_t* diffs;
-  uint16_t* vseed;
+  uint16_t* vseed;           // per stream row, 4 x u16: predictor seeds (legacy path) /
+                             // row offsets O(r, c) (fused path)
   uint32_t n_streams;
   uint32_t total_rows;
-  uint32_t ablate; // profiling aid (RSX_ABLATE): 1 = no K4 stores, 2 = no K4 decode loop, 4 = no K1 decode, 16 = no K1 warm-up, 32 = no K1 Jacobi rounds; 128 = collect the stat_* counters (RSX_DEBUG)
   // NikonDecompressor streams
   const NkStreamDev* nk;
   const uint32_t* nk_tables; // dither tables: base | delta << 16 per 15-bit value
@@ -193,5 +197,28 @@ struct ReconLaunch {
 
 // K5 + K6 (and their Nikon / Pentax counterparts) on `stream`
 void ljpeg_launch_reconstruct(const LjArgs& a, const ReconLaunch& r, hipStream_t stream);
+
+// optional per-kernel timing of a plan run: an event after every launch
+struct KernelTimer {
+  static constexpr int MAX = 48;
+  hipEvent_t ev[MAX + 1] = {};
+  const char* name[MAX] = {};
+  int n = 0;       // launches recorded in this run
+  int created = 0; // events created so far
+  hipStream_t stream = nullptr;
+  void begin(hipStream_t s);
+  void mark(const char* kernel); // the launch just issued
+};
+
+// what the fused decode launch needs to know about the plan
+struct DirectLaunch {
+  uint32_t n_streams = 0;
+  uint32_t total_blocks = 0;
+  uint32_t total_rows = 0;
+  int max_tables = 1;
+  bool present[2][5] = {}; // [several tables][components]
+};
+void ljpeg_launch_direct(const LjArgs& a, const DirectLaunch& d, hipStream_t stream,
+                         KernelTimer* timer);
 
 } // namespace rsx

@@ -1,0 +1,594 @@
+// rsx_ljpeg_direct.hip -- fused decode + predictor reconstruction for LJPEG / CR2
+// streams with 1, 2 or 4 interleaved components: the final decode writes pixels
+// straight into the image; there is no difference scratch and no second pass.
+//
+// Replaces the inner loops of
+//   LJpegDecompressor::decodeRowN  (decompressors/LJpegDecompressor.cpp:184-251, 326-332)
+//   Cr2Decompressor::decompressN_X_Y  (decompressors/Cr2DecompressorImpl.h:431-465)
+// for these shapes.  Arithmetic (model in tests/test_direct_recon_model.py;
+// everything mod 2^16): with N components, row length RS and D the differences in
+// stream order,
+//   X[r][s] = (s >= N ? X[r][s-N] : (r ? X[r-1][s] : init[s])) + D[r][s].
+// Let P(i) be the running sum over the WHOLE stream of the differences of i's
+// component (no reset at row starts).  Then X(i) = P(i) + O(row(i), comp(i)) with
+//   E(r, c) = P just before the row's first symbol,   F(r, c) = P at its c-th symbol,
+//   V(r, c) = sum_{r' < r} (F(r', c) - E(r', c))        (the vertical chain),
+//   O(r, c) = init[c] + V(r, c) - E(r, c).
+// The synchronisation kernels (rsx_ljpeg.hip) have left the sums of every
+// subsequence's differences (by relative phase) and lj_scan_kernel P before every
+// workgroup, so:
+//   K5a lj_rowedge  E and F of every stream row: the workgroups that hold a row
+//                   start walk from the start of its subsequence to it
+//   K5b lj_rowoff   O: one scan over the rows of each stream
+//   K4d lj_decode_direct  final decode from validated start states; every lane turns
+//                   the differences of its subsequence into pixels (running packed
+//                   16-bit sums from its own P, plus O of the row) and stores them
+//                   through the output mapping (tile crop, discarded MCUs, 2x2 MCUs,
+//                   CR2 strips)
+// Damaged streams (symbols past the end of the data) are flagged by lj_scan_kernel
+// and take the legacy route instead.
+#include "rsx_ljpeg_bits.h"
+
+namespace rsx {
+
+namespace {
+
+// inclusive scan of x over the wavefront
+__device__ __forceinline__ uint32_t wave_scan(uint32_t x, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o, 64);
+    if (lane >= o)
+      x += y;
+  }
+  return x;
+}
+__device__ __forceinline__ uint2 wave_scan_pk(uint2 x, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint2 y = make_uint2(__shfl_up(x.x, o, 64), __shfl_up(x.y, o, 64));
+    if (lane >= o)
+      x = pk_add2(x, y);
+  }
+  return x;
+}
+
+// Per-lane records of a workgroup and their scans: the symbols before the lane's
+// slot (inside the workgroup) and P before it by phases relative to the
+// workgroup's first symbol.  scratch: 16 dwords of LDS.  Two barriers.
+template <int N>
+__device__ __forceinline__ void lj_lane_prefix(const LjArgs& a, uint32_t gsub, int j,
+                                               uint32_t* scratch, uint32_t& my_rec,
+                                               uint32_t& before, uint2& pex) {
+  const int lane = j & 63, wv = j >> 6;
+  my_rec = j >= 1 ? a.sub_state[gsub] : 0u;
+  const uint2 my_sums = j >= 1 ? a.sub_sums[gsub] : make_uint2(0u, 0u);
+  const uint32_t my_count = my_rec >> 16;
+  const uint32_t incl = wave_scan(my_count, lane);
+  if (lane == 63)
+    scratch[wv] = incl;
+  __syncthreads();
+  before = incl - my_count;
+  for (int w = 0; w < wv; ++w)
+    before += scratch[w];
+  const uint2 r = lj_rot_fields<N>(my_sums, before & uint32_t(N - 1));
+  const uint2 pincl = wave_scan_pk(r, lane);
+  if (lane == 63) {
+    scratch[4 + 2 * wv] = pincl.x;
+    scratch[5 + 2 * wv] = pincl.y;
+  }
+  __syncthreads();
+  pex = pk_sub2(pincl, r);
+  for (int w = 0; w < wv; ++w)
+    pex = pk_add2(pex, make_uint2(scratch[4 + 2 * w], scratch[5 + 2 * w]));
+}
+
+// ---------------------------------------------------------------------------
+// K5a: row edges.  One workgroup per workgroup of the entropy stream; those whose
+// symbol range holds no row start leave at once (most of them: a workgroup covers
+// ~16 K symbols).  Lane k takes the k-th row start of the range: it finds the
+// subsequence the symbol lies in, walks there from the subsequence's first symbol
+// (reading the un-stuffed image and the code table from global memory: the walks
+// are few and independent) and then over the row's first MCU.
+// ---------------------------------------------------------------------------
+struct GlobalCursor {
+  const uint32_t* B; // image of the current workgroup
+  uint32_t b, slot, pos, ob, last_block;
+};
+
+__device__ __forceinline__ void gc_open(GlobalCursor& c, const LjArgs& a, uint32_t b,
+                                        uint32_t slot, uint32_t pos, uint32_t last_block) {
+  c.b = b;
+  c.slot = slot;
+  c.pos = pos;
+  c.last_block = last_block;
+  c.B = reinterpret_cast<const uint32_t*>(a.unstuffed + size_t(b) * LJ_IMG_U4);
+  c.ob = c.B[LJ_BW * LJ_T + slot];
+}
+
+// move to the subsequence the position belongs to (a symbol belongs to the
+// subsequence it starts in); false = ran off the end of the stream
+__device__ __forceinline__ bool gc_normalise(GlobalCursor& c, const LjArgs& a) {
+  while (c.pos >= c.ob) {
+    c.pos -= c.ob;
+    if (++c.slot == uint32_t(LJ_T)) {
+      if (c.b == c.last_block)
+        return false;
+      ++c.b;
+      c.slot = 1;
+      c.B = reinterpret_cast<const uint32_t*>(a.unstuffed + size_t(c.b) * LJ_IMG_U4);
+    }
+    c.ob = c.B[LJ_BW * LJ_T + c.slot];
+  }
+  return true;
+}
+
+template <int N>
+__global__ __launch_bounds__(LJ_T) void lj_rowedge_kernel(LjArgs a) {
+  __shared__ uint32_t s_first[LJ_T];
+  __shared__ uint2 s_pex[LJ_T];
+  __shared__ uint32_t scratch[16];
+  const uint32_t b = blockIdx.x;
+  const uint32_t s = a.block_stream[b];
+  const LjStreamDev& S = a.streams[s];
+  if (int(S.direct) != N || (a.results[s].flags & FL_NEED_LEGACY))
+    return;
+  const uint32_t base = a.block_base[b], sum = a.block_sum[b];
+  const uint64_t needed = S.needed;
+  if (sum == 0 || base >= needed)
+    return;
+  const uint32_t RS = S.row_samples;
+  const uint64_t hi = (uint64_t(base) + sum < needed) ? uint64_t(base) + sum : needed;
+  const uint32_t r0 = uint32_t((uint64_t(base) + RS - 1) / RS); // first row that starts at or after `base`
+  if (uint64_t(r0) * RS >= hi)
+    return; // no row starts inside this workgroup's symbols
+  const uint32_t r1 = uint32_t((hi - 1) / RS);
+  const uint32_t n_here = r1 - r0 + 1;
+  const uint32_t lb = b - S.first_block;
+  const int j = threadIdx.x;
+  const uint32_t g0 = S.first_subseq + lb * LJ_OWN; // record of slot 1
+  uint32_t my_rec, before;
+  uint2 pex;
+  lj_lane_prefix<N>(a, g0 + uint32_t(j - 1), j, scratch, my_rec, before, pex);
+  s_first[j] = before;
+  s_pex[j] = pex;
+  __syncthreads();
+  const uint2 pbase = a.block_pbase[b];
+  const TabLds* tabs = a.tables + S.table_base;
+  const bool multi = S.n_tables > 1;
+  const uint32_t last_block = S.first_block + S.n_blocks - 1;
+  for (uint32_t k = j; k < n_here; k += LJ_T) {
+    const uint32_t r = r0 + k;
+    const uint32_t tl = r * RS - base; // workgroup-relative index of the row's first symbol
+    // the last slot whose first symbol is at or before tl
+    uint32_t lo = 1, hq = LJ_T - 1;
+    while (lo < hq) {
+      const uint32_t mid = (lo + hq + 1) >> 1;
+      if (s_first[mid] <= tl)
+        lo = mid;
+      else
+        hq = mid - 1;
+    }
+    const uint32_t q = lo;
+    uint32_t skip = tl - s_first[q];
+    // P before the slot's first symbol, by absolute component
+    uint2 P = pk_add2(pbase, lj_rot_fields<N>(s_pex[q], base & uint32_t(N - 1)));
+    const uint32_t st0 = q == 1 ? a.block_start[b] : (a.sub_state[g0 + q - 2] & ST_MASK);
+    uint32_t idx = base + s_first[q]; // absolute index of the next symbol
+    GlobalCursor c;
+    gc_open(c, a, b, q, st0 & ST_OFF_MASK, last_block);
+    bool ok = !(st0 & ST_ERR);
+    uint2 E = make_uint2(0, 0), F = make_uint2(0, 0);
+    // `skip` symbols up to the row start, then the N symbols of its first MCU
+    for (uint32_t n = 0; ok && n < skip + uint32_t(N); ++n) {
+      if (n == skip)
+        E = P;
+      if (!gc_normalise(c, a)) {
+        ok = false;
+        break;
+      }
+      const uint32_t ph = idx & uint32_t(N - 1);
+      const uint32_t w = lj_window(c.B, int(c.slot), c.pos);
+      const uint32_t e = lj_entry_global(w, tabs + (multi ? S.tab_of_phase[ph] : 0));
+      if (e == 0u) {
+        ok = false;
+        break;
+      }
+      const uint32_t d = lj_extend(w, e);
+      const uint32_t t = d << (16u * (ph & 1u));
+      P = (ph & 2u) ? make_uint2(P.x, pk_add(P.y, t)) : make_uint2(pk_add(P.x, t), P.y);
+      c.pos += e >> 10;
+      ++idx;
+    }
+    F = P;
+    // (a stream in error never shows its pixels: the values do not matter then)
+    a.row_edge[uint64_t(S.first_row) + r] = make_uint4(E.x, E.y, F.x, F.y);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K5b: row offsets O(r, c) = init[c] + V(r, c) - E(r, c), V = exclusive scan over
+// the rows of F - E.  One workgroup per stream.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(VS_T) void lj_rowoff_kernel(LjArgs a) {
+  __shared__ uint2 wtot[VS_T / 64];
+  __shared__ uint2 carry_s;
+  const uint32_t s = blockIdx.x;
+  const LjStreamDev& S = a.streams[s];
+  if (!S.direct || (a.results[s].flags & FL_NEED_LEGACY))
+    return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // only the rows that are decoded have edges
+  const uint64_t last_sym = S.needed ? S.needed - 1 : 0;
+  const uint32_t rows = S.needed ? uint32_t(last_sym / S.row_samples) + 1 : 0u;
+  const uint2 init = make_uint2(uint32_t(S.init_pred[0]) | (uint32_t(S.init_pred[1]) << 16),
+                                uint32_t(S.init_pred[2]) | (uint32_t(S.init_pred[3]) << 16));
+  const uint4* __restrict__ RE = a.row_edge + S.first_row;
+  uint2* __restrict__ O = reinterpret_cast<uint2*>(a.vseed) + S.first_row;
+  if (tid == 0)
+    carry_s = make_uint2(0, 0);
+  __syncthreads();
+  for (uint32_t rb = 0; rb < rows; rb += VS_T) {
+    const uint32_t r = rb + tid;
+    uint4 ef = make_uint4(0, 0, 0, 0);
+    if (r < rows)
+      ef = RE[r];
+    const uint2 E = make_uint2(ef.x, ef.y), F = make_uint2(ef.z, ef.w);
+    const uint2 d = pk_sub2(F, E);
+    const uint2 incl = wave_scan_pk(d, lane);
+    if (lane == 63)
+      wtot[wv] = incl;
+    __syncthreads();
+    uint2 v = pk_add2(carry_s, pk_sub2(incl, d));
+    for (int w = 0; w < wv; ++w)
+      v = pk_add2(v, wtot[w]);
+    if (r < rows)
+      O[r] = pk_sub2(pk_add2(init, v), E);
+    __syncthreads();
+    if (tid == VS_T - 1)
+      carry_s = pk_add2(v, d);
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// K4d: final decode straight into the image
+// ---------------------------------------------------------------------------
+// where the next sample of a lane goes: the current run of samples that are stored
+// contiguously (or all discarded) and the row's offsets
+struct OutCursor {
+  uint16_t* p;       // address of the next sample (nullptr: the run is discarded)
+  uint32_t left;     // samples left in the run (0: no contiguous run -- per-sample path)
+  uint32_t r, sidx;  // stream row and sample index inside it
+  uint2 off;         // O(r, .) by the lane's relative phases
+};
+
+__device__ __forceinline__ void strip_divmod32(uint64_t off, uint32_t w, uint32_t* row,
+                                               uint32_t* col) {
+  if ((off >> 32) == 0) {
+    const uint32_t o = uint32_t(off), q = o / w;
+    *row = q;
+    *col = o - q * w;
+  } else {
+    *row = uint32_t(off / w);
+    *col = uint32_t(off % w);
+  }
+}
+
+// one sample through the general output mapping (decodeRowN :200-250 / CR2 strips)
+__device__ __forceinline__ void lj_put_sample(const LjArgs& a, const LjStreamDev& S,
+                                              uint32_t r, uint32_t sidx, uint16_t val) {
+  uint8_t* img = a.out_base + S.img_offset;
+  if (S.kind == 0) {
+    const uint32_t m = sidx / S.n_comp, c = sidx - m * S.n_comp;
+    const uint32_t col = S.mcu_w * m + (c % S.mcu_w);
+    if (col >= S.keep_samples)
+      return;
+    const uint32_t row = S.out_y + S.mcu_h * r + c / S.mcu_w;
+    reinterpret_cast<uint16_t*>(img + uint64_t(row) * S.img_pitch)[S.out_x + col] = val;
+  } else {
+    const uint64_t k = uint64_t(r) * S.row_samples + sidx;
+    const Cr2Strip* st = a.strips + S.strip_base;
+    uint32_t q = 0;
+    while (q + 1 < S.n_strips && k >= st[q + 1].first_sample)
+      ++q;
+    uint32_t srow, scol;
+    strip_divmod32(k - st[q].first_sample, st[q].w, &srow, &scol);
+    reinterpret_cast<uint16_t*>(img + uint64_t(st[q].y0 + srow) * S.img_pitch)[st[q].x0 + scol] =
+        val;
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void lj_locate(const LjArgs& a, const LjStreamDev& S, uint32_t i,
+                                          uint32_t rot, OutCursor& c) {
+  const uint32_t RS = S.row_samples;
+  const uint32_t r = i / RS, sidx = i - r * RS;
+  c.r = r;
+  c.sidx = sidx;
+  c.off = lj_rot_fields<N>(reinterpret_cast<const uint2*>(a.vseed)[uint64_t(S.first_row) + r],
+                           rot);
+  uint8_t* img = a.out_base + S.img_offset;
+  c.p = nullptr;
+  c.left = 0;
+  if (S.kind == 0) {
+    if (S.mcu_h == 1) { // sample s of a stream row = output column s
+      if (sidx < S.keep_samples) {
+        c.left = (S.keep_samples < RS ? S.keep_samples : RS) - sidx;
+        c.p = reinterpret_cast<uint16_t*>(img + uint64_t(S.out_y + r) * S.img_pitch) + S.out_x +
+              sidx;
+      } else {
+        c.left = RS - sidx; // trailing MCUs of the frame that the tile does not keep
+      }
+    }
+  } else {
+    const Cr2Strip* st = a.strips + S.strip_base;
+    uint32_t z = 0;
+    while (z + 1 < S.n_strips && uint64_t(i) >= st[z + 1].first_sample)
+      ++z;
+    uint32_t srow, col;
+    strip_divmod32(uint64_t(i) - st[z].first_sample, st[z].w, &srow, &col);
+    const uint32_t in_strip = st[z].w - col, in_row = RS - sidx;
+    c.left = in_strip < in_row ? in_strip : in_row;
+    c.p = reinterpret_cast<uint16_t*>(img + uint64_t(st[z].y0 + srow) * S.img_pitch) + st[z].x0 +
+          col;
+  }
+}
+
+#ifndef RSX_K4D_BURST
+#define RSX_K4D_BURST 4
+#endif
+constexpr int K4D_BURST = RSX_K4D_BURST; // groups of 8 samples decoded before their stores
+
+constexpr size_t k4d_lds_bytes(int n_tables) {
+  return size_t(LJ_BW_DEC) * LJ_T * 4 + 16 * 4 + size_t(n_tables) * sizeof(TabLds);
+}
+
+template <bool MULTI, int N>
+__global__ __launch_bounds__(LJ_T) void lj_decode_direct_kernel(LjArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const uint32_t b = blockIdx.x;
+  const uint32_t s = a.block_stream[b];
+  const LjStreamDev& S = a.streams[s];
+  if ((S.n_tables > 1) != MULTI || int(S.direct) != N)
+    return;
+  if (a.results[s].flags & FL_NEED_LEGACY)
+    return;
+  Lds L{};
+  L.B = reinterpret_cast<uint32_t*>(smem);
+  L.misc = L.B + LJ_BW_DEC * LJ_T;
+  L.tabs = reinterpret_cast<TabLds*>(L.misc + 16);
+  const uint32_t lb = b - S.first_block;
+  const int j = threadIdx.x;
+  const uint64_t needed = S.needed;
+  const uint32_t base = a.block_base[b];
+  const uint32_t sum = a.block_sum[b];
+  if (base >= needed || sum == 0)
+    return; // nothing of this workgroup is delivered
+  uint64_t M = a.results[s].marker_pos;
+  if (M > lj_data_end(S))
+    M = lj_data_end(S);
+  if (uint64_t(lb) * LJ_R > M)
+    return; // past the end of data
+
+  lj_stage_tables(L, a, S);
+  // the image (no ob[] here: the records say how many symbols a slot holds)
+  {
+    const uint4* __restrict__ src = a.unstuffed + size_t(b) * LJ_IMG_U4;
+    uint4* dst = reinterpret_cast<uint4*>(L.B);
+    constexpr int n4 = LJ_BW_DEC * LJ_T / 4;
+#pragma unroll
+    for (int h = 0; h < (n4 + LJ_T - 1) / LJ_T; ++h) {
+      const int i = h * LJ_T + j;
+      if (i < n4)
+        dst[i] = src[i];
+    }
+  }
+  const DecodeParams dp = lj_params(S);
+  const uint32_t g0 = S.first_subseq + lb * LJ_OWN;
+  const uint32_t gsub = g0 + uint32_t(j - 1);
+  uint32_t my_rec, before;
+  uint2 pex;
+  lj_lane_prefix<N>(a, gsub, j, L.misc, my_rec, before, pex); // barriers: image + tables complete
+  const uint32_t my_count = my_rec >> 16, my_exit = my_rec & ST_MASK;
+  uint32_t my_start = 0;
+  if (j >= 1)
+    my_start = (j == 1) ? a.block_start[b] : (a.sub_state[gsub - 1] & ST_MASK);
+  const uint64_t first = uint64_t(base) + before; // first symbol of this lane
+
+  // a bad Huffman code inside the delivered range is a real error
+  // (PrefixCodeLookupDecoder.h:152-155)
+  if (j >= 1 && (my_exit & ST_ERR) && first + my_count < needed &&
+      int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P < int64_t(M))
+    atomicCAS(&a.results[s].status, 0u, uint32_t(RSX_ERR_BAD_HUFFMAN_CODE));
+
+  uint32_t remaining = (my_start & ST_ERR) ? 0u : my_count;
+  if (first >= needed)
+    remaining = 0;
+  else if (first + remaining > needed)
+    remaining = uint32_t(needed - first);
+
+  uint32_t wmax = remaining;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    wmax = max(wmax, uint32_t(__shfl_xor(wmax, o, 64)));
+  const uint32_t n_groups = (wmax + 7) >> 3;
+
+  // P before the lane's first symbol by absolute component, then by the lane's own
+  // relative phases (the k-th symbol of the lane has phase k mod N: groups of 8
+  // keep that alignment)
+  const uint32_t i0 = uint32_t(first);
+  const uint32_t rot = (0u - i0) & uint32_t(N - 1);
+  const uint2 p_abs =
+      pk_add2(a.block_pbase[b], lj_rot_fields<N>(pex, base & uint32_t(N - 1)));
+  uint2 run = lj_rot_fields<N>(p_abs, rot);
+  if (N == 1)
+    run.x = (run.x & 0xFFFFu) * 0x10001u; // both halves carry the one running sum
+  OutCursor oc{};
+  if (remaining)
+    lj_locate<N>(a, S, i0, rot, oc);
+  uint32_t i = i0; // index of the next sample to be stored
+
+  uint32_t phase = (my_start >> ST_PHASE_SHIFT) & 7u;
+  BitReader<LJ_BW_DEC> r;
+  r.open(L.B, j, my_start & ST_OFF_MASK);
+  auto decode_group = [&](uint32_t g, uint32_t (&p)[4]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const bool live = 8 * g + q < remaining;
+      const uint32_t w = r.head();
+      const uint32_t e = lj_entry(w, lj_table<MULTI>(L, dp, phase), live);
+      r.advance(L.B, j, live ? (e >> 10) : 0u);
+      if (MULTI)
+        phase = live ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
+      const uint32_t diff = live ? lj_extend(w, e) : 0u;
+      if (q & 1)
+        p[q >> 1] |= diff << 16;
+      else
+        p[q >> 1] = diff;
+    }
+    // differences -> running sums P (packed; dword k holds samples 2k, 2k+1)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (N == 1) {
+        // (d0, d1) -> (run + d0, run + d0 + d1)
+        const uint32_t t = pk_add(p[k], p[k] << 16);
+        p[k] = pk_add(t, run.x);
+        run.x = (p[k] >> 16) * 0x10001u;
+      } else if (N == 2) {
+        run.x = pk_add(run.x, p[k]);
+        p[k] = run.x;
+      } else if (k & 1) {
+        run.y = pk_add(run.y, p[k]);
+        p[k] = run.y;
+      } else {
+        run.x = pk_add(run.x, p[k]);
+        p[k] = run.x;
+      }
+    }
+  };
+  // store the `cnt` samples of a group (running sums in p) that start at sample i
+  auto store_group = [&](const uint32_t (&p)[4], uint32_t cnt) {
+    if (cnt <= oc.left) {
+      // the whole group lies inside the current run
+      if (oc.p) {
+        const uint32_t o0 = N == 1 ? (oc.off.x & 0xFFFFu) * 0x10001u : oc.off.x;
+        const uint32_t o1 = N == 4 ? oc.off.y : o0;
+        const uint4 v = make_uint4(pk_add(p[0], o0), pk_add(p[1], o1), pk_add(p[2], o0),
+                                   pk_add(p[3], o1));
+        if (cnt == 8) {
+          __builtin_memcpy(oc.p, &v, 16);
+        } else {
+          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int t = 0; t < 7; ++t)
+            if (uint32_t(t) < cnt)
+              oc.p[t] = uint16_t(w[t >> 1] >> (16 * (t & 1)));
+        }
+        oc.p += cnt;
+      }
+      oc.left -= cnt;
+      oc.sidx += cnt;
+      i += cnt;
+      if (oc.left == 0 && cnt == 8)
+        lj_locate<N>(a, S, i, rot, oc); // (a partial group is the lane's last)
+    } else {
+      // the group crosses the end of a run (row end, kept width, strip) or the
+      // mapping has no contiguous runs (2x2 MCUs): sample by sample
+      const uint2* O = reinterpret_cast<const uint2*>(a.vseed) + S.first_row;
+      const uint32_t RS = S.row_samples;
+      uint32_t rr = oc.r, ss = oc.sidx;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (uint32_t(t) < cnt) {
+          const uint32_t pv = (p[t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
+          const uint32_t c = (i + uint32_t(t)) & uint32_t(N - 1);
+          const uint2 o = O[rr];
+          const uint32_t ov = ((c & 2u) ? o.y : o.x) >> (16u * (c & 1u));
+          lj_put_sample(a, S, rr, ss, uint16_t(pv + ov));
+          if (++ss == RS) {
+            ss = 0;
+            ++rr;
+          }
+        }
+      }
+      i += cnt;
+      if (cnt == 8)
+        lj_locate<N>(a, S, i, rot, oc);
+    }
+  };
+  for (uint32_t gb = 0; gb < n_groups; gb += K4D_BURST) {
+    uint32_t pv[K4D_BURST][4];
+#pragma unroll
+    for (int u = 0; u < K4D_BURST; ++u)
+      if (gb + u < n_groups) // wave-uniform
+        decode_group(gb + u, pv[u]);
+#pragma unroll
+    for (int u = 0; u < K4D_BURST; ++u) {
+      const uint32_t g = gb + u;
+      if (g >= n_groups)
+        break;
+      if (8 * g < remaining) {
+        const uint32_t cnt = remaining - 8 * g;
+        store_group(pv[u], cnt < 8u ? cnt : 8u);
+      }
+    }
+  }
+  // K7 needs the bit position at which the reference's last symbol starts:
+  // exactly one lane of the whole stream owns it and walks there again
+  if (needed >= 1 && needed - 1 >= first && needed - 1 < first + remaining) {
+    const uint32_t target = uint32_t(needed - 1 - first);
+    uint32_t p2 = my_start & ST_OFF_MASK, ph2 = (my_start >> ST_PHASE_SHIFT) & 7u;
+    for (uint32_t t = 0; t < target; ++t) {
+      const uint32_t w = lj_window(L.B, j, p2);
+      const TabLds& tb = lj_table<MULTI>(L, dp, ph2);
+      uint32_t e = tb.lut[w >> (32 - LUT_BITS)];
+      if ((e & 31u) == 0u)
+        e = lj_slow_entry(w, &tb);
+      p2 += e >> 10;
+      if (MULTI)
+        ph2 = (ph2 + 1 == dp.period) ? 0u : ph2 + 1;
+    }
+    a.results[s].last_slot = lb * LJ_OWN + uint32_t(j - 1);
+    a.results[s].last_pos = p2;
+  }
+}
+
+template <bool MULTI, int N>
+void launch_direct_one(const LjArgs& a, const DirectLaunch& d, hipStream_t s,
+                       KernelTimer* timer) {
+  if (!d.present[MULTI ? 1 : 0][N])
+    return;
+  hipLaunchKernelGGL((lj_decode_direct_kernel<MULTI, N>), dim3(d.total_blocks), dim3(LJ_T),
+                     k4d_lds_bytes(MULTI ? d.max_tables : 1), s, a);
+  if (timer)
+    timer->mark(MULTI ? "lj_decode_direct_kernel<multi>" : "lj_decode_direct_kernel");
+}
+
+} // namespace
+
+void ljpeg_launch_direct(const LjArgs& a, const DirectLaunch& d, hipStream_t s,
+                         KernelTimer* timer) {
+  const bool n1 = d.present[0][1] || d.present[1][1];
+  const bool n2 = d.present[0][2] || d.present[1][2];
+  const bool n4 = d.present[0][4] || d.present[1][4];
+  if (n1)
+    hipLaunchKernelGGL((lj_rowedge_kernel<1>), dim3(d.total_blocks), dim3(LJ_T), 0, s, a);
+  if (n2)
+    hipLaunchKernelGGL((lj_rowedge_kernel<2>), dim3(d.total_blocks), dim3(LJ_T), 0, s, a);
+  if (n4)
+    hipLaunchKernelGGL((lj_rowedge_kernel<4>), dim3(d.total_blocks), dim3(LJ_T), 0, s, a);
+  if (timer)
+    timer->mark("lj_rowedge_kernel");
+  hipLaunchKernelGGL(lj_rowoff_kernel, dim3(d.n_streams), dim3(VS_T), 0, s, a);
+  if (timer)
+    timer->mark("lj_rowoff_kernel");
+  launch_direct_one<false, 1>(a, d, s, timer);
+  launch_direct_one<false, 2>(a, d, s, timer);
+  launch_direct_one<false, 4>(a, d, s, timer);
+  launch_direct_one<true, 1>(a, d, s, timer);
+  launch_direct_one<true, 2>(a, d, s, timer);
+  launch_direct_one<true, 4>(a, d, s, timer);
+}
+
+} // namespace rsx

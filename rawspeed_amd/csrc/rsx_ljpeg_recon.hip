@@ -43,6 +43,8 @@ __global__ __launch_bounds__(VS_T) void lj_vseed_kernel(LjArgs a) {
   const LjStreamDev& S = a.streams[s];
   if (a.results[s].status != 0 || S.kind == 2)
     return;
+  if (S.direct && !(a.results[s].flags & FL_NEED_LEGACY))
+    return; // reconstructed by the fused decode (rsx_ljpeg_direct.hip)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // (the stream record is read once: stores to V could alias it for the compiler)
   const uint32_t rows = S.rows, N = S.n_comp, row_samples = S.row_samples;
@@ -179,6 +181,8 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
   const LjStreamDev& S = a.streams[lo];
   if (int(S.n_comp) != N || int(S.period) != P || S.kind == 2 ||
       a.results[lo].status != 0)
+    return;
+  if (S.direct && !(a.results[lo].flags & FL_NEED_LEGACY))
     return;
   const uint32_t r = grow - S.first_row;
   if (r >= S.rows)
@@ -397,6 +401,8 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_fast_kernel(LjArgs a) {
   const LjStreamDev& S = a.streams[lo];
   if (int(S.n_comp) != N || int(S.period) != N || S.kind == 2 ||
       a.results[lo].status != 0)
+    return;
+  if (S.direct && !(a.results[lo].flags & FL_NEED_LEGACY))
     return;
   const uint32_t r = grow - S.first_row;
   if (r >= S.rows)
