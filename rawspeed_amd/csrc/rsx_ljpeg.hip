@@ -521,12 +521,13 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     // known start state; every other slot decodes from its warm-up guess
     // (slot 0 of later workgroups from bit 0)
     const bool real_slot = !(lb == 0 && j == 0);
-    const uint32_t guess = lj_warmup<MULTI, PAIR>(L, dp, j);
+    const uint32_t guess = (LJ_ABLATE & 16u) ? 0u : lj_warmup<MULTI, PAIR>(L, dp, j);
     if (j >= 2 || (j == 1 && lb > 0))
       start = guess;
     else if (j == 1)
       start = S.start_bit; // the stream's first symbol
-    lj_decode_span<MULTI, NS, PAIR>(L, dp, j, start, own_bits, e, c, &sums, real_slot);
+    lj_decode_span<MULTI, NS, PAIR>(L, dp, j, start, own_bits, e, c, &sums,
+                                    real_slot && !(LJ_ABLATE & 4u));
     if (!real_slot) {
       e = S.start_bit;
       c = 0;
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     }
     __syncthreads();
     const uint32_t n = L.misc[8];
-    if (n == 0)
+    if (n == 0 || (LJ_ABLATE & 32u))
       break;
 #ifdef RSX_EXPERIMENT
     if (j == 0) {
@@ -1896,6 +1897,10 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     cls.sony |= g.kind == 2 && J.nikon.sony;
     if (g.kind != 2)
       cls.comp[g.period == g.n_comp ? g.n_comp : (g.period == 4 ? 5u : 6u)] = true;
+    if (S.direct && (LJ_ABLATE & 512u)) { // experiment: a linear scratch for K4d's stores
+      S.diff_offset = p->total_diffs;
+      p->total_diffs += (needed + 7 + 8) & ~uint64_t(7);
+    }
     if (S.direct) {
       p->any_direct = true;
       p->direct_present[multi ? 1 : 0][S.direct] = true;

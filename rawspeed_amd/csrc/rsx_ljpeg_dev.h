@@ -36,6 +36,17 @@ constexpr int LJ_IMG_U4 = (LJ_BW + 1) * LJ_T / 4; // per-workgroup un-stuffed im
 #endif
 constexpr uint32_t LJ_WARM = RSX_LJ_WARM;     // warm-up bits decoded ahead of a slot for its start guess
 
+// Ablation switches of the experiment builds (rawspeed_amd/build.py build_variant with
+// -DRSX_EXPERIMENT -DRSX_ABLATE=<bits>; compile-time constants, 0 in the shipped
+// library): 1 = K4d without stores, 2 = K4d without its decode loop, 4 = K1 without
+// the recorded pass, 16 = K1 without warm-up, 32 = K1 without re-decode rounds,
+// 64 = K5a without its walks, 256 = K4d stores to 64-byte aligned (wrong) addresses.
+#if defined(RSX_EXPERIMENT) && defined(RSX_ABLATE)
+constexpr uint32_t LJ_ABLATE = RSX_ABLATE;
+#else
+constexpr uint32_t LJ_ABLATE = 0;
+#endif
+
 constexpr uint32_t ST_OFF_MASK = 63u;
 constexpr uint32_t ST_PHASE_SHIFT = 6;
 constexpr uint32_t ST_ERR = 1u << 9;

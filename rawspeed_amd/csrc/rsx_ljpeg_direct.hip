@@ -180,6 +180,8 @@ __global__ __launch_bounds__(LJ_T) void lj_rowedge_kernel(LjArgs a) {
     bool ok = !(st0 & ST_ERR);
     uint2 E = make_uint2(0, 0), F = make_uint2(0, 0);
     // `skip` symbols up to the row start, then the N symbols of its first MCU
+    if (LJ_ABLATE & 64u)
+      skip = 0;
     for (uint32_t n = 0; ok && n < skip + uint32_t(N); ++n) {
       if (n == skip)
         E = P;
@@ -255,12 +257,19 @@ __global__ __launch_bounds__(VS_T) void lj_rowoff_kernel(LjArgs a) {
 // K4d: final decode straight into the image
 // ---------------------------------------------------------------------------
 // where the next sample of a lane goes: the current run of samples that are stored
-// contiguously (or all discarded) and the row's offsets
+// contiguously (or all discarded) and the offsets of its row
 struct OutCursor {
-  uint16_t* p;       // address of the next sample (nullptr: the run is discarded)
-  uint32_t left;     // samples left in the run (0: no contiguous run -- per-sample path)
-  uint32_t r, sidx;  // stream row and sample index inside it
-  uint2 off;         // O(r, .) by the lane's relative phases
+  uint16_t* p;   // address of the next sample (nullptr: the run is discarded)
+  uint32_t left; // samples left in the run (0: no contiguous run -- per-sample path)
+  uint2 off;     // O(row, .) by the lane's relative phases
+};
+
+// what the store paths need to know
+struct StoreCtx {
+  uint8_t* img;          // out_base + img_offset
+  const uint2* rowoff;   // O of the stream's rows
+  const Cr2Strip* strips;
+  const LjStreamDev* S;
 };
 
 __device__ __forceinline__ void strip_divmod32(uint64_t off, uint32_t w, uint32_t* row,
@@ -276,53 +285,52 @@ __device__ __forceinline__ void strip_divmod32(uint64_t off, uint32_t w, uint32_
 }
 
 // one sample through the general output mapping (decodeRowN :200-250 / CR2 strips)
-__device__ __forceinline__ void lj_put_sample(const LjArgs& a, const LjStreamDev& S,
-                                              uint32_t r, uint32_t sidx, uint16_t val) {
-  uint8_t* img = a.out_base + S.img_offset;
+__device__ __forceinline__ void lj_put_sample(const StoreCtx& x, uint32_t r, uint32_t sidx,
+                                              uint16_t val) {
+  const LjStreamDev& S = *x.S;
   if (S.kind == 0) {
     const uint32_t m = sidx / S.n_comp, c = sidx - m * S.n_comp;
     const uint32_t col = S.mcu_w * m + (c % S.mcu_w);
     if (col >= S.keep_samples)
       return;
     const uint32_t row = S.out_y + S.mcu_h * r + c / S.mcu_w;
-    reinterpret_cast<uint16_t*>(img + uint64_t(row) * S.img_pitch)[S.out_x + col] = val;
+    reinterpret_cast<uint16_t*>(x.img + uint64_t(row) * S.img_pitch)[S.out_x + col] = val;
   } else {
     const uint64_t k = uint64_t(r) * S.row_samples + sidx;
-    const Cr2Strip* st = a.strips + S.strip_base;
+    const Cr2Strip* st = x.strips;
     uint32_t q = 0;
     while (q + 1 < S.n_strips && k >= st[q + 1].first_sample)
       ++q;
     uint32_t srow, scol;
     strip_divmod32(k - st[q].first_sample, st[q].w, &srow, &scol);
-    reinterpret_cast<uint16_t*>(img + uint64_t(st[q].y0 + srow) * S.img_pitch)[st[q].x0 + scol] =
+    reinterpret_cast<uint16_t*>(x.img + uint64_t(st[q].y0 + srow) * S.img_pitch)[st[q].x0 + scol] =
         val;
   }
 }
 
+// the run that sample i of the stream starts (once per lane, and again at the end of
+// every run)
 template <int N>
-__device__ __forceinline__ void lj_locate(const LjArgs& a, const LjStreamDev& S, uint32_t i,
-                                          uint32_t rot, OutCursor& c) {
+__device__ __forceinline__ OutCursor lj_locate(const StoreCtx& x, uint32_t i, uint32_t rot) {
+  const LjStreamDev& S = *x.S;
+  OutCursor c;
   const uint32_t RS = S.row_samples;
   const uint32_t r = i / RS, sidx = i - r * RS;
-  c.r = r;
-  c.sidx = sidx;
-  c.off = lj_rot_fields<N>(reinterpret_cast<const uint2*>(a.vseed)[uint64_t(S.first_row) + r],
-                           rot);
-  uint8_t* img = a.out_base + S.img_offset;
+  c.off = lj_rot_fields<N>(x.rowoff[r], rot);
   c.p = nullptr;
   c.left = 0;
   if (S.kind == 0) {
     if (S.mcu_h == 1) { // sample s of a stream row = output column s
       if (sidx < S.keep_samples) {
         c.left = (S.keep_samples < RS ? S.keep_samples : RS) - sidx;
-        c.p = reinterpret_cast<uint16_t*>(img + uint64_t(S.out_y + r) * S.img_pitch) + S.out_x +
-              sidx;
+        c.p = reinterpret_cast<uint16_t*>(x.img + uint64_t(S.out_y + r) * S.img_pitch) +
+              S.out_x + sidx;
       } else {
         c.left = RS - sidx; // trailing MCUs of the frame that the tile does not keep
       }
     }
   } else {
-    const Cr2Strip* st = a.strips + S.strip_base;
+    const Cr2Strip* st = x.strips;
     uint32_t z = 0;
     while (z + 1 < S.n_strips && uint64_t(i) >= st[z + 1].first_sample)
       ++z;
@@ -330,9 +338,66 @@ __device__ __forceinline__ void lj_locate(const LjArgs& a, const LjStreamDev& S,
     strip_divmod32(uint64_t(i) - st[z].first_sample, st[z].w, &srow, &col);
     const uint32_t in_strip = st[z].w - col, in_row = RS - sidx;
     c.left = in_strip < in_row ? in_strip : in_row;
-    c.p = reinterpret_cast<uint16_t*>(img + uint64_t(st[z].y0 + srow) * S.img_pitch) + st[z].x0 +
-          col;
+    c.p = reinterpret_cast<uint16_t*>(x.img + uint64_t(st[z].y0 + srow) * S.img_pitch) +
+          st[z].x0 + col;
   }
+  return c;
+}
+
+// Everything that is not "a full group of 8 inside a stored run": groups that cross the
+// end of a run (row end, kept width, strip), discarded runs, mappings without
+// contiguous runs (2x2 MCUs), and -- when it is not inside one run -- the lane's last,
+// partial group.  pv = the group's running sums P (sample t in half t&1 of dword
+// t>>1), i = index of its first sample.  The group is cut at the run ends: each piece
+// is stored (or dropped) as a whole and the cursor moved on, so the row offsets are
+// loaded once per run, not per sample.  Returns the cursor for sample i + cnt.
+template <int N>
+__device__ __forceinline__ OutCursor lj_store_general(const StoreCtx& x, OutCursor oc,
+                                                      uint32_t i, uint32_t rot, uint4 pv,
+                                                      uint32_t cnt) {
+  auto pick = [&](uint32_t t) -> uint32_t { // sample t of the group
+    const uint32_t k = t >> 1;
+    const uint32_t d = k == 0 ? pv.x : (k == 1 ? pv.y : (k == 2 ? pv.z : pv.w));
+    return (d >> (16u * (t & 1u))) & 0xFFFFu;
+  };
+  uint32_t t = 0;
+#pragma unroll 1
+  while (t < cnt) {
+    if (oc.left == 0)
+      oc = lj_locate<N>(x, i + t, rot);
+    uint32_t n = cnt - t < oc.left ? cnt - t : oc.left;
+    if (n == 0) {
+      // no contiguous runs in this mapping: sample by sample
+      const uint32_t RS = x.S->row_samples;
+      uint32_t rr = (i + t) / RS, ss = (i + t) - rr * RS;
+#pragma unroll 1
+      for (; t < cnt; ++t) {
+        const uint32_t c = (i + t) & uint32_t(N - 1);
+        const uint2 o = x.rowoff[rr];
+        const uint32_t ov = ((c & 2u) ? o.y : o.x) >> (16u * (c & 1u));
+        lj_put_sample(x, rr, ss, uint16_t(pick(t) + ov));
+        if (++ss == RS) {
+          ss = 0;
+          ++rr;
+        }
+      }
+      break;
+    }
+    if (oc.p) {
+      const uint32_t o0 = N == 1 ? (oc.off.x & 0xFFFFu) * 0x10001u : oc.off.x;
+      const uint32_t o1 = N == 4 ? oc.off.y : o0;
+#pragma unroll 1
+      for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t q = t + k; // (the offsets go by the sample's phase: q mod N)
+        const uint32_t o = (q & 2u) ? o1 : o0;
+        oc.p[k] = uint16_t(pick(q) + (o >> (16u * (q & 1u))));
+      }
+      oc.p += n;
+    }
+    oc.left -= n;
+    t += n;
+  }
+  return oc;
 }
 
 #ifndef RSX_K4D_BURST
@@ -344,8 +409,11 @@ constexpr size_t k4d_lds_bytes(int n_tables) {
   return size_t(LJ_BW_DEC) * LJ_T * 4 + 16 * 4 + size_t(n_tables) * sizeof(TabLds);
 }
 
+#ifndef RSX_K4D_MIN_WAVES
+#define RSX_K4D_MIN_WAVES 1
+#endif
 template <bool MULTI, int N>
-__global__ __launch_bounds__(LJ_T) void lj_decode_direct_kernel(LjArgs a) {
+__global__ __launch_bounds__(LJ_T, RSX_K4D_MIN_WAVES) void lj_decode_direct_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t b = blockIdx.x;
   const uint32_t s = a.block_stream[b];
@@ -372,16 +440,26 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_direct_kernel(LjArgs a) {
     return; // past the end of data
 
   lj_stage_tables(L, a, S);
-  // the image (no ob[] here: the records say how many symbols a slot holds)
+  // the image (no ob[] here: the records say how many symbols a slot holds): all
+  // loads are issued before the first LDS store (written as one loop the compiler
+  // waits for every load before it issues the next)
   {
     const uint4* __restrict__ src = a.unstuffed + size_t(b) * LJ_IMG_U4;
     uint4* dst = reinterpret_cast<uint4*>(L.B);
-    constexpr int n4 = LJ_BW_DEC * LJ_T / 4;
+    constexpr int n4 = LJ_BW_DEC * LJ_T / 4, n_it = (n4 + LJ_T - 1) / LJ_T;
+    uint4 t[n_it];
 #pragma unroll
-    for (int h = 0; h < (n4 + LJ_T - 1) / LJ_T; ++h) {
+    for (int h = 0; h < n_it; ++h) {
+      const int i = h * LJ_T + j;
+      t[h] = make_uint4(0, 0, 0, 0);
+      if (i < n4)
+        t[h] = src[i];
+    }
+#pragma unroll
+    for (int h = 0; h < n_it; ++h) {
       const int i = h * LJ_T + j;
       if (i < n4)
-        dst[i] = src[i];
+        dst[i] = t[h];
     }
   }
   const DecodeParams dp = lj_params(S);
@@ -412,7 +490,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_direct_kernel(LjArgs a) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1)
     wmax = max(wmax, uint32_t(__shfl_xor(wmax, o, 64)));
-  const uint32_t n_groups = (wmax + 7) >> 3;
+  const uint32_t n_groups = (LJ_ABLATE & 2u) ? 0u : (wmax + 7) >> 3;
 
   // P before the lane's first symbol by absolute component, then by the lane's own
   // relative phases (the k-th symbol of the lane has phase k mod N: groups of 8
@@ -424,11 +502,18 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_direct_kernel(LjArgs a) {
   uint2 run = lj_rot_fields<N>(p_abs, rot);
   if (N == 1)
     run.x = (run.x & 0xFFFFu) * 0x10001u; // both halves carry the one running sum
+  StoreCtx sx;
+  sx.img = a.out_base + S.img_offset;
+  sx.rowoff = reinterpret_cast<const uint2*>(a.vseed) + S.first_row;
+  sx.strips = a.strips + S.strip_base;
+  sx.S = &S;
   OutCursor oc{};
-  if (remaining)
-    lj_locate<N>(a, S, i0, rot, oc);
-  uint32_t i = i0; // index of the next sample to be stored
-
+  if (LJ_ABLATE & 16384u) {
+    oc.p = reinterpret_cast<uint16_t*>(sx.img) + i0;
+    oc.left = 0x7FFFFFFFu;
+  } else if (remaining) {
+    oc = lj_locate<N>(sx, i0, rot);
+  }
   uint32_t phase = (my_start >> ST_PHASE_SHIFT) & 7u;
   BitReader<LJ_BW_DEC> r;
   r.open(L.B, j, my_start & ST_OFF_MASK);
@@ -467,71 +552,98 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_direct_kernel(LjArgs a) {
       }
     }
   };
-  // store the `cnt` samples of a group (running sums in p) that start at sample i
-  auto store_group = [&](const uint32_t (&p)[4], uint32_t cnt) {
-    if (cnt <= oc.left) {
-      // the whole group lies inside the current run
-      if (oc.p) {
-        const uint32_t o0 = N == 1 ? (oc.off.x & 0xFFFFu) * 0x10001u : oc.off.x;
-        const uint32_t o1 = N == 4 ? oc.off.y : o0;
-        const uint4 v = make_uint4(pk_add(p[0], o0), pk_add(p[1], o1), pk_add(p[2], o0),
-                                   pk_add(p[3], o1));
-        if (cnt == 8) {
-          __builtin_memcpy(oc.p, &v, 16);
-        } else {
-          const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int t = 0; t < 7; ++t)
-            if (uint32_t(t) < cnt)
-              oc.p[t] = uint16_t(w[t >> 1] >> (16 * (t & 1)));
-        }
-        oc.p += cnt;
-      }
-      oc.left -= cnt;
-      oc.sidx += cnt;
-      i += cnt;
-      if (oc.left == 0 && cnt == 8)
-        lj_locate<N>(a, S, i, rot, oc); // (a partial group is the lane's last)
-    } else {
-      // the group crosses the end of a run (row end, kept width, strip) or the
-      // mapping has no contiguous runs (2x2 MCUs): sample by sample
-      const uint2* O = reinterpret_cast<const uint2*>(a.vseed) + S.first_row;
-      const uint32_t RS = S.row_samples;
-      uint32_t rr = oc.r, ss = oc.sidx;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        if (uint32_t(t) < cnt) {
-          const uint32_t pv = (p[t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
-          const uint32_t c = (i + uint32_t(t)) & uint32_t(N - 1);
-          const uint2 o = O[rr];
-          const uint32_t ov = ((c & 2u) ? o.y : o.x) >> (16u * (c & 1u));
-          lj_put_sample(a, S, rr, ss, uint16_t(pv + ov));
-          if (++ss == RS) {
-            ss = 0;
-            ++rr;
-          }
-        }
-      }
-      i += cnt;
-      if (cnt == 8)
-        lj_locate<N>(a, S, i, rot, oc);
-    }
-  };
+  // the packed offsets of the current row for dwords 0/2 and 1/3 of a group
+  auto off0 = [&]() { return N == 1 ? (oc.off.x & 0xFFFFu) * 0x10001u : oc.off.x; };
+  auto off1 = [&]() { return N == 4 ? oc.off.y : off0(); };
+  uint32_t tp[4] = {0, 0, 0, 0}; // the lane's last, partial group
   for (uint32_t gb = 0; gb < n_groups; gb += K4D_BURST) {
     uint32_t pv[K4D_BURST][4];
 #pragma unroll
     for (int u = 0; u < K4D_BURST; ++u)
       if (gb + u < n_groups) // wave-uniform
         decode_group(gb + u, pv[u]);
+    if (LJ_ABLATE & 1u) {
+#pragma unroll
+      for (int u = 0; u < K4D_BURST; ++u)
+        asm volatile("" ::"v"(pv[u][0]), "v"(pv[u][1]), "v"(pv[u][2]), "v"(pv[u][3]));
+      continue;
+    }
+    // Full groups inside a stored run leave as one (unaligned) 16-byte store each.
+    // A lane whose group ends a run (or is discarded) stops here: that group and the
+    // ones after it in the burst are marked and go through the general path below, in
+    // order (the general path moves the cursor).
+    uint32_t pend = 0;
 #pragma unroll
     for (int u = 0; u < K4D_BURST; ++u) {
-      const uint32_t g = gb + u;
+      const uint32_t g = gb + uint32_t(u);
       if (g >= n_groups)
         break;
-      if (8 * g < remaining) {
-        const uint32_t cnt = remaining - 8 * g;
-        store_group(pv[u], cnt < 8u ? cnt : 8u);
+      const bool full = 8 * g + 8 <= remaining;
+      if (!full && 8 * g < remaining) {
+        tp[0] = pv[u][0];
+        tp[1] = pv[u][1];
+        tp[2] = pv[u][2];
+        tp[3] = pv[u][3];
       }
+      if (full && pend == 0 && oc.left >= 8 && oc.p != nullptr) {
+        const uint32_t o0 = off0(), o1 = off1();
+        const uint4 v = make_uint4(pk_add(pv[u][0], o0), pk_add(pv[u][1], o1),
+                                   pk_add(pv[u][2], o0), pk_add(pv[u][3], o1));
+        if (LJ_ABLATE & 1024u)
+          asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(oc.p));
+        else
+          __builtin_memcpy(oc.p, &v, 16);
+        oc.p += 8;
+        oc.left -= 8;
+      } else if (full) {
+        pend |= 1u << u;
+      }
+    }
+    if (!(LJ_ABLATE & 4096u) && __any(pend != 0)) {
+#pragma unroll 1
+      for (uint32_t u = 0; u < uint32_t(K4D_BURST); ++u) {
+        uint32_t p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uint32_t v = pv[0][k];
+#pragma unroll
+          for (int q = 1; q < K4D_BURST; ++q)
+            v = u == uint32_t(q) ? pv[q][k] : v;
+          p[k] = v;
+        }
+        if ((pend >> u) & 1u)
+          oc = lj_store_general<N>(sx, oc, i0 + 8 * (gb + u), rot,
+                                   make_uint4(p[0], p[1], p[2], p[3]), 8u);
+      }
+    }
+  }
+  // the partial last group: inside one stored run (the rule) it leaves as at most
+  // three stores -- 4, 2 and 1 samples -- instead of up to seven 2-byte ones (a
+  // scattered store instruction costs the memory pipeline the same whatever its width)
+  if (!(LJ_ABLATE & (1u | 8192u)) && (remaining & 7u) != 0) {
+    const uint32_t cnt = remaining & 7u;
+    if (cnt <= oc.left && oc.p != nullptr) {
+      const uint32_t o0 = off0(), o1 = off1();
+      uint32_t w0 = pk_add(tp[0], o0), w1 = pk_add(tp[1], o1), w2 = pk_add(tp[2], o0),
+               w3 = pk_add(tp[3], o1);
+      uint16_t* q = oc.p;
+      if (cnt & 4u) {
+        const uint2 v = make_uint2(w0, w1);
+        __builtin_memcpy(q, &v, 8);
+        q += 4;
+        w0 = w2;
+        w1 = w3;
+      }
+      if (cnt & 2u) {
+        __builtin_memcpy(q, &w0, 4);
+        q += 2;
+        w0 = w1;
+      }
+      if (cnt & 1u)
+        *q = uint16_t(w0);
+    } else {
+      (void)lj_store_general<N>(sx, oc, i0 + (remaining & ~7u), rot,
+                                make_uint4(tp[0], tp[1], tp[2], tp[3]), cnt);
     }
   }
   // K7 needs the bit position at which the reference's last symbol starts:
