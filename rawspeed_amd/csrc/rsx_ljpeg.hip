@@ -27,9 +27,7 @@
 //                  state, symbol count and, for the fused path, the sums of its
 //                  differences by relative component phase -- and the workgroup
 //                  iterates "re-decode from the predecessor's exit state" on a
-//                  dense list of the few slots that guessed wrong.  A re-decode
-//                  walks the new parse and the recorded one in lock step (always
-//                  the one that is behind) and stops where they meet.
+//                  dense list of the few slots that guessed wrong.
 //  K2 lj_sync<STITCH>  cross-workgroup fix-up: a workgroup whose assumed start
 //                  differs from its predecessor's recorded exit re-converges.
 //                  (Jacobi iteration: a fixed point is the serial decode.)
@@ -353,75 +351,6 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
     *sums = acc.get();
 }
 
-// Re-decode slot `col` from a new start state (single-table streams).  The new
-// parse and the recorded one (from old_start) are advanced alternately -- always
-// the one that is behind -- until they stand on the same bit: from there on they
-// are the same parse, so the recorded exit, the recorded count and the recorded
-// sums of the tail stand (the tail's phases shift by the difference of the symbol
-// counts before the meeting point).  Huffman parses re-synchronise within a few
-// dozen bits, so a re-decode costs a fraction of a slot instead of all of it, and
-// no trajectory has to be kept in LDS.  (Model: tests/test_direct_recon_model.py.)
-template <int NS, bool PAIR = false>
-__device__ __forceinline__ void lj_redecode_merge(const Lds& L, const DecodeParams& dp,
-                                                  int col, uint32_t new_start,
-                                                  uint32_t old_start, uint32_t end_bits,
-                                                  uint32_t old_exit, uint32_t old_cn,
-                                                  uint2 old_sums, uint32_t& exit,
-                                                  uint32_t& count, uint2& sums,
-                                                  bool enabled) {
-  constexpr int N = NS ? NS : 1;
-  uint32_t pa = new_start & ST_OFF_MASK, pb = old_start & ST_OFF_MASK;
-  uint32_t na = 0, nb = 0;
-  PhaseSums<N> sa, sb;
-  bool ok = true, merged = false;
-  bool old_ok = !(old_start & ST_ERR); // the recorded parse can still be followed
-  uint32_t enda = enabled ? end_bits : 0u;
-  while (__any(pa < enda)) {
-    bool live = pa < enda;
-    if (live && old_ok && pa == pb) {
-      merged = true;
-      enda = 0;
-      live = false;
-    }
-    // the recorded parse steps while it is behind (and still inside the slot)
-    const bool step_b = live && old_ok && pb < pa && pb < end_bits;
-    uint32_t w;
-    const uint32_t e = lj_step<false, PAIR>(L, dp, col, step_b ? pb : pa, 0u, live, &w);
-    const bool bad = live && e == 0u;
-    const uint32_t adv = e >> 10;
-    const uint32_t d = NS ? lj_extend(w, e) : 0u;
-    const bool adv_b = step_b && !bad, adv_a = live && !step_b && !bad;
-    pb += adv_b ? adv : 0u;
-    nb += adv_b ? 1u : 0u;
-    pa += adv_a ? adv : 0u;
-    na += adv_a ? 1u : 0u;
-    if (NS) {
-      sb.add(d, adv_b);
-      sa.add(d, adv_a);
-    }
-    old_ok = old_ok && !(step_b && bad); // the recorded parse ran into an invalid code
-    if (live && !step_b && bad) {
-      ok = false;
-      enda = 0;
-    }
-  }
-  if (!enabled)
-    return;
-  if (merged) {
-    count = na + old_cn - nb;
-    exit = old_exit;
-    if (NS) {
-      const uint2 tail = pk_sub2(old_sums, sb.get());
-      sums = pk_add2(sa.get(), lj_rot_fields<N>(tail, (na - nb) & uint32_t(N - 1)));
-    }
-  } else {
-    exit = ok ? (pa - end_bits) : ST_ERR;
-    count = na;
-    if (NS)
-      sums = sa.get();
-  }
-}
-
 // Start-state guess for slot j: decode the last LJ_WARM bits of slot j-1 from an
 // arbitrary bit position; Huffman streams self-synchronise within a few
 // symbols, so the position at which this runs into slot j is almost always the
@@ -613,13 +542,13 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       const bool mine = uint32_t(j) < n;
       idx = mine ? uint32_t(L.list[j]) : 1u;
       w = (STITCH && idx == 1) ? true_start : L.st[idx - 1];
-      if (MULTI) {
-        lj_decode_span<MULTI, NS, PAIR>(L, dp, int(idx), w, L.ob[idx], e, c, &sums, mine);
-      } else {
-        const uint2 old_sums = make_uint2(NS ? L.sm[2 * idx] : 0u, NS ? L.sm[2 * idx + 1] : 0u);
-        lj_redecode_merge<NS, PAIR>(L, dp, int(idx), w, L.su[idx], L.ob[idx], L.st[idx],
-                                    L.cn[idx], old_sums, e, c, sums, mine);
-      }
+      // (a plain re-decode of the whole slot.  Two ways to stop early where the new parse
+      // meets the recorded one were measured and lost: a bitmap of the first 64 bits'
+      // symbol starts (round 1) cannot carry the difference sums, and walking both
+      // parses in lock step costs two steps per symbol while the slowest of the few
+      // lanes of a round still runs to the end of its slot: 0.625 vs 0.596 ms per 8
+      // cfg-3 frames.)
+      lj_decode_span<MULTI, NS, PAIR>(L, dp, int(idx), w, L.ob[idx], e, c, &sums, mine);
     }
     __syncthreads(); // every read of the records precedes the updates
     if (uint32_t(j) < n) {
@@ -645,9 +574,10 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     a.block_start[b] = L.su[1];
   if (j == LJ_T - 1)
     a.block_exit[b] = L.st[j];
-  // block totals: symbols, and the difference sums with phases relative to the
-  // workgroup's first symbol (a slot's own phases start at its first symbol:
-  // rotate by the number of symbols before it)
+  // Per slot: the symbols before it inside the workgroup and (fused path) the
+  // running sums P before it, by phases relative to the workgroup's first symbol (a
+  // slot's own phases start at its first symbol: rotate by the number of symbols
+  // before it).  Block totals: symbols, sums.
   const int lane = j & 63, wv = j >> 6;
   const uint32_t incl = lj_wave_scan(my_count, lane);
   if (lane == 63)
@@ -659,21 +589,28 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   if (j == 0)
     a.block_sum[b] = L.misc[0] + L.misc[1] + L.misc[2] + L.misc[3];
   if (NS) {
-    uint2 r = lj_rot_fields<N>(my_sums, before & uint32_t(N - 1));
+    const uint2 r = lj_rot_fields<N>(my_sums, before & uint32_t(N - 1));
+    uint2 pincl = r;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-      r = pk_add2(r, make_uint2(__shfl_xor(r.x, o, 64), __shfl_xor(r.y, o, 64)));
-    if (lane == 0) {
-      L.misc[4 + 2 * wv] = r.x;
-      L.misc[5 + 2 * wv] = r.y;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint2 y = make_uint2(__shfl_up(pincl.x, o, 64), __shfl_up(pincl.y, o, 64));
+      if (lane >= o)
+        pincl = pk_add2(pincl, y);
+    }
+    if (lane == 63) {
+      L.misc[4 + 2 * wv] = pincl.x;
+      L.misc[5 + 2 * wv] = pincl.y;
     }
     __syncthreads();
-    if (j == 0) {
-      uint2 t = make_uint2(L.misc[4], L.misc[5]);
-      for (int w = 1; w < 4; ++w)
-        t = pk_add2(t, make_uint2(L.misc[4 + 2 * w], L.misc[5 + 2 * w]));
-      a.block_psum[b] = t;
+    uint2 pex = pk_sub2(pincl, r);
+    for (int w = 0; w < wv; ++w)
+      pex = pk_add2(pex, make_uint2(L.misc[4 + 2 * w], L.misc[5 + 2 * w]));
+    if (j >= 1) {
+      a.sub_first[gsub] = before;
+      a.sub_psum[gsub] = pex;
     }
+    if (j == LJ_T - 1)
+      a.block_psum[b] = pk_add2(pex, r);
   }
 }
 
@@ -1569,6 +1506,7 @@ struct LJpegPlan {
   bool any_direct = false, any_legacy = false;
   bool legacy_fallback_ready = false; // difference scratch of the fused streams allocated
   DeviceBuffer d_streams, d_tables, d_block_stream, d_strips, d_sub_state, d_sub_sums,
+      d_sub_first, d_sub_psum,
       d_block_start, d_block_exit, d_block_sum, d_block_base, d_block_psum, d_block_pbase,
       d_block_drops, d_block_drop_base, d_results, d_diffs, d_vseed, d_row_edge, d_unstuffed;
   KernelTimer* timer = nullptr; // set for the duration of a timed run
@@ -1626,6 +1564,8 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.strips = static_cast<const Cr2Strip*>(p->d_strips.ptr);
   a.sub_state = static_cast<uint32_t*>(p->d_sub_state.ptr);
   a.sub_sums = static_cast<uint2*>(p->d_sub_sums.ptr);
+  a.sub_first = static_cast<uint32_t*>(p->d_sub_first.ptr);
+  a.sub_psum = static_cast<uint2*>(p->d_sub_psum.ptr);
   a.block_psum = static_cast<uint2*>(p->d_block_psum.ptr);
   a.block_pbase = static_cast<uint2*>(p->d_block_pbase.ptr);
   a.row_edge = static_cast<uint4*>(p->d_row_edge.ptr);
@@ -1897,10 +1837,6 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     cls.sony |= g.kind == 2 && J.nikon.sony;
     if (g.kind != 2)
       cls.comp[g.period == g.n_comp ? g.n_comp : (g.period == 4 ? 5u : 6u)] = true;
-    if (S.direct && (LJ_ABLATE & 512u)) { // experiment: a linear scratch for K4d's stores
-      S.diff_offset = p->total_diffs;
-      p->total_diffs += (needed + 7 + 8) & ~uint64_t(7);
-    }
     if (S.direct) {
       p->any_direct = true;
       p->direct_present[multi ? 1 : 0][S.direct] = true;
@@ -1965,6 +1901,8 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       return st;
     if (p->any_direct &&
         ((st = p->d_sub_sums.ensure(size_t(p->total_subseq) * 8 + 16)) ||
+         (st = p->d_sub_first.ensure(size_t(p->total_subseq) * 4 + 16)) ||
+         (st = p->d_sub_psum.ensure(size_t(p->total_subseq) * 8 + 16)) ||
          (st = p->d_block_psum.ensure(size_t(p->total_blocks) * 8)) ||
          (st = p->d_block_pbase.ensure(size_t(p->total_blocks) * 8)) ||
          (st = p->d_row_edge.ensure(size_t(p->total_rows) * 16 + 16))))
@@ -2481,7 +2419,7 @@ void ljpeg_plan_destroy(LJpegPlan* p) {
   p->d_marker_list.release();
   for (DeviceBuffer* b :
        {&p->d_streams, &p->d_tables, &p->d_block_stream, &p->d_strips,
-        &p->d_sub_state, &p->d_sub_sums, &p->d_block_start, &p->d_block_exit,
+        &p->d_sub_state, &p->d_sub_sums, &p->d_sub_first, &p->d_sub_psum, &p->d_block_start, &p->d_block_exit,
         &p->d_block_sum, &p->d_block_base, &p->d_block_psum, &p->d_block_pbase,
         &p->d_block_drops, &p->d_block_drop_base, &p->d_results, &p->d_diffs, &p->d_vseed,
         &p->d_row_edge, &p->d_unstuffed})

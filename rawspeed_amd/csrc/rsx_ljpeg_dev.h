@@ -38,9 +38,10 @@ constexpr uint32_t LJ_WARM = RSX_LJ_WARM;     // warm-up bits decoded ahead of a
 
 // Ablation switches of the experiment builds (rawspeed_amd/build.py build_variant with
 // -DRSX_EXPERIMENT -DRSX_ABLATE=<bits>; compile-time constants, 0 in the shipped
-// library): 1 = K4d without stores, 2 = K4d without its decode loop, 4 = K1 without
-// the recorded pass, 16 = K1 without warm-up, 32 = K1 without re-decode rounds,
-// 64 = K5a without its walks, 256 = K4d stores to 64-byte aligned (wrong) addresses.
+// library).  K1: 4 = no recorded pass, 16 = no warm-up, 32 = no re-decode rounds.
+// K5a: 64 = no walks.  K4d: 1 = nothing after the decode of a burst, 2 = no decode
+// loop, 1024 = no 16-byte stores, 4096 = no general store path, 8192 = no tail
+// stores, 16384 = no initial cursor.
 #if defined(RSX_EXPERIMENT) && defined(RSX_ABLATE)
 constexpr uint32_t LJ_ABLATE = RSX_ABLATE;
 #else
@@ -168,6 +169,9 @@ struct LjArgs {
   const Cr2Strip* strips;
   uint32_t* sub_state;       // per subsequence: exit state | symbols << 16
   uint2* sub_sums;           // per subsequence: sums of its differences by relative phase
+  uint32_t* sub_first;       // per subsequence: symbols before it inside its workgroup
+  uint2* sub_psum;           // per subsequence: running sums P before it inside its
+                             // workgroup, by phases relative to the workgroup's first symbol
   uint32_t* block_start;
   uint32_t* block_exit;
   uint32_t* block_sum;

@@ -53,62 +53,44 @@ __device__ __forceinline__ uint2 wave_scan_pk(uint2 x, int lane) {
   return x;
 }
 
-// Per-lane records of a workgroup and their scans: the symbols before the lane's
-// slot (inside the workgroup) and P before it by phases relative to the
-// workgroup's first symbol.  scratch: 16 dwords of LDS.  Two barriers.
-template <int N>
-__device__ __forceinline__ void lj_lane_prefix(const LjArgs& a, uint32_t gsub, int j,
-                                               uint32_t* scratch, uint32_t& my_rec,
-                                               uint32_t& before, uint2& pex) {
-  const int lane = j & 63, wv = j >> 6;
-  my_rec = j >= 1 ? a.sub_state[gsub] : 0u;
-  const uint2 my_sums = j >= 1 ? a.sub_sums[gsub] : make_uint2(0u, 0u);
-  const uint32_t my_count = my_rec >> 16;
-  const uint32_t incl = wave_scan(my_count, lane);
-  if (lane == 63)
-    scratch[wv] = incl;
-  __syncthreads();
-  before = incl - my_count;
-  for (int w = 0; w < wv; ++w)
-    before += scratch[w];
-  const uint2 r = lj_rot_fields<N>(my_sums, before & uint32_t(N - 1));
-  const uint2 pincl = wave_scan_pk(r, lane);
-  if (lane == 63) {
-    scratch[4 + 2 * wv] = pincl.x;
-    scratch[5 + 2 * wv] = pincl.y;
-  }
-  __syncthreads();
-  pex = pk_sub2(pincl, r);
-  for (int w = 0; w < wv; ++w)
-    pex = pk_add2(pex, make_uint2(scratch[4 + 2 * w], scratch[5 + 2 * w]));
+// run-time flavour of lj_rot_fields (lanes of one wavefront may serve streams with
+// different component counts)
+__device__ __forceinline__ uint2 rot_fields_rt(uint2 v, uint32_t f, uint32_t n) {
+  return n == 2 ? lj_rot_fields<2>(v, f) : (n == 4 ? lj_rot_fields<4>(v, f) : v);
 }
 
 // ---------------------------------------------------------------------------
-// K5a: row edges.  One workgroup per workgroup of the entropy stream; those whose
-// symbol range holds no row start leave at once (most of them: a workgroup covers
-// ~16 K symbols).  Lane k takes the k-th row start of the range: it finds the
-// subsequence the symbol lies in, walks there from the subsequence's first symbol
-// (reading the un-stuffed image and the code table from global memory: the walks
-// are few and independent) and then over the row's first MCU.
+// K5a: row edges, one lane per stream row.  The lane finds the workgroup and the
+// subsequence its row's first symbol lies in (two binary searches over the scans the
+// synchronisation kernels left: symbols before every workgroup / before every
+// subsequence of it), copies that subsequence and the next one into its LDS column and
+// walks from the subsequence's first symbol to the row start and on over the row's
+// first MCU, adding up the differences on the way.  All rows of the launch walk at
+// once (35 840 lanes for 8 cfg-3 frames): the first version had one walker per
+// wavefront and workgroup of the entropy stream and spent 0.16 ms on ~60 serial steps
+// of LDS latency each; this one takes as long as its longest walk.
 // ---------------------------------------------------------------------------
-struct GlobalCursor {
-  const uint32_t* B; // image of the current workgroup
+constexpr int RE_T = 64;             // lanes per workgroup
+constexpr int RE_SLOT_W = LJ_PW + 2; // 17 dwords of a subsequence + its data bits
+
+struct WalkCursor {
   uint32_t b, slot, pos, ob, last_block;
 };
 
-__device__ __forceinline__ void gc_open(GlobalCursor& c, const LjArgs& a, uint32_t b,
-                                        uint32_t slot, uint32_t pos, uint32_t last_block) {
-  c.b = b;
-  c.slot = slot;
-  c.pos = pos;
-  c.last_block = last_block;
-  c.B = reinterpret_cast<const uint32_t*>(a.unstuffed + size_t(b) * LJ_IMG_U4);
-  c.ob = c.B[LJ_BW * LJ_T + slot];
+// the staged copies (LDS, [dword][lane]): [0] = (b0, q0), [1] = the subsequence after it
+struct WalkStage {
+  const uint32_t* lds; // this lane's column: dword d of copy w at (w * RE_SLOT_W + d) * RE_T
+  uint32_t b[2], q[2];
+};
+
+__device__ __forceinline__ const uint32_t* walk_image(const LjArgs& a, uint32_t b) {
+  return reinterpret_cast<const uint32_t*>(a.unstuffed + size_t(b) * LJ_IMG_U4);
 }
 
 // move to the subsequence the position belongs to (a symbol belongs to the
 // subsequence it starts in); false = ran off the end of the stream
-__device__ __forceinline__ bool gc_normalise(GlobalCursor& c, const LjArgs& a) {
+__device__ __forceinline__ bool walk_normalise(WalkCursor& c, const LjArgs& a,
+                                               const WalkStage& st) {
   while (c.pos >= c.ob) {
     c.pos -= c.ob;
     if (++c.slot == uint32_t(LJ_T)) {
@@ -116,96 +98,147 @@ __device__ __forceinline__ bool gc_normalise(GlobalCursor& c, const LjArgs& a) {
         return false;
       ++c.b;
       c.slot = 1;
-      c.B = reinterpret_cast<const uint32_t*>(a.unstuffed + size_t(c.b) * LJ_IMG_U4);
     }
-    c.ob = c.B[LJ_BW * LJ_T + c.slot];
+    if (c.b == st.b[1] && c.slot == st.q[1])
+      c.ob = st.lds[(RE_SLOT_W + LJ_PW + 1) * RE_T];
+    else
+      c.ob = walk_image(a, c.b)[LJ_BW * LJ_T + c.slot];
   }
   return true;
 }
 
-template <int N>
-__global__ __launch_bounds__(LJ_T) void lj_rowedge_kernel(LjArgs a) {
-  __shared__ uint32_t s_first[LJ_T];
-  __shared__ uint2 s_pex[LJ_T];
-  __shared__ uint32_t scratch[16];
-  const uint32_t b = blockIdx.x;
-  const uint32_t s = a.block_stream[b];
-  const LjStreamDev& S = a.streams[s];
-  if (int(S.direct) != N || (a.results[s].flags & FL_NEED_LEGACY))
+__device__ __forceinline__ uint32_t walk_window(const WalkCursor& c, const LjArgs& a,
+                                                const WalkStage& st) {
+  const uint32_t wi = c.pos >> 5;
+  uint32_t d0, d1;
+  if (c.b == st.b[0] && c.slot == st.q[0]) {
+    d0 = st.lds[wi * RE_T];
+    d1 = st.lds[(wi + 1) * RE_T];
+  } else if (c.b == st.b[1] && c.slot == st.q[1]) {
+    d0 = st.lds[(RE_SLOT_W + wi) * RE_T];
+    d1 = st.lds[(RE_SLOT_W + wi + 1) * RE_T];
+  } else {
+    const uint32_t* B = walk_image(a, c.b);
+    d0 = B[wi * LJ_T + c.slot];
+    d1 = B[(wi + 1) * LJ_T + c.slot];
+  }
+  return uint32_t((((uint64_t(d0) << 32) | d1) << (c.pos & 31u)) >> 32);
+}
+
+__global__ __launch_bounds__(RE_T) void lj_rowedge_kernel(LjArgs a) {
+  __shared__ uint32_t s_slots[2 * RE_SLOT_W * RE_T];
+  const int lane = threadIdx.x;
+  const uint32_t grow = blockIdx.x * RE_T + uint32_t(lane);
+  if (grow >= a.total_rows)
     return;
-  const uint32_t base = a.block_base[b], sum = a.block_sum[b];
-  const uint64_t needed = S.needed;
-  if (sum == 0 || base >= needed)
+  // row -> stream (first_row is increasing)
+  uint32_t slo = 0, shi = a.n_streams - 1;
+  while (slo < shi) {
+    const uint32_t mid = (slo + shi + 1) >> 1;
+    if (a.streams[mid].first_row <= grow)
+      slo = mid;
+    else
+      shi = mid - 1;
+  }
+  const LjStreamDev& S = a.streams[slo];
+  const uint32_t nd = S.direct;
+  if (!nd || (a.results[slo].flags & FL_NEED_LEGACY))
     return;
+  const uint32_t r = grow - S.first_row;
   const uint32_t RS = S.row_samples;
-  const uint64_t hi = (uint64_t(base) + sum < needed) ? uint64_t(base) + sum : needed;
-  const uint32_t r0 = uint32_t((uint64_t(base) + RS - 1) / RS); // first row that starts at or after `base`
-  if (uint64_t(r0) * RS >= hi)
-    return; // no row starts inside this workgroup's symbols
-  const uint32_t r1 = uint32_t((hi - 1) / RS);
-  const uint32_t n_here = r1 - r0 + 1;
-  const uint32_t lb = b - S.first_block;
-  const int j = threadIdx.x;
-  const uint32_t g0 = S.first_subseq + lb * LJ_OWN; // record of slot 1
-  uint32_t my_rec, before;
-  uint2 pex;
-  lj_lane_prefix<N>(a, g0 + uint32_t(j - 1), j, scratch, my_rec, before, pex);
-  s_first[j] = before;
-  s_pex[j] = pex;
-  __syncthreads();
-  const uint2 pbase = a.block_pbase[b];
+  const uint64_t t64 = uint64_t(r) * RS;
+  if (r >= S.rows || t64 >= S.needed)
+    return;
+  const uint32_t t = uint32_t(t64); // the row's first symbol
+  // the last workgroup with base <= t
+  const uint32_t fb = S.first_block;
+  uint32_t lo = 0, hi = S.n_blocks - 1;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    if (a.block_base[fb + mid] <= t)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  const uint32_t b = fb + lo;
+  const uint32_t base = a.block_base[b];
+  const uint32_t tl = t - base; // workgroup-relative index of the row's first symbol
+  if (tl >= a.block_sum[b])
+    return; // past the end of the data: the stream is flagged for the legacy route
+  // the last slot of it whose first symbol is at or before tl
+  const uint32_t g0 = S.first_subseq + lo * LJ_OWN; // record of slot 1
+  uint32_t qlo = 0, qhi = LJ_OWN - 1;
+  while (qlo < qhi) {
+    const uint32_t mid = (qlo + qhi + 1) >> 1;
+    if (a.sub_first[g0 + mid] <= tl)
+      qlo = mid;
+    else
+      qhi = mid - 1;
+  }
+  const uint32_t q = qlo + 1;
+  uint32_t skip = tl - a.sub_first[g0 + qlo];
+  // P before the slot's first symbol, by absolute component
+  uint2 P = pk_add2(a.block_pbase[b], rot_fields_rt(a.sub_psum[g0 + qlo], base % nd, nd));
+  const uint32_t st0 = q == 1 ? a.block_start[b] : (a.sub_state[g0 + qlo - 1] & ST_MASK);
+  const uint32_t last_block = fb + S.n_blocks - 1;
+  // stage the slot and its successor
+  WalkStage st;
+  st.lds = s_slots + lane;
+  st.b[0] = b;
+  st.q[0] = q;
+  st.b[1] = q + 1 < uint32_t(LJ_T) ? b : b + 1;
+  st.q[1] = q + 1 < uint32_t(LJ_T) ? q + 1 : 1u;
+  const bool have_next = st.b[1] <= last_block;
+  {
+    const uint32_t* B0 = walk_image(a, b);
+    const uint32_t* B1 = walk_image(a, have_next ? st.b[1] : b);
+    const uint32_t q1 = have_next ? st.q[1] : q;
+#pragma unroll
+    for (int d = 0; d <= LJ_PW; ++d) {
+      s_slots[d * RE_T + lane] = B0[uint32_t(d) * LJ_T + q];
+      s_slots[(RE_SLOT_W + d) * RE_T + lane] = B1[uint32_t(d) * LJ_T + q1];
+    }
+    s_slots[(LJ_PW + 1) * RE_T + lane] = B0[LJ_BW * LJ_T + q];
+    s_slots[(RE_SLOT_W + LJ_PW + 1) * RE_T + lane] = B1[LJ_BW * LJ_T + q1];
+  }
+  if (!have_next)
+    st.b[1] = 0xFFFFFFFFu;
+  uint32_t idx = base + a.sub_first[g0 + qlo]; // absolute index of the next symbol
+  WalkCursor c;
+  c.b = b;
+  c.slot = q;
+  c.pos = st0 & ST_OFF_MASK;
+  c.ob = st.lds[(LJ_PW + 1) * RE_T];
+  c.last_block = last_block;
+  bool ok = !(st0 & ST_ERR);
+  uint2 E = make_uint2(0, 0);
   const TabLds* tabs = a.tables + S.table_base;
   const bool multi = S.n_tables > 1;
-  const uint32_t last_block = S.first_block + S.n_blocks - 1;
-  for (uint32_t k = j; k < n_here; k += LJ_T) {
-    const uint32_t r = r0 + k;
-    const uint32_t tl = r * RS - base; // workgroup-relative index of the row's first symbol
-    // the last slot whose first symbol is at or before tl
-    uint32_t lo = 1, hq = LJ_T - 1;
-    while (lo < hq) {
-      const uint32_t mid = (lo + hq + 1) >> 1;
-      if (s_first[mid] <= tl)
-        lo = mid;
-      else
-        hq = mid - 1;
+  if (LJ_ABLATE & 64u)
+    skip = 0;
+  // `skip` symbols up to the row start, then the nd symbols of its first MCU
+  for (uint32_t n = 0; ok && n < skip + nd; ++n) {
+    if (n == skip)
+      E = P;
+    if (!walk_normalise(c, a, st)) {
+      ok = false;
+      break;
     }
-    const uint32_t q = lo;
-    uint32_t skip = tl - s_first[q];
-    // P before the slot's first symbol, by absolute component
-    uint2 P = pk_add2(pbase, lj_rot_fields<N>(s_pex[q], base & uint32_t(N - 1)));
-    const uint32_t st0 = q == 1 ? a.block_start[b] : (a.sub_state[g0 + q - 2] & ST_MASK);
-    uint32_t idx = base + s_first[q]; // absolute index of the next symbol
-    GlobalCursor c;
-    gc_open(c, a, b, q, st0 & ST_OFF_MASK, last_block);
-    bool ok = !(st0 & ST_ERR);
-    uint2 E = make_uint2(0, 0), F = make_uint2(0, 0);
-    // `skip` symbols up to the row start, then the N symbols of its first MCU
-    if (LJ_ABLATE & 64u)
-      skip = 0;
-    for (uint32_t n = 0; ok && n < skip + uint32_t(N); ++n) {
-      if (n == skip)
-        E = P;
-      if (!gc_normalise(c, a)) {
-        ok = false;
-        break;
-      }
-      const uint32_t ph = idx & uint32_t(N - 1);
-      const uint32_t w = lj_window(c.B, int(c.slot), c.pos);
-      const uint32_t e = lj_entry_global(w, tabs + (multi ? S.tab_of_phase[ph] : 0));
-      if (e == 0u) {
-        ok = false;
-        break;
-      }
-      const uint32_t d = lj_extend(w, e);
-      const uint32_t t = d << (16u * (ph & 1u));
-      P = (ph & 2u) ? make_uint2(P.x, pk_add(P.y, t)) : make_uint2(pk_add(P.x, t), P.y);
-      c.pos += e >> 10;
-      ++idx;
+    const uint32_t ph = idx % nd;
+    const uint32_t w = walk_window(c, a, st);
+    const uint32_t e = lj_entry_global(w, tabs + (multi ? S.tab_of_phase[ph] : 0));
+    if (e == 0u) {
+      ok = false;
+      break;
     }
-    F = P;
-    // (a stream in error never shows its pixels: the values do not matter then)
-    a.row_edge[uint64_t(S.first_row) + r] = make_uint4(E.x, E.y, F.x, F.y);
+    const uint32_t d = lj_extend(w, e);
+    const uint32_t v = d << (16u * (ph & 1u));
+    P = (ph & 2u) ? make_uint2(P.x, pk_add(P.y, v)) : make_uint2(pk_add(P.x, v), P.y);
+    c.pos += e >> 10;
+    ++idx;
   }
+  // (a stream in error never shows its pixels: the values do not matter then)
+  a.row_edge[uint64_t(S.first_row) + r] = make_uint4(E.x, E.y, P.x, P.y);
 }
 
 // ---------------------------------------------------------------------------
@@ -465,9 +498,16 @@ __global__ __launch_bounds__(LJ_T, RSX_K4D_MIN_WAVES) void lj_decode_direct_kern
   const DecodeParams dp = lj_params(S);
   const uint32_t g0 = S.first_subseq + lb * LJ_OWN;
   const uint32_t gsub = g0 + uint32_t(j - 1);
-  uint32_t my_rec, before;
-  uint2 pex;
-  lj_lane_prefix<N>(a, gsub, j, L.misc, my_rec, before, pex); // barriers: image + tables complete
+  // the lane's records: symbols and running sums P before its slot (both inside the
+  // workgroup; left by the synchronisation kernels)
+  uint32_t my_rec = 0, before = 0;
+  uint2 pex = make_uint2(0, 0);
+  if (j >= 1) {
+    my_rec = a.sub_state[gsub];
+    before = a.sub_first[gsub];
+    pex = a.sub_psum[gsub];
+  }
+  __syncthreads(); // image + tables complete
   const uint32_t my_count = my_rec >> 16, my_exit = my_rec & ST_MASK;
   uint32_t my_start = 0;
   if (j >= 1)
@@ -684,12 +724,11 @@ void ljpeg_launch_direct(const LjArgs& a, const DirectLaunch& d, hipStream_t s,
   const bool n1 = d.present[0][1] || d.present[1][1];
   const bool n2 = d.present[0][2] || d.present[1][2];
   const bool n4 = d.present[0][4] || d.present[1][4];
-  if (n1)
-    hipLaunchKernelGGL((lj_rowedge_kernel<1>), dim3(d.total_blocks), dim3(LJ_T), 0, s, a);
-  if (n2)
-    hipLaunchKernelGGL((lj_rowedge_kernel<2>), dim3(d.total_blocks), dim3(LJ_T), 0, s, a);
-  if (n4)
-    hipLaunchKernelGGL((lj_rowedge_kernel<4>), dim3(d.total_blocks), dim3(LJ_T), 0, s, a);
+  (void)n1;
+  (void)n2;
+  (void)n4;
+  hipLaunchKernelGGL(lj_rowedge_kernel, dim3((d.total_rows + RE_T - 1) / RE_T), dim3(RE_T), 0,
+                     s, a);
   if (timer)
     timer->mark("lj_rowedge_kernel");
   hipLaunchKernelGGL(lj_rowoff_kernel, dim3(d.n_streams), dim3(VS_T), 0, s, a);
