@@ -286,19 +286,21 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
 
 
 // Entry of the symbol that starts at `pos` (0 = invalid code); *w_out = its window.
-template <bool MULTI, bool PAIR = false>
+// REVBW: layout of the image (lj_window).
+template <bool MULTI, bool PAIR, int REVBW>
 __device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp, int col,
                                             uint32_t pos, uint32_t phase, bool live,
                                             uint32_t* w_out = nullptr) {
-  const uint32_t w = lj_window(L.B, col, pos);
+  const uint32_t w = lj_window<REVBW>(L.B, col, pos);
   if (w_out)
     *w_out = w;
   const TabLds& tb = lj_table<MULTI>(L, dp, phase);
-  const uint32_t e = lj_entry(w, tb, live);
+  const uint32_t e = lj_entry(w, tb, live, dp.long_codes);
   if (PAIR) {
     // HasselbladDecompressor.cpp:87-92: two length codes, then the two bit fields.
     // The step covers the whole pair: advance = both codes + both fields (<= 64).
-    const uint32_t e2 = lj_entry(lj_window(L.B, col, pos + (e & 31u)), tb, live && e != 0u);
+    const uint32_t e2 = lj_entry(lj_window<REVBW>(L.B, col, pos + (e & 31u)), tb,
+                                 live && e != 0u, dp.long_codes);
     return (e != 0u && e2 != 0u) ? ((((e >> 10) + (e2 >> 10)) << 10) | 1u) : 0u;
   }
   return e;
@@ -311,7 +313,7 @@ __device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp
 // the hot loop).  With one shared table the component phase does not influence the
 // parse, so it is left out of the state (it would never self-synchronise); with
 // several tables it is part of what has to match.
-template <bool MULTI, int NS, bool PAIR = false>
+template <bool MULTI, int NS, bool PAIR, int REVBW>
 __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams& dp,
                                                int col, uint32_t start,
                                                uint32_t end_bits, uint32_t& exit,
@@ -329,7 +331,7 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
   while (__any(pos < end_bits)) {
     const bool live = pos < end_bits;
     uint32_t w;
-    const uint32_t e = lj_step<MULTI, PAIR>(L, dp, col, pos, phase, live, &w);
+    const uint32_t e = lj_step<MULTI, PAIR, REVBW>(L, dp, col, pos, phase, live, &w);
     const bool bad = live && e == 0u;
     const bool good = live && !bad;
     if (NS)
@@ -355,7 +357,7 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
 // arbitrary bit position; Huffman streams self-synchronise within a few
 // symbols, so the position at which this runs into slot j is almost always the
 // true one.  (Checked against the predecessor's real exit afterwards.)
-template <bool MULTI, bool PAIR = false>
+template <bool MULTI, bool PAIR, int REVBW>
 __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& dp,
                                               int j) {
   // j == 0 has no predecessor slot in LDS: it takes no steps (`enabled` false)
@@ -363,7 +365,7 @@ __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& 
   const uint32_t prev_bits = enabled ? L.ob[j - 1] : 0u;
   const uint32_t from = prev_bits > LJ_WARM ? prev_bits - LJ_WARM : 0u;
   uint32_t e = 0, c = 0;
-  lj_decode_span<MULTI, 0, PAIR>(L, dp, enabled ? j - 1 : 0, 0u, prev_bits, e, c, nullptr,
+  lj_decode_span<MULTI, 0, PAIR, REVBW>(L, dp, enabled ? j - 1 : 0, 0u, prev_bits, e, c, nullptr,
                                  enabled && prev_bits != 0, from);
   return (e & ST_ERR) ? 0u : e;
 }
@@ -437,9 +439,10 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     atomicAdd(&a.results[s].stat_stitch, 1u);
 #endif
   lj_stage_tables(L, a, S);
-  lj_load_image<BWK>(L, a, b, j); // ends with a barrier
+  lj_load_image<BWK, true>(L, a, b, j); // ends with a barrier (tables complete, too)
   const uint32_t own_bits = L.ob[j];
-  const DecodeParams dp = lj_params(S);
+  DecodeParams dp = lj_params(S);
+  dp.long_codes = lj_long_codes(L, S.n_tables);
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1); // j >= 1
 
   // initial decode / initial records
@@ -450,12 +453,12 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     // known start state; every other slot decodes from its warm-up guess
     // (slot 0 of later workgroups from bit 0)
     const bool real_slot = !(lb == 0 && j == 0);
-    const uint32_t guess = (LJ_ABLATE & 16u) ? 0u : lj_warmup<MULTI, PAIR>(L, dp, j);
+    const uint32_t guess = (LJ_ABLATE & 16u) ? 0u : lj_warmup<MULTI, PAIR, BWK>(L, dp, j);
     if (j >= 2 || (j == 1 && lb > 0))
       start = guess;
     else if (j == 1)
       start = S.start_bit; // the stream's first symbol
-    lj_decode_span<MULTI, NS, PAIR>(L, dp, j, start, own_bits, e, c, &sums,
+    lj_decode_span<MULTI, NS, PAIR, BWK>(L, dp, j, start, own_bits, e, c, &sums,
                                     real_slot && !(LJ_ABLATE & 4u));
     if (!real_slot) {
       e = S.start_bit;
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       // parses in lock step costs two steps per symbol while the slowest of the few
       // lanes of a round still runs to the end of its slot: 0.625 vs 0.596 ms per 8
       // cfg-3 frames.)
-      lj_decode_span<MULTI, NS, PAIR>(L, dp, int(idx), w, L.ob[idx], e, c, &sums, mine);
+      lj_decode_span<MULTI, NS, PAIR, BWK>(L, dp, int(idx), w, L.ob[idx], e, c, &sums, mine);
     }
     __syncthreads(); // every read of the records precedes the updates
     if (uint32_t(j) < n) {
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(LJ_T) void lj_transfer_kernel(LjArgs a) {
   uint32_t state = off | (phase << ST_PHASE_SHIFT);
   for (int slot = 1; slot < LJ_T; ++slot) {
     uint32_t e = ST_ERR, c = 0;
-    lj_decode_span<MULTI, 0, PAIR>(L, dp, slot, state, ob32[slot], e, c, nullptr, enabled);
+    lj_decode_span<MULTI, 0, PAIR, 0>(L, dp, slot, state, ob32[slot], e, c, nullptr, enabled);
     state = e;
   }
   if (enabled)
@@ -839,7 +842,8 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
 
   lj_stage_tables(L, a, S);
   lj_load_image<LJ_BW_DEC>(L, a, b, j); // ends with a barrier
-  const DecodeParams dp = lj_params(S);
+  DecodeParams dp = lj_params(S);
+  dp.long_codes = lj_long_codes(L, S.n_tables);
 
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1);
   uint32_t my_start = 0, my_count = 0, my_exit = 0;
@@ -905,7 +909,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
     for (int q = 0; q < 8; ++q) {
       const bool live = 8 * g + q < remaining;
       const uint32_t w = r.head();
-      const uint32_t e = lj_entry(w, lj_table<MULTI>(L, dp, phase), live);
+      const uint32_t e = lj_entry(w, lj_table<MULTI>(L, dp, phase), live, dp.long_codes);
       r.advance(L.B, j, live ? (e >> 10) : 0u);
       if (MULTI)
         phase = live ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
@@ -1089,7 +1093,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_pair_kernel(LjArgs a) {
     const uint32_t target = uint32_t(needed - 1 - first);
     uint32_t p2 = my_start & ST_OFF_MASK;
     for (uint32_t t = 0; t < target; ++t)
-      p2 += lj_step<false, true>(L, dp, j, p2, 0u, true) >> 10;
+      p2 += lj_step<false, true, 0>(L, dp, j, p2, 0u, true) >> 10;
     a.results[s].last_slot = lb * LJ_OWN + uint32_t(j - 1);
     a.results[s].last_pos = p2;
   }

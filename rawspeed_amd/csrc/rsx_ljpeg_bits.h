@@ -78,8 +78,10 @@ __device__ __forceinline__ uint64_t lj_data_end(const LjStreamDev& S) {
 }
 
 // Load the first BW dword rows of the workgroup's un-stuffed image (K0's output)
-// into LDS, plus ob[].  Ends with a workgroup barrier.
-template <int BW = LJ_BW>
+// into LDS, plus ob[].  REV: dword row k goes to LDS row BW-1-k -- the window reader
+// of the synchronisation kernels then finds the two dwords of a window in the order
+// of a 64-bit register pair (lj_window).  Ends with a workgroup barrier.
+template <int BW = LJ_BW, bool REV = false>
 __device__ __forceinline__ void lj_load_image(const Lds& L, const LjArgs& a, uint32_t b,
                                               int j) {
   const uint4* __restrict__ src = a.unstuffed + size_t(b) * LJ_IMG_U4;
@@ -89,6 +91,8 @@ __device__ __forceinline__ void lj_load_image(const Lds& L, const LjArgs& a, uin
   // are wanted (a register array here ends up in scratch; copy in groups of three)
   constexpr int n4 = BW * LJ_T / 4;
   auto want = [&](int i) { return BW == LJ_BW || i < n4; };
+  // uint4 i of the image = dwords 4 * (i % 64) .. of row i / 64
+  auto at = [&](int i) { return REV ? (BW - 1 - (i >> 6)) * (LJ_T / 4) + (i & 63) : i; };
 #pragma unroll
   for (int h = 0; h < LJ_BW / 4; h += 3) {
     const int i0 = h * LJ_T + j, i1 = i0 + LJ_T, i2 = i1 + LJ_T;
@@ -100,21 +104,32 @@ __device__ __forceinline__ void lj_load_image(const Lds& L, const LjArgs& a, uin
     if (h + 2 < LJ_BW / 4 && want(i2))
       t2 = src[i2];
     if (want(i0))
-      dst[i0] = t0;
+      dst[at(i0)] = t0;
     if (h + 1 < LJ_BW / 4 && want(i1))
-      dst[i1] = t1;
+      dst[at(i1)] = t1;
     if (h + 2 < LJ_BW / 4 && want(i2))
-      dst[i2] = t2;
+      dst[at(i2)] = t2;
   }
   L.ob[j] = uint16_t(ob);
   __syncthreads();
 }
 
-// The 32 stream bits at bit position `pos` of slot `col` (column stride STRIDE).
-template <int STRIDE = LJ_T>
+// The 32 stream bits at bit position `pos` of slot `col`.  REVBW != 0: the image lies
+// in LDS with its REVBW dword rows reversed (lj_load_image<REVBW, true>): dword wi + 1
+// then sits one row BELOW dword wi, a ds_read2st64 delivers (d1, d0) as the low and
+// high half of a register pair and the 64-bit shift needs no moves.
+template <int REVBW = 0>
 __device__ __forceinline__ uint32_t lj_window(const uint32_t* B, int col, uint32_t pos) {
   const uint32_t wi = pos >> 5;
-  const uint32_t d0 = B[wi * STRIDE + col], d1 = B[(wi + 1) * STRIDE + col];
+  uint32_t d0, d1;
+  if (REVBW) {
+    const uint32_t r1 = uint32_t(REVBW - 2) - wi; // row of dword wi + 1
+    d1 = B[r1 * LJ_T + col];
+    d0 = B[(r1 + 1) * LJ_T + col];
+  } else {
+    d0 = B[wi * LJ_T + col];
+    d1 = B[(wi + 1) * LJ_T + col];
+  }
   return uint32_t((((uint64_t(d0) << 32) | d1) << (pos & 31u)) >> 32);
 }
 
@@ -140,9 +155,11 @@ __device__ __noinline__ uint32_t lj_slow_entry(uint32_t w, const TabLds* tb) {
 // out-of-line search only runs when some live lane missed the LUT (codes longer
 // than LUT_BITS are rare, and never occur with the short tables real files use),
 // so the common path has no divergent control flow at all.
-__device__ __forceinline__ uint32_t lj_entry(uint32_t w, const TabLds& tb, bool live) {
+// long_codes (wave-uniform): the stream's tables have codes longer than the LUT at all.
+__device__ __forceinline__ uint32_t lj_entry(uint32_t w, const TabLds& tb, bool live,
+                                             bool long_codes = true) {
   uint32_t e = tb.lut[w >> (32 - LUT_BITS)];
-  if (__builtin_expect(__any(live && (e & 31u) == 0u), 0)) {
+  if (long_codes && __builtin_expect(__any(live && (e & 31u) == 0u), 0)) {
     if (live && (e & 31u) == 0u)
       e = lj_slow_entry(w, &tb);
   }
@@ -161,9 +178,12 @@ __device__ __forceinline__ uint32_t lj_entry_global(uint32_t w, const TabLds* tb
 // AbstractPrefixCodeDecoder.h:55-76), as 16 bits: w = the symbol's window, e its entry.
 __device__ __forceinline__ uint32_t lj_extend(uint32_t w, uint32_t e) {
   const uint32_t cl = e & 31u, ssss = (e >> 5) & 31u;
-  const uint32_t v = uint32_t((uint64_t(w << cl) << ssss) >> 32);
-  const uint32_t half = (1u << ssss) >> 1;
-  uint32_t diff = v >= half ? v : v + 1u - (1u << ssss);
+  const uint32_t x = w << cl;                    // the SSSS difference bits, top-aligned
+  const uint32_t v = (x >> 1) >> (31u - ssss);   // (SSSS = 0: nothing)
+  // a leading 0 bit means a negative difference: v - (2^SSSS - 1)
+  const uint32_t all = (1u << ssss) - 1u;
+  const uint32_t neg = ~uint32_t(int32_t(x) >> 31);
+  uint32_t diff = v - (all & neg);
   diff = ssss == 16u ? 0x8000u : diff;
   return diff & 0xFFFFu;
 }
@@ -172,6 +192,7 @@ __device__ __forceinline__ uint32_t lj_extend(uint32_t w, uint32_t e) {
 struct DecodeParams {
   uint32_t period;
   uint64_t tabmap; // byte p = table slot of phase p
+  bool long_codes; // some table has codes longer than the LUT (default: assume so)
 };
 
 __device__ __forceinline__ DecodeParams lj_params(const LjStreamDev& S) {
@@ -182,6 +203,7 @@ __device__ __forceinline__ DecodeParams lj_params(const LjStreamDev& S) {
   for (int i = 0; i < 8; ++i)
     m |= uint64_t(S.tab_of_phase[i]) << (8 * i);
   d.tabmap = m;
+  d.long_codes = true;
   return d;
 }
 
@@ -220,6 +242,15 @@ struct BitReader {
   }
   __device__ __forceinline__ uint32_t head() const { return uint32_t(buf >> 32); }
 };
+
+// whether any of the stream's n tables (staged in LDS) has codes longer than the LUT
+// (wave-uniform)
+__device__ __forceinline__ bool lj_long_codes(const Lds& L, uint32_t n_tables) {
+  uint32_t m = 0;
+  for (uint32_t t = 0; t < n_tables; ++t)
+    m = max(m, uint32_t(L.tabs[t].max_len));
+  return __builtin_amdgcn_readfirstlane(int(m)) > LUT_BITS;
+}
 
 template <bool MULTI>
 __device__ __forceinline__ const TabLds& lj_table(const Lds& L, const DecodeParams& dp,

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(LJ_T, RSX_K4D_MIN_WAVES) void lj_decode_direct_kern
         dst[i] = t[h];
     }
   }
-  const DecodeParams dp = lj_params(S);
+  DecodeParams dp = lj_params(S);
   const uint32_t g0 = S.first_subseq + lb * LJ_OWN;
   const uint32_t gsub = g0 + uint32_t(j - 1);
   // the lane's records: symbols and running sums P before its slot (both inside the
@@ -508,6 +508,7 @@ __global__ __launch_bounds__(LJ_T, RSX_K4D_MIN_WAVES) void lj_decode_direct_kern
     pex = a.sub_psum[gsub];
   }
   __syncthreads(); // image + tables complete
+  dp.long_codes = lj_long_codes(L, S.n_tables);
   const uint32_t my_count = my_rec >> 16, my_exit = my_rec & ST_MASK;
   uint32_t my_start = 0;
   if (j >= 1)
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(LJ_T, RSX_K4D_MIN_WAVES) void lj_decode_direct_kern
     for (int q = 0; q < 8; ++q) {
       const bool live = 8 * g + q < remaining;
       const uint32_t w = r.head();
-      const uint32_t e = lj_entry(w, lj_table<MULTI>(L, dp, phase), live);
+      const uint32_t e = lj_entry(w, lj_table<MULTI>(L, dp, phase), live, dp.long_codes);
       r.advance(L.B, j, live ? (e >> 10) : 0u);
       if (MULTI)
         phase = live ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
