@@ -485,8 +485,15 @@ __global__ __launch_bounds__(LJ_T, RSX_K4D_MIN_WAVES) void lj_decode_direct_kern
     for (int h = 0; h < n_it; ++h) {
       const int i = h * LJ_T + j;
       t[h] = make_uint4(0, 0, 0, 0);
-      if (i < n4)
+      if (i < n4) {
+#ifdef RSX_K4D_NT_LOADS
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src + i));
+        t[h] = make_uint4(q.x, q.y, q.z, q.w);
+#else
         t[h] = src[i];
+#endif
+      }
     }
 #pragma unroll
     for (int h = 0; h < n_it; ++h) {

@@ -8,6 +8,7 @@ OUT=$REPO/gpurun_out/pmc_lj_traffic
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/plt_$c
   rocprofv3 --pmc $c --output-format csv -d /tmp/plt_$c -- \
     python $REPO/bench_ljpeg.py --only cfg3 --frames 8 --steps 2 > /dev/null 2>&1
   cp $(find /tmp/plt_$c -name "*counter_collection.csv" | head -1) $OUT/ljpeg_pmc_$c.csv
