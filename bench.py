@@ -11,23 +11,32 @@ the 256 MiB Infinity Cache on purpose, so the rate is an HBM rate.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
 
-N>1: one process per GPU (torchrun), every rank decodes its own shard of
-independent frames (weak scaling, no data-path collective; RCCL is used for the
-barrier / max-reduction of the timing and, with --broadcast, to distribute the
-packed buffer from rank 0 over xGMI, timed separately).
+N > 1: one process per GPU.  Started under a launcher (torchrun: WORLD_SIZE set) the
+process is one rank; started bare, `--gpus N` re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` on 127.0.0.1.  Every rank decodes
+its own shard of independent frames -- weak scaling for the headline leg, no data-path
+collective; RCCL carries the barrier / max-reduction of the timing and, for the
+batched-LJPEG leg (BASELINE configs[4]: 256 frames sharded with dist.shard_range over
+the ranks), optionally the distribution of the packed batch from rank 0
+(--broadcast: one RCCL broadcast of the whole batch; --scatter: grouped send/recv of
+each rank's shard), timed separately from the decode.
 
 Rank 0 prints ONE JSON line.  At N=1 it also carries
   roofline      -- dominant kernel: algorithmic bytes / hipEvent-measured launch time,
                    plus the measured copy ceiling of the device for the same bytes
   cpu_baseline  -- the unmodified reference (oracle/_ref) timed on this host's cores
-  extra         -- the other legs measured the same way (bench_ljpeg.py): the LJPEG
-                   configs (cfg 3 / cfg 4 / cfg 5), the fixed-layout unpack entry
-                   points, Canon sRaw + Cr2sRawInterpolator, Nikon, Hasselblad, Sony ARW1
+  extra         -- the other legs measured the same way (bench_ljpeg.py): configs[0]
+                   (12-bit LSB 4096x3072), single-frame latency of configs[1], the LJPEG
+                   configs (cfg 3 / cfg 4 / cfg 5) with their own CPU baselines, the
+                   fixed-layout unpack entry points, Canon sRaw + Cr2sRawInterpolator,
+                   Nikon, Hasselblad, Sony ARW1
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,7 +48,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); ~6300 achievable
 
-CFG2 = dict(w=8192, h=5464, bps=14, order=1)  # BitOrder::MSB
+CFG1 = dict(w=4096, h=3072, bps=12, order=0)  # BASELINE configs[0]: BitOrder::LSB
+CFG2 = dict(w=8192, h=5464, bps=14, order=1)  # BASELINE configs[1]: BitOrder::MSB
+CFG5_TOTAL_FRAMES = 256                       # BASELINE configs[4]
 
 
 def log(*a):
@@ -56,33 +67,55 @@ def parse():
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--no-cfg5", action="store_true",
                     help="skip the batched-LJPEG-frames leg (BASELINE configs[4])")
-    ap.add_argument("--cfg5-frames", type=int, default=32, help="LJPEG frames per GPU")
+    ap.add_argument("--cfg5-total-frames", type=int, default=CFG5_TOTAL_FRAMES,
+                    help="frames of the whole LJPEG batch, sharded over the ranks")
     ap.add_argument("--broadcast", action="store_true",
-                    help="N>1: rank 0 synthesises the packed batch and broadcasts it over RCCL")
+                    help="cfg 5: rank 0 holds the packed batch and broadcasts it over RCCL")
+    ap.add_argument("--scatter", action="store_true",
+                    help="cfg 5: rank 0 holds the packed batch and sends every rank its shard")
     return ap.parse_args()
 
 
-def out_pitch():
-    return (CFG2["w"] * 2 + 15) // 16 * 16  # RawImageData pitch (RawImage.cpp:80-83)
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
-def make_frames(frames, seed0):
-    """Packed strips of `frames` uniform-random 14-bit frames (+ frame 0's pixels)."""
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: one rank per GPU under torchrun."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log("bench.py: no launcher in the environment, starting %d ranks: %s"
+        % (args.gpus, " ".join(cmd[1:8])))
+    return subprocess.call(cmd, env=env)
+
+
+def out_pitch(w):
+    return (w * 2 + 15) // 16 * 16  # RawImageData pitch (RawImage.cpp:80-83)
+
+
+def make_frames(cfg, frames, seed0):
+    """Packed strips of `frames` uniform-random frames (+ their pixels)."""
     from rawspeed_amd import synth
-    w, h, bps, order = CFG2["w"], CFG2["h"], CFG2["bps"], CFG2["order"]
-    packed, px0 = [], None
+    w, h, bps, order = cfg["w"], cfg["h"], cfg["bps"], cfg["order"]
+    packed, pxs = [], []
     for f in range(frames):
         px = synth.uniform(w * h, bps, seed0 + f).reshape(h, w)
         packed.append(synth.pack_rows(px, bps, order))
-        if f == 0:
-            px0 = px
-    return np.concatenate(packed), px0
+        pxs.append(px)
+    return np.concatenate(packed), pxs
 
 
-def unpack_jobs(frames):
+def unpack_jobs(cfg, frames):
     from rawspeed_amd import abi
-    w, h, bps, order = CFG2["w"], CFG2["h"], CFG2["bps"], CFG2["order"]
-    pitch, opitch = w * bps // 8, out_pitch()
+    w, h, bps, order = cfg["w"], cfg["h"], cfg["bps"], cfg["order"]
+    pitch, opitch = w * bps // 8, out_pitch(w)
     jobs = []
     for f in range(frames):
         j = abi.UnpackJob()
@@ -95,32 +128,46 @@ def unpack_jobs(frames):
     return jobs
 
 
+def frame_of(out_t, cfg, f):
+    w, h = cfg["w"], cfg["h"]
+    op = out_pitch(w)
+    return out_t[f * h * op:(f + 1) * h * op].cpu().numpy().view(np.uint16) \
+        .reshape(h, op // 2)[:, :w]
+
+
 def pmc_traffic(frames):
-    """HBM bytes per launch from the rocprofv3 PMC passes of this kernel
-    (profiles/r01/unpack_pmc.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
-    --pmc runs of this same command).  bench.py cannot run rocprofv3 on itself,
-    so the committed per-launch measurement is scaled to the batch size."""
-    path = os.path.join(ROOT, "profiles", "r01", "unpack_pmc.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        return int(d["traffic_bytes_per_launch"] * frames / 8)
-    except Exception:
-        return None
+    """HBM bytes per launch of the headline kernel from rocprofv3's PMC passes
+    (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc runs of this same command).
+    bench.py cannot run rocprofv3 on itself: the newest committed per-launch
+    measurement under profiles/ is scaled to the batch size, and the JSON says so."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, "unpack_pmc.json")
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            return (int(d["traffic_bytes_per_launch"] * frames / 8),
+                    "replayed from profiles/%s/unpack_pmc.json (rocprofv3 --pmc FETCH_SIZE / "
+                    "WRITE_SIZE of this command, per launch, scaled to %d frames); not "
+                    "measured in this run" % (rnd, frames))
+        except Exception:
+            continue
+    return None, "no committed PMC measurement found"
 
 
-def cpu_baseline_unpack(packed_frame, budget_s=20.0):
+def cpu_baseline_unpack(cfg, packed_frame, budget_s=20.0, expect=None):
     """The unmodified reference (oracle/_ref) on this host: 1 thread, then
-    independent frames on all cores (the shape of rstest's omp-for over files)."""
+    independent frames on all cores (the shape of rstest's omp-for over files).
+    expect: the pixels the GPU produced for this frame -- the reference must agree."""
     from oracle_lib import Ref
     from rawspeed_amd import abi
     if not Ref.available():
         return None
     ref = Ref()
-    w, h, bps, order = CFG2["w"], CFG2["h"], CFG2["bps"], CFG2["order"]
+    w, h, bps, order = cfg["w"], cfg["h"], cfg["bps"], cfg["order"]
     d = abi.UnpackDesc(0, 0, w, h, w * bps // 8, bps, order)
     img = ref.image(w, h, 1)
     ref.unpack(d, packed_frame, img)  # warm-up / page touch
+    agrees = None if expect is None else bool(np.array_equal(img.pixels(), expect))
     times = []
     t_end = time.perf_counter() + budget_s / 3
     while len(times) < 5 and (time.perf_counter() < t_end or len(times) < 2):
@@ -147,22 +194,151 @@ def cpu_baseline_unpack(packed_frame, budget_s=20.0):
     return {"value": round(multi, 1), "unit": "MPix/s", "cores": nthreads,
             "kind": "reference",
             "single_thread_value": round(single, 1),
-            "sample": "%d x one 8192x5464 14-bit MSB frame on %d threads (best of %d), "
+            "reference_output_equals_gpu_output": agrees,
+            "sample": "%d x one %dx%d %d-bit frame on %d threads (best of %d), "
                       "and 1 frame on 1 thread (best of %d); UncompressedDecompressor::"
                       "readUncompressedRaw of the unmodified reference (oracle/_ref, "
-                      "clang -O3 -march=x86-64-v2)" % (nthreads, nthreads, len(mt), len(times))}
+                      "clang -O3 -march=x86-64-v2)"
+                      % (nthreads, w, h, bps, nthreads, len(mt), len(times))}
+
+
+def time_plan(torch, grp, plan, inp, out, steps, warmup, stream):
+    """max over ranks of the seconds for `steps` launches, bracketed by barriers"""
+    for _ in range(warmup):
+        plan.run(inp.data_ptr(), out.data_ptr(), stream)
+    grp.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.run(inp.data_ptr(), out.data_ptr(), stream)
+    grp.barrier()
+    return grp.max_over_ranks(time.perf_counter() - t0)
+
+
+def small_unpack_leg(ctx, torch, cfg, frames, steps, stream, what, cpu):
+    """one of the secondary uncompressed legs: bit-exact check of every frame + timing"""
+    packed, pxs = make_frames(cfg, frames, 4242)
+    w, h, bps = cfg["w"], cfg["h"], cfg["bps"]
+    inp = torch.from_numpy(packed).cuda()
+    out = torch.empty(frames * h * out_pitch(w), dtype=torch.uint8, device="cuda")
+    plan = ctx.unpack_plan(unpack_jobs(cfg, frames))
+    plan.run(inp.data_ptr(), out.data_ptr(), stream)
+    rc, st, _ = plan.results()
+    exact = rc == 0 and all(np.array_equal(frame_of(out, cfg, f), pxs[f])
+                            for f in range(frames))
+    for _ in range(10):
+        plan.run(inp.data_ptr(), out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.run(inp.data_ptr(), out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    alg = frames * (h * (w * bps // 8) + h * w * 2)
+    res = {"workload": what, "frames_per_step": frames, "ms_per_step": round(dt * 1e3, 4),
+           "mpix_per_s": round(frames * w * h / dt / 1e6, 1), "bit_exact": bool(exact),
+           "algorithmic_bytes_per_step": alg,
+           "achieved_gbps": round(alg / dt / 1e9, 1),
+           "frac_of_hbm_peak": round(alg / dt / 1e9 / HBM_PEAK_GBPS, 4)}
+    if cpu:
+        try:
+            res["cpu_baseline"] = cpu_baseline_unpack(cfg, packed[:h * (w * bps // 8)],
+                                                      budget_s=8.0, expect=pxs[0])
+        except Exception as e:
+            res["cpu_baseline"] = {"error": repr(e)}
+    return res
+
+
+def cfg5_leg(args, ctx, torch, grp, rank, n_gpus, stream):
+    """BASELINE configs[4]: a batch of 256 independent 8192x5464 LJPEG frames sharded over
+    the ranks with dist.shard_range(256, N, rank) -- 32 per GPU on the 8 GPUs of a node,
+    all 256 on one (the batch is fixed: strong scaling for this leg).  The packed batch
+    is either synthesised by every rank for itself or, with --broadcast / --scatter,
+    handed out by rank 0 over RCCL, timed separately from the decode."""
+    import bench_ljpeg
+    from rawspeed_amd import dist as rdist
+    total = args.cfg5_total_frames
+    lo, hi = rdist.shard_range(total, n_gpus, rank)
+    f5 = hi - lo
+    plan5, inp5, out5, meta = bench_ljpeg.make_cfg5_plan(ctx, torch, f5, seed0=1000)
+    dist_info = {"mode": "every rank synthesises its own shard (no exchange)"}
+    if grp.enabled and (args.broadcast or args.scatter):
+        shard_bytes = int(inp5.numel())
+        grp.barrier()
+        t0 = time.perf_counter()
+        if args.broadcast:
+            # rank 0's copy of the whole job's packed batch goes to every rank
+            whole = torch.cat([inp5] * n_gpus) if rank == 0 else \
+                torch.empty(shard_bytes * n_gpus, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            grp.barrier()
+            t0 = time.perf_counter()
+            grp.broadcast_bytes(whole, src=0)
+            torch.cuda.synchronize()
+            grp.barrier()
+            dt = grp.max_over_ranks(time.perf_counter() - t0)
+            inp5 = whole[rank * shard_bytes:(rank + 1) * shard_bytes].clone()
+            moved = shard_bytes * n_gpus
+            del whole
+            mode = "RCCL broadcast of the whole packed batch from rank 0"
+        else:
+            recv = torch.empty_like(inp5)
+            torch.cuda.synchronize()
+            grp.barrier()
+            t0 = time.perf_counter()
+            grp.scatter_shards(inp5, recv, src=0)
+            torch.cuda.synchronize()
+            grp.barrier()
+            dt = grp.max_over_ranks(time.perf_counter() - t0)
+            if rank != 0:
+                inp5 = recv
+            moved = shard_bytes * (n_gpus - 1)
+            mode = "grouped RCCL send/recv: rank 0 sends every other rank its shard"
+        dist_info = {"mode": mode, "ms": round(dt * 1e3, 2), "bytes": moved,
+                     "gbps": round(moved / dt / 1e9, 1)}
+    plan5.run(inp5.data_ptr(), out5.data_ptr(), stream)
+    rc5, st5, cons5 = plan5.results()
+    ref_frames = cpu5 = None
+    if rank == 0 and not args.no_cpu_baseline:
+        k = meta["distinct"]
+        ref_frames, cpu5 = bench_ljpeg.ref_scan_baseline(
+            0, [b[0] for b in meta["blobs"]], [b[1] for b in meta["blobs"]],
+            meta["W"], meta["H"], "LJpegDecompressor::decode")
+    exact5 = rc5 == 0 and bench_ljpeg.check_cfg5(out5, meta, cons5, f5, ref_frames)
+    k5 = 5
+    dt5 = time_plan(torch, grp, plan5, inp5, out5, k5, 2, stream) / k5
+    all_exact = grp.sum_over_ranks(1.0 if exact5 else 0.0) == n_gpus
+    W5, H5 = meta["W"], meta["H"]
+    res = {
+        "workload": "%d independent 8192x5464 LJPEG frames (2 components, predictor 1; "
+                    "BASELINE configs[4]) sharded with shard_range over %d GPU(s): %d on "
+                    "this rank, one plan launch per step" % (total, n_gpus, f5),
+        "scaling": "strong (the batch is %d frames at every N)" % total,
+        "mpix_per_s": round(total * W5 * H5 / dt5 / 1e6, 1),
+        "ms_per_step": round(dt5 * 1e3, 3),
+        "bit_exact": bool(all_exact),
+        "bit_exact_against": "every frame of every rank against its source image"
+                             + (" and oracle/_ref" if ref_frames is not None else ""),
+        "entropy_bits_per_px": round(meta["bits_per_px"], 3),
+        "frames_on_this_rank": f5,
+        "achieved_gbps_whole_pipeline_per_gpu": round(meta["alg_bytes"] / dt5 / 1e9, 1),
+        "frac_of_hbm_peak": round(meta["alg_bytes"] / dt5 / 1e9 / HBM_PEAK_GBPS, 4),
+        "input_distribution": dist_info,
+    }
+    if cpu5:
+        res["cpu_baseline"] = cpu5
+    return res
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     from rawspeed_amd import dist as rdist
     world, rank, local_rank = rdist.env_world()
     torch.cuda.set_device(local_rank)
     grp = rdist.Group(backend="nccl", device=torch.device("cuda", local_rank))
-    distributed = grp.enabled
-    dist = grp.dist if distributed else None
-    n_gpus = world if distributed else 1
+    n_gpus = world if grp.enabled else 1
     if args.gpus != n_gpus and rank == 0:
         log("note: --gpus %d but WORLD_SIZE=%d; using %d" % (args.gpus, world, n_gpus))
 
@@ -173,55 +349,35 @@ def main():
     ctx = capi.Context(local_rank)
     F = args.frames
     w, h, bps = CFG2["w"], CFG2["h"], CFG2["bps"]
-    opitch = out_pitch()
-    jobs = unpack_jobs(F)
-    bcast_ms = None
-    if distributed and args.broadcast:
-        # rank 0 synthesises the batch; everyone receives it over RCCL / xGMI
-        if rank == 0:
-            packed, px0 = make_frames(F, 1000)
-            inp = torch.from_numpy(packed).cuda()
-        else:
-            packed, px0 = None, None
-            inp = torch.empty(F * h * (w * bps // 8), dtype=torch.uint8, device="cuda")
-        torch.cuda.synchronize()
-        dist.barrier()
-        tb = time.perf_counter()
-        dist.broadcast(inp, src=0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - tb) * 1e3
-    else:
-        packed, px0 = make_frames(F, 1000 + 100 * rank)
-        inp = torch.from_numpy(packed).cuda()
+    opitch = out_pitch(w)
+    packed, pxs = make_frames(CFG2, F, 1000 + 100 * rank)
+    inp = torch.from_numpy(packed).cuda()
     out = torch.empty(F * h * opitch, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    plan = ctx.unpack_plan(jobs)
+    plan = ctx.unpack_plan(unpack_jobs(CFG2, F))
 
-    barrier = grp.barrier
-
-    # untimed: first-touch of the buffers, bit-exactness of the path being timed
+    # untimed: first touch of the buffers, bit-exactness of the path being timed --
+    # every frame against the pixels it was packed from (and, at N=1, the reference)
     plan.run(inp.data_ptr(), out.data_ptr(), stream)
     rc, st, _ = plan.results()
     assert rc == 0, (rc, st)
-    bit_exact = None
-    if px0 is not None:
-        got = out[:h * opitch].cpu().numpy().view(np.uint16).reshape(h, opitch // 2)[:, :w]
-        bit_exact = bool(np.array_equal(got, px0))
-        assert bit_exact, "GPU output differs from the packed source"
+    bit_exact = all(np.array_equal(frame_of(out, CFG2, f), pxs[f]) for f in range(F))
+    assert bit_exact, "GPU output differs from the packed source"
     plan.set_timing(True)  # pre-creates the event pool (slow on ROCm) outside the timed region
     plan.set_timing(False)
     for _ in range(args.warmup):
         plan.run(inp.data_ptr(), out.data_ptr(), stream)
     plan.set_timing(True)
-    barrier()
+    grp.barrier()
     t_start = time.perf_counter()
     for _ in range(args.steps):
         plan.run(inp.data_ptr(), out.data_ptr(), stream)
-    barrier()
-    elapsed = time.perf_counter() - t_start
+    grp.barrier()
+    my_elapsed = time.perf_counter() - t_start
     ktime = plan.kernel_time()
     plan.set_timing(False)
-    elapsed = grp.max_over_ranks(elapsed)
+    elapsed = grp.max_over_ranks(my_elapsed)
+    per_rank = grp.gather_objects(round(F * w * h * args.steps / my_elapsed / 1e6, 1), dst=0)
     # copy ceiling for the same read:write mix (outside the timed region): a plain
     # streaming kernel over the very same buffers
     copy_ms = None
@@ -248,58 +404,27 @@ def main():
         "vs_baseline": None,
         "dtype": "u16",
         "data": "synthetic",
-        "bit_exact": bit_exact,
+        "bit_exact": bool(bit_exact),
+        "rccl_ranks": world if grp.enabled else 0,
+        "per_rank_mpix_per_s": per_rank,
         "config": {
             "workload": "UncompressedDecompressor 14-bit packed MSB 8192x5464 "
                         "(BASELINE configs[1]), %d independent frames per GPU per step, "
                         "inputs and outputs resident in HBM" % F,
             "frames_per_gpu": F,
-            "parallelism": "frames sharded across %d GPU(s), no data-path collective"
-                           % n_gpus,
+            "parallelism": "frames sharded across %d GPU(s), one process per GPU, no "
+                           "data-path collective (RCCL: barrier + max-reduction of the "
+                           "timing)" % n_gpus,
         },
     }
-    if bcast_ms is not None:
-        result["config"]["input_broadcast_ms"] = round(bcast_ms, 2)
 
     # BASELINE configs[4]: batch of independent LJPEG frames sharded over the GPUs
-    # (256 frames on 8 GPUs = 32 per GPU; weak scaling, same per-GPU shard at any N)
     cfg5 = None
     if not args.no_cfg5:
         try:
-            import bench_ljpeg
             del out, inp
             torch.cuda.empty_cache()
-            f5 = args.cfg5_frames
-            plan5, inp5, out5, meta = bench_ljpeg.make_cfg5_plan(ctx, torch, f5,
-                                                                 seed0=1000 + 10 * rank)
-            plan5.run(inp5.data_ptr(), out5.data_ptr(), stream)
-            rc5, st5, cons5 = plan5.results()
-            W5, H5 = meta["W"], meta["H"]
-            op5 = bench_ljpeg.out_pitch(W5)
-            got5 = out5[:op5 * H5].cpu().numpy().view(np.uint16).reshape(H5, op5 // 2)[:, :W5]
-            exact5 = bool(rc5 == 0 and np.array_equal(got5, meta["src0"])
-                          and cons5 == meta["lens"])
-            for _ in range(2):
-                plan5.run(inp5.data_ptr(), out5.data_ptr(), stream)
-            barrier()
-            t5 = time.perf_counter()
-            k5 = 5
-            for _ in range(k5):
-                plan5.run(inp5.data_ptr(), out5.data_ptr(), stream)
-            barrier()
-            dt5 = grp.max_over_ranks((time.perf_counter() - t5) / k5)
-            all_exact = grp.sum_over_ranks(1.0 if exact5 else 0.0) == n_gpus
-            cfg5 = {
-                "workload": "%d independent 8192x5464 LJPEG frames per GPU (2 components, "
-                            "predictor 1), %d GPU(s), one plan launch per step" % (f5, n_gpus),
-                "mpix_per_s": round(n_gpus * f5 * W5 * H5 / dt5 / 1e6, 1),
-                "ms_per_step": round(dt5 * 1e3, 3),
-                "bit_exact": bool(all_exact),
-                "entropy_bits_per_px": round(meta["bits_per_px"], 3),
-                "achieved_gbps_whole_pipeline_per_gpu": round(meta["alg_bytes"] / dt5 / 1e9, 1),
-                "frac_of_hbm_peak": round(meta["alg_bytes"] / dt5 / 1e9 / HBM_PEAK_GBPS, 4),
-            }
-            del plan5, inp5, out5
+            cfg5 = cfg5_leg(args, ctx, torch, grp, rank, n_gpus, stream)
         except Exception as e:  # the headline number must survive
             cfg5 = {"error": repr(e)}
 
@@ -308,11 +433,12 @@ def main():
         if ktime:
             name, avg_ms, n = ktime
             achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+            traffic, source = pmc_traffic(F)
             result["roofline"] = {
                 "bound": "hbm", "kernel": name,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": pmc_traffic(F),
+                "traffic": traffic, "traffic_source": source,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_kernel_ms": round(avg_ms, 5), "launches_timed": n,
             }
@@ -325,15 +451,28 @@ def main():
                             "buffers (same bytes in, same bytes out)",
                 }
         if not args.no_extra:
+            extra = {}
+            try:
+                extra["cfg1_12bit_lsb_4096x3072"] = small_unpack_leg(
+                    ctx, torch, CFG1, 8, 50, stream,
+                    "UncompressedDecompressor 12-bit packed LSB 4096x3072 (BASELINE "
+                    "configs[0]), 8 frames per step", not args.no_cpu_baseline)
+                extra["cfg2_single_frame_latency"] = small_unpack_leg(
+                    ctx, torch, CFG2, 1, 200, stream,
+                    "one 8192x5464 14-bit MSB frame per launch (latency of a single "
+                    "decode; 168 MB fit the Infinity Cache)", False)
+            except Exception as e:
+                extra["unpack_legs_error"] = repr(e)
             try:
                 import bench_ljpeg
-                result["extra"] = bench_ljpeg.run(ctx, torch, log)
+                extra.update(bench_ljpeg.run(ctx, torch, log))
             except Exception as e:  # the headline number must survive
-                result["extra"] = {"error": repr(e)}
+                extra["error"] = repr(e)
+            result["extra"] = extra
         if not args.no_cpu_baseline:
             try:
                 result["cpu_baseline"] = cpu_baseline_unpack(
-                    packed[:h * (w * bps // 8)])
+                    CFG2, packed[:h * (w * bps // 8)], expect=pxs[0])
             except Exception as e:
                 result["cpu_baseline"] = {"error": repr(e)}
     if cfg5 is not None:

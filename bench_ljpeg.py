@@ -43,18 +43,76 @@ def make_cr2_frame(W, H, slices, seed):
     return d, data, src, len(scan), bits
 
 
-def make_tile(src_tile, tx, ty, tw, th):
+def make_tile(src_tile, tx, ty, tw, th, rows_per_ri=0, want_blob=False):
+    """One DNG-style tile: SOF3 (tw/2) x th, 2 components, predictor 1.  Returns the
+    descriptor + entropy-coded scan for the C-ABI and (want_blob) the whole SOI..EOI
+    container for AbstractDngDecompressor."""
     from rawspeed_amd import abi, synth
-    scan, bits = synth.ljpeg_encode_scan(np.ascontiguousarray(src_tile), 2, [1 << 13] * 2,
-                                         [_nikon(), _nikon()])
+    blob, nh, scan_len, bits = synth.ljpeg_container(np.ascontiguousarray(src_tile), 2, 14,
+                                                     [0, 0], [_nikon()],
+                                                     rows_per_ri=rows_per_ri)
     d = abi.LJpegDesc()
     d.tile_x, d.tile_y, d.tile_w, d.tile_h = tx, ty, tw, th
     d.mcu_w, d.mcu_h, d.frame_w, d.frame_h = 2, 1, tw // 2, th
-    d.n_comp, d.rows_per_restart_interval = 2, th
+    d.n_comp, d.rows_per_restart_interval = 2, rows_per_ri if rows_per_ri else th
     abi.fill_recipe(d, synth.huff_tables(_nikon()), [0, 0], [1 << 13] * 2)
-    pad = (-(len(scan) + 2)) % 16 + 16
-    data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), np.zeros(pad, np.uint8)])
-    return d, data, len(scan), bits
+    pad = (-(scan_len + 2)) % 16 + 16
+    data = np.concatenate([blob[nh:nh + scan_len + 2], np.zeros(pad, np.uint8)])
+    if want_blob:
+        return d, data, scan_len, bits, blob
+    return d, data, scan_len, bits
+
+
+def gpu_frame(out_t, f, W, H):
+    """frame f of a batch output tensor as a (H, W) uint16 array"""
+    op = out_pitch(W)
+    return out_t[f * op * H:(f + 1) * op * H].cpu().numpy().view(np.uint16) \
+        .reshape(H, op // 2)[:, :W]
+
+
+def host_threads(ref):
+    return max(1, min(os.cpu_count() or 1, ref.lib.ref_max_threads()))
+
+
+def ref_scan_baseline(kind, descs, datas, W, H, what, budget_s=8.0):
+    """The unmodified reference on this host: one frame on one thread
+    (the decoders have no threading of their own) and N frames on N cores (one frame
+    per OpenMP thread, the shape of rstest.cpp:570).  Returns (the decoded distinct
+    frames, the cpu_baseline dict)."""
+    from oracle_lib import Ref
+    if not Ref.available():
+        return None, None
+    ref = Ref()
+    n = len(descs)
+    imgs = [ref.image(W, H, 1) for _ in range(n)]
+    one = []
+    for k in range(n):
+        t0 = time.perf_counter()
+        st, _ = (ref.ljpeg if kind == 0 else ref.cr2)(descs[k], datas[k], imgs[k])
+        one.append(time.perf_counter() - t0)
+        assert st == 0, ref.last_error()
+    frames = [i.pixels().copy() for i in imgs]
+    nt = host_threads(ref)
+    pimgs = imgs + [ref.image(W, H, 1) for _ in range(nt - n)] if nt > n else imgs[:nt]
+    pd = [descs[k % n] for k in range(len(pimgs))]
+    pdata = [datas[k % n] for k in range(len(pimgs))]
+    ref.scan_frames_parallel(pimgs, pd, pdata, kind, nt)  # page touch
+    best, t_end = None, time.perf_counter() + budget_s
+    reps = 0
+    while reps < 3 or (reps < 5 and time.perf_counter() < t_end):
+        t0 = time.perf_counter()
+        st = ref.scan_frames_parallel(pimgs, pd, pdata, kind, nt)
+        dt = time.perf_counter() - t0
+        assert st == 0
+        best = dt if best is None else min(best, dt)
+        reps += 1
+    cpu = {"value": round(len(pimgs) * W * H / best / 1e6, 1), "unit": "MPix/s",
+           "cores": nt, "kind": "reference",
+           "single_thread_value": round(W * H / min(one) / 1e6, 1),
+           "sample": "%s of the unmodified reference (oracle/_ref): %d frames on %d "
+                     "threads, one frame per thread (best of %d); single_thread_value = "
+                     "one frame on one thread" % (what, len(pimgs), nt, reps)}
+    return frames, cpu
 
 
 LAST_KERNEL_TABLE = None  # per-kernel averages (ms per run) of the last _time_plan call
@@ -97,13 +155,28 @@ def _dominant(res, kt):
         res["kernels_ms"] = dict(LAST_KERNEL_TABLE)
 
 
-def run_cfg3(ctx, torch, log, frames=8, steps=10, warmup=2):
-    """configs[2]: CR2-style 6720x4480, 2 components, 3 slices; `frames` frames/step."""
+def _lj_result(workload, frames, W, H, dt, scan_bytes, exact, kt, extra=None):
+    alg = scan_bytes + frames * W * H * 2
+    res = {
+        "workload": workload,
+        "mpix_per_s": round(frames * W * H / dt / 1e6, 1),
+        "ms_per_step": round(dt * 1e3, 4),
+        "bit_exact": exact,
+        "entropy_bits_per_px": round(scan_bytes * 8 / (frames * W * H), 3),
+        "algorithmic_bytes_per_step": alg,
+        "achieved_gbps_whole_pipeline": round(alg / dt / 1e9, 1),
+        "frac_of_hbm_peak": round(alg / dt / 1e9 / 8000.0, 4),
+    }
+    if extra:
+        res.update(extra)
+    _dominant(res, kt)
+    return res
+
+
+def _cr2_batch(ctx, torch, frames_desc, W, H):
     from rawspeed_amd import abi
-    W, H = 6720, 4480
-    d, data, src, scan_len, bits = make_cr2_frame(W, H, (3, 2240, 2240), seed=1)
-    jobs, off = [], 0
-    for f in range(frames):
+    jobs, off, parts = [], 0, []
+    for f, (d, data) in enumerate(frames_desc):
         j = abi.Cr2Job()
         j.desc = d
         j.in_offset, j.in_bytes = off, data.size
@@ -111,26 +184,115 @@ def run_cfg3(ctx, torch, log, frames=8, steps=10, warmup=2):
         j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
             out_pitch(W), W, H, 1, 1
         jobs.append(j)
+        parts.append(data)
         off += data.size
-    inp = torch.from_numpy(np.tile(data, frames)).cuda()
-    out = torch.zeros(frames * out_pitch(W) * H, dtype=torch.uint8, device="cuda")
-    plan = ctx.cr2_plan(jobs)
+    inp = torch.from_numpy(np.concatenate(parts)).cuda()
+    out = torch.zeros(len(frames_desc) * out_pitch(W) * H, dtype=torch.uint8, device="cuda")
+    return ctx.cr2_plan(jobs), inp, out
+
+
+def run_cfg3(ctx, torch, log, frames=8, steps=10, warmup=2, cpu=True):
+    """configs[2]: CR2-style 6720x4480, 2 components, 3 slices; `frames` DIFFERENT
+    frames per step (seeds 1..frames), every one compared with the reference build."""
+    W, H = 6720, 4480
+    made = [make_cr2_frame(W, H, (3, 2240, 2240), seed=1 + f) for f in range(frames)]
+    plan, inp, out = _cr2_batch(ctx, torch, [(m[0], m[1]) for m in made], W, H)
     dt, kt, cons = _time_plan(torch, plan, inp, out, steps, warmup)
-    got = out[:out_pitch(W) * H].cpu().numpy().view(np.uint16).reshape(H, out_pitch(W) // 2)[:, :W]
-    exact = bool(np.array_equal(got, src)) and all(c == scan_len for c in cons)
-    alg = frames * (scan_len + W * H * 2)
-    res = {
-        "workload": "Cr2Decompressor <2,1,1> 6720x4480, 3 slices, %d frames/step" % frames,
-        "mpix_per_s": round(frames * W * H / dt / 1e6, 1),
-        "ms_per_step": round(dt * 1e3, 4),
-        "bit_exact": exact,
-        "entropy_bits_per_px": round(scan_len * 8 / (W * H), 3),
-        "algorithmic_bytes_per_step": alg,
-        "achieved_gbps_whole_pipeline": round(alg / dt / 1e9, 1),
-        "frac_of_hbm_peak": round(alg / dt / 1e9 / 8000.0, 4),
-    }
-    _dominant(res, kt)
-    return res, (d, data, W, H)
+    exact = all(c == m[3] for c, m in zip(cons, made))
+    ref_frames, cpu_b = (None, None)
+    if cpu:
+        ref_frames, cpu_b = ref_scan_baseline(1, [m[0] for m in made], [m[1] for m in made],
+                                              W, H, "Cr2Decompressor::decompress")
+    checked = "source image"
+    for f in range(frames):
+        got = gpu_frame(out, f, W, H)
+        exact = exact and bool(np.array_equal(got, made[f][2]))
+        if ref_frames is not None:
+            exact = exact and bool(np.array_equal(got, ref_frames[f]))
+            checked = "oracle/_ref (every frame) and the source images"
+    res = _lj_result("Cr2Decompressor <2,1,1> 6720x4480, 3 slices, %d different frames/step"
+                     % frames, frames, W, H, dt, sum(m[3] for m in made), exact, kt,
+                     {"bit_exact_against": checked})
+    if cpu_b:
+        res["cpu_baseline"] = cpu_b
+    return res, None
+
+
+def run_cfg3_uniform(ctx, torch, log, frames=4, steps=10, warmup=2):
+    """SURVEY 8(d) second distribution: uniform-random 14-bit values (~21 bit/px with
+    this table: the entropy-coded input is larger than the 16 bit/px output)."""
+    from rawspeed_amd import abi, synth
+    import cases
+    W, H = 6720, 4480
+    made = []
+    for f in range(frames):
+        src = synth.uniform(W * H, 14, 77 + f).reshape(H, W)
+        rows = cases.cr2_stream_from_image(src, 2, W // 2, H, cases.cr2_slices(3, 2240, 2240))
+        scan, bits = synth.ljpeg_encode_scan(rows, 2, [1 << 13] * 2, [_nikon(), _nikon()])
+        d = abi.Cr2Desc()
+        d.n_comp, d.x_s_f, d.y_s_f = 2, 1, 1
+        d.frame_w, d.frame_h = W // 2, H
+        d.num_slices, d.slice_width, d.last_slice_width = 3, 2240, 2240
+        abi.fill_recipe(d, synth.huff_tables(_nikon()), [0, 0], [1 << 13] * 2)
+        pad = (-(len(scan) + 2)) % 16 + 16
+        data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), np.zeros(pad, np.uint8)])
+        made.append((d, data, src, len(scan)))
+    plan, inp, out = _cr2_batch(ctx, torch, [(m[0], m[1]) for m in made], W, H)
+    dt, kt, cons = _time_plan(torch, plan, inp, out, steps, warmup)
+    exact = all(c == m[3] for c, m in zip(cons, made))
+    for f in range(frames):
+        exact = exact and bool(np.array_equal(gpu_frame(out, f, W, H), made[f][2]))
+    return _lj_result("Cr2Decompressor <2,1,1> 6720x4480, uniform-random 14-bit values "
+                      "(worst case for the entropy stage), %d frames/step" % frames,
+                      frames, W, H, dt, sum(m[3] for m in made), exact, kt)
+
+
+def clipped_image(W, H, seed):
+    """A frame as cameras deliver them: sensor-like, ~10 % of it blown out (a disc of
+    16383) and a black border (masked pixels) -- constant regions make the bit stream
+    periodic, which a self-synchronising decoder has to cope with."""
+    from rawspeed_amd import synth
+    src = synth.sensor_image(W, H, 14, seed=seed)
+    yy, xx = np.ogrid[:H, :W]
+    r2 = 0.10 * W * H / np.pi
+    src[(yy - H * 0.45) ** 2 + (xx - W * 0.55) ** 2 < r2] = 16383
+    b = 48
+    src[:b, :] = 0
+    src[-b:, :] = 0
+    src[:, :b] = 0
+    src[:, -b:] = 0
+    return src
+
+
+def run_clipped(ctx, torch, log, frames=8, steps=10, warmup=2):
+    """cfg-3 shape with blown highlights and a black border, against the reference."""
+    from rawspeed_amd import abi, synth
+    import cases
+    W, H = 6720, 4480
+    made = []
+    for f in range(frames):
+        src = clipped_image(W, H, 31 + f)
+        rows = cases.cr2_stream_from_image(src, 2, W // 2, H, cases.cr2_slices(3, 2240, 2240))
+        scan, bits = synth.ljpeg_encode_scan(rows, 2, [1 << 13] * 2, [_nikon(), _nikon()])
+        d = abi.Cr2Desc()
+        d.n_comp, d.x_s_f, d.y_s_f = 2, 1, 1
+        d.frame_w, d.frame_h = W // 2, H
+        d.num_slices, d.slice_width, d.last_slice_width = 3, 2240, 2240
+        abi.fill_recipe(d, synth.huff_tables(_nikon()), [0, 0], [1 << 13] * 2)
+        pad = (-(len(scan) + 2)) % 16 + 16
+        data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), np.zeros(pad, np.uint8)])
+        made.append((d, data, src, len(scan)))
+    plan, inp, out = _cr2_batch(ctx, torch, [(m[0], m[1]) for m in made], W, H)
+    dt, kt, cons = _time_plan(torch, plan, inp, out, steps, warmup)
+    exact = all(c == m[3] for c, m in zip(cons, made))
+    ref_frames, _ = ref_scan_baseline(1, [made[0][0]], [made[0][1]], W, H, "Cr2Decompressor")
+    for f in range(frames):
+        exact = exact and bool(np.array_equal(gpu_frame(out, f, W, H), made[f][2]))
+    if ref_frames is not None:
+        exact = exact and bool(np.array_equal(gpu_frame(out, 0, W, H), ref_frames[0]))
+    return _lj_result("Cr2Decompressor <2,1,1> 6720x4480 with ~10 %% blown highlights (16383) "
+                      "and a 48-px black border, %d different frames/step" % frames,
+                      frames, W, H, dt, sum(m[3] for m in made), exact, kt)
 
 
 def run_sraw(ctx, torch, log, frames=8, steps=10, warmup=2):
@@ -197,43 +359,92 @@ def run_sraw(ctx, torch, log, frames=8, steps=10, warmup=2):
     }
 
 
-def run_cfg4(ctx, torch, log, steps=10, warmup=2):
-    """configs[3]: 8192x5464 as 2x2 DNG tiles of 4096x2732 (one plan, tiles-parallel)."""
+def _dng_tiles(W, H, tw, th, seed, rows_per_ri=0):
+    """A WxH sensor-like image as DNG tiles of tw x th (right / bottom tiles overhang when
+    W, H are not multiples: the part outside the image is padding, decodeRowN drops it)."""
     from rawspeed_amd import abi, synth
-    W, H, tw, th = 8192, 5464, 4096, 2732
-    src = synth.sensor_image(W, H, 14, seed=2)
-    jobs, blobs, off, lens = [], [], 0, []
-    for ty in range(2):
-        for tx in range(2):
-            d, data, scan_len, bits = make_tile(src[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw],
-                                                tx * tw, ty * th, tw, th)
+    src = synth.sensor_image(W, H, 14, seed=seed)
+    jobs, datas, blobs, lens, off = [], [], [], [], 0
+    for ty in range((H + th - 1) // th):
+        for tx in range((W + tw - 1) // tw):
+            part = src[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw]
+            tile = np.full((th, tw), 1000, np.uint16)
+            tile[:part.shape[0], :part.shape[1]] = part
+            d, data, scan_len, bits, blob = make_tile(tile, tx * tw, ty * th, tw, th,
+                                                      rows_per_ri, want_blob=True)
+            # AbstractDngDecompressor.cpp:64-68: the tile is clipped to the image
+            d.tile_w = min(tw, W - tx * tw)
+            d.tile_h = min(th, H - ty * th)
             j = abi.LJpegJob()
             j.desc = d
             j.in_offset, j.in_bytes, j.img_offset = off, data.size, 0
             j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
                 out_pitch(W), W, H, 1, 1
             jobs.append(j)
-            blobs.append(data)
+            datas.append(data)
+            blobs.append(blob)
             lens.append(scan_len)
             off += data.size
-    inp = torch.from_numpy(np.concatenate(blobs)).cuda()
+    return src, jobs, datas, blobs, lens
+
+
+def _cfg4_variant(ctx, torch, W, H, tw, th, seed, rows_per_ri, steps, warmup, what, cpu):
+    from oracle_lib import Ref
+    src, jobs, datas, blobs, lens = _dng_tiles(W, H, tw, th, seed, rows_per_ri)
+    inp = torch.from_numpy(np.concatenate(datas)).cuda()
     out = torch.zeros(out_pitch(W) * H, dtype=torch.uint8, device="cuda")
     plan = ctx.ljpeg_plan(jobs)
     dt, kt, cons = _time_plan(torch, plan, inp, out, steps, warmup)
-    got = out.cpu().numpy().view(np.uint16).reshape(H, out_pitch(W) // 2)[:, :W]
-    exact = bool(np.array_equal(got, src)) and cons == lens
-    alg = sum(lens) + W * H * 2
-    res = {
-        "workload": "LJpegDecompressor via DNG tiles: 8192x5464 as 2x2 tiles, 1 frame/step",
-        "mpix_per_s": round(W * H / dt / 1e6, 1),
-        "ms_per_step": round(dt * 1e3, 4),
-        "bit_exact": exact,
-        "entropy_bits_per_px": round(sum(lens) * 8 / (W * H), 3),
-        "algorithmic_bytes_per_step": alg,
-        "achieved_gbps_whole_pipeline": round(alg / dt / 1e9, 1),
-        "frac_of_hbm_peak": round(alg / dt / 1e9 / 8000.0, 4),
-    }
-    _dominant(res, kt)
+    got = gpu_frame(out, 0, W, H)
+    exact = bool(np.array_equal(got, src))
+    extra = {"bit_exact_against": "the source image"}
+    if Ref.available():
+        # the same tiles through AbstractDngDecompressor::decompress() of the unmodified
+        # reference, its OpenMP fan-out over the tiles on all cores (only 4 are busy)
+        ref = Ref()
+        img = ref.image(W, H, 1)
+        nt = host_threads(ref)
+        st = ref.dng(img, 7, tw, th, blobs, threads=nt)
+        exact = exact and st == 0 and bool(np.array_equal(got, img.pixels()))
+        extra["bit_exact_against"] = "oracle/_ref (AbstractDngDecompressor::decompress) " \
+                                     "and the source image"
+        if cpu:
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                ref.dng(img, 7, tw, th, blobs, threads=nt)
+                ts.append(time.perf_counter() - t0)
+            t1 = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                ref.dng(img, 7, tw, th, blobs, threads=1)
+                t1.append(time.perf_counter() - t0)
+            extra["cpu_baseline"] = {
+                "value": round(W * H / min(ts) / 1e6, 1), "unit": "MPix/s", "cores": nt,
+                "kind": "reference", "single_thread_value": round(W * H / min(t1) / 1e6, 1),
+                "sample": "AbstractDngDecompressor::decompress() of the unmodified reference "
+                          "on the same %d tiles, OpenMP threads = %d (at most %d busy), best "
+                          "of 5; single_thread_value = 1 thread" % (len(blobs), nt, len(blobs))}
+    # consumed: full-height tiles end on their marker; bottom-overhanging ones stop early
+    if H % th == 0:
+        exact = exact and cons == lens
+    return _lj_result(what, 1, W, H, dt, sum(lens), exact, kt, extra)
+
+
+def run_cfg4(ctx, torch, log, steps=10, warmup=2, cpu=True, variants=True):
+    """configs[3]: 8192x5464 as 2x2 DNG tiles of 4096x2732 (one plan, tiles-parallel),
+    plus SURVEY 8(d)'s parity extras at full size: 8189x5462 (right / bottom tiles
+    overhang, odd width) and the restart-interval variant."""
+    res = _cfg4_variant(ctx, torch, 8192, 5464, 4096, 2732, 2, 0, steps, warmup,
+                        "LJpegDecompressor via DNG tiles: 8192x5464 as 2x2 tiles, 1 frame/step",
+                        cpu)
+    if variants:
+        res["overhang_8189x5462"] = _cfg4_variant(
+            ctx, torch, 8189, 5462, 4096, 2732, 3, 0, steps, warmup,
+            "8189x5462 as 2x2 tiles of 4096x2732 (overhanging right/bottom tiles)", False)
+        res["restart_intervals"] = _cfg4_variant(
+            ctx, torch, 8192, 5464, 4096, 2732, 2, 683, steps, warmup,
+            "8192x5464 as 2x2 tiles, restart interval = 683 rows (4 intervals per tile)", False)
     return res
 
 
@@ -250,9 +461,8 @@ def make_cfg5_plan(ctx, torch, frames, distinct=4, seed0=1000):
         d, data, scan_len, bits = make_tile(src, 0, 0, W, H)
         blobs.append((d, data))
         lens.append(scan_len)
-        if k == 0:
-            srcs.append(src)
-    jobs, off, parts = [], 0, []
+        srcs.append(src)
+    jobs, off = [], 0
     for f in range(frames):
         d, data = blobs[f % distinct]
         j = abi.LJpegJob()
@@ -262,36 +472,35 @@ def make_cfg5_plan(ctx, torch, frames, distinct=4, seed0=1000):
         j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
             out_pitch(W), W, H, 1, 1
         jobs.append(j)
-        parts.append(data)
         off += data.size
-    inp = torch.from_numpy(np.concatenate(parts)).cuda()
+    # the packed batch is assembled on the device (256 frames are 12 GB)
+    dev = [torch.from_numpy(b[1]).cuda() for b in blobs]
+    inp = torch.cat([dev[f % distinct] for f in range(frames)])
     out = torch.zeros(frames * out_pitch(W) * H, dtype=torch.uint8, device="cuda")
     plan = ctx.ljpeg_plan(jobs)
-    meta = dict(W=W, H=H, src0=srcs[0], lens=[lens[f % distinct] for f in range(frames)],
+    meta = dict(W=W, H=H, srcs=srcs, distinct=distinct, blobs=blobs,
+                lens=[lens[f % distinct] for f in range(frames)],
                 alg_bytes=sum(lens[f % distinct] for f in range(frames)) + frames * W * H * 2,
                 bits_per_px=sum(lens) * 8 / (distinct * W * H))
     return plan, inp, out, meta
 
 
-def cpu_baseline_cr2(d, data, W, H, budget_s=10.0):
-    from oracle_lib import Ref
-    if not Ref.available():
-        return None
-    ref = Ref()
-    img = ref.image(W, H, 1)
-    st, _ = ref.cr2(d, data, img)
-    assert st == 0
-    times = []
-    t_end = time.perf_counter() + budget_s
-    while len(times) < 5 and (time.perf_counter() < t_end or len(times) < 2):
-        t0 = time.perf_counter()
-        ref.cr2(d, data, img)
-        times.append(time.perf_counter() - t0)
-    return {"value": round(W * H / min(times) / 1e6, 1), "unit": "MPix/s", "cores": 1,
-            "kind": "reference",
-            "sample": "Cr2Decompressor::decompress of the unmodified reference on the same "
-                      "6720x4480 stream, 1 thread (the decoder has no internal threading), "
-                      "best of %d" % len(times)}
+def check_cfg5(out, meta, cons, frames, ref_frames=None):
+    """every frame of the batch against its source image (and the reference's decode of
+    it); compared on the device -- 256 frames are 23 GB"""
+    import torch
+    W, H, k = meta["W"], meta["H"], meta["distinct"]
+    ok = list(cons) == list(meta["lens"])
+    op = out_pitch(W)
+    view = out.view(torch.int16).reshape(frames, H, op // 2)[:, :, :W]
+    want = [torch.from_numpy(np.ascontiguousarray(s).view(np.int16)).cuda()
+            for s in meta["srcs"]]
+    if ref_frames is not None:
+        for i in range(k):
+            ok = ok and bool(np.array_equal(ref_frames[i], meta["srcs"][i]))
+    for f in range(frames):
+        ok = ok and bool(torch.equal(view[f], want[f % k]))
+    return ok
 
 
 def run_nikon(ctx, torch, log, frames=8, steps=10, warmup=2, cpu=True):
@@ -505,33 +714,22 @@ def run_variants(ctx, torch, log, frames=8, steps=50, warmup=20):
 
 def run(ctx, torch, log):
     out = {}
-    try:
-        out["uncompressed_variants_8280x5520"] = run_variants(ctx, torch, log)
-    except Exception as e:
-        out["uncompressed_variants_8280x5520"] = {"error": repr(e)}
-    r3, ref_args = run_cfg3(ctx, torch, log)
-    out["cfg3_cr2_6720x4480"] = r3
-    out["cfg4_dng_tiles_8192x5464"] = run_cfg4(ctx, torch, log)
-    try:
-        out["nikon_lossless14_6016x4016"] = run_nikon(ctx, torch, log)
-    except Exception as e:
-        out["nikon_lossless14_6016x4016"] = {"error": repr(e)}
-    try:
-        out["hasselblad_8272x6200"] = run_hasselblad(ctx, torch, log)
-    except Exception as e:
-        out["hasselblad_8272x6200"] = {"error": repr(e)}
-    try:
-        out["sony_arw1_3881x2608"] = run_sony_arw1(ctx, torch, log)
-    except Exception as e:
-        out["sony_arw1_3881x2608"] = {"error": repr(e)}
-    try:
-        out["cr2_sraw1_3960x2640"] = run_sraw(ctx, torch, log)
-    except Exception as e:
-        out["cr2_sraw1_3960x2640"] = {"error": repr(e)}
-    try:
-        out["cfg3_cpu_baseline"] = cpu_baseline_cr2(*ref_args)
-    except Exception as e:
-        out["cfg3_cpu_baseline"] = {"error": repr(e)}
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:  # the other legs must survive
+            out[name] = {"error": repr(e)}
+
+    leg("uncompressed_variants_8280x5520", lambda: run_variants(ctx, torch, log))
+    leg("cfg3_cr2_6720x4480", lambda: run_cfg3(ctx, torch, log)[0])
+    leg("cfg3_uniform_random_14bit", lambda: run_cfg3_uniform(ctx, torch, log))
+    leg("cfg3_clipped_highlights", lambda: run_clipped(ctx, torch, log))
+    leg("cfg4_dng_tiles_8192x5464", lambda: run_cfg4(ctx, torch, log))
+    leg("nikon_lossless14_6016x4016", lambda: run_nikon(ctx, torch, log))
+    leg("hasselblad_8272x6200", lambda: run_hasselblad(ctx, torch, log))
+    leg("sony_arw1_3881x2608", lambda: run_sony_arw1(ctx, torch, log))
+    leg("cr2_sraw1_3960x2640", lambda: run_sraw(ctx, torch, log))
     return out
 
 
@@ -563,6 +761,11 @@ if __name__ == "__main__":
         print(json.dumps(run_hasselblad(ctx, torch, print, steps=args.steps), indent=1))
     elif args.only == "sraw":
         print(json.dumps(run_sraw(ctx, torch, print, frames=args.frames, steps=args.steps),
+                         indent=1))
+    elif args.only == "uniform":
+        print(json.dumps(run_cfg3_uniform(ctx, torch, print, steps=args.steps), indent=1))
+    elif args.only == "clipped":
+        print(json.dumps(run_clipped(ctx, torch, print, frames=args.frames, steps=args.steps),
                          indent=1))
     elif args.only == "cfg4":
         print(json.dumps(run_cfg4(ctx, torch, print, steps=args.steps), indent=1))

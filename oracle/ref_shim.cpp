@@ -473,6 +473,37 @@ int ref_ljpeg_frames_parallel(int n_frames, void* const* images,
   return rc;
 }
 
+// The same fan-out at the decompressor level (what bench_ljpeg.py's plans are made
+// of): `n_frames` independent entropy-coded scans, each with its own descriptor,
+// decoded by LJpegDecompressor::decode (kind 0, descs = rsx_ljpeg_desc[]) or
+// Cr2Decompressor::decompress (kind 1, descs = rsx_cr2_desc[]) on `threads` OpenMP
+// threads -- one whole frame per thread, the decoders have no threading of their own.
+int ref_scan_frames_parallel(int n_frames, void* const* images, const void* descs,
+                             const uint8_t* const* ins, const size_t* in_bytes,
+                             int kind, int threads) {
+  int rc = RSX_OK;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+#endif
+  for (int i = 0; i < n_frames; ++i) {
+    int st;
+    if (kind == 0)
+      st = ref_ljpeg_decompress(images[i],
+                                static_cast<const rsx_ljpeg_desc*>(descs) + i, ins[i],
+                                in_bytes[i], nullptr);
+    else
+      st = ref_cr2_decompress(images[i], static_cast<const rsx_cr2_desc*>(descs) + i,
+                              ins[i], in_bytes[i], nullptr);
+    if (st != RSX_OK) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+      rc = st;
+    }
+  }
+  return rc;
+}
+
 int ref_unpack_frames_parallel(int n_frames, void* const* images,
                                const rsx_unpack_desc* d,
                                const uint8_t* const* ins, size_t in_bytes,

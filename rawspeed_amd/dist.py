@@ -23,11 +23,13 @@ def shard_range(n_units, world, rank):
 
 
 class Group:
-    def __init__(self, backend=None, device=None):
+    def __init__(self, backend=None, device=None, force=False):
+        """force: create the process group even for a world of one (tests of the
+        collective path on a single-GPU box)."""
         import torch
         self.torch = torch
         self.world, self.rank, self.local_rank = env_world()
-        self.enabled = self.world > 1
+        self.enabled = self.world > 1 or force
         self.device = device
         if self.enabled:
             import torch.distributed as dist
@@ -70,6 +72,20 @@ class Group:
         if self.enabled:
             self.dist.broadcast(tensor, src=src)
         return tensor
+
+    def scatter_shards(self, send, recv, src=0):
+        """Every rank but `src` receives one shard into `recv`; `src` sends `send` (its own
+        copy of a shard -- the shards of the synthetic batch are identical) to each of them
+        as one group of point-to-point operations (ncclGroupStart/End underneath)."""
+        if not self.enabled:
+            return
+        if self.rank == src:
+            ops = [self.dist.P2POp(self.dist.isend, send, r)
+                   for r in range(self.world) if r != src]
+        else:
+            ops = [self.dist.P2POp(self.dist.irecv, recv, src)]
+        for req in self.dist.batch_isend_irecv(ops):
+            req.wait()
 
     def gather_objects(self, obj, dst=0):
         if not self.enabled:

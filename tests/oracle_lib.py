@@ -349,6 +349,8 @@ class Ref:
         L.ref_unpack_frames_parallel.argtypes = [C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_size_t, C.c_int]
         L.ref_set_threads.argtypes = [C.c_int]
+        L.ref_scan_frames_parallel.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_int, C.c_int]
 
     def last_error(self):
         return self.lib.ref_last_error().decode(errors="replace")
@@ -412,6 +414,17 @@ class Ref:
         st = self.lib.ref_cr2_decompress(img.h, C.byref(desc), p, n,
                                          C.byref(consumed))
         return st, consumed.value
+
+    def scan_frames_parallel(self, imgs, descs, datas, kind, threads):
+        """LJpegDecompressor (kind 0) / Cr2Decompressor (kind 1) over independent frames,
+        one frame per OpenMP thread.  descs: list of rsx_ljpeg_desc / rsx_cr2_desc."""
+        n = len(imgs)
+        arrs = [np.ascontiguousarray(d, dtype=np.uint8) for d in datas]
+        darr = (type(descs[0]) * n)(*descs)
+        ptrs = (C.c_void_p * n)(*[i.h for i in imgs])
+        ins = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        sizes = (C.c_size_t * n)(*[a.size for a in arrs])
+        return self.lib.ref_scan_frames_parallel(n, ptrs, darr, ins, sizes, kind, threads)
 
     def ljpeg_container(self, blob, img, off_x, off_y, w, h, max_dim, fix16=False):
         a, p, n = _as_u8(blob)

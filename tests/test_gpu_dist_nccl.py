@@ -1,0 +1,58 @@
+"""The N>1 code path on real GPUs: torch.distributed backend "nccl" (RCCL) at whatever
+world size the box offers (1 on the single-GPU test box, up to 8 on a node): process
+group, barrier, all-reduce, broadcast and grouped send/recv of the packed batch,
+sharded decode through the C-ABI, gathered results."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+pytestmark = pytest.mark.gpu
+
+
+def _run(world, tmp_path, port):
+    out = tmp_path / ("result_%d.json" % world)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(HERE, "dist_worker_gpu.py"), str(out)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:]
+    return json.loads(out.read_text())
+
+
+def test_nccl_sharded_decode_at_visible_world_size(tmp_path):
+    import torch
+    n = torch.cuda.device_count()
+    assert n >= 1
+    res = _run(1, tmp_path, 29541)
+    assert res == {"ok": True, "frames": 6, "world": 1, "backend": "nccl"}
+    if n >= 2:
+        world = min(n, 8)
+        res = _run(world, tmp_path, 29543)
+        assert res == {"ok": True, "frames": 6, "world": world, "backend": "nccl"}
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus N` without a launcher starts N ranks itself (N = the
+    GPUs of the box, at most 2 here) and reports n_gpus = N."""
+    import torch
+    n = min(torch.cuda.device_count(), 2)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(n),
+           "--steps", "3", "--warmup", "1", "--frames", "2", "--no-extra", "--no-cfg5",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == n and res["bit_exact"] is True
+    assert len(res["per_rank_mpix_per_s"]) == n
+    assert res["rccl_ranks"] == (n if n > 1 else 0)
