@@ -118,8 +118,10 @@ def ref_scan_baseline(kind, descs, datas, W, H, what, budget_s=8.0):
 LAST_KERNEL_TABLE = None  # per-kernel averages (ms per run) of the last _time_plan call
 
 
-def _time_plan(torch, plan, inp, out, steps, warmup):
+def _time_plan(torch, plan, inp, out, steps, warmup, with_results=False):
     """(seconds per step with timing off, dominant kernel (name, ms, runs), consumed).
+    with_results: every step also fetches the per-job results (a host round trip; it is
+    there that a stream which did not converge in-stream is finished).
     The per-kernel table of LJPEG-family plans comes from 3 extra runs with an event
     after every launch; the dominant kernel is the largest entry of that table."""
     global LAST_KERNEL_TABLE
@@ -133,6 +135,8 @@ def _time_plan(torch, plan, inp, out, steps, warmup):
     t0 = time.perf_counter()
     for _ in range(steps):
         plan.run(inp.data_ptr(), out.data_ptr(), s)
+        if with_results:
+            assert plan.results()[0] == 0
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     plan.set_timing(True)
@@ -283,7 +287,8 @@ def run_clipped(ctx, torch, log, frames=8, steps=10, warmup=2):
         data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), np.zeros(pad, np.uint8)])
         made.append((d, data, src, len(scan)))
     plan, inp, out = _cr2_batch(ctx, torch, [(m[0], m[1]) for m in made], W, H)
-    dt, kt, cons = _time_plan(torch, plan, inp, out, steps, warmup)
+    # (results fetched every step: nothing may be left to the host-side fallback unseen)
+    dt, kt, cons = _time_plan(torch, plan, inp, out, steps, warmup, with_results=True)
     exact = all(c == m[3] for c, m in zip(cons, made))
     ref_frames, _ = ref_scan_baseline(1, [made[0][0]], [made[0][1]], W, H, "Cr2Decompressor")
     for f in range(frames):
@@ -443,8 +448,8 @@ def run_cfg4(ctx, torch, log, steps=10, warmup=2, cpu=True, variants=True):
             ctx, torch, 8189, 5462, 4096, 2732, 3, 0, steps, warmup,
             "8189x5462 as 2x2 tiles of 4096x2732 (overhanging right/bottom tiles)", False)
         res["restart_intervals"] = _cfg4_variant(
-            ctx, torch, 8192, 5464, 4096, 2732, 2, 683, steps, warmup,
-            "8192x5464 as 2x2 tiles, restart interval = 683 rows (4 intervals per tile)", False)
+            ctx, torch, 8192, 5464, 4096, 2732, 2, 28, steps, warmup,
+            "8192x5464 as 2x2 tiles, restart interval = 28 rows = 57344 MCUs (the DRI field is 16 bits), 98 intervals per tile", False)
     return res
 
 

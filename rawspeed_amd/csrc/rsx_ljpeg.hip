@@ -408,6 +408,125 @@ __device__ __forceinline__ uint32_t lj_wave_scan(uint32_t x, int lane) {
 }
 
 // ---------------------------------------------------------------------------
+// Periodic data (stitch kernels only).  Slots with IDENTICAL content -- inside a
+// constant region there are only a few different ones -- have identical transfer
+// functions, and a slot's exit depends on nothing but its content and its entry
+// state.  Up to PER_CLASSES classes of identical slots get a table: (exit, count, sums)
+// for each of the 32 entry offsets, 256 decodes = one pass of the workgroup.  With the
+// tables one lane walks the chain through the class slots with look-ups; what is left
+// for the re-decode rounds are the few slots that are not in a class.
+// ---------------------------------------------------------------------------
+constexpr uint32_t LJ_SYNC_MAX_ROUNDS = 4, LJ_STITCH_MAX_ROUNDS = 32, LJ_STITCH_CLASS_ROUND = 3;
+constexpr int PER_CLASSES = 8;
+
+struct PeriodicEntry {
+  uint16_t exit, count;
+  uint32_t s0, s1;
+};
+
+struct PeriodicLds {
+  uint32_t* hash;      // [LJ_T] content hash of every slot
+  uint32_t* members;   // [LJ_T] slots whose representative is this one
+  uint8_t* cls;        // [LJ_T] class of every slot (0xFF = none)
+  uint32_t* rep_of;    // [PER_CLASSES] representative slot of a class
+  PeriodicEntry* tbl;  // [PER_CLASSES * 32]
+};
+constexpr size_t lj_periodic_bytes() {
+  return 2 * LJ_T * 4 + LJ_T + PER_CLASSES * 4 + PER_CLASSES * 32 * sizeof(PeriodicEntry) + 16;
+}
+
+__device__ __forceinline__ PeriodicLds carve_periodic(const Lds& L, int n_tables) {
+  PeriodicLds p;
+  p.hash = reinterpret_cast<uint32_t*>(L.tabs + n_tables);
+  p.members = p.hash + LJ_T;
+  p.rep_of = p.members + LJ_T;
+  p.tbl = reinterpret_cast<PeriodicEntry*>(p.rep_of + PER_CLASSES);
+  p.cls = reinterpret_cast<uint8_t*>(p.tbl + PER_CLASSES * 32);
+  return p;
+}
+
+// Classes of identical slots and their tables.  Called by the whole workgroup.
+template <int NS, int BWK>
+__device__ __forceinline__ void lj_periodic_build(const Lds& L, const PeriodicLds& P,
+                                                  const DecodeParams& dp, int j) {
+  // content = the slot's dwords + its data-bit count
+  uint32_t h = L.ob[j];
+#pragma unroll
+  for (int k = 0; k < BWK; ++k)
+    h = (h ^ L.B[k * LJ_T + j]) * 0x9E3779B1u + (h >> 15);
+  P.hash[j] = h;
+  P.members[j] = 0;
+  P.cls[j] = 0xFF;
+  __syncthreads();
+  // representative = the first slot (>= 1) with the same content
+  uint32_t rep = uint32_t(j);
+  for (uint32_t i = 1; i < uint32_t(LJ_T); ++i)
+    if (P.hash[i] == h && i < rep)
+      rep = i;
+  if (rep != uint32_t(j)) {
+    bool same = L.ob[rep] == L.ob[j];
+    for (int k = 0; k < BWK; ++k)
+      same = same && L.B[k * LJ_T + rep] == L.B[k * LJ_T + j];
+    if (!same)
+      rep = uint32_t(j); // (a hash collision: the slot stays on its own)
+  }
+  if (j >= 1)
+    atomicAdd(&P.members[rep], 1u);
+  __syncthreads();
+  // the first PER_CLASSES representatives with at least 3 members become classes
+  if (j == 0) {
+    uint32_t nc = 0;
+    for (uint32_t i = 1; i < uint32_t(LJ_T) && nc < uint32_t(PER_CLASSES); ++i)
+      if (P.members[i] >= 3u) {
+        P.rep_of[nc] = i;
+        P.members[i] = 0x80000000u | nc;
+        ++nc;
+      }
+    for (uint32_t c = nc; c < uint32_t(PER_CLASSES); ++c)
+      P.rep_of[c] = 0;
+  }
+  __syncthreads();
+  if (j >= 1 && (P.members[rep] & 0x80000000u))
+    P.cls[j] = uint8_t(P.members[rep] & 0xFFu);
+  // table entry t: class t / 32 decoded from entry offset t % 32
+  const uint32_t c = uint32_t(j) >> 5, e0 = uint32_t(j) & 31u;
+  const uint32_t r = P.rep_of[c];
+  uint32_t e = ST_ERR, n = 0;
+  uint2 sums = make_uint2(0, 0);
+  lj_decode_span<false, NS, false, BWK>(L, dp, int(r ? r : 1u), e0, L.ob[r ? r : 1u], e, n,
+                                        &sums, r != 0);
+  PeriodicEntry t;
+  t.exit = uint16_t(e);
+  t.count = uint16_t(n);
+  t.s0 = sums.x;
+  t.s1 = sums.y;
+  P.tbl[j] = t;
+  __syncthreads();
+}
+
+// One lane: follow the chain through the slots that belong to a class.
+template <int NS>
+__device__ __forceinline__ void lj_periodic_walk(const Lds& L, const PeriodicLds& P,
+                                                 uint32_t true_start) {
+  for (int q = 1; q < LJ_T; ++q) {
+    const uint32_t want = q == 1 ? true_start : uint32_t(L.st[q - 1]);
+    if (want == L.su[q] || (want & ST_ERR) || !(L.ob[q] != 0 || q == 1))
+      continue;
+    const uint32_t c = P.cls[q];
+    if (c == 0xFFu || (want & ST_OFF_MASK) > 31u)
+      continue; // left to the re-decode rounds
+    const PeriodicEntry t = P.tbl[c * 32u + (want & 31u)];
+    L.su[q] = uint16_t(want);
+    L.st[q] = t.exit;
+    L.cn[q] = t.count;
+    if (NS) {
+      L.sm[2 * q] = t.s0;
+      L.sm[2 * q + 1] = t.s1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // K1 / K2: synchronisation.  NS = interleaved components of a fused-path stream
 // (its difference sums are recorded), 0 = none.
 // ---------------------------------------------------------------------------
@@ -426,12 +545,16 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   const int j = threadIdx.x;
 
   uint32_t true_start = 0;
+  bool unresolved = false;
   if (STITCH) {
-    if (lb == 0)
-      return;
-    true_start = a.block_exit[b - 1];
-    if (true_start == a.block_start[b] || (true_start & ST_ERR))
-      return; // chain already consistent here / broken by an error before it
+    // a workgroup comes here when its assumed start differs from its predecessor's
+    // recorded exit, or when it gave up on its own re-decode rounds (periodic data)
+    unresolved = (a.block_flags[b] & 1u) != 0;
+    true_start = lb == 0 ? uint32_t(S.start_bit) : a.block_exit[b - 1];
+    if (true_start & ST_ERR)
+      return; // chain broken by an error before this workgroup
+    if (true_start == a.block_start[b] && !unresolved)
+      return; // consistent already
   }
 
 #ifdef RSX_EXPERIMENT
@@ -480,7 +603,9 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       const uint32_t rec = a.sub_state[gsub];
       L.st[j] = rec & ST_MASK;
       L.cn[j] = rec >> 16;
-      L.su[j] = (j == 1) ? a.block_start[b] : (a.sub_state[gsub - 1] & ST_MASK);
+      // (the state the slot was decoded FROM: a workgroup that gave up on its rounds
+      // left records that are not a consistent chain yet)
+      L.su[j] = a.sub_start[gsub];
       if (NS) {
         const uint2 sums = a.sub_sums[gsub];
         L.sm[2 * j] = sums.x;
@@ -498,7 +623,16 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   // packed onto the first lanes so that a handful of stragglers do not cost a
   // whole-workgroup pass.
   const int first_chained = STITCH ? 2 : 1;
+  uint32_t rounds = 0;
+  bool gave_up = false, classes_ready = false;
+  const PeriodicLds PL = carve_periodic(L, MULTI ? int(S.n_tables) : 1);
   while (true) {
+    if (STITCH && !MULTI && !PAIR && classes_ready) {
+      // slots with identical content: their exits come from the class tables
+      if (j == 0)
+        lj_periodic_walk<NS>(L, PL, true_start);
+      __syncthreads();
+    }
     if (j == 0)
       L.misc[8] = 0;
     __syncthreads();
@@ -530,6 +664,25 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     const uint32_t n = L.misc[8];
     if (n == 0 || (LJ_ABLATE & 32u))
       break;
+    // Constant image regions (blown highlights, masked borders, the padding of DNG
+    // tiles) make the bit stream periodic: a mis-aligned parse can cycle for ever
+    // without meeting the true one, the start of such a slot is only known from its
+    // predecessor, and the rounds advance ONE slot each -- up to 255 rounds of one
+    // active lane.  So the rounds are limited.  K1 gives up (the workgroup is flagged
+    // and the stitch pass takes it); the stitch pass, which is launched for a handful
+    // of workgroups and can afford the LDS, then builds the exits of the slots with
+    // identical content for every entry state once (lj_periodic_build) and walks the
+    // chain through them with table look-ups.
+    ++rounds;
+    if (rounds > (STITCH ? LJ_STITCH_MAX_ROUNDS : LJ_SYNC_MAX_ROUNDS)) {
+      gave_up = true;
+      break;
+    }
+    if (STITCH && !MULTI && !PAIR && rounds == LJ_STITCH_CLASS_ROUND && !classes_ready) {
+      lj_periodic_build<NS, BWK>(L, PL, dp, j); // (workgroup-uniform; has barriers)
+      classes_ready = true;
+      continue;
+    }
 #ifdef RSX_EXPERIMENT
     if (j == 0) {
       atomicAdd(&a.results[s].stat_rounds, 1u);
@@ -570,6 +723,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       (NS && j >= 1) ? make_uint2(L.sm[2 * j], L.sm[2 * j + 1]) : make_uint2(0u, 0u);
   if (j >= 1) {
     a.sub_state[gsub] = L.st[j] | (my_count << 16);
+    a.sub_start[gsub] = L.su[j];
     if (NS)
       a.sub_sums[gsub] = my_sums;
   }
@@ -577,6 +731,34 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     a.block_start[b] = L.su[1];
   if (j == LJ_T - 1)
     a.block_exit[b] = L.st[j];
+  // A workgroup of periodic data: its exit for EVERY entry state, by following the
+  // chain with the class tables (slots outside a class must be entered the way they
+  // were recorded).  lj_pchain_kernel strings these together so that a constant region
+  // that spans many workgroups is settled by one more stitch pass, not one per workgroup.
+  bool tf_written = false;
+  if (STITCH && !MULTI && !PAIR && classes_ready) {
+    if (j < 32) {
+      uint32_t state = uint32_t(j);
+      for (int q = 1; q < LJ_T && state != 0xFFFFu; ++q) {
+        if (!(L.ob[q] != 0 || q == 1) || (state & ST_ERR))
+          continue;
+        const uint32_t c = PL.cls[q];
+        if (c != 0xFFu && (state & ST_OFF_MASK) <= 31u)
+          state = PL.tbl[c * 32u + (state & 31u)].exit;
+        else if (state == L.su[q])
+          state = L.st[q];
+        else
+          state = 0xFFFFu; // unknown for this entry
+      }
+      a.block_tf[size_t(b) * 32 + j] = uint16_t(state);
+    }
+    tf_written = true;
+  }
+  if (j == 0) {
+    a.block_flags[b] = (gave_up ? 1u : 0u) | (tf_written ? 2u : 0u);
+    if (gave_up || tf_written)
+      atomicOr(&a.results[s].flags, FL_PERIODIC);
+  }
   // Per slot: the symbols before it inside the workgroup and (fused path) the
   // running sums P before it, by phases relative to the workgroup's first symbol (a
   // slot's own phases start at its first symbol: rotate by the number of symbols
@@ -680,6 +862,60 @@ __global__ __launch_bounds__(64) void lj_chain_kernel(LjArgs a) {
   }
 }
 
+// Chain of the workgroups of a stream that holds periodic data (FL_PERIODIC): the
+// stitch pass has left, for the workgroups it took, the exit for every entry state
+// (block_tf).  One wavefront per stream walks the workgroups in order, 64 at a time
+// (records coalesced into registers, the tables into LDS), and rewrites the recorded
+// exits of those workgroups with the ones their TRUE entry states lead to; the next
+// stitch pass then re-converges every workgroup whose assumed start has moved.
+__global__ __launch_bounds__(64) void lj_pchain_kernel(LjArgs a) {
+  __shared__ uint16_t tf[64][32];
+  const uint32_t s = blockIdx.x;
+  const LjStreamDev& S = a.streams[s];
+  if (!(a.results[s].flags & FL_PERIODIC))
+    return;
+  const int lane = threadIdx.x;
+  const uint32_t fb = S.first_block, nb = S.n_blocks;
+  uint32_t state = S.start_bit;
+  for (uint32_t c0 = 0; c0 < nb; c0 += 64) {
+    const uint32_t i = c0 + uint32_t(lane);
+    uint32_t bs = 0, be = 0, fl = 0;
+    if (i < nb) {
+      bs = a.block_start[fb + i];
+      be = a.block_exit[fb + i];
+      fl = a.block_flags[fb + i];
+      if (fl & 2u) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.block_tf + size_t(fb + i) * 32);
+        uint4* dst = reinterpret_cast<uint4*>(tf[lane]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          dst[k] = src[k];
+      }
+    }
+    __syncthreads();
+    uint32_t mine = be;
+    const uint32_t n_here = nb - c0 < 64u ? nb - c0 : 64u;
+    for (uint32_t k = 0; k < n_here; ++k) {
+      const uint32_t bs_k = __shfl(bs, int(k), 64), be_k = __shfl(be, int(k), 64);
+      const uint32_t fl_k = __shfl(fl, int(k), 64);
+      uint32_t ex = be_k;
+      if (state & ST_ERR) {
+        ex = ST_ERR;
+      } else if ((fl_k & 2u) && (state & ~31u) == 0u && tf[k][state & 31u] != 0xFFFFu) {
+        ex = tf[k][state & 31u];
+      } else if (state != bs_k) {
+        ex = be_k; // unknown: the recorded exit is the best guess there is
+      }
+      if (uint32_t(lane) == k)
+        mine = ex;
+      state = ex;
+    }
+    if (i < nb && (fl & 2u) && !(mine & ST_ERR) && mine != be)
+      a.block_exit[fb + i] = mine;
+    __syncthreads();
+  }
+}
+
 // run-time flavour of lj_rot_fields (the per-stream scan kernel is not
 // instantiated per component count)
 __device__ __forceinline__ uint2 lj_rot_fields_rt(uint2 v, uint32_t f, uint32_t n) {
@@ -718,6 +954,8 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
     if (i >= 1 && i < nb && a.block_start[fb + i] != a.block_exit[fb + i - 1] &&
         !(a.block_exit[fb + i - 1] & ST_ERR))
       unconv_s = 1;
+    if (i < nb && (a.block_flags[fb + i] & 1u) != 0)
+      unconv_s = 1; // a workgroup that gave up on its re-decode rounds
     // inclusive wave scans
     uint32_t x = v, dx = dv;
 #pragma unroll
@@ -794,7 +1032,7 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
         avail += a.sub_state[g0 + q] >> 16;
     }
     R.avail_lo = avail;
-    uint32_t flags = R.flags & ~(FL_UNCONVERGED | FL_NEED_LEGACY);
+    uint32_t flags = R.flags & ~(FL_UNCONVERGED | FL_NEED_LEGACY | FL_PERIODIC);
     if (unconv_s)
       flags |= FL_UNCONVERGED;
     // symbols past the end of the data: the reference's end-of-stream semantics
@@ -1440,15 +1678,37 @@ __global__ __launch_bounds__(64) void lj_consumed_kernel(LjArgs a) {
       else
         hi = mid - 1;
     }
-    uint64_t x = uint64_t(lo) * LJ_R;
-    uint64_t logical = x - a.block_drop_base[S.first_block + lo];
-    // <= 16 KiB sequential walk; only bottom-overhanging tiles get here
-    while (logical < target && x < M) {
-      const bool drop = in[x] == 0x00 && x > 0 && in[x - 1] == 0xFF;
-      if (!drop)
-        ++logical;
-      ++x;
+    const uint64_t x0 = uint64_t(lo) * LJ_R;
+    const uint64_t logical0 = x0 - a.block_drop_base[S.first_block + lo];
+    // Inside the region (<= 16 KiB; only bottom-overhanging tiles get here): every
+    // lane counts the data bytes of its 256-byte piece, a wave scan finds the piece
+    // the target falls into, and that lane alone walks it.  (One lane walking the
+    // whole region took 1.7 ms on an 8189x5462 DNG.)
+    const uint64_t xs = x0 + 256u * uint32_t(lane);
+    uint64_t xe = xs + 256u;
+    if (xe > M)
+      xe = M;
+    uint32_t data = 0;
+    for (uint64_t q = xs; q < xe; ++q)
+      data += (in[q] == 0x00 && q > 0 && in[q - 1] == 0xFF) ? 0u : 1u;
+    const uint32_t incl = lj_wave_scan(data, lane);
+    const uint64_t want = target - logical0; // data bytes of the region still to pass (>= 0)
+    // the first piece whose running count reaches `want` (the last one if none does)
+    const bool mine_or_later = uint64_t(incl) >= want;
+    const uint64_t ballot = __ballot(mine_or_later);
+    const int owner = ballot ? __builtin_ctzll(ballot) : 63;
+    uint64_t x = xs;
+    uint64_t logical = logical0 + incl - data;
+    if (lane == owner) {
+      while (logical < target && x < M) {
+        const bool drop = in[x] == 0x00 && x > 0 && in[x - 1] == 0xFF;
+        if (!drop)
+          ++logical;
+        ++x;
+      }
     }
+    x = uint64_t(__shfl(uint32_t(x), owner, 64)) |
+        (uint64_t(__shfl(uint32_t(x >> 32), owner, 64)) << 32);
     // a data FF is consumed together with its stuffing byte
     // (BitStreamerJPEG.h:145-151)
     if (x < M && x > 0 && in[x - 1] == 0xFF && in[x] == 0x00)
@@ -1509,6 +1769,7 @@ struct LJpegPlan {
   bool direct_present[2][5] = {}; // fused path: [several tables][components]
   bool any_direct = false, any_legacy = false;
   bool legacy_fallback_ready = false; // difference scratch of the fused streams allocated
+  DeviceBuffer d_block_flags, d_block_tf, d_sub_start;
   DeviceBuffer d_streams, d_tables, d_block_stream, d_strips, d_sub_state, d_sub_sums,
       d_sub_first, d_sub_psum,
       d_block_start, d_block_exit, d_block_sum, d_block_base, d_block_psum, d_block_pbase,
@@ -1570,6 +1831,9 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.sub_sums = static_cast<uint2*>(p->d_sub_sums.ptr);
   a.sub_first = static_cast<uint32_t*>(p->d_sub_first.ptr);
   a.sub_psum = static_cast<uint2*>(p->d_sub_psum.ptr);
+  a.block_flags = static_cast<uint32_t*>(p->d_block_flags.ptr);
+  a.block_tf = static_cast<uint16_t*>(p->d_block_tf.ptr);
+  a.sub_start = static_cast<uint16_t*>(p->d_sub_start.ptr);
   a.block_psum = static_cast<uint2*>(p->d_block_psum.ptr);
   a.block_pbase = static_cast<uint2*>(p->d_block_pbase.ptr);
   a.row_edge = static_cast<uint4*>(p->d_row_edge.ptr);
@@ -1603,7 +1867,10 @@ void launch_sync_one(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
   if (!p->sync_present[MULTI ? 1 : 0][NS])
     return;
   hipLaunchKernelGGL((lj_sync_kernel<STITCH, MULTI, false, NS>), dim3(p->total_blocks),
-                     dim3(LJ_T), lj_lds_bytes(MULTI ? p->max_tables : 1, LJ_BW_SYNC), s, a);
+                     dim3(LJ_T),
+                     lj_lds_bytes(MULTI ? p->max_tables : 1, LJ_BW_SYNC) +
+                         (STITCH ? lj_periodic_bytes() : 0),
+                     s, a);
   mark(p, STITCH ? "lj_sync_kernel<stitch>" : "lj_sync_kernel");
 }
 
@@ -1893,6 +2160,9 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       return st;
     if ((st = p->d_sub_state.ensure(size_t(p->total_subseq) * 4 + 16)) ||
         (st = p->d_block_start.ensure(size_t(p->total_blocks) * 4)) ||
+        (st = p->d_block_flags.ensure(size_t(p->total_blocks) * 4)) ||
+        (st = p->d_block_tf.ensure(size_t(p->total_blocks) * 64)) ||
+        (st = p->d_sub_start.ensure(size_t(p->total_subseq) * 2 + 16)) ||
         (st = p->d_block_exit.ensure(size_t(p->total_blocks) * 4)) ||
         (st = p->d_block_sum.ensure(size_t(p->total_blocks) * 4)) ||
         (st = p->d_block_base.ensure(size_t(p->total_blocks) * 4)) ||
@@ -2165,8 +2435,13 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
                      lj_lds_bytes(0), s, a);
   mark(p, "lj_unstuff_kernel");
   launch_sync<false>(p, a, s);
-  for (int r = 0; r < p->stitch_rounds; ++r)
+  for (int r = 0; r < p->stitch_rounds; ++r) {
     launch_sync<true>(p, a, s);
+    if (r + 1 < p->stitch_rounds) {
+      hipLaunchKernelGGL(lj_pchain_kernel, dim3(n_streams), dim3(64), 0, s, a);
+      mark(p, "lj_pchain_kernel");
+    }
+  }
   hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
   mark(p, "lj_scan_kernel");
   if (int st = launch_tail(p, a, s))
@@ -2256,7 +2531,9 @@ int converge(LJpegPlan* p, hipStream_t s) {
       return st;
   }
   uint32_t rounds = 0;
-  while (unconverged() && rounds <= p->total_blocks) {
+  // (a stitch launch settles at least LJ_STITCH_MAX_ROUNDS slots of a workgroup that
+  // is still chaining, and at least one more workgroup of a chain of workgroups)
+  while (unconverged() && rounds <= 9 * p->total_blocks + 16) {
     for (int k = 0; k < 4; ++k)
       launch_sync<true>(p, a, s);
     rounds += 4;
@@ -2423,7 +2700,7 @@ void ljpeg_plan_destroy(LJpegPlan* p) {
   p->d_marker_list.release();
   for (DeviceBuffer* b :
        {&p->d_streams, &p->d_tables, &p->d_block_stream, &p->d_strips,
-        &p->d_sub_state, &p->d_sub_sums, &p->d_sub_first, &p->d_sub_psum, &p->d_block_start, &p->d_block_exit,
+        &p->d_block_flags, &p->d_block_tf, &p->d_sub_start, &p->d_sub_state, &p->d_sub_sums, &p->d_sub_first, &p->d_sub_psum, &p->d_block_start, &p->d_block_exit,
         &p->d_block_sum, &p->d_block_base, &p->d_block_psum, &p->d_block_pbase,
         &p->d_block_drops, &p->d_block_drop_base, &p->d_results, &p->d_diffs, &p->d_vseed,
         &p->d_row_edge, &p->d_unstuffed})

@@ -61,6 +61,8 @@ constexpr uint32_t FL_UNCONVERGED = 1u;
 // truncated input): it is redone by the legacy kernels, which know the reference's
 // end-of-stream semantics (lj_tail_kernel)
 constexpr uint32_t FL_NEED_LEGACY = 2u;
+// some workgroup of the stream met periodic data (constant image regions)
+constexpr uint32_t FL_PERIODIC = 4u;
 
 struct TabLds {
   uint16_t lut[LUT_SIZE];
@@ -168,12 +170,17 @@ struct LjArgs {
   const uint32_t* block_stream;
   const Cr2Strip* strips;
   uint32_t* sub_state;       // per subsequence: exit state | symbols << 16
+  uint16_t* sub_start;       // per subsequence: the state it was decoded from
   uint2* sub_sums;           // per subsequence: sums of its differences by relative phase
   uint32_t* sub_first;       // per subsequence: symbols before it inside its workgroup
   uint2* sub_psum;           // per subsequence: running sums P before it inside its
                              // workgroup, by phases relative to the workgroup's first symbol
   uint32_t* block_start;
   uint32_t* block_exit;
+  uint32_t* block_flags;     // per workgroup: 1 = gave up on its re-decode rounds,
+                             //                2 = block_tf holds its transfer function
+  uint16_t* block_tf;        // per workgroup: exit state for each of the 32 entry offsets
+                             //                (0xFFFF = unknown), periodic data only
   uint32_t* block_sum;
   uint32_t* block_base;
   uint2* block_psum;         // per workgroup: sums of its differences, phases relative to

@@ -84,6 +84,8 @@ class Group:
                    for r in range(self.world) if r != src]
         else:
             ops = [self.dist.P2POp(self.dist.irecv, recv, src)]
+        if not ops:  # a world of one
+            return
         for req in self.dist.batch_isend_irecv(ops):
             req.wait()
 
