@@ -678,7 +678,9 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       gave_up = true;
       break;
     }
-    if (STITCH && !MULTI && !PAIR && rounds == LJ_STITCH_CLASS_ROUND && !classes_ready) {
+    // (a round earlier for a workgroup that has given up before: it is chaining)
+    if (STITCH && !MULTI && !PAIR && !classes_ready &&
+        rounds == (unresolved ? 2u : LJ_STITCH_CLASS_ROUND)) {
       lj_periodic_build<NS, BWK>(L, PL, dp, j); // (workgroup-uniform; has barriers)
       classes_ready = true;
       continue;
@@ -895,6 +897,14 @@ __global__ __launch_bounds__(64) void lj_pchain_kernel(LjArgs a) {
     __syncthreads();
     uint32_t mine = be;
     const uint32_t n_here = nb - c0 < 64u ? nb - c0 : 64u;
+    if (__ballot((fl & 2u) != 0) == 0ull) {
+      // no table among these 64 workgroups: whatever state enters one of them, the
+      // recorded exit is all there is -- the chain leaves with the last one's
+      if (!(state & ST_ERR))
+        state = __shfl(be, int(n_here - 1), 64);
+      __syncthreads();
+      continue;
+    }
     for (uint32_t k = 0; k < n_here; ++k) {
       const uint32_t bs_k = __shfl(bs, int(k), 64), be_k = __shfl(be, int(k), 64);
       const uint32_t fl_k = __shfl(fl, int(k), 64);

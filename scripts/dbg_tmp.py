@@ -1,18 +1,27 @@
-import sys, os
+import sys, os, time
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import numpy as np, torch
 import bench_ljpeg as B
-import __graft_entry__ as ge
-ge.build()
-from rawspeed_amd import capi
+from rawspeed_amd import capi, abi, synth
+import cases
 ctx=capi.Context(0)
-for (W,H,tw,th,ri) in ((1024,64,512,32,8),(8192,5464,4096,2732,683),(8192,5464,4096,2732,1366)):
-    src, jobs, datas, blobs, lens = B._dng_tiles(W,H,tw,th,2, rows_per_ri=ri)
-    inp=torch.from_numpy(np.concatenate(datas)).cuda()
-    out=torch.zeros(B.out_pitch(W)*H,dtype=torch.uint8,device='cuda')
-    plan=ctx.ljpeg_plan(jobs)
-    plan.run(inp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+W,H=6720,4480
+made=[]
+for f in range(2):
+    src=B.clipped_image(W,H,31+f)
+    rows=cases.cr2_stream_from_image(src,2,W//2,H,cases.cr2_slices(3,2240,2240))
+    scan,bits=synth.ljpeg_encode_scan(rows,2,[1<<13]*2,[B._nikon(),B._nikon()])
+    d=abi.Cr2Desc(); d.n_comp,d.x_s_f,d.y_s_f=2,1,1; d.frame_w,d.frame_h=W//2,H
+    d.num_slices,d.slice_width,d.last_slice_width=3,2240,2240
+    abi.fill_recipe(d,synth.huff_tables(B._nikon()),[0,0],[1<<13]*2)
+    pad=(-(len(scan)+2))%16+16
+    data=np.concatenate([scan,np.array([0xFF,0xD9],np.uint8),np.zeros(pad,np.uint8)])
+    made.append((d,data,src,len(scan)))
+plan,inp,out=B._cr2_batch(ctx,torch,[(m[0],m[1]) for m in made],W,H)
+s=torch.cuda.current_stream().cuda_stream
+for i in range(3):
+    plan.run(inp.data_ptr(),out.data_ptr(),s)
+    torch.cuda.synchronize()
+    t0=time.perf_counter()
     rc,st,cons=plan.results()
-    got=B.gpu_frame(out,0,W,H)
-    bad=np.argwhere(got!=src)
-    print(W,H,ri,"rc",rc,st,"cons",cons,lens,"mismatch",len(bad), bad[:3].tolist())
+    print("results ms", (time.perf_counter()-t0)*1e3, rc, file=sys.stderr)
