@@ -105,6 +105,10 @@ int rsx_ctx_create(int device, rsx_ctx** out_ctx);
 void rsx_ctx_destroy(rsx_ctx* ctx);
 /* Last error text of this context (never NULL). */
 const char* rsx_ctx_last_error(const rsx_ctx* ctx);
+/* Number of host-pointer calls (rsx_*_decode / rsx_unpack_* / rsx_dng_decompress_* ...)
+ * this context has served: lets an integration check that the batched DNG hunk
+ *  really makes one call per image. */
+uint64_t rsx_ctx_host_calls(const rsx_ctx* ctx);
 
 /* ------------------------------------------------------------------------ */
 /* 1. UncompressedDecompressor                                               */

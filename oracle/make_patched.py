@@ -16,9 +16,15 @@ S = os.path.join(REF, "src", "librawspeed")
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_ref", "patched")
 
+# Every hunk has the same shape: forward to the MI355X core and return when it
+# succeeded; on ANY other status -- no device, unsupported shape, no memory, a damaged
+# stream -- fall through to the method's original body, which does the work on the CPU
+# or throws exactly what the reference throws (message, partial image, ErrorLog).  The
+# C-ABI copies back only what a successful decode produced, so the image is untouched
+# when the original body takes over.
 HUNK_UNPACK = r'''
   // ---- rsx: forward to the MI355X core (INTEGRATION.md 1) ----
-  if (mRaw->getDataType() == RawImageType::F32) {
+  if (rsx_ctx* rsx = rsx_shim::context()) {
     rsx_unpack_desc d{};
     d.crop_x = offset.x;
     d.crop_y = offset.y;
@@ -29,30 +35,28 @@ HUNK_UNPACK = r'''
     d.bit_order = static_cast<int32_t>(order);
     const rsx_image img = rsx_shim::view(mRaw);
     const Buffer in = input.peekRemainingBuffer();
-    if (int st = rsx_unpack_f32(rsx_shim::context(), &d, in.begin(), in.getSize(), &img))
-      rsx_shim::raise(st);
-    return;
-  }
-  if (mRaw->getDataType() == RawImageType::UINT16) {
-    rsx_unpack_desc d{};
-    d.crop_x = offset.x;
-    d.crop_y = offset.y;
-    d.crop_w = size.x;
-    d.crop_h = size.y;
-    d.input_pitch_bytes = inputPitchBytes;
-    d.bits_per_pixel = bitPerPixel;
-    d.bit_order = static_cast<int32_t>(order);
-    const rsx_image img = rsx_shim::view(mRaw);
-    const Buffer in = input.peekRemainingBuffer();
-    if (int st = rsx_unpack_u16(rsx_shim::context(), &d, in.begin(), in.getSize(), &img))
-      rsx_shim::raise(st);
-    return;
+    const bool f32 = mRaw->getDataType() == RawImageType::F32;
+    // a tile of a DNG whose tiles are decoded by one batched call (INTEGRATION.md 4)
+    if (const auto b = rsx_shim::DngBatch::find(in.begin()); b.batch && !f32) {
+      if (!b.batch->replaying) {
+        b.slot->kind = 2;
+        b.slot->up.desc = d;
+        b.slot->up.in = in.begin();
+        b.slot->up.in_bytes = in.getSize();
+        return;
+      }
+      if (b.slot->status == RSX_OK)
+        return;
+    } else if ((f32 ? rsx_unpack_f32(rsx, &d, in.begin(), in.getSize(), &img)
+                    : rsx_unpack_u16(rsx, &d, in.begin(), in.getSize(), &img)) == RSX_OK) {
+      return;
+    }
   }
 '''
 
 HUNK_VARIANT = r'''
   // ---- rsx: forward to the MI355X core (INTEGRATION.md 1b) ----
-  {
+  if (rsx_ctx* rsx = rsx_shim::context()) {
     rsx_unpack_variant_desc d{};
     d.variant = %(variant)s;
     d.big_endian = %(big)s;
@@ -60,16 +64,16 @@ HUNK_VARIANT = r'''
     d.h = size.y;
     const rsx_image img = rsx_shim::view(mRaw);
     const Buffer in = input.peekRemainingBuffer();
-    if (int st = rsx_unpack_variant_u16(rsx_shim::context(), &d, in.begin(), in.getSize(), &img))
-      rsx_shim::raise(st);
-    input.skipBytes(input.getRemainSize());
-    return;
+    if (rsx_unpack_variant_u16(rsx, &d, in.begin(), in.getSize(), &img) == RSX_OK) {
+      input.skipBytes(input.getRemainSize());
+      return;
+    }
   }
 '''
 
 HUNK_8BIT = r'''
   // ---- rsx: forward to the MI355X core (INTEGRATION.md 1b) ----
-  {
+  if (rsx_ctx* rsx = rsx_shim::context()) {
     rsx_unpack_variant_desc d{};
     d.variant = uncorrectedRawValues ? RSX_UNPACK_8BIT_RAW : RSX_UNPACK_8BIT_LOOKUP;
     d.w = size.x;
@@ -86,10 +90,10 @@ HUNK_8BIT = r'''
     }
     const rsx_image img = rsx_shim::view(mRaw);
     const Buffer in = input.peekRemainingBuffer();
-    if (int st = rsx_unpack_variant_u16(rsx_shim::context(), &d, in.begin(), in.getSize(), &img))
-      rsx_shim::raise(st);
-    input.skipBytes(input.getRemainSize());
-    return;
+    if (rsx_unpack_variant_u16(rsx, &d, in.begin(), in.getSize(), &img) == RSX_OK) {
+      input.skipBytes(input.getRemainSize());
+      return;
+    }
   }
 '''
 HUNK_CONTROL = HUNK_VARIANT % dict(variant="RSX_UNPACK_12BIT_WITH_CONTROL",
@@ -99,7 +103,7 @@ HUNK_LEFT = HUNK_VARIANT % dict(variant="RSX_UNPACK_12BIT_UNPACKED_LEFT_ALIGNED"
 
 HUNK_LJPEG = r'''
   // ---- rsx: forward to the MI355X core (INTEGRATION.md 2) ----
-  {
+  if (rsx_ctx* rsx = rsx_shim::context()) {
     rsx_ljpeg_desc d{};
     d.tile_x = imgFrame.pos.x;
     d.tile_y = imgFrame.pos.y;
@@ -112,18 +116,33 @@ HUNK_LJPEG = r'''
     d.n_comp = implicit_cast<int32_t>(rec.size());
     d.rows_per_restart_interval = numLJpegRowsPerRestartInterval;
     rsx_shim::recipes(rec, &d);
-    const rsx_image img = rsx_shim::view(mRaw);
-    uint32_t consumed = 0;
-    if (int st = rsx_ljpeg_decode(rsx_shim::context(), &d, input.begin(),
-                                  implicit_cast<size_t>(input.size()), &img, &consumed))
-      rsx_shim::raise(st);
-    return consumed;
+    // a tile of a DNG whose tiles are decoded by one batched call (INTEGRATION.md 4):
+    // record it; LJpegDecoder's marker walk goes on from the end of the scan
+    if (const auto b = rsx_shim::DngBatch::find(input.begin()); b.batch) {
+      if (!b.batch->replaying) {
+        b.slot->kind = 1;
+        b.slot->lj.desc = d;
+        b.slot->lj.in = input.begin();
+        b.slot->lj.in_bytes = implicit_cast<size_t>(input.size());
+        b.slot->consumed = rsx_shim::DngBatch::endOfScan(input.begin(),
+                                                         implicit_cast<size_t>(input.size()));
+        return b.slot->consumed;
+      }
+      if (b.slot->status == RSX_OK)
+        return b.slot->consumed;
+    } else {
+      const rsx_image img = rsx_shim::view(mRaw);
+      uint32_t consumed = 0;
+      if (rsx_ljpeg_decode(rsx, &d, input.begin(), implicit_cast<size_t>(input.size()), &img,
+                           &consumed) == RSX_OK)
+        return consumed;
+    }
   }
 '''
 
 HUNK_CR2 = r'''
   // ---- rsx: forward to the MI355X core (INTEGRATION.md 3) ----
-  {
+  if (rsx_ctx* rsx = rsx_shim::context()) {
     // the constructor divided frame / slice widths by the sampling factors
     // (Cr2DecompressorImpl.h:305-341); the C-ABI takes them as in the file
     rsx_cr2_desc d{};
@@ -138,16 +157,17 @@ HUNK_CR2 = r'''
     rsx_shim::recipes(rec, &d);
     const rsx_image img = rsx_shim::view(mRaw);
     uint32_t consumed = 0;
-    if (int st = rsx_cr2_decode(rsx_shim::context(), &d, input.begin(),
-                                implicit_cast<size_t>(input.size()), &img, &consumed))
-      rsx_shim::raise(st);
-    return consumed;
+    if (rsx_cr2_decode(rsx, &d, input.begin(), implicit_cast<size_t>(input.size()), &img,
+                       &consumed) == RSX_OK)
+      return consumed;
   }
 '''
 
 HUNK_NIKON = r'''
   // ---- rsx: forward to the MI355X core (INTEGRATION.md 3b) ----
-  {
+  // (after the method's own RawImageCurveGuard: the table state it sets up and leaves
+  // behind is the reference's, whatever path decodes)
+  if (rsx_ctx* rsx = rsx_shim::context()) {
     rsx_nikon_desc d{};
     d.bits_ps = implicit_cast<int32_t>(bitsPS);
     d.split = implicit_cast<int32_t>(split);
@@ -169,34 +189,27 @@ HUNK_NIKON = r'''
       d.tables[t].n_code_values = implicit_cast<uint8_t>(n);
     }
     const rsx_image img = rsx_shim::view(mRaw);
-    if (int st = rsx_nikon_decompress(rsx_shim::context(), &d, input.begin(),
-                                      implicit_cast<size_t>(input.size()), &img))
-      rsx_shim::raise(st);
-    // what ~RawImageCurveGuard leaves behind (common/RawImage.h:376-382)
-    if (uncorrectedRawValues)
-      mRaw->setTable(curve, false);
-    else
-      mRaw->setTable(nullptr);
-    return;
+    if (rsx_nikon_decompress(rsx, &d, input.begin(), implicit_cast<size_t>(input.size()),
+                             &img) == RSX_OK)
+      return;
   }
 '''
 
 HUNK_PENTAX = r'''
   // ---- rsx: forward to the MI355X core (INTEGRATION.md 3c) ----
-  {
+  if (rsx_ctx* rsx = rsx_shim::context()) {
     rsx_pentax_desc d{};
     d.table = rsx_shim::table(ht);
     const rsx_image img = rsx_shim::view(mRaw);
     const Buffer in = data.peekRemainingBuffer();
-    if (int st = rsx_pentax_decompress(rsx_shim::context(), &d, in.begin(), in.getSize(), &img))
-      rsx_shim::raise(st);
-    return;
+    if (rsx_pentax_decompress(rsx, &d, in.begin(), in.getSize(), &img) == RSX_OK)
+      return;
   }
 '''
 
 HUNK_SAMSUNG_V1 = r'''
   // ---- rsx: forward to the MI355X core (INTEGRATION.md 3d) ----
-  {
+  if (rsx_ctx* rsx = rsx_shim::context()) {
     // the encoding table of this method (same pairs as `tab` below)
     static const std::array<std::array<uint8_t, 2>, 14> rsx_tab = {{{3, 4}, {3, 7}, {2, 6}, {2, 5},
         {4, 3}, {6, 0}, {7, 9}, {8, 10}, {9, 11}, {10, 12}, {10, 13}, {5, 1}, {4, 8}, {4, 2}}};
@@ -209,15 +222,14 @@ HUNK_SAMSUNG_V1 = r'''
     }
     const rsx_image img = rsx_shim::view(mRaw);
     const Buffer in = bs.peekRemainingBuffer();
-    if (int st = rsx_samsung_v1_decompress(rsx_shim::context(), &d, in.begin(), in.getSize(), &img))
-      rsx_shim::raise(st);
-    return;
+    if (rsx_samsung_v1_decompress(rsx, &d, in.begin(), in.getSize(), &img) == RSX_OK)
+      return;
   }
 '''
 
 HUNK_SRAW = r'''
   // ---- rsx: forward to the MI355X core (INTEGRATION.md 3a) ----
-  {
+  if (rsx_ctx* rsx = rsx_shim::context()) {
     rsx_sraw_desc d{};
     d.version = version;
     d.subsampling_y = mRaw->metadata.subsampling.y;
@@ -234,40 +246,72 @@ HUNK_SRAW = r'''
     in.dim_y = input.height();
     in.cpp = 1;
     const rsx_image out = rsx_shim::view(mRaw);
-    if (int st = rsx_sraw_interpolate(rsx_shim::context(), &d, &in, &out))
-      rsx_shim::raise(st);
-    return;
+    if (rsx_sraw_interpolate(rsx, &d, &in, &out) == RSX_OK)
+      return;
   }
 '''
 
 HUNK_SONY_ARW1 = r'''
   // ---- rsx: forward to the MI355X core (INTEGRATION.md 3f) ----
-  {
+  if (rsx_ctx* rsx = rsx_shim::context()) {
     const rsx_image img = rsx_shim::view(mRaw);
     const Buffer in = input.peekRemainingBuffer();
-    if (int st = rsx_sony_arw1_decompress(rsx_shim::context(), in.begin(), in.getSize(), &img))
-      rsx_shim::raise(st);
-    return;
+    if (rsx_sony_arw1_decompress(rsx, in.begin(), in.getSize(), &img) == RSX_OK)
+      return;
   }
 '''
 
 HUNK_HASSELBLAD = r'''
   // ---- rsx: forward to the MI355X core (INTEGRATION.md 3e) ----
-  {
+  if (rsx_ctx* rsx = rsx_shim::context()) {
     rec.ht.verifyCodeValuesAsDiffLengths();
     rsx_hasselblad_desc d{};
     d.table = rsx_shim::table(rec.ht);
     d.init_pred = rec.initPred;
     const rsx_image img = rsx_shim::view(mRaw);
     uint32_t consumed = 0;
-    if (int st = rsx_hasselblad_decompress(rsx_shim::context(), &d, input.begin(),
-                                           implicit_cast<size_t>(input.size()), &img, &consumed))
-      rsx_shim::raise(st);
-    return consumed;
+    if (rsx_hasselblad_decompress(rsx, &d, input.begin(), implicit_cast<size_t>(input.size()),
+                                  &img, &consumed) == RSX_OK)
+      return consumed;
   }
 '''
 
+HUNK_DNG = r'''
+  // ---- rsx: one batched call for all tiles (INTEGRATION.md 4) ----
+  // The fan-out below runs as it is, but while `batch` is registered for the tiles'
+  // input ranges the per-tile hunks of UncompressedDecompressor / LJpegDecompressor
+  // record their work instead of doing it; run() then makes ONE
+  // rsx_dng_decompress_* call.  Tiles it did not finish get a second pass of the same
+  // fan-out on the CPU (the finished ones return at once).
+  bool rsxDone = false;
+  if ((compression == 1 || compression == 7) && rsx_shim::context() != nullptr) {
+    rsx_shim::DngBatch batch;
+    for (const auto& e : slices) {
+      const Buffer b = e.bs.peekRemainingBuffer();
+      batch.add(b.begin(), b.getSize());
+    }
+    batch.registerTiles();
+#ifdef HAVE_OPENMP
+#pragma omp parallel default(none) num_threads(                                \
+        rawspeed_get_number_of_processor_cores()) if (slices.size() > 1)
+#endif
+    decompressThread();
+    if (!batch.run(rsx_shim::view(mRaw))) {
+      batch.replaying = true;
+#ifdef HAVE_OPENMP
+#pragma omp parallel default(none) num_threads(                                \
+        rawspeed_get_number_of_processor_cores()) if (slices.size() > 1)
+#endif
+      decompressThread();
+    }
+    rsxDone = true;
+  }
+  if (!rsxDone)
+'''
+
 PATCHES = [
+    ("decompressors/AbstractDngDecompressor.cpp", [
+        ("void AbstractDngDecompressor::decompress() const {", HUNK_DNG)]),
     ("decompressors/UncompressedDecompressor.cpp", [
         ("void UncompressedDecompressor::readUncompressedRaw() {", HUNK_UNPACK),
         ("void UncompressedDecompressor::decode8BitRaw() {", HUNK_8BIT),
@@ -275,8 +319,7 @@ PATCHES = [
         ("void UncompressedDecompressor::decode12BitRawUnpackedLeftAligned() {", HUNK_LEFT),
     ]),
     ("decompressors/NikonDecompressor.cpp", [
-        ("void NikonDecompressor::decompress(Array1DRef<const uint8_t> input,\n"
-         "                                   bool uncorrectedRawValues) {", HUNK_NIKON)]),
+        ("  RawImageCurveGuard curveHandler(&mRaw, curve, uncorrectedRawValues);\n", HUNK_NIKON)]),
     ("decompressors/PentaxDecompressor.cpp", [
         ("void PentaxDecompressor::decompress(ByteStream data) const {", HUNK_PENTAX)]),
     ("decompressors/SamsungV1Decompressor.cpp", [
@@ -297,15 +340,28 @@ PATCHES = [
 
 def main():
     for rel, hunks in PATCHES:
-        src = open(os.path.join(S, rel)).read()
-        # the shim include goes after the file's last #include
-        last_inc = src.rfind("#include ")
-        eol = src.index("\n", last_inc) + 1
-        src = src[:eol] + '#include "rsx_rawspeed_shim.h" // rsx drop-in\n' + src[eol:]
+        orig = open(os.path.join(S, rel)).read()
+        # Insertions, applied back to front so that the offsets stay those of the original.
+        # Every insertion ends with a #line directive that restores the original line
+        # numbering: the reference's exception texts embed __LINE__
+        # (common/RawspeedException.h:83-86), and with the numbering intact a failure that
+        # falls through to the original body reads the same as in the unmodified build.
+        edits = []
+        ns = orig.index("namespace rawspeed {")
+        edits.append((ns, '#include "rsx_rawspeed_shim.h" // rsx drop-in\n#line %d\n'
+                      % (orig.count("\n", 0, ns) + 1)))
         for anchor, hunk in hunks:
-            if src.count(anchor) != 1:
+            if orig.count(anchor) != 1:
                 raise SystemExit("anchor %r not found exactly once in %s" % (anchor, rel))
-            src = src.replace(anchor, anchor + hunk, 1)
+            end = orig.index(anchor) + len(anchor)
+            if anchor.endswith("\n"):  # the anchor is whole lines: the hunk follows them
+                text = hunk.lstrip("\n") + "#line %d\n" % (orig.count("\n", 0, end) + 1)
+            else:                      # the anchor ends a line ("... {")
+                text = hunk + "#line %d" % (orig.count("\n", 0, end) + 2)
+            edits.append((end, text))
+        src = orig
+        for pos, text in sorted(edits, reverse=True):
+            src = src[:pos] + text + src[pos:]
         dst = os.path.join(OUT, rel)
         os.makedirs(os.path.dirname(dst), exist_ok=True)
         with open(dst, "w") as f:

@@ -42,6 +42,9 @@
 #include "io/IOException.h"
 
 #include "../include/rsx.h"
+#ifdef RSX_PATCHED_BUILD
+#include "rsx_rawspeed_shim.h"
+#endif
 
 #include <cstdio>
 #include <cstring>
@@ -118,6 +121,35 @@ extern "C" {
 const char* ref_last_error() { return g_last_error.c_str(); }
 
 void ref_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+
+// The image's ErrorLog (what AbstractDngDecompressor's tile threads append to),
+// newline-separated, so that the tests can compare it between the two builds.
+int ref_image_errors(void* h, char* out, int cap) {
+  auto* r = static_cast<RefImage*>(h);
+  std::string all;
+  const std::vector<std::string> errs = r->img->getErrors(); // (moves them out of the log)
+  for (const auto& e : errs) {
+    all += e;
+    all += '\n';
+  }
+  if (out && cap > 0) {
+    const int n = int(all.size()) < cap - 1 ? int(all.size()) : cap - 1;
+    std::memcpy(out, all.data(), size_t(n));
+    out[n] = 0;
+  }
+  return int(all.size());
+}
+
+// Host-pointer calls the C-ABI has served for this build's context (-1: this is the
+// unmodified build) -- the batched DNG hunk makes ONE per decompress().
+long ref_rsx_host_calls() {
+#ifdef RSX_PATCHED_BUILD
+  rsx_ctx* c = rawspeed::rsx_shim::context();
+  return c ? long(rsx_ctx_host_calls(c)) : 0;
+#else
+  return -1;
+#endif
+}
 
 int ref_max_threads() {
 #ifdef _OPENMP

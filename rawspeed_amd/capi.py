@@ -16,7 +16,7 @@ _lib = None
 # every symbol include/rsx.h declares (tests check that all of them resolve)
 EXPORTS = [
     "rsx_abi_version", "rsx_status_string", "rsx_device_count", "rsx_ctx_create",
-    "rsx_ctx_destroy", "rsx_ctx_last_error",
+    "rsx_ctx_destroy", "rsx_ctx_last_error", "rsx_ctx_host_calls",
     "rsx_unpack_validate", "rsx_unpack_u16",
     "rsx_unpack_f32_validate", "rsx_unpack_f32", "rsx_unpack_f32_plan_create",
     "rsx_unpack_variant_validate", "rsx_unpack_variant_u16", "rsx_unpack_variant_plan_create",

@@ -204,6 +204,10 @@ extern "C" const char* rsx_ctx_last_error(const rsx_ctx* ctx) {
   return ctx ? ctx->last_error.c_str() : "";
 }
 
+extern "C" uint64_t rsx_ctx_host_calls(const rsx_ctx* ctx) {
+  return ctx ? ctx->host_calls.load() : 0;
+}
+
 extern "C" int rsx_unpack_validate(const rsx_unpack_desc* d, const rsx_image* img,
                                    size_t in_bytes) {
   if (!d || !img)
@@ -707,6 +711,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
                 const uint8_t* const* ins, const size_t* in_bytes,
                 const rsx_image* img, int32_t* statuses) {
+  ++ctx->host_calls;
   // device-side layout: inputs back to back (16-byte aligned), one compact
   // output rectangle per tile
   std::vector<rsx_unpack_job> jobs(n);
@@ -1478,6 +1483,7 @@ template <typename JobT, typename CreateFn>
 int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
                       const uint8_t* const* ins, const rsx_image* img,
                       CreateFn create, int32_t* statuses, uint32_t* consumed) {
+  ++ctx->host_calls;
   // the staging buffers belong to the context: one host-pointer call at a time
   std::lock_guard<std::recursive_mutex> whole_call(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));

@@ -4,6 +4,7 @@
 
 #include "rsx.h"
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <mutex>
@@ -151,6 +152,7 @@ struct rsx_ctx {
   // own the context's staging buffers) and call the plan API underneath
   std::recursive_mutex mu;
   std::string last_error;
+  std::atomic<uint64_t> host_calls{0}; // host-pointer entry points served
   // staging for the host-pointer calls
   rsx::DeviceBuffer d_in, d_out;
   void* h_pinned = nullptr;

@@ -24,18 +24,22 @@
 #include "io/IOException.h"
 
 #include <cstdint>
+#include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <vector>
 
 namespace rawspeed::rsx_shim {
 
 // One lazily created context per process; rsx calls are re-entrant per context
 // (the DNG tile threads may all enter: AbstractDngDecompressor.cpp:112-131).
+// nullptr when there is no usable device: every hunk then falls through to the
+// method's original body, so a patched rawspeed still works without a GPU.
 inline rsx_ctx* context() {
   static rsx_ctx* ctx = [] {
     rsx_ctx* c = nullptr;
     if (rsx_ctx_create(/*device=*/0, &c) != RSX_OK)
-      ThrowRDE("rsx: no usable MI355X device");
+      c = nullptr;
     return c;
   }();
   return ctx;
@@ -66,6 +70,137 @@ inline rsx_image view(const RawImage& img) {
     ThrowRDE("rsx: %s: %s", rsx_status_string(st), rsx_ctx_last_error(context()));
   }
 }
+
+// ---------------------------------------------------------------------------
+// AbstractDngDecompressor::decompress(): ONE batched call for all tiles
+// (INTEGRATION.md 4).  The reference's own fan-out (decompressThread<1> / <7>, an
+// `omp for` over the tiles) runs unchanged, but while a batch is registered for the
+// tiles' input ranges the per-tile hunks of UncompressedDecompressor /
+// LJpegDecompressor RECORD their descriptor instead of decoding.  run() then hands
+// all recorded tiles to rsx_dng_decompress_* in one call.  Tiles the device path did
+// not finish (damaged stream, unsupported shape, no memory) are left to a second
+// pass of the same fan-out in which the hunks of the finished tiles return at once
+// and the others fall through to the original CPU code -- which decodes them, or
+// throws exactly what the reference throws.
+// ---------------------------------------------------------------------------
+class DngBatch final {
+public:
+  struct Slot {
+    int kind = 0; // 0 = not recorded, 1 = LJPEG scan, 2 = uncompressed strip
+    rsx_dng_ljpeg_tile lj{};
+    rsx_dng_unpack_tile up{};
+    int32_t status = RSX_ERR_UNSUPPORTED;
+    uint32_t consumed = 0;
+  };
+  struct Found {
+    DngBatch* batch = nullptr;
+    Slot* slot = nullptr;
+  };
+
+  DngBatch() = default;
+  DngBatch(const DngBatch&) = delete;
+  DngBatch& operator=(const DngBatch&) = delete;
+  ~DngBatch() {
+    std::unique_lock lock(registry().m);
+    for (auto it = registry().ranges.begin(); it != registry().ranges.end();)
+      it = it->second.batch == this ? registry().ranges.erase(it) : std::next(it);
+  }
+
+  // one tile: the bytes the reference hands to its per-tile decompressor
+  void add(const uint8_t* begin, size_t size) {
+    slots.emplace_back();
+    pending.push_back({begin, size});
+  }
+  void registerTiles() {
+    std::unique_lock lock(registry().m);
+    for (size_t i = 0; i < pending.size(); ++i)
+      registry().ranges[pending[i].first] = {pending[i].first + pending[i].second, this, &slots[i]};
+  }
+  // the batch (if any) whose tile holds `p`
+  static Found find(const uint8_t* p) {
+    std::shared_lock lock(registry().m);
+    auto& r = registry().ranges;
+    auto it = r.upper_bound(p);
+    if (it == r.begin())
+      return {};
+    --it;
+    if (p >= it->second.end)
+      return {};
+    return {it->second.batch, it->second.slot};
+  }
+
+  bool replaying = false;
+
+  // true: every recorded tile is done; false: a second (CPU) pass is needed
+  bool run(const rsx_image& img) {
+    std::vector<rsx_dng_ljpeg_tile> lj;
+    std::vector<rsx_dng_unpack_tile> up;
+    std::vector<Slot*> ljs, ups;
+    for (Slot& s : slots) {
+      if (s.kind == 1) {
+        lj.push_back(s.lj);
+        ljs.push_back(&s);
+      } else if (s.kind == 2) {
+        up.push_back(s.up);
+        ups.push_back(&s);
+      }
+    }
+    bool all = true;
+    if (!lj.empty()) {
+      std::vector<int32_t> st(lj.size(), RSX_ERR_DEVICE);
+      std::vector<uint32_t> cons(lj.size(), 0);
+      (void)rsx_dng_decompress_ljpeg(context(), implicit_cast<int>(lj.size()), lj.data(), &img,
+                                     st.data(), cons.data());
+      for (size_t i = 0; i < ljs.size(); ++i) {
+        ljs[i]->status = st[i];
+        // LJpegDecoder's marker walk went on from the end of the scan (endOfScan()).  A
+        // bottom-overhanging tile stops earlier; that makes no difference to the walk
+        // unless there are restart markers left in between, which the reference trips
+        // over -- such a tile is redone by the original code.
+        const bool dri = lj[i].desc.rows_per_restart_interval < lj[i].desc.frame_h;
+        if (st[i] == RSX_OK && cons[i] != ljs[i]->consumed && dri)
+          ljs[i]->status = RSX_ERR_UNSUPPORTED;
+        all = all && ljs[i]->status == RSX_OK;
+      }
+    }
+    if (!up.empty()) {
+      std::vector<int32_t> st(up.size(), RSX_ERR_DEVICE);
+      (void)rsx_dng_decompress_uncompressed(context(), implicit_cast<int>(up.size()), up.data(),
+                                            &img, st.data());
+      for (size_t i = 0; i < ups.size(); ++i) {
+        ups[i]->status = st[i];
+        all = all && st[i] == RSX_OK;
+      }
+    }
+    return all;
+  }
+
+  // offset of the marker that ends an entropy-coded segment: the first FF xx with xx
+  // neither 00 (a stuffed FF) nor D0..D7 (RSTn); the size if there is none
+  static uint32_t endOfScan(const uint8_t* p, size_t n) {
+    for (size_t i = 0; i + 1 < n; ++i)
+      if (p[i] == 0xFF && p[i + 1] != 0x00 && (p[i + 1] < 0xD0 || p[i + 1] > 0xD7))
+        return implicit_cast<uint32_t>(i);
+    return implicit_cast<uint32_t>(n);
+  }
+
+private:
+  struct Range {
+    const uint8_t* end;
+    DngBatch* batch;
+    Slot* slot;
+  };
+  struct Registry {
+    std::shared_mutex m;
+    std::map<const uint8_t*, Range> ranges;
+  };
+  static Registry& registry() {
+    static Registry r;
+    return r;
+  }
+  std::vector<Slot> slots;
+  std::vector<std::pair<const uint8_t*, size_t>> pending;
+};
 
 // DHT payload of a borrowed decoder -> rsx_huff_table
 inline rsx_huff_table table(const PrefixCodeDecoder<>& ht) {

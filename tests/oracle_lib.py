@@ -349,6 +349,8 @@ class Ref:
         L.ref_unpack_frames_parallel.argtypes = [C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_size_t, C.c_int]
         L.ref_set_threads.argtypes = [C.c_int]
+        L.ref_image_errors.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.ref_rsx_host_calls.restype = C.c_long
         L.ref_scan_frames_parallel.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_int, C.c_int]
 
@@ -414,6 +416,15 @@ class Ref:
         st = self.lib.ref_cr2_decompress(img.h, C.byref(desc), p, n,
                                          C.byref(consumed))
         return st, consumed.value
+
+    def image_errors(self, img):
+        """the image's ErrorLog (moved out of it), one entry per line"""
+        buf = C.create_string_buffer(1 << 16)
+        self.lib.ref_image_errors(img.h, buf, len(buf))
+        return buf.value.decode(errors="replace")
+
+    def rsx_host_calls(self):
+        return int(self.lib.ref_rsx_host_calls())
 
     def scan_frames_parallel(self, imgs, descs, datas, kind, threads):
         """LJpegDecompressor (kind 0) / Cr2Decompressor (kind 1) over independent frames,

@@ -292,3 +292,105 @@ def test_sony_arw1_decompressor(pair):
         assert s0 == s1, (e0, e1)
         if s0 == 0:
             assert np.array_equal(a, b)
+
+
+# ---- one batched call per DNG, fall-through, error parity ---------------------------
+def _dng_case(rng, W, H, tw, th, corrupt=()):
+    src = C.smooth_image(rng, H, W)
+    blobs = []
+    k = 0
+    for ty in range((H + th - 1) // th):
+        for tx in range((W + tw - 1) // tw):
+            tile = np.full((th, tw), 1000, np.uint16)
+            part = src[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw]
+            tile[:part.shape[0], :part.shape[1]] = part
+            blob, hdr, scan_len, _ = synth.ljpeg_container(tile, 2, 14, [0, 0], [C.NIKON])
+            if k in corrupt:
+                blob = blob.copy()
+                blob[hdr + scan_len // 2:hdr + scan_len // 2 + 2] = 0xFF  # FF FF: early end
+            blobs.append(blob)
+            k += 1
+    return src, blobs
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_dng_decompress_makes_one_batched_call(pair, threads):
+    """AbstractDngDecompressor::decompress() of the patched build: the reference's own
+    tile fan-out runs (headers, marker walks), the tiles are decoded by ONE
+    rsx_dng_decompress_ljpeg call."""
+    ref, rsx = pair
+    rng = np.random.default_rng(41)
+    W, H, tw, th = 1500, 700, 512, 256   # 3 x 3 tiles, right and bottom ones overhang
+    src, blobs = _dng_case(rng, W, H, tw, th)
+    before = rsx.rsx_host_calls()
+    (s0, a, e0), (s1, b, e1) = both(
+        pair, lambda lib, img: lib.dng(img, 7, tw, th, blobs, threads=threads), (W, H, 1))
+    assert ref.rsx_host_calls() == -1
+    assert rsx.rsx_host_calls() - before == 1
+    assert s0 == 0 and s1 == 0, (e0, e1)
+    assert np.array_equal(a, b) and np.array_equal(a[:, :W], src)
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_dng_uncompressed_tiles_make_one_batched_call(pair, threads):
+    ref, rsx = pair
+    rng = np.random.default_rng(42)
+    W, H, tw, th, bps = 1000, 300, 256, 128, 16
+    blobs = [rng.integers(0, 256, size=th * tw * bps // 8, dtype=np.uint8)
+             for _ in range(((H + th - 1) // th) * ((W + tw - 1) // tw))]
+    before = rsx.rsx_host_calls()
+    (s0, a, e0), (s1, b, e1) = both(
+        pair, lambda lib, img: lib.dng(img, 1, tw, th, blobs, bps=bps, threads=threads),
+        (W, H, 1))
+    assert rsx.rsx_host_calls() - before == 1
+    assert s0 == 0 and s1 == 0, (e0, e1)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("corrupt", [(4,), (0, 7)])
+def test_dng_corrupt_tiles_same_image_and_error_log(pair, corrupt):
+    """A damaged tile: the device path reports it, the tile is redone by the original
+    CPU loop -- same partial image, same ErrorLog, same "too many errors" decision."""
+    rng = np.random.default_rng(43)
+    W, H, tw, th = 1536, 768, 512, 256
+    src, blobs = _dng_case(rng, W, H, tw, th, corrupt)
+    out = []
+    for lib in pair:
+        img = lib.image(W, H, 1)
+        st = lib.dng(img, 7, tw, th, blobs, threads=2)
+        out.append((st, img.u16().copy(), lib.last_error(), lib.image_errors(img)))
+    (s0, a, e0, log0), (s1, b, e1, log1) = out
+    assert s0 == s1 != 0  # (isTooManyErrors(1): one failed tile fails the image)
+    assert e0 == e1
+    assert sorted(log0.splitlines()) == sorted(log1.splitlines()) and log0
+    assert np.array_equal(a, b)
+
+
+def test_corrupt_scan_same_partial_image_and_message(pair):
+    """LJpegDecoder on a stream that ends early: the patched build falls through to the
+    reference's own loop, so the exception text and the partially decoded image agree."""
+    rng = np.random.default_rng(44)
+    W, H = 512, 128
+    src = C.smooth_image(rng, H, W)
+    blob, hdr, scan_len, _ = synth.ljpeg_container(src, 2, 14, [0, 0], [C.NIKON])
+    bad = blob.copy()
+    bad[hdr + scan_len // 2:hdr + scan_len // 2 + 2] = 0xFF
+    (s0, a, e0), (s1, b, e1) = both(
+        pair, lambda lib, img: lib.ljpeg_container(bad, img, 0, 0, W, H, (W, H)), (W, H, 1))
+    assert s0 == s1 != 0 and e0 == e1 and e0
+    assert np.array_equal(a, b)
+
+
+def test_unsupported_shape_falls_through_to_the_cpu_loop(pair):
+    """More CR2 output strips than the device path takes (RSX_ERR_UNSUPPORTED): the
+    patched Cr2Decompressor::decompress() runs its original body."""
+    rng = np.random.default_rng(45)
+    n_slices, sw = 70, 4
+    W, H = n_slices * sw, 16
+    src = C.smooth_image(rng, H, W)
+    rows = C.cr2_stream_from_image(src, 2, W // 2, H, [sw] * n_slices)
+    blob, _, _, _ = synth.ljpeg_container(rows, 2, 14, [0, 0], [C.NIKON])
+    (s0, a, e0), (s1, b, e1) = both(
+        pair, lambda lib, img: lib.cr2_container(blob, img, n_slices, sw, sw), (W, H, 1))
+    assert s0 == 0 and s1 == 0, (e0, e1)
+    assert np.array_equal(a, b) and np.array_equal(a[:, :W], src)
