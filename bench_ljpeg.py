@@ -723,6 +723,96 @@ def run_variants(ctx, torch, log, frames=8, steps=50, warmup=20):
     return out
 
 
+def run_host_path(torch, log, reps=7):
+    """What a patched rawspeed sees: the reference's own entry points of
+    the GPU-backed build (oracle/_ref/librawspeed_rsx.so) on pageable host buffers --
+    staging over PCIe included -- next to this box's plain pageable copy of the same
+    bytes (hipMemcpy H2D of the input + D2H of the output, nothing else)."""
+    from oracle_lib import Ref
+    from rawspeed_amd import abi, synth
+    here = os.path.join(ROOT, "oracle", "_ref", "librawspeed_rsx.so")
+    if not os.path.exists(here):
+        return {"error": "oracle/_ref/librawspeed_rsx.so is not built"}
+    rsx = Ref(here)
+    ref = Ref() if Ref.available() else None
+
+    def copy_rate(n_in, n_out):
+        hin = np.zeros(n_in, np.uint8)
+        hout = np.zeros(n_out, np.uint8)
+        din = torch.empty(n_in, dtype=torch.uint8, device="cuda")
+        dout = torch.empty(n_out, dtype=torch.uint8, device="cuda")
+        tin, tout = torch.from_numpy(hin), torch.from_numpy(hout)
+        best = None
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            din.copy_(tin)
+            tout.copy_(dout)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best
+
+    def timed(fn):
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            st = fn()
+            dt = time.perf_counter() - t0
+            assert st == 0, rsx.last_error()
+            best = dt if best is None else min(best, dt)
+        return best
+
+    def leg(what, W, H, n_in, fn, check):
+        n_out = W * H * 2
+        fn()  # first call: context, module load
+        dt = timed(fn)
+        dc = copy_rate(n_in, n_out)
+        return {"workload": what, "ms_per_call": round(dt * 1e3, 3),
+                "mpix_per_s": round(W * H / dt / 1e6, 1),
+                "link_gbps": round((n_in + n_out) / dt / 1e9, 1),
+                "pageable_copy_ms": round(dc * 1e3, 3),
+                "pageable_copy_gbps": round((n_in + n_out) / dc / 1e9, 1),
+                "frac_of_pageable_copy_rate": round(dc / dt, 3),
+                "bit_exact": bool(check())}
+
+    out = {}
+    # cfg 2: UncompressedDecompressor::readUncompressedRaw
+    W, H, bps = 8192, 5464, 14
+    px = synth.uniform(W * H, bps, 7).reshape(H, W)
+    packed = synth.pack_rows(px, bps, 1)
+    d = abi.UnpackDesc(0, 0, W, H, W * bps // 8, bps, 1)
+    img = rsx.image(W, H, 1)
+    out["cfg2_unpack_14bit_8192x5464"] = leg(
+        "UncompressedDecompressor::readUncompressedRaw of the patched reference, one frame",
+        W, H, packed.size, lambda: rsx.unpack(d, packed, img),
+        lambda: np.array_equal(img.pixels(), px))
+    # cfg 3: Cr2Decompressor::decompress
+    W, H = 6720, 4480
+    d3, data3, src3, n3, _ = make_cr2_frame(W, H, (3, 2240, 2240), seed=1)
+    img3 = rsx.image(W, H, 1)
+    out["cfg3_cr2_6720x4480"] = leg(
+        "Cr2Decompressor::decompress of the patched reference, one frame",
+        W, H, data3.size, lambda: rsx.cr2(d3, data3, img3)[0],
+        lambda: np.array_equal(img3.pixels(), src3))
+    # cfg 4: AbstractDngDecompressor::decompress -> one batched call for the 4 tiles
+    W, H, tw, th = 8192, 5464, 4096, 2732
+    src4, jobs, datas, blobs, lens = _dng_tiles(W, H, tw, th, 2)
+    img4 = rsx.image(W, H, 1)
+    # (rawspeed_get_number_of_processor_cores() = the tile count: an OpenMP team of all
+    # 256 host threads for four tiles costs more than the decode)
+    nt4 = min(host_threads(rsx), len(blobs))
+    calls0 = rsx.rsx_host_calls()
+    res4 = leg("AbstractDngDecompressor::decompress of the patched reference (4 LJPEG tiles, "
+               "one batched call), one frame",
+               W, H, sum(b.size for b in blobs), lambda: rsx.dng(img4, 7, tw, th, blobs, threads=nt4),
+               lambda: np.array_equal(img4.pixels(), src4))
+    res4["openmp_threads"] = nt4
+    res4["rsx_calls_per_decompress"] = round((rsx.rsx_host_calls() - calls0) / (reps + 1), 2)
+    out["cfg4_dng_tiles_8192x5464"] = res4
+    return out
+
+
 def run(ctx, torch, log):
     out = {}
 
@@ -741,6 +831,7 @@ def run(ctx, torch, log):
     leg("hasselblad_8272x6200", lambda: run_hasselblad(ctx, torch, log))
     leg("sony_arw1_3881x2608", lambda: run_sony_arw1(ctx, torch, log))
     leg("cr2_sraw1_3960x2640", lambda: run_sraw(ctx, torch, log))
+    leg("host_path", lambda: run_host_path(torch, log))
     return out
 
 
@@ -778,6 +869,8 @@ if __name__ == "__main__":
     elif args.only == "clipped":
         print(json.dumps(run_clipped(ctx, torch, print, frames=args.frames, steps=args.steps),
                          indent=1))
+    elif args.only == "host":
+        print(json.dumps(run_host_path(torch, print), indent=1))
     elif args.only == "cfg4":
         print(json.dumps(run_cfg4(ctx, torch, print, steps=args.steps), indent=1))
     else:

@@ -124,8 +124,9 @@ HUNK_LJPEG = r'''
         b.slot->lj.desc = d;
         b.slot->lj.in = input.begin();
         b.slot->lj.in_bytes = implicit_cast<size_t>(input.size());
-        b.slot->consumed = rsx_shim::DngBatch::endOfScan(input.begin(),
-                                                         implicit_cast<size_t>(input.size()));
+        b.slot->consumed = rsx_shim::DngBatch::endOfScan(
+            input.begin(), implicit_cast<size_t>(input.size()),
+            /*full_height=*/d.tile_h >= d.frame_h * d.mcu_h);
         return b.slot->consumed;
       }
       if (b.slot->status == RSX_OK)

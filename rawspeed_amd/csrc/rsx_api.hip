@@ -1519,14 +1519,39 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
     return rc;
   // only the rectangle a successful job decoded goes back to the host image:
   // pixels outside it (other tiles, padding) are never touched
+  std::vector<HostRect> rects;
   for (int i = 0; i < n; ++i) {
     if (statuses)
       statuses[i] = st[i];
     if (consumed)
       consumed[i] = cons[i];
-    if (st[i] != RSX_OK)
-      continue;
-    const HostRect r = out_rect(jobs[i]);
+    if (st[i] == RSX_OK)
+      rects.push_back(out_rect(jobs[i]));
+  }
+  // Tiles that together fill their bounding box (the rule: every tile of a DNG decoded)
+  // go back as ONE rectangle -- a pageable 2D copy per tile cost 2 ms more on the four
+  // tiles of an 8192x5464 frame than the copy of the whole frame.
+  if (rects.size() > 1) {
+    size_t r0 = ~size_t(0), r1 = 0, b0 = ~size_t(0), b1 = 0, area = 0;
+    for (const HostRect& r : rects) {
+      r0 = std::min(r0, r.row0);
+      r1 = std::max(r1, r.row0 + r.rows);
+      b0 = std::min(b0, r.byte0);
+      b1 = std::max(b1, r.byte0 + r.bytes);
+      area += r.rows * r.bytes;
+    }
+    bool disjoint = true; // (tiles of one image never overlap; checked for the few there are)
+    for (size_t x = 0; x < rects.size() && disjoint && rects.size() <= 64; ++x)
+      for (size_t y = x + 1; y < rects.size(); ++y) {
+        const HostRect &p = rects[x], &q = rects[y];
+        if (p.row0 < q.row0 + q.rows && q.row0 < p.row0 + p.rows &&
+            p.byte0 < q.byte0 + q.bytes && q.byte0 < p.byte0 + p.bytes)
+          disjoint = false;
+      }
+    if (disjoint && rects.size() <= 64 && area == (r1 - r0) * (b1 - b0))
+      rects.assign(1, HostRect{r0, r1 - r0, b0, b1 - b0});
+  }
+  for (const HostRect& r : rects) {
     const size_t off = r.row0 * img->pitch_bytes + r.byte0;
     RSX_HIP_CHECK(ctx, hipMemcpy2DAsync(static_cast<uint8_t*>(img->data) + off,
                                         img->pitch_bytes,

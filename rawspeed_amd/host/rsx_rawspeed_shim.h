@@ -24,6 +24,7 @@
 #include "io/IOException.h"
 
 #include <cstdint>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <shared_mutex>
@@ -154,11 +155,14 @@ public:
       for (size_t i = 0; i < ljs.size(); ++i) {
         ljs[i]->status = st[i];
         // LJpegDecoder's marker walk went on from the end of the scan (endOfScan()).  A
+        // tile decoded to its full height must have stopped exactly there.  A
         // bottom-overhanging tile stops earlier; that makes no difference to the walk
         // unless there are restart markers left in between, which the reference trips
-        // over -- such a tile is redone by the original code.
-        const bool dri = lj[i].desc.rows_per_restart_interval < lj[i].desc.frame_h;
-        if (st[i] == RSX_OK && cons[i] != ljs[i]->consumed && dri)
+        // over.  Anything else is redone by the original code.
+        const rsx_ljpeg_desc& d = lj[i].desc;
+        const bool dri = d.rows_per_restart_interval < d.frame_h;
+        const bool full = d.tile_h >= d.frame_h * d.mcu_h;
+        if (st[i] == RSX_OK && cons[i] != ljs[i]->consumed && (full || dri))
           ljs[i]->status = RSX_ERR_UNSUPPORTED;
         all = all && ljs[i]->status == RSX_OK;
       }
@@ -175,12 +179,33 @@ public:
     return all;
   }
 
-  // offset of the marker that ends an entropy-coded segment: the first FF xx with xx
-  // neither 00 (a stuffed FF) nor D0..D7 (RSTn); the size if there is none
-  static uint32_t endOfScan(const uint8_t* p, size_t n) {
-    for (size_t i = 0; i + 1 < n; ++i)
-      if (p[i] == 0xFF && p[i + 1] != 0x00 && (p[i + 1] < 0xD0 || p[i + 1] > 0xD7))
-        return implicit_cast<uint32_t>(i);
+  // Offset of the marker that ends the entropy-coded segment [p, p + n) -- the first
+  // FF xx with xx neither 00 (a stuffed FF) nor D0..D7 (RSTn); n if there is none.
+  // A tile that is decoded to its full height ends ON that marker, and in a well-formed
+  // tile it is the last thing in the buffer: it is looked for from the end (a few bytes)
+  // and run() checks the guess against what the decode reports -- a stream with an
+  // earlier marker is redone by the original code.  A bottom-overhanging tile stops
+  // before the marker, nothing checks the guess then, so it is searched from the front.
+  static uint32_t endOfScan(const uint8_t* p, size_t n, bool full_height) {
+    auto is_end = [&](size_t i) {
+      return p[i] == 0xFF && p[i + 1] != 0x00 && (p[i + 1] < 0xD0 || p[i + 1] > 0xD7);
+    };
+    if (full_height) {
+      for (size_t i = n; i >= 2; --i)
+        if (is_end(i - 2))
+          return implicit_cast<uint32_t>(i - 2);
+      return implicit_cast<uint32_t>(n);
+    }
+    const uint8_t* q = p;
+    const uint8_t* const last = p + (n ? n - 1 : 0);
+    while (q < last) {
+      q = static_cast<const uint8_t*>(std::memchr(q, 0xFF, size_t(last - q)));
+      if (!q)
+        break;
+      if (is_end(size_t(q - p)))
+        return implicit_cast<uint32_t>(q - p);
+      ++q;
+    }
     return implicit_cast<uint32_t>(n);
   }
 
