@@ -1484,6 +1484,10 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
                       const uint8_t* const* ins, const rsx_image* img,
                       CreateFn create, int32_t* statuses, uint32_t* consumed) {
   ++ctx->host_calls;
+  // (the image view sizes the staging: check it before anything is allocated or copied;
+  // every decompressor's own validation rejects such an image as well)
+  if (img->dim_x <= 0 || img->dim_y <= 0 || img->pitch_bytes == 0 || n < 1)
+    return RSX_ERR_INVALID_ARG;
   // the staging buffers belong to the context: one host-pointer call at a time
   std::lock_guard<std::recursive_mutex> whole_call(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));

@@ -281,6 +281,8 @@ int validate_ljpeg(const rsx_ljpeg_desc& d, const rsx_image& img) {
   if (int64_t(mw) * d.frame_w > 0x7FFFFFFF ||
       int64_t(mh) * d.frame_h > 0x7FFFFFFF) // :118-122
     return RSX_ERR_INVALID_ARG;
+  if (int64_t(img.cpp) * d.tile_w > 0x7FFFFFFF) // "Img frame is too big" :124-126
+    return RSX_ERR_INVALID_ARG;
   if (d.tile_w < mw || d.tile_h < mh) // :128-129
     return RSX_ERR_INVALID_ARG;
   if (d.tile_h % mh != 0) // :131-132
@@ -333,6 +335,11 @@ std::vector<Rect> all_output_tiles(const Cr2Geom& g) {
     }
     if (oy == g.dim_y) {
       oy = 0;
+      // a column that starts at or past the right edge holds nothing of the image: the
+      // reference's walk stops at the first tile that lies outside it
+      // (Cr2DecompressorImpl.h:404-407), and ox must not run away over many wide slices
+      if (int64_t(ox) + t.w >= int64_t(g.dim_x))
+        break;
       ox += t.w;
     }
     if (t.h <= 0 && tiles.size() > 100000)
@@ -685,7 +692,9 @@ namespace {
 
 struct BlockCache {
   static constexpr int kMaxDevices = 64;
-  static constexpr size_t kMaxCachedBytes = size_t(8) << 30;
+  // (freed device blocks kept for reuse by the next plan: a batch pipeline recycles a
+  // few hundred MB per image; anything beyond this goes back to the driver at once)
+  static constexpr size_t kMaxCachedBytes = size_t(2) << 30;
   std::mutex mu;
   std::multimap<size_t, void*> free_blocks[kMaxDevices];
   size_t cached_bytes = 0;

@@ -136,9 +136,30 @@ int build_cr2_stream(const rsx_cr2_desc& d, const rsx_image& img,
 // ------------------------------------------------------------------------
 // Context / plan
 // ------------------------------------------------------------------------
+// Owning handle of a device allocation (blocks are recycled through a small
+// size-keyed cache, rsx_host.cpp).  Released on destruction, so every early return of
+// the plan builders gives its memory back.
 struct DeviceBuffer {
   void* ptr = nullptr;
   size_t bytes = 0;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  DeviceBuffer(DeviceBuffer&& o) noexcept : ptr(o.ptr), bytes(o.bytes) {
+    o.ptr = nullptr;
+    o.bytes = 0;
+  }
+  DeviceBuffer& operator=(DeviceBuffer&& o) noexcept {
+    if (this != &o) {
+      release();
+      ptr = o.ptr;
+      bytes = o.bytes;
+      o.ptr = nullptr;
+      o.bytes = 0;
+    }
+    return *this;
+  }
+  ~DeviceBuffer() { release(); }
   int ensure(size_t n); // grow-only; returns RSX_OK / RSX_ERR_NOMEM
   void release();
 };

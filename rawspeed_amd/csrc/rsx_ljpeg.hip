@@ -1980,6 +1980,22 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
                                 : g.strip_first_sample[g.n_strips];
     if (st == RSX_OK && needed >= 0xFFFFFFF0ull)
       st = RSX_ERR_UNSUPPORTED;
+    // LJPEG / CR2 streams with 1, 2 or 4 interleaved components take the fused
+    // decode + reconstruction; everything else (sRaw groups, 3 components, the
+    // Nikon-type kinds, Hasselblad pairs) the legacy route through differences
+    uint8_t direct_n = 0;
+#ifndef RSX_NO_DIRECT
+    if ((g.kind == 0 || g.kind == 1) && !g.raw && !g.las && !g.pair && !g.no_vertical &&
+        g.period == g.n_comp && (g.n_comp == 1 || g.n_comp == 2 || g.n_comp == 4) &&
+        J.explicit_n == 0)
+      direct_n = uint8_t(g.n_comp);
+#endif
+    // The legacy route keeps a 2-byte difference per symbol, sized by the frame the
+    // header declares, not by the input: a small tile that claims a huge frame is
+    // refused (the forwarding hunks then leave it to the original CPU loop) instead of
+    // asking the driver for gigabytes.
+    if (st == RSX_OK && !direct_n && needed > (uint64_t(1) << 30))
+      st = RSX_ERR_UNSUPPORTED;
     p->job_status[i] = st;
     if (st != RSX_OK)
       continue;
@@ -2015,15 +2031,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     S.las = g.las;
     S.pair = g.pair;
     S.no_vertical = g.no_vertical;
-    // LJPEG / CR2 streams with 1, 2 or 4 interleaved components take the fused
-    // decode + reconstruction; everything else (sRaw groups, 3 components, the
-    // Nikon-type kinds, Hasselblad pairs) the legacy route through differences
-#ifndef RSX_NO_DIRECT
-    if ((g.kind == 0 || g.kind == 1) && !g.raw && !g.las && !g.pair && !g.no_vertical &&
-        g.period == g.n_comp && (g.n_comp == 1 || g.n_comp == 2 || g.n_comp == 4) &&
-        J.explicit_n == 0)
-      S.direct = uint8_t(g.n_comp);
-#endif
+    S.direct = direct_n;
     S.raw_limit = g.raw_limit;
     S.rows = g.rows;
     S.row_samples = g.row_samples;
