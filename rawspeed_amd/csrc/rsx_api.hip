@@ -142,6 +142,41 @@ int flatten_unpack_job(const rsx_unpack_job& j, UnpackJobDev* out, int* order) {
 // ---------------------------------------------------------------------------
 // Misc
 // ---------------------------------------------------------------------------
+rsx_ctx::HostLane* rsx_ctx::acquire_lane() {
+  {
+    std::lock_guard<std::mutex> g(lanes_mu);
+    if (!lanes_free.empty()) {
+      HostLane* l = lanes_free.back();
+      lanes_free.pop_back();
+      return l;
+    }
+  }
+  auto l = std::make_unique<HostLane>();
+  if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess)
+    return nullptr;
+  std::lock_guard<std::mutex> g(lanes_mu);
+  lanes_all.push_back(std::move(l));
+  return lanes_all.back().get();
+}
+
+void rsx_ctx::release_lane(HostLane* l) {
+  std::lock_guard<std::mutex> g(lanes_mu);
+  lanes_free.push_back(l);
+}
+
+namespace {
+struct LaneGuard {
+  rsx_ctx* ctx;
+  rsx_ctx::HostLane* lane;
+  explicit LaneGuard(rsx_ctx* c) : ctx(c), lane(c->acquire_lane()) {}
+  LaneGuard(const LaneGuard&) = delete;
+  ~LaneGuard() {
+    if (lane)
+      ctx->release_lane(lane);
+  }
+};
+} // namespace
+
 extern "C" int rsx_abi_version(void) { return RSX_ABI_VERSION; }
 
 extern "C" const char* rsx_status_string(int status) {
@@ -195,8 +230,14 @@ extern "C" void rsx_ctx_destroy(rsx_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamDestroy(ctx->stream);
   }
-  ctx->d_in.release();
-  ctx->d_out.release();
+  for (auto& l : ctx->lanes_all) {
+    if (l->stream) {
+      (void)hipStreamSynchronize(l->stream);
+      (void)hipStreamDestroy(l->stream);
+    }
+    l->d_in.release();
+    l->d_out.release();
+  }
   delete ctx;
 }
 
@@ -752,15 +793,18 @@ int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
     j.img.pitch_bytes = uint32_t(r.dev_pitch);
     j.img_offset = 0; // patched below via desc-relative offset
   }
-  if (int e = ctx->d_in.ensure(in_total + 16))
+  LaneGuard lane(ctx); // staging + stream of this call
+  if (!lane.lane)
+    return RSX_ERR_DEVICE;
+  if (int e = lane.lane->d_in.ensure(in_total + 16))
     return e;
-  if (int e = ctx->d_out.ensure(out_total + 16))
+  if (int e = lane.lane->d_out.ensure(out_total + 16))
     return e;
-  hipStream_t s = ctx->stream;
+  hipStream_t s = lane.lane->stream;
   for (int i = 0; i < n; ++i) {
     if (st[i] != RSX_OK)
       continue;
-    RSX_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t*>(ctx->d_in.ptr) +
+    RSX_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t*>(lane.lane->d_in.ptr) +
                                           jobs[i].in_offset,
                                       ins[i], jobs[i].in_bytes,
                                       hipMemcpyHostToDevice, s));
@@ -782,7 +826,7 @@ int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
     u.bps = uint32_t(d.bits_per_pixel);
     u.out_offset = rects[i].dev_off;
     unpack_blocks_for(&u);
-    const uintptr_t a = reinterpret_cast<uintptr_t>(ctx->d_out.ptr) + u.out_offset;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(lane.lane->d_out.ptr) + u.out_offset;
     u.out_aligned = ((a & 15) == 0 && (u.out_pitch & 15) == 0) ? 1u : 0u;
     per_order[d.bit_order].push_back(u);
   }
@@ -807,8 +851,8 @@ int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
                                       hipMemcpyHostToDevice, s));
     RSX_HIP_CHECK(ctx, launch_unpack(order, static_cast<UnpackJobDev*>(d_jobs.ptr),
                                      static_cast<uint32_t*>(d_starts.ptr),
-                                     int(v.size()), starts.back(), ctx->d_in.ptr,
-                                     ctx->d_out.ptr, s));
+                                     int(v.size()), starts.back(), lane.lane->d_in.ptr,
+                                     lane.lane->d_out.ptr, s));
     RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
   }
   for (int i = 0; i < n; ++i) {
@@ -817,7 +861,7 @@ int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
     const OutRect& r = rects[i];
     RSX_HIP_CHECK(ctx, hipMemcpy2DAsync(static_cast<uint8_t*>(img->data) + r.host_off,
                                         img->pitch_bytes,
-                                        static_cast<uint8_t*>(ctx->d_out.ptr) + r.dev_off,
+                                        static_cast<uint8_t*>(lane.lane->d_out.ptr) + r.dev_off,
                                         r.dev_pitch, r.width_bytes, r.rows,
                                         hipMemcpyDeviceToHost, s));
   }
@@ -841,7 +885,6 @@ extern "C" int rsx_unpack_u16(rsx_ctx* ctx, const rsx_unpack_desc* d,
                               const rsx_image* img) {
   if (!ctx || !d || !in || !img || !img->data)
     return RSX_ERR_INVALID_ARG;
-  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   return unpack_host(ctx, 1, d, &in, &in_bytes, img, nullptr);
 }
@@ -850,7 +893,6 @@ extern "C" int rsx_unpack_f32(rsx_ctx* ctx, const rsx_unpack_desc* d, const uint
                               size_t in_bytes, const rsx_image* img) {
   if (!ctx || !d || !in || !img || !img->data)
     return RSX_ERR_INVALID_ARG;
-  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (int st = validate_unpack_f32(*d, *img, in_bytes))
     return st;
@@ -868,22 +910,25 @@ extern "C" int rsx_unpack_f32(rsx_ctx* ctx, const rsx_unpack_desc* d, const uint
   job.img = *img;
   job.img.dim_y = int32_t(rows);
   job.img.pitch_bytes = uint32_t(align_up(width_bytes, 16));
-  if (int e = ctx->d_in.ensure(used + 16))
+  LaneGuard lane(ctx); // staging + stream of this call
+  if (!lane.lane)
+    return RSX_ERR_DEVICE;
+  if (int e = lane.lane->d_in.ensure(used + 16))
     return e;
-  if (int e = ctx->d_out.ensure(size_t(job.img.pitch_bytes) * size_t(rows) + 16))
+  if (int e = lane.lane->d_out.ensure(size_t(job.img.pitch_bytes) * size_t(rows) + 16))
     return e;
-  hipStream_t s = ctx->stream;
-  RSX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_in.ptr, in, used, hipMemcpyHostToDevice, s));
+  hipStream_t s = lane.lane->stream;
+  RSX_HIP_CHECK(ctx, hipMemcpyAsync(lane.lane->d_in.ptr, in, used, hipMemcpyHostToDevice, s));
   rsx_plan* plan = nullptr;
   if (int st = rsx_unpack_f32_plan_create(ctx, 1, &job, &plan))
     return st;
-  int rc = rsx_plan_run(plan, ctx->d_in.ptr, ctx->d_out.ptr, s);
+  int rc = rsx_plan_run(plan, lane.lane->d_in.ptr, lane.lane->d_out.ptr, s);
   if (rc == RSX_OK) {
     const size_t x0 = d->bits_per_pixel == 32 ? size_t(d->crop_x) * img->cpp
                                               : size_t(d->crop_x);
     uint8_t* dst = static_cast<uint8_t*>(img->data) +
                    size_t(d->crop_y) * img->pitch_bytes + x0 * 4;
-    hipError_t e = hipMemcpy2DAsync(dst, img->pitch_bytes, ctx->d_out.ptr,
+    hipError_t e = hipMemcpy2DAsync(dst, img->pitch_bytes, lane.lane->d_out.ptr,
                                     job.img.pitch_bytes, width_bytes, size_t(rows),
                                     hipMemcpyDeviceToHost, s);
     if (e == hipSuccess)
@@ -902,7 +947,6 @@ extern "C" int rsx_unpack_variant_u16(rsx_ctx* ctx, const rsx_unpack_variant_des
                                       const rsx_image* img) {
   if (!ctx || !d || !in || !img || !img->data)
     return RSX_ERR_INVALID_ARG;
-  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (int st = validate_unpack_variant(*d, *img, in_bytes))
     return st;
@@ -918,18 +962,21 @@ extern "C" int rsx_unpack_variant_u16(rsx_ctx* ctx, const rsx_unpack_variant_des
   job.img = *img;
   job.img.pitch_bytes = uint32_t(align_up(size_t(d->w) * 2, 16));
   const size_t out_bytes = size_t(job.img.pitch_bytes) * size_t(d->h);
-  if (int e = ctx->d_in.ensure(used + 16))
+  LaneGuard lane(ctx); // staging + stream of this call
+  if (!lane.lane)
+    return RSX_ERR_DEVICE;
+  if (int e = lane.lane->d_in.ensure(used + 16))
     return e;
-  if (int e = ctx->d_out.ensure(out_bytes + 16))
+  if (int e = lane.lane->d_out.ensure(out_bytes + 16))
     return e;
-  hipStream_t s = ctx->stream;
-  RSX_HIP_CHECK(ctx, hipMemcpyAsync(ctx->d_in.ptr, in, used, hipMemcpyHostToDevice, s));
+  hipStream_t s = lane.lane->stream;
+  RSX_HIP_CHECK(ctx, hipMemcpyAsync(lane.lane->d_in.ptr, in, used, hipMemcpyHostToDevice, s));
   rsx_plan* plan = nullptr;
   if (int st = rsx_unpack_variant_plan_create(ctx, 1, &job, &plan))
     return st;
-  int rc = rsx_plan_run(plan, ctx->d_in.ptr, ctx->d_out.ptr, s);
+  int rc = rsx_plan_run(plan, lane.lane->d_in.ptr, lane.lane->d_out.ptr, s);
   if (rc == RSX_OK) {
-    hipError_t e = hipMemcpy2DAsync(img->data, img->pitch_bytes, ctx->d_out.ptr,
+    hipError_t e = hipMemcpy2DAsync(img->data, img->pitch_bytes, lane.lane->d_out.ptr,
                                     job.img.pitch_bytes, size_t(d->w) * 2, size_t(d->h),
                                     hipMemcpyDeviceToHost, s);
     if (e == hipSuccess)
@@ -949,7 +996,6 @@ extern "C" int rsx_dng_decompress_uncompressed(rsx_ctx* ctx, int n_tiles,
                                                int32_t* tile_status) {
   if (!ctx || !tiles || n_tiles < 1 || !img || !img->data)
     return RSX_ERR_INVALID_ARG;
-  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   std::vector<rsx_unpack_desc> descs(n_tiles);
   std::vector<const uint8_t*> ins(n_tiles);
@@ -1098,7 +1144,6 @@ extern "C" int rsx_sraw_interpolate(rsx_ctx* ctx, const rsx_sraw_desc* d,
                                     const rsx_image* in, const rsx_image* out) {
   if (!ctx || !d || !in || !out || !in->data || !out->data)
     return RSX_ERR_INVALID_ARG;
-  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (int st = validate_sraw(*d, *in, *out))
     return st;
@@ -1112,20 +1157,23 @@ extern "C" int rsx_sraw_interpolate(rsx_ctx* ctx, const rsx_sraw_desc* d,
   job.img.pitch_bytes = uint32_t(align_up(out_w, 16));
   const size_t in_bytes = size_t(job.in.pitch_bytes) * in->dim_y;
   const size_t out_bytes = size_t(job.img.pitch_bytes) * out->dim_y;
-  if (int e = ctx->d_in.ensure(in_bytes + 16))
+  LaneGuard lane(ctx); // staging + stream of this call
+  if (!lane.lane)
+    return RSX_ERR_DEVICE;
+  if (int e = lane.lane->d_in.ensure(in_bytes + 16))
     return e;
-  if (int e = ctx->d_out.ensure(out_bytes + 16))
+  if (int e = lane.lane->d_out.ensure(out_bytes + 16))
     return e;
-  hipStream_t s = ctx->stream;
-  RSX_HIP_CHECK(ctx, hipMemcpy2DAsync(ctx->d_in.ptr, job.in.pitch_bytes, in->data,
+  hipStream_t s = lane.lane->stream;
+  RSX_HIP_CHECK(ctx, hipMemcpy2DAsync(lane.lane->d_in.ptr, job.in.pitch_bytes, in->data,
                                       in->pitch_bytes, in_w, size_t(in->dim_y),
                                       hipMemcpyHostToDevice, s));
   rsx_plan* plan = nullptr;
   if (int st = rsx_sraw_plan_create(ctx, 1, &job, &plan))
     return st;
-  int rc = rsx_plan_run(plan, ctx->d_in.ptr, ctx->d_out.ptr, s);
+  int rc = rsx_plan_run(plan, lane.lane->d_in.ptr, lane.lane->d_out.ptr, s);
   if (rc == RSX_OK) {
-    hipError_t e = hipMemcpy2DAsync(out->data, out->pitch_bytes, ctx->d_out.ptr,
+    hipError_t e = hipMemcpy2DAsync(out->data, out->pitch_bytes, lane.lane->d_out.ptr,
                                     job.img.pitch_bytes, out_w, size_t(out->dim_y),
                                     hipMemcpyDeviceToHost, s);
     if (e == hipSuccess)
@@ -1488,8 +1536,6 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
   // every decompressor's own validation rejects such an image as well)
   if (img->dim_x <= 0 || img->dim_y <= 0 || img->pitch_bytes == 0 || n < 1)
     return RSX_ERR_INVALID_ARG;
-  // the staging buffers belong to the context: one host-pointer call at a time
-  std::lock_guard<std::recursive_mutex> whole_call(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   // inputs back to back (16-byte aligned) + 64 zero bytes of slack each
   size_t in_total = 0;
@@ -1500,14 +1546,17 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
     jobs[i].img_offset = 0;
   }
   const size_t out_bytes = size_t(img->pitch_bytes) * size_t(img->dim_y);
-  if (int e = ctx->d_in.ensure(in_total + 64))
+  LaneGuard lane(ctx); // staging + stream of this call
+  if (!lane.lane)
+    return RSX_ERR_DEVICE;
+  if (int e = lane.lane->d_in.ensure(in_total + 64))
     return e;
-  if (int e = ctx->d_out.ensure(out_bytes + 64))
+  if (int e = lane.lane->d_out.ensure(out_bytes + 64))
     return e;
-  hipStream_t s = ctx->stream;
-  RSX_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_in.ptr, 0, in_total + 64, s));
+  hipStream_t s = lane.lane->stream;
+  RSX_HIP_CHECK(ctx, hipMemsetAsync(lane.lane->d_in.ptr, 0, in_total + 64, s));
   for (int i = 0; i < n; ++i)
-    RSX_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t*>(ctx->d_in.ptr) +
+    RSX_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t*>(lane.lane->d_in.ptr) +
                                           jobs[i].in_offset,
                                       ins[i], jobs[i].in_bytes, hipMemcpyHostToDevice, s));
   rsx_plan* plan = nullptr;
@@ -1515,7 +1564,7 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
     return st;
   std::vector<int32_t> st(n, RSX_OK);
   std::vector<uint32_t> cons(n, 0);
-  int rc = rsx_plan_run(plan, ctx->d_in.ptr, ctx->d_out.ptr, s);
+  int rc = rsx_plan_run(plan, lane.lane->d_in.ptr, lane.lane->d_out.ptr, s);
   if (rc == RSX_OK)
     rc = rsx_plan_results(plan, st.data(), cons.data());
   rsx_plan_destroy(plan);
@@ -1559,7 +1608,7 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
     const size_t off = r.row0 * img->pitch_bytes + r.byte0;
     RSX_HIP_CHECK(ctx, hipMemcpy2DAsync(static_cast<uint8_t*>(img->data) + off,
                                         img->pitch_bytes,
-                                        static_cast<uint8_t*>(ctx->d_out.ptr) + off,
+                                        static_cast<uint8_t*>(lane.lane->d_out.ptr) + off,
                                         img->pitch_bytes, r.bytes, r.rows,
                                         hipMemcpyDeviceToHost, s));
   }

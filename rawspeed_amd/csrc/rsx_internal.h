@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -168,24 +169,35 @@ struct DeviceBuffer {
 
 struct rsx_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
-  // recursive: the host-pointer calls hold it for their whole duration (they
-  // own the context's staging buffers) and call the plan API underneath
+  hipStream_t stream = nullptr; // default stream of the plan API (rsx_plan_run(.., NULL))
+  // Plan bookkeeping takes this for a moment (device selection, uploads); the
+  // host-pointer calls do NOT hold it while they run: each takes a lane of its own.
   std::recursive_mutex mu;
+  std::mutex err_mu;
   std::string last_error;
   std::atomic<uint64_t> host_calls{0}; // host-pointer entry points served
-  // staging for the host-pointer calls
-  rsx::DeviceBuffer d_in, d_out;
-  void* h_pinned = nullptr;
-  size_t h_pinned_bytes = 0;
+  // Staging of one host-pointer call: device buffers + a stream.  Lanes are pooled, so
+  // calls from different threads (rstest-style file loops, DNG tile threads of an
+  // unbatched build) stage and decode side by side instead of queueing on one mutex.
+  struct HostLane {
+    rsx::DeviceBuffer d_in, d_out;
+    hipStream_t stream = nullptr;
+  };
+  std::mutex lanes_mu;
+  std::vector<std::unique_ptr<HostLane>> lanes_all;
+  std::vector<HostLane*> lanes_free;
+  HostLane* acquire_lane();
+  void release_lane(HostLane* l);
 };
 
 #define RSX_HIP_CHECK(ctx, expr)                                               \
   do {                                                                         \
     hipError_t _e = (expr);                                                    \
     if (_e != hipSuccess) {                                                    \
-      if (ctx)                                                                 \
+      if (ctx) {                                                               \
+        std::lock_guard<std::mutex> _g((ctx)->err_mu);                         \
         (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e); \
+      }                                                                        \
       return RSX_ERR_DEVICE;                                                   \
     }                                                                          \
   } while (0)

@@ -379,3 +379,53 @@ def test_sraw_decode_then_interpolate_on_device(gpu, oracle):
     assert np.array_equal(d_out.cpu().numpy(), want.buf)
     p1.close()
     p2.close()
+
+
+def test_host_pointer_calls_from_many_threads(gpu, oracle):
+    """The host-pointer entry points stage on a lane of their own (buffers + stream):
+    calls from different threads of one context run side by side and do not disturb
+    each other (rstest-style file loops; the reference's tile threads)."""
+    import threading
+    rng = np.random.default_rng(77)
+    work = []
+    for k in range(8):
+        W, H = 1024 + 64 * k, 160 + 8 * k
+        d, data, _, _ = C.make_ljpeg_case(rng, img_w=W, img_h=H, cpp=1, tile=(0, 0, W, H),
+                                          mcu=(2, 1))
+        want = HostImage(W, H)
+        so = oracle.ljpeg(d, data, want)
+        work.append((d, data, W, H, want, so))
+    # and some unpack work in between
+    upk = []
+    for k in range(4):
+        W, H, bps = 2048, 64 + 16 * k, 12
+        data = rng.integers(0, 256, size=H * W * bps // 8, dtype=np.uint8)
+        d = abi.UnpackDesc(0, 0, W, H, W * bps // 8, bps, abi.ORDER_MSB)
+        want = HostImage(W, H)
+        assert oracle.unpack(d, data, want) == 0
+        upk.append((d, data, W, H, want))
+    errors = []
+
+    def lj(item, reps):
+        d, data, W, H, want, so = item
+        for _ in range(reps):
+            img = HostImage(W, H)
+            got = gpu.ljpeg_decode(d, data, img.view())
+            if got != so or not np.array_equal(img.u16(), want.u16()):
+                errors.append(("ljpeg", W, H, got, so))
+
+    def up(item, reps):
+        d, data, W, H, want = item
+        for _ in range(reps):
+            img = HostImage(W, H)
+            if gpu.unpack_u16(d, data, img.view()) != 0 or \
+                    not np.array_equal(img.u16(), want.u16()):
+                errors.append(("unpack", W, H))
+
+    threads = [threading.Thread(target=lj, args=(w, 6)) for w in work] + \
+              [threading.Thread(target=up, args=(u, 6)) for u in upk]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
