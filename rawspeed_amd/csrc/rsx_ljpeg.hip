@@ -290,12 +290,17 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
 template <bool MULTI, bool PAIR, int REVBW>
 __device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp, int col,
                                             uint32_t pos, uint32_t phase, bool live,
-                                            uint32_t* w_out = nullptr) {
+                                            uint32_t* w_out = nullptr,
+                                            uint32_t* d_out = nullptr) {
   const uint32_t w = lj_window<REVBW>(L.B, col, pos);
   if (w_out)
     *w_out = w;
   const TabLds& tb = lj_table<MULTI>(L, dp, phase);
-  const uint32_t e = lj_entry(w, tb, live, dp.long_codes);
+  uint32_t e;
+  if (d_out) // (the loops that accumulate differences)
+    e = lj_entry_diff(w, tb, live, dp.long_codes, d_out);
+  else
+    e = lj_entry(w, tb, live, dp.long_codes);
   if (PAIR) {
     // HasselbladDecompressor.cpp:87-92: two length codes, then the two bit fields.
     // The step covers the whole pair: advance = both codes + both fields (<= 64).
@@ -330,12 +335,13 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
   PhaseSums<NS ? NS : 1> acc;
   while (__any(pos < end_bits)) {
     const bool live = pos < end_bits;
-    uint32_t w;
-    const uint32_t e = lj_step<MULTI, PAIR, REVBW>(L, dp, col, pos, phase, live, &w);
+    uint32_t w, d = 0;
+    const uint32_t e =
+        lj_step<MULTI, PAIR, REVBW>(L, dp, col, pos, phase, live, &w, NS ? &d : nullptr);
     const bool bad = live && e == 0u;
     const bool good = live && !bad;
     if (NS)
-      acc.add(lj_extend(w, e), good);
+      acc.add(d, good);
     pos += good ? (e >> 10) : 0u;
     n += good ? 1u : 0u;
     if (MULTI)
@@ -1219,7 +1225,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
     for (uint32_t t = 0; t < target; ++t) {
       const uint32_t w = lj_window(L.B, j, p2);
       const TabLds& tb = lj_table<MULTI>(L, dp, ph2);
-      uint32_t e = tb.lut[w >> (32 - LUT_BITS)];
+      uint32_t e = lj_lut16(tb, w >> (32 - LUT_BITS));
       if ((e & 31u) == 0u)
         e = lj_slow_entry(w, &tb);
       p2 += e >> 10;
@@ -1373,7 +1379,7 @@ struct Sym {
 };
 
 __device__ __forceinline__ Sym lj_symbol_global(uint32_t w, const TabLds* tb) {
-  const uint32_t e = tb->lut[w >> (32 - LUT_BITS)];
+  const uint32_t e = lj_lut16(*tb, w >> (32 - LUT_BITS));
   if (e & 31u)
     return {e >> 10, (e >> 5) & 31u, e & 31u, true};
   for (uint32_t l = LUT_BITS + 1; l <= tb->max_len; ++l) {
@@ -2152,8 +2158,34 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     // the LDS layout (16-byte sized records)
     std::vector<TabLds> tl(tables.size());
     for (size_t t = 0; t < tables.size(); ++t) {
-      std::memset(&tl[t], 0, sizeof(TabLds));
-      std::memcpy(&tl[t], &tables[t], sizeof(DeviceHuffTable));
+      const DeviceHuffTable& dt = tables[t];
+      TabLds& o = tl[t];
+      std::memset(&o, 0, sizeof(TabLds));
+      std::memcpy(o.max_code, dt.max_code, sizeof o.max_code);
+      std::memcpy(o.val_offset, dt.val_offset, sizeof o.val_offset);
+      std::memcpy(o.values, dt.values, sizeof o.values);
+      o.max_len = dt.max_len;
+      o.fix16 = dt.fix16;
+      o.zero_sym_bits = dt.zero_sym_bits;
+      o.las = dt.las;
+      for (uint32_t i = 0; i < uint32_t(LUT_SIZE); ++i) {
+        const uint32_t e = dt.lut[i];
+        uint32_t hi = 0;
+#if RSX_LUT_DIFF
+        // the symbol's difference, if code and difference bits lie inside the index
+        const uint32_t cl = e & 31u, ssss = (e >> 5) & 31u, total = e >> 10;
+        if (e != 0 && !dt.las && total <= uint32_t(LUT_BITS)) {
+          if (ssss == 16u) {
+            hi = 0x8000u;
+          } else if (ssss != 0u) {
+            const uint32_t v = (i >> (uint32_t(LUT_BITS) - total)) & ((1u << ssss) - 1u);
+            hi = (v >= (1u << (ssss - 1)) ? v : v + 1u - (1u << ssss)) & 0xFFFFu;
+          }
+          (void)cl;
+        }
+#endif
+        o.lut[i] = LutEntry(e | (hi << 16));
+      }
     }
     auto up = [&](DeviceBuffer& b, const void* src, size_t n) -> int {
       if (int st = b.ensure(n ? n : 16))
@@ -2205,8 +2237,6 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
   return RSX_OK;
 }
 
-// the device-side table record must be what build_device_table() produced
-static_assert(sizeof(TabLds) >= sizeof(DeviceHuffTable), "TabLds too small");
 
 namespace {
 

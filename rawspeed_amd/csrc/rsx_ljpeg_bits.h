@@ -56,7 +56,8 @@ __device__ __forceinline__ Lds carve(uint8_t* smem, int bw = LJ_BW) {
 constexpr size_t lj_lds_bytes(int n_tables, int bw = LJ_BW) {
   return lj_lds_words(bw) * 4 + size_t(n_tables) * sizeof(TabLds);
 }
-static_assert(lj_lds_bytes(1, LJ_BW_SYNC) <= 21 * 1280, "six sync workgroups per CU");
+static_assert(lj_lds_bytes(1, LJ_BW_SYNC) <= (RSX_LUT_DIFF ? 24 : 21) * 1280,
+              "six sync workgroups per CU (five with the difference LUT)");
 static_assert(lj_lds_words(LJ_BW_SYNC) % 4 == 0 && lj_lds_words(LJ_BW_SYNC_PAIR) % 4 == 0 &&
                   lj_lds_words(LJ_BW) % 4 == 0,
               "the tables start on a 16-byte boundary");
@@ -156,24 +157,6 @@ __device__ __noinline__ uint32_t lj_slow_entry(uint32_t w, const TabLds* tb) {
 // than LUT_BITS are rare, and never occur with the short tables real files use),
 // so the common path has no divergent control flow at all.
 // long_codes (wave-uniform): the stream's tables have codes longer than the LUT at all.
-__device__ __forceinline__ uint32_t lj_entry(uint32_t w, const TabLds& tb, bool live,
-                                             bool long_codes = true) {
-  uint32_t e = tb.lut[w >> (32 - LUT_BITS)];
-  if (long_codes && __builtin_expect(__any(live && (e & 31u) == 0u), 0)) {
-    if (live && (e & 31u) == 0u)
-      e = lj_slow_entry(w, &tb);
-  }
-  return e;
-}
-
-// the same for a single lane reading the table from global memory
-__device__ __forceinline__ uint32_t lj_entry_global(uint32_t w, const TabLds* tb) {
-  uint32_t e = tb->lut[w >> (32 - LUT_BITS)];
-  if ((e & 31u) == 0u)
-    e = lj_slow_entry(w, tb);
-  return e;
-}
-
 // The difference a symbol stands for (JPEG F.2.2.1 "EXTEND"; SSSS = 16 is -32768,
 // AbstractPrefixCodeDecoder.h:55-76), as 16 bits: w = the symbol's window, e its entry.
 __device__ __forceinline__ uint32_t lj_extend(uint32_t w, uint32_t e) {
@@ -186,6 +169,55 @@ __device__ __forceinline__ uint32_t lj_extend(uint32_t w, uint32_t e) {
   uint32_t diff = v - (all & neg);
   diff = ssss == 16u ? 0x8000u : diff;
   return diff & 0xFFFFu;
+}
+
+// the 16-bit entry (code length | SSSS << 5 | bits consumed << 10) at LUT index i
+__device__ __forceinline__ uint32_t lj_lut16(const TabLds& tb, uint32_t i) {
+  return reinterpret_cast<const uint16_t*>(tb.lut)[i * (sizeof(LutEntry) / 2)];
+}
+
+__device__ __forceinline__ uint32_t lj_entry(uint32_t w, const TabLds& tb, bool live,
+                                             bool long_codes = true) {
+  uint32_t e = lj_lut16(tb, w >> (32 - LUT_BITS));
+  if (long_codes && __builtin_expect(__any(live && (e & 31u) == 0u), 0)) {
+    if (live && (e & 31u) == 0u)
+      e = lj_slow_entry(w, &tb);
+  }
+  return e;
+}
+
+// Entry AND difference of the symbol whose first 32 bits are w (the loops that need
+// both): *diff = the 16-bit difference.  With RSX_LUT_DIFF it comes out of the LUT's
+// high half when the symbol lies inside the index bits; otherwise (wave-uniform branch:
+// only when some live lane has a longer symbol) it is computed.
+__device__ __forceinline__ uint32_t lj_entry_diff(uint32_t w, const TabLds& tb, bool live,
+                                                  bool long_codes, uint32_t* diff) {
+#if RSX_LUT_DIFF
+  const uint32_t e32 = tb.lut[w >> (32 - LUT_BITS)];
+  uint32_t e = e32 & 0xFFFFu;
+  uint32_t d = e32 >> 16;
+  const bool computed = live && ((e >> 10) > uint32_t(LUT_BITS) || e == 0u);
+  if (__builtin_expect(__any(computed), 0)) {
+    if (long_codes && live && (e & 31u) == 0u)
+      e = lj_slow_entry(w, &tb);
+    if (computed)
+      d = lj_extend(w, e);
+  }
+  *diff = d;
+  return e;
+#else
+  const uint32_t e = lj_entry(w, tb, live, long_codes);
+  *diff = lj_extend(w, e);
+  return e;
+#endif
+}
+
+// the same for a single lane reading the table from global memory
+__device__ __forceinline__ uint32_t lj_entry_global(uint32_t w, const TabLds* tb) {
+  uint32_t e = lj_lut16(*tb, w >> (32 - LUT_BITS));
+  if ((e & 31u) == 0u)
+    e = lj_slow_entry(w, tb);
+  return e;
 }
 
 // Per-stream decode parameters held in registers.

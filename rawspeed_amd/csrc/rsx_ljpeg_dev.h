@@ -64,8 +64,23 @@ constexpr uint32_t FL_NEED_LEGACY = 2u;
 // some workgroup of the stream met periodic data (constant image regions)
 constexpr uint32_t FL_PERIODIC = 4u;
 
-struct TabLds {
-  uint16_t lut[LUT_SIZE];
+// The code table as the kernels keep it in LDS.  RSX_LUT_DIFF: a LUT entry also
+// carries, in its high half, the DIFFERENCE the symbol stands for whenever the whole
+// symbol -- code and difference bits -- lies inside the LUT_BITS index bits (total <=
+// LUT_BITS; sensor data: nearly always), so that the loops which need differences (the
+// recorded synchronisation pass, the final decode) read them instead of computing the
+// JPEG "EXTEND"; longer symbols take the computed path, wave-uniformly.
+#ifndef RSX_LUT_DIFF
+#define RSX_LUT_DIFF 1
+#endif
+#if RSX_LUT_DIFF
+typedef uint32_t LutEntry;
+#else
+typedef uint16_t LutEntry;
+#endif
+
+struct alignas(16) TabLds {
+  LutEntry lut[LUT_SIZE];
   uint32_t max_code[18];
   uint16_t val_offset[18];
   uint8_t values[RSX_MAX_CODE_VALUES];
@@ -73,14 +88,8 @@ struct TabLds {
   uint8_t fix16;
   uint8_t zero_sym_bits;
   uint8_t las;
-  uint8_t pad[12];
 };
-static_assert(sizeof(TabLds) == sizeof(DeviceHuffTable) + 12 ||
-                  sizeof(TabLds) % 16 == 0,
-              "TabLds layout");
 static_assert(sizeof(TabLds) % 16 == 0, "TabLds must be 16-byte sized");
-static_assert(offsetof(TabLds, max_code) == offsetof(DeviceHuffTable, max_code), "");
-static_assert(offsetof(TabLds, values) == offsetof(DeviceHuffTable, values), "");
 
 struct Cr2Strip {
   uint32_t x0, w, y0, h;

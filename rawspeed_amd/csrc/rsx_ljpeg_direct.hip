@@ -570,11 +570,13 @@ __global__ __launch_bounds__(LJ_T, RSX_K4D_MIN_WAVES) void lj_decode_direct_kern
     for (int q = 0; q < 8; ++q) {
       const bool live = 8 * g + q < remaining;
       const uint32_t w = r.head();
-      const uint32_t e = lj_entry(w, lj_table<MULTI>(L, dp, phase), live, dp.long_codes);
+      uint32_t d;
+      const uint32_t e =
+          lj_entry_diff(w, lj_table<MULTI>(L, dp, phase), live, dp.long_codes, &d);
       r.advance(L.B, j, live ? (e >> 10) : 0u);
       if (MULTI)
         phase = live ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
-      const uint32_t diff = live ? lj_extend(w, e) : 0u;
+      const uint32_t diff = live ? d : 0u;
       if (q & 1)
         p[q >> 1] |= diff << 16;
       else
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(LJ_T, RSX_K4D_MIN_WAVES) void lj_decode_direct_kern
     for (uint32_t t = 0; t < target; ++t) {
       const uint32_t w = lj_window(L.B, j, p2);
       const TabLds& tb = lj_table<MULTI>(L, dp, ph2);
-      uint32_t e = tb.lut[w >> (32 - LUT_BITS)];
+      uint32_t e = lj_lut16(tb, w >> (32 - LUT_BITS));
       if ((e & 31u) == 0u)
         e = lj_slow_entry(w, &tb);
       p2 += e >> 10;
