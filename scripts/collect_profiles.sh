@@ -1,20 +1,40 @@
 #!/bin/bash
-# Round profile collection (run on the GPU box through gpurun): bench JSON, kernel
-# stats of the same command under rocprofv3, and the two PMC passes of the headline
-# kernel.  Outputs land in gpurun_out/prof_r01/ (copied to profiles/r01/ afterwards).
+# Round profile collection (run on the GPU box through gpurun):
+#   bench JSON; kernel stats of the same command under rocprofv3; the two PMC passes of
+#   the headline kernel; kernel stats + per-kernel HBM traffic of the LJPEG legs; the
+#   re-decode round statistics of an experiment build.
+# Outputs land in gpurun_out/prof_$ROUND/ (copied to profiles/$ROUND/ afterwards).
 set -u
+ROUND=${ROUND:-r02}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/prof_r01
+OUT=$REPO/gpurun_out/prof_$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $REPO/bench.py > $OUT/bench_full.json 2> $OUT/bench_full.log
+rm -rf /tmp/p_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- \
-  python $REPO/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> /dev/null
-cp $(find /tmp/p_stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+  python $REPO/bench.py --no-cpu-baseline --no-extra --no-cfg5 > $OUT/bench_under_rocprof.json 2> /dev/null
+cp $(find /tmp/p_stats -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/p_$c
   rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -- \
     python $REPO/bench.py --steps 3 --warmup 1 --no-extra --no-cpu-baseline --no-cfg5 > /dev/null 2>&1
   cp $(find /tmp/p_$c -name "*counter_collection.csv" | head -1) $OUT/unpack_pmc_$c.csv
 done
+python $REPO/scripts/pmc_to_json.py $OUT > /dev/null
+for leg in cfg3 cfg4 clipped; do
+  rm -rf /tmp/p_$leg
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$leg -- \
+    python $REPO/bench_ljpeg.py --only $leg --steps 10 > $OUT/${leg}_under_rocprof.json 2> /dev/null
+  cp $(find /tmp/p_$leg -name "*kernel_stats.csv" | head -1) $OUT/${leg}_kernel_stats.csv
+done
+bash $REPO/scripts/pmc_ljpeg_traffic.sh > /dev/null 2>&1
+mkdir -p $OUT/ljpeg_traffic
+cp $REPO/gpurun_out/pmc_lj_traffic/* $OUT/ljpeg_traffic/
+# re-decode round statistics (experiment build: RSX_EXPERIMENT collects them, RSX_DEBUG prints)
+if [ -f $REPO/rawspeed_amd/variants/librsx_dbg.so ]; then
+  RSX_DEBUG=1 RSX_LIB=$REPO/rawspeed_amd/variants/librsx_dbg.so \
+    python $REPO/bench_ljpeg.py --only cfg3 --steps 1 2>&1 | grep "^\[rsx\]" | head -12 > $OUT/cfg3_round_stats.txt
+fi
 ls -la $OUT
-tail -c 600 $OUT/bench_full.json
+tail -c 400 $OUT/bench_full.json

@@ -28,5 +28,5 @@ s = torch.cuda.current_stream().cuda_stream
 for _ in range(4):
     plan.run(inp.data_ptr(), out.data_ptr(), s)
 torch.cuda.synchronize()
-if os.environ.get("RSX_DEBUG"):
+if os.environ.get("RSX_SHOW_RESULTS"):  # script-local switch, not read by librsx
     print(plan.results()[0])

@@ -127,6 +127,9 @@ def merge_fixup(D, n, old_start, new_start, lens):
     that is behind) until they stand on the same bit; from there on they are the same
     parse, so count and relative-phase sums of the recorded tail are reused -- the
     tail's phases shift by (new symbols - old symbols) before the merge point.
+    (The kernel variant of this was measured slower than a plain re-decode and is not in
+    librsx; the model stays because the phase rotation it checks is the identity
+    lj_rot_fields<N> applies when slot-relative sums become workgroup-relative ones.)
     lens[p] = length of the symbol that starts at bit p; D[p] = its difference."""
     end = len(lens)
 
