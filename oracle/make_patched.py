@@ -47,8 +47,8 @@ HUNK_UNPACK = r'''
       }
       if (b.slot->status == RSX_OK)
         return;
-    } else if ((f32 ? rsx_unpack_f32(rsx, &d, in.begin(), in.getSize(), &img)
-                    : rsx_unpack_u16(rsx, &d, in.begin(), in.getSize(), &img)) == RSX_OK) {
+    } else if (rsx_shim::done((f32 ? rsx_unpack_f32(rsx, &d, in.begin(), in.getSize(), &img)
+                    : rsx_unpack_u16(rsx, &d, in.begin(), in.getSize(), &img)))) {
       return;
     }
   }
@@ -64,7 +64,7 @@ HUNK_VARIANT = r'''
     d.h = size.y;
     const rsx_image img = rsx_shim::view(mRaw);
     const Buffer in = input.peekRemainingBuffer();
-    if (rsx_unpack_variant_u16(rsx, &d, in.begin(), in.getSize(), &img) == RSX_OK) {
+    if (rsx_shim::done(rsx_unpack_variant_u16(rsx, &d, in.begin(), in.getSize(), &img))) {
       input.skipBytes(input.getRemainSize());
       return;
     }
@@ -90,7 +90,7 @@ HUNK_8BIT = r'''
     }
     const rsx_image img = rsx_shim::view(mRaw);
     const Buffer in = input.peekRemainingBuffer();
-    if (rsx_unpack_variant_u16(rsx, &d, in.begin(), in.getSize(), &img) == RSX_OK) {
+    if (rsx_shim::done(rsx_unpack_variant_u16(rsx, &d, in.begin(), in.getSize(), &img))) {
       input.skipBytes(input.getRemainSize());
       return;
     }
@@ -134,8 +134,8 @@ HUNK_LJPEG = r'''
     } else {
       const rsx_image img = rsx_shim::view(mRaw);
       uint32_t consumed = 0;
-      if (rsx_ljpeg_decode(rsx, &d, input.begin(), implicit_cast<size_t>(input.size()), &img,
-                           &consumed) == RSX_OK)
+      if (rsx_shim::done(rsx_ljpeg_decode(rsx, &d, input.begin(), implicit_cast<size_t>(input.size()), &img,
+                           &consumed)))
         return consumed;
     }
   }
@@ -158,8 +158,8 @@ HUNK_CR2 = r'''
     rsx_shim::recipes(rec, &d);
     const rsx_image img = rsx_shim::view(mRaw);
     uint32_t consumed = 0;
-    if (rsx_cr2_decode(rsx, &d, input.begin(), implicit_cast<size_t>(input.size()), &img,
-                       &consumed) == RSX_OK)
+    if (rsx_shim::done(rsx_cr2_decode(rsx, &d, input.begin(), implicit_cast<size_t>(input.size()), &img,
+                       &consumed)))
       return consumed;
   }
 '''
@@ -190,8 +190,8 @@ HUNK_NIKON = r'''
       d.tables[t].n_code_values = implicit_cast<uint8_t>(n);
     }
     const rsx_image img = rsx_shim::view(mRaw);
-    if (rsx_nikon_decompress(rsx, &d, input.begin(), implicit_cast<size_t>(input.size()),
-                             &img) == RSX_OK)
+    if (rsx_shim::done(rsx_nikon_decompress(rsx, &d, input.begin(), implicit_cast<size_t>(input.size()),
+                             &img)))
       return;
   }
 '''
@@ -203,7 +203,7 @@ HUNK_PENTAX = r'''
     d.table = rsx_shim::table(ht);
     const rsx_image img = rsx_shim::view(mRaw);
     const Buffer in = data.peekRemainingBuffer();
-    if (rsx_pentax_decompress(rsx, &d, in.begin(), in.getSize(), &img) == RSX_OK)
+    if (rsx_shim::done(rsx_pentax_decompress(rsx, &d, in.begin(), in.getSize(), &img)))
       return;
   }
 '''
@@ -223,7 +223,7 @@ HUNK_SAMSUNG_V1 = r'''
     }
     const rsx_image img = rsx_shim::view(mRaw);
     const Buffer in = bs.peekRemainingBuffer();
-    if (rsx_samsung_v1_decompress(rsx, &d, in.begin(), in.getSize(), &img) == RSX_OK)
+    if (rsx_shim::done(rsx_samsung_v1_decompress(rsx, &d, in.begin(), in.getSize(), &img)))
       return;
   }
 '''
@@ -247,7 +247,7 @@ HUNK_SRAW = r'''
     in.dim_y = input.height();
     in.cpp = 1;
     const rsx_image out = rsx_shim::view(mRaw);
-    if (rsx_sraw_interpolate(rsx, &d, &in, &out) == RSX_OK)
+    if (rsx_shim::done(rsx_sraw_interpolate(rsx, &d, &in, &out)))
       return;
   }
 '''
@@ -257,7 +257,7 @@ HUNK_SONY_ARW1 = r'''
   if (rsx_ctx* rsx = rsx_shim::context()) {
     const rsx_image img = rsx_shim::view(mRaw);
     const Buffer in = input.peekRemainingBuffer();
-    if (rsx_sony_arw1_decompress(rsx, in.begin(), in.getSize(), &img) == RSX_OK)
+    if (rsx_shim::done(rsx_sony_arw1_decompress(rsx, in.begin(), in.getSize(), &img)))
       return;
   }
 '''
@@ -271,8 +271,8 @@ HUNK_HASSELBLAD = r'''
     d.init_pred = rec.initPred;
     const rsx_image img = rsx_shim::view(mRaw);
     uint32_t consumed = 0;
-    if (rsx_hasselblad_decompress(rsx, &d, input.begin(), implicit_cast<size_t>(input.size()),
-                                  &img, &consumed) == RSX_OK)
+    if (rsx_shim::done(rsx_hasselblad_decompress(rsx, &d, input.begin(), implicit_cast<size_t>(input.size()),
+                                  &img, &consumed)))
       return consumed;
   }
 '''

@@ -10,6 +10,7 @@
 //   Cr2Decompressor<>::decompress                  (Cr2DecompressorImpl.h:471)
 //   LJpegDecoder::decode / Cr2LJpegDecoder::decode (container level)
 //   AbstractDngDecompressor::decompress            (AbstractDngDecompressor.cpp:240)
+//   RawParser::getDecoder + RawDecoder::decodeRaw   (whole files: RawParser.cpp:45, RawDecoder.cpp:320)
 // It is used (a) to validate oracle/rsx_oracle.c, (b) to generate/verify
 // golden vectors, (c) as bench.py's cpu_baseline (kind "reference").
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load it.
@@ -23,6 +24,7 @@
 #include "codes/PrefixCodeDecoder.h"
 #include "common/RawImage.h"
 #include "common/RawspeedException.h"
+#include "decoders/RawDecoder.h"
 #include "decoders/RawDecoderException.h"
 #include "decompressors/AbstractDngDecompressor.h"
 #include "decompressors/Cr2Decompressor.h"
@@ -40,6 +42,7 @@
 #include "io/ByteStream.h"
 #include "io/Endianness.h"
 #include "io/IOException.h"
+#include "parsers/RawParser.h"
 
 #include "../include/rsx.h"
 #ifdef RSX_PATCHED_BUILD
@@ -151,6 +154,23 @@ long ref_rsx_host_calls() {
 #endif
 }
 
+// Units of work (strips, scans, tiles) the patched methods handed to the device and got
+// back decoded / left to their original bodies (-1: this is the unmodified build).
+long ref_rsx_forwarded() {
+#ifdef RSX_PATCHED_BUILD
+  return long(rawspeed::rsx_shim::stats().forwarded.load());
+#else
+  return -1;
+#endif
+}
+long ref_rsx_fell_through() {
+#ifdef RSX_PATCHED_BUILD
+  return long(rawspeed::rsx_shim::stats().fell_through.load());
+#else
+  return -1;
+#endif
+}
+
 int ref_max_threads() {
 #ifdef _OPENMP
   return omp_get_max_threads();
@@ -186,6 +206,43 @@ void* ref_image_create_f32(int dim_x, int dim_y, int cpp) {
   }
 }
 void ref_image_destroy(void* h) { delete static_cast<RefImage*>(h); }
+
+// A whole file through the reference's front door, the way rstest / darktable call it
+// (rstest.cpp:245-262): RawParser::getDecoder() picks the per-camera decoder,
+// decodeRaw() runs it.  No camera database (meta == nullptr), no decodeMetaData().
+// Returns the decoded image (ref_image_* accessors; the caller destroys it) or nullptr.
+void* ref_decode_file(const uint8_t* file, size_t bytes, int uncorrected, int* status) {
+  RefImage* out = nullptr;
+  const int st = guarded([&] {
+    const Buffer buf(file, implicit_cast<Buffer::size_type>(bytes));
+    RawParser parser(buf);
+    std::unique_ptr<RawDecoder> dec = parser.getDecoder(nullptr);
+    dec->failOnUnknown = false;
+    dec->interpolateBadPixels = false;
+    dec->uncorrectedRawValues = uncorrected != 0;
+    RawImage img = dec->decodeRaw();
+    out = new RefImage(img);
+  });
+  if (status)
+    *status = st;
+  return out;
+}
+// [0..1] uncropped dim, [2] cpp, [3] pitch, [4..5] cropped dim, [6..7] crop offset,
+// [8] 0 = UINT16 / 1 = F32, [9] isCFA
+void ref_image_info(void* h, int out[10]) {
+  const RawImage& img = static_cast<RefImage*>(h)->img;
+  const iPoint2D u = img->getUncroppedDim(), off = img->getCropOffset();
+  out[0] = u.x;
+  out[1] = u.y;
+  out[2] = int(img->getCpp());
+  out[3] = img->pitch;
+  out[4] = img->dim.x;
+  out[5] = img->dim.y;
+  out[6] = off.x;
+  out[7] = off.y;
+  out[8] = img->getDataType() == RawImageType::F32 ? 1 : 0;
+  out[9] = img->isCFA ? 1 : 0;
+}
 // what Cr2Decoder sets for sRaw files before decoding (Cr2Decoder.cpp sRaw path);
 // AbstractLJpegDecoder::parseSOF checks the SOF against it (:172-176)
 void ref_image_set_subsampling(void* h, int x, int y) {

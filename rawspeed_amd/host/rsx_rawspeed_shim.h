@@ -23,6 +23,7 @@
 #include "decoders/RawDecoderException.h"
 #include "io/IOException.h"
 
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -44,6 +45,22 @@ inline rsx_ctx* context() {
     return c;
   }();
   return ctx;
+}
+
+// What became of the units of work (a strip, a scan, a DNG tile) the hunks saw: decoded
+// by the device, or left to the method's original body.  Diagnostics only -- the tests
+// use it to show that an image was produced by the GPU and not by a silent fall-through.
+struct Stats {
+  std::atomic<uint64_t> forwarded{0}, fell_through{0};
+};
+inline Stats& stats() {
+  static Stats s;
+  return s;
+}
+// the test every hunk makes on its call's status
+inline bool done(int status) {
+  ++(status == RSX_OK ? stats().forwarded : stats().fell_through);
+  return status == RSX_OK;
 }
 
 inline rsx_image view(const RawImage& img) {
@@ -164,7 +181,7 @@ public:
         const bool full = d.tile_h >= d.frame_h * d.mcu_h;
         if (st[i] == RSX_OK && cons[i] != ljs[i]->consumed && (full || dri))
           ljs[i]->status = RSX_ERR_UNSUPPORTED;
-        all = all && ljs[i]->status == RSX_OK;
+        all = done(ljs[i]->status) && all;
       }
     }
     if (!up.empty()) {
@@ -173,7 +190,7 @@ public:
                                             &img, st.data());
       for (size_t i = 0; i < ups.size(); ++i) {
         ups[i]->status = st[i];
-        all = all && st[i] == RSX_OK;
+        all = done(st[i]) && all;
       }
     }
     return all;

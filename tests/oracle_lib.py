@@ -299,6 +299,41 @@ class RefImage:
         self.close()
 
 
+class DecodedFile:
+    """The RawImage a whole-file decode returned (owned by the reference build)."""
+
+    def __init__(self, ref, h):
+        self.ref, self.h = ref, h
+        info = (C.c_int * 10)()
+        ref.lib.ref_image_info(h, info)
+        (self.full_w, self.full_h, self.cpp, self.pitch, self.w, self.h_px, self.off_x,
+         self.off_y, self.is_f32, self.is_cfa) = list(info)
+
+    def raw(self):
+        """Every byte of the uncropped buffer, padding included, as (rows, pitch) uint8."""
+        p = self.ref.lib.ref_image_data(self.h)
+        n = self.pitch * self.full_h
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)),
+                                     shape=(n,)).reshape(self.full_h, self.pitch)
+
+    def u16(self):
+        """The uncropped image as (rows, full_w * cpp) uint16."""
+        return self.raw().view(np.uint16)[:, :self.full_w * self.cpp]
+
+    def errors(self):
+        buf = C.create_string_buffer(1 << 16)
+        self.ref.lib.ref_image_errors(self.h, buf, len(buf))
+        return buf.value.decode(errors="replace")
+
+    def close(self):
+        if self.h:
+            self.ref.lib.ref_image_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 class Ref:
     @staticmethod
     def available(path=None):
@@ -349,13 +384,35 @@ class Ref:
         L.ref_unpack_frames_parallel.argtypes = [C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_void_p, C.c_size_t, C.c_int]
         L.ref_set_threads.argtypes = [C.c_int]
+        if hasattr(L, "ref_decode_file"):
+            L.ref_decode_file.restype = C.c_void_p
+            L.ref_decode_file.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+            L.ref_image_info.argtypes = [C.c_void_p, C.c_void_p]
         L.ref_image_errors.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.ref_rsx_host_calls.restype = C.c_long
+        if hasattr(L, "ref_rsx_forwarded"):
+            L.ref_rsx_forwarded.restype = C.c_long
+            L.ref_rsx_fell_through.restype = C.c_long
         L.ref_scan_frames_parallel.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_int, C.c_int]
 
     def last_error(self):
         return self.lib.ref_last_error().decode(errors="replace")
+
+    def rsx_counts(self):
+        """(host calls served, units decoded by the device, units left to the CPU code)."""
+        return (self.lib.ref_rsx_host_calls(), self.lib.ref_rsx_forwarded(),
+                self.lib.ref_rsx_fell_through())
+
+    def decode_file(self, blob, uncorrected=False, threads=1):
+        """A whole raw file through RawParser::getDecoder + RawDecoder::decodeRaw.
+        Returns (status, DecodedFile or None)."""
+        a, p, n = _as_u8(blob)
+        st = C.c_int(0)
+        self.lib.ref_set_threads(threads)
+        h = self.lib.ref_decode_file(p, n, 1 if uncorrected else 0, C.byref(st))
+        self.lib.ref_set_threads(1)
+        return st.value, (DecodedFile(self, h) if h else None)
 
     def image(self, dim_x, dim_y, cpp=1, is_cfa=True, fill=0xA5, f32=False):
         return RefImage(self, dim_x, dim_y, cpp, is_cfa, fill, f32)

@@ -1,0 +1,116 @@
+"""TEST INFRASTRUCTURE: the synthetic raw files of the decoder-level tests.
+CASES[name]() -> (file bytes, expected uncropped image as (rows, width*cpp) uint16)."""
+import numpy as np
+
+from rawspeed_amd import abi, synth
+
+import cases as C
+import rawfiles
+
+
+def _tiles(src, tw, th, pad=1000, **kw):
+    H, W = src.shape
+    blobs = []
+    for ty in range((H + th - 1) // th):
+        for tx in range((W + tw - 1) // tw):
+            tile = np.full((th, tw), pad, np.uint16)
+            part = src[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw]
+            tile[:part.shape[0], :part.shape[1]] = part
+            blob, _, _, _ = synth.ljpeg_container(tile, 2, 14, [0, 0], [C.NIKON], **kw)
+            blobs.append(blob)
+    return blobs
+
+
+def dng_ljpeg_tiles():
+    """DngDecoder -> AbstractDngDecompressor::decompress<7>: 1021x700, 2x3 LJPEG tiles
+    with overhang on the right and at the bottom."""
+    rng = np.random.default_rng(501)
+    W, H, tw, th = 1021, 700, 512, 256
+    src = C.smooth_image(rng, H, W)
+    return rawfiles.dng_file(W, H, tw, th, _tiles(src, tw, th)), src
+
+
+def dng_ljpeg_tiles_dri():
+    """The same with restart intervals inside every tile."""
+    rng = np.random.default_rng(502)
+    W, H, tw, th = 1024, 512, 512, 256
+    src = C.smooth_image(rng, H, W)
+    return rawfiles.dng_file(W, H, tw, th, _tiles(src, tw, th, rows_per_ri=32)), src
+
+
+def dng_ljpeg_strips():
+    """LJPEG in strips (one tile column: DngDecoder::getTilingDescription, strips branch)."""
+    rng = np.random.default_rng(503)
+    W, H, th = 768, 600, 200
+    src = C.smooth_image(rng, H, W)
+    return rawfiles.dng_file(W, H, W, th, _tiles(src, W, th), strips=True), src
+
+
+def dng_uncompressed_12bit_strips():
+    """DngDecoder -> decompress<1> -> UncompressedDecompressor (12-bit MSB packed)."""
+    rng = np.random.default_rng(504)
+    W, H, th, bps = 1024, 300, 128, 12
+    src = rng.integers(0, 1 << bps, size=(H, W), dtype=np.uint16)
+    blobs = [synth.pack_rows(src[y:y + th], bps, abi.ORDER_MSB) for y in range(0, H, th)]
+    return rawfiles.dng_file(W, H, W, th, blobs, compression=1, bps=bps, strips=True), src
+
+
+def dng_uncompressed_16bit_tiles():
+    """16-bit little-endian tiles in several tile columns (the copyPixels path)."""
+    rng = np.random.default_rng(505)
+    W, H, tw, th = 1000, 300, 256, 128
+    src = rng.integers(0, 1 << 16, size=(H, W), dtype=np.uint16)
+    blobs = []
+    for ty in range((H + th - 1) // th):
+        for tx in range((W + tw - 1) // tw):
+            tile = np.zeros((th, tw), np.uint16)
+            part = src[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw]
+            tile[:part.shape[0], :part.shape[1]] = part
+            blobs.append(tile.view(np.uint8).reshape(-1))
+    return rawfiles.dng_file(W, H, tw, th, blobs, compression=1, bps=16), src
+
+
+def arw_ljpeg_tiles():
+    """ArwDecoder::DecodeLJpeg (ArwDecoder.cpp:296-411): one LJpegDecoder per tile in an
+    OpenMP loop, each decoding straight into the image."""
+    rng = np.random.default_rng(506)
+    W, H, tw, th = 1024, 768, 512, 256
+    src = C.smooth_image(rng, H, W)
+    return rawfiles.arw_file(W, H, tw, th, _tiles(src, tw, th)), src
+
+
+def arw_uncompressed():
+    """ArwDecoder::DecodeUncompressed: 16-bit LSB containers."""
+    rng = np.random.default_rng(507)
+    W, H = 1024, 512
+    src = rng.integers(0, 1 << 14, size=(H, W), dtype=np.uint16)
+    return rawfiles.arw_uncompressed_file(W, H, src.view(np.uint8).reshape(-1)), src
+
+
+def arw1_compressed():
+    """ArwDecoder -> SonyArw1Decompressor (compression 32767, strip size != w*h*bpp/8)."""
+    rng = np.random.default_rng(508)
+    W, H = 640, 488
+    x = np.arange(W)[None, :]
+    y = np.arange(H)[:, None]
+    src = np.clip(900 + 900.0 * x / W + 700.0 * y / H + rng.normal(0, 12, (H, W)),
+                  0, 4095).astype(np.uint16)
+    data, _ = synth.sony_arw1_encode(src)
+    data = np.concatenate([data, np.zeros(8, np.uint8)])
+    return rawfiles.arw1_file(W, H, data), src
+
+
+def cr2_three_slices():
+    """Cr2Decoder::decodeNewFormat -> Cr2LJpegDecoder -> Cr2Decompressor<2,1,1>."""
+    rng = np.random.default_rng(509)
+    W, H = 2016, 1100
+    src = C.smooth_image(rng, H, W)
+    rows = C.cr2_stream_from_image(src, 2, W // 2, H, [672, 672, 672])
+    blob, _, _, _ = synth.ljpeg_container(rows, 2, 14, [0, 0], [C.NIKON])
+    return rawfiles.cr2_file(W, H, blob, (2, 672, 672)), src
+
+
+CASES = {f.__name__: f for f in (
+    dng_ljpeg_tiles, dng_ljpeg_tiles_dri, dng_ljpeg_strips, dng_uncompressed_12bit_strips,
+    dng_uncompressed_16bit_tiles, arw_ljpeg_tiles, arw_uncompressed, arw1_compressed,
+    cr2_three_slices)}

@@ -1,0 +1,104 @@
+"""Whole synthetic raw files through the reference's front door, on both builds of the
+reference: RawParser::getDecoder() -> DngDecoder / ArwDecoder / Cr2Decoder ->
+decodeRaw() (parsers/RawParser.cpp:45-98, decoders/RawDecoder.cpp:320-340).  In the
+GPU-backed build (oracle/_ref/librawspeed_rsx.so: the whole library with INTEGRATION.md's
+hunks) the decoders reach librsx through the very call sites a user's files would take:
+  DngDecoder::decodeData -> AbstractDngDecompressor::decompress   (one batched call)
+  ArwDecoder::DecodeLJpeg -> LJpegDecoder::decode per tile, OpenMP (ArwDecoder.cpp:371-404)
+  ArwDecoder::DecodeUncompressed / SonyArw1Decompressor
+  Cr2Decoder::decodeNewFormat -> Cr2LJpegDecoder -> Cr2Decompressor
+The images must be identical byte for byte, the error logs equal, and the shim's counters
+must show that the device decoded every unit (no silent fall-through to the CPU loops)."""
+import numpy as np
+import pytest
+
+from rawspeed_amd import capi
+
+import raw_file_cases as F
+from oracle_lib import REF_RSX_SO, Ref
+
+pytestmark = pytest.mark.gpu
+
+# units of work the device must have decoded (tiles / strips / scans) and host calls
+EXPECT = {
+    "dng_ljpeg_tiles": (6, 1),
+    "dng_ljpeg_tiles_dri": (4, 1),
+    "dng_ljpeg_strips": (3, 1),
+    "dng_uncompressed_12bit_strips": (3, 1),
+    "dng_uncompressed_16bit_tiles": (12, 1),
+    "arw_ljpeg_tiles": (6, 6),
+    "arw_uncompressed": (1, 1),
+    "arw1_compressed": (1, 1),
+    "cr2_three_slices": (1, 1),
+}
+
+
+@pytest.fixture(scope="module")
+def pair():
+    if not (Ref.available() and Ref.available(REF_RSX_SO)):
+        pytest.skip("oracle/_ref builds absent")
+    capi.lib()  # torch's HIP runtime first (one runtime per process)
+    ref, rsx = Ref(), Ref(REF_RSX_SO)
+    if not hasattr(rsx.lib, "ref_decode_file"):
+        pytest.skip("oracle/_ref predates the whole-file entry point")
+    return ref, rsx
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+@pytest.mark.parametrize("name", sorted(F.CASES))
+def test_file_decodes_identically_on_the_gpu(pair, name, threads):
+    ref, rsx = pair
+    blob, want = F.CASES[name]()
+    s0, a = ref.decode_file(blob, threads=threads)
+    c0 = rsx.rsx_counts()
+    s1, b = rsx.decode_file(blob, threads=threads)
+    c1 = rsx.rsx_counts()
+    assert s0 == 0 and s1 == 0, (ref.last_error(), rsx.last_error())
+    assert (a.full_w, a.full_h, a.cpp, a.pitch) == (b.full_w, b.full_h, b.cpp, b.pitch)
+    assert np.array_equal(a.u16(), b.u16())
+    assert np.array_equal(b.u16(), want)
+    assert a.errors() == b.errors() == ""
+    units, calls = EXPECT[name]
+    assert c1[2] - c0[2] == 0, "some unit fell through to the CPU code"
+    assert c1[1] - c0[1] == units
+    assert c1[0] - c0[0] == calls
+
+
+def test_arw_tile_with_damaged_stream_matches_reference(pair):
+    """ArwDecoder catches the tile's exception into the ErrorLog and gives up on the first
+    error (isTooManyErrors(1), ArwDecoder.cpp:406-410): same status and message from both
+    builds; the damaged tile falls through to the reference's own loop."""
+    ref, rsx = pair
+    blob, _ = F.CASES["arw_ljpeg_tiles"]()
+    blob = blob.copy()
+    # an invalid code in the middle of the last tile's scan
+    blob[-3000:-2990] = 0xFF
+    blob[-2999:-2990:2] = 0xFE
+    s0, a = ref.decode_file(blob, threads=4)
+    c0 = rsx.rsx_counts()
+    s1, b = rsx.decode_file(blob, threads=4)
+    c1 = rsx.rsx_counts()
+    assert s0 == s1 != 0
+    assert ref.last_error() == rsx.last_error()
+    assert a is None and b is None
+    assert c1[2] - c0[2] >= 1
+
+
+def test_dng_with_one_corrupt_tile_matches_reference(pair):
+    """DngDecoder: the damaged tile's exception lands in the ErrorLog and decompress()
+    gives up (isTooManyErrors(1), AbstractDngDecompressor.cpp:122-129, :247-252).  The
+    batched call decodes the good tiles, the damaged one is replayed through the
+    reference's own loop, so status and message are the reference's."""
+    ref, rsx = pair
+    blob, want = F.CASES["dng_ljpeg_tiles"]()
+    blob = blob.copy()
+    blob[-3000:-2990] = 0xFF
+    blob[-2999:-2990:2] = 0xFE
+    s0, a = ref.decode_file(blob, threads=4)
+    c0 = rsx.rsx_counts()
+    s1, b = rsx.decode_file(blob, threads=4)
+    c1 = rsx.rsx_counts()
+    assert s0 == s1 != 0
+    assert ref.last_error() == rsx.last_error()
+    assert a is None and b is None
+    assert (c1[1] - c0[1], c1[2] - c0[2]) == (5, 1)  # five tiles from the device, one replayed
