@@ -1878,6 +1878,9 @@ void mark(LJpegPlan* p, const char* name) {
     p->timer->mark(name);
 }
 
+#ifndef RSX_K1_LDS_PAD
+#define RSX_K1_LDS_PAD 0 // (experiments: unused LDS that limits K1's workgroups per CU)
+#endif
 template <bool STITCH, bool MULTI, int NS>
 void launch_sync_one(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
   if (!p->sync_present[MULTI ? 1 : 0][NS])
@@ -1885,7 +1888,7 @@ void launch_sync_one(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((lj_sync_kernel<STITCH, MULTI, false, NS>), dim3(p->total_blocks),
                      dim3(LJ_T),
                      lj_lds_bytes(MULTI ? p->max_tables : 1, LJ_BW_SYNC) +
-                         (STITCH ? lj_periodic_bytes() : 0),
+                         (STITCH ? lj_periodic_bytes() : RSX_K1_LDS_PAD),
                      s, a);
   mark(p, STITCH ? "lj_sync_kernel<stitch>" : "lj_sync_kernel");
 }

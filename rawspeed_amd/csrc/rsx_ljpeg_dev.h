@@ -70,8 +70,12 @@ constexpr uint32_t FL_PERIODIC = 4u;
 // LUT_BITS; sensor data: nearly always), so that the loops which need differences (the
 // recorded synchronisation pass, the final decode) read them instead of computing the
 // JPEG "EXTEND"; longer symbols take the computed path, wave-uniformly.
+// OFF: the 8 KB table costs the synchronisation kernel its sixth workgroup per CU, which
+// is worth more than the instructions saved (production builds side by side, one GPU
+// session: cfg 3 1.274 -> 1.232 ms, uniform-random 14-bit 1.09 -> 0.96, clipped
+// highlights 2.48 -> 2.25 with the table off).  Kept for experiments.
 #ifndef RSX_LUT_DIFF
-#define RSX_LUT_DIFF 1
+#define RSX_LUT_DIFF 0
 #endif
 #if RSX_LUT_DIFF
 typedef uint32_t LutEntry;

@@ -438,8 +438,12 @@ __device__ __forceinline__ OutCursor lj_store_general(const StoreCtx& x, OutCurs
 #endif
 constexpr int K4D_BURST = RSX_K4D_BURST; // groups of 8 samples decoded before their stores
 
+#ifndef RSX_K4D_LDS_PAD
+#define RSX_K4D_LDS_PAD 0 // (experiments: unused LDS that limits the workgroups per CU)
+#endif
 constexpr size_t k4d_lds_bytes(int n_tables) {
-  return size_t(LJ_BW_DEC) * LJ_T * 4 + 16 * 4 + size_t(n_tables) * sizeof(TabLds);
+  return size_t(LJ_BW_DEC) * LJ_T * 4 + 16 * 4 + size_t(n_tables) * sizeof(TabLds) +
+         RSX_K4D_LDS_PAD;
 }
 
 #ifndef RSX_K4D_MIN_WAVES

@@ -70,10 +70,7 @@ def test_arw_tile_with_damaged_stream_matches_reference(pair):
     builds; the damaged tile falls through to the reference's own loop."""
     ref, rsx = pair
     blob, _ = F.CASES["arw_ljpeg_tiles"]()
-    blob = blob.copy()
-    # an invalid code in the middle of the last tile's scan
-    blob[-3000:-2990] = 0xFF
-    blob[-2999:-2990:2] = 0xFE
+    blob = _damage_first_tile(blob)
     s0, a = ref.decode_file(blob, threads=4)
     c0 = rsx.rsx_counts()
     s1, b = rsx.decode_file(blob, threads=4)
@@ -84,6 +81,19 @@ def test_arw_tile_with_damaged_stream_matches_reference(pair):
     assert c1[2] - c0[2] >= 1
 
 
+def _damage_first_tile(blob):
+    """An invalid code in the middle of the first tile's scan (a tile that is decoded to
+    its full height, so the damage is met).  The first tile is the first SOI in the file."""
+    blob = blob.copy()
+    raw = blob.tobytes()
+    start = raw.find(b"\xff\xd8")
+    nxt = raw.find(b"\xff\xd8", start + 2)
+    mid = (start + nxt) // 2
+    blob[mid:mid + 12] = 0xFF
+    blob[mid + 1:mid + 12:2] = 0xFE
+    return blob
+
+
 def test_dng_with_one_corrupt_tile_matches_reference(pair):
     """DngDecoder: the damaged tile's exception lands in the ErrorLog and decompress()
     gives up (isTooManyErrors(1), AbstractDngDecompressor.cpp:122-129, :247-252).  The
@@ -91,9 +101,7 @@ def test_dng_with_one_corrupt_tile_matches_reference(pair):
     reference's own loop, so status and message are the reference's."""
     ref, rsx = pair
     blob, want = F.CASES["dng_ljpeg_tiles"]()
-    blob = blob.copy()
-    blob[-3000:-2990] = 0xFF
-    blob[-2999:-2990:2] = 0xFE
+    blob = _damage_first_tile(blob)
     s0, a = ref.decode_file(blob, threads=4)
     c0 = rsx.rsx_counts()
     s1, b = rsx.decode_file(blob, threads=4)
