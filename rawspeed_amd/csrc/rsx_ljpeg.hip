@@ -61,6 +61,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <type_traits>
 
 namespace rsx {
 
@@ -287,7 +288,7 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
 
 // Entry of the symbol that starts at `pos` (0 = invalid code); *w_out = its window.
 // REVBW: layout of the image (lj_window).
-template <bool MULTI, bool PAIR, int REVBW>
+template <bool MULTI, bool PAIR, int REVBW, typename TB = TabLds>
 __device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp, int col,
                                             uint32_t pos, uint32_t phase, bool live,
                                             uint32_t* w_out = nullptr,
@@ -295,7 +296,7 @@ __device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp
   const uint32_t w = lj_window<REVBW>(L.B, col, pos);
   if (w_out)
     *w_out = w;
-  const TabLds& tb = lj_table<MULTI>(L, dp, phase);
+  const TB& tb = lj_table<MULTI, TB>(L, dp, phase);
   uint32_t e;
   if (d_out) // (the loops that accumulate differences)
     e = lj_entry_diff(w, tb, live, dp.long_codes, d_out);
@@ -318,7 +319,7 @@ __device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp
 // the hot loop).  With one shared table the component phase does not influence the
 // parse, so it is left out of the state (it would never self-synchronise); with
 // several tables it is part of what has to match.
-template <bool MULTI, int NS, bool PAIR, int REVBW>
+template <bool MULTI, int NS, bool PAIR, int REVBW, typename TB = TabLds>
 __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams& dp,
                                                int col, uint32_t start,
                                                uint32_t end_bits, uint32_t& exit,
@@ -337,7 +338,7 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
     const bool live = pos < end_bits;
     uint32_t w, d = 0;
     const uint32_t e =
-        lj_step<MULTI, PAIR, REVBW>(L, dp, col, pos, phase, live, &w, NS ? &d : nullptr);
+        lj_step<MULTI, PAIR, REVBW, TB>(L, dp, col, pos, phase, live, &w, NS ? &d : nullptr);
     const bool bad = live && e == 0u;
     const bool good = live && !bad;
     if (NS)
@@ -363,7 +364,7 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
 // arbitrary bit position; Huffman streams self-synchronise within a few
 // symbols, so the position at which this runs into slot j is almost always the
 // true one.  (Checked against the predecessor's real exit afterwards.)
-template <bool MULTI, bool PAIR, int REVBW>
+template <bool MULTI, bool PAIR, int REVBW, typename TB = TabLds>
 __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& dp,
                                               int j) {
   // j == 0 has no predecessor slot in LDS: it takes no steps (`enabled` false)
@@ -371,8 +372,8 @@ __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& 
   const uint32_t prev_bits = enabled ? L.ob[j - 1] : 0u;
   const uint32_t from = prev_bits > LJ_WARM ? prev_bits - LJ_WARM : 0u;
   uint32_t e = 0, c = 0;
-  lj_decode_span<MULTI, 0, PAIR, REVBW>(L, dp, enabled ? j - 1 : 0, 0u, prev_bits, e, c, nullptr,
-                                 enabled && prev_bits != 0, from);
+  lj_decode_span<MULTI, 0, PAIR, REVBW, TB>(L, dp, enabled ? j - 1 : 0, 0u, prev_bits, e, c,
+                                            nullptr, enabled && prev_bits != 0, from);
   return (e & ST_ERR) ? 0u : e;
 }
 
@@ -441,9 +442,10 @@ constexpr size_t lj_periodic_bytes() {
   return 2 * LJ_T * 4 + LJ_T + PER_CLASSES * 4 + PER_CLASSES * 32 * sizeof(PeriodicEntry) + 16;
 }
 
+template <typename TB>
 __device__ __forceinline__ PeriodicLds carve_periodic(const Lds& L, int n_tables) {
   PeriodicLds p;
-  p.hash = reinterpret_cast<uint32_t*>(L.tabs + n_tables);
+  p.hash = reinterpret_cast<uint32_t*>(reinterpret_cast<TB*>(L.tabs) + n_tables);
   p.members = p.hash + LJ_T;
   p.rep_of = p.members + LJ_T;
   p.tbl = reinterpret_cast<PeriodicEntry*>(p.rep_of + PER_CLASSES);
@@ -452,7 +454,7 @@ __device__ __forceinline__ PeriodicLds carve_periodic(const Lds& L, int n_tables
 }
 
 // Classes of identical slots and their tables.  Called by the whole workgroup.
-template <int NS, int BWK>
+template <int NS, int BWK, typename TB>
 __device__ __forceinline__ void lj_periodic_build(const Lds& L, const PeriodicLds& P,
                                                   const DecodeParams& dp, int j) {
   // content = the slot's dwords + its data-bit count
@@ -499,8 +501,8 @@ __device__ __forceinline__ void lj_periodic_build(const Lds& L, const PeriodicLd
   const uint32_t r = P.rep_of[c];
   uint32_t e = ST_ERR, n = 0;
   uint2 sums = make_uint2(0, 0);
-  lj_decode_span<false, NS, false, BWK>(L, dp, int(r ? r : 1u), e0, L.ob[r ? r : 1u], e, n,
-                                        &sums, r != 0);
+  lj_decode_span<false, NS, false, BWK, TB>(L, dp, int(r ? r : 1u), e0, L.ob[r ? r : 1u], e, n,
+                                            &sums, r != 0);
   PeriodicEntry t;
   t.exit = uint16_t(e);
   t.count = uint16_t(n);
@@ -515,20 +517,15 @@ template <int NS>
 __device__ __forceinline__ void lj_periodic_walk(const Lds& L, const PeriodicLds& P,
                                                  uint32_t true_start) {
   for (int q = 1; q < LJ_T; ++q) {
-    const uint32_t want = q == 1 ? true_start : uint32_t(L.st[q - 1]);
-    if (want == L.su[q] || (want & ST_ERR) || !(L.ob[q] != 0 || q == 1))
+    const uint32_t want = q == 1 ? true_start : rec_st(L.rec[q - 1]);
+    if (want == rec_su(L.rec[q]) || (want & ST_ERR) || !(L.ob[q] != 0 || q == 1))
       continue;
     const uint32_t c = P.cls[q];
     if (c == 0xFFu || (want & ST_OFF_MASK) > 31u)
       continue; // left to the re-decode rounds
     const PeriodicEntry t = P.tbl[c * 32u + (want & 31u)];
-    L.su[q] = uint16_t(want);
-    L.st[q] = t.exit;
-    L.cn[q] = t.count;
-    if (NS) {
-      L.sm[2 * q] = t.s0;
-      L.sm[2 * q + 1] = t.s1;
-    }
+    L.rec[q] = rec_make(want, t.exit, t.count);
+    sm_set<NS>(L, q, make_uint2(t.s0, t.s1));
   }
 }
 
@@ -536,17 +533,27 @@ __device__ __forceinline__ void lj_periodic_walk(const Lds& L, const PeriodicLds
 // K1 / K2: synchronisation.  NS = interleaved components of a fused-path stream
 // (its difference sums are recorded), 0 = none.
 // ---------------------------------------------------------------------------
+// Which synchronisation instantiation takes a stream: the MULTI one also takes
+// single-table streams that need the full 11-bit LUT (its states carry the component
+// phase, which stays 0 for them).
+__device__ __forceinline__ bool lj_sync_multi(const LjStreamDev& S) {
+  return S.n_tables > 1 || S.sync_lut11 != 0;
+}
+template <bool MULTI, bool PAIR>
+using SyncTable = std::conditional_t<(!MULTI && !PAIR), TabLds10, TabLds>;
+
 template <bool STITCH, bool MULTI, bool PAIR, int NS>
 __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t b = blockIdx.x;
   const uint32_t s = a.block_stream[b];
   const LjStreamDev& S = a.streams[s];
-  if ((S.n_tables > 1) != MULTI || (S.pair != 0) != PAIR || int(S.direct) != NS)
+  if (lj_sync_multi(S) != MULTI || (S.pair != 0) != PAIR || int(S.direct) != NS)
     return; // another instantiation handles this stream
   constexpr int BWK = PAIR ? LJ_BW_SYNC_PAIR : LJ_BW_SYNC;
   constexpr int N = NS ? NS : 1;
-  const Lds L = carve(smem, BWK);
+  using TB = SyncTable<MULTI, PAIR>;
+  const Lds L = carve_sync(smem, BWK, NS);
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
 
@@ -567,11 +574,14 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   if (STITCH && j == 0)
     atomicAdd(&a.results[s].stat_stitch, 1u);
 #endif
-  lj_stage_tables(L, a, S);
+  if (TabBits<TB>::value == LUT_BITS)
+    lj_stage_tables(L, a, S);
+  else
+    lj_stage_tables10(L, a, S);
   lj_load_image<BWK, true>(L, a, b, j); // ends with a barrier (tables complete, too)
   const uint32_t own_bits = L.ob[j];
   DecodeParams dp = lj_params(S);
-  dp.long_codes = lj_long_codes(L, S.n_tables);
+  dp.long_codes = lj_long_codes<TB>(L, S.n_tables);
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1); // j >= 1
 
   // initial decode / initial records
@@ -582,41 +592,29 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     // known start state; every other slot decodes from its warm-up guess
     // (slot 0 of later workgroups from bit 0)
     const bool real_slot = !(lb == 0 && j == 0);
-    const uint32_t guess = (LJ_ABLATE & 16u) ? 0u : lj_warmup<MULTI, PAIR, BWK>(L, dp, j);
+    const uint32_t guess = (LJ_ABLATE & 16u) ? 0u : lj_warmup<MULTI, PAIR, BWK, TB>(L, dp, j);
     if (j >= 2 || (j == 1 && lb > 0))
       start = guess;
     else if (j == 1)
       start = S.start_bit; // the stream's first symbol
-    lj_decode_span<MULTI, NS, PAIR, BWK>(L, dp, j, start, own_bits, e, c, &sums,
-                                    real_slot && !(LJ_ABLATE & 4u));
+    lj_decode_span<MULTI, NS, PAIR, BWK, TB>(L, dp, j, start, own_bits, e, c, &sums,
+                                             real_slot && !(LJ_ABLATE & 4u));
     if (!real_slot) {
       e = S.start_bit;
       c = 0;
     }
-    L.su[j] = start;
-    L.st[j] = e;
-    L.cn[j] = c;
-    if (NS) {
-      L.sm[2 * j] = sums.x;
-      L.sm[2 * j + 1] = sums.y;
-    }
+    L.rec[j] = rec_make(start, e, c);
+    sm_set<NS>(L, j, sums);
   } else {
     if (j == 0) {
-      L.su[0] = 0;
-      L.st[0] = 0;
-      L.cn[0] = 0;
+      L.rec[0] = 0;
     } else {
       const uint32_t rec = a.sub_state[gsub];
-      L.st[j] = rec & ST_MASK;
-      L.cn[j] = rec >> 16;
-      // (the state the slot was decoded FROM: a workgroup that gave up on its rounds
-      // left records that are not a consistent chain yet)
-      L.su[j] = a.sub_start[gsub];
-      if (NS) {
-        const uint2 sums = a.sub_sums[gsub];
-        L.sm[2 * j] = sums.x;
-        L.sm[2 * j + 1] = sums.y;
-      }
+      // (su = the state the slot was decoded FROM: a workgroup that gave up on its
+      // rounds left records that are not a consistent chain yet)
+      L.rec[j] = rec_make(a.sub_start[gsub], rec & ST_MASK, rec >> 16);
+      if (NS)
+        sm_set<NS>(L, j, a.sub_sums[gsub]);
     }
   }
 
@@ -631,7 +629,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   const int first_chained = STITCH ? 2 : 1;
   uint32_t rounds = 0;
   bool gave_up = false, classes_ready = false;
-  const PeriodicLds PL = carve_periodic(L, MULTI ? int(S.n_tables) : 1);
+  const PeriodicLds PL = carve_periodic<TB>(L, MULTI ? int(S.n_tables) : 1);
   while (true) {
     if (STITCH && !MULTI && !PAIR && classes_ready) {
       // slots with identical content: their exits come from the class tables
@@ -642,11 +640,12 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     if (j == 0)
       L.misc[8] = 0;
     __syncthreads();
-    uint32_t want = L.su[j];
+    const uint32_t my_su = rec_su(L.rec[j]);
+    uint32_t want = my_su;
     if (STITCH && j == 1)
       want = true_start;
     else if (j >= first_chained)
-      want = L.st[j - 1];
+      want = rec_st(L.rec[j - 1]);
     // Slots past the end of the data hold no symbol start: whatever state enters
     // them leaves them unchanged, and nothing after them is ever decoded (only a
     // suffix of a stream can be empty).  Chaining them would cost one round PER
@@ -662,7 +661,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     // alone: if the error is transient the predecessor is repaired and the slot is
     // compared again next round; if it is real, nothing after it is needed (the
     // decode kernel reports it from the failing slot's own record).
-    if (want != L.su[j] && chained && !(want & ST_ERR)) {
+    if (want != my_su && chained && !(want & ST_ERR)) {
       const uint32_t k = atomicAdd(&L.misc[8], 1u);
       L.list[k] = uint16_t(j);
     }
@@ -687,7 +686,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     // (a round earlier for a workgroup that has given up before: it is chaining)
     if (STITCH && !MULTI && !PAIR && !classes_ready &&
         rounds == (unresolved ? 2u : LJ_STITCH_CLASS_ROUND)) {
-      lj_periodic_build<NS, BWK>(L, PL, dp, j); // (workgroup-uniform; has barriers)
+      lj_periodic_build<NS, BWK, TB>(L, PL, dp, j); // (workgroup-uniform; has barriers)
       classes_ready = true;
       continue;
     }
@@ -705,40 +704,36 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
     if (uint32_t(j & ~63) < n) {
       const bool mine = uint32_t(j) < n;
       idx = mine ? uint32_t(L.list[j]) : 1u;
-      w = (STITCH && idx == 1) ? true_start : L.st[idx - 1];
+      w = (STITCH && idx == 1) ? true_start : rec_st(L.rec[idx - 1]);
       // (a plain re-decode of the whole slot.  Two ways to stop early where the new parse
       // meets the recorded one were measured and lost: a bitmap of the first 64 bits'
       // symbol starts (round 1) cannot carry the difference sums, and walking both
       // parses in lock step costs two steps per symbol while the slowest of the few
       // lanes of a round still runs to the end of its slot: 0.625 vs 0.596 ms per 8
       // cfg-3 frames.)
-      lj_decode_span<MULTI, NS, PAIR, BWK>(L, dp, int(idx), w, L.ob[idx], e, c, &sums, mine);
+      lj_decode_span<MULTI, NS, PAIR, BWK, TB>(L, dp, int(idx), w, L.ob[idx], e, c, &sums,
+                                               mine);
     }
     __syncthreads(); // every read of the records precedes the updates
     if (uint32_t(j) < n) {
-      L.su[idx] = w;
-      L.st[idx] = e;
-      L.cn[idx] = c;
-      if (NS) {
-        L.sm[2 * idx] = sums.x;
-        L.sm[2 * idx + 1] = sums.y;
-      }
+      L.rec[idx] = rec_make(w, e, c);
+      sm_set<NS>(L, int(idx), sums);
     }
   }
 
-  const uint32_t my_count = j >= 1 ? uint32_t(L.cn[j]) : 0u;
-  const uint2 my_sums =
-      (NS && j >= 1) ? make_uint2(L.sm[2 * j], L.sm[2 * j + 1]) : make_uint2(0u, 0u);
+  const uint32_t my_rec = L.rec[j];
+  const uint32_t my_count = j >= 1 ? rec_cn(my_rec) : 0u;
+  const uint2 my_sums = (NS && j >= 1) ? sm_get<NS>(L, j) : make_uint2(0u, 0u);
   if (j >= 1) {
-    a.sub_state[gsub] = L.st[j] | (my_count << 16);
-    a.sub_start[gsub] = L.su[j];
+    a.sub_state[gsub] = rec_st(my_rec) | (my_count << 16);
+    a.sub_start[gsub] = uint16_t(rec_su(my_rec));
     if (NS)
       a.sub_sums[gsub] = my_sums;
   }
   if (j == 1)
-    a.block_start[b] = L.su[1];
+    a.block_start[b] = rec_su(my_rec);
   if (j == LJ_T - 1)
-    a.block_exit[b] = L.st[j];
+    a.block_exit[b] = rec_st(my_rec);
   // A workgroup of periodic data: its exit for EVERY entry state, by following the
   // chain with the class tables (slots outside a class must be entered the way they
   // were recorded).  lj_pchain_kernel strings these together so that a constant region
@@ -753,8 +748,8 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
         const uint32_t c = PL.cls[q];
         if (c != 0xFFu && (state & ST_OFF_MASK) <= 31u)
           state = PL.tbl[c * 32u + (state & 31u)].exit;
-        else if (state == L.su[q])
-          state = L.st[q];
+        else if (state == rec_su(L.rec[q]))
+          state = rec_st(L.rec[q]);
         else
           state = 0xFFFFu; // unknown for this entry
       }
@@ -1814,7 +1809,7 @@ struct LJpegPlan {
   LJpegPlan* child = nullptr;          // one stream per restart interval
   std::vector<std::pair<int, int>> child_owner; // child job -> (dri index, interval)
   // NikonDecompressor streams
-  bool any_nikon = false, any_pair = false, any_multi = false;
+  bool any_nikon = false, any_pair = false, any_multi = false, any_lut11 = false;
   std::vector<NkStreamDev> nk;         // parallel to streams
   DeviceBuffer d_nk, d_nk_tables, d_nk_rowpow, d_nk_pup;
   DeviceBuffer d_transfer; // fallback path only (allocated on first use)
@@ -1885,11 +1880,11 @@ template <bool STITCH, bool MULTI, int NS>
 void launch_sync_one(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
   if (!p->sync_present[MULTI ? 1 : 0][NS])
     return;
+  using TB = SyncTable<MULTI, false>;
+  const size_t lds = lj_sync_lds_bytes<TB>(MULTI ? p->max_tables : 1, LJ_BW_SYNC, NS) +
+                     (STITCH ? lj_periodic_bytes() : RSX_K1_LDS_PAD);
   hipLaunchKernelGGL((lj_sync_kernel<STITCH, MULTI, false, NS>), dim3(p->total_blocks),
-                     dim3(LJ_T),
-                     lj_lds_bytes(MULTI ? p->max_tables : 1, LJ_BW_SYNC) +
-                         (STITCH ? lj_periodic_bytes() : RSX_K1_LDS_PAD),
-                     s, a);
+                     dim3(LJ_T), lds, s, a);
   mark(p, STITCH ? "lj_sync_kernel<stitch>" : "lj_sync_kernel");
 }
 
@@ -1904,8 +1899,11 @@ void launch_sync(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
   launch_sync_one<STITCH, true, 2>(p, a, s);
   launch_sync_one<STITCH, true, 4>(p, a, s);
   if (p->any_pair) {
+    using TB = SyncTable<false, true>;
+    const size_t lds =
+        lj_sync_lds_bytes<TB>(1, LJ_BW_SYNC_PAIR, 0); // (no class tables for pair symbols)
     hipLaunchKernelGGL((lj_sync_kernel<STITCH, false, true, 0>), dim3(p->total_blocks),
-                       dim3(LJ_T), lj_lds_bytes(1, LJ_BW_SYNC_PAIR), s, a);
+                       dim3(LJ_T), lds, s, a);
     mark(p, STITCH ? "lj_sync_kernel<stitch,pair>" : "lj_sync_kernel<pair>");
   }
 }
@@ -2041,6 +2039,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     S.pair = g.pair;
     S.no_vertical = g.no_vertical;
     S.direct = direct_n;
+    S.sync_lut11 = (J.explicit_n > 0 && J.explicit_bits > 10) ? 1 : 0;
     S.raw_limit = g.raw_limit;
     S.rows = g.rows;
     S.row_samples = g.row_samples;
@@ -2124,8 +2123,9 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     const bool multi = J.n_tables > 1;
     p->any_multi |= multi;
     p->any_pair |= g.pair != 0;
+    p->any_lut11 |= S.sync_lut11 != 0;
     if (!g.pair)
-      p->sync_present[multi ? 1 : 0][S.direct] = true;
+      p->sync_present[(multi || S.sync_lut11) ? 1 : 0][S.direct] = true;
     LJpegPlan::Classes& cls = S.direct ? p->fallback : p->legacy;
     cls.plain |= !multi && !g.las && !g.pair;
     cls.las |= g.las != 0;
@@ -2564,7 +2564,7 @@ int converge(LJpegPlan* p, hipStream_t s) {
   const LjArgs a = make_args(p, p->last_in, p->last_out);
   {
     if (p->sync_present[0][0] || p->sync_present[0][1] || p->sync_present[0][2] ||
-        p->sync_present[0][4])
+        p->sync_present[0][4] || p->any_lut11)
       hipLaunchKernelGGL((lj_transfer_kernel<false>), dim3(p->total_blocks), dim3(64),
                          sizeof(TabLds), s, a);
     if (p->any_pair)

@@ -25,6 +25,7 @@ struct Lds {
                   //          (4 x u16; K0 parks its 16 byte-compaction selectors here)
   uint32_t* misc; // [16]
   TabLds* tabs;
+  uint32_t* rec;  // [LJ_T] synchronisation kernels only: su, st, cn packed (carve_sync)
 };
 
 // Sized to the byte: gfx950 hands out LDS in 1280-byte granules (160 KB / 128) and
@@ -56,8 +57,84 @@ __device__ __forceinline__ Lds carve(uint8_t* smem, int bw = LJ_BW) {
 constexpr size_t lj_lds_bytes(int n_tables, int bw = LJ_BW) {
   return lj_lds_words(bw) * 4 + size_t(n_tables) * sizeof(TabLds);
 }
-static_assert(lj_lds_bytes(1, LJ_BW_SYNC) <= (RSX_LUT_DIFF ? 24 : 21) * 1280,
-              "six sync workgroups per CU (five with the difference LUT)");
+
+// The synchronisation kernels' own, tighter layout.  Their speed is the number of
+// workgroups a CU holds (measured with padded allocations, 8 cfg-3 frames: 3 / 4 / 5 / 6
+// workgroups = 0.785 / 0.617 / 0.525 / 0.472 ms), so everything is packed to get a
+// SEVENTH one in (18 granules of 1280 bytes):
+//  * one 32-bit record per slot instead of three 16-bit arrays: exit state (10 bits:
+//    ST_ERR | phase | offset), the start state it was decoded from (10), symbols (12);
+//  * the difference sums take one dword per slot for up to two components, none when
+//    the stream does not take the fused path;
+//  * single-table streams look their codes up on 10 bits instead of 11 (TabLds10: 2 KB
+//    less; codes of 11 bits and more -- the rarest categories -- take the search).
+struct alignas(16) TabLds10 {
+  uint16_t lut[1024];
+  uint32_t max_code[18];
+  uint16_t val_offset[18];
+  uint8_t values[RSX_MAX_CODE_VALUES];
+  uint8_t max_len;
+  uint8_t fix16;
+  uint8_t zero_sym_bits;
+  uint8_t las;
+};
+static_assert(sizeof(TabLds10) % 16 == 0, "TabLds10 must be 16-byte sized");
+template <typename TB> struct TabBits { static constexpr int value = LUT_BITS; };
+template <> struct TabBits<TabLds10> { static constexpr int value = 10; };
+
+constexpr uint32_t REC_ST_MASK = 0x3FFu, REC_SU_SHIFT = 10, REC_CN_SHIFT = 20;
+static_assert(ST_ERR < 1024u, "a state fits the record's 10 bits");
+__device__ __forceinline__ uint32_t rec_make(uint32_t su, uint32_t st, uint32_t cn) {
+  return (st & REC_ST_MASK) | ((su & REC_ST_MASK) << REC_SU_SHIFT) | (cn << REC_CN_SHIFT);
+}
+__device__ __forceinline__ uint32_t rec_st(uint32_t r) { return r & REC_ST_MASK; }
+__device__ __forceinline__ uint32_t rec_su(uint32_t r) { return (r >> REC_SU_SHIFT) & REC_ST_MASK; }
+__device__ __forceinline__ uint32_t rec_cn(uint32_t r) { return r >> REC_CN_SHIFT; }
+
+constexpr size_t lj_sync_sm_words(int ns) { return ns == 0 ? 0 : (ns <= 2 ? LJ_T : 2 * LJ_T); }
+constexpr size_t lj_sync_lds_words(int bw, int ns) {
+  return size_t(bw) * LJ_T + LJ_T + LJ_T / 2 + lj_sync_sm_words(ns) + LJ_T / 2 + 16;
+}
+template <typename TB>
+constexpr size_t lj_sync_lds_bytes(int n_tables, int bw, int ns) {
+  return lj_sync_lds_words(bw, ns) * 4 + size_t(n_tables) * sizeof(TB);
+}
+static_assert(lj_sync_lds_bytes<TabLds10>(1, LJ_BW_SYNC, 2) <= 18 * 1280,
+              "seven synchronisation workgroups per CU");
+static_assert(lj_sync_lds_words(LJ_BW_SYNC, 0) % 4 == 0 && lj_sync_lds_words(LJ_BW_SYNC_PAIR, 4) % 4 == 0,
+              "the tables start on a 16-byte boundary");
+
+__device__ __forceinline__ Lds carve_sync(uint8_t* smem, int bw, int ns) {
+  Lds l{};
+  l.B = reinterpret_cast<uint32_t*>(smem);
+  l.rec = l.B + bw * LJ_T;
+  l.ob = reinterpret_cast<uint16_t*>(l.rec + LJ_T);
+  l.sm = reinterpret_cast<uint32_t*>(l.ob + LJ_T);
+  l.list = reinterpret_cast<uint16_t*>(l.sm + lj_sync_sm_words(ns));
+  l.misc = reinterpret_cast<uint32_t*>(l.list + LJ_T);
+  l.tabs = reinterpret_cast<TabLds*>(l.misc + 16);
+  return l;
+}
+// the difference sums of slot j (N components)
+template <int NS>
+__device__ __forceinline__ uint2 sm_get(const Lds& L, int j) {
+  if (NS == 0)
+    return make_uint2(0u, 0u);
+  if (NS <= 2)
+    return make_uint2(L.sm[j], 0u);
+  return make_uint2(L.sm[2 * j], L.sm[2 * j + 1]);
+}
+template <int NS>
+__device__ __forceinline__ void sm_set(const Lds& L, int j, uint2 v) {
+  if (NS == 0)
+    return;
+  if (NS <= 2) {
+    L.sm[j] = v.x;
+  } else {
+    L.sm[2 * j] = v.x;
+    L.sm[2 * j + 1] = v.y;
+  }
+}
 static_assert(lj_lds_words(LJ_BW_SYNC) % 4 == 0 && lj_lds_words(LJ_BW_SYNC_PAIR) % 4 == 0 &&
                   lj_lds_words(LJ_BW) % 4 == 0,
               "the tables start on a 16-byte boundary");
@@ -69,6 +146,29 @@ __device__ __forceinline__ void lj_stage_tables(const Lds& L, const LjArgs& a,
   const int n16 = int(S.n_tables * sizeof(TabLds) / 16);
   for (int i = threadIdx.x; i < n16; i += int(blockDim.x))
     dst[i] = src[i];
+}
+
+// ... as TabLds10: every other entry of the 11-bit LUT (the two entries of a code of at
+// most 10 bits are the same; an 11-bit code becomes "not in the LUT")
+__device__ __forceinline__ void lj_stage_tables10(const Lds& L, const LjArgs& a,
+                                                  const LjStreamDev& S) {
+  static_assert(LUT_BITS == 11, "TabLds10 halves an 11-bit LUT");
+  const TabLds* src = a.tables + S.table_base;
+  TabLds10* dst = reinterpret_cast<TabLds10*>(L.tabs);
+  for (uint32_t t = 0; t < S.n_tables; ++t) {
+    for (int i = threadIdx.x; i < 1024; i += int(blockDim.x)) {
+      const uint32_t e =
+          reinterpret_cast<const uint16_t*>(src[t].lut)[2 * i * (sizeof(LutEntry) / 2)];
+      dst[t].lut[i] = uint16_t((e & 31u) > 10u ? 0u : e);
+    }
+    // (max_code .. las: the same bytes in both structs)
+    constexpr int tail = int(sizeof(TabLds10) - sizeof(dst[t].lut));
+    static_assert(sizeof(TabLds) - sizeof(src[t].lut) == size_t(tail), "same tail");
+    const uint32_t* ts = reinterpret_cast<const uint32_t*>(src[t].max_code);
+    uint32_t* td = reinterpret_cast<uint32_t*>(dst[t].max_code);
+    for (int i = threadIdx.x; i < tail / 4; i += int(blockDim.x))
+      td[i] = ts[i];
+  }
 }
 
 // End of the data the bit reader hands out before its zero padding.  An MSB32
@@ -136,9 +236,10 @@ __device__ __forceinline__ uint32_t lj_window(const uint32_t* B, int col, uint32
 
 // Packed symbol entry (the LUT's format): bits 0..4 code length, 5..9 SSSS,
 // 10..15 bits consumed.  0 = invalid code.
-__device__ __noinline__ uint32_t lj_slow_entry(uint32_t w, const TabLds* tb) {
+template <typename TB>
+__device__ __noinline__ uint32_t lj_slow_entry(uint32_t w, const TB* tb) {
   // codes longer than the LUT: JPEG Annex F.2.2.3 search
-  for (uint32_t l = LUT_BITS + 1; l <= tb->max_len; ++l) {
+  for (uint32_t l = TabBits<TB>::value + 1; l <= tb->max_len; ++l) {
     const uint32_t c = w >> (32 - l);
     const uint32_t mc = tb->max_code[l];
     if (mc != NO_CODE && c <= mc) {
@@ -175,10 +276,14 @@ __device__ __forceinline__ uint32_t lj_extend(uint32_t w, uint32_t e) {
 __device__ __forceinline__ uint32_t lj_lut16(const TabLds& tb, uint32_t i) {
   return reinterpret_cast<const uint16_t*>(tb.lut)[i * (sizeof(LutEntry) / 2)];
 }
+__device__ __forceinline__ uint32_t lj_lut16(const TabLds10& tb, uint32_t i) {
+  return tb.lut[i];
+}
 
-__device__ __forceinline__ uint32_t lj_entry(uint32_t w, const TabLds& tb, bool live,
+template <typename TB>
+__device__ __forceinline__ uint32_t lj_entry(uint32_t w, const TB& tb, bool live,
                                              bool long_codes = true) {
-  uint32_t e = lj_lut16(tb, w >> (32 - LUT_BITS));
+  uint32_t e = lj_lut16(tb, w >> (32 - TabBits<TB>::value));
   if (long_codes && __builtin_expect(__any(live && (e & 31u) == 0u), 0)) {
     if (live && (e & 31u) == 0u)
       e = lj_slow_entry(w, &tb);
@@ -190,6 +295,12 @@ __device__ __forceinline__ uint32_t lj_entry(uint32_t w, const TabLds& tb, bool 
 // both): *diff = the 16-bit difference.  With RSX_LUT_DIFF it comes out of the LUT's
 // high half when the symbol lies inside the index bits; otherwise (wave-uniform branch:
 // only when some live lane has a longer symbol) it is computed.
+__device__ __forceinline__ uint32_t lj_entry_diff(uint32_t w, const TabLds10& tb, bool live,
+                                                  bool long_codes, uint32_t* diff) {
+  const uint32_t e = lj_entry(w, tb, live, long_codes);
+  *diff = lj_extend(w, e);
+  return e;
+}
 __device__ __forceinline__ uint32_t lj_entry_diff(uint32_t w, const TabLds& tb, bool live,
                                                   bool long_codes, uint32_t* diff) {
 #if RSX_LUT_DIFF
@@ -277,17 +388,19 @@ struct BitReader {
 
 // whether any of the stream's n tables (staged in LDS) has codes longer than the LUT
 // (wave-uniform)
+template <typename TB = TabLds>
 __device__ __forceinline__ bool lj_long_codes(const Lds& L, uint32_t n_tables) {
   uint32_t m = 0;
   for (uint32_t t = 0; t < n_tables; ++t)
-    m = max(m, uint32_t(L.tabs[t].max_len));
-  return __builtin_amdgcn_readfirstlane(int(m)) > LUT_BITS;
+    m = max(m, uint32_t(reinterpret_cast<const TB*>(L.tabs)[t].max_len));
+  return __builtin_amdgcn_readfirstlane(int(m)) > TabBits<TB>::value;
 }
 
-template <bool MULTI>
-__device__ __forceinline__ const TabLds& lj_table(const Lds& L, const DecodeParams& dp,
-                                                  uint32_t phase) {
-  return L.tabs[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu : 0u];
+template <bool MULTI, typename TB = TabLds>
+__device__ __forceinline__ const TB& lj_table(const Lds& L, const DecodeParams& dp,
+                                              uint32_t phase) {
+  return reinterpret_cast<const TB*>(L.tabs)[MULTI ? uint32_t(dp.tabmap >> (8 * phase)) & 0xFFu
+                                                   : 0u];
 }
 
 // ---- packed 16-bit arithmetic (predictors wrap mod 2^16) ---------------------

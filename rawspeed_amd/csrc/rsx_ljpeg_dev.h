@@ -126,7 +126,9 @@ struct LjStreamDev {
   uint8_t no_vertical; // every stream row starts from init_pred (no seed chain)
   uint8_t direct;      // != 0: fused decode + reconstruction (rsx_ljpeg_direct.hip); the
                        //       value is the number of interleaved components (1, 2 or 4)
-  uint8_t pad8[2];
+  uint8_t sync_lut11;  // its table has no search path past the LUT (an explicit 11-bit table):
+                       // the synchronisation kernels must not use their 10-bit LUT for it
+  uint8_t pad8[1];
   uint32_t rows;
   uint32_t row_samples;
   uint32_t first_row; // global stream-row index
