@@ -319,6 +319,73 @@ __device__ __forceinline__ uint32_t lj_step(const Lds& L, const DecodeParams& dp
 // the hot loop).  With one shared table the component phase does not influence the
 // parse, so it is left out of the state (it would never self-synchronise); with
 // several tables it is part of what has to match.
+// The same loop for the common case -- one table, plain symbols, the reversed image --
+// with the address arithmetic spelled out (this loop is what the synchronisation kernel
+// IS: 100 % of the VALU issue slots are busy while it runs, so every instruction per
+// symbol is 1.4 % of the kernel).  LDS addresses are integers: the window's row comes out
+// of one multiply-add, the LUT entry's address out of an OR (the table sits at LDS
+// address 0), the symbol count is an add-with-carry on the "good" mask, and the phase
+// of a difference is its symbol's number.
+template <int NS, int REVBW, typename TB>
+__device__ __forceinline__ void lj_decode_span_single(const Lds& L, const DecodeParams& dp,
+                                                      int col, uint32_t start,
+                                                      uint32_t end_bits, uint32_t& exit,
+                                                      uint32_t& count, uint2* sums,
+                                                      bool enabled, uint32_t pos_override) {
+  static_assert(REVBW != 0, "the reversed image");
+  constexpr int LB = TabBits<TB>::value;
+  uint32_t pos = pos_override != 0xFFFFFFFFu ? pos_override : (start & ST_OFF_MASK);
+  bool ok = !(start & ST_ERR);
+  if (!ok || !enabled)
+    end_bits = 0; // lane takes no steps
+  const TB& tb = *reinterpret_cast<const TB*>(L.tabs);
+  const uint32_t vrow = lds_addr(&L.B[(REVBW - 2) * LJ_T + col]); // dword 1 of the slot
+  const uint32_t lut = lds_addr(tb.lut);
+  uint32_t n = 0, a0 = 0, a1 = 0;
+  bool live = pos < end_bits;
+  if (__any(live)) {
+    do {
+      // dword wi + 1 lies wi rows below `vrow`, dword wi one row further down
+      const uint32_t ad = vrow + uint32_t(__mul24(int(pos >> 5), -4 * LJ_T));
+      const uint32_t d1 = *(lds_u32p)(ad), d0 = *(lds_u32p)(ad + 4u * LJ_T);
+      const uint32_t w = uint32_t((((uint64_t(d0) << 32) | d1) << (pos & 31u)) >> 32);
+      uint32_t e = *(lds_u16p)(lut | ((w >> (31 - LB)) & ((2u << LB) - 2u)));
+      if (dp.long_codes && __builtin_expect(__any(live && (e & 31u) == 0u), 0)) {
+        if (live && (e & 31u) == 0u)
+          e = lj_slow_entry(w, &tb);
+      }
+      const bool good = live && e != 0u;
+      if (NS) {
+        const uint32_t dx = lj_extend(w, e);
+        const uint32_t d = good ? dx : 0u;
+        const uint32_t t = d << ((n << 4) & 31u); // (phase = symbol number: 16 * (n & 1))
+        if (NS <= 2) {
+          a0 = NS == 1 ? a0 + d : pk_add(a0, t);
+        } else {
+          a0 = pk_add(a0, (n & 2u) ? 0u : t);
+          a1 = pk_add(a1, (n & 2u) ? t : 0u);
+        }
+      }
+      pos += good ? (e >> 10) : 0u;
+      n += good ? 1u : 0u;
+      if (live && !good) {
+        ok = false;
+        end_bits = 0;
+      }
+      live = pos < end_bits;
+    } while (__any(live));
+  }
+  if (!enabled)
+    return;
+  exit = ok ? (pos - end_bits) : ST_ERR;
+  count = n;
+  if (NS)
+    *sums = make_uint2(NS == 1 ? (a0 & 0xFFFFu) : a0, NS == 4 ? a1 : 0u);
+}
+
+#ifndef RSX_SPAN_GENERIC
+#define RSX_SPAN_GENERIC 0 // (experiments: 1 = the generic loop everywhere)
+#endif
 template <bool MULTI, int NS, bool PAIR, int REVBW, typename TB = TabLds>
 __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams& dp,
                                                int col, uint32_t start,
@@ -326,6 +393,11 @@ __device__ __forceinline__ void lj_decode_span(const Lds& L, const DecodeParams&
                                                uint32_t& count, uint2* sums,
                                                bool enabled = true,
                                                uint32_t pos_override = 0xFFFFFFFFu) {
+  if (!MULTI && !PAIR && REVBW != 0 && !RSX_SPAN_GENERIC) {
+    lj_decode_span_single<NS, REVBW ? REVBW : 1, TB>(L, dp, col, start, end_bits, exit, count,
+                                                     sums, enabled, pos_override);
+    return;
+  }
   // pos_override: start at an arbitrary bit position of the slot (warm-up)
   uint32_t pos = pos_override != 0xFFFFFFFFu ? pos_override : (start & ST_OFF_MASK);
   uint32_t phase = (start >> ST_PHASE_SHIFT) & 7u;
@@ -442,10 +514,9 @@ constexpr size_t lj_periodic_bytes() {
   return 2 * LJ_T * 4 + LJ_T + PER_CLASSES * 4 + PER_CLASSES * 32 * sizeof(PeriodicEntry) + 16;
 }
 
-template <typename TB>
-__device__ __forceinline__ PeriodicLds carve_periodic(const Lds& L, int n_tables) {
+__device__ __forceinline__ PeriodicLds carve_periodic(const Lds& L) {
   PeriodicLds p;
-  p.hash = reinterpret_cast<uint32_t*>(reinterpret_cast<TB*>(L.tabs) + n_tables);
+  p.hash = reinterpret_cast<uint32_t*>(sync_lds_end(L));
   p.members = p.hash + LJ_T;
   p.rep_of = p.members + LJ_T;
   p.tbl = reinterpret_cast<PeriodicEntry*>(p.rep_of + PER_CLASSES);
@@ -553,7 +624,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   constexpr int BWK = PAIR ? LJ_BW_SYNC_PAIR : LJ_BW_SYNC;
   constexpr int N = NS ? NS : 1;
   using TB = SyncTable<MULTI, PAIR>;
-  const Lds L = carve_sync(smem, BWK, NS);
+  const Lds L = carve_sync(smem, BWK, NS, size_t(MULTI ? S.n_tables : 1u) * sizeof(TB));
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
 
@@ -629,7 +700,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   const int first_chained = STITCH ? 2 : 1;
   uint32_t rounds = 0;
   bool gave_up = false, classes_ready = false;
-  const PeriodicLds PL = carve_periodic<TB>(L, MULTI ? int(S.n_tables) : 1);
+  const PeriodicLds PL = carve_periodic(L);
   while (true) {
     if (STITCH && !MULTI && !PAIR && classes_ready) {
       // slots with identical content: their exits come from the class tables

@@ -104,16 +104,30 @@ static_assert(lj_sync_lds_bytes<TabLds10>(1, LJ_BW_SYNC, 2) <= 18 * 1280,
 static_assert(lj_sync_lds_words(LJ_BW_SYNC, 0) % 4 == 0 && lj_sync_lds_words(LJ_BW_SYNC_PAIR, 4) % 4 == 0,
               "the tables start on a 16-byte boundary");
 
-__device__ __forceinline__ Lds carve_sync(uint8_t* smem, int bw, int ns) {
+// (the tables come FIRST: the single table's LUT then starts at LDS address 0, and the
+// lookup forms its address with an OR instead of an add)
+__device__ __forceinline__ Lds carve_sync(uint8_t* smem, int bw, int ns, size_t table_bytes) {
   Lds l{};
-  l.B = reinterpret_cast<uint32_t*>(smem);
+  l.tabs = reinterpret_cast<TabLds*>(smem);
+  l.B = reinterpret_cast<uint32_t*>(smem + table_bytes);
   l.rec = l.B + bw * LJ_T;
   l.ob = reinterpret_cast<uint16_t*>(l.rec + LJ_T);
   l.sm = reinterpret_cast<uint32_t*>(l.ob + LJ_T);
   l.list = reinterpret_cast<uint16_t*>(l.sm + lj_sync_sm_words(ns));
   l.misc = reinterpret_cast<uint32_t*>(l.list + LJ_T);
-  l.tabs = reinterpret_cast<TabLds*>(l.misc + 16);
   return l;
+}
+// the byte after the layout (the stitch kernels' class tables)
+__device__ __forceinline__ uint8_t* sync_lds_end(const Lds& l) {
+  return reinterpret_cast<uint8_t*>(l.misc + 16);
+}
+
+// LDS addresses as integers (the dynamic LDS of these kernels starts at address 0)
+typedef const __attribute__((address_space(3))) uint32_t* lds_u32p;
+typedef const __attribute__((address_space(3))) uint16_t* lds_u16p;
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return uint32_t(reinterpret_cast<uintptr_t>(
+      (const __attribute__((address_space(3))) void*)(p)));
 }
 // the difference sums of slot j (N components)
 template <int NS>
