@@ -460,9 +460,11 @@ __global__ __launch_bounds__(LJ_T, RSX_K4D_MIN_WAVES) void lj_decode_direct_kern
   if (a.results[s].flags & FL_NEED_LEGACY)
     return;
   Lds L{};
-  L.B = reinterpret_cast<uint32_t*>(smem);
+  // (the tables first: a single table's LUT then starts at LDS address 0 and its entries
+  // are addressed with an OR; the image lies with its dword rows reversed, see lj_window)
+  L.tabs = reinterpret_cast<TabLds*>(smem);
+  L.B = reinterpret_cast<uint32_t*>(smem + size_t(MULTI ? S.n_tables : 1u) * sizeof(TabLds));
   L.misc = L.B + LJ_BW_DEC * LJ_T;
-  L.tabs = reinterpret_cast<TabLds*>(L.misc + 16);
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
   const uint64_t needed = S.needed;
@@ -502,8 +504,8 @@ __global__ __launch_bounds__(LJ_T, RSX_K4D_MIN_WAVES) void lj_decode_direct_kern
 #pragma unroll
     for (int h = 0; h < n_it; ++h) {
       const int i = h * LJ_T + j;
-      if (i < n4)
-        dst[i] = t[h];
+      if (i < n4) // uint4 i = dwords 4 * (i % 64) .. of row i / 64 -> row BW - 1 - i / 64
+        dst[(LJ_BW_DEC - 1 - (i >> 6)) * (LJ_T / 4) + (i & 63)] = t[h];
     }
   }
   DecodeParams dp = lj_params(S);
@@ -567,17 +569,31 @@ __global__ __launch_bounds__(LJ_T, RSX_K4D_MIN_WAVES) void lj_decode_direct_kern
     oc = lj_locate<N>(sx, i0, rot);
   }
   uint32_t phase = (my_start >> ST_PHASE_SHIFT) & 7u;
-  BitReader<LJ_BW_DEC> r;
-  r.open(L.B, j, my_start & ST_OFF_MASK);
+  // Window reader on integer LDS addresses (this kernel is bound by VALU issue, too: the
+  // register bit reader it had keeps the window load off the critical path but costs 11
+  // instructions more per symbol).
+  uint32_t pos = my_start & ST_OFF_MASK;
+  const uint32_t vrow = lds_addr(&L.B[(LJ_BW_DEC - 2) * LJ_T + j]); // row of dword 1
+  const uint32_t lut0 = lds_addr(L.tabs[0].lut);
   auto decode_group = [&](uint32_t g, uint32_t (&p)[4]) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const bool live = 8 * g + q < remaining;
-      const uint32_t w = r.head();
-      uint32_t d;
-      const uint32_t e =
-          lj_entry_diff(w, lj_table<MULTI>(L, dp, phase), live, dp.long_codes, &d);
-      r.advance(L.B, j, live ? (e >> 10) : 0u);
+      const uint32_t ad = vrow + uint32_t(__mul24(int(pos >> 5), -4 * LJ_T));
+      const uint32_t d1 = *(lds_u32p)(ad), d0 = *(lds_u32p)(ad + 4u * LJ_T);
+      const uint32_t w = uint32_t((((uint64_t(d0) << 32) | d1) << (pos & 31u)) >> 32);
+      uint32_t d, e;
+      if (MULTI || RSX_LUT_DIFF) {
+        e = lj_entry_diff(w, lj_table<MULTI>(L, dp, phase), live, dp.long_codes, &d);
+      } else {
+        e = *(lds_u16p)(lut0 | ((w >> (31 - LUT_BITS)) & ((2u << LUT_BITS) - 2u)));
+        if (dp.long_codes && __builtin_expect(__any(live && (e & 31u) == 0u), 0)) {
+          if (live && (e & 31u) == 0u)
+            e = lj_slow_entry(w, &L.tabs[0]);
+        }
+        d = lj_extend(w, e);
+      }
+      pos += live ? (e >> 10) : 0u;
       if (MULTI)
         phase = live ? ((phase + 1 == dp.period) ? 0u : phase + 1) : phase;
       const uint32_t diff = live ? d : 0u;
@@ -706,7 +722,7 @@ __global__ __launch_bounds__(LJ_T, RSX_K4D_MIN_WAVES) void lj_decode_direct_kern
     const uint32_t target = uint32_t(needed - 1 - first);
     uint32_t p2 = my_start & ST_OFF_MASK, ph2 = (my_start >> ST_PHASE_SHIFT) & 7u;
     for (uint32_t t = 0; t < target; ++t) {
-      const uint32_t w = lj_window(L.B, j, p2);
+      const uint32_t w = lj_window<LJ_BW_DEC>(L.B, j, p2);
       const TabLds& tb = lj_table<MULTI>(L, dp, ph2);
       uint32_t e = lj_lut16(tb, w >> (32 - LUT_BITS));
       if ((e & 31u) == 0u)
