@@ -22,7 +22,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   cp $(find /tmp/p_$c -name "*counter_collection.csv" | head -1) $OUT/unpack_pmc_$c.csv
 done
 python $REPO/scripts/pmc_to_json.py $OUT > /dev/null
-for leg in cfg3 cfg4 clipped; do
+for leg in cfg3 cfg4; do
   rm -rf /tmp/p_$leg
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$leg -- \
     python $REPO/bench_ljpeg.py --only $leg --steps 10 > $OUT/${leg}_under_rocprof.json 2> /dev/null
