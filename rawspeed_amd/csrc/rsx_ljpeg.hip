@@ -652,6 +652,9 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   lj_load_image<BWK, true>(L, a, b, j); // ends with a barrier (tables complete, too)
   const uint32_t own_bits = L.ob[j];
   DecodeParams dp = lj_params(S);
+  if (MULTI && S.n_tables == 1)
+    dp.period = 1; // (here for its 11-bit LUT: the phase does not influence the parse and
+                   // must stay out of the state -- it would never self-synchronise)
   dp.long_codes = lj_long_codes<TB>(L, S.n_tables);
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1); // j >= 1
 
@@ -700,9 +703,12 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   const int first_chained = STITCH ? 2 : 1;
   uint32_t rounds = 0;
   bool gave_up = false, classes_ready = false;
+  // the class tables of the stitch pass are per entry OFFSET: single-table streams only
+  // (also the ones the multi-table instantiation takes for their 11-bit LUT: their phase stays 0)
+  const bool classes_ok = STITCH && !PAIR && (!MULTI || S.n_tables == 1);
   const PeriodicLds PL = carve_periodic(L);
   while (true) {
-    if (STITCH && !MULTI && !PAIR && classes_ready) {
+    if (classes_ok && classes_ready) {
       // slots with identical content: their exits come from the class tables
       if (j == 0)
         lj_periodic_walk<NS>(L, PL, true_start);
@@ -755,7 +761,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
       break;
     }
     // (a round earlier for a workgroup that has given up before: it is chaining)
-    if (STITCH && !MULTI && !PAIR && !classes_ready &&
+    if (classes_ok && !classes_ready &&
         rounds == (unresolved ? 2u : LJ_STITCH_CLASS_ROUND)) {
       lj_periodic_build<NS, BWK, TB>(L, PL, dp, j); // (workgroup-uniform; has barriers)
       classes_ready = true;
@@ -810,7 +816,7 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   // were recorded).  lj_pchain_kernel strings these together so that a constant region
   // that spans many workgroups is settled by one more stitch pass, not one per workgroup.
   bool tf_written = false;
-  if (STITCH && !MULTI && !PAIR && classes_ready) {
+  if (classes_ok && classes_ready) {
     if (j < 32) {
       uint32_t state = uint32_t(j);
       for (int q = 1; q < LJ_T && state != 0xFFFFu; ++q) {
