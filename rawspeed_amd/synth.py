@@ -179,6 +179,17 @@ def ljpeg_container(stream_rows, n_comp, prec, comp_slot, slot_tables,
     return blob, nh, len(scan), bits
 
 
+def ljpeg_header(prec, frame_w, frame_h, n_comp, comp_slot, slot_tables):
+    """SOI, SOF3, DHT(s), SOS of a lossless-JPEG container (no scan data)."""
+    keep = _table_ptrs(slot_tables)
+    _, _, cp, vp, nv = keep
+    hdr = np.empty(1024, dtype=np.uint8)
+    cs = (C.c_int * n_comp)(*comp_slot)
+    nh = lib().rsx_synth_ljpeg_header(hdr.ctypes.data, prec, frame_w, frame_h, n_comp, cs,
+                                      len(slot_tables), cp, vp, nv, 0, None, None)
+    return hdr[:nh].copy()
+
+
 # NikonDecompressor::nikon_tree (decompressors/NikonDecompressor.cpp:47-66): the
 # six Huffman trees of the NEF format, (16 counts, values).  Trees 1 and 4
 # ("after split") carry len | shl << 4 values decoded by NikonLASDecompressor.

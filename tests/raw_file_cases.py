@@ -110,7 +110,63 @@ def cr2_three_slices():
     return rawfiles.cr2_file(W, H, blob, (2, 672, 672)), src
 
 
+def pef_compressed():
+    """PefDecoder -> PentaxDecompressor with the makernote's Huffman table."""
+    import nikon_cases as N
+    rng = np.random.default_rng(510)
+    W, H = 1200, 300
+    tree = synth.PENTAX_TREE
+    src = N.smooth15(rng, H, W, maxv=4095, sigma=6.0)
+    data, _ = N.pentax_encode(src, tree)
+    data = np.concatenate([data, np.zeros(8, np.uint8)])
+    return rawfiles.pef_file(W, H, data, N.pentax_metadata(tree)), src
+
+
+def _nef(seed, unc):
+    import golden_cases as G
+    import nikon_cases as N
+    rng = np.random.default_rng(seed)
+    W, H, bits = 1200, 300, 14
+    p_up = [int(x) for x in rng.integers(1500, 2500, size=4)]
+    pts = [] if unc else list(G.nikon_curve_points(300, 4000))
+    meta = N.metadata(70, 0, p_up, pts, 0, pad_to=3000)
+    P = N.parse(meta, bits, H)
+    src = N.smooth15(rng, H, W, maxv=(1 << bits) - 1)
+    pu = P["p_up"]
+    data, _ = synth.nikon_encode(src, [pu[0][0], pu[0][1], pu[1][0], pu[1][1]],
+                                 synth.NIKON_TREE[P["huff_select"]])
+    data = np.concatenate([data, np.zeros(8, np.uint8)])
+    return rawfiles.nef_file(W, H, bits, data, meta), src
+
+
+def nef_compressed_uncorrected():
+    """NefDecoder -> NikonDecompressor, uncorrectedRawValues: the image is the source."""
+    return _nef(511, True)
+
+
+def nef_compressed_curve():
+    """... with the linearisation curve and its dither: no closed-form expectation here,
+    the two builds of the reference must agree (the class-level tests pin the values)."""
+    blob, _ = _nef(512, False)
+    return blob, None
+
+
+def threefr_ljpeg():
+    """ThreefrDecoder -> HasselbladLJpegDecoder -> HasselbladDecompressor."""
+    rng = np.random.default_rng(513)
+    W, H = 1024, 300
+    src = C.smooth_image(rng, H, W, 14)
+    scan, _ = synth.hasselblad_encode(src, 0x2000, C.FULL17)
+    hdr = synth.ljpeg_header(14, W, H, 1, [0], [C.FULL17])
+    blob = np.concatenate([hdr, scan, np.array([0xFF, 0xD9], np.uint8), np.zeros(16, np.uint8)])
+    return rawfiles.threefr_file(W, H, blob), src
+
+
+# decodeRaw() options of a case (default: corrected values)
+UNCORRECTED = {"nef_compressed_uncorrected"}
+
 CASES = {f.__name__: f for f in (
     dng_ljpeg_tiles, dng_ljpeg_tiles_dri, dng_ljpeg_strips, dng_uncompressed_12bit_strips,
     dng_uncompressed_16bit_tiles, arw_ljpeg_tiles, arw_uncompressed, arw1_compressed,
-    cr2_three_slices)}
+    cr2_three_slices, pef_compressed, nef_compressed_uncorrected, nef_compressed_curve,
+    threefr_ljpeg)}

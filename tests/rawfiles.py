@@ -6,6 +6,9 @@ reference (unmodified and GPU-backed).  Only the tags those decoders read are wr
       (decoders/DngDecoder.cpp:448-534, :361-446, :303-359, :230-278)
   ArwDecoder::decodeRawInternal / DecodeLJpeg / DecodeUncompressed
       (decoders/ArwDecoder.cpp:166-260, :296-411)
+  Cr2Decoder::decodeNewFormat (Cr2Decoder.cpp:125-209), NefDecoder::decodeRawInternal
+      (NefDecoder.cpp:73-138), PefDecoder::decodeRawInternal (PefDecoder.cpp:58-117),
+      ThreefrDecoder::decodeRawInternal (ThreefrDecoder.cpp:56-84)
   TiffParser::parse, TiffIFD (parsers/TiffParser.cpp:52-78, tiff/TiffIFD.cpp:46-120)
 """
 import struct
@@ -13,8 +16,8 @@ import struct
 import numpy as np
 
 # TIFF field types
-BYTE, ASCII, SHORT, LONG, RATIONAL = 1, 2, 3, 4, 5
-_SIZE = {BYTE: 1, ASCII: 1, SHORT: 2, LONG: 4, RATIONAL: 8}
+BYTE, ASCII, SHORT, LONG, RATIONAL, UNDEFINED = 1, 2, 3, 4, 5, 7
+_SIZE = {BYTE: 1, ASCII: 1, SHORT: 2, LONG: 4, RATIONAL: 8, UNDEFINED: 1}
 
 # tags (tiff/TiffTag.h)
 NEWSUBFILETYPE, IMAGEWIDTH, IMAGELENGTH, BITSPERSAMPLE, COMPRESSION = 254, 256, 257, 258, 259
@@ -28,19 +31,19 @@ SONYRAWIMAGESIZE, SONYCURVE = 0x7038, 0x7010
 CANON_CAMERA_SETTINGS, CANON_SENSOR_INFO, CANONCR2SLICE = 0x0001, 0x00E0, 0xC640
 
 
-def _payload(typ, values):
+def _payload(typ, values, en="<"):
     if typ == ASCII:
         b = values.encode() + b"\0"
         return b, len(b)
-    if typ == BYTE:
+    if typ in (BYTE, UNDEFINED):
         return bytes(values), len(values)
     if typ == SHORT:
-        return struct.pack("<%dH" % len(values), *values), len(values)
+        return struct.pack(en + "%dH" % len(values), *values), len(values)
     if typ == LONG:
-        return struct.pack("<%dI" % len(values), *values), len(values)
+        return struct.pack(en + "%dI" % len(values), *values), len(values)
     if typ == RATIONAL:
         flat = [x for pair in values for x in pair]
-        return struct.pack("<%dI" % len(flat), *flat), len(values)
+        return struct.pack(en + "%dI" % len(flat), *flat), len(values)
     raise ValueError(typ)
 
 
@@ -55,7 +58,7 @@ class Ifd:
         self.next = None  # the IFD this one chains to ("next IFD" pointer)
 
     def add(self, tag, typ, values):
-        if typ != ASCII and not isinstance(values, (list, tuple, bytes)):
+        if typ != ASCII and not isinstance(values, (list, tuple, bytes, bytearray)):
             values = [values]
         self.entries[tag] = (typ, values)
         return self
@@ -70,9 +73,11 @@ class Ifd:
         return self
 
 
-def tiff_file(root, gap=0):
-    """Serialise little-endian: header, IFDs (depth first) with their out-of-line
-    values, then the blobs (each followed by `gap` bytes that belong to nobody)."""
+def tiff_file(root, gap=0, big=False):
+    """Serialise (little-endian, or big-endian like the files of Nikon and Pentax): header,
+    IFDs (depth first) with their out-of-line values, then the blobs (each followed by
+    `gap` bytes that belong to nobody)."""
+    en = ">" if big else "<"
     ifds = []
 
     def walk(i):
@@ -99,7 +104,7 @@ def tiff_file(root, gap=0):
     def ifd_bytes(e):
         n = 2 + 12 * len(e) + 4
         for typ, values in e.values():
-            p, _ = _payload(typ, values)
+            p, _ = _payload(typ, values, en)
             if len(p) > 4:
                 n += len(p) + (len(p) & 1)
         return n
@@ -120,7 +125,7 @@ def tiff_file(root, gap=0):
     total = pos
 
     out = bytearray(total)
-    out[0:8] = b"II" + struct.pack("<HI", 42, 8)
+    out[0:8] = (b"MM" if big else b"II") + struct.pack(en + "HI", 42, 8)
     index = {id(i): k for k, i in enumerate(ifds)}
     for k, (i, e) in enumerate(zip(ifds, tables)):
         if i.blobs:
@@ -128,21 +133,21 @@ def tiff_file(root, gap=0):
         if i.subs:
             e[SUBIFDS] = (LONG, [ifd_pos[index[id(s)]] for s in i.subs])
         p = ifd_pos[k]
-        struct.pack_into("<H", out, p, len(e))
+        struct.pack_into(en + "H", out, p, len(e))
         q = p + 2
         extra = p + 2 + 12 * len(e) + 4
         for tag in sorted(e):
             typ, values = e[tag]
-            data, count = _payload(typ, values)
-            struct.pack_into("<HHI", out, q, tag, typ, count)
+            data, count = _payload(typ, values, en)
+            struct.pack_into(en + "HHI", out, q, tag, typ, count)
             if len(data) <= 4:
                 out[q + 8:q + 8 + len(data)] = data
             else:
-                struct.pack_into("<I", out, q + 8, extra)
+                struct.pack_into(en + "I", out, q + 8, extra)
                 out[extra:extra + len(data)] = data
                 extra += len(data) + (len(data) & 1)
             q += 12
-        struct.pack_into("<I", out, q, ifd_pos[index[id(i.next)]] if i.next is not None else 0)
+        struct.pack_into(en + "I", out, q, ifd_pos[index[id(i.next)]] if i.next is not None else 0)
         if i.blobs:
             for off, b in zip(blob_pos[k], i.blobs[2]):
                 out[off:off + len(b)] = b
@@ -252,3 +257,54 @@ def cr2_file(width, height, blob, slices):
     i3.add_blobs(STRIPOFFSETS, STRIPBYTECOUNTS, [blob])
     i0.next, i1.next, i2.next = i1, i2, i3
     return tiff_file(i0)
+
+
+def pef_file(width, height, data, meta):
+    """Pentax PEF, compression 65535 (PefDecoder.cpp:58-117): one strip, and the Huffman
+    table of the makernote (tag 0x220, type UNDEFINED), found recursively."""
+    raw = Ifd()
+    raw.add(IMAGEWIDTH, LONG, width).add(IMAGELENGTH, LONG, height)
+    raw.add(COMPRESSION, LONG, 65535)
+    raw.add(PHOTOMETRIC, SHORT, 32803)
+    raw.add(0x220, UNDEFINED, bytes(np.asarray(meta, np.uint8).tobytes()))
+    raw.add_blobs(STRIPOFFSETS, STRIPBYTECOUNTS, [data])
+    root = Ifd()
+    root.add(MAKE, ASCII, "PENTAX").add(MODEL, ASCII, "PENTAX RSX")
+    root.add_sub(raw)
+    return tiff_file(root, big=True)  # (the table's fields are read in the file's byte order)
+
+
+def nef_file(width, height, bps, data, meta):
+    """Nikon NEF, compression 34713 (NefDecoder.cpp:73-138): the raw IFD is the one with
+    CFAPATTERN, one strip whose size is not that of an uncompressed image, the
+    linearisation blob is tag 0x96 (makernote; found recursively)."""
+    raw = Ifd()
+    raw.add(IMAGEWIDTH, LONG, width).add(IMAGELENGTH, LONG, height)
+    raw.add(BITSPERSAMPLE, SHORT, bps)
+    raw.add(COMPRESSION, LONG, 34713)
+    raw.add(PHOTOMETRIC, SHORT, 32803)
+    raw.add(CFAREPEATPATTERNDIM, SHORT, [2, 2])
+    raw.add(CFAPATTERN, BYTE, [0, 1, 1, 2])
+    raw.add(0x96, UNDEFINED, bytes(np.asarray(meta, np.uint8).tobytes()))
+    raw.add_blobs(STRIPOFFSETS, STRIPBYTECOUNTS, [data])
+    root = Ifd()
+    root.add(MAKE, ASCII, "NIKON CORPORATION").add(MODEL, ASCII, "NIKON RSX")
+    root.add_sub(raw)
+    return tiff_file(root, big=True)  # (the blob's fields are read in the file's byte order)
+
+
+def threefr_file(width, height, blob):
+    """Hasselblad 3FR, compression 7 (ThreefrDecoder.cpp:56-84): the raw IFD is the SECOND
+    one that has STRIPOFFSETS; its strip is an LJPEG container whose scan holds the
+    pair-coded Hasselblad stream."""
+    thumb = Ifd()
+    thumb.add(IMAGEWIDTH, LONG, 8).add(IMAGELENGTH, LONG, 8)
+    thumb.add_blobs(STRIPOFFSETS, STRIPBYTECOUNTS, [np.zeros(64, np.uint8)])
+    raw = Ifd()
+    raw.add(IMAGEWIDTH, LONG, width).add(IMAGELENGTH, LONG, height)
+    raw.add(COMPRESSION, SHORT, 7)
+    raw.add_blobs(STRIPOFFSETS, STRIPBYTECOUNTS, [blob])
+    root = Ifd()
+    root.add(MAKE, ASCII, "Hasselblad").add(MODEL, ASCII, "RSX")
+    root.add_sub(thumb).add_sub(raw)
+    return tiff_file(root)
