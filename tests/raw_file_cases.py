@@ -162,6 +162,17 @@ def threefr_ljpeg():
     return rawfiles.threefr_file(W, H, blob), src
 
 
+def srw_samsung_v1():
+    """SrwDecoder -> SamsungV1Decompressor (compression 32772)."""
+    import nikon_cases as N
+    rng = np.random.default_rng(514)
+    W, H = 1024, 300
+    src = N.smooth15(rng, H, W, maxv=4095, sigma=6.0)
+    data, _ = synth.prefix_encode(src, [0, 0, 0, 0], synth.SAMSUNG_V1_TAB)
+    data = np.concatenate([data, np.zeros(8, np.uint8)])
+    return rawfiles.srw_v1_file(W, H, data), src
+
+
 # decodeRaw() options of a case (default: corrected values)
 UNCORRECTED = {"nef_compressed_uncorrected"}
 
@@ -169,4 +180,4 @@ CASES = {f.__name__: f for f in (
     dng_ljpeg_tiles, dng_ljpeg_tiles_dri, dng_ljpeg_strips, dng_uncompressed_12bit_strips,
     dng_uncompressed_16bit_tiles, arw_ljpeg_tiles, arw_uncompressed, arw1_compressed,
     cr2_three_slices, pef_compressed, nef_compressed_uncorrected, nef_compressed_curve,
-    threefr_ljpeg)}
+    threefr_ljpeg, srw_samsung_v1)}

@@ -8,7 +8,7 @@ reference (unmodified and GPU-backed).  Only the tags those decoders read are wr
       (decoders/ArwDecoder.cpp:166-260, :296-411)
   Cr2Decoder::decodeNewFormat (Cr2Decoder.cpp:125-209), NefDecoder::decodeRawInternal
       (NefDecoder.cpp:73-138), PefDecoder::decodeRawInternal (PefDecoder.cpp:58-117),
-      ThreefrDecoder::decodeRawInternal (ThreefrDecoder.cpp:56-84)
+      ThreefrDecoder::decodeRawInternal (ThreefrDecoder.cpp:56-84), SrwDecoder (SrwDecoder.cpp:56-120)
   TiffParser::parse, TiffIFD (parsers/TiffParser.cpp:52-78, tiff/TiffIFD.cpp:46-120)
 """
 import struct
@@ -307,4 +307,17 @@ def threefr_file(width, height, blob):
     root = Ifd()
     root.add(MAKE, ASCII, "Hasselblad").add(MODEL, ASCII, "RSX")
     root.add_sub(thumb).add_sub(raw)
+    return tiff_file(root)
+
+
+def srw_v1_file(width, height, data, bits=12):
+    """Samsung SRW, compression 32772 (SrwDecoder.cpp:56-120): SamsungV1Decompressor."""
+    raw = Ifd()
+    raw.add(IMAGEWIDTH, LONG, width).add(IMAGELENGTH, LONG, height)
+    raw.add(BITSPERSAMPLE, SHORT, bits)
+    raw.add(COMPRESSION, LONG, 32772)
+    raw.add_blobs(STRIPOFFSETS, STRIPBYTECOUNTS, [data])
+    root = Ifd()
+    root.add(MAKE, ASCII, "SAMSUNG").add(MODEL, ASCII, "RSX")
+    root.add_sub(raw)
     return tiff_file(root)

@@ -36,6 +36,7 @@ EXPECT = {
     "nef_compressed_uncorrected": (1, 1),
     "nef_compressed_curve": (1, 1),
     "threefr_ljpeg": (1, 1),
+    "srw_samsung_v1": (1, 1),
 }
 
 
