@@ -173,6 +173,37 @@ def srw_samsung_v1():
     return rawfiles.srw_v1_file(W, H, data), src
 
 
+def _cr2_sraw(seed, ysf):
+    rng = np.random.default_rng(seed)
+    groups = (3, 216, 160)
+    gs, dim_x, dim_y = 2 + 2 * ysf, 2 * 216 + 160, 300
+    # luma mid-range, chroma near its zero (16384): the RGB values stay inside 16 bits
+    img = C.smooth_image(rng, dim_y, dim_x * gs, 13).astype(np.int64) + 2000
+    chroma = np.zeros(dim_x * gs, bool)
+    chroma[gs - 2::gs] = chroma[gs - 1::gs] = True
+    img[:, chroma] = 16384 + (img[:, chroma] - 6000) // 16
+    d, data, src, _, rows = C.make_cr2_sraw_case(rng, ysf, groups, dim_y, with_rows=True,
+                                                 img=img.astype(np.uint16))
+    blob, _, _, _ = synth.ljpeg_container(
+        rows, 3, 14, [0, 0, 0], [C.NIKON], frame_wh=(d.frame_w, d.frame_h),
+        samp=[(2, ysf), (1, 1), (1, 1)], pattern=synth.SRAW_PATTERN[2 + 2 * ysf])
+    unit = 4 if ysf == 1 else 6
+    h, w = src.shape                      # samples per row = groups * (2 + 2 ysf)
+    sensor_w = w // (2 + 2 * ysf) * 2     # dim.x = sensor_w / 2 * (2 + 2 ysf)
+    return rawfiles.cr2_sraw_file(sensor_w, h * ysf, blob,
+                                  (2, groups[1] * unit, groups[2] * unit), ysf), None
+
+
+def cr2_sraw_2x1():
+    """Cr2Decoder sRaw 4:2:2: Cr2Decompressor<3,2,1>, then Cr2sRawInterpolator -> RGB."""
+    return _cr2_sraw(515, 1)
+
+
+def cr2_sraw_2x2():
+    """... 4:2:0: Cr2Decompressor<3,2,2> and the two-row interpolation."""
+    return _cr2_sraw(516, 2)
+
+
 # decodeRaw() options of a case (default: corrected values)
 UNCORRECTED = {"nef_compressed_uncorrected"}
 
@@ -180,4 +211,4 @@ CASES = {f.__name__: f for f in (
     dng_ljpeg_tiles, dng_ljpeg_tiles_dri, dng_ljpeg_strips, dng_uncompressed_12bit_strips,
     dng_uncompressed_16bit_tiles, arw_ljpeg_tiles, arw_uncompressed, arw1_compressed,
     cr2_three_slices, pef_compressed, nef_compressed_uncorrected, nef_compressed_curve,
-    threefr_ljpeg, srw_samsung_v1)}
+    threefr_ljpeg, srw_samsung_v1, cr2_sraw_2x1, cr2_sraw_2x2)}

@@ -29,6 +29,7 @@ DNGVERSION, DNGBACKWARDVERSION, UNIQUECAMERAMODEL = 50706, 50707, 50708
 ACTIVEAREA = 50829
 SONYRAWIMAGESIZE, SONYCURVE = 0x7038, 0x7010
 CANON_CAMERA_SETTINGS, CANON_SENSOR_INFO, CANONCR2SLICE = 0x0001, 0x00E0, 0xC640
+CANON_SRAWTYPE, CANONCOLORDATA = 0xC6C5, 0x4001
 
 
 def _payload(typ, values, en="<"):
@@ -237,6 +238,32 @@ def arw1_file(width, height, packed, curve_points=(0, 0, 0, 0)):
     root.add(MAKE, ASCII, "SONY").add(MODEL, ASCII, "DSLR-RSX")
     root.add_sub(raw)
     return tiff_file(root)
+
+
+def cr2_sraw_file(sensor_w, sensor_h, blob, slices, ysf, coeffs=(1900, 1024, 1024, 1500)):
+    """A Canon sRaw CR2: SRAWType 4 in the fourth IFD, SRAWQuality (CameraSettings[46]) 1 =
+    2x2 or 2 = 2x1 subsampling (Cr2Decoder.cpp:511-541), and the white-balance block the
+    sRaw interpolation takes its three coefficients from (ColorData[78..81], :563-576).
+    After the decode Cr2Decoder runs Cr2sRawInterpolator (version 1, hue 0 without a
+    camera database / model id)."""
+    i0 = Ifd()
+    i0.add(MAKE, ASCII, "Canon").add(MODEL, ASCII, "Canon EOS RSX")
+    cs = [0] * 48
+    cs[46] = 1 if ysf == 2 else 2
+    i0.add(CANON_CAMERA_SETTINGS, SHORT, cs)
+    i0.add(CANON_SENSOR_INFO, SHORT, [0, sensor_w, sensor_h, 0, 0, 0, 0, 0])
+    cd = [0] * 90
+    cd[78:82] = list(coeffs)
+    i0.add(CANONCOLORDATA, SHORT, cd)
+    i1 = Ifd().add(IMAGEWIDTH, LONG, 160)
+    i2 = Ifd().add(IMAGEWIDTH, LONG, 320)
+    i3 = Ifd()
+    i3.add(COMPRESSION, SHORT, 6)
+    i3.add(CANONCR2SLICE, SHORT, list(slices))
+    i3.add(CANON_SRAWTYPE, LONG, 4)
+    i3.add_blobs(STRIPOFFSETS, STRIPBYTECOUNTS, [blob])
+    i0.next, i1.next, i2.next = i1, i2, i3
+    return tiff_file(i0)
 
 
 def cr2_file(width, height, blob, slices):
