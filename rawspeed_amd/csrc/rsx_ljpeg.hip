@@ -346,7 +346,9 @@ __device__ __forceinline__ void lj_decode_span_single(const Lds& L, const Decode
   if (__any(live)) {
     do {
       // dword wi + 1 lies wi rows below `vrow`, dword wi one row further down
-      const uint32_t ad = vrow + uint32_t(__mul24(int(pos >> 5), -4 * LJ_T));
+      // (one multiply-add: left to itself the compiler makes a shift, an AND and a subtract of it)
+      uint32_t ad;
+      asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(ad) : "v"(pos >> 5), "s"(-4 * LJ_T), "v"(vrow));
       const uint32_t d1 = *(lds_u32p)(ad), d0 = *(lds_u32p)(ad + 4u * LJ_T);
       const uint32_t w = uint32_t((((uint64_t(d0) << 32) | d1) << (pos & 31u)) >> 32);
       uint32_t e = *(lds_u16p)(lut | ((w >> (31 - LB)) & ((2u << LB) - 2u)));
