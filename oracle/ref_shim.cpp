@@ -35,6 +35,7 @@
 #include "decompressors/NikonDecompressor.h"
 #include "decompressors/PentaxDecompressor.h"
 #include "decompressors/SamsungV1Decompressor.h"
+#include "decompressors/SamsungV2Decompressor.h"
 #include "decompressors/SonyArw1Decompressor.h"
 #include "decompressors/UncompressedDecompressor.h"
 #include "interpolators/Cr2sRawInterpolator.h"
@@ -442,6 +443,18 @@ int ref_samsung_v1_decompress(void* h, int bits, const uint8_t* in, size_t in_by
 }
 
 // SonyArw1Decompressor, as ArwDecoder drives it (ArwDecoder.cpp:133-136, :252-254)
+// SamsungV2Decompressor (not served by librsx yet; the oracle's restatement is pinned
+// against this): the strip as SrwDecoder hands it over, header included.
+int ref_samsung_v2_decompress(void* h, int bits, const uint8_t* in, size_t in_bytes) {
+  auto* r = static_cast<RefImage*>(h);
+  return guarded([&] {
+    const Buffer b(in, implicit_cast<Buffer::size_type>(in_bytes));
+    const ByteStream bs(DataBuffer(b, Endianness::little));
+    SamsungV2Decompressor d(r->img, bs, implicit_cast<unsigned>(bits));
+    d.decompress();
+  });
+}
+
 int ref_sony_arw1_decompress(void* h, const uint8_t* in, size_t in_bytes) {
   auto* r = static_cast<RefImage*>(h);
   return guarded([&] {

@@ -1769,3 +1769,207 @@ int oracle_hasselblad_decompress(const rsx_hasselblad_desc* d, const uint8_t* in
   return RSX_OK;
 }
 
+
+/* ======================================================================== */
+/* SamsungV2Decompressor (decompressors/SamsungV2Decompressor.cpp)           */
+/* Not yet served by the GPU library: the restatement is here  */
+/* so that the kernel of a later round has its checker; pinned against the   */
+/* reference build in tests/test_oracle_samsung_v2.py.                       */
+/* ======================================================================== */
+
+typedef struct sv2 {
+  const rsx_image* img;
+  int bits, width, height;
+  unsigned optflags; /* 1 SKIP, 2 MV, 4 QP  (:46-54) */
+  int init_val;
+  int motion, scale;
+  int mode[3][2]; /* diffBitsMode */
+} sv2;
+
+static uint16_t* sv2_px(const sv2* s, int row, int col) {
+  return (uint16_t*)((uint8_t*)s->img->data + (size_t)row * s->img->pitch_bytes) + col;
+}
+
+/* prepareBaselineValues :152-230 */
+static int sv2_baseline(sv2* s, bitreader* b, int row, int col, uint16_t base[16]) {
+  if (!(s->optflags & 4u) && (col % 64) == 0) { /* :159-164 */
+    static const int scalevals[3] = {0, -2, 2};
+    const uint32_t i = br_get(b, 2);
+    s->scale = i < 3 ? s->scale + scalevals[i] : (int)br_get(b, 12);
+  }
+  if (s->optflags & 2u) /* :167-170 */
+    s->motion = br_get(b, 1) ? 3 : 7;
+  else if (!br_get(b, 1))
+    s->motion = (int)br_get(b, 3);
+  if (b->err)
+    return b->err;
+  if ((row == 0 || row == 1) && s->motion != 7)
+    return RSX_ERR_INVALID_ARG; /* :172-173 */
+  if (s->motion == 7) { /* :175-188 */
+    if (col == 0) {
+      for (int i = 0; i < 16; ++i)
+        base[i] = (uint16_t)s->init_val;
+      return RSX_OK;
+    }
+    for (int i = 0; i < 16; ++i)
+      base[i] = *sv2_px(s, row, col + (i & 1) - 2);
+    return RSX_OK;
+  }
+  if (row < 2)
+    return RSX_ERR_INVALID_ARG; /* :191-192 */
+  static const int motion_offset[7] = {-4, -2, -2, 0, 0, 2, 4};
+  static const int motion_avg[7] = {0, 0, 1, 0, 1, 0, 0};
+  const int slide = motion_offset[s->motion], avg = motion_avg[s->motion];
+  for (int i = 0; i < 16; ++i) { /* :202-227 */
+    int ref_row = row, ref_col = col + i + slide;
+    if ((row + i) & 1) {
+      ref_row -= 2;
+    } else {
+      ref_row -= 1;
+      ref_col += (i & 1) ? -1 : 1;
+    }
+    if (ref_col < 0)
+      return RSX_ERR_INVALID_ARG;
+    if (ref_col >= s->width || (avg && ref_col + 2 >= s->width))
+      return RSX_ERR_INVALID_ARG;
+    if (avg)
+      base[i] = (uint16_t)((*sv2_px(s, ref_row, ref_col) + *sv2_px(s, ref_row, ref_col + 2) + 1) >> 1);
+    else
+      base[i] = *sv2_px(s, ref_row, ref_col);
+  }
+  return RSX_OK;
+}
+
+/* decodeDiffLengths :232-277 + decodeDifferences :279-314 */
+static int sv2_differences(sv2* s, bitreader* b, int row, int scaled[16]) {
+  uint32_t diff_bits[4] = {0, 0, 0, 0};
+  if ((s->optflags & 1u) || !br_get(b, 1)) { /* :234 (SKIP: always coded) */
+    uint32_t flags[4];
+    for (int i = 0; i < 4; ++i)
+      flags[i] = br_get(b, 2);
+    for (int i = 0; i < 4; ++i) {
+      const int colornum = (row % 2 != 0) ? i >> 1 : ((i >> 1) + 2) % 3;
+      switch (flags[i]) {
+      case 0:
+        diff_bits[i] = (uint32_t)s->mode[colornum][0];
+        break;
+      case 1:
+        diff_bits[i] = (uint32_t)s->mode[colornum][0] + 1;
+        break;
+      case 2:
+        if (s->mode[colornum][0] == 0)
+          return RSX_ERR_INVALID_ARG; /* :258-259 */
+        diff_bits[i] = (uint32_t)s->mode[colornum][0] - 1;
+        break;
+      default:
+        diff_bits[i] = br_get(b, 4);
+        break;
+      }
+      s->mode[colornum][0] = s->mode[colornum][1];
+      s->mode[colornum][1] = (int)diff_bits[i];
+      if (diff_bits[i] > (uint32_t)s->bits + 1)
+        return RSX_ERR_INVALID_ARG; /* :271-272 */
+    }
+  }
+  if (b->err)
+    return b->err;
+  int16_t diffs[16], shuffled[16];
+  for (int i = 0; i < 16; ++i) { /* :286-290 with getDiff :79-85 */
+    const uint32_t len = diff_bits[i >> 2];
+    int v = 0;
+    if (len) {
+      const uint32_t u = br_get(b, (int)len);
+      v = (int)(u << (32 - len)) >> (32 - len); /* signExtend */
+    }
+    diffs[i] = (int16_t)v;
+  }
+  if (b->err)
+    return b->err;
+  for (int i = 0; i < 16; ++i) { /* :293-304 */
+    const int p = (row % 2) ? ((i % 8) << 1) - (i >> 3) + 1 : ((i % 8) << 1) + (i >> 3);
+    shuffled[p] = diffs[i];
+  }
+  for (int i = 0; i < 16; ++i) /* :307-311 */
+    scaled[i] = (int)shuffled[i] * (s->scale * 2 + 1) + s->scale;
+  return RSX_OK;
+}
+
+/* The constructor's header parse (:87-141) and decompress / decompressRow (:312-338).
+ * `in` = the strip the container hands over (header included). */
+int oracle_samsung_v2_decompress(const uint8_t* in, size_t in_bytes, int bits,
+                                 const rsx_image* img) {
+  if (img->cpp != 1)
+    return RSX_ERR_INVALID_ARG; /* :90-92 */
+  if (bits != 12 && bits != 14)
+    return RSX_ERR_INVALID_ARG; /* :94-100 */
+  if (in_bytes < 16)
+    return RSX_ERR_IO; /* bs.check(headerSize) :103 */
+  bitreader h;
+  br_init(&h, in, (int64_t)in_bytes, RSX_ORDER_MSB32);
+  sv2 s;
+  memset(&s, 0, sizeof s);
+  s.img = img;
+  br_get(&h, 16);
+  br_get(&h, 4);
+  s.bits = (int)br_get(&h, 4) + 1;
+  if (s.bits != bits)
+    return RSX_ERR_INVALID_ARG; /* :112-113 */
+  br_get(&h, 4);
+  br_get(&h, 4);
+  s.width = (int)br_get(&h, 16);
+  s.height = (int)br_get(&h, 16);
+  br_get(&h, 16);
+  br_get(&h, 4);
+  s.optflags = br_get(&h, 4);
+  if (s.optflags > 7u)
+    return RSX_ERR_INVALID_ARG; /* :123-125 */
+  br_get(&h, 8);
+  br_get(&h, 8);
+  br_get(&h, 8);
+  br_get(&h, 2);
+  s.init_val = (int)br_get(&h, 14);
+  if (s.width == 0 || s.height == 0 || s.width % 16 != 0 || s.width > 6496 || s.height > 4336)
+    return RSX_ERR_INVALID_ARG; /* :134-136 */
+  if (s.width != img->dim_x || s.height != img->dim_y)
+    return RSX_ERR_INVALID_ARG; /* :138-139 */
+  const uint8_t* data = in + 16;
+  const int64_t size = (int64_t)in_bytes - 16;
+  int64_t pos = 0;
+  for (int row = 0; row < s.height; ++row) {
+    if (pos & 0xf) { /* :314-316 */
+      const int64_t skip = 16 - (pos & 0xf);
+      if (pos + skip > size)
+        return RSX_ERR_IO;
+      pos += skip;
+    }
+    bitreader b;
+    br_init(&b, data + pos, size - pos, RSX_ORDER_MSB32);
+    if (b.err)
+      return b.err;
+    s.motion = 7;
+    s.scale = 0;
+    for (int c = 0; c < 3; ++c)
+      s.mode[c][0] = s.mode[c][1] = (row == 0 || row == 1) ? 7 : 4;
+    for (int col = 0; col < s.width; col += 16) { /* processBlock :316-330 */
+      uint16_t base[16];
+      int scaled[16];
+      int st = sv2_baseline(&s, &b, row, col, base);
+      if (st)
+        return st;
+      st = sv2_differences(&s, &b, row, scaled);
+      if (st)
+        return st;
+      for (int i = 0; i < 16; ++i) {
+        int v = (int)base[i] + scaled[i];
+        const int hi = (1 << s.bits) - 1;
+        v = v < 0 ? 0 : (v > hi ? hi : v); /* clampBits */
+        *sv2_px(&s, row, col + i) = (uint16_t)v;
+      }
+    }
+    const int64_t used = b.pos - (b.fill >> 3); /* getStreamPosition */
+    if (pos + used > size)
+      return RSX_ERR_IO;
+    pos += used;
+  }
+  return RSX_OK;
+}

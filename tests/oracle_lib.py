@@ -168,6 +168,13 @@ class Oracle:
         v = img.view()
         return self.lib.oracle_samsung_v1_decompress(C.byref(desc), p, n, C.byref(v))
 
+    def samsung_v2(self, bits, data, img):
+        a, p, n = _as_u8(data)
+        v = img.view()
+        self.lib.oracle_samsung_v2_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_int,
+                                                          C.c_void_p]
+        return self.lib.oracle_samsung_v2_decompress(p, n, bits, C.byref(v))
+
     def sony_arw1(self, data, img):
         a, p, n = _as_u8(data)
         v = img.view()
@@ -360,6 +367,8 @@ class Ref:
                                             C.c_int, C.c_void_p, C.c_size_t]
         L.ref_samsung_v1_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.ref_sony_arw1_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        if hasattr(L, "ref_samsung_v2_decompress"):
+            L.ref_samsung_v2_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.ref_hasselblad_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p]
         L.ref_pentax_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
@@ -433,6 +442,10 @@ class Ref:
     def samsung_v1(self, bits, data, img):
         a, p, n = _as_u8(data)
         return self.lib.ref_samsung_v1_decompress(img.h, bits, p, n)
+
+    def samsung_v2(self, bits, data, img):
+        a, p, n = _as_u8(data)
+        return self.lib.ref_samsung_v2_decompress(img.h, bits, p, n)
 
     def sony_arw1(self, data, img):
         a, p, n = _as_u8(data)
