@@ -204,6 +204,20 @@ def cr2_sraw_2x2():
     return _cr2_sraw(516, 2)
 
 
+def srw_samsung_v2():
+    """SrwDecoder -> SamsungV2Decompressor (compression 32773): NOT forwarded to the GPU --
+    the patched build must decode it with the reference's own code, untouched."""
+    import samsung_v2_cases as V2
+    rng = np.random.default_rng(517)
+    W, H, bits = 256, 60, 12
+    x = np.arange(W)[None, :]
+    y = np.arange(H)[:, None]
+    target = np.clip(1200 + 900.0 * x / W + 600.0 * y / H + rng.normal(0, 12, (H, W)),
+                     0, 4095).astype(np.int64)
+    data, want = V2.encode(rng, target, bits, optflags=0)
+    return rawfiles.srw_v1_file(W, H, data, bits=bits, compression=32773), want
+
+
 # decodeRaw() options of a case (default: corrected values)
 UNCORRECTED = {"nef_compressed_uncorrected"}
 
@@ -211,4 +225,4 @@ CASES = {f.__name__: f for f in (
     dng_ljpeg_tiles, dng_ljpeg_tiles_dri, dng_ljpeg_strips, dng_uncompressed_12bit_strips,
     dng_uncompressed_16bit_tiles, arw_ljpeg_tiles, arw_uncompressed, arw1_compressed,
     cr2_three_slices, pef_compressed, nef_compressed_uncorrected, nef_compressed_curve,
-    threefr_ljpeg, srw_samsung_v1, cr2_sraw_2x1, cr2_sraw_2x2)}
+    threefr_ljpeg, srw_samsung_v1, cr2_sraw_2x1, cr2_sraw_2x2, srw_samsung_v2)}

@@ -337,12 +337,13 @@ def threefr_file(width, height, blob):
     return tiff_file(root)
 
 
-def srw_v1_file(width, height, data, bits=12):
-    """Samsung SRW, compression 32772 (SrwDecoder.cpp:56-120): SamsungV1Decompressor."""
+def srw_v1_file(width, height, data, bits=12, compression=32772):
+    """Samsung SRW, compression 32772 (SrwDecoder.cpp:56-120): SamsungV1Decompressor;
+    32773: SamsungV2Decompressor (:121-135)."""
     raw = Ifd()
     raw.add(IMAGEWIDTH, LONG, width).add(IMAGELENGTH, LONG, height)
     raw.add(BITSPERSAMPLE, SHORT, bits)
-    raw.add(COMPRESSION, LONG, 32772)
+    raw.add(COMPRESSION, LONG, compression)
     raw.add_blobs(STRIPOFFSETS, STRIPBYTECOUNTS, [data])
     root = Ifd()
     root.add(MAKE, ASCII, "SAMSUNG").add(MODEL, ASCII, "RSX")
