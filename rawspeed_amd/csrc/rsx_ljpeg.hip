@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_kernel(LjArgs a) {
   const LjStreamDev& S = a.streams[s];
   if ((S.n_tables > 1) != MULTI || (S.las != 0) != LAS || S.pair)
     return;
-  if (S.direct && !(a.results[s].flags & FL_NEED_LEGACY))
+  if (!lj_legacy_takes(a, s, S))
     return; // decoded by lj_decode_direct_kernel
   const Lds L = carve(smem, LJ_BW_DEC);
   const uint32_t lb = b - S.first_block;
@@ -1478,6 +1478,8 @@ __global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
   const uint32_t avail = R.avail_lo;
   if (R.status != 0 || uint64_t(avail) >= S.needed)
     return; // the common case: every symbol starts inside the data
+  if (!lj_legacy_takes(a, s, S))
+    return; // a fused-path stream whose difference scratch does not exist yet
   const uint8_t* in = a.in_base + S.in_offset;
   const bool has_marker = R.marker_pos != 0xFFFFFFFFu && R.marker_pos < S.in_bytes;
   const uint64_t M = has_marker ? R.marker_pos : lj_data_end(S);
@@ -2118,6 +2120,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     S.pair = g.pair;
     S.no_vertical = g.no_vertical;
     S.direct = direct_n;
+    S.diff_offset = direct_n ? LJ_NO_DIFFS : 0; // (legacy streams: assigned below)
     S.sync_lut11 = (J.explicit_n > 0 && J.explicit_bits > 10) ? 1 : 0;
     S.raw_limit = g.raw_limit;
     S.rows = g.rows;

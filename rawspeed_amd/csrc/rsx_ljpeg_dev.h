@@ -64,6 +64,13 @@ constexpr uint32_t FL_NEED_LEGACY = 2u;
 // some workgroup of the stream met periodic data (constant image regions)
 constexpr uint32_t FL_PERIODIC = 4u;
 
+// diff_offset of a fused-path stream before its difference scratch exists (it is set up
+// on first use, LJpegPlan::legacy_fallback_ready): the legacy kernels must not touch such a
+// stream even when it is flagged FL_NEED_LEGACY -- in a plan that mixes legacy-route and
+// fused-path streams they run in the FIRST pass too, and would write the damaged stream's
+// differences over a healthy stream's region.
+constexpr uint64_t LJ_NO_DIFFS = ~uint64_t(0);
+
 // The code table as the kernels keep it in LDS.  RSX_LUT_DIFF: a LUT entry also
 // carries, in its high half, the DIFFERENCE the symbol stands for whenever the whole
 // symbol -- code and difference bits -- lies inside the LUT_BITS index bits (total <=
@@ -220,6 +227,15 @@ struct LjArgs {
   int32_t* nk_pup;           // [stream][4]: pUp after the stream's last row
   uint16_t* transfer;        // [workgroup][512]: exit state per entry state (fallback path)
 };
+
+// whether the legacy route (int16 differences + K5 / K6, lj_tail_kernel's end-of-stream
+// rules) takes stream s in this launch
+__device__ __forceinline__ bool lj_legacy_takes(const LjArgs& a, uint32_t s,
+                                                const LjStreamDev& S) {
+  if (!S.direct)
+    return true;
+  return (a.results[s].flags & FL_NEED_LEGACY) != 0 && S.diff_offset != LJ_NO_DIFFS;
+}
 
 constexpr int VS_T = 1024; // lanes of the per-stream seed kernels
 

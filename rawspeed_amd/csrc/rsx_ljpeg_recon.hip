@@ -43,7 +43,7 @@ __global__ __launch_bounds__(VS_T) void lj_vseed_kernel(LjArgs a) {
   const LjStreamDev& S = a.streams[s];
   if (a.results[s].status != 0 || S.kind == 2)
     return;
-  if (S.direct && !(a.results[s].flags & FL_NEED_LEGACY))
+  if (!lj_legacy_takes(a, s, S))
     return; // reconstructed by the fused decode (rsx_ljpeg_direct.hip)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // (the stream record is read once: stores to V could alias it for the compiler)
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
   if (int(S.n_comp) != N || int(S.period) != P || S.kind == 2 ||
       a.results[lo].status != 0)
     return;
-  if (S.direct && !(a.results[lo].flags & FL_NEED_LEGACY))
+  if (!lj_legacy_takes(a, lo, S))
     return;
   const uint32_t r = grow - S.first_row;
   if (r >= S.rows)
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_fast_kernel(LjArgs a) {
   if (int(S.n_comp) != N || int(S.period) != N || S.kind == 2 ||
       a.results[lo].status != 0)
     return;
-  if (S.direct && !(a.results[lo].flags & FL_NEED_LEGACY))
+  if (!lj_legacy_takes(a, lo, S))
     return;
   const uint32_t r = grow - S.first_row;
   if (r >= S.rows)

@@ -24,13 +24,49 @@ def pair():
     return Ref(), Ref(REF_RSX_SO)
 
 
-def both(pair, fn, dims):
+class Forwarding:
+    """What the patched build's hunks did with the units of work of a call (a strip, a
+    scan, a DNG tile): `fwd` decoded by the device, `fell` left to the method's original
+    body (rsx_shim::stats()).  The hunks fall through on ANY non-OK status, so an
+    identical image alone proves nothing: every test states what it expects here."""
+
+    def __init__(self, rsx):
+        self.rsx = rsx
+        self.c0 = rsx.rsx_counts()
+
+    def delta(self):
+        c1 = self.rsx.rsx_counts()
+        return c1[1] - self.c0[1], c1[2] - self.c0[2]
+
+
+def both(pair, fn, dims, fwd=1, fell=0):
+    """Run fn on the unmodified and on the patched build.  fwd / fell: units the patched
+    build must have forwarded to the device / left to the CPU loop (None = do not check;
+    a (lo, hi) tuple = a range)."""
     out = []
-    for lib in pair:
+    for k, lib in enumerate(pair):
         img = lib.image(*dims)
+        f = Forwarding(lib) if k == 1 else None
         st = fn(lib, img)
+        if f is not None:
+            if fwd == "auto":  # the unmodified build decides: success = forwarded, failure = CPU loop
+                st0 = out[0][0]
+                ok = (st0[0] if isinstance(st0, tuple) else st0) == 0
+                check_forwarding(f, 1 if ok else 0, 0 if ok else 1)
+            else:
+                check_forwarding(f, fwd, fell)
         out.append((st, img.u16().copy(), lib.last_error()))
     return out
+
+
+def check_forwarding(f, fwd=1, fell=0):
+    got_fwd, got_fell = f.delta()
+    for name, want, got in (("forwarded", fwd, got_fwd), ("fell through", fell, got_fell)):
+        if want is None:
+            continue
+        lo, hi = want if isinstance(want, tuple) else (want, want)
+        assert lo <= got <= hi, "%s: %d units, expected %s (forwarded %d, fell through %d)" % (
+            name, got, want, got_fwd, got_fell)
 
 
 def test_ljpeg_container_full_image(pair):
@@ -111,7 +147,8 @@ def test_dng_ljpeg_tiles_through_reference_fanout(pair, threads):
             blob, _, _, _ = synth.ljpeg_container(tile, 2, 14, [0, 0], [C.NIKON])
             blobs.append(blob)
     (s0, a, e0), (s1, b, e1) = both(
-        pair, lambda lib, img: lib.dng(img, 7, tw, th, blobs, threads=threads), (W, H, 1))
+        pair, lambda lib, img: lib.dng(img, 7, tw, th, blobs, threads=threads), (W, H, 1),
+        fwd=len(blobs))
     assert s0 == 0 and s1 == 0, (e0, e1)
     assert np.array_equal(a, b)
     assert np.array_equal(a[:, :W], src)
@@ -129,7 +166,8 @@ def test_dng_uncompressed_tiles_through_reference_fanout(pair):
     blobs = [rng.integers(0, 256, size=th * tw * bps // 8, dtype=np.uint8)
              for _ in range((H + th - 1) // th)]
     (s0, a, e0), (s1, b, e1) = both(
-        pair, lambda lib, img: lib.dng(img, 1, tw, th, blobs, bps=bps, threads=4), (W, H, 1))
+        pair, lambda lib, img: lib.dng(img, 1, tw, th, blobs, bps=bps, threads=4), (W, H, 1),
+        fwd=len(blobs))
     assert s0 == 0 and s1 == 0, (e0, e1)
     assert np.array_equal(a, b)
     # 4 x 3 tiles of 16-bit little-endian data
@@ -137,7 +175,8 @@ def test_dng_uncompressed_tiles_through_reference_fanout(pair):
     blobs = [rng.integers(0, 256, size=th * tw * bps // 8, dtype=np.uint8)
              for _ in range(((H + th - 1) // th) * ((W + tw - 1) // tw))]
     (s0, a, e0), (s1, b, e1) = both(
-        pair, lambda lib, img: lib.dng(img, 1, tw, th, blobs, bps=bps, threads=4), (W, H, 1))
+        pair, lambda lib, img: lib.dng(img, 1, tw, th, blobs, bps=bps, threads=4), (W, H, 1),
+        fwd=len(blobs))
     assert s0 == 0 and s1 == 0, (e0, e1)
     assert np.array_equal(a, b)
 
@@ -163,7 +202,7 @@ def test_corrupt_tile_is_reported_by_both(pair):
     bad = blob.copy()
     bad[hdr + 100:hdr + 102] = 0xFF   # FF FF: the scan ends here, far too early
     res = both(pair, lambda lib, img: lib.ljpeg_container(bad, img, 0, 0, W, H, (W, H)),
-               (W, H, 1))
+               (W, H, 1), fwd=0, fell=1)
     assert res[0][0] != 0 and res[1][0] != 0
 
 
@@ -179,7 +218,7 @@ def test_uncompressed_variant_methods(pair):
                 data = rng.integers(0, 256, size=bpl * h - cut, dtype=np.uint8)
                 d = abi.UnpackVariantDesc(variant, big, w, h)
                 (s0, a, e0), (s1, b, e1) = both(
-                    pair, lambda lib, img: lib.unpack_variant(d, data, img), (w, h, 1))
+                    pair, lambda lib, img: lib.unpack_variant(d, data, img), (w, h, 1), fwd="auto")
                 assert s0 == s1 and (s0 == 0) == (cut == 0), (variant, big, w, e0, e1)
                 assert np.array_equal(a, b)
 
@@ -223,7 +262,10 @@ def test_uncompressed_f32_image(pair):
         out = []
         for lib in pair:
             img = lib.image(w + 2, h + 1, cpp, f32=True)
+            f = Forwarding(lib)
             out.append((lib.unpack(d, data, img), img.u32().copy(), lib.last_error()))
+            if lib is pair[1]:
+                check_forwarding(f, 1, 0)
         (s0, a, e0), (s1, b, e1) = out
         assert s0 == 0 and s1 == 0, (e0, e1)
         assert np.array_equal(a, b)
@@ -237,7 +279,7 @@ def test_pentax_decompressor(pair):
         c = next(c for c in G.PENTAX_CASES if c["name"] == name)
         meta, d, data, (w, h, cpp), _ = G.build_pentax(c)
         (s0, a, e0), (s1, b, e1) = both(
-            pair, lambda lib, img: lib.pentax(meta, data, img), (w, h, cpp))
+            pair, lambda lib, img: lib.pentax(meta, data, img), (w, h, cpp), fwd="auto")
         assert s0 == s1, (e0, e1)
         if s0 == 0:
             assert np.array_equal(a, b)
@@ -249,7 +291,7 @@ def test_samsung_v1_decompressor(pair):
         c = next(c for c in G.SAMSUNG_V1_CASES if c["name"] == name)
         d, data, (w, h, cpp), _ = G.build_samsung_v1(c)
         (s0, a, e0), (s1, b, e1) = both(
-            pair, lambda lib, img: lib.samsung_v1(12, data, img), (w, h, cpp))
+            pair, lambda lib, img: lib.samsung_v1(12, data, img), (w, h, cpp), fwd="auto")
         assert s0 == s1, (e0, e1)
         if s0 == 0:
             assert np.array_equal(a, b)
@@ -265,7 +307,10 @@ def test_sraw_interpolator(pair):
         for lib in pair:
             src, dst = lib.image(iw, ih, 1, False), lib.image(ow, oh, 3, False)
             src.set_pixels(px)
+            f = Forwarding(lib)
             out.append((lib.sraw(d, src, dst), dst.u16().copy(), lib.last_error()))
+            if lib is pair[1]:
+                check_forwarding(f, 1, 0)
         (s0, a, e0), (s1, b, e1) = out
         assert s0 == 0 and s1 == 0, (e0, e1)
         assert np.array_equal(a, b)
@@ -288,7 +333,7 @@ def test_sony_arw1_decompressor(pair):
         c = next(c for c in G.SONY_ARW1_CASES if c["name"] == name)
         data, (w, h, cpp), _ = G.build_sony_arw1(c)
         (s0, a, e0), (s1, b, e1) = both(
-            pair, lambda lib, img: lib.sony_arw1(data, img), (w, h, cpp))
+            pair, lambda lib, img: lib.sony_arw1(data, img), (w, h, cpp), fwd="auto")
         assert s0 == s1, (e0, e1)
         if s0 == 0:
             assert np.array_equal(a, b)
@@ -324,7 +369,8 @@ def test_dng_decompress_makes_one_batched_call(pair, threads):
     src, blobs = _dng_case(rng, W, H, tw, th)
     before = rsx.rsx_host_calls()
     (s0, a, e0), (s1, b, e1) = both(
-        pair, lambda lib, img: lib.dng(img, 7, tw, th, blobs, threads=threads), (W, H, 1))
+        pair, lambda lib, img: lib.dng(img, 7, tw, th, blobs, threads=threads), (W, H, 1),
+        fwd=len(blobs))
     assert ref.rsx_host_calls() == -1
     assert rsx.rsx_host_calls() - before == 1
     assert s0 == 0 and s1 == 0, (e0, e1)
@@ -341,7 +387,7 @@ def test_dng_uncompressed_tiles_make_one_batched_call(pair, threads):
     before = rsx.rsx_host_calls()
     (s0, a, e0), (s1, b, e1) = both(
         pair, lambda lib, img: lib.dng(img, 1, tw, th, blobs, bps=bps, threads=threads),
-        (W, H, 1))
+        (W, H, 1), fwd=len(blobs))
     assert rsx.rsx_host_calls() - before == 1
     assert s0 == 0 and s1 == 0, (e0, e1)
     assert np.array_equal(a, b)
@@ -357,7 +403,10 @@ def test_dng_corrupt_tiles_same_image_and_error_log(pair, corrupt):
     out = []
     for lib in pair:
         img = lib.image(W, H, 1)
+        f = Forwarding(lib)
         st = lib.dng(img, 7, tw, th, blobs, threads=2)
+        if lib is pair[1]:  # the good tiles from the device, the damaged ones from the CPU loop
+            check_forwarding(f, len(blobs) - len(corrupt), (len(corrupt), 2 * len(corrupt)))
         out.append((st, img.u16().copy(), lib.last_error(), lib.image_errors(img)))
     (s0, a, e0, log0), (s1, b, e1, log1) = out
     assert s0 == s1 != 0  # (isTooManyErrors(1): one failed tile fails the image)
@@ -376,7 +425,8 @@ def test_corrupt_scan_same_partial_image_and_message(pair):
     bad = blob.copy()
     bad[hdr + scan_len // 2:hdr + scan_len // 2 + 2] = 0xFF
     (s0, a, e0), (s1, b, e1) = both(
-        pair, lambda lib, img: lib.ljpeg_container(bad, img, 0, 0, W, H, (W, H)), (W, H, 1))
+        pair, lambda lib, img: lib.ljpeg_container(bad, img, 0, 0, W, H, (W, H)), (W, H, 1),
+        fwd=0, fell=1)
     assert s0 == s1 != 0 and e0 == e1 and e0
     assert np.array_equal(a, b)
 
@@ -391,6 +441,7 @@ def test_unsupported_shape_falls_through_to_the_cpu_loop(pair):
     rows = C.cr2_stream_from_image(src, 2, W // 2, H, [sw] * n_slices)
     blob, _, _, _ = synth.ljpeg_container(rows, 2, 14, [0, 0], [C.NIKON])
     (s0, a, e0), (s1, b, e1) = both(
-        pair, lambda lib, img: lib.cr2_container(blob, img, n_slices, sw, sw), (W, H, 1))
+        pair, lambda lib, img: lib.cr2_container(blob, img, n_slices, sw, sw), (W, H, 1),
+        fwd=0, fell=1)
     assert s0 == 0 and s1 == 0, (e0, e1)
     assert np.array_equal(a, b) and np.array_equal(a[:, :W], src)
