@@ -475,6 +475,12 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   reinterpret_cast<uint32_t*>(dst + (LJ_BW / 4) * LJ_T)[j] = L.ob[j];
   if (j == 0)
     a.block_drops[b] = L.misc[9];
+  // state of the single-pass kernel that follows (rsx_ljpeg_fast.hip): its look-back
+  // granules and workgroup tickets start from zero in every run
+  if (a.lb && j < LF_LB_WORDS)
+    a.lb[size_t(b) * LF_LB_WORDS + j] = 0ull;
+  if (a.tickets && b == 0 && j < 4)
+    a.tickets[j] = 0u;
 }
 
 // inclusive scan of x over the wavefront
@@ -623,6 +629,8 @@ __global__ __launch_bounds__(LJ_T) void lj_sync_kernel(LjArgs a) {
   const LjStreamDev& S = a.streams[s];
   if (lj_sync_multi(S) != MULTI || (S.pair != 0) != PAIR || int(S.direct) != NS)
     return; // another instantiation handles this stream
+  if (!lj_pipeline_takes(a, s, S))
+    return; // the single-pass kernel's
   constexpr int BWK = PAIR ? LJ_BW_SYNC_PAIR : LJ_BW_SYNC;
   constexpr int N = NS ? NS : 1;
   using TB = SyncTable<MULTI, PAIR>;
@@ -904,7 +912,7 @@ __global__ __launch_bounds__(LJ_T) void lj_transfer_kernel(LjArgs a) {
   const uint32_t s = a.block_stream[b];
   const LjStreamDev& S = a.streams[s];
   if ((S.n_tables > 1) != MULTI || (S.pair != 0) != PAIR ||
-      !(a.results[s].flags & FL_UNCONVERGED))
+      !(a.results[s].flags & FL_UNCONVERGED) || !lj_pipeline_takes(a, s, S))
     return;
   Lds L{};
   L.B = const_cast<uint32_t*>(
@@ -933,7 +941,8 @@ __global__ __launch_bounds__(LJ_T) void lj_transfer_kernel(LjArgs a) {
 __global__ __launch_bounds__(64) void lj_chain_kernel(LjArgs a) {
   const uint32_t s = blockIdx.x;
   const LjStreamDev& S = a.streams[s];
-  if (threadIdx.x != 0 || !(a.results[s].flags & FL_UNCONVERGED))
+  if (threadIdx.x != 0 || !(a.results[s].flags & FL_UNCONVERGED) ||
+      !lj_pipeline_takes(a, s, S))
     return;
   uint32_t state = S.start_bit;
   for (uint32_t lb = 0; lb < S.n_blocks; ++lb) {
@@ -954,7 +963,7 @@ __global__ __launch_bounds__(64) void lj_pchain_kernel(LjArgs a) {
   __shared__ uint16_t tf[64][32];
   const uint32_t s = blockIdx.x;
   const LjStreamDev& S = a.streams[s];
-  if (!(a.results[s].flags & FL_PERIODIC))
+  if (!(a.results[s].flags & FL_PERIODIC) || !lj_pipeline_takes(a, s, S))
     return;
   const int lane = threadIdx.x;
   const uint32_t fb = S.first_block, nb = S.n_blocks;
@@ -1026,6 +1035,8 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
   __shared__ uint32_t unconv_s;
   const uint32_t s = blockIdx.x;
   const LjStreamDev& S = a.streams[s];
+  if (!lj_bookkeeping_takes(a, s, S))
+    return;
   const int tid = threadIdx.x;
   const uint32_t fb = S.first_block, nb = S.n_blocks;
   const uint32_t nd = S.direct;
@@ -1129,6 +1140,10 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
     // live in the legacy tail kernel
     if (nd && uint64_t(avail) < S.needed)
       flags |= FL_NEED_LEGACY;
+    // a single-pass stream with a broken chain or symbols past its data: the
+    // multi-kernel pipeline redoes it (and finds out again, from its own records)
+    if (S.fast && a.pass == 0 && (flags & (FL_UNCONVERGED | FL_NEED_LEGACY)))
+      flags = (flags & ~(FL_UNCONVERGED | FL_NEED_LEGACY)) | FL_SLOW;
     R.flags = flags;
   }
 }
@@ -1330,7 +1345,7 @@ __global__ __launch_bounds__(LJ_T) void lj_decode_pair_kernel(LjArgs a) {
   const uint32_t b = blockIdx.x;
   const uint32_t s = a.block_stream[b];
   const LjStreamDev& S = a.streams[s];
-  if (!S.pair)
+  if (!S.pair || !lj_pipeline_takes(a, s, S))
     return;
   const Lds L = carve(smem);
   const uint32_t lb = b - S.first_block;
@@ -1711,6 +1726,8 @@ __global__ __launch_bounds__(64) void lj_consumed_kernel(LjArgs a) {
   const LjStreamDev& S = a.streams[s];
   LjResult& R = a.results[s];
   const int lane = threadIdx.x;
+  if (!lj_bookkeeping_takes(a, s, S))
+    return;
   if (R.status != 0 || uint64_t(R.avail_lo) < S.needed)
     return;
   const uint8_t* in = a.in_base + S.in_offset;
@@ -1861,6 +1878,13 @@ struct LJpegPlan {
   bool direct_present[2][5] = {}; // fused path: [several tables][components]
   bool any_direct = false, any_legacy = false;
   bool legacy_fallback_ready = false; // difference scratch of the fused streams allocated
+  // single-pass path (rsx_ljpeg_fast.hip)
+  bool fast_present[5] = {};   // [components]
+  bool any_fast = false;       // some stream takes the single-pass kernel
+  bool any_pipeline = false;   // some stream takes the multi-kernel pipeline in the first pass
+  bool expect_slow = false;    // the last run left FL_SLOW streams: launch the second pass at once
+  bool slow_pass_launched = false; // ... this run already has
+  DeviceBuffer d_fast_tabs, d_lb, d_tickets;
   DeviceBuffer d_block_flags, d_block_tf, d_sub_start;
   DeviceBuffer d_streams, d_tables, d_block_stream, d_strips, d_sub_state, d_sub_sums,
       d_sub_first, d_sub_psum,
@@ -1946,6 +1970,10 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.nk_rowpow = static_cast<const uint32_t*>(p->d_nk_rowpow.ptr);
   a.nk_pup = static_cast<int32_t*>(p->d_nk_pup.ptr);
   a.transfer = static_cast<uint16_t*>(p->d_transfer.ptr);
+  a.fast_tabs = static_cast<const uint2*>(p->d_fast_tabs.ptr);
+  a.lb = static_cast<unsigned long long*>(p->d_lb.ptr);
+  a.tickets = static_cast<uint32_t*>(p->d_tickets.ptr);
+  a.pass = 0;
   return a;
 }
 
@@ -2121,6 +2149,15 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     S.no_vertical = g.no_vertical;
     S.direct = direct_n;
     S.diff_offset = direct_n ? LJ_NO_DIFFS : 0; // (legacy streams: assigned below)
+    // the single-pass kernel: fused-path streams with one table whose MCU is a row of
+    // its components (or CR2 strips)
+#ifndef RSX_NO_FAST
+    S.fast = (direct_n && J.n_tables == 1 &&
+              (g.kind == 1 || (g.mcu_h == 1 && g.mcu_w == g.n_comp)) &&
+              g.row_samples >= g.n_comp)
+                 ? 1
+                 : 0;
+#endif
     S.sync_lut11 = (J.explicit_n > 0 && J.explicit_bits > 10) ? 1 : 0;
     S.raw_limit = g.raw_limit;
     S.rows = g.rows;
@@ -2217,6 +2254,12 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     cls.sony |= g.kind == 2 && J.nikon.sony;
     if (g.kind != 2)
       cls.comp[g.period == g.n_comp ? g.n_comp : (g.period == 4 ? 5u : 6u)] = true;
+    if (S.fast) {
+      p->any_fast = true;
+      p->fast_present[S.direct] = true;
+    } else {
+      p->any_pipeline = true;
+    }
     if (S.direct) {
       p->any_direct = true;
       p->direct_present[multi ? 1 : 0][S.direct] = true;
@@ -2308,6 +2351,15 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         (st = p->d_diffs.ensure(size_t(p->total_diffs) * 2 + 64)) ||
         (st = p->d_vseed.ensure(size_t(p->total_rows) * 8 + 16)))
       return st;
+    if (p->any_fast) {
+      std::vector<uint2> ft(tl.size() * 1024);
+      for (size_t t = 0; t < tl.size(); ++t)
+        ljpeg_build_fast_table(tl[t], ft.data() + t * 1024);
+      if ((st = up(p->d_fast_tabs, ft.data(), ft.size() * sizeof(uint2))) ||
+          (st = p->d_lb.ensure(size_t(p->total_blocks) * LF_LB_WORDS * 8)) ||
+          (st = p->d_tickets.ensure(16)))
+        return st;
+    }
     if (p->any_direct &&
         ((st = p->d_sub_sums.ensure(size_t(p->total_subseq) * 8 + 16)) ||
          (st = p->d_sub_first.ensure(size_t(p->total_subseq) * 4 + 16)) ||
@@ -2343,11 +2395,26 @@ void launch_legacy(LJpegPlan* p, const LJpegPlan::Classes& c, const LjArgs& a,
   mark(p, "legacy reconstruction (K5 + K6)");
 }
 
+// K1, the stitch passes and the chain of periodic workgroups
+void launch_synchronisation(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
+  const uint32_t n_streams = uint32_t(p->streams.size());
+  launch_sync<false>(p, a, s);
+  for (int r = 0; r < p->stitch_rounds; ++r) {
+    launch_sync<true>(p, a, s);
+    if (r + 1 < p->stitch_rounds) {
+      hipLaunchKernelGGL(lj_pchain_kernel, dim3(n_streams), dim3(64), 0, s, a);
+      mark(p, "lj_pchain_kernel");
+    }
+  }
+}
+
 // everything after synchronisation and the scan: decode, reconstruct, consumed
-int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
+// (pipeline: some stream of this launch takes the multi-kernel pipeline)
+int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s, bool pipeline = true,
+                bool legacy = true) {
   rsx_ctx* ctx = p->ctx;
   const uint32_t n_streams = uint32_t(p->streams.size());
-  if (p->any_direct) {
+  if (p->any_direct && pipeline) {
     DirectLaunch dl;
     dl.n_streams = n_streams;
     dl.total_blocks = p->total_blocks;
@@ -2356,12 +2423,25 @@ int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
     std::memcpy(dl.present, p->direct_present, sizeof dl.present);
     ljpeg_launch_direct(a, dl, s, p->timer);
   }
-  if (p->any_legacy)
+  if (p->any_legacy && legacy)
     launch_legacy(p, p->legacy, a, s);
   hipLaunchKernelGGL(lj_consumed_kernel, dim3(n_streams), dim3(64), 0, s, a);
   mark(p, "lj_consumed_kernel");
   RSX_HIP_CHECK(ctx, hipGetLastError());
   return RSX_OK;
+}
+
+// Second pass: the streams the single-pass kernel gave up on (FL_SLOW, set on the
+// device) go through the multi-kernel pipeline; every other stream is left alone.
+int launch_slow_pass(LJpegPlan* p, hipStream_t s) {
+  LjArgs a = make_args(p, p->last_in, p->last_out);
+  a.pass = 1;
+  const uint32_t n_streams = uint32_t(p->streams.size());
+  launch_synchronisation(p, a, s);
+  hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
+  mark(p, "lj_scan_kernel");
+  p->slow_pass_launched = true;
+  return launch_tail(p, a, s, true, false);
 }
 
 } // namespace
@@ -2567,18 +2647,26 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
   hipLaunchKernelGGL(lj_unstuff_kernel, dim3(p->total_blocks), dim3(LJ_T),
                      lj_lds_bytes(0), s, a);
   mark(p, "lj_unstuff_kernel");
-  launch_sync<false>(p, a, s);
-  for (int r = 0; r < p->stitch_rounds; ++r) {
-    launch_sync<true>(p, a, s);
-    if (r + 1 < p->stitch_rounds) {
-      hipLaunchKernelGGL(lj_pchain_kernel, dim3(n_streams), dim3(64), 0, s, a);
-      mark(p, "lj_pchain_kernel");
-    }
+  // the single-pass kernel for the streams it takes ...
+  if (p->any_fast) {
+    FastLaunch fl;
+    fl.total_blocks = p->total_blocks;
+    std::memcpy(fl.present, p->fast_present, sizeof fl.present);
+    ljpeg_launch_fast(a, fl, s, p->timer);
   }
+  // ... the multi-kernel pipeline for the others
+  if (p->any_pipeline)
+    launch_synchronisation(p, a, s);
   hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
   mark(p, "lj_scan_kernel");
-  if (int st = launch_tail(p, a, s))
+  if (int st = launch_tail(p, a, s, p->any_pipeline))
     return st;
+  p->slow_pass_launched = false;
+  if (p->any_fast && p->expect_slow) {
+    // the last run needed it: no host round trip to find out again
+    if (int st = launch_slow_pass(p, s))
+      return st;
+  }
   if (!p->nk_split.empty())
     return run_nikon_split(p, in_dev, out_dev, s);
   return RSX_OK;
@@ -2602,6 +2690,20 @@ int converge(LJpegPlan* p, hipStream_t s) {
   };
   if (int st = fetch())
     return st;
+  // streams the single-pass kernel gave up on: the second pass (unless the run
+  // launched it already, because the run before needed it)
+  if (p->any_fast) {
+    bool slow = false;
+    for (size_t k = 0; k < p->streams.size(); ++k)
+      slow |= p->streams[k].fast && (p->h_results[k].flags & FL_SLOW) != 0;
+    p->expect_slow = slow;
+    if (slow && !p->slow_pass_launched) {
+      if (int st = launch_slow_pass(p, s))
+        return st;
+      if (int st = fetch())
+        return st;
+    }
+  }
   auto unconverged = [&]() {
     for (const LjResult& R : p->h_results)
       if (R.flags & FL_UNCONVERGED)
@@ -2631,7 +2733,8 @@ int converge(LJpegPlan* p, hipStream_t s) {
                                    hipMemcpyHostToDevice));
       p->legacy_fallback_ready = true;
     }
-    const LjArgs a2 = make_args(p, p->last_in, p->last_out);
+    LjArgs a2 = make_args(p, p->last_in, p->last_out);
+    a2.pass = 2;
     launch_legacy(p, p->fallback, a2, s);
     hipLaunchKernelGGL(lj_consumed_kernel, dim3(n_streams), dim3(64), 0, s, a2);
     RSX_HIP_CHECK(ctx, hipGetLastError());
@@ -2643,7 +2746,8 @@ int converge(LJpegPlan* p, hipStream_t s) {
   // once, however badly the stream synchronises; one stitch pass then settles it
   if (int st = p->d_transfer.ensure(size_t(p->total_blocks) * TF_ENTRIES * 2))
     return st;
-  const LjArgs a = make_args(p, p->last_in, p->last_out);
+  LjArgs a = make_args(p, p->last_in, p->last_out);
+  a.pass = 2;
   {
     if (p->sync_present[0][0] || p->sync_present[0][1] || p->sync_present[0][2] ||
         p->sync_present[0][4] || p->any_lut11)
@@ -2677,7 +2781,11 @@ int converge(LJpegPlan* p, hipStream_t s) {
   }
   p->extra_stitch_rounds += int(rounds);
   // the optimistic tail ran on an inconsistent chain: forget what it reported
-  for (LjResult& R : p->h_results) {
+  // (not for the streams the single-pass kernel finished: nothing is redone for them)
+  for (size_t k = 0; k < p->h_results.size(); ++k) {
+    LjResult& R = p->h_results[k];
+    if (p->streams[k].fast && !(R.flags & FL_SLOW))
+      continue;
     R.status = 0;
     R.tail_used = 0;
     R.last_slot = R.last_pos = R.consumed = 0;
@@ -2826,8 +2934,8 @@ void ljpeg_plan_destroy(LJpegPlan* p) {
     ljpeg_plan_destroy(p->child);
   if (p->nk_child)
     ljpeg_plan_destroy(p->nk_child);
-  for (DeviceBuffer* b :
-       {&p->d_nk, &p->d_nk_tables, &p->d_nk_rowpow, &p->d_nk_pup, &p->d_transfer})
+  for (DeviceBuffer* b : {&p->d_nk, &p->d_nk_tables, &p->d_nk_rowpow, &p->d_nk_pup,
+                          &p->d_transfer, &p->d_fast_tabs, &p->d_lb, &p->d_tickets})
     b->release();
   p->d_marker_count.release();
   p->d_marker_list.release();

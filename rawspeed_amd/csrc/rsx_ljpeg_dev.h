@@ -63,6 +63,11 @@ constexpr uint32_t FL_UNCONVERGED = 1u;
 constexpr uint32_t FL_NEED_LEGACY = 2u;
 // some workgroup of the stream met periodic data (constant image regions)
 constexpr uint32_t FL_PERIODIC = 4u;
+// a stream of the single-pass path (rsx_ljpeg_fast.hip) that it could not finish --
+// periodic data beyond its round limit, a subsequence of more than LF_MAXSYM symbols,
+// an invalid code, an entry state that moved after it was published: the stream is
+// redone by the multi-kernel pipeline (LjArgs::pass == 1)
+constexpr uint32_t FL_SLOW = 8u;
 
 // diff_offset of a fused-path stream before its difference scratch exists (it is set up
 // on first use, LJpegPlan::legacy_fallback_ready): the legacy kernels must not touch such a
@@ -135,7 +140,7 @@ struct LjStreamDev {
                        //       value is the number of interleaved components (1, 2 or 4)
   uint8_t sync_lut11;  // its table has no search path past the LUT (an explicit 11-bit table):
                        // the synchronisation kernels must not use their 10-bit LUT for it
-  uint8_t pad8[1];
+  uint8_t fast;        // != 0: the single-pass kernel decodes it (rsx_ljpeg_fast.hip)
   uint32_t rows;
   uint32_t row_samples;
   uint32_t first_row; // global stream-row index
@@ -226,12 +231,43 @@ struct LjArgs {
   const uint32_t* nk_rowpow; // 15700^(y * W) mod (15700 * 2^16 - 1) per output row
   int32_t* nk_pup;           // [stream][4]: pUp after the stream's last row
   uint16_t* transfer;        // [workgroup][512]: exit state per entry state (fallback path)
+  // single-pass path (rsx_ljpeg_fast.hip)
+  const uint2* fast_tabs;    // [table][1024]: the 10-bit LUT of the single-pass loops
+  unsigned long long* lb;    // [workgroup][LF_LB_WORDS]: look-back records (zeroed by K0)
+  uint32_t* tickets;         // [4]: workgroup tickets of the single-pass launches (zeroed by K0)
+  uint32_t pass;             // 0: first pass; 1: the multi-kernel pipeline redoes FL_SLOW
+                             // streams; 2: its streams of both passes
 };
+
+// words of a workgroup's look-back record (8-byte granules, each self-validating):
+// [0] entry / exit state, symbols, inclusive symbol base; [1..4] LOCAL transfer of the
+// predictor state (a, v; two words each for 4 components); [5..8] the inclusive state
+constexpr int LF_LB_WORDS = 9;
+
+// Which streams a kernel of the multi-kernel pipeline works on.  First pass: every
+// stream the single-pass kernel does not take.  Second pass (launched when the first one
+// left FL_SLOW streams): exactly those.
+__device__ __forceinline__ bool lj_pipeline_takes(const LjArgs& a, uint32_t s,
+                                                  const LjStreamDev& S) {
+  if (S.fast == 0)
+    return a.pass != 1;
+  // (pass 2: the host-driven convergence rounds, after both passes: everything the
+  // multi-kernel pipeline owns by now)
+  return a.pass != 0 && (a.results[s].flags & FL_SLOW) != 0;
+}
+// ... the per-stream bookkeeping kernels (scan, consumed) that also serve the
+// single-pass streams in the first pass
+__device__ __forceinline__ bool lj_bookkeeping_takes(const LjArgs& a, uint32_t s,
+                                                     const LjStreamDev& S) {
+  return a.pass == 0 || lj_pipeline_takes(a, s, S);
+}
 
 // whether the legacy route (int16 differences + K5 / K6, lj_tail_kernel's end-of-stream
 // rules) takes stream s in this launch
 __device__ __forceinline__ bool lj_legacy_takes(const LjArgs& a, uint32_t s,
                                                 const LjStreamDev& S) {
+  if (!lj_pipeline_takes(a, s, S))
+    return false;
   if (!S.direct)
     return true;
   return (a.results[s].flags & FL_NEED_LEGACY) != 0 && S.diff_offset != LJ_NO_DIFFS;
@@ -273,5 +309,15 @@ struct DirectLaunch {
 };
 void ljpeg_launch_direct(const LjArgs& a, const DirectLaunch& d, hipStream_t stream,
                          KernelTimer* timer);
+
+// the single-pass path (rsx_ljpeg_fast.hip)
+struct FastLaunch {
+  uint32_t total_blocks = 0;
+  bool present[5] = {}; // [components]
+};
+void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t stream,
+                       KernelTimer* timer);
+// the 10-bit LUT of the single-pass loops for one table (1024 entries)
+void ljpeg_build_fast_table(const TabLds& t, uint2* out);
 
 } // namespace rsx

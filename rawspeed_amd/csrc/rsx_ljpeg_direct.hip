@@ -142,7 +142,7 @@ __global__ __launch_bounds__(RE_T) void lj_rowedge_kernel(LjArgs a) {
   }
   const LjStreamDev& S = a.streams[slo];
   const uint32_t nd = S.direct;
-  if (!nd || (a.results[slo].flags & FL_NEED_LEGACY))
+  if (!nd || (a.results[slo].flags & FL_NEED_LEGACY) || !lj_pipeline_takes(a, slo, S))
     return;
   const uint32_t r = grow - S.first_row;
   const uint32_t RS = S.row_samples;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(VS_T) void lj_rowoff_kernel(LjArgs a) {
   __shared__ uint2 carry_s;
   const uint32_t s = blockIdx.x;
   const LjStreamDev& S = a.streams[s];
-  if (!S.direct || (a.results[s].flags & FL_NEED_LEGACY))
+  if (!S.direct || (a.results[s].flags & FL_NEED_LEGACY) || !lj_pipeline_takes(a, s, S))
     return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // only the rows that are decoded have edges
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(LJ_T, RSX_K4D_MIN_WAVES) void lj_decode_direct_kern
   const LjStreamDev& S = a.streams[s];
   if ((S.n_tables > 1) != MULTI || int(S.direct) != N)
     return;
-  if (a.results[s].flags & FL_NEED_LEGACY)
+  if ((a.results[s].flags & FL_NEED_LEGACY) || !lj_pipeline_takes(a, s, S))
     return;
   Lds L{};
   // (the tables first: a single table's LUT then starts at LDS address 0 and its entries

@@ -1,0 +1,1154 @@
+// rsx_ljpeg_fast.hip -- single-pass lossless-JPEG decode for gfx950: ONE kernel turns
+// the un-stuffed entropy stream of a clean single-table LJPEG / CR2 scan into pixels.
+//
+// Replaces, for these streams, the walk of
+//   LJpegDecompressor::decodeN / decodeRowN  (decompressors/LJpegDecompressor.cpp:184-251, 300-332)
+//   Cr2Decompressor::decompressN_X_Y         (decompressors/Cr2DecompressorImpl.h:419-465)
+// and the multi-kernel pipeline of rsx_ljpeg.hip / rsx_ljpeg_direct.hip (synchronisation
+// with a recorded pass, two stitch passes, scan, row edges, row offsets, final decode:
+// every symbol parsed three times at ~131 lane-instructions per symbol), which stays
+// in the library as the slow path: streams the single pass cannot finish are flagged
+// FL_SLOW and redone by it (LjArgs::pass == 1).
+//
+// Per workgroup (256 lanes = 255 own 64-byte subsequences + a copy of the predecessor's
+// last one; workgroups take TICKETS so that every predecessor is resident or finished):
+//  1. warm-up: lane j parses subsequence j-1 from bit 0; where that parse runs into
+//     subsequence j is its start guess (Huffman streams self-synchronise).  8 VALU
+//     instructions per symbol, 6 of them of the 2-cycle class.
+//  2. decode: every lane decodes its subsequence ONCE from its guess and KEEPS the
+//     running sums of its differences (by component phase, packed 2 x 16 bit) in 64
+//     VGPRs: 17 VALU instructions per symbol.  A lane that meets a code longer than
+//     the 10-bit LUT, an invalid code or SSSS = 16 stops there.
+//  3. Jacobi rounds (as lj_sync_kernel): subsequences whose guess was not their
+//     predecessor's exit, or that stopped, are re-decoded by the first lanes with the
+//     general loop into an LDS side buffer; their owners fetch the sums from there.
+//  4. look-back 0 (decoupled, one 8-byte granule per workgroup: assumed entry state,
+//     exit state, symbols, inclusive symbol base): the workgroup's entry state is
+//     checked against its predecessor's exit (1.4 % differ: those re-converge from
+//     the true state) and its first symbol's index comes out of the walk.
+//  5. rows: with the index known, the lanes that hold the first MCU of a stream row
+//     put (running sum before it, its difference) into a row table; a scan over the
+//     rows gives the workgroup's transfer of the predictor state
+//        (T = left-neighbour values, Vc = first-MCU values of the last started row),
+//     look-back 1 carries that state across workgroups.
+//  6. output: wave by wave the running sums are staged in LDS in stream order (the
+//     un-stuffed image is dead by then), and the whole workgroup writes them out,
+//     run by run (row, kept width, CR2 strip), as 16-byte stores on the destination's
+//     16-byte grid: pixel = running sum + constant of (row, component).
+//
+// Arithmetic (everything mod 2^16; cf. tests/test_direct_recon_model.py): with Ploc(i)
+// the running sum of i's component over the workgroup's symbols up to i,
+//   X(i) = Ploc(i) + C(row(i), comp(i)),
+//   C(r, c) = Vc_in[c] + sum of the first-MCU differences D(r', c) of the rows r' < r
+//             that start inside the workgroup - Ploc before (r, c)'s first-MCU symbol,
+//   C(r, c) = T_in[c] for the row that is open when the workgroup starts.
+//
+// Instruction selection follows scripts/ubench/valu_rates2.hip (profiles/r03/): on
+// gfx950 add / sub / and / or / xor / lshr / ashr / mov issue in ~2.4 cycles per
+// wave64, everything else (lshl, bfe, alignbit, mad, SDWA, packed, v_cmp) in ~4.3.
+// The position is kept as Pn = -32 * pos - 32 so that the window's LDS row is an AND +
+// ADD and its shift amount a logical shift right; the un-stuffed image lies in LDS
+// delayed by one bit so that v_alignbit's 5-bit amount (31 - pos % 32) selects the
+// window exactly.  No MFMA: there is no contraction anywhere.
+#include "rsx_ljpeg_bits.h"
+
+namespace rsx {
+
+namespace {
+
+constexpr int LF_BW = LJ_PW + 1;        // dword rows of a subsequence the loops can touch
+constexpr int LF_MAXSYM = 128;          // symbols a lane keeps (64 VGPRs)
+constexpr int LF_NR = LF_MAXSYM / 2;
+constexpr int LF_NSIDE = 16;            // side-buffer entries (re-decodes per chunk)
+constexpr int LF_SIDE_STRIDE = 272;     // bytes: 128 x u16 + 16 (16-byte aligned rows)
+constexpr int LF_RMAX = 256;            // stream rows that may start inside one workgroup
+constexpr uint32_t LF_MAX_ROUNDS = 4;   // re-decode rounds before the stream is given up
+constexpr uint32_t LF_SPIN_LIMIT = 1u << 22;
+
+// ---- LDS layout (bytes) ------------------------------------------------------
+constexpr uint32_t LF_OFF_LUT = 0;                       // 1024 x uint2: LDS address 0
+constexpr uint32_t LF_OFF_TAB10 = 8192;                  // TabLds10 (2 KB aligned: OR-addressable)
+constexpr uint32_t LF_OFF_B = LF_OFF_TAB10 + ((sizeof(TabLds10) + 15) & ~size_t(15));
+constexpr uint32_t LF_OFF_REC = LF_OFF_B + LF_BW * LJ_T * 4;   // u32[256]
+constexpr uint32_t LF_OFF_OB = LF_OFF_REC + LJ_T * 4;          // u16[256]
+constexpr uint32_t LF_OFF_SM = LF_OFF_OB + LJ_T * 2;           // uint2[256]
+constexpr uint32_t LF_OFF_LIST = LF_OFF_SM + LJ_T * 8;         // u16[256]
+constexpr uint32_t LF_OFF_MISC = LF_OFF_LIST + LJ_T * 2;       // u32[64]
+constexpr uint32_t LF_OFF_SIDE = LF_OFF_MISC + 64 * 4;
+constexpr uint32_t LF_LDS_BYTES = LF_OFF_SIDE + LF_NSIDE * LF_SIDE_STRIDE;
+// after the records are dead: the row table (E and D / C of the rows that start here)
+constexpr uint32_t LF_OFF_ROWE = LF_OFF_REC;                   // uint2[LF_RMAX]
+constexpr uint32_t LF_OFF_ROWD = LF_OFF_ROWE + LF_RMAX * 8;    // uint2[LF_RMAX]
+static_assert(LF_OFF_ROWD + LF_RMAX * 8 <= LF_OFF_MISC, "the row table fits over the records");
+static_assert(LF_OFF_B % 16 == 0 && LF_OFF_SIDE % 16 == 0, "16-byte aligned regions");
+static_assert(LF_BW * LJ_T * 4 >= 64 * LF_MAXSYM * 2, "a wavefront's pixels fit the image's place");
+static_assert(4 * ((LF_LDS_BYTES + 1279) / 1280) * 1280 <= 160 * 1024, "four workgroups per CU");
+
+// misc[] indices
+enum : int {
+  M_WCNT = 0,   // [4] symbols per wavefront
+  M_WSUM = 4,   // [8] difference sums per wavefront (uint2 x 4)
+  M_LIST = 12,  // re-decode list length
+  M_TICKET = 13,
+  M_BASE = 14,  // index of the workgroup's first symbol
+  M_PRED = 15,  // predecessor's exit state
+  M_SLOW = 16,  // != 0: give the stream to the slow path
+  M_DUMP = 17,  // lanes that dump their registers (row table)
+  M_TIN = 18,   // [2] T_in
+  M_VIN = 20,   // [2] Vc_in
+  M_RSUM = 22,  // [8] row scan: per-wavefront totals (uint2 x 4)
+  M_LB1 = 30,   // [8] the LOCAL record (a, v) / (T_out, Vc_out)
+  M_NSIDE = 38, // side-buffer entries handed out
+};
+
+struct FastLds {
+  uint8_t* base;
+  uint32_t* B;
+  uint32_t* rec;
+  uint16_t* ob;
+  uint2* sm;
+  uint16_t* list;
+  uint32_t* misc;
+  uint8_t* side;
+  uint2* rowE;
+  uint2* rowD;
+  const TabLds10* tab10;
+};
+
+__device__ __forceinline__ FastLds carve_fast(uint8_t* smem) {
+  FastLds f;
+  f.base = smem;
+  f.B = reinterpret_cast<uint32_t*>(smem + LF_OFF_B);
+  f.rec = reinterpret_cast<uint32_t*>(smem + LF_OFF_REC);
+  f.ob = reinterpret_cast<uint16_t*>(smem + LF_OFF_OB);
+  f.sm = reinterpret_cast<uint2*>(smem + LF_OFF_SM);
+  f.list = reinterpret_cast<uint16_t*>(smem + LF_OFF_LIST);
+  f.misc = reinterpret_cast<uint32_t*>(smem + LF_OFF_MISC);
+  f.side = smem + LF_OFF_SIDE;
+  f.rowE = reinterpret_cast<uint2*>(smem + LF_OFF_ROWE);
+  f.rowD = reinterpret_cast<uint2*>(smem + LF_OFF_ROWD);
+  f.tab10 = reinterpret_cast<const TabLds10*>(smem + LF_OFF_TAB10);
+  return f;
+}
+
+typedef uint32_t lf_u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) lf_u32x2* lds_u2p;
+typedef __attribute__((address_space(3))) uint16_t* lds_u16w;
+typedef __attribute__((address_space(3))) uint32_t* lds_u32w;
+
+// a value every lane holds (read from LDS after a barrier): tell the compiler, so that
+// what is derived from it lives in SGPRs
+__device__ __forceinline__ uint32_t uni(uint32_t x) {
+  return uint32_t(__builtin_amdgcn_readfirstlane(int(x)));
+}
+
+__device__ __forceinline__ uint32_t pack16(uint32_t lo, uint32_t hi) {
+  return __builtin_amdgcn_perm(hi, lo, 0x05040100u); // {hi[15:0], lo[15:0]}
+}
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t x, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o, 64);
+    if (lane >= o)
+      x += y;
+  }
+  return x;
+}
+__device__ __forceinline__ uint2 wave_scan_pk2(uint2 x, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint2 y = make_uint2(__shfl_up(x.x, o, 64), __shfl_up(x.y, o, 64));
+    if (lane >= o)
+      x = pk_add2(x, y);
+  }
+  return x;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    x += __shfl_xor(x, o, 64);
+  return x;
+}
+// 16-bit field q (0..3) of a packed uint2
+__device__ __forceinline__ uint32_t fld(uint2 v, uint32_t q) {
+  return (((q & 2u) ? v.y : v.x) >> (16u * (q & 1u))) & 0xFFFFu;
+}
+// the fields whose flag bit is set, as 16-bit masks
+__device__ __forceinline__ uint2 fld_mask(uint32_t flags) {
+  return make_uint2(((flags & 1u) ? 0xFFFFu : 0u) | ((flags & 2u) ? 0xFFFF0000u : 0u),
+                    ((flags & 4u) ? 0xFFFFu : 0u) | ((flags & 8u) ? 0xFFFF0000u : 0u));
+}
+__device__ __forceinline__ uint2 sel2(uint2 m, uint2 x, uint2 y) { // m ? x : y, field-wise
+  return make_uint2((x.x & m.x) | (y.x & ~m.x), (x.y & m.y) | (y.y & ~m.y));
+}
+
+// ---- look-back granules ----------------------------------------------------------
+typedef unsigned long long u64;
+__device__ __forceinline__ void lb_store(u64* p, u64 v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 lb_load(const u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// word 0: status (2 bits: 1 LOCAL, 2 FINAL) | assumed entry (6) | exit (6 + error bit) |
+// symbols (16) | inclusive symbol base (32, FINAL only)
+constexpr u64 LB0_LOCAL = 1, LB0_FINAL = 2;
+__device__ __forceinline__ uint32_t st_to7(uint32_t st) {
+  return (st & ST_OFF_MASK) | ((st & ST_ERR) ? 64u : 0u);
+}
+__device__ __forceinline__ uint32_t st_from7(uint32_t v) {
+  return (v & 64u) ? ST_ERR : (v & 63u);
+}
+__device__ __forceinline__ u64 lb0_make(u64 status, uint32_t assumed, uint32_t exit7,
+                                        uint32_t cnt, uint32_t incl) {
+  return status | (u64(assumed & 63u) << 2) | (u64(exit7 & 127u) << 8) | (u64(cnt & 0xFFFFu) << 15) |
+         (u64(incl) << 32);
+}
+// words 1..8: bit 63 valid | flags (8 bits at 32) | payload (two 16-bit fields)
+constexpr u64 LB_VALID = 1ull << 63;
+
+// ---------------------------------------------------------------------------
+// The fast loops.  LUT entry (uint2; built by ljpeg_build_fast_table):
+//   x: bits 0..4  shift that right-aligns the symbol's difference bits (32 - total)
+//      bits 5..10 total bits of the symbol, i.e. 32 * total at bit 0
+//      bit 31     special: code longer than 10 bits, invalid code, SSSS = 16
+//   y: 2^SSSS - 1
+// ---------------------------------------------------------------------------
+struct FastState {
+  uint32_t Pn;   // -32 * pos - 32
+  uint32_t n;    // symbols decoded
+  uint32_t acc[4];
+  uint32_t ev;   // running sum after the last even-numbered symbol
+};
+
+template <int N, int K>
+__device__ __forceinline__ void lf_step(FastState& s, uint32_t vbase) {
+  const uint32_t ad = vbase + (s.Pn & ~1023u);
+  const uint32_t d1 = *(lds_u32p)(ad), d0 = *(lds_u32p)(ad + 4u * LJ_T);
+  const uint32_t w = __builtin_amdgcn_alignbit(d0, d1, s.Pn >> 5);
+  const lf_u32x2 e = *(lds_u2p)((w >> 19) & 0x1FF8u);
+  const uint32_t v = (w >> (e.x & 31u)) & e.y;
+  // JPEG EXTEND without a shift left: u = all - v; t = u - v < 0 iff the top
+  // difference bit is set (positive difference): diff = v, else v - all
+  const uint32_t u = e.y - v;
+  const uint32_t m = uint32_t(int32_t(u - v) >> 31);
+  s.acc[K % N] += (e.y & m) - u;
+  s.Pn -= (e.x & 0x800007E0u);
+  s.n += 1;
+}
+
+template <int N, int K, int KEND>
+struct LfChain {
+  static __device__ __forceinline__ void run(FastState& s, uint32_t vbase, uint32_t pend,
+                                             uint32_t (&R)[LF_NR], int qbase) {
+    if (s.Pn > pend) {
+      lf_step<N, K>(s, vbase);
+      if ((K & 1) == 0)
+        s.ev = s.acc[K % N];
+      else
+        R[qbase + (K >> 1)] = pack16(s.ev, s.acc[K % N]);
+      if constexpr (K + 1 < KEND)
+        LfChain<N, K + 1, KEND>::run(s, vbase, pend, R, qbase);
+    }
+  }
+};
+
+template <int N, int G>
+__device__ __forceinline__ void lf_groups(FastState& s, uint32_t vbase, uint32_t pend,
+                                          uint32_t (&R)[LF_NR]) {
+  if (__any(s.Pn > pend)) {
+    LfChain<N, 0, 8>::run(s, vbase, pend, R, 4 * G);
+    if constexpr (G + 1 < LF_MAXSYM / 8)
+      lf_groups<N, G + 1>(s, vbase, pend, R);
+  }
+}
+
+// warm-up: where the parse of a slot from bit 0 ends (offset into the next slot)
+__device__ __forceinline__ uint32_t lf_warmup(uint32_t vbase, uint32_t end_bits, bool enabled) {
+  uint32_t Pn = uint32_t(-32);
+  const uint32_t pend = uint32_t(-32) - 32u * end_bits;
+  if (enabled) {
+    while (Pn > pend) {
+      const uint32_t ad = vbase + (Pn & ~1023u);
+      const uint32_t d1 = *(lds_u32p)(ad), d0 = *(lds_u32p)(ad + 4u * LJ_T);
+      const uint32_t w = __builtin_amdgcn_alignbit(d0, d1, Pn >> 5);
+      const uint32_t e0 = *(lds_u32p)((w >> 19) & 0x1FF8u);
+      Pn -= (e0 & 0x7E0u);
+    }
+  }
+  return (pend - Pn) >> 5;
+}
+
+// lj_slow_entry, inlined: a CALL while 64 VGPRs of running sums are live makes the
+// register allocator park half of them in scratch (the ABI's caller-saved registers)
+__device__ __forceinline__ uint32_t lf_slow_entry(uint32_t w, const TabLds10& tb) {
+  uint32_t r = 0;
+  for (uint32_t l = 11; l <= tb.max_len && r == 0u; ++l) {
+    const uint32_t c = w >> (32 - l);
+    const uint32_t mc = tb.max_code[l];
+    if (mc != NO_CODE && c <= mc) {
+      const uint32_t ssss = tb.values[(c - tb.val_offset[l]) & 0xFFFFu];
+      const uint32_t extra = ssss == 16u ? (tb.fix16 ? 16u : 0u) : ssss;
+      r = l | (ssss << 5) | ((l + extra) << 10);
+    }
+  }
+  return r;
+}
+
+// The general loop (re-decodes): any code length, SSSS = 16, invalid codes; running
+// sums of every symbol into the lane's side-buffer entry.  Window of the DELAYED image:
+// stream bit p is image bit p + 1.
+template <int N>
+__device__ __forceinline__ void lf_careful(const FastLds& F, bool long_codes, int col,
+                                           uint32_t start, uint32_t end_bits, uint32_t side_addr,
+                                           bool enabled, uint32_t& exit, uint32_t& count,
+                                           uint2& sums, bool& overflow) {
+  uint32_t pos = start & ST_OFF_MASK;
+  bool ok = !(start & ST_ERR);
+  if (!ok || !enabled)
+    end_bits = 0;
+  const TabLds10& tb = *F.tab10;
+  uint32_t n = 0, a0 = 0, a1 = 0;
+  bool live = pos < end_bits;
+  while (__any(live)) {
+    const uint32_t w = lj_window<LF_BW>(F.B, col, pos + 1u);
+    uint32_t e = tb.lut[w >> 22];
+    if (long_codes && __any(live && (e & 31u) == 0u)) {
+      if (live && (e & 31u) == 0u)
+        e = lf_slow_entry(w, tb);
+    }
+    const bool good = live && e != 0u;
+    const uint32_t d = good ? lj_extend(w, e) : 0u;
+    const uint32_t sh = 16u * (n & 1u);
+    uint32_t val;
+    if (N == 1) {
+      a0 = (a0 + d) & 0xFFFFu;
+      val = a0;
+    } else if (N == 2) {
+      a0 = pk_add(a0, d << sh);
+      val = (a0 >> sh) & 0xFFFFu;
+    } else {
+      if (n & 2u)
+        a1 = pk_add(a1, d << sh);
+      else
+        a0 = pk_add(a0, d << sh);
+      val = (((n & 2u) ? a1 : a0) >> sh) & 0xFFFFu;
+    }
+    if (good) {
+      if (n < uint32_t(LF_MAXSYM))
+        *(lds_u16w)(side_addr + 2u * n) = uint16_t(val);
+      else
+        overflow = true;
+    }
+    pos += good ? (e >> 10) : 0u;
+    n += good ? 1u : 0u;
+    if (live && !good) {
+      ok = false;
+      end_bits = 0;
+    }
+    live = pos < end_bits;
+  }
+  if (!enabled)
+    return;
+  exit = ok ? (pos - end_bits) : ST_ERR;
+  count = n;
+  sums = make_uint2(a0, a1);
+}
+
+// ---------------------------------------------------------------------------
+// Look-back 0 (wavefront 0): exit state of the predecessor and the index of the
+// workgroup's first symbol.  A LOCAL record counts when its assumed entry is its own
+// predecessor's exit; otherwise its owner is re-converging and will publish FINAL.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool lb0_walk(const LjArgs& a, uint32_t b, uint32_t first_block,
+                                         uint32_t start_bit, int lane, uint32_t* pred_exit,
+                                         uint32_t* base_out) {
+  const u64* A = a.lb;
+  const u64 virt = lb0_make(LB0_FINAL, 0, st_to7(start_bit), 0, 0);
+  uint32_t acc = 0;
+  int64_t pos = int64_t(b) - 1;
+  bool have_pred = false;
+  for (uint32_t spins = 0; spins < LF_SPIN_LIMIT; ++spins) {
+    const int64_t idx = pos - lane;
+    const u64 r = idx >= int64_t(first_block) ? lb_load(A + size_t(idx) * LF_LB_WORDS) : virt;
+    const u64 rp =
+        idx - 1 >= int64_t(first_block) ? lb_load(A + size_t(idx - 1) * LF_LB_WORDS) : virt;
+    const uint32_t st = uint32_t(r & 3u), stp = uint32_t(rp & 3u);
+    const uint32_t cnt = uint32_t(r >> 15) & 0xFFFFu, assumed = uint32_t(r >> 2) & 63u;
+    const uint32_t exitp = uint32_t(rp >> 8) & 127u;
+    if (!have_pred) {
+      const uint32_t st0 = __shfl(st, 0, 64);
+      if (st0 == 0) {
+        __builtin_amdgcn_s_sleep(2);
+        continue;
+      }
+      *pred_exit = st_from7(__shfl(uint32_t(r >> 8) & 127u, 0, 64));
+      have_pred = true;
+    }
+    const bool fin = st == 2;
+    // (an error exit is not propagated: the successor keeps its own guess -- the stream
+    // is damaged and goes to the slow path anyway)
+    const bool ok = st == 1 && stp != 0 && (assumed == (exitp & 63u) || (exitp & 64u));
+    const u64 m_ok = __ballot(ok), m_fin = __ballot(fin);
+    const int f = (~m_ok) ? __builtin_ctzll(~m_ok) : 64;
+    const uint32_t part = wave_sum_u32(lane < f ? cnt : 0u);
+    if (f == 64) {
+      acc += part;
+      pos -= 64;
+      continue;
+    }
+    if ((m_fin >> f) & 1ull) {
+      const uint32_t incl = __shfl(uint32_t(r >> 32), f, 64);
+      *base_out = incl + part + acc;
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return false;
+}
+
+// transfer of the predictor state over a run of symbols: T' = f ? Vc + a : T + a,
+// Vc' = Vc + v (field-wise; f as 16-bit masks)
+struct Xfer {
+  uint2 f, a, v;
+};
+// first h, then g
+__device__ __forceinline__ Xfer xfer_compose(const Xfer& h, const Xfer& g) {
+  Xfer r;
+  r.f = make_uint2(h.f.x | g.f.x, h.f.y | g.f.y);
+  r.a = pk_add2(g.a, sel2(g.f, h.v, h.a));
+  r.v = pk_add2(h.v, g.v);
+  return r;
+}
+
+// Look-back 1 (wavefront 0): the predictor state (T, Vc) before the workgroup.
+template <int N>
+__device__ __forceinline__ bool lb1_walk(const LjArgs& a, uint32_t b, uint32_t first_block,
+                                         uint2 init, int lane, uint2* T_in, uint2* V_in) {
+  constexpr int NW = (N + 1) / 2;
+  const u64* A = a.lb;
+  Xfer g; // the blocks nearer than the window, composed
+  g.f = g.a = g.v = make_uint2(0, 0);
+  int64_t pos = int64_t(b) - 1;
+  for (uint32_t spins = 0; spins < LF_SPIN_LIMIT; ++spins) {
+    const int64_t idx = pos - lane;
+    const bool real = idx >= int64_t(first_block);
+    u64 w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      w[k] = 0;
+    if (real) {
+      const u64* p = A + size_t(idx) * LF_LB_WORDS + 1;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        w[k] = lb_load(p + k);         // a
+        w[2 + k] = lb_load(p + 2 + k); // v
+        w[4 + k] = lb_load(p + 4 + k); // T
+        w[6 + k] = lb_load(p + 6 + k); // Vc
+      }
+    }
+    bool loc = true, pre = true;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      loc = loc && (w[k] & LB_VALID) && (w[2 + k] & LB_VALID);
+      pre = pre && (w[4 + k] & LB_VALID) && (w[6 + k] & LB_VALID);
+    }
+    if (!real) { // before the stream: the initial predictors
+      pre = true;
+      loc = false;
+    }
+    const u64 m_pre = __ballot(pre), m_loc = __ballot(loc && !pre);
+    // lanes 0 .. f-1 LOCAL, lane f PREFIX
+    const int f = m_pre ? __builtin_ctzll(m_pre) : 64;
+    const u64 need = f == 64 ? ~0ull : ((1ull << f) - 1ull);
+    if ((m_loc & need) != need) {
+      __builtin_amdgcn_s_sleep(2);
+      continue;
+    }
+    Xfer mine;
+    mine.a = make_uint2(uint32_t(w[0]), uint32_t(w[1]));
+    mine.v = make_uint2(uint32_t(w[2]), uint32_t(w[3]));
+    mine.f = fld_mask(uint32_t(w[0] >> 32) & 0xFu);
+    // fold the LOCAL transfers, nearest first: g = g o h_l
+    const int nl = f == 64 ? 64 : f;
+    for (int l = 0; l < nl; ++l) {
+      Xfer h;
+      h.a = make_uint2(__shfl(mine.a.x, l, 64), __shfl(mine.a.y, l, 64));
+      h.v = make_uint2(__shfl(mine.v.x, l, 64), __shfl(mine.v.y, l, 64));
+      h.f = make_uint2(__shfl(mine.f.x, l, 64), __shfl(mine.f.y, l, 64));
+      g = xfer_compose(h, g);
+    }
+    if (f == 64) {
+      pos -= 64;
+      continue;
+    }
+    uint2 T = make_uint2(uint32_t(w[4]), uint32_t(w[5]));
+    uint2 V = make_uint2(uint32_t(w[6]), uint32_t(w[7]));
+    if (!real)
+      T = V = init;
+    T = make_uint2(__shfl(T.x, f, 64), __shfl(T.y, f, 64));
+    V = make_uint2(__shfl(V.x, f, 64), __shfl(V.y, f, 64));
+    *T_in = pk_add2(g.a, sel2(g.f, V, T));
+    *V_in = pk_add2(V, g.v);
+    return true;
+  }
+  return false;
+}
+
+__device__ __forceinline__ void strip_divmod(uint64_t off, uint32_t w, uint32_t* row,
+                                             uint32_t* col) {
+  if ((off >> 32) == 0) {
+    const uint32_t o = uint32_t(off), q = o / w;
+    *row = q;
+    *col = o - q * w;
+  } else {
+    *row = uint32_t(off / w);
+    *col = uint32_t(off % w);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Copy-out: the staged running sums of stream symbols [A0, A1) (LDS, stream order from
+// byte address sb) -> image, run by run, 16-byte chunks on the destination's grid.
+// ---------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void lf_copy_out(const FastLds& F, const LjArgs& a,
+                                            const LjStreamDev& S, uint32_t A0, uint32_t A1,
+                                            uint32_t sb, uint32_t r0, int tid) {
+  const uint32_t RS = S.row_samples;
+  uint8_t* img = a.out_base + S.img_offset;
+  uint32_t i = A0;
+  uint32_t z = 0; // current CR2 strip
+  while (i < A1) {
+    const uint32_t r = i / RS, sidx = i - r * RS;
+    uint8_t* dst = nullptr;
+    uint32_t pend;
+    if (S.kind == 0) {
+      const uint32_t keep = S.keep_samples < RS ? S.keep_samples : RS;
+      if (sidx < keep) {
+        pend = r * RS + keep;
+        dst = img + uint64_t(S.out_y + r) * S.img_pitch + 2u * (S.out_x + sidx);
+      } else {
+        pend = (r + 1) * RS; // trailing MCUs of the frame that the tile does not keep
+      }
+    } else {
+      const Cr2Strip* st = a.strips + S.strip_base;
+      while (z + 1 < S.n_strips && uint64_t(i) >= st[z + 1].first_sample)
+        ++z;
+      uint32_t srow, col;
+      strip_divmod(uint64_t(i) - st[z].first_sample, st[z].w, &srow, &col);
+      const uint32_t in_strip = st[z].w - col, in_row = RS - sidx;
+      pend = i + (in_strip < in_row ? in_strip : in_row);
+      dst = img + uint64_t(st[z].y0 + srow) * S.img_pitch + 2u * (st[z].x0 + col);
+    }
+    if (pend > A1)
+      pend = A1;
+    const uint32_t n = pend - i;
+    if (dst) {
+      const uint2 Cv = F.rowE[r - r0];
+      const uint2 C = make_uint2(uni(Cv.x), uni(Cv.y));
+      const uint32_t delta = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u) >> 1;
+      const uint32_t ph0 = (i + 8u - delta) & uint32_t(N - 1);
+      uint32_t cd[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        cd[t] = fld(C, (ph0 + 2u * t) & uint32_t(N - 1)) |
+                (fld(C, (ph0 + 2u * t + 1u) & uint32_t(N - 1)) << 16);
+      const uint32_t nch = (delta + n + 7u) >> 3;
+      const uint32_t lds0 = sb + 2u * (i - A0) - 2u * delta;
+      const uint32_t sh = 8u * (lds0 & 2u); // the staged samples start mid-dword: 16, else 0
+      uint8_t* d0 = dst - 2u * delta;
+      for (uint32_t m = uint32_t(tid); m < nch; m += uint32_t(LJ_T)) {
+        const int32_t sf = int32_t(8u * m) - int32_t(delta);
+        const uint32_t la = (lds0 + 16u * m) & ~3u;
+        uint32_t dw[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+          dw[t] = *(lds_u32p)(la + 4u * t);
+        uint32_t o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          o[t] = pk_add(__builtin_amdgcn_alignbit(dw[t + 1], dw[t], sh), cd[t]);
+        uint8_t* p = d0 + 16u * m;
+        if (sf >= 0 && uint32_t(sf) + 8u <= n) {
+          *reinterpret_cast<uint4*>(p) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const int32_t q = sf + t;
+            if (q >= 0 && uint32_t(q) < n)
+              reinterpret_cast<uint16_t*>(p)[t] = uint16_t(o[t >> 1] >> (16 * (t & 1)));
+          }
+        }
+      }
+    }
+    i = pend;
+  }
+}
+
+// Staging of a lane's register pairs q < nq (static register indices; groups of four
+// pairs are skipped wave-uniformly once nobody has any left)
+template <int Q4>
+__device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad, uint32_t nq,
+                                         uint32_t nqmax, uint32_t k0, uint32_t k1) {
+  if (uint32_t(4 * Q4) < nqmax) { // (wave-uniform)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int q = 4 * Q4 + u;
+      if (uint32_t(q) < nq) {
+        const uint32_t v = pk_add(R[q], (q & 1) ? k1 : k0);
+        *(lds_u16w)(ad + 4u * q) = uint16_t(v);
+        *(lds_u16w)(ad + 4u * q + 2u) = uint16_t(v >> 16);
+      }
+    }
+    if constexpr (Q4 + 1 < LF_NR / 4)
+      lf_stage<Q4 + 1>(R, ad, nq, nqmax, k0, k1);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The kernel
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const FastLds F = carve_fast(smem);
+  const int j = threadIdx.x, lane = j & 63, wv = j >> 6;
+  if (j == 0)
+    F.misc[M_TICKET] = atomicAdd(&a.tickets[N == 4 ? 2 : N - 1], 1u);
+  __syncthreads();
+  const uint32_t b = uni(F.misc[M_TICKET]);
+  const uint32_t s = a.block_stream[b];
+  const LjStreamDev& S = a.streams[s];
+  if (!S.fast || int(S.direct) != N)
+    return; // (workgroup-uniform)
+  const uint32_t lb = b - S.first_block;
+
+  // tables + image
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(a.fast_tabs + size_t(S.table_base) * 1024);
+    uint4* dst = reinterpret_cast<uint4*>(smem + LF_OFF_LUT);
+    dst[j] = src[j];
+    dst[j + LJ_T] = src[j + LJ_T];
+  }
+  Lds L{};
+  L.tabs = reinterpret_cast<TabLds*>(smem + LF_OFF_TAB10);
+  L.B = F.B;
+  L.ob = F.ob;
+  lj_stage_tables10(L, a, S);
+  if (j == 0) {
+    F.misc[M_SLOW] = 0;
+    F.misc[M_DUMP] = 0;
+    F.misc[M_NSIDE] = 0;
+  }
+  lj_load_image<LF_BW, true>(L, a, b, j); // ends with a barrier
+  // delay the lane's column by one bit (see the header): dword k := d[k-1] : d[k] >> 1
+  {
+    uint32_t prev = 0;
+#pragma unroll
+    for (int k = 0; k < LF_BW; ++k) {
+      uint32_t* p = &F.B[(LF_BW - 1 - k) * LJ_T + j];
+      const uint32_t d = *p;
+      *p = __builtin_amdgcn_alignbit(prev, d, 1);
+      prev = d;
+    }
+  }
+  __syncthreads();
+  const uint32_t own_bits = F.ob[j];
+  const bool long_codes = F.tab10->max_len > 10;
+  // LDS address of the row of dword 0 of a column
+  const uint32_t vbase_own = lds_addr(&F.B[(LF_BW - 1) * LJ_T + j]);
+
+  // 1. warm-up: slot j-1 from bit 0 (j == 0 has no predecessor slot here)
+  const uint32_t guess = lf_warmup(vbase_own - 4u, j >= 1 ? uint32_t(F.ob[j >= 1 ? j - 1 : 0]) : 0u,
+                                   j >= 1 && F.ob[j >= 1 ? j - 1 : 0] != 0);
+  uint32_t start = guess & ST_OFF_MASK;
+  if (j == 1 && lb == 0)
+    start = S.start_bit;
+
+  // 2. decode, keeping the running sums
+  uint32_t R[LF_NR];
+  FastState fs;
+  fs.Pn = uint32_t(-32) - 32u * start;
+  fs.n = 0;
+  fs.acc[0] = fs.acc[1] = fs.acc[2] = fs.acc[3] = 0;
+  fs.ev = 0;
+  const uint32_t pend = uint32_t(-32) - 32u * own_bits;
+  if (j == 0)
+    fs.Pn = pend; // (slot 0 belongs to the previous workgroup: nothing to decode)
+  lf_groups<N, 0>(fs, vbase_own, pend, R);
+  bool need_redo = false;
+  {
+    const bool special = !(fs.Pn & 0x80000000u);
+    const bool over = !special && fs.Pn > pend; // more than LF_MAXSYM symbols
+    uint32_t ex = special ? ST_ERR : ((pend - fs.Pn) >> 5);
+    if (over) {
+      ex = ST_ERR;
+      F.misc[M_SLOW] = 1;
+    }
+    need_redo = special;
+    if (j >= 1)
+      F.rec[j] = rec_make(start, ex, fs.n);
+    F.sm[j] = make_uint2(pack16(fs.acc[0], fs.acc[1]), pack16(fs.acc[2], fs.acc[3]));
+  }
+  __syncthreads();
+  // slot 0 stands for the workgroup's entry state: its "exit" is what lane 1 assumed
+  if (j == 0)
+    F.rec[0] = rec_make(0, rec_su(F.rec[1]), 0);
+
+  const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1); // j >= 1
+  uint32_t my_cnt = 0, before = 0, cnt_wg = 0, base = 0;
+  uint2 my_sums = make_uint2(0, 0), pex = make_uint2(0, 0), S_wg = make_uint2(0, 0);
+  uint32_t published_exit = 0;
+  // Subsequences that are re-decoded get a side-buffer entry of their own for the rest
+  // of the kernel and their owners fetch the sums ONCE, after all rounds: a fetch inside
+  // the loops makes every register of R loop-carried, and the compiler then keeps two
+  // copies of the 64 (measured: 180 VGPRs).
+  int my_entry = -1;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    // 3. Jacobi rounds with a dense list (lj_sync_kernel's scheme)
+    uint32_t rounds = 0;
+    while (true) {
+      if (j == 0)
+        F.misc[M_LIST] = 0;
+      __syncthreads();
+      const uint32_t my_su = rec_su(F.rec[j]);
+      const uint32_t want = j >= 1 ? rec_st(F.rec[j - 1]) : my_su;
+      const bool chained = own_bits != 0u && j >= 1;
+      const bool listed = chained && (need_redo || (want != my_su && !(want & ST_ERR)));
+      if (listed) {
+        if (my_entry < 0)
+          my_entry = int(atomicAdd(&F.misc[M_NSIDE], 1u));
+        if (my_entry < LF_NSIDE)
+          F.list[atomicAdd(&F.misc[M_LIST], 1u)] = uint16_t(j | (my_entry << 8));
+      }
+      need_redo = false;
+      __syncthreads();
+      const uint32_t nl = uni(F.misc[M_LIST]);
+      if (uni(F.misc[M_NSIDE]) > uint32_t(LF_NSIDE)) {
+        if (j == 0)
+          F.misc[M_SLOW] = 1; // more re-decodes than the side buffer has entries
+      }
+      if (nl == 0)
+        break;
+      if (++rounds > LF_MAX_ROUNDS) {
+        if (j == 0)
+          F.misc[M_SLOW] = 1; // periodic data: not this kernel's business
+        break;
+      }
+      uint32_t idx = 1, w = 0, e = 0, c = 0;
+      uint2 sums = make_uint2(0, 0);
+      bool ovf = false;
+      const bool mine = wv == 0 && uint32_t(lane) < nl; // (nl <= LF_NSIDE <= 64)
+      if (wv == 0) {
+        const uint32_t le = mine ? uint32_t(F.list[lane]) : 1u;
+        idx = le & 0xFFu;
+        w = rec_st(F.rec[idx - 1]);
+        if (w & ST_ERR) // (listed for its own sake: from the state it started from)
+          w = rec_su(F.rec[idx]) & ST_OFF_MASK;
+        lf_careful<N>(F, long_codes, int(idx), w, F.ob[idx],
+                      lds_addr(F.side) + (le >> 8) * LF_SIDE_STRIDE, mine, e, c, sums, ovf);
+      }
+      __syncthreads(); // every read of the records precedes the updates
+      if (mine) {
+        F.rec[idx] = rec_make(w, e, c > 0xFFFu ? 0xFFFu : c);
+        F.sm[idx] = sums;
+        if (ovf)
+          F.misc[M_SLOW] = 1;
+      }
+    }
+
+    // per slot: symbols before it, running sums before it (workgroup-relative phases)
+    const uint32_t my_rec = F.rec[j];
+    my_cnt = j >= 1 ? rec_cn(my_rec) : 0u;
+    if (my_cnt > uint32_t(LF_MAXSYM))
+      my_cnt = uint32_t(LF_MAXSYM); // (flagged slow already)
+    my_sums = j >= 1 ? F.sm[j] : make_uint2(0u, 0u);
+    if (N == 1)
+      my_sums = make_uint2(my_sums.x & 0xFFFFu, 0u);
+    if (N == 2)
+      my_sums.y = 0u;
+    const uint32_t incl = wave_scan_u32(my_cnt, lane);
+    if (lane == 63)
+      F.misc[M_WCNT + wv] = incl;
+    __syncthreads();
+    before = incl - my_cnt;
+    for (int w = 0; w < wv; ++w)
+      before += F.misc[M_WCNT + w];
+    cnt_wg = uni(F.misc[M_WCNT] + F.misc[M_WCNT + 1] + F.misc[M_WCNT + 2] + F.misc[M_WCNT + 3]);
+    {
+      const uint2 r = lj_rot_fields<N>(my_sums, before & uint32_t(N - 1));
+      const uint2 pincl = wave_scan_pk2(r, lane);
+      if (lane == 63) {
+        F.misc[M_WSUM + 2 * wv] = pincl.x;
+        F.misc[M_WSUM + 2 * wv + 1] = pincl.y;
+      }
+      __syncthreads();
+      pex = pk_sub2(pincl, r);
+      S_wg = make_uint2(0, 0);
+      for (int w = 0; w < 4; ++w) {
+        const uint2 t = make_uint2(uni(F.misc[M_WSUM + 2 * w]), uni(F.misc[M_WSUM + 2 * w + 1]));
+        if (w < wv)
+          pex = pk_add2(pex, t);
+        S_wg = pk_add2(S_wg, t);
+      }
+    }
+    const uint32_t exit_now = uni(rec_st(F.rec[LJ_T - 1]));
+    const uint32_t entry_now = uni(rec_st(F.rec[0]));
+
+    // 4. look-back 0
+    if (attempt == 0) {
+      published_exit = exit_now;
+      if (lb == 0) {
+        base = 0;
+        break;
+      }
+      if (j == 0)
+        lb_store(a.lb + size_t(b) * LF_LB_WORDS,
+                 lb0_make(LB0_LOCAL, entry_now, st_to7(exit_now), cnt_wg, 0));
+      if (wv == 0) {
+        uint32_t pe = 0, bs = 0;
+        const bool ok = lb0_walk(a, b, S.first_block, S.start_bit, lane, &pe, &bs);
+        if (lane == 0) {
+          F.misc[M_PRED] = pe;
+          F.misc[M_BASE] = bs;
+          if (!ok)
+            F.misc[M_SLOW] = 1;
+        }
+      }
+      __syncthreads();
+      base = uni(F.misc[M_BASE]);
+      const uint32_t pe = uni(F.misc[M_PRED]);
+      if (pe == entry_now || (pe & ST_ERR))
+        break;
+      // the assumed entry was wrong: re-converge from the true one
+      if (j == 0)
+        F.rec[0] = rec_make(0, pe, 0);
+      // (the barrier at the top of the rounds orders this store)
+    } else {
+      if (exit_now != published_exit && j == 0)
+        F.misc[M_SLOW] = 1; // successors may have used the exit published first
+    }
+  }
+  if (__any(my_entry >= 0 && my_entry < LF_NSIDE)) {
+    if (my_entry >= 0 && my_entry < LF_NSIDE) {
+      // (dword by dword: a uint4 view turns R into 16 vectors for the compiler)
+      const uint32_t sa = lds_addr(F.side) + uint32_t(my_entry) * LF_SIDE_STRIDE;
+#pragma unroll
+      for (int q = 0; q < LF_NR; ++q)
+        R[q] = *(lds_u32p)(sa + 4u * q);
+    }
+  }
+  // FINAL: from here on successors stop at this record
+  if (j == 0)
+    lb_store(a.lb + size_t(b) * LF_LB_WORDS,
+             lb0_make(LB0_FINAL, rec_st(F.rec[0]), st_to7(published_exit), cnt_wg, base + cnt_wg));
+
+  // records the per-stream bookkeeping kernels read (lj_scan_kernel, lj_consumed_kernel)
+  {
+    const uint32_t my_rec = F.rec[j];
+    if (j >= 1)
+      a.sub_state[gsub] = rec_st(my_rec) | (rec_cn(my_rec) << 16);
+    if (j == 0) {
+      a.block_start[b] = rec_st(F.rec[0]);
+      a.block_exit[b] = published_exit;
+      a.block_sum[b] = cnt_wg;
+      a.block_flags[b] = 0;
+      a.block_psum[b] = S_wg;
+    }
+  }
+  const uint64_t needed = S.needed;
+  const uint32_t i0 = base + before; // index of the lane's first symbol
+  uint32_t cnt_eff = my_cnt;
+  if (uint64_t(i0) >= needed)
+    cnt_eff = 0;
+  else if (uint64_t(i0) + cnt_eff > needed)
+    cnt_eff = uint32_t(needed - i0);
+  const uint32_t my_start = rec_su(F.rec[j]), my_exit = rec_st(F.rec[j]);
+  // an invalid code inside the delivered range: the slow path reports it the
+  // reference's way (PrefixCodeLookupDecoder.h:152-155)
+  if (j >= 1 && (my_exit & ST_ERR) && uint64_t(i0) + my_cnt < needed && own_bits != 0)
+    F.misc[M_SLOW] = 1;
+  // lj_consumed_kernel needs the bit position at which the reference's last symbol
+  // starts: exactly one lane of the stream owns it and walks there again
+  if (needed >= 1 && needed - 1 >= i0 && needed - 1 < uint64_t(i0) + my_cnt && j >= 1) {
+    const uint32_t target = uint32_t(needed - 1 - i0);
+    uint32_t p2 = my_start & ST_OFF_MASK;
+    const TabLds10& tb = *F.tab10;
+    for (uint32_t t = 0; t < target; ++t) {
+      const uint32_t w = lj_window<LF_BW>(F.B, j, p2 + 1u);
+      uint32_t e = tb.lut[w >> 22];
+      if ((e & 31u) == 0u)
+        e = lf_slow_entry(w, tb);
+      p2 += e >> 10;
+    }
+    a.results[s].last_slot = lb * LJ_OWN + uint32_t(j - 1);
+    a.results[s].last_pos = p2;
+  }
+
+  // 5. rows.  Lane-relative phase p = workgroup-relative phase (before + p) mod N.
+  const uint32_t RS = S.row_samples;
+  const uint2 pexrel = lj_rot_fields<N>(pex, (uint32_t(N) - (before & uint32_t(N - 1))) & uint32_t(N - 1));
+  uint64_t lim64 = uint64_t(base) + cnt_wg;
+  if (lim64 > needed)
+    lim64 = needed;
+  const uint32_t lim = uint32_t(lim64); // symbols of the workgroup that are delivered end here
+  const bool any_out = lim > base;
+  const uint32_t r0 = base / RS;
+  const uint32_t r_end = any_out ? (lim - 1) / RS : r0;
+  const uint32_t nr = r_end - r0 + 1;
+  if (nr > uint32_t(LF_RMAX) && j == 0)
+    F.misc[M_SLOW] = 1;
+  __syncthreads(); // the records are dead: their place becomes the row table
+  const bool rows_ok = nr <= uint32_t(LF_RMAX);
+  {
+    // zero the table (a component whose first-MCU symbol is not in this workgroup has D = 0)
+    uint32_t* z = reinterpret_cast<uint32_t*>(F.rowE);
+    for (int k = j; k < LF_RMAX * 4; k += LJ_T)
+      z[k] = 0;
+  }
+  __syncthreads();
+  {
+    // first-MCU symbols of this lane: stream indices r * RS + c inside [i0, i0 + cnt_eff)
+    const uint32_t rl = i0 / RS;
+    const uint32_t ml = i0 - rl * RS;
+    // the first row whose first MCU can reach into the lane
+    uint32_t r = ml < uint32_t(N) ? rl : rl + 1;
+    const bool has = rows_ok && cnt_eff != 0 &&
+                     (ml < uint32_t(N) || uint64_t(rl + 1) * RS < uint64_t(i0) + cnt_eff);
+    int my_d = -1;
+    if (has)
+      my_d = int(atomicAdd(&F.misc[M_DUMP], 1u));
+    __syncthreads();
+    const uint32_t nd = uni(F.misc[M_DUMP]);
+    for (uint32_t d0 = 0; d0 < nd; d0 += uint32_t(LF_NSIDE)) {
+      const bool dump = my_d >= int(d0) && my_d < int(d0) + LF_NSIDE;
+      if (__any(dump)) {
+        if (dump) {
+          uint8_t* sp = F.side + size_t(my_d - int(d0)) * LF_SIDE_STRIDE;
+          const uint32_t sa = lds_addr(sp);
+#pragma unroll
+          for (int q = 0; q < LF_NR; ++q)
+            *(lds_u32w)(sa + 4u * q) = R[q];
+          // the last symbol of an odd count lives in the accumulator, not in R
+          if (my_cnt & 1u)
+            reinterpret_cast<uint16_t*>(sp)[my_cnt - 1] = uint16_t(fld(my_sums, (my_cnt - 1) & uint32_t(N - 1)));
+          const uint16_t* rv = reinterpret_cast<const uint16_t*>(sp);
+          for (; uint64_t(r) * RS < uint64_t(i0) + cnt_eff; ++r) {
+#pragma unroll
+            for (uint32_t c = 0; c < uint32_t(N); ++c) {
+              const uint64_t i = uint64_t(r) * RS + c;
+              if (i < i0 || i >= uint64_t(i0) + cnt_eff)
+                continue;
+              const uint32_t k = uint32_t(i - i0);
+              const uint32_t fv = rv[k];
+              const uint32_t pv = k >= uint32_t(N) ? uint32_t(rv[k - N]) : 0u;
+              const uint32_t E = (fld(pexrel, k & uint32_t(N - 1)) + pv) & 0xFFFFu;
+              const uint32_t D = (fv - pv) & 0xFFFFu;
+              const uint32_t t = r - r0;
+              reinterpret_cast<uint16_t*>(F.rowE)[4 * t + c] = uint16_t(E);
+              reinterpret_cast<uint16_t*>(F.rowD)[4 * t + c] = uint16_t(D);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // scan over the rows: Vloc (exclusive) and the workgroup's transfer
+  uint2 Cloc = make_uint2(0, 0), Vsum = make_uint2(0, 0);
+  {
+    const bool act = rows_ok && uint32_t(j) < nr;
+    const uint2 D = act ? F.rowD[j] : make_uint2(0u, 0u);
+    const uint2 E = act ? F.rowE[j] : make_uint2(0u, 0u);
+    const uint2 dincl = wave_scan_pk2(D, lane);
+    if (lane == 63) {
+      F.misc[M_RSUM + 2 * wv] = dincl.x;
+      F.misc[M_RSUM + 2 * wv + 1] = dincl.y;
+    }
+    __syncthreads();
+    uint2 vex = pk_sub2(dincl, D);
+    for (int w = 0; w < 4; ++w) {
+      const uint2 t = make_uint2(uni(F.misc[M_RSUM + 2 * w]), uni(F.misc[M_RSUM + 2 * w + 1]));
+      if (w < wv)
+        vex = pk_add2(vex, t);
+      Vsum = pk_add2(Vsum, t);
+    }
+    Cloc = pk_sub2(vex, E);
+    if (act)
+      F.rowE[j] = Cloc;
+  }
+  __syncthreads();
+  // the sums of the workgroup's differences by component (absolute)
+  const uint2 S_abs = lj_rot_fields<N>(S_wg, base & uint32_t(N - 1));
+  const uint2 init = make_uint2(uint32_t(S.init_pred[0]) | (uint32_t(S.init_pred[1]) << 16),
+                                uint32_t(S.init_pred[2]) | (uint32_t(S.init_pred[3]) << 16));
+  // 5b. look-back 1
+  if (wv == 0) {
+    // which components start a row here, and from which table row their last start is
+    uint32_t flags = 0;
+    uint2 al = S_abs;
+    if (rows_ok && any_out) {
+      uint32_t av[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (uint32_t c = 0; c < uint32_t(N); ++c) {
+        int tl = -1;
+        const uint64_t il = uint64_t(r_end) * RS + c;
+        if (il >= base && il < lim)
+          tl = int(nr) - 1;
+        else if (nr >= 2 && uint64_t(r_end - 1) * RS + c >= base)
+          tl = int(nr) - 2;
+        if (tl >= 0) {
+          flags |= 1u << c;
+          av[c] = (fld(F.rowE[tl], c) + fld(S_abs, c)) & 0xFFFFu;
+        } else {
+          av[c] = fld(S_abs, c);
+        }
+      }
+      al = make_uint2(av[0] | (av[1] << 16), av[2] | (av[3] << 16));
+    }
+    if (lane == 0) {
+      u64* p = a.lb + size_t(b) * LF_LB_WORDS + 1;
+      constexpr int NW = (N + 1) / 2;
+      lb_store(p + 2, LB_VALID | Vsum.x);
+      if (NW == 2)
+        lb_store(p + 3, LB_VALID | Vsum.y);
+      if (NW == 2)
+        lb_store(p + 1, LB_VALID | (u64(flags) << 32) | al.y);
+      lb_store(p + 0, LB_VALID | (u64(flags) << 32) | al.x);
+    }
+    uint2 T_in = init, V_in = init;
+    bool ok = true;
+    if (lb != 0)
+      ok = lb1_walk<N>(a, b, S.first_block, init, lane, &T_in, &V_in);
+    if (lane == 0) {
+      F.misc[M_TIN] = T_in.x;
+      F.misc[M_TIN + 1] = T_in.y;
+      F.misc[M_VIN] = V_in.x;
+      F.misc[M_VIN + 1] = V_in.y;
+      if (!ok)
+        F.misc[M_SLOW] = 1;
+      // the inclusive state
+      const uint2 fm = fld_mask(flags);
+      const uint2 T_out = pk_add2(al, sel2(fm, V_in, T_in));
+      const uint2 V_out = pk_add2(V_in, Vsum);
+      u64* p = a.lb + size_t(b) * LF_LB_WORDS + 5;
+      constexpr int NW = (N + 1) / 2;
+      lb_store(p + 2, LB_VALID | V_out.x);
+      if (NW == 2)
+        lb_store(p + 3, LB_VALID | V_out.y);
+      if (NW == 2)
+        lb_store(p + 1, LB_VALID | T_out.y);
+      lb_store(p + 0, LB_VALID | T_out.x);
+    }
+  }
+  __syncthreads();
+  {
+    // C(r, c): Vc_in + Cloc for the components whose first-MCU symbol is in this
+    // workgroup, T_in for the row that is open when it starts
+    const uint2 T_in = make_uint2(uni(F.misc[M_TIN]), uni(F.misc[M_TIN + 1]));
+    const uint2 V_in = make_uint2(uni(F.misc[M_VIN]), uni(F.misc[M_VIN + 1]));
+    if (rows_ok && uint32_t(j) < nr) {
+      uint2 C = pk_add2(V_in, Cloc);
+      if (j == 0) {
+        uint32_t present = 0;
+#pragma unroll
+        for (uint32_t c = 0; c < uint32_t(N); ++c)
+          if (uint64_t(r0) * RS + c >= base)
+            present |= 1u << c;
+        C = sel2(fld_mask(present), C, T_in);
+      }
+      F.rowE[j] = C;
+    }
+  }
+  if (F.misc[M_SLOW] != 0 && j == 0)
+    atomicOr(&a.results[s].flags, FL_SLOW);
+  __syncthreads();
+  if (!rows_ok)
+    return;
+
+  // 6. output, wave by wave: stage the running sums (+ P before the lane) in stream
+  // order where the image lay, then everybody copies out
+  const uint32_t sb = lds_addr(F.B);
+  uint32_t wfirst = 0; // symbols before the wavefront inside the workgroup
+  for (int w = 0; w < 4; ++w) {
+    const uint32_t wcnt = uni(F.misc[M_WCNT + w]);
+    uint32_t A0 = base + wfirst, A1 = A0 + wcnt;
+    if (A1 > lim)
+      A1 = lim;
+    if (A0 < A1) { // (workgroup-uniform)
+      if (wv == w) {
+        const uint32_t ad = sb + 2u * (before - wfirst);
+        // pairs that are written from the registers (a count clipped by `needed`
+        // writes one sample more: nothing after it is delivered)
+        const uint32_t nq = cnt_eff == my_cnt ? (cnt_eff >> 1) : ((cnt_eff + 1) >> 1);
+        uint32_t nqmax = nq;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+          nqmax = max(nqmax, uint32_t(__shfl_xor(nqmax, o, 64)));
+        uint32_t k0 = N == 1 ? (pexrel.x & 0xFFFFu) * 0x10001u : pexrel.x;
+        uint32_t k1 = N == 4 ? pexrel.y : k0;
+        uint32_t nqw = nq;
+        // (opaque per round: left alone, the compiler hoists the 64 sums, their high
+        // halves and the 64 compare masks out of the loop over the wavefronts -- 190 VGPRs)
+        asm volatile("" : "+v"(k0), "+v"(k1), "+v"(nqw));
+        lf_stage<0>(R, ad, nqw, nqmax, k0, k1);
+        if ((cnt_eff & 1u) && cnt_eff == my_cnt) {
+          const uint32_t k = cnt_eff - 1;
+          const uint32_t v = fld(my_sums, k & uint32_t(N - 1)) + fld(pexrel, k & uint32_t(N - 1));
+          *(lds_u16w)(ad + 2u * k) = uint16_t(v);
+        }
+      }
+      __syncthreads();
+      lf_copy_out<N>(F, a, S, A0, A1, sb, r0, j);
+      __syncthreads();
+    }
+    wfirst += wcnt;
+  }
+}
+
+template <int N>
+void launch_fast_one(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
+  if (!f.present[N])
+    return;
+  hipLaunchKernelGGL((lj_fast_kernel<N>), dim3(f.total_blocks), dim3(LJ_T), LF_LDS_BYTES, s, a);
+  if (timer)
+    timer->mark("lj_fast_kernel");
+}
+
+} // namespace
+
+void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
+  launch_fast_one<1>(a, f, s, timer);
+  launch_fast_one<2>(a, f, s, timer);
+  launch_fast_one<4>(a, f, s, timer);
+}
+
+// The LUT of the fast loops from the 11-bit table of the general ones.
+void ljpeg_build_fast_table(const TabLds& t, uint2* out) {
+  for (uint32_t i = 0; i < 1024; ++i) {
+    const uint32_t ea = reinterpret_cast<const uint16_t*>(t.lut)[2 * i * (sizeof(LutEntry) / 2)];
+    const uint32_t eb =
+        reinterpret_cast<const uint16_t*>(t.lut)[(2 * i + 1) * (sizeof(LutEntry) / 2)];
+    const uint32_t cl = ea & 31u, ssss = (ea >> 5) & 31u, total = ea >> 10;
+    const bool plain = ea != 0 && cl <= 10u && ssss < 16u && total == cl + ssss && total >= 1u &&
+                       total <= 26u;
+    if (plain) {
+      out[i] = make_uint2((32u - total) | (total << 5), (1u << ssss) - 1u);
+    } else {
+      // the warm-up just moves on: by the symbol's length if an 11-bit code says so
+      uint32_t adv = 16;
+      if (ea != 0 && (ea >> 10) >= 1u)
+        adv = ea >> 10;
+      else if (eb != 0 && (eb >> 10) >= 1u)
+        adv = eb >> 10;
+      if (adv > 63u)
+        adv = 63u;
+      out[i] = make_uint2(0x80000000u | (adv << 5), 0u);
+    }
+  }
+}
+
+} // namespace rsx

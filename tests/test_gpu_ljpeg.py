@@ -429,3 +429,29 @@ def test_host_pointer_calls_from_many_threads(gpu, oracle):
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_mixed_plan_legacy_route_and_damaged_fused_stream(gpu, oracle):
+    """One batched call with a 3-component tile (legacy route: int16 differences + K5 / K6)
+    and a TRUNCATED 2-component tile (fused path -> flagged for the legacy route's
+    end-of-stream rules).  The damaged stream's differences must not land in the healthy
+    stream's scratch: the legacy kernels leave a fused-path stream alone until its own
+    scratch exists."""
+    rng = np.random.default_rng(77)
+    W, H = 1280, 200
+    dA, dataA, pxA, _ = C.make_ljpeg_case(rng, img_w=W, img_h=H, cpp=1, tile=(0, 0, 768, H),
+                                          mcu=(3, 1))
+    dB, dataB, pxB, _ = C.make_ljpeg_case(rng, img_w=W, img_h=H, cpp=1, tile=(768, 0, 512, H),
+                                          mcu=(2, 1))
+    for cut in (len(dataB), len(dataB) // 3, len(dataB) // 2):
+        bad = dataB[:cut]
+        img, want = HostImage(W, H), HostImage(W, H)
+        soA = oracle.ljpeg(dA, dataA, want)
+        soB = oracle.ljpeg(dB, bad, want)
+        rc, st, cons = gpu.dng_decompress_ljpeg([dA, dB], [dataA, bad], img.view())
+        assert soA[0] == 0 and st[0] == 0 and cons[0] == soA[1]
+        assert (st[1] != 0) == (soB[0] != 0), (cut, st, soB)
+        assert np.array_equal(img.pixels()[:, :768], pxA), cut
+        if soB[0] == 0:
+            assert cons[1] == soB[1]
+            assert np.array_equal(img.u16(), want.u16())
