@@ -844,12 +844,14 @@ if __name__ == "__main__":
     ap.add_argument("--only", default="")
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the reference CPU baseline")
     args = ap.parse_args()
     ge.build()
     from rawspeed_amd import capi
     ctx = capi.Context(0)
     if args.only == "cfg3":
-        r, _ = run_cfg3(ctx, torch, print, frames=args.frames, steps=args.steps)
+        r, _ = run_cfg3(ctx, torch, print, frames=args.frames, steps=args.steps,
+                        cpu=not args.no_cpu)
         print(json.dumps(r, indent=1))
     elif args.only == "variants":
         print(json.dumps(run_variants(ctx, torch, print, frames=args.frames,

@@ -458,6 +458,22 @@ __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& 
 // that image with plain 16-byte coalesced loads.  Keeping the byte-level work in
 // its own light kernel (25 KB LDS) hides its latency.
 // ---------------------------------------------------------------------------
+// Start guesses for the single-pass kernel (rsx_ljpeg_fast.hip): where the parse of a
+// slot from bit `from` ends, as an offset into the next slot.  lut8 = total bits of the
+// symbol a 10-bit window starts with.
+__device__ __forceinline__ uint32_t lj_guess_parse(const uint32_t* B, const uint8_t* lut8,
+                                                   int col, uint32_t end_bits, uint32_t from) {
+  uint32_t pos = from;
+  while (pos < end_bits) {
+    const uint32_t wi = pos >> 5;
+    const uint32_t d0 = B[wi * LJ_T + col], d1 = B[(wi + 1) * LJ_T + col];
+    const uint32_t w = uint32_t((((uint64_t(d0) << 32) | d1) << (pos & 31u)) >> 32);
+    pos += lut8[w >> 22];
+  }
+  return pos - end_bits;
+}
+constexpr int LJ_GUESS_SLOTS = 3; // slots parsed for a guess
+
 __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const uint32_t b = blockIdx.x;
@@ -466,6 +482,16 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   const Lds L = carve(smem);
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
+  // (single-pass streams: the symbol lengths of their 10-bit LUT, behind the layout)
+  uint8_t* lut8 = smem + lj_lds_bytes(0);
+  if (S.fast && a.fast_tabs) {
+    const uint2* ft = a.fast_tabs + size_t(S.table_base) * 1024 + 4 * j;
+    uint32_t pk = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      pk |= ((ft[k].x >> 5) & 63u) << (8 * k);
+    reinterpret_cast<uint32_t*>(lut8)[j] = pk;
+  }
   lj_stage_slots(L, a, S, s, lb, j, true); // ends with a barrier
   uint4* __restrict__ dst = a.unstuffed + size_t(b) * LJ_IMG_U4;
   const uint4* src = reinterpret_cast<const uint4*>(L.B);
@@ -481,6 +507,32 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     a.lb[size_t(b) * LF_LB_WORDS + j] = 0ull;
   if (a.tickets && b == 0 && j < 4)
     a.tickets[j] = 0u;
+  // Start guesses of the single-pass kernel.  Lane j parses the LJ_GUESS_SLOTS slots before
+  // slot j from bit 0 (Huffman streams self-synchronise: one slot leaves 1.7 % of the
+  // guesses wrong, two 0.03 %, three next to none); lane 0 does it for slot 1 of the NEXT
+  // workgroup, whose own lanes 1.. would have fewer slots to go by.  Here and not there: a
+  // wrong guess costs the single-pass kernel a re-decode round, and every workgroup
+  // behind the re-decoding one waits for its symbol count (measured with two slots parsed
+  // in that kernel: 9 % of the workgroups re-decode, and the average workgroup waits 26 us
+  // for its predecessors) -- while this kernel is bound by HBM and has the issue slots free.
+  if (S.fast && a.fast_tabs) {
+    const int tgt = j == 0 ? LJ_T : j; // the slot the guess is for (LJ_T = slot 1 of the next block)
+    uint32_t e = 0;
+#pragma unroll
+    for (int k = LJ_GUESS_SLOTS; k >= 1; --k) {
+      const int col = tgt - k;
+      const uint32_t eb = col >= 0 ? uint32_t(L.ob[col >= 0 ? col : 0]) : 0u;
+      if (col >= 0 && eb != 0 && !(col == 0 && lb == 0))
+        e = lj_guess_parse(L.B, lut8, col, eb, e & ST_OFF_MASK);
+      else
+        e = 0;
+    }
+    const uint32_t g1 = S.first_subseq + lb * LJ_OWN; // record of this workgroup's slot 1
+    if (j >= 2)
+      a.sub_start[g1 + uint32_t(j - 1)] = uint16_t(e & ST_OFF_MASK);
+    else if (j == 0 && lb + 1 < S.n_blocks)
+      a.sub_start[g1 + uint32_t(LJ_OWN)] = uint16_t(e & ST_OFF_MASK);
+  }
 }
 
 // inclusive scan of x over the wavefront
@@ -1881,10 +1933,12 @@ struct LJpegPlan {
   // single-pass path (rsx_ljpeg_fast.hip)
   bool fast_present[5] = {};   // [components]
   bool any_fast = false;       // some stream takes the single-pass kernel
+  uint32_t fast_lds = 0;       // LDS bytes of its launches
   bool any_pipeline = false;   // some stream takes the multi-kernel pipeline in the first pass
   bool expect_slow = false;    // the last run left FL_SLOW streams: launch the second pass at once
   bool slow_pass_launched = false; // ... this run already has
-  DeviceBuffer d_fast_tabs, d_lb, d_tickets;
+  DeviceBuffer d_fast_tabs, d_lb, d_tickets, d_fast_order;
+  DeviceBuffer d_dbg; // experiment builds: phase time stamps of the single-pass kernel
   DeviceBuffer d_block_flags, d_block_tf, d_sub_start;
   DeviceBuffer d_streams, d_tables, d_block_stream, d_strips, d_sub_state, d_sub_sums,
       d_sub_first, d_sub_psum,
@@ -1973,6 +2027,9 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.fast_tabs = static_cast<const uint2*>(p->d_fast_tabs.ptr);
   a.lb = static_cast<unsigned long long*>(p->d_lb.ptr);
   a.tickets = static_cast<uint32_t*>(p->d_tickets.ptr);
+  a.fast_lds = p->fast_lds;
+  a.fast_order = static_cast<const uint32_t*>(p->d_fast_order.ptr);
+  a.dbg = static_cast<unsigned long long*>(p->d_dbg.ptr);
   a.pass = 0;
   return a;
 }
@@ -2157,6 +2214,17 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
               g.row_samples >= g.n_comp)
                  ? 1
                  : 0;
+    if (S.fast) {
+      // its workgroups stage all their samples in LDS at once: the allocation follows the
+      // stream's symbols per workgroup (+ 15 % for local variation; a workgroup that
+      // still does not fit sends the stream to the slow path)
+      const uint64_t per_wg = (needed + S.n_blocks - 1) / (S.n_blocks ? S.n_blocks : 1);
+      const uint32_t lds = ljpeg_fast_lds_for(per_wg + per_wg / 7 + 512);
+      if (lds == 0)
+        S.fast = 0; // (fewer than ~4 bits per symbol: the multi-kernel pipeline)
+      else
+        p->fast_lds = std::max(p->fast_lds, lds);
+    }
 #endif
     S.sync_lut11 = (J.explicit_n > 0 && J.explicit_bits > 10) ? 1 : 0;
     S.raw_limit = g.raw_limit;
@@ -2355,10 +2423,29 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       std::vector<uint2> ft(tl.size() * 1024);
       for (size_t t = 0; t < tl.size(); ++t)
         ljpeg_build_fast_table(tl[t], ft.data() + t * 1024);
+      // ticket order of the single-pass launches: round robin over the streams
+      std::vector<uint32_t> order;
+      order.reserve(p->total_blocks);
+      uint32_t max_blocks = 0;
+      for (const LjStreamDev& S : p->streams)
+        max_blocks = std::max(max_blocks, S.n_blocks);
+      for (uint32_t k = 0; k < max_blocks; ++k)
+        for (const LjStreamDev& S : p->streams)
+          if (k < S.n_blocks)
+            order.push_back(S.first_block + k);
+      if ((st = up(p->d_fast_order, order.data(), order.size() * sizeof(uint32_t))))
+        return st;
       if ((st = up(p->d_fast_tabs, ft.data(), ft.size() * sizeof(uint2))) ||
           (st = p->d_lb.ensure(size_t(p->total_blocks) * LF_LB_WORDS * 8)) ||
           (st = p->d_tickets.ensure(16)))
         return st;
+#ifdef RSX_EXPERIMENT
+      if (getenv("RSX_DEBUG")) {
+        if ((st = p->d_dbg.ensure(size_t(p->total_blocks) * 16 * 8)))
+          return st;
+        (void)hipMemset(p->d_dbg.ptr, 0, size_t(p->total_blocks) * 16 * 8);
+      }
+#endif
     }
     if (p->any_direct &&
         ((st = p->d_sub_sums.ensure(size_t(p->total_subseq) * 8 + 16)) ||
@@ -2645,7 +2732,7 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
                                     hipMemcpyHostToDevice, s));
   const uint32_t n_streams = uint32_t(p->streams.size());
   hipLaunchKernelGGL(lj_unstuff_kernel, dim3(p->total_blocks), dim3(LJ_T),
-                     lj_lds_bytes(0), s, a);
+                     lj_lds_bytes(0) + (p->any_fast ? 1024 : 0), s, a);
   mark(p, "lj_unstuff_kernel");
   // the single-pass kernel for the streams it takes ...
   if (p->any_fast) {
@@ -2869,6 +2956,42 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
         dri_status[d] = RSX_ERR_IO;
   }
 #ifdef RSX_EXPERIMENT
+  if (getenv("RSX_DEBUG") && p->d_dbg.ptr && ran) {
+    // mean duration of the single-pass kernel's phases (shader clock ticks -> us at 2.4 GHz)
+    std::vector<unsigned long long> t(size_t(p->total_blocks) * 16);
+    if (hipMemcpy(t.data(), p->d_dbg.ptr, t.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      double sum[16] = {}, mx[16] = {};
+      size_t n = 0;
+      unsigned long long tmin = ~0ull, tmax = 0;
+      for (uint32_t b = 0; b < p->total_blocks; ++b) {
+        const unsigned long long* r = &t[size_t(b) * 16];
+        if (!r[0] || !r[15])
+          continue;
+        ++n;
+        tmin = std::min(tmin, r[0]);
+        tmax = std::max(tmax, r[15]);
+        unsigned long long prev = r[0];
+        for (int k = 1; k < 16; ++k) {
+          const unsigned long long cur = r[k] ? r[k] : prev;
+          const double d = double(cur - prev) / 2400.0;
+          sum[k] += d;
+          mx[k] = std::max(mx[k], d);
+          prev = cur;
+        }
+      }
+      static const char* nm[16] = {"", "ticket+stream", "tables+image", "bit delay", "guess", "decode",
+                                   "rounds+scan", "lb0 walk", "(redo)", "fetch+records",
+                                   "row dump", "row scan", "lb1", "C table", "staging", "copy-out"};
+      fprintf(stderr, "[rsx] single-pass phases over %zu workgroups, kernel span %.1f us:\n", n,
+              double(tmax - tmin) / 2400.0);
+      double tot = 0;
+      for (int k = 1; k < 16; ++k) {
+        fprintf(stderr, "[rsx]   %-14s mean %7.2f us  max %8.2f us\n", nm[k], n ? sum[k] / n : 0.0, mx[k]);
+        tot += n ? sum[k] / n : 0.0;
+      }
+      fprintf(stderr, "[rsx]   %-14s mean %7.2f us\n", "lifetime", tot);
+    }
+  }
   if (getenv("RSX_DEBUG")) {
     fprintf(stderr, "[rsx] ljpeg plan: %zu streams, extra stitch rounds %d\n",
             p->streams.size(), p->extra_stitch_rounds);
@@ -2935,7 +3058,8 @@ void ljpeg_plan_destroy(LJpegPlan* p) {
   if (p->nk_child)
     ljpeg_plan_destroy(p->nk_child);
   for (DeviceBuffer* b : {&p->d_nk, &p->d_nk_tables, &p->d_nk_rowpow, &p->d_nk_pup,
-                          &p->d_transfer, &p->d_fast_tabs, &p->d_lb, &p->d_tickets})
+                          &p->d_transfer, &p->d_fast_tabs, &p->d_lb, &p->d_tickets, &p->d_dbg,
+                          &p->d_fast_order})
     b->release();
   p->d_marker_count.release();
   p->d_marker_list.release();

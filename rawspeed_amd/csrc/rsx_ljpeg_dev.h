@@ -235,6 +235,10 @@ struct LjArgs {
   const uint2* fast_tabs;    // [table][1024]: the 10-bit LUT of the single-pass loops
   unsigned long long* lb;    // [workgroup][LF_LB_WORDS]: look-back records (zeroed by K0)
   uint32_t* tickets;         // [4]: workgroup tickets of the single-pass launches (zeroed by K0)
+  uint32_t fast_lds;         // LDS bytes of the single-pass launches (staging capacity)
+  const uint32_t* fast_order; // [ticket]: the workgroup's block -- the streams' blocks
+                             // interleaved, each stream's in order
+  unsigned long long* dbg;   // experiment builds: [workgroup][16] phase time stamps
   uint32_t pass;             // 0: first pass; 1: the multi-kernel pipeline redoes FL_SLOW
                              // streams; 2: its streams of both passes
 };
@@ -319,5 +323,6 @@ void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t stream,
                        KernelTimer* timer);
 // the 10-bit LUT of the single-pass loops for one table (1024 entries)
 void ljpeg_build_fast_table(const TabLds& t, uint2* out);
+uint32_t ljpeg_fast_lds_for(uint64_t samples_per_workgroup);
 
 } // namespace rsx

@@ -64,25 +64,46 @@ constexpr int LF_SIDE_STRIDE = 272;     // bytes: 128 x u16 + 16 (16-byte aligne
 constexpr int LF_RMAX = 256;            // stream rows that may start inside one workgroup
 constexpr uint32_t LF_MAX_ROUNDS = 4;   // re-decode rounds before the stream is given up
 constexpr uint32_t LF_SPIN_LIMIT = 1u << 22;
+#ifndef RSX_LF_WARM_SLOTS
+#define RSX_LF_WARM_SLOTS 0
+#endif
+constexpr int LF_WARM_SLOTS = RSX_LF_WARM_SLOTS; // slots parsed HERE for a start guess (0: K0's guesses)
+// Ablation switches of experiment builds (scripts/exp_ab.py; wrong pixels, timing only):
+// 1 no staging + copy-out, 2 no copy-out, 4 no look-back 0, 8 no look-back 1, 16 no
+// decode loop, 32 no warm-up, 64 no re-decode rounds, 128 no row table
+#if defined(RSX_EXPERIMENT) && defined(RSX_LF_ABLATE)
+constexpr uint32_t LF_ABLATE = RSX_LF_ABLATE;
+#else
+constexpr uint32_t LF_ABLATE = 0;
+#endif
 
 // ---- LDS layout (bytes) ------------------------------------------------------
 constexpr uint32_t LF_OFF_LUT = 0;                       // 1024 x uint2: LDS address 0
-constexpr uint32_t LF_OFF_TAB10 = 8192;                  // TabLds10 (2 KB aligned: OR-addressable)
-constexpr uint32_t LF_OFF_B = LF_OFF_TAB10 + ((sizeof(TabLds10) + 15) & ~size_t(15));
+constexpr uint32_t LF_OFF_B = 8192;
 constexpr uint32_t LF_OFF_REC = LF_OFF_B + LF_BW * LJ_T * 4;   // u32[256]
 constexpr uint32_t LF_OFF_OB = LF_OFF_REC + LJ_T * 4;          // u16[256]
 constexpr uint32_t LF_OFF_SM = LF_OFF_OB + LJ_T * 2;           // uint2[256]
 constexpr uint32_t LF_OFF_LIST = LF_OFF_SM + LJ_T * 8;         // u16[256]
-constexpr uint32_t LF_OFF_MISC = LF_OFF_LIST + LJ_T * 2;       // u32[64]
-constexpr uint32_t LF_OFF_SIDE = LF_OFF_MISC + 64 * 4;
-constexpr uint32_t LF_LDS_BYTES = LF_OFF_SIDE + LF_NSIDE * LF_SIDE_STRIDE;
-// after the records are dead: the row table (E and D / C of the rows that start here)
-constexpr uint32_t LF_OFF_ROWE = LF_OFF_REC;                   // uint2[LF_RMAX]
-constexpr uint32_t LF_OFF_ROWD = LF_OFF_ROWE + LF_RMAX * 8;    // uint2[LF_RMAX]
-static_assert(LF_OFF_ROWD + LF_RMAX * 8 <= LF_OFF_MISC, "the row table fits over the records");
-static_assert(LF_OFF_B % 16 == 0 && LF_OFF_SIDE % 16 == 0, "16-byte aligned regions");
-static_assert(LF_BW * LJ_T * 4 >= 64 * LF_MAXSYM * 2, "a wavefront's pixels fit the image's place");
-static_assert(4 * ((LF_LDS_BYTES + 1279) / 1280) * 1280 <= 160 * 1024, "four workgroups per CU");
+constexpr uint32_t LF_OFF_SIDE = LF_OFF_LIST + LJ_T * 2;
+constexpr uint32_t LF_OFF_FIXED_END = LF_OFF_SIDE + LF_NSIDE * LF_SIDE_STRIDE;
+// ... and at the END of the allocation (its size is a launch parameter, LjArgs::fast_lds):
+// misc[128], the C table (uint2[LF_RMAX]), the stream's CR2 strips
+constexpr uint32_t LF_TAIL_MISC = 0, LF_TAIL_CTAB = 512, LF_TAIL_STRIPS = 512 + LF_RMAX * 8;
+constexpr uint32_t LF_TAIL_BYTES =
+    (LF_TAIL_STRIPS + (MAX_CR2_STRIPS + 1) * uint32_t(sizeof(Cr2Strip)) + 15u) & ~15u;
+// Output staging: when the pixels are staged, everything in front of the tail is dead --
+// LUT, image, records, side buffer -- and ALL of the workgroup's running sums are staged
+// there at once, in stream order (34 KB = 17 000 samples with the smallest allocation;
+// streams with more symbols per byte get a larger one, or the slow path).  Then the
+// registers that held them are free for the rest of the kernel, and the first-MCU symbols
+// of the stream rows are read from the staged samples.  (Earlier versions kept the 64
+// registers through both look-backs and staged wavefront by wavefront: spills in the
+// decode loop at 128 VGPRs, and 4 x (stage, barrier, copy, barrier).)
+constexpr uint32_t LF_STAGE_BASE = 16; // (a partial first chunk reads up to 14 bytes before)
+constexpr uint32_t LF_LDS_MIN = LF_OFF_FIXED_END + LF_TAIL_BYTES;
+static_assert(LF_OFF_B % 16 == 0 && LF_OFF_SIDE % 16 == 0 && LF_OFF_FIXED_END % 16 == 0,
+              "16-byte aligned regions");
+static_assert(4 * ((LF_LDS_MIN + 1279) / 1280) * 1280 <= 160 * 1024, "four workgroups per CU");
 
 // misc[] indices
 enum : int {
@@ -93,12 +114,13 @@ enum : int {
   M_BASE = 14,  // index of the workgroup's first symbol
   M_PRED = 15,  // predecessor's exit state
   M_SLOW = 16,  // != 0: give the stream to the slow path
-  M_DUMP = 17,  // lanes that dump their registers (row table)
+  M_SPARE = 17,
   M_TIN = 18,   // [2] T_in
   M_VIN = 20,   // [2] Vc_in
   M_RSUM = 22,  // [8] row scan: per-wavefront totals (uint2 x 4)
   M_LB1 = 30,   // [8] the LOCAL record (a, v) / (T_out, Vc_out)
   M_NSIDE = 38, // side-buffer entries handed out
+  M_LBX = 40,   // [48] look-back: per-wavefront window summaries
 };
 
 struct FastLds {
@@ -110,24 +132,25 @@ struct FastLds {
   uint16_t* list;
   uint32_t* misc;
   uint8_t* side;
-  uint2* rowE;
-  uint2* rowD;
-  const TabLds10* tab10;
+  uint2* ctab;    // C(r, c) of the stream rows the workgroup touches
+  uint8_t* strips;
+  uint32_t stage_cap; // samples the staging region holds
 };
 
-__device__ __forceinline__ FastLds carve_fast(uint8_t* smem) {
+__device__ __forceinline__ FastLds carve_fast(uint8_t* smem, uint32_t lds_bytes) {
   FastLds f;
+  uint8_t* tail = smem + (lds_bytes - LF_TAIL_BYTES);
   f.base = smem;
   f.B = reinterpret_cast<uint32_t*>(smem + LF_OFF_B);
   f.rec = reinterpret_cast<uint32_t*>(smem + LF_OFF_REC);
   f.ob = reinterpret_cast<uint16_t*>(smem + LF_OFF_OB);
   f.sm = reinterpret_cast<uint2*>(smem + LF_OFF_SM);
   f.list = reinterpret_cast<uint16_t*>(smem + LF_OFF_LIST);
-  f.misc = reinterpret_cast<uint32_t*>(smem + LF_OFF_MISC);
+  f.misc = reinterpret_cast<uint32_t*>(tail + LF_TAIL_MISC);
   f.side = smem + LF_OFF_SIDE;
-  f.rowE = reinterpret_cast<uint2*>(smem + LF_OFF_ROWE);
-  f.rowD = reinterpret_cast<uint2*>(smem + LF_OFF_ROWD);
-  f.tab10 = reinterpret_cast<const TabLds10*>(smem + LF_OFF_TAB10);
+  f.ctab = reinterpret_cast<uint2*>(tail + LF_TAIL_CTAB);
+  f.strips = tail + LF_TAIL_STRIPS;
+  f.stage_cap = (lds_bytes - LF_TAIL_BYTES - LF_STAGE_BASE - 16u) / 2u;
   return f;
 }
 
@@ -263,9 +286,10 @@ __device__ __forceinline__ void lf_groups(FastState& s, uint32_t vbase, uint32_t
   }
 }
 
-// warm-up: where the parse of a slot from bit 0 ends (offset into the next slot)
-__device__ __forceinline__ uint32_t lf_warmup(uint32_t vbase, uint32_t end_bits, bool enabled) {
-  uint32_t Pn = uint32_t(-32);
+// warm-up: where the parse of a slot from bit `from` ends (offset into the next slot)
+__device__ __forceinline__ uint32_t lf_warmup(uint32_t vbase, uint32_t end_bits, bool enabled,
+                                              uint32_t from = 0) {
+  uint32_t Pn = uint32_t(-32) - 32u * from;
   const uint32_t pend = uint32_t(-32) - 32u * end_bits;
   if (enabled) {
     while (Pn > pend) {
@@ -276,14 +300,21 @@ __device__ __forceinline__ uint32_t lf_warmup(uint32_t vbase, uint32_t end_bits,
       Pn -= (e0 & 0x7E0u);
     }
   }
-  return (pend - Pn) >> 5;
+  return enabled ? (pend - Pn) >> 5 : from;
 }
 
 // lj_slow_entry, inlined: a CALL while 64 VGPRs of running sums are live makes the
 // register allocator park half of them in scratch (the ABI's caller-saved registers)
-__device__ __forceinline__ uint32_t lf_slow_entry(uint32_t w, const TabLds10& tb) {
-  uint32_t r = 0;
-  for (uint32_t l = 11; l <= tb.max_len && r == 0u; ++l) {
+// The symbol entry (code length | SSSS << 5 | total << 10, 0 = invalid code) the general
+// way, from the stream's table in GLOBAL memory: the symbols the 10-bit LUT does not
+// cover are rare, and the 2.3 KB of LDS the table took (plus the four dependent
+// load-store rounds that staged it) are not.
+__device__ __forceinline__ uint32_t lf_slow_entry(uint32_t w, const TabLds& tb) {
+  uint32_t r = lj_lut16(tb, w >> (32 - LUT_BITS));
+  if ((r & 31u) != 0u)
+    return r;
+  r = 0;
+  for (uint32_t l = LUT_BITS + 1; l <= tb.max_len && r == 0u; ++l) {
     const uint32_t c = w >> (32 - l);
     const uint32_t mc = tb.max_code[l];
     if (mc != NO_CODE && c <= mc) {
@@ -295,30 +326,45 @@ __device__ __forceinline__ uint32_t lf_slow_entry(uint32_t w, const TabLds10& tb
   return r;
 }
 
-// The general loop (re-decodes): any code length, SSSS = 16, invalid codes; running
-// sums of every symbol into the lane's side-buffer entry.  Window of the DELAYED image:
-// stream bit p is image bit p + 1.
+// Re-decode of a slot from a known entry state: the lean step of the fast loop for the
+// symbols the 10-bit LUT covers, the general one (any code length, SSSS = 16, invalid
+// codes) for the others; the running sum of every symbol goes into the lane's
+// side-buffer entry.  (The first version ran the general loop for every symbol: 14-50 us
+// per round, and every workgroup behind the re-decoding one waits for its record.)
 template <int N>
-__device__ __forceinline__ void lf_careful(const FastLds& F, bool long_codes, int col,
-                                           uint32_t start, uint32_t end_bits, uint32_t side_addr,
-                                           bool enabled, uint32_t& exit, uint32_t& count,
-                                           uint2& sums, bool& overflow) {
-  uint32_t pos = start & ST_OFF_MASK;
+__device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds& tb, int col,
+                                            uint32_t start, uint32_t end_bits,
+                                            uint32_t side_addr, bool enabled,
+                                            uint32_t& exit, uint32_t& count, uint2& sums,
+                                            bool& overflow) {
+  const uint32_t vbase = lds_addr(&F.B[(LF_BW - 1) * LJ_T + col]);
+  const uint32_t pend = uint32_t(-32) - 32u * end_bits;
+  uint32_t Pn = uint32_t(-32) - 32u * (start & ST_OFF_MASK);
   bool ok = !(start & ST_ERR);
   if (!ok || !enabled)
-    end_bits = 0;
-  const TabLds10& tb = *F.tab10;
+    Pn = pend; // no steps
   uint32_t n = 0, a0 = 0, a1 = 0;
-  bool live = pos < end_bits;
-  while (__any(live)) {
-    const uint32_t w = lj_window<LF_BW>(F.B, col, pos + 1u);
-    uint32_t e = tb.lut[w >> 22];
-    if (long_codes && __any(live && (e & 31u) == 0u)) {
-      if (live && (e & 31u) == 0u)
-        e = lf_slow_entry(w, tb);
+  while (Pn > pend) {
+    const uint32_t ad = vbase + (Pn & ~1023u);
+    const uint32_t d1 = *(lds_u32p)(ad), d0 = *(lds_u32p)(ad + 4u * LJ_T);
+    const uint32_t w = __builtin_amdgcn_alignbit(d0, d1, Pn >> 5);
+    const lf_u32x2 e = *(lds_u2p)((w >> 19) & 0x1FF8u);
+    uint32_t d, tot;
+    if (e.x & 0x80000000u) {
+      const uint32_t e16 = lf_slow_entry(w, tb);
+      if (e16 == 0u) {
+        ok = false;
+        break;
+      }
+      d = lj_extend(w, e16);
+      tot = e16 >> 10;
+    } else {
+      const uint32_t v = (w >> (e.x & 31u)) & e.y;
+      const uint32_t u = e.y - v;
+      const uint32_t m = uint32_t(int32_t(u - v) >> 31);
+      d = ((e.y & m) - u) & 0xFFFFu;
+      tot = (e.x >> 5) & 63u;
     }
-    const bool good = live && e != 0u;
-    const uint32_t d = good ? lj_extend(w, e) : 0u;
     const uint32_t sh = 16u * (n & 1u);
     uint32_t val;
     if (N == 1) {
@@ -334,57 +380,43 @@ __device__ __forceinline__ void lf_careful(const FastLds& F, bool long_codes, in
         a0 = pk_add(a0, d << sh);
       val = (((n & 2u) ? a1 : a0) >> sh) & 0xFFFFu;
     }
-    if (good) {
-      if (n < uint32_t(LF_MAXSYM))
-        *(lds_u16w)(side_addr + 2u * n) = uint16_t(val);
-      else
-        overflow = true;
-    }
-    pos += good ? (e >> 10) : 0u;
-    n += good ? 1u : 0u;
-    if (live && !good) {
-      ok = false;
-      end_bits = 0;
-    }
-    live = pos < end_bits;
+    if (n < uint32_t(LF_MAXSYM))
+      *(lds_u16w)(side_addr + 2u * n) = uint16_t(val);
+    else
+      overflow = true;
+    Pn -= 32u * tot;
+    ++n;
   }
   if (!enabled)
     return;
-  exit = ok ? (pos - end_bits) : ST_ERR;
+  exit = ok ? ((pend - Pn) >> 5) : ST_ERR;
   count = n;
   sums = make_uint2(a0, a1);
 }
 
 // ---------------------------------------------------------------------------
-// Look-back 0 (wavefront 0): exit state of the predecessor and the index of the
+// Look-back 0 (the whole workgroup, one record per lane and pass): the index of the
 // workgroup's first symbol.  A LOCAL record counts when its assumed entry is its own
-// predecessor's exit; otherwise its owner is re-converging and will publish FINAL.
+// predecessor's exit; otherwise its owner is re-converging and will publish again.
+// (With one wavefront walking, 64 records per pass, the walks of the ~300 workgroups
+// in flight took 5 passes each -- and every pass made the walks longer: 22 us a workgroup.)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ bool lb0_walk(const LjArgs& a, uint32_t b, uint32_t first_block,
-                                         uint32_t start_bit, int lane, uint32_t* pred_exit,
-                                         uint32_t* base_out) {
+__device__ __forceinline__ bool lb0_walk(const LjArgs& a, const FastLds& F, uint32_t b,
+                                         uint32_t first_block, uint32_t start_bit, int j,
+                                         uint32_t* pred_exit, uint32_t* base_out) {
+  const int lane = j & 63, wv = j >> 6;
   const u64* A = a.lb;
   const u64 virt = lb0_make(LB0_FINAL, 0, st_to7(start_bit), 0, 0);
   uint32_t acc = 0;
   int64_t pos = int64_t(b) - 1;
-  bool have_pred = false;
   for (uint32_t spins = 0; spins < LF_SPIN_LIMIT; ++spins) {
-    const int64_t idx = pos - lane;
+    const int64_t idx = pos - j;
     const u64 r = idx >= int64_t(first_block) ? lb_load(A + size_t(idx) * LF_LB_WORDS) : virt;
     const u64 rp =
         idx - 1 >= int64_t(first_block) ? lb_load(A + size_t(idx - 1) * LF_LB_WORDS) : virt;
     const uint32_t st = uint32_t(r & 3u), stp = uint32_t(rp & 3u);
     const uint32_t cnt = uint32_t(r >> 15) & 0xFFFFu, assumed = uint32_t(r >> 2) & 63u;
     const uint32_t exitp = uint32_t(rp >> 8) & 127u;
-    if (!have_pred) {
-      const uint32_t st0 = __shfl(st, 0, 64);
-      if (st0 == 0) {
-        __builtin_amdgcn_s_sleep(2);
-        continue;
-      }
-      *pred_exit = st_from7(__shfl(uint32_t(r >> 8) & 127u, 0, 64));
-      have_pred = true;
-    }
     const bool fin = st == 2;
     // (an error exit is not propagated: the successor keeps its own guess -- the stream
     // is damaged and goes to the slow path anyway)
@@ -392,15 +424,44 @@ __device__ __forceinline__ bool lb0_walk(const LjArgs& a, uint32_t b, uint32_t f
     const u64 m_ok = __ballot(ok), m_fin = __ballot(fin);
     const int f = (~m_ok) ? __builtin_ctzll(~m_ok) : 64;
     const uint32_t part = wave_sum_u32(lane < f ? cnt : 0u);
-    if (f == 64) {
-      acc += part;
-      pos -= 64;
-      continue;
+    if (lane == 0) {
+      F.misc[M_LBX + 4 * wv] = uint32_t(f);
+      F.misc[M_LBX + 4 * wv + 1] = part;
+      F.misc[M_LBX + 4 * wv + 2] = f < 64 ? uint32_t((m_fin >> f) & 1ull) : 0u;
     }
-    if ((m_fin >> f) & 1ull) {
-      const uint32_t incl = __shfl(uint32_t(r >> 32), f, 64);
-      *base_out = incl + part + acc;
+    if (f < 64 && lane == f)
+      F.misc[M_LBX + 4 * wv + 3] = uint32_t(r >> 32);
+    if (j == 0 && pos == int64_t(b) - 1)
+      F.misc[M_PRED] = st ? (0x100u | (uint32_t(r >> 8) & 127u)) : 0u; // the predecessor's exit
+    __syncthreads();
+    // the four wavefronts' windows in order (nearest first)
+    int state = 0; // 0: all 256 linked, 1: found FINAL, 2: blocked
+    uint32_t sum = 0, incl = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (state != 0)
+        continue;
+      const uint32_t fw = uni(F.misc[M_LBX + 4 * w]);
+      sum += uni(F.misc[M_LBX + 4 * w + 1]);
+      if (fw < 64u) {
+        state = uni(F.misc[M_LBX + 4 * w + 2]) ? 1 : 2;
+        incl = uni(F.misc[M_LBX + 4 * w + 3]);
+      }
+    }
+    if (pos == int64_t(b) - 1) {
+      const uint32_t pw = uni(F.misc[M_PRED]);
+      if (pw)
+        *pred_exit = st_from7(pw & 127u);
+    }
+    __syncthreads(); // (the exchange words are free again)
+    if (state == 1) {
+      *base_out = incl + sum + acc;
       return true;
+    }
+    if (state == 0) {
+      acc += sum;
+      pos -= LJ_T;
+      continue;
     }
     __builtin_amdgcn_s_sleep(2);
   }
@@ -408,91 +469,219 @@ __device__ __forceinline__ bool lb0_walk(const LjArgs& a, uint32_t b, uint32_t f
 }
 
 // transfer of the predictor state over a run of symbols: T' = f ? Vc + a : T + a,
-// Vc' = Vc + v (field-wise; f as 16-bit masks)
-struct Xfer {
-  uint2 f, a, v;
+// Vc' = Vc + v (field-wise; f as 16-bit masks).  NW dwords per quantity (two 16-bit
+// fields each): written out per dword so that nothing is carried for absent components.
+template <int NW>
+struct XferT {
+  uint32_t f[NW], a[NW], v[NW];
 };
 // first h, then g
-__device__ __forceinline__ Xfer xfer_compose(const Xfer& h, const Xfer& g) {
-  Xfer r;
-  r.f = make_uint2(h.f.x | g.f.x, h.f.y | g.f.y);
-  r.a = pk_add2(g.a, sel2(g.f, h.v, h.a));
-  r.v = pk_add2(h.v, g.v);
+template <int NW>
+__device__ __forceinline__ XferT<NW> xfer_compose(const XferT<NW>& h, const XferT<NW>& g) {
+  XferT<NW> r;
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    r.f[k] = h.f[k] | g.f[k];
+    r.a[k] = pk_add(g.a[k], (h.v[k] & g.f[k]) | (h.a[k] & ~g.f[k]));
+    r.v[k] = pk_add(h.v[k], g.v[k]);
+  }
   return r;
 }
+__device__ __forceinline__ uint32_t fld_mask1(uint32_t flags2) { // two flag bits -> two 16-bit masks
+  return ((flags2 & 1u) ? 0xFFFFu : 0u) | ((flags2 & 2u) ? 0xFFFF0000u : 0u);
+}
 
-// Look-back 1 (wavefront 0): the predictor state (T, Vc) before the workgroup.
+// Look-back 1 (the whole workgroup, one record per lane and pass): the predictor state
+// (T, Vc) before the workgroup = the nearest inclusive state, carried through the LOCAL
+// transfers of the workgroups in between.  The transfers compose associatively: a
+// wavefront scan (nearer workgroups applied later), the four wavefronts' results in LDS.
+// (First version: one wavefront, a serial fold over its 64 lanes -- 10 us a workgroup.)
 template <int N>
-__device__ __forceinline__ bool lb1_walk(const LjArgs& a, uint32_t b, uint32_t first_block,
-                                         uint2 init, int lane, uint2* T_in, uint2* V_in) {
+__device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint32_t b,
+                                         uint32_t first_block, uint2 init, int j, uint2* T_in,
+                                         uint2* V_in) {
   constexpr int NW = (N + 1) / 2;
+  const int lane = j & 63, wv = j >> 6;
   const u64* A = a.lb;
-  Xfer g; // the blocks nearer than the window, composed
-  g.f = g.a = g.v = make_uint2(0, 0);
+  XferT<NW> g; // the workgroups nearer than the window, composed
+#pragma unroll
+  for (int k = 0; k < NW; ++k)
+    g.f[k] = g.a[k] = g.v[k] = 0;
+  const uint32_t initw[2] = {init.x, init.y};
   int64_t pos = int64_t(b) - 1;
   for (uint32_t spins = 0; spins < LF_SPIN_LIMIT; ++spins) {
-    const int64_t idx = pos - lane;
+    const int64_t idx = pos - j;
     const bool real = idx >= int64_t(first_block);
-    u64 w[8];
+    u64 wa[NW], wv_[NW], wt[NW], wc[NW];
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      w[k] = 0;
+    for (int k = 0; k < NW; ++k)
+      wa[k] = wv_[k] = wt[k] = wc[k] = 0;
     if (real) {
       const u64* p = A + size_t(idx) * LF_LB_WORDS + 1;
 #pragma unroll
       for (int k = 0; k < NW; ++k) {
-        w[k] = lb_load(p + k);         // a
-        w[2 + k] = lb_load(p + 2 + k); // v
-        w[4 + k] = lb_load(p + 4 + k); // T
-        w[6 + k] = lb_load(p + 6 + k); // Vc
+        wa[k] = lb_load(p + k);
+        wv_[k] = lb_load(p + 2 + k);
+        wt[k] = lb_load(p + 4 + k);
+        wc[k] = lb_load(p + 6 + k);
       }
     }
     bool loc = true, pre = true;
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
-      loc = loc && (w[k] & LB_VALID) && (w[2 + k] & LB_VALID);
-      pre = pre && (w[4 + k] & LB_VALID) && (w[6 + k] & LB_VALID);
+      loc = loc && (wa[k] & LB_VALID) && (wv_[k] & LB_VALID);
+      pre = pre && (wt[k] & LB_VALID) && (wc[k] & LB_VALID);
     }
     if (!real) { // before the stream: the initial predictors
       pre = true;
       loc = false;
     }
     const u64 m_pre = __ballot(pre), m_loc = __ballot(loc && !pre);
-    // lanes 0 .. f-1 LOCAL, lane f PREFIX
+    // lanes 0 .. f-1 LOCAL, lane f inclusive state
     const int f = m_pre ? __builtin_ctzll(m_pre) : 64;
     const u64 need = f == 64 ? ~0ull : ((1ull << f) - 1ull);
-    if ((m_loc & need) != need) {
-      __builtin_amdgcn_s_sleep(2);
+    const bool wave_ok = (m_loc & need) == need;
+    // inclusive scan of the transfers: lane t <- lanes 0..t, lane 0 (nearest) applied last
+    XferT<NW> c;
+    const uint32_t fl = uint32_t(wa[0] >> 32) & 0xFu;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      c.a[k] = uint32_t(wa[k]);
+      c.v[k] = uint32_t(wv_[k]);
+      c.f[k] = fld_mask1(fl >> (2 * k));
+    }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      XferT<NW> nr; // the segment of the `o` nearer lanes
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        nr.a[k] = __shfl_up(c.a[k], o, 64);
+        nr.v[k] = __shfl_up(c.v[k], o, 64);
+        nr.f[k] = __shfl_up(c.f[k], o, 64);
+      }
+      if (lane >= o)
+        c = xfer_compose<NW>(c, nr); // own (farther) first, then the nearer ones
+    }
+    // summary of the wavefront: [0] f, [1] ok, [2..7] transfer of lanes 0..f-1,
+    // [8..11] state of lane f
+    uint32_t* X = F.misc + M_LBX + 12 * wv;
+    if (lane == 0) {
+      X[0] = uint32_t(f);
+      X[1] = wave_ok ? 1u : 0u;
+      if (f == 0) { // (no LOCAL lanes in front of the state: identity)
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          X[2 + k] = 0u;
+      }
+    }
+    if (f > 0 && lane == (f == 64 ? 63 : f - 1)) {
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        X[2 + k] = c.f[k];
+        X[4 + k] = c.a[k];
+        X[6 + k] = c.v[k];
+      }
+    }
+    if (f < 64 && lane == f) {
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        X[8 + k] = real ? uint32_t(wt[k]) : initw[k];
+        X[10 + k] = real ? uint32_t(wc[k]) : initw[k];
+      }
+    }
+    __syncthreads();
+    int state = 0; // 0: all 256 LOCAL, 1: found an inclusive state, 2: blocked
+    uint32_t Tf[NW], Vf[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k)
+      Tf[k] = Vf[k] = 0;
+#pragma unroll
+    for (int w4 = 0; w4 < 4; ++w4) {
+      if (state != 0)
+        continue;
+      const uint32_t* Y = F.misc + M_LBX + 12 * w4;
+      if (!uni(Y[1])) {
+        state = 2;
+        continue;
+      }
+      XferT<NW> h;
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        h.f[k] = uni(Y[2 + k]);
+        h.a[k] = uni(Y[4 + k]);
+        h.v[k] = uni(Y[6 + k]);
+      }
+      g = xfer_compose<NW>(h, g); // this wavefront's lanes are farther than everything so far
+      if (uni(Y[0]) < 64u) {
+        state = 1;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+          Tf[k] = uni(Y[8 + k]);
+          Vf[k] = uni(Y[10 + k]);
+        }
+      }
+    }
+    __syncthreads(); // (the exchange words are free again)
+    if (state == 1) {
+      uint32_t to[2] = {0, 0}, vo[2] = {0, 0};
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        to[k] = pk_add(g.a[k], (Vf[k] & g.f[k]) | (Tf[k] & ~g.f[k]));
+        vo[k] = pk_add(Vf[k], g.v[k]);
+      }
+      *T_in = make_uint2(to[0], to[1]);
+      *V_in = make_uint2(vo[0], vo[1]);
+      return true;
+    }
+    if (state == 0) {
+      pos -= LJ_T;
       continue;
     }
-    Xfer mine;
-    mine.a = make_uint2(uint32_t(w[0]), uint32_t(w[1]));
-    mine.v = make_uint2(uint32_t(w[2]), uint32_t(w[3]));
-    mine.f = fld_mask(uint32_t(w[0] >> 32) & 0xFu);
-    // fold the LOCAL transfers, nearest first: g = g o h_l
-    const int nl = f == 64 ? 64 : f;
-    for (int l = 0; l < nl; ++l) {
-      Xfer h;
-      h.a = make_uint2(__shfl(mine.a.x, l, 64), __shfl(mine.a.y, l, 64));
-      h.v = make_uint2(__shfl(mine.v.x, l, 64), __shfl(mine.v.y, l, 64));
-      h.f = make_uint2(__shfl(mine.f.x, l, 64), __shfl(mine.f.y, l, 64));
-      g = xfer_compose(h, g);
-    }
-    if (f == 64) {
-      pos -= 64;
-      continue;
-    }
-    uint2 T = make_uint2(uint32_t(w[4]), uint32_t(w[5]));
-    uint2 V = make_uint2(uint32_t(w[6]), uint32_t(w[7]));
-    if (!real)
-      T = V = init;
-    T = make_uint2(__shfl(T.x, f, 64), __shfl(T.y, f, 64));
-    V = make_uint2(__shfl(V.x, f, 64), __shfl(V.y, f, 64));
-    *T_in = pk_add2(g.a, sel2(g.f, V, T));
-    *V_in = pk_add2(V, g.v);
-    return true;
+    // blocked: forget this pass's partial composition and look again
+#pragma unroll
+    for (int k = 0; k < NW; ++k)
+      g.f[k] = g.a[k] = g.v[k] = 0;
+    pos = int64_t(b) - 1;
+    __builtin_amdgcn_s_sleep(2);
   }
   return false;
+}
+
+// The stream's fields the kernel uses, read ONCE and made wave-uniform.  Through a
+// reference to a.streams[s] -- s itself a loaded value -- the compiler takes every field
+// for a per-lane value: a vector load plus a wait at every use, re-issued after every
+// store (measured: 16 us of a workgroup's 55 in the copy-out alone).
+struct FastStream {
+  uint32_t fast_n; // fast ? direct : 0
+  uint32_t first_block, first_subseq, table_base, start_bit, n_blocks;
+  uint32_t RS, kind, keep, out_x, out_y, pitch, n_strips, strip_base;
+  uint64_t needed, img_offset;
+  uint2 init;
+};
+__device__ __forceinline__ uint64_t uni64(uint64_t x) {
+  return uint64_t(uni(uint32_t(x))) | (uint64_t(uni(uint32_t(x >> 32))) << 32);
+}
+__device__ __forceinline__ FastStream lf_stream(const LjStreamDev& S) {
+  FastStream f;
+  f.fast_n = uni(S.fast ? uint32_t(S.direct) : 0u);
+  f.first_block = uni(S.first_block);
+  f.first_subseq = uni(S.first_subseq);
+  f.table_base = uni(S.table_base);
+  f.start_bit = uni(S.start_bit);
+  f.n_blocks = uni(S.n_blocks);
+  f.RS = uni(S.row_samples);
+  f.kind = uni(S.kind);
+  f.keep = uni(S.keep_samples < S.row_samples ? S.keep_samples : S.row_samples);
+  f.out_x = uni(S.out_x);
+  f.out_y = uni(S.out_y);
+  f.pitch = uni(S.img_pitch);
+  f.n_strips = uni(S.n_strips);
+  f.strip_base = uni(S.strip_base);
+  f.needed = uni64(S.needed);
+  f.img_offset = uni64(S.img_offset);
+  f.init = make_uint2(uni(uint32_t(S.init_pred[0]) | (uint32_t(S.init_pred[1]) << 16)),
+                      uni(uint32_t(S.init_pred[2]) | (uint32_t(S.init_pred[3]) << 16)));
+  return f;
 }
 
 __device__ __forceinline__ void strip_divmod(uint64_t off, uint32_t w, uint32_t* row,
@@ -513,9 +702,9 @@ __device__ __forceinline__ void strip_divmod(uint64_t off, uint32_t w, uint32_t*
 // ---------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void lf_copy_out(const FastLds& F, const LjArgs& a,
-                                            const LjStreamDev& S, uint32_t A0, uint32_t A1,
+                                            const FastStream& S, uint32_t A0, uint32_t A1,
                                             uint32_t sb, uint32_t r0, int tid) {
-  const uint32_t RS = S.row_samples;
+  const uint32_t RS = S.RS;
   uint8_t* img = a.out_base + S.img_offset;
   uint32_t i = A0;
   uint32_t z = 0; // current CR2 strip
@@ -524,28 +713,31 @@ __device__ __forceinline__ void lf_copy_out(const FastLds& F, const LjArgs& a,
     uint8_t* dst = nullptr;
     uint32_t pend;
     if (S.kind == 0) {
-      const uint32_t keep = S.keep_samples < RS ? S.keep_samples : RS;
+      const uint32_t keep = S.keep;
       if (sidx < keep) {
         pend = r * RS + keep;
-        dst = img + uint64_t(S.out_y + r) * S.img_pitch + 2u * (S.out_x + sidx);
+        dst = img + uint64_t(S.out_y + r) * S.pitch + 2u * (S.out_x + sidx);
       } else {
         pend = (r + 1) * RS; // trailing MCUs of the frame that the tile does not keep
       }
     } else {
-      const Cr2Strip* st = a.strips + S.strip_base;
-      while (z + 1 < S.n_strips && uint64_t(i) >= st[z + 1].first_sample)
+      // (the strips lie in LDS: on gfx9 a load's s_waitcnt vmcnt also waits for the
+      // acknowledgements of the pixel stores issued before it -- 2 us per run)
+      const Cr2Strip* st = reinterpret_cast<const Cr2Strip*>(F.strips);
+      while (z + 1 < S.n_strips && uint64_t(i) >= uni64(st[z + 1].first_sample))
         ++z;
+      const uint32_t sx0 = uni(st[z].x0), sw = uni(st[z].w), sy0 = uni(st[z].y0);
       uint32_t srow, col;
-      strip_divmod(uint64_t(i) - st[z].first_sample, st[z].w, &srow, &col);
-      const uint32_t in_strip = st[z].w - col, in_row = RS - sidx;
+      strip_divmod(uint64_t(i) - uni64(st[z].first_sample), sw, &srow, &col);
+      const uint32_t in_strip = sw - col, in_row = RS - sidx;
       pend = i + (in_strip < in_row ? in_strip : in_row);
-      dst = img + uint64_t(st[z].y0 + srow) * S.img_pitch + 2u * (st[z].x0 + col);
+      dst = img + uint64_t(sy0 + srow) * S.pitch + 2u * (sx0 + col);
     }
     if (pend > A1)
       pend = A1;
     const uint32_t n = pend - i;
     if (dst) {
-      const uint2 Cv = F.rowE[r - r0];
+      const uint2 Cv = F.ctab[r - r0];
       const uint2 C = make_uint2(uni(Cv.x), uni(Cv.y));
       const uint32_t delta = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u) >> 1;
       const uint32_t ph0 = (i + 8u - delta) & uint32_t(N - 1);
@@ -608,23 +800,48 @@ __device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad
   }
 }
 
+// phase time stamps of experiment builds (scripts/exp_lj_stats.py prints their means)
+#ifdef RSX_EXPERIMENT
+#define LF_STAMP(k)                                                      \
+  do {                                                                   \
+    if (a.dbg && j == 0)                                                 \
+      a.dbg[size_t(b) * 16 + (k)] = __builtin_amdgcn_s_memtime();        \
+  } while (0)
+#else
+#define LF_STAMP(k) \
+  do {              \
+  } while (0)
+#endif
+
 // ---------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const FastLds F = carve_fast(smem);
+  const FastLds F = carve_fast(smem, a.fast_lds);
   const int j = threadIdx.x, lane = j & 63, wv = j >> 6;
+#ifdef RSX_EXPERIMENT
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
   if (j == 0)
     F.misc[M_TICKET] = atomicAdd(&a.tickets[N == 4 ? 2 : N - 1], 1u);
   __syncthreads();
-  const uint32_t b = uni(F.misc[M_TICKET]);
-  const uint32_t s = a.block_stream[b];
-  const LjStreamDev& S = a.streams[s];
-  if (!S.fast || int(S.direct) != N)
+  // ticket -> block: the blocks of the launch's streams interleaved (each stream's in
+  // order, so every predecessor holds an earlier ticket).  A workgroup waits for ALL its
+  // stream's workgroups in flight; with one stream after the other that is everything on
+  // the chip, and it pays the slowest of ~1000 -- interleaved, 1000 / streams.
+  const uint32_t b = uni(a.fast_order[uni(F.misc[M_TICKET])]);
+  const uint32_t s = uni(a.block_stream[b]);
+  const FastStream S = lf_stream(a.streams[s]);
+  if (int(S.fast_n) != N)
     return; // (workgroup-uniform)
   const uint32_t lb = b - S.first_block;
+#ifdef RSX_EXPERIMENT
+  if (a.dbg && j == 0)
+    a.dbg[size_t(b) * 16] = t_start;
+#endif
+  LF_STAMP(1);
 
   // tables + image
   {
@@ -634,16 +851,14 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
     dst[j + LJ_T] = src[j + LJ_T];
   }
   Lds L{};
-  L.tabs = reinterpret_cast<TabLds*>(smem + LF_OFF_TAB10);
   L.B = F.B;
   L.ob = F.ob;
-  lj_stage_tables10(L, a, S);
   if (j == 0) {
     F.misc[M_SLOW] = 0;
-    F.misc[M_DUMP] = 0;
     F.misc[M_NSIDE] = 0;
   }
   lj_load_image<LF_BW, true>(L, a, b, j); // ends with a barrier
+  LF_STAMP(2);
   // delay the lane's column by one bit (see the header): dword k := d[k-1] : d[k] >> 1
   {
     uint32_t prev = 0;
@@ -656,14 +871,26 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
     }
   }
   __syncthreads();
+  LF_STAMP(3);
   const uint32_t own_bits = F.ob[j];
-  const bool long_codes = F.tab10->max_len > 10;
   // LDS address of the row of dword 0 of a column
   const uint32_t vbase_own = lds_addr(&F.B[(LF_BW - 1) * LJ_T + j]);
 
-  // 1. warm-up: slot j-1 from bit 0 (j == 0 has no predecessor slot here)
-  const uint32_t guess = lf_warmup(vbase_own - 4u, j >= 1 ? uint32_t(F.ob[j >= 1 ? j - 1 : 0]) : 0u,
-                                   j >= 1 && F.ob[j >= 1 ? j - 1 : 0] != 0);
+  // 1. the start guess: left by lj_unstuff_kernel (a parse of the three slots before the
+  // lane's from bit 0).  With LF_WARM_SLOTS != 0 it is made here instead, from one or two
+  // slots (experiments: every slot parsed here adds 6 us to the workgroup's lifetime).
+  uint32_t guess = 0;
+  if (LF_WARM_SLOTS == 0) {
+    if (j >= 1)
+      guess = a.sub_start[S.first_subseq + lb * LJ_OWN + uint32_t(j - 1)];
+  } else {
+    const uint32_t ob2 = (LF_WARM_SLOTS >= 2 && j >= 2) ? uint32_t(F.ob[j >= 2 ? j - 2 : 0]) : 0u;
+    const uint32_t ob1 = j >= 1 ? uint32_t(F.ob[j >= 1 ? j - 1 : 0]) : 0u;
+    const bool en = !(LF_ABLATE & 32u);
+    const uint32_t g2 = lf_warmup(vbase_own - 8u, ob2, en && j >= 2 && ob2 != 0);
+    guess = lf_warmup(vbase_own - 4u, ob1, en && j >= 1 && ob1 != 0, g2 & ST_OFF_MASK);
+  }
+  LF_STAMP(4);
   uint32_t start = guess & ST_OFF_MASK;
   if (j == 1 && lb == 0)
     start = S.start_bit;
@@ -678,7 +905,10 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
   const uint32_t pend = uint32_t(-32) - 32u * own_bits;
   if (j == 0)
     fs.Pn = pend; // (slot 0 belongs to the previous workgroup: nothing to decode)
+  if (LF_ABLATE & 16u)
+    fs.Pn = pend;
   lf_groups<N, 0>(fs, vbase_own, pend, R);
+  LF_STAMP(5);
   bool need_redo = false;
   {
     const bool special = !(fs.Pn & 0x80000000u);
@@ -726,7 +956,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
       }
       need_redo = false;
       __syncthreads();
-      const uint32_t nl = uni(F.misc[M_LIST]);
+      const uint32_t nl = (LF_ABLATE & 64u) ? 0u : uni(F.misc[M_LIST]);
       if (uni(F.misc[M_NSIDE]) > uint32_t(LF_NSIDE)) {
         if (j == 0)
           F.misc[M_SLOW] = 1; // more re-decodes than the side buffer has entries
@@ -738,6 +968,14 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
           F.misc[M_SLOW] = 1; // periodic data: not this kernel's business
         break;
       }
+#ifdef RSX_EXPERIMENT
+      if (j == 0) {
+        atomicAdd(&a.results[s].stat_rounds, 1u);
+        atomicAdd(&a.results[s].stat_redo, nl);
+        if (attempt == 1)
+          atomicAdd(&a.results[s].stat_stitch, 1u);
+      }
+#endif
       uint32_t idx = 1, w = 0, e = 0, c = 0;
       uint2 sums = make_uint2(0, 0);
       bool ovf = false;
@@ -748,8 +986,8 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
         w = rec_st(F.rec[idx - 1]);
         if (w & ST_ERR) // (listed for its own sake: from the state it started from)
           w = rec_su(F.rec[idx]) & ST_OFF_MASK;
-        lf_careful<N>(F, long_codes, int(idx), w, F.ob[idx],
-                      lds_addr(F.side) + (le >> 8) * LF_SIDE_STRIDE, mine, e, c, sums, ovf);
+        lf_redecode<N>(F, a.tables[S.table_base], int(idx), w, F.ob[idx],
+                       lds_addr(F.side) + (le >> 8) * LF_SIDE_STRIDE, mine, e, c, sums, ovf);
       }
       __syncthreads(); // every read of the records precedes the updates
       if (mine) {
@@ -798,40 +1036,39 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
     const uint32_t exit_now = uni(rec_st(F.rec[LJ_T - 1]));
     const uint32_t entry_now = uni(rec_st(F.rec[0]));
 
-    // 4. look-back 0
+    // 4. the workgroup's record (LOCAL: entry, exit and symbols of this decode), then
+    // look-back 0: the predecessor's exit and the index of the workgroup's first symbol
+    // in one sweep over the predecessors' records.  A wrong entry assumption is repaired
+    // and the record published again; the symbol index does not depend on it.
     if (attempt == 0) {
       published_exit = exit_now;
-      if (lb == 0) {
-        base = 0;
-        break;
-      }
-      if (j == 0)
-        lb_store(a.lb + size_t(b) * LF_LB_WORDS,
-                 lb0_make(LB0_LOCAL, entry_now, st_to7(exit_now), cnt_wg, 0));
-      if (wv == 0) {
-        uint32_t pe = 0, bs = 0;
-        const bool ok = lb0_walk(a, b, S.first_block, S.start_bit, lane, &pe, &bs);
-        if (lane == 0) {
-          F.misc[M_PRED] = pe;
-          F.misc[M_BASE] = bs;
-          if (!ok)
-            F.misc[M_SLOW] = 1;
-        }
-      }
-      __syncthreads();
-      base = uni(F.misc[M_BASE]);
-      const uint32_t pe = uni(F.misc[M_PRED]);
-      if (pe == entry_now || (pe & ST_ERR))
-        break;
-      // the assumed entry was wrong: re-converge from the true one
-      if (j == 0)
-        F.rec[0] = rec_make(0, pe, 0);
-      // (the barrier at the top of the rounds orders this store)
-    } else {
-      if (exit_now != published_exit && j == 0)
-        F.misc[M_SLOW] = 1; // successors may have used the exit published first
+      LF_STAMP(6);
+    } else if (exit_now != published_exit && j == 0) {
+      F.misc[M_SLOW] = 1; // successors may have used the exit published first
     }
+    if (lb == 0)
+      break;
+    if (j == 0)
+      lb_store(a.lb + size_t(b) * LF_LB_WORDS,
+               lb0_make(LB0_LOCAL, entry_now, st_to7(exit_now), cnt_wg, 0));
+    if (attempt == 1)
+      break;
+    uint32_t pe = entry_now, bs = lb * 15500u;
+    if (!(LF_ABLATE & 4u)) {
+      const bool ok = lb0_walk(a, F, b, S.first_block, S.start_bit, j, &pe, &bs);
+      if (!ok && j == 0)
+        F.misc[M_SLOW] = 1;
+    }
+    base = bs;
+    LF_STAMP(7);
+    if (pe == entry_now || (pe & ST_ERR))
+      break;
+    // the assumed entry was wrong: re-converge from the true one
+    // (the barrier at the top of the rounds orders this store)
+    if (j == 0)
+      F.rec[0] = rec_make(0, pe, 0);
   }
+  LF_STAMP(8);
   if (__any(my_entry >= 0 && my_entry < LF_NSIDE)) {
     if (my_entry >= 0 && my_entry < LF_NSIDE) {
       // (dword by dword: a uint4 view turns R into 16 vectors for the compiler)
@@ -845,20 +1082,11 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
   if (j == 0)
     lb_store(a.lb + size_t(b) * LF_LB_WORDS,
              lb0_make(LB0_FINAL, rec_st(F.rec[0]), st_to7(published_exit), cnt_wg, base + cnt_wg));
-
-  // records the per-stream bookkeeping kernels read (lj_scan_kernel, lj_consumed_kernel)
-  {
-    const uint32_t my_rec = F.rec[j];
-    if (j >= 1)
-      a.sub_state[gsub] = rec_st(my_rec) | (rec_cn(my_rec) << 16);
-    if (j == 0) {
-      a.block_start[b] = rec_st(F.rec[0]);
-      a.block_exit[b] = published_exit;
-      a.block_sum[b] = cnt_wg;
-      a.block_flags[b] = 0;
-      a.block_psum[b] = S_wg;
-    }
-  }
+  // (the records the per-stream bookkeeping kernels read are stored at the very end: on
+  // gfx9 a store in front of the look-back's loads makes their s_waitcnt wait for its
+  // acknowledgement, too)
+  const uint32_t my_rec_final = F.rec[j];
+  const uint32_t entry_final = uni(rec_st(F.rec[0]));
   const uint64_t needed = S.needed;
   const uint32_t i0 = base + before; // index of the lane's first symbol
   uint32_t cnt_eff = my_cnt;
@@ -866,103 +1094,101 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
     cnt_eff = 0;
   else if (uint64_t(i0) + cnt_eff > needed)
     cnt_eff = uint32_t(needed - i0);
-  const uint32_t my_start = rec_su(F.rec[j]), my_exit = rec_st(F.rec[j]);
-  // an invalid code inside the delivered range: the slow path reports it the
-  // reference's way (PrefixCodeLookupDecoder.h:152-155)
-  if (j >= 1 && (my_exit & ST_ERR) && uint64_t(i0) + my_cnt < needed && own_bits != 0)
-    F.misc[M_SLOW] = 1;
-  // lj_consumed_kernel needs the bit position at which the reference's last symbol
-  // starts: exactly one lane of the stream owns it and walks there again
-  if (needed >= 1 && needed - 1 >= i0 && needed - 1 < uint64_t(i0) + my_cnt && j >= 1) {
-    const uint32_t target = uint32_t(needed - 1 - i0);
-    uint32_t p2 = my_start & ST_OFF_MASK;
-    const TabLds10& tb = *F.tab10;
-    for (uint32_t t = 0; t < target; ++t) {
-      const uint32_t w = lj_window<LF_BW>(F.B, j, p2 + 1u);
-      uint32_t e = tb.lut[w >> 22];
-      if ((e & 31u) == 0u)
-        e = lf_slow_entry(w, tb);
-      p2 += e >> 10;
+  {
+    const uint32_t my_start = rec_su(my_rec_final), my_exit = rec_st(my_rec_final);
+    // an invalid code inside the delivered range: the slow path reports it the
+    // reference's way (PrefixCodeLookupDecoder.h:152-155)
+    if (j >= 1 && (my_exit & ST_ERR) && uint64_t(i0) + my_cnt < needed && own_bits != 0)
+      F.misc[M_SLOW] = 1;
+    // lj_consumed_kernel needs the bit position at which the reference's last symbol
+    // starts: exactly one lane of the stream owns it and walks there again
+    if (needed >= 1 && needed - 1 >= i0 && needed - 1 < uint64_t(i0) + my_cnt && j >= 1) {
+      const uint32_t target = uint32_t(needed - 1 - i0);
+      uint32_t p2 = my_start & ST_OFF_MASK;
+      const TabLds& tb = a.tables[S.table_base];
+      for (uint32_t t = 0; t < target; ++t) {
+        const uint32_t w = lj_window<LF_BW>(F.B, j, p2 + 1u);
+        p2 += lf_slow_entry(w, tb) >> 10;
+      }
+      a.results[s].last_slot = lb * LJ_OWN + uint32_t(j - 1);
+      a.results[s].last_pos = p2;
     }
-    a.results[s].last_slot = lb * LJ_OWN + uint32_t(j - 1);
-    a.results[s].last_pos = p2;
   }
+  LF_STAMP(9);
 
-  // 5. rows.  Lane-relative phase p = workgroup-relative phase (before + p) mod N.
-  const uint32_t RS = S.row_samples;
-  const uint2 pexrel = lj_rot_fields<N>(pex, (uint32_t(N) - (before & uint32_t(N - 1))) & uint32_t(N - 1));
+  // 5. geometry of the delivered symbols [base, lim) and the stream rows they touch
+  const uint32_t RS = S.RS;
   uint64_t lim64 = uint64_t(base) + cnt_wg;
   if (lim64 > needed)
     lim64 = needed;
-  const uint32_t lim = uint32_t(lim64); // symbols of the workgroup that are delivered end here
+  const uint32_t lim = uint32_t(lim64);
   const bool any_out = lim > base;
   const uint32_t r0 = base / RS;
   const uint32_t r_end = any_out ? (lim - 1) / RS : r0;
   const uint32_t nr = r_end - r0 + 1;
-  if (nr > uint32_t(LF_RMAX) && j == 0)
+  // (more rows than lanes, or more samples than the staging region holds: slow path)
+  const bool fits = nr <= uint32_t(LF_RMAX) && (lim - base) <= F.stage_cap;
+  if (!fits && j == 0)
     F.misc[M_SLOW] = 1;
-  __syncthreads(); // the records are dead: their place becomes the row table
-  const bool rows_ok = nr <= uint32_t(LF_RMAX);
-  {
-    // zero the table (a component whose first-MCU symbol is not in this workgroup has D = 0)
-    uint32_t* z = reinterpret_cast<uint32_t*>(F.rowE);
-    for (int k = j; k < LF_RMAX * 4; k += LJ_T)
-      z[k] = 0;
-  }
-  __syncthreads();
-  {
-    // first-MCU symbols of this lane: stream indices r * RS + c inside [i0, i0 + cnt_eff)
-    const uint32_t rl = i0 / RS;
-    const uint32_t ml = i0 - rl * RS;
-    // the first row whose first MCU can reach into the lane
-    uint32_t r = ml < uint32_t(N) ? rl : rl + 1;
-    const bool has = rows_ok && cnt_eff != 0 &&
-                     (ml < uint32_t(N) || uint64_t(rl + 1) * RS < uint64_t(i0) + cnt_eff);
-    int my_d = -1;
-    if (has)
-      my_d = int(atomicAdd(&F.misc[M_DUMP], 1u));
-    __syncthreads();
-    const uint32_t nd = uni(F.misc[M_DUMP]);
-    for (uint32_t d0 = 0; d0 < nd; d0 += uint32_t(LF_NSIDE)) {
-      const bool dump = my_d >= int(d0) && my_d < int(d0) + LF_NSIDE;
-      if (__any(dump)) {
-        if (dump) {
-          uint8_t* sp = F.side + size_t(my_d - int(d0)) * LF_SIDE_STRIDE;
-          const uint32_t sa = lds_addr(sp);
+  const uint32_t sb = LF_STAGE_BASE;
+  __syncthreads(); // every lane is done with the image, the records and the side buffer
+
+  // 6. staging: running sums + P before the lane = Ploc, in stream order
+  if (fits && !(LF_ABLATE & 1u)) {
+    const uint2 pexrel =
+        lj_rot_fields<N>(pex, (uint32_t(N) - (before & uint32_t(N - 1))) & uint32_t(N - 1));
+    const uint32_t ad = sb + 2u * before;
+    // pairs that are written from the registers (a count clipped by `needed` writes one
+    // sample more: nothing after it is delivered)
+    const uint32_t nq = cnt_eff == my_cnt ? (cnt_eff >> 1) : ((cnt_eff + 1) >> 1);
+    uint32_t nqmax = nq;
 #pragma unroll
-          for (int q = 0; q < LF_NR; ++q)
-            *(lds_u32w)(sa + 4u * q) = R[q];
-          // the last symbol of an odd count lives in the accumulator, not in R
-          if (my_cnt & 1u)
-            reinterpret_cast<uint16_t*>(sp)[my_cnt - 1] = uint16_t(fld(my_sums, (my_cnt - 1) & uint32_t(N - 1)));
-          const uint16_t* rv = reinterpret_cast<const uint16_t*>(sp);
-          for (; uint64_t(r) * RS < uint64_t(i0) + cnt_eff; ++r) {
-#pragma unroll
-            for (uint32_t c = 0; c < uint32_t(N); ++c) {
-              const uint64_t i = uint64_t(r) * RS + c;
-              if (i < i0 || i >= uint64_t(i0) + cnt_eff)
-                continue;
-              const uint32_t k = uint32_t(i - i0);
-              const uint32_t fv = rv[k];
-              const uint32_t pv = k >= uint32_t(N) ? uint32_t(rv[k - N]) : 0u;
-              const uint32_t E = (fld(pexrel, k & uint32_t(N - 1)) + pv) & 0xFFFFu;
-              const uint32_t D = (fv - pv) & 0xFFFFu;
-              const uint32_t t = r - r0;
-              reinterpret_cast<uint16_t*>(F.rowE)[4 * t + c] = uint16_t(E);
-              reinterpret_cast<uint16_t*>(F.rowD)[4 * t + c] = uint16_t(D);
-            }
-          }
-        }
-      }
-      __syncthreads();
+    for (int o = 32; o > 0; o >>= 1)
+      nqmax = max(nqmax, uint32_t(__shfl_xor(nqmax, o, 64)));
+    const uint32_t k0 = N == 1 ? (pexrel.x & 0xFFFFu) * 0x10001u : pexrel.x;
+    const uint32_t k1 = N == 4 ? pexrel.y : k0;
+    lf_stage<0>(R, ad, nq, nqmax, k0, k1);
+    if ((cnt_eff & 1u) && cnt_eff == my_cnt) {
+      const uint32_t k = cnt_eff - 1;
+      const uint32_t v = fld(my_sums, k & uint32_t(N - 1)) + fld(pexrel, k & uint32_t(N - 1));
+      *(lds_u16w)(ad + 2u * k) = uint16_t(v);
     }
   }
-  // scan over the rows: Vloc (exclusive) and the workgroup's transfer
+  // the CR2 strips into LDS (pixel stores in front of a load: see above)
+  if (S.kind == 1) {
+    const uint32_t nw = (S.n_strips + 1) * uint32_t(sizeof(Cr2Strip) / 4);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.strips + S.strip_base);
+    for (uint32_t k = uint32_t(j); k < nw; k += uint32_t(LJ_T))
+      reinterpret_cast<uint32_t*>(F.strips)[k] = src[k];
+  }
+  __syncthreads();
+  LF_STAMP(10);
+
+  // 7. rows.  Lane t takes stream row r0 + t: for each component whose first-MCU symbol
+  // r * RS + c lies in the workgroup, E = Ploc before it (the staged sample N back, 0 at
+  // the workgroup's start) and D = its difference.
   uint2 Cloc = make_uint2(0, 0), Vsum = make_uint2(0, 0);
   {
-    const bool act = rows_ok && uint32_t(j) < nr;
-    const uint2 D = act ? F.rowD[j] : make_uint2(0u, 0u);
-    const uint2 E = act ? F.rowE[j] : make_uint2(0u, 0u);
+    uint32_t ev[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0};
+    if (fits && uint32_t(j) < nr && !(LF_ABLATE & 128u)) {
+      const uint64_t rs = uint64_t(r0 + uint32_t(j)) * RS;
+#pragma unroll
+      for (uint32_t c = 0; c < uint32_t(N); ++c) {
+        const uint64_t i = rs + c;
+        if (i >= base && i < lim) {
+          const uint32_t e = uint32_t(i - base);
+          const uint32_t fv = *(const __attribute__((address_space(3))) uint16_t*)(sb + 2u * e);
+          const uint32_t pv =
+              e >= uint32_t(N)
+                  ? uint32_t(*(const __attribute__((address_space(3))) uint16_t*)(sb + 2u * (e - N)))
+                  : 0u;
+          ev[c] = pv;
+          dv[c] = (fv - pv) & 0xFFFFu;
+        }
+      }
+    }
+    const uint2 E = make_uint2(ev[0] | (ev[1] << 16), ev[2] | (ev[3] << 16));
+    const uint2 D = make_uint2(dv[0] | (dv[1] << 16), dv[2] | (dv[3] << 16));
     const uint2 dincl = wave_scan_pk2(D, lane);
     if (lane == 63) {
       F.misc[M_RSUM + 2 * wv] = dincl.x;
@@ -977,20 +1203,21 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
       Vsum = pk_add2(Vsum, t);
     }
     Cloc = pk_sub2(vex, E);
-    if (act)
-      F.rowE[j] = Cloc;
+    if (uint32_t(j) < nr && nr <= uint32_t(LF_RMAX))
+      F.ctab[j] = Cloc;
   }
   __syncthreads();
+  LF_STAMP(11);
   // the sums of the workgroup's differences by component (absolute)
   const uint2 S_abs = lj_rot_fields<N>(S_wg, base & uint32_t(N - 1));
-  const uint2 init = make_uint2(uint32_t(S.init_pred[0]) | (uint32_t(S.init_pred[1]) << 16),
-                                uint32_t(S.init_pred[2]) | (uint32_t(S.init_pred[3]) << 16));
-  // 5b. look-back 1
-  if (wv == 0) {
+  const uint2 init = S.init;
+  // 8. look-back 1
+  uint2 T_in = init, V_in = init;
+  {
     // which components start a row here, and from which table row their last start is
     uint32_t flags = 0;
     uint2 al = S_abs;
-    if (rows_ok && any_out) {
+    if (fits && any_out) {
       uint32_t av[4] = {0, 0, 0, 0};
 #pragma unroll
       for (uint32_t c = 0; c < uint32_t(N); ++c) {
@@ -1002,16 +1229,16 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
           tl = int(nr) - 2;
         if (tl >= 0) {
           flags |= 1u << c;
-          av[c] = (fld(F.rowE[tl], c) + fld(S_abs, c)) & 0xFFFFu;
+          av[c] = (fld(F.ctab[tl], c) + fld(S_abs, c)) & 0xFFFFu;
         } else {
           av[c] = fld(S_abs, c);
         }
       }
       al = make_uint2(av[0] | (av[1] << 16), av[2] | (av[3] << 16));
     }
-    if (lane == 0) {
+    constexpr int NW = (N + 1) / 2;
+    if (j == 0) {
       u64* p = a.lb + size_t(b) * LF_LB_WORDS + 1;
-      constexpr int NW = (N + 1) / 2;
       lb_store(p + 2, LB_VALID | Vsum.x);
       if (NW == 2)
         lb_store(p + 3, LB_VALID | Vsum.y);
@@ -1019,15 +1246,10 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
         lb_store(p + 1, LB_VALID | (u64(flags) << 32) | al.y);
       lb_store(p + 0, LB_VALID | (u64(flags) << 32) | al.x);
     }
-    uint2 T_in = init, V_in = init;
     bool ok = true;
-    if (lb != 0)
-      ok = lb1_walk<N>(a, b, S.first_block, init, lane, &T_in, &V_in);
-    if (lane == 0) {
-      F.misc[M_TIN] = T_in.x;
-      F.misc[M_TIN + 1] = T_in.y;
-      F.misc[M_VIN] = V_in.x;
-      F.misc[M_VIN + 1] = V_in.y;
+    if (lb != 0 && !(LF_ABLATE & 8u))
+      ok = lb1_walk<N>(a, F, b, S.first_block, init, j, &T_in, &V_in);
+    if (j == 0) {
       if (!ok)
         F.misc[M_SLOW] = 1;
       // the inclusive state
@@ -1035,7 +1257,6 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
       const uint2 T_out = pk_add2(al, sel2(fm, V_in, T_in));
       const uint2 V_out = pk_add2(V_in, Vsum);
       u64* p = a.lb + size_t(b) * LF_LB_WORDS + 5;
-      constexpr int NW = (N + 1) / 2;
       lb_store(p + 2, LB_VALID | V_out.x);
       if (NW == 2)
         lb_store(p + 3, LB_VALID | V_out.y);
@@ -1044,13 +1265,11 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
       lb_store(p + 0, LB_VALID | T_out.x);
     }
   }
-  __syncthreads();
+  LF_STAMP(12);
   {
     // C(r, c): Vc_in + Cloc for the components whose first-MCU symbol is in this
     // workgroup, T_in for the row that is open when it starts
-    const uint2 T_in = make_uint2(uni(F.misc[M_TIN]), uni(F.misc[M_TIN + 1]));
-    const uint2 V_in = make_uint2(uni(F.misc[M_VIN]), uni(F.misc[M_VIN + 1]));
-    if (rows_ok && uint32_t(j) < nr) {
+    if (fits && uint32_t(j) < nr) {
       uint2 C = pk_add2(V_in, Cloc);
       if (j == 0) {
         uint32_t present = 0;
@@ -1060,65 +1279,52 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
             present |= 1u << c;
         C = sel2(fld_mask(present), C, T_in);
       }
-      F.rowE[j] = C;
+      F.ctab[j] = C;
     }
   }
   if (F.misc[M_SLOW] != 0 && j == 0)
     atomicOr(&a.results[s].flags, FL_SLOW);
   __syncthreads();
-  if (!rows_ok)
-    return;
-
-  // 6. output, wave by wave: stage the running sums (+ P before the lane) in stream
-  // order where the image lay, then everybody copies out
-  const uint32_t sb = lds_addr(F.B);
-  uint32_t wfirst = 0; // symbols before the wavefront inside the workgroup
-  for (int w = 0; w < 4; ++w) {
-    const uint32_t wcnt = uni(F.misc[M_WCNT + w]);
-    uint32_t A0 = base + wfirst, A1 = A0 + wcnt;
-    if (A1 > lim)
-      A1 = lim;
-    if (A0 < A1) { // (workgroup-uniform)
-      if (wv == w) {
-        const uint32_t ad = sb + 2u * (before - wfirst);
-        // pairs that are written from the registers (a count clipped by `needed`
-        // writes one sample more: nothing after it is delivered)
-        const uint32_t nq = cnt_eff == my_cnt ? (cnt_eff >> 1) : ((cnt_eff + 1) >> 1);
-        uint32_t nqmax = nq;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-          nqmax = max(nqmax, uint32_t(__shfl_xor(nqmax, o, 64)));
-        uint32_t k0 = N == 1 ? (pexrel.x & 0xFFFFu) * 0x10001u : pexrel.x;
-        uint32_t k1 = N == 4 ? pexrel.y : k0;
-        uint32_t nqw = nq;
-        // (opaque per round: left alone, the compiler hoists the 64 sums, their high
-        // halves and the 64 compare masks out of the loop over the wavefronts -- 190 VGPRs)
-        asm volatile("" : "+v"(k0), "+v"(k1), "+v"(nqw));
-        lf_stage<0>(R, ad, nqw, nqmax, k0, k1);
-        if ((cnt_eff & 1u) && cnt_eff == my_cnt) {
-          const uint32_t k = cnt_eff - 1;
-          const uint32_t v = fld(my_sums, k & uint32_t(N - 1)) + fld(pexrel, k & uint32_t(N - 1));
-          *(lds_u16w)(ad + 2u * k) = uint16_t(v);
-        }
-      }
-      __syncthreads();
-      lf_copy_out<N>(F, a, S, A0, A1, sb, r0, j);
-      __syncthreads();
-    }
-    wfirst += wcnt;
+  LF_STAMP(13);
+  LF_STAMP(14);
+  // 9. copy-out
+  if (fits && any_out && !(LF_ABLATE & 3u))
+    lf_copy_out<N>(F, a, S, base, lim, sb, r0, j);
+  // records the per-stream bookkeeping kernels read (lj_scan_kernel, lj_consumed_kernel)
+  if (j >= 1)
+    a.sub_state[gsub] = rec_st(my_rec_final) | (rec_cn(my_rec_final) << 16);
+  if (j == 0) {
+    a.block_start[b] = entry_final;
+    a.block_exit[b] = published_exit;
+    a.block_sum[b] = cnt_wg;
+    a.block_flags[b] = 0;
+    a.block_psum[b] = S_wg;
   }
+  LF_STAMP(15);
 }
 
 template <int N>
 void launch_fast_one(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
   if (!f.present[N])
     return;
-  hipLaunchKernelGGL((lj_fast_kernel<N>), dim3(f.total_blocks), dim3(LJ_T), LF_LDS_BYTES, s, a);
+  hipLaunchKernelGGL((lj_fast_kernel<N>), dim3(f.total_blocks), dim3(LJ_T), a.fast_lds, s, a);
   if (timer)
     timer->mark("lj_fast_kernel");
 }
 
 } // namespace
+
+// LDS bytes of a launch whose workgroups deliver up to `samples` symbols each (0 if no
+// allocation that keeps two workgroups on a CU holds them)
+uint32_t ljpeg_fast_lds_for(uint64_t samples) {
+  uint64_t need = 2 * samples + LF_TAIL_BYTES + LF_STAGE_BASE + 16;
+  if (need < LF_LDS_MIN)
+    need = LF_LDS_MIN;
+  need = (need + 1279) / 1280 * 1280;
+  if (need < 40960)
+    need = 40960; // (four workgroups per CU take 40 KB each anyway)
+  return need <= 64 * 1024 ? uint32_t(need) : 0u; // (more needs hipFuncSetAttribute)
+}
 
 void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
   launch_fast_one<1>(a, f, s, timer);

@@ -38,7 +38,8 @@ def main():
         env = dict(os.environ)
         if name != "base":
             env["RSX_LIB"] = os.path.join(ROOT, "rawspeed_amd", "variants", "librsx_%s.so" % name)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_ljpeg.py"), "--only", what],
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_ljpeg.py"), "--only", what,
+                            "--no-cpu"],
                            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         try:
             j = json.loads(r.stdout[r.stdout.index("{"):])

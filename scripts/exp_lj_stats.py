@@ -1,0 +1,15 @@
+"""Round statistics of the LJPEG synchronisation on cfg 3 (experiment build with
+-DRSX_EXPERIMENT; RSX_DEBUG=1 makes the plan print its per-stream counters)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import bench_ljpeg as B
+from rawspeed_amd import capi
+ctx = capi.Context(0)
+W, H = 6720, 4480
+frames = int(os.environ.get("FRAMES", "8"))
+made = [B.make_cr2_frame(W, H, (3, 2240, 2240), seed=1 + f) for f in range(frames)]
+plan, inp, out = B._cr2_batch(ctx, torch, [(m[0], m[1]) for m in made], W, H)
+plan.run(inp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+print(plan.results()[0])
