@@ -472,7 +472,7 @@ __device__ __forceinline__ uint32_t lj_guess_parse(const uint32_t* B, const uint
   }
   return pos - end_bits;
 }
-constexpr int LJ_GUESS_SLOTS = 3; // slots parsed for a guess
+constexpr int LJ_GUESS_SLOTS = 3; // slots parsed for a guess, at most (LjArgs::guess_slots)
 
 __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -522,7 +522,9 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     for (int k = LJ_GUESS_SLOTS; k >= 1; --k) {
       const int col = tgt - k;
       const uint32_t eb = col >= 0 ? uint32_t(L.ob[col >= 0 ? col : 0]) : 0u;
-      if (col >= 0 && eb != 0 && !(col == 0 && lb == 0))
+      if (uint32_t(k) > a.guess_slots) // (launch-uniform)
+        e = 0;
+      else if (col >= 0 && eb != 0 && !(col == 0 && lb == 0))
         e = lj_guess_parse(L.B, lut8, col, eb, e & ST_OFF_MASK);
       else
         e = 0;
@@ -1934,6 +1936,7 @@ struct LJpegPlan {
   bool fast_present[5] = {};   // [components]
   bool any_fast = false;       // some stream takes the single-pass kernel
   uint32_t fast_lds = 0;       // LDS bytes of its launches
+  std::vector<uint8_t> slow_strikes; // per stream: consecutive runs it went to the slow path
   bool any_pipeline = false;   // some stream takes the multi-kernel pipeline in the first pass
   bool expect_slow = false;    // the last run left FL_SLOW streams: launch the second pass at once
   bool slow_pass_launched = false; // ... this run already has
@@ -2028,7 +2031,13 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.lb = static_cast<unsigned long long*>(p->d_lb.ptr);
   a.tickets = static_cast<uint32_t*>(p->d_tickets.ptr);
   a.fast_lds = p->fast_lds;
-  a.fast_order = static_cast<const uint32_t*>(p->d_fast_order.ptr);
+  // A wrong guess delays the workgroups of ITS stream that are in flight; with many
+  // streams interleaved those are few, and two slots (0.03 % wrong) do.
+  uint32_t n_fast = 0;
+  for (const LjStreamDev& S : p->streams)
+    n_fast += S.fast ? 1u : 0u;
+  a.guess_slots = n_fast >= 32 ? 2u : 3u;
+  a.fast_order = static_cast<const uint2*>(p->d_fast_order.ptr);
   a.dbg = static_cast<unsigned long long*>(p->d_dbg.ptr);
   a.pass = 0;
   return a;
@@ -2424,16 +2433,16 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       for (size_t t = 0; t < tl.size(); ++t)
         ljpeg_build_fast_table(tl[t], ft.data() + t * 1024);
       // ticket order of the single-pass launches: round robin over the streams
-      std::vector<uint32_t> order;
+      std::vector<uint2> order;
       order.reserve(p->total_blocks);
       uint32_t max_blocks = 0;
       for (const LjStreamDev& S : p->streams)
         max_blocks = std::max(max_blocks, S.n_blocks);
       for (uint32_t k = 0; k < max_blocks; ++k)
-        for (const LjStreamDev& S : p->streams)
-          if (k < S.n_blocks)
-            order.push_back(S.first_block + k);
-      if ((st = up(p->d_fast_order, order.data(), order.size() * sizeof(uint32_t))))
+        for (size_t si = 0; si < p->streams.size(); ++si)
+          if (k < p->streams[si].n_blocks)
+            order.push_back(make_uint2(p->streams[si].first_block + k, uint32_t(si)));
+      if ((st = up(p->d_fast_order, order.data(), order.size() * sizeof(uint2))))
         return st;
       if ((st = up(p->d_fast_tabs, ft.data(), ft.size() * sizeof(uint2))) ||
           (st = p->d_lb.ensure(size_t(p->total_blocks) * LF_LB_WORDS * 8)) ||
@@ -2789,6 +2798,36 @@ int converge(LJpegPlan* p, hipStream_t s) {
         return st;
       if (int st = fetch())
         return st;
+    }
+    // A stream the single-pass kernel gave up on twice in a row (the same data decoded
+    // again: a batch loop, a benchmark) goes straight to the multi-kernel pipeline from
+    // now on; one that it finished is given another chance.
+    bool changed = false;
+    p->slow_strikes.resize(p->streams.size(), 0);
+    for (size_t k = 0; k < p->streams.size(); ++k) {
+      if (!p->streams[k].fast)
+        continue;
+      if (p->h_results[k].flags & FL_SLOW) {
+        if (++p->slow_strikes[k] >= 2) {
+          p->streams[k].fast = 0;
+          changed = true;
+        }
+      } else {
+        p->slow_strikes[k] = 0;
+      }
+    }
+    if (changed) {
+      RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->d_streams.ptr, p->streams.data(),
+                                        p->streams.size() * sizeof(LjStreamDev),
+                                        hipMemcpyHostToDevice, s));
+      RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+      p->any_pipeline = true;
+      p->any_fast = false;
+      for (const LjStreamDev& S : p->streams)
+        p->any_fast |= S.fast != 0;
+      p->expect_slow = false;
+      for (size_t k = 0; k < p->streams.size(); ++k)
+        p->expect_slow |= p->streams[k].fast && (p->h_results[k].flags & FL_SLOW);
     }
   }
   auto unconverged = [&]() {

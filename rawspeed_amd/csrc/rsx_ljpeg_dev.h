@@ -236,8 +236,9 @@ struct LjArgs {
   unsigned long long* lb;    // [workgroup][LF_LB_WORDS]: look-back records (zeroed by K0)
   uint32_t* tickets;         // [4]: workgroup tickets of the single-pass launches (zeroed by K0)
   uint32_t fast_lds;         // LDS bytes of the single-pass launches (staging capacity)
-  const uint32_t* fast_order; // [ticket]: the workgroup's block -- the streams' blocks
-                             // interleaved, each stream's in order
+  uint32_t guess_slots;      // slots K0 parses for a start guess (2 or 3)
+  const uint2* fast_order;   // [ticket]: the workgroup's (block, stream) -- the streams'
+                             // blocks interleaved, each stream's in order
   unsigned long long* dbg;   // experiment builds: [workgroup][16] phase time stamps
   uint32_t pass;             // 0: first pass; 1: the multi-kernel pipeline redoes FL_SLOW
                              // streams; 2: its streams of both passes

@@ -698,7 +698,14 @@ __device__ __forceinline__ void strip_divmod(uint64_t off, uint32_t w, uint32_t*
 
 // ---------------------------------------------------------------------------
 // Copy-out: the staged running sums of stream symbols [A0, A1) (LDS, stream order from
-// byte address sb) -> image, run by run, 16-byte chunks on the destination's grid.
+// byte address sb) -> image.  The samples fall into RUNS that are contiguous in the image
+// (a stream row's kept part, a CR2 strip row); a run is written as 16-byte chunks on the
+// destination's 16-byte grid (partial chunks at its ends sample by sample).  All chunks of
+// all runs are numbered through and dealt to the lanes round robin; every lane walks the
+// run list itself, incrementally (adds and compares: the divisions are in the first run
+// only), as its chunk number grows.  (First version: the workgroup went run by run -- two
+// passes of 256 lanes per 280-chunk run, the second one nearly empty, and two divisions
+// per run: 13 us a workgroup, then 5.6.)
 // ---------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ void lf_copy_out(const FastLds& F, const LjArgs& a,
@@ -706,75 +713,109 @@ __device__ __forceinline__ void lf_copy_out(const FastLds& F, const LjArgs& a,
                                             uint32_t sb, uint32_t r0, int tid) {
   const uint32_t RS = S.RS;
   uint8_t* img = a.out_base + S.img_offset;
-  uint32_t i = A0;
-  uint32_t z = 0; // current CR2 strip
-  while (i < A1) {
-    const uint32_t r = i / RS, sidx = i - r * RS;
-    uint8_t* dst = nullptr;
-    uint32_t pend;
-    if (S.kind == 0) {
-      const uint32_t keep = S.keep;
-      if (sidx < keep) {
-        pend = r * RS + keep;
-        dst = img + uint64_t(S.out_y + r) * S.pitch + 2u * (S.out_x + sidx);
-      } else {
-        pend = (r + 1) * RS; // trailing MCUs of the frame that the tile does not keep
-      }
-    } else {
-      // (the strips lie in LDS: on gfx9 a load's s_waitcnt vmcnt also waits for the
-      // acknowledgements of the pixel stores issued before it -- 2 us per run)
-      const Cr2Strip* st = reinterpret_cast<const Cr2Strip*>(F.strips);
-      while (z + 1 < S.n_strips && uint64_t(i) >= uni64(st[z + 1].first_sample))
-        ++z;
-      const uint32_t sx0 = uni(st[z].x0), sw = uni(st[z].w), sy0 = uni(st[z].y0);
-      uint32_t srow, col;
-      strip_divmod(uint64_t(i) - uni64(st[z].first_sample), sw, &srow, &col);
-      const uint32_t in_strip = sw - col, in_row = RS - sidx;
-      pend = i + (in_strip < in_row ? in_strip : in_row);
-      dst = img + uint64_t(sy0 + srow) * S.pitch + 2u * (sx0 + col);
-    }
-    if (pend > A1)
-      pend = A1;
-    const uint32_t n = pend - i;
-    if (dst) {
-      const uint2 Cv = F.ctab[r - r0];
-      const uint2 C = make_uint2(uni(Cv.x), uni(Cv.y));
-      const uint32_t delta = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u) >> 1;
-      const uint32_t ph0 = (i + 8u - delta) & uint32_t(N - 1);
-      uint32_t cd[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        cd[t] = fld(C, (ph0 + 2u * t) & uint32_t(N - 1)) |
-                (fld(C, (ph0 + 2u * t + 1u) & uint32_t(N - 1)) << 16);
-      const uint32_t nch = (delta + n + 7u) >> 3;
-      const uint32_t lds0 = sb + 2u * (i - A0) - 2u * delta;
-      const uint32_t sh = 8u * (lds0 & 2u); // the staged samples start mid-dword: 16, else 0
-      uint8_t* d0 = dst - 2u * delta;
-      for (uint32_t m = uint32_t(tid); m < nch; m += uint32_t(LJ_T)) {
-        const int32_t sf = int32_t(8u * m) - int32_t(delta);
-        const uint32_t la = (lds0 + 16u * m) & ~3u;
-        uint32_t dw[5];
-#pragma unroll
-        for (int t = 0; t < 5; ++t)
-          dw[t] = *(lds_u32p)(la + 4u * t);
-        uint32_t o[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          o[t] = pk_add(__builtin_amdgcn_alignbit(dw[t + 1], dw[t], sh), cd[t]);
-        uint8_t* p = d0 + 16u * m;
-        if (sf >= 0 && uint32_t(sf) + 8u <= n) {
-          *reinterpret_cast<uint4*>(p) = make_uint4(o[0], o[1], o[2], o[3]);
-        } else {
-#pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            const int32_t q = sf + t;
-            if (q >= 0 && uint32_t(q) < n)
-              reinterpret_cast<uint16_t*>(p)[t] = uint16_t(o[t >> 1] >> (16 * (t & 1)));
+  const Cr2Strip* st = reinterpret_cast<const Cr2Strip*>(F.strips);
+  // cursor: the run that starts at sample i
+  uint32_t i = A0, r = A0 / RS, sidx = A0 - r * RS;
+  uint32_t z = 0, srow = 0, col = 0, sw = 1, sx0 = 0, sy0 = 0, znext = 0xFFFFFFFFu;
+  if (S.kind == 1) {
+    while (z + 1 < S.n_strips && uint64_t(i) >= uni64(st[z + 1].first_sample))
+      ++z;
+    sx0 = uni(st[z].x0);
+    sw = uni(st[z].w);
+    sy0 = uni(st[z].y0);
+    strip_divmod(uint64_t(i) - uni64(st[z].first_sample), sw, &srow, &col);
+    znext = z + 1 < S.n_strips ? uint32_t(uni64(st[z + 1].first_sample)) : 0xFFFFFFFFu;
+  }
+  uint32_t gstart = 0, nch = 0, n = 0, lds0 = 0, sh = 0, cd[4] = {0, 0, 0, 0};
+  uint8_t* d0 = nullptr;
+  bool have = false; // the cursor's run is set up (nch, d0, ...)
+  uint32_t g = uint32_t(tid);
+  while (true) {
+    // set up runs until the one that holds chunk g
+    while (!have || g >= gstart + nch) {
+      if (have) { // move the cursor past the run
+        gstart += nch;
+        i += n;
+        sidx += n;
+        if (sidx == RS) {
+          sidx = 0;
+          ++r;
+        }
+        if (S.kind == 1) {
+          col += n;
+          if (col == sw) {
+            col = 0;
+            ++srow;
+          }
+          if (i >= znext) {
+            ++z;
+            sx0 = st[z].x0;
+            sw = st[z].w;
+            sy0 = st[z].y0;
+            srow = 0;
+            col = 0;
+            znext = z + 1 < S.n_strips ? uint32_t(st[z + 1].first_sample) : 0xFFFFFFFFu;
           }
         }
       }
+      if (i >= A1)
+        return;
+      uint8_t* dst = nullptr;
+      if (S.kind == 0) {
+        if (sidx < S.keep) {
+          n = S.keep - sidx;
+          dst = img + uint64_t(S.out_y + r) * S.pitch + 2u * (S.out_x + sidx);
+        } else {
+          n = RS - sidx; // trailing MCUs of the frame that the tile does not keep
+        }
+      } else {
+        const uint32_t in_strip = sw - col, in_row = RS - sidx;
+        n = in_strip < in_row ? in_strip : in_row;
+        dst = img + uint64_t(sy0 + srow) * S.pitch + 2u * (sx0 + col);
+      }
+      if (n > A1 - i)
+        n = A1 - i;
+      have = true;
+      nch = 0;
+      if (dst) {
+        const uint2 C = F.ctab[r - r0];
+        const uint32_t delta = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u) >> 1;
+        const uint32_t ph0 = (i + 8u - delta) & uint32_t(N - 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          cd[t] = fld(C, (ph0 + 2u * t) & uint32_t(N - 1)) |
+                  (fld(C, (ph0 + 2u * t + 1u) & uint32_t(N - 1)) << 16);
+        nch = (delta + n + 7u) >> 3;
+        lds0 = sb + 2u * (i - A0) - 2u * delta;
+        sh = 8u * (lds0 & 2u); // the staged samples start mid-dword: 16, else 0
+        d0 = dst - 2u * delta;
+        sh |= delta << 8; // (the run's delta rides along above the shift amount)
+      }
     }
-    i = pend;
+    const uint32_t m = g - gstart;
+    const uint32_t delta = sh >> 8;
+    const int32_t sf = int32_t(8u * m) - int32_t(delta);
+    const uint32_t la = (lds0 + 16u * m) & ~3u;
+    uint32_t dw[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+      dw[t] = *(lds_u32p)(la + 4u * t);
+    uint32_t o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      o[t] = pk_add(__builtin_amdgcn_alignbit(dw[t + 1], dw[t], sh & 31u), cd[t]);
+    uint8_t* p = d0 + 16u * m;
+    if (sf >= 0 && uint32_t(sf) + 8u <= n) {
+      *reinterpret_cast<uint4*>(p) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int32_t q = sf + t;
+        if (q >= 0 && uint32_t(q) < n)
+          reinterpret_cast<uint16_t*>(p)[t] = uint16_t(o[t >> 1] >> (16 * (t & 1)));
+      }
+    }
+    g += uint32_t(LJ_T);
   }
 }
 
@@ -831,12 +872,29 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
   // order, so every predecessor holds an earlier ticket).  A workgroup waits for ALL its
   // stream's workgroups in flight; with one stream after the other that is everything on
   // the chip, and it pays the slowest of ~1000 -- interleaved, 1000 / streams.
-  const uint32_t b = uni(a.fast_order[uni(F.misc[M_TICKET])]);
-  const uint32_t s = uni(a.block_stream[b]);
+  const uint2 bs = a.fast_order[uni(F.misc[M_TICKET])];
+  const uint32_t b = uni(bs.x), s = uni(bs.y);
   const FastStream S = lf_stream(a.streams[s]);
   if (int(S.fast_n) != N)
     return; // (workgroup-uniform)
   const uint32_t lb = b - S.first_block;
+  // A stream that some workgroup has given up on (periodic data, an invalid code, ...) is
+  // redone by the multi-kernel pipeline anyway: leave records the workgroups in flight
+  // can walk over and go.
+  if (uni(a.results[s].flags) & FL_SLOW) {
+    if (j == 0) {
+      u64* p = a.lb + size_t(b) * LF_LB_WORDS;
+      lb_store(p, lb0_make(LB0_FINAL, 0, 0, 0, 0));
+      for (int k = 1; k < LF_LB_WORDS; ++k)
+        lb_store(p + k, LB_VALID);
+      a.block_start[b] = 0;
+      a.block_exit[b] = 0;
+      a.block_sum[b] = 0;
+      a.block_flags[b] = 0;
+      a.block_psum[b] = make_uint2(0, 0);
+    }
+    return;
+  }
 #ifdef RSX_EXPERIMENT
   if (a.dbg && j == 0)
     a.dbg[size_t(b) * 16] = t_start;
@@ -964,8 +1022,10 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
       if (nl == 0)
         break;
       if (++rounds > LF_MAX_ROUNDS) {
-        if (j == 0)
+        if (j == 0) {
           F.misc[M_SLOW] = 1; // periodic data: not this kernel's business
+          atomicOr(&a.results[s].flags, FL_SLOW); // (at once: later workgroups leave early)
+        }
         break;
       }
 #ifdef RSX_EXPERIMENT
