@@ -21,15 +21,19 @@ the ranks), optionally the distribution of the packed batch from rank 0
 (--broadcast: one RCCL broadcast of the whole batch; --scatter: grouped send/recv of
 each rank's shard), timed separately from the decode.
 
-Rank 0 prints ONE JSON line.  At N=1 it also carries
+Rank 0 prints ONE JSON line (kept under 6 KB: the driver holds a tail of stdout).  At
+N=1 it also carries
   roofline      -- dominant kernel: algorithmic bytes / hipEvent-measured launch time,
                    plus the measured copy ceiling of the device for the same bytes
   cpu_baseline  -- the unmodified reference (oracle/_ref) timed on this host's cores
-  extra         -- the other legs measured the same way (bench_ljpeg.py): configs[0]
-                   (12-bit LSB 4096x3072), single-frame latency of configs[1], the LJPEG
-                   configs (cfg 3 / cfg 4 / cfg 5) with their own CPU baselines, the
-                   fixed-layout unpack entry points, Canon sRaw + Cr2sRawInterpolator,
-                   Nikon, Hasselblad, Sony ARW1
+  ljpeg         -- summary of the LJPEG configs (cfg 3 / cfg 4 / cfg 5, clipped highlights,
+                   uniform-random data): ms, GPix/s, fraction of the HBM peak, per-kernel
+                   ms, CPU baselines, and -- replayed from profiles/ and labelled so -- the
+                   VALU issue fraction and the measured HBM traffic of the pipeline
+Everything else measured the same way (bench_ljpeg.py: configs[0], single-frame latency of
+configs[1], the fixed-layout unpack entry points, Canon sRaw + Cr2sRawInterpolator, Nikon,
+Hasselblad, Sony ARW1, the host-pointer path, the full LJPEG legs) goes to
+bench_extra.json next to this file (and to stderr); the line names it in `extra_file`.
 """
 import argparse
 import ctypes as C
@@ -69,6 +73,8 @@ def parse():
                     help="skip the batched-LJPEG-frames leg (BASELINE configs[4])")
     ap.add_argument("--cfg5-total-frames", type=int, default=CFG5_TOTAL_FRAMES,
                     help="frames of the whole LJPEG batch, sharded over the ranks")
+    ap.add_argument("--cfg5-distinct", type=int, default=32,
+                    help="different frames synthesised for the LJPEG batch")
     ap.add_argument("--broadcast", action="store_true",
                     help="cfg 5: rank 0 holds the packed batch and broadcasts it over RCCL")
     ap.add_argument("--scatter", action="store_true",
@@ -259,16 +265,26 @@ def cfg5_leg(args, ctx, torch, grp, rank, n_gpus, stream):
     total = args.cfg5_total_frames
     lo, hi = rdist.shard_range(total, n_gpus, rank)
     f5 = hi - lo
-    plan5, inp5, out5, meta = bench_ljpeg.make_cfg5_plan(ctx, torch, f5, seed0=1000)
+    # global frame g of the batch is distinct frame (g + g // D) % D (seed 1000 + that):
+    # D = 32 different frames (seeds 1000 + frame), and the shards of the
+    # ranks differ from one another
+    plan5, inp5, out5, meta = bench_ljpeg.make_cfg5_plan(ctx, torch, f5, seed0=1000,
+                                                         distinct=args.cfg5_distinct,
+                                                         first_frame=lo)
     dist_info = {"mode": "every rank synthesises its own shard (no exchange)"}
     if grp.enabled and (args.broadcast or args.scatter):
         shard_bytes = int(inp5.numel())
         grp.barrier()
         t0 = time.perf_counter()
         if args.broadcast:
-            # rank 0's copy of the whole job's packed batch goes to every rank
-            whole = torch.cat([inp5] * n_gpus) if rank == 0 else \
-                torch.empty(shard_bytes * n_gpus, dtype=torch.uint8, device="cuda")
+            # rank 0 assembles the WHOLE job's packed batch (every rank's own, different
+            # shard) and broadcasts it; a rank keeps its slice
+            sizes = [bench_ljpeg.cfg5_frame_bytes(meta, g) for g in range(total)]
+            start = sum(sizes[:lo])
+            if rank == 0:
+                whole = bench_ljpeg.cfg5_assemble(torch, meta, range(total))
+            else:
+                whole = torch.empty(sum(sizes), dtype=torch.uint8, device="cuda")
             torch.cuda.synchronize()
             grp.barrier()
             t0 = time.perf_counter()
@@ -276,10 +292,10 @@ def cfg5_leg(args, ctx, torch, grp, rank, n_gpus, stream):
             torch.cuda.synchronize()
             grp.barrier()
             dt = grp.max_over_ranks(time.perf_counter() - t0)
-            inp5 = whole[rank * shard_bytes:(rank + 1) * shard_bytes].clone()
-            moved = shard_bytes * n_gpus
+            inp5 = whole[start:start + shard_bytes].clone()
+            moved = int(whole.numel())
             del whole
-            mode = "RCCL broadcast of the whole packed batch from rank 0"
+            mode = "RCCL broadcast of the whole packed batch from rank 0 (shards differ)"
         else:
             recv = torch.empty_like(inp5)
             torch.cuda.synchronize()
@@ -320,6 +336,7 @@ def cfg5_leg(args, ctx, torch, grp, rank, n_gpus, stream):
                              + (" and oracle/_ref" if ref_frames is not None else ""),
         "entropy_bits_per_px": round(meta["bits_per_px"], 3),
         "frames_on_this_rank": f5,
+        "distinct_frames": meta["distinct"],
         "achieved_gbps_whole_pipeline_per_gpu": round(meta["alg_bytes"] / dt5 / 1e9, 1),
         "frac_of_hbm_peak": round(meta["alg_bytes"] / dt5 / 1e9 / HBM_PEAK_GBPS, 4),
         "input_distribution": dist_info,
@@ -327,6 +344,72 @@ def cfg5_leg(args, ctx, torch, grp, rank, n_gpus, stream):
     if cpu5:
         res["cpu_baseline"] = cpu5
     return res
+
+
+def replayed_ljpeg_counters():
+    """VALU issue fraction and HBM traffic of the cfg-3 LJPEG pipeline from the newest
+    committed rocprofv3 PMC passes (scripts/pmc_ljpeg.sh, pmc_ljpeg_traffic.sh); bench.py
+    cannot run rocprofv3 on itself."""
+    out = {}
+    for rnd in ("r03", "r02"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "ljpeg_traffic", "ljpeg_traffic.json")) as f:
+                t = json.load(f)
+            out["traffic_over_algorithmic"] = t["traffic_over_algorithmic"]
+            out["traffic_source"] = "replayed from profiles/%s/ljpeg_traffic/ljpeg_traffic.json " \
+                "(rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, cfg 3, 8 frames); not measured in this run" % rnd
+            break
+        except Exception:
+            continue
+    for rnd in ("r03",):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "ljpeg_pmc", "ljpeg_pmc.json")) as f:
+                t = json.load(f)
+            out["valu_issue_frac"] = t["valu_issue_frac"]
+            out["valu_issue_source"] = "replayed from profiles/%s/ljpeg_pmc/ljpeg_pmc.json: %s" % (
+                rnd, t.get("how", ""))
+        except Exception:
+            continue
+    return out
+
+
+def ljpeg_summary(extra):
+    """the LJPEG legs of `extra`, compressed for the one-line JSON"""
+    def leg(d, cpu=True):
+        if not isinstance(d, dict) or "ms_per_step" not in d:
+            return d if isinstance(d, dict) and "error" in d else None
+        r = {"ms_per_step": d["ms_per_step"], "gpix_per_s": round(d["mpix_per_s"] / 1e3, 1),
+             "hbm_frac": d.get("frac_of_hbm_peak"), "bit_exact": d.get("bit_exact")}
+        if "kernels_ms" in d:
+            r["kernels_ms"] = {k.replace("lj_", "").replace("_kernel", ""): round(v, 3)
+                               for k, v in d["kernels_ms"].items()}
+        c = d.get("cpu_baseline")
+        if cpu and isinstance(c, dict) and "value" in c:
+            r["cpu_ref_mpix"] = {"threads_%d" % c["cores"]: c["value"],
+                                 "threads_1": c.get("single_thread_value")}
+            if "value_threads4" in c:
+                r["cpu_ref_mpix"]["threads_4"] = c["value_threads4"]
+        return r
+    s = {
+        "cfg3_cr2_6720x4480_8frames": leg(extra.get("cfg3_cr2_6720x4480")),
+        "cfg4_dng_2x2_tiles_8192x5464_1frame": leg(extra.get("cfg4_dng_tiles_8192x5464")),
+        "cfg5_batch_8192x5464": leg(extra.get("cfg5_ljpeg_frames_batch")),
+        "cfg3_clipped_highlights": leg(extra.get("cfg3_clipped_highlights"), cpu=False),
+        "cfg3_uniform_random_14bit": leg(extra.get("cfg3_uniform_random_14bit"), cpu=False),
+    }
+    c4 = extra.get("cfg4_dng_tiles_8192x5464")
+    if isinstance(c4, dict):
+        for k in ("overhang_8189x5462", "restart_intervals"):
+            if isinstance(c4.get(k), dict) and "ms_per_step" in c4[k]:
+                s["cfg4_" + k] = {"ms_per_step": c4[k]["ms_per_step"],
+                                  "bit_exact": c4[k].get("bit_exact")}
+    c5 = extra.get("cfg5_ljpeg_frames_batch")
+    if isinstance(c5, dict) and s.get("cfg5_batch_8192x5464"):
+        s["cfg5_batch_8192x5464"]["frames_on_this_rank"] = c5.get("frames_on_this_rank")
+        s["cfg5_batch_8192x5464"]["distinct_frames"] = c5.get("distinct_frames")
+        s["cfg5_batch_8192x5464"]["input_distribution"] = c5.get("input_distribution")
+    s.update(replayed_ljpeg_counters())
+    return s
 
 
 def main():
@@ -478,6 +561,17 @@ def main():
     if cfg5 is not None:
         result.setdefault("extra", {})["cfg5_ljpeg_frames_batch"] = cfg5
     if rank == 0:
+        extra = result.pop("extra", None)
+        if extra is not None:
+            result["ljpeg"] = ljpeg_summary(extra)
+            path = os.path.join(ROOT, "bench_extra.json")
+            try:
+                with open(path, "w") as f:
+                    json.dump(extra, f, indent=1)
+                result["extra_file"] = "bench_extra.json (every other leg, full detail)"
+            except OSError as e:
+                result["extra_file"] = "not written: %r" % (e,)
+            log("bench_extra: " + json.dumps(extra))
         print(json.dumps(result), flush=True)
     grp.close()
 

@@ -1,0 +1,169 @@
+"""GPU parity of the single-pass LJPEG kernel (rsx_ljpeg_fast.hip) on the shapes that
+exercise ITS machinery -- the look-backs, the row table, the staging capacity, the
+re-decode rounds, the hand-over to the multi-kernel pipeline -- through the C-ABI against
+the oracle.  (The general LJPEG / CR2 / DNG parity tests run through it as well: every
+single-table stream with 1, 2 or 4 components in a row of an MCU takes it.)"""
+import numpy as np
+import pytest
+import torch
+
+from rawspeed_amd import abi, synth
+
+import cases as C
+from oracle_lib import HostImage
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import gpu_util
+    return gpu_util.ctx()
+
+
+def _check(gpu, oracle, d, data, w, h, cpp=1):
+    img, want = HostImage(w, h, cpp), HostImage(w, h, cpp)
+    so = oracle.ljpeg(d, data, want)
+    sg = gpu.ljpeg_decode(d, data, img.view())
+    assert sg == so, (sg, so)
+    if so[0] == 0:
+        assert np.array_equal(img.u16(), want.u16())
+    return so
+
+
+@pytest.mark.parametrize("tw,n", [(256, 2), (128, 2), (64, 2), (32, 2), (16, 1), (48, 4), (8, 2)])
+def test_narrow_tiles_many_rows_per_workgroup(gpu, oracle, tw, n):
+    """A workgroup (15 000 symbols) of a narrow tile holds up to 256 stream rows in the
+    kernel's row table; narrower than that, the stream goes to the multi-kernel pipeline.
+    Either way the pixels are the reference's."""
+    rng = np.random.default_rng([7, tw, n])
+    H = 1200 if tw >= 64 else 2400
+    d, data, px, _ = C.make_ljpeg_case(rng, img_w=tw + 10, img_h=H, cpp=1, tile=(3, 0, tw, H),
+                                       mcu=(n, 1))
+    so = _check(gpu, oracle, d, data, tw + 10, H)
+    assert so[0] == 0
+
+
+@pytest.mark.parametrize("sigma", [0.3, 1.0, 3.0])
+def test_low_entropy_streams(gpu, oracle, sigma):
+    """Few bits per symbol: more than 128 symbols in a 64-byte subsequence (the registers
+    a lane keeps) and more samples per workgroup than its LDS stages -- the plan sizes the
+    allocation from the stream, or keeps the stream off the single-pass kernel, or a
+    workgroup hands it over."""
+    rng = np.random.default_rng([8, int(sigma * 10)])
+    W, H = 2048, 600
+    d, data, px, _ = C.make_ljpeg_case(rng, img_w=W, img_h=H, cpp=1, tile=(0, 0, W, H),
+                                       mcu=(2, 1), sigma=sigma)
+    so = _check(gpu, oracle, d, data, W, H)
+    assert so[0] == 0
+
+
+def test_flat_then_noisy_image_hands_over(gpu, oracle):
+    """An image whose first rows are noisy and whose rest is nearly flat: the allocation
+    sized from the stream's average does not hold the flat part's workgroups."""
+    rng = np.random.default_rng(9)
+    W, H = 2048, 800
+    px = C.smooth_image(rng, H, W, sigma=30.0)
+    flat = C.smooth_image(rng, H, W, sigma=0.4)
+    px[H // 4:] = flat[H // 4:]
+    rows = C.ljpeg_stream_rows(px, 2, 1, W // 2, H, rng)
+    scan, bits = synth.ljpeg_encode_scan(rows, 2, [1 << 13] * 2, [C.NIKON, C.NIKON], 0, False)
+    d = abi.LJpegDesc()
+    d.tile_x, d.tile_y, d.tile_w, d.tile_h = 0, 0, W, H
+    d.mcu_w, d.mcu_h, d.frame_w, d.frame_h = 2, 1, W // 2, H
+    d.n_comp, d.rows_per_restart_interval = 2, H
+    abi.fill_recipe(d, synth.huff_tables(C.NIKON), [0, 0], [1 << 13] * 2)
+    data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), np.zeros(16, np.uint8)])
+    so = _check(gpu, oracle, d, data, W, H)
+    assert so[0] == 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_tables_with_long_codes(gpu, oracle, seed):
+    """Random canonical tables: codes longer than the 10-bit LUT and SSSS = 16 stop a lane
+    of the fast loop; those subsequences are re-decoded with the general step."""
+    rng = np.random.default_rng([10, seed])
+    counts, values = C.random_huffman_table(rng, n_cat=17, skew=float(rng.uniform(0.5, 2.5)))
+    W, H = 1024, 300
+    d, data, px, _ = C.make_ljpeg_case(rng, img_w=W, img_h=H, cpp=1, tile=(0, 0, W, H),
+                                       mcu=(2, 1), tables=((counts, values),), prec=16,
+                                       full_range=bool(seed & 1), fix16=bool(seed & 2))
+    _check(gpu, oracle, d, data, W, H)
+
+
+def test_many_streams_of_unequal_length_interleaved(gpu, oracle):
+    """One batched call, tiles of very different sizes: the workgroups of all streams
+    take their tickets interleaved, each stream's in order."""
+    rng = np.random.default_rng(11)
+    W, H = 3000, 700
+    img, want = HostImage(W, H), HostImage(W, H)
+    descs, datas = [], []
+    x = 0
+    for k, tw in enumerate((2048, 16, 512, 128, 256, 32)):
+        th = (700, 80, 300, 700, 33, 500)[k]
+        d, data, _, _ = C.make_ljpeg_case(rng, img_w=W, img_h=H, cpp=1, tile=(x, 0, tw, th),
+                                          mcu=(2, 1))
+        descs.append(d)
+        datas.append(data)
+        x += tw
+    cons = []
+    for d, data in zip(descs, datas):
+        st, c = oracle.ljpeg(d, data, want)
+        assert st == 0
+        cons.append(c)
+    rc, st, got = gpu.dng_decompress_ljpeg(descs, datas, img.view())
+    assert rc == 0 and not any(st) and got == cons
+    assert np.array_equal(img.u16(), want.u16())
+
+
+def test_damaged_streams_in_a_batch_leave_the_others_alone(gpu, oracle):
+    """A truncated stream and one with an invalid code among healthy ones, every run of the
+    same plan: the damaged streams are handed to the multi-kernel pipeline (and demoted
+    after two runs), the healthy ones keep their pixels."""
+    rng = np.random.default_rng(12)
+    W, H, tw = 2048, 400, 512
+    descs, datas = [], []
+    for k in range(4):
+        d, data, _, _ = C.make_ljpeg_case(rng, img_w=W, img_h=H, cpp=1, tile=(k * tw, 0, tw, H),
+                                          mcu=(2, 1))
+        descs.append(d)
+        datas.append(data)
+    datas[1] = datas[1][:len(datas[1]) // 2]
+    bad = datas[3].copy()
+    bad[len(bad) // 3:len(bad) // 3 + 8] = 0xFF
+    bad[len(bad) // 3 + 1:len(bad) // 3 + 8:2] = 0xFE
+    datas[3] = bad
+    want = HostImage(W, H)
+    so = [oracle.ljpeg(d, data, want) for d, data in zip(descs, datas)]
+    assert so[0][0] == 0 and so[2][0] == 0
+    for run in range(4):
+        img = HostImage(W, H)
+        rc, st, cons = gpu.dng_decompress_ljpeg(descs, datas, img.view())
+        for k in range(4):
+            assert (st[k] != 0) == (so[k][0] != 0), (run, k, st, so)
+            if so[k][0] == 0:
+                assert cons[k] == so[k][1]
+                assert np.array_equal(img.pixels()[:, k * tw:(k + 1) * tw],
+                                      want.pixels()[:, k * tw:(k + 1) * tw]), (run, k)
+
+
+def test_plan_reruns_are_identical(gpu):
+    """The look-back records and tickets start from zero in every run of a plan."""
+    import gpu_util
+    import bench_ljpeg as B
+    W, H = 1536, 512
+    made = [B.make_cr2_frame(W, H, (3, 512, 512), seed=50 + f) for f in range(3)]
+    plan, inp, out = B._cr2_batch(gpu, torch, [(m[0], m[1]) for m in made], W, H)
+    s = torch.cuda.current_stream().cuda_stream
+    ref = None
+    for run in range(5):
+        out.zero_()
+        plan.run(inp.data_ptr(), out.data_ptr(), s)
+        rc, st, cons = plan.results()
+        assert rc == 0 and list(cons) == [m[3] for m in made]
+        got = out.cpu().numpy().copy()
+        for f in range(3):
+            assert np.array_equal(B.gpu_frame(out, f, W, H), made[f][2])
+        if ref is None:
+            ref = got
+        assert np.array_equal(got, ref)
