@@ -908,6 +908,7 @@ if __name__ == "__main__":
     elif args.only == "host":
         print(json.dumps(run_host_path(torch, print), indent=1))
     elif args.only == "cfg4":
-        print(json.dumps(run_cfg4(ctx, torch, print, steps=args.steps), indent=1))
+        print(json.dumps(run_cfg4(ctx, torch, print, steps=args.steps, cpu=not args.no_cpu),
+                         indent=1))
     else:
         print(json.dumps(run(ctx, torch, print), indent=1))

@@ -5,7 +5,7 @@
 #   re-decode round statistics of an experiment build.
 # Outputs land in gpurun_out/prof_$ROUND/ (copied to profiles/$ROUND/ afterwards).
 set -u
-ROUND=${ROUND:-r02}
+ROUND=${ROUND:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$ROUND
 mkdir -p $OUT
@@ -25,16 +25,22 @@ python $REPO/scripts/pmc_to_json.py $OUT > /dev/null
 for leg in cfg3 cfg4; do
   rm -rf /tmp/p_$leg
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$leg -- \
-    python $REPO/bench_ljpeg.py --only $leg --steps 10 > $OUT/${leg}_under_rocprof.json 2> /dev/null
+    python $REPO/bench_ljpeg.py --only $leg --steps 10 --no-cpu > $OUT/${leg}_under_rocprof.json 2> /dev/null
   cp $(find /tmp/p_$leg -name "*kernel_stats.csv" | head -1) $OUT/${leg}_kernel_stats.csv
 done
 bash $REPO/scripts/pmc_ljpeg_traffic.sh > /dev/null 2>&1
 mkdir -p $OUT/ljpeg_traffic
 cp $REPO/gpurun_out/pmc_lj_traffic/* $OUT/ljpeg_traffic/
+# instruction mix of the LJPEG kernels (cfg 3): needs cfg3_kernel_stats.csv (above) for the times
+cp $OUT/cfg3_kernel_stats.csv $REPO/gpurun_out/pmc_lj/ 2>/dev/null
+bash $REPO/scripts/pmc_ljpeg.sh > $OUT/ljpeg_pmc.log 2>&1
+mkdir -p $OUT/ljpeg_pmc
+cp $REPO/gpurun_out/pmc_lj/*.txt $REPO/gpurun_out/pmc_lj/ljpeg_pmc.json $OUT/ljpeg_pmc/ 2>/dev/null
+cp $REPO/bench_extra.json $OUT/ 2>/dev/null
 # re-decode round statistics (experiment build: RSX_EXPERIMENT collects them, RSX_DEBUG prints)
-if [ -f $REPO/rawspeed_amd/variants/librsx_dbg.so ]; then
-  RSX_DEBUG=1 RSX_LIB=$REPO/rawspeed_amd/variants/librsx_dbg.so \
-    python $REPO/bench_ljpeg.py --only cfg3 --steps 1 2>&1 | grep "^\[rsx\]" | head -12 > $OUT/cfg3_round_stats.txt
+if [ -f $REPO/rawspeed_amd/variants/librsx_stats.so ]; then
+  RSX_DEBUG=1 RSX_LIB=$REPO/rawspeed_amd/variants/librsx_stats.so \
+    python $REPO/scripts/exp_lj_stats.py 2>&1 | grep "^\[rsx\]" | cut -c1-400 > $OUT/cfg3_phase_and_round_stats.txt
 fi
 ls -la $OUT
 tail -c 400 $OUT/bench_full.json

@@ -10,7 +10,7 @@ for v in "$@"; do
   for c in WRITE_SIZE FETCH_SIZE; do
     rm -rf /tmp/pw_$v
     RSX_LIB=$lib rocprofv3 --pmc $c --output-format csv -d /tmp/pw_$v -- \
-      python $REPO/bench_ljpeg.py --only cfg3 --frames 8 --steps 2 > /dev/null 2>&1
+      python $REPO/bench_ljpeg.py --only cfg3 --frames 8 --steps 2 --no-cpu > /dev/null 2>&1
     python - "$v" "$c" $(find /tmp/pw_$v -name "*counter_collection.csv" | head -1) <<'PY'
 import csv, sys, collections
 v, c, path = sys.argv[1:4]

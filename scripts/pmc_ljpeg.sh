@@ -14,7 +14,9 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
   i=$((i+1))
   rm -rf /tmp/pl_$i
   rocprofv3 --pmc $set --output-format csv -d /tmp/pl_$i -- \
-    python $REPO/bench_ljpeg.py --only cfg3 --frames 8 --steps 2 > /dev/null 2>&1
+    python $REPO/bench_ljpeg.py --only cfg3 --frames 8 --steps 2 --no-cpu > /dev/null 2>&1
   cp $(find /tmp/pl_$i -name "*counter_collection.csv" | head -1) $OUT/set$i.csv
-  python $REPO/scripts/pmc_summary.py $OUT/set$i.csv lj_ | grep -A6 "lj_sync_kernel<false\|lj_decode_direct" | grep -v "^--"
+  python $REPO/scripts/pmc_summary.py $OUT/set$i.csv lj_ > $OUT/set$i.txt
+  grep -A6 "lj_fast_kernel\|lj_unstuff_kernel" $OUT/set$i.txt | grep -v "^--"
 done
+python $REPO/scripts/pmc_ljpeg_json.py $OUT
