@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSX_ABI_VERSION 1
+#define RSX_ABI_VERSION 2
 
 /* ------------------------------------------------------------------------ */
 /* Status codes.  Kernels cannot throw; the C++ forwarding shim converts a   */

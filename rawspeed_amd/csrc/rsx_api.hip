@@ -177,6 +177,11 @@ struct LaneGuard {
 };
 } // namespace
 
+static void set_error(rsx_ctx* ctx, const std::string& msg) {
+  std::lock_guard<std::mutex> g(ctx->err_mu);
+  ctx->last_error = msg;
+}
+
 extern "C" int rsx_abi_version(void) { return RSX_ABI_VERSION; }
 
 extern "C" const char* rsx_status_string(int status) {
@@ -241,8 +246,17 @@ extern "C" void rsx_ctx_destroy(rsx_ctx* ctx) {
   delete ctx;
 }
 
+// (a copy made under the lock, per calling thread: host-pointer calls from several
+// threads may be writing the context's string at the same time)
 extern "C" const char* rsx_ctx_last_error(const rsx_ctx* ctx) {
-  return ctx ? ctx->last_error.c_str() : "";
+  if (!ctx)
+    return "";
+  static thread_local std::string copy;
+  {
+    std::lock_guard<std::mutex> g(const_cast<rsx_ctx*>(ctx)->err_mu);
+    copy = ctx->last_error;
+  }
+  return copy.c_str();
 }
 
 extern "C" uint64_t rsx_ctx_host_calls(const rsx_ctx* ctx) {
@@ -934,7 +948,7 @@ extern "C" int rsx_unpack_f32(rsx_ctx* ctx, const rsx_unpack_desc* d, const uint
     if (e == hipSuccess)
       e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
-      ctx->last_error = std::string("unpack_f32 D2H: ") + hipGetErrorString(e);
+      set_error(ctx, std::string("unpack_f32 D2H: ") + hipGetErrorString(e));
       rc = RSX_ERR_DEVICE;
     }
   }
@@ -982,7 +996,7 @@ extern "C" int rsx_unpack_variant_u16(rsx_ctx* ctx, const rsx_unpack_variant_des
     if (e == hipSuccess)
       e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
-      ctx->last_error = std::string("unpack_variant D2H: ") + hipGetErrorString(e);
+      set_error(ctx, std::string("unpack_variant D2H: ") + hipGetErrorString(e));
       rc = RSX_ERR_DEVICE;
     }
   }
@@ -1179,7 +1193,7 @@ extern "C" int rsx_sraw_interpolate(rsx_ctx* ctx, const rsx_sraw_desc* d,
     if (e == hipSuccess)
       e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
-      ctx->last_error = std::string("sraw D2H: ") + hipGetErrorString(e);
+      set_error(ctx, std::string("sraw D2H: ") + hipGetErrorString(e));
       rc = RSX_ERR_DEVICE;
     }
   }
@@ -1532,6 +1546,13 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
                       const uint8_t* const* ins, const rsx_image* img,
                       CreateFn create, int32_t* statuses, uint32_t* consumed) {
   ++ctx->host_calls;
+#ifdef RSX_FORCE_UNSUPPORTED
+  // (experiment build: every LJPEG-family host-pointer call refuses -- the drop-in tests
+  // must notice that the images then come from the reference's own loops)
+  for (int i = 0; i < n; ++i)
+    statuses[i] = RSX_ERR_UNSUPPORTED;
+  return RSX_ERR_UNSUPPORTED;
+#endif
   // (the image view sizes the staging: check it before anything is allocated or copied;
   // every decompressor's own validation rejects such an image as well)
   if (img->dim_x <= 0 || img->dim_y <= 0 || img->pitch_bytes == 0 || n < 1)

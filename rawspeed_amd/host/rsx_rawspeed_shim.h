@@ -40,7 +40,8 @@ namespace rawspeed::rsx_shim {
 inline rsx_ctx* context() {
   static rsx_ctx* ctx = [] {
     rsx_ctx* c = nullptr;
-    if (rsx_ctx_create(/*device=*/0, &c) != RSX_OK)
+    // (a librsx.so with another ABI than this header's: every hunk falls through)
+    if (rsx_abi_version() != RSX_ABI_VERSION || rsx_ctx_create(/*device=*/0, &c) != RSX_OK)
       c = nullptr;
     return c;
   }();
@@ -205,7 +206,9 @@ public:
   // before the marker, nothing checks the guess then, so it is searched from the front.
   static uint32_t endOfScan(const uint8_t* p, size_t n, bool full_height) {
     auto is_end = [&](size_t i) {
-      return p[i] == 0xFF && p[i + 1] != 0x00 && (p[i + 1] < 0xD0 || p[i + 1] > 0xD7);
+      // (FF FF is fill, not a marker: AbstractLJpegDecoder's peekMarker does not take it)
+      return p[i] == 0xFF && p[i + 1] != 0x00 && p[i + 1] != 0xFF &&
+             (p[i + 1] < 0xD0 || p[i + 1] > 0xD7);
     };
     if (full_height) {
       for (size_t i = n; i >= 2; --i)

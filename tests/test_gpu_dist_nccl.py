@@ -56,3 +56,26 @@ def test_bench_self_launches_its_ranks():
     assert res["n_gpus"] == n and res["bit_exact"] is True
     assert len(res["per_rank_mpix_per_s"]) == n
     assert res["rccl_ranks"] == (n if n > 1 else 0)
+
+
+@pytest.mark.parametrize("mode", ["--scatter", "--broadcast"])
+def test_bench_cfg5_distribution_over_rccl(mode):
+    """The cfg-5 distribution path on RCCL when the box has at least two GPUs: rank 0
+    hands the packed batch out (grouped send/recv of the shards, or one broadcast of the
+    whole batch whose shards differ), every rank decodes its shard bit-exactly."""
+    import torch
+    n = min(torch.cuda.device_count(), 8)
+    if n < 2:
+        pytest.skip("one GPU: nothing to distribute (the gloo test covers the logic)")
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(n),
+           "--steps", "2", "--warmup", "1", "--frames", "1", "--no-extra", "--no-cpu-baseline",
+           "--cfg5-total-frames", str(2 * n), "--cfg5-distinct", "3", mode]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c5 = res["ljpeg"]["cfg5_batch_8192x5464"]
+    assert res["n_gpus"] == n and c5["bit_exact"] is True
+    assert c5["frames_on_this_rank"] == 2 and "bytes" in c5["input_distribution"]
