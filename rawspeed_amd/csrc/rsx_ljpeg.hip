@@ -461,16 +461,53 @@ __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& 
 // Start guesses for the single-pass kernel (rsx_ljpeg_fast.hip): where the parse of a
 // slot from bit `from` ends, as an offset into the next slot.  lut8 = total bits of the
 // symbol a 10-bit window starts with.
+template <bool COUNT>
 __device__ __forceinline__ uint32_t lj_guess_parse(const uint32_t* B, const uint8_t* lut8,
-                                                   int col, uint32_t end_bits, uint32_t from) {
-  uint32_t pos = from;
+                                                   int col, uint32_t end_bits, uint32_t from,
+                                                   uint32_t* count = nullptr) {
+  uint32_t pos = from, n = 0;
   while (pos < end_bits) {
     const uint32_t wi = pos >> 5;
     const uint32_t d0 = B[wi * LJ_T + col], d1 = B[(wi + 1) * LJ_T + col];
     const uint32_t w = uint32_t((((uint64_t(d0) << 32) | d1) << (pos & 31u)) >> 32);
     pos += lut8[w >> 22];
+    if (COUNT)
+      ++n;
   }
+  if (COUNT)
+    *count = n;
   return pos - end_bits;
+}
+// A slot inside a constant region of the image is the code of the zero difference over
+// and over.  No parse from an arbitrary bit finds its way into such a stretch reliably
+// (with Nikon's 14-bit table, 111110 repeated also reads as a chain of 12-bit symbols),
+// but the BITS say where its symbols start: if the slot has period `zl` and the code `zc`
+// at exactly one phase p, the first symbol boundary behind the slot follows.  A guess like
+// any other: the single-pass kernel checks it against the predecessor's exit.
+__device__ __forceinline__ bool lj_guess_constant(const uint32_t* B, int col, uint32_t zl,
+                                                  uint32_t zc, bool candidate, uint32_t* guess,
+                                                  uint32_t* count) {
+  bool per = candidate;
+  for (int wi = 0; wi < LJ_PW && __any(per); ++wi) {
+    const uint32_t d0 = B[wi * LJ_T + col], d1 = B[(wi + 1) * LJ_T + col];
+    per = per && d0 == uint32_t((((uint64_t(d0) << 32) | d1) << zl) >> 32);
+  }
+  if (!per)
+    return false;
+  const uint64_t w64 = (uint64_t(B[col]) << 32) | B[LJ_T + col];
+  uint32_t hits = 0, p0 = 0;
+  for (uint32_t p = 0; p < zl; ++p)
+    if (uint32_t((w64 << p) >> (64u - zl)) == zc) {
+      ++hits;
+      p0 = p;
+    }
+  if (hits != 1)
+    return false;
+  const uint32_t bits = uint32_t(LJ_PW) * 32u;
+  const uint32_t r = (bits - p0) % zl;
+  *guess = r ? zl - r : 0u;
+  *count = (bits - p0 + zl - 1u) / zl;
+  return true;
 }
 constexpr int LJ_GUESS_SLOTS = 3; // slots parsed for a guess, at most (LjArgs::guess_slots)
 
@@ -491,6 +528,8 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     for (int k = 0; k < 4; ++k)
       pk |= ((ft[k].x >> 5) & 63u) << (8 * k);
     reinterpret_cast<uint32_t*>(lut8)[j] = pk;
+    if (j == 0)
+      reinterpret_cast<uint32_t*>(lut8)[256] = 0; // symbols of the workgroup (estimate)
   }
   lj_stage_slots(L, a, S, s, lb, j, true); // ends with a barrier
   uint4* __restrict__ dst = a.unstuffed + size_t(b) * LJ_IMG_U4;
@@ -505,8 +544,12 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   // granules and workgroup tickets start from zero in every run
   if (a.lb && j < LF_LB_WORDS)
     a.lb[size_t(b) * LF_LB_WORDS + j] = 0ull;
-  if (a.tickets && b == 0 && j < 4)
-    a.tickets[j] = 0u;
+  if (a.tickets && b == 0 && j < 13) {
+    if (j < 12)
+      a.tickets[j] = 0u;
+    else
+      a.fast_level[a.run_parity ^ 1u] = a.fast_level[2u + (a.run_parity ^ 1u)] = 0u; // (the NEXT run's)
+  }
   // Start guesses of the single-pass kernel.  Lane j parses the LJ_GUESS_SLOTS slots before
   // slot j from bit 0 (Huffman streams self-synchronise: one slot leaves 1.7 % of the
   // guesses wrong, two 0.03 %, three next to none); lane 0 does it for slot 1 of the NEXT
@@ -517,23 +560,63 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   // for its predecessors) -- while this kernel is bound by HBM and has the issue slots free.
   if (S.fast && a.fast_tabs) {
     const int tgt = j == 0 ? LJ_T : j; // the slot the guess is for (LJ_T = slot 1 of the next block)
-    uint32_t e = 0;
+    const uint32_t zi = uint32_t(__builtin_amdgcn_readfirstlane(int(a.fast_z[S.table_base])));
+    const uint32_t zl = zi & 31u, zc = zi >> 8;
+    uint32_t e = 0, cnt = 0;
+    bool constant = false;
+    if (zl >= 4u) // (shorter: more than 128 symbols in a slot, the multi-kernel pipeline's)
+      constant = lj_guess_constant(L.B, tgt - 1, zl, zc,
+                                   uint32_t(L.ob[tgt - 1]) == uint32_t(LJ_PW) * 32u &&
+                                       !(tgt == 1 && lb == 0),
+                                   &e, &cnt);
+    if (!constant) {
 #pragma unroll
-    for (int k = LJ_GUESS_SLOTS; k >= 1; --k) {
-      const int col = tgt - k;
-      const uint32_t eb = col >= 0 ? uint32_t(L.ob[col >= 0 ? col : 0]) : 0u;
-      if (uint32_t(k) > a.guess_slots) // (launch-uniform)
-        e = 0;
-      else if (col >= 0 && eb != 0 && !(col == 0 && lb == 0))
-        e = lj_guess_parse(L.B, lut8, col, eb, e & ST_OFF_MASK);
-      else
-        e = 0;
+      for (int k = LJ_GUESS_SLOTS; k >= 1; --k) {
+        const int col = tgt - k;
+        const uint32_t eb = col >= 0 ? uint32_t(L.ob[col >= 0 ? col : 0]) : 0u;
+        if (uint32_t(k) > a.guess_slots) // (launch-uniform)
+          e = 0;
+        else if (col >= 0 && eb != 0 && !(col == 0 && lb == 0)) {
+          if (k == 1)
+            e = lj_guess_parse<true>(L.B, lut8, col, eb, e & ST_OFF_MASK, &cnt);
+          else
+            e = lj_guess_parse<false>(L.B, lut8, col, eb, e & ST_OFF_MASK);
+        } else
+          e = 0;
+      }
     }
     const uint32_t g1 = S.first_subseq + lb * LJ_OWN; // record of this workgroup's slot 1
     if (j >= 2)
       a.sub_start[g1 + uint32_t(j - 1)] = uint16_t(e & ST_OFF_MASK);
     else if (j == 0 && lb + 1 < S.n_blocks)
       a.sub_start[g1 + uint32_t(LJ_OWN)] = uint16_t(e & ST_OFF_MASK);
+    // the LDS level of the single-pass launches: the symbols of this workgroup's slots
+    // 1..255 (lane j counted slot j - 1, lane 0 slot 255) against what a level stages
+    uint32_t c = j == 1 ? 0u : cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+      c += uint32_t(__shfl_xor(int(c), o, 64));
+    uint32_t* est = reinterpret_cast<uint32_t*>(lut8) + 256;
+    if ((j & 63) == 0)
+      atomicAdd(est, c);
+    __syncthreads();
+    if (j == 0) {
+      const uint32_t need = *est + (*est >> 6) + 64u;
+      uint32_t lv = 0;
+      while (lv < 2u && need > a.fast_cap_lv[lv])
+        ++lv;
+      if (lv) {
+        atomicMax(&a.fast_level[2u + a.run_parity], lv);
+        // the lowest launched level that holds it, or the highest launched one
+        uint32_t use = lv;
+        while (use < 2u && !((a.fast_level_mask >> use) & 1u))
+          ++use;
+        while (use > 0u && !((a.fast_level_mask >> use) & 1u))
+          --use;
+        if (use)
+          atomicMax(&a.fast_level[a.run_parity], use);
+      }
+    }
   }
 }
 
@@ -1940,7 +2023,10 @@ struct LJpegPlan {
   bool any_pipeline = false;   // some stream takes the multi-kernel pipeline in the first pass
   bool expect_slow = false;    // the last run left FL_SLOW streams: launch the second pass at once
   bool slow_pass_launched = false; // ... this run already has
-  DeviceBuffer d_fast_tabs, d_lb, d_tickets, d_fast_order;
+  DeviceBuffer d_fast_tabs, d_lb, d_tickets, d_fast_order, d_fast_z, d_fast_level;
+  uint32_t run_count = 0;      // runs so far (parity: which level word a run uses)
+  uint32_t level_mask = 7;     // LDS levels the single-pass kernel is launched at (LjArgs::fast_level_mask)
+  uint32_t h_level[4] = {};
   DeviceBuffer d_dbg; // experiment builds: phase time stamps of the single-pass kernel
   DeviceBuffer d_block_flags, d_block_tf, d_sub_start;
   DeviceBuffer d_streams, d_tables, d_block_stream, d_strips, d_sub_state, d_sub_sums,
@@ -2031,6 +2117,27 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.lb = static_cast<unsigned long long*>(p->d_lb.ptr);
   a.tickets = static_cast<uint32_t*>(p->d_tickets.ptr);
   a.fast_lds = p->fast_lds;
+  {
+    // LDS levels: the plan's (from the streams' average symbols per workgroup, 4 per CU
+    // as a rule), then 3 and 2 workgroups per CU
+    const uint32_t steps[2] = {53760u, 65536u};
+    a.fast_lds_lv[0] = p->fast_lds;
+    for (int l = 1; l < 3; ++l) {
+      a.fast_lds_lv[l] = a.fast_lds_lv[l - 1];
+      for (uint32_t c : steps)
+        if (c > a.fast_lds_lv[l - 1]) {
+          a.fast_lds_lv[l] = c;
+          break;
+        }
+    }
+    for (int l = 0; l < 3; ++l)
+      a.fast_cap_lv[l] = a.fast_lds_lv[l] ? ljpeg_fast_stage_cap(a.fast_lds_lv[l]) : 0u;
+  }
+  a.run_parity = p->run_count & 1u;
+  a.fast_level_mask = p->level_mask & (1u | (a.fast_lds_lv[1] != a.fast_lds_lv[0] ? 2u : 0u) |
+                                       (a.fast_lds_lv[2] != a.fast_lds_lv[1] ? 4u : 0u));
+  a.fast_z = static_cast<const uint32_t*>(p->d_fast_z.ptr);
+  a.fast_level = static_cast<uint32_t*>(p->d_fast_level.ptr);
   // A wrong guess delays the workgroups of ITS stream that are in flight; with many
   // streams interleaved those are few, and two slots (0.03 % wrong) do.
   uint32_t n_fast = 0;
@@ -2430,8 +2537,11 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       return st;
     if (p->any_fast) {
       std::vector<uint2> ft(tl.size() * 1024);
+      std::vector<uint32_t> fz(tl.size());
       for (size_t t = 0; t < tl.size(); ++t)
-        ljpeg_build_fast_table(tl[t], ft.data() + t * 1024);
+        ljpeg_build_fast_table(tl[t], ft.data() + t * 1024, &fz[t]);
+      if ((st = up(p->d_fast_z, fz.data(), fz.size() * 4)))
+        return st;
       // ticket order of the single-pass launches: round robin over the streams
       std::vector<uint2> order;
       order.reserve(p->total_blocks);
@@ -2446,8 +2556,12 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         return st;
       if ((st = up(p->d_fast_tabs, ft.data(), ft.size() * sizeof(uint2))) ||
           (st = p->d_lb.ensure(size_t(p->total_blocks) * LF_LB_WORDS * 8)) ||
-          (st = p->d_tickets.ensure(16)))
+          (st = p->d_tickets.ensure(LF_TICKET_WORDS * 4)))
         return st;
+      if ((st = p->d_fast_level.ensure(256)))
+        return st;
+      RSX_HIP_CHECK(ctx, hipMemset(p->d_tickets.ptr, 0, LF_TICKET_WORDS * 4));
+      RSX_HIP_CHECK(ctx, hipMemset(p->d_fast_level.ptr, 0, 256));
 #ifdef RSX_EXPERIMENT
       if (getenv("RSX_DEBUG")) {
         if ((st = p->d_dbg.ensure(size_t(p->total_blocks) * 16 * 8)))
@@ -2730,6 +2844,7 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
       return st;
   if (p->streams.empty())
     return RSX_OK;
+  ++p->run_count;
   const LjArgs a = make_args(p, in_dev, out_dev);
   // results: marker_pos = 0xFFFFFFFF, everything else 0
   for (auto& r : p->h_results) {
@@ -2741,7 +2856,7 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
                                     hipMemcpyHostToDevice, s));
   const uint32_t n_streams = uint32_t(p->streams.size());
   hipLaunchKernelGGL(lj_unstuff_kernel, dim3(p->total_blocks), dim3(LJ_T),
-                     lj_lds_bytes(0) + (p->any_fast ? 1024 : 0), s, a);
+                     lj_lds_bytes(0) + (p->any_fast ? 1040 : 0), s, a);
   mark(p, "lj_unstuff_kernel");
   // the single-pass kernel for the streams it takes ...
   if (p->any_fast) {
@@ -2781,11 +2896,17 @@ int converge(LJpegPlan* p, hipStream_t s) {
     RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->h_results.data(), p->d_results.ptr,
                                       p->h_results.size() * sizeof(LjResult),
                                       hipMemcpyDeviceToHost, s));
+    if (p->any_fast)
+      RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->h_level, p->d_fast_level.ptr, sizeof p->h_level,
+                                        hipMemcpyDeviceToHost, s));
     RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
     return RSX_OK;
   };
   if (int st = fetch())
     return st;
+  // the LDS level this data needed: the next runs launch no higher one
+  if (p->any_fast)
+    p->level_mask = (2u << std::min(p->h_level[2u + (p->run_count & 1u)], 2u)) - 1u;
   // streams the single-pass kernel gave up on: the second pass (unless the run
   // launched it already, because the run before needed it)
   if (p->any_fast) {
@@ -3039,12 +3160,14 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
       fprintf(stderr,
               "[rsx]  stream %zu: marker %u status %u flags %u avail %u needed %llu "
               "last_slot %u last_pos %u consumed %u tail %u blocks %u in_bytes %llu "
-              "redo_rounds %u redo_slots %u not_merged+stitched %u max_rounds %u (workgroup %u%s)\n",
+              "redo_rounds %u redo_slots %u not_merged+stitched %u max_rounds %u (workgroup %u%s) "
+              "single-pass gave up: reasons 0x%x\n",
               k, R.marker_pos, R.status, R.flags, R.avail_lo,
               (unsigned long long)p->streams[k].needed, R.last_slot, R.last_pos,
               R.consumed, R.tail_used, p->streams[k].n_blocks,
               (unsigned long long)p->streams[k].in_bytes, R.stat_rounds, R.stat_redo,
-              R.stat_stitch, R.pad2 >> 16, R.pad2 & 0x7FFFu, (R.pad2 & 0x8000u) ? ", stitch" : "");
+              R.stat_stitch, R.pad2 >> 16, R.pad2 & 0x7FFFu, (R.pad2 & 0x8000u) ? ", stitch" : "",
+              R.stat_why);
     }
   }
 #endif
@@ -3097,7 +3220,7 @@ void ljpeg_plan_destroy(LJpegPlan* p) {
   if (p->nk_child)
     ljpeg_plan_destroy(p->nk_child);
   for (DeviceBuffer* b : {&p->d_nk, &p->d_nk_tables, &p->d_nk_rowpow, &p->d_nk_pup,
-                          &p->d_transfer, &p->d_fast_tabs, &p->d_lb, &p->d_tickets, &p->d_dbg,
+                          &p->d_transfer, &p->d_fast_tabs, &p->d_lb, &p->d_tickets, &p->d_dbg, &p->d_fast_z, &p->d_fast_level,
                           &p->d_fast_order})
     b->release();
   p->d_marker_count.release();

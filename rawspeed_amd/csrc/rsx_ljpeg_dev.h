@@ -179,6 +179,8 @@ struct LjResult {
   uint32_t last_pos;   // its bit offset inside the compacted subsequence
   uint32_t consumed;
   uint32_t tail_used;  // 1: the tail kernel delivered the last symbols
+  uint32_t stat_why;   // statistics (experiment builds): why the single-pass kernel gave up
+  uint32_t pad3[3];
   uint32_t last_c_lo;  // un-stuffed bit offset of the last symbol (tail path)
   uint32_t last_c_hi;
   uint32_t stat_rounds; // statistics: re-decode rounds summed over workgroups
@@ -234,8 +236,26 @@ struct LjArgs {
   // single-pass path (rsx_ljpeg_fast.hip)
   const uint2* fast_tabs;    // [table][1024]: the 10-bit LUT of the single-pass loops
   unsigned long long* lb;    // [workgroup][LF_LB_WORDS]: look-back records (zeroed by K0)
-  uint32_t* tickets;         // [4]: workgroup tickets of the single-pass launches (zeroed by K0)
+  uint32_t* tickets;         // [3][4]: workgroup tickets of the single-pass launches by
+                             // LDS level and components (zeroed by K0)
+  uint32_t* fast_level;      // [2]: the LDS level K0 chose for this run (see fast_lds_lv), by
+                             // run parity; [2 + parity]: the level it would have needed.  (Not next to the tickets: 15 000 workgroups'
+                             // atomics and loads on one cache line take 7 ns each, in turn.)
   uint32_t fast_lds;         // LDS bytes of the single-pass launches (staging capacity)
+  // The single-pass kernel stages all samples of a workgroup in LDS.  How many that are
+  // depends on the DATA (a constant region has six times the symbols per byte of sensor
+  // noise), so the kernel is launched once per LDS level -- 4, 3 and 2 workgroups per CU --
+  // and K0, which counts the symbols of every workgroup on the way, says which of the
+  // launches does the work; the workgroups of the others leave at once.
+  uint32_t fast_lds_lv[3];   // LDS bytes per level (ascending; equal entries = level absent)
+  uint32_t fast_cap_lv[3];   // samples a workgroup can stage at that level
+  uint32_t run_parity;       // which of the two level words this run uses (K0 clears the other)
+  uint32_t fast_level_mask;  // bit l: level l is launched in this run.  (An empty launch costs
+                             // 7 us; once the host has seen which level a plan's data needs --
+                             // fast_level[2 + parity], fetched with the results -- it launches no
+                             // higher one.  K0 picks among the launched levels; workgroups that
+                             // do not fit theirs send the stream to the multi-kernel pipeline.)
+  const uint32_t* fast_z;    // [table]: code of the zero difference: length | code << 8 (0: none)
   uint32_t guess_slots;      // slots K0 parses for a start guess (2 or 3)
   const uint2* fast_order;   // [ticket]: the workgroup's (block, stream) -- the streams'
                              // blocks interleaved, each stream's in order
@@ -323,7 +343,9 @@ struct FastLaunch {
 void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t stream,
                        KernelTimer* timer);
 // the 10-bit LUT of the single-pass loops for one table (1024 entries)
-void ljpeg_build_fast_table(const TabLds& t, uint2* out);
+void ljpeg_build_fast_table(const TabLds& t, uint2* out, uint32_t* zinfo);
 uint32_t ljpeg_fast_lds_for(uint64_t samples_per_workgroup);
+uint32_t ljpeg_fast_stage_cap(uint32_t lds_bytes);
+constexpr int LF_TICKET_WORDS = 16; // [3][4] tickets
 
 } // namespace rsx

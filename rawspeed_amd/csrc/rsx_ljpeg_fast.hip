@@ -62,7 +62,7 @@ constexpr int LF_NR = LF_MAXSYM / 2;
 constexpr int LF_NSIDE = 16;            // side-buffer entries (re-decodes per chunk)
 constexpr int LF_SIDE_STRIDE = 272;     // bytes: 128 x u16 + 16 (16-byte aligned rows)
 constexpr int LF_RMAX = 256;            // stream rows that may start inside one workgroup
-constexpr uint32_t LF_MAX_ROUNDS = 4;   // re-decode rounds before the stream is given up
+constexpr uint32_t LF_MAX_ROUNDS = 6;   // re-decode rounds before the stream is given up
 constexpr uint32_t LF_SPIN_LIMIT = 1u << 22;
 #ifndef RSX_LF_WARM_SLOTS
 #define RSX_LF_WARM_SLOTS 0
@@ -150,7 +150,7 @@ __device__ __forceinline__ FastLds carve_fast(uint8_t* smem, uint32_t lds_bytes)
   f.side = smem + LF_OFF_SIDE;
   f.ctab = reinterpret_cast<uint2*>(tail + LF_TAIL_CTAB);
   f.strips = tail + LF_TAIL_STRIPS;
-  f.stage_cap = (lds_bytes - LF_TAIL_BYTES - LF_STAGE_BASE - 16u) / 2u;
+  f.stage_cap = (lds_bytes - LF_TAIL_BYTES - LF_STAGE_BASE - 16u) / 2u; // (ljpeg_fast_stage_cap)
   return f;
 }
 
@@ -858,15 +858,20 @@ __device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad
 // The kernel
 // ---------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
+__global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds_bytes,
+                                                          uint32_t level) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const FastLds F = carve_fast(smem, a.fast_lds);
+  const FastLds F = carve_fast(smem, lds_bytes);
   const int j = threadIdx.x, lane = j & 63, wv = j >> 6;
 #ifdef RSX_EXPERIMENT
   const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
+  // (a scalar load: K0 wrote the word before this kernel started)
+  if (uint32_t(__builtin_amdgcn_readfirstlane(
+          int(static_cast<const uint32_t*>(a.fast_level)[a.run_parity]))) != level)
+    return; // this run's workgroups need another LDS level: that launch does the work
   if (j == 0)
-    F.misc[M_TICKET] = atomicAdd(&a.tickets[N == 4 ? 2 : N - 1], 1u);
+    F.misc[M_TICKET] = atomicAdd(&a.tickets[4 * level + (N == 4 ? 2 : N - 1)], 1u);
   __syncthreads();
   // ticket -> block: the blocks of the launch's streams interleaved (each stream's in
   // order, so every predecessor holds an earlier ticket).  A workgroup waits for ALL its
@@ -1005,7 +1010,19 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
       const uint32_t my_su = rec_su(F.rec[j]);
       const uint32_t want = j >= 1 ? rec_st(F.rec[j - 1]) : my_su;
       const bool chained = own_bits != 0u && j >= 1;
-      const bool listed = chained && (need_redo || (want != my_su && !(want & ST_ERR)));
+      // After the first round only the HEAD of a run of inconsistent slots is redone.
+      // Plain Jacobi re-decodes slot j from the exit its predecessor had BEFORE this round:
+      // where the data does not synchronise (a constant region, its zero-difference code
+      // over and over: a slot started off the symbol grid can leave off the grid) that
+      // stale exit breaks slot j in the round that repairs slot j - 1, and the error travels
+      // down the region one slot per round, the repair one slot behind it.
+      bool pred_stale = false;
+      if (rounds != 0 && j >= 2) {
+        const uint32_t pp = rec_st(F.rec[j - 2]);
+        pred_stale = rec_su(F.rec[j - 1]) != pp && !(pp & ST_ERR) && F.ob[j - 1] != 0;
+      }
+      const bool listed =
+          chained && (need_redo || (want != my_su && !(want & ST_ERR) && !pred_stale));
       if (listed) {
         if (my_entry < 0)
           my_entry = int(atomicAdd(&F.misc[M_NSIDE], 1u));
@@ -1017,13 +1034,13 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
       const uint32_t nl = (LF_ABLATE & 64u) ? 0u : uni(F.misc[M_LIST]);
       if (uni(F.misc[M_NSIDE]) > uint32_t(LF_NSIDE)) {
         if (j == 0)
-          F.misc[M_SLOW] = 1; // more re-decodes than the side buffer has entries
+          F.misc[M_SLOW] = 2; // more re-decodes than the side buffer has entries
       }
       if (nl == 0)
         break;
       if (++rounds > LF_MAX_ROUNDS) {
         if (j == 0) {
-          F.misc[M_SLOW] = 1; // periodic data: not this kernel's business
+          F.misc[M_SLOW] = 3; // periodic data: not this kernel's business
           atomicOr(&a.results[s].flags, FL_SLOW); // (at once: later workgroups leave early)
         }
         break;
@@ -1054,7 +1071,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
         F.rec[idx] = rec_make(w, e, c > 0xFFFu ? 0xFFFu : c);
         F.sm[idx] = sums;
         if (ovf)
-          F.misc[M_SLOW] = 1;
+          F.misc[M_SLOW] = 4;
       }
     }
 
@@ -1104,7 +1121,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
       published_exit = exit_now;
       LF_STAMP(6);
     } else if (exit_now != published_exit && j == 0) {
-      F.misc[M_SLOW] = 1; // successors may have used the exit published first
+      F.misc[M_SLOW] = 5; // successors may have used the exit published first
     }
     if (lb == 0)
       break;
@@ -1117,7 +1134,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
     if (!(LF_ABLATE & 4u)) {
       const bool ok = lb0_walk(a, F, b, S.first_block, S.start_bit, j, &pe, &bs);
       if (!ok && j == 0)
-        F.misc[M_SLOW] = 1;
+        F.misc[M_SLOW] = 6;
     }
     base = bs;
     LF_STAMP(7);
@@ -1159,7 +1176,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
     // an invalid code inside the delivered range: the slow path reports it the
     // reference's way (PrefixCodeLookupDecoder.h:152-155)
     if (j >= 1 && (my_exit & ST_ERR) && uint64_t(i0) + my_cnt < needed && own_bits != 0)
-      F.misc[M_SLOW] = 1;
+      F.misc[M_SLOW] = 7;
     // lj_consumed_kernel needs the bit position at which the reference's last symbol
     // starts: exactly one lane of the stream owns it and walks there again
     if (needed >= 1 && needed - 1 >= i0 && needed - 1 < uint64_t(i0) + my_cnt && j >= 1) {
@@ -1187,9 +1204,11 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
   const uint32_t r_end = any_out ? (lim - 1) / RS : r0;
   const uint32_t nr = r_end - r0 + 1;
   // (more rows than lanes, or more samples than the staging region holds: slow path)
-  const bool fits = nr <= uint32_t(LF_RMAX) && (lim - base) <= F.stage_cap;
+  // (a workgroup past the last delivered symbol -- the padding rows of an overhanging DNG
+  // tile -- delivers nothing)
+  const bool fits = !any_out || (nr <= uint32_t(LF_RMAX) && (lim - base) <= F.stage_cap);
   if (!fits && j == 0)
-    F.misc[M_SLOW] = 1;
+    F.misc[M_SLOW] = 8;
   const uint32_t sb = LF_STAGE_BASE;
   __syncthreads(); // every lane is done with the image, the records and the side buffer
 
@@ -1311,7 +1330,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
       ok = lb1_walk<N>(a, F, b, S.first_block, init, j, &T_in, &V_in);
     if (j == 0) {
       if (!ok)
-        F.misc[M_SLOW] = 1;
+        F.misc[M_SLOW] = 9;
       // the inclusive state
       const uint2 fm = fld_mask(flags);
       const uint2 T_out = pk_add2(al, sel2(fm, V_in, T_in));
@@ -1342,8 +1361,15 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a) {
       F.ctab[j] = C;
     }
   }
-  if (F.misc[M_SLOW] != 0 && j == 0)
+  if (F.misc[M_SLOW] != 0 && j == 0) {
     atomicOr(&a.results[s].flags, FL_SLOW);
+#ifdef RSX_EXPERIMENT
+    // why (bit k = reason k: 1 more than 128 symbols in a slot, 2 side buffer full, 3 round
+    // limit, 4 re-decode overflow, 5 exit changed by a repair, 6 look-back 0 gave up, 7
+    // invalid code, 8 staging capacity / rows, 9 look-back 1 gave up)
+    atomicOr(&a.results[s].stat_why, 1u << F.misc[M_SLOW]);
+#endif
+  }
   __syncthreads();
   LF_STAMP(13);
   LF_STAMP(14);
@@ -1367,9 +1393,14 @@ template <int N>
 void launch_fast_one(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
   if (!f.present[N])
     return;
-  hipLaunchKernelGGL((lj_fast_kernel<N>), dim3(f.total_blocks), dim3(LJ_T), a.fast_lds, s, a);
-  if (timer)
-    timer->mark("lj_fast_kernel");
+  for (uint32_t lv = 0; lv < 3; ++lv) {
+    if (!((a.fast_level_mask >> lv) & 1u))
+      continue;
+    hipLaunchKernelGGL((lj_fast_kernel<N>), dim3(f.total_blocks), dim3(LJ_T), a.fast_lds_lv[lv],
+                       s, a, a.fast_lds_lv[lv], lv);
+    if (timer)
+      timer->mark(lv == 0 ? "lj_fast_kernel" : (lv == 1 ? "lj_fast_kernel(3/CU)" : "lj_fast_kernel(2/CU)"));
+  }
 }
 
 } // namespace
@@ -1386,6 +1417,10 @@ uint32_t ljpeg_fast_lds_for(uint64_t samples) {
   return need <= 64 * 1024 ? uint32_t(need) : 0u; // (more needs hipFuncSetAttribute)
 }
 
+uint32_t ljpeg_fast_stage_cap(uint32_t lds_bytes) {
+  return (lds_bytes - LF_TAIL_BYTES - LF_STAGE_BASE - 16u) / 2u;
+}
+
 void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
   launch_fast_one<1>(a, f, s, timer);
   launch_fast_one<2>(a, f, s, timer);
@@ -1393,7 +1428,8 @@ void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t s, Kern
 }
 
 // The LUT of the fast loops from the 11-bit table of the general ones.
-void ljpeg_build_fast_table(const TabLds& t, uint2* out) {
+void ljpeg_build_fast_table(const TabLds& t, uint2* out, uint32_t* zinfo) {
+  *zinfo = 0;
   for (uint32_t i = 0; i < 1024; ++i) {
     const uint32_t ea = reinterpret_cast<const uint16_t*>(t.lut)[2 * i * (sizeof(LutEntry) / 2)];
     const uint32_t eb =
@@ -1403,6 +1439,8 @@ void ljpeg_build_fast_table(const TabLds& t, uint2* out) {
                        total <= 26u;
     if (plain) {
       out[i] = make_uint2((32u - total) | (total << 5), (1u << ssss) - 1u);
+      if (ssss == 0)
+        *zinfo = cl | ((i >> (10u - cl)) << 8);
     } else {
       // the warm-up just moves on: by the symbol's length if an 11-bit code says so
       uint32_t adv = 16;

@@ -144,4 +144,4 @@ def test_cfg5_batch_every_frame_vs_reference(gpu, ref):
         refs.append(img.pixels().copy())
     assert B.check_cfg5(out, meta, cons, frames, refs)
     for f in range(frames):
-        assert same(B.gpu_frame(out, f, meta["W"], meta["H"]), refs[f % 3]), f
+        assert same(B.gpu_frame(out, f, meta["W"], meta["H"]), refs[meta["pick"][f]]), f

@@ -167,3 +167,49 @@ def test_plan_reruns_are_identical(gpu):
         if ref is None:
             ref = got
         assert np.array_equal(got, ref)
+
+
+def _kernel_names(plan, inp, out):
+    s = torch.cuda.current_stream().cuda_stream
+    plan.set_timing(True)
+    plan.run(inp.data_ptr(), out.data_ptr(), s)
+    torch.cuda.synchronize()
+    tab = plan.kernel_table()
+    plan.set_timing(False)
+    return [n for n, _ in tab[0]] if tab else []
+
+
+@pytest.mark.parametrize("W,H", [(2048, 768), (4480, 1024)])
+def test_constant_regions_stay_on_the_single_pass_kernel(gpu, W, H):
+    """Blown highlights and a black border: inside them the stream is the code of the zero
+    difference over and over -- no parse from an arbitrary bit synchronises there, and a
+    workgroup holds six times the symbols of sensor noise.  K0 reads the symbol grid of
+    such slots from their bits and picks the LDS level of the run; the multi-kernel
+    pipeline (its synchronisation kernel) is not launched at all."""
+    import bench_ljpeg as B
+    from rawspeed_amd import abi, synth
+    made = []
+    for f in range(2):
+        src = B.clipped_image(W, H, 70 + f)
+        rows = C.cr2_stream_from_image(src, 2, W // 2, H, C.cr2_slices(2, W // 2, W // 2))
+        scan, bits = synth.ljpeg_encode_scan(rows, 2, [1 << 13] * 2, [B._nikon(), B._nikon()])
+        d = abi.Cr2Desc()
+        d.n_comp, d.x_s_f, d.y_s_f = 2, 1, 1
+        d.frame_w, d.frame_h = W // 2, H
+        d.num_slices, d.slice_width, d.last_slice_width = 2, W // 2, W // 2
+        abi.fill_recipe(d, synth.huff_tables(B._nikon()), [0, 0], [1 << 13] * 2)
+        pad = (-(len(scan) + 2)) % 16 + 16
+        data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), np.zeros(pad, np.uint8)])
+        made.append((d, data, src, len(scan)))
+    plan, inp, out = B._cr2_batch(gpu, torch, [(m[0], m[1]) for m in made], W, H)
+    s = torch.cuda.current_stream().cuda_stream
+    for run in range(3):
+        out.zero_()
+        plan.run(inp.data_ptr(), out.data_ptr(), s)
+        rc, st, cons = plan.results()
+        assert rc == 0 and list(cons) == [m[3] for m in made]
+        for f in range(2):
+            assert np.array_equal(B.gpu_frame(out, f, W, H), made[f][2]), (run, f)
+    names = _kernel_names(plan, inp, out)
+    assert any("lj_fast_kernel" in n for n in names), names
+    assert not any("sync" in n for n in names), names
