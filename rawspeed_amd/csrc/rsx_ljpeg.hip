@@ -605,17 +605,18 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       uint32_t lv = 0;
       while (lv < 2u && need > a.fast_cap_lv[lv])
         ++lv;
-      if (lv) {
+      while (lv > 0u && a.fast_cap_lv[lv] == a.fast_cap_lv[lv - 1u])
+        --lv; // (an absent level: the one below has the same LDS)
+      if (lv)
         atomicMax(&a.fast_level[2u + a.run_parity], lv);
-        // the lowest launched level that holds it, or the highest launched one
-        uint32_t use = lv;
-        while (use < 2u && !((a.fast_level_mask >> use) & 1u))
-          ++use;
-        while (use > 0u && !((a.fast_level_mask >> use) & 1u))
-          --use;
-        if (use)
-          atomicMax(&a.fast_level[a.run_parity], use);
-      }
+      // the lowest launched level that holds it, or the highest launched one
+      uint32_t use = lv;
+      while (use < 2u && !((a.fast_level_mask >> use) & 1u))
+        ++use;
+      while (use > 0u && !((a.fast_level_mask >> use) & 1u))
+        --use;
+      if (use)
+        atomicMax(&a.fast_level[a.run_parity], use);
     }
   }
 }
@@ -2904,9 +2905,9 @@ int converge(LJpegPlan* p, hipStream_t s) {
   };
   if (int st = fetch())
     return st;
-  // the LDS level this data needed: the next runs launch no higher one
+  // the LDS level this data needed: the next runs launch that one only
   if (p->any_fast)
-    p->level_mask = (2u << std::min(p->h_level[2u + (p->run_count & 1u)], 2u)) - 1u;
+    p->level_mask = 1u << std::min(p->h_level[2u + (p->run_count & 1u)], 2u);
   // streams the single-pass kernel gave up on: the second pass (unless the run
   // launched it already, because the run before needed it)
   if (p->any_fast) {
@@ -3161,13 +3162,13 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
               "[rsx]  stream %zu: marker %u status %u flags %u avail %u needed %llu "
               "last_slot %u last_pos %u consumed %u tail %u blocks %u in_bytes %llu "
               "redo_rounds %u redo_slots %u not_merged+stitched %u max_rounds %u (workgroup %u%s) "
-              "single-pass gave up: reasons 0x%x\n",
+              "single-pass gave up: reasons 0x%x (block %u slot %u symbols before it %u base %u)\n",
               k, R.marker_pos, R.status, R.flags, R.avail_lo,
               (unsigned long long)p->streams[k].needed, R.last_slot, R.last_pos,
               R.consumed, R.tail_used, p->streams[k].n_blocks,
               (unsigned long long)p->streams[k].in_bytes, R.stat_rounds, R.stat_redo,
               R.stat_stitch, R.pad2 >> 16, R.pad2 & 0x7FFFu, (R.pad2 & 0x8000u) ? ", stitch" : "",
-              R.stat_why);
+              R.stat_why, R.pad3[0], R.pad3[1] & 0xFFFFu, R.pad3[1] >> 16, R.pad3[2]);
     }
   }
 #endif

@@ -252,9 +252,9 @@ struct LjArgs {
   uint32_t run_parity;       // which of the two level words this run uses (K0 clears the other)
   uint32_t fast_level_mask;  // bit l: level l is launched in this run.  (An empty launch costs
                              // 7 us; once the host has seen which level a plan's data needs --
-                             // fast_level[2 + parity], fetched with the results -- it launches no
-                             // higher one.  K0 picks among the launched levels; workgroups that
-                             // do not fit theirs send the stream to the multi-kernel pipeline.)
+                             // fast_level[2 + parity], fetched with the results -- it launches
+                             // that one only.  K0 picks among the launched levels; workgroups
+                             // that do not fit theirs send the stream to the multi-kernel pipeline.)
   const uint32_t* fast_z;    // [table]: code of the zero difference: length | code << 8 (0: none)
   uint32_t guess_slots;      // slots K0 parses for a start guess (2 or 3)
   const uint2* fast_order;   // [ticket]: the workgroup's (block, stream) -- the streams'

@@ -111,12 +111,11 @@ enum : int {
   M_WSUM = 4,   // [8] difference sums per wavefront (uint2 x 4)
   M_LIST = 12,  // re-decode list length
   M_TICKET = 13,
-  M_BASE = 14,  // index of the workgroup's first symbol
+  M_UNRESB = 14, // symbols in front of slot misc[M_UNRES]
   M_PRED = 15,  // predecessor's exit state
   M_SLOW = 16,  // != 0: give the stream to the slow path
-  M_SPARE = 17,
-  M_TIN = 18,   // [2] T_in
-  M_VIN = 20,   // [2] Vc_in
+  M_UNRES = 17, // first slot the kernel could not finish (0xFFFF: none)
+  M_WNE = 18,   // [4] side entries the wavefronts ask for in a round
   M_RSUM = 22,  // [8] row scan: per-wavefront totals (uint2 x 4)
   M_LB1 = 30,   // [8] the LOCAL record (a, v) / (T_out, Vc_out)
   M_NSIDE = 38, // side-buffer entries handed out
@@ -866,13 +865,28 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
 #ifdef RSX_EXPERIMENT
   const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
-  // (a scalar load: K0 wrote the word before this kernel started)
-  if (uint32_t(__builtin_amdgcn_readfirstlane(
-          int(static_cast<const uint32_t*>(a.fast_level)[a.run_parity]))) != level)
-    return; // this run's workgroups need another LDS level: that launch does the work
-  if (j == 0)
-    F.misc[M_TICKET] = atomicAdd(&a.tickets[4 * level + (N == 4 ? 2 : N - 1)], 1u);
+  // Is this launch the one that works (LjArgs::fast_lds_lv)?  An L2 load: the word changes
+  // from run to run, and nothing invalidates a CU's scalar cache between two kernels of a
+  // stream (measured: stale level words).  At level 0, the usual one, the ticket is taken
+  // in the same round trip (every level has tickets of its own, on another cache line --
+  // 15 000 atomics on one address take 0.17 ms, so the other levels ask first).
+  if (j == 0) {
+    uint32_t chosen, t = 0;
+    if (level == 0) {
+      chosen = __hip_atomic_load(&a.fast_level[a.run_parity], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+      t = atomicAdd(&a.tickets[N == 4 ? 2 : N - 1], 1u);
+    } else {
+      chosen = __hip_atomic_load(&a.fast_level[a.run_parity], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+      if (chosen == level)
+        t = atomicAdd(&a.tickets[4 * level + (N == 4 ? 2 : N - 1)], 1u);
+    }
+    F.misc[M_TICKET] = chosen == level ? t : 0xFFFFFFFFu;
+  }
   __syncthreads();
+  if (uni(F.misc[M_TICKET]) == 0xFFFFFFFFu)
+    return; // this run's workgroups need another LDS level: that launch does the work
   // ticket -> block: the blocks of the launch's streams interleaved (each stream's in
   // order, so every predecessor holds an earlier ticket).  A workgroup waits for ALL its
   // stream's workgroups in flight; with one stream after the other that is everything on
@@ -919,6 +933,8 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   if (j == 0) {
     F.misc[M_SLOW] = 0;
     F.misc[M_NSIDE] = 0;
+    F.misc[M_UNRES] = 0xFFFFu;
+    F.misc[M_UNRESB] = 0;
   }
   lj_load_image<LF_BW, true>(L, a, b, j); // ends with a barrier
   LF_STAMP(2);
@@ -979,7 +995,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     uint32_t ex = special ? ST_ERR : ((pend - fs.Pn) >> 5);
     if (over) {
       ex = ST_ERR;
-      F.misc[M_SLOW] = 1;
+      atomicMin(&F.misc[M_UNRES], uint32_t(j));
     }
     need_redo = special;
     if (j >= 1)
@@ -1000,6 +1016,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // the loops makes every register of R loop-carried, and the compiler then keeps two
   // copies of the 64 (measured: 180 VGPRs).
   int my_entry = -1;
+  bool exit_changed = false;
   for (int attempt = 0; attempt < 2; ++attempt) {
     // 3. Jacobi rounds with a dense list (lj_sync_kernel's scheme)
     uint32_t rounds = 0;
@@ -1023,28 +1040,40 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       }
       const bool listed =
           chained && (need_redo || (want != my_su && !(want & ST_ERR) && !pred_stale));
-      if (listed) {
-        if (my_entry < 0)
-          my_entry = int(atomicAdd(&F.misc[M_NSIDE], 1u));
-        if (my_entry < LF_NSIDE)
-          F.list[atomicAdd(&F.misc[M_LIST], 1u)] = uint16_t(j | (my_entry << 8));
+      // side-buffer entries in slot order: what follows the last delivered symbol (zeros
+      // behind the end-of-image marker, trailing bytes: periodic, every slot inconsistent)
+      // must not take them from the slots in front of it
+      {
+        const bool ask = listed && my_entry < 0;
+        const unsigned long long am = __ballot(ask);
+        if (lane == 0)
+          F.misc[M_WNE + wv] = uint32_t(__builtin_popcountll(am));
+        const uint32_t handed = F.misc[M_NSIDE];
+        __syncthreads();
+        uint32_t first = handed, all = handed;
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t t = F.misc[M_WNE + w];
+          first += w < wv ? t : 0u;
+          all += t;
+        }
+        // (the first round leaves four entries for slots that turn up later, further in front)
+        const uint32_t limit = rounds == 0 ? uint32_t(LF_NSIDE) - 4u : uint32_t(LF_NSIDE);
+        if (ask) {
+          const uint32_t k = first + uint32_t(__builtin_popcountll(am & ((1ull << lane) - 1ull)));
+          my_entry = k < limit ? int(k) : -1;
+        }
+        if (j == 0)
+          F.misc[M_NSIDE] = all < limit ? all : (handed > limit ? handed : limit);
       }
+      if (listed && my_entry >= 0)
+        F.list[atomicAdd(&F.misc[M_LIST], 1u)] = uint16_t(j | (my_entry << 8));
       need_redo = false;
       __syncthreads();
       const uint32_t nl = (LF_ABLATE & 64u) ? 0u : uni(F.misc[M_LIST]);
-      if (uni(F.misc[M_NSIDE]) > uint32_t(LF_NSIDE)) {
-        if (j == 0)
-          F.misc[M_SLOW] = 2; // more re-decodes than the side buffer has entries
-      }
-      if (nl == 0)
+      // (more re-decodes than the side buffer has entries, or data that does not
+      // synchronise: what is left inconsistent is dealt with below)
+      if (nl == 0 || ++rounds > LF_MAX_ROUNDS)
         break;
-      if (++rounds > LF_MAX_ROUNDS) {
-        if (j == 0) {
-          F.misc[M_SLOW] = 3; // periodic data: not this kernel's business
-          atomicOr(&a.results[s].flags, FL_SLOW); // (at once: later workgroups leave early)
-        }
-        break;
-      }
 #ifdef RSX_EXPERIMENT
       if (j == 0) {
         atomicAdd(&a.results[s].stat_rounds, 1u);
@@ -1071,8 +1100,19 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
         F.rec[idx] = rec_make(w, e, c > 0xFFFu ? 0xFFFu : c);
         F.sm[idx] = sums;
         if (ovf)
-          F.misc[M_SLOW] = 4;
+          atomicMin(&F.misc[M_UNRES], idx);
       }
+    }
+    // Slots the rounds have left inconsistent (periodic data, more re-decodes than side
+    // entries, more than LF_MAXSYM symbols): everything from the first of them on is
+    // unknown.  That only matters if the stream's delivered symbols reach that far --
+    // what follows the last of them (the zeros the bit pump feeds after the end-of-image
+    // marker, any trailing bytes of the input) is periodic as a rule and nobody's business.
+    {
+      const uint32_t su = rec_su(F.rec[j]);
+      const uint32_t wn = j >= 1 ? rec_st(F.rec[j - 1]) : su;
+      if (own_bits != 0u && j >= 1 && wn != su && !(wn & ST_ERR))
+        atomicMin(&F.misc[M_UNRES], uint32_t(j));
     }
 
     // per slot: symbols before it, running sums before it (workgroup-relative phases)
@@ -1092,6 +1132,8 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     before = incl - my_cnt;
     for (int w = 0; w < wv; ++w)
       before += F.misc[M_WCNT + w];
+    if (uint32_t(j) == F.misc[M_UNRES])
+      F.misc[M_UNRESB] = before;
     cnt_wg = uni(F.misc[M_WCNT] + F.misc[M_WCNT + 1] + F.misc[M_WCNT + 2] + F.misc[M_WCNT + 3]);
     {
       const uint2 r = lj_rot_fields<N>(my_sums, before & uint32_t(N - 1));
@@ -1120,8 +1162,8 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     if (attempt == 0) {
       published_exit = exit_now;
       LF_STAMP(6);
-    } else if (exit_now != published_exit && j == 0) {
-      F.misc[M_SLOW] = 5; // successors may have used the exit published first
+    } else if (exit_now != published_exit) {
+      exit_changed = true; // successors may have used the exit published first
     }
     if (lb == 0)
       break;
@@ -1191,6 +1233,19 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       a.results[s].last_pos = p2;
     }
   }
+  // does a delivered symbol lie in the part of the workgroup the rounds did not finish?
+  // (the barrier in front of the staging orders the flag)
+  if (j == 0 && F.misc[M_UNRES] != 0xFFFFu && uint64_t(base) + F.misc[M_UNRESB] < needed) {
+    F.misc[M_SLOW] = 3;
+#ifdef RSX_EXPERIMENT
+    a.results[s].pad3[0] = lb;
+    a.results[s].pad3[1] = F.misc[M_UNRES] | (F.misc[M_UNRESB] << 16);
+    a.results[s].pad3[2] = base;
+#endif
+  }
+  // (an exit that a repair changed: the same, seen from the successors)
+  if (j == 0 && exit_changed && uint64_t(base) + cnt_wg < needed)
+    F.misc[M_SLOW] = 5;
   LF_STAMP(9);
 
   // 5. geometry of the delivered symbols [base, lim) and the stream rows they touch

@@ -16,7 +16,7 @@ H = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 ns = 2
 made = []
 for f in range(2):
-    src = B.clipped_image(W, H, 70 + f)
+    src = B.clipped_image(W, H, int(os.environ.get("SEED", "70")) + f)
     rows = C.cr2_stream_from_image(src, 2, W // 2, H, C.cr2_slices(ns, W // ns, W // ns))
     scan, bits = synth.ljpeg_encode_scan(rows, 2, [1 << 13] * 2, [B._nikon(), B._nikon()])
     d = abi.Cr2Desc()

@@ -213,3 +213,91 @@ def test_constant_regions_stay_on_the_single_pass_kernel(gpu, W, H):
     names = _kernel_names(plan, inp, out)
     assert any("lj_fast_kernel" in n for n in names), names
     assert not any("sync" in n for n in names), names
+
+
+def test_lds_level_follows_the_data_of_a_reused_plan(gpu):
+    """One plan, first a noisy frame, then (same byte count) a frame with constant regions:
+    the host has seen that the plan's data needs the smallest LDS level only and launches
+    no other, so the run with the dense frame hands its streams to the multi-kernel pipeline
+    -- same pixels -- and the run after that launches the level the data asked for."""
+    import bench_ljpeg as B
+    from rawspeed_amd import abi, synth
+    W, H = 4480, 1024
+
+    def encode(src):
+        rows = C.cr2_stream_from_image(src, 2, W // 2, H, C.cr2_slices(2, W // 2, W // 2))
+        scan, _ = synth.ljpeg_encode_scan(rows, 2, [1 << 13] * 2, [B._nikon(), B._nikon()])
+        return scan
+
+    noisy = synth.sensor_image(W, H, 14, seed=90)
+    dense = B.clipped_image(W, H, 91)
+    sa, sb = encode(noisy), encode(dense)
+    assert len(sb) < len(sa)
+    n = len(sa) + 2 + ((-(len(sa) + 2)) % 16 + 16)
+
+    def blob(scan):
+        out = np.zeros(n, np.uint8)
+        out[:len(scan)] = scan
+        out[len(scan):len(scan) + 2] = (0xFF, 0xD9)
+        return out
+
+    d = abi.Cr2Desc()
+    d.n_comp, d.x_s_f, d.y_s_f = 2, 1, 1
+    d.frame_w, d.frame_h = W // 2, H
+    d.num_slices, d.slice_width, d.last_slice_width = 2, W // 2, W // 2
+    abi.fill_recipe(d, synth.huff_tables(B._nikon()), [0, 0], [1 << 13] * 2)
+    plan, inp, out = B._cr2_batch(gpu, torch, [(d, blob(sa))], W, H)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run(scan, src):
+        inp.copy_(torch.from_numpy(blob(scan)))
+        out.zero_()
+        plan.run(inp.data_ptr(), out.data_ptr(), s)
+        rc, st, cons = plan.results()
+        assert rc == 0 and list(cons) == [len(scan)]
+        assert np.array_equal(B.gpu_frame(out, 0, W, H), src)
+
+    run(sa, noisy)
+    run(sa, noisy)
+    run(sb, dense)
+    run(sb, dense)
+    names = _kernel_names(plan, inp, out)
+    assert any("lj_fast_kernel(" in n for n in names), names
+    assert not any("sync" in n for n in names), names
+    run(sa, noisy)
+
+
+@pytest.mark.parametrize("tail", ["zeros", "pattern", "random"])
+def test_trailing_bytes_after_the_last_symbol_are_nobodys_business(gpu, oracle, tail):
+    """200 KB behind the end-of-image marker inside the job's byte range (the bit pump
+    feeds zeros there; the kernel's slots are periodic, nothing synchronises): no delivered
+    symbol lies in them, the stream stays on the single-pass kernel."""
+    import bench_ljpeg as B
+    from rawspeed_amd import abi
+    rng = np.random.default_rng([13, len(tail)])
+    W, H = 2048, 700
+    d, data, px, _ = C.make_ljpeg_case(rng, img_w=W, img_h=H, cpp=1, tile=(0, 0, W, H), mcu=(2, 1))
+    extra = {"zeros": np.zeros(200000, np.uint8),
+             "pattern": np.tile(np.array([0x55, 0xAA, 0x3C], np.uint8), 70000),
+             "random": rng.integers(0, 256, 200000, dtype=np.uint8)}[tail]
+    data = np.concatenate([data, extra])
+    so = _check(gpu, oracle, d, data, W, H)
+    assert so[0] == 0
+    j = abi.LJpegJob()
+    j.desc = d
+    j.in_offset, j.in_bytes, j.img_offset = 0, data.size, 0
+    j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
+        B.out_pitch(W), W, H, 1, 1
+    plan = gpu.ljpeg_plan([j])
+    inp = torch.from_numpy(data).cuda()
+    out = torch.zeros(B.out_pitch(W) * H, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for run in range(3):
+        out.zero_()
+        plan.run(inp.data_ptr(), out.data_ptr(), s)
+        rc, st, cons = plan.results()
+        assert rc == 0 and not any(st) and list(cons) == [so[1]]
+        assert np.array_equal(B.gpu_frame(out, 0, W, H), px)
+    names = _kernel_names(plan, inp, out)
+    assert any("lj_fast_kernel" in n for n in names), names
+    assert not any("sync" in n for n in names), names
