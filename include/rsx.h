@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSX_ABI_VERSION 2
+#define RSX_ABI_VERSION 3
 
 /* ------------------------------------------------------------------------ */
 /* Status codes.  Kernels cannot throw; the C++ forwarding shim converts a   */
@@ -350,6 +350,36 @@ int rsx_samsung_v1_decompress(rsx_ctx* ctx, const rsx_samsung_v1_desc* d,
                               const uint8_t* in, size_t in_bytes, const rsx_image* img);
 
 /* ------------------------------------------------------------------------ */
+/* 3g. SamsungV2Decompressor                                                 */
+/*    replaces SamsungV2Decompressor::decompress()                           */
+/*    (decompressors/SamsungV2Decompressor.h:74, .cpp:340-343: decompressRow */
+/*    for every row, .cpp:312-338).  The descriptor is what the constructor  */
+/*    (.cpp:85-141) reads from the 16-byte header -- bitDepth, width,        */
+/*    height, optflags, initVal -- and `in` is its member `data`: the bytes   */
+/*    behind that header.  Every row is a BitStreamerMSB32 of its own that   */
+/*    starts at the next 16-byte boundary of `data` (.cpp:314-318); a row is */
+/*    width / 16 blocks (processBlock .cpp:312-327: prepareBaselineValues    */
+/*    .cpp:152-230, decodeDiffLengths .cpp:232-277, decodeDifferences        */
+/*    .cpp:279-311), pixels are clampBits(baseline + difference, bitDepth).  */
+/*    rsx_samsung_v2_validate = the constructor's checks (.cpp:88-100,       */
+/*    :123-125, :134-139).  Statuses: what the reference throws, in its      */
+/*    order -- RSX_ERR_INVALID_ARG for its ThrowRDEs (.cpp:172-173, :191-    */
+/*    192, :212-219, :258-259, :271-272), RSX_ERR_IO / RSX_ERR_INPUT_        */
+/*    OVERFLOW for the stream running out; the image is unspecified then.    */
+/* ------------------------------------------------------------------------ */
+typedef struct rsx_samsung_v2_desc {
+  int32_t bit_depth;  /* bitDepth: 12 or 14 */
+  int32_t width;      /* multiple of 16, <= 6496 */
+  int32_t height;     /* <= 4336 */
+  uint32_t optflags;  /* OptFlags (.cpp:46-54): 1 SKIP, 2 MV, 4 QP */
+  uint32_t init_val;  /* initVal (14 bits) */
+} rsx_samsung_v2_desc;
+
+int rsx_samsung_v2_validate(const rsx_samsung_v2_desc* d, const rsx_image* img);
+int rsx_samsung_v2_decompress(rsx_ctx* ctx, const rsx_samsung_v2_desc* d, const uint8_t* in,
+                              size_t in_bytes, const rsx_image* img);
+
+/* ------------------------------------------------------------------------ */
 /* 3e. HasselbladDecompressor                                                */
 /*    replaces HasselbladDecompressor::decompress()                          */
 /*    (decompressors/HasselbladDecompressor.h:53, .cpp:71-100): BitStreamer- */
@@ -508,6 +538,14 @@ typedef struct rsx_samsung_v1_job {
   rsx_image img; /* .data ignored */
 } rsx_samsung_v1_job;
 
+typedef struct rsx_samsung_v2_job {
+  rsx_samsung_v2_desc desc;
+  uint64_t in_offset; /* multiple of 16: the rows start at 16-byte boundaries of the data */
+  uint64_t in_bytes;
+  uint64_t img_offset;
+  rsx_image img; /* .data ignored */
+} rsx_samsung_v2_job;
+
 typedef struct rsx_sony_arw1_job {
   uint64_t in_offset;
   uint64_t in_bytes;
@@ -534,6 +572,8 @@ int rsx_nikon_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_nikon_job* jobs,
 int rsx_pentax_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_pentax_job* jobs,
                            rsx_plan** out_plan);
 int rsx_samsung_v1_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_samsung_v1_job* jobs,
+                               rsx_plan** out_plan);
+int rsx_samsung_v2_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_samsung_v2_job* jobs,
                                rsx_plan** out_plan);
 int rsx_sraw_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_sraw_job* jobs,
                          rsx_plan** out_plan);

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-RSX_ABI_VERSION = 2
+RSX_ABI_VERSION = 3
 
 # rsx_status
 RSX_OK = 0
@@ -147,6 +147,42 @@ class SamsungV1Desc(C.Structure):
 
 class SamsungV1Job(C.Structure):
     _fields_ = [("desc", SamsungV1Desc), ("in_offset", C.c_uint64),
+                ("in_bytes", C.c_uint64), ("img_offset", C.c_uint64),
+                ("img", Image)]
+
+
+class SamsungV2Desc(C.Structure):
+    _fields_ = [("bit_depth", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("optflags", C.c_uint32), ("init_val", C.c_uint32)]
+
+    @classmethod
+    def from_header(cls, hdr):
+        """The fields SamsungV2Decompressor's constructor reads from the 16-byte header
+        (SamsungV2Decompressor.cpp:106-132; BitStreamerMSB32: little-endian 32-bit words,
+        most significant bit first).  Returns (desc, raw optflags)."""
+        w = [int.from_bytes(bytes(hdr[4 * k:4 * k + 4]), "little") for k in range(4)]
+        bits = "".join(format(x, "032b") for x in w)
+        pos = [0]
+
+        def get(n):
+            v = int(bits[pos[0]:pos[0] + n], 2)
+            pos[0] += n
+            return v
+        d = cls()
+        get(16), get(4)
+        d.bit_depth = get(4) + 1
+        get(4), get(4)
+        d.width, d.height = get(16), get(16)
+        get(16), get(4)
+        flags = get(4)
+        get(8), get(8), get(8), get(2)
+        d.init_val = get(14)
+        d.optflags = flags
+        return d, flags
+
+
+class SamsungV2Job(C.Structure):
+    _fields_ = [("desc", SamsungV2Desc), ("in_offset", C.c_uint64),
                 ("in_bytes", C.c_uint64), ("img_offset", C.c_uint64),
                 ("img", Image)]
 

@@ -19,9 +19,10 @@ LIB_CORE = os.path.join(PKG, "librsx.so")
 LIB_SYNTH = os.path.join(PKG, "librsx_synth.so")
 
 CORE_SOURCES = ["rsx_api.hip", "rsx_unpack.hip", "rsx_ljpeg.hip", "rsx_ljpeg_direct.hip",
-                "rsx_ljpeg_fast.hip", "rsx_ljpeg_recon.hip", "rsx_sraw.hip", "rsx_host.cpp"]
+                "rsx_ljpeg_fast.hip", "rsx_ljpeg_recon.hip", "rsx_sraw.hip", "rsx_samsung_v2.hip",
+                "rsx_host.cpp"]
 CORE_HEADERS = ["rsx_internal.h", "rsx_device.h", "rsx_ljpeg.h", "rsx_ljpeg_dev.h",
-                "rsx_ljpeg_bits.h"]
+                "rsx_ljpeg_bits.h", "rsx_samsung_v2.h"]
 
 
 def _hipcc():

@@ -27,6 +27,7 @@ EXPORTS = [
     "rsx_pentax_validate", "rsx_pentax_decompress", "rsx_pentax_plan_create",
     "rsx_hasselblad_validate", "rsx_hasselblad_decompress", "rsx_hasselblad_plan_create",
     "rsx_samsung_v1_validate", "rsx_samsung_v1_decompress", "rsx_samsung_v1_plan_create",
+    "rsx_samsung_v2_validate", "rsx_samsung_v2_decompress", "rsx_samsung_v2_plan_create",
     "rsx_sony_arw1_validate", "rsx_sony_arw1_decompress", "rsx_sony_arw1_plan_create",
     "rsx_dng_decompress_ljpeg", "rsx_dng_decompress_uncompressed",
     "rsx_unpack_plan_create", "rsx_ljpeg_plan_create", "rsx_cr2_plan_create",
@@ -89,6 +90,9 @@ def lib():
         L.rsx_sony_arw1_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t,
                                                C.c_void_p]
         L.rsx_samsung_v1_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.rsx_samsung_v2_validate.argtypes = [C.c_void_p, C.c_void_p]
+        L.rsx_samsung_v2_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_size_t, C.c_void_p]
         L.rsx_samsung_v1_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p]
         L.rsx_pentax_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
@@ -103,6 +107,7 @@ def lib():
                      "rsx_cr2_plan_create", "rsx_unpack_variant_plan_create",
                      "rsx_nikon_plan_create", "rsx_unpack_f32_plan_create",
                      "rsx_pentax_plan_create", "rsx_samsung_v1_plan_create",
+                     "rsx_samsung_v2_plan_create",
                      "rsx_sraw_plan_create", "rsx_hasselblad_plan_create",
                      "rsx_sony_arw1_plan_create"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p,
@@ -223,6 +228,11 @@ class Context:
         return lib().rsx_samsung_v1_decompress(self._h, C.byref(desc), a.ctypes.data,
                                                a.size, C.byref(img_view))
 
+    def samsung_v2_decompress(self, desc, data, img_view):
+        a = _u8(data)
+        return lib().rsx_samsung_v2_decompress(self._h, C.byref(desc), a.ctypes.data,
+                                               a.size, C.byref(img_view))
+
     def sony_arw1_decompress(self, data, img_view):
         a = _u8(data)
         return lib().rsx_sony_arw1_decompress(self._h, a.ctypes.data, a.size,
@@ -273,6 +283,9 @@ class Context:
 
     def hasselblad_plan(self, jobs):
         return Plan(self, "rsx_hasselblad_plan_create", abi.HasselbladJob, jobs)
+
+    def samsung_v2_plan(self, jobs):
+        return Plan(self, "rsx_samsung_v2_plan_create", abi.SamsungV2Job, jobs)
 
     def samsung_v1_plan(self, jobs):
         return Plan(self, "rsx_samsung_v1_plan_create", abi.SamsungV1Job, jobs)

@@ -7,6 +7,7 @@
 #include "rsx_internal.h"
 #include "rsx_ljpeg.h"
 #include "rsx_ljpeg_dev.h"
+#include "rsx_samsung_v2.h"
 
 #include <algorithm>
 #include <cstring>
@@ -19,7 +20,7 @@ using namespace rsx;
 // ---------------------------------------------------------------------------
 namespace {
 
-enum PlanKind { PLAN_UNPACK = 0, PLAN_LJPEG = 1, PLAN_SRAW = 2 };
+enum PlanKind { PLAN_UNPACK = 0, PLAN_LJPEG = 1, PLAN_SRAW = 2, PLAN_SV2 = 3 };
 
 struct UnpackLaunch {
   int mode = UNPACK_MODE_PACKED;
@@ -44,6 +45,7 @@ struct rsx_plan {
   std::vector<int32_t> job_status; // host-side validation result per job
   std::vector<UnpackLaunch> unpack;
   std::unique_ptr<LJpegPlan, LJpegPlanDeleter> ljpeg;
+  Sv2Plan* sv2 = nullptr; // PLAN_SV2
   // PLAN_SRAW
   DeviceBuffer d_sraw_jobs, d_sraw_starts;
   int n_sraw = 0;
@@ -589,14 +591,17 @@ extern "C" int rsx_plan_run(rsx_plan* plan, const void* in_dev, void* out_dev,
     return RSX_OK;
   }
   (void)ev;
+  const bool sv2 = plan->kind == PLAN_SV2;
   if (!plan->timing)
-    return ljpeg_plan_run(plan->ljpeg.get(), in_dev, out_dev, s, nullptr);
+    return sv2 ? samsung_v2_plan_run(plan->sv2, in_dev, out_dev, s, nullptr)
+               : ljpeg_plan_run(plan->ljpeg.get(), in_dev, out_dev, s, nullptr);
   if (int st = fold_kernel_timer(plan)) // (waits for the previous timed run)
     return st;
   if (!plan->ktimer)
     plan->ktimer = std::make_unique<KernelTimer>();
   plan->ktimer_pending = true;
-  return ljpeg_plan_run(plan->ljpeg.get(), in_dev, out_dev, s, plan->ktimer.get());
+  return sv2 ? samsung_v2_plan_run(plan->sv2, in_dev, out_dev, s, plan->ktimer.get())
+             : ljpeg_plan_run(plan->ljpeg.get(), in_dev, out_dev, s, plan->ktimer.get());
 }
 
 extern "C" int rsx_plan_results(rsx_plan* plan, int32_t* job_status,
@@ -620,6 +625,12 @@ extern "C" int rsx_plan_results(rsx_plan* plan, int32_t* job_status,
     }
     return rc;
   }
+  if (plan->kind == PLAN_SV2) {
+    if (job_consumed)
+      for (int i = 0; i < plan->n_jobs; ++i)
+        job_consumed[i] = 0;
+    return samsung_v2_plan_results(plan->sv2, plan->last_stream, plan->ran, job_status);
+  }
   return ljpeg_plan_results(plan->ljpeg.get(), plan->last_stream, plan->ran,
                             job_status, job_consumed);
 }
@@ -632,7 +643,7 @@ extern "C" int rsx_plan_set_timing(rsx_plan* plan, int enable) {
   plan->ktotals.clear();
   plan->kruns = 0;
   plan->ktimer_pending = false;
-  if (plan->kind == PLAN_LJPEG)
+  if (plan->kind == PLAN_LJPEG || plan->kind == PLAN_SV2)
     return RSX_OK; // its events are created on the first timed run
   if (plan->timing && plan->events.size() < 64) {
     // event creation is slow on ROCm: pre-create the pool outside timed regions
@@ -651,7 +662,7 @@ extern "C" int rsx_plan_set_timing(rsx_plan* plan, int enable) {
 
 extern "C" int rsx_plan_kernel_table(rsx_plan* plan, int cap, const char** names,
                                      double* avg_ms, int* n_kernels, int* n_runs) {
-  if (!plan || plan->kind != PLAN_LJPEG || !plan->timing)
+  if (!plan || (plan->kind != PLAN_LJPEG && plan->kind != PLAN_SV2) || !plan->timing)
     return RSX_ERR_INVALID_ARG;
   rsx_ctx* ctx = plan->ctx;
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
@@ -684,7 +695,7 @@ extern "C" int rsx_plan_kernel_time(rsx_plan* plan, const char** kernel_name,
   rsx_ctx* ctx = plan->ctx;
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (plan->kind == PLAN_LJPEG) {
+  if (plan->kind == PLAN_LJPEG || plan->kind == PLAN_SV2) {
     // the dominant kernel = the one with the largest share of the timed runs
     if (int st = fold_kernel_timer(plan))
       return st;
@@ -751,6 +762,7 @@ extern "C" void rsx_plan_destroy(rsx_plan* plan) {
       for (int i = 0; i < plan->ktimer->created; ++i)
         (void)hipEventDestroy(plan->ktimer->ev[i]);
     plan->ljpeg.reset();
+    samsung_v2_plan_destroy(plan->sv2);
   }
   delete plan;
 }
@@ -1090,6 +1102,33 @@ extern "C" int rsx_cr2_plan_create(rsx_ctx* ctx, int n_jobs,
   if (int st = ljpeg_plan_create(ctx, in, &lp))
     return st;
   plan->ljpeg.reset(lp);
+  *out_plan = plan.release();
+  return RSX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// SamsungV2Decompressor
+// ---------------------------------------------------------------------------
+extern "C" int rsx_samsung_v2_validate(const rsx_samsung_v2_desc* d, const rsx_image* img) {
+  if (!d || !img)
+    return RSX_ERR_INVALID_ARG;
+  return samsung_v2_validate(*d, *img);
+}
+
+extern "C" int rsx_samsung_v2_plan_create(rsx_ctx* ctx, int n_jobs,
+                                          const rsx_samsung_v2_job* jobs,
+                                          rsx_plan** out_plan) {
+  if (!ctx || !jobs || n_jobs < 1 || !out_plan)
+    return RSX_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  auto plan = std::make_unique<rsx_plan>();
+  plan->ctx = ctx;
+  plan->kind = PLAN_SV2;
+  plan->n_jobs = n_jobs;
+  plan->job_status.assign(n_jobs, RSX_OK);
+  if (int st = samsung_v2_plan_create(ctx, n_jobs, jobs, &plan->sv2))
+    return st;
   *out_plan = plan.release();
   return RSX_OK;
 }
@@ -1534,6 +1573,9 @@ HostRect out_rect(const rsx_pentax_job& j) {
 HostRect out_rect(const rsx_samsung_v1_job& j) {
   return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
 }
+HostRect out_rect(const rsx_samsung_v2_job& j) {
+  return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
+}
 HostRect out_rect(const rsx_sony_arw1_job& j) {
   return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
 }
@@ -1724,6 +1766,18 @@ extern "C" int rsx_samsung_v1_decompress(rsx_ctx* ctx, const rsx_samsung_v1_desc
   jobs[0].in_bytes = in_bytes;
   int32_t st = RSX_OK;
   return ljpeg_family_host(ctx, 1, jobs, &in, img, rsx_samsung_v1_plan_create, &st, nullptr);
+}
+
+extern "C" int rsx_samsung_v2_decompress(rsx_ctx* ctx, const rsx_samsung_v2_desc* d,
+                                         const uint8_t* in, size_t in_bytes,
+                                         const rsx_image* img) {
+  if (!ctx || !d || !in || !img || !img->data)
+    return RSX_ERR_INVALID_ARG;
+  std::vector<rsx_samsung_v2_job> jobs(1);
+  jobs[0].desc = *d;
+  jobs[0].in_bytes = in_bytes;
+  int32_t st = RSX_OK;
+  return ljpeg_family_host(ctx, 1, jobs, &in, img, rsx_samsung_v2_plan_create, &st, nullptr);
 }
 
 extern "C" int rsx_sony_arw1_decompress(rsx_ctx* ctx, const uint8_t* in, size_t in_bytes,

@@ -2145,6 +2145,10 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   for (const LjStreamDev& S : p->streams)
     n_fast += S.fast ? 1u : 0u;
   a.guess_slots = n_fast >= 32 ? 2u : 3u;
+#ifdef RSX_EXPERIMENT
+  if (const char* e = getenv("RSX_GUESS_SLOTS"))
+    a.guess_slots = uint32_t(atoi(e));
+#endif
   a.fast_order = static_cast<const uint2*>(p->d_fast_order.ptr);
   a.dbg = static_cast<unsigned long long*>(p->d_dbg.ptr);
   a.pass = 0;

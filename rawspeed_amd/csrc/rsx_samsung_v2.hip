@@ -1,0 +1,650 @@
+// SamsungV2Decompressor on the device (include/rsx.h section 3g).
+//
+// What the reference does (decompressors/SamsungV2Decompressor.cpp): an image row is a
+// bit stream of its own (BitStreamerMSB32) that starts at the 16-byte boundary behind
+// the previous row's last byte (:312-338).  A row is W/16 blocks; a block is a few bits
+// that choose the reference pixels ("motion": the two pixels to the left, or 16 pixels
+// of the two rows above, optionally averaged, :152-230), the lengths of its 16
+// differences in four groups -- coded against a short history per colour (:232-277) --,
+// and the differences (:279-311).  Pixel = clampBits(reference + difference * (2 * scale
+// + 1) + scale).
+//
+// Two things are serial in that: where a row STARTS (only known when the row before it
+// has been parsed), and the pixel values (a block needs the block to its left or the two
+// rows above it).  Neither is serial in the way the reference walks it:
+//
+//   sv2_spec_kernel     one lane per 16-byte boundary of the input: "if a row started
+//                       here, at which boundary would the next one start?"  The parse of a
+//                       row depends on nothing but its bits -- the history is reset at
+//                       every row start (:322-329), the pixel values never enter it --
+//                       and not on the row's parity either: the parity only renames the
+//                       two colour histories a row uses, and both start equal.  (Rows 0
+//                       and 1 start from another history: parsed in the chain kernel.)
+//   sv2_double_kernel   pointer doubling over that table, five times: 32 rows per hop
+//   sv2_chain_kernel    rows 0 and 1, then every 32nd row start by hops
+//   sv2_fill_kernel     the 31 row starts behind each of those
+//   sv2_parse_kernel    one lane per row: the parse proper -- motion, scale, the sixteen
+//                       differences of every block -- and every error the reference
+//                       throws, in the reference's order (none of them depends on pixel
+//                       values)
+//   sv2_status_kernel   the first failing row's status is the job's
+//   sv2_recon_kernel    one workgroup per image: the blocks with the same c + 2 r do not
+//                       depend on each other (a block reads block c - 1 of its row and
+//                       blocks c - 1 .. c + 1 of the two rows above), so the image is
+//                       swept in W/16 + 2 H anti-diagonals; the pixels a diagonal reads
+//                       are the ones the last few diagonals wrote and live in an LDS ring
+//                       (64 KB: 256 rows x the last 8 blocks), differences and block
+//                       headers are loaded four diagonals ahead.
+//
+// All of it is bit-exact against oracle_samsung_v2_decompress (tests/test_gpu_samsung_v2.py),
+// which is pinned against the reference build including damaged streams.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "rsx_internal.h"
+#include "rsx_ljpeg_dev.h"
+#include "rsx_samsung_v2.h"
+
+namespace rsx {
+
+namespace {
+
+constexpr uint32_t SV2_NONE = 0xFFFFFFFFu;
+constexpr int SV2_HOP = 32; // rows per hop of the doubled table
+
+struct Sv2JobDev {
+  uint64_t in_offset;  // the rows' data (behind the 16-byte header), 16-byte aligned
+  uint64_t in_bytes;
+  uint64_t img_offset;
+  uint64_t px_base;    // first difference (int16) of the job
+  uint32_t pitch;
+  uint32_t width, height, bits, optflags, init_val;
+  uint32_t nb;         // blocks per row
+  uint32_t n_bounds;   // 16-byte boundaries of the data: in_bytes / 16 + 1
+  uint32_t bound_base; // first entry of the job in the boundary tables
+  uint32_t row_base;   // first entry in row_start[] / row_status[]
+  uint32_t blk_base;   // first entry in hdr[]
+  uint32_t valid;      // 0: the host rejected the job
+};
+
+struct Sv2Args {
+  const uint8_t* in_base;
+  uint8_t* out_base;
+  const Sv2JobDev* jobs;
+  uint32_t* next;      // [boundary]: boundary at which the following row starts
+  uint32_t* jump_a;    // doubling buffers
+  uint32_t* jump_b;
+  uint32_t* row_start; // [row]: boundary index, SV2_NONE = not reached
+  uint32_t* row_status; // [row]: rsx_status of the row's parse
+  uint32_t* hdr;       // [block]: motion | scale << 16
+  int16_t* diffs;      // [pixel]: the differences in pixel order, unscaled
+  uint32_t* job_status; // [job]: first failing row << 8 | status, SV2_NONE = fine
+  uint32_t n_jobs;
+};
+
+// ---------------------------------------------------------------------------
+// BitStreamerMSB32 over one row (bitstreams/BitStreamerMSB32.h: little-endian 32-bit
+// words, most significant bit first; io/BitStreamer.h:100-132: loads past the end of the
+// input are zero-padded, a load that starts more than 8 bytes past it throws)
+// ---------------------------------------------------------------------------
+struct Sv2Bits {
+  const uint8_t* base; // the row's first byte (16-byte aligned)
+  uint32_t size;       // bytes from there to the end of the data
+  uint32_t limit;      // a getBits may reach this bit offset without an overflow
+  uint32_t q;          // bits consumed
+  uint64_t buf;        // the next `have` bits, left-aligned
+  uint32_t have;
+  uint32_t k;          // next word to push
+  uint32_t ahead;      // word k, loaded early
+  uint32_t err;        // sticky rsx_status (the oracle's bitreader::err)
+};
+
+__device__ __forceinline__ uint32_t sv2_word(const uint8_t* base, uint32_t size, uint32_t k) {
+  const uint32_t off = 4u * k;
+  if (off + 4u <= size)
+    return *reinterpret_cast<const uint32_t*>(base + off);
+  uint32_t v = 0;
+  for (uint32_t b = 0; b < 4u; ++b)
+    if (off + b < size)
+      v |= uint32_t(base[off + b]) << (8u * b);
+  return v;
+}
+
+__device__ __forceinline__ void sv2_bits_init(Sv2Bits& b, const uint8_t* base, uint32_t size) {
+  b.base = base;
+  b.size = size;
+  // fill k loads bytes [4k, 4k + 4) and throws if 4k > size + 8 (BitStreamer.h:125-127)
+  b.limit = 32u * ((size + 8u) / 4u + 1u);
+  b.q = 0;
+  b.buf = 0;
+  b.have = 0;
+  b.k = 0;
+  b.ahead = sv2_word(base, size, 0);
+  b.err = size < 4u ? uint32_t(RSX_ERR_IO) : 0u; // (BitStreamer.h:56-60)
+}
+
+__device__ __forceinline__ uint32_t sv2_get(Sv2Bits& b, uint32_t n) {
+  if (n == 0u)
+    return 0u;
+  if (b.q + n > b.limit && b.err == 0u)
+    b.err = uint32_t(RSX_ERR_INPUT_OVERFLOW);
+  if (b.have < n) {
+    b.buf |= uint64_t(b.ahead) << (32u - b.have);
+    b.have += 32u;
+    ++b.k;
+    b.ahead = sv2_word(b.base, b.size, b.k);
+  }
+  const uint32_t v = uint32_t(b.buf >> (64u - n));
+  b.buf <<= n;
+  b.have -= n;
+  b.q += n;
+  return v;
+}
+
+__device__ __forceinline__ void sv2_skip(Sv2Bits& b, uint32_t n) { // n <= 64
+  while (n > 16u) {
+    (void)sv2_get(b, 16u);
+    n -= 16u;
+  }
+  (void)sv2_get(b, n);
+}
+
+// ---------------------------------------------------------------------------
+// One row.  FULL: the parse proper (block headers, differences, every check of the
+// reference in its order); otherwise only how many bytes the row takes.
+// Returns an rsx_status; *used = getStreamPosition() of the row's bit pump.
+// ---------------------------------------------------------------------------
+template <bool FULL>
+__device__ __forceinline__ uint32_t sv2_row(const Sv2JobDev& J, const uint8_t* row_base,
+                                            uint32_t size, int row, int first_mode,
+                                            uint32_t* hdr, int16_t* diffs, uint32_t* used) {
+  Sv2Bits b;
+  sv2_bits_init(b, row_base, size);
+  if (b.err)
+    return b.err;
+  int motion = 7, scale = 0;
+  // diffBitsMode: a row uses two of the three colour histories (groups 0-1 one, groups
+  // 2-3 the other, :246-247) and all of them start equal: two histories, by group pair
+  int mode[2][2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+    mode[c][0] = mode[c][1] = first_mode;
+  const bool qp = (J.optflags & 4u) != 0, mv = (J.optflags & 2u) != 0, skip = (J.optflags & 1u) != 0;
+  const int width = int(J.width);
+  for (uint32_t blk = 0; blk < J.nb; ++blk) {
+    const int col = int(blk) * 16;
+    // prepareBaselineValues :152-230 (the bits it reads and its checks)
+    if (!qp && (blk & 3u) == 0u) {
+      const uint32_t i = sv2_get(b, 2);
+      if (i < 3u)
+        scale += i == 1u ? -2 : (i == 2u ? 2 : 0);
+      else
+        scale = int(sv2_get(b, 12));
+    }
+    if (mv)
+      motion = sv2_get(b, 1) ? 3 : 7;
+    else if (!sv2_get(b, 1))
+      motion = int(sv2_get(b, 3));
+    if (b.err)
+      return b.err;
+    if (FULL) {
+      if (row < 2 && motion != 7)
+        return uint32_t(RSX_ERR_INVALID_ARG); // :172-173
+      if (motion != 7) {
+        const int slide = motion == 0 ? -4 : (motion <= 2 ? -2 : (motion <= 4 ? 0 : (motion == 5 ? 2 : 4)));
+        const bool avg = motion == 2 || motion == 4;
+        for (int i = 0; i < 16; ++i) { // :202-227
+          int ref_col = col + i + slide;
+          if (!((row + i) & 1))
+            ref_col += (i & 1) ? -1 : 1;
+          if (ref_col < 0 || ref_col >= width || (avg && ref_col + 2 >= width))
+            return uint32_t(RSX_ERR_INVALID_ARG);
+        }
+      }
+    }
+    // decodeDiffLengths :232-277
+    uint32_t len[4] = {0, 0, 0, 0};
+    if (skip || !sv2_get(b, 1)) {
+      uint32_t flags[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        flags[i] = sv2_get(b, 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int* m = mode[i >> 1];
+        uint32_t v;
+        if (flags[i] == 0u) {
+          v = uint32_t(m[0]);
+        } else if (flags[i] == 1u) {
+          v = uint32_t(m[0]) + 1u;
+        } else if (flags[i] == 2u) {
+          if (m[0] == 0)
+            return uint32_t(RSX_ERR_INVALID_ARG); // :258-259
+          v = uint32_t(m[0]) - 1u;
+        } else {
+          v = sv2_get(b, 4);
+        }
+        m[0] = m[1];
+        m[1] = int(v);
+        if (v > J.bits + 1u)
+          return uint32_t(RSX_ERR_INVALID_ARG); // :271-272
+        len[i] = v;
+      }
+    }
+    if (b.err)
+      return b.err;
+    // decodeDifferences :279-311
+    if (FULL) {
+      int16_t* o = diffs + size_t(blk) * 16;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const uint32_t l = len[i >> 2];
+        int v = 0;
+        if (l) {
+          const uint32_t u = sv2_get(b, l);
+          v = int(u << (32u - l)) >> (32u - l);
+        }
+        const int p = (row & 1) ? ((i & 7) << 1) - (i >> 3) + 1 : ((i & 7) << 1) + (i >> 3);
+        o[p] = int16_t(v);
+      }
+      hdr[blk] = uint32_t(motion) | (uint32_t(uint16_t(int16_t(scale))) << 16);
+    } else {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        sv2_skip(b, 4u * len[g]);
+    }
+    if (b.err)
+      return b.err;
+  }
+  *used = (b.q + 7u) >> 3; // getStreamPosition(): whole bytes the pump has taken
+  return 0u;
+}
+
+// "a row that starts at boundary i ends where?" -> the boundary the next row starts at,
+// SV2_NONE if such a row would throw (then the reference stops there as well)
+__device__ __forceinline__ uint32_t sv2_next_boundary(const Sv2JobDev& J, const uint8_t* data,
+                                                      uint32_t i, int row, int first_mode) {
+  const uint64_t a = uint64_t(i) * 16u;
+  if (a > J.in_bytes)
+    return SV2_NONE;
+  uint32_t used = 0;
+  const uint32_t st = sv2_row<false>(J, data + a, uint32_t(J.in_bytes - a), row, first_mode,
+                                     nullptr, nullptr, &used);
+  if (st != 0u || a + used > J.in_bytes)
+    return SV2_NONE;
+  return uint32_t((a + used + 15u) >> 4);
+}
+
+__global__ __launch_bounds__(256) void sv2_spec_kernel(Sv2Args A) {
+  const Sv2JobDev& J = A.jobs[blockIdx.y];
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (!J.valid || i >= J.n_bounds)
+    return;
+  // (row 2: any row but the first two -- the parity does not matter for the lengths)
+  A.next[J.bound_base + i] = sv2_next_boundary(J, A.in_base + J.in_offset, i, 2, 4);
+}
+
+__global__ __launch_bounds__(256) void sv2_double_kernel(Sv2Args A, const uint32_t* from,
+                                                         uint32_t* to) {
+  const Sv2JobDev& J = A.jobs[blockIdx.y];
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (!J.valid || i >= J.n_bounds)
+    return;
+  const uint32_t x = from[J.bound_base + i];
+  to[J.bound_base + i] = (x == SV2_NONE || x >= J.n_bounds) ? SV2_NONE : from[J.bound_base + x];
+}
+
+// rows 0 and 1 (their histories start at 7, :325-326), then every SV2_HOP-th row
+__global__ void sv2_chain_kernel(Sv2Args A, const uint32_t* hop) {
+  const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+  if (job >= A.n_jobs)
+    return;
+  const Sv2JobDev& J = A.jobs[job];
+  if (!J.valid)
+    return;
+  uint32_t* rs = A.row_start + J.row_base;
+  const uint8_t* data = A.in_base + J.in_offset;
+  uint32_t x = 0;
+  for (uint32_t r = 0; r < 2u && r < J.height; ++r) {
+    rs[r] = x;
+    if (x != SV2_NONE)
+      x = sv2_next_boundary(J, data, x, int(r), 7);
+  }
+  for (uint32_t r = 2; r < J.height; r += uint32_t(SV2_HOP)) {
+    rs[r] = x;
+    if (x != SV2_NONE)
+      x = x < J.n_bounds ? hop[J.bound_base + x] : SV2_NONE;
+  }
+}
+
+__global__ __launch_bounds__(256) void sv2_fill_kernel(Sv2Args A) {
+  const Sv2JobDev& J = A.jobs[blockIdx.y];
+  const uint32_t seg = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t r0 = 2u + seg * uint32_t(SV2_HOP);
+  if (!J.valid || r0 >= J.height)
+    return;
+  uint32_t* rs = A.row_start + J.row_base;
+  uint32_t x = rs[r0];
+  for (uint32_t r = r0 + 1; r < r0 + uint32_t(SV2_HOP) && r < J.height; ++r) {
+    if (x != SV2_NONE)
+      x = x < J.n_bounds ? A.next[J.bound_base + x] : SV2_NONE;
+    rs[r] = x;
+  }
+}
+
+__global__ __launch_bounds__(64) void sv2_parse_kernel(Sv2Args A) {
+  const Sv2JobDev& J = A.jobs[blockIdx.y];
+  const uint32_t row = blockIdx.x * 64u + threadIdx.x;
+  if (!J.valid || row >= J.height)
+    return;
+  uint32_t st = 0;
+  const uint32_t x = A.row_start[J.row_base + row];
+  if (x == SV2_NONE) {
+    st = SV2_NONE; // not reached: an earlier row has failed
+  } else {
+    const uint64_t a = uint64_t(x) * 16u;
+    if (a > J.in_bytes) {
+      st = uint32_t(RSX_ERR_IO); // data.skipBytes() to the boundary, :314-316
+    } else {
+      uint32_t used = 0;
+      st = sv2_row<true>(J, A.in_base + J.in_offset + a, uint32_t(J.in_bytes - a), int(row),
+                         row < 2u ? 7 : 4, A.hdr + J.blk_base + size_t(row) * J.nb,
+                         A.diffs + J.px_base + size_t(row) * J.width, &used);
+      if (st == 0u && a + used > J.in_bytes)
+        st = uint32_t(RSX_ERR_IO); // data.skipBytes(pump.getStreamPosition()), :337
+      // (the table of row starts comes from the same parse: a row that is fine here has a
+      // successor there)
+      if (st == 0u && row + 1u < J.height && A.row_start[J.row_base + row + 1u] == SV2_NONE)
+        st = uint32_t(RSX_ERR_DEVICE);
+    }
+  }
+  A.row_status[J.row_base + row] = st;
+  if (st != 0u && st != SV2_NONE)
+    atomicMin(&A.job_status[blockIdx.y], (row << 8) | (st & 0xFFu));
+}
+
+// ---------------------------------------------------------------------------
+// Reconstruction: anti-diagonals t = c + 2 r
+// ---------------------------------------------------------------------------
+constexpr int SV2_RT = 1024;                 // lanes: 64 blocks of 16 pixels at a time
+constexpr int SV2_RING_ROWS = 256, SV2_RING_BLKS = 8;
+constexpr int SV2_AHEAD = 4;                 // diagonals the loads run ahead
+constexpr int SV2_ITERS = 4;                 // block slots per lane and diagonal (<= 256 blocks)
+
+__device__ __forceinline__ uint32_t sv2_ring_addr(int row, int col) {
+  return uint32_t(((row & (SV2_RING_ROWS - 1)) * SV2_RING_BLKS + ((col >> 4) & (SV2_RING_BLKS - 1))) * 16 +
+                  (col & 15));
+}
+
+struct Sv2Fetch {
+  uint32_t hdr;
+  int diff;
+};
+
+// what lane (slot, px) needs on diagonal t, iteration it
+__device__ __forceinline__ bool sv2_diag_block(const Sv2JobDev& J, int t, int slot, int* r, int* c) {
+  const int nb = int(J.nb), H = int(J.height);
+  int r_lo = (t - (nb - 1) + 1) >> 1; // ceil((t - nb + 1) / 2)
+  if (r_lo < 0)
+    r_lo = 0;
+  const int rr = r_lo + slot;
+  const int cc = t - 2 * rr;
+  *r = rr;
+  *c = cc;
+  return rr < H && cc >= 0 && cc < nb;
+}
+
+__global__ __launch_bounds__(SV2_RT) void sv2_recon_kernel(Sv2Args A) {
+  __shared__ uint16_t ring[SV2_RING_ROWS * SV2_RING_BLKS * 16];
+  const Sv2JobDev& J = A.jobs[blockIdx.x];
+  if (!J.valid)
+    return;
+  // (a vector load: the word was written by the kernel before this one)
+  if (__hip_atomic_load(&A.job_status[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+      SV2_NONE)
+    return; // the reference throws somewhere: nothing of the image is promised
+  const int tid = threadIdx.x, px = tid & 15, slot0 = tid >> 4;
+  const int nb = int(J.nb), H = int(J.height);
+  const int T = nb + 2 * (H - 1);
+  const uint32_t* hdr = A.hdr + J.blk_base;
+  const int16_t* diffs = A.diffs + J.px_base;
+  uint8_t* out = A.out_base + J.img_offset;
+  const int hi = (1 << J.bits) - 1;
+  const int init = int(J.init_val);
+  const int W = int(J.width);
+  // blocks on a diagonal: at most min(H, (nb + 1) / 2) <= 204 (W <= 6496): 4 slots a lane
+  Sv2Fetch f[SV2_AHEAD][SV2_ITERS];
+  auto fetch = [&](int t, Sv2Fetch(&dst)[SV2_ITERS]) {
+#pragma unroll
+    for (int it = 0; it < SV2_ITERS; ++it) {
+      int r, c;
+      dst[it].hdr = 0;
+      dst[it].diff = 0;
+      if (t < T && sv2_diag_block(J, t, slot0 + 64 * it, &r, &c)) {
+        dst[it].hdr = hdr[size_t(r) * nb + c];
+        dst[it].diff = diffs[size_t(r) * W + c * 16 + px];
+      }
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < SV2_AHEAD; ++k)
+    fetch(k, f[k]);
+  for (int t0 = 0; t0 < T; t0 += SV2_AHEAD) {
+#pragma unroll
+    for (int k = 0; k < SV2_AHEAD; ++k) {
+      const int t = t0 + k;
+      if (t < T) {
+#pragma unroll
+        for (int it = 0; it < SV2_ITERS; ++it) {
+          int r, c;
+          if (!sv2_diag_block(J, t, slot0 + 64 * it, &r, &c))
+            continue;
+          const uint32_t h = f[k][it].hdr;
+          const int motion = int(h & 7u), scale = int(int16_t(h >> 16));
+          const int col = c * 16;
+          int base;
+          if (motion == 7) { // :175-188
+            base = c == 0 ? init : int(ring[sv2_ring_addr(r, col + (px & 1) - 2)]);
+          } else { // :194-227
+            const int slide =
+                motion == 0 ? -4 : (motion <= 2 ? -2 : (motion <= 4 ? 0 : (motion == 5 ? 2 : 4)));
+            const bool avg = motion == 2 || motion == 4;
+            int ref_row = r, ref_col = col + px + slide;
+            if ((r + px) & 1) {
+              ref_row -= 2;
+            } else {
+              ref_row -= 1;
+              ref_col += (px & 1) ? -1 : 1;
+            }
+            base = int(ring[sv2_ring_addr(ref_row, ref_col)]);
+            if (avg)
+              base = (base + int(ring[sv2_ring_addr(ref_row, ref_col + 2)]) + 1) >> 1;
+          }
+          int v = base + f[k][it].diff * (scale * 2 + 1) + scale;
+          v = v < 0 ? 0 : (v > hi ? hi : v);
+          ring[sv2_ring_addr(r, col + px)] = uint16_t(v);
+          *reinterpret_cast<uint16_t*>(out + size_t(r) * J.pitch + size_t(col + px) * 2) = uint16_t(v);
+        }
+      }
+      fetch(t + SV2_AHEAD, f[k]);
+      __syncthreads();
+    }
+  }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// Host side
+// ---------------------------------------------------------------------------
+struct Sv2Plan {
+  rsx_ctx* ctx = nullptr;
+  std::vector<Sv2JobDev> jobs;
+  std::vector<int32_t> host_status; // validation result per job
+  DeviceBuffer d_jobs, d_next, d_ja, d_jb, d_row_start, d_row_status, d_hdr, d_diffs, d_status;
+  std::vector<uint32_t> h_status;
+  uint32_t max_bounds = 0, max_rows = 0;
+};
+
+int samsung_v2_validate(const rsx_samsung_v2_desc& d, const rsx_image& img) {
+  // the constructor, SamsungV2Decompressor.cpp:87-141
+  if (img.cpp != 1)
+    return RSX_ERR_INVALID_ARG;
+  if (d.bit_depth != 12 && d.bit_depth != 14)
+    return RSX_ERR_INVALID_ARG;
+  if (d.optflags > 7u)
+    return RSX_ERR_INVALID_ARG;
+  if (d.width <= 0 || d.height <= 0 || d.width % 16 != 0 || d.width > 6496 || d.height > 4336)
+    return RSX_ERR_INVALID_ARG;
+  if (d.width != img.dim_x || d.height != img.dim_y)
+    return RSX_ERR_INVALID_ARG;
+  if (img.pitch_bytes < uint32_t(d.width) * 2u)
+    return RSX_ERR_INVALID_ARG;
+  return RSX_OK;
+}
+
+int samsung_v2_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_samsung_v2_job* jobs,
+                           Sv2Plan** out) {
+  auto p = std::make_unique<Sv2Plan>();
+  p->ctx = ctx;
+  p->host_status.assign(n_jobs, RSX_OK);
+  p->jobs.resize(n_jobs);
+  uint64_t bounds = 0, rows = 0, blocks = 0, px = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const rsx_samsung_v2_job& j = jobs[i];
+    Sv2JobDev& J = p->jobs[i];
+    std::memset(&J, 0, sizeof J);
+    int st = samsung_v2_validate(j.desc, j.img);
+    // (row starts are 16-byte boundaries of the data and the kernels load whole words)
+    if (st == RSX_OK && (j.in_offset % 16 != 0 || j.img_offset % 2 != 0 || j.img.pitch_bytes % 2 != 0))
+      st = RSX_ERR_INVALID_ARG;
+    if (st == RSX_OK && j.in_bytes >= (1ull << 32) - 64)
+      st = RSX_ERR_UNSUPPORTED;
+    p->host_status[i] = st;
+    if (st != RSX_OK)
+      continue;
+    J.valid = 1;
+    J.in_offset = j.in_offset;
+    J.in_bytes = j.in_bytes;
+    J.img_offset = j.img_offset;
+    J.pitch = j.img.pitch_bytes;
+    J.width = uint32_t(j.desc.width);
+    J.height = uint32_t(j.desc.height);
+    J.bits = uint32_t(j.desc.bit_depth);
+    J.optflags = j.desc.optflags;
+    J.init_val = j.desc.init_val & 0x3FFFu;
+    J.nb = J.width / 16u;
+    J.n_bounds = uint32_t(j.in_bytes / 16u) + 1u;
+    J.bound_base = uint32_t(bounds);
+    J.row_base = uint32_t(rows);
+    J.blk_base = uint32_t(blocks);
+    J.px_base = px;
+    bounds += J.n_bounds;
+    rows += J.height;
+    blocks += uint64_t(J.height) * J.nb;
+    px += uint64_t(J.height) * J.width;
+    p->max_bounds = std::max(p->max_bounds, J.n_bounds);
+    p->max_rows = std::max(p->max_rows, J.height);
+    if (bounds >= (1ull << 32) || blocks >= (1ull << 32))
+      return RSX_ERR_UNSUPPORTED;
+  }
+  RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int st;
+  if ((st = p->d_jobs.ensure(p->jobs.size() * sizeof(Sv2JobDev))) ||
+      (st = p->d_next.ensure(bounds * 4 + 16)) || (st = p->d_ja.ensure(bounds * 4 + 16)) ||
+      (st = p->d_jb.ensure(bounds * 4 + 16)) || (st = p->d_row_start.ensure(rows * 4 + 16)) ||
+      (st = p->d_row_status.ensure(rows * 4 + 16)) || (st = p->d_hdr.ensure(blocks * 4 + 16)) ||
+      (st = p->d_diffs.ensure(px * 2 + 16)) || (st = p->d_status.ensure(size_t(n_jobs) * 4 + 16)))
+    return st;
+  RSX_HIP_CHECK(ctx, hipMemcpy(p->d_jobs.ptr, p->jobs.data(), p->jobs.size() * sizeof(Sv2JobDev),
+                               hipMemcpyHostToDevice));
+  p->h_status.assign(n_jobs, SV2_NONE);
+  *out = p.release();
+  return RSX_OK;
+}
+
+void samsung_v2_plan_destroy(Sv2Plan* p) {
+  if (!p)
+    return;
+  for (DeviceBuffer* b : {&p->d_jobs, &p->d_next, &p->d_ja, &p->d_jb, &p->d_row_start,
+                          &p->d_row_status, &p->d_hdr, &p->d_diffs, &p->d_status})
+    b->release();
+  delete p;
+}
+
+int samsung_v2_plan_run(Sv2Plan* p, const void* in_dev, void* out_dev, hipStream_t s,
+                        KernelTimer* timer) {
+  rsx_ctx* ctx = p->ctx;
+  const uint32_t n = uint32_t(p->jobs.size());
+  if (p->max_rows == 0)
+    return RSX_OK; // (every job was rejected by the host)
+  if (timer)
+    timer->begin(s);
+  Sv2Args A{};
+  A.in_base = static_cast<const uint8_t*>(in_dev);
+  A.out_base = static_cast<uint8_t*>(out_dev);
+  A.jobs = static_cast<const Sv2JobDev*>(p->d_jobs.ptr);
+  A.next = static_cast<uint32_t*>(p->d_next.ptr);
+  A.jump_a = static_cast<uint32_t*>(p->d_ja.ptr);
+  A.jump_b = static_cast<uint32_t*>(p->d_jb.ptr);
+  A.row_start = static_cast<uint32_t*>(p->d_row_start.ptr);
+  A.row_status = static_cast<uint32_t*>(p->d_row_status.ptr);
+  A.hdr = static_cast<uint32_t*>(p->d_hdr.ptr);
+  A.diffs = static_cast<int16_t*>(p->d_diffs.ptr);
+  A.job_status = static_cast<uint32_t*>(p->d_status.ptr);
+  A.n_jobs = n;
+  auto mark = [&](const char* name) {
+    if (timer)
+      timer->mark(name);
+  };
+  RSX_HIP_CHECK(ctx, hipMemsetAsync(p->d_status.ptr, 0xFF, size_t(n) * 4, s));
+  const dim3 gb((p->max_bounds + 255) / 256, n);
+  hipLaunchKernelGGL(sv2_spec_kernel, gb, dim3(256), 0, s, A);
+  mark("sv2_spec_kernel");
+  // 2, 4, 8, 16, 32 rows per hop
+  const uint32_t* from = A.next;
+  uint32_t* to = A.jump_a;
+  for (int k = 0; k < 5; ++k) {
+    hipLaunchKernelGGL(sv2_double_kernel, gb, dim3(256), 0, s, A, from, to);
+    from = to;
+    to = to == A.jump_a ? A.jump_b : A.jump_a;
+  }
+  mark("sv2_double_kernel");
+  hipLaunchKernelGGL(sv2_chain_kernel, dim3((n + 63) / 64), dim3(64), 0, s, A, from);
+  mark("sv2_chain_kernel");
+  const uint32_t segs = (p->max_rows + SV2_HOP - 1) / SV2_HOP;
+  hipLaunchKernelGGL(sv2_fill_kernel, dim3((segs + 255) / 256, n), dim3(256), 0, s, A);
+  mark("sv2_fill_kernel");
+  hipLaunchKernelGGL(sv2_parse_kernel, dim3((p->max_rows + 63) / 64, n), dim3(64), 0, s, A);
+  mark("sv2_parse_kernel");
+  hipLaunchKernelGGL(sv2_recon_kernel, dim3(n), dim3(SV2_RT), 0, s, A);
+  mark("sv2_recon_kernel");
+  RSX_HIP_CHECK(ctx, hipGetLastError());
+  return RSX_OK;
+}
+
+int samsung_v2_plan_results(Sv2Plan* p, hipStream_t s, bool ran, int32_t* job_status) {
+  rsx_ctx* ctx = p->ctx;
+  if (ran && p->max_rows != 0) {
+    RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->h_status.data(), p->d_status.ptr, p->h_status.size() * 4,
+                                      hipMemcpyDeviceToHost, s));
+    RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  }
+  int rc = RSX_OK;
+  for (size_t i = 0; i < p->jobs.size(); ++i) {
+    int st = p->host_status[i];
+    if (st == RSX_OK && ran && p->h_status[i] != SV2_NONE)
+      st = int(int8_t(p->h_status[i] & 0xFFu));
+    if (job_status)
+      job_status[i] = st;
+    if (st != RSX_OK)
+      rc = st;
+  }
+  return rc;
+}
+
+} // namespace rsx
