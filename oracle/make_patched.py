@@ -228,6 +228,22 @@ HUNK_SAMSUNG_V1 = r'''
   }
 '''
 
+HUNK_SAMSUNG_V2 = r'''
+  // ---- rsx: forward to the MI355X core (INTEGRATION.md 3g) ----
+  if (rsx_ctx* rsx = rsx_shim::context()) {
+    rsx_samsung_v2_desc d{};
+    d.bit_depth = implicit_cast<int32_t>(bitDepth);
+    d.width = width;
+    d.height = height;
+    d.optflags = static_cast<uint32_t>(optflags);
+    d.init_val = initVal;
+    const rsx_image img = rsx_shim::view(mRaw);
+    const Buffer in = data.peekRemainingBuffer();
+    if (rsx_shim::done(rsx_samsung_v2_decompress(rsx, &d, in.begin(), in.getSize(), &img)))
+      return;
+  }
+'''
+
 HUNK_SRAW = r'''
   // ---- rsx: forward to the MI355X core (INTEGRATION.md 3a) ----
   if (rsx_ctx* rsx = rsx_shim::context()) {
@@ -325,6 +341,8 @@ PATCHES = [
         ("void PentaxDecompressor::decompress(ByteStream data) const {", HUNK_PENTAX)]),
     ("decompressors/SamsungV1Decompressor.cpp", [
         ("void SamsungV1Decompressor::decompress() const {", HUNK_SAMSUNG_V1)]),
+    ("decompressors/SamsungV2Decompressor.cpp", [
+        ("void SamsungV2Decompressor::decompress() {", HUNK_SAMSUNG_V2)]),
     ("interpolators/Cr2sRawInterpolator.cpp", [
         ("void Cr2sRawInterpolator::interpolate(int version) {", HUNK_SRAW)]),
     ("decompressors/HasselbladDecompressor.cpp", [

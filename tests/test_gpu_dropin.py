@@ -299,6 +299,32 @@ def test_samsung_v1_decompressor(pair):
             assert np.array_equal(a, b)
 
 
+def test_samsung_v2_decompressor(pair):
+    """SamsungV2Decompressor::decompress() through the patched class: streams of every
+    optimisation-flag combination (forwarded, same image) and damaged ones (the original
+    body takes over: same exception)."""
+    import samsung_v2_cases as V2
+    from test_oracle_samsung_v2 import _target
+    if not hasattr(pair[0].lib, "ref_samsung_v2_decompress"):
+        pytest.skip("oracle/_ref predates the SamsungV2 entry point")
+    rng = np.random.default_rng(77)
+    for k in range(10):
+        bits = (12, 14)[k & 1]
+        h, w = int(rng.integers(4, 60)), 16 * int(rng.integers(2, 24))
+        data, want = V2.encode(rng, _target(rng, h, w, bits), bits, k % 8)
+        if k >= 8:
+            data = data[:16 + (data.size - 16) // 2]
+        (s0, a, e0), (s1, b, e1) = both(
+            pair, lambda lib, img: lib.samsung_v2(bits, data, img), (w, h, 1),
+            fwd=1 if k < 8 else 0, fell=0 if k < 8 else 1)
+        assert s0 == s1, (e0, e1)
+        assert (s0 == 0) == (k < 8)
+        if s0 == 0:
+            assert np.array_equal(a, b) and np.array_equal(a, want)
+        else:
+            assert e0 == e1
+
+
 def test_sraw_interpolator(pair):
     """Cr2sRawInterpolator::interpolate through the patched class."""
     import golden_cases as G

@@ -40,7 +40,7 @@ EXPECT = {
     "srw_samsung_v1": (1, 1),
     "cr2_sraw_2x1": (2, None),   # the scan, then Cr2sRawInterpolator
     "cr2_sraw_2x2": (2, None),
-    "srw_samsung_v2": (0, 0),    # not forwarded: the reference's own code in both builds
+    "srw_samsung_v2": (1, 1),
 }
 
 
