@@ -717,6 +717,90 @@ def run_sony_arw1(ctx, torch, log, frames=8, steps=10, warmup=2, cpu=True):
     return out
 
 
+def make_samsung_v2_frame(W, H, bits=14, seed=21, band=34):
+    """A WxH SamsungV2 stream (header + rows).  The Python writer (tests/samsung_v2_cases.py)
+    does 0.1 MPix/s, so `band` rows are written for a sensor-like target and the rows
+    behind the first two are repeated down the frame: every row of such a stream is a valid
+    row at any position of its parity (the first two rows are special, :172-173, :325-326),
+    the decoders reconstruct SOME image from it -- the same one, which is what is checked."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import samsung_v2_cases as V2
+    from rawspeed_amd import synth
+    rng = np.random.default_rng(seed)
+    band += band & 1
+    target = (synth.sensor_image(W, band, 14, seed=seed) >> (14 - bits)).astype(np.int64)
+    rows = []
+    data, _ = V2.encode(rng, target, bits, 0, rows_out=rows)
+    # the header with the frame's height: the writer's, re-written
+    head = bytearray(data[:16].tobytes())
+    bits_s = "".join(format(int.from_bytes(head[4 * k:4 * k + 4], "little"), "032b") for k in range(4))
+    bits_s = bits_s[:48] + format(H, "016b") + bits_s[64:]
+    head = b"".join(int(bits_s[32 * k:32 * k + 32], 2).to_bytes(4, "little") for k in range(4))
+    out = [np.frombuffer(head, np.uint8)] + rows[:2]
+    k = 2
+    for r in range(2, H):
+        out.append(rows[k])
+        k = k + 1 if k + 1 < band else 2
+    return np.concatenate(out + [np.zeros(16, np.uint8)])
+
+
+def run_samsung_v2(ctx, torch, log, frames=4, steps=5, warmup=1, cpu=True):
+    """SamsungV2Decompressor: an NX1-sized 6480x4320 14-bit frame."""
+    from rawspeed_amd import abi
+    W, H, bits = 6480, 4320, 14
+    data = make_samsung_v2_frame(W, H, bits)
+    d, _ = abi.SamsungV2Desc.from_header(data[:16])
+    payload = data[16:]
+    payload = np.concatenate([payload, np.zeros((-payload.size) % 16, np.uint8)])
+    jobs = []
+    for f in range(frames):
+        j = abi.SamsungV2Job()
+        j.desc = d
+        j.in_offset, j.in_bytes = f * payload.size, data.size - 16
+        j.img_offset = f * out_pitch(W) * H
+        j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
+            out_pitch(W), W, H, 1, 1
+        jobs.append(j)
+    inp = torch.from_numpy(np.tile(payload, frames)).cuda()
+    outb = torch.zeros(frames * out_pitch(W) * H, dtype=torch.uint8, device="cuda")
+    plan = ctx.samsung_v2_plan(jobs)
+    dt, kt, _ = _time_plan(torch, plan, inp, outb, steps, warmup)
+    ktab = dict(LAST_KERNEL_TABLE or {})
+    plan.close()
+    out = {"workload": "SamsungV2Decompressor %dx%d %d-bit, %d frames/step" % (W, H, bits, frames),
+           "mpix_per_s": round(frames * W * H / dt / 1e6, 1),
+           "ms_per_step": round(dt * 1e3, 4),
+           "compressed_bits_per_px": round(data.size * 8 / (W * H), 3),
+           "kernels_ms": ktab}
+    if cpu:
+        try:
+            from oracle_lib import Ref
+            if Ref.available():
+                ref = Ref()
+                img = ref.image(W, H, 1)
+                assert ref.samsung_v2(bits, data, img) == 0
+                want = img.pixels().copy()
+                exact = True
+                for f in (0, frames - 1):
+                    exact = exact and bool(np.array_equal(gpu_frame(outb, f, W, H), want))
+                out["bit_exact"] = exact
+                out["checked_against"] = "the reference build's output"
+                times = []
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    ref.samsung_v2(bits, data, img)
+                    times.append(time.perf_counter() - t0)
+                out["cpu_baseline"] = {
+                    "value": round(W * H / min(times) / 1e6, 1), "unit": "MPix/s", "cores": 1,
+                    "kind": "reference",
+                    "sample": "SamsungV2Decompressor::decompress of the unmodified reference on "
+                              "the same stream, 1 thread, best of 2"}
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
 def run_variants(ctx, torch, log, frames=8, steps=50, warmup=20):
     """The fixed-layout UncompressedDecompressor entry points at the
     cfg2 sensor size: decode12BitRawWithControl<big>, decode12BitRawUnpacked-
@@ -864,6 +948,7 @@ def run(ctx, torch, log):
     leg("nikon_lossless14_6016x4016", lambda: run_nikon(ctx, torch, log))
     leg("hasselblad_8272x6200", lambda: run_hasselblad(ctx, torch, log))
     leg("sony_arw1_3881x2608", lambda: run_sony_arw1(ctx, torch, log))
+    leg("samsung_v2_6480x4320", lambda: run_samsung_v2(ctx, torch, log))
     leg("cr2_sraw1_3960x2640", lambda: run_sraw(ctx, torch, log))
     leg("host_path", lambda: run_host_path(torch, log))
     return out
@@ -895,6 +980,8 @@ if __name__ == "__main__":
                          indent=1))
     elif args.only == "sony":
         print(json.dumps(run_sony_arw1(ctx, torch, print, steps=args.steps), indent=1))
+    elif args.only == "samsung_v2":
+        print(json.dumps(run_samsung_v2(ctx, torch, print, steps=args.steps), indent=1))
     elif args.only == "hasselblad":
         print(json.dumps(run_hasselblad(ctx, torch, print, steps=args.steps), indent=1))
     elif args.only == "sraw":

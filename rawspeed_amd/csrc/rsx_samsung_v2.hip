@@ -26,8 +26,7 @@
 //   sv2_parse_kernel    one lane per row: the parse proper -- motion, scale, the sixteen
 //                       differences of every block -- and every error the reference
 //                       throws, in the reference's order (none of them depends on pixel
-//                       values)
-//   sv2_status_kernel   the first failing row's status is the job's
+//                       values); the first failing row's status is the job's
 //   sv2_recon_kernel    one workgroup per image: the blocks with the same c + 2 r do not
 //                       depend on each other (a block reads block c - 1 of its row and
 //                       blocks c - 1 .. c + 1 of the two rows above), so the image is
@@ -173,9 +172,12 @@ __device__ __forceinline__ uint32_t sv2_row(const Sv2JobDev& J, const uint8_t* r
 #pragma unroll
   for (int c = 0; c < 2; ++c)
     mode[c][0] = mode[c][1] = first_mode;
-  const bool qp = (J.optflags & 4u) != 0, mv = (J.optflags & 2u) != 0, skip = (J.optflags & 1u) != 0;
+  // (the job's fields in registers: read through the reference they are loaded again
+  // behind every store, each time behind a wait for everything in flight)
+  const uint32_t optflags = J.optflags, nb = J.nb, max_len = J.bits + 1u;
+  const bool qp = (optflags & 4u) != 0, mv = (optflags & 2u) != 0, skip = (optflags & 1u) != 0;
   const int width = int(J.width);
-  for (uint32_t blk = 0; blk < J.nb; ++blk) {
+  for (uint32_t blk = 0; blk < nb; ++blk) {
     const int col = int(blk) * 16;
     // prepareBaselineValues :152-230 (the bits it reads and its checks)
     if (!qp && (blk & 3u) == 0u) {
@@ -230,7 +232,7 @@ __device__ __forceinline__ uint32_t sv2_row(const Sv2JobDev& J, const uint8_t* r
         }
         m[0] = m[1];
         m[1] = int(v);
-        if (v > J.bits + 1u)
+        if (v > max_len)
           return uint32_t(RSX_ERR_INVALID_ARG); // :271-272
         len[i] = v;
       }
@@ -239,7 +241,7 @@ __device__ __forceinline__ uint32_t sv2_row(const Sv2JobDev& J, const uint8_t* r
       return b.err;
     // decodeDifferences :279-311
     if (FULL) {
-      int16_t* o = diffs + size_t(blk) * 16;
+      uint32_t dv[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const uint32_t l = len[i >> 2];
@@ -248,9 +250,17 @@ __device__ __forceinline__ uint32_t sv2_row(const Sv2JobDev& J, const uint8_t* r
           const uint32_t u = sv2_get(b, l);
           v = int(u << (32u - l)) >> (32u - l);
         }
-        const int p = (row & 1) ? ((i & 7) << 1) - (i >> 3) + 1 : ((i & 7) << 1) + (i >> 3);
-        o[p] = int16_t(v);
+        dv[i] = uint32_t(v) & 0xFFFFu;
       }
+      // the shuffle of :293-304: pixels 2k, 2k + 1 are differences k and 8 + k of the
+      // stream, in this order on even rows and the other way round on odd ones
+      uint32_t pk[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        pk[k] = (row & 1) ? (dv[8 + k] | (dv[k] << 16)) : (dv[k] | (dv[8 + k] << 16));
+      uint4* o = reinterpret_cast<uint4*>(diffs + size_t(blk) * 16);
+      o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
       hdr[blk] = uint32_t(motion) | (uint32_t(uint16_t(int16_t(scale))) << 16);
     } else {
 #pragma unroll
@@ -308,16 +318,18 @@ __global__ void sv2_chain_kernel(Sv2Args A, const uint32_t* hop) {
     return;
   uint32_t* rs = A.row_start + J.row_base;
   const uint8_t* data = A.in_base + J.in_offset;
+  const uint32_t height = J.height, n_bounds = J.n_bounds;
+  const uint32_t* hop_j = hop + J.bound_base;
   uint32_t x = 0;
-  for (uint32_t r = 0; r < 2u && r < J.height; ++r) {
+  for (uint32_t r = 0; r < 2u && r < height; ++r) {
     rs[r] = x;
     if (x != SV2_NONE)
       x = sv2_next_boundary(J, data, x, int(r), 7);
   }
-  for (uint32_t r = 2; r < J.height; r += uint32_t(SV2_HOP)) {
+  for (uint32_t r = 2; r < height; r += uint32_t(SV2_HOP)) {
     rs[r] = x;
     if (x != SV2_NONE)
-      x = x < J.n_bounds ? hop[J.bound_base + x] : SV2_NONE;
+      x = x < n_bounds ? hop_j[x] : SV2_NONE;
   }
 }
 
@@ -328,10 +340,12 @@ __global__ __launch_bounds__(256) void sv2_fill_kernel(Sv2Args A) {
   if (!J.valid || r0 >= J.height)
     return;
   uint32_t* rs = A.row_start + J.row_base;
+  const uint32_t height = J.height, n_bounds = J.n_bounds;
+  const uint32_t* next_j = A.next + J.bound_base;
   uint32_t x = rs[r0];
-  for (uint32_t r = r0 + 1; r < r0 + uint32_t(SV2_HOP) && r < J.height; ++r) {
+  for (uint32_t r = r0 + 1; r < r0 + uint32_t(SV2_HOP) && r < height; ++r) {
     if (x != SV2_NONE)
-      x = x < J.n_bounds ? A.next[J.bound_base + x] : SV2_NONE;
+      x = x < n_bounds ? next_j[x] : SV2_NONE;
     rs[r] = x;
   }
 }
@@ -370,10 +384,9 @@ __global__ __launch_bounds__(64) void sv2_parse_kernel(Sv2Args A) {
 // ---------------------------------------------------------------------------
 // Reconstruction: anti-diagonals t = c + 2 r
 // ---------------------------------------------------------------------------
-constexpr int SV2_RT = 1024;                 // lanes: 64 blocks of 16 pixels at a time
+constexpr int SV2_RT = 1024;                 // lanes: 256 blocks x 4 lanes of 4 pixels
 constexpr int SV2_RING_ROWS = 256, SV2_RING_BLKS = 8;
 constexpr int SV2_AHEAD = 4;                 // diagonals the loads run ahead
-constexpr int SV2_ITERS = 4;                 // block slots per lane and diagonal (<= 256 blocks)
 
 __device__ __forceinline__ uint32_t sv2_ring_addr(int row, int col) {
   return uint32_t(((row & (SV2_RING_ROWS - 1)) * SV2_RING_BLKS + ((col >> 4) & (SV2_RING_BLKS - 1))) * 16 +
@@ -382,12 +395,11 @@ __device__ __forceinline__ uint32_t sv2_ring_addr(int row, int col) {
 
 struct Sv2Fetch {
   uint32_t hdr;
-  int diff;
+  uint2 diff; // four differences
 };
 
-// what lane (slot, px) needs on diagonal t, iteration it
-__device__ __forceinline__ bool sv2_diag_block(const Sv2JobDev& J, int t, int slot, int* r, int* c) {
-  const int nb = int(J.nb), H = int(J.height);
+// the block lane group `slot` has on diagonal t
+__device__ __forceinline__ bool sv2_diag_block(int nb, int H, int t, int slot, int* r, int* c) {
   int r_lo = (t - (nb - 1) + 1) >> 1; // ceil((t - nb + 1) / 2)
   if (r_lo < 0)
     r_lo = 0;
@@ -399,7 +411,7 @@ __device__ __forceinline__ bool sv2_diag_block(const Sv2JobDev& J, int t, int sl
 }
 
 __global__ __launch_bounds__(SV2_RT) void sv2_recon_kernel(Sv2Args A) {
-  __shared__ uint16_t ring[SV2_RING_ROWS * SV2_RING_BLKS * 16];
+  __shared__ __attribute__((aligned(16))) uint16_t ring[SV2_RING_ROWS * SV2_RING_BLKS * 16];
   const Sv2JobDev& J = A.jobs[blockIdx.x];
   if (!J.valid)
     return;
@@ -407,7 +419,8 @@ __global__ __launch_bounds__(SV2_RT) void sv2_recon_kernel(Sv2Args A) {
   if (__hip_atomic_load(&A.job_status[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
       SV2_NONE)
     return; // the reference throws somewhere: nothing of the image is promised
-  const int tid = threadIdx.x, px = tid & 15, slot0 = tid >> 4;
+  // a block = 4 lanes of 4 pixels; at most (nb + 1) / 2 <= 203 blocks on a diagonal
+  const int tid = threadIdx.x, px0 = (tid & 3) * 4, slot = tid >> 2;
   const int nb = int(J.nb), H = int(J.height);
   const int T = nb + 2 * (H - 1);
   const uint32_t* hdr = A.hdr + J.blk_base;
@@ -416,18 +429,15 @@ __global__ __launch_bounds__(SV2_RT) void sv2_recon_kernel(Sv2Args A) {
   const int hi = (1 << J.bits) - 1;
   const int init = int(J.init_val);
   const int W = int(J.width);
-  // blocks on a diagonal: at most min(H, (nb + 1) / 2) <= 204 (W <= 6496): 4 slots a lane
-  Sv2Fetch f[SV2_AHEAD][SV2_ITERS];
-  auto fetch = [&](int t, Sv2Fetch(&dst)[SV2_ITERS]) {
-#pragma unroll
-    for (int it = 0; it < SV2_ITERS; ++it) {
-      int r, c;
-      dst[it].hdr = 0;
-      dst[it].diff = 0;
-      if (t < T && sv2_diag_block(J, t, slot0 + 64 * it, &r, &c)) {
-        dst[it].hdr = hdr[size_t(r) * nb + c];
-        dst[it].diff = diffs[size_t(r) * W + c * 16 + px];
-      }
+  const size_t pitch = J.pitch;
+  Sv2Fetch f[SV2_AHEAD];
+  auto fetch = [&](int t, Sv2Fetch& dst) {
+    int r, c;
+    dst.hdr = 0;
+    dst.diff = make_uint2(0, 0);
+    if (t < T && sv2_diag_block(nb, H, t, slot, &r, &c)) {
+      dst.hdr = hdr[size_t(r) * nb + c];
+      dst.diff = *reinterpret_cast<const uint2*>(diffs + size_t(r) * W + c * 16 + px0);
     }
   };
 #pragma unroll
@@ -437,22 +447,31 @@ __global__ __launch_bounds__(SV2_RT) void sv2_recon_kernel(Sv2Args A) {
 #pragma unroll
     for (int k = 0; k < SV2_AHEAD; ++k) {
       const int t = t0 + k;
-      if (t < T) {
+      int r, c;
+      if (t < T && sv2_diag_block(nb, H, t, slot, &r, &c)) {
+        const uint32_t h = f[k].hdr;
+        const int motion = int(h & 7u), scale = int(int16_t(h >> 16));
+        const int col = c * 16;
+        const int d4[4] = {int(int16_t(f[k].diff.x)), int(int16_t(f[k].diff.x >> 16)),
+                           int(int16_t(f[k].diff.y)), int(int16_t(f[k].diff.y >> 16))};
+        int v4[4];
+        if (motion == 7) { // :175-188: the two pixels to the left of the block
+          int b0 = init, b1 = init;
+          if (c != 0) {
+            const uint32_t two = *reinterpret_cast<const uint32_t*>(&ring[sv2_ring_addr(r, col - 2)]);
+            b0 = int(two & 0xFFFFu);
+            b1 = int(two >> 16);
+          }
 #pragma unroll
-        for (int it = 0; it < SV2_ITERS; ++it) {
-          int r, c;
-          if (!sv2_diag_block(J, t, slot0 + 64 * it, &r, &c))
-            continue;
-          const uint32_t h = f[k][it].hdr;
-          const int motion = int(h & 7u), scale = int(int16_t(h >> 16));
-          const int col = c * 16;
-          int base;
-          if (motion == 7) { // :175-188
-            base = c == 0 ? init : int(ring[sv2_ring_addr(r, col + (px & 1) - 2)]);
-          } else { // :194-227
-            const int slide =
-                motion == 0 ? -4 : (motion <= 2 ? -2 : (motion <= 4 ? 0 : (motion == 5 ? 2 : 4)));
-            const bool avg = motion == 2 || motion == 4;
+          for (int i = 0; i < 4; ++i)
+            v4[i] = (i & 1) ? b1 : b0;
+        } else { // :194-227: sixteen pixels of the two rows above
+          const int slide =
+              motion == 0 ? -4 : (motion <= 2 ? -2 : (motion <= 4 ? 0 : (motion == 5 ? 2 : 4)));
+          const bool avg = motion == 2 || motion == 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int px = px0 + i;
             int ref_row = r, ref_col = col + px + slide;
             if ((r + px) & 1) {
               ref_row -= 2;
@@ -460,14 +479,28 @@ __global__ __launch_bounds__(SV2_RT) void sv2_recon_kernel(Sv2Args A) {
               ref_row -= 1;
               ref_col += (px & 1) ? -1 : 1;
             }
-            base = int(ring[sv2_ring_addr(ref_row, ref_col)]);
+            int base = int(ring[sv2_ring_addr(ref_row, ref_col)]);
             if (avg)
               base = (base + int(ring[sv2_ring_addr(ref_row, ref_col + 2)]) + 1) >> 1;
+            v4[i] = base;
           }
-          int v = base + f[k][it].diff * (scale * 2 + 1) + scale;
-          v = v < 0 ? 0 : (v > hi ? hi : v);
-          ring[sv2_ring_addr(r, col + px)] = uint16_t(v);
-          *reinterpret_cast<uint16_t*>(out + size_t(r) * J.pitch + size_t(col + px) * 2) = uint16_t(v);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int v = v4[i] + d4[i] * (scale * 2 + 1) + scale;
+          v4[i] = v < 0 ? 0 : (v > hi ? hi : v);
+        }
+        const uint2 pk = make_uint2(uint32_t(v4[0]) | (uint32_t(v4[1]) << 16),
+                                    uint32_t(v4[2]) | (uint32_t(v4[3]) << 16));
+        *reinterpret_cast<uint2*>(&ring[sv2_ring_addr(r, col + px0)]) = pk;
+        uint8_t* o = out + size_t(r) * pitch + size_t(col + px0) * 2;
+        if ((reinterpret_cast<uintptr_t>(o) & 7u) == 0) {
+          *reinterpret_cast<uint2*>(o) = pk;
+        } else {
+          reinterpret_cast<uint16_t*>(o)[0] = uint16_t(v4[0]);
+          reinterpret_cast<uint16_t*>(o)[1] = uint16_t(v4[1]);
+          reinterpret_cast<uint16_t*>(o)[2] = uint16_t(v4[2]);
+          reinterpret_cast<uint16_t*>(o)[3] = uint16_t(v4[3]);
         }
       }
       fetch(t + SV2_AHEAD, f[k]);

@@ -61,7 +61,7 @@ def _baseline(img, row, col, motion, init_val, width):
     return base
 
 
-def encode(rng, target, bits, optflags=0, init_val=None, allow_scale=True):
+def encode(rng, target, bits, optflags=0, init_val=None, allow_scale=True, rows_out=None):
     """target: (h, w) wanted values (w % 16 == 0).  Returns (stream incl. the 16-byte
     header, the image a decoder reconstructs -- equal to `target` wherever the quantisation
     scale is 0)."""
@@ -169,4 +169,6 @@ def encode(rng, target, bits, optflags=0, init_val=None, allow_scale=True):
                 v = base[i] + c * q + scale
                 img[row, col + i] = min(max(v, 0), hi)
         out.append(wr.finish(align=16))
+        if rows_out is not None:
+            rows_out.append(out[-1])  # the row's bytes, padded to the next 16-byte boundary
     return np.concatenate(out + [np.zeros(16, np.uint8)]), img.astype(np.uint16)
