@@ -244,6 +244,9 @@ extern "C" void rsx_ctx_destroy(rsx_ctx* ctx) {
     }
     l->d_in.release();
     l->d_out.release();
+    if (l->cached_plan)
+      rsx_plan_destroy(l->cached_plan);
+    l->cached_plan = nullptr;
   }
   delete ctx;
 }
@@ -1622,17 +1625,40 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
     RSX_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t*>(lane.lane->d_in.ptr) +
                                           jobs[i].in_offset,
                                       ins[i], jobs[i].in_bytes, hipMemcpyHostToDevice, s));
+  // the lane's cached plan, if it was made from these very jobs (descriptors, sizes,
+  // offsets, image geometry; not the host pointer of the image)
+  std::vector<uint8_t> key(sizeof(void*) + size_t(n) * sizeof(JobT));
+  {
+    const void* fn = reinterpret_cast<const void*>(create);
+    std::memcpy(key.data(), &fn, sizeof fn);
+    for (int i = 0; i < n; ++i) {
+      JobT j = jobs[i];
+      j.img.data = nullptr;
+      std::memcpy(key.data() + sizeof fn + size_t(i) * sizeof(JobT), &j, sizeof(JobT));
+    }
+  }
   rsx_plan* plan = nullptr;
-  if (int st = create(ctx, n, jobs.data(), &plan))
-    return st;
+  if (lane.lane->cached_plan && lane.lane->cached_key == key) {
+    plan = lane.lane->cached_plan;
+  } else {
+    if (lane.lane->cached_plan)
+      rsx_plan_destroy(lane.lane->cached_plan);
+    lane.lane->cached_plan = nullptr;
+    if (int st = create(ctx, n, jobs.data(), &plan))
+      return st;
+    lane.lane->cached_plan = plan;
+    lane.lane->cached_key = std::move(key);
+  }
   std::vector<int32_t> st(n, RSX_OK);
   std::vector<uint32_t> cons(n, 0);
   int rc = rsx_plan_run(plan, lane.lane->d_in.ptr, lane.lane->d_out.ptr, s);
   if (rc == RSX_OK)
     rc = rsx_plan_results(plan, st.data(), cons.data());
-  rsx_plan_destroy(plan);
-  if (rc == RSX_ERR_DEVICE || rc == RSX_ERR_NOMEM)
+  if (rc == RSX_ERR_DEVICE || rc == RSX_ERR_NOMEM) {
+    rsx_plan_destroy(lane.lane->cached_plan);
+    lane.lane->cached_plan = nullptr;
     return rc;
+  }
   // only the rectangle a successful job decoded goes back to the host image:
   // pixels outside it (other tiles, padding) are never touched
   std::vector<HostRect> rects;

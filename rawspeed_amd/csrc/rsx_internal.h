@@ -182,6 +182,11 @@ struct rsx_ctx {
   struct HostLane {
     rsx::DeviceBuffer d_in, d_out;
     hipStream_t stream = nullptr;
+    // the plan of the lane's last LJPEG-family call and what it was made from: a caller
+    // that decodes the same layout again (a burst, a benchmark loop, the tiles of one
+    // camera's files) skips the plan's construction -- tables, block lists, a dozen uploads
+    struct rsx_plan* cached_plan = nullptr;
+    std::vector<uint8_t> cached_key;
   };
   std::mutex lanes_mu;
   std::vector<std::unique_ptr<HostLane>> lanes_all;
