@@ -461,16 +461,20 @@ __device__ __forceinline__ uint32_t lj_warmup(const Lds& L, const DecodeParams& 
 // Start guesses for the single-pass kernel (rsx_ljpeg_fast.hip): where the parse of a
 // slot from bit `from` ends, as an offset into the next slot.  lut8 = total bits of the
 // symbol a 10-bit window starts with.
+// (LDS addresses by hand: left to itself the compiler keeps two base pointers for the two
+// dwords of the window and spends four instructions on their addresses; this way the row
+// offset is an AND and a shift-add and the pair is one ds_read2st64_b32)
+typedef const __attribute__((address_space(3))) uint8_t* lds_u8p;
 template <bool COUNT>
-__device__ __forceinline__ uint32_t lj_guess_parse(const uint32_t* B, const uint8_t* lut8,
-                                                   int col, uint32_t end_bits, uint32_t from,
-                                                   uint32_t* count = nullptr) {
+__device__ __forceinline__ uint32_t lj_guess_parse(uint32_t bcol, uint32_t lut, uint32_t end_bits,
+                                                   uint32_t from, uint32_t* count = nullptr) {
+  static_assert(LJ_T == 256, "row stride 1 KB = 32 bits << 5");
   uint32_t pos = from, n = 0;
   while (pos < end_bits) {
-    const uint32_t wi = pos >> 5;
-    const uint32_t d0 = B[wi * LJ_T + col], d1 = B[(wi + 1) * LJ_T + col];
+    const uint32_t ad = bcol + ((pos & ~31u) << 5);
+    const uint32_t d0 = *(lds_u32p)(ad), d1 = *(lds_u32p)(ad + 4u * LJ_T);
     const uint32_t w = uint32_t((((uint64_t(d0) << 32) | d1) << (pos & 31u)) >> 32);
-    pos += lut8[w >> 22];
+    pos += *(lds_u8p)(lut + (w >> 22));
     if (COUNT)
       ++n;
   }
@@ -478,6 +482,38 @@ __device__ __forceinline__ uint32_t lj_guess_parse(const uint32_t* B, const uint
     *count = n;
   return pos - end_bits;
 }
+// The same loop instruction by instruction, for the layout the kernel really has (the
+// image at LDS address 0, the length table behind the layout): the position is kept as
+// 32 * pos, so the window's row is one v_and_or, its two dwords come with one
+// ds_read2st64_b32 in the order v_lshlrev_b64 wants them, the advance is one v_lshl_add --
+// 6 vector instructions and 2 LDS reads per symbol where the compiler's version has 11 and 2
+// (K0 parses three slots per slot: 0.20 of its 0.33 ms on cfg 3 are this loop).
+constexpr uint32_t LJ_GUESS_LUT_OFF = uint32_t(lj_lds_bytes(0));
+template <bool COUNT>
+__device__ __forceinline__ uint32_t lj_guess_parse_asm(uint32_t col4, uint32_t end_bits,
+                                                       uint32_t from, uint32_t* count = nullptr) {
+  uint32_t q = from << 5, n = 0;
+  const uint32_t qend = end_bits << 5;
+  while (q < qend) {
+    uint32_t ad, len;
+    uint64_t pr;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(q), "s"(0xFFFFFC00u), "v"(col4));
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:4 offset1:0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=v"(pr)
+                 : "v"(ad));
+    const uint32_t w = uint32_t((pr << ((q >> 5) & 31u)) >> 32);
+    asm volatile("ds_read_u8 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)"
+                 : "=v"(len)
+                 : "v"(w >> 22), "n"(LJ_GUESS_LUT_OFF));
+    q += len << 5;
+    if (COUNT)
+      ++n;
+  }
+  if (COUNT)
+    *count = n;
+  return (q - qend) >> 5;
+}
+
 // A slot inside a constant region of the image is the code of the zero difference over
 // and over.  No parse from an arbitrary bit finds its way into such a stretch reliably
 // (with Nikon's 14-bit table, 111110 repeated also reads as a chain of 12-bit symbols),
@@ -569,6 +605,8 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
                                    uint32_t(L.ob[tgt - 1]) == uint32_t(LJ_PW) * 32u &&
                                        !(tgt == 1 && lb == 0),
                                    &e, &cnt);
+    // (the hand-written loop assumes the layout it was written for)
+    const bool hand = lds_addr(L.B) == 0u && lds_addr(lut8) == LJ_GUESS_LUT_OFF;
     if (!constant) {
 #pragma unroll
       for (int k = LJ_GUESS_SLOTS; k >= 1; --k) {
@@ -577,10 +615,16 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
         if (uint32_t(k) > a.guess_slots) // (launch-uniform)
           e = 0;
         else if (col >= 0 && eb != 0 && !(col == 0 && lb == 0)) {
-          if (k == 1)
-            e = lj_guess_parse<true>(L.B, lut8, col, eb, e & ST_OFF_MASK, &cnt);
-          else
-            e = lj_guess_parse<false>(L.B, lut8, col, eb, e & ST_OFF_MASK);
+          if (hand) {
+            if (k == 1)
+              e = lj_guess_parse_asm<true>(uint32_t(col) * 4u, eb, e & ST_OFF_MASK, &cnt);
+            else
+              e = lj_guess_parse_asm<false>(uint32_t(col) * 4u, eb, e & ST_OFF_MASK);
+          } else if (k == 1) {
+            e = lj_guess_parse<true>(lds_addr(&L.B[col]), lds_addr(lut8), eb, e & ST_OFF_MASK, &cnt);
+          } else {
+            e = lj_guess_parse<false>(lds_addr(&L.B[col]), lds_addr(lut8), eb, e & ST_OFF_MASK);
+          }
         } else
           e = 0;
       }
