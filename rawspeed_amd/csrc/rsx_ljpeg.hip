@@ -2183,12 +2183,11 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
                                        (a.fast_lds_lv[2] != a.fast_lds_lv[1] ? 4u : 0u));
   a.fast_z = static_cast<const uint32_t*>(p->d_fast_z.ptr);
   a.fast_level = static_cast<uint32_t*>(p->d_fast_level.ptr);
-  // A wrong guess delays the workgroups of ITS stream that are in flight; with many
-  // streams interleaved those are few, and two slots (0.03 % wrong) do.
-  uint32_t n_fast = 0;
-  for (const LjStreamDev& S : p->streams)
-    n_fast += S.fast ? 1u : 0u;
-  a.guess_slots = n_fast >= 32 ? 2u : 3u;
+  // Three slots, whatever the number of streams.  (Round 3's first version took two for
+  // batches of 32 streams and more -- a wrong guess delays only the workgroups of ITS stream
+  // -- but every re-decode round still costs its workgroup 6 us and the ones behind it their
+  // wait: 256 cfg-5 frames 348 GPix/s with three slots, 318 with two.)
+  a.guess_slots = 3u;
 #ifdef RSX_EXPERIMENT
   if (const char* e = getenv("RSX_GUESS_SLOTS"))
     a.guess_slots = uint32_t(atoi(e));
