@@ -32,7 +32,7 @@ bash $REPO/scripts/pmc_ljpeg_traffic.sh > /dev/null 2>&1
 mkdir -p $OUT/ljpeg_traffic
 cp $REPO/gpurun_out/pmc_lj_traffic/* $OUT/ljpeg_traffic/
 # instruction mix of the LJPEG kernels (cfg 3): needs cfg3_kernel_stats.csv (above) for the times
-cp $OUT/cfg3_kernel_stats.csv $REPO/gpurun_out/pmc_lj/ 2>/dev/null
+mkdir -p $REPO/gpurun_out/pmc_lj; cp $OUT/cfg3_kernel_stats.csv $REPO/gpurun_out/pmc_lj/ 2>/dev/null
 bash $REPO/scripts/pmc_ljpeg.sh > $OUT/ljpeg_pmc.log 2>&1
 mkdir -p $OUT/ljpeg_pmc
 cp $REPO/gpurun_out/pmc_lj/*.txt $REPO/gpurun_out/pmc_lj/ljpeg_pmc.json $OUT/ljpeg_pmc/ 2>/dev/null
