@@ -2192,7 +2192,7 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   if (const char* e = getenv("RSX_GUESS_SLOTS"))
     a.guess_slots = uint32_t(atoi(e));
 #endif
-  a.fast_order = static_cast<const uint2*>(p->d_fast_order.ptr);
+  a.fast_order = static_cast<const uint4*>(p->d_fast_order.ptr);
   a.dbg = static_cast<unsigned long long*>(p->d_dbg.ptr);
   a.pass = 0;
   return a;
@@ -2591,7 +2591,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       if ((st = up(p->d_fast_z, fz.data(), fz.size() * 4)))
         return st;
       // ticket order of the single-pass launches: round robin over the streams
-      std::vector<uint2> order;
+      std::vector<uint4> order;
       order.reserve(p->total_blocks);
       uint32_t max_blocks = 0;
       for (const LjStreamDev& S : p->streams)
@@ -2599,8 +2599,9 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       for (uint32_t k = 0; k < max_blocks; ++k)
         for (size_t si = 0; si < p->streams.size(); ++si)
           if (k < p->streams[si].n_blocks)
-            order.push_back(make_uint2(p->streams[si].first_block + k, uint32_t(si)));
-      if ((st = up(p->d_fast_order, order.data(), order.size() * sizeof(uint2))))
+            order.push_back(make_uint4(p->streams[si].first_block + k, uint32_t(si),
+                                       p->streams[si].table_base, 0u));
+      if ((st = up(p->d_fast_order, order.data(), order.size() * sizeof(uint4))))
         return st;
       if ((st = up(p->d_fast_tabs, ft.data(), ft.size() * sizeof(uint2))) ||
           (st = p->d_lb.ensure(size_t(p->total_blocks) * LF_LB_WORDS * 8)) ||

@@ -257,7 +257,7 @@ struct LjArgs {
                              // that do not fit theirs send the stream to the multi-kernel pipeline.)
   const uint32_t* fast_z;    // [table]: code of the zero difference: length | code << 8 (0: none)
   uint32_t guess_slots;      // slots K0 parses for a start guess (2 or 3)
-  const uint2* fast_order;   // [ticket]: the workgroup's (block, stream) -- the streams'
+  const uint4* fast_order;   // [ticket]: the workgroup's (block, stream, table) -- the streams'
                              // blocks interleaved, each stream's in order
   unsigned long long* dbg;   // experiment builds: [workgroup][16] phase time stamps
   uint32_t pass;             // 0: first pass; 1: the multi-kernel pipeline redoes FL_SLOW

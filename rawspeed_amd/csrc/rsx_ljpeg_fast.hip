@@ -891,8 +891,27 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // order, so every predecessor holds an earlier ticket).  A workgroup waits for ALL its
   // stream's workgroups in flight; with one stream after the other that is everything on
   // the chip, and it pays the slowest of ~1000 -- interleaved, 1000 / streams.
-  const uint2 bs = a.fast_order[uni(F.misc[M_TICKET])];
-  const uint32_t b = uni(bs.x), s = uni(bs.y);
+  const uint4 bs = a.fast_order[uni(F.misc[M_TICKET])];
+  const uint32_t b = uni(bs.x), s = uni(bs.y), table_base = uni(bs.z);
+  // The workgroup's image and the stream's flags are asked for NOW, next to the stream's
+  // record: the head of a workgroup is a chain of dependent loads (ticket -> block ->
+  // stream -> flags -> table and image, 0.7-1.5 us each); the ticket's entry names the
+  // table, so nothing waits for the record.  (lj_load_image's loads for LF_BW rows, reversed: five uint4 a lane.)
+  const uint4* __restrict__ img_src = a.unstuffed + size_t(b) * LJ_IMG_U4;
+  const uint32_t flags_now = a.results[s].flags;
+  uint4 im[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int i = k * LJ_T + j;
+    im[k] = i < LF_BW * LJ_T / 4 ? img_src[i] : make_uint4(0, 0, 0, 0);
+  }
+  const uint32_t ob_now = reinterpret_cast<const uint32_t*>(img_src + (LJ_BW / 4) * LJ_T)[j];
+  uint4 lut_now[2];
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(a.fast_tabs + size_t(table_base) * 1024);
+    lut_now[0] = src[j];
+    lut_now[1] = src[j + LJ_T];
+  }
   const FastStream S = lf_stream(a.streams[s]);
   if (int(S.fast_n) != N)
     return; // (workgroup-uniform)
@@ -900,7 +919,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // A stream that some workgroup has given up on (periodic data, an invalid code, ...) is
   // redone by the multi-kernel pipeline anyway: leave records the workgroups in flight
   // can walk over and go.
-  if (uni(a.results[s].flags) & FL_SLOW) {
+  if (uni(flags_now) & FL_SLOW) {
     if (j == 0) {
       u64* p = a.lb + size_t(b) * LF_LB_WORDS;
       lb_store(p, lb0_make(LB0_FINAL, 0, 0, 0, 0));
@@ -922,10 +941,9 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
 
   // tables + image
   {
-    const uint4* src = reinterpret_cast<const uint4*>(a.fast_tabs + size_t(S.table_base) * 1024);
     uint4* dst = reinterpret_cast<uint4*>(smem + LF_OFF_LUT);
-    dst[j] = src[j];
-    dst[j + LJ_T] = src[j + LJ_T];
+    dst[j] = lut_now[0];
+    dst[j + LJ_T] = lut_now[1];
   }
   Lds L{};
   L.B = F.B;
@@ -936,7 +954,17 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     F.misc[M_UNRES] = 0xFFFFu;
     F.misc[M_UNRESB] = 0;
   }
-  lj_load_image<LF_BW, true>(L, a, b, j); // ends with a barrier
+  {
+    uint4* dst = reinterpret_cast<uint4*>(F.B);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int i = k * LJ_T + j; // uint4 i of the image = dwords 4 * (i % 64) .. of row i / 64
+      if (i < LF_BW * LJ_T / 4)
+        dst[(LF_BW - 1 - (i >> 6)) * (LJ_T / 4) + (i & 63)] = im[k];
+    }
+    F.ob[j] = uint16_t(ob_now);
+  }
+  __syncthreads();
   LF_STAMP(2);
   // delay the lane's column by one bit (see the header): dword k := d[k-1] : d[k] >> 1
   {
