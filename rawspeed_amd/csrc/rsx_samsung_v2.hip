@@ -274,6 +274,94 @@ __device__ __forceinline__ uint32_t sv2_row(const Sv2JobDev& J, const uint8_t* r
   return 0u;
 }
 
+// The 32 bits at bit offset q of a row (MSB32 words; zeros behind the end of the data)
+__device__ __forceinline__ uint32_t sv2_peek(const uint8_t* base, uint32_t size, uint32_t q) {
+  const uint32_t k = q >> 5;
+  uint32_t w0, w1;
+  if (4u * k + 8u <= size) {
+    const uint2 w = *reinterpret_cast<const uint2*>(base + 4u * k); // (4-byte aligned)
+    w0 = w.x;
+    w1 = w.y;
+  } else {
+    w0 = sv2_word(base, size, k);
+    w1 = sv2_word(base, size, k + 1u);
+  }
+  return uint32_t((((uint64_t(w0) << 32) | w1) << (q & 31u)) >> 32);
+}
+
+// How many bytes a row takes, by position: everything in front of a block's differences
+// fits one 32-bit peek (2 + 12 scale, 1 + 3 motion, 1 coded, 8 flags = 27 bits), the up to
+// four explicit lengths a second one, the differences themselves are skipped.  Less than
+// half the instructions of the bit-by-bit reader (sv2_row<false>), which the speculative
+// parse is bound by.  Returns 0, or 1 if the reference would throw in such a row.
+__device__ __forceinline__ uint32_t sv2_row_bytes(const Sv2JobDev& J, const uint8_t* base,
+                                                  uint32_t size, int first_mode, uint32_t* used) {
+  if (size < 4u)
+    return 1u;
+  const uint32_t limit = 32u * ((size + 8u) / 4u + 1u);
+  const uint32_t optflags = J.optflags, nb = J.nb, max_len = J.bits + 1u;
+  const bool qp = (optflags & 4u) != 0, mv = (optflags & 2u) != 0, skip = (optflags & 1u) != 0;
+  uint32_t m00 = uint32_t(first_mode), m01 = m00, m10 = m00, m11 = m00;
+  uint32_t q = 0;
+  for (uint32_t blk = 0; blk < nb; ++blk) {
+    const uint32_t w = sv2_peek(base, size, q);
+    uint32_t n = 0;
+    if (!qp && (blk & 3u) == 0u) {
+      n = (w >> 30) == 3u ? 14u : 2u;
+    }
+    if (mv) {
+      n += 1u;
+    } else {
+      n += ((w << n) >> 31) ? 1u : 4u;
+    }
+    bool coded = true;
+    if (!skip) {
+      coded = ((w << n) >> 31) == 0u;
+      n += 1u;
+    }
+    uint32_t total = 0;
+    if (coded) {
+      const uint32_t flags = (w << n) >> 24;
+      n += 8u;
+      q += n;
+      // (all four explicit lengths in one peek, whether or not they are there)
+      const uint32_t w2 = sv2_peek(base, size, q);
+      uint32_t n2 = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t f = (flags >> (6 - 2 * i)) & 3u;
+        uint32_t& a0 = i < 2 ? m00 : m10;
+        uint32_t& a1 = i < 2 ? m01 : m11;
+        uint32_t v;
+        if (f == 0u) {
+          v = a0;
+        } else if (f == 1u) {
+          v = a0 + 1u;
+        } else if (f == 2u) {
+          if (a0 == 0u)
+            return 1u;
+          v = a0 - 1u;
+        } else {
+          v = (w2 << n2) >> 28;
+          n2 += 4u;
+        }
+        a0 = a1;
+        a1 = v;
+        if (v > max_len)
+          return 1u;
+        total += v;
+      }
+      q += n2 + 4u * total;
+    } else {
+      q += n;
+    }
+    if (q > limit)
+      return 1u; // some getBits has run past the end of the data
+  }
+  *used = (q + 7u) >> 3;
+  return 0u;
+}
+
 // "a row that starts at boundary i ends where?" -> the boundary the next row starts at,
 // SV2_NONE if such a row would throw (then the reference stops there as well)
 __device__ __forceinline__ uint32_t sv2_next_boundary(const Sv2JobDev& J, const uint8_t* data,
@@ -282,8 +370,8 @@ __device__ __forceinline__ uint32_t sv2_next_boundary(const Sv2JobDev& J, const 
   if (a > J.in_bytes)
     return SV2_NONE;
   uint32_t used = 0;
-  const uint32_t st = sv2_row<false>(J, data + a, uint32_t(J.in_bytes - a), row, first_mode,
-                                     nullptr, nullptr, &used);
+  (void)row;
+  const uint32_t st = sv2_row_bytes(J, data + a, uint32_t(J.in_bytes - a), first_mode, &used);
   if (st != 0u || a + used > J.in_bytes)
     return SV2_NONE;
   return uint32_t((a + used + 15u) >> 4);
@@ -386,7 +474,8 @@ __global__ __launch_bounds__(64) void sv2_parse_kernel(Sv2Args A) {
 // ---------------------------------------------------------------------------
 constexpr int SV2_RT = 1024;                 // lanes: 256 blocks x 4 lanes of 4 pixels
 constexpr int SV2_RING_ROWS = 256, SV2_RING_BLKS = 8;
-constexpr int SV2_AHEAD = 4;                 // diagonals the loads run ahead
+constexpr int SV2_AHEAD = 8;                 // diagonals the loads run ahead (and the unroll: the
+                                             // loop edge costs one full wait)
 
 __device__ __forceinline__ uint32_t sv2_ring_addr(int row, int col) {
   return uint32_t(((row & (SV2_RING_ROWS - 1)) * SV2_RING_BLKS + ((col >> 4) & (SV2_RING_BLKS - 1))) * 16 +
@@ -410,6 +499,13 @@ __device__ __forceinline__ bool sv2_diag_block(int nb, int H, int t, int slot, i
   return rr < H && cc >= 0 && cc < nb;
 }
 
+// Every lane issues the same global loads and stores on every path of a step -- clamped
+// addresses for the lanes that have no block, a dump word for their stores: with a load or a
+// store under an `if` the compiler cannot count what is in flight behind the loads it waits
+// for and waits for everything (s_waitcnt vmcnt(0)), which puts the latency of the loads
+// issued four diagonals ahead AND of the pixel stores into every step (1.35 us a step,
+// 12.2 ms a frame, with the conditional version).
+template <bool ALIGNED8>
 __global__ __launch_bounds__(SV2_RT) void sv2_recon_kernel(Sv2Args A) {
   __shared__ __attribute__((aligned(16))) uint16_t ring[SV2_RING_ROWS * SV2_RING_BLKS * 16];
   const Sv2JobDev& J = A.jobs[blockIdx.x];
@@ -426,6 +522,8 @@ __global__ __launch_bounds__(SV2_RT) void sv2_recon_kernel(Sv2Args A) {
   const uint32_t* hdr = A.hdr + J.blk_base;
   const int16_t* diffs = A.diffs + J.px_base;
   uint8_t* out = A.out_base + J.img_offset;
+  // (stores of lanes without a block: the slack behind the job's differences)
+  uint8_t* dump = reinterpret_cast<uint8_t*>(A.diffs + J.px_base + size_t(H) * J.width);
   const int hi = (1 << J.bits) - 1;
   const int init = int(J.init_val);
   const int W = int(J.width);
@@ -433,12 +531,10 @@ __global__ __launch_bounds__(SV2_RT) void sv2_recon_kernel(Sv2Args A) {
   Sv2Fetch f[SV2_AHEAD];
   auto fetch = [&](int t, Sv2Fetch& dst) {
     int r, c;
-    dst.hdr = 0;
-    dst.diff = make_uint2(0, 0);
-    if (t < T && sv2_diag_block(nb, H, t, slot, &r, &c)) {
-      dst.hdr = hdr[size_t(r) * nb + c];
-      dst.diff = *reinterpret_cast<const uint2*>(diffs + size_t(r) * W + c * 16 + px0);
-    }
+    const bool ok = sv2_diag_block(nb, H, t, slot, &r, &c) && t < T;
+    const int rr = ok ? r : 0, cc = ok ? c : 0;
+    dst.hdr = hdr[size_t(rr) * nb + cc];
+    dst.diff = *reinterpret_cast<const uint2*>(diffs + size_t(rr) * W + cc * 16 + px0);
   };
 #pragma unroll
   for (int k = 0; k < SV2_AHEAD; ++k)
@@ -448,13 +544,14 @@ __global__ __launch_bounds__(SV2_RT) void sv2_recon_kernel(Sv2Args A) {
     for (int k = 0; k < SV2_AHEAD; ++k) {
       const int t = t0 + k;
       int r, c;
-      if (t < T && sv2_diag_block(nb, H, t, slot, &r, &c)) {
-        const uint32_t h = f[k].hdr;
-        const int motion = int(h & 7u), scale = int(int16_t(h >> 16));
-        const int col = c * 16;
-        const int d4[4] = {int(int16_t(f[k].diff.x)), int(int16_t(f[k].diff.x >> 16)),
-                           int(int16_t(f[k].diff.y)), int(int16_t(f[k].diff.y >> 16))};
-        int v4[4];
+      const bool ok = sv2_diag_block(nb, H, t, slot, &r, &c) && t < T;
+      const uint32_t h = f[k].hdr;
+      const int motion = int(h & 7u), scale = int(int16_t(h >> 16));
+      const int col = c * 16;
+      const int d4[4] = {int(int16_t(f[k].diff.x)), int(int16_t(f[k].diff.x >> 16)),
+                         int(int16_t(f[k].diff.y)), int(int16_t(f[k].diff.y >> 16))};
+      int v4[4] = {0, 0, 0, 0};
+      if (ok) {
         if (motion == 7) { // :175-188: the two pixels to the left of the block
           int b0 = init, b1 = init;
           if (c != 0) {
@@ -490,18 +587,19 @@ __global__ __launch_bounds__(SV2_RT) void sv2_recon_kernel(Sv2Args A) {
           const int v = v4[i] + d4[i] * (scale * 2 + 1) + scale;
           v4[i] = v < 0 ? 0 : (v > hi ? hi : v);
         }
-        const uint2 pk = make_uint2(uint32_t(v4[0]) | (uint32_t(v4[1]) << 16),
-                                    uint32_t(v4[2]) | (uint32_t(v4[3]) << 16));
+      }
+      const uint2 pk = make_uint2(uint32_t(v4[0]) | (uint32_t(v4[1]) << 16),
+                                  uint32_t(v4[2]) | (uint32_t(v4[3]) << 16));
+      if (ok)
         *reinterpret_cast<uint2*>(&ring[sv2_ring_addr(r, col + px0)]) = pk;
-        uint8_t* o = out + size_t(r) * pitch + size_t(col + px0) * 2;
-        if ((reinterpret_cast<uintptr_t>(o) & 7u) == 0) {
-          *reinterpret_cast<uint2*>(o) = pk;
-        } else {
-          reinterpret_cast<uint16_t*>(o)[0] = uint16_t(v4[0]);
-          reinterpret_cast<uint16_t*>(o)[1] = uint16_t(v4[1]);
-          reinterpret_cast<uint16_t*>(o)[2] = uint16_t(v4[2]);
-          reinterpret_cast<uint16_t*>(o)[3] = uint16_t(v4[3]);
-        }
+      uint8_t* o = ok ? out + size_t(r) * pitch + size_t(col + px0) * 2 : dump;
+      if (ALIGNED8) {
+        *reinterpret_cast<uint2*>(o) = pk;
+      } else {
+        reinterpret_cast<uint16_t*>(o)[0] = uint16_t(v4[0]);
+        reinterpret_cast<uint16_t*>(o)[1] = uint16_t(v4[1]);
+        reinterpret_cast<uint16_t*>(o)[2] = uint16_t(v4[2]);
+        reinterpret_cast<uint16_t*>(o)[3] = uint16_t(v4[3]);
       }
       fetch(t + SV2_AHEAD, f[k]);
       __syncthreads();
@@ -521,6 +619,7 @@ struct Sv2Plan {
   DeviceBuffer d_jobs, d_next, d_ja, d_jb, d_row_start, d_row_status, d_hdr, d_diffs, d_status;
   std::vector<uint32_t> h_status;
   uint32_t max_bounds = 0, max_rows = 0;
+  bool aligned8 = true; // every job's image rows start at multiples of 8 bytes
 };
 
 int samsung_v2_validate(const rsx_samsung_v2_desc& d, const rsx_image& img) {
@@ -561,6 +660,8 @@ int samsung_v2_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_samsung_v2_job* j
     if (st != RSX_OK)
       continue;
     J.valid = 1;
+    if (j.img_offset % 8 != 0 || j.img.pitch_bytes % 8 != 0)
+      p->aligned8 = false;
     J.in_offset = j.in_offset;
     J.in_bytes = j.in_bytes;
     J.img_offset = j.img_offset;
@@ -654,7 +755,10 @@ int samsung_v2_plan_run(Sv2Plan* p, const void* in_dev, void* out_dev, hipStream
   mark("sv2_fill_kernel");
   hipLaunchKernelGGL(sv2_parse_kernel, dim3((p->max_rows + 63) / 64, n), dim3(64), 0, s, A);
   mark("sv2_parse_kernel");
-  hipLaunchKernelGGL(sv2_recon_kernel, dim3(n), dim3(SV2_RT), 0, s, A);
+  if (p->aligned8)
+    hipLaunchKernelGGL(sv2_recon_kernel<true>, dim3(n), dim3(SV2_RT), 0, s, A);
+  else
+    hipLaunchKernelGGL(sv2_recon_kernel<false>, dim3(n), dim3(SV2_RT), 0, s, A);
   mark("sv2_recon_kernel");
   RSX_HIP_CHECK(ctx, hipGetLastError());
   return RSX_OK;
