@@ -488,7 +488,9 @@ __device__ __forceinline__ uint32_t lj_guess_parse(uint32_t bcol, uint32_t lut, 
 // ds_read2st64_b32 in the order v_lshlrev_b64 wants them, the advance is one v_lshl_add --
 // 6 vector instructions and 2 LDS reads per symbol where the compiler's version has 11 and 2
 // (K0 parses three slots per slot: 0.20 of its 0.33 ms on cfg 3 are this loop).
-constexpr uint32_t LJ_GUESS_LUT_OFF = uint32_t(lj_lds_bytes(0));
+constexpr uint32_t LJ_GUESS_LUT_OFF = uint32_t(LJ_PW + 1) * LJ_T * 4; // dword row 17 of the image
+constexpr uint32_t LJ_K0_OFF_OB = uint32_t(LJ_BW) * LJ_T * 4;
+constexpr uint32_t LJ_K0_LDS = LJ_K0_OFF_OB + 3 * LJ_T * 2 + 16 * 4 + 16 * 4 + 16;
 template <bool COUNT>
 __device__ __forceinline__ uint32_t lj_guess_parse_asm(uint32_t col4, uint32_t end_bits,
                                                        uint32_t from, uint32_t* count = nullptr) {
@@ -552,20 +554,28 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   const uint32_t b = blockIdx.x;
   const uint32_t s = a.block_stream[b];
   const LjStreamDev& S = a.streams[s];
-  const Lds L = carve(smem);
+  // This kernel's own layout: the arrays of the general one that only the synchronisation
+  // kernels use are left out, and the length table of the start guesses goes where dword
+  // rows 17..19 of the image were once the image is written out -- 18 LDS granules, a
+  // SEVENTH workgroup on a CU (the guesses are bound by LDS latency: 0.315 -> 0.29 ms).
+  Lds L{};
+  L.B = reinterpret_cast<uint32_t*>(smem);
+  L.ob = reinterpret_cast<uint16_t*>(smem + LJ_K0_OFF_OB);
+  L.su = L.ob + LJ_T;
+  L.list = L.su + LJ_T;
+  L.sm = reinterpret_cast<uint32_t*>(L.list + LJ_T);
+  L.misc = L.sm + 16;
+  uint32_t* est = L.misc + 16; // symbols of the workgroup (estimate)
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
-  // (single-pass streams: the symbol lengths of their 10-bit LUT, behind the layout)
-  uint8_t* lut8 = smem + lj_lds_bytes(0);
+  uint8_t* lut8 = smem + LJ_GUESS_LUT_OFF;
+  uint32_t lut_pk = 0;
   if (S.fast && a.fast_tabs) {
+    // (the symbol lengths of the stream's 10-bit LUT: asked for now, parked later)
     const uint2* ft = a.fast_tabs + size_t(S.table_base) * 1024 + 4 * j;
-    uint32_t pk = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      pk |= ((ft[k].x >> 5) & 63u) << (8 * k);
-    reinterpret_cast<uint32_t*>(lut8)[j] = pk;
-    if (j == 0)
-      reinterpret_cast<uint32_t*>(lut8)[256] = 0; // symbols of the workgroup (estimate)
+      lut_pk |= ((ft[k].x >> 5) & 63u) << (8 * k);
   }
   lj_stage_slots(L, a, S, s, lb, j, true); // ends with a barrier
   uint4* __restrict__ dst = a.unstuffed + size_t(b) * LJ_IMG_U4;
@@ -595,6 +605,11 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   // in that kernel: 9 % of the workgroups re-decode, and the average workgroup waits 26 us
   // for its predecessors) -- while this kernel is bound by HBM and has the issue slots free.
   if (S.fast && a.fast_tabs) {
+    __syncthreads(); // every lane has written its part of the image out
+    reinterpret_cast<uint32_t*>(lut8)[j] = lut_pk;
+    if (j == 0)
+      *est = 0;
+    __syncthreads();
     const int tgt = j == 0 ? LJ_T : j; // the slot the guess is for (LJ_T = slot 1 of the next block)
     const uint32_t zi = uint32_t(__builtin_amdgcn_readfirstlane(int(a.fast_z[S.table_base])));
     const uint32_t zl = zi & 31u, zc = zi >> 8;
@@ -640,7 +655,6 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
       c += uint32_t(__shfl_xor(int(c), o, 64));
-    uint32_t* est = reinterpret_cast<uint32_t*>(lut8) + 256;
     if ((j & 63) == 0)
       atomicAdd(est, c);
     __syncthreads();
@@ -2905,7 +2919,7 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
                                     hipMemcpyHostToDevice, s));
   const uint32_t n_streams = uint32_t(p->streams.size());
   hipLaunchKernelGGL(lj_unstuff_kernel, dim3(p->total_blocks), dim3(LJ_T),
-                     lj_lds_bytes(0) + (p->any_fast ? 1040 : 0), s, a);
+                     LJ_K0_LDS, s, a);
   mark(p, "lj_unstuff_kernel");
   // the single-pass kernel for the streams it takes ...
   if (p->any_fast) {
