@@ -906,6 +906,8 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     im[k] = i < LF_BW * LJ_T / 4 ? img_src[i] : make_uint4(0, 0, 0, 0);
   }
   const uint32_t ob_now = reinterpret_cast<const uint32_t*>(img_src + (LJ_BW / 4) * LJ_T)[j];
+  // (a stream's subsequences are numbered from first_block * LJ_OWN: the guesses too)
+  const uint32_t guess_now = j >= 1 ? uint32_t(a.sub_start[size_t(b) * LJ_OWN + uint32_t(j - 1)]) : 0u;
   uint4 lut_now[2];
   {
     const uint4* src = reinterpret_cast<const uint4*>(a.fast_tabs + size_t(table_base) * 1024);
@@ -988,8 +990,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // slots (experiments: every slot parsed here adds 6 us to the workgroup's lifetime).
   uint32_t guess = 0;
   if (LF_WARM_SLOTS == 0) {
-    if (j >= 1)
-      guess = a.sub_start[S.first_subseq + lb * LJ_OWN + uint32_t(j - 1)];
+    guess = guess_now;
   } else {
     const uint32_t ob2 = (LF_WARM_SLOTS >= 2 && j >= 2) ? uint32_t(F.ob[j >= 2 ? j - 2 : 0]) : 0u;
     const uint32_t ob1 = j >= 1 ? uint32_t(F.ob[j >= 1 ? j - 1 : 0]) : 0u;
