@@ -624,13 +624,17 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
                                        !(tgt == 1 && lb == 0),
                                    &e, &cnt);
     // (the hand-written loop assumes the layout it was written for)
-    const bool hand = lds_addr(L.B) == 0u && lds_addr(lut8) == LJ_GUESS_LUT_OFF;
+    bool hand = lds_addr(L.B) == 0u && lds_addr(lut8) == LJ_GUESS_LUT_OFF;
+#ifdef RSX_EXPERIMENT
+    if (a.guess_slots & 0x100u) // (experiments: the compiler's loop)
+      hand = false;
+#endif
     if (!constant) {
 #pragma unroll
       for (int k = LJ_GUESS_SLOTS; k >= 1; --k) {
         const int col = tgt - k;
         const uint32_t eb = col >= 0 ? uint32_t(L.ob[col >= 0 ? col : 0]) : 0u;
-        if (uint32_t(k) > a.guess_slots) // (launch-uniform)
+        if (uint32_t(k) > (a.guess_slots & 0xFFu)) // (launch-uniform)
           e = 0;
         else if (col >= 0 && eb != 0 && !(col == 0 && lb == 0)) {
           if (hand) {
