@@ -1,0 +1,135 @@
+"""Differential fuzzing of the single-pass LJPEG kernel at sizes where its machinery works
+-- tens of workgroups per stream, look-backs over them, re-decode rounds, LDS levels --
+against the oracle: images stitched from bands of sensor noise, constant values, ramps and
+short-period patterns (where the bit stream does not synchronise), random canonical tables,
+1 / 2 / 4 components, tiles narrower than their frames, bytes behind the end-of-image marker,
+several streams per call."""
+import numpy as np
+import pytest
+
+from rawspeed_amd import abi, synth
+
+import cases as C
+from oracle_lib import HostImage
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import gpu_util
+    return gpu_util.ctx()
+
+
+def banded_image(rng, h, w, prec):
+    """Bands of rows (and within them stretches of columns) of different character."""
+    maxv = (1 << prec) - 1
+    img = np.zeros((h, w), np.int64)
+    y = 0
+    while y < h:
+        bh = int(rng.integers(1, max(2, h // 3)))
+        x = 0
+        while x < w:
+            bw = int(rng.integers(8, max(9, w)))
+            kind = int(rng.integers(0, 6))
+            hh, ww = min(bh, h - y), min(bw, w - x)
+            base = int(rng.integers(0, maxv + 1))
+            if kind == 0:                                  # sensor-like noise
+                blk = base + rng.normal(0, float(rng.choice([1.0, 8.0, 60.0])), (hh, ww))
+            elif kind == 1:                                # constant
+                blk = np.full((hh, ww), base)
+            elif kind == 2:                                # clipped
+                blk = np.full((hh, ww), int(rng.choice([0, maxv])))
+            elif kind == 3:                                # ramp (constant differences)
+                blk = base + int(rng.integers(-3, 4)) * np.arange(ww)[None, :] + np.zeros((hh, 1))
+            elif kind == 4:                                # short period
+                p = int(rng.integers(2, 5))
+                blk = base + (np.arange(ww)[None, :] % p) * int(rng.integers(1, 40)) + np.zeros((hh, 1))
+            else:                                          # white noise
+                blk = rng.integers(0, maxv + 1, (hh, ww))
+            img[y:y + hh, x:x + ww] = blk
+            x += bw
+        y += bh
+    return np.clip(img, 0, maxv).astype(np.uint16)
+
+
+def make_stream(rng, W, H, tx, ty, tw, th, n, prec, table, tail):
+    px = banded_image(rng, th, tw, prec)
+    fw = (tw + n - 1) // n + int(rng.integers(0, 3))       # frame wider than the tile (in MCUs)
+    rows = C.ljpeg_stream_rows(px, n, 1, fw, th, rng, prec)
+    init = [1 << (prec - 1)] * n
+    scan, _ = synth.ljpeg_encode_scan(rows, n, init, [table] * n, 0, False)
+    d = abi.LJpegDesc()
+    d.tile_x, d.tile_y, d.tile_w, d.tile_h = tx, ty, tw, th
+    d.mcu_w, d.mcu_h, d.frame_w, d.frame_h = n, 1, fw, th
+    d.n_comp, d.rows_per_restart_interval = n, th
+    abi.fill_recipe(d, synth.huff_tables(table), [0] * n, init)
+    extra = {0: np.zeros(16, np.uint8), 1: np.zeros(int(rng.integers(16, 40000)), np.uint8),
+             2: rng.integers(0, 256, int(rng.integers(16, 40000)), dtype=np.uint8),
+             3: np.tile(np.array([0x24, 0x92, 0x49], np.uint8), int(rng.integers(6, 9000)))}[tail]
+    data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), extra])
+    return d, data, px
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_fuzz_single_pass_kernel(gpu, oracle, seed):
+    rng = np.random.default_rng([2027, seed])
+    n = int(rng.choice([1, 2, 2, 4]))
+    prec = int(rng.choice([12, 14, 14, 16]))
+    n_cat = 17 if prec == 16 else prec + 1
+    table = C.random_huffman_table(rng, n_cat, skew=float(rng.uniform(0.4, 2.5)))
+    k = int(rng.integers(1, 4))                             # streams in the call
+    tiles, x = [], 0
+    H = int(rng.integers(120, 500))
+    for _ in range(k):
+        tw = n * int(rng.integers(40, 1400 // n))
+        tiles.append((x, tw))
+        x += tw
+    W = x + int(rng.integers(0, 9))
+    img, want = HostImage(W, H), HostImage(W, H)
+    descs, datas, pxs = [], [], []
+    for tx, tw in tiles:
+        th = H - int(rng.integers(0, 3))
+        d, data, px = make_stream(rng, W, H, tx, 0, tw, th, n, prec, table,
+                                  int(rng.integers(0, 4)))
+        descs.append(d)
+        datas.append(data)
+        pxs.append(px)
+    so = [oracle.ljpeg(d, data, want) for d, data in zip(descs, datas)]
+    rc, st, cons = gpu.dng_decompress_ljpeg(descs, datas, img.view())
+    for i in range(k):
+        assert st[i] == so[i][0], (i, st, so)
+        if so[i][0] == 0:
+            assert cons[i] == so[i][1], (i, cons, so)
+    if all(s[0] == 0 for s in so):
+        assert np.array_equal(img.u16(), want.u16())
+        for (tx, tw), px in zip(tiles, pxs):
+            assert np.array_equal(img.pixels()[:px.shape[0], tx:tx + tw], px)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_single_pass_kernel_large(gpu, oracle, seed):
+    """The same at hundreds of workgroups per stream (look-back windows of 256 records and
+    more, the kernel's rounds of resident workgroups, both LDS levels in one call)."""
+    rng = np.random.default_rng([2028, seed])
+    n = int(rng.choice([1, 2, 4]))
+    prec = int(rng.choice([12, 14]))
+    table = C.random_huffman_table(rng, prec + 1, skew=float(rng.uniform(0.6, 2.0)))
+    H = int(rng.integers(900, 1600))
+    tiles, x = [], 0
+    for _ in range(int(rng.integers(1, 3))):
+        tw = n * int(rng.integers(1500 // n, 5200 // n))
+        tiles.append((x, tw))
+        x += tw
+    W = x
+    img, want = HostImage(W, H), HostImage(W, H)
+    descs, datas = [], []
+    for tx, tw in tiles:
+        d, data, _ = make_stream(rng, W, H, tx, 0, tw, H, n, prec, table, int(rng.integers(0, 4)))
+        descs.append(d)
+        datas.append(data)
+    so = [oracle.ljpeg(d, data, want) for d, data in zip(descs, datas)]
+    assert all(s[0] == 0 for s in so)
+    rc, st, cons = gpu.dng_decompress_ljpeg(descs, datas, img.view())
+    assert rc == 0 and not any(st) and list(cons) == [s[1] for s in so]
+    assert np.array_equal(img.u16(), want.u16())
