@@ -64,10 +64,6 @@ constexpr int LF_SIDE_STRIDE = 272;     // bytes: 128 x u16 + 16 (16-byte aligne
 constexpr int LF_RMAX = 256;            // stream rows that may start inside one workgroup
 constexpr uint32_t LF_MAX_ROUNDS = 6;   // re-decode rounds before the stream is given up
 constexpr uint32_t LF_SPIN_LIMIT = 1u << 22;
-#ifndef RSX_LF_WARM_SLOTS
-#define RSX_LF_WARM_SLOTS 0
-#endif
-constexpr int LF_WARM_SLOTS = RSX_LF_WARM_SLOTS; // slots parsed HERE for a start guess (0: K0's guesses)
 // Ablation switches of experiment builds (scripts/exp_ab.py; wrong pixels, timing only):
 // 1 no staging + copy-out, 2 no copy-out, 4 no look-back 0, 8 no look-back 1, 16 no
 // decode loop, 32 no warm-up, 64 no re-decode rounds, 128 no row table
@@ -283,23 +279,6 @@ __device__ __forceinline__ void lf_groups(FastState& s, uint32_t vbase, uint32_t
     if constexpr (G + 1 < LF_MAXSYM / 8)
       lf_groups<N, G + 1>(s, vbase, pend, R);
   }
-}
-
-// warm-up: where the parse of a slot from bit `from` ends (offset into the next slot)
-__device__ __forceinline__ uint32_t lf_warmup(uint32_t vbase, uint32_t end_bits, bool enabled,
-                                              uint32_t from = 0) {
-  uint32_t Pn = uint32_t(-32) - 32u * from;
-  const uint32_t pend = uint32_t(-32) - 32u * end_bits;
-  if (enabled) {
-    while (Pn > pend) {
-      const uint32_t ad = vbase + (Pn & ~1023u);
-      const uint32_t d1 = *(lds_u32p)(ad), d0 = *(lds_u32p)(ad + 4u * LJ_T);
-      const uint32_t w = __builtin_amdgcn_alignbit(d0, d1, Pn >> 5);
-      const uint32_t e0 = *(lds_u32p)((w >> 19) & 0x1FF8u);
-      Pn -= (e0 & 0x7E0u);
-    }
-  }
-  return enabled ? (pend - Pn) >> 5 : from;
 }
 
 // lj_slow_entry, inlined: a CALL while 64 VGPRs of running sums are live makes the
@@ -947,9 +926,6 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     dst[j] = lut_now[0];
     dst[j + LJ_T] = lut_now[1];
   }
-  Lds L{};
-  L.B = F.B;
-  L.ob = F.ob;
   if (j == 0) {
     F.misc[M_SLOW] = 0;
     F.misc[M_NSIDE] = 0;
@@ -986,18 +962,9 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   const uint32_t vbase_own = lds_addr(&F.B[(LF_BW - 1) * LJ_T + j]);
 
   // 1. the start guess: left by lj_unstuff_kernel (a parse of the three slots before the
-  // lane's from bit 0).  With LF_WARM_SLOTS != 0 it is made here instead, from one or two
-  // slots (experiments: every slot parsed here adds 6 us to the workgroup's lifetime).
-  uint32_t guess = 0;
-  if (LF_WARM_SLOTS == 0) {
-    guess = guess_now;
-  } else {
-    const uint32_t ob2 = (LF_WARM_SLOTS >= 2 && j >= 2) ? uint32_t(F.ob[j >= 2 ? j - 2 : 0]) : 0u;
-    const uint32_t ob1 = j >= 1 ? uint32_t(F.ob[j >= 1 ? j - 1 : 0]) : 0u;
-    const bool en = !(LF_ABLATE & 32u);
-    const uint32_t g2 = lf_warmup(vbase_own - 8u, ob2, en && j >= 2 && ob2 != 0);
-    guess = lf_warmup(vbase_own - 4u, ob1, en && j >= 1 && ob1 != 0, g2 & ST_OFF_MASK);
-  }
+  // lane's from bit 0; made in this kernel, from one or two slots, every slot parsed added
+  // 6 us to the workgroup's lifetime)
+  const uint32_t guess = guess_now;
   LF_STAMP(4);
   uint32_t start = guess & ST_OFF_MASK;
   if (j == 1 && lb == 0)

@@ -144,20 +144,11 @@ __device__ __forceinline__ uint32_t sv2_get(Sv2Bits& b, uint32_t n) {
   return v;
 }
 
-__device__ __forceinline__ void sv2_skip(Sv2Bits& b, uint32_t n) { // n <= 64
-  while (n > 16u) {
-    (void)sv2_get(b, 16u);
-    n -= 16u;
-  }
-  (void)sv2_get(b, n);
-}
-
 // ---------------------------------------------------------------------------
-// One row.  FULL: the parse proper (block headers, differences, every check of the
-// reference in its order); otherwise only how many bytes the row takes.
-// Returns an rsx_status; *used = getStreamPosition() of the row's bit pump.
+// One row, the parse proper: block headers, differences, every check of the reference in
+// its order.  Returns an rsx_status; *used = getStreamPosition() of the row's bit pump.
+// (How many bytes a row takes, without the rest: sv2_row_bytes below.)
 // ---------------------------------------------------------------------------
-template <bool FULL>
 __device__ __forceinline__ uint32_t sv2_row(const Sv2JobDev& J, const uint8_t* row_base,
                                             uint32_t size, int row, int first_mode,
                                             uint32_t* hdr, int16_t* diffs, uint32_t* used) {
@@ -193,7 +184,7 @@ __device__ __forceinline__ uint32_t sv2_row(const Sv2JobDev& J, const uint8_t* r
       motion = int(sv2_get(b, 3));
     if (b.err)
       return b.err;
-    if (FULL) {
+    {
       if (row < 2 && motion != 7)
         return uint32_t(RSX_ERR_INVALID_ARG); // :172-173
       if (motion != 7) {
@@ -240,7 +231,7 @@ __device__ __forceinline__ uint32_t sv2_row(const Sv2JobDev& J, const uint8_t* r
     if (b.err)
       return b.err;
     // decodeDifferences :279-311
-    if (FULL) {
+    {
       uint32_t dv[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -262,10 +253,6 @@ __device__ __forceinline__ uint32_t sv2_row(const Sv2JobDev& J, const uint8_t* r
       o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
       o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
       hdr[blk] = uint32_t(motion) | (uint32_t(uint16_t(int16_t(scale))) << 16);
-    } else {
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        sv2_skip(b, 4u * len[g]);
     }
     if (b.err)
       return b.err;
@@ -292,8 +279,7 @@ __device__ __forceinline__ uint32_t sv2_peek(const uint8_t* base, uint32_t size,
 // How many bytes a row takes, by position: everything in front of a block's differences
 // fits one 32-bit peek (2 + 12 scale, 1 + 3 motion, 1 coded, 8 flags = 27 bits), the up to
 // four explicit lengths a second one, the differences themselves are skipped.  Less than
-// half the instructions of the bit-by-bit reader (sv2_row<false>), which the speculative
-// parse is bound by.  Returns 0, or 1 if the reference would throw in such a row.
+// half the instructions of a bit-by-bit reader, which the speculative parse is bound by.  Returns 0, or 1 if the reference would throw in such a row.
 __device__ __forceinline__ uint32_t sv2_row_bytes(const Sv2JobDev& J, const uint8_t* base,
                                                   uint32_t size, int first_mode, uint32_t* used) {
   if (size < 4u)
@@ -453,7 +439,7 @@ __global__ __launch_bounds__(64) void sv2_parse_kernel(Sv2Args A) {
       st = uint32_t(RSX_ERR_IO); // data.skipBytes() to the boundary, :314-316
     } else {
       uint32_t used = 0;
-      st = sv2_row<true>(J, A.in_base + J.in_offset + a, uint32_t(J.in_bytes - a), int(row),
+      st = sv2_row(J, A.in_base + J.in_offset + a, uint32_t(J.in_bytes - a), int(row),
                          row < 2u ? 7 : 4, A.hdr + J.blk_base + size_t(row) * J.nb,
                          A.diffs + J.px_base + size_t(row) * J.width, &used);
       if (st == 0u && a + used > J.in_bytes)
