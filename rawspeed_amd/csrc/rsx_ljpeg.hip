@@ -599,66 +599,84 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     else
       a.fast_level[a.run_parity ^ 1u] = a.fast_level[2u + (a.run_parity ^ 1u)] = 0u; // (the NEXT run's)
   }
-  // Start guesses of the single-pass kernel.  Lane j parses the LJ_GUESS_SLOTS slots before
-  // slot j from bit 0 (Huffman streams self-synchronise: one slot leaves 1.7 % of the
-  // guesses wrong, two 0.03 %, three next to none); lane 0 does it for slot 1 of the NEXT
-  // workgroup, whose own lanes 1.. would have fewer slots to go by.  Here and not there: a
-  // wrong guess costs the single-pass kernel a re-decode round, and every workgroup
-  // behind the re-decoding one waits for its symbol count (measured with two slots parsed
-  // in that kernel: 9 % of the workgroups re-decode, and the average workgroup waits 26 us
-  // for its predecessors) -- while this kernel is bound by HBM and has the issue slots free.
+  // Start guesses of the single-pass kernel: where does the parse that starts at bit 0 three
+  // slots earlier run into slot t?  (Huffman streams self-synchronise: one slot leaves 1.7 %
+  // of the guesses wrong, two 0.03 %, three next to none.)  Here and not in that kernel: a
+  // wrong guess costs it a re-decode round, and every workgroup behind the re-decoding one
+  // waits for its symbol count (measured with two slots parsed there: 9 % of the workgroups
+  // re-decode, and the average workgroup waits 26 us for its predecessors).
+  // Lane c parses slot c, three times at most, each time from where the same chain left
+  // slot c - 1:  A[c] = parse(c, 0),  B[c] = parse(c, A[c-1]),  C[c] = parse(c, B[c-1]) --
+  // and C[c] = B[c] without a parse wherever B[c-1] = A[c-1], which is 98 % of the slots;
+  // the others go through a dense list on the first wavefront.  2.25 parses a slot
+  // instead of 3, the same guesses.  The guess for slot t is C[t-1]; lane 255's is for slot
+  // 1 of the NEXT workgroup, whose own lanes 1.. would have fewer slots to go by.
   if (S.fast && a.fast_tabs) {
+    uint16_t* EA = reinterpret_cast<uint16_t*>(smem + LJ_GUESS_LUT_OFF + 1024); // (dword rows 18, 19)
+    uint16_t* EB = EA + LJ_T;
+    uint16_t* glist = EB + LJ_T;
+    uint32_t* nlist = reinterpret_cast<uint32_t*>(glist + LJ_T);
     __syncthreads(); // every lane has written its part of the image out
     reinterpret_cast<uint32_t*>(lut8)[j] = lut_pk;
-    if (j == 0)
+    if (j == 0) {
       *est = 0;
+      *nlist = 0;
+    }
     __syncthreads();
-    const int tgt = j == 0 ? LJ_T : j; // the slot the guess is for (LJ_T = slot 1 of the next block)
     const uint32_t zi = uint32_t(__builtin_amdgcn_readfirstlane(int(a.fast_z[S.table_base])));
     const uint32_t zl = zi & 31u, zc = zi >> 8;
-    uint32_t e = 0, cnt = 0;
-    bool constant = false;
-    if (zl >= 4u) // (shorter: more than 128 symbols in a slot, the multi-kernel pipeline's)
-      constant = lj_guess_constant(L.B, tgt - 1, zl, zc,
-                                   uint32_t(L.ob[tgt - 1]) == uint32_t(LJ_PW) * 32u &&
-                                       !(tgt == 1 && lb == 0),
-                                   &e, &cnt);
+    const uint32_t gs = a.guess_slots & 0xFFu; // (3; experiments: fewer)
     // (the hand-written loop assumes the layout it was written for)
     bool hand = lds_addr(L.B) == 0u && lds_addr(lut8) == LJ_GUESS_LUT_OFF;
 #ifdef RSX_EXPERIMENT
     if (a.guess_slots & 0x100u) // (experiments: the compiler's loop)
       hand = false;
 #endif
-    if (!constant) {
-#pragma unroll
-      for (int k = LJ_GUESS_SLOTS; k >= 1; --k) {
-        const int col = tgt - k;
-        const uint32_t eb = col >= 0 ? uint32_t(L.ob[col >= 0 ? col : 0]) : 0u;
-        if (uint32_t(k) > (a.guess_slots & 0xFFu)) // (launch-uniform)
-          e = 0;
-        else if (col >= 0 && eb != 0 && !(col == 0 && lb == 0)) {
-          if (hand) {
-            if (k == 1)
-              e = lj_guess_parse_asm<true>(uint32_t(col) * 4u, eb, e & ST_OFF_MASK, &cnt);
-            else
-              e = lj_guess_parse_asm<false>(uint32_t(col) * 4u, eb, e & ST_OFF_MASK);
-          } else if (k == 1) {
-            e = lj_guess_parse<true>(lds_addr(&L.B[col]), lds_addr(lut8), eb, e & ST_OFF_MASK, &cnt);
-          } else {
-            e = lj_guess_parse<false>(lds_addr(&L.B[col]), lds_addr(lut8), eb, e & ST_OFF_MASK);
-          }
-        } else
-          e = 0;
+    auto parse = [&](int col, uint32_t bits, uint32_t from, uint32_t* count) -> uint32_t {
+      if (hand)
+        return count ? lj_guess_parse_asm<true>(uint32_t(col) * 4u, bits, from, count)
+                     : lj_guess_parse_asm<false>(uint32_t(col) * 4u, bits, from);
+      return count ? lj_guess_parse<true>(lds_addr(&L.B[col]), lds_addr(lut8), bits, from, count)
+                   : lj_guess_parse<false>(lds_addr(&L.B[col]), lds_addr(lut8), bits, from);
+    };
+    const uint32_t eb = L.ob[j];
+    const bool exists = eb != 0u && !(j == 0 && lb == 0);
+    uint32_t ea = 0, cnt = 0;
+    bool constant = false;
+    if (zl >= 4u) // (shorter: more than 128 symbols in a slot, the multi-kernel pipeline's)
+      constant = lj_guess_constant(L.B, j, zl, zc, eb == uint32_t(LJ_PW) * 32u && exists, &ea, &cnt);
+    if (!constant && exists)
+      ea = parse(j, eb, 0u, &cnt) & ST_OFF_MASK;
+    EA[j] = uint16_t(ea);
+    __syncthreads();
+    const uint32_t xa = j >= 1 ? uint32_t(EA[j - 1]) : 0u;
+    uint32_t ebv = ea;
+    if (!constant && exists && xa != 0u && gs >= 2u)
+      ebv = parse(j, eb, xa, nullptr) & ST_OFF_MASK;
+    EB[j] = uint16_t(ebv);
+    __syncthreads();
+    const uint32_t xb = j >= 1 ? uint32_t(EB[j - 1]) : 0u;
+    const bool third = !constant && exists && xb != xa && gs >= 3u;
+    if (third)
+      glist[atomicAdd(nlist, 1u)] = uint16_t(j);
+    const uint32_t g1 = S.first_subseq + lb * LJ_OWN; // record of this workgroup's slot 1
+    // (the guess for slot c + 1; lane 255's goes to the next workgroup's slot 1)
+    const bool stored = j >= 1 && (j < LJ_T - 1 || lb + 1 < S.n_blocks);
+    if (stored && !third)
+      a.sub_start[g1 + uint32_t(j)] = uint16_t(ebv);
+    __syncthreads();
+    const uint32_t nth = *nlist;
+    if (j < 64) {
+      for (uint32_t k = uint32_t(j); k < nth; k += 64u) {
+        const int c = int(glist[k]);
+        const uint32_t e3 = parse(c, L.ob[c], uint32_t(EB[c - 1]), nullptr) & ST_OFF_MASK;
+        if (c < LJ_T - 1 || lb + 1 < S.n_blocks)
+          a.sub_start[g1 + uint32_t(c)] = uint16_t(e3);
       }
     }
-    const uint32_t g1 = S.first_subseq + lb * LJ_OWN; // record of this workgroup's slot 1
-    if (j >= 2)
-      a.sub_start[g1 + uint32_t(j - 1)] = uint16_t(e & ST_OFF_MASK);
-    else if (j == 0 && lb + 1 < S.n_blocks)
-      a.sub_start[g1 + uint32_t(LJ_OWN)] = uint16_t(e & ST_OFF_MASK);
     // the LDS level of the single-pass launches: the symbols of this workgroup's slots
-    // 1..255 (lane j counted slot j - 1, lane 0 slot 255) against what a level stages
-    uint32_t c = j == 1 ? 0u : cnt;
+    // 1..255 (parsed from bit 0: an estimate) against what a level stages
+    uint32_t c = j == 0 ? 0u : cnt;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1)
       c += uint32_t(__shfl_xor(int(c), o, 64));
