@@ -1248,6 +1248,8 @@ __device__ __forceinline__ uint2 lj_rot_fields_rt(uint2 v, uint32_t f, uint32_t 
 // latter become P, the running sum of every component's differences over the
 // whole stream, before each workgroup's first symbol.
 // ---------------------------------------------------------------------------
+__device__ void lj_consumed_body(const LjArgs& a, uint32_t s, int lane);
+
 __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
   __shared__ uint32_t wsum[4], dsum[4];
   __shared__ uint2 psum[4];
@@ -1366,6 +1368,15 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
     if (S.fast && a.pass == 0 && (flags & (FL_UNCONVERGED | FL_NEED_LEGACY)))
       flags = (flags & ~(FL_UNCONVERGED | FL_NEED_LEGACY)) | FL_SLOW;
     R.flags = flags;
+  }
+  // Plans whose streams all take the single-pass kernel have nothing between this kernel
+  // and lj_consumed_kernel: its work is done here, by the first wavefront (a launch less:
+  // 10 us of a single frame's 235).
+  if (a.fuse_consumed) {
+    __threadfence_block();
+    __syncthreads();
+    if (tid < 64)
+      lj_consumed_body(a, s, tid);
   }
 }
 
@@ -1942,11 +1953,9 @@ __device__ __forceinline__ uint64_t lj_drops_before(const LjArgs& a,
          lj_count_drops(in, lb * LJ_R, x, lane);
 }
 
-__global__ __launch_bounds__(64) void lj_consumed_kernel(LjArgs a) {
-  const uint32_t s = blockIdx.x;
+__device__ void lj_consumed_body(const LjArgs& a, uint32_t s, int lane) {
   const LjStreamDev& S = a.streams[s];
   LjResult& R = a.results[s];
-  const int lane = threadIdx.x;
   if (!lj_bookkeeping_takes(a, s, S))
     return;
   if (R.status != 0 || uint64_t(R.avail_lo) < S.needed)
@@ -2047,6 +2056,10 @@ __global__ __launch_bounds__(64) void lj_consumed_kernel(LjArgs a) {
   }
   if (lane == 0)
     R.consumed = uint32_t(result);
+}
+
+__global__ __launch_bounds__(64) void lj_consumed_kernel(LjArgs a) {
+  lj_consumed_body(a, blockIdx.x, int(threadIdx.x));
 }
 
 // ---------------------------------------------------------------------------
@@ -2234,6 +2247,7 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.fast_order = static_cast<const uint4*>(p->d_fast_order.ptr);
   a.dbg = static_cast<unsigned long long*>(p->d_dbg.ptr);
   a.pass = 0;
+  a.fuse_consumed = 0;
   return a;
 }
 
@@ -2723,8 +2737,10 @@ int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s, bool pipeline = tr
   }
   if (p->any_legacy && legacy)
     launch_legacy(p, p->legacy, a, s);
-  hipLaunchKernelGGL(lj_consumed_kernel, dim3(n_streams), dim3(64), 0, s, a);
-  mark(p, "lj_consumed_kernel");
+  if (!a.fuse_consumed) {
+    hipLaunchKernelGGL(lj_consumed_kernel, dim3(n_streams), dim3(64), 0, s, a);
+    mark(p, "lj_consumed_kernel");
+  }
   RSX_HIP_CHECK(ctx, hipGetLastError());
   return RSX_OK;
 }
@@ -2933,7 +2949,8 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
   if (p->streams.empty())
     return RSX_OK;
   ++p->run_count;
-  const LjArgs a = make_args(p, in_dev, out_dev);
+  LjArgs a = make_args(p, in_dev, out_dev);
+  a.fuse_consumed = (p->any_fast && !p->any_pipeline && !p->any_legacy) ? 1u : 0u;
   // results: marker_pos = 0xFFFFFFFF, everything else 0
   for (auto& r : p->h_results) {
     std::memset(&r, 0, sizeof r);

@@ -260,6 +260,7 @@ struct LjArgs {
   const uint4* fast_order;   // [ticket]: the workgroup's (block, stream, table) -- the streams'
                              // blocks interleaved, each stream's in order
   unsigned long long* dbg;   // experiment builds: [workgroup][16] phase time stamps
+  uint32_t fuse_consumed;    // != 0: lj_scan_kernel does lj_consumed_kernel's work as well
   uint32_t pass;             // 0: first pass; 1: the multi-kernel pipeline redoes FL_SLOW
                              // streams; 2: its streams of both passes
 };
