@@ -23,10 +23,11 @@
 //   sv2_double_kernel   pointer doubling over that table, five times: 32 rows per hop
 //   sv2_chain_kernel    rows 0 and 1, then every 32nd row start by hops
 //   sv2_fill_kernel     the 31 row starts behind each of those
-//   sv2_parse_kernel    one lane per row: the parse proper -- motion, scale, the sixteen
-//                       differences of every block -- and every error the reference
+//   sv2_parse_kernel    one lane per row: the parse proper -- motion, scale, where the
+//                       differences of every block lie -- and every error the reference
 //                       throws, in the reference's order (none of them depends on pixel
 //                       values); the first failing row's status is the job's
+//   sv2_diffs_kernel    one lane per block: its sixteen differences, in pixel order
 //   sv2_recon_kernel    one workgroup per image: the blocks with the same c + 2 r do not
 //                       depend on each other (a block reads block c - 1 of its row and
 //                       blocks c - 1 .. c + 1 of the two rows above), so the image is
@@ -79,7 +80,8 @@ struct Sv2Args {
   uint32_t* jump_b;
   uint32_t* row_start; // [row]: boundary index, SV2_NONE = not reached
   uint32_t* row_status; // [row]: rsx_status of the row's parse
-  uint32_t* hdr;       // [block]: motion | scale << 16
+  uint32_t* hdr;       // [block]: motion | length of difference group 3 << 4 | scale << 16
+  uint32_t* dq;        // [block]: bit offset of its differences | lengths of groups 0..2 << 20
   int16_t* diffs;      // [pixel]: the differences in pixel order, unscaled
   uint32_t* job_status; // [job]: first failing row << 8 | status, SV2_NONE = fine
   uint32_t n_jobs;
@@ -88,20 +90,10 @@ struct Sv2Args {
 // ---------------------------------------------------------------------------
 // BitStreamerMSB32 over one row (bitstreams/BitStreamerMSB32.h: little-endian 32-bit
 // words, most significant bit first; io/BitStreamer.h:100-132: loads past the end of the
-// input are zero-padded, a load that starts more than 8 bytes past it throws)
+// input are zero-padded, a load that starts more than 8 bytes past it throws), read by
+// POSITION: the bits at an offset are a funnel shift of two words, and the reference's
+// overflow rule becomes a limit on the offsets a getBits may reach.
 // ---------------------------------------------------------------------------
-struct Sv2Bits {
-  const uint8_t* base; // the row's first byte (16-byte aligned)
-  uint32_t size;       // bytes from there to the end of the data
-  uint32_t limit;      // a getBits may reach this bit offset without an overflow
-  uint32_t q;          // bits consumed
-  uint64_t buf;        // the next `have` bits, left-aligned
-  uint32_t have;
-  uint32_t k;          // next word to push
-  uint32_t ahead;      // word k, loaded early
-  uint32_t err;        // sticky rsx_status (the oracle's bitreader::err)
-};
-
 __device__ __forceinline__ uint32_t sv2_word(const uint8_t* base, uint32_t size, uint32_t k) {
   const uint32_t off = 4u * k;
   if (off + 4u <= size)
@@ -111,154 +103,6 @@ __device__ __forceinline__ uint32_t sv2_word(const uint8_t* base, uint32_t size,
     if (off + b < size)
       v |= uint32_t(base[off + b]) << (8u * b);
   return v;
-}
-
-__device__ __forceinline__ void sv2_bits_init(Sv2Bits& b, const uint8_t* base, uint32_t size) {
-  b.base = base;
-  b.size = size;
-  // fill k loads bytes [4k, 4k + 4) and throws if 4k > size + 8 (BitStreamer.h:125-127)
-  b.limit = 32u * ((size + 8u) / 4u + 1u);
-  b.q = 0;
-  b.buf = 0;
-  b.have = 0;
-  b.k = 0;
-  b.ahead = sv2_word(base, size, 0);
-  b.err = size < 4u ? uint32_t(RSX_ERR_IO) : 0u; // (BitStreamer.h:56-60)
-}
-
-__device__ __forceinline__ uint32_t sv2_get(Sv2Bits& b, uint32_t n) {
-  if (n == 0u)
-    return 0u;
-  if (b.q + n > b.limit && b.err == 0u)
-    b.err = uint32_t(RSX_ERR_INPUT_OVERFLOW);
-  if (b.have < n) {
-    b.buf |= uint64_t(b.ahead) << (32u - b.have);
-    b.have += 32u;
-    ++b.k;
-    b.ahead = sv2_word(b.base, b.size, b.k);
-  }
-  const uint32_t v = uint32_t(b.buf >> (64u - n));
-  b.buf <<= n;
-  b.have -= n;
-  b.q += n;
-  return v;
-}
-
-// ---------------------------------------------------------------------------
-// One row, the parse proper: block headers, differences, every check of the reference in
-// its order.  Returns an rsx_status; *used = getStreamPosition() of the row's bit pump.
-// (How many bytes a row takes, without the rest: sv2_row_bytes below.)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t sv2_row(const Sv2JobDev& J, const uint8_t* row_base,
-                                            uint32_t size, int row, int first_mode,
-                                            uint32_t* hdr, int16_t* diffs, uint32_t* used) {
-  Sv2Bits b;
-  sv2_bits_init(b, row_base, size);
-  if (b.err)
-    return b.err;
-  int motion = 7, scale = 0;
-  // diffBitsMode: a row uses two of the three colour histories (groups 0-1 one, groups
-  // 2-3 the other, :246-247) and all of them start equal: two histories, by group pair
-  int mode[2][2];
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-    mode[c][0] = mode[c][1] = first_mode;
-  // (the job's fields in registers: read through the reference they are loaded again
-  // behind every store, each time behind a wait for everything in flight)
-  const uint32_t optflags = J.optflags, nb = J.nb, max_len = J.bits + 1u;
-  const bool qp = (optflags & 4u) != 0, mv = (optflags & 2u) != 0, skip = (optflags & 1u) != 0;
-  const int width = int(J.width);
-  for (uint32_t blk = 0; blk < nb; ++blk) {
-    const int col = int(blk) * 16;
-    // prepareBaselineValues :152-230 (the bits it reads and its checks)
-    if (!qp && (blk & 3u) == 0u) {
-      const uint32_t i = sv2_get(b, 2);
-      if (i < 3u)
-        scale += i == 1u ? -2 : (i == 2u ? 2 : 0);
-      else
-        scale = int(sv2_get(b, 12));
-    }
-    if (mv)
-      motion = sv2_get(b, 1) ? 3 : 7;
-    else if (!sv2_get(b, 1))
-      motion = int(sv2_get(b, 3));
-    if (b.err)
-      return b.err;
-    {
-      if (row < 2 && motion != 7)
-        return uint32_t(RSX_ERR_INVALID_ARG); // :172-173
-      if (motion != 7) {
-        const int slide = motion == 0 ? -4 : (motion <= 2 ? -2 : (motion <= 4 ? 0 : (motion == 5 ? 2 : 4)));
-        const bool avg = motion == 2 || motion == 4;
-        for (int i = 0; i < 16; ++i) { // :202-227
-          int ref_col = col + i + slide;
-          if (!((row + i) & 1))
-            ref_col += (i & 1) ? -1 : 1;
-          if (ref_col < 0 || ref_col >= width || (avg && ref_col + 2 >= width))
-            return uint32_t(RSX_ERR_INVALID_ARG);
-        }
-      }
-    }
-    // decodeDiffLengths :232-277
-    uint32_t len[4] = {0, 0, 0, 0};
-    if (skip || !sv2_get(b, 1)) {
-      uint32_t flags[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        flags[i] = sv2_get(b, 2);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int* m = mode[i >> 1];
-        uint32_t v;
-        if (flags[i] == 0u) {
-          v = uint32_t(m[0]);
-        } else if (flags[i] == 1u) {
-          v = uint32_t(m[0]) + 1u;
-        } else if (flags[i] == 2u) {
-          if (m[0] == 0)
-            return uint32_t(RSX_ERR_INVALID_ARG); // :258-259
-          v = uint32_t(m[0]) - 1u;
-        } else {
-          v = sv2_get(b, 4);
-        }
-        m[0] = m[1];
-        m[1] = int(v);
-        if (v > max_len)
-          return uint32_t(RSX_ERR_INVALID_ARG); // :271-272
-        len[i] = v;
-      }
-    }
-    if (b.err)
-      return b.err;
-    // decodeDifferences :279-311
-    {
-      uint32_t dv[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const uint32_t l = len[i >> 2];
-        int v = 0;
-        if (l) {
-          const uint32_t u = sv2_get(b, l);
-          v = int(u << (32u - l)) >> (32u - l);
-        }
-        dv[i] = uint32_t(v) & 0xFFFFu;
-      }
-      // the shuffle of :293-304: pixels 2k, 2k + 1 are differences k and 8 + k of the
-      // stream, in this order on even rows and the other way round on odd ones
-      uint32_t pk[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        pk[k] = (row & 1) ? (dv[8 + k] | (dv[k] << 16)) : (dv[k] | (dv[8 + k] << 16));
-      uint4* o = reinterpret_cast<uint4*>(diffs + size_t(blk) * 16);
-      o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-      o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-      hdr[blk] = uint32_t(motion) | (uint32_t(uint16_t(int16_t(scale))) << 16);
-    }
-    if (b.err)
-      return b.err;
-  }
-  *used = (b.q + 7u) >> 3; // getStreamPosition(): whole bytes the pump has taken
-  return 0u;
 }
 
 // The 32 bits at bit offset q of a row (MSB32 words; zeros behind the end of the data)
@@ -345,6 +189,123 @@ __device__ __forceinline__ uint32_t sv2_row_bytes(const Sv2JobDev& J, const uint
       return 1u; // some getBits has run past the end of the data
   }
   *used = (q + 7u) >> 3;
+  return 0u;
+}
+
+// One row, the parse proper: for every block motion, scale and where its differences lie
+// (bit offset and the four lengths), with every check of the reference in its order.  The
+// bit pump's sticky overflow (a getBits past `limit`) is looked at where the reference's
+// control flow would meet the exception: behind the bits of prepareBaselineValues
+// (:159-170), behind the difference lengths (:234-276) and behind the differences
+// (:286-290) -- the offsets only grow, so "some getBits has run past the limit" is "the
+// offset behind the last one has".  Returns an rsx_status; *used = getStreamPosition().
+// (A first version read bit by bit like the reference and wrote the 16 differences of a
+// block itself: 800 instructions a block on a lane that is alone on its SIMD, 4.4 ms for
+// the rows of four frames; the differences are sv2_diffs_kernel's now, a lane per block.)
+__device__ __forceinline__ uint32_t sv2_row_parse(const Sv2JobDev& J, const uint8_t* base,
+                                                  uint32_t size, int row, int first_mode,
+                                                  uint32_t* hdr, uint32_t* dq, uint32_t* used) {
+  if (size < 4u)
+    return uint32_t(RSX_ERR_IO); // (BitStreamer.h:56-60)
+  const uint32_t limit = 32u * ((size + 8u) / 4u + 1u);
+  const uint32_t optflags = J.optflags, nb = J.nb, max_len = J.bits + 1u;
+  const bool qp = (optflags & 4u) != 0, mv = (optflags & 2u) != 0, skip = (optflags & 1u) != 0;
+  const int width = int(J.width);
+  // diffBitsMode: a row uses two of the three colour histories (groups 0-1 one, groups
+  // 2-3 the other, :246-247) and all of them start equal: two histories, by group pair
+  uint32_t m00 = uint32_t(first_mode), m01 = m00, m10 = m00, m11 = m00;
+  int motion = 7, scale = 0;
+  uint32_t q = 0;
+  for (uint32_t blk = 0; blk < nb; ++blk) {
+    const int col = int(blk) * 16;
+    const uint32_t w = sv2_peek(base, size, q);
+    uint32_t n = 0;
+    // prepareBaselineValues :152-230 (the bits it reads and its checks)
+    if (!qp && (blk & 3u) == 0u) {
+      const uint32_t i = w >> 30;
+      n = 2u;
+      if (i < 3u) {
+        scale += i == 1u ? -2 : (i == 2u ? 2 : 0);
+      } else {
+        scale = int((w << 2) >> 20);
+        n = 14u;
+      }
+    }
+    if (mv) {
+      motion = ((w << n) >> 31) ? 3 : 7;
+      n += 1u;
+    } else {
+      const uint32_t keep = (w << n) >> 31;
+      n += 1u;
+      if (!keep) {
+        motion = int((w << n) >> 29);
+        n += 3u;
+      }
+    }
+    if (q + n > limit)
+      return uint32_t(RSX_ERR_INPUT_OVERFLOW);
+    if (row < 2 && motion != 7)
+      return uint32_t(RSX_ERR_INVALID_ARG); // :172-173
+    if (motion != 7) {
+      const int slide = motion == 0 ? -4 : (motion <= 2 ? -2 : (motion <= 4 ? 0 : (motion == 5 ? 2 : 4)));
+      const bool avg = motion == 2 || motion == 4;
+      for (int i = 0; i < 16; ++i) { // :202-227
+        int ref_col = col + i + slide;
+        if (!((row + i) & 1))
+          ref_col += (i & 1) ? -1 : 1;
+        if (ref_col < 0 || ref_col >= width || (avg && ref_col + 2 >= width))
+          return uint32_t(RSX_ERR_INVALID_ARG);
+      }
+    }
+    // decodeDiffLengths :232-277
+    uint32_t len[4] = {0, 0, 0, 0};
+    bool coded = true;
+    if (!skip) {
+      coded = ((w << n) >> 31) == 0u;
+      n += 1u;
+    }
+    if (coded) {
+      const uint32_t flags = (w << n) >> 24; // (n <= 19: all of it is in the first peek)
+      n += 8u;
+      const uint32_t w2 = sv2_peek(base, size, q + n);
+      uint32_t n2 = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t f = (flags >> (6 - 2 * i)) & 3u;
+        uint32_t& a0 = i < 2 ? m00 : m10;
+        uint32_t& a1 = i < 2 ? m01 : m11;
+        uint32_t v;
+        if (f == 0u) {
+          v = a0;
+        } else if (f == 1u) {
+          v = a0 + 1u;
+        } else if (f == 2u) {
+          if (a0 == 0u)
+            return uint32_t(RSX_ERR_INVALID_ARG); // :258-259
+          v = a0 - 1u;
+        } else {
+          v = (w2 << n2) >> 28;
+          n2 += 4u;
+        }
+        a0 = a1;
+        a1 = v;
+        if (v > max_len)
+          return uint32_t(RSX_ERR_INVALID_ARG); // :271-272
+        len[i] = v;
+      }
+      n += n2;
+    }
+    q += n;
+    if (q > limit)
+      return uint32_t(RSX_ERR_INPUT_OVERFLOW);
+    // decodeDifferences :279-311: sv2_diffs_kernel's; here only where they lie
+    dq[blk] = q | (len[0] << 20) | (len[1] << 24) | (len[2] << 28);
+    hdr[blk] = uint32_t(motion) | (len[3] << 4) | (uint32_t(uint16_t(int16_t(scale))) << 16);
+    q += 4u * (len[0] + len[1] + len[2] + len[3]);
+    if (q > limit)
+      return uint32_t(RSX_ERR_INPUT_OVERFLOW);
+  }
+  *used = (q + 7u) >> 3; // getStreamPosition(): whole bytes the pump has taken
   return 0u;
 }
 
@@ -439,9 +400,9 @@ __global__ __launch_bounds__(64) void sv2_parse_kernel(Sv2Args A) {
       st = uint32_t(RSX_ERR_IO); // data.skipBytes() to the boundary, :314-316
     } else {
       uint32_t used = 0;
-      st = sv2_row(J, A.in_base + J.in_offset + a, uint32_t(J.in_bytes - a), int(row),
+      st = sv2_row_parse(J, A.in_base + J.in_offset + a, uint32_t(J.in_bytes - a), int(row),
                          row < 2u ? 7 : 4, A.hdr + J.blk_base + size_t(row) * J.nb,
-                         A.diffs + J.px_base + size_t(row) * J.width, &used);
+                         A.dq + J.blk_base + size_t(row) * J.nb, &used);
       if (st == 0u && a + used > J.in_bytes)
         st = uint32_t(RSX_ERR_IO); // data.skipBytes(pump.getStreamPosition()), :337
       // (the table of row starts comes from the same parse: a row that is fine here has a
@@ -453,6 +414,49 @@ __global__ __launch_bounds__(64) void sv2_parse_kernel(Sv2Args A) {
   A.row_status[J.row_base + row] = st;
   if (st != 0u && st != SV2_NONE)
     atomicMin(&A.job_status[blockIdx.y], (row << 8) | (st & 0xFFu));
+}
+
+// The differences, one lane per block: sixteen fields of the block's four lengths from the
+// offset the row's parse has left (getDiff :79-85: sign extension of `len` bits), into
+// pixel order (the shuffle of :293-304: pixels 2k, 2k + 1 are differences k and 8 + k of
+// the stream, in this order on even rows and the other way round on odd ones).
+__global__ __launch_bounds__(256) void sv2_diffs_kernel(Sv2Args A) {
+  const Sv2JobDev& J = A.jobs[blockIdx.y];
+  if (!J.valid)
+    return;
+  if (__hip_atomic_load(&A.job_status[blockIdx.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) !=
+      SV2_NONE)
+    return; // (some row has failed: what lies behind the failure was never parsed)
+  const uint32_t nb = J.nb;
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= J.height * nb)
+    return;
+  const uint32_t row = g / nb;
+  const uint64_t a = uint64_t(A.row_start[J.row_base + row]) * 16u;
+  const uint8_t* base = A.in_base + J.in_offset + a;
+  const uint32_t size = uint32_t(J.in_bytes - a);
+  const uint32_t d = A.dq[J.blk_base + g], h = A.hdr[J.blk_base + g];
+  const uint32_t len[4] = {(d >> 20) & 15u, (d >> 24) & 15u, d >> 28, (h >> 4) & 15u};
+  uint32_t q = d & 0xFFFFFu;
+  uint32_t dv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t l = len[i >> 2];
+    int v = 0;
+    if (l) {
+      const uint32_t u = sv2_peek(base, size, q);
+      v = int(u) >> (32u - l);
+      q += l;
+    }
+    dv[i] = uint32_t(v) & 0xFFFFu;
+  }
+  uint32_t pk[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    pk[k] = (row & 1u) ? (dv[8 + k] | (dv[k] << 16)) : (dv[k] | (dv[8 + k] << 16));
+  uint4* o = reinterpret_cast<uint4*>(A.diffs + J.px_base + size_t(g) * 16);
+  o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+  o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
 }
 
 // ---------------------------------------------------------------------------
@@ -602,9 +606,9 @@ struct Sv2Plan {
   rsx_ctx* ctx = nullptr;
   std::vector<Sv2JobDev> jobs;
   std::vector<int32_t> host_status; // validation result per job
-  DeviceBuffer d_jobs, d_next, d_ja, d_jb, d_row_start, d_row_status, d_hdr, d_diffs, d_status;
+  DeviceBuffer d_jobs, d_next, d_ja, d_jb, d_row_start, d_row_status, d_hdr, d_dq, d_diffs, d_status;
   std::vector<uint32_t> h_status;
-  uint32_t max_bounds = 0, max_rows = 0;
+  uint32_t max_bounds = 0, max_rows = 0, max_blocks = 0;
   bool aligned8 = true; // every job's image rows start at multiples of 8 bytes
 };
 
@@ -669,6 +673,7 @@ int samsung_v2_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_samsung_v2_job* j
     px += uint64_t(J.height) * J.width;
     p->max_bounds = std::max(p->max_bounds, J.n_bounds);
     p->max_rows = std::max(p->max_rows, J.height);
+    p->max_blocks = std::max(p->max_blocks, J.height * J.nb);
     if (bounds >= (1ull << 32) || blocks >= (1ull << 32))
       return RSX_ERR_UNSUPPORTED;
   }
@@ -677,7 +682,7 @@ int samsung_v2_plan_create(rsx_ctx* ctx, int n_jobs, const rsx_samsung_v2_job* j
   if ((st = p->d_jobs.ensure(p->jobs.size() * sizeof(Sv2JobDev))) ||
       (st = p->d_next.ensure(bounds * 4 + 16)) || (st = p->d_ja.ensure(bounds * 4 + 16)) ||
       (st = p->d_jb.ensure(bounds * 4 + 16)) || (st = p->d_row_start.ensure(rows * 4 + 16)) ||
-      (st = p->d_row_status.ensure(rows * 4 + 16)) || (st = p->d_hdr.ensure(blocks * 4 + 16)) ||
+      (st = p->d_row_status.ensure(rows * 4 + 16)) || (st = p->d_hdr.ensure(blocks * 4 + 16)) || (st = p->d_dq.ensure(blocks * 4 + 16)) ||
       (st = p->d_diffs.ensure(px * 2 + 16)) || (st = p->d_status.ensure(size_t(n_jobs) * 4 + 16)))
     return st;
   RSX_HIP_CHECK(ctx, hipMemcpy(p->d_jobs.ptr, p->jobs.data(), p->jobs.size() * sizeof(Sv2JobDev),
@@ -691,7 +696,7 @@ void samsung_v2_plan_destroy(Sv2Plan* p) {
   if (!p)
     return;
   for (DeviceBuffer* b : {&p->d_jobs, &p->d_next, &p->d_ja, &p->d_jb, &p->d_row_start,
-                          &p->d_row_status, &p->d_hdr, &p->d_diffs, &p->d_status})
+                          &p->d_row_status, &p->d_hdr, &p->d_dq, &p->d_diffs, &p->d_status})
     b->release();
   delete p;
 }
@@ -714,6 +719,7 @@ int samsung_v2_plan_run(Sv2Plan* p, const void* in_dev, void* out_dev, hipStream
   A.row_start = static_cast<uint32_t*>(p->d_row_start.ptr);
   A.row_status = static_cast<uint32_t*>(p->d_row_status.ptr);
   A.hdr = static_cast<uint32_t*>(p->d_hdr.ptr);
+  A.dq = static_cast<uint32_t*>(p->d_dq.ptr);
   A.diffs = static_cast<int16_t*>(p->d_diffs.ptr);
   A.job_status = static_cast<uint32_t*>(p->d_status.ptr);
   A.n_jobs = n;
@@ -741,6 +747,8 @@ int samsung_v2_plan_run(Sv2Plan* p, const void* in_dev, void* out_dev, hipStream
   mark("sv2_fill_kernel");
   hipLaunchKernelGGL(sv2_parse_kernel, dim3((p->max_rows + 63) / 64, n), dim3(64), 0, s, A);
   mark("sv2_parse_kernel");
+  hipLaunchKernelGGL(sv2_diffs_kernel, dim3((p->max_blocks + 255) / 256, n), dim3(256), 0, s, A);
+  mark("sv2_diffs_kernel");
   if (p->aligned8)
     hipLaunchKernelGGL(sv2_recon_kernel<true>, dim3(n), dim3(SV2_RT), 0, s, A);
   else
