@@ -33,7 +33,7 @@
 //                       blocks c - 1 .. c + 1 of the two rows above), so the image is
 //                       swept in W/16 + 2 H anti-diagonals; the pixels a diagonal reads
 //                       are the ones the last few diagonals wrote and live in an LDS ring
-//                       (64 KB: 256 rows x the last 8 blocks), differences and block
+//                       (66 KB: 256 rows x the last 8 blocks, padded against bank conflicts), differences and block
 //                       headers are loaded four diagonals ahead.
 //
 // All of it is bit-exact against oracle_samsung_v2_decompress (tests/test_gpu_samsung_v2.py),
@@ -464,14 +464,24 @@ __global__ __launch_bounds__(256) void sv2_diffs_kernel(Sv2Args A) {
 // ---------------------------------------------------------------------------
 constexpr int SV2_RT = 1024;                 // lanes: 256 blocks x 4 lanes of 4 pixels
 constexpr int SV2_RING_ROWS = 256, SV2_RING_BLKS = 8;
+// A ring row is 8 blocks = 256 bytes, padded to 264: the 16 blocks a wavefront works on lie
+// on a diagonal (row + 1, block - 2), 264 - 64 = 200 bytes apart = 18 banks, and 18 k mod 32
+// is a different even bank for each of them (unpadded: 16 banks apart, two bank groups for
+// sixteen blocks).  Worth 4 % of the kernel's cycles (SQ_LDS_BANK_CONFLICT): the kernel is
+// bound by the vector instructions of its 16 wavefronts on one CU (SQ_ACTIVE_INST_VALU x 4
+// cycles = 94 % of its wave cycles, profiles/r03/samsung_v2_pmc/).
+constexpr int SV2_RING_STRIDE = SV2_RING_BLKS * 16 + 4; // in pixels
+constexpr int SV2_RING_PX = SV2_RING_ROWS * SV2_RING_STRIDE;
+constexpr size_t SV2_RING_BYTES = size_t(SV2_RING_PX + 16) * 2;
 constexpr int SV2_AHEAD = 8;                 // diagonals the loads run ahead (and the unroll: the
                                              // loop edge costs one full wait)
 
 __device__ __forceinline__ uint32_t sv2_ring_addr(int row, int col) {
-  return uint32_t(((row & (SV2_RING_ROWS - 1)) * SV2_RING_BLKS + ((col >> 4) & (SV2_RING_BLKS - 1))) * 16 +
-                  (col & 15));
+  return uint32_t((row & (SV2_RING_ROWS - 1)) * SV2_RING_STRIDE +
+                  ((col >> 4) & (SV2_RING_BLKS - 1)) * 16 + (col & 15));
 }
 
+typedef uint32_t sv2_u32x2 __attribute__((ext_vector_type(2)));
 struct Sv2Fetch {
   uint32_t hdr;
   uint2 diff; // four differences
@@ -489,15 +499,15 @@ __device__ __forceinline__ bool sv2_diag_block(int nb, int H, int t, int slot, i
   return rr < H && cc >= 0 && cc < nb;
 }
 
-// Every lane issues the same global loads and stores on every path of a step -- clamped
-// addresses for the lanes that have no block, a dump word for their stores: with a load or a
+// Every lane issues the same global loads and stores on every path of a step -- offsets
+// out of range for the lanes that have no block (buffer instructions drop those): with a load or a
 // store under an `if` the compiler cannot count what is in flight behind the loads it waits
 // for and waits for everything (s_waitcnt vmcnt(0)), which puts the latency of the loads
 // issued four diagonals ahead AND of the pixel stores into every step (1.35 us a step,
 // 12.2 ms a frame, with the conditional version).
 template <bool ALIGNED8>
 __global__ __launch_bounds__(SV2_RT) void sv2_recon_kernel(Sv2Args A) {
-  __shared__ __attribute__((aligned(16))) uint16_t ring[SV2_RING_ROWS * SV2_RING_BLKS * 16];
+  extern __shared__ __attribute__((aligned(16))) uint16_t ring[]; // SV2_RING_BYTES
   const Sv2JobDev& J = A.jobs[blockIdx.x];
   if (!J.valid)
     return;
@@ -512,19 +522,30 @@ __global__ __launch_bounds__(SV2_RT) void sv2_recon_kernel(Sv2Args A) {
   const uint32_t* hdr = A.hdr + J.blk_base;
   const int16_t* diffs = A.diffs + J.px_base;
   uint8_t* out = A.out_base + J.img_offset;
-  // (stores of lanes without a block: the slack behind the job's differences)
-  uint8_t* dump = reinterpret_cast<uint8_t*>(A.diffs + J.px_base + size_t(H) * J.width);
   const int hi = (1 << J.bits) - 1;
   const int init = int(J.init_val);
   const int W = int(J.width);
   const size_t pitch = J.pitch;
   Sv2Fetch f[SV2_AHEAD];
+  // Buffer loads and stores (a resource in scalar registers + a 32-bit offset; out of range =
+  // zero / dropped): with 64-bit address arithmetic in vector registers the compiler's
+  // temporaries landed on registers that loads were still in flight to, and every step
+  // waited for the loads of the step before.
+  const __amdgpu_buffer_rsrc_t rs_hdr = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint32_t*>(hdr), 0, int(uint32_t(H) * uint32_t(nb) * 4u), 0x00027000);
+  const __amdgpu_buffer_rsrc_t rs_diff = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int16_t*>(diffs), 0, int(uint32_t(H) * uint32_t(W) * 2u), 0x00027000);
+  const __amdgpu_buffer_rsrc_t rs_out =
+      __builtin_amdgcn_make_buffer_rsrc(out, 0, int(uint32_t(H) * uint32_t(pitch)), 0x00027000);
   auto fetch = [&](int t, Sv2Fetch& dst) {
     int r, c;
     const bool ok = sv2_diag_block(nb, H, t, slot, &r, &c) && t < T;
-    const int rr = ok ? r : 0, cc = ok ? c : 0;
-    dst.hdr = hdr[size_t(rr) * nb + cc];
-    dst.diff = *reinterpret_cast<const uint2*>(diffs + size_t(rr) * W + cc * 16 + px0);
+    const uint32_t okm = ok ? 0xFFFFFFFFu : 0u;
+    const uint32_t oh = (uint32_t(r) * uint32_t(nb) + uint32_t(c)) * 4u;
+    const uint32_t od = (uint32_t(r) * uint32_t(W) + uint32_t(c) * 16u + uint32_t(px0)) * 2u;
+    dst.hdr = __builtin_amdgcn_raw_buffer_load_b32(rs_hdr, oh | ~okm, 0, 0);
+    const sv2_u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(rs_diff, od | ~okm, 0, 0);
+    dst.diff = make_uint2(d.x, d.y);
   };
 #pragma unroll
   for (int k = 0; k < SV2_AHEAD; ++k)
@@ -540,56 +561,62 @@ __global__ __launch_bounds__(SV2_RT) void sv2_recon_kernel(Sv2Args A) {
       const int col = c * 16;
       const int d4[4] = {int(int16_t(f[k].diff.x)), int(int16_t(f[k].diff.x >> 16)),
                          int(int16_t(f[k].diff.y)), int(int16_t(f[k].diff.y >> 16))};
-      int v4[4] = {0, 0, 0, 0};
-      if (ok) {
-        if (motion == 7) { // :175-188: the two pixels to the left of the block
-          int b0 = init, b1 = init;
-          if (c != 0) {
-            const uint32_t two = *reinterpret_cast<const uint32_t*>(&ring[sv2_ring_addr(r, col - 2)]);
-            b0 = int(two & 0xFFFFu);
-            b1 = int(two >> 16);
-          }
+      // Without branches, and with the reference's per-pixel case distinctions folded into
+      // two offsets: every lane reads two ring pixels per pixel and selects.  (As branches
+      // -- motion 7 or not, averaged or not, the pixel's parity -- the lanes of a wavefront
+      // take all of them, one after the other: 266 instructions a step, 13 of them exec-mask
+      // saves; the kernel is bound by the instructions of its 16 wavefronts on one CU:
+      // 157 vector instructions a step and wavefront now.)
+      //   motion 7 (:175-188): the two pixels to the left of the block, init in block 0
+      //   else (:194-227): where row + pixel is odd, row - 2, same column + slide; where it
+      //   is even, row - 1, one column to the side (+1 for even pixels, -1 for odd ones);
+      //   averaged with the pixel two further (motion 2, 4).
+      // A lane's pixels are px0 + i with px0 a multiple of 4: pixels 0, 2 have the parity of
+      // the row, pixels 1, 3 the other one.
+      const bool left = motion == 7;
+      const int slide =
+          motion == 0 ? -4 : (motion <= 2 ? -2 : (motion <= 4 ? 0 : (motion == 5 ? 2 : 4)));
+      const uint32_t av = (motion == 2 || motion == 4) ? 2u : 0u;
+      const bool rodd = (r & 1) != 0;
+      const uint32_t rb0 = uint32_t(r & (SV2_RING_ROWS - 1)) * uint32_t(SV2_RING_STRIDE);
+      const uint32_t rb1 = uint32_t((r - 1) & (SV2_RING_ROWS - 1)) * uint32_t(SV2_RING_STRIDE);
+      const uint32_t rb2 = uint32_t((r - 2) & (SV2_RING_ROWS - 1)) * uint32_t(SV2_RING_STRIDE);
+      // pixels 0, 2 (A) and 1, 3 (B): ring row and column of the first of the two
+      const uint32_t rowA = left ? rb0 : (rodd ? rb2 : rb1);
+      const uint32_t rowB = left ? rb0 : (rodd ? rb1 : rb2);
+      const int colA = col + (left ? -2 : px0 + slide + (rodd ? 0 : 1));
+      const int colB = col + (left ? -1 : px0 + 1 + slide + (rodd ? -1 : 0));
+      const uint32_t step2 = left ? 0u : 2u; // pixels 2, 3 lie two columns further
+      constexpr uint32_t CM = uint32_t(SV2_RING_BLKS * 16 - 1);
+      const bool first = left && c == 0;
+      const int mul = scale * 2 + 1;
+      int v4[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            v4[i] = (i & 1) ? b1 : b0;
-        } else { // :194-227: sixteen pixels of the two rows above
-          const int slide =
-              motion == 0 ? -4 : (motion <= 2 ? -2 : (motion <= 4 ? 0 : (motion == 5 ? 2 : 4)));
-          const bool avg = motion == 2 || motion == 4;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int px = px0 + i;
-            int ref_row = r, ref_col = col + px + slide;
-            if ((r + px) & 1) {
-              ref_row -= 2;
-            } else {
-              ref_row -= 1;
-              ref_col += (px & 1) ? -1 : 1;
-            }
-            int base = int(ring[sv2_ring_addr(ref_row, ref_col)]);
-            if (avg)
-              base = (base + int(ring[sv2_ring_addr(ref_row, ref_col + 2)]) + 1) >> 1;
-            v4[i] = base;
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int v = v4[i] + d4[i] * (scale * 2 + 1) + scale;
-          v4[i] = v < 0 ? 0 : (v > hi ? hi : v);
-        }
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t row = (i & 1) ? rowB : rowA;
+        const uint32_t cc0 = uint32_t((i & 1) ? colB : colA) + ((i & 2) ? step2 : 0u);
+        const int p0 = int(ring[row + (cc0 & CM)]);
+        const int p2 = int(ring[row + ((cc0 + av) & CM)]);
+        int base = (p0 + p2 + 1) >> 1;
+        base = first ? init : base;
+        const int v = base + d4[i] * mul + scale;
+        v4[i] = v < 0 ? 0 : (v > hi ? hi : v);
       }
       const uint2 pk = make_uint2(uint32_t(v4[0]) | (uint32_t(v4[1]) << 16),
                                   uint32_t(v4[2]) | (uint32_t(v4[3]) << 16));
-      if (ok)
-        *reinterpret_cast<uint2*>(&ring[sv2_ring_addr(r, col + px0)]) = pk;
-      uint8_t* o = ok ? out + size_t(r) * pitch + size_t(col + px0) * 2 : dump;
+      // (lanes without a block: the dump words behind the ring, an offset out of range)
+      const uint32_t okm = ok ? 0xFFFFFFFFu : 0u;
+      const uint32_t wi = (sv2_ring_addr(r, col + px0) & okm) | (uint32_t(SV2_RING_PX) & ~okm);
+      *reinterpret_cast<uint2*>(&ring[wi]) = pk;
+      const uint32_t oo = (uint32_t(r) * uint32_t(pitch) + uint32_t(col + px0) * 2u) | ~okm;
       if (ALIGNED8) {
-        *reinterpret_cast<uint2*>(o) = pk;
+        const sv2_u32x2 pv = {pk.x, pk.y};
+        __builtin_amdgcn_raw_buffer_store_b64(pv, rs_out, oo, 0, 0);
       } else {
-        reinterpret_cast<uint16_t*>(o)[0] = uint16_t(v4[0]);
-        reinterpret_cast<uint16_t*>(o)[1] = uint16_t(v4[1]);
-        reinterpret_cast<uint16_t*>(o)[2] = uint16_t(v4[2]);
-        reinterpret_cast<uint16_t*>(o)[3] = uint16_t(v4[3]);
+        __builtin_amdgcn_raw_buffer_store_b16(uint16_t(v4[0]), rs_out, oo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b16(uint16_t(v4[1]), rs_out, oo | ~okm, 2, 0);
+        __builtin_amdgcn_raw_buffer_store_b16(uint16_t(v4[2]), rs_out, oo | ~okm, 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b16(uint16_t(v4[3]), rs_out, oo | ~okm, 6, 0);
       }
       fetch(t + SV2_AHEAD, f[k]);
       __syncthreads();
@@ -749,10 +776,18 @@ int samsung_v2_plan_run(Sv2Plan* p, const void* in_dev, void* out_dev, hipStream
   mark("sv2_parse_kernel");
   hipLaunchKernelGGL(sv2_diffs_kernel, dim3((p->max_blocks + 255) / 256, n), dim3(256), 0, s, A);
   mark("sv2_diffs_kernel");
+  // (the ring is 66 KB: more than a kernel gets without asking)
+  static const bool ring_ok =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&sv2_recon_kernel<true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, int(SV2_RING_BYTES)) == hipSuccess &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&sv2_recon_kernel<false>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, int(SV2_RING_BYTES)) == hipSuccess;
+  if (!ring_ok)
+    return RSX_ERR_DEVICE;
   if (p->aligned8)
-    hipLaunchKernelGGL(sv2_recon_kernel<true>, dim3(n), dim3(SV2_RT), 0, s, A);
+    hipLaunchKernelGGL(sv2_recon_kernel<true>, dim3(n), dim3(SV2_RT), SV2_RING_BYTES, s, A);
   else
-    hipLaunchKernelGGL(sv2_recon_kernel<false>, dim3(n), dim3(SV2_RT), 0, s, A);
+    hipLaunchKernelGGL(sv2_recon_kernel<false>, dim3(n), dim3(SV2_RT), SV2_RING_BYTES, s, A);
   mark("sv2_recon_kernel");
   RSX_HIP_CHECK(ctx, hipGetLastError());
   return RSX_OK;
