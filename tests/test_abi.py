@@ -241,6 +241,38 @@ def test_samsung_v1_validate_matches_oracle(lib, oracle):
     assert seen == {abi.RSX_OK, abi.RSX_ERR_INVALID_ARG}
 
 
+def test_samsung_v2_validate_is_the_constructor(lib, oracle):
+    """rsx_samsung_v2_validate + the header fields of abi.SamsungV2Desc.from_header against
+    the oracle's restatement of the constructor (SamsungV2Decompressor.cpp:87-141): a
+    header the oracle accepts parses to a descriptor that validates, one it rejects does
+    not (for the fields the descriptor carries)."""
+    import samsung_v2_cases as V2
+    rng = np.random.default_rng(19)
+    seen = set()
+    for trial in range(200):
+        bits = int(rng.choice([12, 14]))
+        h, w = int(rng.integers(2, 6)), 16 * int(rng.integers(1, 4))
+        data, _ = V2.encode(rng, np.full((h, w), 1000, np.int64), bits, int(rng.integers(0, 8)))
+        data = data.copy()
+        if trial % 2:
+            data[int(rng.integers(0, 16))] ^= 1 << int(rng.integers(0, 8))
+        d, flags = abi.SamsungV2Desc.from_header(data[:16])
+        img = HostImage(w, h)
+        v = img.view()
+        mine = lib.rsx_samsung_v2_validate(C.byref(d), C.byref(v))
+        if d.bit_depth != bits or flags > 7:
+            mine = abi.RSX_ERR_INVALID_ARG      # (checked by the constructor's caller side)
+        host = HostImage(w, h)
+        ref = oracle.samsung_v2(bits, data, host)
+        # the oracle goes on to decode: a header it accepts may still meet a damaged row
+        if mine != 0:
+            assert ref != 0, trial
+        if ref == 0:
+            assert mine == 0, trial
+        seen.add(mine)
+    assert seen == {abi.RSX_OK, abi.RSX_ERR_INVALID_ARG}
+
+
 def test_sony_arw1_validate_matches_oracle(lib, oracle):
     rng = np.random.default_rng(18)
     seen = set()
