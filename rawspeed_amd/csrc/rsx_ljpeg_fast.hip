@@ -1131,6 +1131,14 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     if (uint32_t(j) == F.misc[M_UNRES])
       F.misc[M_UNRESB] = before;
     cnt_wg = uni(F.misc[M_WCNT] + F.misc[M_WCNT + 1] + F.misc[M_WCNT + 2] + F.misc[M_WCNT + 3]);
+    const uint32_t exit_now = uni(rec_st(F.rec[LJ_T - 1]));
+    const uint32_t entry_now = uni(rec_st(F.rec[0]));
+    // 4a. the workgroup's record (LOCAL: entry, exit and symbols of this decode) as soon as
+    // its three fields are known -- the scan of the difference sums below is nobody else's
+    // business, and the successors' first poll should find the record
+    if (lb != 0 && j == 0)
+      lb_store(a.lb + size_t(b) * LF_LB_WORDS,
+               lb0_make(LB0_LOCAL, entry_now, st_to7(exit_now), cnt_wg, 0));
     {
       const uint2 r = lj_rot_fields<N>(my_sums, before & uint32_t(N - 1));
       const uint2 pincl = wave_scan_pk2(r, lane);
@@ -1148,11 +1156,8 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
         S_wg = pk_add2(S_wg, t);
       }
     }
-    const uint32_t exit_now = uni(rec_st(F.rec[LJ_T - 1]));
-    const uint32_t entry_now = uni(rec_st(F.rec[0]));
 
-    // 4. the workgroup's record (LOCAL: entry, exit and symbols of this decode), then
-    // look-back 0: the predecessor's exit and the index of the workgroup's first symbol
+    // 4. look-back 0: the predecessor's exit and the index of the workgroup's first symbol
     // in one sweep over the predecessors' records.  A wrong entry assumption is repaired
     // and the record published again; the symbol index does not depend on it.
     if (attempt == 0) {
@@ -1163,9 +1168,6 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     }
     if (lb == 0)
       break;
-    if (j == 0)
-      lb_store(a.lb + size_t(b) * LF_LB_WORDS,
-               lb0_make(LB0_LOCAL, entry_now, st_to7(exit_now), cnt_wg, 0));
     if (attempt == 1)
       break;
     uint32_t pe = entry_now, bs = lb * 15500u;
