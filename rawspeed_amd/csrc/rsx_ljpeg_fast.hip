@@ -11,30 +11,40 @@
 // FL_SLOW and redone by it (LjArgs::pass == 1).
 //
 // Per workgroup (256 lanes = 255 own 64-byte subsequences + a copy of the predecessor's
-// last one; workgroups take TICKETS so that every predecessor is resident or finished):
-//  1. warm-up: lane j parses subsequence j-1 from bit 0; where that parse runs into
-//     subsequence j is its start guess (Huffman streams self-synchronise).  8 VALU
-//     instructions per symbol, 6 of them of the 2-cycle class.
+// last one; workgroups take TICKETS -- the streams' blocks interleaved -- so that every
+// predecessor is resident or finished):
+//  1. start guesses: made by lj_unstuff_kernel (rsx_ljpeg.hip: a parse of the three
+//     subsequences before each one from bit 0 -- Huffman streams self-synchronise --, the
+//     symbol grid of constant runs from their bits, and the LDS level of the launch:
+//     the kernel is launched at up to three allocations and the one whose level the
+//     data needs does the work).  Image, table, guesses and the stream's flags are asked
+//     for as soon as the ticket names the block.
 //  2. decode: every lane decodes its subsequence ONCE from its guess and KEEPS the
 //     running sums of its differences (by component phase, packed 2 x 16 bit) in 64
-//     VGPRs: 17 VALU instructions per symbol.  A lane that meets a code longer than
+//     VGPRs: 16 VALU instructions per symbol.  A lane that meets a code longer than
 //     the 10-bit LUT, an invalid code or SSSS = 16 stops there.
-//  3. Jacobi rounds (as lj_sync_kernel): subsequences whose guess was not their
-//     predecessor's exit, or that stopped, are re-decoded by the first lanes with the
-//     general loop into an LDS side buffer; their owners fetch the sums from there.
+//  3. Jacobi rounds: subsequences whose guess was not their predecessor's exit, or that
+//     stopped, are re-decoded by the first lanes into an LDS side buffer (entries handed
+//     out in slot order); after the first round only the head of a run of inconsistent
+//     slots is redone.  What the rounds cannot finish only matters if a delivered symbol
+//     lies behind it (trailing bytes, padding rows: nobody's business).
 //  4. look-back 0 (decoupled, one 8-byte granule per workgroup: assumed entry state,
-//     exit state, symbols, inclusive symbol base): the workgroup's entry state is
-//     checked against its predecessor's exit (1.4 % differ: those re-converge from
-//     the true state) and its first symbol's index comes out of the walk.
-//  5. rows: with the index known, the lanes that hold the first MCU of a stream row
-//     put (running sum before it, its difference) into a row table; a scan over the
-//     rows gives the workgroup's transfer of the predictor state
+//     exit state, symbols, inclusive symbol base; published as soon as the three are
+//     known): the workgroup's entry state is checked against its predecessor's exit (a
+//     wrong one is repaired and published again) and its first symbol's index comes out
+//     of the walk.
+//  5. staging: ALL running sums of the workgroup go to LDS in stream order, over the LUT,
+//     the image and the records, which are dead by then.
+//  6. rows: the lanes read, for the stream rows that start in the workgroup, the first
+//     MCU's (running sum before it, its difference) from the staged samples; a scan over
+//     the rows gives the workgroup's transfer of the predictor state
 //        (T = left-neighbour values, Vc = first-MCU values of the last started row),
 //     look-back 1 carries that state across workgroups.
-//  6. output: wave by wave the running sums are staged in LDS in stream order (the
-//     un-stuffed image is dead by then), and the whole workgroup writes them out,
-//     run by run (row, kept width, CR2 strip), as 16-byte stores on the destination's
-//     16-byte grid: pixel = running sum + constant of (row, component).
+//  7. output: the whole workgroup writes the staged samples out, run by run (row, kept
+//     width, CR2 strip), as 16-byte stores on the destination's 16-byte grid:
+//     pixel = staged sample + constant of (row, component).
+// A stream the kernel cannot finish (periodic data that is not a run of the zero code,
+// invalid codes, fewer than ~4 bits per symbol) is flagged FL_SLOW.
 //
 // Arithmetic (everything mod 2^16; cf. tests/test_direct_recon_model.py): with Ploc(i)
 // the running sum of i's component over the workgroup's symbols up to i,
