@@ -84,6 +84,11 @@ constexpr uint32_t LF_ABLATE = 0;
 #endif
 
 // ---- LDS layout (bytes) ------------------------------------------------------
+// (The LUT is addressed ABSOLUTELY -- (window >> 19) & 0x1FF8 is the LDS address of its
+// entry --, so the kernel's dynamic LDS has to start at LDS address 0: nothing in it may
+// bring static LDS along.  __syncthreads_or() does -- 256 bytes, .amdhsa_group_segment_
+// fixed_size -- and with it every look-up read 256 bytes off: wrong symbols, broken
+// look-back links, workgroups spinning to their limits.)
 constexpr uint32_t LF_OFF_LUT = 0;                       // 1024 x uint2: LDS address 0
 constexpr uint32_t LF_OFF_B = 8192;
 constexpr uint32_t LF_OFF_REC = LF_OFF_B + LF_BW * LJ_T * 4;   // u32[256]
