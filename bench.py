@@ -273,44 +273,23 @@ def cfg5_leg(args, ctx, torch, grp, rank, n_gpus, stream):
                                                          first_frame=lo)
     dist_info = {"mode": "every rank synthesises its own shard (no exchange)"}
     if grp.enabled and (args.broadcast or args.scatter):
+        # rank 0 assembles every rank's OWN shard (they differ in content and in size) and
+        # either broadcasts the whole batch or sends rank r exactly its shard
         shard_bytes = int(inp5.numel())
-        grp.barrier()
-        t0 = time.perf_counter()
-        if args.broadcast:
-            # rank 0 assembles the WHOLE job's packed batch (every rank's own, different
-            # shard) and broadcasts it; a rank keeps its slice
-            sizes = [bench_ljpeg.cfg5_frame_bytes(meta, g) for g in range(total)]
-            start = sum(sizes[:lo])
-            if rank == 0:
-                whole = bench_ljpeg.cfg5_assemble(torch, meta, range(total))
-            else:
-                whole = torch.empty(sum(sizes), dtype=torch.uint8, device="cuda")
-            torch.cuda.synchronize()
-            grp.barrier()
-            t0 = time.perf_counter()
-            grp.broadcast_bytes(whole, src=0)
-            torch.cuda.synchronize()
-            grp.barrier()
-            dt = grp.max_over_ranks(time.perf_counter() - t0)
-            inp5 = whole[start:start + shard_bytes].clone()
-            moved = int(whole.numel())
-            del whole
-            mode = "RCCL broadcast of the whole packed batch from rank 0 (shards differ)"
-        else:
-            recv = torch.empty_like(inp5)
-            torch.cuda.synchronize()
-            grp.barrier()
-            t0 = time.perf_counter()
-            grp.scatter_shards(inp5, recv, src=0)
-            torch.cuda.synchronize()
-            grp.barrier()
-            dt = grp.max_over_ranks(time.perf_counter() - t0)
-            if rank != 0:
-                inp5 = recv
-            moved = shard_bytes * (n_gpus - 1)
-            mode = "grouped RCCL send/recv: rank 0 sends every other rank its shard"
-        dist_info = {"mode": mode, "ms": round(dt * 1e3, 2), "bytes": moved,
-                     "gbps": round(moved / dt / 1e9, 1)}
+        mode = "broadcast" if args.broadcast else "scatter"
+        got, dt, moved = rdist.distribute_units(
+            grp, total, lambda g: bench_ljpeg.cfg5_frame_bytes(meta, g),
+            lambda units: bench_ljpeg.cfg5_assemble(torch, meta, units), mode,
+            lambda n: torch.empty(n, dtype=torch.uint8, device="cuda"),
+            sync=torch.cuda.synchronize)
+        assert int(got.numel()) == shard_bytes, (int(got.numel()), shard_bytes)
+        inp5 = got
+        dist_info = {"mode": ("RCCL broadcast of the whole packed batch from rank 0 (shards differ)"
+                              if args.broadcast else
+                              "grouped RCCL send/recv: rank 0 sends every other rank ITS shard "
+                              "(shards differ in content and size)"),
+                     "ms": round(dt * 1e3, 2), "bytes": moved,
+                     "gbps": round(moved / max(dt, 1e-9) / 1e9, 1)}
     plan5.run(inp5.data_ptr(), out5.data_ptr(), stream)
     rc5, st5, cons5 = plan5.results()
     ref_frames = cpu5 = None

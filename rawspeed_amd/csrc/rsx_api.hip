@@ -144,26 +144,34 @@ int flatten_unpack_job(const rsx_unpack_job& j, UnpackJobDev* out, int* order) {
 // ---------------------------------------------------------------------------
 // Misc
 // ---------------------------------------------------------------------------
+// The lane pool is capped (RSX_MAX_LANES: every lane owns a stream, staging for a whole
+// image and a cached plan with its scratch): a caller beyond the cap waits for a lane to
+// come back instead of growing the pool with the thread count of the host program.
 rsx_ctx::HostLane* rsx_ctx::acquire_lane() {
-  {
-    std::lock_guard<std::mutex> g(lanes_mu);
+  std::unique_lock<std::mutex> g(lanes_mu);
+  while (true) {
     if (!lanes_free.empty()) {
       HostLane* l = lanes_free.back();
       lanes_free.pop_back();
       return l;
     }
+    if (lanes_all.size() < size_t(RSX_MAX_LANES))
+      break;
+    lanes_cv.wait(g);
   }
   auto l = std::make_unique<HostLane>();
   if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess)
     return nullptr;
-  std::lock_guard<std::mutex> g(lanes_mu);
   lanes_all.push_back(std::move(l));
   return lanes_all.back().get();
 }
 
 void rsx_ctx::release_lane(HostLane* l) {
-  std::lock_guard<std::mutex> g(lanes_mu);
-  lanes_free.push_back(l);
+  {
+    std::lock_guard<std::mutex> g(lanes_mu);
+    lanes_free.push_back(l);
+  }
+  lanes_cv.notify_one();
 }
 
 namespace {
@@ -238,15 +246,17 @@ extern "C" void rsx_ctx_destroy(rsx_ctx* ctx) {
     (void)hipStreamDestroy(ctx->stream);
   }
   for (auto& l : ctx->lanes_all) {
-    if (l->stream) {
+    // the cached plan first: its destructor synchronises the stream it last ran on,
+    // which is this lane's
+    if (l->stream)
       (void)hipStreamSynchronize(l->stream);
-      (void)hipStreamDestroy(l->stream);
-    }
-    l->d_in.release();
-    l->d_out.release();
     if (l->cached_plan)
       rsx_plan_destroy(l->cached_plan);
     l->cached_plan = nullptr;
+    if (l->stream)
+      (void)hipStreamDestroy(l->stream);
+    l->d_in.release();
+    l->d_out.release();
   }
   delete ctx;
 }
@@ -1586,6 +1596,29 @@ HostRect out_rect(const rsx_hasselblad_job& j) {
   return {0, size_t(j.img.dim_y), 0, size_t(j.img.dim_x) * 2};
 }
 
+// What a job's plan is made FROM beyond the bytes of its struct: data behind host pointers.
+// The plan-cache key holds the contents, never the address (a freed and re-allocated
+// curve at the same address, or one mutated in place, must not find the old plan).
+template <typename JobT>
+void key_job(std::vector<uint8_t>& key, const JobT& job) {
+  JobT j = job;
+  j.img.data = nullptr;
+  const uint8_t* p = reinterpret_cast<const uint8_t*>(&j);
+  key.insert(key.end(), p, p + sizeof(JobT));
+}
+template <>
+void key_job<rsx_nikon_job>(std::vector<uint8_t>& key, const rsx_nikon_job& job) {
+  rsx_nikon_job j = job;
+  j.img.data = nullptr;
+  j.desc.curve = nullptr;
+  const uint8_t* p = reinterpret_cast<const uint8_t*>(&j);
+  key.insert(key.end(), p, p + sizeof j);
+  if (job.desc.curve && job.desc.curve_size > 0 && job.desc.curve_size <= 65536) {
+    const uint8_t* c = reinterpret_cast<const uint8_t*>(job.desc.curve);
+    key.insert(key.end(), c, c + size_t(job.desc.curve_size) * sizeof(uint16_t));
+  }
+}
+
 template <typename JobT, typename CreateFn>
 int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
                       const uint8_t* const* ins, const rsx_image* img,
@@ -1611,7 +1644,20 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
     jobs[i].img = *img;
     jobs[i].img_offset = 0;
   }
-  const size_t out_bytes = size_t(img->pitch_bytes) * size_t(img->dim_y);
+  // the output staging holds the image ROWS the jobs write (a DNG tile call: the tile's
+  // rows, not the image); the kernels get the address row 0 would have
+  size_t row_lo = size_t(img->dim_y), row_hi = 0;
+  for (int i = 0; i < n; ++i) {
+    const HostRect r = out_rect(jobs[i]);
+    row_lo = std::min(row_lo, r.row0);
+    row_hi = std::max(row_hi, std::min(r.row0 + r.rows, size_t(img->dim_y)));
+  }
+  if (row_hi <= row_lo) {
+    row_lo = 0;
+    row_hi = size_t(img->dim_y);
+  }
+  const size_t out_bytes = size_t(img->pitch_bytes) * (row_hi - row_lo);
+  const size_t out_skip = size_t(img->pitch_bytes) * row_lo;
   LaneGuard lane(ctx); // staging + stream of this call
   if (!lane.lane)
     return RSX_ERR_DEVICE;
@@ -1627,15 +1673,14 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
                                       ins[i], jobs[i].in_bytes, hipMemcpyHostToDevice, s));
   // the lane's cached plan, if it was made from these very jobs (descriptors, sizes,
   // offsets, image geometry; not the host pointer of the image)
-  std::vector<uint8_t> key(sizeof(void*) + size_t(n) * sizeof(JobT));
+  std::vector<uint8_t> key;
+  key.reserve(sizeof(void*) + size_t(n) * sizeof(JobT));
   {
     const void* fn = reinterpret_cast<const void*>(create);
-    std::memcpy(key.data(), &fn, sizeof fn);
-    for (int i = 0; i < n; ++i) {
-      JobT j = jobs[i];
-      j.img.data = nullptr;
-      std::memcpy(key.data() + sizeof fn + size_t(i) * sizeof(JobT), &j, sizeof(JobT));
-    }
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(&fn);
+    key.insert(key.end(), p, p + sizeof fn);
+    for (int i = 0; i < n; ++i)
+      key_job(key, jobs[i]);
   }
   rsx_plan* plan = nullptr;
   if (lane.lane->cached_plan && lane.lane->cached_key == key) {
@@ -1651,7 +1696,8 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
   }
   std::vector<int32_t> st(n, RSX_OK);
   std::vector<uint32_t> cons(n, 0);
-  int rc = rsx_plan_run(plan, lane.lane->d_in.ptr, lane.lane->d_out.ptr, s);
+  uint8_t* const out_row0 = static_cast<uint8_t*>(lane.lane->d_out.ptr) - out_skip;
+  int rc = rsx_plan_run(plan, lane.lane->d_in.ptr, out_row0, s);
   if (rc == RSX_OK)
     rc = rsx_plan_results(plan, st.data(), cons.data());
   if (rc == RSX_ERR_DEVICE || rc == RSX_ERR_NOMEM) {
@@ -1697,7 +1743,7 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
     const size_t off = r.row0 * img->pitch_bytes + r.byte0;
     RSX_HIP_CHECK(ctx, hipMemcpy2DAsync(static_cast<uint8_t*>(img->data) + off,
                                         img->pitch_bytes,
-                                        static_cast<uint8_t*>(lane.lane->d_out.ptr) + off,
+                                        out_row0 + off,
                                         img->pitch_bytes, r.bytes, r.rows,
                                         hipMemcpyDeviceToHost, s));
   }

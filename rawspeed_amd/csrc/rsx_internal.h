@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -188,7 +189,9 @@ struct rsx_ctx {
     struct rsx_plan* cached_plan = nullptr;
     std::vector<uint8_t> cached_key;
   };
+  static constexpr int RSX_MAX_LANES = 16;
   std::mutex lanes_mu;
+  std::condition_variable lanes_cv;
   std::vector<std::unique_ptr<HostLane>> lanes_all;
   std::vector<HostLane*> lanes_free;
   HostLane* acquire_lane();

@@ -2117,6 +2117,13 @@ struct LJpegPlan {
   bool any_fast = false;       // some stream takes the single-pass kernel
   uint32_t fast_lds = 0;       // LDS bytes of its launches
   std::vector<uint8_t> slow_strikes; // per stream: consecutive runs it went to the slow path
+  // streams taken off the single-pass kernel after two such runs: the value `fast` had and
+  // the run in which it was cleared (0: not demoted).  The demotion DECAYS: a cached plan
+  // sees other images later (host-pointer calls), and one pair of hard frames must not
+  // send every later frame of that layout to the slower pipeline for good.
+  std::vector<uint8_t> demoted_fast;
+  std::vector<uint32_t> demoted_at;
+  static constexpr uint32_t DEMOTION_RUNS = 8;
   bool any_pipeline = false;   // some stream takes the multi-kernel pipeline in the first pass
   bool expect_slow = false;    // the last run left FL_SLOW streams: launch the second pass at once
   bool slow_pass_launched = false; // ... this run already has
@@ -2949,6 +2956,24 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
   if (p->streams.empty())
     return RSX_OK;
   ++p->run_count;
+  // demoted streams get the single-pass kernel back after DEMOTION_RUNS runs
+  if (!p->demoted_at.empty()) {
+    bool back = false;
+    for (size_t k = 0; k < p->streams.size(); ++k)
+      if (p->demoted_at[k] != 0 && p->run_count - p->demoted_at[k] >= LJpegPlan::DEMOTION_RUNS) {
+        p->streams[k].fast = p->demoted_fast[k];
+        p->demoted_at[k] = 0;
+        p->slow_strikes[k] = 0;
+        back = true;
+      }
+    if (back) {
+      RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->d_streams.ptr, p->streams.data(),
+                                        p->streams.size() * sizeof(LjStreamDev),
+                                        hipMemcpyHostToDevice, s));
+      RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+      p->any_fast = true;
+    }
+  }
   LjArgs a = make_args(p, in_dev, out_dev);
   a.fuse_consumed = (p->any_fast && !p->any_pipeline && !p->any_legacy) ? 1u : 0u;
   // results: marker_pos = 0xFFFFFFFF, everything else 0
@@ -3035,6 +3060,10 @@ int converge(LJpegPlan* p, hipStream_t s) {
         continue;
       if (p->h_results[k].flags & FL_SLOW) {
         if (++p->slow_strikes[k] >= 2) {
+          p->demoted_fast.resize(p->streams.size(), 0);
+          p->demoted_at.resize(p->streams.size(), 0);
+          p->demoted_fast[k] = uint8_t(p->streams[k].fast);
+          p->demoted_at[k] = p->run_count ? p->run_count : 1u;
           p->streams[k].fast = 0;
           changed = true;
         }

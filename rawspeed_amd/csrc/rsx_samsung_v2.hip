@@ -324,6 +324,17 @@ __device__ __forceinline__ uint32_t sv2_next_boundary(const Sv2JobDev& J, const 
   return uint32_t((a + used + 15u) >> 4);
 }
 
+// One step along a successor table.  Boundary n_bounds -- 16 * n_bounds > in_bytes, reached
+// when in_bytes % 16 != 0 and a row ends in the last partial 16 bytes -- is a legal
+// successor: "the next row starts past the data".  It stays what it is (the row that starts
+// there fails with RSX_ERR_IO in sv2_parse_kernel, data.skipBytes() :314-316, like the rows
+// the fill kernel reaches the same way); only NONE and values beyond it mean "not reached".
+__device__ __forceinline__ uint32_t sv2_follow(const uint32_t* tab, uint32_t x, uint32_t n_bounds) {
+  if (x == SV2_NONE || x > n_bounds)
+    return SV2_NONE;
+  return x == n_bounds ? n_bounds : tab[x];
+}
+
 __global__ __launch_bounds__(256) void sv2_spec_kernel(Sv2Args A) {
   const Sv2JobDev& J = A.jobs[blockIdx.y];
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -340,7 +351,7 @@ __global__ __launch_bounds__(256) void sv2_double_kernel(Sv2Args A, const uint32
   if (!J.valid || i >= J.n_bounds)
     return;
   const uint32_t x = from[J.bound_base + i];
-  to[J.bound_base + i] = (x == SV2_NONE || x >= J.n_bounds) ? SV2_NONE : from[J.bound_base + x];
+  to[J.bound_base + i] = sv2_follow(from + J.bound_base, x, J.n_bounds);
 }
 
 // rows 0 and 1 (their histories start at 7, :325-326), then every SV2_HOP-th row
@@ -363,8 +374,7 @@ __global__ void sv2_chain_kernel(Sv2Args A, const uint32_t* hop) {
   }
   for (uint32_t r = 2; r < height; r += uint32_t(SV2_HOP)) {
     rs[r] = x;
-    if (x != SV2_NONE)
-      x = x < n_bounds ? hop_j[x] : SV2_NONE;
+    x = sv2_follow(hop_j, x, n_bounds);
   }
 }
 
@@ -379,8 +389,7 @@ __global__ __launch_bounds__(256) void sv2_fill_kernel(Sv2Args A) {
   const uint32_t* next_j = A.next + J.bound_base;
   uint32_t x = rs[r0];
   for (uint32_t r = r0 + 1; r < r0 + uint32_t(SV2_HOP) && r < height; ++r) {
-    if (x != SV2_NONE)
-      x = x < n_bounds ? next_j[x] : SV2_NONE;
+    x = sv2_follow(next_j, x, n_bounds);
     rs[r] = x;
   }
 }
@@ -734,6 +743,16 @@ int samsung_v2_plan_run(Sv2Plan* p, const void* in_dev, void* out_dev, hipStream
   const uint32_t n = uint32_t(p->jobs.size());
   if (p->max_rows == 0)
     return RSX_OK; // (every job was rejected by the host)
+  // The reconstruction's LDS ring is 66 KB: more than a kernel gets without asking, and
+  // the attribute is per DEVICE (a function-local static set it for whichever device was
+  // current on the process's first call).  Asked for on the context's device, before the
+  // timer is begun.
+  if (hipSetDevice(ctx->device) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&sv2_recon_kernel<true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, int(SV2_RING_BYTES)) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&sv2_recon_kernel<false>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, int(SV2_RING_BYTES)) != hipSuccess)
+    return RSX_ERR_DEVICE;
   if (timer)
     timer->begin(s);
   Sv2Args A{};
@@ -776,14 +795,6 @@ int samsung_v2_plan_run(Sv2Plan* p, const void* in_dev, void* out_dev, hipStream
   mark("sv2_parse_kernel");
   hipLaunchKernelGGL(sv2_diffs_kernel, dim3((p->max_blocks + 255) / 256, n), dim3(256), 0, s, A);
   mark("sv2_diffs_kernel");
-  // (the ring is 66 KB: more than a kernel gets without asking)
-  static const bool ring_ok =
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&sv2_recon_kernel<true>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, int(SV2_RING_BYTES)) == hipSuccess &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&sv2_recon_kernel<false>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, int(SV2_RING_BYTES)) == hipSuccess;
-  if (!ring_ok)
-    return RSX_ERR_DEVICE;
   if (p->aligned8)
     hipLaunchKernelGGL(sv2_recon_kernel<true>, dim3(n), dim3(SV2_RT), SV2_RING_BYTES, s, A);
   else

@@ -73,21 +73,25 @@ class Group:
             self.dist.broadcast(tensor, src=src)
         return tensor
 
-    def scatter_shards(self, send, recv, src=0):
-        """Every rank but `src` receives one shard into `recv`; `src` sends `send` (its own
-        copy of a shard -- the shards of the synthetic batch are identical) to each of them
-        as one group of point-to-point operations (ncclGroupStart/End underneath)."""
-        if not self.enabled:
-            return
+    def scatter_shards(self, shards, recv, src=0):
+        """Rank `src` holds `shards`, one uint8 tensor PER RANK (they differ in content and
+        in size: shard r is what rank r's plan expects); every other rank receives its own
+        into `recv`, which it has sized from the same unit sizes.  One group of
+        point-to-point operations (ncclGroupStart/End underneath): 1/N of the bytes per
+        xGMI link instead of the whole batch around a ring.  Returns the rank's shard."""
+        if not self.enabled or self.world == 1:
+            return shards[self.rank] if shards is not None else recv
         if self.rank == src:
-            ops = [self.dist.P2POp(self.dist.isend, send, r)
+            assert len(shards) == self.world
+            ops = [self.dist.P2POp(self.dist.isend, shards[r], r)
                    for r in range(self.world) if r != src]
+            mine = shards[src]
         else:
             ops = [self.dist.P2POp(self.dist.irecv, recv, src)]
-        if not ops:  # a world of one
-            return
+            mine = recv
         for req in self.dist.batch_isend_irecv(ops):
             req.wait()
+        return mine
 
     def gather_objects(self, obj, dst=0):
         if not self.enabled:
@@ -100,3 +104,50 @@ class Group:
         if self.enabled and self.dist.is_initialized():
             self.dist.barrier()
             self.dist.destroy_process_group()
+
+
+def distribute_units(grp, n_units, unit_bytes, assemble, mode, empty, sync=lambda: None,
+                     clock=None):
+    """Hand the packed input of a batch of `n_units` independent units (frames) out from
+    rank 0 -- the only exchange the workload has (BASELINE configs[4]).
+
+      unit_bytes(g)        packed size of global unit g (every rank can compute it)
+      assemble(units)      rank 0 only: the packed bytes of the given global units, one tensor
+      mode                 "broadcast": the WHOLE batch to everybody, a rank keeps its slice;
+                           "scatter":   rank r is sent exactly ITS shard (shard_range), sized
+                                        from unit_bytes -- the shards differ in content and size
+      empty(nbytes)        an uninitialised uint8 tensor on the rank's device
+      sync()               device synchronisation around the timed exchange (cuda)
+
+    Returns (this rank's shard, seconds = max over ranks, bytes moved)."""
+    import time
+    clock = clock or time.perf_counter
+    world, rank = grp.world, grp.rank
+    sizes = [int(unit_bytes(g)) for g in range(n_units)]
+    ranges = [shard_range(n_units, world, r) for r in range(world)]
+    shard_bytes = [sum(sizes[lo:hi]) for lo, hi in ranges]
+    lo, hi = ranges[rank]
+    if mode == "broadcast":
+        whole = assemble(range(n_units)) if rank == 0 else empty(sum(sizes))
+        sync()
+        grp.barrier()
+        t0 = clock()
+        grp.broadcast_bytes(whole, src=0)
+        sync()
+        grp.barrier()
+        dt = grp.max_over_ranks(clock() - t0)
+        start = sum(sizes[:lo])
+        mine = whole[start:start + shard_bytes[rank]].clone()
+        return mine, dt, int(whole.numel())
+    if mode != "scatter":
+        raise ValueError(mode)
+    shards = [assemble(range(*ranges[r])) for r in range(world)] if rank == 0 else None
+    recv = None if rank == 0 else empty(shard_bytes[rank])
+    sync()
+    grp.barrier()
+    t0 = clock()
+    mine = grp.scatter_shards(shards, recv, src=0)
+    sync()
+    grp.barrier()
+    dt = grp.max_over_ranks(clock() - t0)
+    return mine, dt, sum(shard_bytes) - shard_bytes[0]

@@ -41,6 +41,32 @@ def main():
         img = HostImage(W, H)
         assert oracle.unpack(d, packed[f * H * pitch:(f + 1) * H * pitch], img) == 0
         mine[f] = G.image_hash(img.pixels())
+    # The cfg-5 distribution code of bench.py (dist.distribute_units) with units that differ
+    # in content AND in byte count: every rank must end up with exactly the bytes its own
+    # plan expects (what it would have synthesised for its shard), in both modes.
+    def unit(g):  # deterministic, size and content depend on g
+        r = np.random.default_rng(7000 + g)
+        return r.integers(0, 256, size=1000 + 137 * ((g * 5) % 7), dtype=np.uint8)
+    n_units = 11
+    want_mine = np.concatenate([unit(g) for g in range(*dist.shard_range(n_units, grp.world,
+                                                                       grp.rank))] or
+                               [np.zeros(0, np.uint8)])
+    for mode in ("scatter", "broadcast"):
+        calls = []
+
+        def assemble(units):
+            assert grp.rank == 0     # only rank 0 owns the batch
+            calls.append(list(units))
+            return torch.from_numpy(np.concatenate([unit(g) for g in units] or
+                                                   [np.zeros(0, np.uint8)]))
+        got, dt, moved = dist.distribute_units(
+            grp, n_units, lambda g: unit(g).size, assemble, mode,
+            lambda n: torch.zeros(n, dtype=torch.uint8))
+        assert got.numpy().tobytes() == want_mine.tobytes(), (mode, grp.rank)
+        total_b = sum(unit(g).size for g in range(n_units))
+        own0 = sum(unit(g).size for g in range(*dist.shard_range(n_units, grp.world, 0)))
+        assert moved == (total_b if mode == "broadcast" else total_b - own0), (mode, moved)
+        assert dt >= 0.0
     grp.barrier()
     t_max = grp.max_over_ranks(0.5 + grp.rank)      # rank r "took" 0.5 + r seconds
     n_total = grp.sum_over_ranks(hi - lo)

@@ -49,11 +49,16 @@ def main():
     else:
         buf = torch.zeros(total, dtype=torch.uint8, device="cuda")
     grp.broadcast_bytes(buf, src=0)
-    recv = torch.zeros_like(buf)
-    grp.scatter_shards(buf, recv, src=0)
-    if rank != 0:
-        assert torch.equal(recv, buf)
     lo, hi = dist.shard_range(N_FRAMES, grp.world, grp.rank)
+    # ... and the scatter path: rank r gets exactly ITS shard (the frames differ in size)
+    dev = [torch.from_numpy(d).cuda() for d in datas]
+    mine_sc, _, _ = dist.distribute_units(
+        grp, N_FRAMES, lambda g: sizes[g],
+        lambda units: torch.cat([dev[g] for g in units]) if len(units) else
+        torch.empty(0, dtype=torch.uint8, device="cuda"), "scatter",
+        lambda n: torch.zeros(n, dtype=torch.uint8, device="cuda"),
+        sync=torch.cuda.synchronize)
+    assert torch.equal(mine_sc, buf[int(offs[lo]):int(offs[hi])])
     ctx = capi.Context(local_rank)
     op = (W * 2 + 15) // 16 * 16
     jobs = []

@@ -77,6 +77,32 @@ def test_nikon_split_sizes(gpu, oracle, bits, v1, w, h, split):
         assert np.array_equal(img.u16(), want.u16())
 
 
+def test_nikon_curve_mutated_in_place_between_calls(gpu, oracle):
+    """The lane keeps the plan of its last call, keyed by what the plan was made FROM.  The
+    curve is handed over as a host pointer and baked into the plan (dither table): two
+    calls with the same descriptor and the same curve ADDRESS but other curve CONTENTS must
+    not share a plan (the key holds the contents, rsx_api.hip key_job)."""
+    bits, w, h = 12, 640, 96
+    rng = np.random.default_rng(77)
+    pts = G.nikon_curve_points(300, 4000)
+    meta = N.metadata(68, 0, [2000, 2100, 2200, 2300], pts)
+    P = N.parse(meta, bits, h)
+    data = N.symbol_stream(rng, w * h, synth.NIKON_TREE[P["huff_select"]])
+    d = N.desc(P, bits, False)
+    addr = d.curve
+    outs = []
+    for round_ in range(3):
+        img, want = HostImage(w, h), HostImage(w, h)
+        assert gpu.nikon_decompress(d, data, img.view()) == oracle.nikon(d, data, want) == 0
+        assert np.array_equal(img.u16(), want.u16()), round_
+        outs.append(img.u16().copy())
+        # same buffer, other contents (still monotonic, still the same size)
+        d._curve[:] = np.minimum(d._curve.astype(np.uint32) * 3 // 4 + 5 * (round_ + 1),
+                                 65535).astype(np.uint16)
+        assert d.curve == addr
+    assert not np.array_equal(outs[0], outs[1]) and not np.array_equal(outs[1], outs[2])
+
+
 def test_nikon_truncated(gpu, oracle):
     """Status parity at every cut of a split stream (BitStreamerMSB reads zeros
     for 8 bytes past the end, then throws)."""
