@@ -1060,6 +1060,42 @@ extern "C" int rsx_dng_decompress_uncompressed(rsx_ctx* ctx, int n_tiles,
 // ---------------------------------------------------------------------------
 // LJPEG / CR2 entry points: see rsx_ljpeg.hip for the implementation.
 // ---------------------------------------------------------------------------
+namespace {
+// Tables with the same CONTENTS are one table.  The reference binds a decoder per DHT
+// slot (AbstractLJpegDecoder.h:112-125) and the shim de-duplicates by object address; a
+// file that declares the same code twice (Canon's Th = 0 / Th = 1, many DNG writers) must
+// not look like a two-table stream to the kernels: one table keeps the component phase
+// out of the synchronisation state and takes the single-pass kernel.
+struct UniqueTables {
+  rsx_huff_table t[RSX_MAX_COMPONENTS];
+};
+bool same_table(const rsx_huff_table& a, const rsx_huff_table& b) {
+  return a.n_code_values == b.n_code_values && a.fix_dng_bug16 == b.fix_dng_bug16 &&
+         std::memcmp(a.n_codes_per_length, b.n_codes_per_length, 16) == 0 &&
+         std::memcmp(a.code_values, b.code_values, a.n_code_values) == 0;
+}
+void dedupe_tables(LJpegJobIn& in, UniqueTables& store) {
+  if (in.status != RSX_OK || in.n_tables <= 1 || in.n_tables > RSX_MAX_COMPONENTS)
+    return;
+  int map[RSX_MAX_COMPONENTS], n = 0;
+  for (int t = 0; t < in.n_tables; ++t) {
+    int u = 0;
+    while (u < n && !same_table(store.t[u], in.tables[t]))
+      ++u;
+    if (u == n)
+      store.t[n++] = in.tables[t];
+    map[t] = u;
+  }
+  if (n == in.n_tables)
+    return;
+  for (uint8_t& c : in.geom.comp_of_phase)
+    if (int(c) < in.n_tables)
+      c = uint8_t(map[c]);
+  in.tables = store.t;
+  in.n_tables = n;
+}
+} // namespace
+
 extern "C" int rsx_ljpeg_plan_create(rsx_ctx* ctx, int n_jobs,
                                      const rsx_ljpeg_job* jobs,
                                      rsx_plan** out_plan) {
@@ -1072,6 +1108,7 @@ extern "C" int rsx_ljpeg_plan_create(rsx_ctx* ctx, int n_jobs,
   plan->kind = PLAN_LJPEG;
   plan->n_jobs = n_jobs;
   std::vector<LJpegJobIn> in(n_jobs);
+  std::vector<UniqueTables> unique(n_jobs);
   for (int i = 0; i < n_jobs; ++i) {
     in[i].status = build_ljpeg_stream(jobs[i].desc, jobs[i].img, &in[i].geom);
     in[i].geom.in_offset = jobs[i].in_offset;
@@ -1081,6 +1118,7 @@ extern "C" int rsx_ljpeg_plan_create(rsx_ctx* ctx, int n_jobs,
     in[i].n_tables = jobs[i].desc.n_tables;
     in[i].rows_per_restart_interval = jobs[i].desc.rows_per_restart_interval;
     in[i].frame_h = jobs[i].desc.frame_h;
+    dedupe_tables(in[i], unique[i]);
   }
   LJpegPlan* lp = nullptr;
   if (int st = ljpeg_plan_create(ctx, in, &lp))
@@ -1101,6 +1139,7 @@ extern "C" int rsx_cr2_plan_create(rsx_ctx* ctx, int n_jobs,
   plan->kind = PLAN_LJPEG;
   plan->n_jobs = n_jobs;
   std::vector<LJpegJobIn> in(n_jobs);
+  std::vector<UniqueTables> unique(n_jobs);
   for (int i = 0; i < n_jobs; ++i) {
     in[i].status = build_cr2_stream(jobs[i].desc, jobs[i].img, &in[i].geom);
     in[i].geom.in_offset = jobs[i].in_offset;
@@ -1110,6 +1149,7 @@ extern "C" int rsx_cr2_plan_create(rsx_ctx* ctx, int n_jobs,
     in[i].n_tables = jobs[i].desc.n_tables;
     in[i].rows_per_restart_interval = 0; // CR2 rejects DRI (Cr2LJpegDecoder.cpp:59-60)
     in[i].frame_h = 0;
+    dedupe_tables(in[i], unique[i]);
   }
   LJpegPlan* lp = nullptr;
   if (int st = ljpeg_plan_create(ctx, in, &lp))

@@ -519,6 +519,69 @@ __device__ __forceinline__ uint32_t lj_guess_parse_asm(uint32_t col4, uint32_t e
   return (q - qend) >> 5;
 }
 
+// Two symbols per window read (round 4).  The loop above spends, per symbol, two LDS reads
+// for the window, one random byte read in a 1 KB table (four dwords per bank: conflicts)
+// and ~7 vector instructions.  Here a second, 256-byte table -- 64 dwords, one per LDS bank:
+// conflict-free -- holds the symbol's total length for the codes of up to 8 bits (0x80:
+// longer code, special entry), and ONE 32-bit window serves two look-ups: the second
+// symbol's code starts at bit l1 of it, and l1 <= 24 for every entry of the small table (a
+// code of at most 8 bits + at most 16 difference bits), so the 8 index bits are the stream's.
+// Pairs are taken while the first symbol cannot reach the end of the slot (q + 26 symbols'
+// bits < end), so the second one always starts inside it; the last two or three symbols go
+// through the one-symbol loop.  A miss in either look-up (0x80 + anything >= 128) takes ONE
+// symbol by the 10-bit table, as the loop above would.
+// 10 vector instructions and 4 LDS reads per PAIR where the loop above takes 14-16 and 6.
+constexpr uint32_t LJ_GUESS_LUT8_OFF = LJ_GUESS_LUT_OFF + 1024u + 3u * 512u + 64u;
+static_assert(LJ_GUESS_LUT8_OFF + 256u <= uint32_t(LJ_BW) * LJ_T * 4, "inside dword rows 17..19");
+template <bool COUNT>
+__device__ __forceinline__ uint32_t lj_guess_parse_pairs(uint32_t col4, uint32_t end_bits,
+                                                         uint32_t from, uint32_t* count = nullptr) {
+  uint32_t q = from << 5, n = 0;
+  const uint32_t qend = end_bits << 5;
+  // (unsigned: a slot shorter than 27 bits has no pair region at all)
+  const uint32_t qpair = qend > (26u << 5) ? qend - (26u << 5) : 0u;
+  while (q < qpair) {
+    uint32_t ad;
+    uint64_t pr;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(q), "s"(0xFFFFFC00u), "v"(col4));
+    // (dword row + 1 into the LOW register, dword row into the high one: the pair the
+    // 64-bit shift wants, without moves)
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:4 offset1:0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=v"(pr)
+                 : "v"(ad));
+    const uint32_t w = uint32_t((pr << ((q >> 5) & 31u)) >> 32);
+    const uint32_t l1 = *(lds_u8p)(LJ_GUESS_LUT8_OFF + (w >> 24));
+    // (a hit is a code of at most 8 bits + at most 16 difference bits: l1 <= 24, so the
+    // second symbol's 8 index bits are the stream's; a miss shifts by 0x80 & 31 = 0 and
+    // the sum says so)
+    const uint32_t w2 = w << (l1 & 31u);
+    const uint32_t l2 = *(lds_u8p)(LJ_GUESS_LUT8_OFF + (w2 >> 24));
+    const uint32_t sum = l1 + l2;
+    if (sum < 128u) {
+      q += sum << 5;
+      if (COUNT)
+        n += 2;
+    } else {
+      q += uint32_t(*(lds_u8p)(LJ_GUESS_LUT_OFF + (w >> 22))) << 5;
+      if (COUNT)
+        n += 1;
+    }
+  }
+  // the rest, symbol by symbol
+  while (q < qend) {
+    uint32_t ad;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(q), "s"(0xFFFFFC00u), "v"(col4));
+    const uint32_t d0 = *(lds_u32p)(ad), d1 = *(lds_u32p)(ad + 4u * LJ_T);
+    const uint32_t w = uint32_t((((uint64_t(d0) << 32) | d1) << ((q >> 5) & 31u)) >> 32);
+    q += uint32_t(*(lds_u8p)(LJ_GUESS_LUT_OFF + (w >> 22))) << 5;
+    if (COUNT)
+      ++n;
+  }
+  if (COUNT)
+    *count = n;
+  return (q - qend) >> 5;
+}
+
 // A slot inside a constant region of the image is the code of the zero difference over
 // and over.  No parse from an arbitrary bit finds its way into such a stretch reliably
 // (with Nikon's 14-bit table, 111110 repeated also reads as a chain of 12-bit symbols),
@@ -572,13 +635,24 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
   uint8_t* lut8 = smem + LJ_GUESS_LUT_OFF;
-  uint32_t lut_pk = 0;
+  uint32_t lut_pk = 0, lut8b = 0x80u;
   if (S.fast && a.fast_tabs) {
     // (the symbol lengths of the stream's 10-bit LUT: asked for now, parked later)
     const uint2* ft = a.fast_tabs + size_t(S.table_base) * 1024 + 4 * j;
+    uint2 e0 = make_uint2(0u, 0u);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      lut_pk |= ((ft[k].x >> 5) & 63u) << (8 * k);
+    for (int k = 0; k < 4; ++k) {
+      const uint2 e = ft[k];
+      if (k == 0)
+        e0 = e;
+      lut_pk |= ((e.x >> 5) & 63u) << (8 * k);
+    }
+    // the 8-bit table's entry j: the four 10-bit entries 4j.. agree iff the code has at most
+    // 8 bits (code length = total - SSSS, SSSS = popcount of the entry's 2^SSSS - 1)
+    const uint32_t total = (e0.x >> 5) & 63u;
+    const uint32_t code = total - uint32_t(__builtin_popcount(e0.y));
+    if (!(e0.x & 0x80000000u) && code <= 8u && total >= 1u)
+      lut8b = total;
   }
   lj_stage_slots(L, a, S, s, lb, j, true); // ends with a barrier
   uint4* __restrict__ dst = a.unstuffed + size_t(b) * LJ_IMG_U4;
@@ -618,6 +692,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     uint32_t* nlist = reinterpret_cast<uint32_t*>(glist + LJ_T);
     __syncthreads(); // every lane has written its part of the image out
     reinterpret_cast<uint32_t*>(lut8)[j] = lut_pk;
+    smem[LJ_GUESS_LUT8_OFF + uint32_t(j)] = uint8_t(lut8b);
     if (j == 0) {
       *est = 0;
       *nlist = 0;
@@ -633,6 +708,11 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       hand = false;
 #endif
     auto parse = [&](int col, uint32_t bits, uint32_t from, uint32_t* count) -> uint32_t {
+#ifndef RSX_K0_SINGLE_SYMBOL
+      if (hand)
+        return count ? lj_guess_parse_pairs<true>(uint32_t(col) * 4u, bits, from, count)
+                     : lj_guess_parse_pairs<false>(uint32_t(col) * 4u, bits, from);
+#endif
       if (hand)
         return count ? lj_guess_parse_asm<true>(uint32_t(col) * 4u, bits, from, count)
                      : lj_guess_parse_asm<false>(uint32_t(col) * 4u, bits, from);

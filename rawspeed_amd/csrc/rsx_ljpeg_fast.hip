@@ -178,29 +178,42 @@ __device__ __forceinline__ uint32_t uni(uint32_t x) {
 __device__ __forceinline__ uint32_t pack16(uint32_t lo, uint32_t hi) {
   return __builtin_amdgcn_perm(hi, lo, 0x05040100u); // {hi[15:0], lo[15:0]}
 }
-__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t x, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t y = __shfl_up(x, o, 64);
-    if (lane >= o)
-      x += y;
-  }
+// Wavefront scans on the DPP network (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes,
+// row_bcast 15 / 31 across them; lanes without a source get `old` = 0, the identity of
+// every operator used here): six dependent VALU instructions.  The __shfl_up versions
+// they replace compile to six dependent ds_bpermute_b32 -- an LDS round trip each, ~0.3 us
+// a scan, ~2 us of a workgroup's 30 over its scans.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t x) {
+  return uint32_t(__builtin_amdgcn_update_dpp(0, int(x), CTRL, ROW_MASK, 0xF, false));
+}
+#define LF_DPP_SCAN(STEP)     \
+  STEP(0x111, 0xF)            \
+  STEP(0x112, 0xF)            \
+  STEP(0x114, 0xF)            \
+  STEP(0x118, 0xF)            \
+  STEP(0x142, 0xA)            \
+  STEP(0x143, 0xC)
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t x, int) {
+#define LF_STEP_ADD(C, M) x += dpp0<C, M>(x);
+  LF_DPP_SCAN(LF_STEP_ADD)
+#undef LF_STEP_ADD
   return x;
 }
-__device__ __forceinline__ uint2 wave_scan_pk2(uint2 x, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint2 y = make_uint2(__shfl_up(x.x, o, 64), __shfl_up(x.y, o, 64));
-    if (lane >= o)
-      x = pk_add2(x, y);
-  }
+__device__ __forceinline__ uint2 wave_scan_pk2(uint2 x, int) {
+#define LF_STEP_PK(C, M) x = make_uint2(pk_add(x.x, dpp0<C, M>(x.x)), pk_add(x.y, dpp0<C, M>(x.y)));
+  LF_DPP_SCAN(LF_STEP_PK)
+#undef LF_STEP_PK
   return x;
 }
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-    x += __shfl_xor(x, o, 64);
-  return x;
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) { // (uniform result)
+#define LF_STEP_MAX(C, M) x = max(x, dpp0<C, M>(x));
+  LF_DPP_SCAN(LF_STEP_MAX)
+#undef LF_STEP_MAX
+  return uint32_t(__builtin_amdgcn_readlane(int(x), 63));
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) { // (uniform result)
+  return uint32_t(__builtin_amdgcn_readlane(int(wave_scan_u32(x, 0)), 63));
 }
 // 16-bit field q (0..3) of a packed uint2
 __device__ __forceinline__ uint32_t fld(uint2 v, uint32_t q) {
@@ -543,18 +556,19 @@ __device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint
       c.v[k] = uint32_t(wv_[k]);
       c.f[k] = fld_mask1(fl >> (2 * k));
     }
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      XferT<NW> nr; // the segment of the `o` nearer lanes
-#pragma unroll
-      for (int k = 0; k < NW; ++k) {
-        nr.a[k] = __shfl_up(c.a[k], o, 64);
-        nr.v[k] = __shfl_up(c.v[k], o, 64);
-        nr.f[k] = __shfl_up(c.f[k], o, 64);
-      }
-      if (lane >= o)
-        c = xfer_compose<NW>(c, nr); // own (farther) first, then the nearer ones
-    }
+    // (DPP network; a lane without a source composes with the identity transfer 0 / 0 / 0)
+#define LF_STEP_XFER(C, M)                         \
+  {                                                \
+    XferT<NW> nr; /* the nearer lanes' segment */  \
+    _Pragma("unroll") for (int k = 0; k < NW; ++k) { \
+      nr.a[k] = dpp0<C, M>(c.a[k]);                \
+      nr.v[k] = dpp0<C, M>(c.v[k]);                \
+      nr.f[k] = dpp0<C, M>(c.f[k]);                \
+    }                                              \
+    c = xfer_compose<NW>(c, nr); /* own (farther) first, then the nearer ones */ \
+  }
+    LF_DPP_SCAN(LF_STEP_XFER)
+#undef LF_STEP_XFER
     // summary of the wavefront: [0] f, [1] ok, [2..7] transfer of lanes 0..f-1,
     // [8..11] state of lane f
     uint32_t* X = F.misc + M_LBX + 12 * wv;
@@ -812,6 +826,127 @@ __device__ __forceinline__ void lf_copy_out(const FastLds& F, const LjArgs& a,
   }
 }
 
+// Copy-out, second version (round 4).  The version above deals CHUNKS to lanes and has every
+// lane walk the run list for itself: with runs of ~280 chunks and a stride of 256 nearly
+// every chunk of a lane lies in another run than its last one, so the run's set-up (address
+// arithmetic in 64 bits, the row's constants, the CR2 strip) -- ~100 vector instructions --
+// was paid per 16 bytes: a third of the kernel's vector instructions.  Here the run list is
+// walked ONCE PER WAVEFRONT with wave-uniform state (scalar registers, the scalar unit),
+// every run is cut into segments of 64 chunks, and the segments are dealt to the four
+// wavefronts round robin; a lane's work per chunk is what only it can do: five LDS reads,
+// four funnel shifts, four packed adds, one 16-byte store.
+template <int N>
+__device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
+                                             const FastStream& S, uint32_t A0_, uint32_t A1_,
+                                             uint32_t sb, uint32_t r0_, int tid) {
+  const uint32_t lane = uint32_t(tid) & 63u;
+  const uint32_t wv = uni(uint32_t(tid) >> 6);
+  // (every lane holds the same values: said so, or the walk below runs on vector registers)
+  const uint32_t A0 = uni(A0_), A1 = uni(A1_), r0 = uni(r0_);
+  const uint32_t RS = S.RS;
+  uint8_t* img = a.out_base + S.img_offset;
+  const Cr2Strip* st = reinterpret_cast<const Cr2Strip*>(F.strips);
+  // cursor (wave-uniform): the run that starts at sample i
+  uint32_t i = A0, r = r0, sidx = A0 - r0 * RS;
+  uint32_t z = 0, srow = 0, col = 0, sw = 1, sx0 = 0, sy0 = 0, znext = 0xFFFFFFFFu;
+  if (S.kind == 1) {
+    while (z + 1 < S.n_strips && uint64_t(i) >= uni64(st[z + 1].first_sample))
+      ++z;
+    sx0 = uni(st[z].x0);
+    sw = uni(st[z].w);
+    sy0 = uni(st[z].y0);
+    strip_divmod(uint64_t(i) - uni64(st[z].first_sample), sw, &srow, &col);
+    srow = uni(srow);
+    col = uni(col);
+    znext = z + 1 < S.n_strips ? uint32_t(uni64(st[z + 1].first_sample)) : 0xFFFFFFFFu;
+  }
+  uint32_t gseg = 0; // segments dealt so far
+  while (i < A1) {
+    uint32_t n;
+    uint8_t* dst = nullptr;
+    if (S.kind == 0) {
+      if (sidx < S.keep) {
+        n = S.keep - sidx;
+        dst = img + uint64_t(S.out_y + r) * S.pitch + 2u * (S.out_x + sidx);
+      } else {
+        n = RS - sidx; // trailing MCUs of the frame that the tile does not keep
+      }
+    } else {
+      const uint32_t in_strip = sw - col, in_row = RS - sidx;
+      n = in_strip < in_row ? in_strip : in_row;
+      dst = img + uint64_t(sy0 + srow) * S.pitch + 2u * (sx0 + col);
+    }
+    if (n > A1 - i)
+      n = A1 - i;
+    if (dst) {
+      const uint2 Cv = F.ctab[r - r0];
+      const uint2 C = make_uint2(uni(Cv.x), uni(Cv.y));
+      const uint32_t delta = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u) >> 1;
+      const uint32_t ph0 = (i + 8u - delta) & uint32_t(N - 1);
+      uint32_t cd[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        cd[t] = fld(C, (ph0 + 2u * t) & uint32_t(N - 1)) |
+                (fld(C, (ph0 + 2u * t + 1u) & uint32_t(N - 1)) << 16);
+      const uint32_t nch = (delta + n + 7u) >> 3;
+      const uint32_t lds0 = sb + 2u * (i - A0) - 2u * delta;
+      const uint32_t sh = 8u * (lds0 & 2u); // the staged samples start mid-dword: 16, else 0
+      uint8_t* const d0 = dst - 2u * delta;
+      const uint32_t nseg = (nch + 63u) >> 6;
+      for (uint32_t seg = (wv - gseg) & 3u; seg < nseg; seg += 4u) {
+        const uint32_t m = seg * 64u + lane;
+        if (m < nch) {
+          const int32_t sf = int32_t(8u * m) - int32_t(delta);
+          const uint32_t la = (lds0 + 16u * m) & ~3u;
+          uint32_t dw[5];
+#pragma unroll
+          for (int t = 0; t < 5; ++t)
+            dw[t] = *(lds_u32p)(la + 4u * t);
+          uint32_t o[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            o[t] = pk_add(__builtin_amdgcn_alignbit(dw[t + 1], dw[t], sh), cd[t]);
+          uint8_t* p = d0 + 16u * m;
+          if (sf >= 0 && uint32_t(sf) + 8u <= n) {
+            *reinterpret_cast<uint4*>(p) = make_uint4(o[0], o[1], o[2], o[3]);
+          } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+              const int32_t q = sf + t;
+              if (q >= 0 && uint32_t(q) < n)
+                reinterpret_cast<uint16_t*>(p)[t] = uint16_t(o[t >> 1] >> (16 * (t & 1)));
+            }
+          }
+        }
+      }
+      gseg += nseg;
+    }
+    // move the cursor past the run
+    i += n;
+    sidx += n;
+    if (sidx == RS) {
+      sidx = 0;
+      ++r;
+    }
+    if (S.kind == 1) {
+      col += n;
+      if (col == sw) {
+        col = 0;
+        ++srow;
+      }
+      if (i >= znext && i < A1) {
+        ++z;
+        sx0 = uni(st[z].x0);
+        sw = uni(st[z].w);
+        sy0 = uni(st[z].y0);
+        srow = 0;
+        col = 0;
+        znext = z + 1 < S.n_strips ? uint32_t(uni64(st[z + 1].first_sample)) : 0xFFFFFFFFu;
+      }
+    }
+  }
+}
+
 // Staging of a lane's register pairs q < nq (static register indices; groups of four
 // pairs are skipped wave-uniformly once nobody has any left)
 template <int Q4>
@@ -1012,11 +1147,14 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     if (j >= 1)
       F.rec[j] = rec_make(start, ex, fs.n);
     F.sm[j] = make_uint2(pack16(fs.acc[0], fs.acc[1]), pack16(fs.acc[2], fs.acc[3]));
+    // slot 0 stands for the workgroup's entry state: its "exit" is what lane 1 assumed
+    // (written by lane 1 itself, in front of the barrier the first round starts from)
+    if (j == 1)
+      F.rec[0] = rec_make(0, start, 0);
+    if (j == 0)
+      F.misc[M_LIST] = 0;
   }
   __syncthreads();
-  // slot 0 stands for the workgroup's entry state: its "exit" is what lane 1 assumed
-  if (j == 0)
-    F.rec[0] = rec_make(0, rec_su(F.rec[1]), 0);
 
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1); // j >= 1
   uint32_t my_cnt = 0, before = 0, cnt_wg = 0, base = 0;
@@ -1032,9 +1170,14 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     // 3. Jacobi rounds with a dense list (lj_sync_kernel's scheme)
     uint32_t rounds = 0;
     while (true) {
-      if (j == 0)
-        F.misc[M_LIST] = 0;
-      __syncthreads();
+      // (the first round of the first attempt starts from the barrier behind the decode:
+      // records, slot 0's entry and the empty list are all in front of it)
+      const bool first_pass = attempt == 0 && rounds == 0;
+      if (!first_pass) {
+        if (j == 0)
+          F.misc[M_LIST] = 0;
+        __syncthreads();
+      }
       const uint32_t my_su = rec_su(F.rec[j]);
       const uint32_t want = j >= 1 ? rec_st(F.rec[j - 1]) : my_su;
       const bool chained = own_bits != 0u && j >= 1;
@@ -1075,6 +1218,14 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
         }
         if (j == 0)
           F.misc[M_NSIDE] = all < limit ? all : (handed > limit ? handed : limit);
+        // Nothing to re-decode anywhere (99 % of the workgroups): in the first pass nobody
+        // holds an entry yet, so "nobody asks" (the four counts every lane has just read)
+        // is "nobody is listed" -- no list, no third barrier.  (The same test with
+        // __syncthreads_or brings static LDS along: see the layout's note.)
+        if (first_pass && all == handed) {
+          need_redo = false;
+          break;
+        }
       }
       if (listed && my_entry >= 0)
         F.list[atomicAdd(&F.misc[M_LIST], 1u)] = uint16_t(j | (my_entry << 8));
@@ -1288,10 +1439,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     // pairs that are written from the registers (a count clipped by `needed` writes one
     // sample more: nothing after it is delivered)
     const uint32_t nq = cnt_eff == my_cnt ? (cnt_eff >> 1) : ((cnt_eff + 1) >> 1);
-    uint32_t nqmax = nq;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-      nqmax = max(nqmax, uint32_t(__shfl_xor(nqmax, o, 64)));
+    const uint32_t nqmax = wave_max_u32(nq);
     const uint32_t k0 = N == 1 ? (pexrel.x & 0xFFFFu) * 0x10001u : pexrel.x;
     const uint32_t k1 = N == 4 ? pexrel.y : k0;
     lf_stage<0>(R, ad, nq, nqmax, k0, k1);
@@ -1442,8 +1590,13 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   LF_STAMP(13);
   LF_STAMP(14);
   // 9. copy-out
-  if (fits && any_out && !(LF_ABLATE & 3u))
+  if (fits && any_out && !(LF_ABLATE & 3u)) {
+#ifdef RSX_LF_OLD_COPY
     lf_copy_out<N>(F, a, S, base, lim, sb, r0, j);
+#else
+    lf_copy_out2<N>(F, a, S, base, lim, sb, r0, j);
+#endif
+  }
   // records the per-stream bookkeeping kernels read (lj_scan_kernel, lj_consumed_kernel)
   if (j >= 1)
     a.sub_state[gsub] = rec_st(my_rec_final) | (rec_cn(my_rec_final) << 16);

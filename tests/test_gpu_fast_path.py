@@ -301,3 +301,40 @@ def test_trailing_bytes_after_the_last_symbol_are_nobodys_business(gpu, oracle, 
     names = _kernel_names(plan, inp, out)
     assert any("lj_fast_kernel" in n for n in names), names
     assert not any("sync" in n for n in names), names
+
+
+def test_identical_tables_in_two_dht_slots_take_the_single_pass_kernel(gpu, oracle):
+    """The reference binds a decoder per DHT slot (AbstractLJpegDecoder.h:112-125); writers
+    commonly declare the same code twice, once per component.  The library compares table
+    CONTENTS: such a stream is a one-table stream for the kernels (single-pass kernel, no
+    synchronisation kernel); two different codes still go through the multi-kernel
+    pipeline, bit-exactly."""
+    import bench_ljpeg as B
+    from oracle_lib import HostImage
+    rng = np.random.default_rng(4242)
+    W, H = 2048, 512
+    other = C.random_huffman_table(rng, n_cat=16)
+    for tables, expect_fast in (((C.NIKON, C.NIKON), True), ((C.NIKON, other), False)):
+        d, data, tile_px, scan_len = C.make_ljpeg_case(
+            rng, img_w=W, img_h=H, cpp=1, tile=(0, 0, W, H), mcu=(2, 1), tables=tables,
+            table_index=[0, 1])
+        assert d.n_tables == 2
+        want = HostImage(W, H)
+        st_o, cons_o = oracle.ljpeg(d, data, want)
+        assert st_o == 0
+        j = abi.LJpegJob()
+        j.desc = d
+        j.in_offset, j.in_bytes, j.img_offset = 0, data.size, 0
+        op = B.out_pitch(W)
+        j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = op, W, H, 1, 1
+        plan = gpu.ljpeg_plan([j])
+        inp = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+        out = torch.zeros(op * H, dtype=torch.uint8, device="cuda")
+        plan.run(inp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        rc, st, cons = plan.results()
+        assert rc == 0 and list(cons) == [cons_o]
+        px = out.cpu().numpy().view(np.uint16).reshape(H, op // 2)[:, :W]
+        assert np.array_equal(px, want.pixels()) and np.array_equal(px, tile_px)
+        names = _kernel_names(plan, inp, out)
+        assert any("lj_fast_kernel" in n for n in names) == expect_fast, names
+        assert any("sync" in n for n in names) == (not expect_fast), names
