@@ -141,12 +141,22 @@ def frame_of(out_t, cfg, f):
         .reshape(h, op // 2)[:, :w]
 
 
+def profile_rounds():
+    """profiles/rNN, newest first"""
+    try:
+        d = sorted((x for x in os.listdir(os.path.join(ROOT, "profiles"))
+                    if x.startswith("r") and x[1:].isdigit()), key=lambda x: -int(x[1:]))
+    except OSError:
+        d = []
+    return d
+
+
 def pmc_traffic(frames):
     """HBM bytes per launch of the headline kernel from rocprofv3's PMC passes
     (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc runs of this same command).
     bench.py cannot run rocprofv3 on itself: the newest committed per-launch
     measurement under profiles/ is scaled to the batch size, and the JSON says so."""
-    for rnd in ("r02", "r01"):
+    for rnd in profile_rounds():
         path = os.path.join(ROOT, "profiles", rnd, "unpack_pmc.json")
         try:
             with open(path) as f:
@@ -330,7 +340,7 @@ def replayed_ljpeg_counters():
     committed rocprofv3 PMC passes (scripts/pmc_ljpeg.sh, pmc_ljpeg_traffic.sh); bench.py
     cannot run rocprofv3 on itself."""
     out = {}
-    for rnd in ("r03", "r02"):
+    for rnd in profile_rounds():
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "ljpeg_traffic", "ljpeg_traffic.json")) as f:
                 t = json.load(f)
@@ -340,13 +350,30 @@ def replayed_ljpeg_counters():
             break
         except Exception:
             continue
-    for rnd in ("r03",):
+    for rnd in profile_rounds():
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "ljpeg_pmc", "ljpeg_pmc.json")) as f:
                 t = json.load(f)
             out["valu_issue_frac"] = t["valu_issue_frac"]
             out["valu_issue_source"] = "replayed from profiles/%s/ljpeg_pmc/ljpeg_pmc.json: %s" % (
                 rnd, t.get("how", ""))
+            break
+        except Exception:
+            continue
+    # what bounds the single-pass kernel: workgroups x lifetime / resident slots, and how
+    # often a symbol is parsed (profiles/rNN/ljpeg_limiter.json, scripts/ljpeg_limiter.py:
+    # phase stamps of an experiment build + the PMC instruction counts + the ISA's resources)
+    for rnd in profile_rounds():
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "ljpeg_limiter.json")) as f:
+                t = json.load(f)
+            for k in ("parses_per_symbol", "lane_instr_per_symbol", "wg_lifetime_us",
+                      "resident_wg_per_cu", "wg_phases_us"):
+                if k in t:
+                    out[k] = t[k]
+            out["limiter_source"] = "replayed from profiles/%s/ljpeg_limiter.json (%s); not " \
+                "measured in this run" % (rnd, t.get("how", ""))
+            break
         except Exception:
             continue
     return out

@@ -469,17 +469,19 @@ template <bool COUNT>
 __device__ __forceinline__ uint32_t lj_guess_parse(uint32_t bcol, uint32_t lut, uint32_t end_bits,
                                                    uint32_t from, uint32_t* count = nullptr) {
   static_assert(LJ_T == 256, "row stride 1 KB = 32 bits << 5");
-  uint32_t pos = from, n = 0;
+  uint32_t pos = from, n = 0, spec = 0;
   while (pos < end_bits) {
     const uint32_t ad = bcol + ((pos & ~31u) << 5);
     const uint32_t d0 = *(lds_u32p)(ad), d1 = *(lds_u32p)(ad + 4u * LJ_T);
     const uint32_t w = uint32_t((((uint64_t(d0) << 32) | d1) << (pos & 31u)) >> 32);
-    pos += *(lds_u8p)(lut + (w >> 22));
+    const uint32_t len = *(lds_u8p)(lut + (w >> 22));
+    spec |= len;
+    pos += len & 0x7Fu;
     if (COUNT)
       ++n;
   }
   if (COUNT)
-    *count = n;
+    *count = n | ((spec & 0x80u) << 24);
   return pos - end_bits;
 }
 // The same loop instruction by instruction, for the layout the kernel really has (the
@@ -494,7 +496,7 @@ constexpr uint32_t LJ_K0_LDS = LJ_K0_OFF_OB + 3 * LJ_T * 2 + 16 * 4 + 16 * 4 + 1
 template <bool COUNT>
 __device__ __forceinline__ uint32_t lj_guess_parse_asm(uint32_t col4, uint32_t end_bits,
                                                        uint32_t from, uint32_t* count = nullptr) {
-  uint32_t q = from << 5, n = 0;
+  uint32_t q = from << 5, n = 0, spec = 0;
   const uint32_t qend = end_bits << 5;
   while (q < qend) {
     uint32_t ad, len;
@@ -510,12 +512,13 @@ __device__ __forceinline__ uint32_t lj_guess_parse_asm(uint32_t col4, uint32_t e
     asm volatile("ds_read_u8 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)"
                  : "=v"(len)
                  : "v"(w >> 22), "n"(LJ_GUESS_LUT_OFF));
-    q += len << 5;
+    spec |= len;
+    q += (len & 0x7Fu) << 5;
     if (COUNT)
       ++n;
   }
   if (COUNT)
-    *count = n;
+    *count = n | ((spec & 0x80u) << 24);
   return (q - qend) >> 5;
 }
 
@@ -531,12 +534,14 @@ __device__ __forceinline__ uint32_t lj_guess_parse_asm(uint32_t col4, uint32_t e
 // through the one-symbol loop.  A miss in either look-up (0x80 + anything >= 128) takes ONE
 // symbol by the 10-bit table, as the loop above would.
 // 10 vector instructions and 4 LDS reads per PAIR where the loop above takes 14-16 and 6.
+constexpr uint32_t LJ_GUESS_ROUNDS = 6; // rounds of the chain's fixed-point iteration, at most
 constexpr uint32_t LJ_GUESS_LUT8_OFF = LJ_GUESS_LUT_OFF + 1024u + 3u * 512u + 64u;
+static_assert((4 + 2 * LJ_GUESS_ROUNDS) * 4 <= 64, "the rounds' words lie in front of the 8-bit table");
 static_assert(LJ_GUESS_LUT8_OFF + 256u <= uint32_t(LJ_BW) * LJ_T * 4, "inside dword rows 17..19");
 template <bool COUNT>
 __device__ __forceinline__ uint32_t lj_guess_parse_pairs(uint32_t col4, uint32_t end_bits,
                                                          uint32_t from, uint32_t* count = nullptr) {
-  uint32_t q = from << 5, n = 0;
+  uint32_t q = from << 5, n = 0, spec = 0;
   const uint32_t qend = end_bits << 5;
   // (unsigned: a slot shorter than 27 bits has no pair region at all)
   const uint32_t qpair = qend > (26u << 5) ? qend - (26u << 5) : 0u;
@@ -557,15 +562,19 @@ __device__ __forceinline__ uint32_t lj_guess_parse_pairs(uint32_t col4, uint32_t
     const uint32_t w2 = w << (l1 & 31u);
     const uint32_t l2 = *(lds_u8p)(LJ_GUESS_LUT8_OFF + (w2 >> 24));
     const uint32_t sum = l1 + l2;
-    if (sum < 128u) {
-      q += sum << 5;
-      if (COUNT)
-        n += 2;
-    } else {
-      q += uint32_t(*(lds_u8p)(LJ_GUESS_LUT_OFF + (w >> 22))) << 5;
-      if (COUNT)
-        n += 1;
+    // (the pair's advance first, overridden on a miss: ONE skipped block per iteration -- as
+    // an if / else the compiler gave each arm a block of its own and the loop three taken
+    // branches an iteration: K0 0.245 -> 0.275 ms)
+    uint32_t qadd = sum << 5, nadd = 2u;
+    if (__builtin_expect(sum >= 128u, 0)) {
+      const uint32_t len = *(lds_u8p)(LJ_GUESS_LUT_OFF + (w >> 22));
+      spec |= len;
+      qadd = (len & 0x7Fu) << 5;
+      nadd = 1u;
     }
+    q += qadd;
+    if (COUNT)
+      n += nadd;
   }
   // the rest, symbol by symbol
   while (q < qend) {
@@ -573,12 +582,16 @@ __device__ __forceinline__ uint32_t lj_guess_parse_pairs(uint32_t col4, uint32_t
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(q), "s"(0xFFFFFC00u), "v"(col4));
     const uint32_t d0 = *(lds_u32p)(ad), d1 = *(lds_u32p)(ad + 4u * LJ_T);
     const uint32_t w = uint32_t((((uint64_t(d0) << 32) | d1) << ((q >> 5) & 31u)) >> 32);
-    q += uint32_t(*(lds_u8p)(LJ_GUESS_LUT_OFF + (w >> 22))) << 5;
+    const uint32_t len = *(lds_u8p)(LJ_GUESS_LUT_OFF + (w >> 22));
+    spec |= len;
+    q += (len & 0x7Fu) << 5;
     if (COUNT)
       ++n;
   }
+  // (bit 31 of the count: the parse met an entry the 10-bit table only approximates -- a
+  // code of more than 10 bits, SSSS = 16, a hole in the code space: bit 7 of its length)
   if (COUNT)
-    *count = n;
+    *count = n | ((spec & 0x80u) << 24);
   return (q - qend) >> 5;
 }
 
@@ -590,7 +603,7 @@ __device__ __forceinline__ uint32_t lj_guess_parse_pairs(uint32_t col4, uint32_t
 // any other: the single-pass kernel checks it against the predecessor's exit.
 __device__ __forceinline__ bool lj_guess_constant(const uint32_t* B, int col, uint32_t zl,
                                                   uint32_t zc, bool candidate, uint32_t* guess,
-                                                  uint32_t* count) {
+                                                  uint32_t* count, uint32_t* entry) {
   bool per = candidate;
   for (int wi = 0; wi < LJ_PW && __any(per); ++wi) {
     const uint32_t d0 = B[wi * LJ_T + col], d1 = B[(wi + 1) * LJ_T + col];
@@ -611,6 +624,7 @@ __device__ __forceinline__ bool lj_guess_constant(const uint32_t* B, int col, ui
   const uint32_t r = (bits - p0) % zl;
   *guess = r ? zl - r : 0u;
   *count = (bits - p0 + zl - 1u) / zl;
+  *entry = p0; // the symbol grid of the slot: its first symbol starts at bit p0
   return true;
 }
 constexpr int LJ_GUESS_SLOTS = 3; // slots parsed for a guess, at most (LjArgs::guess_slots)
@@ -645,7 +659,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       const uint2 e = ft[k];
       if (k == 0)
         e0 = e;
-      lut_pk |= ((e.x >> 5) & 63u) << (8 * k);
+      lut_pk |= (((e.x >> 5) & 63u) | ((e.x >> 24) & 0x80u)) << (8 * k); // (bit 7: special)
     }
     // the 8-bit table's entry j: the four 10-bit entries 4j.. agree iff the code has at most
     // 8 bits (code length = total - SSSS, SSSS = popcount of the entry's 2^SSSS - 1)
@@ -679,24 +693,34 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   // wrong guess costs it a re-decode round, and every workgroup behind the re-decoding one
   // waits for its symbol count (measured with two slots parsed there: 9 % of the workgroups
   // re-decode, and the average workgroup waits 26 us for its predecessors).
-  // Lane c parses slot c, three times at most, each time from where the same chain left
-  // slot c - 1:  A[c] = parse(c, 0),  B[c] = parse(c, A[c-1]),  C[c] = parse(c, B[c-1]) --
-  // and C[c] = B[c] without a parse wherever B[c-1] = A[c-1], which is 98 % of the slots;
-  // the others go through a dense list on the first wavefront.  2.25 parses a slot
-  // instead of 3, the same guesses.  The guess for slot t is C[t-1]; lane 255's is for slot
-  // 1 of the NEXT workgroup, whose own lanes 1.. would have fewer slots to go by.
+  // Lane c parses slot c, each time from where the same chain left slot c - 1:
+  //   A[c] = parse(c, 0),  B[c] = parse(c, A[c-1]),  then rounds  X[c] = parse(c, X'[c-1])
+  // for the slots whose last parse did not start where their predecessor's last parse ended
+  // (2 % after B; they go through a dense list on the first wavefront) until nothing changes:
+  // a fixed point of the workgroup's chain -- every slot parsed from exactly the exit of the
+  // slot before it, given slot 0's.  2.25 parses a slot, and since round 4 the slots'
+  // SYMBOL COUNTS under those very entries, which are the entries the single-pass kernel
+  // decodes from: the kernel takes its first symbol's index from the counts of the workgroups
+  // before it (a sum it reads when it starts) instead of waiting for their decodes in a
+  // look-back (3.6 us of a workgroup's 30).  What K0 cannot know -- slot 0's true exit is the
+  // predecessor workgroup's business, codes the 10-bit table does not cover, data that does
+  // not synchronise -- is marked, and the kernel asks those workgroups (and only those) for
+  // the difference (rsx_ljpeg_fast.hip, "symbol base").
   if (S.fast && a.fast_tabs) {
     uint16_t* EA = reinterpret_cast<uint16_t*>(smem + LJ_GUESS_LUT_OFF + 1024); // (dword rows 18, 19)
     uint16_t* EB = EA + LJ_T;
     uint16_t* glist = EB + LJ_T;
+    // [2] uncertain; [4 + 2 r] list length of round r, [5 + 2 r] "an exit moved in round r"
     uint32_t* nlist = reinterpret_cast<uint32_t*>(glist + LJ_T);
+    uint16_t* EU = EA;      // (after the B parses) the entry a slot's last parse started from
+    uint16_t* ECNT = L.su;  // symbols of a slot's last parse (su[] is the staging's)
     __syncthreads(); // every lane has written its part of the image out
     reinterpret_cast<uint32_t*>(lut8)[j] = lut_pk;
     smem[LJ_GUESS_LUT8_OFF + uint32_t(j)] = uint8_t(lut8b);
-    if (j == 0) {
+    if (j < 4 + 2 * int(LJ_GUESS_ROUNDS))
+      nlist[j] = 0;
+    if (j == 0)
       *est = 0;
-      *nlist = 0;
-    }
     __syncthreads();
     const uint32_t zi = uint32_t(__builtin_amdgcn_readfirstlane(int(a.fast_z[S.table_base])));
     const uint32_t zl = zi & 31u, zc = zi >> 8;
@@ -721,38 +745,98 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     };
     const uint32_t eb = L.ob[j];
     const bool exists = eb != 0u && !(j == 0 && lb == 0);
-    uint32_t ea = 0, cnt = 0;
+    uint32_t ea = 0, cnt = 0, grid = 0;
     bool constant = false;
     if (zl >= 4u) // (shorter: more than 128 symbols in a slot, the multi-kernel pipeline's)
-      constant = lj_guess_constant(L.B, j, zl, zc, eb == uint32_t(LJ_PW) * 32u && exists, &ea, &cnt);
+      constant = lj_guess_constant(L.B, j, zl, zc, eb == uint32_t(LJ_PW) * 32u && exists, &ea,
+                                   &cnt, &grid);
     if (!constant && exists)
       ea = parse(j, eb, 0u, &cnt) & ST_OFF_MASK;
+    if (j == 0 && lb == 0)
+      ea = S.start_bit & ST_OFF_MASK; // (the stream's first slot starts where the stream does)
     EA[j] = uint16_t(ea);
     __syncthreads();
     const uint32_t xa = j >= 1 ? uint32_t(EA[j - 1]) : 0u;
     uint32_t ebv = ea;
+#ifdef RSX_K0_X1 // (diagnostic build: the B parse without its count -- wrong counts, K0's time only)
     if (!constant && exists && xa != 0u && gs >= 2u)
       ebv = parse(j, eb, xa, nullptr) & ST_OFF_MASK;
+#else
+    if (!constant && exists && xa != 0u && gs >= 2u)
+      ebv = parse(j, eb, xa, &cnt) & ST_OFF_MASK;
+#endif
     EB[j] = uint16_t(ebv);
-    __syncthreads();
-    const uint32_t xb = j >= 1 ? uint32_t(EB[j - 1]) : 0u;
-    const bool third = !constant && exists && xb != xa && gs >= 3u;
-    if (third)
-      glist[atomicAdd(nlist, 1u)] = uint16_t(j);
+    // (15 bits of symbols, 0x7FFF = too many to say; bit 15: the parse met a special entry)
+    auto pack_cnt = [](uint32_t c) -> uint16_t {
+      const uint32_t n = c & 0x7FFFFFFFu;
+      return uint16_t((n > 0x7FFFu ? 0x7FFFu : n) | ((c >> 31) << 15));
+    };
+    ECNT[j] = pack_cnt(cnt);
+    __syncthreads(); // (every EA[j - 1] has been read: the array becomes EU)
+    EU[j] = uint16_t(xa);
+    // the guess for slot j + 1 (lane 255's goes to the next workgroup's slot 1): stored now,
+    // behind the rounds' parses, and again by the rounds for the slots they move -- stores
+    // at the very end of a workgroup are latency nothing hides
     const uint32_t g1 = S.first_subseq + lb * LJ_OWN; // record of this workgroup's slot 1
-    // (the guess for slot c + 1; lane 255's goes to the next workgroup's slot 1)
     const bool stored = j >= 1 && (j < LJ_T - 1 || lb + 1 < S.n_blocks);
-    if (stored && !third)
+    // (a slot the first round parses again is stored by that round: one writer at a time.
+    // The guesses are hints -- the kernel checks every one against the exit before it --,
+    // so a rare stale one costs a re-decode round there, never a pixel.)
+    const bool first_listed =
+        !constant && exists && j >= 1 && gs >= 3u && uint32_t(EB[j - 1]) != xa;
+    if (stored && !first_listed)
       a.sub_start[g1 + uint32_t(j)] = uint16_t(ebv);
-    __syncthreads();
-    const uint32_t nth = *nlist;
-    if (j < 64) {
-      for (uint32_t k = uint32_t(j); k < nth; k += 64u) {
-        const int c = int(glist[k]);
-        const uint32_t e3 = parse(c, L.ob[c], uint32_t(EB[c - 1]), nullptr) & ST_OFF_MASK;
-        if (c < LJ_T - 1 || lb + 1 < S.n_blocks)
-          a.sub_start[g1 + uint32_t(c)] = uint16_t(e3);
+    // rounds: a slot is parsed again when its predecessor's last exit is not what its own
+    // last parse started from; constant slots never are (their symbol grid is read from
+    // their bits -- a parse from a wrong entry would only carry the error down the region)
+    // (per round a list length and a "some exit moved" word of its own: nothing to reset
+    // between rounds, two barriers a round -- what the three-slot chain took before)
+    bool settled = false;
+    for (uint32_t round = 0; round < LJ_GUESS_ROUNDS && gs >= 3u; ++round) {
+      const uint32_t x = j >= 1 ? uint32_t(EB[j - 1]) : 0u;
+      if (!constant && exists && j >= 1 && x != uint32_t(EU[j]))
+        glist[atomicAdd(&nlist[4 + 2 * round], 1u)] = uint16_t(j);
+      __syncthreads();
+      const uint32_t nth = nlist[4 + 2 * round];
+      if (nth == 0) {
+        settled = true;
+        break;
       }
+      if (j < 64) {
+        bool changed = false;
+        for (uint32_t k = uint32_t(j); k < nth; k += 64u) {
+          const int c = int(glist[k]);
+          const uint32_t from = uint32_t(EB[c - 1]);
+          uint32_t n = 0;
+          const uint32_t e = parse(c, L.ob[c], from, &n) & ST_OFF_MASK;
+          if (e != uint32_t(EB[c]))
+            changed = true;
+          if ((round == 0u || e != uint32_t(EB[c])) && (c < LJ_T - 1 || lb + 1 < S.n_blocks))
+            a.sub_start[g1 + uint32_t(c)] = uint16_t(e);
+          EB[c] = uint16_t(e);
+          EU[c] = uint16_t(from);
+          ECNT[c] = pack_cnt(n);
+        }
+        if (changed)
+          nlist[5 + 2 * round] = 1u;
+      }
+      __syncthreads();
+      if (nlist[5 + 2 * round] == 0u) { // (no exit moved: every successor's entry still stands)
+        settled = true;
+        break;
+      }
+    }
+    ebv = uint32_t(EB[j]);
+    const uint32_t cnt_word = uint32_t(ECNT[j]);
+    cnt = cnt_word & 0x7FFFu;
+    // what the count cannot vouch for: a chain that did not settle, a constant slot whose
+    // symbol grid is not where its predecessor ends, symbols the 10-bit table only
+    // approximates, more symbols than the word holds
+    {
+      const uint32_t x = j >= 1 ? uint32_t(EB[j - 1]) : 0u;
+      if (j >= 1 && (!settled || (constant && exists && x != grid) || (cnt_word & 0x8000u) ||
+                     cnt == 0x7FFFu))
+        nlist[2] = 1u;
     }
     // the LDS level of the single-pass launches: the symbols of this workgroup's slots
     // 1..255 (parsed from bit 0: an estimate) against what a level stages
@@ -763,6 +847,22 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     if ((j & 63) == 0)
       atomicAdd(est, c);
     __syncthreads();
+    // The workgroup's word for the single-pass kernel's symbol base (LjArgs::k0w): symbols
+    // of slots 1..255 (32 bits) | the exit of slot 0 the chain started from | bit 7: the
+    // count is not to be trusted (16 bits) | the TRUE exit of slot 0 = the predecessor
+    // workgroup's slot 255 under ITS chain, valid bit 15 (16 bits, written by that one).
+    if (a.k0w) {
+      uint8_t* w = reinterpret_cast<uint8_t*>(a.k0w + b);
+      if (j == 0) {
+        *reinterpret_cast<uint32_t*>(w) = *est;
+        *reinterpret_cast<uint16_t*>(w + 4) =
+            uint16_t((uint32_t(EB[0]) & 0x7Fu) | (nlist[2] ? 0x80u : 0u));
+        if (lb == 0)
+          *reinterpret_cast<uint16_t*>(w + 6) = uint16_t(0x8000u | (uint32_t(EB[0]) & 0x7Fu));
+      }
+      if (j == LJ_T - 1 && lb + 1 < S.n_blocks)
+        *reinterpret_cast<uint16_t*>(w + 8 + 6) = uint16_t(0x8000u | (ebv & 0x7Fu));
+    }
     if (j == 0) {
       const uint32_t need = *est + (*est >> 6) + 64u;
       uint32_t lv = 0;
@@ -1336,6 +1436,11 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
   __shared__ uint32_t carry_s, dcarry_s;
   __shared__ uint2 pcarry_s;
   __shared__ uint32_t unconv_s;
+#ifdef RSX_EXPERIMENT
+  __shared__ uint32_t dbg_first_s;
+  if (threadIdx.x == 0)
+    dbg_first_s = 0xFFFFFFFFu;
+#endif
   const uint32_t s = blockIdx.x;
   const LjStreamDev& S = a.streams[s];
   if (!lj_bookkeeping_takes(a, s, S))
@@ -1355,8 +1460,13 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
     const uint32_t v = i < nb ? a.block_sum[fb + i] : 0u;
     const uint32_t dv = i < nb ? a.block_drops[fb + i] : 0u;
     // (a workgroup after a real error keeps whatever entry state it has: see K1)
-    if (i >= 1 && i < nb && a.block_start[fb + i] != a.block_exit[fb + i - 1] &&
-        !(a.block_exit[fb + i - 1] & ST_ERR))
+    // (single-pass streams, first pass: judged below, where the workgroup's first symbol is
+    // known -- what lies behind the last delivered symbol is nobody's business)
+    const bool fast_first = S.fast && a.pass == 0;
+    const bool link_broken = i >= 1 && i < nb &&
+                             a.block_start[fb + i] != a.block_exit[fb + i - 1] &&
+                             !(a.block_exit[fb + i - 1] & ST_ERR);
+    if (link_broken && !fast_first)
       unconv_s = 1;
     if (i < nb && (a.block_flags[fb + i] & 1u) != 0)
       unconv_s = 1; // a workgroup that gave up on its re-decode rounds
@@ -1387,7 +1497,40 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
       a.block_base[fb + i] = excl;
       a.block_drop_base[fb + i] = dexcl;
     }
-    if (nd) {
+    // The single-pass kernel took the index of a workgroup's first symbol from K0's counts
+    // (+ the corrections of the workgroups K0 had flagged).  Here are the counts of its own
+    // decodes: a workgroup that delivered symbols from another base than their sum has put
+    // them in the wrong place (a count K0 got wrong without knowing: the multi-kernel
+    // pipeline redoes the stream).  Workgroups behind the last delivered symbol do not matter.
+    // (and the entry state it decoded from -- K0's chain of the workgroup before -- is what
+    // that workgroup's decode arrived at, wherever delivered symbols follow)
+    if (fast_first && link_broken && uint64_t(excl) < S.needed)
+      unconv_s = 1;
+    if (fast_first && a.block_base0 && i < nb && a.block_base0[fb + i] != excl &&
+        (uint64_t(excl) < S.needed || uint64_t(a.block_base0[fb + i]) < S.needed)) {
+      unconv_s = 1;
+#ifdef RSX_EXPERIMENT
+      if (atomicMin(&dbg_first_s, i) > i) { // (statistics: the first workgroup off its base)
+        a.results[s].pad3[0] = 0x40000000u | i;
+        a.results[s].pad3[1] = a.block_base0[fb + i];
+        a.results[s].pad3[2] = excl;
+      }
+#endif
+    }
+#ifdef RSX_EXPERIMENT
+    if (fast_first && link_broken && uint64_t(excl) < S.needed &&
+        atomicMin(&dbg_first_s, i) > i) {
+      a.results[s].pad3[0] = 0x20000000u | i;
+      a.results[s].pad3[1] = a.block_start[fb + i];
+      a.results[s].pad3[2] = a.block_exit[fb + i - 1];
+    }
+    if (S.fast && a.pass == 0 && i < nb && (a.block_flags[fb + i] & 1u) != 0 &&
+        atomicMin(&dbg_first_s, i) > i)
+      a.results[s].pad3[0] = 0x10000000u | i;
+#endif
+    // (single-pass streams carry the predictor state through their own look-back: P before
+    // each workgroup is the multi-kernel pipeline's, computed when it takes the stream over)
+    if (nd && !fast_first) {
       // the workgroup's sums are kept by phases relative to its first symbol,
       // whose index is now known
       const uint2 pv = i < nb ? lj_rot_fields_rt(a.block_psum[fb + i], excl % nd, nd)
@@ -1418,23 +1561,40 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
     }
     __syncthreads();
   }
+  // symbols that start before the end of data M = min(marker, in_bytes): those in front of
+  // M's workgroup + those of its slots up to M's (a lane per slot; one lane walking them
+  // was up to 255 load latencies in a row)
+  {
+    LjResult& R = a.results[s];
+    uint64_t M = R.marker_pos;
+    if (M > lj_data_end(S))
+      M = lj_data_end(S);
+    const uint64_t lbm = M / LJ_R;
+    uint32_t part = 0;
+    if (lbm < nb) {
+      const uint32_t js = uint32_t((M - lbm * LJ_R) / LJ_P);
+      const uint32_t g0 = S.first_subseq + uint32_t(lbm) * LJ_OWN;
+      if (uint32_t(tid) <= js && tid < LJ_OWN)
+        part = a.sub_state[g0 + uint32_t(tid)] >> 16;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+      part += uint32_t(__shfl_xor(int(part), o, 64));
+    if ((tid & 63) == 0)
+      wsum[tid >> 6] = part;
+  }
+  __syncthreads();
   if (tid == 0) {
     LjResult& R = a.results[s];
-    // symbols that start before the end of data M = min(marker, in_bytes)
     uint64_t M = R.marker_pos;
     if (M > lj_data_end(S))
       M = lj_data_end(S);
     uint32_t avail;
     const uint64_t lbm = M / LJ_R;
-    if (lbm >= nb) {
+    if (lbm >= nb)
       avail = carry_s;
-    } else {
-      const uint32_t js = uint32_t((M - lbm * LJ_R) / LJ_P);
-      avail = a.block_base[fb + lbm];
-      const uint32_t g0 = S.first_subseq + uint32_t(lbm) * LJ_OWN;
-      for (uint32_t q = 0; q <= js && q < uint32_t(LJ_OWN); ++q)
-        avail += a.sub_state[g0 + q] >> 16;
-    }
+    else
+      avail = a.block_base[fb + lbm] + wsum[0] + wsum[1] + wsum[2] + wsum[3];
     R.avail_lo = avail;
     uint32_t flags = R.flags & ~(FL_UNCONVERGED | FL_NEED_LEGACY | FL_PERIODIC);
     if (unconv_s)
@@ -1991,26 +2151,45 @@ __device__ __forceinline__ uint32_t lj_zero_bytes(uint32_t d) { // 0x80 per zero
 __device__ __forceinline__ uint32_t lj_count_drops(const uint8_t* in, uint64_t from,
                                                    uint64_t to, int lane) {
   uint32_t n = 0;
-  for (uint64_t p0 = from + uint64_t(lane) * 16; p0 < to; p0 += 64 * 16) {
-    uint32_t prev = p0 > 0 ? in[p0 - 1] : 0u;
-    if (p0 + 16 <= to) {
-      // one 16-byte load (global loads take unaligned addresses); a stuffing byte
-      // is a zero byte whose predecessor is FF
-      uint4 v;
-      __builtin_memcpy(&v, in + p0, 16);
-      const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+  // (four 16-byte pieces of a lane in flight at once: the loop is as long as its loads'
+  // latencies in a row -- 16 of them for a workgroup's 16 KB, 10 us of lj_scan_kernel's 40)
+  for (uint64_t q0 = from + uint64_t(lane) * 16; q0 < to; q0 += 4 * 64 * 16) {
+    uint4 v[4];
+    uint32_t pv[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const uint32_t z = lj_zero_bytes(d[k]), f = lj_zero_bytes(~d[k]);
-        n += uint32_t(__builtin_popcount(z & ((f << 8) | (prev == 0xFFu ? 0x80u : 0u))));
-        prev = d[k] >> 24;
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t p0 = q0 + uint64_t(u) * 64 * 16;
+      v[u] = make_uint4(0, 0, 0, 0);
+      pv[u] = 0;
+      if (p0 + 16 <= to) {
+        // one 16-byte load (global loads take unaligned addresses)
+        __builtin_memcpy(&v[u], in + p0, 16);
+        pv[u] = p0 > 0 ? in[p0 - 1] : 0u;
       }
-      continue;
     }
-    for (uint64_t p = p0; p < to; ++p) {
-      const uint32_t c = in[p];
-      n += (c == 0u && prev == 0xFFu) ? 1u : 0u;
-      prev = c;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t p0 = q0 + uint64_t(u) * 64 * 16;
+      if (p0 >= to)
+        continue;
+      uint32_t prev = pv[u];
+      if (p0 + 16 <= to) {
+        // a stuffing byte is a zero byte whose predecessor is FF
+        const uint32_t d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint32_t z = lj_zero_bytes(d[k]), f = lj_zero_bytes(~d[k]);
+          n += uint32_t(__builtin_popcount(z & ((f << 8) | (prev == 0xFFu ? 0x80u : 0u))));
+          prev = d[k] >> 24;
+        }
+        continue;
+      }
+      prev = p0 > 0 ? in[p0 - 1] : 0u;
+      for (uint64_t p = p0; p < to; ++p) {
+        const uint32_t c = in[p];
+        n += (c == 0u && prev == 0xFFu) ? 1u : 0u;
+        prev = c;
+      }
     }
   }
 #pragma unroll
@@ -2045,8 +2224,8 @@ __device__ void lj_consumed_body(const LjArgs& a, uint32_t s, int lane) {
   const uint64_t M = has_marker ? R.marker_pos : lj_data_end(S);
   // un-stuffed bit offset of the last symbol's start
   const uint64_t slot_phys = uint64_t(R.last_slot) * LJ_P;
-  uint64_t c =
-      (slot_phys - lj_drops_before(a, S, in, slot_phys, lane)) * 8 + R.last_pos;
+  const uint64_t drops_slot = lj_drops_before(a, S, in, slot_phys, lane);
+  uint64_t c = (slot_phys - drops_slot) * 8 + R.last_pos;
   if (R.tail_used)
     c = (uint64_t(R.last_c_hi) << 32) | R.last_c_lo;
   if (S.raw) {
@@ -2079,7 +2258,20 @@ __device__ void lj_consumed_body(const LjArgs& a, uint32_t s, int lane) {
     return;
   }
   const uint64_t K = (c + 31) / 32 + 1;
-  const uint64_t D = M - lj_drops_before(a, S, in, M, lane);
+  // (the last symbol's slot and the end of data lie in the same workgroup's region as a
+  // rule: the stuffing bytes between them are all that is left to count)
+  uint64_t drops_M;
+  {
+    uint64_t lbs = slot_phys / LJ_R, lbm = M / LJ_R;
+    if (lbs >= S.n_blocks)
+      lbs = S.n_blocks - 1;
+    if (lbm >= S.n_blocks)
+      lbm = S.n_blocks - 1;
+    drops_M = (!S.raw && lbs == lbm && slot_phys <= M)
+                  ? drops_slot + lj_count_drops(in, slot_phys, M, lane)
+                  : lj_drops_before(a, S, in, M, lane);
+  }
+  const uint64_t D = M - drops_M;
   uint64_t result;
   if (4 * K > D) {
     // the last refill touched the marker (or ran off the end of the buffer)
@@ -2207,7 +2399,8 @@ struct LJpegPlan {
   bool any_pipeline = false;   // some stream takes the multi-kernel pipeline in the first pass
   bool expect_slow = false;    // the last run left FL_SLOW streams: launch the second pass at once
   bool slow_pass_launched = false; // ... this run already has
-  DeviceBuffer d_fast_tabs, d_lb, d_tickets, d_fast_order, d_fast_z, d_fast_level;
+  DeviceBuffer d_fast_tabs, d_lb, d_tickets, d_fast_order, d_fast_z, d_fast_level, d_k0w,
+      d_block_base0;
   uint32_t run_count = 0;      // runs so far (parity: which level word a run uses)
   uint32_t level_mask = 7;     // LDS levels the single-pass kernel is launched at (LjArgs::fast_level_mask)
   uint32_t h_level[4] = {};
@@ -2299,6 +2492,8 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.transfer = static_cast<uint16_t*>(p->d_transfer.ptr);
   a.fast_tabs = static_cast<const uint2*>(p->d_fast_tabs.ptr);
   a.lb = static_cast<unsigned long long*>(p->d_lb.ptr);
+  a.k0w = static_cast<unsigned long long*>(p->d_k0w.ptr);
+  a.block_base0 = static_cast<uint32_t*>(p->d_block_base0.ptr);
   a.tickets = static_cast<uint32_t*>(p->d_tickets.ptr);
   a.fast_lds = p->fast_lds;
   {
@@ -2740,16 +2935,20 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         for (size_t si = 0; si < p->streams.size(); ++si)
           if (k < p->streams[si].n_blocks)
             order.push_back(make_uint4(p->streams[si].first_block + k, uint32_t(si),
-                                       p->streams[si].table_base, 0u));
+                                       p->streams[si].table_base, p->streams[si].first_block));
       if ((st = up(p->d_fast_order, order.data(), order.size() * sizeof(uint4))))
         return st;
       if ((st = up(p->d_fast_tabs, ft.data(), ft.size() * sizeof(uint2))) ||
           (st = p->d_lb.ensure(size_t(p->total_blocks) * LF_LB_WORDS * 8)) ||
+          (st = p->d_k0w.ensure(size_t(p->total_blocks + 1) * 8)) ||
+          (st = p->d_block_base0.ensure(size_t(p->total_blocks) * 4)) ||
           (st = p->d_tickets.ensure(LF_TICKET_WORDS * 4)))
         return st;
       if ((st = p->d_fast_level.ensure(256)))
         return st;
       RSX_HIP_CHECK(ctx, hipMemset(p->d_tickets.ptr, 0, LF_TICKET_WORDS * 4));
+      RSX_HIP_CHECK(ctx, hipMemset(p->d_k0w.ptr, 0, size_t(p->total_blocks + 1) * 8));
+      RSX_HIP_CHECK(ctx, hipMemset(p->d_block_base0.ptr, 0, size_t(p->total_blocks) * 4));
       RSX_HIP_CHECK(ctx, hipMemset(p->d_fast_level.ptr, 0, 256));
 #ifdef RSX_EXPERIMENT
       if (getenv("RSX_DEBUG")) {
@@ -3375,13 +3574,14 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
               "[rsx]  stream %zu: marker %u status %u flags %u avail %u needed %llu "
               "last_slot %u last_pos %u consumed %u tail %u blocks %u in_bytes %llu "
               "redo_rounds %u redo_slots %u not_merged+stitched %u max_rounds %u (workgroup %u%s) "
-              "single-pass gave up: reasons 0x%x (block %u slot %u symbols before it %u base %u)\n",
+              "single-pass gave up: reasons 0x%x (block %u slot %u symbols before it %u base %u; scan: 0x%x %u %u)\n",
               k, R.marker_pos, R.status, R.flags, R.avail_lo,
               (unsigned long long)p->streams[k].needed, R.last_slot, R.last_pos,
               R.consumed, R.tail_used, p->streams[k].n_blocks,
               (unsigned long long)p->streams[k].in_bytes, R.stat_rounds, R.stat_redo,
               R.stat_stitch, R.pad2 >> 16, R.pad2 & 0x7FFFu, (R.pad2 & 0x8000u) ? ", stitch" : "",
-              R.stat_why, R.pad3[0], R.pad3[1] & 0xFFFFu, R.pad3[1] >> 16, R.pad3[2]);
+              R.stat_why, R.pad3[0], R.pad3[1] & 0xFFFFu, R.pad3[1] >> 16, R.pad3[2], R.pad3[0],
+              R.pad3[1], R.pad3[2]);
     }
   }
 #endif
@@ -3435,6 +3635,7 @@ void ljpeg_plan_destroy(LJpegPlan* p) {
     ljpeg_plan_destroy(p->nk_child);
   for (DeviceBuffer* b : {&p->d_nk, &p->d_nk_tables, &p->d_nk_rowpow, &p->d_nk_pup,
                           &p->d_transfer, &p->d_fast_tabs, &p->d_lb, &p->d_tickets, &p->d_dbg, &p->d_fast_z, &p->d_fast_level,
+                          &p->d_k0w, &p->d_block_base0,
                           &p->d_fast_order})
     b->release();
   p->d_marker_count.release();

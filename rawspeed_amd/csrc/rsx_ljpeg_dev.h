@@ -259,6 +259,9 @@ struct LjArgs {
   uint32_t guess_slots;      // slots K0 parses for a start guess (2 or 3)
   const uint4* fast_order;   // [ticket]: the workgroup's (block, stream, table) -- the streams'
                              // blocks interleaved, each stream's in order
+  unsigned long long* k0w;   // [workgroup]: what K0 knows about its symbols (lj_unstuff_kernel):
+                             // count | own estimate of its entry state, "uncertain" | true entry
+  uint32_t* block_base0;     // [workgroup]: the symbol base the single-pass kernel worked from
   unsigned long long* dbg;   // experiment builds: [workgroup][16] phase time stamps
   uint32_t fuse_consumed;    // != 0: lj_scan_kernel does lj_consumed_kernel's work as well
   uint32_t pass;             // 0: first pass; 1: the multi-kernel pipeline redoes FL_SLOW

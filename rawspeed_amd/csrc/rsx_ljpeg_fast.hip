@@ -73,7 +73,9 @@ constexpr int LF_NSIDE = 16;            // side-buffer entries (re-decodes per c
 constexpr int LF_SIDE_STRIDE = 272;     // bytes: 128 x u16 + 16 (16-byte aligned rows)
 constexpr int LF_RMAX = 256;            // stream rows that may start inside one workgroup
 constexpr uint32_t LF_MAX_ROUNDS = 6;   // re-decode rounds before the stream is given up
+constexpr int LF_K0_IT = 16;            // K0 words a lane asks for at once (4096 workgroups)
 constexpr uint32_t LF_SPIN_LIMIT = 1u << 22;
+constexpr uint32_t LF_SPIN_LIMIT_K0 = 1u << 15; // polls of a flagged predecessor's granule (~20 ms)
 // Ablation switches of experiment builds (scripts/exp_ab.py; wrong pixels, timing only):
 // 1 no staging + copy-out, 2 no copy-out, 4 no look-back 0, 8 no look-back 1, 16 no
 // decode loop, 32 no warm-up, 64 no re-decode rounds, 128 no row table
@@ -236,22 +238,16 @@ __device__ __forceinline__ void lb_store(u64* p, u64 v) {
 __device__ __forceinline__ u64 lb_load(const u64* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// word 0: status (2 bits: 1 LOCAL, 2 FINAL) | assumed entry (6) | exit (6 + error bit) |
-// symbols (16) | inclusive symbol base (32, FINAL only)
-constexpr u64 LB0_LOCAL = 1, LB0_FINAL = 2;
-__device__ __forceinline__ uint32_t st_to7(uint32_t st) {
-  return (st & ST_OFF_MASK) | ((st & ST_ERR) ? 64u : 0u);
-}
-__device__ __forceinline__ uint32_t st_from7(uint32_t v) {
-  return (v & 64u) ? ST_ERR : (v & 63u);
-}
-__device__ __forceinline__ u64 lb0_make(u64 status, uint32_t assumed, uint32_t exit7,
-                                        uint32_t cnt, uint32_t incl) {
-  return status | (u64(assumed & 63u) << 2) | (u64(exit7 & 127u) << 8) | (u64(cnt & 0xFFFFu) << 15) |
-         (u64(incl) << 32);
-}
 // words 1..8: bit 63 valid | flags (8 bits at 32) | payload (two 16-bit fields)
 constexpr u64 LB_VALID = 1ull << 63;
+// word 0 since round 4: bit 63 valid | (symbols the workgroup decoded - symbols K0 counted
+// for it), 32 bits: what a successor adds to K0's count of a FLAGGED workgroup.
+// K0's word of a workgroup (LjArgs::k0w, lj_unstuff_kernel): symbols (32) | own estimate of
+// the entry state, bit 7: count uncertain (16) | true entry state, bit 15: on record (16).
+__device__ __forceinline__ bool lf_k0_flagged(u64 w) {
+  const uint32_t own = uint32_t(w >> 32) & 0xFFFFu, tru = uint32_t(w >> 48);
+  return w != 0ull && (own != (tru & 0x7Fu) || !(tru & 0x8000u));
+}
 
 // ---------------------------------------------------------------------------
 // The fast loops.  LUT entry (uint2; built by ljpeg_build_fast_table):
@@ -270,7 +266,16 @@ struct FastState {
 template <int N, int K>
 __device__ __forceinline__ void lf_step(FastState& s, uint32_t vbase) {
   const uint32_t ad = vbase + (s.Pn & ~1023u);
+#ifdef RSX_LF_SPLIT_READS
+  // (two ds_read_b32: 56 cycles where the ds_read2st64_b32 the compiler makes of them takes
+  // 73, scripts/ubench/valu_rates.hip)
+  uint32_t d0, d1;
+  asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(d1), "=&v"(d0)
+               : "v"(ad));
+#else
   const uint32_t d1 = *(lds_u32p)(ad), d0 = *(lds_u32p)(ad + 4u * LJ_T);
+#endif
   const uint32_t w = __builtin_amdgcn_alignbit(d0, d1, s.Pn >> 5);
   const lf_u32x2 e = *(lds_u2p)((w >> 19) & 0x1FF8u);
   const uint32_t v = (w >> (e.x & 31u)) & e.y;
@@ -398,80 +403,6 @@ __device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds& tb, 
   exit = ok ? ((pend - Pn) >> 5) : ST_ERR;
   count = n;
   sums = make_uint2(a0, a1);
-}
-
-// ---------------------------------------------------------------------------
-// Look-back 0 (the whole workgroup, one record per lane and pass): the index of the
-// workgroup's first symbol.  A LOCAL record counts when its assumed entry is its own
-// predecessor's exit; otherwise its owner is re-converging and will publish again.
-// (With one wavefront walking, 64 records per pass, the walks of the ~300 workgroups
-// in flight took 5 passes each -- and every pass made the walks longer: 22 us a workgroup.)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ bool lb0_walk(const LjArgs& a, const FastLds& F, uint32_t b,
-                                         uint32_t first_block, uint32_t start_bit, int j,
-                                         uint32_t* pred_exit, uint32_t* base_out) {
-  const int lane = j & 63, wv = j >> 6;
-  const u64* A = a.lb;
-  const u64 virt = lb0_make(LB0_FINAL, 0, st_to7(start_bit), 0, 0);
-  uint32_t acc = 0;
-  int64_t pos = int64_t(b) - 1;
-  for (uint32_t spins = 0; spins < LF_SPIN_LIMIT; ++spins) {
-    const int64_t idx = pos - j;
-    const u64 r = idx >= int64_t(first_block) ? lb_load(A + size_t(idx) * LF_LB_WORDS) : virt;
-    const u64 rp =
-        idx - 1 >= int64_t(first_block) ? lb_load(A + size_t(idx - 1) * LF_LB_WORDS) : virt;
-    const uint32_t st = uint32_t(r & 3u), stp = uint32_t(rp & 3u);
-    const uint32_t cnt = uint32_t(r >> 15) & 0xFFFFu, assumed = uint32_t(r >> 2) & 63u;
-    const uint32_t exitp = uint32_t(rp >> 8) & 127u;
-    const bool fin = st == 2;
-    // (an error exit is not propagated: the successor keeps its own guess -- the stream
-    // is damaged and goes to the slow path anyway)
-    const bool ok = st == 1 && stp != 0 && (assumed == (exitp & 63u) || (exitp & 64u));
-    const u64 m_ok = __ballot(ok), m_fin = __ballot(fin);
-    const int f = (~m_ok) ? __builtin_ctzll(~m_ok) : 64;
-    const uint32_t part = wave_sum_u32(lane < f ? cnt : 0u);
-    if (lane == 0) {
-      F.misc[M_LBX + 4 * wv] = uint32_t(f);
-      F.misc[M_LBX + 4 * wv + 1] = part;
-      F.misc[M_LBX + 4 * wv + 2] = f < 64 ? uint32_t((m_fin >> f) & 1ull) : 0u;
-    }
-    if (f < 64 && lane == f)
-      F.misc[M_LBX + 4 * wv + 3] = uint32_t(r >> 32);
-    if (j == 0 && pos == int64_t(b) - 1)
-      F.misc[M_PRED] = st ? (0x100u | (uint32_t(r >> 8) & 127u)) : 0u; // the predecessor's exit
-    __syncthreads();
-    // the four wavefronts' windows in order (nearest first)
-    int state = 0; // 0: all 256 linked, 1: found FINAL, 2: blocked
-    uint32_t sum = 0, incl = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (state != 0)
-        continue;
-      const uint32_t fw = uni(F.misc[M_LBX + 4 * w]);
-      sum += uni(F.misc[M_LBX + 4 * w + 1]);
-      if (fw < 64u) {
-        state = uni(F.misc[M_LBX + 4 * w + 2]) ? 1 : 2;
-        incl = uni(F.misc[M_LBX + 4 * w + 3]);
-      }
-    }
-    if (pos == int64_t(b) - 1) {
-      const uint32_t pw = uni(F.misc[M_PRED]);
-      if (pw)
-        *pred_exit = st_from7(pw & 127u);
-    }
-    __syncthreads(); // (the exchange words are free again)
-    if (state == 1) {
-      *base_out = incl + sum + acc;
-      return true;
-    }
-    if (state == 0) {
-      acc += sum;
-      pos -= LJ_T;
-      continue;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-  return false;
 }
 
 // transfer of the predictor state over a run of symbols: T' = f ? Vc + a : T + a,
@@ -1037,6 +968,27 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   const uint32_t ob_now = reinterpret_cast<const uint32_t*>(img_src + (LJ_BW / 4) * LJ_T)[j];
   // (a stream's subsequences are numbered from first_block * LJ_OWN: the guesses too)
   const uint32_t guess_now = j >= 1 ? uint32_t(a.sub_start[size_t(b) * LJ_OWN + uint32_t(j - 1)]) : 0u;
+  // Symbol base (round 4): K0 has counted every workgroup's symbols under the very entry
+  // states this kernel decodes from (its chain's fixed point), so the index of the
+  // workgroup's first symbol is a SUM the workgroup reads when it starts -- the words of
+  // its stream's workgroups in front of it, 16 per lane in flight next to the image -- and
+  // not the end of a look-back over their decodes (3.6-3.9 us of waiting for the slowest of
+  // the nearest predecessors, every one of them waiting the same way).  What K0 cannot
+  // vouch for is marked in the word ("flagged": its own estimate of the workgroup's entry
+  // state is not what the predecessor's chain arrives at -- 1.7 % --, a code outside the
+  // 10-bit table, data that does not synchronise); those workgroups' true counts are asked
+  // for below, and they alone.  lj_scan_kernel checks every base afterwards.
+  const uint32_t fb_now = uni(bs.w), lb_now = b - fb_now;
+  u64 kw_mine = 0, kwv[LF_K0_IT];
+  {
+    const u64* kw = a.k0w + fb_now;
+    kw_mine = kw[lb_now];
+#pragma unroll
+    for (int it = 0; it < LF_K0_IT; ++it) {
+      const uint32_t k = uint32_t(it) * uint32_t(LJ_T) + uint32_t(j);
+      kwv[it] = k < lb_now ? kw[k] : 0ull;
+    }
+  }
   uint4 lut_now[2];
   {
     const uint4* src = reinterpret_cast<const uint4*>(a.fast_tabs + size_t(table_base) * 1024);
@@ -1053,8 +1005,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   if (uni(flags_now) & FL_SLOW) {
     if (j == 0) {
       u64* p = a.lb + size_t(b) * LF_LB_WORDS;
-      lb_store(p, lb0_make(LB0_FINAL, 0, 0, 0, 0));
-      for (int k = 1; k < LF_LB_WORDS; ++k)
+      for (int k = 0; k < LF_LB_WORDS; ++k)
         lb_store(p + k, LB_VALID);
       a.block_start[b] = 0;
       a.block_exit[b] = 0;
@@ -1092,6 +1043,22 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     }
     F.ob[j] = uint16_t(ob_now);
   }
+  // the symbols in front of the workgroup as K0 counted them, and which of those
+  // workgroups are flagged (own estimate ^ true entry = the "on record" bit and nothing else
+  // -- "uncertain" sits in the own half -- means neither)
+  uint32_t kacc = 0, kflag = 0;
+#pragma unroll
+  for (int it = 0; it < LF_K0_IT; ++it) {
+    const u64 w = kwv[it];
+    kacc += uint32_t(w);
+    const uint32_t hi = uint32_t(w >> 32);
+    kflag |= (((hi >> 16) ^ hi) & 0xFFFFu) != 0x8000u ? (1u << it) : 0u;
+  }
+  {
+    const uint32_t nval =
+        lb_now > uint32_t(j) ? min(uint32_t(LF_K0_IT), (lb_now - uint32_t(j) + 255u) >> 8) : 0u;
+    kflag &= (1u << nval) - 1u;
+  }
   __syncthreads();
   LF_STAMP(2);
   // delay the lane's column by one bit (see the header): dword k := d[k-1] : d[k] >> 1
@@ -1103,6 +1070,24 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       const uint32_t d = *p;
       *p = __builtin_amdgcn_alignbit(prev, d, 1);
       prev = d;
+    }
+  }
+  // (streams of more than LF_K0_IT * 256 workgroups -- 67 MB of entropy-coded data --: the
+  // rest of the words, group by group)
+  for (uint32_t k0 = uint32_t(LF_K0_IT) * uint32_t(LJ_T); k0 < lb_now; k0 += uint32_t(LJ_T)) {
+    const uint32_t k = k0 + uint32_t(j);
+    if (k < lb_now) {
+      const u64 w = a.k0w[fb_now + k];
+      kacc += uint32_t(w);
+      if (lf_k0_flagged(w)) {
+        u64 g = 0;
+        for (uint32_t spins = 0; spins < LF_SPIN_LIMIT_K0 && !(g & LB_VALID); ++spins)
+          g = lb_load(a.lb + size_t(fb_now + k) * LF_LB_WORDS);
+        if (g & LB_VALID)
+          kacc += uint32_t(g);
+        else
+          F.misc[M_SLOW] = 6;
+      }
     }
   }
   __syncthreads();
@@ -1117,6 +1102,12 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   const uint32_t guess = guess_now;
   LF_STAMP(4);
   uint32_t start = guess & ST_OFF_MASK;
+  // slot 1 starts where the predecessor workgroup's chain ends (its lane 255 left it in this
+  // workgroup's word), the stream's first slot where the stream does
+  const uint32_t e1_word = uni(uint32_t(kw_mine >> 48));
+  const uint32_t k0_cnt_mine = uni(uint32_t(kw_mine));
+  if (j == 1 && (e1_word & 0x8000u))
+    start = e1_word & ST_OFF_MASK;
   if (j == 1 && lb == 0)
     start = S.start_bit;
 
@@ -1134,6 +1125,19 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     fs.Pn = pend;
   lf_groups<N, 0>(fs, vbase_own, pend, R);
   LF_STAMP(5);
+  // the granules of the flagged workgroups in front (1.7 % of them: 0.24 per lane on
+  // average, the first two of a lane asked for now): in flight behind the rounds and scans
+  u64 kg0 = 0, kg1 = 0;
+  uint32_t kit0 = 0, kit1 = 0;
+  if (kflag != 0u) {
+    kit0 = uint32_t(__builtin_ctz(kflag));
+    kg0 = lb_load(a.lb + size_t(fb_now + kit0 * uint32_t(LJ_T) + uint32_t(j)) * LF_LB_WORDS);
+    const uint32_t rest = kflag & (kflag - 1u);
+    if (rest != 0u) {
+      kit1 = uint32_t(__builtin_ctz(rest));
+      kg1 = lb_load(a.lb + size_t(fb_now + kit1 * uint32_t(LJ_T) + uint32_t(j)) * LF_LB_WORDS);
+    }
+  }
   bool need_redo = false;
   {
     const bool special = !(fs.Pn & 0x80000000u);
@@ -1165,8 +1169,9 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // the loops makes every register of R loop-carried, and the compiler then keeps two
   // copies of the 64 (measured: 180 VGPRs).
   int my_entry = -1;
-  bool exit_changed = false;
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  {
+    constexpr int attempt = 0; // (rounds 1-3 repaired a wrong entry state in a second attempt, after
+                               // look-back 0 had told the workgroup; see "symbol base")
     // 3. Jacobi rounds with a dense list (lj_sync_kernel's scheme)
     uint32_t rounds = 0;
     while (true) {
@@ -1240,8 +1245,6 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       if (j == 0) {
         atomicAdd(&a.results[s].stat_rounds, 1u);
         atomicAdd(&a.results[s].stat_redo, nl);
-        if (attempt == 1)
-          atomicAdd(&a.results[s].stat_stitch, 1u);
       }
 #endif
       uint32_t idx = 1, w = 0, e = 0, c = 0;
@@ -1298,13 +1301,11 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       F.misc[M_UNRESB] = before;
     cnt_wg = uni(F.misc[M_WCNT] + F.misc[M_WCNT + 1] + F.misc[M_WCNT + 2] + F.misc[M_WCNT + 3]);
     const uint32_t exit_now = uni(rec_st(F.rec[LJ_T - 1]));
-    const uint32_t entry_now = uni(rec_st(F.rec[0]));
-    // 4a. the workgroup's record (LOCAL: entry, exit and symbols of this decode) as soon as
-    // its three fields are known -- the scan of the difference sums below is nobody else's
-    // business, and the successors' first poll should find the record
-    if (lb != 0 && j == 0)
-      lb_store(a.lb + size_t(b) * LF_LB_WORDS,
-               lb0_make(LB0_LOCAL, entry_now, st_to7(exit_now), cnt_wg, 0));
+    // 4a. the workgroup's granule as soon as its symbols are known: what it decoded beyond
+    // (or short of) K0's count.  Only successors that find this workgroup FLAGGED in K0's
+    // words read it.
+    if (j == 0)
+      lb_store(a.lb + size_t(b) * LF_LB_WORDS, LB_VALID | u64(uint32_t(cnt_wg - k0_cnt_mine)));
     {
       const uint2 r = lj_rot_fields<N>(my_sums, before & uint32_t(N - 1));
       const uint2 pincl = wave_scan_pk2(r, lane);
@@ -1323,33 +1324,46 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       }
     }
 
-    // 4. look-back 0: the predecessor's exit and the index of the workgroup's first symbol
-    // in one sweep over the predecessors' records.  A wrong entry assumption is repaired
-    // and the record published again; the symbol index does not depend on it.
-    if (attempt == 0) {
-      published_exit = exit_now;
-      LF_STAMP(6);
-    } else if (exit_now != published_exit) {
-      exit_changed = true; // successors may have used the exit published first
+    // 4. the symbol base: K0's counts of the workgroups in front (read at the start) + the
+    // corrections of the flagged ones.  Those still in flight when this workgroup started --
+    // flagged ones among its ~128 nearest predecessors: two on average, and only the very
+    // nearest can still be decoding -- are asked again now.
+    published_exit = exit_now;
+    LF_STAMP(6);
+    {
+      if (kg0 & LB_VALID) {
+        kacc += uint32_t(kg0);
+        kflag &= ~(1u << kit0);
+      }
+      if (kg1 & LB_VALID) {
+        kacc += uint32_t(kg1);
+        kflag &= ~(1u << kit1);
+      }
+      uint32_t spins = 0;
+      while (__any(kflag != 0u)) {
+        if (kflag != 0u) {
+          const uint32_t it = uint32_t(__builtin_ctz(kflag));
+          const u64 g = lb_load(a.lb + size_t(fb_now + it * uint32_t(LJ_T) + uint32_t(j)) * LF_LB_WORDS);
+          if (g & LB_VALID) {
+            kacc += uint32_t(g);
+            kflag &= kflag - 1u;
+          }
+        }
+        if (++spins > LF_SPIN_LIMIT_K0) {
+          F.misc[M_SLOW] = 6;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const uint32_t part = wave_sum_u32(kacc);
+      if (lane == 0)
+        F.misc[M_LBX + wv] = part;
+      __syncthreads();
+      base = uni(F.misc[M_LBX] + F.misc[M_LBX + 1] + F.misc[M_LBX + 2] + F.misc[M_LBX + 3]);
+      if (LF_ABLATE & 4u)
+        base = lb * 15500u;
     }
-    if (lb == 0)
-      break;
-    if (attempt == 1)
-      break;
-    uint32_t pe = entry_now, bs = lb * 15500u;
-    if (!(LF_ABLATE & 4u)) {
-      const bool ok = lb0_walk(a, F, b, S.first_block, S.start_bit, j, &pe, &bs);
-      if (!ok && j == 0)
-        F.misc[M_SLOW] = 6;
-    }
-    base = bs;
     LF_STAMP(7);
-    if (pe == entry_now || (pe & ST_ERR))
-      break;
-    // the assumed entry was wrong: re-converge from the true one
-    // (the barrier at the top of the rounds orders this store)
-    if (j == 0)
-      F.rec[0] = rec_make(0, pe, 0);
   }
   LF_STAMP(8);
   if (__any(my_entry >= 0 && my_entry < LF_NSIDE)) {
@@ -1361,10 +1375,6 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
         R[q] = *(lds_u32p)(sa + 4u * q);
     }
   }
-  // FINAL: from here on successors stop at this record
-  if (j == 0)
-    lb_store(a.lb + size_t(b) * LF_LB_WORDS,
-             lb0_make(LB0_FINAL, rec_st(F.rec[0]), st_to7(published_exit), cnt_wg, base + cnt_wg));
   // (the records the per-stream bookkeeping kernels read are stored at the very end: on
   // gfx9 a store in front of the look-back's loads makes their s_waitcnt wait for its
   // acknowledgement, too)
@@ -1407,9 +1417,6 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     a.results[s].pad3[2] = base;
 #endif
   }
-  // (an exit that a repair changed: the same, seen from the successors)
-  if (j == 0 && exit_changed && uint64_t(base) + cnt_wg < needed)
-    F.misc[M_SLOW] = 5;
   LF_STAMP(9);
 
   // 5. geometry of the delivered symbols [base, lim) and the stream rows they touch
@@ -1603,6 +1610,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   if (j == 0) {
     a.block_start[b] = entry_final;
     a.block_exit[b] = published_exit;
+    a.block_base0[b] = base;
     a.block_sum[b] = cnt_wg;
     a.block_flags[b] = 0;
     a.block_psum[b] = S_wg;

@@ -49,6 +49,25 @@ def run_plan(plan, inp, out):
     return cons
 
 
+def route(plan, inp, out):
+    """which kernels a run of the plan launches (rsx_plan_kernel_table): parity holds on
+    either route, but a BASELINE shape silently demoted to the multi-kernel pipeline would
+    otherwise show in the bench only"""
+    plan.set_timing(True)
+    plan.run(inp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    tab = plan.kernel_table()
+    plan.set_timing(False)
+    return [n for n, _ in tab[0]] if tab else []
+
+
+def assert_single_pass(names, also_allowed=()):
+    assert any(n.startswith("lj_fast_kernel") for n in names), names
+    slow = [n for n in names if ("sync" in n or "decode" in n or "rowedge" in n)
+            and n not in also_allowed]
+    assert not slow, names
+
+
 def test_cfg2_every_frame_vs_reference(gpu, ref):
     import bench
     cfg, frames = bench.CFG2, 3
@@ -65,9 +84,11 @@ def test_cfg2_every_frame_vs_reference(gpu, ref):
         assert same(bench.frame_of(out, cfg, f), img.pixels()), f
 
 
-def _cr2_frames(gpu, ref, made, W, H):
+def _cr2_frames(gpu, ref, made, W, H, single_pass=True):
     plan, inp, out = B._cr2_batch(gpu, torch, [(m[0], m[1]) for m in made], W, H)
     cons = run_plan(plan, inp, out)
+    if single_pass:
+        assert_single_pass(route(plan, inp, out))
     for f, m in enumerate(made):
         img = ref.image(W, H, 1)
         st, rcons = ref.cr2(m[0], m[1], img)
@@ -117,7 +138,10 @@ def test_cfg4_dng_tiles_vs_reference_fanout(gpu, ref, shape):
     src, jobs, datas, blobs, lens = B._dng_tiles(W, H, tw, th, 21, ri)
     inp = torch.from_numpy(np.concatenate(datas)).cuda()
     out = torch.zeros(B.out_pitch(W) * H, dtype=torch.uint8, device="cuda")
-    cons = run_plan(gpu.ljpeg_plan(jobs), inp, out)
+    plan = gpu.ljpeg_plan(jobs)
+    cons = run_plan(plan, inp, out)
+    if ri == 0:  # (restart intervals: the intervals are streams of a child plan)
+        assert_single_pass(route(plan, inp, out))
     img = ref.image(W, H, 1)
     assert ref.dng(img, 7, tw, th, blobs, threads=4) == 0, ref.last_error()
     got = B.gpu_frame(out, 0, W, H)
@@ -136,6 +160,7 @@ def test_cfg5_batch_every_frame_vs_reference(gpu, ref):
     frames = 6
     plan, inp, out, meta = B.make_cfg5_plan(gpu, torch, frames, distinct=3, seed0=4000)
     cons = run_plan(plan, inp, out)
+    assert_single_pass(route(plan, inp, out))
     refs = []
     for d, data in meta["blobs"]:
         img = ref.image(meta["W"], meta["H"], 1)
