@@ -631,7 +631,16 @@ constexpr int LJ_GUESS_SLOTS = 3; // slots parsed for a guess, at most (LjArgs::
 
 __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // The LAST workgroups first: the kernels behind this one read the un-stuffed image from
+  // its first workgroup on, and what went through the 256 MB memory-side cache last is
+  // what they find there (cfg 3: the image alone is 343 MB; in block order the cache holds
+  // its END when the readers start at its beginning -- measured: K0 -3 %, the single-pass
+  // kernel -1 %, a single cfg-4 frame -2.8 %).  K0's workgroups are independent of one another.
+#ifdef RSX_K0_FORWARD
   const uint32_t b = blockIdx.x;
+#else
+  const uint32_t b = gridDim.x - 1u - blockIdx.x;
+#endif
   const uint32_t s = a.block_stream[b];
   const LjStreamDev& S = a.streams[s];
   // This kernel's own layout: the arrays of the general one that only the synchronisation
@@ -3553,13 +3562,14 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
         }
       }
       static const char* nm[16] = {"", "ticket+stream", "tables+image", "bit delay", "guess", "decode",
-                                   "rounds+scan", "lb0 walk", "(redo)", "fetch+records",
-                                   "row dump", "row scan", "lb1", "C table", "staging", "copy-out"};
+                                   "rounds+scan", "symbol base", "fetch+records", "geometry+barrier",
+                                   "staging", "rows + scan", "lb1", "C table",
+                                   "-", "copy-out"};
       fprintf(stderr, "[rsx] single-pass phases over %zu workgroups, kernel span %.1f us:\n", n,
               double(tmax - tmin) / 2400.0);
       double tot = 0;
       for (int k = 1; k < 16; ++k) {
-        fprintf(stderr, "[rsx]   %-14s mean %7.2f us  max %8.2f us\n", nm[k], n ? sum[k] / n : 0.0, mx[k]);
+        fprintf(stderr, "[rsx]   %-18s mean %7.2f us  max %8.2f us\n", nm[k], n ? sum[k] / n : 0.0, mx[k]);
         tot += n ? sum[k] / n : 0.0;
       }
       fprintf(stderr, "[rsx]   %-14s mean %7.2f us\n", "lifetime", tot);

@@ -638,138 +638,49 @@ __device__ __forceinline__ void strip_divmod(uint64_t off, uint32_t w, uint32_t*
 // Copy-out: the staged running sums of stream symbols [A0, A1) (LDS, stream order from
 // byte address sb) -> image.  The samples fall into RUNS that are contiguous in the image
 // (a stream row's kept part, a CR2 strip row); a run is written as 16-byte chunks on the
-// destination's 16-byte grid (partial chunks at its ends sample by sample).  All chunks of
-// all runs are numbered through and dealt to the lanes round robin; every lane walks the
-// run list itself, incrementally (adds and compares: the divisions are in the first run
-// only), as its chunk number grows.  (First version: the workgroup went run by run -- two
-// passes of 256 lanes per 280-chunk run, the second one nearly empty, and two divisions
-// per run: 13 us a workgroup, then 5.6.)
+// destination's 16-byte grid (partial chunks at its ends sample by sample).
+// (Round 3 dealt CHUNKS to lanes and had every lane walk the run list for itself: with runs
+// of ~280 chunks and a stride of 256 nearly every chunk of a lane lay in another run than
+// its last one, so the run's set-up -- address arithmetic in 64 bits, the row's constants,
+// the CR2 strip: ~100 vector instructions -- was paid per 16 bytes, a third of the kernel's
+// vector instructions.)  The run list is walked ONCE PER WAVEFRONT with wave-uniform state
+// (scalar registers, the scalar unit), every run is cut into segments of 64 chunks, and the
+// segments are dealt to the four wavefronts round robin; a lane's work per chunk is what
+// only it can do: five LDS reads, four funnel shifts, four packed adds, one 16-byte store.
 // ---------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void lf_copy_out(const FastLds& F, const LjArgs& a,
-                                            const FastStream& S, uint32_t A0, uint32_t A1,
-                                            uint32_t sb, uint32_t r0, int tid) {
-  const uint32_t RS = S.RS;
-  uint8_t* img = a.out_base + S.img_offset;
-  const Cr2Strip* st = reinterpret_cast<const Cr2Strip*>(F.strips);
-  // cursor: the run that starts at sample i
-  uint32_t i = A0, r = A0 / RS, sidx = A0 - r * RS;
-  uint32_t z = 0, srow = 0, col = 0, sw = 1, sx0 = 0, sy0 = 0, znext = 0xFFFFFFFFu;
+// where the walk over the runs starts (CR2: the strip of the workgroup's first sample and
+// the place in it: a search over the strips and a division) -- worked out BEFORE look-back 1,
+// in the shadow of its wait, not behind it
+struct WalkStart {
+  uint32_t z, srow, col, sw, sx0, sy0, znext;
+};
+__device__ __forceinline__ WalkStart lf_walk_start(const FastLds& F, const FastStream& S,
+                                                   uint32_t A0_) {
+  WalkStart w{0, 0, 0, 1, 0, 0, 0xFFFFFFFFu};
   if (S.kind == 1) {
+    const uint32_t i = uni(A0_);
+    const Cr2Strip* st = reinterpret_cast<const Cr2Strip*>(F.strips);
+    uint32_t z = 0;
     while (z + 1 < S.n_strips && uint64_t(i) >= uni64(st[z + 1].first_sample))
       ++z;
-    sx0 = uni(st[z].x0);
-    sw = uni(st[z].w);
-    sy0 = uni(st[z].y0);
-    strip_divmod(uint64_t(i) - uni64(st[z].first_sample), sw, &srow, &col);
-    znext = z + 1 < S.n_strips ? uint32_t(uni64(st[z + 1].first_sample)) : 0xFFFFFFFFu;
+    w.z = z;
+    w.sx0 = uni(st[z].x0);
+    w.sw = uni(st[z].w);
+    w.sy0 = uni(st[z].y0);
+    uint32_t srow, col;
+    strip_divmod(uint64_t(i) - uni64(st[z].first_sample), w.sw, &srow, &col);
+    w.srow = uni(srow);
+    w.col = uni(col);
+    w.znext = z + 1 < S.n_strips ? uint32_t(uni64(st[z + 1].first_sample)) : 0xFFFFFFFFu;
   }
-  uint32_t gstart = 0, nch = 0, n = 0, lds0 = 0, sh = 0, cd[4] = {0, 0, 0, 0};
-  uint8_t* d0 = nullptr;
-  bool have = false; // the cursor's run is set up (nch, d0, ...)
-  uint32_t g = uint32_t(tid);
-  while (true) {
-    // set up runs until the one that holds chunk g
-    while (!have || g >= gstart + nch) {
-      if (have) { // move the cursor past the run
-        gstart += nch;
-        i += n;
-        sidx += n;
-        if (sidx == RS) {
-          sidx = 0;
-          ++r;
-        }
-        if (S.kind == 1) {
-          col += n;
-          if (col == sw) {
-            col = 0;
-            ++srow;
-          }
-          if (i >= znext) {
-            ++z;
-            sx0 = st[z].x0;
-            sw = st[z].w;
-            sy0 = st[z].y0;
-            srow = 0;
-            col = 0;
-            znext = z + 1 < S.n_strips ? uint32_t(st[z + 1].first_sample) : 0xFFFFFFFFu;
-          }
-        }
-      }
-      if (i >= A1)
-        return;
-      uint8_t* dst = nullptr;
-      if (S.kind == 0) {
-        if (sidx < S.keep) {
-          n = S.keep - sidx;
-          dst = img + uint64_t(S.out_y + r) * S.pitch + 2u * (S.out_x + sidx);
-        } else {
-          n = RS - sidx; // trailing MCUs of the frame that the tile does not keep
-        }
-      } else {
-        const uint32_t in_strip = sw - col, in_row = RS - sidx;
-        n = in_strip < in_row ? in_strip : in_row;
-        dst = img + uint64_t(sy0 + srow) * S.pitch + 2u * (sx0 + col);
-      }
-      if (n > A1 - i)
-        n = A1 - i;
-      have = true;
-      nch = 0;
-      if (dst) {
-        const uint2 C = F.ctab[r - r0];
-        const uint32_t delta = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u) >> 1;
-        const uint32_t ph0 = (i + 8u - delta) & uint32_t(N - 1);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          cd[t] = fld(C, (ph0 + 2u * t) & uint32_t(N - 1)) |
-                  (fld(C, (ph0 + 2u * t + 1u) & uint32_t(N - 1)) << 16);
-        nch = (delta + n + 7u) >> 3;
-        lds0 = sb + 2u * (i - A0) - 2u * delta;
-        sh = 8u * (lds0 & 2u); // the staged samples start mid-dword: 16, else 0
-        d0 = dst - 2u * delta;
-        sh |= delta << 8; // (the run's delta rides along above the shift amount)
-      }
-    }
-    const uint32_t m = g - gstart;
-    const uint32_t delta = sh >> 8;
-    const int32_t sf = int32_t(8u * m) - int32_t(delta);
-    const uint32_t la = (lds0 + 16u * m) & ~3u;
-    uint32_t dw[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t)
-      dw[t] = *(lds_u32p)(la + 4u * t);
-    uint32_t o[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      o[t] = pk_add(__builtin_amdgcn_alignbit(dw[t + 1], dw[t], sh & 31u), cd[t]);
-    uint8_t* p = d0 + 16u * m;
-    if (sf >= 0 && uint32_t(sf) + 8u <= n) {
-      *reinterpret_cast<uint4*>(p) = make_uint4(o[0], o[1], o[2], o[3]);
-    } else {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int32_t q = sf + t;
-        if (q >= 0 && uint32_t(q) < n)
-          reinterpret_cast<uint16_t*>(p)[t] = uint16_t(o[t >> 1] >> (16 * (t & 1)));
-      }
-    }
-    g += uint32_t(LJ_T);
-  }
+  return w;
 }
 
-// Copy-out, second version (round 4).  The version above deals CHUNKS to lanes and has every
-// lane walk the run list for itself: with runs of ~280 chunks and a stride of 256 nearly
-// every chunk of a lane lies in another run than its last one, so the run's set-up (address
-// arithmetic in 64 bits, the row's constants, the CR2 strip) -- ~100 vector instructions --
-// was paid per 16 bytes: a third of the kernel's vector instructions.  Here the run list is
-// walked ONCE PER WAVEFRONT with wave-uniform state (scalar registers, the scalar unit),
-// every run is cut into segments of 64 chunks, and the segments are dealt to the four
-// wavefronts round robin; a lane's work per chunk is what only it can do: five LDS reads,
-// four funnel shifts, four packed adds, one 16-byte store.
 template <int N>
 __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
                                              const FastStream& S, uint32_t A0_, uint32_t A1_,
-                                             uint32_t sb, uint32_t r0_, int tid) {
+                                             uint32_t sb, uint32_t r0_, int tid,
+                                             const WalkStart& ws) {
   const uint32_t lane = uint32_t(tid) & 63u;
   const uint32_t wv = uni(uint32_t(tid) >> 6);
   // (every lane holds the same values: said so, or the walk below runs on vector registers)
@@ -779,17 +690,13 @@ __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
   const Cr2Strip* st = reinterpret_cast<const Cr2Strip*>(F.strips);
   // cursor (wave-uniform): the run that starts at sample i
   uint32_t i = A0, r = r0, sidx = A0 - r0 * RS;
-  uint32_t z = 0, srow = 0, col = 0, sw = 1, sx0 = 0, sy0 = 0, znext = 0xFFFFFFFFu;
-  if (S.kind == 1) {
-    while (z + 1 < S.n_strips && uint64_t(i) >= uni64(st[z + 1].first_sample))
-      ++z;
-    sx0 = uni(st[z].x0);
-    sw = uni(st[z].w);
-    sy0 = uni(st[z].y0);
-    strip_divmod(uint64_t(i) - uni64(st[z].first_sample), sw, &srow, &col);
-    srow = uni(srow);
-    col = uni(col);
-    znext = z + 1 < S.n_strips ? uint32_t(uni64(st[z + 1].first_sample)) : 0xFFFFFFFFu;
+  uint32_t z = uni(ws.z), srow = uni(ws.srow), col = uni(ws.col), sw = uni(ws.sw),
+           sx0 = uni(ws.sx0), sy0 = uni(ws.sy0), znext = uni(ws.znext);
+  // (the row's constants: read when the row changes, not per run)
+  uint2 C;
+  {
+    const uint2 Cv = F.ctab[0];
+    C = make_uint2(uni(Cv.x), uni(Cv.y));
   }
   uint32_t gseg = 0; // segments dealt so far
   while (i < A1) {
@@ -810,8 +717,6 @@ __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
     if (n > A1 - i)
       n = A1 - i;
     if (dst) {
-      const uint2 Cv = F.ctab[r - r0];
-      const uint2 C = make_uint2(uni(Cv.x), uni(Cv.y));
       const uint32_t delta = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u) >> 1;
       const uint32_t ph0 = (i + 8u - delta) & uint32_t(N - 1);
       uint32_t cd[4];
@@ -858,6 +763,10 @@ __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
     if (sidx == RS) {
       sidx = 0;
       ++r;
+      if (i < A1) {
+        const uint2 Cv = F.ctab[r - r0];
+        C = make_uint2(uni(Cv.x), uni(Cv.y));
+      }
     }
     if (S.kind == 1) {
       col += n;
@@ -879,22 +788,45 @@ __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
 }
 
 // Staging of a lane's register pairs q < nq (static register indices; groups of four
-// pairs are skipped wave-uniformly once nobody has any left)
+// pairs are skipped wave-uniformly once nobody has any left).  Round 4: the four pairs of
+// a group in one hand-written block.  Left to the compiler every pair was "compare, save
+// exec, branch, add, two writes, restore exec" with the branches taken or not lane set by
+// lane set -- 2 us a workgroup whether four lanes staged or all of them (the two-phase
+// experiment, profiles/r04).  The lanes that still have pair q are a SUBSET of those that
+// had pair q - 1, so v_cmpx (it writes EXEC) only ever narrows the set: no branch, no
+// restore inside the group; 18 instructions for four pairs.
 template <int Q4>
 __device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad, uint32_t nq,
                                          uint32_t nqmax, uint32_t k0, uint32_t k1) {
   if (uint32_t(4 * Q4) < nqmax) { // (wave-uniform)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      constexpr int dummy = 0;
-      (void)dummy;
-      const int q = 4 * Q4 + u;
-      if (uint32_t(q) < nq) {
-        const uint32_t v = pk_add(R[q], (q & 1) ? k1 : k0);
-        *(lds_u16w)(ad + 4u * q) = uint16_t(v);
-        *(lds_u16w)(ad + 4u * q + 2u) = uint16_t(v >> 16);
-      }
-    }
+    uint64_t saved;
+    uint32_t t;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_lt_u32_e32 vcc, %[q0], %[nq]\n\t"
+                 "v_pk_add_u16 %[t], %[r0], %[k0]\n\t"
+                 "ds_write_b16 %[ad], %[t] offset:%[o0]\n\t"
+                 "ds_write_b16_d16_hi %[ad], %[t] offset:%[o0h]\n\t"
+                 "v_cmpx_lt_u32_e32 vcc, %[q1], %[nq]\n\t"
+                 "v_pk_add_u16 %[t], %[r1], %[k1]\n\t"
+                 "ds_write_b16 %[ad], %[t] offset:%[o1]\n\t"
+                 "ds_write_b16_d16_hi %[ad], %[t] offset:%[o1h]\n\t"
+                 "v_cmpx_lt_u32_e32 vcc, %[q2], %[nq]\n\t"
+                 "v_pk_add_u16 %[t], %[r2], %[k0]\n\t"
+                 "ds_write_b16 %[ad], %[t] offset:%[o2]\n\t"
+                 "ds_write_b16_d16_hi %[ad], %[t] offset:%[o2h]\n\t"
+                 "v_cmpx_lt_u32_e32 vcc, %[q3], %[nq]\n\t"
+                 "v_pk_add_u16 %[t], %[r3], %[k1]\n\t"
+                 "ds_write_b16 %[ad], %[t] offset:%[o3]\n\t"
+                 "ds_write_b16_d16_hi %[ad], %[t] offset:%[o3h]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(saved), [t] "=&v"(t)
+                 : [nq] "v"(nq), [ad] "v"(ad), [k0] "v"(k0), [k1] "v"(k1), [r0] "v"(R[4 * Q4]),
+                   [r1] "v"(R[4 * Q4 + 1]), [r2] "v"(R[4 * Q4 + 2]), [r3] "v"(R[4 * Q4 + 3]),
+                   [q0] "n"(4 * Q4), [q1] "n"(4 * Q4 + 1), [q2] "n"(4 * Q4 + 2),
+                   [q3] "n"(4 * Q4 + 3), [o0] "n"(16 * Q4), [o0h] "n"(16 * Q4 + 2),
+                   [o1] "n"(16 * Q4 + 4), [o1h] "n"(16 * Q4 + 6), [o2] "n"(16 * Q4 + 8),
+                   [o2h] "n"(16 * Q4 + 10), [o3] "n"(16 * Q4 + 12), [o3h] "n"(16 * Q4 + 14)
+                 : "vcc", "memory");
     if constexpr (Q4 + 1 < LF_NR / 4)
       lf_stage<Q4 + 1>(R, ad, nq, nqmax, k0, k1);
   }
@@ -1043,6 +975,20 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     }
     F.ob[j] = uint16_t(ob_now);
   }
+  // the CR2 strips (into LDS behind the bit delay: their region at the end of the allocation
+  // is nobody else's; asked for in front of the rows, as they were, a global-memory round
+  // trip of 1 us stood in every workgroup's way.  In LDS because a load behind the pixel
+  // stores would wait for their acknowledgements.)
+  static_assert((MAX_CR2_STRIPS + 1) * sizeof(Cr2Strip) / 4 <= 2 * LJ_T, "two dwords a lane");
+  uint32_t strip_w0 = 0, strip_w1 = 0;
+  const uint32_t strip_nw = S.kind == 1 ? (S.n_strips + 1) * uint32_t(sizeof(Cr2Strip) / 4) : 0u;
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.strips + S.strip_base);
+    if (uint32_t(j) < strip_nw)
+      strip_w0 = src[j];
+    if (uint32_t(j) + uint32_t(LJ_T) < strip_nw)
+      strip_w1 = src[j + LJ_T];
+  }
   // the symbols in front of the workgroup as K0 counted them, and which of those
   // workgroups are flagged (own estimate ^ true entry = the "on record" bit and nothing else
   // -- "uncertain" sits in the own half -- means neither)
@@ -1090,6 +1036,10 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       }
     }
   }
+  if (uint32_t(j) < strip_nw)
+    reinterpret_cast<uint32_t*>(F.strips)[j] = strip_w0;
+  if (uint32_t(j) + uint32_t(LJ_T) < strip_nw)
+    reinterpret_cast<uint32_t*>(F.strips)[j + LJ_T] = strip_w1;
   __syncthreads();
   LF_STAMP(3);
   const uint32_t own_bits = F.ob[j];
@@ -1290,6 +1240,39 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       my_sums = make_uint2(my_sums.x & 0xFFFFu, 0u);
     if (N == 2)
       my_sums.y = 0u;
+    // (the symbol base rides on the same barrier: K0's counts of the workgroups in front, read
+    // at the start, + the corrections of the flagged ones; those still in flight when this
+    // workgroup started -- flagged ones among its ~128 nearest predecessors: two on average,
+    // and only the very nearest can still be decoding -- are asked again here)
+    {
+      if (kg0 & LB_VALID) {
+        kacc += uint32_t(kg0);
+        kflag &= ~(1u << kit0);
+      }
+      if (kg1 & LB_VALID) {
+        kacc += uint32_t(kg1);
+        kflag &= ~(1u << kit1);
+      }
+      uint32_t spins = 0;
+      while (__any(kflag != 0u)) {
+        if (kflag != 0u) {
+          const uint32_t it = uint32_t(__builtin_ctz(kflag));
+          const u64 g = lb_load(a.lb + size_t(fb_now + it * uint32_t(LJ_T) + uint32_t(j)) * LF_LB_WORDS);
+          if (g & LB_VALID) {
+            kacc += uint32_t(g);
+            kflag &= kflag - 1u;
+          }
+        }
+        if (++spins > LF_SPIN_LIMIT_K0) {
+          F.misc[M_SLOW] = 6;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const uint32_t part = wave_sum_u32(kacc);
+      if (lane == 0)
+        F.misc[M_LBX + wv] = part;
+    }
     const uint32_t incl = wave_scan_u32(my_cnt, lane);
     if (lane == 63)
       F.misc[M_WCNT + wv] = incl;
@@ -1330,42 +1313,11 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     // nearest can still be decoding -- are asked again now.
     published_exit = exit_now;
     LF_STAMP(6);
-    {
-      if (kg0 & LB_VALID) {
-        kacc += uint32_t(kg0);
-        kflag &= ~(1u << kit0);
-      }
-      if (kg1 & LB_VALID) {
-        kacc += uint32_t(kg1);
-        kflag &= ~(1u << kit1);
-      }
-      uint32_t spins = 0;
-      while (__any(kflag != 0u)) {
-        if (kflag != 0u) {
-          const uint32_t it = uint32_t(__builtin_ctz(kflag));
-          const u64 g = lb_load(a.lb + size_t(fb_now + it * uint32_t(LJ_T) + uint32_t(j)) * LF_LB_WORDS);
-          if (g & LB_VALID) {
-            kacc += uint32_t(g);
-            kflag &= kflag - 1u;
-          }
-        }
-        if (++spins > LF_SPIN_LIMIT_K0) {
-          F.misc[M_SLOW] = 6;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      const uint32_t part = wave_sum_u32(kacc);
-      if (lane == 0)
-        F.misc[M_LBX + wv] = part;
-      __syncthreads();
-      base = uni(F.misc[M_LBX] + F.misc[M_LBX + 1] + F.misc[M_LBX + 2] + F.misc[M_LBX + 3]);
-      if (LF_ABLATE & 4u)
-        base = lb * 15500u;
-    }
+    base = uni(F.misc[M_LBX] + F.misc[M_LBX + 1] + F.misc[M_LBX + 2] + F.misc[M_LBX + 3]);
+    if (LF_ABLATE & 4u)
+      base = lb * 15500u;
     LF_STAMP(7);
   }
-  LF_STAMP(8);
   if (__any(my_entry >= 0 && my_entry < LF_NSIDE)) {
     if (my_entry >= 0 && my_entry < LF_NSIDE) {
       // (dword by dword: a uint4 view turns R into 16 vectors for the compiler)
@@ -1417,7 +1369,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     a.results[s].pad3[2] = base;
 #endif
   }
-  LF_STAMP(9);
+  LF_STAMP(8);
 
   // 5. geometry of the delivered symbols [base, lim) and the stream rows they touch
   const uint32_t RS = S.RS;
@@ -1437,8 +1389,17 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     F.misc[M_SLOW] = 8;
   const uint32_t sb = LF_STAGE_BASE;
   __syncthreads(); // every lane is done with the image, the records and the side buffer
+  LF_STAMP(9);
 
-  // 6. staging: running sums + P before the lane = Ploc, in stream order
+  // 6. staging: running sums + P before the lane = Ploc, in stream order.  (Tried in round
+  // 4: in two phases -- first the few lanes that hold the first MCUs of the rows starting
+  // here, then the LOCAL record of look-back 1, then everybody else behind it.  No gain: the
+  // compiler's staging took 2 us whoever staged; the hand-written block of lf_stage takes
+  // 0.4 us for everybody.)
+  uint2 Cloc = make_uint2(0, 0), Vsum = make_uint2(0, 0);
+  uint32_t lb1_flags = 0;
+  uint2 lb1_al = make_uint2(0, 0);
+  const uint2 S_abs = lj_rot_fields<N>(S_wg, base & uint32_t(N - 1));
   if (fits && !(LF_ABLATE & 1u)) {
     const uint2 pexrel =
         lj_rot_fields<N>(pex, (uint32_t(N) - (before & uint32_t(N - 1))) & uint32_t(N - 1));
@@ -1456,20 +1417,12 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       *(lds_u16w)(ad + 2u * k) = uint16_t(v);
     }
   }
-  // the CR2 strips into LDS (pixel stores in front of a load: see above)
-  if (S.kind == 1) {
-    const uint32_t nw = (S.n_strips + 1) * uint32_t(sizeof(Cr2Strip) / 4);
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.strips + S.strip_base);
-    for (uint32_t k = uint32_t(j); k < nw; k += uint32_t(LJ_T))
-      reinterpret_cast<uint32_t*>(F.strips)[k] = src[k];
-  }
   __syncthreads();
   LF_STAMP(10);
 
   // 7. rows.  Lane t takes stream row r0 + t: for each component whose first-MCU symbol
   // r * RS + c lies in the workgroup, E = Ploc before it (the staged sample N back, 0 at
   // the workgroup's start) and D = its difference.
-  uint2 Cloc = make_uint2(0, 0), Vsum = make_uint2(0, 0);
   {
     uint32_t ev[4] = {0, 0, 0, 0}, dv[4] = {0, 0, 0, 0};
     if (fits && uint32_t(j) < nr && !(LF_ABLATE & 128u)) {
@@ -1510,11 +1463,8 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   }
   __syncthreads();
   LF_STAMP(11);
-  // the sums of the workgroup's differences by component (absolute)
-  const uint2 S_abs = lj_rot_fields<N>(S_wg, base & uint32_t(N - 1));
-  const uint2 init = S.init;
-  // 8. look-back 1
-  uint2 T_in = init, V_in = init;
+  // 8a. the LOCAL record of look-back 1 (S_abs: the sums of the workgroup's differences by
+  // absolute component)
   {
     // which components start a row here, and from which table row their last start is
     uint32_t flags = 0;
@@ -1548,6 +1498,17 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
         lb_store(p + 1, LB_VALID | (u64(flags) << 32) | al.y);
       lb_store(p + 0, LB_VALID | (u64(flags) << 32) | al.x);
     }
+    lb1_flags = flags;
+    lb1_al = al;
+  }
+  const uint2 init = S.init;
+  const WalkStart walk0 = lf_walk_start(F, S, base); // (the strips are in LDS since phase one)
+  // 8. look-back 1
+  uint2 T_in = init, V_in = init;
+  {
+    constexpr int NW = (N + 1) / 2;
+    const uint32_t flags = lb1_flags;
+    const uint2 al = lb1_al;
     bool ok = true;
     if (lb != 0 && !(LF_ABLATE & 8u))
       ok = lb1_walk<N>(a, F, b, S.first_block, init, j, &T_in, &V_in);
@@ -1597,13 +1558,8 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   LF_STAMP(13);
   LF_STAMP(14);
   // 9. copy-out
-  if (fits && any_out && !(LF_ABLATE & 3u)) {
-#ifdef RSX_LF_OLD_COPY
-    lf_copy_out<N>(F, a, S, base, lim, sb, r0, j);
-#else
-    lf_copy_out2<N>(F, a, S, base, lim, sb, r0, j);
-#endif
-  }
+  if (fits && any_out && !(LF_ABLATE & 3u))
+    lf_copy_out2<N>(F, a, S, base, lim, sb, r0, j, walk0);
   // records the per-stream bookkeeping kernels read (lj_scan_kernel, lj_consumed_kernel)
   if (j >= 1)
     a.sub_state[gsub] = rec_st(my_rec_final) | (rec_cn(my_rec_final) << 16);

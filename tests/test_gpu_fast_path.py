@@ -338,3 +338,66 @@ def test_identical_tables_in_two_dht_slots_take_the_single_pass_kernel(gpu, orac
         names = _kernel_names(plan, inp, out)
         assert any("lj_fast_kernel" in n for n in names) == expect_fast, names
         assert any("sync" in n for n in names) == (not expect_fast), names
+
+
+def _cr2_general_case(rng, W, H, n_comp, n_slices, slice_w, last_w, frame_h):
+    """<N,1,1> CR2 stream of a W x H (samples x rows) image whose LJPEG frame is frame_h rows
+    tall -- frame_h != H: the slices wrap to the next output column
+    (Cr2DecompressorImpl.h:104-154) -- cut into n_slices slices (widths in samples)."""
+    widths = [slice_w] * (n_slices - 1) + [last_w]
+    img = C.smooth_image(rng, H, W, 14)
+    tiles = C.cr2_output_tiles([w // n_comp for w in widths], W // n_comp, H, frame_h)
+    flat = np.concatenate([img[y:y + h, x * n_comp:(x + w) * n_comp].reshape(-1)
+                           for x, y, w, h in tiles])
+    assert flat.size == W * H, (flat.size, W * H)
+    frame_w = W * H // (frame_h * n_comp)
+    assert frame_w * frame_h * n_comp == W * H
+    rows = np.ascontiguousarray(flat.reshape(frame_h, frame_w * n_comp))
+    init_pred = [1 << 13] * n_comp
+    scan, _ = synth.ljpeg_encode_scan(rows, n_comp, init_pred, [C.NIKON] * n_comp)
+    d = abi.Cr2Desc()
+    d.n_comp, d.x_s_f, d.y_s_f = n_comp, 1, 1
+    d.frame_w, d.frame_h = frame_w, frame_h
+    d.num_slices, d.slice_width, d.last_slice_width = n_slices, slice_w, last_w
+    abi.fill_recipe(d, synth.huff_tables(C.NIKON), [0] * n_comp, init_pred)
+    data = np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), np.zeros(16, np.uint8)])
+    return d, data, img, len(scan)
+
+
+@pytest.mark.parametrize("shape", [
+    # W, H, N, slices, slice_w, last_w, frame_h
+    (3000, 1200, 2, 4, 1000, 1000, 900),    # wrapped slices: frame.y < dim.y
+    (3000, 1200, 2, 3, 1500, 1500, 800),    # three wide slices over two columns
+    (6000, 700, 2, 3, 2208, 1584, 700),     # unequal last slice
+    (4096, 900, 4, 4, 1024, 1024, 900),     # <4,1,1>
+    (4096, 900, 4, 4, 2048, 2048, 450),     # <4,1,1>, wrapped
+], ids=["wrapped", "wrapped_wide", "unequal_last", "n4", "n4_wrapped"])
+def test_cr2_strip_copy_out_at_hundreds_of_workgroups(gpu, oracle, shape):
+    """The single-pass kernel's CR2 copy-out (runs cut at strip rows AND stream rows, strips
+    that change inside a workgroup, slices that wrap to the next output column) at sizes
+    where a stream is hundreds of workgroups, against the oracle and -- where it is built --
+    the unmodified reference (Cr2DecompressorImpl.h:121-205)."""
+    import bench_ljpeg as B
+    from oracle_lib import Ref
+    W, H, N, ns, sw, lw, fh = shape
+    rng = np.random.default_rng([606, W, H, N, fh])
+    d, data, img, scan_len = _cr2_general_case(rng, W, H, N, ns, sw, lw, fh)
+    want = HostImage(W, H)
+    st_o, cons_o = oracle.cr2(d, data, want)
+    assert st_o == 0 and cons_o == scan_len
+    assert np.array_equal(want.pixels(), img)
+    if Ref.available():
+        r = Ref()
+        rimg = r.image(W, H, 1)
+        st_r, cons_r = r.cr2(d, data, rimg)
+        assert st_r == 0 and cons_r == scan_len and np.array_equal(rimg.pixels(), img)
+    plan, inp, out = B._cr2_batch(gpu, torch, [(d, data), (d, data)], W, H)
+    plan.run(inp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    rc, st, cons = plan.results()
+    assert rc == 0 and list(cons) == [scan_len, scan_len]
+    for f in range(2):
+        assert np.array_equal(B.gpu_frame(out, f, W, H), img), f
+    assert data.size > 100 * 255 * 64   # hundreds of workgroups a stream
+    names = _kernel_names(plan, inp, out)
+    assert any("lj_fast_kernel" in n for n in names), names
+    assert not any("sync" in n for n in names), names

@@ -455,3 +455,41 @@ def test_mixed_plan_legacy_route_and_damaged_fused_stream(gpu, oracle):
         if soB[0] == 0:
             assert cons[1] == soB[1]
             assert np.array_equal(img.u16(), want.u16())
+
+
+def test_concurrent_single_pass_kernels_from_host_threads(gpu, oracle):
+    """The unbatched DNG / ArwDecoder OpenMP shape (AbstractDngDecompressor.cpp:240-252,
+    ArwDecoder.cpp:371-404): several host threads, each decoding its own tile through
+    rsx_ljpeg_decode at the same time -- several single-pass kernels with ticketed
+    look-backs share the chip, each a hundred workgroups and more.  Pixels and consumed
+    bytes of every call, and no call may give up on a look-back (status stays OK)."""
+    import threading
+    rng = np.random.default_rng(4711)
+    work = []
+    for k in range(6):
+        W, H = 2048 + 256 * (k % 3), 768 + 64 * k
+        d, data, _, _ = C.make_ljpeg_case(rng, img_w=W, img_h=H, cpp=1, tile=(0, 0, W, H),
+                                          mcu=(2, 1))
+        want = HostImage(W, H)
+        so = oracle.ljpeg(d, data, want)
+        assert so[0] == 0
+        assert data.size > 90 * 255 * 64   # a hundred workgroups a call, give or take
+        work.append((d, data, W, H, want, so))
+    errors = []
+    start = threading.Barrier(len(work))
+
+    def lj(item):
+        d, data, W, H, want, so = item
+        start.wait()
+        for rep in range(4):
+            img = HostImage(W, H)
+            got = gpu.ljpeg_decode(d, data, img.view())
+            if got != so or not np.array_equal(img.u16(), want.u16()):
+                errors.append((W, H, rep, got, so))
+
+    threads = [threading.Thread(target=lj, args=(w,)) for w in work]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
