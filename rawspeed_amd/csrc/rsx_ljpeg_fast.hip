@@ -1273,39 +1273,46 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       if (lane == 0)
         F.misc[M_LBX + wv] = part;
     }
+    // (both scans in front of ONE barrier: the sums are rotated by the symbols before the lane
+    // inside its WAVEFRONT first -- rotations add up --, the symbols of the wavefronts in
+    // front are applied to the scanned values afterwards)
     const uint32_t incl = wave_scan_u32(my_cnt, lane);
-    if (lane == 63)
+    const uint32_t lbef = incl - my_cnt;
+    const uint2 r_l = lj_rot_fields<N>(my_sums, lbef & uint32_t(N - 1));
+    const uint2 pincl_l = wave_scan_pk2(r_l, lane);
+    if (lane == 63) {
       F.misc[M_WCNT + wv] = incl;
+      F.misc[M_WSUM + 2 * wv] = pincl_l.x;
+      F.misc[M_WSUM + 2 * wv + 1] = pincl_l.y;
+    }
     __syncthreads();
-    before = incl - my_cnt;
-    for (int w = 0; w < wv; ++w)
-      before += F.misc[M_WCNT + w];
+    uint32_t wprev = 0, wrun = 0;
+    uint2 sprev = make_uint2(0, 0);
+    S_wg = make_uint2(0, 0);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t tc = uni(F.misc[M_WCNT + w]);
+      const uint2 ts = lj_rot_fields<N>(
+          make_uint2(uni(F.misc[M_WSUM + 2 * w]), uni(F.misc[M_WSUM + 2 * w + 1])),
+          wrun & uint32_t(N - 1));
+      if (w < wv) {
+        wprev += tc;
+        sprev = pk_add2(sprev, ts);
+      }
+      S_wg = pk_add2(S_wg, ts);
+      wrun += tc;
+    }
+    before = lbef + wprev;
+    pex = pk_add2(lj_rot_fields<N>(pk_sub2(pincl_l, r_l), wprev & uint32_t(N - 1)), sprev);
     if (uint32_t(j) == F.misc[M_UNRES])
       F.misc[M_UNRESB] = before;
-    cnt_wg = uni(F.misc[M_WCNT] + F.misc[M_WCNT + 1] + F.misc[M_WCNT + 2] + F.misc[M_WCNT + 3]);
+    cnt_wg = wrun;
     const uint32_t exit_now = uni(rec_st(F.rec[LJ_T - 1]));
     // 4a. the workgroup's granule as soon as its symbols are known: what it decoded beyond
     // (or short of) K0's count.  Only successors that find this workgroup FLAGGED in K0's
     // words read it.
     if (j == 0)
       lb_store(a.lb + size_t(b) * LF_LB_WORDS, LB_VALID | u64(uint32_t(cnt_wg - k0_cnt_mine)));
-    {
-      const uint2 r = lj_rot_fields<N>(my_sums, before & uint32_t(N - 1));
-      const uint2 pincl = wave_scan_pk2(r, lane);
-      if (lane == 63) {
-        F.misc[M_WSUM + 2 * wv] = pincl.x;
-        F.misc[M_WSUM + 2 * wv + 1] = pincl.y;
-      }
-      __syncthreads();
-      pex = pk_sub2(pincl, r);
-      S_wg = make_uint2(0, 0);
-      for (int w = 0; w < 4; ++w) {
-        const uint2 t = make_uint2(uni(F.misc[M_WSUM + 2 * w]), uni(F.misc[M_WSUM + 2 * w + 1]));
-        if (w < wv)
-          pex = pk_add2(pex, t);
-        S_wg = pk_add2(S_wg, t);
-      }
-    }
 
     // 4. the symbol base: K0's counts of the workgroups in front (read at the start) + the
     // corrections of the flagged ones.  Those still in flight when this workgroup started --
@@ -1359,16 +1366,6 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       a.results[s].last_pos = p2;
     }
   }
-  // does a delivered symbol lie in the part of the workgroup the rounds did not finish?
-  // (the barrier in front of the staging orders the flag)
-  if (j == 0 && F.misc[M_UNRES] != 0xFFFFu && uint64_t(base) + F.misc[M_UNRESB] < needed) {
-    F.misc[M_SLOW] = 3;
-#ifdef RSX_EXPERIMENT
-    a.results[s].pad3[0] = lb;
-    a.results[s].pad3[1] = F.misc[M_UNRES] | (F.misc[M_UNRESB] << 16);
-    a.results[s].pad3[2] = base;
-#endif
-  }
   LF_STAMP(8);
 
   // 5. geometry of the delivered symbols [base, lim) and the stream rows they touch
@@ -1390,6 +1387,16 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   const uint32_t sb = LF_STAGE_BASE;
   __syncthreads(); // every lane is done with the image, the records and the side buffer
   LF_STAMP(9);
+  // does a delivered symbol lie in the part of the workgroup the rounds did not finish?
+  // (behind the barrier: M_UNRESB comes from the lane that owns slot M_UNRES)
+  if (j == 0 && F.misc[M_UNRES] != 0xFFFFu && uint64_t(base) + F.misc[M_UNRESB] < needed) {
+    F.misc[M_SLOW] = 3;
+#ifdef RSX_EXPERIMENT
+    a.results[s].pad3[0] = lb;
+    a.results[s].pad3[1] = F.misc[M_UNRES] | (F.misc[M_UNRESB] << 16);
+    a.results[s].pad3[2] = base;
+#endif
+  }
 
   // 6. staging: running sums + P before the lane = Ploc, in stream order.  (Tried in round
   // 4: in two phases -- first the few lanes that hold the first MCUs of the rows starting
