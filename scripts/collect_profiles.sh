@@ -5,7 +5,7 @@
 #   re-decode round statistics of an experiment build.
 # Outputs land in gpurun_out/prof_$ROUND/ (copied to profiles/$ROUND/ afterwards).
 set -u
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$ROUND
 mkdir -p $OUT
@@ -42,5 +42,6 @@ if [ -f $REPO/rawspeed_amd/variants/librsx_stats.so ]; then
   RSX_DEBUG=1 RSX_LIB=$REPO/rawspeed_amd/variants/librsx_stats.so \
     python $REPO/scripts/exp_lj_stats.py 2>&1 | grep "^\[rsx\]" | cut -c1-400 > $OUT/cfg3_phase_and_round_stats.txt
 fi
+python $REPO/scripts/ljpeg_limiter.py $OUT > /dev/null 2>&1
 ls -la $OUT
 tail -c 400 $OUT/bench_full.json
