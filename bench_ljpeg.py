@@ -115,6 +115,29 @@ def ref_scan_baseline(kind, descs, datas, W, H, what, budget_s=8.0):
     return frames, cpu
 
 
+def ref_all_threads(ref, W, H, call, what, budget_s=6.0, max_frames=256):
+    """SURVEY 8(d)'s second CPU figure for a decompressor without a parallel entry point in
+    the reference wrapper: one frame per host thread, all threads at once (the calls release
+    the GIL: N Python threads = N busy cores).  `call(img)` decodes the leg's stream into
+    `img`.  Returns the fields to merge into the leg's cpu_baseline."""
+    from concurrent.futures import ThreadPoolExecutor
+    nt = min(host_threads(ref), max_frames)
+    imgs = [ref.image(W, H, 1) for _ in range(nt)]
+    best, reps = None, 0
+    with ThreadPoolExecutor(max_workers=nt) as ex:
+        list(ex.map(call, imgs))          # page touch
+        t_end = time.perf_counter() + budget_s
+        while reps < 2 or (reps < 4 and time.perf_counter() < t_end):
+            t0 = time.perf_counter()
+            list(ex.map(call, imgs))
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            reps += 1
+    return {"value_all_threads": round(nt * W * H / best / 1e6, 1), "cores_all_threads": nt,
+            "sample_all_threads": "%s: %d frames on %d threads, one frame per thread (best of %d)"
+                                  % (what, nt, nt, reps)}
+
+
 LAST_KERNEL_TABLE = None  # per-kernel averages (ms per run) of the last _time_plan call
 
 
@@ -609,6 +632,9 @@ def run_nikon(ctx, torch, log, frames=8, steps=10, warmup=2, cpu=True):
                     "kind": "reference",
                     "sample": "NikonDecompressor::decompress of the unmodified reference on the "
                               "same stream (curve + dither), 1 thread, best of 3"}
+                out["cpu_baseline"].update(ref_all_threads(
+                    ref, W, H, lambda im: ref.nikon(meta, bits, data, im, False),
+                    "NikonDecompressor::decompress"))
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
     return out
@@ -662,6 +688,9 @@ def run_hasselblad(ctx, torch, log, frames=4, steps=10, warmup=2, cpu=True):
                     "kind": "reference",
                     "sample": "HasselbladDecompressor::decompress of the unmodified reference on "
                               "the same stream, 1 thread, best of 3"}
+                out["cpu_baseline"].update(ref_all_threads(
+                    ref, W, H, lambda im: ref.hasselblad(d, data, im),
+                    "HasselbladDecompressor::decompress", max_frames=64))
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
     return out
@@ -712,6 +741,9 @@ def run_sony_arw1(ctx, torch, log, frames=8, steps=10, warmup=2, cpu=True):
                     "kind": "reference",
                     "sample": "SonyArw1Decompressor::decompress of the unmodified reference on "
                               "the same stream, 1 thread, best of 3"}
+                out["cpu_baseline"].update(ref_all_threads(
+                    ref, W, H, lambda im: ref.sony_arw1(data, im),
+                    "SonyArw1Decompressor::decompress"))
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
     return out
@@ -796,6 +828,11 @@ def run_samsung_v2(ctx, torch, log, frames=4, steps=5, warmup=1, cpu=True):
                     "kind": "reference",
                     "sample": "SamsungV2Decompressor::decompress of the unmodified reference on "
                               "the same stream, 1 thread, best of 2"}
+                # (the reference cannot use a second core for a frame, but it can for a batch:
+                # what the device's 6 GPix/s is up against on this host)
+                out["cpu_baseline"].update(ref_all_threads(
+                    ref, W, H, lambda im: ref.samsung_v2(bits, data, im),
+                    "SamsungV2Decompressor::decompress"))
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
     return out
