@@ -43,19 +43,27 @@ def make_cr2_frame(W, H, slices, seed):
     return d, data, src, len(scan), bits
 
 
-def make_tile(src_tile, tx, ty, tw, th, rows_per_ri=0, want_blob=False):
+def _alt():
+    from rawspeed_amd import synth
+    return (synth.ALT_COUNTS, synth.ALT_VALUES)
+
+
+def make_tile(src_tile, tx, ty, tw, th, rows_per_ri=0, want_blob=False, two_tables=False):
     """One DNG-style tile: SOF3 (tw/2) x th, 2 components, predictor 1.  Returns the
     descriptor + entropy-coded scan for the C-ABI and (want_blob) the whole SOI..EOI
-    container for AbstractDngDecompressor."""
+    container for AbstractDngDecompressor.  two_tables: a code of its own per component
+    (DHT slots 0 and 1), as DNG writers emit them."""
     from rawspeed_amd import abi, synth
+    slots = [0, 1] if two_tables else [0, 0]
+    tabs = [_nikon(), _alt()] if two_tables else [_nikon()]
     blob, nh, scan_len, bits = synth.ljpeg_container(np.ascontiguousarray(src_tile), 2, 14,
-                                                     [0, 0], [_nikon()],
+                                                     slots, tabs,
                                                      rows_per_ri=rows_per_ri)
     d = abi.LJpegDesc()
     d.tile_x, d.tile_y, d.tile_w, d.tile_h = tx, ty, tw, th
     d.mcu_w, d.mcu_h, d.frame_w, d.frame_h = 2, 1, tw // 2, th
     d.n_comp, d.rows_per_restart_interval = 2, rows_per_ri if rows_per_ri else th
-    abi.fill_recipe(d, synth.huff_tables(_nikon()), [0, 0], [1 << 13] * 2)
+    abi.fill_recipe(d, synth.huff_tables(*tabs), slots, [1 << 13] * 2)
     pad = (-(scan_len + 2)) % 16 + 16
     data = np.concatenate([blob[nh:nh + scan_len + 2], np.zeros(pad, np.uint8)])
     if want_blob:
@@ -393,7 +401,7 @@ def run_sraw(ctx, torch, log, frames=8, steps=10, warmup=2):
     }
 
 
-def _dng_tiles(W, H, tw, th, seed, rows_per_ri=0):
+def _dng_tiles(W, H, tw, th, seed, rows_per_ri=0, two_tables=False):
     """A WxH sensor-like image as DNG tiles of tw x th (right / bottom tiles overhang when
     W, H are not multiples: the part outside the image is padding, decodeRowN drops it)."""
     from rawspeed_amd import abi, synth
@@ -405,7 +413,8 @@ def _dng_tiles(W, H, tw, th, seed, rows_per_ri=0):
             tile = np.full((th, tw), 1000, np.uint16)
             tile[:part.shape[0], :part.shape[1]] = part
             d, data, scan_len, bits, blob = make_tile(tile, tx * tw, ty * th, tw, th,
-                                                      rows_per_ri, want_blob=True)
+                                                      rows_per_ri, want_blob=True,
+                                                      two_tables=two_tables)
             # AbstractDngDecompressor.cpp:64-68: the tile is clipped to the image
             d.tile_w = min(tw, W - tx * tw)
             d.tile_h = min(th, H - ty * th)
@@ -422,9 +431,10 @@ def _dng_tiles(W, H, tw, th, seed, rows_per_ri=0):
     return src, jobs, datas, blobs, lens
 
 
-def _cfg4_variant(ctx, torch, W, H, tw, th, seed, rows_per_ri, steps, warmup, what, cpu):
+def _cfg4_variant(ctx, torch, W, H, tw, th, seed, rows_per_ri, steps, warmup, what, cpu,
+                  two_tables=False):
     from oracle_lib import Ref
-    src, jobs, datas, blobs, lens = _dng_tiles(W, H, tw, th, seed, rows_per_ri)
+    src, jobs, datas, blobs, lens = _dng_tiles(W, H, tw, th, seed, rows_per_ri, two_tables)
     inp = torch.from_numpy(np.concatenate(datas)).cuda()
     out = torch.zeros(out_pitch(W) * H, dtype=torch.uint8, device="cuda")
     plan = ctx.ljpeg_plan(jobs)
@@ -481,6 +491,10 @@ def run_cfg4(ctx, torch, log, steps=10, warmup=2, cpu=True, variants=True):
                         "LJpegDecompressor via DNG tiles: 8192x5464 as 2x2 tiles, 1 frame/step",
                         cpu)
     if variants:
+        res["two_tables"] = _cfg4_variant(
+            ctx, torch, 8192, 5464, 4096, 2732, 2, 0, steps, warmup,
+            "8192x5464 as 2x2 tiles, a Huffman table of its own per component (DHT slots 0, 1)",
+            False, two_tables=True)
         res["overhang_8189x5462"] = _cfg4_variant(
             ctx, torch, 8189, 5462, 4096, 2732, 3, 0, steps, warmup,
             "8189x5462 as 2x2 tiles of 4096x2732 (overhanging right/bottom tiles)", False)
@@ -1031,6 +1045,11 @@ if __name__ == "__main__":
                          indent=1))
     elif args.only == "host":
         print(json.dumps(run_host_path(torch, print), indent=1))
+    elif args.only == "cfg4mt":
+        print(json.dumps(_cfg4_variant(
+            ctx, torch, 8192, 5464, 4096, 2732, 2, 0, args.steps, 2,
+            "8192x5464 as 2x2 tiles, a Huffman table of its own per component", False,
+            two_tables=True), indent=1))
     elif args.only == "cfg4":
         print(json.dumps(run_cfg4(ctx, torch, print, steps=args.steps, cpu=not args.no_cpu),
                          indent=1))

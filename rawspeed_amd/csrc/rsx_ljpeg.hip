@@ -595,19 +595,56 @@ __device__ __forceinline__ uint32_t lj_guess_parse_pairs(uint32_t col4, uint32_t
   return (q - qend) >> 5;
 }
 
+// Two tables that alternate symbol by symbol (round 4; LjStreamDev::fast == 2): the table of
+// the next symbol is part of the parse state -- offset | (symbol index & 1) << 6 -- and the
+// second table's lengths lie behind the kernel's usual layout (LJ_K0_LDS_MT).  One symbol per
+// window: pairs would need the two tables' 8-bit forms as well.
+constexpr uint32_t LJ_K0_LUTB_OFF = (LJ_K0_LDS + 15u) & ~15u;
+constexpr uint32_t LJ_K0_LDS_MT = LJ_K0_LUTB_OFF + 1024u;
+constexpr uint32_t ST_MT_MASK = 0x7Fu; // offset | table bit
+template <bool COUNT>
+__device__ __forceinline__ uint32_t lj_guess_parse_mt(uint32_t col4, uint32_t end_bits,
+                                                      uint32_t from, uint32_t* count = nullptr) {
+  uint32_t q = (from & ST_OFF_MASK) << 5, n = 0, spec = 0;
+  // (the table's LDS address: toggled by XOR with the two bases' difference)
+  uint32_t lut = (from & 64u) ? LJ_K0_LUTB_OFF : LJ_GUESS_LUT_OFF;
+  const uint32_t qend = end_bits << 5;
+  while (q < qend) {
+    uint32_t ad;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(q), "s"(0xFFFFFC00u), "v"(col4));
+    const uint32_t d0 = *(lds_u32p)(ad), d1 = *(lds_u32p)(ad + 4u * LJ_T);
+    const uint32_t w = uint32_t((((uint64_t(d0) << 32) | d1) << ((q >> 5) & 31u)) >> 32);
+    const uint32_t len = *(lds_u8p)(lut + (w >> 22));
+    spec |= len;
+    q += (len & 0x7Fu) << 5;
+    lut ^= LJ_K0_LUTB_OFF ^ LJ_GUESS_LUT_OFF;
+    ++n;
+  }
+  if (COUNT)
+    *count = n | ((spec & 0x80u) << 24);
+  return ((q - qend) >> 5) | (lut == LJ_K0_LUTB_OFF ? 64u : 0u);
+}
+
 // A slot inside a constant region of the image is the code of the zero difference over
 // and over.  No parse from an arbitrary bit finds its way into such a stretch reliably
 // (with Nikon's 14-bit table, 111110 repeated also reads as a chain of 12-bit symbols),
 // but the BITS say where its symbols start: if the slot has period `zl` and the code `zc`
 // at exactly one phase p, the first symbol boundary behind the slot follows.  A guess like
 // any other: the single-pass kernel checks it against the predecessor's exit.
+// Two alternating tables (zlb != 0): the slot is the two zero codes in turn; zl, zc are the
+// pair's (first table's code, then the second's, zlb bits), the states carry the table bit.
 __device__ __forceinline__ bool lj_guess_constant(const uint32_t* B, int col, uint32_t zl,
                                                   uint32_t zc, bool candidate, uint32_t* guess,
-                                                  uint32_t* count, uint32_t* entry) {
-  bool per = candidate;
+                                                  uint32_t* count, uint32_t* entry,
+                                                  uint32_t zlb, uint32_t bits) {
+  // (the slot's own bits -- fewer than 512 when it held stuffing bytes: two zero codes in
+  // turn easily make a run of eight ones -- and up to 31 + zl of the bits behind them, which
+  // the staging put there: at least 88 of the next slot's)
+  bool per = candidate && bits >= 64u;
   for (int wi = 0; wi < LJ_PW && __any(per); ++wi) {
     const uint32_t d0 = B[wi * LJ_T + col], d1 = B[(wi + 1) * LJ_T + col];
-    per = per && d0 == uint32_t((((uint64_t(d0) << 32) | d1) << zl) >> 32);
+    per = per && (uint32_t(32 * wi) >= bits ||
+                  d0 == uint32_t((((uint64_t(d0) << 32) | d1) << zl) >> 32));
   }
   if (!per)
     return false;
@@ -620,7 +657,18 @@ __device__ __forceinline__ bool lj_guess_constant(const uint32_t* B, int col, ui
     }
   if (hits != 1)
     return false;
-  const uint32_t bits = uint32_t(LJ_PW) * 32u;
+  if (zlb != 0u) {
+    // symbols of the first table start at p0 + k zl, of the second at sb + k zl
+    const uint32_t zla = zl - zlb;
+    const bool b_first = p0 >= zlb;
+    const uint32_t sb = b_first ? p0 - zlb : p0 + zla;
+    const uint32_t na = (bits - p0 + zl - 1u) / zl, nb = (bits - sb + zl - 1u) / zl;
+    const uint32_t end_a = p0 + na * zl, end_b = sb + nb * zl; // the first starts behind the slot
+    *guess = end_a < end_b ? end_a - bits : ((end_b - bits) | 64u);
+    *count = na + nb;
+    *entry = b_first ? (sb | 64u) : p0;
+    return true;
+  }
   const uint32_t r = (bits - p0) % zl;
   *guess = r ? zl - r : 0u;
   *count = (bits - p0 + zl - 1u) / zl;
@@ -658,10 +706,12 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
   uint8_t* lut8 = smem + LJ_GUESS_LUT_OFF;
-  uint32_t lut_pk = 0, lut8b = 0x80u;
+  uint32_t lut_pk = 0, lut8b = 0x80u, lut_pk_b = 0;
+  const bool mt = S.fast == 2;
   if (S.fast && a.fast_tabs) {
     // (the symbol lengths of the stream's 10-bit LUT: asked for now, parked later)
-    const uint2* ft = a.fast_tabs + size_t(S.table_base) * 1024 + 4 * j;
+    const uint2* ft =
+        a.fast_tabs + size_t(S.table_base + (mt ? S.tab_of_phase[0] : 0u)) * 1024 + 4 * j;
     uint2 e0 = make_uint2(0u, 0u);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -669,6 +719,14 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       if (k == 0)
         e0 = e;
       lut_pk |= (((e.x >> 5) & 63u) | ((e.x >> 24) & 0x80u)) << (8 * k); // (bit 7: special)
+    }
+    if (mt) {
+      const uint2* fb = a.fast_tabs + size_t(S.table_base + S.tab_of_phase[1]) * 1024 + 4 * j;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint2 e = fb[k];
+        lut_pk_b |= (((e.x >> 5) & 63u) | ((e.x >> 24) & 0x80u)) << (8 * k);
+      }
     }
     // the 8-bit table's entry j: the four 10-bit entries 4j.. agree iff the code has at most
     // 8 bits (code length = total - SSSS, SSSS = popcount of the entry's 2^SSSS - 1)
@@ -690,8 +748,8 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   // granules and workgroup tickets start from zero in every run
   if (a.lb && j < LF_LB_WORDS)
     a.lb[size_t(b) * LF_LB_WORDS + j] = 0ull;
-  if (a.tickets && b == 0 && j < 13) {
-    if (j < 12)
+  if (a.tickets && b == 0 && j < 25) {
+    if (j < 24)
       a.tickets[j] = 0u;
     else
       a.fast_level[a.run_parity ^ 1u] = a.fast_level[2u + (a.run_parity ^ 1u)] = 0u; // (the NEXT run's)
@@ -726,13 +784,25 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     __syncthreads(); // every lane has written its part of the image out
     reinterpret_cast<uint32_t*>(lut8)[j] = lut_pk;
     smem[LJ_GUESS_LUT8_OFF + uint32_t(j)] = uint8_t(lut8b);
+    if (mt)
+      reinterpret_cast<uint32_t*>(smem + LJ_K0_LUTB_OFF)[j] = lut_pk_b;
     if (j < 4 + 2 * int(LJ_GUESS_ROUNDS))
       nlist[j] = 0;
     if (j == 0)
       *est = 0;
     __syncthreads();
-    const uint32_t zi = uint32_t(__builtin_amdgcn_readfirstlane(int(a.fast_z[S.table_base])));
-    const uint32_t zl = zi & 31u, zc = zi >> 8;
+    // (two tables: such a slot is the two zero codes in turn, a "code" of both lengths)
+    uint32_t zi = uint32_t(__builtin_amdgcn_readfirstlane(
+        int(a.fast_z[S.table_base + (mt ? S.tab_of_phase[0] : 0u)])));
+    uint32_t zl = zi & 31u, zc = zi >> 8, zlb = 0;
+    if (mt) {
+      const uint32_t zb = uint32_t(
+          __builtin_amdgcn_readfirstlane(int(a.fast_z[S.table_base + S.tab_of_phase[1]])));
+      zlb = zb & 31u;
+      zc = (zc << zlb) | (zb >> 8);
+      zl = (zl != 0u && zlb != 0u && zl + zlb <= 31u) ? zl + zlb : 0u;
+    }
+    const uint32_t smask = mt ? ST_MT_MASK : ST_OFF_MASK;
     const uint32_t gs = a.guess_slots & 0xFFu; // (3; experiments: fewer)
     // (the hand-written loop assumes the layout it was written for)
     bool hand = lds_addr(L.B) == 0u && lds_addr(lut8) == LJ_GUESS_LUT_OFF;
@@ -741,6 +811,9 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       hand = false;
 #endif
     auto parse = [&](int col, uint32_t bits, uint32_t from, uint32_t* count) -> uint32_t {
+      if (mt)
+        return count ? lj_guess_parse_mt<true>(uint32_t(col) * 4u, bits, from, count)
+                     : lj_guess_parse_mt<false>(uint32_t(col) * 4u, bits, from);
 #ifndef RSX_K0_SINGLE_SYMBOL
       if (hand)
         return count ? lj_guess_parse_pairs<true>(uint32_t(col) * 4u, bits, from, count)
@@ -757,22 +830,21 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     uint32_t ea = 0, cnt = 0, grid = 0;
     bool constant = false;
     if (zl >= 4u) // (shorter: more than 128 symbols in a slot, the multi-kernel pipeline's)
-      constant = lj_guess_constant(L.B, j, zl, zc, eb == uint32_t(LJ_PW) * 32u && exists, &ea,
-                                   &cnt, &grid);
+      constant = lj_guess_constant(L.B, j, zl, zc, exists, &ea, &cnt, &grid, zlb, eb);
     if (!constant && exists)
-      ea = parse(j, eb, 0u, &cnt) & ST_OFF_MASK;
+      ea = parse(j, eb, 0u, &cnt) & smask;
     if (j == 0 && lb == 0)
-      ea = S.start_bit & ST_OFF_MASK; // (the stream's first slot starts where the stream does)
+      ea = S.start_bit & smask; // (the stream's first slot starts where the stream does)
     EA[j] = uint16_t(ea);
     __syncthreads();
     const uint32_t xa = j >= 1 ? uint32_t(EA[j - 1]) : 0u;
     uint32_t ebv = ea;
 #ifdef RSX_K0_X1 // (diagnostic build: the B parse without its count -- wrong counts, K0's time only)
     if (!constant && exists && xa != 0u && gs >= 2u)
-      ebv = parse(j, eb, xa, nullptr) & ST_OFF_MASK;
+      ebv = parse(j, eb, xa, nullptr) & smask;
 #else
     if (!constant && exists && xa != 0u && gs >= 2u)
-      ebv = parse(j, eb, xa, &cnt) & ST_OFF_MASK;
+      ebv = parse(j, eb, xa, &cnt) & smask;
 #endif
     EB[j] = uint16_t(ebv);
     // (15 bits of symbols, 0x7FFF = too many to say; bit 15: the parse met a special entry)
@@ -817,7 +889,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
           const int c = int(glist[k]);
           const uint32_t from = uint32_t(EB[c - 1]);
           uint32_t n = 0;
-          const uint32_t e = parse(c, L.ob[c], from, &n) & ST_OFF_MASK;
+          const uint32_t e = parse(c, L.ob[c], from, &n) & smask;
           if (e != uint32_t(EB[c]))
             changed = true;
           if ((round == 0u || e != uint32_t(EB[c])) && (c < LJ_T - 1 || lb + 1 < S.n_blocks))
@@ -846,6 +918,17 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       if (j >= 1 && (!settled || (constant && exists && x != grid) || (cnt_word & 0x8000u) ||
                      cnt == 0x7FFFu))
         nlist[2] = 1u;
+#ifdef RSX_EXPERIMENT
+      // (why, for scripts/exp_mt_why.py: bits 16.. of the stream's reasons word)
+      if (j >= 1) {
+        const uint32_t why = (!settled ? 0x10000u : 0u) |
+                             ((constant && exists && x != grid) ? 0x20000u : 0u) |
+                             ((cnt_word & 0x8000u) ? 0x40000u : 0u) |
+                             (cnt == 0x7FFFu ? 0x80000u : 0u);
+        if (why)
+          atomicOr(&a.results[s].stat_why, why);
+      }
+#endif
     }
     // the LDS level of the single-pass launches: the symbols of this workgroup's slots
     // 1..255 (parsed from bit 0: an estimate) against what a level stages
@@ -2442,7 +2525,8 @@ struct LJpegPlan {
   bool any_direct = false, any_legacy = false;
   bool legacy_fallback_ready = false; // difference scratch of the fused streams allocated
   // single-pass path (rsx_ljpeg_fast.hip)
-  bool fast_present[5] = {};   // [components]
+  bool fast_present[2][5] = {}; // [two alternating tables][components]
+  bool any_fast_mt = false;     // some stream takes its two-table instantiation
   bool any_fast = false;       // some stream takes the single-pass kernel
   uint32_t fast_lds = 0;       // LDS bytes of its launches
   std::vector<uint8_t> slow_strikes; // per stream: consecutive runs it went to the slow path
@@ -2765,10 +2849,20 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     // the single-pass kernel: fused-path streams with one table whose MCU is a row of
     // its components (or CR2 strips)
 #ifndef RSX_NO_FAST
-    S.fast = (direct_n && J.n_tables == 1 &&
+    // (round 4: also TWO tables that alternate symbol by symbol -- one per component of a
+    // two-component scan, the usual DNG; A B A B of four --: S.fast = 2, the kernel's
+    // two-table instantiation, the table being part of every parse state)
+    bool two_alternating = J.n_tables == 2 && (g.n_comp == 2 || g.n_comp == 4) &&
+                           g.comp_of_phase[0] != g.comp_of_phase[1];
+    for (uint32_t ph = 0; ph < g.n_comp && two_alternating; ++ph)
+      two_alternating = g.comp_of_phase[ph] == g.comp_of_phase[ph & 1u];
+#ifdef RSX_NO_FAST_MT
+    two_alternating = false;
+#endif
+    S.fast = (direct_n && (J.n_tables == 1 || two_alternating) &&
               (g.kind == 1 || (g.mcu_h == 1 && g.mcu_w == g.n_comp)) &&
               g.row_samples >= g.n_comp)
-                 ? 1
+                 ? (J.n_tables == 1 ? 1 : 2)
                  : 0;
     if (S.fast) {
       // its workgroups stage all their samples in LDS at once: the allocation follows the
@@ -2880,7 +2974,8 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       cls.comp[g.period == g.n_comp ? g.n_comp : (g.period == 4 ? 5u : 6u)] = true;
     if (S.fast) {
       p->any_fast = true;
-      p->fast_present[S.direct] = true;
+      p->any_fast_mt |= S.fast == 2;
+      p->fast_present[S.fast == 2 ? 1 : 0][S.direct] = true;
     } else {
       p->any_pipeline = true;
     }
@@ -2991,8 +3086,12 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       for (uint32_t k = 0; k < max_blocks; ++k)
         for (size_t si = 0; si < p->streams.size(); ++si)
           if (k < p->streams[si].n_blocks)
+            // (.z: the stream's first table | the tables of even / odd symbols << 24 / 28)
             order.push_back(make_uint4(p->streams[si].first_block + k, uint32_t(si),
-                                       p->streams[si].table_base, p->streams[si].first_block));
+                                       p->streams[si].table_base |
+                                           (uint32_t(p->streams[si].tab_of_phase[0] & 15u) << 24) |
+                                           (uint32_t(p->streams[si].tab_of_phase[1] & 15u) << 28),
+                                       p->streams[si].first_block));
       if ((st = up(p->d_fast_order, order.data(), order.size() * sizeof(uint4))))
         return st;
       if ((st = up(p->d_fast_tabs, ft.data(), ft.size() * sizeof(uint2))) ||
@@ -3322,7 +3421,7 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
                                     hipMemcpyHostToDevice, s));
   const uint32_t n_streams = uint32_t(p->streams.size());
   hipLaunchKernelGGL(lj_unstuff_kernel, dim3(p->total_blocks), dim3(LJ_T),
-                     LJ_K0_LDS, s, a);
+                     p->any_fast_mt ? LJ_K0_LDS_MT : LJ_K0_LDS, s, a);
   mark(p, "lj_unstuff_kernel");
   // the single-pass kernel for the streams it takes ...
   if (p->any_fast) {
@@ -3621,6 +3720,26 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
         tot += n ? sum[k] / n : 0.0;
       }
       fprintf(stderr, "[rsx]   %-14s mean %7.2f us\n", "lifetime", tot);
+    }
+    // K0's words: how many workgroups does the single-pass kernel have to ask for their count?
+    std::vector<unsigned long long> kw(size_t(p->total_blocks) + 1);
+    if (p->d_k0w.ptr &&
+        hipMemcpy(kw.data(), p->d_k0w.ptr, kw.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      size_t nz = 0, unc = 0, differ = 0, norec = 0;
+      for (uint32_t b = 0; b < p->total_blocks; ++b) {
+        const unsigned long long w = kw[b];
+        if (!w)
+          continue;
+        ++nz;
+        const uint32_t own = uint32_t(w >> 32) & 0xFFFFu, tru = uint32_t(w >> 48);
+        unc += (own >> 7) & 1u;
+        norec += !(tru & 0x8000u);
+        differ += (tru & 0x8000u) && (own & 0x7Fu) != (tru & 0x7Fu);
+      }
+      fprintf(stderr,
+              "[rsx] K0 words: %zu workgroups, %zu uncertain, %zu entry estimate != true entry, "
+              "%zu without a true entry\n",
+              nz, unc, differ, norec);
     }
   }
   if (getenv("RSX_DEBUG")) {

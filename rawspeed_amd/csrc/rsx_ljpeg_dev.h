@@ -140,7 +140,8 @@ struct LjStreamDev {
                        //       value is the number of interleaved components (1, 2 or 4)
   uint8_t sync_lut11;  // its table has no search path past the LUT (an explicit 11-bit table):
                        // the synchronisation kernels must not use their 10-bit LUT for it
-  uint8_t fast;        // != 0: the single-pass kernel decodes it (rsx_ljpeg_fast.hip)
+  uint8_t fast;        // != 0: the single-pass kernel decodes it (rsx_ljpeg_fast.hip): 1 one
+                       // table, 2 two tables alternating symbol by symbol
   uint32_t rows;
   uint32_t row_samples;
   uint32_t first_row; // global stream-row index
@@ -342,7 +343,7 @@ void ljpeg_launch_direct(const LjArgs& a, const DirectLaunch& d, hipStream_t str
 // the single-pass path (rsx_ljpeg_fast.hip)
 struct FastLaunch {
   uint32_t total_blocks = 0;
-  bool present[5] = {}; // [components]
+  bool present[2][5] = {}; // [two alternating tables][components]
 };
 void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t stream,
                        KernelTimer* timer);
@@ -350,6 +351,6 @@ void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t stream,
 void ljpeg_build_fast_table(const TabLds& t, uint2* out, uint32_t* zinfo);
 uint32_t ljpeg_fast_lds_for(uint64_t samples_per_workgroup);
 uint32_t ljpeg_fast_stage_cap(uint32_t lds_bytes);
-constexpr int LF_TICKET_WORDS = 16; // [3][4] tickets
+constexpr int LF_TICKET_WORDS = 32; // [2][3][4] tickets: [two tables][LDS level][components]
 
 } // namespace rsx

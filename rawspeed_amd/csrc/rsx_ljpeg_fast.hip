@@ -288,29 +288,62 @@ __device__ __forceinline__ void lf_step(FastState& s, uint32_t vbase) {
   s.n += 1;
 }
 
-template <int N, int K, int KEND>
+// Two tables that alternate symbol by symbol (round 4; the kernel's MT instantiations): both
+// 10-bit LUTs in the 8 KB the one table takes otherwise, as 4-byte entries
+//   bits 0..4 shift | bits 5..10 total (as above) | bits 16..31: 2^SSSS - 1
+//   special: 0x0000FFE0 -- "2047 bits": the lane runs far past the end of its slot and stops;
+//   an exit offset of 64 and more is what says so afterwards
+// table of the even symbols at LDS address 0, of the odd ones at 4096; a lane alternates
+// between the two bases starting from the one its entry state names (the steps of a group
+// are unrolled: step K of a lane is symbol K of it, so the base is a static choice of two
+// registers).  One VALU instruction more than the one-table step (the mask's shift).
+constexpr uint32_t LF_MT_SPECIAL = 0x0000FFE0u;
+template <int N, int K>
+__device__ __forceinline__ void lf_step_mt(FastState& s, uint32_t vbase, uint32_t lut0,
+                                           uint32_t lut1) {
+  const uint32_t ad = vbase + (s.Pn & ~1023u);
+  const uint32_t d1 = *(lds_u32p)(ad), d0 = *(lds_u32p)(ad + 4u * LJ_T);
+  const uint32_t w = __builtin_amdgcn_alignbit(d0, d1, s.Pn >> 5);
+  uint32_t ea;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ea) : "v"(w >> 20), "s"(0xFFCu), "v"((K & 1) ? lut1 : lut0));
+  const uint32_t e = *(lds_u32p)(ea);
+  const uint32_t all = e >> 16;
+  const uint32_t v = (w >> (e & 31u)) & all;
+  const uint32_t u = all - v;
+  const uint32_t m = uint32_t(int32_t(u - v) >> 31);
+  s.acc[K % N] += (all & m) - u;
+  s.Pn -= (e & 0xFFE0u);
+  s.n += 1;
+}
+
+template <int N, int K, int KEND, bool MT = false>
 struct LfChain {
   static __device__ __forceinline__ void run(FastState& s, uint32_t vbase, uint32_t pend,
-                                             uint32_t (&R)[LF_NR], int qbase) {
+                                             uint32_t (&R)[LF_NR], int qbase, uint32_t lut0,
+                                             uint32_t lut1) {
     if (s.Pn > pend) {
-      lf_step<N, K>(s, vbase);
+      if constexpr (MT)
+        lf_step_mt<N, K>(s, vbase, lut0, lut1);
+      else
+        lf_step<N, K>(s, vbase);
       if ((K & 1) == 0)
         s.ev = s.acc[K % N];
       else
         R[qbase + (K >> 1)] = pack16(s.ev, s.acc[K % N]);
       if constexpr (K + 1 < KEND)
-        LfChain<N, K + 1, KEND>::run(s, vbase, pend, R, qbase);
+        LfChain<N, K + 1, KEND, MT>::run(s, vbase, pend, R, qbase, lut0, lut1);
     }
   }
 };
 
-template <int N, int G>
+template <int N, int G, bool MT = false>
 __device__ __forceinline__ void lf_groups(FastState& s, uint32_t vbase, uint32_t pend,
-                                          uint32_t (&R)[LF_NR]) {
+                                          uint32_t (&R)[LF_NR], uint32_t lut0 = 0,
+                                          uint32_t lut1 = 0) {
   if (__any(s.Pn > pend)) {
-    LfChain<N, 0, 8>::run(s, vbase, pend, R, 4 * G);
+    LfChain<N, 0, 8, MT>::run(s, vbase, pend, R, 4 * G, lut0, lut1);
     if constexpr (G + 1 < LF_MAXSYM / 8)
-      lf_groups<N, G + 1>(s, vbase, pend, R);
+      lf_groups<N, G + 1, MT>(s, vbase, pend, R, lut0, lut1);
   }
 }
 
@@ -342,8 +375,9 @@ __device__ __forceinline__ uint32_t lf_slow_entry(uint32_t w, const TabLds& tb) 
 // codes) for the others; the running sum of every symbol goes into the lane's
 // side-buffer entry.  (The first version ran the general loop for every symbol: 14-50 us
 // per round, and every workgroup behind the re-decoding one waits for its record.)
-template <int N>
-__device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds& tb, int col,
+template <int N, bool MT>
+__device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds& tb,
+                                            const TabLds& tb_odd, int col,
                                             uint32_t start, uint32_t end_bits,
                                             uint32_t side_addr, bool enabled,
                                             uint32_t& exit, uint32_t& count, uint2& sums,
@@ -355,14 +389,21 @@ __device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds& tb, 
   if (!ok || !enabled)
     Pn = pend; // no steps
   uint32_t n = 0, a0 = 0, a1 = 0;
+  uint32_t odd = MT ? ((start >> ST_PHASE_SHIFT) & 1u) : 0u; // (two tables: which one is next)
   while (Pn > pend) {
     const uint32_t ad = vbase + (Pn & ~1023u);
     const uint32_t d1 = *(lds_u32p)(ad), d0 = *(lds_u32p)(ad + 4u * LJ_T);
     const uint32_t w = __builtin_amdgcn_alignbit(d0, d1, Pn >> 5);
-    const lf_u32x2 e = *(lds_u2p)((w >> 19) & 0x1FF8u);
+    lf_u32x2 e;
+    if (MT) {
+      const uint32_t e4 = *(lds_u32p)(((w >> 20) & 0xFFCu) | (odd ? 4096u : 0u));
+      e = lf_u32x2{e4 == LF_MT_SPECIAL ? 0x80000000u : (e4 & 0x7FFu), e4 >> 16};
+    } else {
+      e = *(lds_u2p)((w >> 19) & 0x1FF8u);
+    }
     uint32_t d, tot;
     if (e.x & 0x80000000u) {
-      const uint32_t e16 = lf_slow_entry(w, tb);
+      const uint32_t e16 = lf_slow_entry(w, odd ? tb_odd : tb);
       if (e16 == 0u) {
         ok = false;
         break;
@@ -397,10 +438,12 @@ __device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds& tb, 
       overflow = true;
     Pn -= 32u * tot;
     ++n;
+    if (MT)
+      odd ^= 1u;
   }
   if (!enabled)
     return;
-  exit = ok ? ((pend - Pn) >> 5) : ST_ERR;
+  exit = ok ? (((pend - Pn) >> 5) | (odd << ST_PHASE_SHIFT)) : ST_ERR;
   count = n;
   sums = make_uint2(a0, a1);
 }
@@ -591,6 +634,8 @@ __device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint
 // store (measured: 16 us of a workgroup's 55 in the copy-out alone).
 struct FastStream {
   uint32_t fast_n; // fast ? direct : 0
+  uint32_t mt;     // two tables alternating symbol by symbol: tab_even, tab_odd
+  uint32_t tab_even, tab_odd;
   uint32_t first_block, first_subseq, table_base, start_bit, n_blocks;
   uint32_t RS, kind, keep, out_x, out_y, pitch, n_strips, strip_base;
   uint64_t needed, img_offset;
@@ -602,6 +647,9 @@ __device__ __forceinline__ uint64_t uni64(uint64_t x) {
 __device__ __forceinline__ FastStream lf_stream(const LjStreamDev& S) {
   FastStream f;
   f.fast_n = uni(S.fast ? uint32_t(S.direct) : 0u);
+  f.mt = uni(S.fast == 2 ? 1u : 0u);
+  f.tab_even = uni(f.mt ? uint32_t(S.tab_of_phase[0]) : 0u);
+  f.tab_odd = uni(f.mt ? uint32_t(S.tab_of_phase[1]) : 0u);
   f.first_block = uni(S.first_block);
   f.first_subseq = uni(S.first_subseq);
   f.table_base = uni(S.table_base);
@@ -848,9 +896,11 @@ __device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad
 // ---------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------
-template <int N>
+template <int N, bool MT>
 __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds_bytes,
                                                           uint32_t level) {
+  constexpr uint32_t TICKET0 = (MT ? 12u : 0u) + (N == 4 ? 2u : uint32_t(N) - 1u);
+  constexpr uint32_t SMASK = MT ? 0x7Fu : ST_OFF_MASK; // offset (| table of the next symbol)
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const FastLds F = carve_fast(smem, lds_bytes);
   const int j = threadIdx.x, lane = j & 63, wv = j >> 6;
@@ -867,12 +917,12 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     if (level == 0) {
       chosen = __hip_atomic_load(&a.fast_level[a.run_parity], __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
-      t = atomicAdd(&a.tickets[N == 4 ? 2 : N - 1], 1u);
+      t = atomicAdd(&a.tickets[TICKET0], 1u);
     } else {
       chosen = __hip_atomic_load(&a.fast_level[a.run_parity], __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_AGENT);
       if (chosen == level)
-        t = atomicAdd(&a.tickets[4 * level + (N == 4 ? 2 : N - 1)], 1u);
+        t = atomicAdd(&a.tickets[4 * level + TICKET0], 1u);
     }
     F.misc[M_TICKET] = chosen == level ? t : 0xFFFFFFFFu;
   }
@@ -884,7 +934,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // stream's workgroups in flight; with one stream after the other that is everything on
   // the chip, and it pays the slowest of ~1000 -- interleaved, 1000 / streams.
   const uint4 bs = a.fast_order[uni(F.misc[M_TICKET])];
-  const uint32_t b = uni(bs.x), s = uni(bs.y), table_base = uni(bs.z);
+  const uint32_t b = uni(bs.x), s = uni(bs.y), table_base = uni(bs.z) & 0xFFFFFFu;
   // The workgroup's image and the stream's flags are asked for NOW, next to the stream's
   // record: the head of a workgroup is a chain of dependent loads (ticket -> block ->
   // stream -> flags -> table and image, 0.7-1.5 us each); the ticket's entry names the
@@ -921,14 +971,22 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       kwv[it] = k < lb_now ? kw[k] : 0ull;
     }
   }
-  uint4 lut_now[2];
+  uint4 lut_now[MT ? 4 : 2];
   {
-    const uint4* src = reinterpret_cast<const uint4*>(a.fast_tabs + size_t(table_base) * 1024);
+    const uint32_t t_even = MT ? ((uni(bs.z) >> 24) & 15u) : 0u;
+    const uint4* src =
+        reinterpret_cast<const uint4*>(a.fast_tabs + size_t(table_base + t_even) * 1024);
     lut_now[0] = src[j];
     lut_now[1] = src[j + LJ_T];
+    if constexpr (MT) {
+      const uint4* srb =
+          reinterpret_cast<const uint4*>(a.fast_tabs + size_t(table_base + (uni(bs.z) >> 28)) * 1024);
+      lut_now[2] = srb[j];
+      lut_now[3] = srb[j + LJ_T];
+    }
   }
   const FastStream S = lf_stream(a.streams[s]);
-  if (int(S.fast_n) != N)
+  if (int(S.fast_n) != N || (S.mt != 0u) != MT)
     return; // (workgroup-uniform)
   const uint32_t lb = b - S.first_block;
   // A stream that some workgroup has given up on (periodic data, an invalid code, ...) is
@@ -954,7 +1012,19 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   LF_STAMP(1);
 
   // tables + image
-  {
+  if constexpr (MT) {
+    // (entries 2j, 2j + 1 and 512 + 2j, 512 + 2j + 1 of either table, in their 4-byte form)
+    auto e4 = [](uint32_t x, uint32_t y) -> uint32_t {
+      return (x & 0x80000000u) ? LF_MT_SPECIAL : ((y << 16) | (x & 0x7FFu));
+    };
+    uint2* dst = reinterpret_cast<uint2*>(smem + LF_OFF_LUT);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const uint4 lo = lut_now[2 * t], hi = lut_now[2 * t + 1];
+      dst[512 * t + j] = make_uint2(e4(lo.x, lo.y), e4(lo.z, lo.w));
+      dst[512 * t + 256 + j] = make_uint2(e4(hi.x, hi.y), e4(hi.z, hi.w));
+    }
+  } else {
     uint4* dst = reinterpret_cast<uint4*>(smem + LF_OFF_LUT);
     dst[j] = lut_now[0];
     dst[j + LJ_T] = lut_now[1];
@@ -1051,20 +1121,20 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // 6 us to the workgroup's lifetime)
   const uint32_t guess = guess_now;
   LF_STAMP(4);
-  uint32_t start = guess & ST_OFF_MASK;
+  uint32_t start = guess & SMASK;
   // slot 1 starts where the predecessor workgroup's chain ends (its lane 255 left it in this
   // workgroup's word), the stream's first slot where the stream does
   const uint32_t e1_word = uni(uint32_t(kw_mine >> 48));
   const uint32_t k0_cnt_mine = uni(uint32_t(kw_mine));
   if (j == 1 && (e1_word & 0x8000u))
-    start = e1_word & ST_OFF_MASK;
+    start = e1_word & SMASK;
   if (j == 1 && lb == 0)
     start = S.start_bit;
 
   // 2. decode, keeping the running sums
   uint32_t R[LF_NR];
   FastState fs;
-  fs.Pn = uint32_t(-32) - 32u * start;
+  fs.Pn = uint32_t(-32) - 32u * (start & ST_OFF_MASK);
   fs.n = 0;
   fs.acc[0] = fs.acc[1] = fs.acc[2] = fs.acc[3] = 0;
   fs.ev = 0;
@@ -1073,7 +1143,13 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     fs.Pn = pend; // (slot 0 belongs to the previous workgroup: nothing to decode)
   if (LF_ABLATE & 16u)
     fs.Pn = pend;
-  lf_groups<N, 0>(fs, vbase_own, pend, R);
+  if constexpr (MT) {
+    // (the LUT of the lane's even-numbered symbols, of its odd-numbered ones)
+    const uint32_t lut0 = (start & 64u) ? 4096u : 0u;
+    lf_groups<N, 0, true>(fs, vbase_own, pend, R, lut0, lut0 ^ 4096u);
+  } else {
+    lf_groups<N, 0>(fs, vbase_own, pend, R);
+  }
   LF_STAMP(5);
   // the granules of the flagged workgroups in front (1.7 % of them: 0.24 per lane on
   // average, the first two of a lane asked for now): in flight behind the rounds and scans
@@ -1090,9 +1166,13 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   }
   bool need_redo = false;
   {
-    const bool special = !(fs.Pn & 0x80000000u);
+    // (two tables: a special entry sends the position far past the slot's end, lf_step_mt)
+    const bool special = MT ? (fs.Pn <= pend && ((pend - fs.Pn) >> 5) >= 64u)
+                            : !(fs.Pn & 0x80000000u);
     const bool over = !special && fs.Pn > pend; // more than LF_MAXSYM symbols
     uint32_t ex = special ? ST_ERR : ((pend - fs.Pn) >> 5);
+    if (MT && !special) // the table the NEXT symbol takes
+      ex |= (((start >> ST_PHASE_SHIFT) ^ fs.n) & 1u) << ST_PHASE_SHIFT;
     if (over) {
       ex = ST_ERR;
       atomicMin(&F.misc[M_UNRES], uint32_t(j));
@@ -1206,8 +1286,9 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
         idx = le & 0xFFu;
         w = rec_st(F.rec[idx - 1]);
         if (w & ST_ERR) // (listed for its own sake: from the state it started from)
-          w = rec_su(F.rec[idx]) & ST_OFF_MASK;
-        lf_redecode<N>(F, a.tables[S.table_base], int(idx), w, F.ob[idx],
+          w = rec_su(F.rec[idx]) & SMASK;
+        lf_redecode<N, MT>(F, a.tables[S.table_base + S.tab_even],
+                           a.tables[S.table_base + S.tab_odd], int(idx), w, F.ob[idx],
                        lds_addr(F.side) + (le >> 8) * LF_SIDE_STRIDE, mine, e, c, sums, ovf);
       }
       __syncthreads(); // every read of the records precedes the updates
@@ -1241,9 +1322,12 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     if (N == 2)
       my_sums.y = 0u;
     // (the symbol base rides on the same barrier: K0's counts of the workgroups in front, read
-    // at the start, + the corrections of the flagged ones; those still in flight when this
-    // workgroup started -- flagged ones among its ~128 nearest predecessors: two on average,
-    // and only the very nearest can still be decoding -- are asked again here)
+    // at the start, + the corrections of the flagged ones asked for behind the decode.  What
+    // is still missing then -- flagged workgroups that were in flight themselves -- is asked
+    // for BEHIND the barrier, after this workgroup's own correction is out: asked for in
+    // front of it, as rounds 4's first version did, a flagged workgroup made its successors
+    // wait for ITS predecessors -- nothing with 1.7 % of them flagged, a chain through the
+    // whole stream with two tables, where one in five is: 26 us of a workgroup's 49.)
     {
       if (kg0 & LB_VALID) {
         kacc += uint32_t(kg0);
@@ -1253,25 +1337,12 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
         kacc += uint32_t(kg1);
         kflag &= ~(1u << kit1);
       }
-      uint32_t spins = 0;
-      while (__any(kflag != 0u)) {
-        if (kflag != 0u) {
-          const uint32_t it = uint32_t(__builtin_ctz(kflag));
-          const u64 g = lb_load(a.lb + size_t(fb_now + it * uint32_t(LJ_T) + uint32_t(j)) * LF_LB_WORDS);
-          if (g & LB_VALID) {
-            kacc += uint32_t(g);
-            kflag &= kflag - 1u;
-          }
-        }
-        if (++spins > LF_SPIN_LIMIT_K0) {
-          F.misc[M_SLOW] = 6;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
+      const bool wave_pending = __any(kflag != 0u);
       const uint32_t part = wave_sum_u32(kacc);
-      if (lane == 0)
+      if (lane == 0) {
         F.misc[M_LBX + wv] = part;
+        F.misc[M_LBX + 4 + wv] = wave_pending ? 1u : 0u;
+      }
     }
     // (both scans in front of ONE barrier: the sums are rotated by the symbols before the lane
     // inside its WAVEFRONT first -- rotations add up --, the symbols of the wavefronts in
@@ -1320,7 +1391,31 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     // nearest can still be decoding -- are asked again now.
     published_exit = exit_now;
     LF_STAMP(6);
-    base = uni(F.misc[M_LBX] + F.misc[M_LBX + 1] + F.misc[M_LBX + 2] + F.misc[M_LBX + 3]);
+    if (uni(F.misc[M_LBX + 4] | F.misc[M_LBX + 5] | F.misc[M_LBX + 6] | F.misc[M_LBX + 7])) {
+      uint32_t spins = 0;
+      while (__any(kflag != 0u)) {
+        if (kflag != 0u) {
+          const uint32_t it = uint32_t(__builtin_ctz(kflag));
+          const u64 g = lb_load(a.lb + size_t(fb_now + it * uint32_t(LJ_T) + uint32_t(j)) * LF_LB_WORDS);
+          if (g & LB_VALID) {
+            kacc += uint32_t(g);
+            kflag &= kflag - 1u;
+          }
+        }
+        if (++spins > LF_SPIN_LIMIT_K0) {
+          F.misc[M_SLOW] = 6;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const uint32_t part = wave_sum_u32(kacc);
+      if (lane == 0)
+        F.misc[M_LBX + 8 + wv] = part;
+      __syncthreads();
+      base = uni(F.misc[M_LBX + 8] + F.misc[M_LBX + 9] + F.misc[M_LBX + 10] + F.misc[M_LBX + 11]);
+    } else {
+      base = uni(F.misc[M_LBX] + F.misc[M_LBX + 1] + F.misc[M_LBX + 2] + F.misc[M_LBX + 3]);
+    }
     if (LF_ABLATE & 4u)
       base = lb * 15500u;
     LF_STAMP(7);
@@ -1357,10 +1452,12 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     if (needed >= 1 && needed - 1 >= i0 && needed - 1 < uint64_t(i0) + my_cnt && j >= 1) {
       const uint32_t target = uint32_t(needed - 1 - i0);
       uint32_t p2 = my_start & ST_OFF_MASK;
-      const TabLds& tb = a.tables[S.table_base];
+      uint32_t odd = MT ? ((my_start >> ST_PHASE_SHIFT) & 1u) : 0u;
       for (uint32_t t = 0; t < target; ++t) {
         const uint32_t w = lj_window<LF_BW>(F.B, j, p2 + 1u);
-        p2 += lf_slow_entry(w, tb) >> 10;
+        p2 += lf_slow_entry(w, a.tables[S.table_base + (odd ? S.tab_odd : S.tab_even)]) >> 10;
+        if (MT)
+          odd ^= 1u;
       }
       a.results[s].last_slot = lb * LJ_OWN + uint32_t(j - 1);
       a.results[s].last_pos = p2;
@@ -1581,15 +1678,15 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   LF_STAMP(15);
 }
 
-template <int N>
+template <int N, bool MT>
 void launch_fast_one(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
-  if (!f.present[N])
+  if (!f.present[MT ? 1 : 0][N])
     return;
   for (uint32_t lv = 0; lv < 3; ++lv) {
     if (!((a.fast_level_mask >> lv) & 1u))
       continue;
-    hipLaunchKernelGGL((lj_fast_kernel<N>), dim3(f.total_blocks), dim3(LJ_T), a.fast_lds_lv[lv],
-                       s, a, a.fast_lds_lv[lv], lv);
+    hipLaunchKernelGGL((lj_fast_kernel<N, MT>), dim3(f.total_blocks), dim3(LJ_T),
+                       a.fast_lds_lv[lv], s, a, a.fast_lds_lv[lv], lv);
     if (timer)
       timer->mark(lv == 0 ? "lj_fast_kernel" : (lv == 1 ? "lj_fast_kernel(3/CU)" : "lj_fast_kernel(2/CU)"));
   }
@@ -1614,9 +1711,11 @@ uint32_t ljpeg_fast_stage_cap(uint32_t lds_bytes) {
 }
 
 void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
-  launch_fast_one<1>(a, f, s, timer);
-  launch_fast_one<2>(a, f, s, timer);
-  launch_fast_one<4>(a, f, s, timer);
+  launch_fast_one<1, false>(a, f, s, timer);
+  launch_fast_one<2, false>(a, f, s, timer);
+  launch_fast_one<4, false>(a, f, s, timer);
+  launch_fast_one<2, true>(a, f, s, timer);
+  launch_fast_one<4, true>(a, f, s, timer);
 }
 
 // The LUT of the fast loops from the 11-bit table of the general ones.

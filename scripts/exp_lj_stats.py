@@ -9,7 +9,15 @@ from rawspeed_amd import capi
 ctx = capi.Context(0)
 W, H = 6720, 4480
 frames = int(os.environ.get("FRAMES", "8"))
-made = [B.make_cr2_frame(W, H, (3, 2240, 2240), seed=1 + f) for f in range(frames)]
-plan, inp, out = B._cr2_batch(ctx, torch, [(m[0], m[1]) for m in made], W, H)
+if os.environ.get("WHAT", "cfg3") == "cfg4mt":  # (cfg 4 with a table per component)
+    import numpy as np
+    W, H = 8192, 5464
+    src, jobs, datas, blobs, lens = B._dng_tiles(W, H, 4096, 2732, 2, 0, two_tables=True)
+    inp = torch.from_numpy(np.concatenate(datas)).cuda()
+    out = torch.zeros(B.out_pitch(W) * H, dtype=torch.uint8, device="cuda")
+    plan = ctx.ljpeg_plan(jobs)
+else:
+    made = [B.make_cr2_frame(W, H, (3, 2240, 2240), seed=1 + f) for f in range(frames)]
+    plan, inp, out = B._cr2_batch(ctx, torch, [(m[0], m[1]) for m in made], W, H)
 plan.run(inp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
 print(plan.results()[0])
