@@ -522,6 +522,30 @@ __device__ __forceinline__ uint32_t lj_guess_parse_asm(uint32_t col4, uint32_t e
   return (q - qend) >> 5;
 }
 
+// Total bits of the symbol a window starts with, the general way (any code length, SSSS = 16;
+// 0: no such code): what the guess parses fall back to where the 10-bit length table only
+// says "special".  Rare -- the codes of 11 bits and more are the rarest categories -- but a
+// count the table merely approximates makes the whole workgroup "uncertain", and every
+// workgroup behind it in flight then waits for its decode (two tables with long codes:
+// 0.2 % of the workgroups, 8 us of the AVERAGE workgroup's 40).  In the two-table parse only:
+// the test per symbol cost the one-table loops 14 % of K0 (cfg 3: 0.255 -> 0.29 ms).
+__device__ __forceinline__ uint32_t lj_exact_symbol_bits(uint32_t w, const TabLds* tb) {
+  uint32_t r = lj_lut16(*tb, w >> (32 - LUT_BITS));
+  if ((r & 31u) == 0u) {
+    r = 0;
+    for (uint32_t l = LUT_BITS + 1; l <= tb->max_len && r == 0u; ++l) {
+      const uint32_t c = w >> (32 - l);
+      const uint32_t mc = tb->max_code[l];
+      if (mc != NO_CODE && c <= mc) {
+        const uint32_t ssss = tb->values[(c - tb->val_offset[l]) & 0xFFFFu];
+        const uint32_t extra = ssss == 16u ? (tb->fix16 ? 16u : 0u) : ssss;
+        r = (l + extra) << 10;
+      }
+    }
+  }
+  return r >> 10;
+}
+
 // Two symbols per window read (round 4).  The loop above spends, per symbol, two LDS reads
 // for the window, one random byte read in a 1 KB table (four dwords per bank: conflicts)
 // and ~7 vector instructions.  Here a second, 256-byte table -- 64 dwords, one per LDS bank:
@@ -535,9 +559,15 @@ __device__ __forceinline__ uint32_t lj_guess_parse_asm(uint32_t col4, uint32_t e
 // symbol by the 10-bit table, as the loop above would.
 // 10 vector instructions and 4 LDS reads per PAIR where the loop above takes 14-16 and 6.
 constexpr uint32_t LJ_GUESS_ROUNDS = 6; // rounds of the chain's fixed-point iteration, at most
-constexpr uint32_t LJ_GUESS_LUT8_OFF = LJ_GUESS_LUT_OFF + 1024u + 3u * 512u + 64u;
-static_assert((4 + 2 * LJ_GUESS_ROUNDS) * 4 <= 64, "the rounds' words lie in front of the 8-bit table");
-static_assert(LJ_GUESS_LUT8_OFF + 256u <= uint32_t(LJ_BW) * LJ_T * 4, "inside dword rows 17..19");
+// dword rows 17..19 of the image (3 KB, free once the image is written out): the 10-bit
+// length table | the 8-bit one, or the SECOND 10-bit table of a two-table stream | the chain's
+// two state arrays.  The rounds' slot list and their words live in the staging's list and
+// selector arrays, which are free by then: the second table costs no LDS, and K0 keeps its
+// seven workgroups a CU.
+constexpr uint32_t LJ_GUESS_LUT8_OFF = LJ_GUESS_LUT_OFF + 1024u;
+constexpr uint32_t LJ_GUESS_EA_OFF = LJ_GUESS_LUT_OFF + 2048u;
+static_assert((4 + 2 * LJ_GUESS_ROUNDS) * 4 <= 64, "the rounds' words fit the selector array");
+static_assert(LJ_GUESS_EA_OFF + 1024u <= uint32_t(LJ_BW) * LJ_T * 4, "inside dword rows 17..19");
 template <bool COUNT>
 __device__ __forceinline__ uint32_t lj_guess_parse_pairs(uint32_t col4, uint32_t end_bits,
                                                          uint32_t from, uint32_t* count = nullptr) {
@@ -596,25 +626,66 @@ __device__ __forceinline__ uint32_t lj_guess_parse_pairs(uint32_t col4, uint32_t
 }
 
 // Two tables that alternate symbol by symbol (round 4; LjStreamDev::fast == 2): the table of
-// the next symbol is part of the parse state -- offset | (symbol index & 1) << 6 -- and the
-// second table's lengths lie behind the kernel's usual layout (LJ_K0_LDS_MT).  One symbol per
-// window: pairs would need the two tables' 8-bit forms as well.
-constexpr uint32_t LJ_K0_LUTB_OFF = (LJ_K0_LDS + 15u) & ~15u;
-constexpr uint32_t LJ_K0_LDS_MT = LJ_K0_LUTB_OFF + 1024u;
+// the next symbol is part of the parse state -- offset | (symbol index & 1) << 6.  The second
+// table's lengths take the 8-bit table's place; the two 8-bit tables of the pair loop lie
+// behind the kernel's usual layout, in what the allocation granule leaves unused anyway.
+constexpr uint32_t LJ_K0_LUTB_OFF = LJ_GUESS_LUT8_OFF;
+constexpr uint32_t LJ_K0_LUT8A_OFF = (LJ_K0_LDS + 15u) & ~15u, LJ_K0_LUT8B_OFF = LJ_K0_LUT8A_OFF + 256u;
+constexpr uint32_t LJ_K0_LDS_MT = LJ_K0_LUT8B_OFF + 256u;
+static_assert(LJ_K0_LDS_MT <= 18u * 1280u, "seven workgroups a CU: 18 granules of LDS each");
 constexpr uint32_t ST_MT_MASK = 0x7Fu; // offset | table bit
 template <bool COUNT>
 __device__ __forceinline__ uint32_t lj_guess_parse_mt(uint32_t col4, uint32_t end_bits,
-                                                      uint32_t from, uint32_t* count = nullptr) {
+                                                      uint32_t from, const TabLds* tb_even,
+                                                      const TabLds* tb_odd,
+                                                      uint32_t* count = nullptr) {
   uint32_t q = (from & ST_OFF_MASK) << 5, n = 0, spec = 0;
-  // (the table's LDS address: toggled by XOR with the two bases' difference)
+  // the tables of the NEXT symbol (10-bit, 8-bit): a single symbol swaps them with the other
+  // pair (XOR with the bases' difference), a pair of symbols leaves them as they are
   uint32_t lut = (from & 64u) ? LJ_K0_LUTB_OFF : LJ_GUESS_LUT_OFF;
+  uint32_t l8 = (from & 64u) ? LJ_K0_LUT8B_OFF : LJ_K0_LUT8A_OFF;
   const uint32_t qend = end_bits << 5;
+  const uint32_t qpair = qend > (26u << 5) ? qend - (26u << 5) : 0u;
+  while (q < qpair) { // (lj_guess_parse_pairs' loop, the second look-up in the other table)
+    uint32_t ad;
+    uint64_t pr;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(q), "s"(0xFFFFFC00u), "v"(col4));
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:4 offset1:0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=v"(pr)
+                 : "v"(ad));
+    const uint32_t w = uint32_t((pr << ((q >> 5) & 31u)) >> 32);
+    const uint32_t l1 = *(lds_u8p)(l8 + (w >> 24));
+    const uint32_t w2 = w << (l1 & 31u);
+    const uint32_t l2 = *(lds_u8p)((l8 ^ (LJ_K0_LUT8A_OFF ^ LJ_K0_LUT8B_OFF)) + (w2 >> 24));
+    const uint32_t sum = l1 + l2;
+    uint32_t qadd = sum << 5, nadd = 2u;
+    if (__builtin_expect(sum >= 128u, 0)) {
+      uint32_t len = *(lds_u8p)(lut + (w >> 22));
+      if (__builtin_expect(len & 0x80u, 0)) {
+        const uint32_t exact = lj_exact_symbol_bits(w, lut == LJ_K0_LUTB_OFF ? tb_odd : tb_even);
+        if (exact)
+          len = exact;
+      }
+      spec |= len;
+      qadd = (len & 0x7Fu) << 5;
+      nadd = 1u;
+      lut ^= LJ_K0_LUTB_OFF ^ LJ_GUESS_LUT_OFF;
+      l8 ^= LJ_K0_LUT8A_OFF ^ LJ_K0_LUT8B_OFF;
+    }
+    q += qadd;
+    n += nadd;
+  }
   while (q < qend) {
     uint32_t ad;
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(q), "s"(0xFFFFFC00u), "v"(col4));
     const uint32_t d0 = *(lds_u32p)(ad), d1 = *(lds_u32p)(ad + 4u * LJ_T);
     const uint32_t w = uint32_t((((uint64_t(d0) << 32) | d1) << ((q >> 5) & 31u)) >> 32);
-    const uint32_t len = *(lds_u8p)(lut + (w >> 22));
+    uint32_t len = *(lds_u8p)(lut + (w >> 22));
+    if (__builtin_expect(len & 0x80u, 0)) {
+      const uint32_t exact = lj_exact_symbol_bits(w, lut == LJ_K0_LUTB_OFF ? tb_odd : tb_even);
+      if (exact)
+        len = exact;
+    }
     spec |= len;
     q += (len & 0x7Fu) << 5;
     lut ^= LJ_K0_LUTB_OFF ^ LJ_GUESS_LUT_OFF;
@@ -677,6 +748,12 @@ __device__ __forceinline__ bool lj_guess_constant(const uint32_t* B, int col, ui
 }
 constexpr int LJ_GUESS_SLOTS = 3; // slots parsed for a guess, at most (LjArgs::guess_slots)
 
+// MTPLAN: the plan has streams with two alternating tables.  Two instantiations because the
+// mere presence of their code -- the two-table parse, the hand-over of entry states between
+// workgroups -- made the kernel 4-10 % slower for plans that never run it (register
+// allocation and layout of the rounds: cfg 3 0.258 -> 0.265-0.29 ms).
+#define K0_CHAIN (MTPLAN && a.k0_chain != 0u)
+template <bool MTPLAN>
 __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // The LAST workgroups first: the kernels behind this one read the un-stuffed image from
@@ -684,11 +761,18 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   // what they find there (cfg 3: the image alone is 343 MB; in block order the cache holds
   // its END when the readers start at its beginning -- measured: K0 -3 %, the single-pass
   // kernel -1 %, a single cfg-4 frame -2.8 %).  K0's workgroups are independent of one another.
+  // (K0_CHAIN, plans with two-table streams: workgroups in block order, because each one asks
+  // its predecessor for its true entry state, see "hand-over" below)
 #ifdef RSX_K0_FORWARD
-  const uint32_t b = blockIdx.x;
+  uint32_t b = blockIdx.x;
 #else
-  const uint32_t b = gridDim.x - 1u - blockIdx.x;
+  uint32_t b = gridDim.x - 1u - blockIdx.x;
 #endif
+  // (no tickets: the dispatcher starts a 1-D grid's workgroups in order, and if it ever did
+  // not, the bounded wait below gives up and the workgroup keeps its own estimate -- a ticket
+  // and its barrier in front of the first load cost every workgroup 1.5 us of its 25)
+  if (K0_CHAIN)
+    b = blockIdx.x;
   const uint32_t s = a.block_stream[b];
   const LjStreamDev& S = a.streams[s];
   // This kernel's own layout: the arrays of the general one that only the synchronisation
@@ -706,8 +790,8 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   const uint32_t lb = b - S.first_block;
   const int j = threadIdx.x;
   uint8_t* lut8 = smem + LJ_GUESS_LUT_OFF;
-  uint32_t lut_pk = 0, lut8b = 0x80u, lut_pk_b = 0;
-  const bool mt = S.fast == 2;
+  uint32_t lut_pk = 0, lut8b = 0x80u, lut_pk_b = 0, lut8b_b = 0x80u;
+  const bool mt = MTPLAN && S.fast == 2;
   if (S.fast && a.fast_tabs) {
     // (the symbol lengths of the stream's 10-bit LUT: asked for now, parked later)
     const uint2* ft =
@@ -722,11 +806,18 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     }
     if (mt) {
       const uint2* fb = a.fast_tabs + size_t(S.table_base + S.tab_of_phase[1]) * 1024 + 4 * j;
+      uint2 b0 = make_uint2(0u, 0u);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const uint2 e = fb[k];
+        if (k == 0)
+          b0 = e;
         lut_pk_b |= (((e.x >> 5) & 63u) | ((e.x >> 24) & 0x80u)) << (8 * k);
       }
+      const uint32_t total = (b0.x >> 5) & 63u;
+      const uint32_t code = total - uint32_t(__builtin_popcount(b0.y));
+      if (!(b0.x & 0x80000000u) && code <= 8u && total >= 1u)
+        lut8b_b = total;
     }
     // the 8-bit table's entry j: the four 10-bit entries 4j.. agree iff the code has at most
     // 8 bits (code length = total - SSSS, SSSS = popcount of the entry's 2^SSSS - 1)
@@ -774,18 +865,22 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   // not synchronise -- is marked, and the kernel asks those workgroups (and only those) for
   // the difference (rsx_ljpeg_fast.hip, "symbol base").
   if (S.fast && a.fast_tabs) {
-    uint16_t* EA = reinterpret_cast<uint16_t*>(smem + LJ_GUESS_LUT_OFF + 1024); // (dword rows 18, 19)
+    uint16_t* EA = reinterpret_cast<uint16_t*>(smem + LJ_GUESS_EA_OFF); // (dword row 19)
     uint16_t* EB = EA + LJ_T;
-    uint16_t* glist = EB + LJ_T;
+    uint16_t* glist = L.list; // (the staging's list of slots with stuffing bytes: done with)
     // [2] uncertain; [4 + 2 r] list length of round r, [5 + 2 r] "an exit moved in round r"
-    uint32_t* nlist = reinterpret_cast<uint32_t*>(glist + LJ_T);
+    uint32_t* nlist = L.sm; // (the staging's 16 compaction selectors: done with)
     uint16_t* EU = EA;      // (after the B parses) the entry a slot's last parse started from
     uint16_t* ECNT = L.su;  // symbols of a slot's last parse (su[] is the staging's)
     __syncthreads(); // every lane has written its part of the image out
     reinterpret_cast<uint32_t*>(lut8)[j] = lut_pk;
-    smem[LJ_GUESS_LUT8_OFF + uint32_t(j)] = uint8_t(lut8b);
-    if (mt)
+    if (mt) {
       reinterpret_cast<uint32_t*>(smem + LJ_K0_LUTB_OFF)[j] = lut_pk_b;
+      smem[LJ_K0_LUT8A_OFF + uint32_t(j)] = uint8_t(lut8b);
+      smem[LJ_K0_LUT8B_OFF + uint32_t(j)] = uint8_t(lut8b_b);
+    } else {
+      smem[LJ_GUESS_LUT8_OFF + uint32_t(j)] = uint8_t(lut8b);
+    }
     if (j < 4 + 2 * int(LJ_GUESS_ROUNDS))
       nlist[j] = 0;
     if (j == 0)
@@ -810,10 +905,13 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     if (a.guess_slots & 0x100u) // (experiments: the compiler's loop)
       hand = false;
 #endif
+    // (the stream's tables in global memory: for the symbols the length tables only flag)
+    const TabLds* tb_even = a.tables + S.table_base + (mt ? S.tab_of_phase[0] : 0u);
+    const TabLds* tb_odd = a.tables + S.table_base + (mt ? S.tab_of_phase[1] : 0u);
     auto parse = [&](int col, uint32_t bits, uint32_t from, uint32_t* count) -> uint32_t {
       if (mt)
-        return count ? lj_guess_parse_mt<true>(uint32_t(col) * 4u, bits, from, count)
-                     : lj_guess_parse_mt<false>(uint32_t(col) * 4u, bits, from);
+        return count ? lj_guess_parse_mt<true>(uint32_t(col) * 4u, bits, from, tb_even, tb_odd, count)
+                     : lj_guess_parse_mt<false>(uint32_t(col) * 4u, bits, from, tb_even, tb_odd);
 #ifndef RSX_K0_SINGLE_SYMBOL
       if (hand)
         return count ? lj_guess_parse_pairs<true>(uint32_t(col) * 4u, bits, from, count)
@@ -847,6 +945,29 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       ebv = parse(j, eb, xa, &cnt) & smask;
 #endif
     EB[j] = uint16_t(ebv);
+    uint32_t handed = 0;
+    // Hand-over (K0_CHAIN): the state this workgroup's chain leaves its last slot in IS the
+    // next workgroup's entry state, and after the B parses it is final in 98 % of the
+    // workgroups -- so lane 255 puts it out now, and lane 0 takes the predecessor's instead of
+    // its own estimate (the parse of ONE slot from bit 0: off in 1.5 % of the workgroups with
+    // one table, in 12 % with two, where offset AND table have to fall into step): behind
+    // the rounds, and if it differs the rounds run once more -- slot 1 is re-parsed from it like
+    // any slot whose predecessor's exit moved.  Without
+    // this every mis-estimated workgroup is a slow one in the single-pass kernel (its first
+    // slots' guesses are off: re-decode rounds), and every workgroup behind a slow one in
+    // flight waits for it, twice: 17 us of a workgroup's 44 with two tables.
+    // (a predecessor whose rounds move its last exit after all puts the new one out at its
+    // end; the successor's word then says "estimate != true entry", as before)
+    if (K0_CHAIN) {
+      const uint32_t tag = 0x8000u | (a.run_parity << 14);
+      if (j == LJ_T - 1 && lb + 1 < S.n_blocks)
+        __hip_atomic_store(&a.k0e[b + 1], tag | (ebv & smask), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      // (asked for now, looked at behind the rounds: the predecessor is at the same point of
+      // its life, give or take -- waiting for it here cost K0 27 %)
+      if (j == 0 && lb > 0)
+        handed = __hip_atomic_load(&a.k0e[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // (15 bits of symbols, 0x7FFF = too many to say; bit 15: the parse met a special entry)
     auto pack_cnt = [](uint32_t c) -> uint16_t {
       const uint32_t n = c & 0x7FFFFFFFu;
@@ -872,39 +993,67 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     // their bits -- a parse from a wrong entry would only carry the error down the region)
     // (per round a list length and a "some exit moved" word of its own: nothing to reset
     // between rounds, two barriers a round -- what the three-slot chain took before)
-    bool settled = false;
-    for (uint32_t round = 0; round < LJ_GUESS_ROUNDS && gs >= 3u; ++round) {
-      const uint32_t x = j >= 1 ? uint32_t(EB[j - 1]) : 0u;
-      if (!constant && exists && j >= 1 && x != uint32_t(EU[j]))
-        glist[atomicAdd(&nlist[4 + 2 * round], 1u)] = uint16_t(j);
-      __syncthreads();
-      const uint32_t nth = nlist[4 + 2 * round];
-      if (nth == 0) {
-        settled = true;
-        break;
-      }
-      if (j < 64) {
-        bool changed = false;
-        for (uint32_t k = uint32_t(j); k < nth; k += 64u) {
-          const int c = int(glist[k]);
-          const uint32_t from = uint32_t(EB[c - 1]);
-          uint32_t n = 0;
-          const uint32_t e = parse(c, L.ob[c], from, &n) & smask;
-          if (e != uint32_t(EB[c]))
-            changed = true;
-          if ((round == 0u || e != uint32_t(EB[c])) && (c < LJ_T - 1 || lb + 1 < S.n_blocks))
-            a.sub_start[g1 + uint32_t(c)] = uint16_t(e);
-          EB[c] = uint16_t(e);
-          EU[c] = uint16_t(from);
-          ECNT[c] = pack_cnt(n);
+    // (a lambda, run a second time after the hand-over below: as ONE loop nest -- "for pass" around
+    // the rounds -- the compiler made the rounds 10 % of K0 slower for everybody, cfg 3 0.26 -> 0.29 ms)
+    auto run_rounds = [&]() -> bool {
+      for (uint32_t round = 0; round < LJ_GUESS_ROUNDS && gs >= 3u; ++round) {
+        const uint32_t x = j >= 1 ? uint32_t(EB[j - 1]) : 0u;
+        if (!constant && exists && j >= 1 && x != uint32_t(EU[j]))
+          glist[atomicAdd(&nlist[4 + 2 * round], 1u)] = uint16_t(j);
+        __syncthreads();
+        const uint32_t nth = nlist[4 + 2 * round];
+        if (nth == 0)
+          return true;
+        if (j < 64) {
+          bool changed = false;
+          for (uint32_t k = uint32_t(j); k < nth; k += 64u) {
+            const int c = int(glist[k]);
+            const uint32_t from = uint32_t(EB[c - 1]);
+            uint32_t n = 0;
+            const uint32_t e = parse(c, L.ob[c], from, &n) & smask;
+            if (e != uint32_t(EB[c]))
+              changed = true;
+            if ((round == 0u || e != uint32_t(EB[c])) && (c < LJ_T - 1 || lb + 1 < S.n_blocks))
+              a.sub_start[g1 + uint32_t(c)] = uint16_t(e);
+            EB[c] = uint16_t(e);
+            EU[c] = uint16_t(from);
+            ECNT[c] = pack_cnt(n);
+          }
+          if (changed)
+            nlist[5 + 2 * round] = 1u;
         }
-        if (changed)
-          nlist[5 + 2 * round] = 1u;
+        __syncthreads();
+        if (nlist[5 + 2 * round] == 0u) // (no exit moved: every successor's entry still stands)
+          return true;
+      }
+      return false;
+    };
+    bool settled = run_rounds();
+    if (K0_CHAIN) {
+      // the hand-over: the predecessor's word (asked for before the rounds; once more if it
+      // was not out yet -- it is by now as a rule: the predecessor started earlier)
+      if (j == 0) {
+        nlist[3] = 0u;
+        if (lb > 0) {
+          const uint32_t tag = 0x8000u | (a.run_parity << 14);
+          uint32_t v = handed;
+          for (uint32_t spins = 0; spins < (1u << 12) && (v & 0xC000u) != tag; ++spins) {
+            __builtin_amdgcn_s_sleep(1);
+            v = __hip_atomic_load(&a.k0e[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if ((v & 0xC000u) == tag && (v & smask) != uint32_t(EB[0])) {
+            EB[0] = uint16_t(v & smask);
+            nlist[3] = 1u;
+          }
+        }
       }
       __syncthreads();
-      if (nlist[5 + 2 * round] == 0u) { // (no exit moved: every successor's entry still stands)
-        settled = true;
-        break;
+      if (nlist[3] != 0u) { // the entry moved: the rounds once more (slot 1 is listed by the first)
+        __syncthreads(); // (everybody has read the word)
+        if (j >= 3 && j < 4 + 2 * int(LJ_GUESS_ROUNDS))
+          nlist[j] = 0u;
+        __syncthreads();
+        settled = run_rounds();
       }
     }
     ebv = uint32_t(EB[j]);
@@ -955,6 +1104,9 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       if (j == LJ_T - 1 && lb + 1 < S.n_blocks)
         *reinterpret_cast<uint16_t*>(w + 8 + 6) = uint16_t(0x8000u | (ebv & 0x7Fu));
     }
+    if (K0_CHAIN && j == LJ_T - 1 && lb + 1 < S.n_blocks)
+      __hip_atomic_store(&a.k0e[b + 1], 0x8000u | (a.run_parity << 14) | (ebv & smask),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (j == 0) {
       const uint32_t need = *est + (*est >> 6) + 64u;
       uint32_t lv = 0;
@@ -2527,6 +2679,7 @@ struct LJpegPlan {
   // single-pass path (rsx_ljpeg_fast.hip)
   bool fast_present[2][5] = {}; // [two alternating tables][components]
   bool any_fast_mt = false;     // some stream takes its two-table instantiation
+  DeviceBuffer d_k0e;           // K0's hand-over words (LjArgs::k0e)
   bool any_fast = false;       // some stream takes the single-pass kernel
   uint32_t fast_lds = 0;       // LDS bytes of its launches
   std::vector<uint8_t> slow_strikes; // per stream: consecutive runs it went to the slow path
@@ -2634,6 +2787,12 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.fast_tabs = static_cast<const uint2*>(p->d_fast_tabs.ptr);
   a.lb = static_cast<unsigned long long*>(p->d_lb.ptr);
   a.k0w = static_cast<unsigned long long*>(p->d_k0w.ptr);
+  a.k0e = static_cast<uint32_t*>(p->d_k0e.ptr);
+#ifdef RSX_NO_K0_CHAIN // (experiments)
+  a.k0_chain = 0u;
+#else
+  a.k0_chain = (p->any_fast_mt && p->d_k0e.ptr) ? 1u : 0u;
+#endif
   a.block_base0 = static_cast<uint32_t*>(p->d_block_base0.ptr);
   a.tickets = static_cast<uint32_t*>(p->d_tickets.ptr);
   a.fast_lds = p->fast_lds;
@@ -3097,6 +3256,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       if ((st = up(p->d_fast_tabs, ft.data(), ft.size() * sizeof(uint2))) ||
           (st = p->d_lb.ensure(size_t(p->total_blocks) * LF_LB_WORDS * 8)) ||
           (st = p->d_k0w.ensure(size_t(p->total_blocks + 1) * 8)) ||
+          (st = p->d_k0e.ensure(size_t(p->total_blocks + 1) * 4)) ||
           (st = p->d_block_base0.ensure(size_t(p->total_blocks) * 4)) ||
           (st = p->d_tickets.ensure(LF_TICKET_WORDS * 4)))
         return st;
@@ -3104,6 +3264,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         return st;
       RSX_HIP_CHECK(ctx, hipMemset(p->d_tickets.ptr, 0, LF_TICKET_WORDS * 4));
       RSX_HIP_CHECK(ctx, hipMemset(p->d_k0w.ptr, 0, size_t(p->total_blocks + 1) * 8));
+      RSX_HIP_CHECK(ctx, hipMemset(p->d_k0e.ptr, 0, size_t(p->total_blocks + 1) * 4));
       RSX_HIP_CHECK(ctx, hipMemset(p->d_block_base0.ptr, 0, size_t(p->total_blocks) * 4));
       RSX_HIP_CHECK(ctx, hipMemset(p->d_fast_level.ptr, 0, 256));
 #ifdef RSX_EXPERIMENT
@@ -3212,36 +3373,70 @@ int run_dri(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s) {
   rsx_ctx* ctx = p->ctx;
   const uint8_t* in_base = static_cast<const uint8_t*>(in_dev);
   std::vector<uint32_t> signature;
-  for (auto& dj : p->dri) {
+  // Marker scans of ALL jobs with restart intervals, then ONE round trip for their counts and
+  // lists (round 3 synchronised once per job: four tiles, four round trips of ~50 us in a
+  // 0.5 ms decode).
+  const size_t nd = p->dri.size();
+  std::vector<uint32_t> caps(nd), offs(nd), counts(nd, 0);
+  size_t total_cap = 0;
+  for (size_t d = 0; d < nd; ++d) {
+    caps[d] = p->dri[d].n_ri + 1024;
+    offs[d] = uint32_t(total_cap);
+    total_cap += caps[d];
+  }
+  if (int st = p->d_marker_count.ensure(nd * 4 + 16))
+    return st;
+  if (int st = p->d_marker_list.ensure(total_cap * sizeof(uint2)))
+    return st;
+  RSX_HIP_CHECK(ctx, hipMemsetAsync(p->d_marker_count.ptr, 0, nd * 4, s));
+  for (size_t d = 0; d < nd; ++d) {
+    const auto& dj = p->dri[d];
+    const uint64_t bytes = dj.in.geom.in_bytes;
+    const uint32_t blocks = uint32_t((bytes + 4095) / 4096);
+    hipLaunchKernelGGL(lj_marker_scan_kernel, dim3(blocks), dim3(256), 0, s,
+                       in_base + dj.in.geom.in_offset, bytes,
+                       static_cast<uint32_t*>(p->d_marker_count.ptr) + d,
+                       static_cast<uint2*>(p->d_marker_list.ptr) + offs[d], caps[d]);
+  }
+  RSX_HIP_CHECK(ctx, hipGetLastError());
+  std::vector<uint2> all_lists(total_cap);
+  RSX_HIP_CHECK(ctx, hipMemcpyAsync(counts.data(), p->d_marker_count.ptr, nd * 4,
+                                    hipMemcpyDeviceToHost, s));
+  RSX_HIP_CHECK(ctx, hipMemcpyAsync(all_lists.data(), p->d_marker_list.ptr,
+                                    total_cap * sizeof(uint2), hipMemcpyDeviceToHost, s));
+  RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  for (size_t d = 0; d < nd; ++d) {
+    auto& dj = p->dri[d];
     dj.status = RSX_OK;
     const uint64_t bytes = dj.in.geom.in_bytes;
-    uint32_t cap = dj.n_ri + 1024;
+    uint32_t count = counts[d];
     std::vector<uint2> list;
-    uint32_t count = 0;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-      if (int st = p->d_marker_count.ensure(16))
-        return st;
-      if (int st = p->d_marker_list.ensure(size_t(cap) * sizeof(uint2)))
+    if (count <= caps[d]) {
+      list.assign(all_lists.begin() + offs[d], all_lists.begin() + offs[d] + count);
+    } else {
+      // rare: lots of FFxx behind the scan -- this job again, with room for all of them
+      const uint32_t cap = count;
+      DeviceBuffer big;
+      if (int st = big.ensure(size_t(cap) * sizeof(uint2)))
         return st;
       RSX_HIP_CHECK(ctx, hipMemsetAsync(p->d_marker_count.ptr, 0, 4, s));
       const uint32_t blocks = uint32_t((bytes + 4095) / 4096);
       hipLaunchKernelGGL(lj_marker_scan_kernel, dim3(blocks), dim3(256), 0, s,
                          in_base + dj.in.geom.in_offset, bytes,
                          static_cast<uint32_t*>(p->d_marker_count.ptr),
-                         static_cast<uint2*>(p->d_marker_list.ptr), cap);
+                         static_cast<uint2*>(big.ptr), cap);
       RSX_HIP_CHECK(ctx, hipGetLastError());
       RSX_HIP_CHECK(ctx, hipMemcpyAsync(&count, p->d_marker_count.ptr, 4,
                                         hipMemcpyDeviceToHost, s));
       RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
-      if (count <= cap)
-        break;
-      cap = count; // rare: lots of FFxx after the scan -- list them all
+      if (count > cap)
+        count = cap;
+      list.resize(count);
+      if (count)
+        RSX_HIP_CHECK(ctx, hipMemcpy(list.data(), big.ptr, size_t(count) * sizeof(uint2),
+                                     hipMemcpyDeviceToHost));
+      big.release();
     }
-    list.resize(count);
-    if (count)
-      RSX_HIP_CHECK(ctx, hipMemcpy(list.data(), p->d_marker_list.ptr,
-                                   size_t(count) * sizeof(uint2),
-                                   hipMemcpyDeviceToHost));
     std::sort(list.begin(), list.end(),
               [](const uint2& x, const uint2& y) { return x.x < y.x; });
     dj.markers.clear();
@@ -3420,8 +3615,12 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
                                     p->h_results.size() * sizeof(LjResult),
                                     hipMemcpyHostToDevice, s));
   const uint32_t n_streams = uint32_t(p->streams.size());
-  hipLaunchKernelGGL(lj_unstuff_kernel, dim3(p->total_blocks), dim3(LJ_T),
-                     p->any_fast_mt ? LJ_K0_LDS_MT : LJ_K0_LDS, s, a);
+  if (p->any_fast_mt)
+    hipLaunchKernelGGL(lj_unstuff_kernel<true>, dim3(p->total_blocks), dim3(LJ_T), LJ_K0_LDS_MT,
+                       s, a);
+  else
+    hipLaunchKernelGGL(lj_unstuff_kernel<false>, dim3(p->total_blocks), dim3(LJ_T), LJ_K0_LDS,
+                       s, a);
   mark(p, "lj_unstuff_kernel");
   // the single-pass kernel for the streams it takes ...
   if (p->any_fast) {
@@ -3690,6 +3889,7 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
     std::vector<unsigned long long> t(size_t(p->total_blocks) * 16);
     if (hipMemcpy(t.data(), p->d_dbg.ptr, t.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
       double sum[16] = {}, mx[16] = {};
+      std::vector<float> all[16];
       size_t n = 0;
       unsigned long long tmin = ~0ull, tmax = 0;
       for (uint32_t b = 0; b < p->total_blocks; ++b) {
@@ -3705,6 +3905,7 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
           const double d = double(cur - prev) / 2400.0;
           sum[k] += d;
           mx[k] = std::max(mx[k], d);
+          all[k].push_back(float(d));
           prev = cur;
         }
       }
@@ -3716,7 +3917,10 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
               double(tmax - tmin) / 2400.0);
       double tot = 0;
       for (int k = 1; k < 16; ++k) {
-        fprintf(stderr, "[rsx]   %-18s mean %7.2f us  max %8.2f us\n", nm[k], n ? sum[k] / n : 0.0, mx[k]);
+        std::sort(all[k].begin(), all[k].end());
+        auto pct = [&](double q) { return all[k].empty() ? 0.0 : double(all[k][size_t(q * (all[k].size() - 1))]); };
+        fprintf(stderr, "[rsx]   %-18s mean %7.2f us  p50 %6.2f  p90 %6.2f  p99 %6.2f  max %8.2f us\n",
+                nm[k], n ? sum[k] / n : 0.0, pct(0.5), pct(0.9), pct(0.99), mx[k]);
         tot += n ? sum[k] / n : 0.0;
       }
       fprintf(stderr, "[rsx]   %-14s mean %7.2f us\n", "lifetime", tot);
@@ -3812,7 +4016,7 @@ void ljpeg_plan_destroy(LJpegPlan* p) {
     ljpeg_plan_destroy(p->nk_child);
   for (DeviceBuffer* b : {&p->d_nk, &p->d_nk_tables, &p->d_nk_rowpow, &p->d_nk_pup,
                           &p->d_transfer, &p->d_fast_tabs, &p->d_lb, &p->d_tickets, &p->d_dbg, &p->d_fast_z, &p->d_fast_level,
-                          &p->d_k0w, &p->d_block_base0,
+                          &p->d_k0w, &p->d_k0e, &p->d_block_base0,
                           &p->d_fast_order})
     b->release();
   p->d_marker_count.release();

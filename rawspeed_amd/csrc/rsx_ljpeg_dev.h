@@ -263,6 +263,9 @@ struct LjArgs {
   unsigned long long* k0w;   // [workgroup]: what K0 knows about its symbols (lj_unstuff_kernel):
                              // count | own estimate of its entry state, "uncertain" | true entry
   uint32_t* block_base0;     // [workgroup]: the symbol base the single-pass kernel worked from
+  uint32_t* k0e;             // [workgroup]: K0's hand-over of entry states between its workgroups:
+                             // 0x8000 | run parity << 14 | the state the predecessor's chain ends in
+  uint32_t k0_chain;         // != 0: K0 runs in block order and hands entry states over
   unsigned long long* dbg;   // experiment builds: [workgroup][16] phase time stamps
   uint32_t fuse_consumed;    // != 0: lj_scan_kernel does lj_consumed_kernel's work as well
   uint32_t pass;             // 0: first pass; 1: the multi-kernel pipeline redoes FL_SLOW

@@ -1130,7 +1130,14 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     start = e1_word & SMASK;
   if (j == 1 && lb == 0)
     start = S.start_bit;
-
+  // (Tried for two tables, where K0's estimate of the entry state was off in 12 % of the
+  // workgroups before its hand-over: the workgroup that sees the mismatch follows the true
+  // chain and K0's through its first slots itself -- two lanes, lengths only, 3.5 us a slot --,
+  // puts the difference of their counts out at once and starts the slots in between from the
+  // true states.  It took the re-decode rounds away and the wait for a predecessor's count from
+  // 17 to 5 us, and moved it into look-back 1: a workgroup that is 3.5 us late there holds up
+  // everyone behind it in flight just the same.  K0's hand-over leaves 1.4 % mis-estimated,
+  // as with one table, and they are left to the rounds.)
   // 2. decode, keeping the running sums
   uint32_t R[LF_NR];
   FastState fs;
@@ -1337,7 +1344,29 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
         kacc += uint32_t(kg1);
         kflag &= ~(1u << kit1);
       }
-      const bool wave_pending = __any(kflag != 0u);
+      // (one table: 1.5 % of the workgroups are flagged and hardly any of them is slow -- asking
+      // right here, in front of the barrier, is 5 % of the kernel faster on cfg 4 than the
+      // second barrier the other order needs now and then)
+      if constexpr (!MT) {
+        uint32_t spins = 0;
+        while (__any(kflag != 0u)) {
+          if (kflag != 0u) {
+            const uint32_t it = uint32_t(__builtin_ctz(kflag));
+            const u64 g = lb_load(a.lb + size_t(fb_now + it * uint32_t(LJ_T) + uint32_t(j)) * LF_LB_WORDS);
+            if (g & LB_VALID) {
+              kacc += uint32_t(g);
+              kflag &= kflag - 1u;
+            }
+          }
+          if (++spins > LF_SPIN_LIMIT_K0) {
+            F.misc[M_SLOW] = 6;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        kflag = 0u;
+      }
+      const bool wave_pending = MT && __any(kflag != 0u);
       const uint32_t part = wave_sum_u32(kacc);
       if (lane == 0) {
         F.misc[M_LBX + wv] = part;
@@ -1391,7 +1420,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     // nearest can still be decoding -- are asked again now.
     published_exit = exit_now;
     LF_STAMP(6);
-    if (uni(F.misc[M_LBX + 4] | F.misc[M_LBX + 5] | F.misc[M_LBX + 6] | F.misc[M_LBX + 7])) {
+    if (MT && uni(F.misc[M_LBX + 4] | F.misc[M_LBX + 5] | F.misc[M_LBX + 6] | F.misc[M_LBX + 7])) {
       uint32_t spins = 0;
       while (__any(kflag != 0u)) {
         if (kflag != 0u) {

@@ -9,10 +9,14 @@ from rawspeed_amd import capi
 ctx = capi.Context(0)
 W, H = 6720, 4480
 frames = int(os.environ.get("FRAMES", "8"))
-if os.environ.get("WHAT", "cfg3") == "cfg4mt":  # (cfg 4 with a table per component)
+if os.environ.get("WHAT", "cfg3") in ("cfg4mt", "cfg4"):  # (cfg 4, with a table per component)
     import numpy as np
     W, H = 8192, 5464
-    src, jobs, datas, blobs, lens = B._dng_tiles(W, H, 4096, 2732, 2, 0, two_tables=True)
+    try:
+        src, jobs, datas, blobs, lens = B._dng_tiles(W, H, 4096, 2732, 2, 0,
+                                                     two_tables=os.environ["WHAT"] == "cfg4mt")
+    except TypeError:  # (an older bench_ljpeg)
+        src, jobs, datas, blobs, lens = B._dng_tiles(W, H, 4096, 2732, 2, 0)
     inp = torch.from_numpy(np.concatenate(datas)).cuda()
     out = torch.zeros(B.out_pitch(W) * H, dtype=torch.uint8, device="cuda")
     plan = ctx.ljpeg_plan(jobs)
