@@ -10,6 +10,8 @@
 #include "rsx_samsung_v2.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstring>
 #include <memory>
 
@@ -255,6 +257,11 @@ extern "C" void rsx_ctx_destroy(rsx_ctx* ctx) {
     l->cached_plan = nullptr;
     if (l->stream)
       (void)hipStreamDestroy(l->stream);
+    for (hipEvent_t e : l->ev_up)
+      (void)hipEventDestroy(e);
+    l->ev_up.clear();
+    if (l->stream_up)
+      (void)hipStreamDestroy(l->stream_up);
     l->d_in.release();
     l->d_out.release();
   }
@@ -840,14 +847,17 @@ int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
   if (int e = lane.lane->d_out.ensure(out_total + 16))
     return e;
   hipStream_t s = lane.lane->stream;
-  for (int i = 0; i < n; ++i) {
-    if (st[i] != RSX_OK)
-      continue;
-    RSX_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t*>(lane.lane->d_in.ptr) +
-                                          jobs[i].in_offset,
-                                      ins[i], jobs[i].in_bytes,
-                                      hipMemcpyHostToDevice, s));
-  }
+  auto upload_all = [&]() -> int {
+    for (int i = 0; i < n; ++i) {
+      if (st[i] != RSX_OK)
+        continue;
+      RSX_HIP_CHECK(ctx, hipMemcpyAsync(static_cast<uint8_t*>(lane.lane->d_in.ptr) +
+                                            jobs[i].in_offset,
+                                        ins[i], jobs[i].in_bytes,
+                                        hipMemcpyHostToDevice, s));
+    }
+    return RSX_OK;
+  };
   // Build device jobs directly (the compact rectangles are not expressible as
   // a plain image view when crop_y > 0, so bypass flatten's offset arithmetic).
   std::vector<UnpackJobDev> per_order[4];
@@ -870,6 +880,138 @@ int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
     per_order[d.bit_order].push_back(u);
   }
   DeviceBuffer d_jobs, d_starts;
+  // Large inputs (a whole frame through readUncompressedRaw, the tiles of an uncompressed
+  // DNG): in row bands, the upload of band k + 1 (a helper thread, a stream of its own) under
+  // the unpack and the download of band k.  PCIe is full duplex and the two directions have
+  // DMA engines of their own, but a copy from or to pageable memory keeps its calling thread
+  // until it is done -- so one thread per direction.  cfg 2: 78 MB up + 89 MB down took their
+  // sum at 56 GB/s, 3.0 ms; banded 2.3 ms.
+  {
+    constexpr size_t BAND_BYTES = size_t(8) << 20, OVERLAP_MIN = size_t(16) << 20;
+    constexpr int MAX_BANDS = 32;
+    struct Band {
+      UnpackJobDev u;
+      int order;
+      const uint8_t* src;
+      uint8_t* dst;
+      uint32_t blocks;
+      size_t dev_pitch, width_bytes;
+    };
+    std::vector<Band> bands;
+    size_t in_used_total = 0;
+    for (int i = 0; i < n; ++i)
+      if (st[i] == RSX_OK && rects[i].rows != 0)
+        in_used_total += size_t(rects[i].rows) * size_t(descs[i].input_pitch_bytes);
+    if (in_used_total >= OVERLAP_MIN && !getenv("RSX_HOST_NO_OVERLAP")) {
+      size_t k_of_order[4] = {0, 0, 0, 0};
+      for (int i = 0; i < n; ++i) {
+        if (st[i] != RSX_OK || rects[i].rows == 0)
+          continue;
+        const rsx_unpack_desc& d = descs[i];
+        const OutRect& r = rects[i];
+        const UnpackJobDev base = per_order[d.bit_order][k_of_order[d.bit_order]++];
+        const size_t in_used = size_t(r.rows) * size_t(d.input_pitch_bytes);
+        const size_t nb = std::max<size_t>(1, std::min<size_t>(8, in_used / BAND_BYTES));
+        const uint32_t rows_per = uint32_t((r.rows + nb - 1) / nb);
+        for (uint32_t r0 = 0; r0 < r.rows; r0 += rows_per) {
+          Band bd;
+          bd.u = base;
+          bd.u.n_rows = uint32_t(std::min<size_t>(rows_per, r.rows - r0));
+          bd.u.in_offset = base.in_offset + uint64_t(r0) * base.in_pitch;
+          bd.u.out_offset = base.out_offset + uint64_t(r0) * base.out_pitch;
+          bd.u.stream_bytes = uint64_t(bd.u.n_rows) * base.in_pitch;
+          bd.blocks = unpack_blocks_for(&bd.u);
+          bd.order = d.bit_order;
+          bd.src = ins[i] + size_t(r0) * base.in_pitch;
+          bd.dst = static_cast<uint8_t*>(img->data) + r.host_off + size_t(r0) * img->pitch_bytes;
+          bd.dev_pitch = r.dev_pitch;
+          bd.width_bytes = r.width_bytes;
+          bands.push_back(bd);
+        }
+      }
+    }
+    const int nb = int(bands.size());
+    if (nb >= 2 && nb <= MAX_BANDS && lane.lane->ensure_overlap(nb)) {
+      std::vector<UnpackJobDev> bj(nb);
+      std::vector<uint32_t> starts(2 * size_t(nb));
+      for (int b = 0; b < nb; ++b) {
+        bj[b] = bands[b].u;
+        starts[2 * b] = 0;
+        starts[2 * b + 1] = bands[b].blocks;
+      }
+      if (int e = d_jobs.ensure(bj.size() * sizeof(UnpackJobDev)))
+        return e;
+      if (int e = d_starts.ensure(starts.size() * sizeof(uint32_t)))
+        return e;
+      RSX_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs.ptr, bj.data(), bj.size() * sizeof(UnpackJobDev),
+                                        hipMemcpyHostToDevice, s));
+      RSX_HIP_CHECK(ctx, hipMemcpyAsync(d_starts.ptr, starts.data(),
+                                        starts.size() * sizeof(uint32_t),
+                                        hipMemcpyHostToDevice, s));
+      std::atomic<int> ready{0};
+      std::atomic<int> up_err{0};
+      uint8_t* d_in_base = static_cast<uint8_t*>(lane.lane->d_in.ptr);
+      hipStream_t s_up = lane.lane->stream_up;
+      const int device = ctx->device;
+      std::thread uploader([&]() {
+        if (hipSetDevice(device) != hipSuccess) {
+          up_err.store(1);
+          ready.store(nb);
+          return;
+        }
+        for (int b = 0; b < nb; ++b) {
+          hipError_t e = hipMemcpyAsync(d_in_base + bands[b].u.in_offset, bands[b].src,
+                                        size_t(bands[b].u.stream_bytes), hipMemcpyHostToDevice,
+                                        s_up);
+          if (e == hipSuccess)
+            e = hipEventRecord(lane.lane->ev_up[b], s_up);
+          if (e != hipSuccess)
+            up_err.store(1);
+          ready.store(b + 1);
+        }
+      });
+      hipError_t err = hipSuccess;
+      for (int b = 0; b < nb && err == hipSuccess; ++b) {
+        while (ready.load() <= b)
+          std::this_thread::yield();
+        if (up_err.load())
+          break;
+        err = hipStreamWaitEvent(s, lane.lane->ev_up[b], 0);
+        if (err == hipSuccess)
+          err = launch_unpack(bands[b].order, static_cast<UnpackJobDev*>(d_jobs.ptr) + b,
+                              static_cast<uint32_t*>(d_starts.ptr) + 2 * b, 1, bands[b].blocks,
+                              lane.lane->d_in.ptr, lane.lane->d_out.ptr, s);
+        if (err == hipSuccess)
+          err = hipMemcpy2DAsync(bands[b].dst, img->pitch_bytes,
+                                 static_cast<uint8_t*>(lane.lane->d_out.ptr) +
+                                     bands[b].u.out_offset,
+                                 bands[b].dev_pitch, bands[b].width_bytes, bands[b].u.n_rows,
+                                 hipMemcpyDeviceToHost, s);
+      }
+      uploader.join();
+      if (err == hipSuccess)
+        err = hipStreamSynchronize(s_up);
+      if (err == hipSuccess)
+        err = hipStreamSynchronize(s);
+      d_jobs.release();
+      d_starts.release();
+      if (err != hipSuccess || up_err.load()) {
+        set_error(ctx, std::string("unpack (banded): ") +
+                           (err != hipSuccess ? hipGetErrorString(err) : "upload failed"));
+        return RSX_ERR_DEVICE;
+      }
+      int rc = RSX_OK;
+      for (int i = 0; i < n; ++i) {
+        if (statuses)
+          statuses[i] = st[i];
+        if (st[i] != RSX_OK)
+          rc = st[i];
+      }
+      return rc;
+    }
+  }
+  if (int e = upload_all())
+    return e;
   for (int order = 0; order < 4; ++order) {
     auto& v = per_order[order];
     if (v.empty())

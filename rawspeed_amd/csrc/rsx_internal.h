@@ -188,6 +188,20 @@ struct rsx_ctx {
     // camera's files) skips the plan's construction -- tables, block lists, a dozen uploads
     struct rsx_plan* cached_plan = nullptr;
     std::vector<uint8_t> cached_key;
+    // upload stream + one event per band of the overlapped host path (rsx_api.hip, unpack_host)
+    hipStream_t stream_up = nullptr;
+    std::vector<hipEvent_t> ev_up;
+    bool ensure_overlap(int bands) {
+      if (!stream_up && hipStreamCreateWithFlags(&stream_up, hipStreamNonBlocking) != hipSuccess)
+        return false;
+      while (int(ev_up.size()) < bands) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+          return false;
+        ev_up.push_back(e);
+      }
+      return true;
+    }
   };
   static constexpr int RSX_MAX_LANES = 16;
   std::mutex lanes_mu;

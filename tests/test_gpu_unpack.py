@@ -398,3 +398,54 @@ def test_decode8bit_lookup(gpu, oracle):
     for j, want in zip(jobs, wants):
         assert np.array_equal(got[j.img_offset:j.img_offset + want.buf.size], want.buf)
     plan.close()
+
+
+@pytest.mark.parametrize("bps,order,crop", [(14, abi.ORDER_MSB, (0, 0)), (12, abi.ORDER_LSB, (16, 7)),
+                                            (16, abi.ORDER_LSB, (8, 3)), (10, abi.ORDER_MSB, (0, 5))])
+def test_host_pointer_call_in_bands(gpu, bps, order, crop, monkeypatch):
+    """Host pointers and a large input: rsx_unpack_u16 uploads, unpacks and downloads in row
+    bands (a helper thread uploads band k + 1 under the download of band k, rsx_api.hip
+    unpack_host).  Same pixels as the one-shot path and as the size-independent round trip
+    pack(v) -> unpack == v, with a crop offset, and nothing outside the rectangle touched."""
+    w, h = 6144, 3000
+    cx, cy = crop
+    px = synth.uniform(w * h, bps, 7).reshape(h, w)
+    packed = synth.pack_rows(px, bps, order)
+    pitch = w * bps // 8
+    assert packed.size >= 16 << 20
+    d = abi.UnpackDesc(cx, cy, w, h, pitch, bps, order)
+    img = HostImage(w + cx + 5, h + cy + 2)
+    assert gpu.unpack_u16(d, packed, img.view()) == 0
+    got = img.u16()
+    # (only the 16-bit little-endian copy honours the x offset; the packed walks start their
+    # rows at column 0, UncompressedDecompressor.cpp:196)
+    x0 = cx if (bps == 16 and order == abi.ORDER_LSB) else 0
+    assert np.array_equal(got[cy:cy + h, x0:x0 + w], px)
+    ref = HostImage(w + cx + 5, h + cy + 2)
+    monkeypatch.setenv("RSX_HOST_NO_OVERLAP", "1")
+    assert gpu.unpack_u16(d, packed, ref.view()) == 0
+    assert np.array_equal(img.buf, ref.buf)
+
+
+def test_host_pointer_tiles_in_bands(gpu, oracle):
+    """Several large tiles in one call (an uncompressed DNG through
+    AbstractDngDecompressor::decompressThread<1>): every tile is one or more bands; tiles of
+    different bit orders, a clipped right column of tiles."""
+    rng = np.random.default_rng(11)
+    W, H, tw, th = 6000, 4096, 2048, 2048
+    img, want = HostImage(W, H), HostImage(W, H)
+    descs, datas = [], []
+    for ty in range(2):
+        for tx in range(3):
+            bps, order = (12, abi.ORDER_MSB) if (tx + ty) % 2 == 0 else (16, abi.ORDER_LSB)
+            w = min(tw, W - tx * tw)
+            pitch = tw * bps // 8
+            data = rng.integers(0, 256, size=th * pitch, dtype=np.uint8)
+            d = abi.UnpackDesc(tx * tw, ty * th, w, th, pitch, bps, order)
+            descs.append(d)
+            datas.append(data)
+            assert oracle.unpack(d, data, want) == 0
+    assert sum(x.size for x in datas) >= 16 << 20
+    rc, st = gpu.dng_decompress_uncompressed(descs, datas, img.view())
+    assert rc == 0 and not any(st)
+    assert np.array_equal(img.u16(), want.u16())
