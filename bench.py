@@ -405,9 +405,11 @@ def ljpeg_summary(extra):
     }
     c4 = extra.get("cfg4_dng_tiles_8192x5464")
     if isinstance(c4, dict):
-        for k in ("overhang_8189x5462", "restart_intervals"):
+        for k in ("two_tables", "two_tables_256x256_tiles", "overhang_8189x5462",
+                  "restart_intervals"):
             if isinstance(c4.get(k), dict) and "ms_per_step" in c4[k]:
                 s["cfg4_" + k] = {"ms_per_step": c4[k]["ms_per_step"],
+                                  "mpix_per_s": c4[k].get("mpix_per_s"),
                                   "bit_exact": c4[k].get("bit_exact")}
     c5 = extra.get("cfg5_ljpeg_frames_batch")
     if isinstance(c5, dict) and s.get("cfg5_batch_8192x5464"):

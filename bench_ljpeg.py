@@ -495,6 +495,10 @@ def run_cfg4(ctx, torch, log, steps=10, warmup=2, cpu=True, variants=True):
             ctx, torch, 8192, 5464, 4096, 2732, 2, 0, steps, warmup,
             "8192x5464 as 2x2 tiles, a Huffman table of its own per component (DHT slots 0, 1)",
             False, two_tables=True)
+        res["two_tables_256x256_tiles"] = _cfg4_variant(
+            ctx, torch, 8192, 5464, 256, 256, 2, 0, steps, warmup,
+            "8192x5464 as 32x22 tiles of 256x256 (what Adobe's DNG converter writes), a Huffman "
+            "table of its own per component", False, two_tables=True)
         res["overhang_8189x5462"] = _cfg4_variant(
             ctx, torch, 8189, 5462, 4096, 2732, 3, 0, steps, warmup,
             "8189x5462 as 2x2 tiles of 4096x2732 (overhanging right/bottom tiles)", False)
@@ -1045,6 +1049,16 @@ if __name__ == "__main__":
                          indent=1))
     elif args.only == "host":
         print(json.dumps(run_host_path(torch, print), indent=1))
+    elif args.only == "cfg4small":
+        # what Adobe's DNG converter writes: 256 x 256 tiles, a table of its own per component
+        print(json.dumps(_cfg4_variant(
+            ctx, torch, 8192, 5464, 256, 256, 2, 0, args.steps, 2,
+            "8192x5464 as 32x22 tiles of 256x256, a Huffman table of its own per component", False,
+            two_tables=True), indent=1))
+    elif args.only == "cfg4small1":
+        print(json.dumps(_cfg4_variant(
+            ctx, torch, 8192, 5464, 256, 256, 2, 0, args.steps, 2,
+            "8192x5464 as 32x22 tiles of 256x256, one table", False), indent=1))
     elif args.only == "cfg4mt":
         print(json.dumps(_cfg4_variant(
             ctx, torch, 8192, 5464, 4096, 2732, 2, 0, args.steps, 2,

@@ -41,6 +41,8 @@ cp $REPO/bench_extra.json $OUT/ 2>/dev/null
 if [ -f $REPO/rawspeed_amd/variants/librsx_stats.so ]; then
   RSX_DEBUG=1 RSX_LIB=$REPO/rawspeed_amd/variants/librsx_stats.so \
     python $REPO/scripts/exp_lj_stats.py 2>&1 | grep "^\[rsx\]" | cut -c1-400 > $OUT/cfg3_phase_and_round_stats.txt
+  WHAT=cfg4mt RSX_DEBUG=1 RSX_LIB=$REPO/rawspeed_amd/variants/librsx_stats.so \
+    python $REPO/scripts/exp_lj_stats.py 2>&1 | grep "^\[rsx\]" | cut -c1-400 > $OUT/cfg4_two_tables_phase_and_round_stats.txt
 fi
 python $REPO/scripts/ljpeg_limiter.py $OUT > /dev/null 2>&1
 ls -la $OUT
