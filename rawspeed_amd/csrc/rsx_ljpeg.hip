@@ -1079,6 +1079,13 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       }
 #endif
     }
+#ifdef RSX_EXPERIMENT
+    // (per-slot record for the single-pass kernel's cross-check, scripts/exp_mt_why.py)
+    if (a.sub_sums && j >= 1)
+      a.sub_sums[S.first_subseq + lb * LJ_OWN + uint32_t(j - 1)] =
+          make_uint2(cnt | (constant ? 0x10000u : 0u) | (eb << 17),
+                     ebv | ((j >= 1 ? uint32_t(EB[j - 1]) : 0u) << 8) | (grid << 16));
+#endif
     // the LDS level of the single-pass launches: the symbols of this workgroup's slots
     // 1..255 (parsed from bit 0: an estimate) against what a level stages
     uint32_t c = j == 0 ? 0u : cnt;
@@ -1710,10 +1717,7 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
     const bool link_broken = i >= 1 && i < nb &&
                              a.block_start[fb + i] != a.block_exit[fb + i - 1] &&
                              !(a.block_exit[fb + i - 1] & ST_ERR);
-    if (link_broken && !fast_first)
-      unconv_s = 1;
-    if (i < nb && (a.block_flags[fb + i] & 1u) != 0)
-      unconv_s = 1; // a workgroup that gave up on its re-decode rounds
+
     // inclusive wave scans
     uint32_t x = v, dx = dv;
 #pragma unroll
@@ -1741,6 +1745,19 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
       a.block_base[fb + i] = excl;
       a.block_drop_base[fb + i] = dexcl;
     }
+    // A workgroup that is not settled -- its entry state is not its predecessor's exit, or
+    // it gave up on its re-decode rounds -- keeps the stream unconverged only if a
+    // DELIVERED symbol lies in or behind it.  (Found by the two-table fuzz of round 4: the
+    // zeros behind the end-of-image marker end in an error state under some tables; the
+    // workgroup behind that never runs again -- "chain broken by an error before this
+    // workgroup" --, its gave-up flag stayed, and the host iterated to its limit and
+    // reported a device error for a stream the reference decodes.  The counts in front of
+    // the first unsettled workgroup are final, so its `excl` is.)
+    const bool matters = uint64_t(excl) < S.needed;
+    if (link_broken && !fast_first && matters)
+      unconv_s = 1;
+    if (i < nb && (a.block_flags[fb + i] & 1u) != 0 && matters)
+      unconv_s = 1; // a workgroup that gave up on its re-decode rounds
     // The single-pass kernel took the index of a workgroup's first symbol from K0's counts
     // (+ the corrections of the workgroups K0 had flagged).  Here are the counts of its own
     // decodes: a workgroup that delivered symbols from another base than their sum has put
@@ -1755,9 +1772,11 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
       unconv_s = 1;
 #ifdef RSX_EXPERIMENT
       if (atomicMin(&dbg_first_s, i) > i) { // (statistics: the first workgroup off its base)
-        a.results[s].pad3[0] = 0x40000000u | i;
-        a.results[s].pad3[1] = a.block_base0[fb + i];
-        a.results[s].pad3[2] = excl;
+        if (a.results[s].pad3[0] == 0u) {
+          a.results[s].pad3[0] = 0x40000000u | i;
+          a.results[s].pad3[1] = a.block_base0[fb + i];
+          a.results[s].pad3[2] = excl;
+        }
       }
 #endif
     }
@@ -3785,7 +3804,10 @@ int converge(LJpegPlan* p, hipStream_t s) {
   uint32_t rounds = 0;
   // (a stitch launch settles at least LJ_STITCH_MAX_ROUNDS slots of a workgroup that
   // is still chaining, and at least one more workgroup of a chain of workgroups)
-  while (unconverged() && rounds <= 9 * p->total_blocks + 16) {
+#ifndef RSX_STITCH_BOUND_X
+#define RSX_STITCH_BOUND_X 1
+#endif
+  while (unconverged() && rounds <= RSX_STITCH_BOUND_X * (9 * p->total_blocks + 16)) {
     for (int k = 0; k < 4; ++k)
       launch_sync<true>(p, a, s);
     rounds += 4;

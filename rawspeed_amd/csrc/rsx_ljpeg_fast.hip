@@ -1693,6 +1693,17 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // 9. copy-out
   if (fits && any_out && !(LF_ABLATE & 3u))
     lf_copy_out2<N>(F, a, S, base, lim, sb, r0, j, walk0);
+#ifdef RSX_EXPERIMENT
+  // K0's count of the slot against this kernel's (the first slot of the stream that differs)
+  if (j >= 1 && a.sub_sums && own_bits != 0u) {
+    const uint2 k = a.sub_sums[gsub];
+    if ((k.x & 0xFFFFu) != rec_cn(my_rec_final) &&
+        atomicCAS(&a.results[s].pad3[0], 0u, 0x08000000u | (lb << 8) | uint32_t(j)) == 0u) {
+      a.results[s].pad3[1] = k.x;
+      a.results[s].pad3[2] = k.y | (rec_cn(my_rec_final) << 24);
+    }
+  }
+#endif
   // records the per-stream bookkeeping kernels read (lj_scan_kernel, lj_consumed_kernel)
   if (j >= 1)
     a.sub_state[gsub] = rec_st(my_rec_final) | (rec_cn(my_rec_final) << 16);

@@ -189,3 +189,121 @@ def test_many_workgroups_and_tiles_with_two_tables(gpu, oracle):
     names = _kernel_names(plan, inp, out)
     assert any("lj_fast_kernel" in x for x in names), names
     assert not any("sync" in x for x in names), names
+
+
+# a second code whose longest word has 10 bits (15 categories, 14-bit data)
+SHORT = ([0, 2, 2, 2, 2, 1, 1, 1, 1, 3, 0, 0, 0, 0, 0, 0],
+         [6, 7, 5, 8, 4, 9, 3, 10, 2, 11, 1, 12, 0, 13, 14])
+
+
+@pytest.mark.parametrize("n_comp,slices", [(2, (3, 1344, 1408)), (4, (2, 2048, 2048))])
+def test_cr2_with_two_tables(gpu, oracle, n_comp, slices):
+    """Cr2Decompressor <N,1,1> whose components take DHT slots 0, 1 (, 0, 1): the strips'
+    copy-out behind the two-table decode.  (Codes of at most 10 bits: where a strip row
+    ends the stream jumps across the image, the differences there are large, and a table
+    that gives the large categories codes the 10-bit LUTs do not hold stops a lane at every
+    such jump -- more of them than a workgroup has re-decode entries, and the stream goes
+    through the multi-kernel pipeline: the next test.)"""
+    from oracle_lib import HostImage
+    rng = np.random.default_rng(31 + n_comp)
+    W = (slices[0] - 1) * slices[1] + slices[2]
+    H = 900
+    d, data, img, scan_len = C.make_cr2_case(rng, W, H, n_comp, slices, tables=(C.NIKON, SHORT),
+                                             table_index=[0, 1] * (n_comp // 2))
+    want, got = HostImage(W, H), HostImage(W, H)
+    st_o, cons_o = oracle.cr2(d, data, want)
+    assert st_o == 0 and np.array_equal(want.pixels(), img)
+    st, cons = gpu.cr2_decode(d, data, got.view())
+    assert (st, cons) == (st_o, cons_o)
+    assert np.array_equal(got.u16(), want.u16())
+    # the route, through a plan
+    j = abi.Cr2Job()
+    j.desc = d
+    j.in_offset, j.in_bytes, j.img_offset = 0, data.size, 0
+    import bench_ljpeg as B
+    op = B.out_pitch(W)
+    j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = op, W, H, 1, 1
+    plan = gpu.cr2_plan([j])
+    inp = torch.from_numpy(np.ascontiguousarray(data)).cuda()
+    out = torch.zeros(op * H, dtype=torch.uint8, device="cuda")
+    plan.run(inp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    rc, st2, cons2 = plan.results()
+    assert rc == 0 and not any(st2) and list(cons2) == [cons_o]
+    px = out.cpu().numpy().view(np.uint16).reshape(H, op // 2)[:, :W]
+    assert np.array_equal(px, img)
+    names = _kernel_names(plan, inp, out)
+    assert any("lj_fast_kernel" in x for x in names), names
+    assert not any("sync" in x for x in names), names
+
+
+def test_cr2_two_tables_long_codes_at_every_strip_row(gpu, oracle):
+    """The same with a table whose large categories have codes of 11-16 bits: whatever the
+    route, the reference's pixels."""
+    from oracle_lib import HostImage
+    rng = np.random.default_rng(33)
+    slices = (3, 1344, 1408)
+    W, H = 2 * 1344 + 1408, 600
+    d, data, img, scan_len = C.make_cr2_case(rng, W, H, 2, slices, tables=(C.NIKON, C.ALT),
+                                             table_index=[0, 1])
+    want, got = HostImage(W, H), HostImage(W, H)
+    st_o, cons_o = oracle.cr2(d, data, want)
+    assert st_o == 0
+    assert gpu.cr2_decode(d, data, got.view()) == (st_o, cons_o)
+    assert np.array_equal(got.u16(), want.u16())
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_two_tables(gpu, oracle, seed):
+    """Differential fuzzing of the two-table instantiation: images stitched from noise,
+    constant and clipped stretches, ramps and short periods (test_gpu_fast_fuzz's), two random
+    canonical tables (long codes, SSSS = 16 with 16-bit data), 2 or 4 components, tiles
+    narrower than their frames, bytes behind the end-of-image marker, several streams a call.
+    Whatever route a stream takes, status, consumed bytes and pixels are the oracle's."""
+    from oracle_lib import HostImage
+    from test_gpu_fast_fuzz import banded_image
+    rng = np.random.default_rng([3031, seed])
+    n = int(rng.choice([2, 2, 4]))
+    prec = int(rng.choice([12, 14, 14, 16]))
+    n_cat = 17 if prec == 16 else prec + 1
+    ta = C.random_huffman_table(rng, n_cat, skew=float(rng.uniform(0.4, 2.5)))
+    tb = C.random_huffman_table(rng, n_cat, skew=float(rng.uniform(0.4, 2.5)))
+    k = int(rng.integers(1, 4))
+    tiles, x = [], 0
+    H = int(rng.integers(120, 500))
+    for _ in range(k):
+        tw = n * int(rng.integers(40, 1400 // n))
+        tiles.append((x, tw))
+        x += tw
+    W = x + int(rng.integers(0, 9))
+    img, want = HostImage(W, H), HostImage(W, H)
+    descs, datas, pxs = [], [], []
+    for tx, tw in tiles:
+        th = H - int(rng.integers(0, 3))
+        px = banded_image(rng, th, tw, prec)
+        fw = (tw + n - 1) // n + int(rng.integers(0, 3))
+        rows = C.ljpeg_stream_rows(px, n, 1, fw, th, rng, prec)
+        init = [1 << (prec - 1)] * n
+        order = [0, 1] if rng.integers(0, 2) else [1, 0]
+        idx = order * (n // 2)
+        scan, _ = synth.ljpeg_encode_scan(rows, n, init, [(ta, tb)[i] for i in idx], 0, False)
+        d = abi.LJpegDesc()
+        d.tile_x, d.tile_y, d.tile_w, d.tile_h = tx, 0, tw, th
+        d.mcu_w, d.mcu_h, d.frame_w, d.frame_h = n, 1, fw, th
+        d.n_comp, d.rows_per_restart_interval = n, th
+        abi.fill_recipe(d, synth.huff_tables(ta, tb), idx, init)
+        tail = int(rng.integers(0, 3))
+        extra = {0: np.zeros(16, np.uint8), 1: np.zeros(int(rng.integers(16, 40000)), np.uint8),
+                 2: rng.integers(0, 256, int(rng.integers(16, 40000)), dtype=np.uint8)}[tail]
+        descs.append(d)
+        datas.append(np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), extra]))
+        pxs.append(px)
+    so = [oracle.ljpeg(d, data, want) for d, data in zip(descs, datas)]
+    rc, st, cons = gpu.dng_decompress_ljpeg(descs, datas, img.view())
+    for i in range(k):
+        assert st[i] == so[i][0], (i, st, so)
+        if so[i][0] == 0:
+            assert cons[i] == so[i][1], (i, cons, so)
+    if all(s[0] == 0 for s in so):
+        assert np.array_equal(img.u16(), want.u16())
+        for (tx, tw), px in zip(tiles, pxs):
+            assert np.array_equal(img.pixels()[:px.shape[0], tx:tx + tw], px)
