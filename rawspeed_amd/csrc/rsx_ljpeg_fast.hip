@@ -69,7 +69,10 @@ namespace {
 constexpr int LF_BW = LJ_PW + 1;        // dword rows of a subsequence the loops can touch
 constexpr int LF_MAXSYM = 128;          // symbols a lane keeps (64 VGPRs)
 constexpr int LF_NR = LF_MAXSYM / 2;
-constexpr int LF_NSIDE = 16;            // side-buffer entries (re-decodes per chunk)
+constexpr int LF_NSIDE = 24;            // side-buffer entries (re-decodes per workgroup): what the
+                                        // 40 KB of four workgroups a CU leave (16 until round 4: a CR2
+                                        // whose table gives large differences long codes stops a lane at
+                                        // every strip-row jump, ~12 a workgroup)
 constexpr int LF_SIDE_STRIDE = 272;     // bytes: 128 x u16 + 16 (16-byte aligned rows)
 constexpr int LF_RMAX = 256;            // stream rows that may start inside one workgroup
 constexpr uint32_t LF_MAX_ROUNDS = 6;   // re-decode rounds before the stream is given up
