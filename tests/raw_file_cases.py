@@ -8,7 +8,7 @@ import cases as C
 import rawfiles
 
 
-def _tiles(src, tw, th, pad=1000, **kw):
+def _tiles(src, tw, th, pad=1000, slots=(0, 0), tables=(C.NIKON,), **kw):
     H, W = src.shape
     blobs = []
     for ty in range((H + th - 1) // th):
@@ -16,7 +16,7 @@ def _tiles(src, tw, th, pad=1000, **kw):
             tile = np.full((th, tw), pad, np.uint16)
             part = src[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw]
             tile[:part.shape[0], :part.shape[1]] = part
-            blob, _, _, _ = synth.ljpeg_container(tile, 2, 14, [0, 0], [C.NIKON], **kw)
+            blob, _, _, _ = synth.ljpeg_container(tile, 2, 14, list(slots), list(tables), **kw)
             blobs.append(blob)
     return blobs
 
@@ -28,6 +28,15 @@ def dng_ljpeg_tiles():
     W, H, tw, th = 1021, 700, 512, 256
     src = C.smooth_image(rng, H, W)
     return rawfiles.dng_file(W, H, tw, th, _tiles(src, tw, th)), src
+
+
+def dng_ljpeg_tiles_two_tables():
+    """What DNG writers emit: a Huffman table of its own per component (DHT slots 0 and 1)."""
+    rng = np.random.default_rng(511)
+    W, H, tw, th = 1021, 700, 512, 256
+    src = C.smooth_image(rng, H, W)
+    return rawfiles.dng_file(W, H, tw, th, _tiles(src, tw, th, slots=(0, 1),
+                                                  tables=(C.NIKON, C.ALT))), src
 
 
 def dng_ljpeg_tiles_dri():
@@ -222,7 +231,7 @@ def srw_samsung_v2():
 UNCORRECTED = {"nef_compressed_uncorrected"}
 
 CASES = {f.__name__: f for f in (
-    dng_ljpeg_tiles, dng_ljpeg_tiles_dri, dng_ljpeg_strips, dng_uncompressed_12bit_strips,
+    dng_ljpeg_tiles, dng_ljpeg_tiles_two_tables, dng_ljpeg_tiles_dri, dng_ljpeg_strips, dng_uncompressed_12bit_strips,
     dng_uncompressed_16bit_tiles, arw_ljpeg_tiles, arw_uncompressed, arw1_compressed,
     cr2_three_slices, pef_compressed, nef_compressed_uncorrected, nef_compressed_curve,
     threefr_ljpeg, srw_samsung_v1, cr2_sraw_2x1, cr2_sraw_2x2, srw_samsung_v2)}

@@ -25,6 +25,7 @@ pytestmark = pytest.mark.gpu
 # units of work the device must have decoded (tiles / strips / scans) and host calls
 EXPECT = {
     "dng_ljpeg_tiles": (6, 1),
+    "dng_ljpeg_tiles_two_tables": (6, 1),
     "dng_ljpeg_tiles_dri": (4, 1),
     "dng_ljpeg_strips": (3, 1),
     "dng_uncompressed_12bit_strips": (3, 1),
