@@ -307,3 +307,93 @@ def test_fuzz_two_tables(gpu, oracle, seed):
         assert np.array_equal(img.u16(), want.u16())
         for (tx, tw), px in zip(tiles, pxs):
             assert np.array_equal(img.pixels()[:px.shape[0], tx:tx + tw], px)
+
+
+def _tile_job(d, data, off, W, H, op):
+    j = abi.LJpegJob()
+    j.desc = d
+    j.in_offset, j.in_bytes, j.img_offset = off, data.size, 0
+    j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = op, W, H, 1, 1
+    return j
+
+
+def test_mixed_plan_one_table_two_tables_and_a_pipeline_stream(gpu, oracle):
+    """One plan, three kinds of streams side by side: a one-table tile, a two-table tile (K0's
+    two-table instantiation and its hand-over then serve the one-table stream as well) and a
+    3-component tile, which the multi-kernel pipeline decodes."""
+    import bench_ljpeg as B
+    from oracle_lib import HostImage
+    rng = np.random.default_rng(12)
+    TW, TH = 1536, 640
+    W, H = 3 * TW, TH
+    op = B.out_pitch(W)
+    want = HostImage(W, H)
+    cases = [
+        dict(mcu=(2, 1), tables=(C.NIKON,), table_index=[0, 0]),
+        dict(mcu=(2, 1), tables=(C.NIKON, C.ALT), table_index=[0, 1]),
+        dict(mcu=(3, 1), tables=(C.NIKON, C.ALT), table_index=[0, 1, 0]),
+    ]
+    jobs, blobs, off = [], [], 0
+    for k, kw in enumerate(cases):
+        d, data, _, _ = C.make_ljpeg_case(rng, img_w=W, img_h=H, cpp=1, tile=(k * TW, 0, TW, TH), **kw)
+        assert oracle.ljpeg(d, data, want)[0] == 0
+        jobs.append(_tile_job(d, data, off, W, H, op))
+        pad = (-data.size) % 16
+        blobs.append(np.concatenate([data, np.zeros(pad, np.uint8)]))
+        off += data.size + pad
+    plan = gpu.ljpeg_plan(jobs)
+    inp = torch.from_numpy(np.concatenate(blobs)).cuda()
+    out = torch.zeros(op * H, dtype=torch.uint8, device="cuda")
+    for _ in range(3):
+        out.zero_()
+        plan.run(inp.data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        rc, st, cons = plan.results()
+        assert rc == 0 and not any(st)
+        px = out.cpu().numpy().view(np.uint16).reshape(H, op // 2)[:, :W]
+        assert np.array_equal(px, want.pixels())
+    names = _kernel_names(plan, inp, out)
+    assert any("lj_fast_kernel" in x for x in names) and any("sync" in x for x in names), names
+
+
+def test_plan_reused_with_other_data(gpu, oracle):
+    """The same plan over different inputs in turn (A, B, A, B, B): what K0's workgroups hand
+    one another -- entry states tagged with the run's parity -- and what the single-pass
+    kernel's workgroups leave for their successors is all per run."""
+    import bench_ljpeg as B
+    from oracle_lib import HostImage
+    W, H = 3072, 1024
+    op = B.out_pitch(W)
+    made = []
+    for seed in (21, 22):
+        rng = np.random.default_rng(seed)
+        tile_px = C.smooth_image(rng, H, W, 14, sigma=30.0 if seed == 21 else 6.0)
+        rows = C.ljpeg_stream_rows(tile_px, 2, 1, W // 2, H, rng, 14)
+        scan, _ = synth.ljpeg_encode_scan(rows, 2, [1 << 13] * 2, [C.NIKON, C.ALT])
+        made.append((tile_px, scan))
+    # (one descriptor for both: the inputs are padded to the same length)
+    n = max(len(s) for _, s in made) + 2 + 4096
+    datas = []
+    for _, scan in made:
+        data = np.zeros(n, np.uint8)
+        data[:len(scan)] = scan
+        data[len(scan):len(scan) + 2] = (0xFF, 0xD9)
+        datas.append(data)
+    rng = np.random.default_rng(5)
+    d, _, _, _ = C.make_ljpeg_case(rng, img_w=W, img_h=H, cpp=1, tile=(0, 0, W, H), mcu=(2, 1),
+                                   tables=(C.NIKON, C.ALT), table_index=[0, 1])
+    wants = []
+    for data in datas:
+        w = HostImage(W, H)
+        assert oracle.ljpeg(d, data, w)[0] == 0
+        wants.append(w.pixels().copy())
+    assert np.array_equal(wants[0], made[0][0]) and np.array_equal(wants[1], made[1][0])
+    plan = gpu.ljpeg_plan([_tile_job(d, datas[0], 0, W, H, op)])
+    ins = [torch.from_numpy(x).cuda() for x in datas]
+    out = torch.zeros(op * H, dtype=torch.uint8, device="cuda")
+    for k in (0, 1, 0, 1, 1):
+        out.zero_()
+        plan.run(ins[k].data_ptr(), out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        rc, st, cons = plan.results()
+        assert rc == 0 and not any(st)
+        px = out.cpu().numpy().view(np.uint16).reshape(H, op // 2)[:, :W]
+        assert np.array_equal(px, wants[k]), k
