@@ -231,6 +231,9 @@ extern "C" int rsx_ctx_create(int device, rsx_ctx** out_ctx) {
     return RSX_ERR_DEVICE;
   auto* ctx = new rsx_ctx();
   ctx->device = device;
+  // (read once per context, not per call: RSX_HOST_NO_OVERLAP=1 keeps large host-pointer
+  // calls of the unpack family in one piece -- what the tests compare the banded path with)
+  ctx->host_overlap = getenv("RSX_HOST_NO_OVERLAP") == nullptr;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
     delete ctx;
     return RSX_ERR_DEVICE;
@@ -902,7 +905,7 @@ int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
     for (int i = 0; i < n; ++i)
       if (st[i] == RSX_OK && rects[i].rows != 0)
         in_used_total += size_t(rects[i].rows) * size_t(descs[i].input_pitch_bytes);
-    if (in_used_total >= OVERLAP_MIN && !getenv("RSX_HOST_NO_OVERLAP")) {
+    if (in_used_total >= OVERLAP_MIN && ctx->host_overlap) {
       size_t k_of_order[4] = {0, 0, 0, 0};
       for (int i = 0; i < n; ++i) {
         if (st[i] != RSX_OK || rects[i].rows == 0)

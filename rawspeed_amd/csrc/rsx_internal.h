@@ -177,6 +177,7 @@ struct rsx_ctx {
   std::mutex err_mu;
   std::string last_error;
   std::atomic<uint64_t> host_calls{0}; // host-pointer entry points served
+  bool host_overlap = true;            // large unpack-family host calls run in row bands
   // Staging of one host-pointer call: device buffers + a stream.  Lanes are pooled, so
   // calls from different threads (rstest-style file loops, DNG tile threads of an
   // unbatched build) stage and decode side by side instead of queueing on one mutex.
