@@ -2650,6 +2650,18 @@ __global__ __launch_bounds__(64) void lj_consumed_kernel(LjArgs a) {
 // the scan is a marker; interval i+1 starts 2 bytes after the i-th one.  This
 // kernel lists them (unordered; the host sorts the handful of entries).
 // ---------------------------------------------------------------------------
+// the results of a run, before it: marker_pos = 0xFFFFFFFF (an atomicMin target), everything else 0
+__global__ __launch_bounds__(256) void lj_init_results_kernel(LjResult* results, uint32_t n) {
+  static_assert(sizeof(LjResult) % 4 == 0, "dwords");
+  constexpr uint32_t DW = uint32_t(sizeof(LjResult) / 4);
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n * DW)
+    return;
+  const uint32_t k = i / DW, f = i - k * DW;
+  reinterpret_cast<uint32_t*>(results + k)[f] =
+      f == uint32_t(offsetof(LjResult, marker_pos) / 4) ? 0xFFFFFFFFu : 0u;
+}
+
 __global__ __launch_bounds__(256) void lj_marker_scan_kernel(
     const uint8_t* __restrict__ in, uint64_t bytes, uint32_t* count, uint2* list,
     uint32_t cap) {
@@ -3630,10 +3642,18 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
     std::memset(&r, 0, sizeof r);
     r.marker_pos = 0xFFFFFFFFu;
   }
+  // (on the device: a copy of a few hundred bytes from pageable memory in front of every run
+  // costs the stream more than a kernel of one wavefront)
+  const uint32_t n_streams = uint32_t(p->streams.size());
+#ifdef RSX_RESULTS_BY_COPY
   RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->d_results.ptr, p->h_results.data(),
                                     p->h_results.size() * sizeof(LjResult),
                                     hipMemcpyHostToDevice, s));
-  const uint32_t n_streams = uint32_t(p->streams.size());
+#else
+  hipLaunchKernelGGL(lj_init_results_kernel, dim3((n_streams * uint32_t(sizeof(LjResult) / 4) + 255) / 256),
+                     dim3(256), 0, s, static_cast<LjResult*>(p->d_results.ptr), n_streams);
+  mark(p, "lj_init_results_kernel");
+#endif
   if (p->any_fast_mt)
     hipLaunchKernelGGL(lj_unstuff_kernel<true>, dim3(p->total_blocks), dim3(LJ_T), LJ_K0_LDS_MT,
                        s, a);
