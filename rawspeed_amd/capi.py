@@ -155,6 +155,12 @@ class Context:
             lib().rsx_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
+    def host_calls(self):
+        """host-pointer entry points this context has served (rsx_ctx_host_calls)"""
+        f = lib().rsx_ctx_host_calls
+        f.restype = C.c_uint64
+        return int(f(self._h))
+
     def __del__(self):
         try:
             self.close()

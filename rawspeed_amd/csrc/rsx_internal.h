@@ -178,6 +178,7 @@ struct rsx_ctx {
   std::string last_error;
   std::atomic<uint64_t> host_calls{0}; // host-pointer entry points served
   bool host_overlap = true;            // large unpack-family host calls run in row bands
+  std::mutex upload_mu, download_mu;   // LJPEG-family host calls: one copy per direction at a time
   // Staging of one host-pointer call: device buffers + a stream.  Lanes are pooled, so
   // calls from different threads (rstest-style file loops, DNG tile threads of an
   // unbatched build) stage and decode side by side instead of queueing on one mutex.
@@ -209,7 +210,7 @@ struct rsx_ctx {
   std::condition_variable lanes_cv;
   std::vector<std::unique_ptr<HostLane>> lanes_all;
   std::vector<HostLane*> lanes_free;
-  HostLane* acquire_lane();
+  HostLane* acquire_lane(const std::vector<uint8_t>* want_key = nullptr);
   void release_lane(HostLane* l);
 };
 

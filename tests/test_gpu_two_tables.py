@@ -397,3 +397,54 @@ def test_plan_reused_with_other_data(gpu, oracle):
         assert rc == 0 and not any(st)
         px = out.cpu().numpy().view(np.uint16).reshape(H, op // 2)[:, :W]
         assert np.array_equal(px, wants[k]), k
+
+
+def test_host_pointer_dng_call_in_bands_of_tile_rows(gpu, oracle, monkeypatch):
+    """A large rsx_dng_decompress_ljpeg call (host pointers, >= 8 MB of tiles) runs as up to
+    four bands of tile rows on helper threads, taking turns on each direction of the link
+    (rsx_api.hip).  Same statuses, consumed bytes and pixels as the call in one piece -- with
+    one damaged tile in the third row, whose status must come back in ITS slot -- and the
+    context counts ONE host call."""
+    from oracle_lib import HostImage
+    from rawspeed_amd import capi
+    rng = np.random.default_rng(77)
+    TW, TH, NX, NY = 2048, 1024, 2, 4
+    W, H = TW * NX, TH * NY
+    descs, datas = [], []
+    want = HostImage(W, H)
+    for ty in range(NY):
+        for tx in range(NX):
+            two = (tx + ty) % 2 == 0
+            d, data, _, scan_len = C.make_ljpeg_case(
+                rng, img_w=W, img_h=H, cpp=1, tile=(tx * TW, ty * TH, TW, TH), mcu=(2, 1),
+                tables=(C.NIKON, C.ALT) if two else (C.NIKON,),
+                table_index=[0, 1] if two else [0, 0], sigma=60.0)
+            if (tx, ty) == (1, 2):       # cut short: the symbols run out of data
+                data = np.concatenate([data[:scan_len // 3], np.zeros(64, np.uint8)])
+            descs.append(d)
+            datas.append(data)
+    assert sum(x.size for x in datas) >= 8 << 20
+    so = [oracle.ljpeg(d, data, want) for d, data in zip(descs, datas)]
+    assert so[5][0] != 0 and all(s[0] == 0 for i, s in enumerate(so) if i != 5)
+    calls0 = gpu.host_calls() if hasattr(gpu, "host_calls") else None
+    img = HostImage(W, H)
+    rc, st, cons = gpu.dng_decompress_ljpeg(descs, datas, img.view())
+    assert rc == abi.RSX_ERR_TILE_ERRORS
+    assert list(st) == [s[0] for s in so]
+    assert all(c == s[1] for c, s in zip(cons, so) if s[0] == 0)
+    if calls0 is not None:
+        assert gpu.host_calls() == calls0 + 1
+    # every good tile's rectangle is the oracle's
+    for i, d in enumerate(descs):
+        if so[i][0] == 0:
+            y, x = d.tile_y, d.tile_x
+            assert np.array_equal(img.pixels()[y:y + TH, x:x + TW], want.pixels()[y:y + TH, x:x + TW])
+    monkeypatch.setenv("RSX_HOST_NO_OVERLAP", "1")
+    one_piece = capi.Context(0)
+    ref = HostImage(W, H)
+    rc2, st2, cons2 = one_piece.dng_decompress_ljpeg(descs, datas, ref.view())
+    assert (rc2, list(st2)) == (rc, list(st))
+    for i, d in enumerate(descs):
+        if so[i][0] == 0:
+            y, x = d.tile_y, d.tile_x
+            assert np.array_equal(img.pixels()[y:y + TH, x:x + TW], ref.pixels()[y:y + TH, x:x + TW])
