@@ -966,7 +966,7 @@ int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
       uint8_t* d_in_base = static_cast<uint8_t*>(lane.lane->d_in.ptr);
       hipStream_t s_up = lane.lane->stream_up;
       const int device = ctx->device;
-      std::thread uploader([&]() {
+      auto upload_bands = [&]() {
         if (hipSetDevice(device) != hipSuccess) {
           up_err.store(1);
           ready.store(nb);
@@ -982,7 +982,13 @@ int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
             up_err.store(1);
           ready.store(b + 1);
         }
-      });
+      };
+      std::thread uploader;
+      try {
+        uploader = std::thread(upload_bands);
+      } catch (...) { // (no thread to be had: the uploads first, then the rest)
+        upload_bands();
+      }
       hipError_t err = hipSuccess;
       for (int b = 0; b < nb && err == hipSuccess; ++b) {
         while (ready.load() <= b)
@@ -1001,7 +1007,8 @@ int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
                                  bands[b].dev_pitch, bands[b].width_bytes, bands[b].u.n_rows,
                                  hipMemcpyDeviceToHost, s);
       }
-      uploader.join();
+      if (uploader.joinable())
+        uploader.join();
       if (err == hipSuccess)
         err = hipStreamSynchronize(s_up);
       if (err == hipSuccess)
@@ -2134,9 +2141,17 @@ extern "C" int rsx_dng_decompress_ljpeg(rsx_ctx* ctx, int n_tiles,
                                   rsx_ljpeg_plan_create, bd.st.data(), bd.cons.data(), count);
       };
       std::vector<std::thread> helpers;
-      for (int k = 1; k < n_bands; ++k)
-        helpers.emplace_back([&, k]() { run_band(bands[k], false); });
+      std::vector<int> inline_bands; // (no thread to be had: in turn, on this one)
+      for (int k = 1; k < n_bands; ++k) {
+        try {
+          helpers.emplace_back([&, k]() { run_band(bands[k], false); });
+        } catch (...) {
+          inline_bands.push_back(k);
+        }
+      }
       run_band(bands[0], true);
+      for (int k : inline_bands)
+        run_band(bands[k], false);
       for (std::thread& t : helpers)
         t.join();
       for (const Band& bd : bands) {
