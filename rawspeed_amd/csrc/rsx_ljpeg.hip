@@ -1029,6 +1029,13 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       return false;
     };
     bool settled = run_rounds();
+#ifndef RSX_K0_NO_FINAL_HANDOVER
+    // (the hand-over once more, now that the rounds have run: marked final)
+    if (K0_CHAIN && j == LJ_T - 1 && lb + 1 < S.n_blocks)
+      __hip_atomic_store(&a.k0e[b + 1],
+                         0xA000u | (a.run_parity << 14) | (uint32_t(EB[LJ_T - 1]) & smask),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     if (K0_CHAIN) {
       // the hand-over: the predecessor's word (asked for before the rounds; once more if it
       // was not out yet -- it is by now as a rule: the predecessor started earlier)
@@ -1041,6 +1048,18 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
             __builtin_amdgcn_s_sleep(1);
             v = __hip_atomic_load(&a.k0e[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+#ifndef RSX_K0_NO_FINAL_HANDOVER
+          // (the predecessor's word from behind ITS rounds, if it comes within a few polls:
+          // in 1.3 % of the workgroups the rounds move the last slot's exit, and a workgroup
+          // that started from the older state is a slow one in the single-pass kernel)
+          for (uint32_t spins = 0; spins < 64u && (v & 0xE000u) != (tag | 0x2000u); ++spins) {
+            const uint32_t w = __hip_atomic_load(&a.k0e[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((w & 0xC000u) == tag)
+              v = w;
+            if ((v & 0xE000u) != (tag | 0x2000u))
+              __builtin_amdgcn_s_sleep(1);
+          }
+#endif
           if ((v & 0xC000u) == tag && (v & smask) != uint32_t(EB[0])) {
             EB[0] = uint16_t(v & smask);
             nlist[3] = 1u;
@@ -1112,7 +1131,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
         *reinterpret_cast<uint16_t*>(w + 8 + 6) = uint16_t(0x8000u | (ebv & 0x7Fu));
     }
     if (K0_CHAIN && j == LJ_T - 1 && lb + 1 < S.n_blocks)
-      __hip_atomic_store(&a.k0e[b + 1], 0x8000u | (a.run_parity << 14) | (ebv & smask),
+      __hip_atomic_store(&a.k0e[b + 1], 0xA000u | (a.run_parity << 14) | (ebv & smask),
                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (j == 0) {
       const uint32_t need = *est + (*est >> 6) + 64u;
