@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
           // (the predecessor's word from behind ITS rounds, if it comes within a few polls:
           // in 1.3 % of the workgroups the rounds move the last slot's exit, and a workgroup
           // that started from the older state is a slow one in the single-pass kernel)
-          for (uint32_t spins = 0; spins < 64u && (v & 0xE000u) != (tag | 0x2000u); ++spins) {
+          for (uint32_t spins = 0; spins < 16u && (v & 0xE000u) != (tag | 0x2000u); ++spins) {
             const uint32_t w = __hip_atomic_load(&a.k0e[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((w & 0xC000u) == tag)
               v = w;
