@@ -1154,6 +1154,8 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   }
 }
 
+#undef K0_CHAIN
+
 // inclusive scan of x over the wavefront
 __device__ __forceinline__ uint32_t lj_wave_scan(uint32_t x, int lane) {
 #pragma unroll
