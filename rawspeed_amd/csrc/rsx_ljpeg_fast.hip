@@ -357,20 +357,34 @@ __device__ __forceinline__ void lf_groups(FastState& s, uint32_t vbase, uint32_t
 // cover are rare, and the 2.3 KB of LDS the table took (plus the four dependent
 // load-store rounds that staged it) are not.
 __device__ __forceinline__ uint32_t lf_slow_entry(uint32_t w, const TabLds& tb) {
+  // (every load that does not depend on another one asked for at once: the table lies in
+  // global memory, and as a loop over the lengths -- look up, compare, next -- a 13-bit code
+  // was five dependent round trips, 3-4 us of the lane that re-decodes for a whole workgroup)
   uint32_t r = lj_lut16(tb, w >> (32 - LUT_BITS));
+  constexpr int NL = 16 - LUT_BITS;
+  uint32_t mc[NL], vo[NL];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    mc[k] = tb.max_code[LUT_BITS + 1 + k];
+    vo[k] = tb.val_offset[LUT_BITS + 1 + k];
+  }
+  const uint32_t max_len = tb.max_len, fix16 = tb.fix16;
   if ((r & 31u) != 0u)
     return r;
-  r = 0;
-  for (uint32_t l = LUT_BITS + 1; l <= tb.max_len && r == 0u; ++l) {
-    const uint32_t c = w >> (32 - l);
-    const uint32_t mc = tb.max_code[l];
-    if (mc != NO_CODE && c <= mc) {
-      const uint32_t ssss = tb.values[(c - tb.val_offset[l]) & 0xFFFFu];
-      const uint32_t extra = ssss == 16u ? (tb.fix16 ? 16u : 0u) : ssss;
-      r = l | (ssss << 5) | ((l + extra) << 10);
+  uint32_t len = 0, idx = 0;
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const uint32_t l = uint32_t(LUT_BITS + 1 + k), c = w >> (32 - l);
+    if (len == 0u && l <= max_len && mc[k] != NO_CODE && c <= mc[k]) {
+      len = l;
+      idx = (c - vo[k]) & 0xFFFFu;
     }
   }
-  return r;
+  if (len == 0u)
+    return 0u;
+  const uint32_t ssss = tb.values[idx];
+  const uint32_t extra = ssss == 16u ? (fix16 ? 16u : 0u) : ssss;
+  return len | (ssss << 5) | ((len + extra) << 10);
 }
 
 // Re-decode of a slot from a known entry state: the lean step of the fast loop for the
