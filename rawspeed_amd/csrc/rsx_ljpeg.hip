@@ -634,7 +634,12 @@ constexpr uint32_t LJ_K0_LUT8A_OFF = (LJ_K0_LDS + 15u) & ~15u, LJ_K0_LUT8B_OFF =
 constexpr uint32_t LJ_K0_LDS_MT = LJ_K0_LUT8B_OFF + 256u;
 static_assert(LJ_K0_LDS_MT <= 18u * 1280u, "seven workgroups a CU: 18 granules of LDS each");
 constexpr uint32_t ST_MT_MASK = 0x7Fu; // offset | table bit
-template <bool COUNT>
+// (EXACT: with the general look-up behind every "special" length -- for the parses that start
+// from a predecessor's exit.  The parse from bit 0 runs through garbage until it falls into
+// step, meets such an entry in one slot of sixteen there, and a wavefront waits for the
+// slowest of its lanes: looked up there too, every wavefront paid a round trip to the
+// table in global memory for lengths nobody needs.)
+template <bool COUNT, bool EXACT>
 __device__ __forceinline__ uint32_t lj_guess_parse_mt(uint32_t col4, uint32_t end_bits,
                                                       uint32_t from, const TabLds* tb_even,
                                                       const TabLds* tb_odd,
@@ -661,7 +666,7 @@ __device__ __forceinline__ uint32_t lj_guess_parse_mt(uint32_t col4, uint32_t en
     uint32_t qadd = sum << 5, nadd = 2u;
     if (__builtin_expect(sum >= 128u, 0)) {
       uint32_t len = *(lds_u8p)(lut + (w >> 22));
-      if (__builtin_expect(len & 0x80u, 0)) {
+      if (EXACT && __builtin_expect(len & 0x80u, 0)) {
         const uint32_t exact = lj_exact_symbol_bits(w, lut == LJ_K0_LUTB_OFF ? tb_odd : tb_even);
         if (exact)
           len = exact;
@@ -681,7 +686,7 @@ __device__ __forceinline__ uint32_t lj_guess_parse_mt(uint32_t col4, uint32_t en
     const uint32_t d0 = *(lds_u32p)(ad), d1 = *(lds_u32p)(ad + 4u * LJ_T);
     const uint32_t w = uint32_t((((uint64_t(d0) << 32) | d1) << ((q >> 5) & 31u)) >> 32);
     uint32_t len = *(lds_u8p)(lut + (w >> 22));
-    if (__builtin_expect(len & 0x80u, 0)) {
+    if (EXACT && __builtin_expect(len & 0x80u, 0)) {
       const uint32_t exact = lj_exact_symbol_bits(w, lut == LJ_K0_LUTB_OFF ? tb_odd : tb_even);
       if (exact)
         len = exact;
@@ -908,10 +913,14 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     // (the stream's tables in global memory: for the symbols the length tables only flag)
     const TabLds* tb_even = a.tables + S.table_base + (mt ? S.tab_of_phase[0] : 0u);
     const TabLds* tb_odd = a.tables + S.table_base + (mt ? S.tab_of_phase[1] : 0u);
+    // (two tables, the parse from bit 0: special lengths as the table approximates them)
+    auto parse_from_0 = [&](int col, uint32_t bits, uint32_t* count) -> uint32_t {
+      return lj_guess_parse_mt<true, false>(uint32_t(col) * 4u, bits, 0u, tb_even, tb_odd, count);
+    };
     auto parse = [&](int col, uint32_t bits, uint32_t from, uint32_t* count) -> uint32_t {
       if (mt)
-        return count ? lj_guess_parse_mt<true>(uint32_t(col) * 4u, bits, from, tb_even, tb_odd, count)
-                     : lj_guess_parse_mt<false>(uint32_t(col) * 4u, bits, from, tb_even, tb_odd);
+        return count ? lj_guess_parse_mt<true, true>(uint32_t(col) * 4u, bits, from, tb_even, tb_odd, count)
+                     : lj_guess_parse_mt<false, true>(uint32_t(col) * 4u, bits, from, tb_even, tb_odd);
 #ifndef RSX_K0_SINGLE_SYMBOL
       if (hand)
         return count ? lj_guess_parse_pairs<true>(uint32_t(col) * 4u, bits, from, count)
@@ -930,7 +939,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     if (zl >= 4u) // (shorter: more than 128 symbols in a slot, the multi-kernel pipeline's)
       constant = lj_guess_constant(L.B, j, zl, zc, exists, &ea, &cnt, &grid, zlb, eb);
     if (!constant && exists)
-      ea = parse(j, eb, 0u, &cnt) & smask;
+      ea = (mt ? parse_from_0(j, eb, &cnt) : parse(j, eb, 0u, &cnt)) & smask;
     if (j == 0 && lb == 0)
       ea = S.start_bit & smask; // (the stream's first slot starts where the stream does)
     EA[j] = uint16_t(ea);
@@ -941,7 +950,9 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     if (!constant && exists && xa != 0u && gs >= 2u)
       ebv = parse(j, eb, xa, nullptr) & smask;
 #else
-    if (!constant && exists && xa != 0u && gs >= 2u)
+    // (two tables: the parse from bit 0 stands for the B parse where the predecessor ends on
+    // bit 0 -- unless it met a special length: then once more, looking them up)
+    if (!constant && exists && gs >= 2u && (xa != 0u || (mt && (cnt >> 31) != 0u)))
       ebv = parse(j, eb, xa, &cnt) & smask;
 #endif
     EB[j] = uint16_t(ebv);
