@@ -37,10 +37,11 @@ def kernel_descriptors():
                         "-o", out], check=True, capture_output=True, timeout=300)
         text = open(out).read()
     found = {}
-    for m in re.finditer(r"\.amdhsa_kernel (\S*lj_fast_kernelILi(\d)E\S*)(.*?)\.end_amdhsa_kernel",
-                         text, re.S):
-        body = m.group(3)
-        found[int(m.group(2))] = {
+    for m in re.finditer(
+            r"\.amdhsa_kernel (\S*lj_fast_kernelILi(\d)ELb([01])E\S*)(.*?)\.end_amdhsa_kernel",
+            text, re.S):
+        body = m.group(4)
+        found[(int(m.group(2)), bool(int(m.group(3))))] = {
             k: int(re.search(r"\.amdhsa_%s (\d+)" % k, body).group(1))
             for k in ("group_segment_fixed_size", "private_segment_fixed_size",
                       "next_free_vgpr")}
@@ -48,7 +49,8 @@ def kernel_descriptors():
 
 
 def test_single_pass_kernel_has_no_static_lds(kernel_descriptors):
-    assert set(kernel_descriptors) == {1, 2, 4}
+    # (components, two alternating tables)
+    assert set(kernel_descriptors) == {(1, False), (2, False), (4, False), (2, True), (4, True)}
     for n, k in kernel_descriptors.items():
         assert k["group_segment_fixed_size"] == 0, (n, k)
 
@@ -56,5 +58,30 @@ def test_single_pass_kernel_has_no_static_lds(kernel_descriptors):
 def test_single_pass_kernel_fits_four_workgroups_per_cu(kernel_descriptors):
     for n, k in kernel_descriptors.items():
         assert k["next_free_vgpr"] <= 128, (n, k)
-        if n in (1, 2):
-            assert k["private_segment_fixed_size"] == 0, (n, k)
+        assert k["private_segment_fixed_size"] == 0, (n, k)
+
+
+def test_unstuff_kernel_keeps_seven_workgroups_per_cu():
+    """K0 (both instantiations: plans without / with two-table streams): seven workgroups of
+    four wavefronts a CU are seven wavefronts a SIMD -- at most 72 vector registers each, no
+    scratch -- and 18 LDS granules of 1280 bytes (a static_assert in the source checks the
+    two-table layout's size)."""
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k0.s")
+        subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S",
+                        "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "rawspeed_amd", "csrc"),
+                        os.path.join(ROOT, "rawspeed_amd", "csrc", "rsx_ljpeg.hip"),
+                        "-o", out], check=True, capture_output=True, timeout=600)
+        text = open(out).read()
+    seen = set()
+    for m in re.finditer(
+            r"\.amdhsa_kernel (\S*lj_unstuff_kernelILb([01])E\S*)(.*?)\.end_amdhsa_kernel",
+            text, re.S):
+        body = m.group(3)
+        get = lambda k: int(re.search(r"\.amdhsa_%s (\d+)" % k, body).group(1))
+        seen.add(bool(int(m.group(2))))
+        assert get("next_free_vgpr") <= 72, (m.group(1), get("next_free_vgpr"))
+        assert get("private_segment_fixed_size") == 0
+        assert get("group_segment_fixed_size") == 0
+    assert seen == {False, True}
