@@ -18,8 +18,9 @@ its own shard of independent frames -- weak scaling for the headline leg, no dat
 collective; RCCL carries the barrier / max-reduction of the timing and, for the
 batched-LJPEG leg (BASELINE configs[4]: 256 frames sharded with dist.shard_range over
 the ranks), optionally the distribution of the packed batch from rank 0
-(--broadcast: one RCCL broadcast of the whole batch; --scatter: grouped send/recv of
-each rank's shard), timed separately from the decode.
+(with N > 1 all three ways in one run -- every rank's own shard, grouped send/recv of
+each rank's shard from rank 0, one RCCL broadcast of the whole batch -- each timed apart
+from the decode and reported as `input_distribution`; --scatter / --broadcast: that one only).
 
 Rank 0 prints ONE JSON line (kept under 6 KB: the driver holds a tail of stdout).  At
 N=1 it also carries
@@ -281,25 +282,25 @@ def cfg5_leg(args, ctx, torch, grp, rank, n_gpus, stream):
     plan5, inp5, out5, meta = bench_ljpeg.make_cfg5_plan(ctx, torch, f5, seed0=1000,
                                                          distinct=args.cfg5_distinct,
                                                          first_frame=lo)
-    dist_info = {"mode": "every rank synthesises its own shard (no exchange)"}
-    if grp.enabled and (args.broadcast or args.scatter):
-        # rank 0 assembles every rank's OWN shard (they differ in content and in size) and
-        # either broadcasts the whole batch or sends rank r exactly its shard
-        shard_bytes = int(inp5.numel())
-        mode = "broadcast" if args.broadcast else "scatter"
-        got, dt, moved = rdist.distribute_units(
+    # kernel-only scaling and distribution-inclusive scaling, reported apart.
+    # With N > 1 and no flag the packed batch reaches the ranks all three ways in this one
+    # run (rawspeed_amd.dist.distribute_all_modes): every rank's own shard, rank 0 sending
+    # each rank ITS shard, rank 0 broadcasting the whole batch -- each must deliver the very
+    # bytes the rank's plan expects, and the shard each mode delivered is decoded and
+    # checked below.  --scatter / --broadcast restrict the run to that one exchange.
+    dist_info = {"own_shard": {"what": "every rank synthesises its own shard: no exchange",
+                               "ms": 0.0, "bytes": 0}}
+    delivered = {}
+    if grp.enabled:
+        modes = (("own_shard", "broadcast") if args.broadcast else
+                 ("own_shard", "scatter") if args.scatter else rdist.MODES)
+        dist_info, delivered = rdist.distribute_all_modes(
             grp, total, lambda g: bench_ljpeg.cfg5_frame_bytes(meta, g),
-            lambda units: bench_ljpeg.cfg5_assemble(torch, meta, units), mode,
-            lambda n: torch.empty(n, dtype=torch.uint8, device="cuda"),
-            sync=torch.cuda.synchronize)
-        assert int(got.numel()) == shard_bytes, (int(got.numel()), shard_bytes)
-        inp5 = got
-        dist_info = {"mode": ("RCCL broadcast of the whole packed batch from rank 0 (shards differ)"
-                              if args.broadcast else
-                              "grouped RCCL send/recv: rank 0 sends every other rank ITS shard "
-                              "(shards differ in content and size)"),
-                     "ms": round(dt * 1e3, 2), "bytes": moved,
-                     "gbps": round(moved / max(dt, 1e-9) / 1e9, 1)}
+            lambda units: bench_ljpeg.cfg5_assemble(torch, meta, units),
+            lambda n: torch.empty(n, dtype=torch.uint8, device="cuda"), inp5,
+            lambda a, b: a.numel() == b.numel() and bool(torch.equal(a, b)),
+            sync=torch.cuda.synchronize, modes=modes)
+        delivered.pop("own_shard", None)
     plan5.run(inp5.data_ptr(), out5.data_ptr(), stream)
     rc5, st5, cons5 = plan5.results()
     ref_frames = cpu5 = None
@@ -309,10 +310,24 @@ def cfg5_leg(args, ctx, torch, grp, rank, n_gpus, stream):
             0, [b[0] for b in meta["blobs"]], [b[1] for b in meta["blobs"]],
             meta["W"], meta["H"], "LJpegDecompressor::decode")
     exact5 = rc5 == 0 and bench_ljpeg.check_cfg5(out5, meta, cons5, f5, ref_frames)
+    # ... and the shard as each exchange delivered it: decoded from THAT buffer, every frame checked
+    for mode, shard in delivered.items():
+        out5.zero_()
+        plan5.run(shard.data_ptr(), out5.data_ptr(), stream)
+        rcm, _, consm = plan5.results()
+        okm = rcm == 0 and bench_ljpeg.check_cfg5(out5, meta, consm, f5, None)
+        dist_info[mode]["decoded_bit_exact"] = bool(
+            grp.sum_over_ranks(1.0 if okm else 0.0) == n_gpus)
+        exact5 = exact5 and okm
+    delivered.clear()
     k5 = 5
     dt5 = time_plan(torch, grp, plan5, inp5, out5, k5, 2, stream) / k5
     all_exact = grp.sum_over_ranks(1.0 if exact5 else 0.0) == n_gpus
     W5, H5 = meta["W"], meta["H"]
+    for mode, rec in dist_info.items():
+        # the batch's rate with that exchange in front of the decode (kernel-only: own_shard)
+        rec["mpix_per_s_incl_distribution"] = round(
+            total * W5 * H5 / (dt5 + rec.get("ms", 0.0) * 1e-3) / 1e6, 1)
     res = {
         "workload": "%d independent 8192x5464 LJPEG frames (2 components, predictor 1; "
                     "BASELINE configs[4]) sharded with shard_range over %d GPU(s): %d on "
@@ -380,13 +395,25 @@ def replayed_ljpeg_counters():
 
 
 def ljpeg_summary(extra):
-    """the LJPEG legs of `extra`, compressed for the one-line JSON"""
-    def leg(d, cpu=True):
+    """the LJPEG legs and the SURVEY 8(f) legs of `extra`, compressed for the one-line JSON.
+    Every entry carries a `roofline` measured IN THIS RUN (algorithmic bytes, the dominant
+    kernel and its hipEvent average, fraction of the HBM peak over the whole step); what
+    comes from committed rocprofv3 PMC passes sits apart under `replayed`."""
+    def roof(d):
+        r = d.get("roofline")
+        if not isinstance(r, dict):
+            return None
+        k = r.get("kernel")
+        return {"alg_bytes": r.get("algorithmic_bytes"), "frac": r.get("frac"),
+                "kernel": k.replace("lj_", "").replace("_kernel", "") if k else None,
+                "avg_kernel_ms": r.get("avg_kernel_ms")}
+
+    def leg(d, cpu=True, kernels=True):
         if not isinstance(d, dict) or "ms_per_step" not in d:
             return d if isinstance(d, dict) and "error" in d else None
         r = {"ms_per_step": d["ms_per_step"], "gpix_per_s": round(d["mpix_per_s"] / 1e3, 1),
-             "hbm_frac": d.get("frac_of_hbm_peak"), "bit_exact": d.get("bit_exact")}
-        if "kernels_ms" in d:
+             "bit_exact": d.get("bit_exact"), "roofline": roof(d)}
+        if kernels and "kernels_ms" in d:
             r["kernels_ms"] = {k.replace("lj_", "").replace("_kernel", ""): round(v, 3)
                                for k, v in d["kernels_ms"].items()}
         c = d.get("cpu_baseline")
@@ -400,23 +427,35 @@ def ljpeg_summary(extra):
         "cfg3_cr2_6720x4480_8frames": leg(extra.get("cfg3_cr2_6720x4480")),
         "cfg4_dng_2x2_tiles_8192x5464_1frame": leg(extra.get("cfg4_dng_tiles_8192x5464")),
         "cfg5_batch_8192x5464": leg(extra.get("cfg5_ljpeg_frames_batch")),
-        "cfg3_clipped_highlights": leg(extra.get("cfg3_clipped_highlights"), cpu=False),
-        "cfg3_uniform_random_14bit": leg(extra.get("cfg3_uniform_random_14bit"), cpu=False),
+        "cfg3_clipped_highlights": leg(extra.get("cfg3_clipped_highlights"), cpu=False, kernels=False),
+        "cfg3_uniform_random_14bit": leg(extra.get("cfg3_uniform_random_14bit"), cpu=False, kernels=False),
+        "ljpeg_3comp_8192x5464": leg(extra.get("ljpeg_3comp_8192x5464"), cpu=False, kernels=False),
     }
     c4 = extra.get("cfg4_dng_tiles_8192x5464")
     if isinstance(c4, dict):
         for k in ("two_tables", "two_tables_256x256_tiles", "overhang_8189x5462",
                   "restart_intervals"):
             if isinstance(c4.get(k), dict) and "ms_per_step" in c4[k]:
-                s["cfg4_" + k] = {"ms_per_step": c4[k]["ms_per_step"],
-                                  "mpix_per_s": c4[k].get("mpix_per_s"),
-                                  "bit_exact": c4[k].get("bit_exact")}
+                s["cfg4_" + k] = leg(c4[k], cpu=False, kernels=False)
     c5 = extra.get("cfg5_ljpeg_frames_batch")
     if isinstance(c5, dict) and s.get("cfg5_batch_8192x5464"):
         s["cfg5_batch_8192x5464"]["frames_on_this_rank"] = c5.get("frames_on_this_rank")
         s["cfg5_batch_8192x5464"]["distinct_frames"] = c5.get("distinct_frames")
         s["cfg5_batch_8192x5464"]["input_distribution"] = c5.get("input_distribution")
-    s.update(replayed_ljpeg_counters())
+    # the other decompressors, one line each
+    f = {}
+    nk = extra.get("nikon_lossless14_6016x4016")
+    if isinstance(nk, dict) and isinstance(nk.get("curve_dither"), dict):
+        f["nikon"] = leg(nk["curve_dither"], cpu=False, kernels=False)
+    for key, name in (("hasselblad_8272x6200", "hasselblad"), ("sony_arw1_3881x2608", "sony_arw1"),
+                      ("pentax_7392x4950", "pentax"), ("samsung_v1_5472x3648", "samsung_v1"),
+                      ("samsung_v2_6480x4320", "samsung_v2"), ("cr2_sraw1_3960x2640", "cr2_sraw_decode")):
+        f[name] = leg(extra.get(key), cpu=False, kernels=False)
+    sr = extra.get("cr2_sraw1_3960x2640")
+    if isinstance(sr, dict) and isinstance(sr.get("interpolate"), dict):
+        f["cr2_sraw_interpolate"] = leg(sr["interpolate"], cpu=False, kernels=False)
+    s["survey_8f"] = {k: v for k, v in f.items() if v}
+    s["replayed"] = replayed_ljpeg_counters()
     return s
 
 

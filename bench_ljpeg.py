@@ -190,6 +190,27 @@ def _dominant(res, kt):
         res["kernels_ms"] = dict(LAST_KERNEL_TABLE)
 
 
+def _roofline(res, alg, dt, kt):
+    """The leg's `roofline` object, measured IN THIS RUN: algorithmic bytes of a step (the
+    entropy-coded / packed input read once + the 16-bit image written once) over (a) the
+    whole step -- every kernel of the plan, wall clock over the timed steps -- and (b) the
+    dominant kernel's average launch duration from the hipEvents the library records after
+    every launch (rsx_plan_set_timing; the table is in `kernels_ms`)."""
+    r = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "algorithmic_bytes": int(alg),
+         "step_ms": round(dt * 1e3, 4),
+         "achieved": round(alg / dt / 1e9, 1), "frac": round(alg / dt / 1e9 / 8000.0, 4),
+         "measured": "in this run: wall clock of the timed steps; hipEvents after every launch"}
+    tab = res.get("kernels_ms") or LAST_KERNEL_TABLE
+    if kt:
+        r["kernel"] = kt[0]
+        r["avg_kernel_ms"] = round(kt[1], 5)
+        r["frac_if_only_that_kernel_ran"] = round(alg / (kt[1] * 1e-3) / 8e12, 4)
+    if tab:
+        r["sum_of_kernels_ms"] = round(sum(tab.values()), 4)
+    res["roofline"] = r
+    return res
+
+
 def _lj_result(workload, frames, W, H, dt, scan_bytes, exact, kt, extra=None):
     alg = scan_bytes + frames * W * H * 2
     res = {
@@ -205,6 +226,7 @@ def _lj_result(workload, frames, W, H, dt, scan_bytes, exact, kt, extra=None):
     if extra:
         res.update(extra)
     _dominant(res, kt)
+    _roofline(res, alg, dt, kt)
     return res
 
 
@@ -334,6 +356,7 @@ def run_clipped(ctx, torch, log, frames=8, steps=10, warmup=2):
                      frames, W, H, dt, sum(m[3] for m in made), exact, kt,
                      {"ms_per_step_with_results_fetch": round(dt_r * 1e3, 4)})
     res["kernels_ms"] = ktab
+    res["roofline"]["sum_of_kernels_ms"] = round(sum(ktab.values()), 4)
     return res
 
 
@@ -361,6 +384,7 @@ def run_sraw(ctx, torch, log, frames=8, steps=10, warmup=2):
     out = torch.zeros(frames * out_pitch(W) * H, dtype=torch.uint8, device="cuda")
     plan = ctx.cr2_plan(jobs)
     dt, kt, cons = _time_plan(torch, plan, inp, out, steps, warmup)
+    ktab_dec = dict(LAST_KERNEL_TABLE or {})
     got = out[-out_pitch(W) * H:].cpu().numpy().view(np.uint16).reshape(H, out_pitch(W) // 2)[:, :W]
     exact = bool(np.array_equal(got, src)) and all(c == scan_len for c in cons)
     # Cr2sRawInterpolator on the decoded frames, still in HBM (Cr2Decoder.cpp:585-625)
@@ -386,8 +410,15 @@ def run_sraw(ctx, torch, log, frames=8, steps=10, warmup=2):
         interp.update(kernel=skt[0], avg_kernel_ms=round(skt[1], 5),
                       achieved_gbps=round(salg / (skt[1] * 1e-3) / 1e9, 1),
                       frac_of_8tbps=round(salg / (skt[1] * 1e-3) / 8e12, 4))
+    if skt:
+        interp["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
+                              "algorithmic_bytes": salg, "kernel": skt[0],
+                              "avg_kernel_ms": round(skt[1], 5),
+                              "achieved": round(salg / (skt[1] * 1e-3) / 1e9, 1),
+                              "frac": round(salg / (skt[1] * 1e-3) / 8e12, 4),
+                              "measured": "in this run: hipEvents around the launch"}
     alg = frames * (scan_len + W * H * 2)
-    return {
+    return _roofline({
         "interpolate": interp,
         "workload": "Cr2Decompressor <3,2,2> (sRaw1) 3960x2640 px = %dx%d samples, 3 slices, "
                     "%d frames/step" % (W, H, frames),
@@ -398,7 +429,8 @@ def run_sraw(ctx, torch, log, frames=8, steps=10, warmup=2):
         "entropy_bits_per_sample": round(scan_len * 8 / (W * H), 3),
         "algorithmic_bytes_per_step": alg,
         "achieved_gbps_whole_pipeline": round(alg / dt / 1e9, 1),
-    }
+        "kernels_ms": ktab_dec,
+    }, alg, dt, kt)
 
 
 def _dng_tiles(W, H, tw, th, seed, rows_per_ri=0, two_tables=False):
@@ -624,7 +656,8 @@ def run_nikon(ctx, torch, log, frames=8, steps=10, warmup=2, cpu=True):
         got = outb[-out_pitch(W) * H:].cpu().numpy().view(np.uint16).reshape(
             H, out_pitch(W) // 2)[:, :W]
         r = {"mpix_per_s": round(frames * W * H / dt / 1e6, 1),
-             "ms_per_step": round(dt * 1e3, 4)}
+             "ms_per_step": round(dt * 1e3, 4), "kernels_ms": dict(LAST_KERNEL_TABLE or {})}
+        _roofline(r, frames * (data.size + W * H * 2), dt, kt)
         if unc:
             r["bit_exact"] = bool(np.array_equal(got, src))
         else:
@@ -688,7 +721,9 @@ def run_hasselblad(ctx, torch, log, frames=4, steps=10, warmup=2, cpu=True):
            "mpix_per_s": round(frames * W * H / dt / 1e6, 1),
            "ms_per_step": round(dt * 1e3, 4),
            "bit_exact": bool(np.array_equal(got, src)),
-           "entropy_bits_per_px": round(sym_bits / (W * H), 3)}
+           "entropy_bits_per_px": round(sym_bits / (W * H), 3),
+           "kernels_ms": dict(LAST_KERNEL_TABLE or {})}
+    _roofline(out, frames * (data.size + W * H * 2), dt, kt)
     if cpu:
         try:
             from oracle_lib import Ref
@@ -741,7 +776,9 @@ def run_sony_arw1(ctx, torch, log, frames=8, steps=10, warmup=2, cpu=True):
            "mpix_per_s": round(frames * W * H / dt / 1e6, 1),
            "ms_per_step": round(dt * 1e3, 4),
            "bit_exact": bool(np.array_equal(got, src)),
-           "entropy_bits_per_px": round(sym_bits / (W * H), 3)}
+           "entropy_bits_per_px": round(sym_bits / (W * H), 3),
+           "kernels_ms": dict(LAST_KERNEL_TABLE or {})}
+    _roofline(out, frames * (data.size + W * H * 2), dt, kt)
     if cpu:
         try:
             from oracle_lib import Ref
@@ -765,6 +802,88 @@ def run_sony_arw1(ctx, torch, log, frames=8, steps=10, warmup=2, cpu=True):
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)}
     return out
+
+
+def _prefix_leg(ctx, torch, log, what, W, H, frames, steps, warmup, plan_of, job_type, desc,
+                data, src, sym_bits, ref_call, cpu):
+    """Pentax / SamsungV1: the Nikon stream kind with its own table, predictors and range
+    check (rsx_ljpeg_recon.hip); `frames` copies of one stream per step."""
+    jobs = []
+    for f in range(frames):
+        j = job_type()
+        j.desc = desc
+        j.in_offset, j.in_bytes = f * data.size, data.size
+        j.img_offset = f * out_pitch(W) * H
+        j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
+            out_pitch(W), W, H, 1, 1
+        jobs.append(j)
+    inp = torch.from_numpy(np.tile(data, frames)).cuda()
+    outb = torch.zeros(frames * out_pitch(W) * H, dtype=torch.uint8, device="cuda")
+    plan = plan_of(jobs)
+    dt, kt, _ = _time_plan(torch, plan, inp, outb, steps, warmup)
+    plan.close()
+    exact = all(bool(np.array_equal(gpu_frame(outb, f, W, H), src)) for f in (0, frames - 1))
+    out = {"workload": "%s %dx%d, %d frames/step" % (what, W, H, frames),
+           "mpix_per_s": round(frames * W * H / dt / 1e6, 1),
+           "ms_per_step": round(dt * 1e3, 4), "bit_exact": exact,
+           "bit_exact_against": "the image the stream was written from",
+           "entropy_bits_per_px": round(sym_bits / (W * H), 3),
+           "kernels_ms": dict(LAST_KERNEL_TABLE or {})}
+    _roofline(out, frames * (data.size + W * H * 2), dt, kt)
+    if cpu:
+        try:
+            from oracle_lib import Ref
+            if Ref.available():
+                ref = Ref()
+                img = ref.image(W, H, 1)
+                assert ref_call(ref, img) == 0
+                out["bit_exact"] = exact and bool(np.array_equal(img.pixels(), gpu_frame(outb, 0, W, H)))
+                out["bit_exact_against"] = "the reference build's output and the source image"
+                times = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    ref_call(ref, img)
+                    times.append(time.perf_counter() - t0)
+                out["cpu_baseline"] = {
+                    "value": round(W * H / min(times) / 1e6, 1), "unit": "MPix/s", "cores": 1,
+                    "kind": "reference",
+                    "sample": "%s::decompress of the unmodified reference on the same stream, "
+                              "1 thread, best of 3" % what}
+                out["cpu_baseline"].update(ref_all_threads(
+                    ref, W, H, lambda im: ref_call(ref, im), "%s::decompress" % what))
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
+def run_pentax(ctx, torch, log, frames=8, steps=10, warmup=2, cpu=True):
+    """PentaxDecompressor: a K-1-sized 7392x4950 14-bit frame, the makernote
+    ("modern") code table."""
+    import nikon_cases as N
+    from rawspeed_amd import abi
+    W, H = 7392, 4950
+    src = N.smooth15(np.random.default_rng(41), H, W, maxv=16383, sigma=9.0)
+    tree = N.PENTAX_MODERN
+    data, sym_bits = N.pentax_encode(src, tree)
+    data = np.concatenate([data, np.zeros(16 + (-len(data)) % 16, np.uint8)])
+    meta = N.pentax_metadata(tree)
+    return _prefix_leg(ctx, torch, log, "PentaxDecompressor", W, H, frames, steps, warmup,
+                       ctx.pentax_plan, abi.PentaxJob, N.pentax_desc(tree), data, src, sym_bits,
+                       lambda ref, img: ref.pentax(meta, data, img), cpu)
+
+
+def run_samsung_v1(ctx, torch, log, frames=8, steps=10, warmup=2, cpu=True):
+    """SamsungV1Decompressor: an NX-sized 5472x3648 12-bit frame."""
+    import nikon_cases as N
+    from rawspeed_amd import abi, synth
+    W, H = 5472, 3648
+    src = N.smooth15(np.random.default_rng(43), H, W, maxv=4095, sigma=6.0)
+    data, sym_bits = synth.prefix_encode(src, [0, 0, 0, 0], synth.SAMSUNG_V1_TAB)
+    data = np.concatenate([data, np.zeros(16 + (-len(data)) % 16, np.uint8)])
+    return _prefix_leg(ctx, torch, log, "SamsungV1Decompressor", W, H, frames, steps, warmup,
+                       ctx.samsung_v1_plan, abi.SamsungV1Job,
+                       abi.SamsungV1Desc.make(synth.SAMSUNG_V1_TAB), data, src, sym_bits,
+                       lambda ref, img: ref.samsung_v1(12, data, img), cpu)
 
 
 def make_samsung_v2_frame(W, H, bits=14, seed=21, band=34):
@@ -823,6 +942,7 @@ def run_samsung_v2(ctx, torch, log, frames=4, steps=5, warmup=1, cpu=True):
            "ms_per_step": round(dt * 1e3, 4),
            "compressed_bits_per_px": round(data.size * 8 / (W * H), 3),
            "kernels_ms": ktab}
+    _roofline(out, frames * (data.size + W * H * 2), dt, kt)
     if cpu:
         try:
             from oracle_lib import Ref
@@ -1003,6 +1123,8 @@ def run(ctx, torch, log):
     leg("nikon_lossless14_6016x4016", lambda: run_nikon(ctx, torch, log))
     leg("hasselblad_8272x6200", lambda: run_hasselblad(ctx, torch, log))
     leg("sony_arw1_3881x2608", lambda: run_sony_arw1(ctx, torch, log))
+    leg("pentax_7392x4950", lambda: run_pentax(ctx, torch, log))
+    leg("samsung_v1_5472x3648", lambda: run_samsung_v1(ctx, torch, log))
     leg("samsung_v2_6480x4320", lambda: run_samsung_v2(ctx, torch, log))
     leg("cr2_sraw1_3960x2640", lambda: run_sraw(ctx, torch, log))
     leg("host_path", lambda: run_host_path(torch, log))
@@ -1035,6 +1157,12 @@ if __name__ == "__main__":
                          indent=1))
     elif args.only == "sony":
         print(json.dumps(run_sony_arw1(ctx, torch, print, steps=args.steps), indent=1))
+    elif args.only == "pentax":
+        print(json.dumps(run_pentax(ctx, torch, print, frames=args.frames, steps=args.steps,
+                                    cpu=not args.no_cpu), indent=1))
+    elif args.only == "samsung_v1":
+        print(json.dumps(run_samsung_v1(ctx, torch, print, frames=args.frames, steps=args.steps,
+                                        cpu=not args.no_cpu), indent=1))
     elif args.only == "samsung_v2":
         print(json.dumps(run_samsung_v2(ctx, torch, print, steps=args.steps), indent=1))
     elif args.only == "hasselblad":

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RSX_ABI_VERSION 3
+#define RSX_ABI_VERSION 4
 
 /* ------------------------------------------------------------------------ */
 /* Status codes.  Kernels cannot throw; the C++ forwarding shim converts a   */
@@ -109,6 +109,23 @@ const char* rsx_ctx_last_error(const rsx_ctx* ctx);
  * this context has served: lets an integration check that the batched DNG hunk
  *  really makes one call per image. */
 uint64_t rsx_ctx_host_calls(const rsx_ctx* ctx);
+
+/* Optional: page-locked host memory for the host-pointer calls (ABI 4).
+ * Those calls take whatever the caller has -- rawspeed's file `Buffer` and the pixel store
+ * of RawImageData::createData() (RawImage.cpp:68-100: `data.resize(pitch * dim.y)` over an
+ * aligned allocator) are pageable, and a copy from / to pageable memory goes through the
+ * driver's staging at a fraction of the link's rate and keeps its calling thread.  An
+ * integration that allocates these two buffers here (or registers them after the fact)
+ * gets direct DMA and copies that overlap the kernels; nothing else changes, and memory
+ * that was not registered keeps working as before.  INTEGRATION.md 6 shows the hunks.
+ *   rsx_host_alloc / rsx_host_free          hipHostMalloc'ed block (64-byte aligned and more)
+ *   rsx_host_register / rsx_host_unregister  page-lock an existing allocation in place
+ * RSX_ERR_NOMEM when the pages cannot be locked (RLIMIT_MEMLOCK, fragmentation): the
+ * caller carries on with pageable memory. */
+int rsx_host_alloc(rsx_ctx* ctx, size_t bytes, void** out);
+int rsx_host_free(rsx_ctx* ctx, void* p);
+int rsx_host_register(rsx_ctx* ctx, void* p, size_t bytes);
+int rsx_host_unregister(rsx_ctx* ctx, void* p);
 
 /* ------------------------------------------------------------------------ */
 /* 1. UncompressedDecompressor                                               */

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-RSX_ABI_VERSION = 3
+RSX_ABI_VERSION = 4
 
 # rsx_status
 RSX_OK = 0

@@ -17,6 +17,7 @@ _lib = None
 EXPORTS = [
     "rsx_abi_version", "rsx_status_string", "rsx_device_count", "rsx_ctx_create",
     "rsx_ctx_destroy", "rsx_ctx_last_error", "rsx_ctx_host_calls",
+    "rsx_host_alloc", "rsx_host_free", "rsx_host_register", "rsx_host_unregister",
     "rsx_unpack_validate", "rsx_unpack_u16",
     "rsx_unpack_f32_validate", "rsx_unpack_f32", "rsx_unpack_f32_plan_create",
     "rsx_unpack_variant_validate", "rsx_unpack_variant_u16", "rsx_unpack_variant_plan_create",
@@ -160,6 +161,29 @@ class Context:
         f = lib().rsx_ctx_host_calls
         f.restype = C.c_uint64
         return int(f(self._h))
+
+    # page-locked host memory (rsx.h: optional, ABI 4)
+    def host_alloc(self, nbytes):
+        """rsx_host_alloc: a page-locked block as a numpy uint8 array (host_free() it)"""
+        import numpy as np
+        p = C.c_void_p()
+        st = lib().rsx_host_alloc(self._h, C.c_size_t(nbytes), C.byref(p))
+        if st != 0:
+            raise RsxError(st, "rsx_host_alloc(%d)" % nbytes)
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=np.uint8)
+        arr.flags.writeable = True
+        return arr
+
+    def host_free(self, arr):
+        return lib().rsx_host_free(self._h, C.c_void_p(arr.ctypes.data))
+
+    def host_register(self, arr):
+        """rsx_host_register: page-lock an existing numpy array in place (status)"""
+        return lib().rsx_host_register(self._h, C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes))
+
+    def host_unregister(self, arr):
+        return lib().rsx_host_unregister(self._h, C.c_void_p(arr.ctypes.data))
 
     def __del__(self):
         try:

@@ -278,6 +278,8 @@ extern "C" void rsx_ctx_destroy(rsx_ctx* ctx) {
     l->d_in.release();
     l->d_out.release();
   }
+  if (ctx->fast_ev)
+    (void)hipEventDestroy(ctx->fast_ev);
   delete ctx;
 }
 
@@ -296,6 +298,62 @@ extern "C" const char* rsx_ctx_last_error(const rsx_ctx* ctx) {
 
 extern "C" uint64_t rsx_ctx_host_calls(const rsx_ctx* ctx) {
   return ctx ? ctx->host_calls.load() : 0;
+}
+
+// Page-locked host memory (rsx.h: optional; replaces nothing in the reference, it changes
+// where RawImageData::createData, RawImage.cpp:68-100, and the file Buffer get their bytes).
+extern "C" int rsx_host_alloc(rsx_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out || bytes == 0)
+    return RSX_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return RSX_ERR_DEVICE;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    return RSX_ERR_NOMEM;
+  }
+  *out = p;
+  return RSX_OK;
+}
+
+extern "C" int rsx_host_free(rsx_ctx* ctx, void* p) {
+  if (!ctx)
+    return RSX_ERR_INVALID_ARG;
+  if (!p)
+    return RSX_OK;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return RSX_ERR_DEVICE;
+  if (hipHostFree(p) != hipSuccess) {
+    (void)hipGetLastError();
+    return RSX_ERR_INVALID_ARG;
+  }
+  return RSX_OK;
+}
+
+extern "C" int rsx_host_register(rsx_ctx* ctx, void* p, size_t bytes) {
+  if (!ctx || !p || bytes == 0)
+    return RSX_ERR_INVALID_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return RSX_ERR_DEVICE;
+  const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return e == hipErrorHostMemoryAlreadyRegistered ? RSX_OK : RSX_ERR_NOMEM;
+  }
+  return RSX_OK;
+}
+
+extern "C" int rsx_host_unregister(rsx_ctx* ctx, void* p) {
+  if (!ctx || !p)
+    return RSX_ERR_INVALID_ARG;
+  if (hipSetDevice(ctx->device) != hipSuccess)
+    return RSX_ERR_DEVICE;
+  if (hipHostUnregister(p) != hipSuccess) {
+    (void)hipGetLastError();
+    return RSX_ERR_INVALID_ARG;
+  }
+  return RSX_OK;
 }
 
 extern "C" int rsx_unpack_validate(const rsx_unpack_desc* d, const rsx_image* img,
@@ -956,44 +1014,61 @@ int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
         return e;
       if (int e = d_starts.ensure(starts.size() * sizeof(uint32_t)))
         return e;
-      RSX_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs.ptr, bj.data(), bj.size() * sizeof(UnpackJobDev),
-                                        hipMemcpyHostToDevice, s));
-      RSX_HIP_CHECK(ctx, hipMemcpyAsync(d_starts.ptr, starts.data(),
-                                        starts.size() * sizeof(uint32_t),
-                                        hipMemcpyHostToDevice, s));
-      std::atomic<int> ready{0};
-      std::atomic<int> up_err{0};
+      {
+        hipError_t e = hipMemcpyAsync(d_jobs.ptr, bj.data(), bj.size() * sizeof(UnpackJobDev),
+                                      hipMemcpyHostToDevice, s);
+        if (e == hipSuccess)
+          e = hipMemcpyAsync(d_starts.ptr, starts.data(), starts.size() * sizeof(uint32_t),
+                             hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) {
+          (void)hipStreamSynchronize(s); // (bj / starts / the device temporaries outlive the copies)
+          set_error(ctx, std::string("unpack (banded): ") + hipGetErrorString(e));
+          return RSX_ERR_DEVICE;
+        }
+      }
+      // progress of the uploader: bands whose copy + event are queued (under a mutex, the
+      // caller sleeps on the condition variable)
+      struct Progress {
+        std::mutex m;
+        std::condition_variable cv;
+        int ready = 0;
+        bool failed = false;
+      } prog;
       uint8_t* d_in_base = static_cast<uint8_t*>(lane.lane->d_in.ptr);
       hipStream_t s_up = lane.lane->stream_up;
       const int device = ctx->device;
       auto upload_bands = [&]() {
-        if (hipSetDevice(device) != hipSuccess) {
-          up_err.store(1);
-          ready.store(nb);
-          return;
-        }
+        bool ok = hipSetDevice(device) == hipSuccess;
         for (int b = 0; b < nb; ++b) {
-          hipError_t e = hipMemcpyAsync(d_in_base + bands[b].u.in_offset, bands[b].src,
-                                        size_t(bands[b].u.stream_bytes), hipMemcpyHostToDevice,
-                                        s_up);
-          if (e == hipSuccess)
-            e = hipEventRecord(lane.lane->ev_up[b], s_up);
-          if (e != hipSuccess)
-            up_err.store(1);
-          ready.store(b + 1);
+          if (ok) {
+            hipError_t e = hipMemcpyAsync(d_in_base + bands[b].u.in_offset, bands[b].src,
+                                          size_t(bands[b].u.stream_bytes), hipMemcpyHostToDevice,
+                                          s_up);
+            if (e == hipSuccess)
+              e = hipEventRecord(lane.lane->ev_up[b], s_up);
+            ok = e == hipSuccess;
+          }
+          {
+            std::lock_guard<std::mutex> g(prog.m);
+            prog.ready = b + 1;
+            prog.failed = prog.failed || !ok;
+          }
+          prog.cv.notify_all();
         }
       };
-      std::thread uploader;
-      try {
-        uploader = std::thread(upload_bands);
-      } catch (...) { // (no thread to be had: the uploads first, then the rest)
+      // (a persistent helper of the context; none to be had: the uploads first, then the rest)
+      rsx::HelperPool::Handle uploader = ctx->helpers.submit(upload_bands);
+      if (!uploader)
         upload_bands();
-      }
       hipError_t err = hipSuccess;
+      bool up_failed = false;
       for (int b = 0; b < nb && err == hipSuccess; ++b) {
-        while (ready.load() <= b)
-          std::this_thread::yield();
-        if (up_err.load())
+        {
+          std::unique_lock<std::mutex> g(prog.m);
+          prog.cv.wait(g, [&]() { return prog.ready > b; });
+          up_failed = prog.failed;
+        }
+        if (up_failed)
           break;
         err = hipStreamWaitEvent(s, lane.lane->ev_up[b], 0);
         if (err == hipSuccess)
@@ -1007,15 +1082,20 @@ int unpack_host(rsx_ctx* ctx, int n, const rsx_unpack_desc* descs,
                                  bands[b].dev_pitch, bands[b].width_bytes, bands[b].u.n_rows,
                                  hipMemcpyDeviceToHost, s);
       }
-      if (uploader.joinable())
-        uploader.join();
+      ctx->helpers.wait(uploader);
+      {
+        std::lock_guard<std::mutex> g(prog.m);
+        up_failed = prog.failed;
+      }
+      // BOTH streams drained on every way out, failed or not: the caller's input (s_up reads
+      // it) and image (s writes it) may be freed the moment this call returns, and the
+      // temporaries below are released
+      const hipError_t e_up = hipStreamSynchronize(s_up), e_s = hipStreamSynchronize(s);
       if (err == hipSuccess)
-        err = hipStreamSynchronize(s_up);
-      if (err == hipSuccess)
-        err = hipStreamSynchronize(s);
+        err = e_up != hipSuccess ? e_up : e_s;
       d_jobs.release();
       d_starts.release();
-      if (err != hipSuccess || up_err.load()) {
+      if (err != hipSuccess || up_failed) {
         set_error(ctx, std::string("unpack (banded): ") +
                            (err != hipSuccess ? hipGetErrorString(err) : "upload failed"));
         return RSX_ERR_DEVICE;
@@ -2090,6 +2170,7 @@ extern "C" int rsx_dng_decompress_ljpeg(rsx_ctx* ctx, int n_tiles,
     jobs[i].in_bytes = tiles[i].in_bytes;
     ins[i] = tiles[i].in;
   }
+  constexpr int32_t ST_UNSET = INT32_MIN; // "ljpeg_family_host never got to this tile"
   std::vector<int32_t> st(n_tiles, RSX_OK);
   std::vector<uint32_t> cons(n_tiles, 0);
   // A large image: bands of its tile ROWS (up to four) as calls of their own, side by side on
@@ -2135,36 +2216,43 @@ extern "C" int rsx_dng_decompress_ljpeg(rsx_ctx* ctx, int n_tiles,
         bd.tile.push_back(i);
       }
       auto run_band = [&](Band& bd, bool count) {
-        bd.st.assign(bd.jobs.size(), RSX_OK);
+        bd.st.assign(bd.jobs.size(), ST_UNSET);
         bd.cons.assign(bd.jobs.size(), 0);
         bd.rc = ljpeg_family_host(ctx, int(bd.jobs.size()), bd.jobs, bd.ins.data(), img,
                                   rsx_ljpeg_plan_create, bd.st.data(), bd.cons.data(), count);
       };
-      std::vector<std::thread> helpers;
-      std::vector<int> inline_bands; // (no thread to be had: in turn, on this one)
+      // (persistent helpers of the context; none to be had: in turn, on this thread)
+      std::vector<rsx::HelperPool::Handle> helpers;
+      std::vector<int> inline_bands;
       for (int k = 1; k < n_bands; ++k) {
-        try {
-          helpers.emplace_back([&, k]() { run_band(bands[k], false); });
-        } catch (...) {
+        rsx::HelperPool::Handle h = ctx->helpers.submit([&, k]() { run_band(bands[k], false); });
+        if (h)
+          helpers.push_back(h);
+        else
           inline_bands.push_back(k);
-        }
       }
       run_band(bands[0], true);
       for (int k : inline_bands)
         run_band(bands[k], false);
-      for (std::thread& t : helpers)
-        t.join();
+      for (const rsx::HelperPool::Handle& h : helpers)
+        ctx->helpers.wait(h);
       for (const Band& bd : bands) {
         for (size_t k = 0; k < bd.tile.size(); ++k) {
-          st[bd.tile[k]] = bd.st[k];
+          // (a band that came back early -- no plan, a bad argument -- never filled its
+          // statuses in: its tiles were NOT decoded, whatever the initial value says)
+          st[bd.tile[k]] = bd.st[k] == ST_UNSET ? (bd.rc != RSX_OK ? bd.rc : RSX_ERR_DEVICE) : bd.st[k];
           cons[bd.tile[k]] = bd.cons[k];
         }
         if (bd.rc == RSX_ERR_DEVICE || bd.rc == RSX_ERR_NOMEM)
           rc = bd.rc; // (only a device / memory failure of a band matters below)
       }
     } else {
+      std::fill(st.begin(), st.end(), ST_UNSET);
       rc = ljpeg_family_host(ctx, n_tiles, jobs, ins.data(), img, rsx_ljpeg_plan_create,
                              st.data(), cons.data());
+      for (int32_t& v : st)
+        if (v == ST_UNSET)
+          v = rc != RSX_OK ? rc : RSX_ERR_DEVICE;
     }
   }
   if (tile_status)

@@ -9,7 +9,10 @@
 #include <cstdio>
 #include <memory>
 #include <condition_variable>
+#include <deque>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -166,6 +169,82 @@ struct DeviceBuffer {
   void release();
 };
 
+// ------------------------------------------------------------------------
+// Helper threads of a context's host-pointer calls (the uploader of a banded unpack call,
+// the bands of a split DNG call): a few PERSISTENT workers that sleep on a condition
+// variable, started on first use and kept -- until round 5 every such call created its
+// own std::thread and the caller spun on an atomic with yield().  Tasks never wait for
+// other tasks, so a full pool only queues.
+class HelperPool {
+public:
+  struct Task {
+    std::function<void()> fn;
+    bool done = false;
+  };
+  typedef std::shared_ptr<Task> Handle;
+  ~HelperPool() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      quit_ = true;
+    }
+    cv_work_.notify_all();
+    for (std::thread& t : threads_)
+      if (t.joinable())
+        t.join();
+  }
+  // nullptr: no worker could be had -- the caller runs fn itself
+  Handle submit(std::function<void()> fn) {
+    Handle h = std::make_shared<Task>();
+    h->fn = std::move(fn);
+    {
+      std::lock_guard<std::mutex> g(m_);
+      if (idle_ <= int(queue_.size()) && int(threads_.size()) < MAX_THREADS) {
+        try {
+          threads_.emplace_back([this]() { work(); });
+        } catch (...) {
+          if (threads_.empty())
+            return nullptr;
+        }
+      }
+      queue_.push_back(h);
+    }
+    cv_work_.notify_one();
+    return h;
+  }
+  void wait(const Handle& h) {
+    if (!h)
+      return;
+    std::unique_lock<std::mutex> g(m_);
+    cv_done_.wait(g, [&]() { return h->done; });
+  }
+
+private:
+  static constexpr int MAX_THREADS = 16;
+  void work() {
+    std::unique_lock<std::mutex> g(m_);
+    for (;;) {
+      ++idle_;
+      cv_work_.wait(g, [&]() { return quit_ || !queue_.empty(); });
+      --idle_;
+      if (queue_.empty())
+        return; // (quit)
+      Handle h = queue_.front();
+      queue_.pop_front();
+      g.unlock();
+      h->fn();
+      g.lock();
+      h->done = true;
+      cv_done_.notify_all();
+    }
+  }
+  std::mutex m_;
+  std::condition_variable cv_work_, cv_done_;
+  std::deque<Handle> queue_;
+  std::vector<std::thread> threads_;
+  int idle_ = 0;
+  bool quit_ = false;
+};
+
 } // namespace rsx
 
 struct rsx_ctx {
@@ -179,6 +258,16 @@ struct rsx_ctx {
   std::atomic<uint64_t> host_calls{0}; // host-pointer entry points served
   bool host_overlap = true;            // large unpack-family host calls run in row bands
   std::mutex upload_mu, download_mu;   // LJPEG-family host calls: one copy per direction at a time
+  // The single-pass LJPEG kernel takes a workgroup's place in its stream's order from its
+  // block index (rsx_ljpeg_fast.hip): safe while the dispatcher starts one grid's workgroups
+  // in order, but two such grids on two HIP streams could each fill the slots the other's
+  // next workgroup needs.  Its launches therefore run one after the other per context: each
+  // waits for the event recorded behind the last one (the kernels around it still overlap).
+  rsx::HelperPool helpers;             // persistent helper threads of the host-pointer calls
+  std::mutex fast_mu;
+  hipEvent_t fast_ev = nullptr;
+  hipStream_t fast_ev_stream = nullptr;
+  bool fast_ev_valid = false;
   // Staging of one host-pointer call: device buffers + a stream.  Lanes are pooled, so
   // calls from different threads (rstest-style file loops, DNG tile threads of an
   // unbatched build) stage and decode side by side instead of queueing on one mutex.

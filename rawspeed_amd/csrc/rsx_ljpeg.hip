@@ -199,6 +199,20 @@ __device__ __forceinline__ void lj_fix_regs(const uint32_t (&in)[LJ_BW + 1], uin
     B[ko * LJ_T + col] = 0u;
 }
 
+// phase time stamps of K0 in experiment builds (second half of LjArgs::dbg; printed next to
+// the single-pass kernel's by ljpeg_plan_results under RSX_DEBUG)
+#ifdef RSX_EXPERIMENT
+#define K0_STAMP(k)                                                                   \
+  do {                                                                                \
+    if (a.dbg && threadIdx.x == 0)                                                    \
+      a.dbg[(size_t(gridDim.x) + (S.first_block + lb)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define K0_STAMP(k) \
+  do {              \
+  } while (0)
+#endif
+
 __device__ __forceinline__ int lj_valid_bytes(const LjStreamDev& S, uint32_t lb, int j) {
   const int64_t vb =
       int64_t(lj_data_end(S)) - (int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P);
@@ -253,9 +267,13 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
   L.ob[j] = 8u * uint32_t(valid > LJ_P ? LJ_P : valid);
   L.su[j] = prev; // su[] doubles as the "byte before the slot" array during staging
   __syncthreads();
+  if (report_marker)
+    K0_STAMP(1);
   if ((any != 0u || prev == 0xFFu) && !S.raw)
     L.list[atomicAdd(&L.misc[10], 1u)] = uint16_t(j);
   __syncthreads();
+  if (report_marker)
+    K0_STAMP(2);
   const uint32_t n = L.misc[10];
   if (uint32_t(j & ~63) < n) { // wave-uniform
     const bool mine = uint32_t(j) < n;
@@ -831,7 +849,9 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     if (!(e0.x & 0x80000000u) && code <= 8u && total >= 1u)
       lut8b = total;
   }
+  K0_STAMP(0);
   lj_stage_slots(L, a, S, s, lb, j, true); // ends with a barrier
+  K0_STAMP(3);
   uint4* __restrict__ dst = a.unstuffed + size_t(b) * LJ_IMG_U4;
   const uint4* src = reinterpret_cast<const uint4*>(L.B);
 #pragma unroll
@@ -877,7 +897,8 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     uint32_t* nlist = L.sm; // (the staging's 16 compaction selectors: done with)
     uint16_t* EU = EA;      // (after the B parses) the entry a slot's last parse started from
     uint16_t* ECNT = L.su;  // symbols of a slot's last parse (su[] is the staging's)
-    __syncthreads(); // every lane has written its part of the image out
+    lds_barrier(); // every lane has written its part of the image out
+    K0_STAMP(4);
     reinterpret_cast<uint32_t*>(lut8)[j] = lut_pk;
     if (mt) {
       reinterpret_cast<uint32_t*>(smem + LJ_K0_LUTB_OFF)[j] = lut_pk_b;
@@ -890,7 +911,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       nlist[j] = 0;
     if (j == 0)
       *est = 0;
-    __syncthreads();
+    lds_barrier();
     // (two tables: such a slot is the two zero codes in turn, a "code" of both lengths)
     uint32_t zi = uint32_t(__builtin_amdgcn_readfirstlane(
         int(a.fast_z[S.table_base + (mt ? S.tab_of_phase[0] : 0u)])));
@@ -943,7 +964,8 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     if (j == 0 && lb == 0)
       ea = S.start_bit & smask; // (the stream's first slot starts where the stream does)
     EA[j] = uint16_t(ea);
-    __syncthreads();
+    lds_barrier();
+    K0_STAMP(5);
     const uint32_t xa = j >= 1 ? uint32_t(EA[j - 1]) : 0u;
     uint32_t ebv = ea;
 #ifdef RSX_K0_X1 // (diagnostic build: the B parse without its count -- wrong counts, K0's time only)
@@ -985,7 +1007,8 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       return uint16_t((n > 0x7FFFu ? 0x7FFFu : n) | ((c >> 31) << 15));
     };
     ECNT[j] = pack_cnt(cnt);
-    __syncthreads(); // (every EA[j - 1] has been read: the array becomes EU)
+    lds_barrier(); // (every EA[j - 1] has been read: the array becomes EU)
+    K0_STAMP(6);
     EU[j] = uint16_t(xa);
     // the guess for slot j + 1 (lane 255's goes to the next workgroup's slot 1): stored now,
     // behind the rounds' parses, and again by the rounds for the slots they move -- stores
@@ -1011,7 +1034,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
         const uint32_t x = j >= 1 ? uint32_t(EB[j - 1]) : 0u;
         if (!constant && exists && j >= 1 && x != uint32_t(EU[j]))
           glist[atomicAdd(&nlist[4 + 2 * round], 1u)] = uint16_t(j);
-        __syncthreads();
+        lds_barrier();
         const uint32_t nth = nlist[4 + 2 * round];
         if (nth == 0)
           return true;
@@ -1033,13 +1056,14 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
           if (changed)
             nlist[5 + 2 * round] = 1u;
         }
-        __syncthreads();
+        lds_barrier();
         if (nlist[5 + 2 * round] == 0u) // (no exit moved: every successor's entry still stands)
           return true;
       }
       return false;
     };
     bool settled = run_rounds();
+    K0_STAMP(7);
 #ifndef RSX_K0_NO_FINAL_HANDOVER
     // (the hand-over once more, now that the rounds have run: marked final)
     if (K0_CHAIN && j == LJ_T - 1 && lb + 1 < S.n_blocks)
@@ -1077,12 +1101,12 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
       if (nlist[3] != 0u) { // the entry moved: the rounds once more (slot 1 is listed by the first)
-        __syncthreads(); // (everybody has read the word)
+        lds_barrier(); // (everybody has read the word)
         if (j >= 3 && j < 4 + 2 * int(LJ_GUESS_ROUNDS))
           nlist[j] = 0u;
-        __syncthreads();
+        lds_barrier();
         settled = run_rounds();
       }
     }
@@ -1124,7 +1148,8 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       c += uint32_t(__shfl_xor(int(c), o, 64));
     if ((j & 63) == 0)
       atomicAdd(est, c);
-    __syncthreads();
+    lds_barrier();
+    K0_STAMP(8);
     // The workgroup's word for the single-pass kernel's symbol base (LjArgs::k0w): symbols
     // of slots 1..255 (32 bits) | the exit of slot 0 the chain started from | bit 7: the
     // count is not to be trusted (16 bits) | the TRUE exit of slot 0 = the predecessor
@@ -1162,6 +1187,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       if (use)
         atomicMax(&a.fast_level[a.run_parity], use);
     }
+    K0_STAMP(9);
   }
 }
 
@@ -2745,6 +2771,7 @@ struct LJpegPlan {
   DeviceBuffer d_k0e;           // K0's hand-over words (LjArgs::k0e)
   bool any_fast = false;       // some stream takes the single-pass kernel
   uint32_t fast_lds = 0;       // LDS bytes of its launches
+  uint32_t fast_uniform_nb = 0, fast_rotate = 0; // (LjArgs)
   std::vector<uint8_t> slow_strikes; // per stream: consecutive runs it went to the slow path
   // streams taken off the single-pass kernel after two such runs: the value `fast` had and
   // the run in which it was cleared (0: not demoted).  The demotion DECAYS: a cached plan
@@ -2857,6 +2884,8 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.k0_chain = (p->any_fast_mt && p->d_k0e.ptr) ? 1u : 0u;
 #endif
   a.block_base0 = static_cast<uint32_t*>(p->d_block_base0.ptr);
+  a.fast_uniform_nb = p->fast_uniform_nb;
+  a.fast_rotate = p->fast_rotate;
   a.tickets = static_cast<uint32_t*>(p->d_tickets.ptr);
   a.fast_lds = p->fast_lds;
   {
@@ -3305,8 +3334,30 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       uint32_t max_blocks = 0;
       for (const LjStreamDev& S : p->streams)
         max_blocks = std::max(max_blocks, S.n_blocks);
+      // Since round 5 a workgroup's ticket is its block index (the dispatcher starts a 1-D
+      // grid's workgroups in order; every wait in the kernel is bounded), and block t runs on
+      // XCD t % 8.  With a multiple of 8 streams in plain round robin a stream would live on
+      // ONE XCD -- all its image loads, pixel stores and look-back polls through one L2
+      // (measured on cfg 3: the kernel +4-10 %) -- so the streams' turn rotates from group to
+      // group then; other counts spread a stream over 8 / gcd(streams, 8) XCDs by themselves.
+      const size_t ns = p->streams.size();
+#if defined(RSX_LF_ROTATE) && RSX_LF_ROTATE == 0
+      p->fast_rotate = 0;
+#elif defined(RSX_LF_ROTATE) && RSX_LF_ROTATE == 2
+      p->fast_rotate = 1;
+#else
+      p->fast_rotate = (ns % 8 == 0) ? 1u : 0u;
+#endif
+      p->fast_uniform_nb = max_blocks;
+      for (const LjStreamDev& S : p->streams)
+        if (S.n_blocks != max_blocks)
+          p->fast_uniform_nb = 0;
+#ifdef RSX_LF_NO_UNIFORM
+      p->fast_uniform_nb = 0;
+#endif
       for (uint32_t k = 0; k < max_blocks; ++k)
-        for (size_t si = 0; si < p->streams.size(); ++si)
+        for (size_t i0 = 0; i0 < ns; ++i0) {
+          const size_t si = p->fast_rotate ? (i0 + k) % ns : i0;
           if (k < p->streams[si].n_blocks)
             // (.z: the stream's first table | the tables of even / odd symbols << 24 / 28)
             order.push_back(make_uint4(p->streams[si].first_block + k, uint32_t(si),
@@ -3314,6 +3365,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
                                            (uint32_t(p->streams[si].tab_of_phase[0] & 15u) << 24) |
                                            (uint32_t(p->streams[si].tab_of_phase[1] & 15u) << 28),
                                        p->streams[si].first_block));
+        }
       if ((st = up(p->d_fast_order, order.data(), order.size() * sizeof(uint4))))
         return st;
       if ((st = up(p->d_fast_tabs, ft.data(), ft.size() * sizeof(uint2))) ||
@@ -3332,9 +3384,9 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       RSX_HIP_CHECK(ctx, hipMemset(p->d_fast_level.ptr, 0, 256));
 #ifdef RSX_EXPERIMENT
       if (getenv("RSX_DEBUG")) {
-        if ((st = p->d_dbg.ensure(size_t(p->total_blocks) * 16 * 8)))
+        if ((st = p->d_dbg.ensure(size_t(p->total_blocks) * 32 * 8)))
           return st;
-        (void)hipMemset(p->d_dbg.ptr, 0, size_t(p->total_blocks) * 16 * 8);
+        (void)hipMemset(p->d_dbg.ptr, 0, size_t(p->total_blocks) * 32 * 8);
       }
 #endif
     }
@@ -3663,8 +3715,18 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
       RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->d_streams.ptr, p->streams.data(),
                                         p->streams.size() * sizeof(LjStreamDev),
                                         hipMemcpyHostToDevice, s));
+      // (K0's hand-over words carry one parity bit as their epoch, and a demoted stream does
+      // not write its own: after an even number of runs the words of the run it was demoted
+      // in would pass for this run's.  Start the re-promoted streams from clean ones.)
+      if (p->d_k0e.ptr)
+        RSX_HIP_CHECK(ctx, hipMemsetAsync(p->d_k0e.ptr, 0, size_t(p->total_blocks + 1) * 4, s));
       RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
       p->any_fast = true;
+      // the demotion decays completely: what the first pass launches follows the streams
+      p->any_pipeline = false;
+      for (const LjStreamDev& S : p->streams)
+        p->any_pipeline |= S.fast == 0;
+      p->expect_slow = false;
     }
   }
   LjArgs a = make_args(p, in_dev, out_dev);
@@ -3698,7 +3760,16 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
     FastLaunch fl;
     fl.total_blocks = p->total_blocks;
     std::memcpy(fl.present, p->fast_present, sizeof fl.present);
+    // one single-pass launch of a context at a time (rsx_ctx::fast_mu)
+    std::lock_guard<std::mutex> g(ctx->fast_mu);
+    if (ctx->fast_ev_valid && ctx->fast_ev_stream != s)
+      RSX_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->fast_ev, 0));
     ljpeg_launch_fast(a, fl, s, p->timer);
+    if (!ctx->fast_ev)
+      RSX_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->fast_ev, hipEventDisableTiming));
+    RSX_HIP_CHECK(ctx, hipEventRecord(ctx->fast_ev, s));
+    ctx->fast_ev_valid = true;
+    ctx->fast_ev_stream = s;
   }
   // ... the multi-kernel pipeline for the others
   if (p->any_pipeline)
@@ -3998,6 +4069,46 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
         tot += n ? sum[k] / n : 0.0;
       }
       fprintf(stderr, "[rsx]   %-14s mean %7.2f us\n", "lifetime", tot);
+    }
+    {
+      // ... and of lj_unstuff_kernel's (second half of the array)
+      std::vector<unsigned long long> t0(size_t(p->total_blocks) * 16);
+      if (hipMemcpy(t0.data(), static_cast<unsigned long long*>(p->d_dbg.ptr) + size_t(p->total_blocks) * 16,
+                    t0.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+        static const char* nm0[10] = {"", "loads+park", "list", "un-stuff", "write-out+barrier",
+                                      "tables+A parse", "B parse", "rounds", "hand-over+count", "word+level"};
+        std::vector<float> all[10];
+        unsigned long long tmin = ~0ull, tmax = 0;
+        size_t n = 0;
+        for (uint32_t b = 0; b < p->total_blocks; ++b) {
+          const unsigned long long* r = &t0[size_t(b) * 16];
+          if (!r[0] || !r[9])
+            continue;
+          ++n;
+          tmin = std::min(tmin, r[0]);
+          tmax = std::max(tmax, r[9]);
+          unsigned long long prev = r[0];
+          for (int k = 1; k < 10; ++k) {
+            const unsigned long long cur = r[k] ? r[k] : prev;
+            all[k].push_back(float(double(cur - prev) / 2400.0));
+            prev = cur;
+          }
+        }
+        fprintf(stderr, "[rsx] K0 phases over %zu workgroups, kernel span %.1f us:\n", n,
+                n ? double(tmax - tmin) / 2400.0 : 0.0);
+        double tot = 0;
+        for (int k = 1; k < 10 && n; ++k) {
+          std::sort(all[k].begin(), all[k].end());
+          double sum = 0;
+          for (float v : all[k])
+            sum += v;
+          auto pct = [&](double q) { return double(all[k][size_t(q * (all[k].size() - 1))]); };
+          fprintf(stderr, "[rsx]   K0 %-18s mean %7.2f us  p50 %6.2f  p90 %6.2f  p99 %6.2f  max %8.2f us\n",
+                  nm0[k], sum / n, pct(0.5), pct(0.9), pct(0.99), double(all[k].back()));
+          tot += sum / n;
+        }
+        fprintf(stderr, "[rsx]   K0 %-14s mean %7.2f us\n", "lifetime", tot);
+      }
     }
     // K0's words: how many workgroups does the single-pass kernel have to ask for their count?
     std::vector<unsigned long long> kw(size_t(p->total_blocks) + 1);

@@ -129,6 +129,21 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return uint32_t(reinterpret_cast<uintptr_t>(
       (const __attribute__((address_space(3))) void*)(p)));
 }
+// Workgroup barrier that orders LDS accesses ONLY.  __syncthreads() is a workgroup-scope
+// release + acquire over every address space, and on gfx9 the release waits for the
+// acknowledgement of every global store (and the return of every load) the wavefront has in
+// flight -- s_waitcnt vmcnt(0) in front of the s_barrier: a workgroup that has just written
+// its slots out, or a guess, or a look-back record, stands still for a memory round trip at
+// its next barrier although nobody in the workgroup will ever read those bytes.  Use where
+// the lanes of a workgroup talk to one another through LDS alone.  (The compiler still waits
+// for a loaded value in front of its first use: it counts the loads itself.)
+#ifdef RSX_PLAIN_BARRIERS
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+#else
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+#endif
 // the difference sums of slot j (N components)
 template <int NS>
 __device__ __forceinline__ uint2 sm_get(const Lds& L, int j) {

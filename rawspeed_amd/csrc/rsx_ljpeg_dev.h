@@ -267,6 +267,12 @@ struct LjArgs {
                              // 0x8000 | run parity << 14 | the state the predecessor's chain ends in
   uint32_t k0_chain;         // != 0: K0 runs in block order and hands entry states over
   unsigned long long* dbg;   // experiment builds: [workgroup][16] phase time stamps
+  uint32_t fast_uniform_nb;  // != 0: every stream of the plan has this many workgroups, so the
+                             // single-pass kernel works its (stream, block) out of its block
+                             // index instead of loading fast_order's entry (one dependent
+                             // round trip less in front of its image loads)
+  uint32_t fast_rotate;      // != 0: the streams' turn inside a group of n_streams tickets
+                             // rotates from group to group (see ljpeg_plan_create)
   uint32_t fuse_consumed;    // != 0: lj_scan_kernel does lj_consumed_kernel's work as well
   uint32_t pass;             // 0: first pass; 1: the multi-kernel pipeline redoes FL_SLOW
                              // streams; 2: its streams of both passes

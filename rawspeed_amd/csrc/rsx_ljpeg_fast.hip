@@ -77,7 +77,7 @@ constexpr int LF_SIDE_STRIDE = 272;     // bytes: 128 x u16 + 16 (16-byte aligne
 constexpr int LF_RMAX = 256;            // stream rows that may start inside one workgroup
 constexpr uint32_t LF_MAX_ROUNDS = 6;   // re-decode rounds before the stream is given up
 constexpr int LF_K0_IT = 16;            // K0 words a lane asks for at once (4096 workgroups)
-constexpr uint32_t LF_SPIN_LIMIT = 1u << 22;
+constexpr uint32_t LF_SPIN_LIMIT = 1u << 17;    // passes of look-back 1 (~2 us each: a quarter of a second)
 constexpr uint32_t LF_SPIN_LIMIT_K0 = 1u << 15; // polls of a flagged predecessor's granule (~20 ms)
 // Ablation switches of experiment builds (scripts/exp_ab.py; wrong pixels, timing only):
 // 1 no staging + copy-out, 2 no copy-out, 4 no look-back 0, 8 no look-back 1, 16 no
@@ -170,6 +170,7 @@ __device__ __forceinline__ FastLds carve_fast(uint8_t* smem, uint32_t lds_bytes)
 }
 
 typedef uint32_t lf_u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t lf_u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) lf_u32x2* lds_u2p;
 typedef __attribute__((address_space(3))) uint16_t* lds_u16w;
 typedef __attribute__((address_space(3))) uint32_t* lds_u32w;
@@ -587,7 +588,7 @@ __device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint
         X[10 + k] = real ? uint32_t(wc[k]) : initw[k];
       }
     }
-    __syncthreads();
+    lds_barrier();
     int state = 0; // 0: all 256 LOCAL, 1: found an inclusive state, 2: blocked
     uint32_t Tf[NW], Vf[NW];
 #pragma unroll
@@ -619,7 +620,7 @@ __device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint
         }
       }
     }
-    __syncthreads(); // (the exchange words are free again)
+    lds_barrier(); // (the exchange words are free again)
     if (state == 1) {
       uint32_t to[2] = {0, 0}, vo[2] = {0, 0};
 #pragma unroll
@@ -808,8 +809,14 @@ __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
           for (int t = 0; t < 4; ++t)
             o[t] = pk_add(__builtin_amdgcn_alignbit(dw[t + 1], dw[t], sh), cd[t]);
           uint8_t* p = d0 + 16u * m;
-          if (sf >= 0 && uint32_t(sf) + 8u <= n) {
+          if (LF_ABLATE & 256u) { // (experiment: everything but the stores)
+            asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(p));
+          } else if (sf >= 0 && uint32_t(sf) + 8u <= n) {
+#ifdef RSX_LF_NT_STORE
+            __builtin_nontemporal_store(lf_u32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<lf_u32x4*>(p));
+#else
             *reinterpret_cast<uint4*>(p) = make_uint4(o[0], o[1], o[2], o[3]);
+#endif
           } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -929,6 +936,42 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // stream (measured: stale level words).  At level 0, the usual one, the ticket is taken
   // in the same round trip (every level has tickets of its own, on another cache line --
   // 15 000 atomics on one address take 0.17 ms, so the other levels ask first).
+#ifndef RSX_LF_TICKETS
+  // Round 5: the block index IS the ticket.  The dispatcher starts a 1-D grid's workgroups
+  // in order (lj_unstuff_kernel's hand-over relies on the same), so a predecessor in
+  // fast_order's sequence has started when its successor runs; an atomic ticket + its LDS
+  // broadcast + barrier stood in front of everything else a workgroup asks for, a dependent
+  // round trip of 1-2 us (and a queue of 1024 on one address at the kernel's start).  Every
+  // wait below is bounded, so an order the dispatcher did not keep costs time -- the stream
+  // goes to the multi-kernel pipeline --, never a hang or a pixel; the host keeps two LARGE
+  // single-pass launches of a context from running side by side (two grids that both fill
+  // the chip could each hold the slots the other's next workgroup needs: ljpeg_plan_run).
+  // Plans whose streams all have the same number of workgroups (frames of a batch, the tiles
+  // of a DNG) work (stream, block) out arithmetically: nothing stands in front of the image
+  // loads; the others read fast_order's entry first.
+  (void)TICKET0;
+  const uint32_t t_blk = blockIdx.x;
+  const uint32_t chosen_now = __hip_atomic_load(&a.fast_level[a.run_parity], __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t b, s, fb_now, tz_now = 0, tbv = 0, tpv = 0;
+  const bool uniform_plan = a.fast_uniform_nb != 0u;
+  if (uniform_plan) {
+    const uint32_t ns = a.n_streams, nb = a.fast_uniform_nb;
+    const uint32_t k = t_blk / ns, i = t_blk - k * ns;
+    s = a.fast_rotate ? (i + k % ns) % ns : i;
+    b = s * nb + k;
+    fb_now = s * nb;
+    // (the stream's tables: asked for now, looked at behind the image loads)
+    tbv = a.streams[s].table_base;
+    tpv = uint32_t(a.streams[s].tab_of_phase[0]) | (uint32_t(a.streams[s].tab_of_phase[1]) << 8);
+  } else {
+    const uint4 bs = a.fast_order[t_blk];
+    b = uni(bs.x);
+    s = uni(bs.y);
+    tz_now = uni(bs.z);
+    fb_now = uni(bs.w);
+  }
+#else
   if (j == 0) {
     uint32_t chosen, t = 0;
     if (level == 0) {
@@ -951,22 +994,30 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // stream's workgroups in flight; with one stream after the other that is everything on
   // the chip, and it pays the slowest of ~1000 -- interleaved, 1000 / streams.
   const uint4 bs = a.fast_order[uni(F.misc[M_TICKET])];
-  const uint32_t b = uni(bs.x), s = uni(bs.y), table_base = uni(bs.z) & 0xFFFFFFu;
+  const uint32_t b = uni(bs.x), s = uni(bs.y), fb_now = uni(bs.w);
+  uint32_t tz_now = uni(bs.z);
+#endif
   // The workgroup's image and the stream's flags are asked for NOW, next to the stream's
   // record: the head of a workgroup is a chain of dependent loads (ticket -> block ->
   // stream -> flags -> table and image, 0.7-1.5 us each); the ticket's entry names the
   // table, so nothing waits for the record.  (lj_load_image's loads for LF_BW rows, reversed: five uint4 a lane.)
   const uint4* __restrict__ img_src = a.unstuffed + size_t(b) * LJ_IMG_U4;
   const uint32_t flags_now = a.results[s].flags;
+  // (Every load of the head UNCONDITIONAL, on an address that is valid for every lane, and
+  // nothing done with a loaded value before the last of them is issued.  Until round 5 the
+  // fifth image load, the guess and the K0 words sat under lane conditions; the compiler put
+  // the first use of a loaded value -- a register copy, the guess's mask -- INTO those blocks,
+  // each behind an s_waitcnt vmcnt(0): the head was four memory round trips one after the
+  // other instead of one, 4-5 us of a workgroup's 25.)
+  static_assert(5 * LJ_T <= LJ_IMG_U4, "five uint4 a lane stay inside the block's image");
   uint4 im[5];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int i = k * LJ_T + j;
-    im[k] = i < LF_BW * LJ_T / 4 ? img_src[i] : make_uint4(0, 0, 0, 0);
-  }
+  for (int k = 0; k < 5; ++k)
+    im[k] = img_src[k * LJ_T + j]; // (rows 17..19 ride along in the last one: not parked)
   const uint32_t ob_now = reinterpret_cast<const uint32_t*>(img_src + (LJ_BW / 4) * LJ_T)[j];
-  // (a stream's subsequences are numbered from first_block * LJ_OWN: the guesses too)
-  const uint32_t guess_now = j >= 1 ? uint32_t(a.sub_start[size_t(b) * LJ_OWN + uint32_t(j - 1)]) : 0u;
+  // (a stream's subsequences are numbered from first_block * LJ_OWN: the guesses too; lane 0
+  // reads lane 1's and ignores it)
+  const uint32_t guess_raw = a.sub_start[size_t(b) * LJ_OWN + uint32_t(j >= 1 ? j - 1 : 0)];
   // Symbol base (round 4): K0 has counted every workgroup's symbols under the very entry
   // states this kernel decodes from (its chain's fixed point), so the index of the
   // workgroup's first symbol is a SUM the workgroup reads when it starts -- the words of
@@ -977,32 +1028,57 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // state is not what the predecessor's chain arrives at -- 1.7 % --, a code outside the
   // 10-bit table, data that does not synchronise); those workgroups' true counts are asked
   // for below, and they alone.  lj_scan_kernel checks every base afterwards.
-  const uint32_t fb_now = uni(bs.w), lb_now = b - fb_now;
+  const uint32_t lb_now = b - fb_now;
   u64 kw_mine = 0, kwv[LF_K0_IT];
   {
     const u64* kw = a.k0w + fb_now;
     kw_mine = kw[lb_now];
 #pragma unroll
     for (int it = 0; it < LF_K0_IT; ++it) {
+      // (words at and behind the workgroup's own are not its predecessors': dropped below)
       const uint32_t k = uint32_t(it) * uint32_t(LJ_T) + uint32_t(j);
-      kwv[it] = k < lb_now ? kw[k] : 0ull;
+      kwv[it] = kw[k < lb_now ? k : lb_now];
     }
   }
+#ifndef RSX_LF_TICKETS
+  if (uniform_plan) {
+    const uint32_t tb = uni(tbv), tp = uni(tpv);
+    tz_now = tb | ((tp & 15u) << 24) | (((tp >> 8) & 15u) << 28);
+  }
+#endif
+  const uint32_t table_base = tz_now & 0xFFFFFFu;
   uint4 lut_now[MT ? 4 : 2];
   {
-    const uint32_t t_even = MT ? ((uni(bs.z) >> 24) & 15u) : 0u;
+    const uint32_t t_even = MT ? ((tz_now >> 24) & 15u) : 0u;
     const uint4* src =
         reinterpret_cast<const uint4*>(a.fast_tabs + size_t(table_base + t_even) * 1024);
     lut_now[0] = src[j];
     lut_now[1] = src[j + LJ_T];
     if constexpr (MT) {
       const uint4* srb =
-          reinterpret_cast<const uint4*>(a.fast_tabs + size_t(table_base + (uni(bs.z) >> 28)) * 1024);
+          reinterpret_cast<const uint4*>(a.fast_tabs + size_t(table_base + (tz_now >> 28)) * 1024);
       lut_now[2] = srb[j];
       lut_now[3] = srb[j + LJ_T];
     }
   }
   const FastStream S = lf_stream(a.streams[s]);
+  // (Pin: every load above is ISSUED before the first exit below.  Left alone the compiler
+  // sinks the loads whose values the exits do not need -- tables, image -- behind them, i.e.
+  // behind the wait for the stream's record: one more round trip in a row.)
+  // (whole 16-byte registers: pinned by one component the compiler splits the load in two)
+  auto v4 = [](const uint4& x) -> lf_u32x4 { return lf_u32x4{x.x, x.y, x.z, x.w}; };
+  asm volatile("" ::"v"(v4(im[0])), "v"(v4(im[1])), "v"(v4(im[2])), "v"(v4(im[3])),
+               "v"(v4(im[4])), "v"(ob_now), "v"(guess_raw), "v"(kw_mine), "v"(flags_now),
+               "v"(v4(lut_now[0])), "v"(v4(lut_now[1])), "v"(v4(lut_now[MT ? 2 : 0])),
+               "v"(v4(lut_now[MT ? 3 : 1])));
+  asm volatile("" ::"v"(kwv[0]), "v"(kwv[1]), "v"(kwv[2]), "v"(kwv[3]), "v"(kwv[4]), "v"(kwv[5]),
+               "v"(kwv[6]), "v"(kwv[7]), "v"(kwv[8]), "v"(kwv[9]), "v"(kwv[10]), "v"(kwv[11]),
+               "v"(kwv[12]), "v"(kwv[13]), "v"(kwv[14]), "v"(kwv[15]));
+  static_assert(LF_K0_IT == 16, "the pin lists the K0 words one by one");
+#ifndef RSX_LF_TICKETS
+  if (uni(chosen_now) != level)
+    return; // this run's workgroups need another LDS level: that launch does the work
+#endif
   if (int(S.fast_n) != N || (S.mt != 0u) != MT)
     return; // (workgroup-uniform)
   const uint32_t lb = b - S.first_block;
@@ -1082,7 +1158,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   uint32_t kacc = 0, kflag = 0;
 #pragma unroll
   for (int it = 0; it < LF_K0_IT; ++it) {
-    const u64 w = kwv[it];
+    const u64 w = uint32_t(it) * uint32_t(LJ_T) + uint32_t(j) < lb_now ? kwv[it] : 0ull;
     kacc += uint32_t(w);
     const uint32_t hi = uint32_t(w >> 32);
     kflag |= (((hi >> 16) ^ hi) & 0xFFFFu) != 0x8000u ? (1u << it) : 0u;
@@ -1092,7 +1168,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
         lb_now > uint32_t(j) ? min(uint32_t(LF_K0_IT), (lb_now - uint32_t(j) + 255u) >> 8) : 0u;
     kflag &= (1u << nval) - 1u;
   }
-  __syncthreads();
+  lds_barrier();
   LF_STAMP(2);
   // delay the lane's column by one bit (see the header): dword k := d[k-1] : d[k] >> 1
   {
@@ -1127,7 +1203,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     reinterpret_cast<uint32_t*>(F.strips)[j] = strip_w0;
   if (uint32_t(j) + uint32_t(LJ_T) < strip_nw)
     reinterpret_cast<uint32_t*>(F.strips)[j + LJ_T] = strip_w1;
-  __syncthreads();
+  lds_barrier();
   LF_STAMP(3);
   const uint32_t own_bits = F.ob[j];
   // LDS address of the row of dword 0 of a column
@@ -1136,7 +1212,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // 1. the start guess: left by lj_unstuff_kernel (a parse of the three slots before the
   // lane's from bit 0; made in this kernel, from one or two slots, every slot parsed added
   // 6 us to the workgroup's lifetime)
-  const uint32_t guess = guess_now;
+  const uint32_t guess = j >= 1 ? guess_raw : 0u;
   LF_STAMP(4);
   uint32_t start = guess & SMASK;
   // slot 1 starts where the predecessor workgroup's chain ends (its lane 255 left it in this
@@ -1212,7 +1288,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     if (j == 0)
       F.misc[M_LIST] = 0;
   }
-  __syncthreads();
+  lds_barrier();
 
   const uint32_t gsub = S.first_subseq + lb * LJ_OWN + uint32_t(j - 1); // j >= 1
   uint32_t my_cnt = 0, before = 0, cnt_wg = 0, base = 0;
@@ -1235,7 +1311,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       if (!first_pass) {
         if (j == 0)
           F.misc[M_LIST] = 0;
-        __syncthreads();
+        lds_barrier();
       }
       const uint32_t my_su = rec_su(F.rec[j]);
       const uint32_t want = j >= 1 ? rec_st(F.rec[j - 1]) : my_su;
@@ -1262,7 +1338,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
         if (lane == 0)
           F.misc[M_WNE + wv] = uint32_t(__builtin_popcountll(am));
         const uint32_t handed = F.misc[M_NSIDE];
-        __syncthreads();
+        lds_barrier();
         uint32_t first = handed, all = handed;
         for (int w = 0; w < 4; ++w) {
           const uint32_t t = F.misc[M_WNE + w];
@@ -1289,7 +1365,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       if (listed && my_entry >= 0)
         F.list[atomicAdd(&F.misc[M_LIST], 1u)] = uint16_t(j | (my_entry << 8));
       need_redo = false;
-      __syncthreads();
+      lds_barrier();
       const uint32_t nl = (LF_ABLATE & 64u) ? 0u : uni(F.misc[M_LIST]);
       // (more re-decodes than the side buffer has entries, or data that does not
       // synchronise: what is left inconsistent is dealt with below)
@@ -1315,7 +1391,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
                            a.tables[S.table_base + S.tab_odd], int(idx), w, F.ob[idx],
                        lds_addr(F.side) + (le >> 8) * LF_SIDE_STRIDE, mine, e, c, sums, ovf);
       }
-      __syncthreads(); // every read of the records precedes the updates
+      lds_barrier(); // every read of the records precedes the updates
       if (mine) {
         F.rec[idx] = rec_make(w, e, c > 0xFFFu ? 0xFFFu : c);
         F.sm[idx] = sums;
@@ -1402,7 +1478,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       F.misc[M_WSUM + 2 * wv] = pincl_l.x;
       F.misc[M_WSUM + 2 * wv + 1] = pincl_l.y;
     }
-    __syncthreads();
+    lds_barrier();
     uint32_t wprev = 0, wrun = 0;
     uint2 sprev = make_uint2(0, 0);
     S_wg = make_uint2(0, 0);
@@ -1457,7 +1533,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       const uint32_t part = wave_sum_u32(kacc);
       if (lane == 0)
         F.misc[M_LBX + 8 + wv] = part;
-      __syncthreads();
+      lds_barrier();
       base = uni(F.misc[M_LBX + 8] + F.misc[M_LBX + 9] + F.misc[M_LBX + 10] + F.misc[M_LBX + 11]);
     } else {
       base = uni(F.misc[M_LBX] + F.misc[M_LBX + 1] + F.misc[M_LBX + 2] + F.misc[M_LBX + 3]);
@@ -1528,7 +1604,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   if (!fits && j == 0)
     F.misc[M_SLOW] = 8;
   const uint32_t sb = LF_STAGE_BASE;
-  __syncthreads(); // every lane is done with the image, the records and the side buffer
+  lds_barrier(); // every lane is done with the image, the records and the side buffer
   LF_STAMP(9);
   // does a delivered symbol lie in the part of the workgroup the rounds did not finish?
   // (behind the barrier: M_UNRESB comes from the lane that owns slot M_UNRES)
@@ -1567,7 +1643,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       *(lds_u16w)(ad + 2u * k) = uint16_t(v);
     }
   }
-  __syncthreads();
+  lds_barrier();
   LF_STAMP(10);
 
   // 7. rows.  Lane t takes stream row r0 + t: for each component whose first-MCU symbol
@@ -1599,7 +1675,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       F.misc[M_RSUM + 2 * wv] = dincl.x;
       F.misc[M_RSUM + 2 * wv + 1] = dincl.y;
     }
-    __syncthreads();
+    lds_barrier();
     uint2 vex = pk_sub2(dincl, D);
     for (int w = 0; w < 4; ++w) {
       const uint2 t = make_uint2(uni(F.misc[M_RSUM + 2 * w]), uni(F.misc[M_RSUM + 2 * w + 1]));
@@ -1611,7 +1687,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     if (uint32_t(j) < nr && nr <= uint32_t(LF_RMAX))
       F.ctab[j] = Cloc;
   }
-  __syncthreads();
+  lds_barrier();
   LF_STAMP(11);
   // 8a. the LOCAL record of look-back 1 (S_abs: the sums of the workgroup's differences by
   // absolute component)
@@ -1704,7 +1780,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     atomicOr(&a.results[s].stat_why, 1u << F.misc[M_SLOW]);
 #endif
   }
-  __syncthreads();
+  lds_barrier();
   LF_STAMP(13);
   LF_STAMP(14);
   // 9. copy-out
@@ -1760,6 +1836,10 @@ uint32_t ljpeg_fast_lds_for(uint64_t samples) {
   need = (need + 1279) / 1280 * 1280;
   if (need < 40960)
     need = 40960; // (four workgroups per CU take 40 KB each anyway)
+#ifdef RSX_LF_MIN_LDS // (experiment: fewer resident workgroups, for the residency slope)
+  if (need < RSX_LF_MIN_LDS)
+    need = RSX_LF_MIN_LDS;
+#endif
   return need <= 64 * 1024 ? uint32_t(need) : 0u; // (more needs hipFuncSetAttribute)
 }
 

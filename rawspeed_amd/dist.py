@@ -151,3 +151,42 @@ def distribute_units(grp, n_units, unit_bytes, assemble, mode, empty, sync=lambd
     grp.barrier()
     dt = grp.max_over_ranks(clock() - t0)
     return mine, dt, sum(shard_bytes) - shard_bytes[0]
+
+
+MODES = ("own_shard", "scatter", "broadcast")
+
+
+def distribute_all_modes(grp, n_units, unit_bytes, assemble, empty, own_shard, equal,
+                         sync=lambda: None, clock=None, modes=MODES):
+    """kernel-only scaling AND distribution-inclusive scaling in one run.  The
+    packed batch reaches a rank's HBM in up to three ways --
+
+      own_shard   the rank holds its shard already (synthesised / read by itself): no exchange
+      scatter     rank 0 holds the batch and sends rank r exactly ITS shard (point to point)
+      broadcast   rank 0 holds the batch and broadcasts all of it (BASELINE configs[4] as
+                  BASELINE.json words it); a rank keeps its slice
+
+    -- and every mode must leave the rank with the very bytes its plan expects, which
+    `equal(got, own_shard)` checks on the rank's device.  Returns (records, shards):
+    records[mode] = {"ms", "bytes", "gbps", "delivers_the_ranks_own_shard"} with ms the max
+    over the ranks, shards[mode] the rank's packed input as that mode delivered it."""
+    recs = {"own_shard": {"what": "every rank synthesises / holds its own shard: no exchange",
+                          "ms": 0.0, "bytes": 0, "gbps": None,
+                          "delivers_the_ranks_own_shard": True}}
+    shards = {"own_shard": own_shard}
+    for mode in modes:
+        if mode == "own_shard":
+            continue
+        got, dt, moved = distribute_units(grp, n_units, unit_bytes, assemble, mode, empty,
+                                          sync=sync, clock=clock)
+        same = bool(equal(got, own_shard))
+        all_same = grp.sum_over_ranks(1.0 if same else 0.0) == (grp.world if grp.enabled else 1)
+        recs[mode] = {
+            "what": ("grouped RCCL send/recv: rank 0 sends every other rank ITS shard (the "
+                     "shards differ in content and size)") if mode == "scatter" else
+                    "RCCL broadcast of the whole packed batch from rank 0; a rank keeps its slice",
+            "ms": round(dt * 1e3, 3), "bytes": int(moved),
+            "gbps": round(moved / max(dt, 1e-9) / 1e9, 2),
+            "delivers_the_ranks_own_shard": bool(all_same)}
+        shards[mode] = got
+    return recs, shards

@@ -67,6 +67,21 @@ def main():
         own0 = sum(unit(g).size for g in range(*dist.shard_range(n_units, grp.world, 0)))
         assert moved == (total_b if mode == "broadcast" else total_b - own0), (mode, moved)
         assert dt >= 0.0
+    # ... and the three-way record a default `bench.py --gpus N` puts in its line
+    # (dist.distribute_all_modes): own shard, scatter, broadcast -- all three present, every
+    # mode delivering the rank's own shard
+    def assemble2(units):
+        assert grp.rank == 0
+        return torch.from_numpy(np.concatenate([unit(g) for g in units] or [np.zeros(0, np.uint8)]))
+    recs, shards = dist.distribute_all_modes(
+        grp, n_units, lambda g: unit(g).size, assemble2,
+        lambda n: torch.zeros(n, dtype=torch.uint8), torch.from_numpy(want_mine.copy()),
+        lambda a, b: a.numpy().tobytes() == b.numpy().tobytes())
+    assert set(recs) == set(dist.MODES) == set(shards), recs
+    for mode in dist.MODES:
+        assert recs[mode]["delivers_the_ranks_own_shard"] is True, (mode, recs)
+        assert shards[mode].numpy().tobytes() == want_mine.tobytes(), mode
+    assert recs["own_shard"]["bytes"] == 0 and recs["broadcast"]["bytes"] > recs["scatter"]["bytes"] > 0
     grp.barrier()
     t_max = grp.max_over_ranks(0.5 + grp.rank)      # rank r "took" 0.5 + r seconds
     n_total = grp.sum_over_ranks(hi - lo)

@@ -58,11 +58,13 @@ def test_bench_self_launches_its_ranks():
     assert res["rccl_ranks"] == (n if n > 1 else 0)
 
 
-@pytest.mark.parametrize("mode", ["--scatter", "--broadcast"])
+@pytest.mark.parametrize("mode", ["", "--scatter", "--broadcast"])
 def test_bench_cfg5_distribution_over_rccl(mode):
     """The cfg-5 distribution path on RCCL when the box has at least two GPUs: rank 0
     hands the packed batch out (grouped send/recv of the shards, or one broadcast of the
-    whole batch whose shards differ), every rank decodes its shard bit-exactly."""
+    whole batch whose shards differ), every rank decodes its shard bit-exactly.  Without a
+    flag -- what the driver's scaling run is -- the ONE JSON line carries all three records
+    (own shard, scatter, broadcast: kernel-only and distribution-inclusive scaling apart)."""
     import torch
     n = min(torch.cuda.device_count(), 8)
     if n < 2:
@@ -71,11 +73,19 @@ def test_bench_cfg5_distribution_over_rccl(mode):
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(n),
            "--steps", "2", "--warmup", "1", "--frames", "1", "--no-extra", "--no-cpu-baseline",
-           "--cfg5-total-frames", str(2 * n), "--cfg5-distinct", "3", mode]
+           "--cfg5-total-frames", str(2 * n), "--cfg5-distinct", "3"] + ([mode] if mode else [])
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=1800)
     assert r.returncode == 0, r.stderr[-4000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     c5 = res["ljpeg"]["cfg5_batch_8192x5464"]
     assert res["n_gpus"] == n and c5["bit_exact"] is True
-    assert c5["frames_on_this_rank"] == 2 and "bytes" in c5["input_distribution"]
+    assert c5["frames_on_this_rank"] == 2 and res["rccl_ranks"] == n
+    d = c5["input_distribution"]
+    want = {"": {"own_shard", "scatter", "broadcast"}, "--scatter": {"own_shard", "scatter"},
+            "--broadcast": {"own_shard", "broadcast"}}[mode]
+    assert set(d) == want, d
+    for m in want - {"own_shard"}:
+        assert d[m]["bytes"] > 0 and d[m]["ms"] > 0 and d[m]["delivers_the_ranks_own_shard"] is True
+        assert d[m]["decoded_bit_exact"] is True
+        assert d[m]["mpix_per_s_incl_distribution"] < d["own_shard"]["mpix_per_s_incl_distribution"]
