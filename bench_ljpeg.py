@@ -540,6 +540,57 @@ def run_cfg4(ctx, torch, log, steps=10, warmup=2, cpu=True, variants=True):
     return res
 
 
+def run_ljpeg3(ctx, torch, log, steps=10, warmup=2):
+    """A linear (3 components per pixel) 8192x5464 DNG as 2x2 LJPEG tiles of 4096x2732, MCU
+    3 x 1 (LJpegDecompressor.cpp:102-105), one Huffman table: the single-pass kernel's <3>
+    instantiation (round 5; until then the legacy route with its int16 difference scratch).
+    Every tile is compared with the image it was written from."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    from rawspeed_amd import abi
+    W, H, tw, th = 8192, 5464, 4096, 2732
+    pitch = (W * 3 * 2 + 15) // 16 * 16
+    rng = np.random.default_rng(33)
+    jobs, parts, tiles, off, scan_total = [], [], [], 0, 0
+    for ty in range(2):
+        for tx in range(2):
+            d, data, tile_px, scan_len = cases.make_ljpeg_case(
+                rng, img_w=W, img_h=H, cpp=3, tile=(tx * tw, ty * th, tw, th), mcu=(3, 1))
+            pad = (-data.size) % 16
+            j = abi.LJpegJob()
+            j.desc = d
+            j.in_offset, j.in_bytes, j.img_offset = off, data.size, 0
+            j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = pitch, W, H, 3, 0
+            jobs.append(j)
+            parts.append(np.concatenate([data, np.zeros(pad, np.uint8)]))
+            tiles.append((tx, ty, tile_px, scan_len))
+            off += data.size + pad
+            scan_total += scan_len
+    inp = torch.from_numpy(np.concatenate(parts)).cuda()
+    out = torch.zeros(pitch * H, dtype=torch.uint8, device="cuda")
+    plan = ctx.ljpeg_plan(jobs)
+    dt, kt, cons = _time_plan(torch, plan, inp, out, steps, warmup)
+    got = out.cpu().numpy().view(np.uint16).reshape(H, pitch // 2)[:, :W * 3]
+    exact = list(cons) == [t[3] for t in tiles]
+    for tx, ty, tile_px, _ in tiles:
+        exact = exact and bool(np.array_equal(
+            got[ty * th:(ty + 1) * th, tx * tw * 3:(tx + 1) * tw * 3], tile_px))
+    plan.close()
+    alg = scan_total + W * H * 3 * 2
+    res = {"workload": "LJpegDecompressor, 3 components (MCU 3x1): linear 8192x5464 DNG as 2x2 "
+                       "tiles of 4096x2732, 1 frame/step",
+           "mpix_per_s": round(W * H / dt / 1e6, 1),
+           "msamples_per_s": round(W * H * 3 / dt / 1e6, 1),
+           "ms_per_step": round(dt * 1e3, 4), "bit_exact": exact,
+           "bit_exact_against": "the image every tile was written from",
+           "entropy_bits_per_sample": round(scan_total * 8 / (W * H * 3), 3),
+           "algorithmic_bytes_per_step": alg}
+    _dominant(res, kt)
+    _roofline(res, alg, dt, kt)
+    return res
+
+
 def cfg5_pick(g, distinct):
     """which of the `distinct` synthesised frames global frame g of the batch is (the
     rotation makes the shards of consecutive ranks differ)"""
@@ -1103,6 +1154,42 @@ def run_host_path(torch, log, reps=7):
     res4["openmp_threads"] = nt4
     res4["rsx_calls_per_decompress"] = round((rsx.rsx_host_calls() - calls0) / (reps + 1), 2)
     out["cfg4_dng_tiles_8192x5464"] = res4
+    # The same three calls with page-locked buffers (rsx.h: rsx_host_alloc / rsx_host_register,
+    # INTEGRATION.md 6): the images come from the pool behind the patched AlignedAllocator
+    # (what RawImageData::createData allocates from), the input arrays are registered in place
+    # -- what an application does with its file buffer.
+    try:
+        from rawspeed_amd import capi
+        if rsx.set_pinned_pool(True):
+            cx = capi.Context(0)
+            pinned = {}
+            for key, W_, H_, data_, call, want in (
+                    ("cfg2_unpack_14bit_8192x5464", 8192, 5464, packed,
+                     lambda im: rsx.unpack(d, packed, im), px),
+                    ("cfg3_cr2_6720x4480", 6720, 4480, data3,
+                     lambda im: rsx.cr2(d3, data3, im)[0], src3),
+                    ("cfg4_dng_tiles_8192x5464", 8192, 5464, None,
+                     lambda im: rsx.dng(im, 7, tw, th, blobs, threads=nt4), src4)):
+                arrays = [data_] if data_ is not None else list(blobs)
+                reg = [a for a in arrays if cx.host_register(a) == 0]
+                im = rsx.image(W_, H_, 1)   # (allocated with the pool on: page-locked)
+                call(im)
+                dt = timed(lambda: call(im))
+                n_in = sum(a.size for a in arrays)
+                pinned[key] = {"ms_per_call": round(dt * 1e3, 3),
+                               "mpix_per_s": round(W_ * H_ / dt / 1e6, 1),
+                               "link_gbps": round((n_in + W_ * H_ * 2) / dt / 1e9, 1),
+                               "inputs_registered": len(reg) == len(arrays),
+                               "bit_exact": bool(np.array_equal(im.pixels(), want)),
+                               "ms_per_call_pageable": out[key]["ms_per_call"]}
+                del im
+                for a in reg:
+                    cx.host_unregister(a)
+            out["page_locked_buffers"] = pinned
+            rsx.set_pinned_pool(False)
+            cx.close()
+    except Exception as e:
+        out["page_locked_buffers"] = {"error": repr(e)}
     return out
 
 
@@ -1120,6 +1207,7 @@ def run(ctx, torch, log):
     leg("cfg3_uniform_random_14bit", lambda: run_cfg3_uniform(ctx, torch, log))
     leg("cfg3_clipped_highlights", lambda: run_clipped(ctx, torch, log))
     leg("cfg4_dng_tiles_8192x5464", lambda: run_cfg4(ctx, torch, log))
+    leg("ljpeg_3comp_8192x5464", lambda: run_ljpeg3(ctx, torch, log))
     leg("nikon_lossless14_6016x4016", lambda: run_nikon(ctx, torch, log))
     leg("hasselblad_8272x6200", lambda: run_hasselblad(ctx, torch, log))
     leg("sony_arw1_3881x2608", lambda: run_sony_arw1(ctx, torch, log))
@@ -1157,6 +1245,8 @@ if __name__ == "__main__":
                          indent=1))
     elif args.only == "sony":
         print(json.dumps(run_sony_arw1(ctx, torch, print, steps=args.steps), indent=1))
+    elif args.only == "ljpeg3":
+        print(json.dumps(run_ljpeg3(ctx, torch, print, steps=args.steps), indent=1))
     elif args.only == "pentax":
         print(json.dumps(run_pentax(ctx, torch, print, frames=args.frames, steps=args.steps,
                                     cpu=not args.no_cpu), indent=1))

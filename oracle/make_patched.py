@@ -326,7 +326,23 @@ HUNK_DNG = r'''
   if (!rsxDone)
 '''
 
+# INTEGRATION.md 6 (optional): large AlignedAllocator blocks -- the pixel store of
+# RawImageData::createData(), common/RawImage.cpp:68-100 -- from a pool of page-locked memory
+HUNK_ALLOC = r'''
+    // rsx drop-in (optional, off by default): page-locked blocks for large buffers
+    if (void* rsxP = rsx_shim::pool_alloc(numBytes))
+      return static_cast<T*>(rsxP);
+'''
+
+HUNK_DEALLOC = r'''
+    if (rsx_shim::pool_free(p)) // rsx drop-in: one of the pool's blocks
+      return;
+'''
+
 PATCHES = [
+    ("adt/AlignedAllocator.h", [
+        ("    std::size_t numBytes = sizeof(T) * numElts;\n", HUNK_ALLOC),
+        ("    invariant(isAligned(p, alignment));\n", HUNK_DEALLOC)], "rsx_pin.h"),
     ("decompressors/AbstractDngDecompressor.cpp", [
         ("void AbstractDngDecompressor::decompress() const {", HUNK_DNG)]),
     ("decompressors/UncompressedDecompressor.cpp", [
@@ -358,7 +374,9 @@ PATCHES = [
 
 
 def main():
-    for rel, hunks in PATCHES:
+    for entry in PATCHES:
+        rel, hunks = entry[0], entry[1]
+        include = entry[2] if len(entry) > 2 else "rsx_rawspeed_shim.h"
         orig = open(os.path.join(S, rel)).read()
         # Insertions, applied back to front so that the offsets stay those of the original.
         # Every insertion ends with a #line directive that restores the original line
@@ -367,8 +385,8 @@ def main():
         # falls through to the original body reads the same as in the unmodified build.
         edits = []
         ns = orig.index("namespace rawspeed {")
-        edits.append((ns, '#include "rsx_rawspeed_shim.h" // rsx drop-in\n#line %d\n'
-                      % (orig.count("\n", 0, ns) + 1)))
+        edits.append((ns, '#include "%s" // rsx drop-in\n#line %d\n'
+                      % (include, orig.count("\n", 0, ns) + 1)))
         for anchor, hunk in hunks:
             if orig.count(anchor) != 1:
                 raise SystemExit("anchor %r not found exactly once in %s" % (anchor, rel))

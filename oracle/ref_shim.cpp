@@ -126,6 +126,18 @@ const char* ref_last_error() { return g_last_error.c_str(); }
 
 void ref_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 
+// the optional page-locked pool behind AlignedAllocator (patched build
+// only; -1 where the build has no such thing)
+int ref_set_pinned_pool(int on) {
+#ifdef RSX_PATCHED_BUILD
+  rawspeed::rsx_shim::set_pinned_pool(on != 0);
+  return on != 0;
+#else
+  (void)on;
+  return -1;
+#endif
+}
+
 // The image's ErrorLog (what AbstractDngDecompressor's tile threads append to),
 // newline-separated, so that the tests can compare it between the two builds.
 int ref_image_errors(void* h, char* out, int cap) {

@@ -2764,6 +2764,7 @@ struct LJpegPlan {
   bool sync_present[2][5] = {};   // [several tables][fused-path components, 0 = legacy]
   bool direct_present[2][5] = {}; // fused path: [several tables][components]
   bool any_direct = false, any_legacy = false;
+  bool any_fast_legacy = false; // legacy-route streams on the single-pass kernel (3 components)
   bool legacy_fallback_ready = false; // difference scratch of the fused streams allocated
   // single-pass path (rsx_ljpeg_fast.hip)
   bool fast_present[2][5] = {}; // [two alternating tables][components]
@@ -3115,6 +3116,20 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
               g.row_samples >= g.n_comp)
                  ? (J.n_tables == 1 ? 1 : 2)
                  : 0;
+    // Round 5: THREE interleaved components (MCU 3 x 1: linear DNG, LJpegDecompressor.cpp:
+    // 102-105) with one table on the single-pass kernel's <3> instantiation -- the rotation
+    // of the component sums by symbol counts mod 3 spelt out.  Such a stream is not one of
+    // the fused multi-kernel path (direct stays 0: that path's kernels are for 1, 2 and 4
+    // components), so a stream the kernel gives up on is redone by the legacy route, whose
+    // difference scratch it keeps.
+#ifndef RSX_NO_FAST3
+    const bool fast3 = !direct_n && g.kind == 0 && !g.raw && !g.las && !g.pair &&
+                       !g.no_vertical && g.n_comp == 3 && g.period == 3 && g.mcu_h == 1 &&
+                       g.mcu_w == 3 && J.n_tables == 1 && J.explicit_n == 0 &&
+                       g.row_samples >= 3 && g.row_samples % 3 == 0;
+    if (fast3)
+      S.fast = 1;
+#endif
     if (S.fast) {
       // its workgroups stage all their samples in LDS at once: the allocation follows the
       // stream's symbols per workgroup (+ 15 % for local variation; a workgroup that
@@ -3226,7 +3241,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     if (S.fast) {
       p->any_fast = true;
       p->any_fast_mt |= S.fast == 2;
-      p->fast_present[S.fast == 2 ? 1 : 0][S.direct] = true;
+      p->fast_present[S.fast == 2 ? 1 : 0][S.direct ? S.direct : g.n_comp] = true;
     } else {
       p->any_pipeline = true;
     }
@@ -3234,7 +3249,12 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       p->any_direct = true;
       p->direct_present[multi ? 1 : 0][S.direct] = true;
     } else {
-      p->any_legacy = true;
+      // (a legacy-route stream the single-pass kernel takes first -- 3 components -- needs
+      // the route's launches only in the pass that redoes what that kernel gave up on)
+      if (S.fast)
+        p->any_fast_legacy = true;
+      else
+        p->any_legacy = true;
       // stream-ordered int16 scratch of the legacy route
       S.diff_offset = p->total_diffs;
       p->total_diffs += ((g.pair ? 2 * needed : needed) + 7 + 8) & ~uint64_t(7);
@@ -3398,6 +3418,11 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
          (st = p->d_block_pbase.ensure(size_t(p->total_blocks) * 8)) ||
          (st = p->d_row_edge.ensure(size_t(p->total_rows) * 16 + 16))))
       return st;
+    // (the single-pass kernel leaves its workgroups' difference sums there whatever route
+    // its streams fall back to: 3-component streams are not fused-path streams)
+    if (p->any_fast && !p->d_block_psum.ptr &&
+        (st = p->d_block_psum.ensure(size_t(p->total_blocks) * 8)))
+      return st;
     p->h_results.resize(p->streams.size());
   }
   *out = p.release();
@@ -3440,8 +3465,10 @@ void launch_synchronisation(LJpegPlan* p, const LjArgs& a, hipStream_t s) {
 
 // everything after synchronisation and the scan: decode, reconstruct, consumed
 // (pipeline: some stream of this launch takes the multi-kernel pipeline)
+// (legacy, bits: 1 the plan's legacy-route streams, first pass; 2 those the single-pass kernel
+// takes first and gave up on, second pass; 0 none)
 int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s, bool pipeline = true,
-                bool legacy = true) {
+                int legacy = 1) {
   rsx_ctx* ctx = p->ctx;
   const uint32_t n_streams = uint32_t(p->streams.size());
   if (p->any_direct && pipeline) {
@@ -3453,7 +3480,7 @@ int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s, bool pipeline = tr
     std::memcpy(dl.present, p->direct_present, sizeof dl.present);
     ljpeg_launch_direct(a, dl, s, p->timer);
   }
-  if (p->any_legacy && legacy)
+  if (((legacy & 1) && p->any_legacy) || ((legacy & 2) && p->any_fast_legacy))
     launch_legacy(p, p->legacy, a, s);
   if (!a.fuse_consumed) {
     hipLaunchKernelGGL(lj_consumed_kernel, dim3(n_streams), dim3(64), 0, s, a);
@@ -3473,7 +3500,7 @@ int launch_slow_pass(LJpegPlan* p, hipStream_t s) {
   hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
   mark(p, "lj_scan_kernel");
   p->slow_pass_launched = true;
-  return launch_tail(p, a, s, true, false);
+  return launch_tail(p, a, s, true, 2);
 }
 
 } // namespace
@@ -3724,8 +3751,12 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
       p->any_fast = true;
       // the demotion decays completely: what the first pass launches follows the streams
       p->any_pipeline = false;
-      for (const LjStreamDev& S : p->streams)
+      p->any_legacy = p->any_fast_legacy = false;
+      for (const LjStreamDev& S : p->streams) {
         p->any_pipeline |= S.fast == 0;
+        p->any_legacy |= !S.fast && !S.direct;
+        p->any_fast_legacy |= S.fast && !S.direct;
+      }
       p->expect_slow = false;
     }
   }
@@ -3854,8 +3885,12 @@ int converge(LJpegPlan* p, hipStream_t s) {
       RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
       p->any_pipeline = true;
       p->any_fast = false;
-      for (const LjStreamDev& S : p->streams)
+      p->any_fast_legacy = false;
+      for (const LjStreamDev& S : p->streams) {
         p->any_fast |= S.fast != 0;
+        p->any_legacy |= !S.fast && !S.direct;
+        p->any_fast_legacy |= S.fast && !S.direct;
+      }
       p->expect_slow = false;
       for (size_t k = 0; k < p->streams.size(); ++k)
         p->expect_slow |= p->streams[k].fast && (p->h_results[k].flags & FL_SLOW);
@@ -3953,7 +3988,7 @@ int converge(LJpegPlan* p, hipStream_t s) {
   RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->d_results.ptr, p->h_results.data(),
                                     p->h_results.size() * sizeof(LjResult),
                                     hipMemcpyHostToDevice, s));
-  if (int st = launch_tail(p, a, s))
+  if (int st = launch_tail(p, a, s, true, 3))
     return st;
   if (int st = fetch())
     return st;

@@ -459,6 +459,14 @@ template <int N>
 __device__ __forceinline__ uint2 lj_rot_fields(uint2 v, uint32_t f) {
   if (N == 1)
     return v;
+  if (N == 3) {
+    // three fields of a 48-bit word (field 3 stays 0): f = 1: (f2, f0, f1), f = 2: (f1, f2, f0)
+    const uint64_t w = (uint64_t(v.x) | (uint64_t(v.y) << 32)) & 0xFFFFFFFFFFFFull;
+    const uint64_t r = f == 0u ? w
+                               : (f == 1u ? ((w << 16) | (w >> 32)) : ((w << 32) | (w >> 16))) &
+                                     0xFFFFFFFFFFFFull;
+    return make_uint2(uint32_t(r), uint32_t(r >> 32));
+  }
   if (N == 2) {
     const uint32_t x = (f & 1u) ? __builtin_amdgcn_alignbit(v.x, v.x, 16) : v.x;
     return make_uint2(x, 0u);

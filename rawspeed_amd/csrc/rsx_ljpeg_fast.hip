@@ -221,6 +221,11 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) { // (uniform resul
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) { // (uniform result)
   return uint32_t(__builtin_amdgcn_readlane(int(wave_scan_u32(x, 0)), 63));
 }
+// index mod N (N = 1, 2, 4: a mask; N = 3 -- round 5 -- a division by a constant)
+template <int N>
+__device__ __forceinline__ uint32_t lf_mod(uint32_t x) {
+  return (N & (N - 1)) == 0 ? (x & uint32_t(N - 1)) : x % uint32_t(N);
+}
 // 16-bit field q (0..3) of a packed uint2
 __device__ __forceinline__ uint32_t fld(uint2 v, uint32_t q) {
   return (((q & 2u) ? v.y : v.x) >> (16u * (q & 1u))) & 0xFFFFu;
@@ -320,22 +325,25 @@ __device__ __forceinline__ void lf_step_mt(FastState& s, uint32_t vbase, uint32_
   s.n += 1;
 }
 
-template <int N, int K, int KEND, bool MT = false>
+// (KB: symbols of the lane in front of this group of eight -- the component of step K is
+// (KB + K) mod N, which is K mod N for 1, 2 and 4 components and not for 3)
+template <int N, int K, int KEND, bool MT = false, int KB = 0>
 struct LfChain {
   static __device__ __forceinline__ void run(FastState& s, uint32_t vbase, uint32_t pend,
                                              uint32_t (&R)[LF_NR], int qbase, uint32_t lut0,
                                              uint32_t lut1) {
+    constexpr int C = (KB + K) % N;
     if (s.Pn > pend) {
       if constexpr (MT)
         lf_step_mt<N, K>(s, vbase, lut0, lut1);
       else
-        lf_step<N, K>(s, vbase);
+        lf_step<N, C>(s, vbase);
       if ((K & 1) == 0)
-        s.ev = s.acc[K % N];
+        s.ev = s.acc[C];
       else
-        R[qbase + (K >> 1)] = pack16(s.ev, s.acc[K % N]);
+        R[qbase + (K >> 1)] = pack16(s.ev, s.acc[C]);
       if constexpr (K + 1 < KEND)
-        LfChain<N, K + 1, KEND, MT>::run(s, vbase, pend, R, qbase, lut0, lut1);
+        LfChain<N, K + 1, KEND, MT, KB>::run(s, vbase, pend, R, qbase, lut0, lut1);
     }
   }
 };
@@ -345,7 +353,7 @@ __device__ __forceinline__ void lf_groups(FastState& s, uint32_t vbase, uint32_t
                                           uint32_t (&R)[LF_NR], uint32_t lut0 = 0,
                                           uint32_t lut1 = 0) {
   if (__any(s.Pn > pend)) {
-    LfChain<N, 0, 8, MT>::run(s, vbase, pend, R, 4 * G, lut0, lut1);
+    LfChain<N, 0, 8, MT, 8 * G>::run(s, vbase, pend, R, 4 * G, lut0, lut1);
     if constexpr (G + 1 < LF_MAXSYM / 8)
       lf_groups<N, G + 1, MT>(s, vbase, pend, R, lut0, lut1);
   }
@@ -406,7 +414,7 @@ __device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds& tb,
   bool ok = !(start & ST_ERR);
   if (!ok || !enabled)
     Pn = pend; // no steps
-  uint32_t n = 0, a0 = 0, a1 = 0;
+  uint32_t n = 0, a0 = 0, a1 = 0, ph3 = 0;
   uint32_t odd = MT ? ((start >> ST_PHASE_SHIFT) & 1u) : 0u; // (two tables: which one is next)
   while (Pn > pend) {
     const uint32_t ad = vbase + (Pn & ~1023u);
@@ -443,6 +451,16 @@ __device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds& tb,
     } else if (N == 2) {
       a0 = pk_add(a0, d << sh);
       val = (a0 >> sh) & 0xFFFFu;
+    } else if (N == 3) {
+      // (component = n mod 3, kept as a counter; fields 0, 1 in a0, field 2 in a1)
+      if (ph3 == 2u) {
+        a1 = (a1 + d) & 0xFFFFu;
+        val = a1;
+      } else {
+        a0 = pk_add(a0, d << (16u * ph3));
+        val = (a0 >> (16u * ph3)) & 0xFFFFu;
+      }
+      ph3 = ph3 == 2u ? 0u : ph3 + 1u;
     } else {
       if (n & 2u)
         a1 = pk_add(a1, d << sh);
@@ -664,7 +682,9 @@ __device__ __forceinline__ uint64_t uni64(uint64_t x) {
 }
 __device__ __forceinline__ FastStream lf_stream(const LjStreamDev& S) {
   FastStream f;
-  f.fast_n = uni(S.fast ? uint32_t(S.direct) : 0u);
+  // (3 components, round 5: not a stream of the fused multi-kernel path -- direct == 0 --, so
+  // the number of components says which instantiation takes it)
+  f.fast_n = uni(S.fast ? (S.direct ? uint32_t(S.direct) : S.n_comp) : 0u);
   f.mt = uni(S.fast == 2 ? 1u : 0u);
   f.tab_even = uni(f.mt ? uint32_t(S.tab_of_phase[0]) : 0u);
   f.tab_odd = uni(f.mt ? uint32_t(S.tab_of_phase[1]) : 0u);
@@ -784,12 +804,19 @@ __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
       n = A1 - i;
     if (dst) {
       const uint32_t delta = uint32_t(reinterpret_cast<uintptr_t>(dst) & 15u) >> 1;
-      const uint32_t ph0 = (i + 8u - delta) & uint32_t(N - 1);
-      uint32_t cd[4];
+      // (the component of a chunk's first sample: i + 8 m - delta mod N -- the same for every
+      // chunk m of the run while 8 is a multiple of N; N = 3: three sets of constants, the
+      // chunk takes the one of its m mod 3)
+      const uint32_t ph0 = lf_mod<N>(i + (N == 3 ? 9u : 8u) - delta); // (delta <= 7)
+      uint32_t cd[4], cd1[4], cd2[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        cd[t] = fld(C, (ph0 + 2u * t) & uint32_t(N - 1)) |
-                (fld(C, (ph0 + 2u * t + 1u) & uint32_t(N - 1)) << 16);
+      for (int t = 0; t < 4; ++t) {
+        cd[t] = fld(C, lf_mod<N>(ph0 + 2u * t)) | (fld(C, lf_mod<N>(ph0 + 2u * t + 1u)) << 16);
+        if (N == 3) { // (8 m mod 3 = 2 m mod 3: m mod 3 = 1 shifts the phase by 2, = 2 by 1)
+          cd1[t] = fld(C, lf_mod<N>(ph0 + 2u + 2u * t)) | (fld(C, lf_mod<N>(ph0 + 3u + 2u * t)) << 16);
+          cd2[t] = fld(C, lf_mod<N>(ph0 + 1u + 2u * t)) | (fld(C, lf_mod<N>(ph0 + 2u + 2u * t)) << 16);
+        }
+      }
       const uint32_t nch = (delta + n + 7u) >> 3;
       const uint32_t lds0 = sb + 2u * (i - A0) - 2u * delta;
       const uint32_t sh = 8u * (lds0 & 2u); // the staged samples start mid-dword: 16, else 0
@@ -805,9 +832,12 @@ __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
           for (int t = 0; t < 5; ++t)
             dw[t] = *(lds_u32p)(la + 4u * t);
           uint32_t o[4];
+          const uint32_t m3 = N == 3 ? m % 3u : 0u;
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            o[t] = pk_add(__builtin_amdgcn_alignbit(dw[t + 1], dw[t], sh), cd[t]);
+          for (int t = 0; t < 4; ++t) {
+            const uint32_t cc = N == 3 ? (m3 == 0u ? cd[t] : (m3 == 1u ? cd1[t] : cd2[t])) : cd[t];
+            o[t] = pk_add(__builtin_amdgcn_alignbit(dw[t + 1], dw[t], sh), cc);
+          }
           uint8_t* p = d0 + 16u * m;
           if (LF_ABLATE & 256u) { // (experiment: everything but the stores)
             asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(p));
@@ -867,12 +897,17 @@ __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
 // experiment, profiles/r04).  The lanes that still have pair q are a SUBSET of those that
 // had pair q - 1, so v_cmpx (it writes EXEC) only ever narrows the set: no branch, no
 // restore inside the group; 18 instructions for four pairs.
-template <int Q4>
+template <int N, int Q4>
 __device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad, uint32_t nq,
-                                         uint32_t nqmax, uint32_t k0, uint32_t k1) {
+                                         uint32_t nqmax, uint32_t kk0, uint32_t kk1,
+                                         uint32_t kk2) {
   if (uint32_t(4 * Q4) < nqmax) { // (wave-uniform)
     uint64_t saved;
     uint32_t t;
+    // the constants of pairs 4 Q4 .. 4 Q4 + 3 (static choices: see the caller)
+    const uint32_t kq[3] = {kk0, kk1, kk2};
+    const uint32_t k0 = N == 3 ? kq[(4 * Q4) % 3] : kk0, k1 = N == 3 ? kq[(4 * Q4 + 1) % 3] : kk1,
+                   k2 = N == 3 ? kq[(4 * Q4 + 2) % 3] : kk0, k3 = N == 3 ? kq[(4 * Q4 + 3) % 3] : kk1;
     asm volatile("s_mov_b64 %[sv], exec\n\t"
                  "v_cmpx_lt_u32_e32 vcc, %[q0], %[nq]\n\t"
                  "v_pk_add_u16 %[t], %[r0], %[k0]\n\t"
@@ -883,16 +918,17 @@ __device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad
                  "ds_write_b16 %[ad], %[t] offset:%[o1]\n\t"
                  "ds_write_b16_d16_hi %[ad], %[t] offset:%[o1h]\n\t"
                  "v_cmpx_lt_u32_e32 vcc, %[q2], %[nq]\n\t"
-                 "v_pk_add_u16 %[t], %[r2], %[k0]\n\t"
+                 "v_pk_add_u16 %[t], %[r2], %[k2]\n\t"
                  "ds_write_b16 %[ad], %[t] offset:%[o2]\n\t"
                  "ds_write_b16_d16_hi %[ad], %[t] offset:%[o2h]\n\t"
                  "v_cmpx_lt_u32_e32 vcc, %[q3], %[nq]\n\t"
-                 "v_pk_add_u16 %[t], %[r3], %[k1]\n\t"
+                 "v_pk_add_u16 %[t], %[r3], %[k3]\n\t"
                  "ds_write_b16 %[ad], %[t] offset:%[o3]\n\t"
                  "ds_write_b16_d16_hi %[ad], %[t] offset:%[o3h]\n\t"
                  "s_mov_b64 exec, %[sv]"
                  : [sv] "=&s"(saved), [t] "=&v"(t)
-                 : [nq] "v"(nq), [ad] "v"(ad), [k0] "v"(k0), [k1] "v"(k1), [r0] "v"(R[4 * Q4]),
+                 : [nq] "v"(nq), [ad] "v"(ad), [k0] "v"(k0), [k1] "v"(k1), [k2] "v"(k2),
+                   [k3] "v"(k3), [r0] "v"(R[4 * Q4]),
                    [r1] "v"(R[4 * Q4 + 1]), [r2] "v"(R[4 * Q4 + 2]), [r3] "v"(R[4 * Q4 + 3]),
                    [q0] "n"(4 * Q4), [q1] "n"(4 * Q4 + 1), [q2] "n"(4 * Q4 + 2),
                    [q3] "n"(4 * Q4 + 3), [o0] "n"(16 * Q4), [o0h] "n"(16 * Q4 + 2),
@@ -900,7 +936,7 @@ __device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad
                    [o2h] "n"(16 * Q4 + 10), [o3] "n"(16 * Q4 + 12), [o3h] "n"(16 * Q4 + 14)
                  : "vcc", "memory");
     if constexpr (Q4 + 1 < LF_NR / 4)
-      lf_stage<Q4 + 1>(R, ad, nq, nqmax, k0, k1);
+      lf_stage<N, Q4 + 1>(R, ad, nq, nqmax, kk0, kk1, kk2);
   }
 }
 
@@ -923,7 +959,7 @@ __device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad
 template <int N, bool MT>
 __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds_bytes,
                                                           uint32_t level) {
-  constexpr uint32_t TICKET0 = (MT ? 12u : 0u) + (N == 4 ? 2u : uint32_t(N) - 1u);
+  constexpr uint32_t TICKET0 = (MT ? 12u : 0u) + (N == 4 ? 2u : (N == 3 ? 3u : uint32_t(N) - 1u));
   constexpr uint32_t SMASK = MT ? 0x7Fu : ST_OFF_MASK; // offset (| table of the next symbol)
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const FastLds F = carve_fast(smem, lds_bytes);
@@ -1421,6 +1457,8 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       my_sums = make_uint2(my_sums.x & 0xFFFFu, 0u);
     if (N == 2)
       my_sums.y = 0u;
+    if (N == 3)
+      my_sums.y &= 0xFFFFu;
     // (the symbol base rides on the same barrier: K0's counts of the workgroups in front, read
     // at the start, + the corrections of the flagged ones asked for behind the decode.  What
     // is still missing then -- flagged workgroups that were in flight themselves -- is asked
@@ -1471,7 +1509,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     // front are applied to the scanned values afterwards)
     const uint32_t incl = wave_scan_u32(my_cnt, lane);
     const uint32_t lbef = incl - my_cnt;
-    const uint2 r_l = lj_rot_fields<N>(my_sums, lbef & uint32_t(N - 1));
+    const uint2 r_l = lj_rot_fields<N>(my_sums, lf_mod<N>(lbef));
     const uint2 pincl_l = wave_scan_pk2(r_l, lane);
     if (lane == 63) {
       F.misc[M_WCNT + wv] = incl;
@@ -1487,7 +1525,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       const uint32_t tc = uni(F.misc[M_WCNT + w]);
       const uint2 ts = lj_rot_fields<N>(
           make_uint2(uni(F.misc[M_WSUM + 2 * w]), uni(F.misc[M_WSUM + 2 * w + 1])),
-          wrun & uint32_t(N - 1));
+          lf_mod<N>(wrun));
       if (w < wv) {
         wprev += tc;
         sprev = pk_add2(sprev, ts);
@@ -1496,7 +1534,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       wrun += tc;
     }
     before = lbef + wprev;
-    pex = pk_add2(lj_rot_fields<N>(pk_sub2(pincl_l, r_l), wprev & uint32_t(N - 1)), sprev);
+    pex = pk_add2(lj_rot_fields<N>(pk_sub2(pincl_l, r_l), lf_mod<N>(wprev)), sprev);
     if (uint32_t(j) == F.misc[M_UNRES])
       F.misc[M_UNRESB] = before;
     cnt_wg = wrun;
@@ -1625,21 +1663,26 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   uint2 Cloc = make_uint2(0, 0), Vsum = make_uint2(0, 0);
   uint32_t lb1_flags = 0;
   uint2 lb1_al = make_uint2(0, 0);
-  const uint2 S_abs = lj_rot_fields<N>(S_wg, base & uint32_t(N - 1));
+  const uint2 S_abs = lj_rot_fields<N>(S_wg, lf_mod<N>(base));
   if (fits && !(LF_ABLATE & 1u)) {
     const uint2 pexrel =
-        lj_rot_fields<N>(pex, (uint32_t(N) - (before & uint32_t(N - 1))) & uint32_t(N - 1));
+        lj_rot_fields<N>(pex, lf_mod<N>(uint32_t(N) - lf_mod<N>(before)));
     const uint32_t ad = sb + 2u * before;
     // pairs that are written from the registers (a count clipped by `needed` writes one
     // sample more: nothing after it is delivered)
     const uint32_t nq = cnt_eff == my_cnt ? (cnt_eff >> 1) : ((cnt_eff + 1) >> 1);
     const uint32_t nqmax = wave_max_u32(nq);
+    // (register pair q holds the lane's symbols 2q, 2q + 1, i.e. relative components 2q mod N,
+    // 2q + 1 mod N: N = 1, 2 one constant, N = 4 two in turn, N = 3 three in turn -- (0, 1),
+    // (2, 0), (1, 2))
     const uint32_t k0 = N == 1 ? (pexrel.x & 0xFFFFu) * 0x10001u : pexrel.x;
-    const uint32_t k1 = N == 4 ? pexrel.y : k0;
-    lf_stage<0>(R, ad, nq, nqmax, k0, k1);
+    const uint32_t k1 = N == 4 ? pexrel.y
+                               : (N == 3 ? pack16(pexrel.y, pexrel.x) : k0);
+    const uint32_t k2 = N == 3 ? pack16(pexrel.x >> 16, pexrel.y) : k0;
+    lf_stage<N, 0>(R, ad, nq, nqmax, k0, k1, k2);
     if ((cnt_eff & 1u) && cnt_eff == my_cnt) {
       const uint32_t k = cnt_eff - 1;
-      const uint32_t v = fld(my_sums, k & uint32_t(N - 1)) + fld(pexrel, k & uint32_t(N - 1));
+      const uint32_t v = fld(my_sums, lf_mod<N>(k)) + fld(pexrel, lf_mod<N>(k));
       *(lds_u16w)(ad + 2u * k) = uint16_t(v);
     }
   }
@@ -1850,6 +1893,7 @@ uint32_t ljpeg_fast_stage_cap(uint32_t lds_bytes) {
 void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
   launch_fast_one<1, false>(a, f, s, timer);
   launch_fast_one<2, false>(a, f, s, timer);
+  launch_fast_one<3, false>(a, f, s, timer);
   launch_fast_one<4, false>(a, f, s, timer);
   launch_fast_one<2, true>(a, f, s, timer);
   launch_fast_one<4, true>(a, f, s, timer);

@@ -15,6 +15,7 @@
 #pragma once
 
 #include "rsx.h"
+#include "rsx_pin.h"
 
 #include "adt/Array1DRef.h"
 #include "adt/Point.h"
@@ -33,20 +34,7 @@
 
 namespace rawspeed::rsx_shim {
 
-// One lazily created context per process; rsx calls are re-entrant per context
-// (the DNG tile threads may all enter: AbstractDngDecompressor.cpp:112-131).
-// nullptr when there is no usable device: every hunk then falls through to the
-// method's original body, so a patched rawspeed still works without a GPU.
-inline rsx_ctx* context() {
-  static rsx_ctx* ctx = [] {
-    rsx_ctx* c = nullptr;
-    // (a librsx.so with another ABI than this header's: every hunk falls through)
-    if (rsx_abi_version() != RSX_ABI_VERSION || rsx_ctx_create(/*device=*/0, &c) != RSX_OK)
-      c = nullptr;
-    return c;
-  }();
-  return ctx;
-}
+// (the process-wide context() and the optional page-locked pool: rsx_pin.h)
 
 // What became of the units of work (a strip, a scan, a DNG tile) the hunks saw: decoded
 // by the device, or left to the method's original body.  Diagnostics only -- the tests

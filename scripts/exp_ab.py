@@ -47,6 +47,13 @@ def main():
             print("%-14s %.4f ms exact=%s  %s" % (name, j["ms_per_step"], j.get("bit_exact"),
                                                   " ".join("%s=%.3f" % (a.replace("lj_", "").replace("_kernel", ""), v)
                                                            for a, v in k.items())))
+            for sub, v in j.items():  # (cfg 4: its variants -- two tables, small tiles, overhang, DRI)
+                if isinstance(v, dict) and "ms_per_step" in v:
+                    kk = v.get("kernels_ms") or {}
+                    print("%-14s   %-26s %.4f ms exact=%s  %s" % (
+                        name, sub, v["ms_per_step"], v.get("bit_exact"),
+                        " ".join("%s=%.3f" % (a.replace("lj_", "").replace("_kernel", ""), x)
+                                 for a, x in kk.items())))
         except Exception as e:  # noqa: BLE001
             print(name, "FAILED", e, r.stdout[-500:], r.stderr[-1500:])
 

@@ -408,6 +408,13 @@ class Ref:
     def last_error(self):
         return self.lib.ref_last_error().decode(errors="replace")
 
+    def set_pinned_pool(self, on):
+        """INTEGRATION.md 6 (patched build): large AlignedAllocator blocks -- the images'
+        pixel stores -- from the page-locked pool.  False where the build has no such hook."""
+        if not hasattr(self.lib, "ref_set_pinned_pool"):
+            return False
+        return self.lib.ref_set_pinned_pool(1 if on else 0) >= 0
+
     def rsx_counts(self):
         """(host calls served, units decoded by the device, units left to the CPU code)."""
         return (self.lib.ref_rsx_host_calls(), self.lib.ref_rsx_forwarded(),

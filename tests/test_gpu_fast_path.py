@@ -401,3 +401,92 @@ def test_cr2_strip_copy_out_at_hundreds_of_workgroups(gpu, oracle, shape):
     names = _kernel_names(plan, inp, out)
     assert any("lj_fast_kernel" in n for n in names), names
     assert not any("sync" in n for n in names), names
+
+
+# ---------------------------------------------------------------------------------------
+# Three interleaved components (MCU 3 x 1, linear DNG: LJpegDecompressor.cpp:102-105) on the
+# single-pass kernel's <3> instantiation (round 5)
+# ---------------------------------------------------------------------------------------
+def _three_comp_plan(gpu, shapes, seed, **kw):
+    """one job per (img_w, img_h, tile) with cpp = 3, MCU 3 x 1; returns plan, buffers, cases"""
+    from oracle_lib import HostImage
+    rng = np.random.default_rng(seed)
+    jobs, parts, made, off, ooff = [], [], [], 0, 0
+    for (w, h, tile, frame) in shapes:
+        d, data, tile_px, scan_len = C.make_ljpeg_case(rng, img_w=w, img_h=h, cpp=3, tile=tile,
+                                                       mcu=(3, 1), frame=frame, **kw)
+        pad = (-data.size) % 16
+        data = np.concatenate([data, np.zeros(pad, np.uint8)])
+        img = HostImage(w, h, 3, is_cfa=False)
+        j = abi.LJpegJob()
+        j.desc = d
+        j.in_offset, j.in_bytes = off, data.size - pad
+        j.img_offset = ooff
+        j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
+            img.pitch, w, h, 3, 0
+        jobs.append(j)
+        parts.append(data)
+        made.append((d, data[:data.size - pad], img, scan_len))
+        off += data.size
+        ooff += img.pitch * h
+    inp = torch.from_numpy(np.concatenate(parts)).cuda()
+    out = torch.full((ooff,), 0xA5, dtype=torch.uint8, device="cuda")
+    return gpu.ljpeg_plan(jobs), inp, out, made
+
+
+@pytest.mark.parametrize("shapes", [
+    [(96, 40, (0, 0, 96, 40), None)],                       # one small tile
+    [(1500, 700, (0, 0, 1500, 700), None)],                 # hundreds of workgroups
+    [(640, 300, (64, 20, 500, 250), (520, 250))],           # a tile inside the image, trailing MCUs of the frame dropped
+    [(2048, 512, (0, 0, 2048, 512), None), (333, 77, (0, 0, 333, 77), None),
+     (1024, 1024, (0, 0, 1024, 1024), None)],               # several streams, odd sizes
+])
+def test_three_components_on_the_single_pass_kernel(gpu, oracle, shapes):
+    plan, inp, out, made = _three_comp_plan(gpu, shapes, seed=len(shapes) * 31 + shapes[0][0])
+    s = torch.cuda.current_stream().cuda_stream
+    for run in range(2):
+        out.fill_(0xA5)
+        plan.run(inp.data_ptr(), out.data_ptr(), s)
+        rc, st, cons = plan.results()
+        assert rc == 0 and all(x == 0 for x in st), (rc, list(st))
+        o = 0
+        got = out.cpu().numpy()
+        for (d, data, img, scan_len), c in zip(made, cons):
+            want_st, want_c = oracle.ljpeg(d, data, img)
+            assert want_st == 0 and c == want_c
+            n = img.pitch * img.dim_y
+            assert np.array_equal(got[o:o + n], img.buf), (run, img.dim_x, img.dim_y)
+            o += n
+    names = _kernel_names(plan, inp, out)
+    assert any("lj_fast_kernel" in n for n in names), names
+    # off the int16-difference route: no legacy decode, no reconstruction, no synchronisation
+    assert not any(("decode" in n) or ("legacy" in n) or ("sync" in n) for n in names), names
+
+
+def test_three_components_damaged_stream_takes_the_legacy_route(gpu, oracle):
+    """A 3-component stream the single-pass kernel cannot finish (it ends early: symbols past
+    the end of the data) is redone by the legacy route -- same status, consumed bytes and
+    pixels as the oracle, and the healthy stream next to it is untouched by that."""
+    plan, inp, out, made = _three_comp_plan(
+        gpu, [(900, 400, (0, 0, 900, 400), None), (600, 200, (0, 0, 600, 200), None)], seed=77)
+    # cut the first stream short: zero out its tail (the scan ends with garbage / zeros)
+    d0, data0, img0, scan0 = made[0]
+    cut = scan0 // 2
+    host = inp.cpu().numpy().copy()
+    host[cut:scan0 + 2] = 0
+    data0 = data0.copy()
+    data0[cut:scan0 + 2] = 0
+    inp = torch.from_numpy(host).cuda()
+    s = torch.cuda.current_stream().cuda_stream
+    plan.run(inp.data_ptr(), out.data_ptr(), s)
+    rc, st, cons = plan.results()
+    want0 = oracle.ljpeg(d0, data0, img0)
+    want1 = oracle.ljpeg(made[1][0], made[1][1], made[1][2])
+    assert (st[0], cons[0]) == want0 or st[0] == want0[0] != 0, ((st[0], cons[0]), want0)
+    assert (st[1], cons[1]) == want1 and want1[0] == 0
+    got = out.cpu().numpy()
+    n0 = img0.pitch * img0.dim_y
+    if want0[0] == 0:
+        assert np.array_equal(got[:n0], img0.buf)
+    n1 = made[1][2].pitch * made[1][2].dim_y
+    assert np.array_equal(got[n0:n0 + n1], made[1][2].buf)
