@@ -49,6 +49,9 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
 struct KernelTimer; // rsx_ljpeg_dev.h: an event after every launch of the run
 int ljpeg_plan_run(LJpegPlan* plan, const void* in_dev, void* out_dev,
                    hipStream_t stream, KernelTimer* timer);
+// (continue_timer: a child plan's launches go on in the parent's kernel table)
+int ljpeg_plan_run_(LJpegPlan* plan, const void* in_dev, void* out_dev, hipStream_t stream,
+                    KernelTimer* timer, bool continue_timer);
 int ljpeg_plan_results(LJpegPlan* plan, hipStream_t stream, bool ran,
                        int32_t* job_status, uint32_t* job_consumed);
 void ljpeg_plan_destroy(LJpegPlan* plan);

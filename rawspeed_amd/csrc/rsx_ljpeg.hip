@@ -797,6 +797,8 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   if (K0_CHAIN)
     b = blockIdx.x;
   const uint32_t s = a.block_stream[b];
+  if (s == 0xFFFFFFFFu)
+    return; // (a block no stream owns: plans laid out on the device, lj_dri_layout_kernel)
   const LjStreamDev& S = a.streams[s];
   // This kernel's own layout: the arrays of the general one that only the synchronisation
   // kernels use are left out, and the length table of the start guesses goes where dword
@@ -2737,10 +2739,150 @@ __global__ __launch_bounds__(256) void lj_marker_scan_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Restart intervals without a host round trip (round 5; LJpegDecompressor.cpp:277-335).
+// Every interval is a stream of a child plan; where an interval starts and how long it is
+// is only known once the RSTn markers have been found.  Until round 5 the marker list went
+// to the host, which built (or re-validated) the child plan and launched it: one
+// synchronisation in the middle of every decode, 0.2 of the 0.41 ms of a cfg-4 frame.  Now
+// the child plan is made ONCE, from the geometry alone, with room for the blocks ANY marker
+// placement needs (sum of ceil(bytes_i / LJ_R) <= bytes / LJ_R + intervals + 2), and two
+// small kernels write its stream records, its block -> stream map and its ticket order
+// from the marker list on the device; K0 and the single-pass kernel follow in the same
+// stream.  The host looks at markers, statuses and RSTn numbering when it fetches the
+// results -- and redoes the job the old way (exact child plan, host-built) whenever
+// something is off: markers missing, more FFxx than the list holds, a stream the
+// single-pass kernel gave up on.
+// ---------------------------------------------------------------------------
+struct DriJobDev {
+  uint64_t in_offset, in_bytes; // the job's scan data
+  uint32_t n_ri;                // restart intervals = streams of the child plan
+  uint32_t first_stream;        // its first child stream
+  uint32_t list_off, cap;       // its slice of the (unsorted) marker list
+  uint32_t sorted_off;          // its slice of the sorted list (n_ri entries)
+  uint32_t pad_;
+};
+constexpr uint32_t DRI_NONE = 0xFFFFFFFFu;
+
+// the first n_ri markers of every job in stream order: rank of an entry = entries in front
+__global__ __launch_bounds__(256) void lj_dri_sort_kernel(const DriJobDev* jobs,
+                                                          const uint32_t* count,
+                                                          const uint2* list, uint2* sorted) {
+  const DriJobDev J = jobs[blockIdx.y];
+  const uint32_t n = min(count[blockIdx.y], J.cap);
+  const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+  if (e >= n)
+    return;
+  const uint2* L = list + J.list_off;
+  const uint2 me = L[e];
+  uint32_t rank = 0;
+  for (uint32_t k = 0; k < n; ++k)
+    rank += L[k].x < me.x ? 1u : 0u; // (positions are distinct)
+  if (rank < J.n_ri)
+    sorted[J.sorted_off + rank] = me;
+}
+
+// stream records, block -> stream map and ticket order of the child plan.  One workgroup.
+// status[d]: 1 markers missing, 2 more FFxx than the list holds; status[n_jobs]: 4 the
+// blocks do not fit the plan (cannot happen with its bound; checked all the same).
+__global__ __launch_bounds__(1024) void lj_dri_layout_kernel(
+    LjStreamDev* streams, uint32_t n_streams, uint32_t* block_stream, uint4* fast_order,
+    uint32_t grid_blocks, const DriJobDev* jobs, uint32_t n_jobs, const uint32_t* count,
+    const uint2* sorted, uint32_t* status) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t total_s;
+  const uint32_t tid = threadIdx.x;
+  // (cross-lane traffic through global memory inside ONE workgroup: agent-scope accesses
+  // bypass the CU's vector cache)
+  auto ld = [](const uint32_t* q) {
+    return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto st = [](uint32_t* q, uint32_t v) {
+    __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  for (uint32_t d = 0; d < n_jobs; ++d) {
+    const DriJobDev J = jobs[d];
+    const uint32_t c = count[d], n = min(c, J.cap);
+    const bool bad = c > J.cap || n + 1u < J.n_ri;
+    if (tid == 0 && bad)
+      status[d] = c > J.cap ? 2u : 1u;
+    for (uint32_t i = tid; i < J.n_ri; i += 1024u) {
+      LjStreamDev& S = streams[J.first_stream + i];
+      uint64_t start = 0, end = 0;
+      if (!bad) {
+        start = i ? uint64_t(sorted[J.sorted_off + i - 1].x) + 2u : 0u;
+        // up to and including the closing marker (the reference hands every interval the
+        // whole remaining buffer; >= 8 bytes: BitStreamer.h:58-59)
+        end = (i + 1 < J.n_ri) ? uint64_t(sorted[J.sorted_off + i].x) + 2u : J.in_bytes;
+        if (end < start + 8u)
+          end = start + 8u;
+        if (end > J.in_bytes)
+          end = J.in_bytes;
+        if (start > end)
+          start = end;
+      }
+      S.in_offset = J.in_offset + start;
+      S.in_bytes = end - start;
+      st(&S.n_blocks, uint32_t((end - start + uint64_t(LJ_R) - 1u) / uint64_t(LJ_R)));
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the block counts: a contiguous chunk of streams per lane
+  const uint32_t chunk = (n_streams + 1023u) / 1024u;
+  const uint32_t lo = min(tid * chunk, n_streams), hi = min(lo + chunk, n_streams);
+  uint32_t sum = 0;
+  for (uint32_t k = lo; k < hi; ++k)
+    sum += ld(&streams[k].n_blocks);
+  part[tid] = sum;
+  __syncthreads();
+  for (uint32_t o = 1; o < 1024u; o <<= 1) {
+    const uint32_t v = tid >= o ? part[tid - o] : 0u;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  if (tid == 1023u)
+    total_s = part[1023];
+  __syncthreads();
+  const bool fits = total_s <= grid_blocks;
+  if (tid == 0 && !fits)
+    status[n_jobs] = 4u;
+  uint32_t base = part[tid] - sum;
+  for (uint32_t k = lo; k < hi; ++k) {
+    LjStreamDev& S = streams[k];
+    const uint32_t nb = fits ? ld(&S.n_blocks) : 0u;
+    if (!fits) {
+      st(&S.n_blocks, 0u);
+      S.in_bytes = 0;
+    }
+    st(&S.first_block, base);
+    S.first_subseq = base * uint32_t(LJ_OWN);
+    base += nb;
+  }
+  for (uint32_t b = tid; b < grid_blocks; b += 1024u) {
+    block_stream[b] = DRI_NONE;
+    fast_order[b] = make_uint4(b, DRI_NONE, 0u, 0u);
+  }
+  __syncthreads();
+  // every stream writes its own blocks: ticket = block (a stream's workgroups wait for the
+  // few in front of them: no need to interleave streams of a handful of blocks each)
+  for (uint32_t k = tid; k < n_streams; k += 1024u) {
+    const LjStreamDev& S = streams[k];
+    const uint32_t fb = ld(&S.first_block), nb = ld(&S.n_blocks);
+    const uint32_t tz = S.table_base | (uint32_t(S.tab_of_phase[0] & 15u) << 24) |
+                        (uint32_t(S.tab_of_phase[1] & 15u) << 28);
+    for (uint32_t q = 0; q < nb; ++q) {
+      block_stream[fb + q] = k;
+      fast_order[fb + q] = make_uint4(fb + q, k, tz, fb);
+    }
+  }
+}
+
 } // namespace
 // ---------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------
+constexpr int RSX_INTERNAL_RETRY = -1000; // a device-laid-out child plan: redo the old way
 struct LJpegPlan {
   rsx_ctx* ctx = nullptr;
   int n_jobs = 0;
@@ -2817,6 +2959,15 @@ struct LJpegPlan {
   DeviceBuffer d_marker_count, d_marker_list;
   std::vector<uint32_t> dri_signature; // marker layout the child plan was built for
   LJpegPlan* child = nullptr;          // one stream per restart interval
+  // ... and its device-laid-out sibling (round 5): made once from the geometry, its stream
+  // records written by lj_dri_layout_kernel in every run
+  LJpegPlan* child_dev = nullptr;
+  std::vector<std::pair<int, int>> child_dev_owner;
+  bool child_dev_failed = false; // this plan's jobs do not fit the scheme: host path only
+  bool dri_ran_dev = false;      // the last run took the device path
+  bool dev_layout = false;       // (on the child) its layout lives on the device
+  std::vector<DriJobDev> dri_dev;
+  DeviceBuffer d_dri_jobs, d_dri_sorted, d_dri_status;
   std::vector<std::pair<int, int>> child_owner; // child job -> (dri index, interval)
   // NikonDecompressor streams
   bool any_nikon = false, any_pair = false, any_multi = false, any_lut11 = false;
@@ -3511,7 +3662,7 @@ namespace {
 // into a stream of a child plan (fresh predictors, byte-aligned start:
 // LJpegDecompressor.cpp:283-300) and run it.  One host round trip per run; the
 // child plan is reused while the marker layout does not change.
-int run_dri(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s) {
+int run_dri_host(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s) {
   rsx_ctx* ctx = p->ctx;
   const uint8_t* in_base = static_cast<const uint8_t*>(in_dev);
   std::vector<uint32_t> signature;
@@ -3636,6 +3787,130 @@ int run_dri(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s) {
   return RSX_OK;
 }
 
+// The same without the round trip: marker scans, sort, layout of the (once-made) child plan
+// on the device, its run -- all in stream order.  RSX_INTERNAL_RETRY: not for this plan.
+int run_dri_device(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s) {
+  rsx_ctx* ctx = p->ctx;
+  const uint8_t* in_base = static_cast<const uint8_t*>(in_dev);
+  const size_t nd = p->dri.size();
+  if (!p->child_dev) {
+    // the child plan from the geometry alone: interval i of a job gets an equal share of
+    // the blocks any marker placement can need (its real place and size come from the
+    // layout kernel in every run)
+    std::vector<LJpegJobIn> jobs;
+    p->child_dev_owner.clear();
+    p->dri_dev.assign(nd, DriJobDev{});
+    size_t total_cap = 0, total_sorted = 0;
+    for (size_t d = 0; d < nd; ++d) {
+      auto& dj = p->dri[d];
+      const StreamGeom& g = dj.in.geom;
+      if (g.in_bytes < 16 || dj.n_ri < 2)
+        return RSX_INTERNAL_RETRY;
+      DriJobDev& D = p->dri_dev[d];
+      D.in_offset = g.in_offset;
+      D.in_bytes = g.in_bytes;
+      D.n_ri = dj.n_ri;
+      D.first_stream = uint32_t(jobs.size());
+      D.list_off = uint32_t(total_cap);
+      D.cap = dj.n_ri + 1024;
+      D.sorted_off = uint32_t(total_sorted);
+      total_cap += D.cap;
+      total_sorted += dj.n_ri;
+      // (intervals overlap by their closing marker and are at least 8 bytes long)
+      const uint64_t bmax = (g.in_bytes + 10ull * dj.n_ri) / LJ_R + dj.n_ri + 2;
+      const uint64_t share = (bmax + dj.n_ri - 1) / dj.n_ri;
+      for (uint32_t i = 0; i < dj.n_ri; ++i) {
+        LJpegJobIn J = dj.in;
+        J.tables = dj.tables.data();
+        J.rows_per_restart_interval = 0;
+        J.geom.in_offset = g.in_offset;
+        J.geom.in_bytes = share * LJ_R; // (a placeholder: sizes the plan's arrays)
+        const uint32_t r0 = i * dj.rows_per_ri;
+        J.geom.rows = std::min(dj.rows_per_ri, g.rows - r0);
+        J.geom.out_y = g.out_y + g.mcu_h * r0;
+        jobs.push_back(J);
+        p->child_dev_owner.emplace_back(int(d), int(i));
+      }
+    }
+    LJpegPlan* c = nullptr;
+    if (int st = ljpeg_plan_create(ctx, jobs, &c))
+      return st == RSX_ERR_NOMEM || st == RSX_ERR_DEVICE ? st : RSX_INTERNAL_RETRY;
+    // only plans whose streams ALL take the single-pass kernel (its kernels and K0 are the
+    // ones that skip blocks without a stream)
+    bool ok = c->any_fast && !c->any_pipeline && !c->any_legacy && !c->any_fast_legacy &&
+              c->dri.empty() && c->nk_split.empty() && c->streams.size() == jobs.size();
+    for (int st : c->job_status)
+      ok = ok && st == RSX_OK;
+    if (!ok) {
+      ljpeg_plan_destroy(c);
+      return RSX_INTERNAL_RETRY;
+    }
+    c->dev_layout = true;
+    c->fast_uniform_nb = 0;
+    p->child_dev = c;
+    if (int st = p->d_dri_jobs.ensure(nd * sizeof(DriJobDev)))
+      return st;
+    if (int st = p->d_dri_sorted.ensure(total_sorted * sizeof(uint2) + 16))
+      return st;
+    if (int st = p->d_dri_status.ensure((nd + 1) * 4 + 16))
+      return st;
+    if (int st = p->d_marker_count.ensure(nd * 4 + 16))
+      return st;
+    if (int st = p->d_marker_list.ensure(total_cap * sizeof(uint2)))
+      return st;
+    RSX_HIP_CHECK(ctx, hipMemcpy(p->d_dri_jobs.ptr, p->dri_dev.data(), nd * sizeof(DriJobDev),
+                                 hipMemcpyHostToDevice));
+  }
+  LJpegPlan* c = p->child_dev;
+  RSX_HIP_CHECK(ctx, hipMemsetAsync(p->d_marker_count.ptr, 0, nd * 4, s));
+  RSX_HIP_CHECK(ctx, hipMemsetAsync(p->d_dri_status.ptr, 0, (nd + 1) * 4, s));
+  uint32_t max_cap = 0;
+  for (size_t d = 0; d < nd; ++d) {
+    const auto& dj = p->dri[d];
+    const uint64_t bytes = dj.in.geom.in_bytes;
+    const uint32_t blocks = uint32_t((bytes + 4095) / 4096);
+    hipLaunchKernelGGL(lj_marker_scan_kernel, dim3(blocks), dim3(256), 0, s,
+                       in_base + dj.in.geom.in_offset, bytes,
+                       static_cast<uint32_t*>(p->d_marker_count.ptr) + d,
+                       static_cast<uint2*>(p->d_marker_list.ptr) + p->dri_dev[d].list_off,
+                       p->dri_dev[d].cap);
+    max_cap = std::max(max_cap, p->dri_dev[d].cap);
+  }
+  hipLaunchKernelGGL(lj_dri_sort_kernel, dim3((max_cap + 255) / 256, uint32_t(nd)), dim3(256), 0,
+                     s, static_cast<const DriJobDev*>(p->d_dri_jobs.ptr),
+                     static_cast<const uint32_t*>(p->d_marker_count.ptr),
+                     static_cast<const uint2*>(p->d_marker_list.ptr),
+                     static_cast<uint2*>(p->d_dri_sorted.ptr));
+  hipLaunchKernelGGL(lj_dri_layout_kernel, dim3(1), dim3(1024), 0, s,
+                     static_cast<LjStreamDev*>(c->d_streams.ptr), uint32_t(c->streams.size()),
+                     static_cast<uint32_t*>(c->d_block_stream.ptr),
+                     static_cast<uint4*>(c->d_fast_order.ptr), c->total_blocks,
+                     static_cast<const DriJobDev*>(p->d_dri_jobs.ptr), uint32_t(nd),
+                     static_cast<const uint32_t*>(p->d_marker_count.ptr),
+                     static_cast<const uint2*>(p->d_dri_sorted.ptr),
+                     static_cast<uint32_t*>(p->d_dri_status.ptr));
+  RSX_HIP_CHECK(ctx, hipGetLastError());
+  mark(p, "lj_marker_scan + lj_dri_sort + lj_dri_layout");
+  return ljpeg_plan_run_(c, in_dev, out_dev, s, p->timer, true);
+}
+
+int run_dri(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s) {
+  p->dri_ran_dev = false;
+#ifndef RSX_DRI_HOST_ONLY
+  if (!p->child_dev_failed) {
+    const int st = run_dri_device(p, in_dev, out_dev, s);
+    if (st == RSX_OK) {
+      p->dri_ran_dev = true;
+      return RSX_OK;
+    }
+    if (st != RSX_INTERNAL_RETRY)
+      return st;
+    p->child_dev_failed = true;
+  }
+#endif
+  return run_dri_host(p, in_dev, out_dev, s);
+}
+
 } // namespace
 
 namespace {
@@ -3712,6 +3987,10 @@ int run_nikon_split(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t
 
 int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
                    hipStream_t s, KernelTimer* timer) {
+  return ljpeg_plan_run_(p, in_dev, out_dev, s, timer, false);
+}
+int ljpeg_plan_run_(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s,
+                    KernelTimer* timer, bool continue_timer) {
   rsx_ctx* ctx = p->ctx;
   p->last_in = in_dev;
   p->last_out = out_dev;
@@ -3720,7 +3999,7 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
     ~TimerScope() { p->timer = nullptr; }
   } scope{p};
   p->timer = timer;
-  if (timer)
+  if (timer && !continue_timer)
     timer->begin(s);
   if (!p->dri.empty())
     if (int st = run_dri(p, in_dev, out_dev, s))
@@ -3844,6 +4123,14 @@ int converge(LJpegPlan* p, hipStream_t s) {
   // the LDS level this data needed: the next runs launch that one only
   if (p->any_fast)
     p->level_mask = 1u << std::min(p->h_level[2u + (p->run_count & 1u)], 2u);
+  // a child plan whose layout lives on the device (restart intervals): anything the
+  // single-pass kernel did not finish is the host-built plan's business (run_dri_host)
+  if (p->dev_layout) {
+    for (const LjResult& R : p->h_results)
+      if (R.flags & (FL_SLOW | FL_UNCONVERGED | FL_NEED_LEGACY))
+        return RSX_INTERNAL_RETRY;
+    return RSX_OK;
+  }
   // streams the single-pass kernel gave up on: the second pass (unless the run
   // launched it already, because the run before needed it)
   if (p->any_fast) {
@@ -4025,7 +4312,69 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
   if (ran && !p->dri.empty()) {
     std::vector<int32_t> cst;
     std::vector<uint32_t> ccons;
-    if (p->child) {
+    rsx_ctx* ctx = p->ctx;
+    if (p->dri_ran_dev) {
+      // The device-laid-out child plan: markers, statuses and the child's results arrive
+      // together, AFTER everything was launched.  Anything irregular -- markers missing, a
+      // list too short for the FFxx of the scan, a stream the single-pass kernel gave up
+      // on -- and the job is redone the old way, by the host-built plan.
+      const size_t nd = p->dri.size();
+      std::vector<uint32_t> counts(nd), status(nd + 1);
+      size_t total_sorted = 0;
+      for (const DriJobDev& D : p->dri_dev)
+        total_sorted += D.n_ri;
+      std::vector<uint2> sorted(total_sorted);
+      RSX_HIP_CHECK(ctx, hipMemcpyAsync(counts.data(), p->d_marker_count.ptr, nd * 4,
+                                        hipMemcpyDeviceToHost, s));
+      RSX_HIP_CHECK(ctx, hipMemcpyAsync(status.data(), p->d_dri_status.ptr, (nd + 1) * 4,
+                                        hipMemcpyDeviceToHost, s));
+      RSX_HIP_CHECK(ctx, hipMemcpyAsync(sorted.data(), p->d_dri_sorted.ptr,
+                                        total_sorted * sizeof(uint2), hipMemcpyDeviceToHost, s));
+      RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+      bool ok = status[nd] == 0;
+      for (size_t d = 0; d < nd && ok; ++d)
+        ok = status[d] == 0 && counts[d] <= p->dri_dev[d].cap && counts[d] + 1 >= p->dri[d].n_ri;
+      if (ok) {
+        LJpegPlan* c = p->child_dev;
+        for (size_t d = 0; d < nd; ++d) {
+          auto& dj = p->dri[d];
+          const DriJobDev& D = p->dri_dev[d];
+          dj.status = RSX_OK;
+          dj.markers.clear();
+          dj.codes.clear();
+          dj.starts.assign(1, 0u);
+          for (uint32_t i = 0; i + 1 < dj.n_ri; ++i) {
+            const uint2 m = sorted[D.sorted_off + i];
+            dj.markers.push_back(m.x);
+            dj.codes.push_back(uint8_t(m.y));
+            dj.starts.push_back(m.x + 2);
+          }
+          // (the host's copy of the child's stream records, as the layout kernel wrote them:
+          // the checks below compare consumed bytes with the streams' sizes)
+          for (uint32_t i = 0; i < dj.n_ri; ++i) {
+            LjStreamDev& S = c->streams[D.first_stream + i];
+            const uint64_t start = dj.starts[i];
+            uint64_t end = (i + 1 < dj.n_ri) ? uint64_t(dj.markers[i]) + 2 : D.in_bytes;
+            end = std::min<uint64_t>(D.in_bytes, std::max<uint64_t>(end, start + 8));
+            S.in_offset = D.in_offset + start;
+            S.in_bytes = end - std::min(start, end);
+          }
+        }
+        cst.assign(c->n_jobs, RSX_OK);
+        ccons.assign(c->n_jobs, 0);
+        const int crc = ljpeg_plan_results(c, s, true, cst.data(), ccons.data());
+        if (crc == RSX_ERR_DEVICE || crc == RSX_ERR_NOMEM)
+          return crc;
+        if (crc == RSX_INTERNAL_RETRY)
+          ok = false;
+      }
+      if (!ok) {
+        p->dri_ran_dev = false;
+        if (int st = run_dri_host(p, p->last_in, p->last_out, s))
+          return st;
+      }
+    }
+    if (!p->dri_ran_dev && p->child) {
       cst.assign(p->child->n_jobs, RSX_OK);
       ccons.assign(p->child->n_jobs, 0);
       const int crc = ljpeg_plan_results(p->child, s, true, cst.data(), ccons.data());
@@ -4034,9 +4383,10 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
     }
     for (size_t d = 0; d < p->dri.size(); ++d)
       dri_status[d] = p->dri[d].status;
-    for (size_t c = 0; c < p->child_owner.size(); ++c) {
-      const int d = p->child_owner[c].first;
-      const uint32_t i = uint32_t(p->child_owner[c].second);
+    const auto& owner = p->dri_ran_dev ? p->child_dev_owner : p->child_owner;
+    for (size_t c = 0; c < owner.size(); ++c) {
+      const int d = owner[c].first;
+      const uint32_t i = uint32_t(owner[c].second);
       const auto& dj = p->dri[d];
       if (dri_status[d] != RSX_OK)
         continue; // the first failing interval decides (the reference stops there)
@@ -4232,6 +4582,8 @@ void ljpeg_plan_destroy(LJpegPlan* p) {
     return;
   if (p->child)
     ljpeg_plan_destroy(p->child);
+  if (p->child_dev)
+    ljpeg_plan_destroy(p->child_dev);
   if (p->nk_child)
     ljpeg_plan_destroy(p->nk_child);
   for (DeviceBuffer* b : {&p->d_nk, &p->d_nk_tables, &p->d_nk_rowpow, &p->d_nk_pup,

@@ -1006,6 +1006,8 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     s = uni(bs.y);
     tz_now = uni(bs.z);
     fb_now = uni(bs.w);
+    if (s == 0xFFFFFFFFu)
+      return; // (a block no stream owns: plans laid out on the device, lj_dri_layout_kernel)
   }
 #else
   if (j == 0) {

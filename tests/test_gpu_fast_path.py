@@ -490,3 +490,84 @@ def test_three_components_damaged_stream_takes_the_legacy_route(gpu, oracle):
         assert np.array_equal(got[:n0], img0.buf)
     n1 = made[1][2].pitch * made[1][2].dim_y
     assert np.array_equal(got[n0:n0 + n1], made[1][2].buf)
+
+
+# ---------------------------------------------------------------------------------------
+# Restart intervals laid out on the device (round 5): marker scan -> sort -> stream records
+# -> K0 -> single-pass kernel in ONE go, no host round trip in between
+# ---------------------------------------------------------------------------------------
+def _dri_plan(gpu, shapes, seed, rows_per_ri):
+    rng = np.random.default_rng(seed)
+    jobs, parts, made, off, ooff = [], [], [], 0, 0
+    for (w, h, cpp, mcu) in shapes:
+        d, data, tile_px, scan_len = C.make_ljpeg_case(rng, img_w=w, img_h=h, cpp=cpp,
+                                                       tile=(0, 0, w, h), mcu=mcu,
+                                                       rows_per_ri=rows_per_ri)
+        pad = (-data.size) % 16
+        img = HostImage(w, h, cpp, is_cfa=cpp == 1)
+        j = abi.LJpegJob()
+        j.desc = d
+        j.in_offset, j.in_bytes, j.img_offset = off, data.size, ooff
+        j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
+            img.pitch, w, h, cpp, int(cpp == 1)
+        jobs.append(j)
+        parts.append(np.concatenate([data, np.zeros(pad, np.uint8)]))
+        made.append((d, data, img, scan_len))
+        off += data.size + pad
+        ooff += img.pitch * h
+    inp = torch.from_numpy(np.concatenate(parts)).cuda()
+    out = torch.full((ooff,), 0xA5, dtype=torch.uint8, device="cuda")
+    return gpu.ljpeg_plan(jobs), inp, out, made
+
+
+@pytest.mark.parametrize("shapes,rows_per_ri", [
+    ([(1024, 600, 1, (2, 1))], 7),                      # 86 intervals, one job
+    ([(2048, 512, 1, (2, 1)), (640, 333, 1, (2, 1)), (512, 96, 1, (4, 1))], 16),   # three jobs
+    ([(4096, 2732, 1, (2, 1))], 28),                    # a cfg-4 tile
+])
+def test_restart_intervals_are_laid_out_on_the_device(gpu, oracle, shapes, rows_per_ri):
+    plan, inp, out, made = _dri_plan(gpu, shapes, 900 + rows_per_ri, rows_per_ri)
+    s = torch.cuda.current_stream().cuda_stream
+    for run in range(3):
+        out.fill_(0xA5)
+        plan.run(inp.data_ptr(), out.data_ptr(), s)
+        rc, st, cons = plan.results()
+        assert rc == 0 and all(x == 0 for x in st), (rc, list(st))
+        got = out.cpu().numpy()
+        o = 0
+        for (d, data, img, scan_len), c in zip(made, cons):
+            want = oracle.ljpeg(d, data, img)
+            assert want[0] == 0 and c == want[1], (c, want)
+            n = img.pitch * img.dim_y
+            assert np.array_equal(got[o:o + n], img.buf), run
+            o += n
+    names = _kernel_names(plan, inp, out)
+    # one table from the marker scan to the single-pass kernel: nothing was fetched in between
+    assert any("lj_dri_layout" in n for n in names), names
+    assert any("lj_fast_kernel" in n for n in names), names
+    assert names.index(next(n for n in names if "lj_dri_layout" in n)) < \
+        names.index(next(n for n in names if "lj_fast_kernel" in n))
+
+
+def test_restart_interval_anomalies_fall_back_to_the_host_built_plan(gpu, oracle):
+    """A marker with the wrong number, a marker missing, FFxx junk behind the scan: statuses,
+    consumed bytes and pixels as the oracle's (LJpegDecompressor.cpp:283-298), whichever way
+    the library got there."""
+    rng = np.random.default_rng(4711)
+    w, h = 768, 200
+    d, data, tile_px, scan_len = C.make_ljpeg_case(rng, img_w=w, img_h=h, cpp=1,
+                                                   tile=(0, 0, w, h), mcu=(2, 1), rows_per_ri=9)
+    pos = [i for i in range(scan_len - 1) if data[i] == 0xFF and 0xD0 <= data[i + 1] <= 0xD7]
+    assert len(pos) == (h + 8) // 9 - 1
+    variants = {"clean": data.copy()}
+    v = data.copy(); v[pos[3] + 1] = 0xD0 + ((data[pos[3] + 1] - 0xD0 + 1) % 8); variants["wrong_number"] = v
+    v = data.copy(); v[pos[5]] = 0x00; variants["marker_missing"] = v
+    v = np.concatenate([data, np.tile(np.array([0xFF, 0xE0], np.uint8), 3000)]); variants["junk_behind"] = v
+    for name, dat in variants.items():
+        img_o, img_g = HostImage(w, h), HostImage(w, h)
+        want = oracle.ljpeg(d, dat, img_o)
+        got = gpu.ljpeg_decode(d, dat, img_g.view())
+        assert got[0] == want[0], (name, got, want)
+        if want[0] == 0:
+            assert got == want, (name, got, want)
+            assert np.array_equal(img_g.buf, img_o.buf), name
