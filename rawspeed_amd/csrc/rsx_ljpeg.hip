@@ -237,9 +237,47 @@ __device__ __forceinline__ void lj_stage_slots(const Lds& L, const LjArgs& a,
   const int64_t in_bytes = int64_t(S.in_bytes);
   const int64_t start = int64_t(lb) * LJ_R + int64_t(j - 1) * LJ_P;
   uint4 v[LJ_BW / 4];
+  // A stream that does not start on the buffer's 16-byte grid -- every restart interval
+  // (it starts two bytes behind a marker), a DNG tile at an odd offset: all its slots are
+  // off the grid by the SAME delta, so a lane takes the six grid chunks its 80 bytes lie in
+  // and funnels them down by delta bytes (a workgroup-uniform amount).  Until round 5 such
+  // streams were assembled byte by byte, eighty loads a lane: K0 took 0.18 ms instead of
+  // 0.07 on the four tiles of a cfg-4 frame with restart intervals.
+  const uint32_t delta = uint32_t(reinterpret_cast<uintptr_t>(in) & 15u);
+#ifdef RSX_NO_FUNNEL // (A/B builds)
+  const bool funnel = false;
+#else
+  const bool funnel = !aligned16 && S.in_offset >= 16u && start >= 0 &&
+                      start - int64_t(delta) + 96 <= in_bytes;
+#endif
+  if (__any(funnel)) {
+    uint32_t w[25];
 #pragma unroll
-  for (int m = 0; m < LJ_BW / 4; ++m)
-    v[m] = lj_load_chunk(in, start + 16 * m, in_bytes, aligned16);
+    for (int k = 0; k < 6; ++k) {
+      const uint4 c = funnel ? *reinterpret_cast<const uint4*>(in + (start - int64_t(delta)) + 16 * k)
+                             : make_uint4(0, 0, 0, 0);
+      w[4 * k] = c.x, w[4 * k + 1] = c.y, w[4 * k + 2] = c.z, w[4 * k + 3] = c.w;
+    }
+    w[24] = 0;
+    const uint32_t q = uint32_t(__builtin_amdgcn_readfirstlane(int(delta >> 2)));
+    const uint32_t r = uint32_t(__builtin_amdgcn_readfirstlane(int(delta & 3u)));
+    uint32_t dd[LJ_BW];
+#pragma unroll
+    for (int i = 0; i < LJ_BW; ++i) {
+      // (q is workgroup-uniform: four static register choices under uniform branches)
+      const uint32_t lo = q == 0 ? w[i] : (q == 1 ? w[i + 1] : (q == 2 ? w[i + 2] : w[i + 3]));
+      const uint32_t hi = q == 0 ? w[i + 1] : (q == 1 ? w[i + 2] : (q == 2 ? w[i + 3] : w[i + 4]));
+      dd[i] = __builtin_amdgcn_alignbyte(hi, lo, r);
+    }
+#pragma unroll
+    for (int m = 0; m < LJ_BW / 4; ++m)
+      v[m] = funnel ? make_uint4(dd[4 * m], dd[4 * m + 1], dd[4 * m + 2], dd[4 * m + 3])
+                    : lj_load_chunk(in, start + 16 * m, in_bytes, aligned16);
+  } else {
+#pragma unroll
+    for (int m = 0; m < LJ_BW / 4; ++m)
+      v[m] = lj_load_chunk(in, start + 16 * m, in_bytes, aligned16);
+  }
   const uint32_t prev =
       (start >= 1 && start - 1 < in_bytes) ? uint32_t(in[start - 1]) : 0u;
   if (j == 0) {
@@ -796,6 +834,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   // and its barrier in front of the first load cost every workgroup 1.5 us of its 25)
   if (K0_CHAIN)
     b = blockIdx.x;
+  lj_fresh_scalars(a);
   const uint32_t s = a.block_stream[b];
   if (s == 0xFFFFFFFFu)
     return; // (a block no stream owns: plans laid out on the device, lj_dri_layout_kernel)
@@ -1753,6 +1792,7 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
     dbg_first_s = 0xFFFFFFFFu;
 #endif
   const uint32_t s = blockIdx.x;
+  lj_fresh_scalars(a);
   const LjStreamDev& S = a.streams[s];
   if (!lj_bookkeeping_takes(a, s, S))
     return;
@@ -2702,6 +2742,7 @@ __device__ void lj_consumed_body(const LjArgs& a, uint32_t s, int lane) {
 }
 
 __global__ __launch_bounds__(64) void lj_consumed_kernel(LjArgs a) {
+  lj_fresh_scalars(a);
   lj_consumed_body(a, blockIdx.x, int(threadIdx.x));
 }
 
@@ -2763,6 +2804,48 @@ struct DriJobDev {
   uint32_t pad_;
 };
 constexpr uint32_t DRI_NONE = 0xFFFFFFFFu;
+
+// The marker scan of ALL jobs in one launch, sixteen bytes a lane as ONE load on the
+// buffer's 16-byte grid (lj_marker_scan_kernel reads byte by byte, one launch per job: 70 of
+// the 89 us the device path's first version spent in front of K0 on four 11 MB tiles).  Only
+// lanes whose bytes hold an FF (one in sixteen) look at them one by one.
+__global__ __launch_bounds__(256) void lj_dri_scan_kernel(const uint8_t* __restrict__ in_base,
+                                                          const DriJobDev* jobs, uint32_t* count,
+                                                          uint2* list) {
+  const DriJobDev J = jobs[blockIdx.y];
+  const uint8_t* in = in_base + J.in_offset;
+  const uint64_t bytes = J.in_bytes;
+  const uint32_t lead = uint32_t(reinterpret_cast<uintptr_t>(in) & 15u);
+  // chunk c = stream bytes [16 c - lead, 16 c - lead + 16)
+  const int64_t p0 = int64_t(uint64_t(blockIdx.x) * 256 + threadIdx.x) * 16 - int64_t(lead);
+  if (p0 >= int64_t(bytes))
+    return;
+  uint32_t w[5] = {0, 0, 0, 0, 0}; // the chunk and the byte behind it
+  if (p0 >= 0 && p0 + 17 <= int64_t(bytes)) {
+    const uint4 v = *reinterpret_cast<const uint4*>(in + p0);
+    w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+    if (!(has_ff(w[0]) | has_ff(w[1]) | has_ff(w[2]) | has_ff(w[3])))
+      return;
+    w[4] = in[p0 + 16];
+  } else {
+    for (int i = 0; i < 17; ++i) {
+      const int64_t p = p0 + i;
+      const uint32_t b = (p >= 0 && p < int64_t(bytes)) ? in[p] : 0u;
+      w[i >> 2] |= b << (8 * (i & 3));
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    const uint32_t x = (w[b >> 2] >> (8 * (b & 3))) & 0xFFu;
+    const uint32_t y = (w[(b + 1) >> 2] >> (8 * ((b + 1) & 3))) & 0xFFu;
+    const int64_t p = p0 + b;
+    if (x == 0xFFu && y != 0u && p >= 0 && p + 1 < int64_t(bytes)) {
+      const uint32_t i = atomicAdd(&count[blockIdx.y], 1u);
+      if (i < J.cap)
+        list[J.list_off + i] = make_uint2(uint32_t(p), y);
+    }
+  }
+}
 
 // the first n_ri markers of every job in stream order: rank of an entry = entries in front
 __global__ __launch_bounds__(256) void lj_dri_sort_kernel(const DriJobDev* jobs,
@@ -3037,6 +3120,7 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
 #endif
   a.block_base0 = static_cast<uint32_t*>(p->d_block_base0.ptr);
   a.fast_uniform_nb = p->fast_uniform_nb;
+  a.dev_layout = p->dev_layout ? 1u : 0u;
   a.fast_rotate = p->fast_rotate;
   a.tickets = static_cast<uint32_t*>(p->d_tickets.ptr);
   a.fast_lds = p->fast_lds;
@@ -3865,17 +3949,15 @@ int run_dri_device(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t 
   RSX_HIP_CHECK(ctx, hipMemsetAsync(p->d_marker_count.ptr, 0, nd * 4, s));
   RSX_HIP_CHECK(ctx, hipMemsetAsync(p->d_dri_status.ptr, 0, (nd + 1) * 4, s));
   uint32_t max_cap = 0;
+  uint64_t max_bytes = 0;
   for (size_t d = 0; d < nd; ++d) {
-    const auto& dj = p->dri[d];
-    const uint64_t bytes = dj.in.geom.in_bytes;
-    const uint32_t blocks = uint32_t((bytes + 4095) / 4096);
-    hipLaunchKernelGGL(lj_marker_scan_kernel, dim3(blocks), dim3(256), 0, s,
-                       in_base + dj.in.geom.in_offset, bytes,
-                       static_cast<uint32_t*>(p->d_marker_count.ptr) + d,
-                       static_cast<uint2*>(p->d_marker_list.ptr) + p->dri_dev[d].list_off,
-                       p->dri_dev[d].cap);
+    max_bytes = std::max<uint64_t>(max_bytes, p->dri[d].in.geom.in_bytes);
     max_cap = std::max(max_cap, p->dri_dev[d].cap);
   }
+  hipLaunchKernelGGL(lj_dri_scan_kernel, dim3(uint32_t((max_bytes + 15 + 4095) / 4096), uint32_t(nd)),
+                     dim3(256), 0, s, in_base, static_cast<const DriJobDev*>(p->d_dri_jobs.ptr),
+                     static_cast<uint32_t*>(p->d_marker_count.ptr),
+                     static_cast<uint2*>(p->d_marker_list.ptr));
   hipLaunchKernelGGL(lj_dri_sort_kernel, dim3((max_cap + 255) / 256, uint32_t(nd)), dim3(256), 0,
                      s, static_cast<const DriJobDev*>(p->d_dri_jobs.ptr),
                      static_cast<const uint32_t*>(p->d_marker_count.ptr),
@@ -3890,7 +3972,7 @@ int run_dri_device(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t 
                      static_cast<const uint2*>(p->d_dri_sorted.ptr),
                      static_cast<uint32_t*>(p->d_dri_status.ptr));
   RSX_HIP_CHECK(ctx, hipGetLastError());
-  mark(p, "lj_marker_scan + lj_dri_sort + lj_dri_layout");
+  mark(p, "lj_dri_scan + lj_dri_sort + lj_dri_layout");
   return ljpeg_plan_run_(c, in_dev, out_dev, s, p->timer, true);
 }
 

@@ -273,6 +273,10 @@ struct LjArgs {
                              // round trip less in front of its image loads)
   uint32_t fast_rotate;      // != 0: the streams' turn inside a group of n_streams tickets
                              // rotates from group to group (see ljpeg_plan_create)
+  uint32_t dev_layout;       // != 0: streams[], block_stream[] and fast_order[] are REWRITTEN by
+                             // a kernel in every run (restart intervals laid out on the device,
+                             // lj_dri_layout_kernel): the kernels that read them through the
+                             // scalar cache invalidate it first (lj_fresh_scalars)
   uint32_t fuse_consumed;    // != 0: lj_scan_kernel does lj_consumed_kernel's work as well
   uint32_t pass;             // 0: first pass; 1: the multi-kernel pipeline redoes FL_SLOW
                              // streams; 2: its streams of both passes
@@ -282,6 +286,18 @@ struct LjArgs {
 // [0] entry / exit state, symbols, inclusive symbol base; [1..4] LOCAL transfer of the
 // predictor state (a, v; two words each for 4 components); [5..8] the inclusive state
 constexpr int LF_LB_WORDS = 9;
+
+// Nothing invalidates a CU's scalar data cache between two kernels of a stream (measured in
+// round 3 on the LDS-level word): a kernel that reads, through scalar loads, words another
+// kernel has rewritten since the cache last saw them must drop the cache itself.  Plans
+// laid out on the host never rewrite such words; plans laid out on the device do, every run.
+__device__ __forceinline__ void lj_fresh_scalars(const LjArgs& a) {
+#ifdef RSX_NO_FRESH_SCALARS // (A/B builds only: wrong for plans laid out on the device)
+  return;
+#endif
+  if (a.dev_layout)
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
 
 // Which streams a kernel of the multi-kernel pipeline works on.  First pass: every
 // stream the single-pass kernel does not take.  Second pass (launched when the first one

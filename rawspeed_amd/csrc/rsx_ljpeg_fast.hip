@@ -986,6 +986,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // of a DNG) work (stream, block) out arithmetically: nothing stands in front of the image
   // loads; the others read fast_order's entry first.
   (void)TICKET0;
+  lj_fresh_scalars(a);
   const uint32_t t_blk = blockIdx.x;
   const uint32_t chosen_now = __hip_atomic_load(&a.fast_level[a.run_parity], __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_AGENT);
