@@ -614,6 +614,9 @@ __device__ __forceinline__ uint32_t lj_exact_symbol_bits(uint32_t w, const TabLd
 // through the one-symbol loop.  A miss in either look-up (0x80 + anything >= 128) takes ONE
 // symbol by the 10-bit table, as the loop above would.
 // 10 vector instructions and 4 LDS reads per PAIR where the loop above takes 14-16 and 6.
+#ifndef RSX_K0_FINAL_POLLS
+#define RSX_K0_FINAL_POLLS 64 // polls for the predecessor's FINAL hand-over word (two-table plans)
+#endif
 constexpr uint32_t LJ_GUESS_ROUNDS = 6; // rounds of the chain's fixed-point iteration, at most
 // dword rows 17..19 of the image (3 KB, free once the image is written out): the 10-bit
 // length table | the 8-bit one, or the SECOND 10-bit table of a two-table stream | the chain's
@@ -1128,7 +1131,9 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
           // (the predecessor's word from behind ITS rounds, if it comes within a few polls:
           // in 1.3 % of the workgroups the rounds move the last slot's exit, and a workgroup
           // that started from the older state is a slow one in the single-pass kernel)
-          for (uint32_t spins = 0; spins < 16u && (v & 0xE000u) != (tag | 0x2000u); ++spins) {
+          for (uint32_t spins = 0; spins < uint32_t(RSX_K0_FINAL_POLLS) &&
+                                   (v & 0xE000u) != (tag | 0x2000u);
+               ++spins) {
             const uint32_t w = __hip_atomic_load(&a.k0e[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((w & 0xC000u) == tag)
               v = w;
@@ -2847,6 +2852,11 @@ __global__ __launch_bounds__(256) void lj_dri_scan_kernel(const uint8_t* __restr
   }
 }
 
+// every CU drops its scalar data cache (rsx_ljpeg_dev.h, lj_fresh_scalars' note)
+__global__ __launch_bounds__(64) void lj_dcache_inv_kernel() {
+  asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // the first n_ri markers of every job in stream order: rank of an entry = entries in front
 __global__ __launch_bounds__(256) void lj_dri_sort_kernel(const DriJobDev* jobs,
                                                           const uint32_t* count,
@@ -3971,6 +3981,8 @@ int run_dri_device(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t 
                      static_cast<const uint32_t*>(p->d_marker_count.ptr),
                      static_cast<const uint2*>(p->d_dri_sorted.ptr),
                      static_cast<uint32_t*>(p->d_dri_status.ptr));
+  // (4096 one-wavefront workgroups: sixteen for each of the 256 CUs)
+  hipLaunchKernelGGL(lj_dcache_inv_kernel, dim3(4096), dim3(64), 0, s);
   RSX_HIP_CHECK(ctx, hipGetLastError());
   mark(p, "lj_dri_scan + lj_dri_sort + lj_dri_layout");
   return ljpeg_plan_run_(c, in_dev, out_dev, s, p->timer, true);

@@ -289,15 +289,14 @@ constexpr int LF_LB_WORDS = 9;
 
 // Nothing invalidates a CU's scalar data cache between two kernels of a stream (measured in
 // round 3 on the LDS-level word): a kernel that reads, through scalar loads, words another
-// kernel has rewritten since the cache last saw them must drop the cache itself.  Plans
-// laid out on the host never rewrite such words; plans laid out on the device do, every run.
-__device__ __forceinline__ void lj_fresh_scalars(const LjArgs& a) {
-#ifdef RSX_NO_FRESH_SCALARS // (A/B builds only: wrong for plans laid out on the device)
-  return;
-#endif
-  if (a.dev_layout)
-    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-}
+// kernel has rewritten since the cache last saw them could see the old ones.  Plans laid
+// out on the host never rewrite such words; plans laid out on the device (restart
+// intervals, lj_dri_layout_kernel) do, every run -- their layout kernel is followed by
+// lj_dcache_inv_kernel, a grid wide enough to put a wavefront on every CU, each of which
+// drops its scalar cache.  (As a conditional `s_dcache_inv` at the top of K0 and the
+// single-pass kernel it cost EVERY plan 1-2 % of both: the asm statement kept the
+// compiler from batching the kernels' first loads.)
+__device__ __forceinline__ void lj_fresh_scalars(const LjArgs&) {}
 
 // Which streams a kernel of the multi-kernel pipeline works on.  First pass: every
 // stream the single-pass kernel does not take.  Second pass (launched when the first one
