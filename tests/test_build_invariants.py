@@ -50,7 +50,8 @@ def kernel_descriptors():
 
 def test_single_pass_kernel_has_no_static_lds(kernel_descriptors):
     # (components, two alternating tables)
-    assert set(kernel_descriptors) == {(1, False), (2, False), (4, False), (2, True), (4, True)}
+    assert set(kernel_descriptors) == {(1, False), (2, False), (3, False), (4, False), (2, True),
+                                       (4, True)}
     for n, k in kernel_descriptors.items():
         assert k["group_segment_fixed_size"] == 0, (n, k)
 
