@@ -47,3 +47,5 @@ fi
 python $REPO/scripts/ljpeg_limiter.py $OUT > /dev/null 2>&1
 ls -la $OUT
 tail -c 400 $OUT/bench_full.json
+timeout 900 python -m pytest $REPO/tests -q -m gpu 2>&1 | tail -5 > $OUT/pytest_gpu_tail.txt
+cat $OUT/pytest_gpu_tail.txt

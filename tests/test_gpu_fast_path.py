@@ -571,3 +571,42 @@ def test_restart_interval_anomalies_fall_back_to_the_host_built_plan(gpu, oracle
         if want[0] == 0:
             assert got == want, (name, got, want)
             assert np.array_equal(img_g.buf, img_o.buf), name
+
+
+def test_device_laid_out_plan_reused_over_different_inputs(gpu, oracle):
+    """One plan, three different images of the same geometry (padded to one byte count): the
+    restart markers sit elsewhere in each, so the layout kernel rewrites the child plan's
+    stream records, block map and ticket order every run -- and the kernels behind it must
+    see THIS run's words, not the ones a cache kept from the run before."""
+    w, h, rpi = 1536, 640, 11
+    cases_ = []
+    for seed in (1, 2, 3):
+        rng = np.random.default_rng(7000 + seed)
+        d, data, tile_px, scan_len = C.make_ljpeg_case(rng, img_w=w, img_h=h, cpp=1,
+                                                       tile=(0, 0, w, h), mcu=(2, 1),
+                                                       rows_per_ri=rpi, sigma=8.0 * seed)
+        cases_.append((d, data, scan_len))
+    size = max(c[1].size for c in cases_) + 64
+    size += (-size) % 16
+    padded = [np.concatenate([c[1], np.zeros(size - c[1].size, np.uint8)]) for c in cases_]
+    img = HostImage(w, h)
+    j = abi.LJpegJob()
+    j.desc = cases_[0][0]
+    j.in_offset, j.in_bytes, j.img_offset = 0, size, 0
+    j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = img.pitch, w, h, 1, 1
+    plan = gpu.ljpeg_plan([j])
+    out = torch.zeros(img.pitch * h, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    for rep in range(2):
+        for k in (0, 1, 2, 1, 0):
+            inp = torch.from_numpy(padded[k]).cuda()
+            out.fill_(0x5A)
+            plan.run(inp.data_ptr(), out.data_ptr(), s)
+            rc, st, cons = plan.results()
+            want_img = HostImage(w, h, fill=0x5A)
+            want = oracle.ljpeg(cases_[k][0], padded[k], want_img)
+            assert rc == 0 and (st[0], cons[0]) == want, (rep, k, st[0], cons[0], want)
+            assert np.array_equal(out.cpu().numpy(), want_img.buf), (rep, k)
+    inp = torch.from_numpy(padded[0]).cuda()
+    names = _kernel_names(plan, inp, out)
+    assert any("lj_dri_layout" in n for n in names), names
