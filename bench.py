@@ -396,22 +396,24 @@ def replayed_ljpeg_counters():
 
 def ljpeg_summary(extra):
     """the LJPEG legs and the SURVEY 8(f) legs of `extra`, compressed for the one-line JSON.
-    Every entry carries a `roofline` measured IN THIS RUN (algorithmic bytes, the dominant
-    kernel and its hipEvent average, fraction of the HBM peak over the whole step); what
-    comes from committed rocprofv3 PMC passes sits apart under `replayed`."""
+    Every entry carries a `roofline` measured IN THIS RUN -- alg_MB: algorithmic bytes of a
+    step, frac: of the 8 TB/s HBM peak over the whole step (wall clock of the timed steps),
+    kernel / kernel_ms: the dominant kernel and its hipEvent average --; what comes from
+    committed rocprofv3 PMC passes sits apart under `replayed`.  (Full objects: bench_extra.json.)"""
     def roof(d):
         r = d.get("roofline")
         if not isinstance(r, dict):
             return None
         k = r.get("kernel")
-        return {"alg_bytes": r.get("algorithmic_bytes"), "frac": r.get("frac"),
-                "kernel": k.replace("lj_", "").replace("_kernel", "") if k else None,
-                "avg_kernel_ms": r.get("avg_kernel_ms")}
+        return {"alg_MB": round(r.get("algorithmic_bytes", 0) / 1e6, 1), "frac": r.get("frac"),
+                "kernel": k.replace("lj_", "").replace("_kernel", "")
+                           .replace("legacy reconstruction (K5 + K6)", "legacy_recon") if k else None,
+                "kernel_ms": round(r["avg_kernel_ms"], 3) if r.get("avg_kernel_ms") else None}
 
     def leg(d, cpu=True, kernels=True):
         if not isinstance(d, dict) or "ms_per_step" not in d:
             return d if isinstance(d, dict) and "error" in d else None
-        r = {"ms_per_step": d["ms_per_step"], "gpix_per_s": round(d["mpix_per_s"] / 1e3, 1),
+        r = {"ms": d["ms_per_step"], "gpix_per_s": round(d["mpix_per_s"] / 1e3, 1),
              "bit_exact": d.get("bit_exact"), "roofline": roof(d)}
         if kernels and "kernels_ms" in d:
             r["kernels_ms"] = {k.replace("lj_", "").replace("_kernel", ""): round(v, 3)
@@ -455,7 +457,17 @@ def ljpeg_summary(extra):
     if isinstance(sr, dict) and isinstance(sr.get("interpolate"), dict):
         f["cr2_sraw_interpolate"] = leg(sr["interpolate"], cpu=False, kernels=False)
     s["survey_8f"] = {k: v for k, v in f.items() if v}
-    s["replayed"] = replayed_ljpeg_counters()
+    # (replayed figures: the numbers and the FILE they come from; phases, parse counts and the
+    # long provenance texts stay in that file and in bench_extra.json -- the line is a tail
+    # of stdout for the driver, 6 KB at most)
+    rep = replayed_ljpeg_counters()
+    short = {k: rep[k] for k in ("traffic_over_algorithmic", "valu_issue_frac",
+                                 "lane_instr_per_symbol", "wg_lifetime_us") if k in rep}
+    import re as _re
+    srcs = sorted({m for v in rep.values() if isinstance(v, str)
+                   for m in _re.findall(r"profiles/r\d+/[\w/.]+", v)})
+    short["source"] = "committed rocprofv3 passes, not measured in this run: " + ", ".join(srcs)
+    s["replayed"] = short
     return s
 
 

@@ -1051,8 +1051,11 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   static_assert(5 * LJ_T <= LJ_IMG_U4, "five uint4 a lane stay inside the block's image");
   uint4 im[5];
 #pragma unroll
-  for (int k = 0; k < 5; ++k)
-    im[k] = img_src[k * LJ_T + j]; // (rows 17..19 ride along in the last one: not parked)
+  for (int k = 0; k < 4; ++k)
+    im[k] = img_src[k * LJ_T + j];
+  // (the fifth: row 16 for the first 64 lanes; the others ask for their first chunk again --
+  // a line they hold -- instead of rows 17..19, which nobody reads: 47 MB of HBM reads on cfg 3)
+  im[4] = img_src[j < LF_BW * LJ_T / 4 - 4 * LJ_T ? 4 * LJ_T + j : j];
   const uint32_t ob_now = reinterpret_cast<const uint32_t*>(img_src + (LJ_BW / 4) * LJ_T)[j];
   // (a stream's subsequences are numbered from first_block * LJ_OWN: the guesses too; lane 0
   // reads lane 1's and ignores it)

@@ -22,7 +22,8 @@ import sys
 d = sys.argv[1]
 symbols = int(sys.argv[2]) if len(sys.argv) > 2 else 8 * 6720 * 4480
 bits = float(sys.argv[3]) if len(sys.argv) > 3 else 8.35
-out = {"how": "scripts/ljpeg_limiter.py over %s (cfg 3, 8 frames, %d symbols)" % (d, symbols)}
+out = {"how": "scripts/ljpeg_limiter.py over the round's collected profiles (%s: cfg 3, 8 frames, %d "
+              "symbols)" % (os.path.basename(os.path.normpath(d)).replace("prof_", "profiles/"), symbols)}
 p = os.path.join(d, "cfg3_phase_and_round_stats.txt")
 if os.path.exists(p):
     phases = {}
