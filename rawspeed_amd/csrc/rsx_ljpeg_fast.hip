@@ -507,12 +507,25 @@ __device__ __forceinline__ uint32_t fld_mask1(uint32_t flags2) { // two flag bit
   return ((flags2 & 1u) ? 0xFFFFu : 0u) | ((flags2 & 2u) ? 0xFFFF0000u : 0u);
 }
 
+// The window of a look-back-1 pass: LF_LB1_WAVES wavefronts of 64 records.  256 records until
+// round 5 -- "whatever the stream has in flight" --; but a pass asks for 32-64 B of EVERY
+// record in its window, a line each, and the nearest inclusive state is a handful of
+// workgroups away: with one wavefront's 64 the kernel is 3 % (cfg 3), 8 % (cfg 4), 15 %
+// (4 frames of noise; 3 components) faster, and a stream alone on the chip (1024 workgroups
+// in flight) still gains 6 % (profiles/r05/ab_lookback_window.txt).  The first pass looks at
+// the LF_LB1_WIN0 nearest only: 16 or 32 are another 2-5 % over 64, 8 and 4 no better.
+#ifndef LF_LB1_WAVES
+#define LF_LB1_WAVES 1
+#endif
+#ifndef LF_LB1_WIN0
+#define LF_LB1_WIN0 16
+#endif
 // Look-back 1 (the whole workgroup, one record per lane and pass): the predictor state
 // (T, Vc) before the workgroup = the nearest inclusive state, carried through the LOCAL
 // transfers of the workgroups in between.  The transfers compose associatively: a
 // wavefront scan (nearer workgroups applied later), the four wavefronts' results in LDS.
 // (First version: one wavefront, a serial fold over its 64 lanes -- 10 us a workgroup.)
-template <int N>
+template <int N, int lbw>
 __device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint32_t b,
                                          uint32_t first_block, uint2 init, int j, uint2* T_in,
                                          uint2* V_in) {
@@ -525,14 +538,18 @@ __device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint
     g.f[k] = g.a[k] = g.v[k] = 0;
   const uint32_t initw[2] = {init.x, init.y};
   int64_t pos = int64_t(b) - 1;
+  // (the records a pass asks for: the first pass of the one-wavefront walk looks at the
+  // LF_LB1_WIN0 nearest only, the passes behind it -- all of them LOCAL -- at 64)
+  int win = lbw == 1 ? LF_LB1_WIN0 : 64;
   for (uint32_t spins = 0; spins < LF_SPIN_LIMIT; ++spins) {
     const int64_t idx = pos - j;
+    const bool inwin = wv < lbw && lane < win; // (outside the window: no record, LOCAL nothing)
     const bool real = idx >= int64_t(first_block);
     u64 wa[NW], wv_[NW], wt[NW], wc[NW];
 #pragma unroll
     for (int k = 0; k < NW; ++k)
       wa[k] = wv_[k] = wt[k] = wc[k] = 0;
-    if (real) {
+    if (real && inwin) {
       const u64* p = A + size_t(idx) * LF_LB_WORDS + 1;
 #pragma unroll
       for (int k = 0; k < NW; ++k) {
@@ -552,9 +569,9 @@ __device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint
       pre = true;
       loc = false;
     }
-    const u64 m_pre = __ballot(pre), m_loc = __ballot(loc && !pre);
-    // lanes 0 .. f-1 LOCAL, lane f inclusive state
-    const int f = m_pre ? __builtin_ctzll(m_pre) : 64;
+    const u64 m_pre = __ballot(pre && inwin), m_loc = __ballot(loc && !pre);
+    // lanes 0 .. f-1 LOCAL, lane f inclusive state (f == win: none in the window)
+    const int f = m_pre ? __builtin_ctzll(m_pre) : win;
     const u64 need = f == 64 ? ~0ull : ((1ull << f) - 1ull);
     const bool wave_ok = (m_loc & need) == need;
     // inclusive scan of the transfers: lane t <- lanes 0..t, lane 0 (nearest) applied last
@@ -591,7 +608,7 @@ __device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint
           X[2 + k] = 0u;
       }
     }
-    if (f > 0 && lane == (f == 64 ? 63 : f - 1)) {
+    if (f > 0 && lane == f - 1) {
 #pragma unroll
       for (int k = 0; k < NW; ++k) {
         X[2 + k] = c.f[k];
@@ -599,7 +616,7 @@ __device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint
         X[6 + k] = c.v[k];
       }
     }
-    if (f < 64 && lane == f) {
+    if (f < win && lane == f) {
 #pragma unroll
       for (int k = 0; k < NW; ++k) {
         X[8 + k] = real ? uint32_t(wt[k]) : initw[k];
@@ -614,7 +631,7 @@ __device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint
       Tf[k] = Vf[k] = 0;
 #pragma unroll
     for (int w4 = 0; w4 < 4; ++w4) {
-      if (state != 0)
+      if (state != 0 || w4 >= lbw)
         continue;
       const uint32_t* Y = F.misc + M_LBX + 12 * w4;
       if (!uni(Y[1])) {
@@ -629,7 +646,7 @@ __device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint
         h.v[k] = uni(Y[6 + k]);
       }
       g = xfer_compose<NW>(h, g); // this wavefront's lanes are farther than everything so far
-      if (uni(Y[0]) < 64u) {
+      if (uni(Y[0]) < uint32_t(win)) {
         state = 1;
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
@@ -651,7 +668,8 @@ __device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint
       return true;
     }
     if (state == 0) {
-      pos -= LJ_T;
+      pos -= lbw == 1 ? win : 64 * lbw;
+      win = 64;
       continue;
     }
     // blocked: forget this pass's partial composition and look again
@@ -956,7 +974,7 @@ __device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad
 // ---------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------
-template <int N, bool MT>
+template <int N, bool MT, bool PROBE>
 __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds_bytes,
                                                           uint32_t level) {
   constexpr uint32_t TICKET0 = (MT ? 12u : 0u) + (N == 4 ? 2u : (N == 3 ? 3u : uint32_t(N) - 1u));
@@ -990,6 +1008,14 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   const uint32_t t_blk = blockIdx.x;
   const uint32_t chosen_now = __hip_atomic_load(&a.fast_level[a.run_parity], __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_AGENT);
+  // (A plan's FIRST run launches every LDS level it might need and one of them works -- the
+  // PROBE instantiation: the others ask for nothing else.  With the level looked at behind
+  // the head's loads, as the runs after it do, each of them read the whole un-stuffed image,
+  // 2 x 300 MB on cfg 3; as a run-time condition in the one instantiation the test cost every
+  // run 1.5-2 %: scripts/r05q.sh.)
+  if constexpr (PROBE)
+    if (uni(chosen_now) != level)
+      return;
   uint32_t b, s, fb_now, tz_now = 0, tbv = 0, tpv = 0;
   const bool uniform_plan = a.fast_uniform_nb != 0u;
   if (uniform_plan) {
@@ -1055,7 +1081,11 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     im[k] = img_src[k * LJ_T + j];
   // (the fifth: row 16 for the first 64 lanes; the others ask for their first chunk again --
   // a line they hold -- instead of rows 17..19, which nobody reads: 47 MB of HBM reads on cfg 3)
+#ifdef RSX_LF_FIFTH_PLAIN // (experiment: rows 17..19 read as well)
+  im[4] = img_src[4 * LJ_T + j];
+#else
   im[4] = img_src[j < LF_BW * LJ_T / 4 - 4 * LJ_T ? 4 * LJ_T + j : j];
+#endif
   const uint32_t ob_now = reinterpret_cast<const uint32_t*>(img_src + (LJ_BW / 4) * LJ_T)[j];
   // (a stream's subsequences are numbered from first_block * LJ_OWN: the guesses too; lane 0
   // reads lane 1's and ignores it)
@@ -1785,8 +1815,9 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     const uint32_t flags = lb1_flags;
     const uint2 al = lb1_al;
     bool ok = true;
-    if (lb != 0 && !(LF_ABLATE & 8u))
-      ok = lb1_walk<N>(a, F, b, S.first_block, init, j, &T_in, &V_in);
+    if (lb != 0 && !(LF_ABLATE & 8u)) {
+      ok = lb1_walk<N, LF_LB1_WAVES>(a, F, b, S.first_block, init, j, &T_in, &V_in);
+    }
     if (j == 0) {
       if (!ok)
         F.misc[M_SLOW] = 9;
@@ -1864,11 +1895,16 @@ template <int N, bool MT>
 void launch_fast_one(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
   if (!f.present[MT ? 1 : 0][N])
     return;
+  const bool probe = (a.fast_level_mask & (a.fast_level_mask - 1u)) != 0u; // (more than one level)
   for (uint32_t lv = 0; lv < 3; ++lv) {
     if (!((a.fast_level_mask >> lv) & 1u))
       continue;
-    hipLaunchKernelGGL((lj_fast_kernel<N, MT>), dim3(f.total_blocks), dim3(LJ_T),
-                       a.fast_lds_lv[lv], s, a, a.fast_lds_lv[lv], lv);
+    if (probe)
+      hipLaunchKernelGGL((lj_fast_kernel<N, MT, true>), dim3(f.total_blocks), dim3(LJ_T),
+                         a.fast_lds_lv[lv], s, a, a.fast_lds_lv[lv], lv);
+    else
+      hipLaunchKernelGGL((lj_fast_kernel<N, MT, false>), dim3(f.total_blocks), dim3(LJ_T),
+                         a.fast_lds_lv[lv], s, a, a.fast_lds_lv[lv], lv);
     if (timer)
       timer->mark(lv == 0 ? "lj_fast_kernel" : (lv == 1 ? "lj_fast_kernel(3/CU)" : "lj_fast_kernel(2/CU)"));
   }

@@ -38,10 +38,10 @@ def kernel_descriptors():
         text = open(out).read()
     found = {}
     for m in re.finditer(
-            r"\.amdhsa_kernel (\S*lj_fast_kernelILi(\d)ELb([01])E\S*)(.*?)\.end_amdhsa_kernel",
+            r"\.amdhsa_kernel (\S*lj_fast_kernelILi(\d)ELb([01])ELb([01])E\S*)(.*?)\.end_amdhsa_kernel",
             text, re.S):
-        body = m.group(4)
-        found[(int(m.group(2)), bool(int(m.group(3))))] = {
+        body = m.group(5)
+        found[(int(m.group(2)), bool(int(m.group(3))), bool(int(m.group(4))))] = {
             k: int(re.search(r"\.amdhsa_%s (\d+)" % k, body).group(1))
             for k in ("group_segment_fixed_size", "private_segment_fixed_size",
                       "next_free_vgpr")}
@@ -49,9 +49,11 @@ def kernel_descriptors():
 
 
 def test_single_pass_kernel_has_no_static_lds(kernel_descriptors):
-    # (components, two alternating tables)
-    assert set(kernel_descriptors) == {(1, False), (2, False), (3, False), (4, False), (2, True),
-                                       (4, True)}
+    # (components, two alternating tables, the first run's instantiation that looks at the LDS
+    # level before it asks for anything else)
+    assert set(kernel_descriptors) == {(n, mt, probe) for probe in (False, True) for n, mt in
+                                       ((1, False), (2, False), (3, False), (4, False), (2, True),
+                                        (4, True))}
     for n, k in kernel_descriptors.items():
         assert k["group_segment_fixed_size"] == 0, (n, k)
 

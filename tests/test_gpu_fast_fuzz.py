@@ -4,6 +4,8 @@ against the oracle: images stitched from bands of sensor noise, constant values,
 short-period patterns (where the bit stream does not synchronise), random canonical tables,
 1 / 2 / 4 components, tiles narrower than their frames, bytes behind the end-of-image marker,
 several streams per call."""
+import os
+
 import numpy as np
 import pytest
 
@@ -13,6 +15,9 @@ import cases as C
 from oracle_lib import HostImage
 
 pytestmark = pytest.mark.gpu
+
+# RSX_FUZZ_BASE=<k> moves every case to another seed (soak runs)
+BASE = int(os.environ.get("RSX_FUZZ_BASE", "0"))
 
 
 @pytest.fixture(scope="module")
@@ -73,7 +78,7 @@ def make_stream(rng, W, H, tx, ty, tw, th, n, prec, table, tail):
 
 @pytest.mark.parametrize("seed", range(48))
 def test_fuzz_single_pass_kernel(gpu, oracle, seed):
-    rng = np.random.default_rng([2027, seed])
+    rng = np.random.default_rng([2027, seed] + ([BASE] if BASE else []))
     n = int(rng.choice([1, 2, 2, 4]))
     prec = int(rng.choice([12, 14, 14, 16]))
     n_cat = 17 if prec == 16 else prec + 1
@@ -111,7 +116,7 @@ def test_fuzz_single_pass_kernel(gpu, oracle, seed):
 def test_fuzz_single_pass_kernel_large(gpu, oracle, seed):
     """The same at hundreds of workgroups per stream (look-back windows of 256 records and
     more, the kernel's rounds of resident workgroups, both LDS levels in one call)."""
-    rng = np.random.default_rng([2028, seed])
+    rng = np.random.default_rng([2028, seed] + ([BASE] if BASE else []))
     n = int(rng.choice([1, 2, 4]))
     prec = int(rng.choice([12, 14]))
     table = C.random_huffman_table(rng, prec + 1, skew=float(rng.uniform(0.6, 2.0)))
