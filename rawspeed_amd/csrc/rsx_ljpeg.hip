@@ -839,6 +839,17 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     b = blockIdx.x;
   lj_fresh_scalars(a);
   const uint32_t s = a.block_stream[b];
+  // The NEXT run's results (marker_pos = 0xFFFFFFFF, an atomicMin target; everything else 0),
+  // a dword a lane of the first workgroups: the plan keeps two sets and takes turns, so a
+  // run finds its set clean without a kernel in front of it (lj_init_results_kernel: 6 us in
+  // front of every run, 3 % of a single cfg-4 frame; still launched for a plan's first run).
+  {
+    constexpr uint32_t DW = uint32_t(sizeof(LjResult) / 4);
+    const uint32_t i = blockIdx.x * uint32_t(LJ_T) + threadIdx.x;
+    if (a.results_next && i < a.n_streams * DW)
+      reinterpret_cast<uint32_t*>(a.results_next)[i] =
+          (i % DW == uint32_t(offsetof(LjResult, marker_pos) / 4)) ? 0xFFFFFFFFu : 0u;
+  }
   if (s == 0xFFFFFFFFu)
     return; // (a block no stream owns: plans laid out on the device, lj_dri_layout_kernel)
   const LjStreamDev& S = a.streams[s];
@@ -1785,6 +1796,86 @@ __device__ __forceinline__ uint2 lj_rot_fields_rt(uint2 v, uint32_t f, uint32_t 
 // ---------------------------------------------------------------------------
 __device__ void lj_consumed_body(const LjArgs& a, uint32_t s, int lane);
 
+// The scan of a single-pass stream's first pass, LJ_T * K workgroups at a time: a thread owns K
+// consecutive workgroups and asks for everything the scan and its checks read of them AT ONCE.
+// (The loop below reads its seven words under the conditions that need them -- i >= 1, i < nb,
+// "delivered symbols behind it" --, which the compiler turns into as many memory round trips
+// in a row: 4 us for every 256 workgroups of a stream, measured as 0.023 / 0.037 / 0.063 ms
+// of kernel for streams of 680 / 1930 / 3200 workgroups.)  carry / dcarry: the symbols and
+// dropped bytes in front of `base`; returns whether a check failed for this thread.
+template <int K>
+__device__ __forceinline__ bool lj_scan_first_pass(const LjArgs& a, uint32_t fb, uint32_t nb,
+                                                   uint64_t needed, uint32_t base,
+                                                   uint32_t* carry, uint32_t* dcarry,
+                                                   uint32_t* wsum, uint32_t* dsum, int tid) {
+  const uint32_t n_here = nb - base < uint32_t(LJ_T * K) ? nb - base : uint32_t(LJ_T * K);
+  const uint32_t kk = (n_here + uint32_t(LJ_T) - 1u) / uint32_t(LJ_T); // (<= K)
+  const uint32_t i0 = base + uint32_t(tid) * kk;
+  uint32_t v[K], dv[K], b0[K], st[K], ex[K], fl[K];
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    // (every address valid, every load unconditional; what lies outside is dropped below)
+    const uint32_t i = i0 + uint32_t(q);
+    const uint32_t ic = (uint32_t(q) < kk && i < nb) ? i : nb - 1u;
+    v[q] = a.block_sum[fb + ic];
+    dv[q] = a.block_drops[fb + ic];
+    b0[q] = a.block_base0[fb + ic];
+    st[q] = a.block_start[fb + ic];
+    ex[q] = a.block_exit[fb + (ic ? ic - 1u : 0u)];
+    fl[q] = a.block_flags[fb + ic];
+  }
+  uint32_t run = 0, drun = 0;
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    const bool in = uint32_t(q) < kk && i0 + uint32_t(q) < nb;
+    v[q] = in ? v[q] : 0u;
+    dv[q] = in ? dv[q] : 0u;
+    run += v[q];
+    drun += dv[q];
+  }
+  // exclusive scan of the threads' totals
+  uint32_t x = run, dx = drun;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o, 64);
+    const uint32_t dy = __shfl_up(dx, o, 64);
+    if ((tid & 63) >= o) {
+      x += y;
+      dx += dy;
+    }
+  }
+  if ((tid & 63) == 63) {
+    wsum[tid >> 6] = x;
+    dsum[tid >> 6] = dx;
+  }
+  __syncthreads();
+  uint32_t excl = *carry + x - run, dexcl = *dcarry + dx - drun;
+  for (int w = 0; w < (tid >> 6); ++w) {
+    excl += wsum[w];
+    dexcl += dsum[w];
+  }
+  *carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  *dcarry += dsum[0] + dsum[1] + dsum[2] + dsum[3];
+  bool bad = false;
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    const uint32_t i = i0 + uint32_t(q);
+    if (uint32_t(q) < kk && i < nb) {
+      a.block_base[fb + i] = excl;
+      a.block_drop_base[fb + i] = dexcl;
+      // (the checks of the loop in lj_scan_kernel, for fast_first: see there)
+      const bool matters = uint64_t(excl) < needed;
+      const bool link_broken = i >= 1u && st[q] != ex[q] && !(ex[q] & ST_ERR);
+      bad = bad || ((fl[q] & 1u) != 0u && matters) || (link_broken && matters) ||
+            (b0[q] != excl && (matters || uint64_t(b0[q]) < needed));
+    }
+    excl += v[q];
+    dexcl += dv[q];
+  }
+  __syncthreads(); // (wsum / dsum are free again)
+  return bad;
+}
+
 __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
   __shared__ uint32_t wsum[4], dsum[4];
   __shared__ uint2 psum[4];
@@ -1811,7 +1902,34 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
     unconv_s = 0;
   }
   __syncthreads();
-  for (uint32_t base = 0; base < nb; base += LJ_T) {
+  // (single-pass streams, first pass -- every run's, unless the kernel gave a stream up)
+#ifndef RSX_EXPERIMENT // (experiment builds keep the loop: it records the first workgroup that fails a check)
+  const bool batched = S.fast && a.pass == 0 && a.block_base0 != nullptr;
+#else
+  const bool batched = false;
+#endif
+  if (batched) {
+    uint32_t carry = 0, dcarry = 0;
+    bool bad = false;
+    const uint64_t needed = S.needed;
+    for (uint32_t base = 0; base < nb;) {
+      if (nb - base <= uint32_t(LJ_T) * 4u) {
+        bad = lj_scan_first_pass<4>(a, fb, nb, needed, base, &carry, &dcarry, wsum, dsum, tid) || bad;
+        base += uint32_t(LJ_T) * 4u;
+      } else {
+        bad = lj_scan_first_pass<16>(a, fb, nb, needed, base, &carry, &dcarry, wsum, dsum, tid) || bad;
+        base += uint32_t(LJ_T) * 16u;
+      }
+    }
+    if (bad)
+      unconv_s = 1;
+    if (tid == 0) {
+      carry_s = carry;
+      dcarry_s = dcarry;
+    }
+    __syncthreads();
+  }
+  for (uint32_t base = batched ? nb : 0u; base < nb; base += LJ_T) {
     const uint32_t i = base + tid;
     const uint32_t v = i < nb ? a.block_sum[fb + i] : 0u;
     const uint32_t dv = i < nb ? a.block_drops[fb + i] : 0u;
@@ -3008,6 +3126,8 @@ struct LJpegPlan {
   bool any_fast = false;       // some stream takes the single-pass kernel
   uint32_t fast_lds = 0;       // LDS bytes of its launches
   uint32_t fast_uniform_nb = 0, fast_rotate = 0; // (LjArgs)
+  uint64_t results_clean_for = 0;          // the run (run_count) whose results K0 has cleared ...
+  hipStream_t results_clean_stream = nullptr; // ... on this stream
   std::vector<uint8_t> slow_strikes; // per stream: consecutive runs it went to the slow path
   // streams taken off the single-pass kernel after two such runs: the value `fast` had and
   // the run in which it was cleared (0: not demoted).  The demotion DECAYS: a cached plan
@@ -3084,6 +3204,11 @@ struct LJpegPlan {
 
 namespace {
 
+// the results of the current run (two sets taking turns: lj_unstuff_kernel clears the next run's)
+LjResult* results_of_run(const LJpegPlan* p) {
+  return static_cast<LjResult*>(p->d_results.ptr) + size_t(p->run_count & 1u) * p->streams.size();
+}
+
 LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   LjArgs a{};
   a.in_base = static_cast<const uint8_t*>(in_dev);
@@ -3109,7 +3234,10 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.block_drops = static_cast<uint32_t*>(p->d_block_drops.ptr);
   a.block_drop_base = static_cast<uint32_t*>(p->d_block_drop_base.ptr);
   a.unstuffed = static_cast<uint4*>(p->d_unstuffed.ptr);
-  a.results = static_cast<LjResult*>(p->d_results.ptr);
+  // (two sets of results, taking turns: K0 clears the next run's, see there)
+  a.results = results_of_run(p);
+  a.results_next = static_cast<LjResult*>(p->d_results.ptr) +
+                   size_t((p->run_count & 1u) ^ 1u) * p->streams.size();
   a.diffs = static_cast<int16_t*>(p->d_diffs.ptr);
   a.vseed = static_cast<uint16_t*>(p->d_vseed.ptr);
   a.n_streams = uint32_t(p->streams.size());
@@ -3582,7 +3710,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         (st = p->d_block_drops.ensure(size_t(p->total_blocks) * 4)) ||
         (st = p->d_block_drop_base.ensure(size_t(p->total_blocks) * 4)) ||
         (st = p->d_unstuffed.ensure(size_t(p->total_blocks) * LJ_IMG_U4 * 16)) ||
-        (st = p->d_results.ensure(p->streams.size() * sizeof(LjResult))) ||
+        (st = p->d_results.ensure(2 * p->streams.size() * sizeof(LjResult))) ||
         (st = p->d_diffs.ensure(size_t(p->total_diffs) * 2 + 64)) ||
         (st = p->d_vseed.ensure(size_t(p->total_rows) * 8 + 16)))
       return st;
@@ -4144,14 +4272,20 @@ int ljpeg_plan_run_(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t
   // costs the stream more than a kernel of one wavefront)
   const uint32_t n_streams = uint32_t(p->streams.size());
 #ifdef RSX_RESULTS_BY_COPY
-  RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->d_results.ptr, p->h_results.data(),
+  RSX_HIP_CHECK(ctx, hipMemcpyAsync(results_of_run(p), p->h_results.data(),
                                     p->h_results.size() * sizeof(LjResult),
                                     hipMemcpyHostToDevice, s));
 #else
-  hipLaunchKernelGGL(lj_init_results_kernel, dim3((n_streams * uint32_t(sizeof(LjResult) / 4) + 255) / 256),
-                     dim3(256), 0, s, static_cast<LjResult*>(p->d_results.ptr), n_streams);
-  mark(p, "lj_init_results_kernel");
+  // (unless the run before this one has cleared them: K0 does that for its successor, on the
+  // same stream)
+  if (p->results_clean_for != p->run_count || p->results_clean_stream != s) {
+    hipLaunchKernelGGL(lj_init_results_kernel, dim3((n_streams * uint32_t(sizeof(LjResult) / 4) + 255) / 256),
+                       dim3(256), 0, s, results_of_run(p), n_streams);
+    mark(p, "lj_init_results_kernel");
+  }
 #endif
+  p->results_clean_for = p->run_count + 1;
+  p->results_clean_stream = s;
   if (p->any_fast_mt)
     hipLaunchKernelGGL(lj_unstuff_kernel<true>, dim3(p->total_blocks), dim3(LJ_T), LJ_K0_LDS_MT,
                        s, a);
@@ -4203,7 +4337,7 @@ namespace {
 int converge(LJpegPlan* p, hipStream_t s) {
   rsx_ctx* ctx = p->ctx;
   auto fetch = [&]() -> int {
-    RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->h_results.data(), p->d_results.ptr,
+    RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->h_results.data(), results_of_run(p),
                                       p->h_results.size() * sizeof(LjResult),
                                       hipMemcpyDeviceToHost, s));
     if (p->any_fast)
@@ -4366,7 +4500,7 @@ int converge(LJpegPlan* p, hipStream_t s) {
     R.tail_used = 0;
     R.last_slot = R.last_pos = R.consumed = 0;
   }
-  RSX_HIP_CHECK(ctx, hipMemcpyAsync(p->d_results.ptr, p->h_results.data(),
+  RSX_HIP_CHECK(ctx, hipMemcpyAsync(results_of_run(p), p->h_results.data(),
                                     p->h_results.size() * sizeof(LjResult),
                                     hipMemcpyHostToDevice, s));
   if (int st = launch_tail(p, a, s, true, 3))

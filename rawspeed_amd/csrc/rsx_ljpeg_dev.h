@@ -223,6 +223,7 @@ struct LjArgs {
   uint32_t* block_drop_base; // exclusive prefix of block_drops within the stream
   uint4* unstuffed;          // per workgroup: its LDS image of un-stuffed slots (LJ_BW*LJ_T dwords)
   LjResult* results;
+  LjResult* results_next;    // the next run's set (cleared by lj_unstuff_kernel); nullptr: none
   int16_t* diffs;
   uint16_t* vseed;           // per stream row, 4 x u16: predictor seeds (legacy path) /
                              // row offsets O(r, c) (fused path)
