@@ -1795,6 +1795,9 @@ __device__ __forceinline__ uint2 lj_rot_fields_rt(uint2 v, uint32_t f, uint32_t 
 // whole stream, before each workgroup's first symbol.
 // ---------------------------------------------------------------------------
 __device__ void lj_consumed_body(const LjArgs& a, uint32_t s, int lane);
+__device__ __forceinline__ uint32_t lj_zero_bytes(uint32_t d) { // 0x80 per zero byte, exact
+  return ~(((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d | 0x7F7F7F7Fu);
+}
 
 // The scan of a single-pass stream's first pass, LJ_T * K workgroups at a time: a thread owns K
 // consecutive workgroups and asks for everything the scan and its checks read of them AT ONCE.
@@ -1807,7 +1810,9 @@ template <int K>
 __device__ __forceinline__ bool lj_scan_first_pass(const LjArgs& a, uint32_t fb, uint32_t nb,
                                                    uint64_t needed, uint32_t base,
                                                    uint32_t* carry, uint32_t* dcarry,
-                                                   uint32_t* wsum, uint32_t* dsum, int tid) {
+                                                   uint32_t* wsum, uint32_t* dsum, int tid,
+                                                   uint32_t cap_base_i, uint32_t cap_drop_i,
+                                                   uint32_t* cap) {
   const uint32_t n_here = nb - base < uint32_t(LJ_T * K) ? nb - base : uint32_t(LJ_T * K);
   const uint32_t kk = (n_here + uint32_t(LJ_T) - 1u) / uint32_t(LJ_T); // (<= K)
   const uint32_t i0 = base + uint32_t(tid) * kk;
@@ -1863,6 +1868,11 @@ __device__ __forceinline__ bool lj_scan_first_pass(const LjArgs& a, uint32_t fb,
     if (uint32_t(q) < kk && i < nb) {
       a.block_base[fb + i] = excl;
       a.block_drop_base[fb + i] = dexcl;
+      // (what the kernel's tail wants of the scan: kept in LDS instead of read back)
+      if (i == cap_base_i)
+        cap[0] = excl;
+      if (i == cap_drop_i)
+        cap[1] = dexcl;
       // (the checks of the loop in lj_scan_kernel, for fast_first: see there)
       const bool matters = uint64_t(excl) < needed;
       const bool link_broken = i >= 1u && st[q] != ex[q] && !(ex[q] & ST_ERR);
@@ -1882,6 +1892,7 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
   __shared__ uint32_t carry_s, dcarry_s;
   __shared__ uint2 pcarry_s;
   __shared__ uint32_t unconv_s;
+  __shared__ uint32_t tail_s[16]; // (batched path: [0..3] part, [4..7] / [8..11] stuffing bytes, [12], [13] captures, [14] done)
 #ifdef RSX_EXPERIMENT
   __shared__ uint32_t dbg_first_s;
   if (threadIdx.x == 0)
@@ -1909,27 +1920,159 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
   const bool batched = false;
 #endif
   if (batched) {
+    // Everything the tail of this kernel and the consumed-bytes rule (lj_consumed_body) read
+    // that does NOT depend on the scan is asked for here, in front of it, by all 256 lanes:
+    // the stream's result record, the symbol counts of the slots in front of the end of data,
+    // the bytes of the workgroup region that holds the last symbol and the end of data (their
+    // stuffing bytes are counted 16 bytes a lane, four pieces in flight).  Behind the scan the
+    // tail is arithmetic.  (As it was, the tail was eight to ten memory round trips in a row
+    // on one wavefront: 0.019 ms of kernel for a stream of 680 workgroups whose scan takes 3 us.)
+    // (through a vector register: written by the kernels in front of this one in THIS run, and
+    // nothing invalidates a CU's scalar cache between two kernels of a stream)
+    uint32_t sv = s;
+    asm volatile("" : "+v"(sv));
+    const LjResult Rv = a.results[sv];
+    const uint64_t needed = S.needed;
+    const uint64_t dend = lj_data_end(S), in_bytes = S.in_bytes;
+    const bool has_marker = Rv.marker_pos != 0xFFFFFFFFu && uint64_t(Rv.marker_pos) < in_bytes;
+    const uint64_t M_av = uint64_t(Rv.marker_pos) < dend ? uint64_t(Rv.marker_pos) : dend;
+    const uint64_t M_c = has_marker ? uint64_t(Rv.marker_pos) : dend;
+    const uint64_t lbm_av = M_av / LJ_R; // (the workgroup region the end of data lies in)
+    const uint64_t slot_phys = uint64_t(Rv.last_slot) * LJ_P;
+    uint64_t lbs = slot_phys / LJ_R, lbm = M_c / LJ_R;
+    lbs = lbs >= nb ? nb - 1 : lbs;
+    lbm = lbm >= nb ? nb - 1 : lbm;
+    // the rule's common case: the last symbol's slot and the end of data in one region
+    const bool quick = a.fuse_consumed && !S.raw && !S.pair && lbs == lbm && slot_phys <= M_c &&
+                       M_c <= (lbs + 1) * uint64_t(LJ_R) && nb != 0;
+    uint32_t part = 0;
+    if (lbm_av < nb) {
+      const uint32_t js = uint32_t((M_av - lbm_av * LJ_R) / LJ_P);
+      const uint32_t g0 = S.first_subseq + uint32_t(lbm_av) * LJ_OWN;
+      if (uint32_t(tid) <= js && tid < LJ_OWN)
+        part = a.sub_state[g0 + uint32_t(tid)] >> 16;
+    }
+    uint32_t drops_a = 0, drops_b = 0; // stuffing bytes in [region start, slot), [slot, end of data)
+    if (quick) {
+      const uint8_t* in = a.in_base + S.in_offset;
+      const uint64_t r0 = lbs * uint64_t(LJ_R);
+      uint4 v[4];
+      uint32_t pv[4];
+      bool whole[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint64_t p0 = r0 + (uint64_t(u) * LJ_T + uint32_t(tid)) * 16u;
+        whole[u] = p0 < M_c && p0 + 16 <= in_bytes;
+        v[u] = make_uint4(0, 0, 0, 0);
+        pv[u] = 0;
+        if (whole[u]) {
+          __builtin_memcpy(&v[u], in + p0, 16);
+          pv[u] = p0 > 0 ? in[p0 - 1] : 0u;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint64_t p0 = r0 + (uint64_t(u) * LJ_T + uint32_t(tid)) * 16u;
+        if (p0 >= M_c)
+          continue;
+        uint32_t n = 0;
+        if (whole[u]) {
+          const uint32_t d[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+          uint32_t prev = pv[u];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            // (bytes at and behind the end of data do not count: 0x80 per byte in front of it)
+            const uint64_t q = p0 + 4u * uint32_t(k);
+            const uint32_t live = q + 4 <= M_c ? 0x80808080u
+                                               : (q >= M_c ? 0u : (0x80808080u >> (8u * uint32_t(q + 4 - M_c))));
+            const uint32_t z = lj_zero_bytes(d[k]), f = lj_zero_bytes(~d[k]);
+            n += uint32_t(__builtin_popcount(z & live & ((f << 8) | (prev == 0xFFu ? 0x80u : 0u))));
+            prev = d[k] >> 24;
+          }
+        } else { // (the last bytes of the buffer)
+          uint32_t prev = p0 > 0 ? in[p0 - 1] : 0u;
+          for (uint64_t q = p0; q < M_c && q < in_bytes; ++q) {
+            const uint32_t c = in[q];
+            n += (c == 0u && prev == 0xFFu) ? 1u : 0u;
+            prev = c;
+          }
+        }
+        // (slots are 64 bytes: a 16-byte piece lies on one side of the slot's start)
+        if (p0 < slot_phys)
+          drops_a += n;
+        else
+          drops_b += n;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      part += uint32_t(__shfl_xor(int(part), o, 64));
+      drops_a += uint32_t(__shfl_xor(int(drops_a), o, 64));
+      drops_b += uint32_t(__shfl_xor(int(drops_b), o, 64));
+    }
+    if ((tid & 63) == 0) {
+      tail_s[tid >> 6] = part;
+      tail_s[4 + (tid >> 6)] = drops_a;
+      tail_s[8 + (tid >> 6)] = drops_b;
+    }
+    // the scan
     uint32_t carry = 0, dcarry = 0;
     bool bad = false;
-    const uint64_t needed = S.needed;
     for (uint32_t base = 0; base < nb;) {
       if (nb - base <= uint32_t(LJ_T) * 4u) {
-        bad = lj_scan_first_pass<4>(a, fb, nb, needed, base, &carry, &dcarry, wsum, dsum, tid) || bad;
+        bad = lj_scan_first_pass<4>(a, fb, nb, needed, base, &carry, &dcarry, wsum, dsum, tid,
+                                    uint32_t(lbm_av), uint32_t(lbs), tail_s + 12) || bad;
         base += uint32_t(LJ_T) * 4u;
       } else {
-        bad = lj_scan_first_pass<16>(a, fb, nb, needed, base, &carry, &dcarry, wsum, dsum, tid) || bad;
+        bad = lj_scan_first_pass<16>(a, fb, nb, needed, base, &carry, &dcarry, wsum, dsum, tid,
+                                     uint32_t(lbm_av), uint32_t(lbs), tail_s + 12) || bad;
         base += uint32_t(LJ_T) * 16u;
       }
     }
     if (bad)
       unconv_s = 1;
-    if (tid == 0) {
-      carry_s = carry;
-      dcarry_s = dcarry;
-    }
     __syncthreads();
+    // the tail (what follows the loop below for the other streams), on lane 0
+    bool consumed_done = false;
+    if (tid == 0) {
+      LjResult& R = a.results[s];
+      const uint32_t avail = lbm_av >= nb ? carry
+                                          : tail_s[12] + tail_s[0] + tail_s[1] + tail_s[2] + tail_s[3];
+      R.avail_lo = avail;
+      uint32_t flags = Rv.flags & ~(FL_UNCONVERGED | FL_NEED_LEGACY | FL_PERIODIC);
+      if (unconv_s)
+        flags |= FL_UNCONVERGED;
+      if (nd && uint64_t(avail) < needed)
+        flags |= FL_NEED_LEGACY;
+      if (flags & (FL_UNCONVERGED | FL_NEED_LEGACY))
+        flags = (flags & ~(FL_UNCONVERGED | FL_NEED_LEGACY)) | FL_SLOW;
+      R.flags = flags;
+      // K7's rule (lj_consumed_body) where it is arithmetic: the last refill touched the
+      // marker, or ran off the end of the buffer
+      if (quick && Rv.status == 0 && uint64_t(avail) >= needed && !Rv.tail_used) {
+        const uint64_t drops_slot = uint64_t(tail_s[13]) + tail_s[4] + tail_s[5] + tail_s[6] + tail_s[7];
+        const uint64_t c = (slot_phys - drops_slot) * 8 + Rv.last_pos;
+        const uint64_t K = (c + 31) / 32 + 1;
+        const uint64_t D = M_c - (drops_slot + tail_s[8] + tail_s[9] + tail_s[10] + tail_s[11]);
+        if (4 * K > D) {
+          R.consumed = uint32_t(has_marker ? M_c : in_bytes + (4 * K - D));
+          consumed_done = true;
+        }
+      }
+      // (a stream that is not to be looked at: status set, or symbols missing)
+      if (a.fuse_consumed && (Rv.status != 0 || uint64_t(avail) < needed))
+        consumed_done = true;
+      tail_s[14] = consumed_done ? 1u : 0u;
+    }
+    if (a.fuse_consumed) {
+      __threadfence_block();
+      __syncthreads();
+      if (tail_s[14] == 0u && tid < 64)
+        lj_consumed_body(a, s, tid);
+    }
+    return;
   }
-  for (uint32_t base = batched ? nb : 0u; base < nb; base += LJ_T) {
+  for (uint32_t base = 0; base < nb; base += LJ_T) {
     const uint32_t i = base + tid;
     const uint32_t v = i < nb ? a.block_sum[fb + i] : 0u;
     const uint32_t dv = i < nb ? a.block_drops[fb + i] : 0u;
@@ -2630,9 +2773,6 @@ __global__ __launch_bounds__(64) void lj_tail_kernel(LjArgs a) {
 // ---------------------------------------------------------------------------
 // stuffing bytes (00 preceded by FF) at stream positions [from, to), one wave;
 // each lane scans 16-byte pieces (byte loads of a 17-byte window hit L1/L2)
-__device__ __forceinline__ uint32_t lj_zero_bytes(uint32_t d) { // 0x80 per zero byte, exact
-  return ~(((d & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d | 0x7F7F7F7Fu);
-}
 
 __device__ __forceinline__ uint32_t lj_count_drops(const uint8_t* in, uint64_t from,
                                                    uint64_t to, int lane) {
