@@ -286,7 +286,11 @@ struct LjArgs {
 // words of a workgroup's look-back record (8-byte granules, each self-validating):
 // [0] entry / exit state, symbols, inclusive symbol base; [1..4] LOCAL transfer of the
 // predictor state (a, v; two words each for 4 components); [5..8] the inclusive state
+#ifdef RSX_LF_LB16 // (experiment: LOCAL / inclusive pairs of a record as 16-byte loads)
+constexpr int LF_LB_WORDS = 10;
+#else
 constexpr int LF_LB_WORDS = 9;
+#endif
 
 // Nothing invalidates a CU's scalar data cache between two kernels of a stream (measured in
 // round 3 on the LDS-level word): a kernel that reads, through scalar loads, words another

@@ -249,6 +249,21 @@ __device__ __forceinline__ u64 lb_load(const u64* p) {
 }
 // words 1..8: bit 63 valid | flags (8 bits at 32) | payload (two 16-bit fields)
 constexpr u64 LB_VALID = 1ull << 63;
+// where the words of component pair k sit in a record: LOCAL transfer (a, v), inclusive state (t, c)
+#ifdef RSX_LF_LB16
+// (experiment: a record of 80 bytes, every (a, v) and (t, c) pair on a 16-byte boundary -- one
+// 16-byte load a pair; every 8-byte word carries its own valid bit, so a pair whose halves
+// were written apart is seen as what it is)
+__device__ __forceinline__ constexpr int lb_wa(int k) { return 2 + 4 * k; }
+__device__ __forceinline__ constexpr int lb_wv(int k) { return 3 + 4 * k; }
+__device__ __forceinline__ constexpr int lb_wt(int k) { return 4 + 4 * k; }
+__device__ __forceinline__ constexpr int lb_wc(int k) { return 5 + 4 * k; }
+#else
+__device__ __forceinline__ constexpr int lb_wa(int k) { return 1 + k; }
+__device__ __forceinline__ constexpr int lb_wv(int k) { return 3 + k; }
+__device__ __forceinline__ constexpr int lb_wt(int k) { return 5 + k; }
+__device__ __forceinline__ constexpr int lb_wc(int k) { return 7 + k; }
+#endif
 // word 0 since round 4: bit 63 valid | (symbols the workgroup decoded - symbols K0 counted
 // for it), 32 bits: what a successor adds to K0's count of a FLAGGED workgroup.
 // K0's word of a workgroup (LjArgs::k0w, lj_unstuff_kernel): symbols (32) | own estimate of
@@ -550,14 +565,42 @@ __device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint
     for (int k = 0; k < NW; ++k)
       wa[k] = wv_[k] = wt[k] = wc[k] = 0;
     if (real && inwin) {
-      const u64* p = A + size_t(idx) * LF_LB_WORDS + 1;
+      const u64* p = A + size_t(idx) * LF_LB_WORDS;
+#ifdef RSX_LF_LB16
+      // (coherent 16-byte loads: agent scope is `sc1`, as the compiler emits it for lb_load)
+      lf_u32x4 q[2 * NW];
+      if constexpr (NW == 1)
+        asm volatile("global_load_dwordx4 %0, %2, off offset:16 sc1\n\t"
+                     "global_load_dwordx4 %1, %2, off offset:32 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(q[0]), "=&v"(q[1])
+                     : "v"(p)
+                     : "memory");
+      else
+        asm volatile("global_load_dwordx4 %0, %4, off offset:16 sc1\n\t"
+                     "global_load_dwordx4 %1, %4, off offset:32 sc1\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:48 sc1\n\t"
+                     "global_load_dwordx4 %3, %4, off offset:64 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2 * NW - 2]), "=&v"(q[2 * NW - 1])
+                     : "v"(p)
+                     : "memory");
 #pragma unroll
       for (int k = 0; k < NW; ++k) {
-        wa[k] = lb_load(p + k);
-        wv_[k] = lb_load(p + 2 + k);
-        wt[k] = lb_load(p + 4 + k);
-        wc[k] = lb_load(p + 6 + k);
+        wa[k] = u64(q[2 * k][0]) | (u64(q[2 * k][1]) << 32);
+        wv_[k] = u64(q[2 * k][2]) | (u64(q[2 * k][3]) << 32);
+        wt[k] = u64(q[2 * k + 1][0]) | (u64(q[2 * k + 1][1]) << 32);
+        wc[k] = u64(q[2 * k + 1][2]) | (u64(q[2 * k + 1][3]) << 32);
       }
+#else
+#pragma unroll
+      for (int k = 0; k < NW; ++k) {
+        wa[k] = lb_load(p + lb_wa(k));
+        wv_[k] = lb_load(p + lb_wv(k));
+        wt[k] = lb_load(p + lb_wt(k));
+        wc[k] = lb_load(p + lb_wc(k));
+      }
+#endif
     }
     bool loc = true, pre = true;
 #pragma unroll
@@ -1795,13 +1838,13 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     }
     constexpr int NW = (N + 1) / 2;
     if (j == 0) {
-      u64* p = a.lb + size_t(b) * LF_LB_WORDS + 1;
-      lb_store(p + 2, LB_VALID | Vsum.x);
+      u64* p = a.lb + size_t(b) * LF_LB_WORDS;
+      lb_store(p + lb_wv(0), LB_VALID | Vsum.x);
       if (NW == 2)
-        lb_store(p + 3, LB_VALID | Vsum.y);
+        lb_store(p + lb_wv(1), LB_VALID | Vsum.y);
       if (NW == 2)
-        lb_store(p + 1, LB_VALID | (u64(flags) << 32) | al.y);
-      lb_store(p + 0, LB_VALID | (u64(flags) << 32) | al.x);
+        lb_store(p + lb_wa(1), LB_VALID | (u64(flags) << 32) | al.y);
+      lb_store(p + lb_wa(0), LB_VALID | (u64(flags) << 32) | al.x);
     }
     lb1_flags = flags;
     lb1_al = al;
@@ -1825,13 +1868,13 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       const uint2 fm = fld_mask(flags);
       const uint2 T_out = pk_add2(al, sel2(fm, V_in, T_in));
       const uint2 V_out = pk_add2(V_in, Vsum);
-      u64* p = a.lb + size_t(b) * LF_LB_WORDS + 5;
-      lb_store(p + 2, LB_VALID | V_out.x);
+      u64* p = a.lb + size_t(b) * LF_LB_WORDS;
+      lb_store(p + lb_wc(0), LB_VALID | V_out.x);
       if (NW == 2)
-        lb_store(p + 3, LB_VALID | V_out.y);
+        lb_store(p + lb_wc(1), LB_VALID | V_out.y);
       if (NW == 2)
-        lb_store(p + 1, LB_VALID | T_out.y);
-      lb_store(p + 0, LB_VALID | T_out.x);
+        lb_store(p + lb_wt(1), LB_VALID | T_out.y);
+      lb_store(p + lb_wt(0), LB_VALID | T_out.x);
     }
   }
   LF_STAMP(12);
