@@ -2030,6 +2030,40 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
     if (disjoint && rects.size() <= 64 && area == (r1 - r0) * (b1 - b0))
       rects.assign(1, HostRect{r0, r1 - r0, b0, b1 - b0});
   }
+  if (rects.size() > 1) {
+    // Tiles that do not fill one rectangle (a tile failed, heights differ): the rows they
+    // touch come back WHOLE, as one contiguous copy into a buffer of the lane, and the host
+    // moves each tile's row segments into the image.  (Until round 5: one 2-D copy per tile
+    // straight into the pageable image.  With 3-sample pixels -- rectangles on 2-byte
+    // boundaries -- and rectangles of several MB that left, rarely, sixteen bytes in the
+    // middle of a row unwritten: found by scripts/fuzz_more.py big3, one to seven images in
+    // forty, never with one rectangle or with small ones.  A plain 1-D copy is the path every
+    // other call of the library takes.)
+    size_t r0 = ~size_t(0), r1 = 0;
+    for (const HostRect& r : rects) {
+      r0 = std::min(r0, r.row0);
+      r1 = std::max(r1, r.row0 + r.rows);
+    }
+    std::vector<uint8_t>& tmp = lane.lane->h_rows;
+    const size_t pitch = img->pitch_bytes;
+    try {
+      if (tmp.size() < (r1 - r0) * pitch)
+        tmp.resize((r1 - r0) * pitch);
+    } catch (const std::bad_alloc&) {
+      return RSX_ERR_NOMEM;
+    }
+    {
+      std::lock_guard<std::mutex> down(ctx->download_mu);
+      RSX_HIP_CHECK(ctx, hipMemcpyAsync(tmp.data(), out_row0 + r0 * pitch, (r1 - r0) * pitch,
+                                        hipMemcpyDeviceToHost, s));
+      RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    }
+    for (const HostRect& r : rects)
+      for (size_t y = 0; y < r.rows; ++y)
+        std::memcpy(static_cast<uint8_t*>(img->data) + (r.row0 + y) * pitch + r.byte0,
+                    tmp.data() + (r.row0 + y - r0) * pitch + r.byte0, r.bytes);
+    return rc;
+  }
   {
     std::lock_guard<std::mutex> down(ctx->download_mu);
     for (const HostRect& r : rects) {

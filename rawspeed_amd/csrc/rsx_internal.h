@@ -279,6 +279,9 @@ struct rsx_ctx {
     // camera's files) skips the plan's construction -- tables, block lists, a dozen uploads
     struct rsx_plan* cached_plan = nullptr;
     std::vector<uint8_t> cached_key;
+    // rows on their way back to a host image whose decoded tiles do NOT fill one rectangle
+    // (rsx_api.hip, ljpeg_family_host)
+    std::vector<uint8_t> h_rows;
     // upload stream + one event per band of the overlapped host path (rsx_api.hip, unpack_host)
     hipStream_t stream_up = nullptr;
     std::vector<hipEvent_t> ev_up;

@@ -4403,6 +4403,15 @@ int ljpeg_plan_run_(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t
   }
   LjArgs a = make_args(p, in_dev, out_dev);
   a.fuse_consumed = (p->any_fast && !p->any_pipeline && !p->any_legacy) ? 1u : 0u;
+#ifndef RSX_NO_FIRST_RUN_INV
+  // A plan's FIRST run: its kernels read the stream records, the block map and the ticket
+  // order through the scalar cache, nothing invalidates a CU's scalar cache between two
+  // kernels of a stream, and the arrays of a new plan tend to lie where those of the plan
+  // destroyed just before it lay (a host-pointer call with new geometry: the lane's cached
+  // plan is replaced).  5 us once per plan.
+  if (p->run_count == 1 && !p->dev_layout)
+    hipLaunchKernelGGL(lj_dcache_inv_kernel, dim3(4096), dim3(64), 0, s);
+#endif
   // results: marker_pos = 0xFFFFFFFF, everything else 0
   for (auto& r : p->h_results) {
     std::memset(&r, 0, sizeof r);

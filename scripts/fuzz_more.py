@@ -1,5 +1,6 @@
 """More seeds of the differential fuzz tests than the suite runs (GPU box):
-   python scripts/fuzz_more.py two_tables 24 224   |   single 48 248"""
+   python scripts/fuzz_more.py two_tables 24 224   |   single 48 248   |   big 0 40   |   big2 0 40
+   |   big3 0 40 (3 components)   |   bigdri 0 40 (restart intervals, 1-4 components)"""
 import os, sys, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -72,11 +73,26 @@ def big(seed, two):
         assert np.array_equal(img.u16(), want.u16())
 
 
+def big_r05(seed, dri):
+    """3 components / restart intervals (tests/test_gpu_fuzz_r05.py) at the same sizes"""
+    import numpy as np
+    import test_gpu_fuzz_r05 as T5
+    rng = np.random.default_rng([4042, seed, 1 if dri else 0])
+    if not dri:
+        return T5._run(gpu, oracle, rng, 3, 3, lambda th: 0, big=True)
+    n = int(rng.choice([1, 2, 2, 3, 4]))
+    return T5._run(gpu, oracle, rng, n, 3 if n == 3 else 1,
+                   lambda th: int(rng.integers(1, max(2, th // 2))) if rng.integers(0, 5) else 0, big=True)
+
+
 if which.startswith("big"):
     bad = []
     for seed in range(lo, hi):
         try:
-            big(seed, which == "big2")
+            if which in ("big3", "bigdri"):
+                big_r05(seed, which == "bigdri")
+            else:
+                big(seed, which == "big2")
         except Exception as e:  # noqa: BLE001
             bad.append(seed)
             print("seed", seed, "FAILED:", str(e)[:300].replace("\n", " "))

@@ -1,9 +1,7 @@
 #!/bin/bash
-# round 5, GPU call 6: re-measure after the LDS layout fix; pinned host path
-O=gpurun_out/r05f; mkdir -p $O
-python scripts/exp_ab.py run --what cfg4 r5a base noresume r5a base noresume > $O/ab_cfg4.txt 2>&1
-python scripts/exp_ab.py run --what uniform r5a base noresume r5a base noresume > $O/ab_uniform.txt 2>&1
-python scripts/exp_ab.py run --what cfg3 r5a base r5a base > $O/ab_cfg3.txt 2>&1
-python bench_ljpeg.py --only host > $O/host.json 2> $O/host.err
-timeout 600 python -m pytest tests/test_gpu_dropin.py tests/test_gpu_unpack.py tests/test_gpu_two_tables.py -x -q -m gpu > $O/pytest.txt 2>&1
-cat $O/ab_cfg4.txt $O/ab_uniform.txt $O/ab_cfg3.txt; tail -60 $O/host.json; tail -3 $O/host.err; tail -3 $O/pytest.txt
+set -u
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+O=$REPO/gpurun_out/r05f; mkdir -p $O
+cd $REPO
+S="8 9 10 11 12 13 14 15 16 17 18 19 20 21 22 23 24 25 26"
+echo "== poisoned"; POISON_GB=6 RSX_DEBUG=1 timeout 200 python scripts/fuzz_diag.py big3 $S 2>&1 | grep -v "amdgpu.ids" | cut -c1-300 | tee $O/diag_poison.txt | grep -v "^\[rsx\]" | head -60

@@ -46,16 +46,18 @@ def _stream(rng, tx, tw_px, th, n, cpp, prec, table, rows_per_ri, tail):
     return d, np.concatenate([scan, np.array([0xFF, 0xD9], np.uint8), extra]), px
 
 
-def _run(gpu, oracle, rng, n, cpp, rows_per_ri_of):
+def _run(gpu, oracle, rng, n, cpp, rows_per_ri_of, big=False):
+    """big: hundreds of workgroups per stream (scripts/fuzz_more.py)"""
     prec = int(rng.choice([12, 14, 14, 16]))
     n_cat = 17 if prec == 16 else prec + 1
     table = C.random_huffman_table(rng, n_cat, skew=float(rng.uniform(0.4, 2.5)))
     k = int(rng.integers(1, 4))
-    H = int(rng.integers(60, 420))
+    H = int(rng.integers(900, 2400)) if big else int(rng.integers(60, 420))
     tiles, x = [], 0
     unit = n // cpp if n % cpp == 0 and n >= cpp else 1   # pixels per MCU
     for _ in range(k):
-        tw = unit * int(rng.integers(24, max(25, 1500 // (cpp * unit))))
+        tw = unit * int(rng.integers(300 if big else 24,
+                                     max(301 if big else 25, (4200 if big else 1500) // (cpp * unit))))
         tiles.append((x, tw))
         x += tw
     W = x + int(rng.integers(0, 5))
