@@ -2030,7 +2030,16 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
     if (disjoint && rects.size() <= 64 && area == (r1 - r0) * (b1 - b0))
       rects.assign(1, HostRect{r0, r1 - r0, b0, b1 - b0});
   }
-  if (rects.size() > 1) {
+  // (... and so does ONE large rectangle that starts off the 16-byte grid -- a tile in the
+  // middle of a 3-sample image decoded by itself --: the copy that failed moved its rows in
+  // 16-byte units from such a start)
+  bool by_rows = rects.size() > 1;
+  if (rects.size() == 1) {
+    const HostRect& r = rects[0];
+    const uintptr_t start = reinterpret_cast<uintptr_t>(img->data) + r.row0 * img->pitch_bytes + r.byte0;
+    by_rows = (start & 15u) != 0 && r.rows * r.bytes >= (size_t(256) << 10);
+  }
+  if (by_rows) {
     // Tiles that do not fill one rectangle (a tile failed, heights differ): the rows they
     // touch come back WHOLE, as one contiguous copy into a buffer of the lane, and the host
     // moves each tile's row segments into the image.  (Until round 5: one 2-D copy per tile
