@@ -23,10 +23,13 @@ each rank's shard from rank 0, one RCCL broadcast of the whole batch -- each tim
 from the decode and reported as `input_distribution`; --scatter / --broadcast: that one only).
 
 Rank 0 prints ONE JSON line (kept under 6 KB: the driver holds a tail of stdout).  At
-N=1 it also carries
-  roofline      -- dominant kernel: algorithmic bytes / hipEvent-measured launch time,
-                   plus the measured copy ceiling of the device for the same bytes
-  cpu_baseline  -- the unmodified reference (oracle/_ref) timed on this host's cores
+every N it carries
+  roofline      -- dominant kernel: algorithmic bytes / hipEvent-measured launch time of
+                   rank 0's launches (per GPU), plus the measured copy ceiling of the device
+                   for the same bytes
+  cpu_baseline  -- the unmodified reference (oracle/_ref) timed on this host's cores (rank 0)
+  ljpeg.cfg5_batch_8192x5464 -- BASELINE configs[4] with its own in-run `roofline`
+and at N=1 also
   ljpeg         -- summary of the LJPEG configs (cfg 3 / cfg 4 / cfg 5, clipped highlights,
                    uniform-random data): ms, GPix/s, fraction of the HBM peak, per-kernel
                    ms, CPU baselines, and -- replayed from profiles/ and labelled so -- the
@@ -321,7 +324,20 @@ def cfg5_leg(args, ctx, torch, grp, rank, n_gpus, stream):
         exact5 = exact5 and okm
     delivered.clear()
     k5 = 5
-    dt5 = time_plan(torch, grp, plan5, inp5, out5, k5, 2, stream) / k5
+    plan5.set_timing(True)   # (event pool made outside the timed steps)
+    plan5.set_timing(False)
+    for _ in range(2):
+        plan5.run(inp5.data_ptr(), out5.data_ptr(), stream)
+    plan5.set_timing(True)
+    dt5 = time_plan(torch, grp, plan5, inp5, out5, k5, 0, stream) / k5
+    kt5 = ktab5 = None
+    try:
+        tab = plan5.kernel_table()   # (before kernel_time(), which resets the totals)
+        ktab5 = {n: round(ms, 4) for n, ms in tab[0]} if tab else None
+        kt5 = plan5.kernel_time()
+    except Exception as e:
+        log("cfg5 kernel table: %r" % (e,))
+    plan5.set_timing(False)
     all_exact = grp.sum_over_ranks(1.0 if exact5 else 0.0) == n_gpus
     W5, H5 = meta["W"], meta["H"]
     for mode, rec in dist_info.items():
@@ -345,6 +361,13 @@ def cfg5_leg(args, ctx, torch, grp, rank, n_gpus, stream):
         "frac_of_hbm_peak": round(meta["alg_bytes"] / dt5 / 1e9 / HBM_PEAK_GBPS, 4),
         "input_distribution": dist_info,
     }
+    # the rank's own shard against the roofline, measured in this run (rank 0's events)
+    if ktab5:
+        res["kernels_ms"] = ktab5
+    if kt5:
+        res["dominant_kernel"] = {"name": kt5[0], "avg_ms": round(kt5[1], 4)}
+    bench_ljpeg._roofline(res, meta["alg_bytes"], dt5, kt5)
+    res["roofline"]["frames_on_this_rank"] = f5
     if cpu5:
         res["cpu_baseline"] = cpu5
     return res
@@ -369,6 +392,16 @@ def replayed_ljpeg_counters():
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "ljpeg_pmc", "ljpeg_pmc.json")) as f:
                 t = json.load(f)
+            # (a fraction of the issue slots cannot exceed 1: round 5's file had the PROBE
+            # instantiation's time under the main kernel's counters and said 1.1-2.0; such a
+            # file is not replayed, and the line says why)
+            bad = {k: v for k, v in t["valu_issue_frac"].items()
+                   if not all(0.0 <= float(x) <= 1.0 for x in (v if isinstance(v, list) else [v]))}
+            if bad:
+                out["valu_issue_frac_rejected"] = "profiles/%s/ljpeg_pmc/ljpeg_pmc.json holds a " \
+                    "fraction > 1 (%s): counters and kernel time of different instantiations" % (
+                        rnd, ", ".join(sorted(bad)))
+                continue
             out["valu_issue_frac"] = t["valu_issue_frac"]
             out["valu_issue_source"] = "replayed from profiles/%s/ljpeg_pmc/ljpeg_pmc.json: %s" % (
                 rnd, t.get("how", ""))
@@ -462,6 +495,7 @@ def ljpeg_summary(extra):
     # of stdout for the driver, 6 KB at most)
     rep = replayed_ljpeg_counters()
     short = {k: rep[k] for k in ("traffic_over_algorithmic", "valu_issue_frac",
+                                 "valu_issue_frac_rejected",
                                  "lane_instr_per_symbol", "wg_lifetime_us") if k in rep}
     import re as _re
     srcs = sorted({m for v in rep.values() if isinstance(v, str)
@@ -523,7 +557,7 @@ def main():
     # copy ceiling for the same read:write mix (outside the timed region): a plain
     # streaming kernel over the very same buffers
     copy_ms = None
-    if rank == 0 and n_gpus == 1:
+    if rank == 0:
         try:
             copy_ms = ctx.probe_stream_copy(inp.data_ptr(), F * h * (w * bps // 8),
                                             out.data_ptr(), F * h * opitch, stream, reps=20)
@@ -570,7 +604,9 @@ def main():
         except Exception as e:  # the headline number must survive
             cfg5 = {"error": repr(e)}
 
-    if rank == 0 and n_gpus == 1:
+    # rank 0 at every N: `roofline` from ITS in-run kernel time (per GPU: every rank runs the
+    # same launch over its own frames) and `cpu_baseline`; the secondary legs at N = 1 only
+    if rank == 0:
         alg_bytes = F * (h * (w * bps // 8) + h * w * 2)  # packed read once + u16 written once
         if ktime:
             name, avg_ms, n = ktime
@@ -583,6 +619,7 @@ def main():
                 "traffic": traffic, "traffic_source": source,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_kernel_ms": round(avg_ms, 5), "launches_timed": n,
+                "scope": "one GPU (rank 0's launches); the job's rate is `value`",
             }
             if copy_ms:
                 ceil = alg_bytes / (copy_ms * 1e-3) / 1e9
@@ -592,7 +629,7 @@ def main():
                     "what": "plain 16-byte load / non-temporal store kernel over the same "
                             "buffers (same bytes in, same bytes out)",
                 }
-        if not args.no_extra:
+        if not args.no_extra and n_gpus == 1:
             extra = {}
             try:
                 extra["cfg1_12bit_lsb_4096x3072"] = small_unpack_leg(

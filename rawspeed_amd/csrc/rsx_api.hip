@@ -2039,6 +2039,9 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
     const uintptr_t start = reinterpret_cast<uintptr_t>(img->data) + r.row0 * img->pitch_bytes + r.byte0;
     by_rows = (start & 15u) != 0 && r.rows * r.bytes >= (size_t(256) << 10);
   }
+#ifdef RSX_DIAG_DOWNLOAD
+  by_rows = false; // (diagnostic build: the 2-D copies of round 5, checked below)
+#endif
   if (by_rows) {
     // Tiles that do not fill one rectangle (a tile failed, heights differ): the rows they
     // touch come back WHOLE, as one contiguous copy into a buffer of the lane, and the host
@@ -2085,6 +2088,63 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
     }
     RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
   }
+#ifdef RSX_DIAG_DOWNLOAD
+  {
+    // Diagnostic build (scripts/r06a.sh): the same device rows once more, as ONE contiguous
+    // copy into memory of our own, and every rectangle of the host image compared with them.
+    // A difference = bytes the 2-D copy did not deliver although the device held them.
+    static std::atomic<uint64_t> calls{0}, bad_calls{0};
+    size_t r0 = ~size_t(0), r1 = 0;
+    for (const HostRect& r : rects) {
+      r0 = std::min(r0, r.row0);
+      r1 = std::max(r1, r.row0 + r.rows);
+    }
+    const size_t pitch = img->pitch_bytes;
+    if (!rects.empty()) {
+      std::vector<uint8_t> chk((r1 - r0) * pitch);
+      RSX_HIP_CHECK(ctx, hipMemcpy(chk.data(), out_row0 + r0 * pitch, chk.size(), hipMemcpyDeviceToHost));
+      ++calls;
+      bool bad = false;
+      for (size_t i = 0; i < rects.size(); ++i) {
+        const HostRect& r = rects[i];
+        for (size_t y = 0; y < r.rows; ++y) {
+          const uint8_t* h = static_cast<uint8_t*>(img->data) + (r.row0 + y) * pitch + r.byte0;
+          const uint8_t* d = chk.data() + (r.row0 + y - r0) * pitch + r.byte0;
+          if (std::memcmp(h, d, r.bytes) != 0) {
+            size_t a = 0, b = r.bytes;
+            while (a < r.bytes && h[a] == d[a]) ++a;
+            while (b > a && h[b - 1] == d[b - 1]) --b;
+            fprintf(stderr, "RSX_DIAG_DOWNLOAD: rect %zu/%zu (row0 %zu rows %zu byte0 %zu bytes %zu) row %zu: "
+                    "host != device in rect-bytes [%zu, %zu) (unit %zu + %zu); host %02x %02x .. device %02x %02x; "
+                    "host row addr %p, image %p pitch %zu\n", i, rects.size(), r.row0, r.rows, r.byte0, r.bytes,
+                    y, a, b, a / 16, a % 16, h[a], h[a + 1], d[a], d[a + 1], static_cast<const void*>(h),
+                    img->data, pitch);
+            bad = true;
+          }
+        }
+      }
+      if (bad) {
+        ++bad_calls;
+        // once more, the same 2-D copies: does a repeat deliver?
+        for (const HostRect& r : rects) {
+          const size_t off = r.row0 * pitch + r.byte0;
+          RSX_HIP_CHECK(ctx, hipMemcpy2DAsync(static_cast<uint8_t*>(img->data) + off, pitch, out_row0 + off,
+                                              pitch, r.bytes, r.rows, hipMemcpyDeviceToHost, s));
+        }
+        RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        size_t still = 0;
+        for (const HostRect& r : rects)
+          for (size_t y = 0; y < r.rows; ++y)
+            still += std::memcmp(static_cast<uint8_t*>(img->data) + (r.row0 + y) * pitch + r.byte0,
+                                 chk.data() + (r.row0 + y - r0) * pitch + r.byte0, r.bytes) != 0;
+        fprintf(stderr, "RSX_DIAG_DOWNLOAD: after repeating the copies %zu rows still differ\n", still);
+      }
+      if ((calls & 63) == 0 || bad)
+        fprintf(stderr, "RSX_DIAG_DOWNLOAD: %llu calls checked, %llu with undelivered bytes\n",
+                (unsigned long long)calls.load(), (unsigned long long)bad_calls.load());
+    }
+  }
+#endif
   return rc;
 }
 

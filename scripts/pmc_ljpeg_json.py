@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
 """profiles/rNN/ljpeg_pmc/ljpeg_pmc.json from the PMC passes of scripts/pmc_ljpeg.sh (cfg 3,
-8 frames): per kernel the wave-level instruction counts, and the VALU issue fraction of
-the two kernels of the single-pass pipeline,
+8 frames): per kernel INSTANTIATION the wave-level instruction counts, and the VALU issue
+fraction of the two kernels of the single-pass pipeline,
   valu_issue_frac = VALU wave-instructions x cycles per instruction / (1024 SIMDs x kernel cycles),
 with the kernel time from `rocprofv3 --kernel-trace --stats` of the same command
 (cfg3_kernel_stats.csv next to this directory) and the two issue costs measured by
 scripts/ubench/valu_rates2.hip: 2.4 cycles (add/sub/and/or/xor/lshr/ashr/mov) and 4.3
-(everything else) -- given as a [low, high] pair; the loops are ~70 % cheap instructions."""
+(everything else) -- given as a [low, high] pair; the loops are ~70 % cheap instructions.
+
+Round 6: counters and times are keyed by the FULL instantiation (`lj_fast_kernel<2, false, false>`),
+not by the template's name: round 5's `lj_\\w+` key let the PROBE instantiation of a plan's first
+run (`<2, false, true>`: two idle launches + one real, 138.6 us "average") overwrite the main
+kernel's 397.8 us, and the published issue fraction came out as 1.1-2.0.  PROBE instantiations
+(third template argument `true`) are left out altogether, and a fraction above 1 is an error."""
 import collections
 import csv
 import json
@@ -14,51 +20,75 @@ import os
 import re
 import sys
 
-d = sys.argv[1]
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for fn in sorted(os.listdir(d)):
-    if not re.match(r"set\d+\.csv", fn):
-        continue
-    for r in csv.DictReader(open(os.path.join(d, fn))):
-        m = re.search(r"(lj_\w+)", r["Kernel_Name"])
-        if m:
-            acc[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
-times = {}
-for cand in (os.path.join(d, "..", "cfg3_kernel_stats.csv"), os.path.join(d, "cfg3_kernel_stats.csv")):
-    if os.path.exists(cand):
-        rows = [(re.search(r"(lj_\w+)", r["Name"]), r) for r in csv.DictReader(open(cand))]
-        runs = max([int(r["Calls"]) for m, r in rows if m and m.group(1) == "lj_unstuff_kernel"] + [0])
-        for m, r in rows:
-            if not m:
-                continue
-            calls, total = int(r["Calls"]), float(r["TotalDurationNs"])
-            # (the single-pass kernel is launched at every LDS level in a plan's first run:
-            # the launches whose workgroups leave at once are not part of the average)
-            if runs and calls > runs:
-                total -= (calls - runs) * float(r["MinNs"])
-                calls = runs
-            times[m.group(1)] = total / calls * 1e-9
-        break
-out = {"workload": "bench_ljpeg.py --only cfg3 --frames 8 (8 x 6720x4480, 3 CR2 slices)",
-       "how": "SQ_INSTS_VALU x [2.4, 4.3] cycles / (1024 SIMDs x kernel time x 2.4 GHz); kernel "
-              "time = rocprofv3 --stats average of the same command",
-       "kernels": {}, "valu_issue_frac": {}}
-for k, cs in sorted(acc.items()):
-    # (launches whose workgroups leave at once -- the other LDS levels in a plan's first run --
-    # are not part of the averages: as many launches as K0 has, the largest ones)
-    def mean(c, v):
-        n = len(acc.get("lj_unstuff_kernel", {}).get(c, [])) or len(v)
-        top = sorted(v, reverse=True)[:min(n, len(v))]
-        return round(sum(top) / len(top), 1)
-    e = {c: mean(c, v) for c, v in sorted(cs.items())}
-    if k in times:
-        e["avg_kernel_us"] = round(times[k] * 1e6, 2)
-        if "SQ_INSTS_VALU" in e:
-            cyc = 1024 * times[k] * 2.4e9
-            e["valu_issue_frac"] = [round(e["SQ_INSTS_VALU"] * 2.4 / cyc, 3),
-                                    round(e["SQ_INSTS_VALU"] * 4.3 / cyc, 3)]
-            if k in ("lj_fast_kernel", "lj_unstuff_kernel"):
-                out["valu_issue_frac"][k] = e["valu_issue_frac"]
-    out["kernels"][k] = e
-json.dump(out, open(os.path.join(d, "ljpeg_pmc.json"), "w"), indent=1)
-print(json.dumps(out["valu_issue_frac"]))
+
+def inst_name(full):
+    """'void rsx::(anonymous namespace)::lj_fast_kernel<2, false, false>(rsx::LjArgs, ...)' ->
+    'lj_fast_kernel<2, false, false>' (None for kernels that are not the LJPEG pipeline's)."""
+    m = re.search(r"(lj_\w+)(<[^>]*>)?", full)
+    if not m:
+        return None
+    return m.group(1) + (m.group(2) or "")
+
+
+def is_probe(name):
+    """the single-pass kernel's first-run instantiation: lj_fast_kernel<N, TWO, PROBE = true>"""
+    m = re.match(r"lj_fast_kernel<\s*\d+\s*,\s*\w+\s*,\s*(\w+)\s*>", name)
+    return bool(m and m.group(1) == "true")
+
+
+def base_name(name):
+    return name.split("<")[0]
+
+
+def load(d):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for fn in sorted(os.listdir(d)):
+        if not re.match(r"set\d+\.csv", fn):
+            continue
+        for r in csv.DictReader(open(os.path.join(d, fn))):
+            k = inst_name(r["Kernel_Name"])
+            if k and not is_probe(k):
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    times = {}
+    for cand in (os.path.join(d, "..", "cfg3_kernel_stats.csv"), os.path.join(d, "cfg3_kernel_stats.csv")):
+        if os.path.exists(cand):
+            for r in csv.DictReader(open(cand)):
+                k = inst_name(r["Name"])
+                if k and not is_probe(k):
+                    times[k] = float(r["TotalDurationNs"]) / int(r["Calls"]) * 1e-9
+            break
+    return acc, times
+
+
+def summarise(acc, times):
+    out = {"workload": "bench_ljpeg.py --only cfg3 --frames 8 (8 x 6720x4480, 3 CR2 slices)",
+           "how": "SQ_INSTS_VALU x [2.4, 4.3] cycles / (1024 SIMDs x kernel time x 2.4 GHz); kernel "
+                  "time = rocprofv3 --stats average of the same command, per instantiation, the "
+                  "first run's PROBE instantiation left out",
+           "kernels": {}, "valu_issue_frac": {}}
+    for k, cs in sorted(acc.items()):
+        e = {c: round(sum(v) / len(v), 1) for c, v in sorted(cs.items())}
+        e["launches_counted"] = max(len(v) for v in cs.values())
+        if k in times:
+            e["avg_kernel_us"] = round(times[k] * 1e6, 2)
+            if "SQ_INSTS_VALU" in e:
+                cyc = 1024 * times[k] * 2.4e9
+                e["valu_issue_frac"] = [round(e["SQ_INSTS_VALU"] * 2.4 / cyc, 3),
+                                        round(e["SQ_INSTS_VALU"] * 4.3 / cyc, 3)]
+                if e["valu_issue_frac"][0] > 1.0:
+                    raise SystemExit("pmc_ljpeg_json: %s: VALU issue fraction %r > 1 -- counters and "
+                                     "kernel time do not belong together" % (k, e["valu_issue_frac"]))
+                if base_name(k) in ("lj_fast_kernel", "lj_unstuff_kernel"):
+                    out["valu_issue_frac"][k] = e["valu_issue_frac"]
+            if "SQ_LDS_BANK_CONFLICT" in e and e.get("SQ_ACTIVE_INST_LDS"):
+                e["lds_conflict_cycles_per_active_lds_cycle"] = round(
+                    e["SQ_LDS_BANK_CONFLICT"] / e["SQ_ACTIVE_INST_LDS"], 3)
+        out["kernels"][k] = e
+    return out
+
+
+if __name__ == "__main__":
+    d = sys.argv[1]
+    out = summarise(*load(d))
+    json.dump(out, open(os.path.join(d, "ljpeg_pmc.json"), "w"), indent=1)
+    print(json.dumps(out["valu_issue_frac"]))
