@@ -341,7 +341,8 @@ HUNK_DEALLOC = r'''
 
 PATCHES = [
     ("adt/AlignedAllocator.h", [
-        ("    std::size_t numBytes = sizeof(T) * numElts;\n", HUNK_ALLOC),
+        # (behind the fuzzing build's 2 GB bail-out, in front of operator new)
+        ("      ThrowRSE(\"FUZZ alloc bailout (%zu bytes)\", numBytes);\n#endif\n", HUNK_ALLOC),
         ("    invariant(isAligned(p, alignment));\n", HUNK_DEALLOC)], "rsx_pin.h"),
     ("decompressors/AbstractDngDecompressor.cpp", [
         ("void AbstractDngDecompressor::decompress() const {", HUNK_DNG)]),

@@ -54,16 +54,42 @@ def build_synth(force=False):
     return LIB_SYNTH
 
 
+def _compile_objects(objdir, extra_flags, force=False):
+    """One object per source under `objdir`, rebuilt when the source or any header is newer;
+    the stale ones in parallel (the sources are independent translation units: one hipcc run
+    over all of them took a minute whatever had changed)."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in CORE_HEADERS] + [os.path.join(INCLUDE, "rsx.h")]
+    jobs, objs = [], []
+    for name in CORE_SOURCES:
+        src = os.path.join(CSRC, name)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(objdir, os.path.splitext(name)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            jobs.append([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c",
+                         "-Wall", "-Wno-unused-function", "-I" + INCLUDE, "-I" + CSRC,
+                         *extra_flags, "-o", obj, src])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            list(ex.map(_run, jobs))
+    return objs, bool(jobs)
+
+
+def _link(out, objs):
+    _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs])
+
+
 def build_core(force=False, extra_flags=()):
     srcs = [os.path.join(CSRC, s) for s in CORE_SOURCES]
     srcs = [s for s in srcs if os.path.exists(s)]
     deps = srcs + [os.path.join(CSRC, h) for h in CORE_HEADERS] + \
         [os.path.join(INCLUDE, "rsx.h")]
     if force or _stale(LIB_CORE, deps):
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-               "-shared", "-Wall", "-Wno-unused-function", "-I" + INCLUDE,
-               "-I" + CSRC, *extra_flags, "-o", LIB_CORE, *srcs]
-        _run(cmd)
+        objs, _ = _compile_objects(os.path.join(PKG, "_build", "core"), extra_flags, force)
+        _link(LIB_CORE, objs)
     return LIB_CORE
 
 
@@ -73,10 +99,10 @@ def build_variant(name, extra_flags):
     d = os.path.join(PKG, "variants")
     os.makedirs(d, exist_ok=True)
     out = os.path.join(d, "librsx_%s.so" % name)
-    srcs = [os.path.join(CSRC, s) for s in CORE_SOURCES]
-    _run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-          "-Wall", "-Wno-unused-function", "-I" + INCLUDE, "-I" + CSRC, *extra_flags,
-          "-o", out, *srcs])
+    import hashlib
+    tag = hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:8]  # (other flags, other objects)
+    objs, _ = _compile_objects(os.path.join(PKG, "_build", "variant_%s_%s" % (name, tag)), extra_flags)
+    _link(out, objs)
     return out
 
 

@@ -180,6 +180,7 @@ public:
   struct Task {
     std::function<void()> fn;
     bool done = false;
+    bool failed = false; // fn threw
   };
   typedef std::shared_ptr<Task> Handle;
   ~HelperPool() {
@@ -231,7 +232,14 @@ private:
       Handle h = queue_.front();
       queue_.pop_front();
       g.unlock();
-      h->fn();
+      // (a task that throws -- std::bad_alloc from a band's vectors -- must not take the
+      // process down from a pool thread, and its waiter must still wake up: the task's own
+      // result fields say "not done", which its caller turns into a status)
+      try {
+        h->fn();
+      } catch (...) {
+        h->failed = true;
+      }
       g.lock();
       h->done = true;
       cv_done_.notify_all();
@@ -279,9 +287,12 @@ struct rsx_ctx {
     // camera's files) skips the plan's construction -- tables, block lists, a dozen uploads
     struct rsx_plan* cached_plan = nullptr;
     std::vector<uint8_t> cached_key;
-    // rows on their way back to a host image whose decoded tiles do NOT fill one rectangle
-    // (rsx_api.hip, ljpeg_family_host)
-    std::vector<uint8_t> h_rows;
+    // page-locked staging of the lane's downloads (rsx_api.hip, download_rects): what does not
+    // lie on the 16-byte grid in the caller's memory goes through here, in two halves that take
+    // turns (the copy of one chunk under the host's scatter of the one before)
+    uint8_t* h_pin = nullptr;
+    size_t h_pin_bytes = 0;
+    hipEvent_t ev_pin[2] = {nullptr, nullptr};
     // upload stream + one event per band of the overlapped host path (rsx_api.hip, unpack_host)
     hipStream_t stream_up = nullptr;
     std::vector<hipEvent_t> ev_up;

@@ -817,7 +817,7 @@ constexpr int LJ_GUESS_SLOTS = 3; // slots parsed for a guess, at most (LjArgs::
 // workgroups -- made the kernel 4-10 % slower for plans that never run it (register
 // allocation and layout of the rounds: cfg 3 0.258 -> 0.265-0.29 ms).
 #define K0_CHAIN (MTPLAN && a.k0_chain != 0u)
-template <bool MTPLAN>
+template <bool MTPLAN, bool INV>
 __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // The LAST workgroups first: the kernels behind this one read the un-stuffed image from
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   // and its barrier in front of the first load cost every workgroup 1.5 us of its 25)
   if (K0_CHAIN)
     b = blockIdx.x;
-  lj_fresh_scalars(a);
+  lj_fresh_scalars<INV>();
   const uint32_t s = a.block_stream[b];
   // The NEXT run's results (marker_pos = 0xFFFFFFFF, an atomicMin target; everything else 0),
   // a dword a lane of the first workgroups: the plan keeps two sets and takes turns, so a
@@ -1886,6 +1886,7 @@ __device__ __forceinline__ bool lj_scan_first_pass(const LjArgs& a, uint32_t fb,
   return bad;
 }
 
+template <bool INV>
 __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
   __shared__ uint32_t wsum[4], dsum[4];
   __shared__ uint2 psum[4];
@@ -1899,7 +1900,7 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
     dbg_first_s = 0xFFFFFFFFu;
 #endif
   const uint32_t s = blockIdx.x;
-  lj_fresh_scalars(a);
+  lj_fresh_scalars<INV>();
   const LjStreamDev& S = a.streams[s];
   if (!lj_bookkeeping_takes(a, s, S))
     return;
@@ -3005,7 +3006,6 @@ __device__ void lj_consumed_body(const LjArgs& a, uint32_t s, int lane) {
 }
 
 __global__ __launch_bounds__(64) void lj_consumed_kernel(LjArgs a) {
-  lj_fresh_scalars(a);
   lj_consumed_body(a, blockIdx.x, int(threadIdx.x));
 }
 
@@ -4010,7 +4010,7 @@ int launch_slow_pass(LJpegPlan* p, hipStream_t s) {
   a.pass = 1;
   const uint32_t n_streams = uint32_t(p->streams.size());
   launch_synchronisation(p, a, s);
-  hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
+  hipLaunchKernelGGL(lj_scan_kernel<false>, dim3(n_streams), dim3(LJ_T), 0, s, a);
   mark(p, "lj_scan_kernel");
   p->slow_pass_launched = true;
   return launch_tail(p, a, s, true, 2);
@@ -4209,19 +4209,28 @@ int run_dri_device(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t 
     }
     c->dev_layout = true;
     c->fast_uniform_nb = 0;
+    // (the child becomes the plan's only once every array the launches below use exists and
+    // the job records are on the device: a later run must not find a child without them)
+    int st = p->d_dri_jobs.ensure(nd * sizeof(DriJobDev));
+    if (st == RSX_OK)
+      st = p->d_dri_sorted.ensure(total_sorted * sizeof(uint2) + 16);
+    if (st == RSX_OK)
+      st = p->d_dri_status.ensure((nd + 1) * 4 + 16);
+    if (st == RSX_OK)
+      st = p->d_marker_count.ensure(nd * 4 + 16);
+    if (st == RSX_OK)
+      st = p->d_marker_list.ensure(total_cap * sizeof(uint2));
+    if (st == RSX_OK &&
+        hipMemcpy(p->d_dri_jobs.ptr, p->dri_dev.data(), nd * sizeof(DriJobDev),
+                  hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipGetLastError();
+      st = RSX_ERR_DEVICE;
+    }
+    if (st != RSX_OK) {
+      ljpeg_plan_destroy(c);
+      return st;
+    }
     p->child_dev = c;
-    if (int st = p->d_dri_jobs.ensure(nd * sizeof(DriJobDev)))
-      return st;
-    if (int st = p->d_dri_sorted.ensure(total_sorted * sizeof(uint2) + 16))
-      return st;
-    if (int st = p->d_dri_status.ensure((nd + 1) * 4 + 16))
-      return st;
-    if (int st = p->d_marker_count.ensure(nd * 4 + 16))
-      return st;
-    if (int st = p->d_marker_list.ensure(total_cap * sizeof(uint2)))
-      return st;
-    RSX_HIP_CHECK(ctx, hipMemcpy(p->d_dri_jobs.ptr, p->dri_dev.data(), nd * sizeof(DriJobDev),
-                                 hipMemcpyHostToDevice));
   }
   LJpegPlan* c = p->child_dev;
   RSX_HIP_CHECK(ctx, hipMemsetAsync(p->d_marker_count.ptr, 0, nd * 4, s));
@@ -4249,8 +4258,9 @@ int run_dri_device(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t 
                      static_cast<const uint32_t*>(p->d_marker_count.ptr),
                      static_cast<const uint2*>(p->d_dri_sorted.ptr),
                      static_cast<uint32_t*>(p->d_dri_status.ptr));
-  // (4096 one-wavefront workgroups: sixteen for each of the 256 CUs)
-  hipLaunchKernelGGL(lj_dcache_inv_kernel, dim3(4096), dim3(64), 0, s);
+  // (the child's K0, single-pass kernel and scan read what the layout kernel has just written
+  // through the scalar cache: the child is a dev_layout plan, its launches are the
+  // instantiations that invalidate that cache in every wavefront -- lj_fresh_scalars)
   RSX_HIP_CHECK(ctx, hipGetLastError());
   mark(p, "lj_dri_scan + lj_dri_sort + lj_dri_layout");
   return ljpeg_plan_run_(c, in_dev, out_dev, s, p->timer, true);
@@ -4435,12 +4445,20 @@ int ljpeg_plan_run_(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t
 #endif
   p->results_clean_for = p->run_count + 1;
   p->results_clean_stream = s;
-  if (p->any_fast_mt)
-    hipLaunchKernelGGL(lj_unstuff_kernel<true>, dim3(p->total_blocks), dim3(LJ_T), LJ_K0_LDS_MT,
-                       s, a);
+  // (plans laid out on the device: the instantiations whose wavefronts drop the scalar cache
+  // first -- lj_fresh_scalars)
+  if (p->any_fast_mt && p->dev_layout)
+    hipLaunchKernelGGL((lj_unstuff_kernel<true, true>), dim3(p->total_blocks), dim3(LJ_T),
+                       LJ_K0_LDS_MT, s, a);
+  else if (p->any_fast_mt)
+    hipLaunchKernelGGL((lj_unstuff_kernel<true, false>), dim3(p->total_blocks), dim3(LJ_T),
+                       LJ_K0_LDS_MT, s, a);
+  else if (p->dev_layout)
+    hipLaunchKernelGGL((lj_unstuff_kernel<false, true>), dim3(p->total_blocks), dim3(LJ_T),
+                       LJ_K0_LDS, s, a);
   else
-    hipLaunchKernelGGL(lj_unstuff_kernel<false>, dim3(p->total_blocks), dim3(LJ_T), LJ_K0_LDS,
-                       s, a);
+    hipLaunchKernelGGL((lj_unstuff_kernel<false, false>), dim3(p->total_blocks), dim3(LJ_T),
+                       LJ_K0_LDS, s, a);
   mark(p, "lj_unstuff_kernel");
   // the single-pass kernel for the streams it takes ...
   if (p->any_fast) {
@@ -4461,7 +4479,10 @@ int ljpeg_plan_run_(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t
   // ... the multi-kernel pipeline for the others
   if (p->any_pipeline)
     launch_synchronisation(p, a, s);
-  hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
+  if (p->dev_layout)
+    hipLaunchKernelGGL(lj_scan_kernel<true>, dim3(n_streams), dim3(LJ_T), 0, s, a);
+  else
+    hipLaunchKernelGGL(lj_scan_kernel<false>, dim3(n_streams), dim3(LJ_T), 0, s, a);
   mark(p, "lj_scan_kernel");
   if (int st = launch_tail(p, a, s, p->any_pipeline))
     return st;
@@ -4617,7 +4638,7 @@ int converge(LJpegPlan* p, hipStream_t s) {
                          size_t(p->max_tables) * sizeof(TabLds), s, a);
     hipLaunchKernelGGL(lj_chain_kernel, dim3(n_streams), dim3(64), 0, s, a);
     launch_sync<true>(p, a, s);
-    hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
+    hipLaunchKernelGGL(lj_scan_kernel<false>, dim3(n_streams), dim3(LJ_T), 0, s, a);
     RSX_HIP_CHECK(ctx, hipGetLastError());
     p->extra_stitch_rounds += 1;
     if (int st = fetch())
@@ -4633,7 +4654,7 @@ int converge(LJpegPlan* p, hipStream_t s) {
     for (int k = 0; k < 4; ++k)
       launch_sync<true>(p, a, s);
     rounds += 4;
-    hipLaunchKernelGGL(lj_scan_kernel, dim3(n_streams), dim3(LJ_T), 0, s, a);
+    hipLaunchKernelGGL(lj_scan_kernel<false>, dim3(n_streams), dim3(LJ_T), 0, s, a);
     RSX_HIP_CHECK(ctx, hipGetLastError());
     if (int st = fetch())
       return st;

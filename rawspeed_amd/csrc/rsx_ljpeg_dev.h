@@ -292,16 +292,23 @@ constexpr int LF_LB_WORDS = 10;
 constexpr int LF_LB_WORDS = 9;
 #endif
 
-// Nothing invalidates a CU's scalar data cache between two kernels of a stream (measured in
-// round 3 on the LDS-level word): a kernel that reads, through scalar loads, words another
-// kernel has rewritten since the cache last saw them could see the old ones.  Plans laid
-// out on the host never rewrite such words; plans laid out on the device (restart
-// intervals, lj_dri_layout_kernel) do, every run -- their layout kernel is followed by
-// lj_dcache_inv_kernel, a grid wide enough to put a wavefront on every CU, each of which
-// drops its scalar cache.  (As a conditional `s_dcache_inv` at the top of K0 and the
-// single-pass kernel it cost EVERY plan 1-2 % of both: the asm statement kept the
-// compiler from batching the kernels' first loads.)
-__device__ __forceinline__ void lj_fresh_scalars(const LjArgs&) {}
+// Nothing invalidates a CU's scalar data cache between two kernels that follow one another on
+// a stream without the host in between (measured in round 3 on the LDS-level word): a kernel
+// that reads, through scalar loads, words another kernel has rewritten since the cache last saw
+// them could see the old ones.  Plans laid out on the host never rewrite such words between
+// kernels; plans laid out on the device (restart intervals, lj_dri_layout_kernel) do, every
+// run: their K0, single-pass kernel and scan are INSTANTIATIONS OF THEIR OWN (INV) whose every
+// wavefront drops the scalar cache before its first load -- deterministic, whatever else
+// occupies the chip, and no instruction in the kernels of the other plans.  (Until round 6: a
+// kernel of 4096 one-wavefront workgroups behind the layout, "a wavefront on every CU" -- true
+// on an idle chip only.  As a run-time `if` at the top of the shared instantiations the
+// invalidation cost EVERY plan 1-2 %: the asm statement kept the compiler from batching the
+// kernels' first loads.)
+template <bool INV>
+__device__ __forceinline__ void lj_fresh_scalars() {
+  if constexpr (INV)
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
 
 // Which streams a kernel of the multi-kernel pipeline works on.  First pass: every
 // stream the single-pass kernel does not take.  Second pass (launched when the first one

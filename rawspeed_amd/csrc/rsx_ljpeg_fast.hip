@@ -1017,9 +1017,13 @@ __device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad
 // ---------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------
-template <int N, bool MT, bool PROBE>
+// MODE 0: the steady state.  1 (PROBE): a plan's first run, when every LDS level is launched
+// and one works.  2: plans laid out on the device (restart intervals) -- PROBE's early look at
+// the level, and every wavefront drops the scalar cache before its first load (lj_fresh_scalars)
+template <int N, bool MT, int MODE>
 __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds_bytes,
                                                           uint32_t level) {
+  constexpr bool PROBE = MODE >= 1, INV = MODE == 2;
   constexpr uint32_t TICKET0 = (MT ? 12u : 0u) + (N == 4 ? 2u : (N == 3 ? 3u : uint32_t(N) - 1u));
   constexpr uint32_t SMASK = MT ? 0x7Fu : ST_OFF_MASK; // offset (| table of the next symbol)
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1047,7 +1051,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // of a DNG) work (stream, block) out arithmetically: nothing stands in front of the image
   // loads; the others read fast_order's entry first.
   (void)TICKET0;
-  lj_fresh_scalars(a);
+  lj_fresh_scalars<INV>();
   const uint32_t t_blk = blockIdx.x;
   const uint32_t chosen_now = __hip_atomic_load(&a.fast_level[a.run_parity], __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_AGENT);
@@ -1942,11 +1946,14 @@ void launch_fast_one(const LjArgs& a, const FastLaunch& f, hipStream_t s, Kernel
   for (uint32_t lv = 0; lv < 3; ++lv) {
     if (!((a.fast_level_mask >> lv) & 1u))
       continue;
-    if (probe)
-      hipLaunchKernelGGL((lj_fast_kernel<N, MT, true>), dim3(f.total_blocks), dim3(LJ_T),
+    if (a.dev_layout)
+      hipLaunchKernelGGL((lj_fast_kernel<N, MT, 2>), dim3(f.total_blocks), dim3(LJ_T),
+                         a.fast_lds_lv[lv], s, a, a.fast_lds_lv[lv], lv);
+    else if (probe)
+      hipLaunchKernelGGL((lj_fast_kernel<N, MT, 1>), dim3(f.total_blocks), dim3(LJ_T),
                          a.fast_lds_lv[lv], s, a, a.fast_lds_lv[lv], lv);
     else
-      hipLaunchKernelGGL((lj_fast_kernel<N, MT, false>), dim3(f.total_blocks), dim3(LJ_T),
+      hipLaunchKernelGGL((lj_fast_kernel<N, MT, 0>), dim3(f.total_blocks), dim3(LJ_T),
                          a.fast_lds_lv[lv], s, a, a.fast_lds_lv[lv], lv);
     if (timer)
       timer->mark(lv == 0 ? "lj_fast_kernel" : (lv == 1 ? "lj_fast_kernel(3/CU)" : "lj_fast_kernel(2/CU)"));

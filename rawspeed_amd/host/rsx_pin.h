@@ -48,6 +48,9 @@ inline std::atomic<int>& pinned_pool_flag() {
 inline void set_pinned_pool(bool on) { pinned_pool_flag().store(on ? 1 : 0); }
 
 struct PinnedPool {
+  // blocks ever handed out: while it is zero pool_free() answers without the mutex or the
+  // look-up -- deallocate() is on every decoder thread's path, the pool is off by default
+  std::atomic<size_t> ever_used{0};
   std::mutex m;
   std::multimap<size_t, void*> free_blocks; // by capacity
   std::unordered_map<void*, size_t> live;   // handed out: block -> capacity
@@ -76,6 +79,7 @@ inline void* pool_alloc(size_t bytes) {
     if (it != P.free_blocks.end() && it->first <= cap + cap / 4) {
       void* p = it->second;
       P.live.emplace(p, it->first);
+      P.ever_used.fetch_add(1, std::memory_order_release);
       P.cached_bytes -= it->first;
       P.free_blocks.erase(it);
       return p;
@@ -86,12 +90,15 @@ inline void* pool_alloc(size_t bytes) {
     return nullptr;
   std::lock_guard<std::mutex> g(P.m);
   P.live.emplace(p, cap);
+  P.ever_used.fetch_add(1, std::memory_order_release);
   return p;
 }
 
 // false: not one of the pool's blocks -- the caller frees it as it always did
 inline bool pool_free(void* p) {
   PinnedPool& P = pinned_pool();
+  if (P.ever_used.load(std::memory_order_acquire) == 0)
+    return false; // (the pool never handed a block out: nothing of it can come back)
   void* evict = nullptr;
   {
     std::lock_guard<std::mutex> g(P.m);

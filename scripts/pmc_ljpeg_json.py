@@ -8,11 +8,11 @@ with the kernel time from `rocprofv3 --kernel-trace --stats` of the same command
 scripts/ubench/valu_rates2.hip: 2.4 cycles (add/sub/and/or/xor/lshr/ashr/mov) and 4.3
 (everything else) -- given as a [low, high] pair; the loops are ~70 % cheap instructions.
 
-Round 6: counters and times are keyed by the FULL instantiation (`lj_fast_kernel<2, false, false>`),
+Round 6: counters and times are keyed by the FULL instantiation (`lj_fast_kernel<2, false, 0>`),
 not by the template's name: round 5's `lj_\\w+` key let the PROBE instantiation of a plan's first
-run (`<2, false, true>`: two idle launches + one real, 138.6 us "average") overwrite the main
+run (round 5's `<2, false, true>`: two idle launches + one real, 138.6 us "average") overwrite the main
 kernel's 397.8 us, and the published issue fraction came out as 1.1-2.0.  PROBE instantiations
-(third template argument `true`) are left out altogether, and a fraction above 1 is an error."""
+(third template argument 1; `true` in round 5's files) are left out altogether, and a fraction above 1 is an error."""
 import collections
 import csv
 import json
@@ -22,8 +22,8 @@ import sys
 
 
 def inst_name(full):
-    """'void rsx::(anonymous namespace)::lj_fast_kernel<2, false, false>(rsx::LjArgs, ...)' ->
-    'lj_fast_kernel<2, false, false>' (None for kernels that are not the LJPEG pipeline's)."""
+    """'void rsx::(anonymous namespace)::lj_fast_kernel<2, false, 0>(rsx::LjArgs, ...)' ->
+    'lj_fast_kernel<2, false, 0>' (None for kernels that are not the LJPEG pipeline's)."""
     m = re.search(r"(lj_\w+)(<[^>]*>)?", full)
     if not m:
         return None
@@ -31,9 +31,10 @@ def inst_name(full):
 
 
 def is_probe(name):
-    """the single-pass kernel's first-run instantiation: lj_fast_kernel<N, TWO, PROBE = true>"""
+    """the single-pass kernel's first-run instantiation: lj_fast_kernel<N, TWO, MODE = 1> (round 5:
+    a bool, `true`); MODE 2 -- plans laid out on the device -- is a kernel of its own and stays"""
     m = re.match(r"lj_fast_kernel<\s*\d+\s*,\s*\w+\s*,\s*(\w+)\s*>", name)
-    return bool(m and m.group(1) == "true")
+    return bool(m and m.group(1) in ("true", "1"))
 
 
 def base_name(name):

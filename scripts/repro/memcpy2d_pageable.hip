@@ -41,6 +41,7 @@
 #include <thread>
 #include <vector>
 
+#include <malloc.h>
 #include <sys/mman.h>
 #include <sys/syscall.h>
 #include <sys/wait.h>
@@ -93,6 +94,7 @@ struct Config {
 
 static std::atomic<uint64_t> g_images{0}, g_rects{0}, g_bad_images{0}, g_bad_bytes{0}, g_outside{0};
 static std::atomic<bool> g_stop{false};
+static bool g_trim = false;
 
 struct Target { // what the stress thread works on
   std::atomic<uint8_t*> base{nullptr};
@@ -180,8 +182,11 @@ static uint8_t* image_alloc(const Config& cfg, size_t bytes, void** handle, size
 static void image_free(const Config& cfg, void* handle, size_t map_len) {
   if (cfg.alloc == "mmap")
     munmap(handle, map_len);
-  else
+  else {
     free(handle);
+    if (g_trim)
+      malloc_trim(128 << 10);
+  }
 }
 
 static void worker(const Config& cfg, int tid, Target* target) {
@@ -318,7 +323,7 @@ static void worker(const Config& cfg, int tid, Target* target) {
 int main(int argc, char** argv) {
   Config cfg;
   if (argc < 6) {
-    fprintf(stderr, "usage: %s rect|rows1d|pinned|rect16 none|collapse|move|fork mmap|malloc|numpy threads seconds [seed]\n", argv[0]);
+    fprintf(stderr, "usage: %s rect|rows1d|pinned|rect16 none|collapse|move|fork mmap|malloc|numpy|heap|heaptrim threads seconds [seed [prefork]]\n", argv[0]);
     return 2;
   }
   cfg.copy = argv[1];
@@ -328,6 +333,36 @@ int main(int argc, char** argv) {
   cfg.seconds = atof(argv[5]);
   if (argc > 6)
     cfg.seed = strtoull(argv[6], nullptr, 10);
+  // "heap": numpy's pattern on the brk heap (glibc's mmap threshold at its maximum from the start,
+  // as it is in a Python process that has freed a few large arrays)
+  // "heaptrim": the same, and after every image the top of the heap goes back to the system down
+  // to 128 KB above the last block in use -- what glibc does by itself (M_TRIM_THRESHOLD, M_TOP_PAD)
+  // when a Python process frees the array that lay topmost: the next image's pages from there on are
+  // NEW pages at OLD addresses
+  if (cfg.alloc == "heap" || cfg.alloc == "heaptrim") {
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);
+    g_trim = cfg.alloc == "heaptrim";
+    cfg.alloc = "numpy";
+  }
+  // prefork: what a Python process has behind it when the tests start -- a heap whose pages were
+  // shared copy-on-write with a child (subprocess: fork + exec) that is gone: 1 GB touched, a child
+  // forked and reaped, the memory freed again for the images to be carved from
+  if (argc > 7 && std::string(argv[7]) == "prefork") {
+    std::vector<void*> blocks;
+    for (int i = 0; i < 64; ++i) {
+      void* b = malloc(size_t(16) << 20);
+      memset(b, 0x5A, size_t(16) << 20);
+      blocks.push_back(b);
+    }
+    pid_t c = fork();
+    if (c == 0)
+      _exit(0);
+    int st = 0;
+    waitpid(c, &st, 0);
+    for (size_t i = 0; i < blocks.size(); i += 2) // (every other block: the heap stays in place)
+      free(blocks[i]);
+    printf("prefork: 1 GB of heap shared with a child that is gone, half of it free again\n");
+  }
   Target target;
   std::atomic<uint64_t> events{0};
   std::vector<std::thread> ws;
