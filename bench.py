@@ -465,6 +465,9 @@ def ljpeg_summary(extra):
         "cfg3_clipped_highlights": leg(extra.get("cfg3_clipped_highlights"), cpu=False, kernels=False),
         "cfg3_uniform_random_14bit": leg(extra.get("cfg3_uniform_random_14bit"), cpu=False, kernels=False),
         "ljpeg_3comp_8192x5464": leg(extra.get("ljpeg_3comp_8192x5464"), cpu=False, kernels=False),
+        "ljpeg_3comp_3tables_8192x5464": leg(extra.get("ljpeg_3comp_3tables_8192x5464"), cpu=False, kernels=False),
+        "ljpeg_4comp_1table_8192x5464": leg(extra.get("ljpeg_4comp_1table_8192x5464"), cpu=False, kernels=False),
+        "ljpeg_4comp_4tables_8192x5464": leg(extra.get("ljpeg_4comp_4tables_8192x5464"), cpu=False, kernels=False),
     }
     c4 = extra.get("cfg4_dng_tiles_8192x5464")
     if isinstance(c4, dict):

@@ -540,28 +540,39 @@ def run_cfg4(ctx, torch, log, steps=10, warmup=2, cpu=True, variants=True):
     return res
 
 
-def run_ljpeg3(ctx, torch, log, steps=10, warmup=2):
+def run_ljpeg3(ctx, torch, log, steps=10, warmup=2, n=3, tables_per_component=False):
     """A linear (3 components per pixel) 8192x5464 DNG as 2x2 LJPEG tiles of 4096x2732, MCU
-    3 x 1 (LJpegDecompressor.cpp:102-105), one Huffman table: the single-pass kernel's <3>
-    instantiation (round 5; until then the legacy route with its int16 difference scratch).
-    Every tile is compared with the image it was written from."""
+    3 x 1 (LJpegDecompressor.cpp:102-105): with ONE Huffman table the single-pass kernel's <3>
+    instantiation (round 5; until then the legacy route with its int16 difference scratch);
+    with a table PER COMPONENT -- what DNG writers emit, AbstractLJpegDecoder.cpp:181-291 -- its
+    table-per-phase instantiation (round 6).  n = 4: a 4-component scan over a 1-sample image
+    (MCU 4 x 1), tables A B C D.  Every tile is compared with the image it was written from."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cases
     from rawspeed_amd import abi
+    cpp = 3 if n == 3 else 1
     W, H, tw, th = 8192, 5464, 4096, 2732
-    pitch = (W * 3 * 2 + 15) // 16 * 16
+    pitch = (W * cpp * 2 + 15) // 16 * 16
     rng = np.random.default_rng(33)
+    tables, index = (cases.NIKON,), None
+    if tables_per_component:
+        trng = np.random.default_rng(3303)
+        tables = (cases.NIKON, cases.ALT) + tuple(
+            cases.random_huffman_table(trng, n_cat=15, skew=1.5) for _ in range(n - 2))
+        index = list(range(n))
     jobs, parts, tiles, off, scan_total = [], [], [], 0, 0
     for ty in range(2):
         for tx in range(2):
             d, data, tile_px, scan_len = cases.make_ljpeg_case(
-                rng, img_w=W, img_h=H, cpp=3, tile=(tx * tw, ty * th, tw, th), mcu=(3, 1))
+                rng, img_w=W, img_h=H, cpp=cpp, tile=(tx * tw, ty * th, tw, th), mcu=(n, 1),
+                tables=tables, table_index=index)
             pad = (-data.size) % 16
             j = abi.LJpegJob()
             j.desc = d
             j.in_offset, j.in_bytes, j.img_offset = off, data.size, 0
-            j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = pitch, W, H, 3, 0
+            j.img.pitch_bytes, j.img.dim_x, j.img.dim_y, j.img.cpp, j.img.is_cfa = \
+                pitch, W, H, cpp, int(cpp == 1)
             jobs.append(j)
             parts.append(np.concatenate([data, np.zeros(pad, np.uint8)]))
             tiles.append((tx, ty, tile_px, scan_len))
@@ -571,20 +582,23 @@ def run_ljpeg3(ctx, torch, log, steps=10, warmup=2):
     out = torch.zeros(pitch * H, dtype=torch.uint8, device="cuda")
     plan = ctx.ljpeg_plan(jobs)
     dt, kt, cons = _time_plan(torch, plan, inp, out, steps, warmup)
-    got = out.cpu().numpy().view(np.uint16).reshape(H, pitch // 2)[:, :W * 3]
+    got = out.cpu().numpy().view(np.uint16).reshape(H, pitch // 2)[:, :W * cpp]
     exact = list(cons) == [t[3] for t in tiles]
     for tx, ty, tile_px, _ in tiles:
         exact = exact and bool(np.array_equal(
-            got[ty * th:(ty + 1) * th, tx * tw * 3:(tx + 1) * tw * 3], tile_px))
+            got[ty * th:(ty + 1) * th, tx * tw * cpp:(tx + 1) * tw * cpp], tile_px))
     plan.close()
-    alg = scan_total + W * H * 3 * 2
-    res = {"workload": "LJpegDecompressor, 3 components (MCU 3x1): linear 8192x5464 DNG as 2x2 "
-                       "tiles of 4096x2732, 1 frame/step",
+    alg = scan_total + W * H * cpp * 2
+    res = {"workload": "LJpegDecompressor, %d components (MCU %dx1), %s: %s 8192x5464 DNG as 2x2 "
+                       "tiles of 4096x2732, 1 frame/step"
+                       % (n, n, "a Huffman table per component (%s)" % " ".join("ABCD"[:n])
+                          if tables_per_component else "one Huffman table",
+                          "linear" if cpp == 3 else "1-sample"),
            "mpix_per_s": round(W * H / dt / 1e6, 1),
-           "msamples_per_s": round(W * H * 3 / dt / 1e6, 1),
+           "msamples_per_s": round(W * H * cpp / dt / 1e6, 1),
            "ms_per_step": round(dt * 1e3, 4), "bit_exact": exact,
            "bit_exact_against": "the image every tile was written from",
-           "entropy_bits_per_sample": round(scan_total * 8 / (W * H * 3), 3),
+           "entropy_bits_per_sample": round(scan_total * 8 / (W * H * cpp), 3),
            "algorithmic_bytes_per_step": alg}
     _dominant(res, kt)
     _roofline(res, alg, dt, kt)
@@ -1208,6 +1222,9 @@ def run(ctx, torch, log):
     leg("cfg3_clipped_highlights", lambda: run_clipped(ctx, torch, log))
     leg("cfg4_dng_tiles_8192x5464", lambda: run_cfg4(ctx, torch, log))
     leg("ljpeg_3comp_8192x5464", lambda: run_ljpeg3(ctx, torch, log))
+    leg("ljpeg_3comp_3tables_8192x5464", lambda: run_ljpeg3(ctx, torch, log, tables_per_component=True))
+    leg("ljpeg_4comp_1table_8192x5464", lambda: run_ljpeg3(ctx, torch, log, n=4))
+    leg("ljpeg_4comp_4tables_8192x5464", lambda: run_ljpeg3(ctx, torch, log, n=4, tables_per_component=True))
     leg("nikon_lossless14_6016x4016", lambda: run_nikon(ctx, torch, log))
     leg("hasselblad_8272x6200", lambda: run_hasselblad(ctx, torch, log))
     leg("sony_arw1_3881x2608", lambda: run_sony_arw1(ctx, torch, log))
@@ -1247,6 +1264,14 @@ if __name__ == "__main__":
         print(json.dumps(run_sony_arw1(ctx, torch, print, steps=args.steps), indent=1))
     elif args.only == "ljpeg3":
         print(json.dumps(run_ljpeg3(ctx, torch, print, steps=args.steps), indent=1))
+    elif args.only == "ljpegpt":  # (a table per component: 3 and 4 components, next to one table)
+        print(json.dumps({
+            "ljpeg_3comp_8192x5464": run_ljpeg3(ctx, torch, print, steps=args.steps),
+            "ljpeg_3comp_3tables_8192x5464": run_ljpeg3(ctx, torch, print, steps=args.steps,
+                                                        tables_per_component=True),
+            "ljpeg_4comp_1table_8192x5464": run_ljpeg3(ctx, torch, print, steps=args.steps, n=4),
+            "ljpeg_4comp_4tables_8192x5464": run_ljpeg3(ctx, torch, print, steps=args.steps, n=4,
+                                                        tables_per_component=True)}, indent=1))
     elif args.only == "pentax":
         print(json.dumps(run_pentax(ctx, torch, print, frames=args.frames, steps=args.steps,
                                     cpu=not args.no_cpu), indent=1))

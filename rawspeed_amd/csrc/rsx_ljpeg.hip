@@ -760,6 +760,81 @@ __device__ __forceinline__ uint32_t lj_guess_parse_mt(uint32_t col4, uint32_t en
   return ((q - qend) >> 5) | (lut == LJ_K0_LUTB_OFF ? 64u : 0u);
 }
 
+// A table per PHASE (round 6; LjStreamDev::fast == 3): the table of a symbol is the one of its
+// index mod N (N = 2, 3, 4 components, up to four tables in any assignment) -- the parse state is
+// offset | phase << 6.  The N 10-bit length tables and the N 8-bit ones of the pair loop lie behind
+// the kernel's usual layout (5 KB: five workgroups a CU for these plans instead of seven).
+// (NP = the most phases a stream of the plan has, LjArgs::pt_np: three phases leave a CU six
+// workgroups, four leave it five)
+constexpr uint32_t LJ_K0_PT10_OFF = (LJ_K0_LDS + 15u) & ~15u;      // NP x 1024 B
+__host__ __device__ constexpr uint32_t lj_k0_pt8_off(uint32_t np) { return LJ_K0_PT10_OFF + np * 1024u; } // NP x 256 B
+__host__ __device__ constexpr uint32_t lj_k0_ptx_off(uint32_t np) { return lj_k0_pt8_off(np) + np * 256u; } // 8 words: the phase pass
+__host__ __device__ constexpr uint32_t lj_k0_lds_pt(uint32_t np) { return lj_k0_ptx_off(np) + 32u; }
+// K0's look-back over symbol counts mod N (LjArgs::k0p): a workgroup's word is its own total
+// (AGG) as soon as its chain has settled, then the phase it ENDS in (INC) once it knows where it starts
+constexpr uint32_t K0P_AGG = 1u << 30, K0P_INC = 1u << 31;
+constexpr uint32_t ST_PT_MASK = 0xFFu; // offset | phase
+template <bool COUNT, bool EXACT>
+__device__ __forceinline__ uint32_t lj_guess_parse_pt(uint32_t col4, uint32_t end_bits, uint32_t from,
+                                                      uint32_t np, const TabLds* tabs0,
+                                                      uint32_t tabsel, uint32_t pt8,
+                                                      uint32_t* count = nullptr) {
+  uint32_t q = (from & ST_OFF_MASK) << 5, n = 0, spec = 0;
+  uint32_t ph = (from >> ST_PHASE_SHIFT) & 3u; // phase of the NEXT symbol
+  const uint32_t qend = end_bits << 5;
+  const uint32_t qpair = qend > (26u << 5) ? qend - (26u << 5) : 0u;
+  auto next = [np](uint32_t p) -> uint32_t { return p + 1u == np ? 0u : p + 1u; };
+  while (q < qpair) { // (lj_guess_parse_pairs' loop, the second look-up in the next phase's table)
+    uint32_t ad;
+    uint64_t pr;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(q), "s"(0xFFFFFC00u), "v"(col4));
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:4 offset1:0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=v"(pr)
+                 : "v"(ad));
+    const uint32_t w = uint32_t((pr << ((q >> 5) & 31u)) >> 32);
+    const uint32_t ph1 = next(ph);
+    const uint32_t l1 = *(lds_u8p)(pt8 + (ph << 8) + (w >> 24));
+    const uint32_t w2 = w << (l1 & 31u);
+    const uint32_t l2 = *(lds_u8p)(pt8 + (ph1 << 8) + (w2 >> 24));
+    const uint32_t sum = l1 + l2;
+    uint32_t qadd = sum << 5, nadd = 2u, phn = next(ph1);
+    if (__builtin_expect(sum >= 128u, 0)) {
+      uint32_t len = *(lds_u8p)(LJ_K0_PT10_OFF + (ph << 10) + (w >> 22));
+      if (EXACT && __builtin_expect(len & 0x80u, 0)) {
+        const uint32_t exact = lj_exact_symbol_bits(w, tabs0 + ((tabsel >> (4u * ph)) & 15u));
+        if (exact)
+          len = exact;
+      }
+      spec |= len;
+      qadd = (len & 0x7Fu) << 5;
+      nadd = 1u;
+      phn = ph1;
+    }
+    q += qadd;
+    n += nadd;
+    ph = phn;
+  }
+  while (q < qend) {
+    uint32_t ad;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ad) : "v"(q), "s"(0xFFFFFC00u), "v"(col4));
+    const uint32_t d0 = *(lds_u32p)(ad), d1 = *(lds_u32p)(ad + 4u * LJ_T);
+    const uint32_t w = uint32_t((((uint64_t(d0) << 32) | d1) << ((q >> 5) & 31u)) >> 32);
+    uint32_t len = *(lds_u8p)(LJ_K0_PT10_OFF + (ph << 10) + (w >> 22));
+    if (EXACT && __builtin_expect(len & 0x80u, 0)) {
+      const uint32_t exact = lj_exact_symbol_bits(w, tabs0 + ((tabsel >> (4u * ph)) & 15u));
+      if (exact)
+        len = exact;
+    }
+    spec |= len;
+    q += (len & 0x7Fu) << 5;
+    ph = next(ph);
+    ++n;
+  }
+  if (COUNT)
+    *count = n | ((spec & 0x80u) << 24);
+  return ((q - qend) >> 5) | (ph << ST_PHASE_SHIFT);
+}
+
 // A slot inside a constant region of the image is the code of the zero difference over
 // and over.  No parse from an arbitrary bit finds its way into such a stretch reliably
 // (with Nikon's 14-bit table, 111110 repeated also reads as a chain of 12-bit symbols),
@@ -810,15 +885,63 @@ __device__ __forceinline__ bool lj_guess_constant(const uint32_t* B, int col, ui
   *entry = p0; // the symbol grid of the slot: its first symbol starts at bit p0
   return true;
 }
+// ... and for a table per phase: the slot is the N zero codes in turn, period zl = the sum of their
+// lengths, zc = the codes one behind the other (phase 0's first), cum[k] = where phase k's code starts
+// inside the pattern.  The pattern sits at exactly one bit p0 of the period; symbols of phase k then
+// start at every bit = p0 + cum[k] (mod zl).  Entry = the first of them in the slot, exit = the
+// first behind it, count = all in between.
+__device__ __forceinline__ bool lj_guess_constant_pt(const uint32_t* B, int col, uint32_t zl, uint32_t zc,
+                                                     const uint32_t (&cum)[4], uint32_t np,
+                                                     bool candidate, uint32_t* guess, uint32_t* count,
+                                                     uint32_t* entry, uint32_t bits) {
+  bool per = candidate && bits >= 64u;
+  for (int wi = 0; wi < LJ_PW && __any(per); ++wi) {
+    const uint32_t d0 = B[wi * LJ_T + col], d1 = B[(wi + 1) * LJ_T + col];
+    per = per && (uint32_t(32 * wi) >= bits ||
+                  d0 == uint32_t((((uint64_t(d0) << 32) | d1) << zl) >> 32));
+  }
+  if (!per)
+    return false;
+  const uint64_t w64 = (uint64_t(B[col]) << 32) | B[LJ_T + col];
+  uint32_t hits = 0, p0 = 0;
+  for (uint32_t p = 0; p < zl; ++p)
+    if (uint32_t((w64 << p) >> (64u - zl)) == zc) {
+      ++hits;
+      p0 = p;
+    }
+  if (hits != 1)
+    return false;
+  uint32_t best_in = 0xFFFFFFFFu, best_out = 0xFFFFFFFFu, n = 0;
+  for (uint32_t k = 0; k < np; ++k) {
+    uint32_t f = p0 + cum[k];
+    f = f >= zl ? f - zl : f; // first start of a phase-k symbol in the slot (p0, cum[k] < zl)
+    if (f >= bits)
+      continue; // (cannot happen: bits >= 64 > zl)
+    const uint32_t m = (bits - f + zl - 1u) / zl; // phase-k symbols that start inside the slot
+    n += m;
+    const uint32_t out = f + m * zl - bits; // its first start behind the slot
+    if ((f << 2 | k) < best_in)
+      best_in = f << 2 | k;
+    if ((out << 2 | k) < best_out)
+      best_out = out << 2 | k;
+  }
+  *entry = (best_in >> 2) | ((best_in & 3u) << ST_PHASE_SHIFT);
+  *guess = (best_out >> 2) | ((best_out & 3u) << ST_PHASE_SHIFT);
+  *count = n;
+  return true;
+}
 constexpr int LJ_GUESS_SLOTS = 3; // slots parsed for a guess, at most (LjArgs::guess_slots)
 
 // MTPLAN: the plan has streams with two alternating tables.  Two instantiations because the
 // mere presence of their code -- the two-table parse, the hand-over of entry states between
 // workgroups -- made the kernel 4-10 % slower for plans that never run it (register
 // allocation and layout of the rounds: cfg 3 0.258 -> 0.265-0.29 ms).
+// KM: 0 plans of one-table streams, 1 plans with two-alternating-table streams, 2 plans with
+// table-per-phase streams (whose two-table streams are table-per-phase streams as well)
 #define K0_CHAIN (MTPLAN && a.k0_chain != 0u)
-template <bool MTPLAN, bool INV>
+template <int KM, bool INV>
 __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
+  constexpr bool MTPLAN = KM != 0;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // The LAST workgroups first: the kernels behind this one read the un-stuffed image from
   // its first workgroup on, and what went through the 256 MB memory-side cache last is
@@ -869,8 +992,36 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
   const int j = threadIdx.x;
   uint8_t* lut8 = smem + LJ_GUESS_LUT_OFF;
   uint32_t lut_pk = 0, lut8b = 0x80u, lut_pk_b = 0, lut8b_b = 0x80u;
-  const bool mt = MTPLAN && S.fast == 2;
-  if (S.fast && a.fast_tabs) {
+  const bool mt = KM == 1 && S.fast == 2;
+  const bool pt = KM == 2 && S.fast == 3;
+  const uint32_t np = pt ? S.tab_period : 1u; // (phases of a table-per-phase stream)
+  const uint32_t tabsel = pt ? (uint32_t(S.tab_of_phase[0] & 15u) | (uint32_t(S.tab_of_phase[1] & 15u) << 4) |
+                                (uint32_t(S.tab_of_phase[2] & 15u) << 8) |
+                                (uint32_t(S.tab_of_phase[3] & 15u) << 12))
+                             : 0u;
+  uint32_t pt_pk[4] = {0, 0, 0, 0}, pt_8[4] = {0x80u, 0x80u, 0x80u, 0x80u};
+  if (KM == 2 && pt && a.fast_tabs) {
+    // (the symbol lengths of every phase's 10-bit LUT: entries 4j .. 4j + 3, and the 8-bit
+    // table's entry j, as below)
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k) {
+      if (k >= np)
+        continue;
+      const uint2* ft = a.fast_tabs + size_t(S.table_base + ((tabsel >> (4u * k)) & 15u)) * 1024 + 4 * j;
+      uint2 e0 = make_uint2(0u, 0u);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint2 e = ft[q];
+        if (q == 0)
+          e0 = e;
+        pt_pk[k] |= (((e.x >> 5) & 63u) | ((e.x >> 24) & 0x80u)) << (8 * q);
+      }
+      const uint32_t total = (e0.x >> 5) & 63u;
+      const uint32_t code = total - uint32_t(__builtin_popcount(e0.y));
+      if (!(e0.x & 0x80000000u) && code <= 8u && total >= 1u)
+        pt_8[k] = total;
+    }
+  } else if (S.fast && a.fast_tabs) {
     // (the symbol lengths of the stream's 10-bit LUT: asked for now, parked later)
     const uint2* ft =
         a.fast_tabs + size_t(S.table_base + (mt ? S.tab_of_phase[0] : 0u)) * 1024 + 4 * j;
@@ -955,7 +1106,15 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     lds_barrier(); // every lane has written its part of the image out
     K0_STAMP(4);
     reinterpret_cast<uint32_t*>(lut8)[j] = lut_pk;
-    if (mt) {
+    if (KM == 2 && pt) {
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; ++k) {
+        if (k >= np)
+          continue;
+        reinterpret_cast<uint32_t*>(smem + LJ_K0_PT10_OFF + (k << 10))[j] = pt_pk[k];
+        smem[lj_k0_pt8_off(a.pt_np) + (k << 8) + uint32_t(j)] = uint8_t(pt_8[k]);
+      }
+    } else if (mt) {
       reinterpret_cast<uint32_t*>(smem + LJ_K0_LUTB_OFF)[j] = lut_pk_b;
       smem[LJ_K0_LUT8A_OFF + uint32_t(j)] = uint8_t(lut8b);
       smem[LJ_K0_LUT8B_OFF + uint32_t(j)] = uint8_t(lut8b_b);
@@ -971,6 +1130,28 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     uint32_t zi = uint32_t(__builtin_amdgcn_readfirstlane(
         int(a.fast_z[S.table_base + (mt ? S.tab_of_phase[0] : 0u)])));
     uint32_t zl = zi & 31u, zc = zi >> 8, zlb = 0;
+    uint32_t zcum[4] = {0, 0, 0, 0};
+    if (pt) {
+      // (the N zero codes in turn: period = the sum of their lengths, the codes one behind the other)
+      zl = 0u;
+      zc = 0u;
+      bool all = true;
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; ++k) {
+        if (k >= np)
+          continue;
+        const uint32_t zk = uint32_t(__builtin_amdgcn_readfirstlane(
+            int(a.fast_z[S.table_base + ((tabsel >> (4u * k)) & 15u)])));
+        const uint32_t lk = zk & 31u;
+        all = all && lk != 0u;
+        zcum[k] = zl;
+        zl += lk;
+        zc = (zc << lk) | (zk >> 8);
+      }
+      // (at most 128 symbols a slot: four bits a symbol on average; the pattern inside 31 bits)
+      if (!all || zl > 31u || zl < 4u * np)
+        zl = 0u;
+    }
     if (mt) {
       const uint32_t zb = uint32_t(
           __builtin_amdgcn_readfirstlane(int(a.fast_z[S.table_base + S.tab_of_phase[1]])));
@@ -978,7 +1159,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       zc = (zc << zlb) | (zb >> 8);
       zl = (zl != 0u && zlb != 0u && zl + zlb <= 31u) ? zl + zlb : 0u;
     }
-    const uint32_t smask = mt ? ST_MT_MASK : ST_OFF_MASK;
+    const uint32_t smask = pt ? ST_PT_MASK : (mt ? ST_MT_MASK : ST_OFF_MASK);
     const uint32_t gs = a.guess_slots & 0xFFu; // (3; experiments: fewer)
     // (the hand-written loop assumes the layout it was written for)
     bool hand = lds_addr(L.B) == 0u && lds_addr(lut8) == LJ_GUESS_LUT_OFF;
@@ -990,11 +1171,18 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     const TabLds* tb_even = a.tables + S.table_base + (mt ? S.tab_of_phase[0] : 0u);
     const TabLds* tb_odd = a.tables + S.table_base + (mt ? S.tab_of_phase[1] : 0u);
     // (two tables, the parse from bit 0: special lengths as the table approximates them)
+    const TabLds* tabs0 = a.tables + S.table_base;
+    const uint32_t pt8 = lj_k0_pt8_off(a.pt_np); // (wave-uniform: a kernel argument)
     auto parse_from_0 = [&](int col, uint32_t bits, uint32_t* count) -> uint32_t {
+      if (KM == 2)
+        return lj_guess_parse_pt<true, false>(uint32_t(col) * 4u, bits, 0u, np, tabs0, tabsel, pt8, count);
       return lj_guess_parse_mt<true, false>(uint32_t(col) * 4u, bits, 0u, tb_even, tb_odd, count);
     };
     auto parse = [&](int col, uint32_t bits, uint32_t from, uint32_t* count) -> uint32_t {
-      if (mt)
+      if (KM == 2 && pt)
+        return count ? lj_guess_parse_pt<true, true>(uint32_t(col) * 4u, bits, from, np, tabs0, tabsel, pt8, count)
+                     : lj_guess_parse_pt<false, true>(uint32_t(col) * 4u, bits, from, np, tabs0, tabsel, pt8);
+      if (KM == 1 && mt)
         return count ? lj_guess_parse_mt<true, true>(uint32_t(col) * 4u, bits, from, tb_even, tb_odd, count)
                      : lj_guess_parse_mt<false, true>(uint32_t(col) * 4u, bits, from, tb_even, tb_odd);
 #ifndef RSX_K0_SINGLE_SYMBOL
@@ -1012,10 +1200,12 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     const bool exists = eb != 0u && !(j == 0 && lb == 0);
     uint32_t ea = 0, cnt = 0, grid = 0;
     bool constant = false;
-    if (zl >= 4u) // (shorter: more than 128 symbols in a slot, the multi-kernel pipeline's)
+    if (pt && zl != 0u)
+      constant = lj_guess_constant_pt(L.B, j, zl, zc, zcum, np, exists, &ea, &cnt, &grid, eb);
+    else if (zl >= 4u) // (shorter: more than 128 symbols in a slot, the multi-kernel pipeline's)
       constant = lj_guess_constant(L.B, j, zl, zc, exists, &ea, &cnt, &grid, zlb, eb);
     if (!constant && exists)
-      ea = (mt ? parse_from_0(j, eb, &cnt) : parse(j, eb, 0u, &cnt)) & smask;
+      ea = ((mt || pt) ? parse_from_0(j, eb, &cnt) : parse(j, eb, 0u, &cnt)) & smask;
     if (j == 0 && lb == 0)
       ea = S.start_bit & smask; // (the stream's first slot starts where the stream does)
     EA[j] = uint16_t(ea);
@@ -1029,7 +1219,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
 #else
     // (two tables: the parse from bit 0 stands for the B parse where the predecessor ends on
     // bit 0 -- unless it met a special length: then once more, looking them up)
-    if (!constant && exists && gs >= 2u && (xa != 0u || (mt && (cnt >> 31) != 0u)))
+    if (!constant && exists && gs >= 2u && (xa != 0u || ((mt || pt) && (cnt >> 31) != 0u)))
       ebv = parse(j, eb, xa, &cnt) & smask;
 #endif
     EB[j] = uint16_t(ebv);
@@ -1084,10 +1274,12 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     // between rounds, two barriers a round -- what the three-slot chain took before)
     // (a lambda, run a second time after the hand-over below: as ONE loop nest -- "for pass" around
     // the rounds -- the compiler made the rounds 10 % of K0 slower for everybody, cfg 3 0.26 -> 0.29 ms)
-    auto run_rounds = [&]() -> bool {
+    // (cmp: the bits of a state that must agree -- all of them, or the offset alone: the first
+    // rounds of a table-per-phase stream, see "the phase pass" below)
+    auto run_rounds = [&](uint32_t cmp) -> bool {
       for (uint32_t round = 0; round < LJ_GUESS_ROUNDS && gs >= 3u; ++round) {
         const uint32_t x = j >= 1 ? uint32_t(EB[j - 1]) : 0u;
-        if (!constant && exists && j >= 1 && x != uint32_t(EU[j]))
+        if (!constant && exists && j >= 1 && ((x ^ uint32_t(EU[j])) & cmp) != 0u)
           glist[atomicAdd(&nlist[4 + 2 * round], 1u)] = uint16_t(j);
         lds_barrier();
         const uint32_t nth = nlist[4 + 2 * round];
@@ -1100,7 +1292,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
             const uint32_t from = uint32_t(EB[c - 1]);
             uint32_t n = 0;
             const uint32_t e = parse(c, L.ob[c], from, &n) & smask;
-            if (e != uint32_t(EB[c]))
+            if (((e ^ uint32_t(EB[c])) & cmp) != 0u)
               changed = true;
             if ((round == 0u || e != uint32_t(EB[c])) && (c < LJ_T - 1 || lb + 1 < S.n_blocks))
               a.sub_start[g1 + uint32_t(c)] = uint16_t(e);
@@ -1117,7 +1309,155 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       }
       return false;
     };
-    bool settled = run_rounds();
+    bool settled = run_rounds(smask);
+    bool phase_from_counts = false; // (this workgroup's phases are the look-back's, below)
+    if (KM == 2) {
+      // The phase pass (streams with a table per phase).  Where the tables of the components
+      // DIFFER a parse in the wrong phase reads wrong lengths and falls into step with the true
+      // one in offset and phase alike, as with two tables: the rounds above settle.  Where they
+      // AGREE -- on the short codes of smooth image regions they do, for channels of one image --
+      // nothing in the bits says which phase a parse is in: its offsets fall into step as with
+      // one table, its phase stays whatever its start assumed, and the fixed point of the chain
+      // travels down the workgroup one slot a round.  But the phase of a symbol is its index mod
+      // N, and in such a stretch the COUNTS are right whatever the phase: a workgroup whose
+      // rounds did not settle gives every slot the phase a prefix sum of the counts gives it,
+      // from the phase the workgroup starts in -- which is the prefix of the counts of ALL
+      // workgroups in front of it: a decoupled look-back over 2-bit sums, every workgroup takes
+      // part --, parses the slots whose last parse started in another phase ONCE more from the
+      // right one, all at a time, and is done if no exit and no count moved.
+      uint32_t* PX = reinterpret_cast<uint32_t*>(smem + lj_k0_ptx_off(a.pt_np));
+      uint32_t* const kp_now = a.k0p + size_t(a.run_parity) * (gridDim.x + 1u);
+      if (j == 0) // (the next run's words of this block: clean when it looks at them)
+        a.k0p[size_t(a.run_parity ^ 1u) * (gridDim.x + 1u) + b] = 0u;
+      // (a workgroup whose rounds settled IS in step with the true chain, phase and all -- a
+      // wrong phase cannot be consistent over 255 slots parsed from bit 0 each --: the phase it
+      // ends in goes out at once, and it looks at nobody.  Only the others walk back, to the
+      // nearest such word: next door as a rule.)
+      if (pt && settled && j == 0)
+        __hip_atomic_store(&kp_now[b],
+                           K0P_INC | K0P_AGG | ((uint32_t(EB[LJ_T - 1]) >> ST_PHASE_SHIFT) & 3u),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (pt && !settled) {
+        const uint32_t my_c = (j >= 1 && exists) ? (uint32_t(ECNT[j]) & 0x7FFFu) : 0u;
+        uint32_t incl = my_c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t y = uint32_t(__shfl_up(int(incl), o, 64));
+          if ((j & 63) >= o)
+            incl += y;
+        }
+        if ((j & 63) == 63)
+          PX[j >> 6] = incl;
+        lds_barrier();
+        const uint32_t w0 = PX[0], w1 = PX[1], w2 = PX[2], w3 = PX[3];
+        const uint32_t total = w0 + w1 + w2 + w3;
+        uint32_t before = incl - my_c + ((j >> 6) >= 1 ? w0 : 0u) + ((j >> 6) >= 2 ? w1 : 0u) +
+                          ((j >> 6) >= 3 ? w2 : 0u);
+        // the workgroup's own sum out, then the look-back (the first wavefront: 64 words a pass)
+        if (j == 0)
+          __hip_atomic_store(&kp_now[b], K0P_AGG | (total % np), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (j < 64) {
+          uint32_t acc = 0, ok = 0;
+          if (lb == 0) {
+            ok = 1; // (the stream's first symbol is phase 0)
+          } else {
+            int64_t pos = int64_t(lb) - 1;
+            for (uint32_t spins = 0; spins < (1u << 14) && !ok; ++spins) {
+              const int64_t idx = pos - j;
+              uint32_t w = K0P_INC; // (in front of the stream: phase 0)
+              if (idx >= 0)
+                w = __hip_atomic_load(&kp_now[S.first_block + uint32_t(idx)], __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+              const uint64_t m_inc = __ballot((w & K0P_INC) != 0u);
+              const uint64_t m_any = __ballot((w & (K0P_INC | K0P_AGG)) != 0u);
+              const int f = m_inc ? __builtin_ctzll(m_inc) : 64;
+              const uint64_t need = f == 64 ? ~0ull : ((2ull << f) - 1ull);
+              if ((m_any & need) != need) {
+                __builtin_amdgcn_s_sleep(2);
+                continue; // (a predecessor in the window has nothing out yet)
+              }
+              uint32_t v = (j <= f) ? (w & 3u) : 0u;
+#pragma unroll
+              for (int o = 32; o > 0; o >>= 1)
+                v += uint32_t(__shfl_xor(int(v), o, 64));
+              acc += v;
+              if (f < 64)
+                ok = 1;
+              else
+                pos -= 64;
+            }
+          }
+          if (j == 0) {
+            PX[4] = ok ? acc % np : ((uint32_t(EB[0]) >> ST_PHASE_SHIFT) & 3u);
+            PX[5] = ok;
+            PX[6] = 0u; // "the phase pass moved an exit or a count"
+          }
+        }
+        lds_barrier();
+        const uint32_t a_b = PX[4];
+        if (j == 0) {
+          __hip_atomic_store(&kp_now[b], K0P_INC | K0P_AGG | ((a_b + total) % np), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+          if (!PX[5] && !settled)
+            nlist[2] = 1u; // (no prefix in time: the workgroup's own estimate, "uncertain")
+#ifdef RSX_EXPERIMENT
+          if (!PX[5])
+            atomicOr(&a.results[s].stat_why, 0x100000u);
+#endif
+          if (!settled)
+            EB[0] = uint16_t((uint32_t(EB[0]) & ST_OFF_MASK) | (a_b << ST_PHASE_SHIFT));
+        }
+        lds_barrier();
+        // every slot's entry: its predecessor's exit offset | the phase the counts give it
+        bool redo = false;
+        uint32_t want_in = 0;
+        const bool relabel = !settled; // (workgroup-uniform)
+        phase_from_counts = relabel;
+        if (relabel && j >= 1 && exists) {
+          want_in = (uint32_t(EB[j - 1]) & ST_OFF_MASK) | (((a_b + before) % np) << ST_PHASE_SHIFT);
+          redo = !constant && want_in != uint32_t(EU[j]);
+          if (constant && want_in != grid) {
+            nlist[2] = 1u; // (a constant slot's grid and phase are read from its bits)
+#ifdef RSX_EXPERIMENT
+            atomicOr(&a.results[s].stat_why, 0x400000u);
+#endif
+          }
+        }
+        lds_barrier(); // (every EB[j - 1] has been read)
+        if (redo) {
+          uint32_t n2 = 0;
+          const uint32_t e2 = parse(j, eb, want_in, &n2) & smask;
+          if (((e2 ^ uint32_t(EB[j])) & ST_OFF_MASK) != 0u || pack_cnt(n2) != ECNT[j])
+            PX[6] = 1u;
+          EB[j] = uint16_t(e2);
+          EU[j] = uint16_t(want_in);
+          ECNT[j] = pack_cnt(n2);
+        } else if (relabel && j >= 1 && exists && !constant) {
+          // (parsed from this very state already: its exit phase follows from its count)
+          EB[j] = uint16_t((uint32_t(EB[j]) & ST_OFF_MASK) |
+                           (((a_b + before + my_c) % np) << ST_PHASE_SHIFT));
+        }
+        lds_barrier();
+        if (relabel && PX[6] == 0u)
+          settled = true; // (every slot parsed from its predecessor's exit, phase and all)
+        if (PX[6] != 0u) { // (the published sums may be off now: nothing downstream trusts them blindly)
+          if (j >= 3 && j < 4 + 2 * int(LJ_GUESS_ROUNDS))
+            nlist[j] = 0u;
+          lds_barrier();
+          settled = run_rounds(smask);
+          if (j == 0)
+            nlist[2] = 1u;
+#ifdef RSX_EXPERIMENT
+          if (j == 0)
+            atomicOr(&a.results[s].stat_why, 0x200000u);
+#endif
+        }
+        // the guesses once more, phases and all (what the B parse and the rounds stored had
+        // the phases of their time)
+        if (relabel && stored)
+          a.sub_start[g1 + uint32_t(j)] = EB[j];
+      }
+    }
     K0_STAMP(7);
 #ifndef RSX_K0_NO_FINAL_HANDOVER
     // (the hand-over once more, now that the rounds have run: marked final)
@@ -1152,8 +1492,13 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
               __builtin_amdgcn_s_sleep(1);
           }
 #endif
-          if ((v & 0xC000u) == tag && (v & smask) != uint32_t(EB[0])) {
-            EB[0] = uint16_t(v & smask);
+          // (a table per phase: the phase of EB[0] is the look-back's, absolute; a predecessor's
+          // word from BEFORE its own phase pass -- not marked final -- only has an offset to give)
+          uint32_t vs = v & smask;
+          if (phase_from_counts && (v & 0xE000u) != (tag | 0x2000u))
+            vs = (vs & ST_OFF_MASK) | (uint32_t(EB[0]) & ~ST_OFF_MASK & smask);
+          if ((v & 0xC000u) == tag && vs != uint32_t(EB[0])) {
+            EB[0] = uint16_t(vs);
             nlist[3] = 1u;
           }
         }
@@ -1164,7 +1509,7 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
         if (j >= 3 && j < 4 + 2 * int(LJ_GUESS_ROUNDS))
           nlist[j] = 0u;
         lds_barrier();
-        settled = run_rounds();
+        settled = run_rounds(smask);
       }
     }
     ebv = uint32_t(EB[j]);
@@ -1215,13 +1560,14 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       uint8_t* w = reinterpret_cast<uint8_t*>(a.k0w + b);
       if (j == 0) {
         *reinterpret_cast<uint32_t*>(w) = *est;
+        // (a state is offset | table bit or phase: 8 bits since round 6; "uncertain" is bit 8)
         *reinterpret_cast<uint16_t*>(w + 4) =
-            uint16_t((uint32_t(EB[0]) & 0x7Fu) | (nlist[2] ? 0x80u : 0u));
+            uint16_t((uint32_t(EB[0]) & 0xFFu) | (nlist[2] ? 0x100u : 0u));
         if (lb == 0)
-          *reinterpret_cast<uint16_t*>(w + 6) = uint16_t(0x8000u | (uint32_t(EB[0]) & 0x7Fu));
+          *reinterpret_cast<uint16_t*>(w + 6) = uint16_t(0x8000u | (uint32_t(EB[0]) & 0xFFu));
       }
       if (j == LJ_T - 1 && lb + 1 < S.n_blocks)
-        *reinterpret_cast<uint16_t*>(w + 8 + 6) = uint16_t(0x8000u | (ebv & 0x7Fu));
+        *reinterpret_cast<uint16_t*>(w + 8 + 6) = uint16_t(0x8000u | (ebv & 0xFFu));
     }
     if (K0_CHAIN && j == LJ_T - 1 && lb + 1 < S.n_blocks)
       __hip_atomic_store(&a.k0e[b + 1], 0xA000u | (a.run_parity << 14) | (ebv & smask),
@@ -3220,8 +3566,8 @@ __global__ __launch_bounds__(1024) void lj_dri_layout_kernel(
   for (uint32_t k = tid; k < n_streams; k += 1024u) {
     const LjStreamDev& S = streams[k];
     const uint32_t fb = ld(&S.first_block), nb = ld(&S.n_blocks);
-    const uint32_t tz = S.table_base | (uint32_t(S.tab_of_phase[0] & 15u) << 24) |
-                        (uint32_t(S.tab_of_phase[1] & 15u) << 28);
+    const uint32_t tz = lf_table_word(S.table_base, S.tab_of_phase[0], S.tab_of_phase[1],
+                                      S.tab_of_phase[2], S.tab_of_phase[3]);
     for (uint32_t q = 0; q < nb; ++q) {
       block_stream[fb + q] = k;
       fast_order[fb + q] = make_uint4(fb + q, k, tz, fb);
@@ -3260,9 +3606,12 @@ struct LJpegPlan {
   bool any_fast_legacy = false; // legacy-route streams on the single-pass kernel (3 components)
   bool legacy_fallback_ready = false; // difference scratch of the fused streams allocated
   // single-pass path (rsx_ljpeg_fast.hip)
-  bool fast_present[2][5] = {}; // [two alternating tables][components]
+  bool fast_present[3][5] = {}; // [one table / two alternating / a table per phase][components]
   bool any_fast_mt = false;     // some stream takes its two-table instantiation
+  bool any_fast_pt = false;     // ... its table-per-phase instantiation (LjStreamDev::fast == 3)
+  uint32_t pt_np = 2;           // the most phases such a stream has (sizes K0's LDS)
   DeviceBuffer d_k0e;           // K0's hand-over words (LjArgs::k0e)
+  DeviceBuffer d_k0p;           // K0's phase look-back words (LjArgs::k0p), table-per-phase plans
   bool any_fast = false;       // some stream takes the single-pass kernel
   uint32_t fast_lds = 0;       // LDS bytes of its launches
   uint32_t fast_uniform_nb = 0, fast_rotate = 0; // (LjArgs)
@@ -3279,7 +3628,7 @@ struct LJpegPlan {
   bool any_pipeline = false;   // some stream takes the multi-kernel pipeline in the first pass
   bool expect_slow = false;    // the last run left FL_SLOW streams: launch the second pass at once
   bool slow_pass_launched = false; // ... this run already has
-  DeviceBuffer d_fast_tabs, d_lb, d_tickets, d_fast_order, d_fast_z, d_fast_level, d_k0w,
+  DeviceBuffer d_fast_tabs, d_fast_tabs16, d_lb, d_tickets, d_fast_order, d_fast_z, d_fast_level, d_k0w,
       d_block_base0;
   uint32_t run_count = 0;      // runs so far (parity: which level word a run uses)
   uint32_t level_mask = 7;     // LDS levels the single-pass kernel is launched at (LjArgs::fast_level_mask)
@@ -3388,13 +3737,16 @@ LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   a.nk_pup = static_cast<int32_t*>(p->d_nk_pup.ptr);
   a.transfer = static_cast<uint16_t*>(p->d_transfer.ptr);
   a.fast_tabs = static_cast<const uint2*>(p->d_fast_tabs.ptr);
+  a.fast_tabs16 = static_cast<const uint16_t*>(p->d_fast_tabs16.ptr);
   a.lb = static_cast<unsigned long long*>(p->d_lb.ptr);
   a.k0w = static_cast<unsigned long long*>(p->d_k0w.ptr);
   a.k0e = static_cast<uint32_t*>(p->d_k0e.ptr);
+  a.k0p = static_cast<uint32_t*>(p->d_k0p.ptr);
+  a.pt_np = p->pt_np;
 #ifdef RSX_NO_K0_CHAIN // (experiments)
   a.k0_chain = 0u;
 #else
-  a.k0_chain = (p->any_fast_mt && p->d_k0e.ptr) ? 1u : 0u;
+  a.k0_chain = ((p->any_fast_mt || p->any_fast_pt) && p->d_k0e.ptr) ? 1u : 0u;
 #endif
   a.block_base0 = static_cast<uint32_t*>(p->d_block_base0.ptr);
   a.fast_uniform_nb = p->fast_uniform_nb;
@@ -3624,10 +3976,22 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
 #ifdef RSX_NO_FAST_MT
     two_alternating = false;
 #endif
-    S.fast = (direct_n && (J.n_tables == 1 || two_alternating) &&
+    // (round 6: ANY assignment of up to four tables to the components -- a table per
+    // component of a three-component scan, what DNG writers emit for linear images; A B C D,
+    // A B B, ... --: S.fast = 3, the kernel's table-per-phase instantiation, the phase
+    // (symbol index mod N) being part of every parse state.  The table word of a workgroup
+    // holds 16 bits of table base and 4 bits a phase.)
+    bool per_phase = J.n_tables >= 2 && !two_alternating && g.n_comp >= 2 && g.n_comp <= 4 &&
+                     g.period == g.n_comp && tables.size() + size_t(J.n_tables) < 0xFFFFu;
+    for (uint32_t ph = 0; ph < g.n_comp && per_phase; ++ph)
+      per_phase = g.comp_of_phase[ph] < J.n_tables && g.comp_of_phase[ph] < 16;
+#ifdef RSX_NO_FAST_PT
+    per_phase = false;
+#endif
+    S.fast = (direct_n && (J.n_tables == 1 || two_alternating || per_phase) &&
               (g.kind == 1 || (g.mcu_h == 1 && g.mcu_w == g.n_comp)) &&
-              g.row_samples >= g.n_comp)
-                 ? (J.n_tables == 1 ? 1 : 2)
+              g.row_samples >= g.n_comp && tables.size() < 0xFFFFu)
+                 ? (J.n_tables == 1 ? 1 : (two_alternating ? 2 : 3))
                  : 0;
     // Round 5: THREE interleaved components (MCU 3 x 1: linear DNG, LJpegDecompressor.cpp:
     // 102-105) with one table on the single-pass kernel's <3> instantiation -- the rotation
@@ -3638,10 +4002,26 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
 #ifndef RSX_NO_FAST3
     const bool fast3 = !direct_n && g.kind == 0 && !g.raw && !g.las && !g.pair &&
                        !g.no_vertical && g.n_comp == 3 && g.period == 3 && g.mcu_h == 1 &&
-                       g.mcu_w == 3 && J.n_tables == 1 && J.explicit_n == 0 &&
+                       g.mcu_w == 3 && (J.n_tables == 1 || per_phase) && J.explicit_n == 0 &&
                        g.row_samples >= 3 && g.row_samples % 3 == 0;
     if (fast3)
-      S.fast = 1;
+      S.fast = J.n_tables == 1 ? 1 : 3;
+    S.tab_period = 0;
+    if (S.fast == 3) {
+      // (the period of the assignment: A B A B over four components is two phases, not four --
+      // phases the tables cannot tell apart would never fall into step)
+      uint32_t tp = g.n_comp;
+      for (uint32_t q = 1; q < g.n_comp; ++q) {
+        bool ok = g.n_comp % q == 0;
+        for (uint32_t ph = 0; ph < g.n_comp && ok; ++ph)
+          ok = g.comp_of_phase[ph] == g.comp_of_phase[ph % q];
+        if (ok) {
+          tp = q;
+          break;
+        }
+      }
+      S.tab_period = uint8_t(tp);
+    }
 #endif
     if (S.fast) {
       // its workgroups stage all their samples in LDS at once: the allocation follows the
@@ -3754,7 +4134,10 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     if (S.fast) {
       p->any_fast = true;
       p->any_fast_mt |= S.fast == 2;
-      p->fast_present[S.fast == 2 ? 1 : 0][S.direct ? S.direct : g.n_comp] = true;
+      p->any_fast_pt |= S.fast == 3;
+      if (S.fast == 3)
+        p->pt_np = std::max(p->pt_np, uint32_t(S.tab_period));
+      p->fast_present[S.fast - 1][S.direct ? S.direct : g.n_comp] = true;
     } else {
       p->any_pipeline = true;
     }
@@ -3779,6 +4162,20 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     p->total_subseq += S.n_blocks * LJ_OWN;
     p->total_rows += S.rows;
     p->streams.push_back(S);
+  }
+  // A plan with table-per-phase streams runs K0's table-per-phase instantiation, which knows
+  // one-table streams and those: its two-table streams become table-per-phase streams too
+  // (A B over 2 or 4 components is a pattern like any other; the kernel's <N, 2> instantiations).
+  if (p->any_fast_pt && p->any_fast_mt) {
+    for (LjStreamDev& S : p->streams)
+      if (S.fast == 2) {
+        S.fast = 3;
+        S.tab_period = 2;
+        p->fast_present[2][S.direct ? S.direct : S.n_comp] = true;
+      }
+    p->any_fast_mt = false;
+    for (int n = 0; n < 5; ++n)
+      p->fast_present[1][n] = false;
   }
   if (!p->streams.empty()) {
     std::vector<uint32_t> block_stream(p->total_blocks);
@@ -3892,15 +4289,24 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         for (size_t i0 = 0; i0 < ns; ++i0) {
           const size_t si = p->fast_rotate ? (i0 + k) % ns : i0;
           if (k < p->streams[si].n_blocks)
-            // (.z: the stream's first table | the tables of even / odd symbols << 24 / 28)
+            // (.z: the stream's first table | its tables by phase: lf_table_word)
             order.push_back(make_uint4(p->streams[si].first_block + k, uint32_t(si),
-                                       p->streams[si].table_base |
-                                           (uint32_t(p->streams[si].tab_of_phase[0] & 15u) << 24) |
-                                           (uint32_t(p->streams[si].tab_of_phase[1] & 15u) << 28),
+                                       lf_table_word(p->streams[si].table_base,
+                                                     p->streams[si].tab_of_phase[0],
+                                                     p->streams[si].tab_of_phase[1],
+                                                     p->streams[si].tab_of_phase[2],
+                                                     p->streams[si].tab_of_phase[3]),
                                        p->streams[si].first_block));
         }
       if ((st = up(p->d_fast_order, order.data(), order.size() * sizeof(uint4))))
         return st;
+      if (p->any_fast_pt) {
+        std::vector<uint16_t> ft16(tl.size() * 1024);
+        for (size_t t = 0; t < tl.size(); ++t)
+          ljpeg_build_fast_table16(ft.data() + t * 1024, ft16.data() + t * 1024);
+        if ((st = up(p->d_fast_tabs16, ft16.data(), ft16.size() * sizeof(uint16_t))))
+          return st;
+      }
       if ((st = up(p->d_fast_tabs, ft.data(), ft.size() * sizeof(uint2))) ||
           (st = p->d_lb.ensure(size_t(p->total_blocks) * LF_LB_WORDS * 8)) ||
           (st = p->d_k0w.ensure(size_t(p->total_blocks + 1) * 8)) ||
@@ -3913,6 +4319,11 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       RSX_HIP_CHECK(ctx, hipMemset(p->d_tickets.ptr, 0, LF_TICKET_WORDS * 4));
       RSX_HIP_CHECK(ctx, hipMemset(p->d_k0w.ptr, 0, size_t(p->total_blocks + 1) * 8));
       RSX_HIP_CHECK(ctx, hipMemset(p->d_k0e.ptr, 0, size_t(p->total_blocks + 1) * 4));
+      if (p->any_fast_pt) {
+        if ((st = p->d_k0p.ensure(2 * size_t(p->total_blocks + 1) * 4)))
+          return st;
+        RSX_HIP_CHECK(ctx, hipMemset(p->d_k0p.ptr, 0, 2 * size_t(p->total_blocks + 1) * 4));
+      }
       RSX_HIP_CHECK(ctx, hipMemset(p->d_block_base0.ptr, 0, size_t(p->total_blocks) * 4));
       RSX_HIP_CHECK(ctx, hipMemset(p->d_fast_level.ptr, 0, 256));
 #ifdef RSX_EXPERIMENT
@@ -4447,17 +4858,23 @@ int ljpeg_plan_run_(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t
   p->results_clean_stream = s;
   // (plans laid out on the device: the instantiations whose wavefronts drop the scalar cache
   // first -- lj_fresh_scalars)
-  if (p->any_fast_mt && p->dev_layout)
-    hipLaunchKernelGGL((lj_unstuff_kernel<true, true>), dim3(p->total_blocks), dim3(LJ_T),
+  if (p->any_fast_pt && p->dev_layout)
+    hipLaunchKernelGGL((lj_unstuff_kernel<2, true>), dim3(p->total_blocks), dim3(LJ_T),
+                       lj_k0_lds_pt(p->pt_np), s, a);
+  else if (p->any_fast_pt)
+    hipLaunchKernelGGL((lj_unstuff_kernel<2, false>), dim3(p->total_blocks), dim3(LJ_T),
+                       lj_k0_lds_pt(p->pt_np), s, a);
+  else if (p->any_fast_mt && p->dev_layout)
+    hipLaunchKernelGGL((lj_unstuff_kernel<1, true>), dim3(p->total_blocks), dim3(LJ_T),
                        LJ_K0_LDS_MT, s, a);
   else if (p->any_fast_mt)
-    hipLaunchKernelGGL((lj_unstuff_kernel<true, false>), dim3(p->total_blocks), dim3(LJ_T),
+    hipLaunchKernelGGL((lj_unstuff_kernel<1, false>), dim3(p->total_blocks), dim3(LJ_T),
                        LJ_K0_LDS_MT, s, a);
   else if (p->dev_layout)
-    hipLaunchKernelGGL((lj_unstuff_kernel<false, true>), dim3(p->total_blocks), dim3(LJ_T),
+    hipLaunchKernelGGL((lj_unstuff_kernel<0, true>), dim3(p->total_blocks), dim3(LJ_T),
                        LJ_K0_LDS, s, a);
   else
-    hipLaunchKernelGGL((lj_unstuff_kernel<false, false>), dim3(p->total_blocks), dim3(LJ_T),
+    hipLaunchKernelGGL((lj_unstuff_kernel<0, false>), dim3(p->total_blocks), dim3(LJ_T),
                        LJ_K0_LDS, s, a);
   mark(p, "lj_unstuff_kernel");
   // the single-pass kernel for the streams it takes ...
@@ -4904,9 +5321,9 @@ int ljpeg_plan_results(LJpegPlan* p, hipStream_t s, bool ran, int32_t* job_statu
           continue;
         ++nz;
         const uint32_t own = uint32_t(w >> 32) & 0xFFFFu, tru = uint32_t(w >> 48);
-        unc += (own >> 7) & 1u;
+        unc += (own >> 8) & 1u;
         norec += !(tru & 0x8000u);
-        differ += (tru & 0x8000u) && (own & 0x7Fu) != (tru & 0x7Fu);
+        differ += (tru & 0x8000u) && (own & 0xFFu) != (tru & 0xFFu);
       }
       fprintf(stderr,
               "[rsx] K0 words: %zu workgroups, %zu uncertain, %zu entry estimate != true entry, "
@@ -4986,7 +5403,7 @@ void ljpeg_plan_destroy(LJpegPlan* p) {
     ljpeg_plan_destroy(p->nk_child);
   for (DeviceBuffer* b : {&p->d_nk, &p->d_nk_tables, &p->d_nk_rowpow, &p->d_nk_pup,
                           &p->d_transfer, &p->d_fast_tabs, &p->d_lb, &p->d_tickets, &p->d_dbg, &p->d_fast_z, &p->d_fast_level,
-                          &p->d_k0w, &p->d_k0e, &p->d_block_base0,
+                          &p->d_k0w, &p->d_k0e, &p->d_k0p, &p->d_block_base0,
                           &p->d_fast_order})
     b->release();
   p->d_marker_count.release();

@@ -141,7 +141,10 @@ struct LjStreamDev {
   uint8_t sync_lut11;  // its table has no search path past the LUT (an explicit 11-bit table):
                        // the synchronisation kernels must not use their 10-bit LUT for it
   uint8_t fast;        // != 0: the single-pass kernel decodes it (rsx_ljpeg_fast.hip): 1 one
-                       // table, 2 two tables alternating symbol by symbol
+                       // table, 2 two tables alternating symbol by symbol, 3 a table per phase
+  uint8_t tab_period;  // fast == 3: the period of tab_of_phase over the components (2, 3 or 4: A B A B
+                       // is 2) -- the phase of a parse state is the symbol index mod this
+  uint8_t pad_fast_[3];
   uint32_t rows;
   uint32_t row_samples;
   uint32_t first_row; // global stream-row index
@@ -237,6 +240,7 @@ struct LjArgs {
   uint16_t* transfer;        // [workgroup][512]: exit state per entry state (fallback path)
   // single-pass path (rsx_ljpeg_fast.hip)
   const uint2* fast_tabs;    // [table][1024]: the 10-bit LUT of the single-pass loops
+  const uint16_t* fast_tabs16; // [table][1024]: its 2-byte form (streams with a table per phase)
   unsigned long long* lb;    // [workgroup][LF_LB_WORDS]: look-back records (zeroed by K0)
   uint32_t* tickets;         // [3][4]: workgroup tickets of the single-pass launches by
                              // LDS level and components (zeroed by K0)
@@ -264,6 +268,10 @@ struct LjArgs {
   unsigned long long* k0w;   // [workgroup]: what K0 knows about its symbols (lj_unstuff_kernel):
                              // count | own estimate of its entry state, "uncertain" | true entry
   uint32_t* block_base0;     // [workgroup]: the symbol base the single-pass kernel worked from
+  uint32_t* k0p;             // [2][workgroup + 1]: K0's look-back over the workgroups' symbol counts mod N
+                             // (streams with a table per phase: the phase a workgroup starts in), one set
+                             // per run parity, each run clears the other one's
+  uint32_t pt_np;            // table-per-phase plans: the most phases a stream has (K0's LDS layout)
   uint32_t* k0e;             // [workgroup]: K0's hand-over of entry states between its workgroups:
                              // 0x8000 | run parity << 14 | the state the predecessor's chain ends in
   uint32_t k0_chain;         // != 0: K0 runs in block order and hands entry states over
@@ -379,12 +387,22 @@ void ljpeg_launch_direct(const LjArgs& a, const DirectLaunch& d, hipStream_t str
 // the single-pass path (rsx_ljpeg_fast.hip)
 struct FastLaunch {
   uint32_t total_blocks = 0;
-  bool present[2][5] = {}; // [two alternating tables][components]
+  bool present[3][5] = {}; // [one table / two alternating / a table per phase][components]
 };
 void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t stream,
                        KernelTimer* timer);
 // the 10-bit LUT of the single-pass loops for one table (1024 entries)
 void ljpeg_build_fast_table(const TabLds& t, uint2* out, uint32_t* zinfo);
+// ... and its 2-byte form (shift | total << 5 | SSSS << 11; bit 15: special)
+void ljpeg_build_fast_table16(const uint2* t8, uint16_t* out);
+// A workgroup's table word (fast_order[].z, or put together from the stream's record): the
+// stream's first table (16 bits) | its table of phase 0, 1, 2, 3 (4 bits each at 16, 20, 24, 28).
+// One table: phase 0's is 0.  Two alternating tables: phase 0 = the even symbols', 1 = the odd ones'.
+__host__ __device__ __forceinline__ uint32_t lf_table_word(uint32_t base, uint32_t t0, uint32_t t1,
+                                                           uint32_t t2, uint32_t t3) {
+  return (base & 0xFFFFu) | ((t0 & 15u) << 16) | ((t1 & 15u) << 20) | ((t2 & 15u) << 24) |
+         ((t3 & 15u) << 28);
+}
 uint32_t ljpeg_fast_lds_for(uint64_t samples_per_workgroup);
 uint32_t ljpeg_fast_stage_cap(uint32_t lds_bytes);
 constexpr int LF_TICKET_WORDS = 32; // [2][3][4] tickets: [two tables][LDS level][components]

@@ -270,7 +270,7 @@ __device__ __forceinline__ constexpr int lb_wc(int k) { return 7 + k; }
 // the entry state, bit 7: count uncertain (16) | true entry state, bit 15: on record (16).
 __device__ __forceinline__ bool lf_k0_flagged(u64 w) {
   const uint32_t own = uint32_t(w >> 32) & 0xFFFFu, tru = uint32_t(w >> 48);
-  return w != 0ull && (own != (tru & 0x7Fu) || !(tru & 0x8000u));
+  return w != 0ull && (own != (tru & 0xFFu) || !(tru & 0x8000u));
 }
 
 // ---------------------------------------------------------------------------
@@ -285,6 +285,7 @@ struct FastState {
   uint32_t n;    // symbols decoded
   uint32_t acc[4];
   uint32_t ev;   // running sum after the last even-numbered symbol
+  uint32_t spec; // (per-phase tables) OR of the entries read: bit 15 = a special one among them
 };
 
 template <int N, int K>
@@ -340,17 +341,53 @@ __device__ __forceinline__ void lf_step_mt(FastState& s, uint32_t vbase, uint32_
   s.n += 1;
 }
 
+// A table PER COMPONENT (round 6; the kernel's TM == 2 instantiations, LjStreamDev::fast == 3):
+// what DNG writers emit for linear (3-component) images -- one DHT per component,
+// AbstractLJpegDecoder.cpp:181-291, LJpegDecompressor.cpp:102-113 -- and any other pattern of
+// up to four tables over the N components of an MCU (A B C, A B B, A B C D, A A B B ...).  The
+// table of a symbol is tab_of_phase[index mod N]: the phase is part of every parse state
+// (offset | phase << 6), as the table bit is for two alternating tables.  N 10-bit LUTs of
+// TWO-byte entries in the 8 KB the one 8-byte table takes (2 KB each):
+//   bits 0..4 shift (32 - total) | bits 5..10 total (32 * total at bit 0) | bits 11..15 SSSS
+//   special: bit 15 set, total 63 (the lane strides on to the end of its slot; the OR of the
+//   entries a lane has read says so afterwards)
+// 2^SSSS - 1 comes out of the entry with a shift and v_bfm_b32: two VALU instructions a symbol
+// more than the two-table step.  Step K of a lane is its K-th symbol (the steps are unrolled),
+// so the LUT's base is a static choice among N registers that the lane rotates by its entry
+// state's phase once.
+constexpr uint32_t LF_PT_SPECIAL = 0x8000u | (63u << 5);
+template <int N, int C>
+__device__ __forceinline__ void lf_step_pt(FastState& s, uint32_t vbase, uint32_t lut) {
+  const uint32_t ad = vbase + (s.Pn & ~1023u);
+  const uint32_t d1 = *(lds_u32p)(ad), d0 = *(lds_u32p)(ad + 4u * LJ_T);
+  const uint32_t w = __builtin_amdgcn_alignbit(d0, d1, s.Pn >> 5);
+  uint32_t ea;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(ea) : "v"(w >> 21), "s"(0x7FEu), "v"(lut));
+  const uint32_t e = *(const __attribute__((address_space(3))) uint16_t*)(ea);
+  uint32_t all;
+  asm("v_bfm_b32 %0, %1, 0" : "=v"(all) : "v"(e >> 11));
+  const uint32_t v = (w >> (e & 31u)) & all;
+  const uint32_t u = all - v;
+  const uint32_t m = uint32_t(int32_t(u - v) >> 31);
+  s.acc[C] += (all & m) - u;
+  s.Pn -= (e & 0x7E0u);
+  s.spec |= e;
+  s.n += 1;
+}
+
 // (KB: symbols of the lane in front of this group of eight -- the component of step K is
 // (KB + K) mod N, which is K mod N for 1, 2 and 4 components and not for 3)
-template <int N, int K, int KEND, bool MT = false, int KB = 0>
+template <int N, int K, int KEND, int TM = 0, int KB = 0>
 struct LfChain {
   static __device__ __forceinline__ void run(FastState& s, uint32_t vbase, uint32_t pend,
                                              uint32_t (&R)[LF_NR], int qbase, uint32_t lut0,
-                                             uint32_t lut1) {
+                                             uint32_t lut1, uint32_t lut2, uint32_t lut3) {
     constexpr int C = (KB + K) % N;
     if (s.Pn > pend) {
-      if constexpr (MT)
+      if constexpr (TM == 1)
         lf_step_mt<N, K>(s, vbase, lut0, lut1);
+      else if constexpr (TM == 2)
+        lf_step_pt<N, C>(s, vbase, C == 0 ? lut0 : (C == 1 ? lut1 : (C == 2 ? lut2 : lut3)));
       else
         lf_step<N, C>(s, vbase);
       if ((K & 1) == 0)
@@ -358,19 +395,19 @@ struct LfChain {
       else
         R[qbase + (K >> 1)] = pack16(s.ev, s.acc[C]);
       if constexpr (K + 1 < KEND)
-        LfChain<N, K + 1, KEND, MT, KB>::run(s, vbase, pend, R, qbase, lut0, lut1);
+        LfChain<N, K + 1, KEND, TM, KB>::run(s, vbase, pend, R, qbase, lut0, lut1, lut2, lut3);
     }
   }
 };
 
-template <int N, int G, bool MT = false>
+template <int N, int G, int TM = 0>
 __device__ __forceinline__ void lf_groups(FastState& s, uint32_t vbase, uint32_t pend,
                                           uint32_t (&R)[LF_NR], uint32_t lut0 = 0,
-                                          uint32_t lut1 = 0) {
+                                          uint32_t lut1 = 0, uint32_t lut2 = 0, uint32_t lut3 = 0) {
   if (__any(s.Pn > pend)) {
-    LfChain<N, 0, 8, MT, 8 * G>::run(s, vbase, pend, R, 4 * G, lut0, lut1);
+    LfChain<N, 0, 8, TM, 8 * G>::run(s, vbase, pend, R, 4 * G, lut0, lut1, lut2, lut3);
     if constexpr (G + 1 < LF_MAXSYM / 8)
-      lf_groups<N, G + 1, MT>(s, vbase, pend, R, lut0, lut1);
+      lf_groups<N, G + 1, TM>(s, vbase, pend, R, lut0, lut1, lut2, lut3);
   }
 }
 
@@ -416,13 +453,17 @@ __device__ __forceinline__ uint32_t lf_slow_entry(uint32_t w, const TabLds& tb) 
 // codes) for the others; the running sum of every symbol goes into the lane's
 // side-buffer entry.  (The first version ran the general loop for every symbol: 14-50 us
 // per round, and every workgroup behind the re-decoding one waits for its record.)
-template <int N, bool MT>
-__device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds& tb,
-                                            const TabLds& tb_odd, int col,
-                                            uint32_t start, uint32_t end_bits,
+// x mod P for the phase periods there are (a table per phase: P = 2, 3 or 4, wave-uniform)
+__device__ __forceinline__ uint32_t lf_pmod(uint32_t x, uint32_t P) {
+  return P == 3u ? x % 3u : (x & (P - 1u));
+}
+template <int N, int TM>
+__device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds* tabs0, uint32_t tabsel,
+                                            uint32_t P, int col, uint32_t start, uint32_t end_bits,
                                             uint32_t side_addr, bool enabled,
                                             uint32_t& exit, uint32_t& count, uint2& sums,
                                             bool& overflow) {
+  constexpr bool MT = TM == 1, PT = TM == 2;
   const uint32_t vbase = lds_addr(&F.B[(LF_BW - 1) * LJ_T + col]);
   const uint32_t pend = uint32_t(-32) - 32u * end_bits;
   uint32_t Pn = uint32_t(-32) - 32u * (start & ST_OFF_MASK);
@@ -430,7 +471,9 @@ __device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds& tb,
   if (!ok || !enabled)
     Pn = pend; // no steps
   uint32_t n = 0, a0 = 0, a1 = 0, ph3 = 0;
-  uint32_t odd = MT ? ((start >> ST_PHASE_SHIFT) & 1u) : 0u; // (two tables: which one is next)
+  // (several tables: which one is next -- the table bit of two alternating tables, the phase
+  // 0 .. N - 1 of per-component tables; tabsel: the stream's table of phase k in bits 4k..4k+3)
+  uint32_t odd = TM != 0 ? ((start >> ST_PHASE_SHIFT) & (MT ? 1u : 3u)) : 0u;
   while (Pn > pend) {
     const uint32_t ad = vbase + (Pn & ~1023u);
     const uint32_t d1 = *(lds_u32p)(ad), d0 = *(lds_u32p)(ad + 4u * LJ_T);
@@ -439,12 +482,16 @@ __device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds& tb,
     if (MT) {
       const uint32_t e4 = *(lds_u32p)(((w >> 20) & 0xFFCu) | (odd ? 4096u : 0u));
       e = lf_u32x2{e4 == LF_MT_SPECIAL ? 0x80000000u : (e4 & 0x7FFu), e4 >> 16};
+    } else if (PT) {
+      const uint32_t e2 =
+          *(const __attribute__((address_space(3))) uint16_t*)(((w >> 21) & 0x7FEu) | (odd << 11));
+      e = lf_u32x2{(e2 & 0x8000u) ? 0x80000000u : (e2 & 0x7FFu), (1u << (e2 >> 11)) - 1u};
     } else {
       e = *(lds_u2p)((w >> 19) & 0x1FF8u);
     }
     uint32_t d, tot;
     if (e.x & 0x80000000u) {
-      const uint32_t e16 = lf_slow_entry(w, odd ? tb_odd : tb);
+      const uint32_t e16 = lf_slow_entry(w, tabs0[(tabsel >> (4u * odd)) & 15u]);
       if (e16 == 0u) {
         ok = false;
         break;
@@ -491,6 +538,8 @@ __device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds& tb,
     ++n;
     if (MT)
       odd ^= 1u;
+    if (PT)
+      odd = odd + 1u == P ? 0u : odd + 1u;
   }
   if (!enabled)
     return;
@@ -731,8 +780,9 @@ __device__ __forceinline__ bool lb1_walk(const LjArgs& a, const FastLds& F, uint
 // store (measured: 16 us of a workgroup's 55 in the copy-out alone).
 struct FastStream {
   uint32_t fast_n; // fast ? direct : 0
-  uint32_t mt;     // two tables alternating symbol by symbol: tab_even, tab_odd
-  uint32_t tab_even, tab_odd;
+  uint32_t tm;     // 0 one table, 1 two tables alternating symbol by symbol, 2 a table per phase
+  uint32_t tabsel; // the stream's table of phase k (symbol index mod N) in bits 4k .. 4k + 3
+  uint32_t tp;     // tm == 2: the period of that assignment (2, 3, 4): a state's phase is mod this
   uint32_t first_block, first_subseq, table_base, start_bit, n_blocks;
   uint32_t RS, kind, keep, out_x, out_y, pitch, n_strips, strip_base;
   uint64_t needed, img_offset;
@@ -746,9 +796,12 @@ __device__ __forceinline__ FastStream lf_stream(const LjStreamDev& S) {
   // (3 components, round 5: not a stream of the fused multi-kernel path -- direct == 0 --, so
   // the number of components says which instantiation takes it)
   f.fast_n = uni(S.fast ? (S.direct ? uint32_t(S.direct) : S.n_comp) : 0u);
-  f.mt = uni(S.fast == 2 ? 1u : 0u);
-  f.tab_even = uni(f.mt ? uint32_t(S.tab_of_phase[0]) : 0u);
-  f.tab_odd = uni(f.mt ? uint32_t(S.tab_of_phase[1]) : 0u);
+  f.tm = uni(S.fast >= 2 ? uint32_t(S.fast) - 1u : 0u);
+  f.tabsel = uni(f.tm ? (uint32_t(S.tab_of_phase[0] & 15u) | (uint32_t(S.tab_of_phase[1] & 15u) << 4) |
+                         (uint32_t(S.tab_of_phase[2] & 15u) << 8) |
+                         (uint32_t(S.tab_of_phase[3] & 15u) << 12))
+                      : 0u);
+  f.tp = uni(f.tm == 2u ? uint32_t(S.tab_period) : 1u);
   f.first_block = uni(S.first_block);
   f.first_subseq = uni(S.first_subseq);
   f.table_base = uni(S.table_base);
@@ -1020,12 +1073,14 @@ __device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad
 // MODE 0: the steady state.  1 (PROBE): a plan's first run, when every LDS level is launched
 // and one works.  2: plans laid out on the device (restart intervals) -- PROBE's early look at
 // the level, and every wavefront drops the scalar cache before its first load (lj_fresh_scalars)
-template <int N, bool MT, int MODE>
+template <int N, int TM, int MODE>
 __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds_bytes,
                                                           uint32_t level) {
   constexpr bool PROBE = MODE >= 1, INV = MODE == 2;
+  constexpr bool MT = TM == 1, PT = TM == 2; // two alternating tables / a table per phase
   constexpr uint32_t TICKET0 = (MT ? 12u : 0u) + (N == 4 ? 2u : (N == 3 ? 3u : uint32_t(N) - 1u));
-  constexpr uint32_t SMASK = MT ? 0x7Fu : ST_OFF_MASK; // offset (| table of the next symbol)
+  // offset (| table bit of the next symbol | its phase, two bits)
+  constexpr uint32_t SMASK = MT ? 0x7Fu : (PT ? 0xFFu : ST_OFF_MASK);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const FastLds F = carve_fast(smem, lds_bytes);
   const int j = threadIdx.x, lane = j & 63, wv = j >> 6;
@@ -1073,7 +1128,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     fb_now = s * nb;
     // (the stream's tables: asked for now, looked at behind the image loads)
     tbv = a.streams[s].table_base;
-    tpv = uint32_t(a.streams[s].tab_of_phase[0]) | (uint32_t(a.streams[s].tab_of_phase[1]) << 8);
+    tpv = *reinterpret_cast<const uint32_t*>(a.streams[s].tab_of_phase); // (phases 0..3, a byte each)
   } else {
     const uint4 bs = a.fast_order[t_blk];
     b = uni(bs.x);
@@ -1162,22 +1217,44 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
 #ifndef RSX_LF_TICKETS
   if (uniform_plan) {
     const uint32_t tb = uni(tbv), tp = uni(tpv);
-    tz_now = tb | ((tp & 15u) << 24) | (((tp >> 8) & 15u) << 28);
+    tz_now = lf_table_word(tb, tp & 15u, (tp >> 8) & 15u, (tp >> 16) & 15u, (tp >> 24) & 15u);
   }
 #endif
-  const uint32_t table_base = tz_now & 0xFFFFFFu;
+  const uint32_t table_base = tz_now & 0xFFFFu;
   uint4 lut_now[MT ? 4 : 2];
   {
-    const uint32_t t_even = MT ? ((tz_now >> 24) & 15u) : 0u;
-    const uint4* src =
-        reinterpret_cast<const uint4*>(a.fast_tabs + size_t(table_base + t_even) * 1024);
-    lut_now[0] = src[j];
-    lut_now[1] = src[j + LJ_T];
-    if constexpr (MT) {
-      const uint4* srb =
-          reinterpret_cast<const uint4*>(a.fast_tabs + size_t(table_base + (tz_now >> 28)) * 1024);
-      lut_now[2] = srb[j];
-      lut_now[3] = srb[j + LJ_T];
+    if constexpr (PT) {
+      // (a table per phase: the 2-byte form of each phase's 10-bit LUT, 8 bytes a lane and table,
+      // built on the host -- ljpeg_build_fast_table16; phases beyond N ask for phase 0's again)
+      const uint2* t16 = reinterpret_cast<const uint2*>(a.fast_tabs16);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t t = (tz_now >> (16 + 4 * (k < N ? k : 0))) & 15u;
+        const uint2 v = t16[size_t(table_base + t) * 256 + uint32_t(j)];
+        if (k < 2) {
+          lut_now[0].x = k == 0 ? v.x : lut_now[0].x;
+          lut_now[0].y = k == 0 ? v.y : lut_now[0].y;
+          lut_now[0].z = k == 1 ? v.x : lut_now[0].z;
+          lut_now[0].w = k == 1 ? v.y : lut_now[0].w;
+        } else {
+          lut_now[1].x = k == 2 ? v.x : lut_now[1].x;
+          lut_now[1].y = k == 2 ? v.y : lut_now[1].y;
+          lut_now[1].z = k == 3 ? v.x : lut_now[1].z;
+          lut_now[1].w = k == 3 ? v.y : lut_now[1].w;
+        }
+      }
+    } else {
+      const uint32_t t_even = MT ? ((tz_now >> 16) & 15u) : 0u;
+      const uint4* src =
+          reinterpret_cast<const uint4*>(a.fast_tabs + size_t(table_base + t_even) * 1024);
+      lut_now[0] = src[j];
+      lut_now[1] = src[j + LJ_T];
+      if constexpr (MT) {
+        const uint4* srb = reinterpret_cast<const uint4*>(
+            a.fast_tabs + size_t(table_base + ((tz_now >> 20) & 15u)) * 1024);
+        lut_now[2] = srb[j];
+        lut_now[3] = srb[j + LJ_T];
+      }
     }
   }
   const FastStream S = lf_stream(a.streams[s]);
@@ -1198,7 +1275,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   if (uni(chosen_now) != level)
     return; // this run's workgroups need another LDS level: that launch does the work
 #endif
-  if (int(S.fast_n) != N || (S.mt != 0u) != MT)
+  if (int(S.fast_n) != N || int(S.tm) != TM)
     return; // (workgroup-uniform)
   const uint32_t lb = b - S.first_block;
   // A stream that some workgroup has given up on (periodic data, an invalid code, ...) is
@@ -1236,6 +1313,15 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       dst[512 * t + j] = make_uint2(e4(lo.x, lo.y), e4(lo.z, lo.w));
       dst[512 * t + 256 + j] = make_uint2(e4(hi.x, hi.y), e4(hi.z, hi.w));
     }
+  } else if constexpr (PT) {
+    // (phase k's table at LDS address 2048 k: entries 4j .. 4j + 3 of each)
+    uint2* dst = reinterpret_cast<uint2*>(smem + LF_OFF_LUT);
+    dst[j] = make_uint2(lut_now[0].x, lut_now[0].y);
+    dst[256 + j] = make_uint2(lut_now[0].z, lut_now[0].w);
+    if (N >= 3)
+      dst[512 + j] = make_uint2(lut_now[1].x, lut_now[1].y);
+    if (N >= 4)
+      dst[768 + j] = make_uint2(lut_now[1].z, lut_now[1].w);
   } else {
     uint4* dst = reinterpret_cast<uint4*>(smem + LF_OFF_LUT);
     dst[j] = lut_now[0];
@@ -1357,15 +1443,25 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   fs.n = 0;
   fs.acc[0] = fs.acc[1] = fs.acc[2] = fs.acc[3] = 0;
   fs.ev = 0;
+  fs.spec = 0;
   const uint32_t pend = uint32_t(-32) - 32u * own_bits;
   if (j == 0)
     fs.Pn = pend; // (slot 0 belongs to the previous workgroup: nothing to decode)
   if (LF_ABLATE & 16u)
     fs.Pn = pend;
+  // (per-phase tables: the phase of the lane's first symbol, 0 .. N - 1)
+  const uint32_t ph0 = PT ? ((start >> ST_PHASE_SHIFT) & 3u) : 0u;
   if constexpr (MT) {
     // (the LUT of the lane's even-numbered symbols, of its odd-numbered ones)
     const uint32_t lut0 = (start & 64u) ? 4096u : 0u;
-    lf_groups<N, 0, true>(fs, vbase_own, pend, R, lut0, lut0 ^ 4096u);
+    lf_groups<N, 0, 1>(fs, vbase_own, pend, R, lut0, lut0 ^ 4096u);
+  } else if constexpr (PT) {
+    // (the LUT of the lane's symbols k mod N == 0, 1, 2, 3: phase (ph0 + k) mod N, 2 KB each)
+    uint32_t lb_[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; ++k)
+      lb_[k] = lf_pmod(ph0 + k, S.tp) << 11;
+    lf_groups<N, 0, 2>(fs, vbase_own, pend, R, lb_[0], lb_[1], lb_[2], lb_[3]);
   } else {
     lf_groups<N, 0>(fs, vbase_own, pend, R);
   }
@@ -1386,12 +1482,16 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   bool need_redo = false;
   {
     // (two tables: a special entry sends the position far past the slot's end, lf_step_mt)
+    // (per-phase tables: a special entry has bit 15, and the lane has read one if the OR of
+    // its entries has)
     const bool special = MT ? (fs.Pn <= pend && ((pend - fs.Pn) >> 5) >= 64u)
-                            : !(fs.Pn & 0x80000000u);
+                            : (PT ? (fs.spec & 0x8000u) != 0u : !(fs.Pn & 0x80000000u));
     const bool over = !special && fs.Pn > pend; // more than LF_MAXSYM symbols
     uint32_t ex = special ? ST_ERR : ((pend - fs.Pn) >> 5);
     if (MT && !special) // the table the NEXT symbol takes
       ex |= (((start >> ST_PHASE_SHIFT) ^ fs.n) & 1u) << ST_PHASE_SHIFT;
+    if (PT && !special) // ... its phase
+      ex |= lf_pmod(ph0 + fs.n, S.tp) << ST_PHASE_SHIFT;
     if (over) {
       ex = ST_ERR;
       atomicMin(&F.misc[M_UNRES], uint32_t(j));
@@ -1506,9 +1606,8 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
         w = rec_st(F.rec[idx - 1]);
         if (w & ST_ERR) // (listed for its own sake: from the state it started from)
           w = rec_su(F.rec[idx]) & SMASK;
-        lf_redecode<N, MT>(F, a.tables[S.table_base + S.tab_even],
-                           a.tables[S.table_base + S.tab_odd], int(idx), w, F.ob[idx],
-                       lds_addr(F.side) + (le >> 8) * LF_SIDE_STRIDE, mine, e, c, sums, ovf);
+        lf_redecode<N, TM>(F, a.tables + S.table_base, S.tabsel, S.tp, int(idx), w, F.ob[idx],
+                           lds_addr(F.side) + (le >> 8) * LF_SIDE_STRIDE, mine, e, c, sums, ovf);
       }
       lds_barrier(); // every read of the records precedes the updates
       if (mine) {
@@ -1695,12 +1794,14 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     if (needed >= 1 && needed - 1 >= i0 && needed - 1 < uint64_t(i0) + my_cnt && j >= 1) {
       const uint32_t target = uint32_t(needed - 1 - i0);
       uint32_t p2 = my_start & ST_OFF_MASK;
-      uint32_t odd = MT ? ((my_start >> ST_PHASE_SHIFT) & 1u) : 0u;
+      uint32_t odd = TM != 0 ? ((my_start >> ST_PHASE_SHIFT) & (MT ? 1u : 3u)) : 0u;
       for (uint32_t t = 0; t < target; ++t) {
         const uint32_t w = lj_window<LF_BW>(F.B, j, p2 + 1u);
-        p2 += lf_slow_entry(w, a.tables[S.table_base + (odd ? S.tab_odd : S.tab_even)]) >> 10;
+        p2 += lf_slow_entry(w, a.tables[S.table_base + ((S.tabsel >> (4u * odd)) & 15u)]) >> 10;
         if (MT)
           odd ^= 1u;
+        if (PT)
+          odd = odd + 1u == S.tp ? 0u : odd + 1u;
       }
       a.results[s].last_slot = lb * LJ_OWN + uint32_t(j - 1);
       a.results[s].last_pos = p2;
@@ -1938,22 +2039,22 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   LF_STAMP(15);
 }
 
-template <int N, bool MT>
+template <int N, int TM>
 void launch_fast_one(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
-  if (!f.present[MT ? 1 : 0][N])
+  if (!f.present[TM][N])
     return;
   const bool probe = (a.fast_level_mask & (a.fast_level_mask - 1u)) != 0u; // (more than one level)
   for (uint32_t lv = 0; lv < 3; ++lv) {
     if (!((a.fast_level_mask >> lv) & 1u))
       continue;
     if (a.dev_layout)
-      hipLaunchKernelGGL((lj_fast_kernel<N, MT, 2>), dim3(f.total_blocks), dim3(LJ_T),
+      hipLaunchKernelGGL((lj_fast_kernel<N, TM, 2>), dim3(f.total_blocks), dim3(LJ_T),
                          a.fast_lds_lv[lv], s, a, a.fast_lds_lv[lv], lv);
     else if (probe)
-      hipLaunchKernelGGL((lj_fast_kernel<N, MT, 1>), dim3(f.total_blocks), dim3(LJ_T),
+      hipLaunchKernelGGL((lj_fast_kernel<N, TM, 1>), dim3(f.total_blocks), dim3(LJ_T),
                          a.fast_lds_lv[lv], s, a, a.fast_lds_lv[lv], lv);
     else
-      hipLaunchKernelGGL((lj_fast_kernel<N, MT, 0>), dim3(f.total_blocks), dim3(LJ_T),
+      hipLaunchKernelGGL((lj_fast_kernel<N, TM, 0>), dim3(f.total_blocks), dim3(LJ_T),
                          a.fast_lds_lv[lv], s, a, a.fast_lds_lv[lv], lv);
     if (timer)
       timer->mark(lv == 0 ? "lj_fast_kernel" : (lv == 1 ? "lj_fast_kernel(3/CU)" : "lj_fast_kernel(2/CU)"));
@@ -1983,12 +2084,15 @@ uint32_t ljpeg_fast_stage_cap(uint32_t lds_bytes) {
 }
 
 void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
-  launch_fast_one<1, false>(a, f, s, timer);
-  launch_fast_one<2, false>(a, f, s, timer);
-  launch_fast_one<3, false>(a, f, s, timer);
-  launch_fast_one<4, false>(a, f, s, timer);
-  launch_fast_one<2, true>(a, f, s, timer);
-  launch_fast_one<4, true>(a, f, s, timer);
+  launch_fast_one<1, 0>(a, f, s, timer);
+  launch_fast_one<2, 0>(a, f, s, timer);
+  launch_fast_one<3, 0>(a, f, s, timer);
+  launch_fast_one<4, 0>(a, f, s, timer);
+  launch_fast_one<2, 1>(a, f, s, timer);
+  launch_fast_one<4, 1>(a, f, s, timer);
+  launch_fast_one<2, 2>(a, f, s, timer);
+  launch_fast_one<3, 2>(a, f, s, timer);
+  launch_fast_one<4, 2>(a, f, s, timer);
 }
 
 // The LUT of the fast loops from the 11-bit table of the general ones.
@@ -2015,6 +2119,19 @@ void ljpeg_build_fast_table(const TabLds& t, uint2* out, uint32_t* zinfo) {
       if (adv > 63u)
         adv = 63u;
       out[i] = make_uint2(0x80000000u | (adv << 5), 0u);
+    }
+  }
+}
+
+// The 2-byte form of the same table for streams with a table per phase (lf_step_pt).
+void ljpeg_build_fast_table16(const uint2* t8, uint16_t* out) {
+  for (uint32_t i = 0; i < 1024; ++i) {
+    const uint2 e = t8[i];
+    if (e.x & 0x80000000u) {
+      out[i] = uint16_t(LF_PT_SPECIAL);
+    } else {
+      const uint32_t ssss = uint32_t(__builtin_popcount(e.y)); // (e.y = 2^SSSS - 1, SSSS <= 15)
+      out[i] = uint16_t((e.x & 0x7FFu) | (ssss << 11));
     }
   }
 }

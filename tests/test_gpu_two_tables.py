@@ -90,9 +90,10 @@ def test_table_order_b_a(gpu, oracle):
     assert any("lj_fast_kernel" in x for x in names), names
 
 
-def test_not_alternating_goes_through_the_pipeline(gpu, oracle):
-    """A A A B over four components is not the A B A B the kernel knows: the multi-kernel
-    pipeline decodes it, bit-exactly."""
+def test_not_alternating_takes_the_table_per_phase_instantiation(gpu, oracle):
+    """A A A B over four components is not the A B A B of the two-table instantiation: until
+    round 5 the multi-kernel pipeline decoded it; since round 6 it is a table-per-phase stream
+    (tests/test_gpu_per_component_tables.py) of the single-pass kernel."""
     rng = np.random.default_rng(6)
     W, H = 2048, 256
     d, data, tile_px, _ = C.make_ljpeg_case(
@@ -100,7 +101,8 @@ def test_not_alternating_goes_through_the_pipeline(gpu, oracle):
         table_index=[0, 0, 0, 1])
     plan, inp, out = _run(gpu, oracle, d, data, W, H)
     names = _kernel_names(plan, inp, out)
-    assert not any("lj_fast_kernel" in x for x in names), names
+    assert any("lj_fast_kernel" in x for x in names), names
+    assert not any("sync" in x for x in names), names
 
 
 @pytest.mark.parametrize("seed", range(4))
@@ -320,7 +322,8 @@ def _tile_job(d, data, off, W, H, op):
 def test_mixed_plan_one_table_two_tables_and_a_pipeline_stream(gpu, oracle):
     """One plan, three kinds of streams side by side: a one-table tile, a two-table tile (K0's
     two-table instantiation and its hand-over then serve the one-table stream as well) and a
-    3-component tile, which the multi-kernel pipeline decodes."""
+    tile with a 2 x 2 MCU, which the multi-kernel pipeline decodes.  (Until round 5 the third was
+    a 3-component tile with tables A B A: a table-per-phase stream of the single-pass kernel now.)"""
     import bench_ljpeg as B
     from oracle_lib import HostImage
     rng = np.random.default_rng(12)
@@ -331,7 +334,7 @@ def test_mixed_plan_one_table_two_tables_and_a_pipeline_stream(gpu, oracle):
     cases = [
         dict(mcu=(2, 1), tables=(C.NIKON,), table_index=[0, 0]),
         dict(mcu=(2, 1), tables=(C.NIKON, C.ALT), table_index=[0, 1]),
-        dict(mcu=(3, 1), tables=(C.NIKON, C.ALT), table_index=[0, 1, 0]),
+        dict(mcu=(2, 2), tables=(C.NIKON, C.ALT), table_index=[0, 1, 0, 1]),
     ]
     jobs, blobs, off = [], [], 0
     for k, kw in enumerate(cases):
