@@ -769,7 +769,13 @@ __device__ __forceinline__ uint32_t lj_guess_parse_mt(uint32_t col4, uint32_t en
 constexpr uint32_t LJ_K0_PT10_OFF = (LJ_K0_LDS + 15u) & ~15u;      // NP x 1024 B
 __host__ __device__ constexpr uint32_t lj_k0_pt8_off(uint32_t np) { return LJ_K0_PT10_OFF + np * 1024u; } // NP x 256 B
 __host__ __device__ constexpr uint32_t lj_k0_ptx_off(uint32_t np) { return lj_k0_pt8_off(np) + np * 256u; } // 8 words: the phase pass
-__host__ __device__ constexpr uint32_t lj_k0_lds_pt(uint32_t np) { return lj_k0_ptx_off(np) + 32u; }
+// ... and the words of its rounds: phases fall into step more slowly than offsets (a parse in the
+// wrong phase meets the true one at the same bit AND in the same phase once in N times), so a
+// table-per-phase stream's chain gets twelve rounds where the others get six -- with twelve every
+// workgroup of tests/test_per_phase_model.py's streams settles, with six half of those with four tables
+constexpr uint32_t LJ_GUESS_ROUNDS_PT = 12;
+__host__ __device__ constexpr uint32_t lj_k0_ptr_off(uint32_t np) { return lj_k0_ptx_off(np) + 32u; } // 2 words a round
+__host__ __device__ constexpr uint32_t lj_k0_lds_pt(uint32_t np) { return lj_k0_ptr_off(np) + 8u * LJ_GUESS_ROUNDS_PT; }
 // K0's look-back over symbol counts mod N (LjArgs::k0p): a workgroup's word is its own total
 // (AGG) as soon as its chain has settled, then the phase it ENDS in (INC) once it knows where it starts
 constexpr uint32_t K0P_AGG = 1u << 30, K0P_INC = 1u << 31;
@@ -1123,6 +1129,11 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     }
     if (j < 4 + 2 * int(LJ_GUESS_ROUNDS))
       nlist[j] = 0;
+    // (the rounds' words: [2 r] list length of round r, [2 r + 1] "an exit moved in round r")
+    uint32_t* const rw = KM == 2 ? reinterpret_cast<uint32_t*>(smem + lj_k0_ptr_off(a.pt_np)) : nlist + 4;
+    const uint32_t max_rounds = (KM == 2 && pt) ? LJ_GUESS_ROUNDS_PT : LJ_GUESS_ROUNDS;
+    if (KM == 2 && j < 2 * int(LJ_GUESS_ROUNDS_PT))
+      rw[j] = 0;
     if (j == 0)
       *est = 0;
     lds_barrier();
@@ -1277,12 +1288,12 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
     // (cmp: the bits of a state that must agree -- all of them, or the offset alone: the first
     // rounds of a table-per-phase stream, see "the phase pass" below)
     auto run_rounds = [&](uint32_t cmp) -> bool {
-      for (uint32_t round = 0; round < LJ_GUESS_ROUNDS && gs >= 3u; ++round) {
+      for (uint32_t round = 0; round < max_rounds && gs >= 3u; ++round) {
         const uint32_t x = j >= 1 ? uint32_t(EB[j - 1]) : 0u;
         if (!constant && exists && j >= 1 && ((x ^ uint32_t(EU[j])) & cmp) != 0u)
-          glist[atomicAdd(&nlist[4 + 2 * round], 1u)] = uint16_t(j);
+          glist[atomicAdd(&rw[2 * round], 1u)] = uint16_t(j);
         lds_barrier();
-        const uint32_t nth = nlist[4 + 2 * round];
+        const uint32_t nth = rw[2 * round];
         if (nth == 0)
           return true;
         if (j < 64) {
@@ -1301,10 +1312,10 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
             ECNT[c] = pack_cnt(n);
           }
           if (changed)
-            nlist[5 + 2 * round] = 1u;
+            rw[2 * round + 1] = 1u;
         }
         lds_barrier();
-        if (nlist[5 + 2 * round] == 0u) // (no exit moved: every successor's entry still stands)
+        if (rw[2 * round + 1] == 0u) // (no exit moved: every successor's entry still stands)
           return true;
       }
       return false;
@@ -1441,8 +1452,8 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
         if (relabel && PX[6] == 0u)
           settled = true; // (every slot parsed from its predecessor's exit, phase and all)
         if (PX[6] != 0u) { // (the published sums may be off now: nothing downstream trusts them blindly)
-          if (j >= 3 && j < 4 + 2 * int(LJ_GUESS_ROUNDS))
-            nlist[j] = 0u;
+          if (j < 2 * int(LJ_GUESS_ROUNDS_PT))
+            rw[j] = 0u;
           lds_barrier();
           settled = run_rounds(smask);
           if (j == 0)
@@ -1508,6 +1519,8 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
         lds_barrier(); // (everybody has read the word)
         if (j >= 3 && j < 4 + 2 * int(LJ_GUESS_ROUNDS))
           nlist[j] = 0u;
+        if (KM == 2 && j < 2 * int(LJ_GUESS_ROUNDS_PT))
+          rw[j] = 0u;
         lds_barrier();
         settled = run_rounds(smask);
       }
@@ -3985,6 +3998,26 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
                      g.period == g.n_comp && tables.size() + size_t(J.n_tables) < 0xFFFFu;
     for (uint32_t ph = 0; ph < g.n_comp && per_phase; ++ph)
       per_phase = g.comp_of_phase[ph] < J.n_tables && g.comp_of_phase[ph] < 16;
+    // Tables that are NEARLY the same (the same code for most bit patterns: channels whose
+    // statistics coincide) leave a parse no way to tell the phases apart from the bits, and they
+    // differ just often enough that a parse in the wrong phase miscounts now and then: K0's chain
+    // would settle in hardly any workgroup (tests/test_per_phase_model.py).  Such streams keep
+    // the route they had; tables that differ in a length early in the canonical order share next
+    // to nothing (measured: 0-13 % of the 11-bit patterns for unrelated tables, 74-99 % for
+    // tables with two values swapped).
+    if (per_phase && J.explicit_n == 0) {
+      std::vector<DeviceHuffTable> tmp(size_t(J.n_tables));
+      for (int t = 0; t < J.n_tables; ++t)
+        build_device_table(J.tables[t], &tmp[size_t(t)], false);
+      for (int x = 0; x < J.n_tables && per_phase; ++x)
+        for (int y = x + 1; y < J.n_tables && per_phase; ++y) {
+          uint32_t same = 0;
+          for (uint32_t i = 0; i < uint32_t(LUT_SIZE); ++i)
+            same += tmp[size_t(x)].lut[i] != 0 && tmp[size_t(x)].lut[i] == tmp[size_t(y)].lut[i];
+          if (2u * same > uint32_t(LUT_SIZE))
+            per_phase = false;
+        }
+    }
 #ifdef RSX_NO_FAST_PT
     per_phase = false;
 #endif

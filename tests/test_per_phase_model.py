@@ -85,7 +85,13 @@ def _stream_bits(rng, n, cpp, tables, index, th=120):
     return np.unpackbits(b[keep])
 
 
-def _chain(bits, tables, index, n, rounds=6):
+def _chain(bits, tables, index, n, rounds=12):
+    """lj_unstuff_kernel<2, .>'s chain of one stream: A parse from (0, phase 0), B parse from the
+    predecessor's A, rounds on whole states; a workgroup that has not settled then takes the PHASE
+    PASS -- every slot's entry phase from a prefix sum of the slots' symbol counts (from the phase
+    the workgroup starts in: the look-back's), one more parse of the slots whose last parse
+    started in another phase, settled if no exit offset and no count moved.  Returns workgroups,
+    those still unsettled, wrong states in the settled ones, workgroups the phase pass settled."""
     sl = [M.symbol_lengths(bits, t) for t in tables]
     n_slots = len(bits) // SLOT
 
@@ -99,34 +105,47 @@ def _chain(bits, tables, index, n, rounds=6):
     true = [0]
     for c in range(n_slots):
         true.append(parse(c, true[-1])[0])
-    own, unsettled, wrong = 255, 0, 0
-    a = {c: parse(c, 0)[0] for c in range(n_slots)}
-    b = {c: parse(c, a[c - 1])[0] if c > 0 else true[1] for c in range(n_slots)}
+    own, unsettled, wrong, by_phase_pass = 255, 0, 0, 0
+    a = {c: parse(c, 0) for c in range(n_slots)}
+    b = {c: parse(c, a[c - 1][0]) if c > 0 else parse(c, 0) for c in range(n_slots)}
     n_wg = (n_slots + own - 1) // own
     for wg in range(n_wg):
         idx = list(range(wg * own, min(n_slots, (wg + 1) * own)))
-        eb = {c: b[c] for c in idx}
-        eu = {c: (a[c - 1] if c > 0 else 0) for c in idx}
-        entry = true[idx[0]]                                      # (the hand-over: the predecessor's exit)
+        eb = {c: b[c][0] for c in idx}
+        cnt = {c: b[c][1] for c in idx}
+        eu = {c: (a[c - 1][0] if c > 0 else 0) for c in idx}
+        entry = true[idx[0]]                                      # (hand-over + look-back)
 
         def pred(c):
             return eb[c - 1] if c > idx[0] else entry
-        ok = False
-        for _ in range(rounds):
-            lst = [c for c in idx if pred(c) != eu[c]]
-            if not lst:
-                ok = True
-                break
-            new = {c: (parse(c, pred(c))[0], pred(c)) for c in lst}
-            moved = any(new[c][0] != eb[c] for c in lst)
-            for c, (e, f) in new.items():
-                eb[c], eu[c] = e, f
-            if not moved:
-                ok = True
-                break
+
+        def run_rounds():
+            for _ in range(rounds):
+                lst = [c for c in idx if pred(c) != eu[c]]
+                if not lst:
+                    return True
+                new = {c: (parse(c, pred(c)), pred(c)) for c in lst}
+                moved = any(new[c][0][0] != eb[c] for c in lst)
+                for c, ((e, k), f) in new.items():
+                    eb[c], cnt[c], eu[c] = e, k, f
+                if not moved:
+                    return True
+            return False
+        ok = run_rounds()
+        if not ok:
+            ph, moved = (entry >> 6) & 3, False
+            for c in idx:                                          # (all slots at a time on the device)
+                want_in = (pred(c) & 63) | (ph << 6)
+                ph = (ph + cnt[c]) % n                             # (the counts of BEFORE the pass)
+                if want_in != eu[c]:
+                    e, k = parse(c, want_in)
+                    moved |= (e & 63) != (eb[c] & 63) or k != cnt[c]
+                    eb[c], cnt[c], eu[c] = e, k, want_in
+            ok = not moved or run_rounds()
+            by_phase_pass += ok
         unsettled += not ok
         wrong += sum(eb[c] != true[c + 1] for c in idx) if ok else 0
-    return n_wg, unsettled, wrong
+    return n_wg, unsettled, wrong, by_phase_pass
 
 
 def test_chain_with_the_phase_in_the_state():
@@ -137,16 +156,46 @@ def test_chain_with_the_phase_in_the_state():
     v3[3], v3[4] = v3[4], v3[3]
     rt = np.random.default_rng(5)
     rnd = [C.random_huffman_table(rt, 15, skew=1.5) for _ in range(4)]
-    cases_ = [("A B C", 3, 3, [C.NIKON, C.ALT, rnd[0]], [0, 1, 2], 0),
-              ("A B C, two values swapped", 3, 3, [C.NIKON, (counts, v2), (counts, v3)], [0, 1, 2], 0),
-              ("A B B", 3, 3, [C.NIKON, C.ALT], [0, 1, 1], 0),
-              ("A B C D", 4, 1, rnd, [0, 1, 2, 3], 6),    # (phases of four fall into step more slowly:
-              ("A A A B", 4, 1, [C.NIKON, C.ALT], [0, 0, 0, 1], 6)]  # a few workgroups stay "uncertain")
-    for name, n, cpp, tabs, index, allowed in cases_:
+    cases_ = [("A B C", 3, 3, [C.NIKON, C.ALT, rnd[0]], [0, 1, 2]),
+              ("A B B", 3, 3, [C.NIKON, C.ALT], [0, 1, 1]),
+              ("A B C D", 4, 1, rnd, [0, 1, 2, 3]),
+              ("A A B B", 4, 1, [C.NIKON, C.ALT], [0, 0, 1, 1])]
+    helped = 0
+    for name, n, cpp, tabs, index in cases_:
         bits = _stream_bits(np.random.default_rng(1), n, cpp, tabs, index)
-        n_wg, unsettled, wrong = _chain(bits, tabs, index, n)
+        n_wg, unsettled, wrong, by_pass = _chain(bits, tabs, index, n)
         assert wrong == 0, name                       # a chain that settles settles on the truth
-        assert unsettled <= allowed, (name, unsettled, n_wg)
+        assert unsettled == 0, (name, unsettled, n_wg)   # (twelve rounds: LJ_GUESS_ROUNDS_PT)
+        # ... and with the six rounds of the other streams the phase pass settles workgroups the
+        # rounds left, but not all of them (four tables: more than half stay "uncertain")
+        _, unsettled6, wrong6, by_pass = _chain(bits, tabs, index, n, rounds=6)
+        assert wrong6 == 0
+        helped += by_pass
+    assert helped > 0
+    # ... and what the plan keeps OFF this route (rsx_ljpeg.hip, "NEARLY the same"): tables that share
+    # most of their code space -- here NIKON with two values swapped, twice -- differ too rarely for a
+    # parse to find its phase and too often for the counts to be right whatever the phase
+    near = [C.NIKON, (counts, v2), (counts, v3)]
+    bits = _stream_bits(np.random.default_rng(1), 3, 3, near, [0, 1, 2])
+    n_wg, unsettled, wrong, _ = _chain(bits, near, [0, 1, 2], 3, rounds=12)
+    assert wrong == 0 and unsettled * 5 >= n_wg      # (a workgroup in three or four stays "uncertain")
+    assert max(_agreement(near[x], near[y]) for x in range(3) for y in range(x + 1, 3)) > 0.5
+    assert max(_agreement(x, y) for x, y in ((C.NIKON, C.ALT), (C.NIKON, rnd[0]), (rnd[0], rnd[1]),
+                                              (rnd[2], rnd[3]))) < 0.25
+
+
+def _agreement(ta, tb, bits=11):
+    """the share of the 11-bit patterns that are the same symbol (code length and SSSS) under both
+    tables: the plan's test for "nearly the same" """
+    def lut(t):
+        out = [None] * (1 << bits)
+        for (l, code), ssss in M.canonical_lengths(t).items():
+            if l <= bits:
+                for i in range(code << (bits - l), (code + 1) << (bits - l)):
+                    out[i] = (l, ssss)
+        return out
+    la, lb = lut(ta), lut(tb)
+    return sum(x is not None and x == y for x, y in zip(la, lb)) / len(la)
 
 
 def _entry16(counts, values):
