@@ -286,6 +286,9 @@ struct FastState {
   uint32_t acc[4];
   uint32_t ev;   // running sum after the last even-numbered symbol
   uint32_t spec; // (per-phase tables) OR of the entries read: bit 15 = a special one among them
+#ifdef RSX_LF_PAIRWIN
+  uint32_t w, wb, sh; // (experiment: the even step's 64-bit window and its entry's shift, for the odd step)
+#endif
 };
 
 template <int N, int K>
@@ -312,6 +315,42 @@ __device__ __forceinline__ void lf_step(FastState& s, uint32_t vbase) {
   s.Pn -= (e.x & 0x800007E0u);
   s.n += 1;
 }
+
+#ifdef RSX_LF_PAIRWIN
+// Experiment (round 6): ONE window read for two symbols.  The even step reads three dwords of the
+// lane's column -- bits [pos, pos + 64) -- and the odd step takes its window out of those: the
+// second symbol starts total1 <= 26 bits further and needs at most 26 bits, 52 <= 64.  The odd
+// step loses its address, its two LDS reads and one of the two LDS round trips of a symbol;
+// the even step pays one more read and one more funnel shift.
+template <int N, int K>
+__device__ __forceinline__ void lf_step_even(FastState& s, uint32_t vbase) {
+  const uint32_t ad = vbase + (s.Pn & ~1023u);
+  const uint32_t d1 = *(lds_u32p)(ad), d0 = *(lds_u32p)(ad + 4u * LJ_T), d2 = *(lds_u32p)(ad - 4u * LJ_T);
+  const uint32_t sh = s.Pn >> 5;
+  const uint32_t w = __builtin_amdgcn_alignbit(d0, d1, sh);
+  s.wb = __builtin_amdgcn_alignbit(d1, d2, sh);
+  s.w = w;
+  const lf_u32x2 e = *(lds_u2p)((w >> 19) & 0x1FF8u);
+  const uint32_t v = (w >> (e.x & 31u)) & e.y;
+  const uint32_t u = e.y - v;
+  const uint32_t m = uint32_t(int32_t(u - v) >> 31);
+  s.acc[K % N] += (e.y & m) - u;
+  s.Pn -= (e.x & 0x800007E0u);
+  s.sh = e.x;
+  s.n += 1;
+}
+template <int N, int K>
+__device__ __forceinline__ void lf_step_odd(FastState& s) {
+  const uint32_t w = __builtin_amdgcn_alignbit(s.w, s.wb, s.sh); // (w : wb) << total1, by 32 - total1 = sh & 31
+  const lf_u32x2 e = *(lds_u2p)((w >> 19) & 0x1FF8u);
+  const uint32_t v = (w >> (e.x & 31u)) & e.y;
+  const uint32_t u = e.y - v;
+  const uint32_t m = uint32_t(int32_t(u - v) >> 31);
+  s.acc[K % N] += (e.y & m) - u;
+  s.Pn -= (e.x & 0x800007E0u);
+  s.n += 1;
+}
+#endif
 
 // Two tables that alternate symbol by symbol (round 4; the kernel's MT instantiations): both
 // 10-bit LUTs in the 8 KB the one table takes otherwise, as 4-byte entries
@@ -388,8 +427,16 @@ struct LfChain {
         lf_step_mt<N, K>(s, vbase, lut0, lut1);
       else if constexpr (TM == 2)
         lf_step_pt<N, C>(s, vbase, C == 0 ? lut0 : (C == 1 ? lut1 : (C == 2 ? lut2 : lut3)));
-      else
+      else {
+#ifdef RSX_LF_PAIRWIN
+        if constexpr ((K & 1) == 0)
+          lf_step_even<N, C>(s, vbase);
+        else
+          lf_step_odd<N, C>(s);
+#else
         lf_step<N, C>(s, vbase);
+#endif
+      }
       if ((K & 1) == 0)
         s.ev = s.acc[C];
       else
@@ -1114,7 +1161,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // PROBE instantiation: the others ask for nothing else.  With the level looked at behind
   // the head's loads, as the runs after it do, each of them read the whole un-stuffed image,
   // 2 x 300 MB on cfg 3; as a run-time condition in the one instantiation the test cost every
-  // run 1.5-2 %: scripts/r05q.sh.)
+  // run 1.5-2 %: scripts/rounds/r05/r05q.sh.)
   if constexpr (PROBE)
     if (uni(chosen_now) != level)
       return;

@@ -22,7 +22,7 @@ for cfg in "rect none mmap 1 30" "rect none numpy 1 40" "rect none numpy 4 40" "
            "rows1d none numpy 4 20" "pinned none numpy 4 20" "pinned none mmap 4 20"; do
   timeout 120 $R $cfg 2>&1 | grep -v "amdgpu.ids" | tail -6 | cut -c1-400 | tee -a $O/repro.txt
 done
-echo "== library, round-5 copies + check (diag2d), the recipe of scripts/r05zz.sh" | tee $O/diag.txt
+echo "== library, round-5 copies + check (diag2d), the recipe of scripts/rounds/r05/r05zz.sh" | tee $O/diag.txt
 timeout 100 python scripts/fuzz_more.py big 0 30 2>&1 | tail -1
 timeout 100 python scripts/fuzz_more.py big2 0 30 2>&1 | tail -1
 for r in 1 2 3 4 5 6 7 8; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# diagnose the big3 seeds that failed (scripts/r05zz.sh): shipped library, then older variants
+# diagnose the big3 seeds that failed (scripts/rounds/r05/r05zz.sh): shipped library, then older variants
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 O=$REPO/gpurun_out/r05d; mkdir -p $O

@@ -1,5 +1,5 @@
 #!/bin/bash
-# does the big3 failure of scripts/r05zz.sh come back behind OTHER processes' work, and does the
+# does the big3 failure of scripts/rounds/r05/r05zz.sh come back behind OTHER processes' work, and does the
 # first-run scalar-cache invalidation change it?  noinv = the library without it
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}

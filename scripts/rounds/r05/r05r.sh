@@ -1,6 +1,6 @@
 #!/bin/bash
 # the first run's instantiation (PROBE) + look-back-1 window per plan: base (new) / w4 (new, window of
-# 256) / r5a (shipped before) / lb1 (before, window of 64); then the fuzz soak (scripts/r05o.sh)
+# 256) / r5a (shipped before) / lb1 (before, window of 64); then the fuzz soak (scripts/rounds/r05/r05o.sh)
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 O=$REPO/gpurun_out/r05r; mkdir -p $O
@@ -24,4 +24,4 @@ rows.sort(key=lambda r:int(r['Dispatch_Id']))
 print("FETCH_SIZE (KB) of the single-pass kernel's launches in order:", [(r['Kernel_Name'][r['Kernel_Name'].find('lj_fast'):][:34], round(float(r['Counter_Value']))) for r in rows])
 PY
 cd $REPO
-bash scripts/r05o.sh 2>&1 | tail -16
+bash scripts/rounds/r05/r05o.sh 2>&1 | tail -16

@@ -12,4 +12,4 @@ WHAT=cfg4 RSX_DEBUG=1 RSX_LIB=$REPO/rawspeed_amd/variants/librsx_stats.so \
   python $REPO/scripts/exp_lj_stats.py 2>&1 | grep "^\[rsx\]" | cut -c1-400 > $OUT/cfg4_phase_and_round_stats.txt
 head -20 $OUT/cfg3_phase_and_round_stats.txt
 head -20 $OUT/cfg4_phase_and_round_stats.txt
-bash scripts/r05o.sh 2>&1 | tail -14
+bash scripts/rounds/r05/r05o.sh 2>&1 | tail -14

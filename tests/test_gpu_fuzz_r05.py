@@ -16,7 +16,7 @@ from test_gpu_fast_fuzz import banded_image
 
 pytestmark = pytest.mark.gpu
 
-# RSX_FUZZ_BASE=<k> moves every case to another seed (soak runs: scripts/r05o.sh)
+# RSX_FUZZ_BASE=<k> moves every case to another seed (soak runs: scripts/rounds/r05/r05o.sh)
 BASE = int(os.environ.get("RSX_FUZZ_BASE", "0"))
 
 
