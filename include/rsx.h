@@ -109,6 +109,11 @@ const char* rsx_ctx_last_error(const rsx_ctx* ctx);
  * this context has served: lets an integration check that the batched DNG hunk
  *  really makes one call per image. */
 uint64_t rsx_ctx_host_calls(const rsx_ctx* ctx);
+/* ... and how many of them ran their one large stream in chunks, the upload and the download
+ * under the decode (round 6; LJpegDecoder::decode / Cr2LJpegDecoder::decode of a frame whose plan
+ * the calling thread's lane holds from the frame before: LJpegDecoder.cpp:161-164,
+ * Cr2LJpegDecoder.cpp:150-153 are the callers): a diagnostic, like the count above. */
+uint64_t rsx_ctx_chunked_calls(const rsx_ctx* ctx);
 
 /* Optional: page-locked host memory for the host-pointer calls (ABI 4).
  * Those calls take whatever the caller has -- rawspeed's file `Buffer` and the pixel store

@@ -16,7 +16,7 @@ _lib = None
 # every symbol include/rsx.h declares (tests check that all of them resolve)
 EXPORTS = [
     "rsx_abi_version", "rsx_status_string", "rsx_device_count", "rsx_ctx_create",
-    "rsx_ctx_destroy", "rsx_ctx_last_error", "rsx_ctx_host_calls",
+    "rsx_ctx_destroy", "rsx_ctx_last_error", "rsx_ctx_host_calls", "rsx_ctx_chunked_calls",
     "rsx_host_alloc", "rsx_host_free", "rsx_host_register", "rsx_host_unregister",
     "rsx_unpack_validate", "rsx_unpack_u16",
     "rsx_unpack_f32_validate", "rsx_unpack_f32", "rsx_unpack_f32_plan_create",
@@ -159,6 +159,12 @@ class Context:
     def host_calls(self):
         """host-pointer entry points this context has served (rsx_ctx_host_calls)"""
         f = lib().rsx_ctx_host_calls
+        f.restype = C.c_uint64
+        return int(f(self._h))
+
+    def chunked_calls(self):
+        """... of which ran one large stream in chunks (rsx_ctx_chunked_calls)"""
+        f = lib().rsx_ctx_chunked_calls
         f.restype = C.c_uint64
         return int(f(self._h))
 

@@ -264,6 +264,7 @@ struct rsx_ctx {
   std::mutex err_mu;
   std::string last_error;
   std::atomic<uint64_t> host_calls{0}; // host-pointer entry points served
+  std::atomic<uint64_t> chunked_calls{0}; // ... of which ran one large stream in chunks
   bool host_overlap = true;            // large unpack-family host calls run in row bands
   std::mutex upload_mu, download_mu;   // LJPEG-family host calls: one copy per direction at a time
   // The single-pass LJPEG kernel takes a workgroup's place in its stream's order from its

@@ -56,6 +56,21 @@ int ljpeg_plan_results(LJpegPlan* plan, hipStream_t stream, bool ran,
                        int32_t* job_status, uint32_t* job_consumed);
 void ljpeg_plan_destroy(LJpegPlan* plan);
 
+// A run in chunks of the plan's blocks (round 6; rsx_api.hip, ljpeg_family_host): one stream of the
+// single-pass kernel, each chunk's K0 + kernel queued behind the upload of its bytes, the pixels a
+// chunk completes fetched while the next one decodes.
+struct LjRegion {
+  size_t byte0, bytes, row0, rows; // a rectangle of the image
+};
+bool ljpeg_plan_chunkable(const LJpegPlan* plan);
+uint32_t ljpeg_plan_blocks(const LJpegPlan* plan);
+int ljpeg_plan_run_begin(LJpegPlan* plan, const void* in_dev, void* out_dev, hipStream_t stream);
+int ljpeg_plan_run_blocks(LJpegPlan* plan, hipStream_t stream, uint32_t blk0, uint32_t blk1);
+int ljpeg_plan_run_end(LJpegPlan* plan, hipStream_t stream);
+int ljpeg_plan_symbols_done(LJpegPlan* plan, hipStream_t stream, uint32_t blk_end, uint64_t* symbols);
+void ljpeg_plan_region(const LJpegPlan* plan, uint64_t sym_lo, uint64_t sym_hi, std::vector<LjRegion>* out);
+bool ljpeg_plan_single_pass_held(const LJpegPlan* plan);
+
 struct LJpegPlanDeleter {
   void operator()(LJpegPlan* p) const { ljpeg_plan_destroy(p); }
 };

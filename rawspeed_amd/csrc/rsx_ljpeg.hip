@@ -205,7 +205,7 @@ __device__ __forceinline__ void lj_fix_regs(const uint32_t (&in)[LJ_BW + 1], uin
 #define K0_STAMP(k)                                                                   \
   do {                                                                                \
     if (a.dbg && threadIdx.x == 0)                                                    \
-      a.dbg[(size_t(gridDim.x) + (S.first_block + lb)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+      a.dbg[(size_t(a.n_blocks_plan) + (S.first_block + lb)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define K0_STAMP(k) \
@@ -959,13 +959,13 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
 #ifdef RSX_K0_FORWARD
   uint32_t b = blockIdx.x;
 #else
-  uint32_t b = gridDim.x - 1u - blockIdx.x;
+  uint32_t b = a.blk0 + (a.blk_n - 1u - blockIdx.x);
 #endif
   // (no tickets: the dispatcher starts a 1-D grid's workgroups in order, and if it ever did
   // not, the bounded wait below gives up and the workgroup keeps its own estimate -- a ticket
   // and its barrier in front of the first load cost every workgroup 1.5 us of its 25)
   if (K0_CHAIN)
-    b = blockIdx.x;
+    b = a.blk0 + blockIdx.x;
   lj_fresh_scalars<INV>();
   const uint32_t s = a.block_stream[b];
   // The NEXT run's results (marker_pos = 0xFFFFFFFF, an atomicMin target; everything else 0),
@@ -1337,9 +1337,9 @@ __global__ __launch_bounds__(LJ_T) void lj_unstuff_kernel(LjArgs a) {
       // part --, parses the slots whose last parse started in another phase ONCE more from the
       // right one, all at a time, and is done if no exit and no count moved.
       uint32_t* PX = reinterpret_cast<uint32_t*>(smem + lj_k0_ptx_off(a.pt_np));
-      uint32_t* const kp_now = a.k0p + size_t(a.run_parity) * (gridDim.x + 1u);
+      uint32_t* const kp_now = a.k0p + size_t(a.run_parity) * (a.n_blocks_plan + 1u);
       if (j == 0) // (the next run's words of this block: clean when it looks at them)
-        a.k0p[size_t(a.run_parity ^ 1u) * (gridDim.x + 1u) + b] = 0u;
+        a.k0p[size_t(a.run_parity ^ 1u) * (a.n_blocks_plan + 1u) + b] = 0u;
       // (a workgroup whose rounds settled IS in step with the true chain, phase and all -- a
       // wrong phase cannot be consistent over 255 slots parsed from bit 0 each --: the phase it
       // ends in goes out at once, and it looks at nobody.  Only the others walk back, to the
@@ -3625,6 +3625,8 @@ struct LJpegPlan {
   uint32_t pt_np = 2;           // the most phases such a stream has (sizes K0's LDS)
   DeviceBuffer d_k0e;           // K0's hand-over words (LjArgs::k0e)
   DeviceBuffer d_k0p;           // K0's phase look-back words (LjArgs::k0p), table-per-phase plans
+  std::vector<Cr2Strip> h_strips; // (host copy: which pixels a prefix of a stream's symbols completes)
+  LjArgs run_args{};            // the run in progress (ljpeg_plan_run_begin .. _end)
   bool any_fast = false;       // some stream takes the single-pass kernel
   uint32_t fast_lds = 0;       // LDS bytes of its launches
   uint32_t fast_uniform_nb = 0, fast_rotate = 0; // (LjArgs)
@@ -3713,6 +3715,8 @@ LjResult* results_of_run(const LJpegPlan* p) {
 
 LjArgs make_args(LJpegPlan* p, const void* in_dev, void* out_dev) {
   LjArgs a{};
+  a.blk0 = 0;
+  a.blk_n = a.n_blocks_plan = p->total_blocks;
   a.in_base = static_cast<const uint8_t*>(in_dev);
   a.out_base = static_cast<uint8_t*>(out_dev);
   a.streams = static_cast<const LjStreamDev*>(p->d_streams.ptr);
@@ -4261,7 +4265,8 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         (st = up(p->d_tables, tl.data(), tl.size() * sizeof(TabLds))) ||
         (st = up(p->d_block_stream, block_stream.data(),
                  block_stream.size() * sizeof(uint32_t))) ||
-        (st = up(p->d_strips, strips.data(), strips.size() * sizeof(Cr2Strip))))
+        (st = up(p->d_strips, strips.data(), strips.size() * sizeof(Cr2Strip))) ||
+        ((p->h_strips = strips), false))
       return st;
     if (p->any_nikon &&
         ((st = up(p->d_nk, p->nk.data(), p->nk.size() * sizeof(NkStreamDev))) ||
@@ -4805,23 +4810,13 @@ int ljpeg_plan_run(LJpegPlan* p, const void* in_dev, void* out_dev,
                    hipStream_t s, KernelTimer* timer) {
   return ljpeg_plan_run_(p, in_dev, out_dev, s, timer, false);
 }
-int ljpeg_plan_run_(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s,
-                    KernelTimer* timer, bool continue_timer) {
+// A run in three parts -- begin (bookkeeping, the results' set), the BLOCKS of K0 and the
+// single-pass kernel, end (pipeline, scan, tail, slow pass) --: ljpeg_plan_run_ queues all blocks
+// at once; a host-pointer call of one large stream queues them chunk by chunk, each behind the
+// upload of its bytes, and fetches the pixels a chunk completes while the next one decodes
+// (rsx_api.hip, ljpeg_family_host; round 6).
+static int ljpeg_plan_run_begin_(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s) {
   rsx_ctx* ctx = p->ctx;
-  p->last_in = in_dev;
-  p->last_out = out_dev;
-  struct TimerScope { // the timer covers this run's own launches only
-    LJpegPlan* p;
-    ~TimerScope() { p->timer = nullptr; }
-  } scope{p};
-  p->timer = timer;
-  if (timer && !continue_timer)
-    timer->begin(s);
-  if (!p->dri.empty())
-    if (int st = run_dri(p, in_dev, out_dev, s))
-      return st;
-  if (p->streams.empty())
-    return RSX_OK;
   ++p->run_count;
   // demoted streams get the single-pass kernel back after DEMOTION_RUNS runs
   if (!p->demoted_at.empty()) {
@@ -4889,31 +4884,43 @@ int ljpeg_plan_run_(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t
 #endif
   p->results_clean_for = p->run_count + 1;
   p->results_clean_stream = s;
+  p->run_args = a;
+  return RSX_OK;
+}
+
+// K0 and the single-pass kernel over the plan's blocks [blk0, blk1)
+static int ljpeg_plan_run_blocks_(LJpegPlan* p, hipStream_t s, uint32_t blk0, uint32_t blk1) {
+  rsx_ctx* ctx = p->ctx;
+  if (blk1 <= blk0)
+    return RSX_OK;
+  LjArgs a = p->run_args;
+  a.blk0 = blk0;
+  a.blk_n = blk1 - blk0;
   // (plans laid out on the device: the instantiations whose wavefronts drop the scalar cache
   // first -- lj_fresh_scalars)
   if (p->any_fast_pt && p->dev_layout)
-    hipLaunchKernelGGL((lj_unstuff_kernel<2, true>), dim3(p->total_blocks), dim3(LJ_T),
+    hipLaunchKernelGGL((lj_unstuff_kernel<2, true>), dim3(a.blk_n), dim3(LJ_T),
                        lj_k0_lds_pt(p->pt_np), s, a);
   else if (p->any_fast_pt)
-    hipLaunchKernelGGL((lj_unstuff_kernel<2, false>), dim3(p->total_blocks), dim3(LJ_T),
+    hipLaunchKernelGGL((lj_unstuff_kernel<2, false>), dim3(a.blk_n), dim3(LJ_T),
                        lj_k0_lds_pt(p->pt_np), s, a);
   else if (p->any_fast_mt && p->dev_layout)
-    hipLaunchKernelGGL((lj_unstuff_kernel<1, true>), dim3(p->total_blocks), dim3(LJ_T),
+    hipLaunchKernelGGL((lj_unstuff_kernel<1, true>), dim3(a.blk_n), dim3(LJ_T),
                        LJ_K0_LDS_MT, s, a);
   else if (p->any_fast_mt)
-    hipLaunchKernelGGL((lj_unstuff_kernel<1, false>), dim3(p->total_blocks), dim3(LJ_T),
+    hipLaunchKernelGGL((lj_unstuff_kernel<1, false>), dim3(a.blk_n), dim3(LJ_T),
                        LJ_K0_LDS_MT, s, a);
   else if (p->dev_layout)
-    hipLaunchKernelGGL((lj_unstuff_kernel<0, true>), dim3(p->total_blocks), dim3(LJ_T),
+    hipLaunchKernelGGL((lj_unstuff_kernel<0, true>), dim3(a.blk_n), dim3(LJ_T),
                        LJ_K0_LDS, s, a);
   else
-    hipLaunchKernelGGL((lj_unstuff_kernel<0, false>), dim3(p->total_blocks), dim3(LJ_T),
+    hipLaunchKernelGGL((lj_unstuff_kernel<0, false>), dim3(a.blk_n), dim3(LJ_T),
                        LJ_K0_LDS, s, a);
   mark(p, "lj_unstuff_kernel");
   // the single-pass kernel for the streams it takes ...
   if (p->any_fast) {
     FastLaunch fl;
-    fl.total_blocks = p->total_blocks;
+    fl.total_blocks = a.blk_n;
     std::memcpy(fl.present, p->fast_present, sizeof fl.present);
     // one single-pass launch of a context at a time (rsx_ctx::fast_mu)
     std::lock_guard<std::mutex> g(ctx->fast_mu);
@@ -4926,6 +4933,12 @@ int ljpeg_plan_run_(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t
     ctx->fast_ev_valid = true;
     ctx->fast_ev_stream = s;
   }
+  return RSX_OK;
+}
+
+static int ljpeg_plan_run_end_(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s) {
+  const LjArgs a = p->run_args;
+  const uint32_t n_streams = uint32_t(p->streams.size());
   // ... the multi-kernel pipeline for the others
   if (p->any_pipeline)
     launch_synchronisation(p, a, s);
@@ -4945,6 +4958,109 @@ int ljpeg_plan_run_(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t
   if (!p->nk_split.empty())
     return run_nikon_split(p, in_dev, out_dev, s);
   return RSX_OK;
+}
+
+int ljpeg_plan_run_(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s,
+                    KernelTimer* timer, bool continue_timer) {
+  p->last_in = in_dev;
+  p->last_out = out_dev;
+  struct TimerScope { // the timer covers this run's own launches only
+    LJpegPlan* p;
+    ~TimerScope() { p->timer = nullptr; }
+  } scope{p};
+  p->timer = timer;
+  if (timer && !continue_timer)
+    timer->begin(s);
+  if (!p->dri.empty())
+    if (int st = run_dri(p, in_dev, out_dev, s))
+      return st;
+  if (p->streams.empty())
+    return RSX_OK;
+  if (int st = ljpeg_plan_run_begin_(p, in_dev, out_dev, s))
+    return st;
+  if (int st = ljpeg_plan_run_blocks_(p, s, 0, p->total_blocks))
+    return st;
+  return ljpeg_plan_run_end_(p, in_dev, out_dev, s);
+}
+
+// ---- a run in chunks (one stream, the single-pass kernel's) ------------------------------
+// whether the plan is one the host may run in chunks: ONE stream that the single-pass kernel
+// takes, nothing else
+bool ljpeg_plan_chunkable(const LJpegPlan* p) {
+  return p->streams.size() == 1 && p->streams[0].fast != 0 && p->dri.empty() &&
+         p->nk_split.empty() && !p->any_pipeline && !p->any_legacy && !p->dev_layout &&
+         !p->expect_slow && p->streams[0].kind == 0u;
+  // (kind 0 only: what a prefix of a CR2 stream completes is rows of a vertical STRIP, narrow 2-D
+  // copies that run at half the rate of whole rows -- measured on a 6720 x 4480 frame in three strips:
+  // 1.94 ms in chunks against 1.87 ms the plain way, profiles/r06/ab/chunked_host_calls.txt)
+}
+uint32_t ljpeg_plan_blocks(const LJpegPlan* p) { return p->total_blocks; }
+int ljpeg_plan_run_begin(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t s) {
+  p->last_in = in_dev;
+  p->last_out = out_dev;
+  p->timer = nullptr;
+  return ljpeg_plan_run_begin_(p, in_dev, out_dev, s);
+}
+int ljpeg_plan_run_blocks(LJpegPlan* p, hipStream_t s, uint32_t blk0, uint32_t blk1) {
+  return ljpeg_plan_run_blocks_(p, s, blk0, blk1);
+}
+int ljpeg_plan_run_end(LJpegPlan* p, hipStream_t s) {
+  return ljpeg_plan_run_end_(p, p->last_in, p->last_out, s);
+}
+// the symbols the stream's blocks [0, blk_end) have delivered (waits for the stream)
+int ljpeg_plan_symbols_done(LJpegPlan* p, hipStream_t s, uint32_t blk_end, uint64_t* symbols) {
+  rsx_ctx* ctx = p->ctx;
+  *symbols = 0;
+  if (blk_end == 0)
+    return RSX_OK;
+  uint32_t w[2] = {0, 0};
+  RSX_HIP_CHECK(ctx, hipMemcpyAsync(&w[0], static_cast<uint32_t*>(p->d_block_base0.ptr) + (blk_end - 1), 4,
+                                    hipMemcpyDeviceToHost, s));
+  RSX_HIP_CHECK(ctx, hipMemcpyAsync(&w[1], static_cast<uint32_t*>(p->d_block_sum.ptr) + (blk_end - 1), 4,
+                                    hipMemcpyDeviceToHost, s));
+  RSX_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  *symbols = uint64_t(w[0]) + w[1];
+  return RSX_OK;
+}
+// The pixels the stream's symbols [lo, hi) COMPLETE, as rectangles of the image (bytes, rows):
+// whole stream rows (LJPEG: a row's kept part) or whole rows of a CR2 strip; a row that the
+// range only touches belongs to the range that finishes it.
+void ljpeg_plan_region(const LJpegPlan* p, uint64_t lo, uint64_t hi, std::vector<LjRegion>* out) {
+  out->clear();
+  const LjStreamDev& S = p->streams[0];
+  if (hi > S.needed)
+    hi = S.needed;
+  if (hi <= lo)
+    return;
+  if (S.kind == 0) {
+    const uint64_t r0 = lo / S.row_samples, r1 = hi == S.needed ? S.rows : hi / S.row_samples;
+    const uint32_t keep = std::min(S.keep_samples, S.row_samples);
+    if (r1 > r0 && keep)
+      out->push_back({size_t(S.out_x) * 2, size_t(keep) * 2, size_t(S.out_y) + size_t(r0), size_t(r1 - r0)});
+    return;
+  }
+  for (uint32_t z = 0; z < S.n_strips; ++z) {
+    const Cr2Strip& st = p->h_strips[S.strip_base + z];
+    const uint64_t f0 = st.first_sample, f1 = p->h_strips[S.strip_base + z + 1].first_sample;
+    auto rows_at = [&](uint64_t n) -> uint64_t {
+      if (n <= f0)
+        return 0;
+      if (n >= f1)
+        return st.h;
+      return std::min<uint64_t>(st.h, (n - f0) / st.w);
+    };
+    const uint64_t a = rows_at(lo), b = rows_at(hi);
+    if (b > a)
+      out->push_back({size_t(st.x0) * 2, size_t(st.w) * 2, size_t(st.y0) + size_t(a), size_t(b - a)});
+  }
+}
+// whether the run's streams all came out of the single-pass kernel (call after the results):
+// if not, pixels fetched before the end of the run may have been rewritten since
+bool ljpeg_plan_single_pass_held(const LJpegPlan* p) {
+  for (const LjResult& R : p->h_results)
+    if (R.flags & (FL_SLOW | FL_NEED_LEGACY | FL_UNCONVERGED))
+      return false;
+  return !p->slow_pass_launched;
 }
 
 namespace {

@@ -287,6 +287,10 @@ struct LjArgs {
                              // lj_dri_layout_kernel): the kernels that read them through the
                              // scalar cache invalidate it first (lj_fresh_scalars)
   uint32_t fuse_consumed;    // != 0: lj_scan_kernel does lj_consumed_kernel's work as well
+  uint32_t blk0, blk_n;      // the blocks of THIS launch of K0 / the single-pass kernel: [blk0, blk0 + blk_n)
+                             // -- all of them as a rule; a part of them when a host-pointer call runs a
+                             // stream in chunks, its upload and download under the decode (round 6)
+  uint32_t n_blocks_plan;    // the plan's blocks (the stride of per-plan arrays that gridDim.x was)
   uint32_t pass;             // 0: first pass; 1: the multi-kernel pipeline redoes FL_SLOW
                              // streams; 2: its streams of both passes
 };

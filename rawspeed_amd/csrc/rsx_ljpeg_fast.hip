@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   // loads; the others read fast_order's entry first.
   (void)TICKET0;
   lj_fresh_scalars<INV>();
-  const uint32_t t_blk = blockIdx.x;
+  const uint32_t t_blk = a.blk0 + blockIdx.x;
   const uint32_t chosen_now = __hip_atomic_load(&a.fast_level[a.run_parity], __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_AGENT);
   // (A plan's FIRST run launches every LDS level it might need and one of them works -- the
@@ -2095,13 +2095,13 @@ void launch_fast_one(const LjArgs& a, const FastLaunch& f, hipStream_t s, Kernel
     if (!((a.fast_level_mask >> lv) & 1u))
       continue;
     if (a.dev_layout)
-      hipLaunchKernelGGL((lj_fast_kernel<N, TM, 2>), dim3(f.total_blocks), dim3(LJ_T),
+      hipLaunchKernelGGL((lj_fast_kernel<N, TM, 2>), dim3(a.blk_n), dim3(LJ_T),
                          a.fast_lds_lv[lv], s, a, a.fast_lds_lv[lv], lv);
     else if (probe)
-      hipLaunchKernelGGL((lj_fast_kernel<N, TM, 1>), dim3(f.total_blocks), dim3(LJ_T),
+      hipLaunchKernelGGL((lj_fast_kernel<N, TM, 1>), dim3(a.blk_n), dim3(LJ_T),
                          a.fast_lds_lv[lv], s, a, a.fast_lds_lv[lv], lv);
     else
-      hipLaunchKernelGGL((lj_fast_kernel<N, TM, 0>), dim3(f.total_blocks), dim3(LJ_T),
+      hipLaunchKernelGGL((lj_fast_kernel<N, TM, 0>), dim3(a.blk_n), dim3(LJ_T),
                          a.fast_lds_lv[lv], s, a, a.fast_lds_lv[lv], lv);
     if (timer)
       timer->mark(lv == 0 ? "lj_fast_kernel" : (lv == 1 ? "lj_fast_kernel(3/CU)" : "lj_fast_kernel(2/CU)"));

@@ -5,7 +5,7 @@
 #   re-decode round statistics of an experiment build.
 # Outputs land in gpurun_out/prof_$ROUND/ (copied to profiles/$ROUND/ afterwards).
 set -u
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$ROUND
 mkdir -p $OUT
