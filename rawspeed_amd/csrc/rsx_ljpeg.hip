@@ -2402,7 +2402,7 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
       uint32_t flags = Rv.flags & ~(FL_UNCONVERGED | FL_NEED_LEGACY | FL_PERIODIC);
       if (unconv_s)
         flags |= FL_UNCONVERGED;
-      if (nd && uint64_t(avail) < needed)
+      if (uint64_t(avail) < needed) // (fused path or not: symbols past the data are the second pass's)
         flags |= FL_NEED_LEGACY;
       if (flags & (FL_UNCONVERGED | FL_NEED_LEGACY))
         flags = (flags & ~(FL_UNCONVERGED | FL_NEED_LEGACY)) | FL_SLOW;
@@ -2590,7 +2590,9 @@ __global__ __launch_bounds__(LJ_T) void lj_scan_kernel(LjArgs a) {
       flags |= FL_UNCONVERGED;
     // symbols past the end of the data: the reference's end-of-stream semantics
     // live in the legacy tail kernel
-    if (nd && uint64_t(avail) < S.needed)
+    // (... and of the single-pass kernel's streams that are not the fused path's -- three
+    // components, the streams that leave differences --: their second pass is the legacy route)
+    if ((nd || (S.fast && a.pass == 0)) && uint64_t(avail) < S.needed)
       flags |= FL_NEED_LEGACY;
     // a single-pass stream with a broken chain or symbols past its data: the
     // multi-kernel pipeline redoes it (and finds out again, from its own records)
@@ -3623,6 +3625,7 @@ struct LJpegPlan {
   bool any_fast_mt = false;     // some stream takes its two-table instantiation
   bool any_fast_pt = false;     // ... its table-per-phase instantiation (LjStreamDev::fast == 3)
   uint32_t pt_np = 2;           // the most phases such a stream has (sizes K0's LDS)
+  bool any_fast_diffs = false;  // ... leaves differences for the legacy reconstruction (fast_diffs)
   DeviceBuffer d_k0e;           // K0's hand-over words (LjArgs::k0e)
   DeviceBuffer d_k0p;           // K0's phase look-back words (LjArgs::k0p), table-per-phase plans
   std::vector<Cr2Strip> h_strips; // (host copy: which pixels a prefix of a stream's symbols completes)
@@ -4043,6 +4046,21 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
                        g.row_samples >= 3 && g.row_samples % 3 == 0;
     if (fast3)
       S.fast = J.n_tables == 1 ? 1 : 3;
+    // Round 6: a stream whose RECONSTRUCTION the legacy kernels do -- a Nikon-type predictor with its
+    // curve and dither, Pentax, SamsungV1's cousins with a canonical table, Canon sRaw groups -- and
+    // that has one canonical table takes the single-pass kernel for its entropy half: the kernel
+    // leaves the differences where lj_decode_kernel would have (its <1, 0, ., true> instantiation),
+    // the reconstruction kernels follow in the same pass.  What it gives up on is redone by the
+    // legacy route's own decode, like a three-component stream's.
+    S.fast_diffs = 0;
+#ifndef RSX_NO_FAST_DIFFS
+    if (!S.fast && !direct_n && J.n_tables == 1 && J.explicit_n == 0 && !g.las && !g.pair &&
+        (g.kind == 2 || g.kind == 1 || g.kind == 0) && !(g.kind == 2 && J.nikon.sony) &&
+        tables.size() < 0xFFFFu && needed >= 1) {
+      S.fast = 1;
+      S.fast_diffs = 1;
+    }
+#endif
     S.tab_period = 0;
     if (S.fast == 3) {
       // (the period of the assignment: A B A B over four components is two phases, not four --
@@ -4174,7 +4192,10 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       p->any_fast_pt |= S.fast == 3;
       if (S.fast == 3)
         p->pt_np = std::max(p->pt_np, uint32_t(S.tab_period));
-      p->fast_present[S.fast - 1][S.direct ? S.direct : g.n_comp] = true;
+      if (S.fast_diffs)
+        p->any_fast_diffs = true;
+      else
+        p->fast_present[S.fast - 1][S.direct ? S.direct : g.n_comp] = true;
     } else {
       p->any_pipeline = true;
     }
@@ -4442,8 +4463,20 @@ int launch_tail(LJpegPlan* p, const LjArgs& a, hipStream_t s, bool pipeline = tr
     std::memcpy(dl.present, p->direct_present, sizeof dl.present);
     ljpeg_launch_direct(a, dl, s, p->timer);
   }
-  if (((legacy & 1) && p->any_legacy) || ((legacy & 2) && p->any_fast_legacy))
+  if (((legacy & 1) && p->any_legacy) || ((legacy & 2) && p->any_fast_legacy)) {
     launch_legacy(p, p->legacy, a, s);
+  } else if ((legacy & 1) && a.pass == 0 && p->any_fast_diffs) {
+    // (the first pass of streams whose differences the single-pass kernel has just left: their
+    // reconstruction -- the kernels skip the streams it gave up on, lj_recon_takes)
+    ReconLaunch rl;
+    rl.n_streams = n_streams;
+    rl.total_rows = p->total_rows;
+    std::copy(p->legacy.comp, p->legacy.comp + 7, rl.comp_present);
+    rl.any_nikon = p->legacy.nikon;
+    rl.any_sony = p->legacy.sony;
+    ljpeg_launch_reconstruct(a, rl, s);
+    mark(p, "legacy reconstruction (K5 + K6)");
+  }
   if (!a.fuse_consumed) {
     hipLaunchKernelGGL(lj_consumed_kernel, dim3(n_streams), dim3(64), 0, s, a);
     mark(p, "lj_consumed_kernel");
@@ -4922,6 +4955,7 @@ static int ljpeg_plan_run_blocks_(LJpegPlan* p, hipStream_t s, uint32_t blk0, ui
     FastLaunch fl;
     fl.total_blocks = a.blk_n;
     std::memcpy(fl.present, p->fast_present, sizeof fl.present);
+    fl.diffs = p->any_fast_diffs;
     // one single-pass launch of a context at a time (rsx_ctx::fast_mu)
     std::lock_guard<std::mutex> g(ctx->fast_mu);
     if (ctx->fast_ev_valid && ctx->fast_ev_stream != s)
@@ -4988,7 +5022,8 @@ int ljpeg_plan_run_(LJpegPlan* p, const void* in_dev, void* out_dev, hipStream_t
 // takes, nothing else
 bool ljpeg_plan_chunkable(const LJpegPlan* p) {
   return p->streams.size() == 1 && p->streams[0].fast != 0 && p->dri.empty() &&
-         p->nk_split.empty() && !p->any_pipeline && !p->any_legacy && !p->dev_layout &&
+         p->nk_split.empty() && !p->any_pipeline && !p->any_legacy && !p->any_fast_diffs &&
+         !p->dev_layout &&
          !p->expect_slow && p->streams[0].kind == 0u;
   // (kind 0 only: what a prefix of a CR2 stream completes is rows of a vertical STRIP, narrow 2-D
   // copies that run at half the rate of whole rows -- measured on a 6720 x 4480 frame in three strips:

@@ -144,7 +144,10 @@ struct LjStreamDev {
                        // table, 2 two tables alternating symbol by symbol, 3 a table per phase
   uint8_t tab_period;  // fast == 3: the period of tab_of_phase over the components (2, 3 or 4: A B A B
                        // is 2) -- the phase of a parse state is the symbol index mod this
-  uint8_t pad_fast_[3];
+  uint8_t fast_diffs;  // fast != 0: the single-pass kernel leaves the stream's DIFFERENCES (int16, stream
+                       // order, at diff_offset) for the legacy reconstruction kernels instead of pixels
+                       // -- Nikon-type predictors, Pentax, Canon sRaw groups: one table (round 6)
+  uint8_t pad_fast_[2];
   uint32_t rows;
   uint32_t row_samples;
   uint32_t first_row; // global stream-row index
@@ -351,6 +354,19 @@ __device__ __forceinline__ bool lj_legacy_takes(const LjArgs& a, uint32_t s,
   return (a.results[s].flags & FL_NEED_LEGACY) != 0 && S.diff_offset != LJ_NO_DIFFS;
 }
 
+// ... whether the reconstruction kernels (seeds, row scans) take it: the legacy route's streams, and in
+// the first pass the streams whose differences the single-pass kernel has just left (fast_diffs)
+// -- unless it gave the stream up: then the second pass decodes and reconstructs it
+__device__ __forceinline__ bool lj_recon_takes(const LjArgs& a, uint32_t s, const LjStreamDev& S) {
+  if (lj_legacy_takes(a, s, S))
+    return true;
+  return S.fast != 0 && S.fast_diffs != 0 && a.pass == 0 && !(a.results[s].flags & FL_SLOW);
+}
+// (the Nikon-type kernels take every stream of their kind: not the ones given up in the first pass)
+__device__ __forceinline__ bool lj_recon_skips_given_up(const LjArgs& a, uint32_t s, const LjStreamDev& S) {
+  return S.fast != 0 && S.fast_diffs != 0 && a.pass == 0 && (a.results[s].flags & FL_SLOW) != 0;
+}
+
 constexpr int VS_T = 1024; // lanes of the per-stream seed kernels
 
 // what the reconstruction launch needs to know about the plan
@@ -392,6 +408,7 @@ void ljpeg_launch_direct(const LjArgs& a, const DirectLaunch& d, hipStream_t str
 struct FastLaunch {
   uint32_t total_blocks = 0;
   bool present[3][5] = {}; // [one table / two alternating / a table per phase][components]
+  bool diffs = false;      // some stream leaves differences (fast_diffs): the <1, 0, ., true> instantiation
 };
 void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t stream,
                        KernelTimer* timer);

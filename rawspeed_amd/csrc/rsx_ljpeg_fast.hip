@@ -291,7 +291,9 @@ struct FastState {
 #endif
 };
 
-template <int N, int K>
+// (DIFF -- round 6, streams whose reconstruction stays with the legacy kernels: the lane keeps
+// the symbols' DIFFERENCES, not their running sums: an assignment where the sum is an addition)
+template <int N, int K, bool DIFF = false>
 __device__ __forceinline__ void lf_step(FastState& s, uint32_t vbase) {
   const uint32_t ad = vbase + (s.Pn & ~1023u);
 #ifdef RSX_LF_SPLIT_READS
@@ -311,7 +313,10 @@ __device__ __forceinline__ void lf_step(FastState& s, uint32_t vbase) {
   // difference bit is set (positive difference): diff = v, else v - all
   const uint32_t u = e.y - v;
   const uint32_t m = uint32_t(int32_t(u - v) >> 31);
-  s.acc[K % N] += (e.y & m) - u;
+  if constexpr (DIFF)
+    s.acc[K % N] = (e.y & m) - u;
+  else
+    s.acc[K % N] += (e.y & m) - u;
   s.Pn -= (e.x & 0x800007E0u);
   s.n += 1;
 }
@@ -416,7 +421,7 @@ __device__ __forceinline__ void lf_step_pt(FastState& s, uint32_t vbase, uint32_
 
 // (KB: symbols of the lane in front of this group of eight -- the component of step K is
 // (KB + K) mod N, which is K mod N for 1, 2 and 4 components and not for 3)
-template <int N, int K, int KEND, int TM = 0, int KB = 0>
+template <int N, int K, int KEND, int TM = 0, int KB = 0, bool DIFF = false>
 struct LfChain {
   static __device__ __forceinline__ void run(FastState& s, uint32_t vbase, uint32_t pend,
                                              uint32_t (&R)[LF_NR], int qbase, uint32_t lut0,
@@ -434,7 +439,7 @@ struct LfChain {
         else
           lf_step_odd<N, C>(s);
 #else
-        lf_step<N, C>(s, vbase);
+        lf_step<N, C, DIFF>(s, vbase);
 #endif
       }
       if ((K & 1) == 0)
@@ -442,19 +447,19 @@ struct LfChain {
       else
         R[qbase + (K >> 1)] = pack16(s.ev, s.acc[C]);
       if constexpr (K + 1 < KEND)
-        LfChain<N, K + 1, KEND, TM, KB>::run(s, vbase, pend, R, qbase, lut0, lut1, lut2, lut3);
+        LfChain<N, K + 1, KEND, TM, KB, DIFF>::run(s, vbase, pend, R, qbase, lut0, lut1, lut2, lut3);
     }
   }
 };
 
-template <int N, int G, int TM = 0>
+template <int N, int G, int TM = 0, bool DIFF = false>
 __device__ __forceinline__ void lf_groups(FastState& s, uint32_t vbase, uint32_t pend,
                                           uint32_t (&R)[LF_NR], uint32_t lut0 = 0,
                                           uint32_t lut1 = 0, uint32_t lut2 = 0, uint32_t lut3 = 0) {
   if (__any(s.Pn > pend)) {
-    LfChain<N, 0, 8, TM, 8 * G>::run(s, vbase, pend, R, 4 * G, lut0, lut1, lut2, lut3);
+    LfChain<N, 0, 8, TM, 8 * G, DIFF>::run(s, vbase, pend, R, 4 * G, lut0, lut1, lut2, lut3);
     if constexpr (G + 1 < LF_MAXSYM / 8)
-      lf_groups<N, G + 1, TM>(s, vbase, pend, R, lut0, lut1, lut2, lut3);
+      lf_groups<N, G + 1, TM, DIFF>(s, vbase, pend, R, lut0, lut1, lut2, lut3);
   }
 }
 
@@ -504,7 +509,7 @@ __device__ __forceinline__ uint32_t lf_slow_entry(uint32_t w, const TabLds& tb) 
 __device__ __forceinline__ uint32_t lf_pmod(uint32_t x, uint32_t P) {
   return P == 3u ? x % 3u : (x & (P - 1u));
 }
-template <int N, int TM>
+template <int N, int TM, bool DIFF = false>
 __device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds* tabs0, uint32_t tabsel,
                                             uint32_t P, int col, uint32_t start, uint32_t end_bits,
                                             uint32_t side_addr, bool enabled,
@@ -555,7 +560,7 @@ __device__ __forceinline__ void lf_redecode(const FastLds& F, const TabLds* tabs
     const uint32_t sh = 16u * (n & 1u);
     uint32_t val;
     if (N == 1) {
-      a0 = (a0 + d) & 0xFFFFu;
+      a0 = DIFF ? (d & 0xFFFFu) : ((a0 + d) & 0xFFFFu);
       val = a0;
     } else if (N == 2) {
       a0 = pk_add(a0, d << sh);
@@ -830,6 +835,8 @@ struct FastStream {
   uint32_t tm;     // 0 one table, 1 two tables alternating symbol by symbol, 2 a table per phase
   uint32_t tabsel; // the stream's table of phase k (symbol index mod N) in bits 4k .. 4k + 3
   uint32_t tp;     // tm == 2: the period of that assignment (2, 3, 4): a state's phase is mod this
+  uint32_t diffs;  // the stream leaves differences for the legacy reconstruction (fast_diffs)
+  uint64_t diff_offset;
   uint32_t first_block, first_subseq, table_base, start_bit, n_blocks;
   uint32_t RS, kind, keep, out_x, out_y, pitch, n_strips, strip_base;
   uint64_t needed, img_offset;
@@ -842,7 +849,10 @@ __device__ __forceinline__ FastStream lf_stream(const LjStreamDev& S) {
   FastStream f;
   // (3 components, round 5: not a stream of the fused multi-kernel path -- direct == 0 --, so
   // the number of components says which instantiation takes it)
-  f.fast_n = uni(S.fast ? (S.direct ? uint32_t(S.direct) : S.n_comp) : 0u);
+  f.diffs = uni(S.fast && S.fast_diffs ? 1u : 0u);
+  f.diff_offset = uni64(S.diff_offset);
+  // (a stream that leaves differences is one "component": its symbols in stream order)
+  f.fast_n = uni(S.fast ? (f.diffs ? 1u : (S.direct ? uint32_t(S.direct) : S.n_comp)) : 0u);
   f.tm = uni(S.fast >= 2 ? uint32_t(S.fast) - 1u : 0u);
   f.tabsel = uni(f.tm ? (uint32_t(S.tab_of_phase[0] & 15u) | (uint32_t(S.tab_of_phase[1] & 15u) << 4) |
                          (uint32_t(S.tab_of_phase[2] & 15u) << 8) |
@@ -927,13 +937,12 @@ template <int N>
 __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
                                              const FastStream& S, uint32_t A0_, uint32_t A1_,
                                              uint32_t sb, uint32_t r0_, int tid,
-                                             const WalkStart& ws) {
+                                             const WalkStart& ws, uint8_t* img) {
   const uint32_t lane = uint32_t(tid) & 63u;
   const uint32_t wv = uni(uint32_t(tid) >> 6);
   // (every lane holds the same values: said so, or the walk below runs on vector registers)
   const uint32_t A0 = uni(A0_), A1 = uni(A1_), r0 = uni(r0_);
   const uint32_t RS = S.RS;
-  uint8_t* img = a.out_base + S.img_offset;
   const Cr2Strip* st = reinterpret_cast<const Cr2Strip*>(F.strips);
   // cursor (wave-uniform): the run that starts at sample i
   uint32_t i = A0, r = r0, sidx = A0 - r0 * RS;
@@ -1120,10 +1129,16 @@ __device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad
 // MODE 0: the steady state.  1 (PROBE): a plan's first run, when every LDS level is launched
 // and one works.  2: plans laid out on the device (restart intervals) -- PROBE's early look at
 // the level, and every wavefront drops the scalar cache before its first load (lj_fresh_scalars)
-template <int N, int TM, int MODE>
+// DIFF (round 6): the stream's reconstruction stays with the legacy kernels (Nikon-type predictors
+// with their curve and dither, Pentax, Canon sRaw groups): the kernel decodes every symbol ONCE, as
+// for the others, and leaves the DIFFERENCES in stream order where lj_decode_kernel would have --
+// no rows, no look-back 1, one contiguous run to write -- in place of the multi-kernel pipeline's
+// warm-up + recorded pass + stitch passes + final decode of such streams.
+template <int N, int TM, int MODE, bool DIFF = false>
 __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds_bytes,
                                                           uint32_t level) {
   constexpr bool PROBE = MODE >= 1, INV = MODE == 2;
+  static_assert(!DIFF || (N == 1 && TM == 0), "differences: one table, symbols in stream order");
   constexpr bool MT = TM == 1, PT = TM == 2; // two alternating tables / a table per phase
   constexpr uint32_t TICKET0 = (MT ? 12u : 0u) + (N == 4 ? 2u : (N == 3 ? 3u : uint32_t(N) - 1u));
   // offset (| table bit of the next symbol | its phase, two bits)
@@ -1304,7 +1319,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       }
     }
   }
-  const FastStream S = lf_stream(a.streams[s]);
+  FastStream S = lf_stream(a.streams[s]);
   // (Pin: every load above is ISSUED before the first exit below.  Left alone the compiler
   // sinks the loads whose values the exits do not need -- tables, image -- behind them, i.e.
   // behind the wait for the stream's record: one more round trip in a row.)
@@ -1322,8 +1337,16 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   if (uni(chosen_now) != level)
     return; // this run's workgroups need another LDS level: that launch does the work
 #endif
-  if (int(S.fast_n) != N || int(S.tm) != TM)
+  if (int(S.fast_n) != N || int(S.tm) != TM || (S.diffs != 0u) != DIFF)
     return; // (workgroup-uniform)
+  if constexpr (DIFF) {
+    // (the differences are ONE run: a "row" as long as the stream, written from its first symbol)
+    S.kind = 0;
+    S.RS = 0xFFFFFFF0u;
+    S.keep = 0xFFFFFFF0u;
+    S.out_x = S.out_y = S.pitch = 0;
+    S.n_strips = 0;
+  }
   const uint32_t lb = b - S.first_block;
   // A stream that some workgroup has given up on (periodic data, an invalid code, ...) is
   // redone by the multi-kernel pipeline anyway: leave records the workgroups in flight
@@ -1510,7 +1533,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       lb_[k] = lf_pmod(ph0 + k, S.tp) << 11;
     lf_groups<N, 0, 2>(fs, vbase_own, pend, R, lb_[0], lb_[1], lb_[2], lb_[3]);
   } else {
-    lf_groups<N, 0>(fs, vbase_own, pend, R);
+    lf_groups<N, 0, 0, DIFF>(fs, vbase_own, pend, R);
   }
   LF_STAMP(5);
   // the granules of the flagged workgroups in front (1.7 % of them: 0.24 per lane on
@@ -1653,7 +1676,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
         w = rec_st(F.rec[idx - 1]);
         if (w & ST_ERR) // (listed for its own sake: from the state it started from)
           w = rec_su(F.rec[idx]) & SMASK;
-        lf_redecode<N, TM>(F, a.tables + S.table_base, S.tabsel, S.tp, int(idx), w, F.ob[idx],
+        lf_redecode<N, TM, DIFF>(F, a.tables + S.table_base, S.tabsel, S.tp, int(idx), w, F.ob[idx],
                            lds_addr(F.side) + (le >> 8) * LF_SIDE_STRIDE, mine, e, c, sums, ovf);
       }
       lds_barrier(); // every read of the records precedes the updates
@@ -1906,20 +1929,31 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     // (register pair q holds the lane's symbols 2q, 2q + 1, i.e. relative components 2q mod N,
     // 2q + 1 mod N: N = 1, 2 one constant, N = 4 two in turn, N = 3 three in turn -- (0, 1),
     // (2, 0), (1, 2))
-    const uint32_t k0 = N == 1 ? (pexrel.x & 0xFFFFu) * 0x10001u : pexrel.x;
+    const uint32_t k0 = DIFF ? 0u : (N == 1 ? (pexrel.x & 0xFFFFu) * 0x10001u : pexrel.x);
     const uint32_t k1 = N == 4 ? pexrel.y
                                : (N == 3 ? pack16(pexrel.y, pexrel.x) : k0);
     const uint32_t k2 = N == 3 ? pack16(pexrel.x >> 16, pexrel.y) : k0;
     lf_stage<N, 0>(R, ad, nq, nqmax, k0, k1, k2);
     if ((cnt_eff & 1u) && cnt_eff == my_cnt) {
       const uint32_t k = cnt_eff - 1;
-      const uint32_t v = fld(my_sums, lf_mod<N>(k)) + fld(pexrel, lf_mod<N>(k));
+      const uint32_t v = fld(my_sums, lf_mod<N>(k)) + (DIFF ? 0u : fld(pexrel, lf_mod<N>(k)));
       *(lds_u16w)(ad + 2u * k) = uint16_t(v);
     }
   }
   lds_barrier();
   LF_STAMP(10);
 
+  WalkStart walk0{0, 0, 0, 1, 0, 0, 0xFFFFFFFFu};
+  if constexpr (DIFF) {
+    // (differences: no rows, no predictor state to carry -- the constants of the one run are zero)
+    if (j == 0)
+      F.ctab[0] = make_uint2(0u, 0u);
+    (void)Cloc;
+    (void)Vsum;
+    (void)lb1_flags;
+    (void)lb1_al;
+    (void)S_abs;
+  } else {
   // 7. rows.  Lane t takes stream row r0 + t: for each component whose first-MCU symbol
   // r * RS + c lies in the workgroup, E = Ploc before it (the staged sample N back, 0 at
   // the workgroup's start) and D = its difference.
@@ -2002,7 +2036,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     lb1_al = al;
   }
   const uint2 init = S.init;
-  const WalkStart walk0 = lf_walk_start(F, S, base); // (the strips are in LDS since phase one)
+  walk0 = lf_walk_start(F, S, base); // (the strips are in LDS since phase one)
   // 8. look-back 1
   uint2 T_in = init, V_in = init;
   {
@@ -2046,6 +2080,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       F.ctab[j] = C;
     }
   }
+  }
   if (F.misc[M_SLOW] != 0 && j == 0) {
     atomicOr(&a.results[s].flags, FL_SLOW);
 #ifdef RSX_EXPERIMENT
@@ -2060,7 +2095,8 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   LF_STAMP(14);
   // 9. copy-out
   if (fits && any_out && !(LF_ABLATE & 3u))
-    lf_copy_out2<N>(F, a, S, base, lim, sb, r0, j, walk0);
+    lf_copy_out2<N>(F, a, S, base, lim, sb, r0, j, walk0,
+                    DIFF ? reinterpret_cast<uint8_t*>(a.diffs + S.diff_offset) : a.out_base + S.img_offset);
 #ifdef RSX_EXPERIMENT
   // K0's count of the slot against this kernel's (the first slot of the stream that differs)
   if (j >= 1 && a.sub_sums && own_bits != 0u) {
@@ -2130,7 +2166,30 @@ uint32_t ljpeg_fast_stage_cap(uint32_t lds_bytes) {
   return (lds_bytes - LF_TAIL_BYTES - LF_STAGE_BASE - 16u) / 2u;
 }
 
+// (streams that leave differences: <1, 0, MODE, true>)
+static void launch_fast_diffs(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
+  if (!f.diffs)
+    return;
+  const bool probe = (a.fast_level_mask & (a.fast_level_mask - 1u)) != 0u;
+  for (uint32_t lv = 0; lv < 3; ++lv) {
+    if (!((a.fast_level_mask >> lv) & 1u))
+      continue;
+    if (a.dev_layout)
+      hipLaunchKernelGGL((lj_fast_kernel<1, 0, 2, true>), dim3(a.blk_n), dim3(LJ_T), a.fast_lds_lv[lv], s, a,
+                         a.fast_lds_lv[lv], lv);
+    else if (probe)
+      hipLaunchKernelGGL((lj_fast_kernel<1, 0, 1, true>), dim3(a.blk_n), dim3(LJ_T), a.fast_lds_lv[lv], s, a,
+                         a.fast_lds_lv[lv], lv);
+    else
+      hipLaunchKernelGGL((lj_fast_kernel<1, 0, 0, true>), dim3(a.blk_n), dim3(LJ_T), a.fast_lds_lv[lv], s, a,
+                         a.fast_lds_lv[lv], lv);
+    if (timer)
+      timer->mark(lv == 0 ? "lj_fast_kernel<differences>" : "lj_fast_kernel<differences>(fewer/CU)");
+  }
+}
+
 void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
+  launch_fast_diffs(a, f, s, timer);
   launch_fast_one<1, 0>(a, f, s, timer);
   launch_fast_one<2, 0>(a, f, s, timer);
   launch_fast_one<3, 0>(a, f, s, timer);

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(VS_T) void lj_vseed_kernel(LjArgs a) {
   const LjStreamDev& S = a.streams[s];
   if (a.results[s].status != 0 || S.kind == 2)
     return;
-  if (!lj_legacy_takes(a, s, S))
+  if (!lj_recon_takes(a, s, S))
     return; // reconstructed by the fused decode (rsx_ljpeg_direct.hip)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // (the stream record is read once: stores to V could alias it for the compiler)
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_kernel(LjArgs a) {
   if (int(S.n_comp) != N || int(S.period) != P || S.kind == 2 ||
       a.results[lo].status != 0)
     return;
-  if (!lj_legacy_takes(a, lo, S))
+  if (!lj_recon_takes(a, lo, S))
     return;
   const uint32_t r = grow - S.first_row;
   if (r >= S.rows)
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(LJ_T) void lj_predict_fast_kernel(LjArgs a) {
   if (int(S.n_comp) != N || int(S.period) != N || S.kind == 2 ||
       a.results[lo].status != 0)
     return;
-  if (!lj_legacy_takes(a, lo, S))
+  if (!lj_recon_takes(a, lo, S))
     return;
   const uint32_t r = grow - S.first_row;
   if (r >= S.rows)
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(VS_T) void nk_vseed_kernel(LjArgs a) {
   __shared__ int32_t carry_s[4];
   const uint32_t s = blockIdx.x;
   const LjStreamDev& S = a.streams[s];
-  if (S.kind != 2 || a.results[s].status != 0)
+  if (S.kind != 2 || a.results[s].status != 0 || lj_recon_skips_given_up(a, s, S))
     return;
   const NkStreamDev& K = a.nk[s];
   if (K.sony)
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(LJ_T) void nk_predict_kernel(LjArgs a) {
       hi = mid - 1;
   }
   const LjStreamDev& S = a.streams[lo];
-  if (S.kind != 2 || a.results[lo].status != 0)
+  if (S.kind != 2 || a.results[lo].status != 0 || lj_recon_skips_given_up(a, lo, S))
     return;
   const NkStreamDev& K = a.nk[lo];
   if (K.sony)

@@ -38,10 +38,10 @@ def kernel_descriptors():
         text = open(out).read()
     found = {}
     for m in re.finditer(
-            r"\.amdhsa_kernel (\S*lj_fast_kernelILi(\d)ELb([01])ELb([01])E\S*)(.*?)\.end_amdhsa_kernel",
+            r"\.amdhsa_kernel (\S*lj_fast_kernelILi(\d)ELi(\d)ELi(\d)ELb([01])E\S*)(.*?)\.end_amdhsa_kernel",
             text, re.S):
-        body = m.group(5)
-        found[(int(m.group(2)), bool(int(m.group(3))), bool(int(m.group(4))))] = {
+        body = m.group(6)
+        found[(int(m.group(2)), int(m.group(3)), int(m.group(4)), bool(int(m.group(5))))] = {
             k: int(re.search(r"\.amdhsa_%s (\d+)" % k, body).group(1))
             for k in ("group_segment_fixed_size", "private_segment_fixed_size",
                       "next_free_vgpr")}
@@ -49,11 +49,14 @@ def kernel_descriptors():
 
 
 def test_single_pass_kernel_has_no_static_lds(kernel_descriptors):
-    # (components, two alternating tables, the first run's instantiation that looks at the LDS
-    # level before it asks for anything else)
-    assert set(kernel_descriptors) == {(n, mt, probe) for probe in (False, True) for n, mt in
-                                       ((1, False), (2, False), (3, False), (4, False), (2, True),
-                                        (4, True))}
+    # (components; tables: 0 one, 1 two alternating, 2 one per phase of the MCU; mode: 0 steady,
+    # 1 the first run's instantiation that looks at the LDS level before it asks for anything
+    # else, 2 the same with the scalar-cache refresh of device-resident layouts; differences
+    # instead of pixels -- the Nikon-type / Pentax / sRaw route, one component, one table)
+    pixels = {(n, tm, mode, False) for mode in (0, 1, 2) for n, tm in
+              ((1, 0), (2, 0), (3, 0), (4, 0), (2, 1), (4, 1), (2, 2), (3, 2), (4, 2))}
+    differences = {(1, 0, mode, True) for mode in (0, 1, 2)}
+    assert set(kernel_descriptors) == pixels | differences
     for n, k in kernel_descriptors.items():
         assert k["group_segment_fixed_size"] == 0, (n, k)
 
@@ -65,7 +68,8 @@ def test_single_pass_kernel_fits_four_workgroups_per_cu(kernel_descriptors):
 
 
 def test_unstuff_kernel_keeps_seven_workgroups_per_cu():
-    """K0 (both instantiations: plans without / with two-table streams): seven workgroups of
+    """K0 (its instantiations: plans with one-table streams only / with two alternating tables /
+    with a table per phase, each without and with the scalar-cache refresh): seven workgroups of
     four wavefronts a CU are seven wavefronts a SIMD -- at most 72 vector registers each, no
     scratch -- and 18 LDS granules of 1280 bytes (a static_assert in the source checks the
     two-table layout's size)."""
@@ -79,12 +83,12 @@ def test_unstuff_kernel_keeps_seven_workgroups_per_cu():
         text = open(out).read()
     seen = set()
     for m in re.finditer(
-            r"\.amdhsa_kernel (\S*lj_unstuff_kernelILb([01])E\S*)(.*?)\.end_amdhsa_kernel",
+            r"\.amdhsa_kernel (\S*lj_unstuff_kernelILi(\d)ELb([01])E\S*)(.*?)\.end_amdhsa_kernel",
             text, re.S):
-        body = m.group(3)
+        body = m.group(4)
         get = lambda k: int(re.search(r"\.amdhsa_%s (\d+)" % k, body).group(1))
-        seen.add(bool(int(m.group(2))))
+        seen.add((int(m.group(2)), bool(int(m.group(3)))))
         assert get("next_free_vgpr") <= 72, (m.group(1), get("next_free_vgpr"))
         assert get("private_segment_fixed_size") == 0
         assert get("group_segment_fixed_size") == 0
-    assert seen == {False, True}
+    assert seen == {(km, inv) for km in (0, 1, 2) for inv in (False, True)}
