@@ -60,6 +60,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <type_traits>
 
@@ -3625,6 +3626,7 @@ struct LJpegPlan {
   bool any_fast_mt = false;     // some stream takes its two-table instantiation
   bool any_fast_pt = false;     // ... its table-per-phase instantiation (LjStreamDev::fast == 3)
   uint32_t pt_np = 2;           // the most phases such a stream has (sizes K0's LDS)
+  bool any_fast_nk = false;     // ... writes the pixels of a Nikon-type stream (fast_nk)
   bool any_fast_diffs = false;  // ... leaves differences for the legacy reconstruction (fast_diffs)
   DeviceBuffer d_k0e;           // K0's hand-over words (LjArgs::k0e)
   DeviceBuffer d_k0p;           // K0's phase look-back words (LjArgs::k0p), table-per-phase plans
@@ -3915,6 +3917,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
   std::vector<DeviceHuffTable> tables;
   std::vector<Cr2Strip> strips;
   std::vector<uint32_t> nk_tables, nk_rowpow;
+  std::map<uint32_t, uint32_t> nk_colpow_of; // row length -> its column powers in nk_rowpow
   for (size_t i = 0; i < jobs.size(); ++i) {
     const LJpegJobIn& J = jobs[i];
     int st = J.status;
@@ -4052,9 +4055,41 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     // leaves the differences where lj_decode_kernel would have (its <1, 0, ., true> instantiation),
     // the reconstruction kernels follow in the same pass.  What it gives up on is redone by the
     // legacy route's own decode, like a three-component stream's.
+    // ... and a Nikon-type stream -- NikonDecompressor without a split, PentaxDecompressor with at most
+    // 15 bits -- has its PIXELS written by that kernel (fast_nk: the <2, 0, ., false, true>
+    // instantiation; the vertical sums by row parity, curve and dither in the copy-out).  The kernel's
+    // sums are mod 2^16: a value outside 0 .. 32767 (outside the sensor's bits for Pentax) hands the
+    // stream to the legacy route, whose sums are the reference's ints.
+    // (RSX_NO_FAST_NK / RSX_NO_FAST_DIFFS in the environment: the route one further back, for the
+    // tests that compare the routes and for A/B timings)
+    const bool env_no_nk = getenv("RSX_NO_FAST_NK") != nullptr;
+    const bool env_no_diffs = getenv("RSX_NO_FAST_DIFFS") != nullptr;
+    S.fast_nk = 0;
+#ifndef RSX_NO_FAST_NK
+    if (!env_no_nk && !S.fast && !direct_n && g.kind == 2 && J.n_tables == 1 && J.explicit_n == 0 && !g.las && !g.pair &&
+        tables.size() < 0xFFFFu && needed >= 2 && g.row_samples >= 2 && g.row_samples % 2 == 0) {
+      const NikonIn& N = J.nikon;
+      bool ok = !N.sony && N.pup_in == nullptr && !(N.split > 0 && N.split < N.height) &&
+                (!N.pentax || (N.range_bits >= 1 && N.range_bits <= 16)) &&
+                (N.uncorrected || N.pentax || N.dither.size() == 32768);
+      // (Pentax with 16 bits: a value from 32768 on could as well be a negative int -- the legacy
+      // route's to tell)
+      const int lim = N.pentax && N.range_bits < 15 ? (1 << N.range_bits) : 32768;
+      for (int k = 0; k < 4 && ok; ++k)
+        ok = N.p_up[k] >= 0 && N.p_up[k] < lim;
+      if (ok) {
+        S.fast = 1;
+        S.fast_nk = 1;
+        // (pUp by the parity of the STREAM row: stream row r is image row out_y + r)
+        for (uint32_t h = 0; h < 2; ++h)
+          for (uint32_t c = 0; c < 2; ++c)
+            S.init_pred[2 * h + c] = uint16_t(N.p_up[2 * ((g.out_y + h) & 1u) + c]);
+      }
+    }
+#endif
     S.fast_diffs = 0;
 #ifndef RSX_NO_FAST_DIFFS
-    if (!S.fast && !direct_n && J.n_tables == 1 && J.explicit_n == 0 && !g.las && !g.pair &&
+    if (!env_no_diffs && !S.fast && !direct_n && J.n_tables == 1 && J.explicit_n == 0 && !g.las && !g.pair &&
         (g.kind == 2 || g.kind == 1 || g.kind == 0) && !(g.kind == 2 && J.nikon.sony) &&
         tables.size() < 0xFFFFu && needed >= 1) {
       S.fast = 1;
@@ -4144,6 +4179,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         nk_tables.insert(nk_tables.end(), N.dither.begin(), N.dither.end());
       // 15700^(y * W) mod m for the stream's rows: the dither state at (y, 0)
       K.rowpow_off = uint32_t(nk_rowpow.size());
+      K.colpow_off = 0;
       if (!N.uncorrected) {
         const uint64_t m = 15700ull * 65536 - 1;
         auto powmod = [&](uint64_t e) {
@@ -4157,6 +4193,17 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         uint64_t cur = powmod(uint64_t(g.out_y) * g.row_samples);
         for (uint32_t r = 0; r < g.rows; ++r, cur = cur * step % m)
           nk_rowpow.push_back(uint32_t(cur));
+        if (S.fast_nk) {
+          // 15700^x mod m for the columns (one list per row length of the plan)
+          auto it = nk_colpow_of.find(g.row_samples);
+          if (it == nk_colpow_of.end()) {
+            it = nk_colpow_of.emplace(g.row_samples, uint32_t(nk_rowpow.size())).first;
+            uint64_t c = 1;
+            for (uint32_t x = 0; x < g.row_samples; ++x, c = c * 15700 % m)
+              nk_rowpow.push_back(uint32_t(c));
+          }
+          K.colpow_off = it->second;
+        }
       }
       p->any_nikon = true;
       if (N.split > 0 && N.pup_in == nullptr && g.out_y == 0 &&
@@ -4194,6 +4241,8 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         p->pt_np = std::max(p->pt_np, uint32_t(S.tab_period));
       if (S.fast_diffs)
         p->any_fast_diffs = true;
+      else if (S.fast_nk)
+        p->any_fast_nk = true;
       else
         p->fast_present[S.fast - 1][S.direct ? S.direct : g.n_comp] = true;
     } else {
@@ -4956,6 +5005,7 @@ static int ljpeg_plan_run_blocks_(LJpegPlan* p, hipStream_t s, uint32_t blk0, ui
     fl.total_blocks = a.blk_n;
     std::memcpy(fl.present, p->fast_present, sizeof fl.present);
     fl.diffs = p->any_fast_diffs;
+    fl.nk = p->any_fast_nk;
     // one single-pass launch of a context at a time (rsx_ctx::fast_mu)
     std::lock_guard<std::mutex> g(ctx->fast_mu);
     if (ctx->fast_ev_valid && ctx->fast_ev_stream != s)

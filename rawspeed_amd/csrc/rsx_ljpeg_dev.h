@@ -147,7 +147,14 @@ struct LjStreamDev {
   uint8_t fast_diffs;  // fast != 0: the single-pass kernel leaves the stream's DIFFERENCES (int16, stream
                        // order, at diff_offset) for the legacy reconstruction kernels instead of pixels
                        // -- Nikon-type predictors, Pentax, Canon sRaw groups: one table (round 6)
-  uint8_t pad_fast_[2];
+  uint8_t fast_nk;     // fast != 0: a Nikon-type stream (kind 2: stride-2 left predictor, the first pair of
+                       // a row predicted from the row TWO above, NikonDecompressor.cpp:518-560 /
+                       // PentaxDecompressor.cpp:155-177) whose PIXELS the single-pass kernel writes, curve
+                       // and dither in its copy-out; init_pred holds pUp by STREAM-row parity
+                       // ([2 * (r & 1) + c]).  The kernel's sums are mod 2^16, the reference's plain ints:
+                       // a value with bit 15 set (Pentax: one that does not fit range_bits) gives the
+                       // stream to the legacy route, whose ints say what it really was
+  uint8_t pad_fast_[1];
   uint32_t rows;
   uint32_t row_samples;
   uint32_t first_row; // global stream-row index
@@ -174,7 +181,7 @@ struct NkStreamDev {
   uint32_t sony;         // != 0: SonyArw1Decompressor (.cpp:59-93): stream row r = image column
                          //    W-1-r (even rows, then odd rows), one predictor through all rows,
                          //    values outside 0..4095 are RSX_ERR_VALUE_RANGE
-  uint32_t pad_;
+  uint32_t colpow_off;   // fast_nk with dither: first entry in nk_rowpow of 15700^x mod m, x < row_samples
 };
 
 struct LjResult {
@@ -362,8 +369,12 @@ __device__ __forceinline__ bool lj_recon_takes(const LjArgs& a, uint32_t s, cons
     return true;
   return S.fast != 0 && S.fast_diffs != 0 && a.pass == 0 && !(a.results[s].flags & FL_SLOW);
 }
-// (the Nikon-type kernels take every stream of their kind: not the ones given up in the first pass)
+// (the Nikon-type kernels take every stream of their kind: not the ones given up in the first pass,
+// and of the streams whose pixels the single-pass kernel writes (fast_nk) only those it gave up on,
+// in the pass that redoes them)
 __device__ __forceinline__ bool lj_recon_skips_given_up(const LjArgs& a, uint32_t s, const LjStreamDev& S) {
+  if (S.fast != 0 && S.fast_nk != 0)
+    return !(a.pass != 0 && (a.results[s].flags & FL_SLOW) != 0);
   return S.fast != 0 && S.fast_diffs != 0 && a.pass == 0 && (a.results[s].flags & FL_SLOW) != 0;
 }
 
@@ -409,6 +420,7 @@ struct FastLaunch {
   uint32_t total_blocks = 0;
   bool present[3][5] = {}; // [one table / two alternating / a table per phase][components]
   bool diffs = false;      // some stream leaves differences (fast_diffs): the <1, 0, ., true> instantiation
+  bool nk = false;         // some Nikon-type stream's pixels (fast_nk): the <2, 0, ., false, true> instantiation
 };
 void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t stream,
                        KernelTimer* timer);

@@ -836,6 +836,7 @@ struct FastStream {
   uint32_t tabsel; // the stream's table of phase k (symbol index mod N) in bits 4k .. 4k + 3
   uint32_t tp;     // tm == 2: the period of that assignment (2, 3, 4): a state's phase is mod this
   uint32_t diffs;  // the stream leaves differences for the legacy reconstruction (fast_diffs)
+  uint32_t nk;     // a Nikon-type stream whose pixels this kernel writes (fast_nk)
   uint64_t diff_offset;
   uint32_t first_block, first_subseq, table_base, start_bit, n_blocks;
   uint32_t RS, kind, keep, out_x, out_y, pitch, n_strips, strip_base;
@@ -850,9 +851,11 @@ __device__ __forceinline__ FastStream lf_stream(const LjStreamDev& S) {
   // (3 components, round 5: not a stream of the fused multi-kernel path -- direct == 0 --, so
   // the number of components says which instantiation takes it)
   f.diffs = uni(S.fast && S.fast_diffs ? 1u : 0u);
+  f.nk = uni(S.fast && S.fast_nk ? 1u : 0u);
   f.diff_offset = uni64(S.diff_offset);
-  // (a stream that leaves differences is one "component": its symbols in stream order)
-  f.fast_n = uni(S.fast ? (f.diffs ? 1u : (S.direct ? uint32_t(S.direct) : S.n_comp)) : 0u);
+  // (a stream that leaves differences is one "component": its symbols in stream order; a Nikon-type
+  // row is two interleaved ones, the columns' parities)
+  f.fast_n = uni(S.fast ? (f.diffs ? 1u : (f.nk ? 2u : (S.direct ? uint32_t(S.direct) : S.n_comp))) : 0u);
   f.tm = uni(S.fast >= 2 ? uint32_t(S.fast) - 1u : 0u);
   f.tabsel = uni(f.tm ? (uint32_t(S.tab_of_phase[0] & 15u) | (uint32_t(S.tab_of_phase[1] & 15u) << 4) |
                          (uint32_t(S.tab_of_phase[2] & 15u) << 8) |
@@ -933,11 +936,30 @@ __device__ __forceinline__ WalkStart lf_walk_start(const FastLds& F, const FastS
   return w;
 }
 
-template <int N>
+// What the copy-out of a Nikon-type stream (fast_nk) does to a value on its way out
+// (NikonDecompressor.cpp:518-560: rawdata->setWithLookUp(clampBits(pLeft, 15), dest, &random);
+// PentaxDecompressor.cpp:155-177: the value must fit the sensor's bits, stored as it is).
+struct NkOut {
+  uint32_t dither;      // the curve with its dither (TableLookUp's dither form, common/RawImage.h:335-353)
+  uint32_t limit_shift; // a value v with v >> limit_shift != 0 gives the stream to the legacy route
+  uint32_t seed;        // the 24 bits at the stream's start: the dither generator's first state
+  const uint32_t* tab;    // 32768 x (base | delta << 16)
+  const uint32_t* rowpow; // 15700^(pixels in front of stream row r) mod m
+  const uint32_t* colpow; // 15700^x mod m, x < RS
+  uint32_t* flags;        // the stream's LjResult::flags
+};
+// (the generator is a lag-1 multiply-with-carry: r' = 15700 (r & 65535) + (r >> 16), i.e.
+// r_n = r_0 15700^n mod m, m = 15700 * 2^16 - 1 -- rsx_ljpeg_recon.hip has the argument)
+__device__ __forceinline__ uint32_t lf_nk_mulmod(uint32_t x, uint32_t y) {
+  return uint32_t((uint64_t(x) * y) % (15700ull * 65536ull - 1ull));
+}
+
+template <int N, bool NK = false>
 __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
                                              const FastStream& S, uint32_t A0_, uint32_t A1_,
                                              uint32_t sb, uint32_t r0_, int tid,
-                                             const WalkStart& ws, uint8_t* img) {
+                                             const WalkStart& ws, uint8_t* img,
+                                             const NkOut& nk = NkOut{}) {
   const uint32_t lane = uint32_t(tid) & 63u;
   const uint32_t wv = uni(uint32_t(tid) >> 6);
   // (every lane holds the same values: said so, or the walk below runs on vector registers)
@@ -955,6 +977,10 @@ __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
     C = make_uint2(uni(Cv.x), uni(Cv.y));
   }
   uint32_t gseg = 0; // segments dealt so far
+  uint32_t rowst = 0; // (Nikon-type with dither: the generator's state at the row's first pixel)
+  if constexpr (NK)
+    if (nk.dither)
+      rowst = uni(lf_nk_mulmod(uni(nk.seed), nk.rowpow[r]));
   while (i < A1) {
     uint32_t n;
     uint8_t* dst = nullptr;
@@ -1008,6 +1034,62 @@ __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
             const uint32_t cc = N == 3 ? (m3 == 0u ? cd[t] : (m3 == 1u ? cd1[t] : cd2[t])) : cd[t];
             o[t] = pk_add(__builtin_amdgcn_alignbit(dw[t + 1], dw[t], sh), cc);
           }
+          if constexpr (NK) {
+            // (the sums are mod 2^16, the reference's are ints: as long as every value so far was
+            // inside 0 .. 2^limit_shift - 1 <= 32767 and a difference is at most 2^15 in size, the
+            // next one is outside as an int exactly if it is outside mod 2^16)
+            const uint32_t over = ((0xFFFFu << nk.limit_shift) & 0xFFFFu) * 0x10001u;
+            if (sf >= 0 && uint32_t(sf) + 8u <= n) {
+              // a whole chunk (nearly all of them)
+              if ((o[0] | o[1] | o[2] | o[3]) & over)
+                atomicOr(nk.flags, FL_SLOW);
+              if (nk.dither) {
+                // (the eight table entries are asked for at once, the generator's steps follow)
+                uint32_t e[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                  e[t] = nk.tab[(o[t >> 1] >> (16 * (t & 1))) & 0x7FFFu];
+                uint32_t st = lf_nk_mulmod(rowst, nk.colpow[sidx + uint32_t(sf)]);
+                uint32_t v[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                  v[t] = ((e[t] & 0xFFFFu) + (((e[t] >> 16) * (st & 2047u) + 1024u) >> 12)) & 0xFFFFu;
+                  st = 15700u * (st & 65535u) + (st >> 16);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                  o[t] = v[2 * t] | (v[2 * t + 1] << 16);
+              }
+            } else {
+              // a run's first or last chunk: its samples qa <= t < qb belong to the run
+              const int32_t qa = sf < 0 ? -sf : 0;
+              const int32_t qb = int32_t(n) - sf < 8 ? int32_t(n) - sf : 8;
+              uint32_t v[8], e[8], bad = 0;
+#pragma unroll
+              for (int t = 0; t < 8; ++t) {
+                v[t] = (o[t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
+                bad |= (t >= qa && t < qb) ? (v[t] & over) : 0u;
+              }
+              if (bad)
+                atomicOr(nk.flags, FL_SLOW);
+              if (nk.dither) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                  e[t] = nk.tab[v[t] & 0x7FFFu]; // (every lane, every sample: no load behind a branch)
+                uint32_t st = lf_nk_mulmod(rowst, nk.colpow[sidx + uint32_t(sf + qa)]);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                  const bool in = t >= qa && t < qb;
+                  const uint32_t px = ((e[t] & 0xFFFFu) + (((e[t] >> 16) * (st & 2047u) + 1024u) >> 12)) & 0xFFFFu;
+                  v[t] = in ? px : v[t];
+                  st = in ? 15700u * (st & 65535u) + (st >> 16) : st;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                  o[t] = v[2 * t] | (v[2 * t + 1] << 16);
+              }
+            }
+          }
           uint8_t* p = d0 + 16u * m;
           if (LF_ABLATE & 256u) { // (experiment: everything but the stores)
             asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(p));
@@ -1038,6 +1120,9 @@ __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
       if (i < A1) {
         const uint2 Cv = F.ctab[r - r0];
         C = make_uint2(uni(Cv.x), uni(Cv.y));
+        if constexpr (NK)
+          if (nk.dither)
+            rowst = uni(lf_nk_mulmod(uni(nk.seed), nk.rowpow[r]));
       }
     }
     if (S.kind == 1) {
@@ -1134,11 +1219,19 @@ __device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad
 // for the others, and leaves the DIFFERENCES in stream order where lj_decode_kernel would have --
 // no rows, no look-back 1, one contiguous run to write -- in place of the multi-kernel pipeline's
 // warm-up + recorded pass + stitch passes + final decode of such streams.
-template <int N, int TM, int MODE, bool DIFF = false>
+// NK (round 6): a Nikon-type stream's PIXELS (fast_nk).  Its row is two interleaved components (the
+// columns' parities, pLeft1 / pLeft2), but the first pair of a row is predicted from the row TWO
+// above (pUp1 / pUp2 by the row's parity): the vertical sums Vc have FOUR fields -- .x the two
+// components of the even stream rows, .y of the odd ones -- and so has the open row's state T, of
+// which a workgroup reads the half of the row that is open when it starts (the other half carries
+// whatever the transfers add to it: nobody looks).  A transfer stays field-wise: a component that
+// starts a row here sets the field of THAT row's parity from the same field of Vc.
+template <int N, int TM, int MODE, bool DIFF = false, bool NK = false>
 __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds_bytes,
                                                           uint32_t level) {
   constexpr bool PROBE = MODE >= 1, INV = MODE == 2;
   static_assert(!DIFF || (N == 1 && TM == 0), "differences: one table, symbols in stream order");
+  static_assert(!NK || (N == 2 && TM == 0 && !DIFF), "Nikon-type pixels: one table, two column parities");
   constexpr bool MT = TM == 1, PT = TM == 2; // two alternating tables / a table per phase
   constexpr uint32_t TICKET0 = (MT ? 12u : 0u) + (N == 4 ? 2u : (N == 3 ? 3u : uint32_t(N) - 1u));
   // offset (| table bit of the next symbol | its phase, two bits)
@@ -1337,8 +1430,16 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   if (uni(chosen_now) != level)
     return; // this run's workgroups need another LDS level: that launch does the work
 #endif
-  if (int(S.fast_n) != N || int(S.tm) != TM || (S.diffs != 0u) != DIFF)
+  if (int(S.fast_n) != N || int(S.tm) != TM || (S.diffs != 0u) != DIFF || (S.nk != 0u) != NK)
     return; // (workgroup-uniform)
+  NkOut nko{};
+  if constexpr (NK) {
+    // (a row of the stream is a row of the image, all of it kept, from column 0)
+    S.kind = 0;
+    S.keep = S.RS;
+    S.out_x = 0;
+    S.n_strips = 0;
+  }
   if constexpr (DIFF) {
     // (the differences are ONE run: a "row" as long as the stream, written from its first symbol)
     S.kind = 0;
@@ -1977,7 +2078,11 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
       }
     }
     const uint2 E = make_uint2(ev[0] | (ev[1] << 16), ev[2] | (ev[3] << 16));
-    const uint2 D = make_uint2(dv[0] | (dv[1] << 16), dv[2] | (dv[3] << 16));
+    uint2 D = make_uint2(dv[0] | (dv[1] << 16), dv[2] | (dv[3] << 16));
+    // (Nikon-type: the row's pair goes to the half of its parity)
+    const bool rodd = NK && ((r0 + uint32_t(j)) & 1u) != 0u;
+    if (rodd)
+      D = make_uint2(0u, D.x);
     const uint2 dincl = wave_scan_pk2(D, lane);
     if (lane == 63) {
       F.misc[M_RSUM + 2 * wv] = dincl.x;
@@ -1991,7 +2096,7 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
         vex = pk_add2(vex, t);
       Vsum = pk_add2(Vsum, t);
     }
-    Cloc = pk_sub2(vex, E);
+    Cloc = NK ? make_uint2(pk_sub(rodd ? vex.y : vex.x, E.x), 0u) : pk_sub2(vex, E);
     if (uint32_t(j) < nr && nr <= uint32_t(LF_RMAX))
       F.ctab[j] = Cloc;
   }
@@ -2013,7 +2118,15 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
           tl = int(nr) - 1;
         else if (nr >= 2 && uint64_t(r_end - 1) * RS + c >= base)
           tl = int(nr) - 2;
-        if (tl >= 0) {
+        if constexpr (NK) {
+          // (both halves carry the component's sum; the half of the started row's parity is set)
+          av[c] = av[c + 2u] = fld(S_abs, c);
+          if (tl >= 0) {
+            const uint32_t h = 2u * ((r0 + uint32_t(tl)) & 1u);
+            flags |= 1u << (c + h);
+            av[c + h] = (fld(F.ctab[tl], c) + fld(S_abs, c)) & 0xFFFFu;
+          }
+        } else if (tl >= 0) {
           flags |= 1u << c;
           av[c] = (fld(F.ctab[tl], c) + fld(S_abs, c)) & 0xFFFFu;
         } else {
@@ -2021,8 +2134,10 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
         }
       }
       al = make_uint2(av[0] | (av[1] << 16), av[2] | (av[3] << 16));
+    } else if constexpr (NK) {
+      al = make_uint2(S_abs.x, S_abs.x);
     }
-    constexpr int NW = (N + 1) / 2;
+    constexpr int NW = NK ? 2 : (N + 1) / 2;
     if (j == 0) {
       u64* p = a.lb + size_t(b) * LF_LB_WORDS;
       lb_store(p + lb_wv(0), LB_VALID | Vsum.x);
@@ -2035,17 +2150,32 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     lb1_flags = flags;
     lb1_al = al;
   }
+  if constexpr (NK) {
+    // what the copy-out needs of the stream's Nikon record, and the dither generator's seed -- the
+    // 24 bits at the stream's start --: asked for here, in the shadow of look-back 1's wait
+    const NkStreamDev& K = a.nk[s];
+    nko.dither = uni(K.uncorrected == 0u && K.pentax == 0u ? 1u : 0u);
+    nko.limit_shift = uni(K.pentax != 0u && K.pentax < 15u ? K.pentax : 15u);
+    nko.tab = a.nk_tables + uni(K.table_off);
+    nko.rowpow = a.nk_rowpow + uni(K.rowpow_off);
+    nko.colpow = a.nk_rowpow + uni(K.colpow_off);
+    nko.flags = &a.results[s].flags;
+    if (nko.dither) {
+      const uint8_t* in0 = a.in_base + uni64(K.seed_offset);
+      nko.seed = (uint32_t(in0[0]) << 16) | (uint32_t(in0[1]) << 8) | in0[2];
+    }
+  }
   const uint2 init = S.init;
   walk0 = lf_walk_start(F, S, base); // (the strips are in LDS since phase one)
   // 8. look-back 1
   uint2 T_in = init, V_in = init;
   {
-    constexpr int NW = (N + 1) / 2;
+    constexpr int NW = NK ? 2 : (N + 1) / 2;
     const uint32_t flags = lb1_flags;
     const uint2 al = lb1_al;
     bool ok = true;
     if (lb != 0 && !(LF_ABLATE & 8u)) {
-      ok = lb1_walk<N, LF_LB1_WAVES>(a, F, b, S.first_block, init, j, &T_in, &V_in);
+      ok = lb1_walk<NK ? 4 : N, LF_LB1_WAVES>(a, F, b, S.first_block, init, j, &T_in, &V_in);
     }
     if (j == 0) {
       if (!ok)
@@ -2069,13 +2199,16 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
     // workgroup, T_in for the row that is open when it starts
     if (fits && uint32_t(j) < nr) {
       uint2 C = pk_add2(V_in, Cloc);
+      if constexpr (NK) // (the row's parity picks the half; row r0's open state likewise)
+        C = make_uint2(pk_add(((r0 + uint32_t(j)) & 1u) ? V_in.y : V_in.x, Cloc.x), 0u);
+      const uint2 T_row = NK && (r0 & 1u) ? make_uint2(T_in.y, 0u) : T_in;
       if (j == 0) {
         uint32_t present = 0;
 #pragma unroll
         for (uint32_t c = 0; c < uint32_t(N); ++c)
           if (uint64_t(r0) * RS + c >= base)
             present |= 1u << c;
-        C = sel2(fld_mask(present), C, T_in);
+        C = sel2(fld_mask(present), C, T_row);
       }
       F.ctab[j] = C;
     }
@@ -2095,8 +2228,9 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   LF_STAMP(14);
   // 9. copy-out
   if (fits && any_out && !(LF_ABLATE & 3u))
-    lf_copy_out2<N>(F, a, S, base, lim, sb, r0, j, walk0,
-                    DIFF ? reinterpret_cast<uint8_t*>(a.diffs + S.diff_offset) : a.out_base + S.img_offset);
+    lf_copy_out2<N, NK>(F, a, S, base, lim, sb, r0, j, walk0,
+                        DIFF ? reinterpret_cast<uint8_t*>(a.diffs + S.diff_offset) : a.out_base + S.img_offset,
+                        nko);
 #ifdef RSX_EXPERIMENT
   // K0's count of the slot against this kernel's (the first slot of the stream that differs)
   if (j >= 1 && a.sub_sums && own_bits != 0u) {
@@ -2188,8 +2322,31 @@ static void launch_fast_diffs(const LjArgs& a, const FastLaunch& f, hipStream_t 
   }
 }
 
+// (Nikon-type streams' pixels: <2, 0, MODE, false, true>)
+static void launch_fast_nk(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
+  if (!f.nk)
+    return;
+  const bool probe = (a.fast_level_mask & (a.fast_level_mask - 1u)) != 0u;
+  for (uint32_t lv = 0; lv < 3; ++lv) {
+    if (!((a.fast_level_mask >> lv) & 1u))
+      continue;
+    if (a.dev_layout)
+      hipLaunchKernelGGL((lj_fast_kernel<2, 0, 2, false, true>), dim3(a.blk_n), dim3(LJ_T), a.fast_lds_lv[lv],
+                         s, a, a.fast_lds_lv[lv], lv);
+    else if (probe)
+      hipLaunchKernelGGL((lj_fast_kernel<2, 0, 1, false, true>), dim3(a.blk_n), dim3(LJ_T), a.fast_lds_lv[lv],
+                         s, a, a.fast_lds_lv[lv], lv);
+    else
+      hipLaunchKernelGGL((lj_fast_kernel<2, 0, 0, false, true>), dim3(a.blk_n), dim3(LJ_T), a.fast_lds_lv[lv],
+                         s, a, a.fast_lds_lv[lv], lv);
+    if (timer)
+      timer->mark(lv == 0 ? "lj_fast_kernel<nikon-type>" : "lj_fast_kernel<nikon-type>(fewer/CU)");
+  }
+}
+
 void ljpeg_launch_fast(const LjArgs& a, const FastLaunch& f, hipStream_t s, KernelTimer* timer) {
   launch_fast_diffs(a, f, s, timer);
+  launch_fast_nk(a, f, s, timer);
   launch_fast_one<1, 0>(a, f, s, timer);
   launch_fast_one<2, 0>(a, f, s, timer);
   launch_fast_one<3, 0>(a, f, s, timer);

@@ -38,10 +38,11 @@ def kernel_descriptors():
         text = open(out).read()
     found = {}
     for m in re.finditer(
-            r"\.amdhsa_kernel (\S*lj_fast_kernelILi(\d)ELi(\d)ELi(\d)ELb([01])E\S*)(.*?)\.end_amdhsa_kernel",
+            r"\.amdhsa_kernel (\S*lj_fast_kernelILi(\d)ELi(\d)ELi(\d)ELb([01])ELb([01])E\S*)(.*?)\.end_amdhsa_kernel",
             text, re.S):
-        body = m.group(6)
-        found[(int(m.group(2)), int(m.group(3)), int(m.group(4)), bool(int(m.group(5))))] = {
+        body = m.group(7)
+        found[(int(m.group(2)), int(m.group(3)), int(m.group(4)),
+               "differences" if int(m.group(5)) else ("nikon-type" if int(m.group(6)) else "pixels"))] = {
             k: int(re.search(r"\.amdhsa_%s (\d+)" % k, body).group(1))
             for k in ("group_segment_fixed_size", "private_segment_fixed_size",
                       "next_free_vgpr")}
@@ -52,10 +53,12 @@ def test_single_pass_kernel_has_no_static_lds(kernel_descriptors):
     # (components; tables: 0 one, 1 two alternating, 2 one per phase of the MCU; mode: 0 steady,
     # 1 the first run's instantiation that looks at the LDS level before it asks for anything
     # else, 2 the same with the scalar-cache refresh of device-resident layouts; differences
-    # instead of pixels -- the Nikon-type / Pentax / sRaw route, one component, one table)
-    pixels = {(n, tm, mode, False) for mode in (0, 1, 2) for n, tm in
+    # instead of pixels -- the sRaw / Sony / split-Nikon route, one component, one table)
+    pixels = {(n, tm, mode, "pixels") for mode in (0, 1, 2) for n, tm in
               ((1, 0), (2, 0), (3, 0), (4, 0), (2, 1), (4, 1), (2, 2), (3, 2), (4, 2))}
-    differences = {(1, 0, mode, True) for mode in (0, 1, 2)}
+    differences = {(1, 0, mode, "differences") for mode in (0, 1, 2)}
+    # (a Nikon-type stream's pixels: two column parities, one table; the vertical sums by row parity)
+    differences |= {(2, 0, mode, "nikon-type") for mode in (0, 1, 2)}
     assert set(kernel_descriptors) == pixels | differences
     for n, k in kernel_descriptors.items():
         assert k["group_segment_fixed_size"] == 0, (n, k)
