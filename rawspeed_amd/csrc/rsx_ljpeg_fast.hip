@@ -66,6 +66,14 @@ namespace rsx {
 
 namespace {
 
+// (experiment, round 6: -DRSX_LF_WG_PER_CU=5 makes the compiler fit the kernel into the 96 vector
+// registers five workgroups a CU would leave it -- the LDS still holds four: what the registers
+// alone would cost, profiles/r06/ab/five_workgroups_register_cap.txt)
+#ifdef RSX_LF_WG_PER_CU
+constexpr int LF_WG_PER_CU = RSX_LF_WG_PER_CU;
+#else
+constexpr int LF_WG_PER_CU = 4;
+#endif
 constexpr int LF_BW = LJ_PW + 1;        // dword rows of a subsequence the loops can touch
 constexpr int LF_MAXSYM = 128;          // symbols a lane keeps (64 VGPRs)
 constexpr int LF_NR = LF_MAXSYM / 2;
@@ -1018,95 +1026,117 @@ __device__ __forceinline__ void lf_copy_out2(const FastLds& F, const LjArgs& a,
       const uint32_t sh = 8u * (lds0 & 2u); // the staged samples start mid-dword: 16, else 0
       uint8_t* const d0 = dst - 2u * delta;
       const uint32_t nseg = (nch + 63u) >> 6;
+      // chunk m of the run: its eight samples, the row's constants added
+      auto chunk = [&](uint32_t m, uint32_t (&o)[4]) {
+        const uint32_t la = (lds0 + 16u * m) & ~3u;
+        uint32_t dw[5];
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+          dw[t] = *(lds_u32p)(la + 4u * t);
+        const uint32_t m3 = N == 3 ? m % 3u : 0u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const uint32_t cc = N == 3 ? (m3 == 0u ? cd[t] : (m3 == 1u ? cd1[t] : cd2[t])) : cd[t];
+          o[t] = pk_add(__builtin_amdgcn_alignbit(dw[t + 1], dw[t], sh), cc);
+        }
+      };
+      // ... written out (whole, or sample by sample at a run's ends)
+      auto put = [&](uint32_t m, const uint32_t (&o)[4]) {
+        const int32_t sf = int32_t(8u * m) - int32_t(delta);
+        uint8_t* p = d0 + 16u * m;
+        if (LF_ABLATE & 256u) { // (experiment: everything but the stores)
+          asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(p));
+        } else if (sf >= 0 && uint32_t(sf) + 8u <= n) {
+#ifndef RSX_LF_PLAIN_MEM
+          __builtin_nontemporal_store(lf_u32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<lf_u32x4*>(p));
+#else
+          *reinterpret_cast<uint4*>(p) = make_uint4(o[0], o[1], o[2], o[3]);
+#endif
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const int32_t q = sf + t;
+            if (q >= 0 && uint32_t(q) < n)
+              reinterpret_cast<uint16_t*>(p)[t] = uint16_t(o[t >> 1] >> (16 * (t & 1)));
+          }
+        }
+      };
+      // Nikon-type: is a value of the chunk outside what the mod-2^16 sums can vouch for?  (The sums
+      // are mod 2^16, the reference's are ints: as long as every value so far was inside
+      // 0 .. 2^limit_shift - 1 <= 32767 and a difference is at most 2^15 in size, the next one is
+      // outside as an int exactly if it is outside mod 2^16.)  A run's first and last chunk: the
+      // samples qa <= t < qb belong to the run -- what lies next to them in the staging region is
+      // another row's, or nobody's.
+      auto nk_check = [&](uint32_t m, const uint32_t (&o)[4]) {
+        const uint32_t over = ((0xFFFFu << nk.limit_shift) & 0xFFFFu) * 0x10001u;
+        const int32_t sf = int32_t(8u * m) - int32_t(delta);
+        const int32_t qa = sf < 0 ? -sf : 0;
+        const int32_t qb = int32_t(n) - sf < 8 ? int32_t(n) - sf : 8;
+        uint32_t bad = (o[0] | o[1] | o[2] | o[3]) & over;
+        if (qa != 0 || qb != 8) {
+          bad = 0;
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+            bad |= (t >= qa && t < qb) ? (o[t >> 1] >> (16 * (t & 1))) & over & 0xFFFFu : 0u;
+        }
+        if (bad)
+          atomicOr(nk.flags, FL_SLOW);
+      };
+      // ... the curve's entries of its eight values and the generator's power of its first column,
+      // asked for at once (no load behind a branch).  The generator's state belongs to the pixel's
+      // place in decode order, so the state of the chunk's sample 0 is right whether or not the
+      // samples in front of qa are the run's -- they are this row's (a run that starts mid-row), and
+      // what is computed for samples outside the run is not stored.  Only a chunk that begins in
+      // front of the row's first pixel (a row that does not start on the 16-byte grid) starts at qa.
+      auto nk_ask = [&](uint32_t m, const uint32_t (&o)[4], uint32_t (&e)[8], uint32_t& cp, int32_t& first) {
+        const int32_t sf = int32_t(8u * m) - int32_t(delta);
+        const int32_t x0 = int32_t(sidx) + sf;
+        first = x0 >= 0 ? 0 : -sf;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          e[t] = nk.tab[(o[t >> 1] >> (16 * (t & 1))) & 0x7FFFu];
+        cp = nk.colpow[uint32_t(x0 + first)];
+      };
+      // ... and the values on their way out (TableLookUp's dither form, common/RawImage.h:335-353)
+      auto nk_dither = [&](uint32_t (&o)[4], const uint32_t (&e)[8], uint32_t cp, int32_t first) {
+        uint32_t st = lf_nk_mulmod(rowst, cp);
+        uint32_t v[8];
+        if (first == 0) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            v[t] = ((e[t] & 0xFFFFu) + (((e[t] >> 16) * (st & 2047u) + 1024u) >> 12)) & 0xFFFFu;
+            st = 15700u * (st & 65535u) + (st >> 16);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            v[t] = ((e[t] & 0xFFFFu) + (((e[t] >> 16) * (st & 2047u) + 1024u) >> 12)) & 0xFFFFu;
+            st = t >= first ? 15700u * (st & 65535u) + (st >> 16) : st;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          o[t] = v[2 * t] | (v[2 * t + 1] << 16);
+      };
+      // (Tried: two of a wavefront's segments at a time, the second one's table entries on their way
+      // while the first one's values are worked out -- 9.4 us a workgroup against 8.6: the entries
+      // are not waited for one after the other as it is; what the curve costs is the 64 lanes' 64
+      // places in a 128 KB table, a cache line each, eight times a chunk.)
       for (uint32_t seg = (wv - gseg) & 3u; seg < nseg; seg += 4u) {
         const uint32_t m = seg * 64u + lane;
         if (m < nch) {
-          const int32_t sf = int32_t(8u * m) - int32_t(delta);
-          const uint32_t la = (lds0 + 16u * m) & ~3u;
-          uint32_t dw[5];
-#pragma unroll
-          for (int t = 0; t < 5; ++t)
-            dw[t] = *(lds_u32p)(la + 4u * t);
           uint32_t o[4];
-          const uint32_t m3 = N == 3 ? m % 3u : 0u;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const uint32_t cc = N == 3 ? (m3 == 0u ? cd[t] : (m3 == 1u ? cd1[t] : cd2[t])) : cd[t];
-            o[t] = pk_add(__builtin_amdgcn_alignbit(dw[t + 1], dw[t], sh), cc);
-          }
+          chunk(m, o);
           if constexpr (NK) {
-            // (the sums are mod 2^16, the reference's are ints: as long as every value so far was
-            // inside 0 .. 2^limit_shift - 1 <= 32767 and a difference is at most 2^15 in size, the
-            // next one is outside as an int exactly if it is outside mod 2^16)
-            const uint32_t over = ((0xFFFFu << nk.limit_shift) & 0xFFFFu) * 0x10001u;
-            if (sf >= 0 && uint32_t(sf) + 8u <= n) {
-              // a whole chunk (nearly all of them)
-              if ((o[0] | o[1] | o[2] | o[3]) & over)
-                atomicOr(nk.flags, FL_SLOW);
-              if (nk.dither) {
-                // (the eight table entries are asked for at once, the generator's steps follow)
-                uint32_t e[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-                  e[t] = nk.tab[(o[t >> 1] >> (16 * (t & 1))) & 0x7FFFu];
-                uint32_t st = lf_nk_mulmod(rowst, nk.colpow[sidx + uint32_t(sf)]);
-                uint32_t v[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                  v[t] = ((e[t] & 0xFFFFu) + (((e[t] >> 16) * (st & 2047u) + 1024u) >> 12)) & 0xFFFFu;
-                  st = 15700u * (st & 65535u) + (st >> 16);
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                  o[t] = v[2 * t] | (v[2 * t + 1] << 16);
-              }
-            } else {
-              // a run's first or last chunk: its samples qa <= t < qb belong to the run
-              const int32_t qa = sf < 0 ? -sf : 0;
-              const int32_t qb = int32_t(n) - sf < 8 ? int32_t(n) - sf : 8;
-              uint32_t v[8], e[8], bad = 0;
-#pragma unroll
-              for (int t = 0; t < 8; ++t) {
-                v[t] = (o[t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
-                bad |= (t >= qa && t < qb) ? (v[t] & over) : 0u;
-              }
-              if (bad)
-                atomicOr(nk.flags, FL_SLOW);
-              if (nk.dither) {
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-                  e[t] = nk.tab[v[t] & 0x7FFFu]; // (every lane, every sample: no load behind a branch)
-                uint32_t st = lf_nk_mulmod(rowst, nk.colpow[sidx + uint32_t(sf + qa)]);
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                  const bool in = t >= qa && t < qb;
-                  const uint32_t px = ((e[t] & 0xFFFFu) + (((e[t] >> 16) * (st & 2047u) + 1024u) >> 12)) & 0xFFFFu;
-                  v[t] = in ? px : v[t];
-                  st = in ? 15700u * (st & 65535u) + (st >> 16) : st;
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                  o[t] = v[2 * t] | (v[2 * t + 1] << 16);
-              }
+            nk_check(m, o);
+            if (nk.dither) {
+              uint32_t e[8], cp;
+              int32_t first;
+              nk_ask(m, o, e, cp, first);
+              nk_dither(o, e, cp, first);
             }
           }
-          uint8_t* p = d0 + 16u * m;
-          if (LF_ABLATE & 256u) { // (experiment: everything but the stores)
-            asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(p));
-          } else if (sf >= 0 && uint32_t(sf) + 8u <= n) {
-#ifdef RSX_LF_NT_STORE
-            __builtin_nontemporal_store(lf_u32x4{o[0], o[1], o[2], o[3]}, reinterpret_cast<lf_u32x4*>(p));
-#else
-            *reinterpret_cast<uint4*>(p) = make_uint4(o[0], o[1], o[2], o[3]);
-#endif
-          } else {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-              const int32_t q = sf + t;
-              if (q >= 0 && uint32_t(q) < n)
-                reinterpret_cast<uint16_t*>(p)[t] = uint16_t(o[t >> 1] >> (16 * (t & 1)));
-            }
-          }
+          put(m, o);
         }
       }
       gseg += nseg;
@@ -1227,7 +1257,7 @@ __device__ __forceinline__ void lf_stage(const uint32_t (&R)[LF_NR], uint32_t ad
 // whatever the transfers add to it: nobody looks).  A transfer stays field-wise: a component that
 // starts a row here sets the field of THAT row's parity from the same field of Vc.
 template <int N, int TM, int MODE, bool DIFF = false, bool NK = false>
-__global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds_bytes,
+__global__ __launch_bounds__(LJ_T, LF_WG_PER_CU) void lj_fast_kernel(LjArgs a, uint32_t lds_bytes,
                                                           uint32_t level) {
   constexpr bool PROBE = MODE >= 1, INV = MODE == 2;
   static_assert(!DIFF || (N == 1 && TM == 0), "differences: one table, symbols in stream order");
@@ -1334,8 +1364,15 @@ __global__ __launch_bounds__(LJ_T, 4) void lj_fast_kernel(LjArgs a, uint32_t lds
   static_assert(5 * LJ_T <= LJ_IMG_U4, "five uint4 a lane stay inside the block's image");
   uint4 im[5];
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 4; ++k) {
+#ifndef RSX_LF_PLAIN_MEM // (the un-stuffed image is read once: non-temporal, like the pixel stores --
+                         // together 1.5-2 % on cfg 3, cfg 4 and the Nikon legs, profiles/r06/ab/nontemporal.txt)
+    const lf_u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const lf_u32x4*>(img_src + k * LJ_T + j));
+    im[k] = make_uint4(q[0], q[1], q[2], q[3]);
+#else
     im[k] = img_src[k * LJ_T + j];
+#endif
+  }
   // (the fifth: row 16 for the first 64 lanes; the others ask for their first chunk again --
   // a line they hold -- instead of rows 17..19, which nobody reads: 47 MB of HBM reads on cfg 3)
 #ifdef RSX_LF_FIFTH_PLAIN // (experiment: rows 17..19 read as well)

@@ -42,9 +42,12 @@ def main():
                             "--no-cpu"],
                            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         try:
-            j = json.loads(r.stdout[r.stdout.index("{"):])
+            # (the JSON is the last thing printed, pretty-printed from a "{" on a line of its own; log
+            # lines in front of it may hold braces of their own)
+            at = r.stdout.rfind("\n{\n")
+            j = json.loads(r.stdout[at + 1:] if at >= 0 else r.stdout[r.stdout.index("{"):])
             k = j.get("kernels_ms", {})
-            print("%-14s %.4f ms exact=%s  %s" % (name, j["ms_per_step"], j.get("bit_exact"),
+            print("%-14s %.4f ms exact=%s  %s" % (name, j.get("ms_per_step", 0.0), j.get("bit_exact"),
                                                   " ".join("%s=%.3f" % (a.replace("lj_", "").replace("_kernel", ""), v)
                                                            for a, v in k.items())))
             for sub, v in j.items():  # (cfg 4: its variants -- two tables, small tiles, overhang, DRI)
