@@ -4066,7 +4066,10 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
     const bool env_no_diffs = getenv("RSX_NO_FAST_DIFFS") != nullptr;
     S.fast_nk = 0;
 #ifndef RSX_NO_FAST_NK
-    if (!env_no_nk && !S.fast && !direct_n && g.kind == 2 && J.n_tables == 1 && J.explicit_n == 0 && !g.las && !g.pair &&
+    // (a table given as the reference's own (encLen, diffLen) pairs -- SamsungV1 -- is as good as a
+    // canonical one while its codes fit the kernel's 10-bit LUT: every entry is a whole symbol)
+    const bool lut10 = J.explicit_n == 0 || J.explicit_bits <= 10;
+    if (!env_no_nk && !S.fast && !direct_n && g.kind == 2 && J.n_tables == 1 && lut10 && !g.las && !g.pair &&
         tables.size() < 0xFFFFu && needed >= 2 && g.row_samples >= 2 && g.row_samples % 2 == 0) {
       const NikonIn& N = J.nikon;
       bool ok = !N.sony && N.pup_in == nullptr && !(N.split > 0 && N.split < N.height) &&
@@ -4089,7 +4092,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
 #endif
     S.fast_diffs = 0;
 #ifndef RSX_NO_FAST_DIFFS
-    if (!env_no_diffs && !S.fast && !direct_n && J.n_tables == 1 && J.explicit_n == 0 && !g.las && !g.pair &&
+    if (!env_no_diffs && !S.fast && !direct_n && J.n_tables == 1 && lut10 && !g.las && !g.pair &&
         (g.kind == 2 || g.kind == 1 || g.kind == 0) && !(g.kind == 2 && J.nikon.sony) &&
         tables.size() < 0xFFFFu && needed >= 1) {
       S.fast = 1;

@@ -230,3 +230,52 @@ def test_pentax_routes_agree(gpu, oracle):
             assert status == [so], (c["name"], route, status, so)
             if so == 0:
                 assert np.array_equal(a[:want.buf.size], want.buf), (c["name"], route)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_nikon_type_plans_of_random_shapes(gpu, oracle, seed):
+    """Plans of two to four Nikon frames of unrelated sizes (widths from 2 samples, single rows, rows
+    that do not start on the 16-byte grid of the batch buffer), both output modes, curves of
+    several sizes, predictors anywhere inside the sensor's bits: against the oracle, twice."""
+    import gpu_util
+    rng = np.random.default_rng([64, seed])
+    jobs, wants, chunks, keep = [], [], [], []
+    in_off = out_off = 0
+    for k in range(int(rng.integers(2, 5))):
+        bits = int(rng.choice([12, 14]))
+        w = 2 * int(rng.integers(1, 1600)) if rng.random() < 0.8 else 2 * int(rng.integers(1, 9))
+        h = int(rng.integers(1, 120))
+        unc = bool(rng.integers(0, 2))
+        pu = [int(v) for v in rng.integers(0, 1 << bits, size=4)]
+        pts = None if rng.random() < 0.4 else G.nikon_curve_points(int(rng.choice([33, 257, 300])),
+                                                                   (1 << bits) - 1)
+        meta = N.metadata(70, 0, pu) if pts is None else N.metadata(68, 0, pu, pts, pad_to=3000)
+        P = N.parse(meta, bits, h)
+        src = N.smooth15(rng, h, w, maxv=(1 << bits) - 1, sigma=float(rng.choice([2.0, 12.0, 60.0])))
+        p = P["p_up"]
+        try:
+            data, _ = synth.nikon_encode(src, [p[0][0], p[0][1], p[1][0], p[1][1]],
+                                         synth.NIKON_TREE[P["huff_select"]])
+        except ValueError:  # (a difference the tree has no code for: a flatter image)
+            src = N.smooth15(rng, h, w, maxv=(1 << (bits - 1)) - 1, sigma=2.0)
+            data, _ = synth.nikon_encode(src, [p[0][0], p[0][1], p[1][0], p[1][1]],
+                                         synth.NIKON_TREE[P["huff_select"]])
+        data = np.concatenate([data, np.zeros(8, np.uint8)])
+        d = N.desc(P, bits, unc)
+        keep.append(d)
+        want = HostImage(w, h)
+        assert oracle.nikon(d, data, want) == 0
+        jobs.append(_nikon_job(gpu_util, d, data, w, h, want.pitch, in_off, out_off))
+        wants.append(want)
+        chunks.append((in_off, data))
+        in_off += data.size + int(rng.integers(0, 40))  # (streams at any byte offset)
+        out_off += want.buf.size
+    in_host = np.zeros(in_off + 64, np.uint8)
+    for off, data in chunks:
+        in_host[off:off + data.size] = data
+    status, a, b, names = _run(gpu, gpu.nikon_plan, jobs, in_host, out_off, ())
+    assert status == [0] * len(jobs)
+    for j, want in zip(jobs, wants):
+        for got in (a, b):
+            assert np.array_equal(got[j.img_offset:j.img_offset + want.buf.size], want.buf), names
+    assert any("nikon-type" in x for x in names), names
