@@ -28,6 +28,11 @@ for leg in cfg3 cfg4; do
     python $REPO/bench_ljpeg.py --only $leg --steps 10 --no-cpu > $OUT/${leg}_under_rocprof.json 2> /dev/null
   cp $(find /tmp/p_$leg -name "*kernel_stats.csv" | head -1) $OUT/${leg}_kernel_stats.csv
 done
+# the Nikon-type instantiation (round 6): kernel stats of the Nikon leg, both output modes
+rm -rf /tmp/p_nikon
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_nikon -- \
+  python $REPO/bench_ljpeg.py --only nikon --steps 10 --no-cpu > $OUT/nikon_under_rocprof.json 2> /dev/null
+cp $(find /tmp/p_nikon -name "*kernel_stats.csv" | head -1) $OUT/nikon_kernel_stats.csv
 bash $REPO/scripts/pmc_ljpeg_traffic.sh > /dev/null 2>&1
 mkdir -p $OUT/ljpeg_traffic
 cp $REPO/gpurun_out/pmc_lj_traffic/* $OUT/ljpeg_traffic/
@@ -43,6 +48,13 @@ if [ -f $REPO/rawspeed_amd/variants/librsx_stats.so ]; then
     python $REPO/scripts/exp_lj_stats.py 2>&1 | grep "^\[rsx\]" | cut -c1-400 > $OUT/cfg3_phase_and_round_stats.txt
   WHAT=cfg4mt RSX_DEBUG=1 RSX_LIB=$REPO/rawspeed_amd/variants/librsx_stats.so \
     python $REPO/scripts/exp_lj_stats.py 2>&1 | grep "^\[rsx\]" | cut -c1-400 > $OUT/cfg4_two_tables_phase_and_round_stats.txt
+fi
+if [ -f $REPO/rawspeed_amd/variants/librsx_stats.so ]; then
+  for unc in 0 1; do
+    echo "== Nikon 6016x4016 x 8, uncorrected=$unc"
+    UNCORRECTED=$unc RSX_DEBUG=1 RSX_LIB=$REPO/rawspeed_amd/variants/librsx_stats.so \
+      python $REPO/scripts/exp_nk_phases.py 2>&1 | grep "^\[rsx\]  \|phases over" | cut -c1-200
+  done > $OUT/nikon_type_phase_stats.txt
 fi
 python $REPO/scripts/ljpeg_limiter.py $OUT > /dev/null 2>&1
 ls -la $OUT
