@@ -2383,6 +2383,67 @@ int ljpeg_family_host(rsx_ctx* ctx, int n, std::vector<JobT>& jobs,
     lane.lane->cached_plan = nullptr;
     return rc;
   }
+#ifdef RSX_DIAG_VERIFY
+  // (diagnostic build, round 6: an intermittent wrong tile with status OK under six host threads --
+  // was the INPUT on the device what the caller handed over, and does the same plan on the same
+  // device input give the same pixels a second time?)
+  {
+    static std::atomic<unsigned long long> calls{0}, bad_in{0}, bad_rerun{0};
+    ++calls;
+    std::vector<uint8_t> back(in_total + 64), out1(out_bytes), out2(out_bytes);
+    (void)hipMemcpyAsync(back.data(), lane.lane->d_in.ptr, in_total + 64, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(out1.data(), lane.lane->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    for (int i = 0; i < n; ++i) {
+      const uint8_t* h = static_cast<const uint8_t*>(ins[i]);
+      const uint8_t* d = back.data() + jobs[i].in_offset;
+      size_t nd = 0, first = 0, zeros = 0;
+      for (size_t k = 0; k < size_t(jobs[i].in_bytes); ++k)
+        if (h[k] != d[k]) {
+          if (!nd)
+            first = k;
+          ++nd;
+          zeros += d[k] == 0;
+        }
+      if (nd) {
+        ++bad_in;
+        fprintf(stderr, "RSX_DIAG_VERIFY: INPUT of job %d/%d on the device differs from the caller's in %zu of %zu "
+                        "bytes (first at %zu; %zu of them zero on the device), in_offset %zu\n",
+                i, n, nd, size_t(jobs[i].in_bytes), first, zeros, size_t(jobs[i].in_offset));
+      }
+    }
+    std::vector<int32_t> st2(n, RSX_OK);
+    std::vector<uint32_t> cons2(n, 0);
+    int rc2 = rsx_plan_run(plan, lane.lane->d_in.ptr, out_row0, s);
+    if (rc2 == RSX_OK)
+      rc2 = rsx_plan_results(plan, st2.data(), cons2.data());
+    (void)hipMemcpyAsync(out2.data(), lane.lane->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    size_t nd = 0, first = 0;
+    for (size_t k = 0; k < out_bytes; ++k)
+      if (out1[k] != out2[k]) {
+        if (!nd)
+          first = k;
+        ++nd;
+      }
+    if (nd || st2 != st || cons2 != cons || rc2 != rc) {
+      ++bad_rerun;
+      fprintf(stderr, "RSX_DIAG_VERIFY: a SECOND run of the plan on the same device input differs: %zu of %zu output "
+                      "bytes (first at %zu = row %zu byte %zu), rc %d -> %d;",
+              nd, out_bytes, first, first / size_t(img->pitch_bytes), first % size_t(img->pitch_bytes), rc, rc2);
+      for (int i = 0; i < n; ++i)
+        fprintf(stderr, " job %d: status %d -> %d consumed %u -> %u (in_bytes %zu);", i, st[i], st2[i], cons[i],
+                cons2[i], size_t(jobs[i].in_bytes));
+      fprintf(stderr, " (the second run's results are the ones delivered)\n");
+      st = st2;
+      cons = cons2;
+      rc = rc2;
+    }
+    if ((calls & 1023ull) == 0)
+      fprintf(stderr, "RSX_DIAG_VERIFY: %llu calls, %llu with a device input that differs, %llu with a second run that differs\n",
+              (unsigned long long)calls, (unsigned long long)bad_in, (unsigned long long)bad_rerun);
+  }
+#endif
   // only the rectangle a successful job decoded goes back to the host image:
   // pixels outside it (other tiles, padding) are never touched
   std::vector<HostRect> rects;

@@ -4437,6 +4437,16 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
       }
       RSX_HIP_CHECK(ctx, hipMemset(p->d_block_base0.ptr, 0, size_t(p->total_blocks) * 4));
       RSX_HIP_CHECK(ctx, hipMemset(p->d_fast_level.ptr, 0, 256));
+      // hipMemset of device memory is ASYNCHRONOUS with respect to the host on this runtime (ROCm 7.2:
+      // scripts/repro/memset_async.hip -- the call returns in 2 us, and a hipStreamNonBlocking stream
+      // reads the old bytes for as long as the null stream is busy), and the plan's kernels run on
+      // such a stream: without this wait the six memsets above raced with the plan's first run
+      // whenever other host threads kept the null stream busy -- K0's words, the hand-over words or
+      // the LDS level zeroed under the kernels' feet; once in ~17 000 calls from six threads a whole
+      // small tile came back wrong with status OK (profiles/r06/host_path_defect/README.md).
+#ifndef RSX_NO_CREATE_SYNC // (experiment: the behaviour until round 6, for scripts/exp_null_stream_stress.py)
+      RSX_HIP_CHECK(ctx, hipStreamSynchronize(nullptr));
+#endif
 #ifdef RSX_EXPERIMENT
       if (getenv("RSX_DEBUG")) {
         if ((st = p->d_dbg.ensure(size_t(p->total_blocks) * 32 * 8)))

@@ -24,6 +24,8 @@ from oracle_lib import HostImage
 pytestmark = pytest.mark.gpu
 
 ROUTES = ((), ("RSX_NO_FAST_NK",), ("RSX_NO_FAST_NK", "RSX_NO_FAST_DIFFS"))
+# RSX_FUZZ_BASE=<k> moves the random-shape cases to other seeds (soak runs)
+BASE = int(os.environ.get("RSX_FUZZ_BASE", "0"))
 
 
 @pytest.fixture(scope="module")
@@ -238,7 +240,7 @@ def test_nikon_type_plans_of_random_shapes(gpu, oracle, seed):
     that do not start on the 16-byte grid of the batch buffer), both output modes, curves of
     several sizes, predictors anywhere inside the sensor's bits: against the oracle, twice."""
     import gpu_util
-    rng = np.random.default_rng([64, seed])
+    rng = np.random.default_rng([64, BASE, seed])
     jobs, wants, chunks, keep = [], [], [], []
     in_off = out_off = 0
     for k in range(int(rng.integers(2, 5))):
