@@ -483,6 +483,10 @@ int rsx_dng_decompress_uncompressed(rsx_ctx* ctx, int n_tiles,
 /* `img_offset` bytes into the output.  `stream` is a hipStream_t (may be    */
 /* NULL = the context's stream).  run() only enqueues; results() blocks on   */
 /* the stream, then reports per-job status / consumed byte counts.           */
+/* The context's stream is hipStreamNonBlocking: with stream == NULL a run   */
+/* is queued behind the work the caller has put on the NULL stream so far    */
+/* (an event wait); a caller who passes a stream orders the run himself --   */
+/* in_dev must be final and out_dev free on THAT stream.                     */
 /* ------------------------------------------------------------------------ */
 typedef struct rsx_plan rsx_plan;
 

@@ -497,6 +497,8 @@ extern "C" void rsx_ctx_destroy(rsx_ctx* ctx) {
   }
   if (ctx->fast_ev)
     (void)hipEventDestroy(ctx->fast_ev);
+  if (ctx->null_ev)
+    (void)hipEventDestroy(ctx->null_ev);
   delete ctx;
 }
 
@@ -885,6 +887,16 @@ extern "C" int rsx_plan_run(rsx_plan* plan, const void* in_dev, void* out_dev,
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   RSX_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  if (!stream) {
+    // The convenience path: the context's own stream is hipStreamNonBlocking, i.e. NOT ordered behind
+    // what the caller has queued on the null stream -- a fill of the output buffer, a device-to-device
+    // copy of the input, a hipMemset (asynchronous with respect to the host on this runtime).  The run is
+    // put behind the null stream's work so far; a caller who passes a stream orders it himself.
+    if (!ctx->null_ev)
+      RSX_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->null_ev, hipEventDisableTiming));
+    RSX_HIP_CHECK(ctx, hipEventRecord(ctx->null_ev, nullptr));
+    RSX_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->null_ev, 0));
+  }
   plan->last_stream = s;
   plan->ran = true;
   if (plan->kind == PLAN_UNPACK)

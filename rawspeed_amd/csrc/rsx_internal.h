@@ -273,6 +273,7 @@ struct rsx_ctx {
   // next workgroup needs.  Its launches therefore run one after the other per context: each
   // waits for the event recorded behind the last one (the kernels around it still overlap).
   rsx::HelperPool helpers;             // persistent helper threads of the host-pointer calls
+  hipEvent_t null_ev = nullptr;        // rsx_plan_run(stream == NULL): the context's stream behind the null stream's work so far
   std::mutex fast_mu;
   hipEvent_t fast_ev = nullptr;
   hipStream_t fast_ev_stream = nullptr;
