@@ -4452,6 +4452,7 @@ int ljpeg_plan_create(rsx_ctx* ctx, const std::vector<LJpegJobIn>& jobs,
         if ((st = p->d_dbg.ensure(size_t(p->total_blocks) * 32 * 8)))
           return st;
         (void)hipMemset(p->d_dbg.ptr, 0, size_t(p->total_blocks) * 32 * 8);
+        (void)hipStreamSynchronize(nullptr); // (asynchronous with respect to the host: see above)
       }
 #endif
     }

@@ -95,3 +95,26 @@ def test_unstuff_kernel_keeps_seven_workgroups_per_cu():
         assert get("private_segment_fixed_size") == 0
         assert get("group_segment_fixed_size") == 0
     assert seen == {(km, inv) for km in (0, 1, 2) for inv in (False, True)}
+
+
+def test_no_hipmemset_is_trusted_to_have_run():
+    """hipMemset of device memory returns before it has run on this runtime, and the library's streams
+    are hipStreamNonBlocking -- not ordered behind the null stream the memset runs on
+    (scripts/repro/memset_async.hip; the round-6 defect of plan creation).  Every group of
+    hipMemset calls in the library's sources is followed by a wait for the null stream before anything
+    else can be queued; hipMemsetAsync on the stream of the kernels that read the bytes needs none."""
+    src = os.path.join(ROOT, "rawspeed_amd", "csrc")
+    seen = 0
+    for name in sorted(os.listdir(src)):
+        if not name.endswith((".hip", ".cpp", ".h")):
+            continue
+        lines = open(os.path.join(src, name)).read().split("\n")
+        for i, line in enumerate(lines):
+            code = line.split("//")[0]
+            if re.search(r"\bhipMemset\(", code) is None:
+                continue
+            seen += 1
+            tail = "\n".join(l.split("//")[0] for l in lines[i + 1:i + 30])
+            assert re.search(r"\bhipMemset\(|hipStreamSynchronize\(nullptr\)|hipDeviceSynchronize\(\)", tail), \
+                "%s:%d: hipMemset without a wait for the null stream behind it" % (name, i + 1)
+    assert seen >= 6
