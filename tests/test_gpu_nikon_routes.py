@@ -281,3 +281,31 @@ def test_nikon_type_plans_of_random_shapes(gpu, oracle, seed):
         for got in (a, b):
             assert np.array_equal(got[j.img_offset:j.img_offset + want.buf.size], want.buf), names
     assert any("nikon-type" in x for x in names), names
+
+
+@pytest.mark.parametrize("w,h", [(2, 700), (4, 1500), (6, 300)])
+def test_nikon_more_rows_than_a_workgroup_takes(gpu, oracle, w, h):
+    """A workgroup of the single-pass kernel takes at most 256 stream rows (LF_RMAX); a frame a few
+    pixels wide has more of them in a workgroup's bytes: the kernel hands such a stream over
+    (whatever route ends up decoding it, the image is the oracle's)."""
+    import gpu_util
+    bits = 14
+    rng = np.random.default_rng([65, w, h])
+    meta = N.metadata(70, 0, [2000, 2100, 2200, 2300])
+    P = N.parse(meta, bits, h)
+    src = N.smooth15(rng, h, w, maxv=(1 << bits) - 1, sigma=3.0)
+    pu = P["p_up"]
+    data, _ = synth.nikon_encode(src, [pu[0][0], pu[0][1], pu[1][0], pu[1][1]], synth.NIKON_TREE[P["huff_select"]])
+    data = np.concatenate([data, np.zeros(8, np.uint8)])
+    for unc in (True, False):
+        d = N.desc(P, bits, unc)
+        want = HostImage(w, h)
+        assert oracle.nikon(d, data, want) == 0
+        jobs = [_nikon_job(gpu_util, d, data, w, h, want.pitch, 0, 0)]
+        in_host = np.concatenate([data, np.zeros(64, np.uint8)])
+        status, a, b, names = _run(gpu, gpu.nikon_plan, jobs, in_host, want.buf.size, ())
+        assert status == [0]
+        assert np.array_equal(a[:want.buf.size], want.buf) and np.array_equal(b[:want.buf.size], want.buf), names
+        img = HostImage(w, h)
+        assert gpu.nikon_decompress(d, data, img.view()) == 0
+        assert np.array_equal(img.buf, want.buf)
